@@ -1,0 +1,125 @@
+"""numpy stand-ins for the third-party calls (Open3D 0.18, faiss 1.7.2) the reference makes on the
+hot path, used ONLY by `gen_golden.py` in the build container to let the reference's own Python run
+end to end.  They delegate to the `o3d_*` / `faiss_*` restatements in `oracle/hmsg_oracle.py`, so the
+fixtures pin the reference's glue (order of operations, thresholds, torch / sklearn / scipy
+semantics) but NOT the third-party internals ("parity unpinned" there, see the oracle header).
+"""
+from __future__ import annotations
+
+import types
+
+import numpy as np
+
+from oracle import hmsg_oracle as O
+
+
+class _AABB:
+    def __init__(self, lo, hi):
+        self._lo = np.asarray(lo, dtype=np.float64)
+        self._hi = np.asarray(hi, dtype=np.float64)
+
+    def get_min_bound(self):
+        return self._lo
+
+    def get_max_bound(self):
+        return self._hi
+
+
+class PointCloud:
+    def __init__(self):
+        self.points = np.zeros((0, 3))
+        self.colors = np.zeros((0, 3))
+
+    def __iadd__(self, other):
+        self.points = np.concatenate([np.asarray(self.points).reshape(-1, 3), np.asarray(other.points).reshape(-1, 3)])
+        # Open3D keeps colours only when both sides have them
+        if len(self.colors) == len(self.points) - len(other.points) and len(other.colors) == len(other.points):
+            self.colors = np.concatenate([np.asarray(self.colors).reshape(-1, 3),
+                                          np.asarray(other.colors).reshape(-1, 3)])
+        else:
+            self.colors = np.zeros((0, 3))
+        return self
+
+    def __add__(self, other):
+        out = PointCloud()
+        out.points = np.asarray(self.points).copy()
+        out.colors = np.asarray(self.colors).copy()
+        out += other
+        return out
+
+    def transform(self, T):
+        p = np.asarray(self.points, dtype=np.float64).reshape(-1, 3)
+        T = np.asarray(T, dtype=np.float64)
+        w = p @ T[:3, :3].T + T[:3, 3]
+        den = p @ T[3, :3] + T[3, 3]
+        self.points = w / den[:, None]
+        return self
+
+    def voxel_down_sample(self, voxel_size):
+        out = PointCloud()
+        cols = np.asarray(self.colors) if len(self.colors) == len(self.points) else None
+        p, c, _, _ = O.o3d_voxel_down_sample(np.asarray(self.points, dtype=np.float64).reshape(-1, 3), cols,
+                                             voxel_size)
+        out.points = p
+        out.colors = c if c is not None else np.zeros((0, 3))
+        return out
+
+    def cluster_dbscan(self, eps, min_points, print_progress=False):
+        return O.o3d_cluster_dbscan(np.asarray(self.points, dtype=np.float64).reshape(-1, 3), eps, min_points).tolist()
+
+    def remove_radius_outlier(self, nb_points, radius):
+        ind = O.o3d_remove_radius_outlier(np.asarray(self.points, dtype=np.float64).reshape(-1, 3), nb_points, radius)
+        return self.select_by_index(ind), ind.tolist()
+
+    def select_by_index(self, ind):
+        out = PointCloud()
+        ind = np.asarray(ind, dtype=np.int64)
+        out.points = np.asarray(self.points)[ind]
+        if len(self.colors) == len(self.points):
+            out.colors = np.asarray(self.colors)[ind]
+        return out
+
+    def get_axis_aligned_bounding_box(self):
+        p = np.asarray(self.points).reshape(-1, 3)
+        if p.shape[0] == 0:
+            return _AABB(np.zeros(3), np.zeros(3))
+        return _AABB(p.min(axis=0), p.max(axis=0))
+
+    def is_empty(self):
+        return len(self.points) == 0
+
+    def get_center(self):
+        return np.asarray(self.points).mean(axis=0)
+
+    def has_points(self):
+        return len(self.points) > 0
+
+
+def make_open3d():
+    o3d = types.ModuleType("open3d")
+    o3d.geometry = types.SimpleNamespace(PointCloud=PointCloud, AxisAlignedBoundingBox=_AABB)
+    o3d.utility = types.SimpleNamespace(
+        Vector3dVector=lambda a: np.array(a, dtype=np.float64).reshape(-1, 3))
+    o3d.io = types.SimpleNamespace(write_point_cloud=lambda *a, **k: True, read_point_cloud=None)
+    o3d.visualization = types.SimpleNamespace()
+    return o3d
+
+
+class IndexFlatL2:
+    def __init__(self, d):
+        self.d = d
+        self.base = np.zeros((0, d), np.float32)
+
+    def add(self, x):
+        self.base = np.concatenate([self.base, np.asarray(x, np.float32)])
+
+    def search(self, q, k=1):
+        assert k == 1
+        d = O.faiss_flat_l2_nn_sqdist(np.asarray(q, np.float32), self.base)
+        return d.reshape(-1, 1), np.zeros((len(q), 1), np.int64)
+
+
+def make_faiss():
+    f = types.ModuleType("faiss")
+    f.IndexFlatL2 = IndexFlatL2
+    return f

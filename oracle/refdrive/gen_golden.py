@@ -1,0 +1,293 @@
+"""Golden-vector generator: runs the REFERENCE's own Python (imported from /root/reference, which
+exists only in the build container) on seeded synthetic inputs and stores inputs + outputs as small
+.npz fixtures under tests/golden/.  Nothing of the reference's source travels: only data.
+
+    python -m oracle.refdrive.gen_golden            # from the repo root
+
+Import recipe: SURVEY.md section 8c (MagicMock the absent third-party modules, inject the numpy
+Open3D / faiss stand-ins of `fake_backends.py`, pin torch to one thread so the duplicate-index `+=`
+of graph.py:410 is last-writer-wins).
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+from unittest.mock import MagicMock
+
+import numpy as np
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path.insert(0, REPO)
+REF = "/root/reference/fsr_vln"
+
+
+def import_reference():
+    from oracle.refdrive import fake_backends as FB
+    for m in ["cv2", "torchmetrics", "torchmetrics.functional", "open_clip", "segment_anything", "oss2",
+              "oss2.credentials", "openai", "hydra", "omegaconf", "torchvision", "pyvista", "skfmm", "plyfile"]:
+        sys.modules[m] = MagicMock()
+    sys.modules["open3d"] = FB.make_open3d()
+    sys.modules["faiss"] = FB.make_faiss()
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    plt.switch_backend = lambda *a, **k: None
+    sys.path.insert(0, REF)
+    import torch
+    torch.set_num_threads(1)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    import memory.hmsg.graph.graph as G
+    import perception.models.sam_clip_feats_extractor as X
+
+    class TorchProxy:
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+        @staticmethod
+        def zeros(*a, device=None, **k):
+            return torch.zeros(*a, **k)
+
+    X.torch = TorchProxy()
+    return G, X
+
+
+class AttrDict(dict):
+    __getattr__ = dict.__getitem__
+
+
+def make_dataset(G, frames):
+    from PIL import Image
+    from memory.hmsg.dataloader.generic import RGBDDataset
+
+    class SynthDataset(RGBDDataset):
+        def __init__(self, frames):
+            self.frames = frames
+            self.depth_intrinsics = frames[0]["K"]
+            self.scale = 1000.0
+            self.data_list = list(range(len(frames)))
+
+        def _get_data_list(self):
+            return self.data_list
+
+        def __getitem__(self, i):
+            f = self.frames[i]
+            return Image.fromarray(f["rgb"]), Image.fromarray(f["depth"]), f["pose"], None, f["K"]
+
+        def get_camera_intrinsics(self):
+            return self.depth_intrinsics
+
+    return SynthDataset(frames)
+
+
+def drive_create_feature_map(G, X, frames, cfg):
+    """Run the reference's Graph.create_feature_map (graph.py:262-491) on synthetic frames."""
+    state = dict(i=-1, phase=0)
+
+    class MaskGen:
+        def generate(self, image):
+            state["i"] += 1
+            fr = frames[state["i"]]
+            return [dict(segmentation=fr["masks"][m], predicted_iou=1.0, bbox=[0, 0, 1, 1])
+                    for m in range(fr["masks"].shape[0])]
+
+    X.get_img_feats = lambda img, pre, model: frames[state["i"]]["f_g"].copy()
+    X.crop_all_bounding_boxs = lambda image, masks, block_background, bbox_margin: \
+        [("masked" if block_background else "crop", m) for m in range(len(masks))]
+
+    def batch(imgs, pre, model):
+        fr = frames[state["i"]]
+        return (fr["f_masked"] if imgs[0][0] == "masked" else fr["f_crop"]).copy()
+
+    X.get_img_feats_batch = batch
+    X.cv2 = MagicMock()
+
+    g = G.Graph.__new__(G.Graph)
+    g.cfg = AttrDict(main=AttrDict(save_path="/tmp/hmsg_golden_tmp"),
+                     pipeline=AttrDict(**cfg))
+    g.full_pcd = sys.modules["open3d"].geometry.PointCloud()
+    g.mask_feats, g.mask_pcds, g.full_feats_array = [], [], []
+    g.dataset = make_dataset(G, frames)
+    g.mask_generator = MaskGen()
+    g.clip_model = None
+    g.preprocess = None
+    g.clip_feat_dim = cfg["feat_dim"]
+    g.save_full_pcd = lambda path=None: None
+    g.create_feature_map()
+    return g
+
+
+def pack_clouds(clouds):
+    pts = [np.asarray(c.points).reshape(-1, 3) for c in clouds]
+    off = np.cumsum([0] + [len(p) for p in pts])
+    return (np.concatenate(pts) if pts else np.zeros((0, 3))), off
+
+
+def pack_frames(frames):
+    return dict(
+        rgb=np.stack([f["rgb"] for f in frames]), depth=np.stack([f["depth"] for f in frames]),
+        pose=np.stack([f["pose"] for f in frames]), K=frames[0]["K"],
+        masks=np.packbits(np.stack([f["masks"] for f in frames]), axis=-1),
+        f_g=np.stack([f["f_g"] for f in frames]), f_masked=np.stack([f["f_masked"] for f in frames]),
+        f_crop=np.stack([f["f_crop"] for f in frames]))
+
+
+def gen_build(G, X, out_dir):
+    from holoagent_amd.synth import SceneSpec, SynthScene
+    for name, spec, merge_type in [
+        ("build_seq", SceneSpec(seed=4321, rooms_x=1, rooms_z=1, room_size=(4.0, 2.6, 3.5), objects_per_room=5,
+                                width=160, height=120, n_frames=36, n_masks=12, feat_dim=32), "sequential"),
+        ("build_hier", SceneSpec(seed=99, rooms_x=1, rooms_z=1, room_size=(3.6, 2.5, 3.2), objects_per_room=4,
+                                 width=128, height=96, n_frames=30, n_masks=10, feat_dim=16,
+                                 yaw_step_deg=12.0), "hierarchical"),
+    ]:
+        sc = SynthScene(spec)
+        frames = [sc.frame(i) for i in range(spec.n_frames)]
+        cfg = dict(voxel_size=0.05, skip_frames=1, init_overlap_thresh=0.75, overlap_thresh_factor=0.025,
+                   iou_thresh=0.05, clip_masked_weight=0.4418, clip_bbox_margin=50, max_mask_distance=10000,
+                   merge_type=merge_type, feat_dim=spec.feat_dim)
+        g = drive_create_feature_map(G, X, frames, cfg)
+        cloud = np.asarray(g.full_pcd.points)
+        mp, moff = pack_clouds(g.mask_pcds)
+        feats = np.stack([np.asarray(f).reshape(-1) for f in g.mask_feats]) if g.mask_feats else np.zeros((0, 1))
+        np.savez_compressed(
+            os.path.join(out_dir, name + ".npz"), **pack_frames(frames),
+            cfg_keys=np.array(list(cfg.keys())), cfg_vals=np.array([str(v) for v in cfg.values()]),
+            ref_cloud=cloud, ref_cloud_cols=np.asarray(g.full_pcd.colors),
+            ref_full_feats=g.full_feats_array.astype(np.float32),
+            ref_mask_pts=mp, ref_mask_off=moff, ref_mask_feats=feats.astype(np.float32))
+        print(name, "cloud", cloud.shape, "instances", len(g.mask_pcds), "feats", feats.shape)
+
+
+def gen_fusion(G, X, out_dir):
+    """extract_feats_per_pixel (sam_clip_feats_extractor.py:82-191) on one frame."""
+    from holoagent_amd.synth import SceneSpec, SynthScene
+    spec = SceneSpec(seed=7, rooms_x=1, rooms_z=1, width=96, height=64, n_frames=4, n_masks=9, feat_dim=48)
+    sc = SynthScene(spec)
+    fr = sc.frame(2)
+    fr["masks"][3] = False                       # an empty mask
+    fr["masks"][4] = True                        # a full-frame mask
+    state = dict()
+
+    class MaskGen:
+        def generate(self, image):
+            return [dict(segmentation=fr["masks"][m], predicted_iou=1.0) for m in range(spec.n_masks)]
+
+    X.get_img_feats = lambda img, pre, model: fr["f_g"].copy()
+    X.crop_all_bounding_boxs = lambda image, masks, block_background, bbox_margin: \
+        [("masked" if block_background else "crop", m) for m in range(len(masks))]
+    X.get_img_feats_batch = lambda imgs, pre, model: (fr["f_masked"] if imgs[0][0] == "masked" else fr["f_crop"]).copy()
+    X.cv2 = MagicMock()
+    out, f_p, masks, f_g = X.extract_feats_per_pixel(fr["rgb"], MaskGen(), None, None, clip_feat_dim=spec.feat_dim,
+                                                     bbox_margin=50, maskedd_weight=0.4418)
+    np.savez_compressed(os.path.join(out_dir, "fusion.npz"), masks=np.packbits(fr["masks"], axis=-1),
+                        shape=np.array(fr["masks"].shape), f_g=fr["f_g"], f_masked=fr["f_masked"],
+                        f_crop=fr["f_crop"], ref_f2d=out.numpy(), ref_f_p=f_p.numpy())
+    print("fusion", out.shape, out.dtype)
+
+
+def gen_feats_dbscan(G, X, out_dir):
+    """feats_denoise_dbscan (graph_utils.py:682-728) on three shapes of input."""
+    from memory.hmsg.utils.graph_utils import feats_denoise_dbscan
+    rng = np.random.Generator(np.random.PCG64(11))
+    D = 24
+    cases = {}
+    base = rng.standard_normal((3, D)).astype(np.float32)
+    base /= np.linalg.norm(base, axis=1, keepdims=True)
+    # (a) two dense clusters + noise, (b) no cluster (too few), (c) single tight cluster with scale jitter
+    a = np.concatenate([base[0] + 0.01 * rng.standard_normal((180, D)), base[1] + 0.01 * rng.standard_normal((140, D)),
+                        rng.standard_normal((25, D))]).astype(np.float32)
+    a = a[rng.permutation(len(a))]
+    b = (base[2] + 0.3 * rng.standard_normal((40, D))).astype(np.float32)
+    c = ((base[0] + 0.004 * rng.standard_normal((130, D))) * rng.uniform(0.2, 1.0, (130, 1))).astype(np.float32)
+    for k, v in dict(a=a, b=b, c=c).items():
+        cases["in_" + k] = v
+        cases["ref_" + k] = np.asarray(feats_denoise_dbscan(v, eps=0.01, min_points=100), dtype=np.float32)
+    np.savez_compressed(os.path.join(out_dir, "feats_dbscan.npz"), **cases)
+    print("feats_dbscan", {k: v.shape for k, v in cases.items()})
+
+
+def gen_query(G, X, out_dir):
+    """query_floor / query_hmsg_room / query_hmsg_object (graph.py:2216-2257, 3056-3272) on a synthetic
+    node table with a deterministic text table in place of the CLIP text encoder."""
+    rng = np.random.Generator(np.random.PCG64(5))
+    D, R, N = 40, 6, 90
+    words = ["background", "wall"] + ["room%d" % i for i in range(R)] + ["thing%d" % i for i in range(20)] + \
+            ["floor %d" % i for i in range(2)]
+    table = {}
+    for w in words:
+        t = rng.standard_normal((2, D)).astype(np.float32)
+        t /= np.linalg.norm(t, axis=1, keepdims=True)
+        table[w] = t.mean(axis=0)
+
+    def text_feats(in_text, clip_model, clip_feat_dim, batch_size=64):
+        return np.stack([table[w] for w in in_text]).astype(np.float32)
+
+    G.get_text_feats_multiple_templates = text_feats
+    g = G.Graph.__new__(G.Graph)
+    g.clip_model, g.clip_feat_dim = None, D
+    ns = types.SimpleNamespace
+    g.floors, g.rooms, g.objects = [], [], []
+    for f in range(2):
+        g.floors.append(ns(floor_id=str(f), floor_zero_level=3.0 * (1 - f), rooms=[]))   # order reversed on purpose
+    obj_emb = np.zeros((N, D), np.float32)
+    for r in range(R):
+        fl = g.floors[r % 2]
+        room = ns(room_id="%s_%d" % (fl.floor_id, len(fl.rooms)), name="room%d" % r, objects=[],
+                  embeddings=[rng.standard_normal(D) for _ in range(3 + r)])
+        fl.rooms.append(room)
+        g.rooms.append(room)
+    for o in range(N):
+        room = g.rooms[int(rng.integers(0, R))]
+        e = table["thing%d" % (o % 20)] + 0.25 * rng.standard_normal(D).astype(np.float32)
+        obj_emb[o] = e
+        obj = ns(object_id="%s_%d" % (room.room_id, len(room.objects)), room_id=room.room_id,
+                 embedding=e.astype(np.float64), name="thing")
+        room.objects.append(obj)
+        g.objects.append(obj)
+    out = dict(table_words=np.array(words), table=np.stack([table[w] for w in words]),
+               obj_emb=np.stack([o.embedding for o in g.objects]),
+               obj_room=np.array([[i for i, r in enumerate(g.rooms) if r.room_id == o.room_id][0] for o in g.objects]),
+               room_floor=np.array([int(r.room_id.split("_")[0]) for r in g.rooms]),
+               room_name=np.array([r.name for r in g.rooms]),
+               room_view_off=np.cumsum([0] + [len(r.embeddings) for r in g.rooms]),
+               room_view_emb=np.concatenate([np.stack(r.embeddings) for r in g.rooms]),
+               floor_zero=np.array([f.floor_zero_level for f in g.floors]))
+    # floors
+    out["ref_floor_int"] = np.array([g.query_floor("1"), g.query_floor("2")])
+    out["ref_floor_clip"] = np.array([g.query_floor("floor 0"), g.query_floor("floor 1")])
+    res_idx, res_room, res_score, res_rooms_label, res_rooms_view, qspec = [], [], [], [], [], []
+    k = 5
+    for q in range(12):
+        obj_q = "thing%d" % q
+        room_q = "room%d" % (q % R)
+        floor_id = [-1, 0, 1][q % 3]
+        rl = g.query_hmsg_room(room_q, floor_id=floor_id, query_method="label")
+        rv = g.query_hmsg_room(room_q, floor_id=floor_id, query_method="view_embedding")
+        negs = ["background"] if q % 4 else ["background", "wall"]
+        oi, ri, sc = g.query_hmsg_object(obj_q, floor_id=floor_id, room_ids=rl, top_k=k, negative_prompt=negs)
+        pad = lambda a, n, v=-1: list(a) + [v] * (n - len(a))
+        res_idx.append(pad(oi, k)); res_room.append(pad(ri, k)); res_score.append(pad(sc, k, np.nan))
+        res_rooms_label.append(pad(rl, R)); res_rooms_view.append(pad(rv, 10))
+        qspec.append([q, q % R, floor_id, len(negs)])
+    # all-rooms query (view mode ids feed object search globally) and a query that IS a negative label
+    oi, ri, sc = g.query_hmsg_object("wall", floor_id=-1, room_ids=list(range(R)), top_k=k,
+                                     negative_prompt=["background", "wall"])
+    out.update(ref_obj_idx=np.array(res_idx), ref_obj_room=np.array(res_room), ref_obj_score=np.array(res_score),
+               ref_rooms_label=np.array(res_rooms_label), ref_rooms_view=np.array(res_rooms_view),
+               qspec=np.array(qspec), ref_neg_idx=np.array(oi), ref_neg_room=np.array(ri), ref_neg_score=np.array(sc))
+    np.savez_compressed(os.path.join(out_dir, "query.npz"), **out)
+    print("query ok", out["ref_obj_idx"][:3])
+
+
+def main():
+    out_dir = os.path.join(REPO, "tests", "golden")
+    os.makedirs(out_dir, exist_ok=True)
+    G, X = import_reference()
+    which = sys.argv[1:] or ["fusion", "feats_dbscan", "query", "build"]
+    for w in which:
+        globals()["gen_" + w](G, X, out_dir)
+
+
+if __name__ == "__main__":
+    main()
