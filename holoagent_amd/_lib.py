@@ -1,0 +1,279 @@
+"""ctypes binding of the C ABI in include/hmsg.h.
+
+The product path loads ONLY `holoagent_amd/libhmsg.so` (hand-written HIP for gfx950, built by
+`__graft_entry__.build()` / `make -C holoagent_amd/csrc`) and raises if it is missing -- there is no
+CPU fallback.  (`HmsgLib(path)` with an explicit path exists so the test-suite can drive the kernel
+simulator build of the same sources, tests/emu/.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhmsg.so")
+
+
+class HmsgConfig(C.Structure):
+    _fields_ = [
+        ("device_id", C.c_int32), ("feat_dim", C.c_int32), ("height", C.c_int32), ("width", C.c_int32),
+        ("max_frames", C.c_int32), ("max_masks", C.c_int32),
+        ("voxel_size", C.c_double), ("depth_scale", C.c_double), ("init_overlap_thresh", C.c_double),
+        ("overlap_thresh_factor", C.c_double), ("iou_thresh", C.c_double), ("clip_masked_weight", C.c_double),
+        ("max_mask_distance", C.c_double), ("merge_type", C.c_int32), ("outlier_nb_points", C.c_int32),
+        ("outlier_radius", C.c_double), ("pool_max_dist", C.c_double), ("feat_dbscan_eps", C.c_double),
+        ("feat_dbscan_min", C.c_int32), ("merge_dbscan_eps", C.c_double), ("merge_dbscan_min", C.c_int32),
+        ("min_instance_points", C.c_int32),
+    ]
+
+
+class HmsgError(RuntimeError):
+    pass
+
+
+_P = C.c_void_p
+_SIGS = {
+    "hmsg_default_config": (None, [C.POINTER(HmsgConfig)]),
+    "hmsg_create": (C.c_int, [C.POINTER(HmsgConfig), C.POINTER(_P)]),
+    "hmsg_destroy": (None, [_P]),
+    "hmsg_last_error": (C.c_char_p, [_P]),
+    "hmsg_version": (C.c_char_p, []),
+    "hmsg_add_frames": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P]),
+    "hmsg_finalize_map": (C.c_int, [_P]),
+    "hmsg_map_size": (C.c_int64, [_P]),
+    "hmsg_map_size_unfiltered": (C.c_int64, [_P]),
+    "hmsg_get_map_points": (C.c_int, [_P, _P, _P]),
+    "hmsg_add_frame_features": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    "hmsg_fuse_frames": (C.c_int, [_P]),
+    "hmsg_get_map_feats": (C.c_int, [_P, _P, _P]),
+    "hmsg_get_frame_nn": (C.c_int, [_P, C.c_int32, _P]),
+    "hmsg_get_frame_fp": (C.c_int, [_P, C.c_int32, _P]),
+    "hmsg_get_frame_mask_sizes": (C.c_int, [_P, C.c_int32, _P]),
+    "hmsg_get_frame_mask_points": (C.c_int, [_P, C.c_int32, _P]),
+    "hmsg_merge_instances": (C.c_int, [_P]),
+    "hmsg_num_instances": (C.c_int64, [_P]),
+    "hmsg_get_instance_sizes": (C.c_int, [_P, _P]),
+    "hmsg_get_instance_points": (C.c_int, [_P, _P]),
+    "hmsg_pool_instances": (C.c_int, [_P]),
+    "hmsg_get_instance_feats": (C.c_int, [_P, _P]),
+    "hmsg_index_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _P, C.c_int32, _P, C.POINTER(_P)]),
+    "hmsg_index_destroy": (None, [_P]),
+    "hmsg_index_last_error": (C.c_char_p, [_P]),
+    "hmsg_query_objects": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
+    "hmsg_similarity": (C.c_int, [_P, C.c_int32, _P, _P]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+
+class HmsgLib:
+    def __init__(self, path: str | None = None):
+        path = path or LIB_PATH
+        if not os.path.exists(path):
+            raise HmsgError(
+                f"{path} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()' "
+                "or make -C holoagent_amd/csrc).  There is no CPU fallback.")
+        self.path = path
+        self.c = C.CDLL(path)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(self.c, name)
+            fn.restype = res
+            fn.argtypes = args
+
+    def default_config(self, **over) -> HmsgConfig:
+        cfg = HmsgConfig()
+        self.c.hmsg_default_config(C.byref(cfg))
+        for k, v in over.items():
+            if not hasattr(cfg, k):
+                raise HmsgError(f"unknown config key {k}")
+            setattr(cfg, k, v)
+        return cfg
+
+
+_default = None
+
+
+def lib() -> HmsgLib:
+    global _default
+    if _default is None:
+        _default = HmsgLib()
+    return _default
+
+
+def _ptr(a):
+    """numpy array / torch tensor (host or device) / int -> void*"""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"], "array must be C-contiguous"
+        return C.c_void_p(a.ctypes.data)
+    if hasattr(a, "data_ptr"):
+        assert a.is_contiguous()
+        return C.c_void_p(a.data_ptr())
+    raise TypeError(type(a))
+
+
+class Scene:
+    """One HMSG scene resident on one GPU (thin handle wrapper over the C ABI)."""
+
+    def __init__(self, cfg: HmsgConfig | None = None, lib_: HmsgLib | None = None, **over):
+        self.L = lib_ or lib()
+        self.cfg = cfg or self.L.default_config(**over)
+        h = _P()
+        rc = self.L.c.hmsg_create(C.byref(self.cfg), C.byref(h))
+        if rc != 0:
+            raise HmsgError(f"hmsg_create failed ({rc})")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.c.hmsg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise HmsgError(f"[{rc}] " + self.L.c.hmsg_last_error(self.h).decode())
+
+    @property
+    def HW(self):
+        return self.cfg.height * self.cfg.width
+
+    # ---- build
+    def add_frames(self, rgb, depth, pose, K):
+        n = int(depth.shape[0])
+        self._ck(self.L.c.hmsg_add_frames(self.h, n, _ptr(rgb), _ptr(depth), _ptr(pose), _ptr(K)))
+
+    def finalize_map(self):
+        self._ck(self.L.c.hmsg_finalize_map(self.h))
+
+    def map_size(self):
+        return int(self.L.c.hmsg_map_size(self.h))
+
+    def map_size_unfiltered(self):
+        return int(self.L.c.hmsg_map_size_unfiltered(self.h))
+
+    def map_points(self, colors=False):
+        V = self.map_size()
+        xyz = np.empty((V, 3), np.float64)
+        rgb = np.empty((V, 3), np.float64) if colors else None
+        self._ck(self.L.c.hmsg_get_map_points(self.h, _ptr(xyz), _ptr(rgb)))
+        return (xyz, rgb) if colors else xyz
+
+    def add_frame_features(self, first, masks, f_g, f_masked, f_crop):
+        n, M = int(f_masked.shape[0]), int(f_masked.shape[1])
+        self._ck(self.L.c.hmsg_add_frame_features(self.h, first, n, M, _ptr(masks), _ptr(f_g), _ptr(f_masked), _ptr(f_crop)))
+        self.M = M
+
+    def fuse_frames(self):
+        self._ck(self.L.c.hmsg_fuse_frames(self.h))
+
+    def map_feats(self, counter=False):
+        V, D = self.map_size(), self.cfg.feat_dim
+        f = np.empty((V, D), np.float32)
+        c = np.empty((V,), np.float32) if counter else None
+        self._ck(self.L.c.hmsg_get_map_feats(self.h, _ptr(f), _ptr(c)))
+        return (f, c) if counter else f
+
+    def frame_nn(self, frame):
+        idx = np.empty((self.cfg.height, self.cfg.width), np.int32)
+        self._ck(self.L.c.hmsg_get_frame_nn(self.h, frame, _ptr(idx)))
+        return idx
+
+    def frame_fp(self, frame):
+        out = np.empty((self.M, self.cfg.feat_dim), np.float32)
+        self._ck(self.L.c.hmsg_get_frame_fp(self.h, frame, _ptr(out)))
+        return out
+
+    def frame_masks3d(self, frame):
+        sizes = np.empty((self.M,), np.int64)
+        self._ck(self.L.c.hmsg_get_frame_mask_sizes(self.h, frame, _ptr(sizes)))
+        pts = np.empty((int(sizes.sum()), 3), np.float64)
+        if pts.shape[0]:
+            self._ck(self.L.c.hmsg_get_frame_mask_points(self.h, frame, _ptr(pts)))
+        off = np.concatenate([[0], np.cumsum(sizes)])
+        return [pts[off[i]:off[i + 1]] for i in range(self.M)]
+
+    def merge_instances(self):
+        self._ck(self.L.c.hmsg_merge_instances(self.h))
+
+    def instances(self):
+        n = int(self.L.c.hmsg_num_instances(self.h))
+        sizes = np.empty((n,), np.int64)
+        self._ck(self.L.c.hmsg_get_instance_sizes(self.h, _ptr(sizes)))
+        pts = np.empty((int(sizes.sum()), 3), np.float64)
+        if pts.shape[0]:
+            self._ck(self.L.c.hmsg_get_instance_points(self.h, _ptr(pts)))
+        off = np.concatenate([[0], np.cumsum(sizes)])
+        return [pts[off[i]:off[i + 1]] for i in range(n)]
+
+    def pool_instances(self):
+        self._ck(self.L.c.hmsg_pool_instances(self.h))
+
+    def instance_feats(self):
+        n = int(self.L.c.hmsg_num_instances(self.h))
+        out = np.empty((n, self.cfg.feat_dim), np.float32)
+        if n:
+            self._ck(self.L.c.hmsg_get_instance_feats(self.h, _ptr(out)))
+        return out
+
+
+class NodeIndex:
+    """Resident node-embedding table for retrieval (graph.py:3056-3162)."""
+
+    def __init__(self, emb: np.ndarray, room_of_node: np.ndarray, device_id=0, lib_: HmsgLib | None = None):
+        self.L = lib_ or lib()
+        emb = np.ascontiguousarray(emb)
+        assert emb.dtype in (np.float32, np.float64)
+        room_of_node = np.ascontiguousarray(room_of_node, dtype=np.int32)
+        self.N, self.D = emb.shape
+        ix = _P()
+        rc = self.L.c.hmsg_index_create(device_id, self.D, self.N, _ptr(emb), int(emb.dtype == np.float64),
+                                        _ptr(room_of_node), C.byref(ix))
+        if rc != 0:
+            raise HmsgError(f"hmsg_index_create failed ({rc})")
+        self.ix = ix
+
+    def close(self):
+        if getattr(self, "ix", None):
+            self.L.c.hmsg_index_destroy(self.ix)
+            self.ix = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise HmsgError(f"[{rc}] " + self.L.c.hmsg_index_last_error(self.ix).decode())
+
+    def query_objects(self, T, qid, room_lists, k, use_negatives=True):
+        T = np.ascontiguousarray(T, dtype=np.float32)
+        Q, Cn, D = T.shape
+        qid = np.ascontiguousarray(qid, dtype=np.int32)
+        off = np.zeros(Q + 1, np.int32)
+        off[1:] = np.cumsum([len(r) for r in room_lists])
+        rooms = np.ascontiguousarray(np.concatenate([np.asarray(r, np.int32) for r in room_lists]) if off[-1] else
+                                     np.zeros(0, np.int32), dtype=np.int32)
+        idx = np.empty((Q, k), np.int32)
+        room = np.empty((Q, k), np.int32)
+        score = np.empty((Q, k), np.float64)
+        self._ck(self.L.c.hmsg_query_objects(self.ix, Q, Cn, _ptr(T), _ptr(qid), _ptr(off), _ptr(rooms), k,
+                                             int(use_negatives), _ptr(idx), _ptr(room), _ptr(score)))
+        return idx, room, score
+
+    def similarity(self, T):
+        T = np.ascontiguousarray(T, dtype=np.float32)
+        S = np.empty((T.shape[0], self.N), np.float64)
+        self._ck(self.L.c.hmsg_similarity(self.ix, T.shape[0], _ptr(T), _ptr(S)))
+        return S

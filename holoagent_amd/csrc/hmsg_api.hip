@@ -1,0 +1,309 @@
+// C ABI of libhmsg (see include/hmsg.h).  Thin: argument checks, host<->HBM staging, error capture.
+#include "hmsg_common.h"
+
+#include <algorithm>
+#include <cstring>
+
+void hmsg_bitset_and_fp(hmsg_ctx* h, int first, int n, int M, const unsigned char* d_masks, const float* d_fg,
+                        const float* d_fm, const float* d_fc);   // hmsg_fuse.hip
+
+namespace {
+
+bool is_device_ptr(const void* p) {
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof(a));
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice;
+}
+
+void copy_in(void* dst, const void* src, size_t bytes, hipStream_t s) {
+    if (!bytes) return;
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, is_device_ptr(src) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+}
+
+template <typename F>
+int guard(hmsg_ctx* h, F&& fn) {
+    try {
+        if (h) HIP_TRY(hipSetDevice(h->cfg.device_id));
+        fn();
+        return HMSG_OK;
+    } catch (const hmsg_error& e) {
+        if (h) h->err = e.msg;
+        return e.code;
+    } catch (const std::exception& e) {
+        if (h) h->err = e.what();
+        return HMSG_ERR_INVALID;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* hmsg_version(void) { return "hmsg-mi355x 0.1 (gfx950)"; }
+
+void hmsg_default_config(hmsg_config* c) {
+    memset(c, 0, sizeof(*c));
+    c->device_id = 0;
+    c->feat_dim = 512;
+    c->height = 480;
+    c->width = 640;
+    c->max_frames = 1024;
+    c->max_masks = 64;
+    c->voxel_size = 0.05;
+    c->depth_scale = 1000.0;
+    c->init_overlap_thresh = 0.75;
+    c->overlap_thresh_factor = 0.025;
+    c->iou_thresh = 0.05;
+    c->clip_masked_weight = 0.4418;
+    c->max_mask_distance = 10000.0;
+    c->merge_type = HMSG_MERGE_SEQUENTIAL;
+    c->outlier_nb_points = 1000;
+    c->outlier_radius = 1.0;
+    c->pool_max_dist = 0.8;
+    c->feat_dbscan_eps = 0.01;
+    c->feat_dbscan_min = 100;
+    c->merge_dbscan_eps = 0.1;
+    c->merge_dbscan_min = 10;
+    c->min_instance_points = 10;
+}
+
+int hmsg_create(const hmsg_config* cfg, hmsg_t** out) {
+    if (!cfg || !out) return HMSG_ERR_INVALID;
+    *out = nullptr;
+    if (cfg->feat_dim <= 0 || cfg->height <= 0 || cfg->width <= 0 || cfg->max_frames <= 0 || cfg->voxel_size <= 0 ||
+        cfg->max_masks <= 0 || cfg->max_masks > 64)
+        return HMSG_ERR_INVALID;
+    hmsg_ctx* h = new hmsg_ctx();
+    h->cfg = *cfg;
+    int rc = guard(h, [&] {
+        int ndev = 0;
+        HIP_TRY(hipGetDeviceCount(&ndev));
+        HMSG_REQUIRE(cfg->device_id >= 0 && cfg->device_id < ndev, HMSG_ERR_INVALID, "device_id out of range");
+        HIP_TRY(hipSetDevice(cfg->device_id));
+        HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        const size_t HW = (size_t)cfg->height * cfg->width;
+        h->rgb.alloc(HW * 3 * cfg->max_frames);
+        h->depth.alloc(HW * cfg->max_frames);
+        h->pose.alloc((size_t)16 * cfg->max_frames);
+    });
+    if (rc != HMSG_OK) {
+        fprintf(stderr, "hmsg_create: %s\n", h->err.c_str());
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return HMSG_OK;
+}
+
+void hmsg_destroy(hmsg_t* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device_id);
+    if (h->stream) {
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipStreamDestroy(h->stream);
+    }
+    delete h;
+}
+
+const char* hmsg_last_error(const hmsg_t* h) { return h ? h->err.c_str() : "null handle"; }
+
+int hmsg_add_frames(hmsg_t* h, int32_t n, const uint8_t* rgb, const uint16_t* depth, const double* pose, const double* K) {
+    if (!h) return HMSG_ERR_INVALID;
+    return guard(h, [&] {
+        HMSG_REQUIRE(n >= 0 && rgb && depth && pose && K, HMSG_ERR_INVALID, "hmsg_add_frames: null argument");
+        HMSG_REQUIRE(!h->map_ready, HMSG_ERR_INVALID, "hmsg_add_frames after hmsg_finalize_map");
+        HMSG_REQUIRE(h->n_frames + n <= h->cfg.max_frames, HMSG_ERR_INVALID, "frame store full (cfg.max_frames)");
+        double Kh[9];
+        if (is_device_ptr(K)) {
+            HIP_TRY(hipMemcpy(Kh, K, sizeof(Kh), hipMemcpyDeviceToHost));
+        } else {
+            memcpy(Kh, K, sizeof(Kh));
+        }
+        if (h->have_K)
+            HMSG_REQUIRE(memcmp(Kh, h->K, sizeof(Kh)) == 0, HMSG_ERR_UNSUPPORTED, "intrinsics must be the same for all frames");
+        memcpy(h->K, Kh, sizeof(Kh));
+        h->have_K = true;
+        h->cam = CamK{Kh[0], Kh[4], Kh[2], Kh[5]};
+        const size_t HW = (size_t)h->cfg.height * h->cfg.width;
+        copy_in(h->rgb.p + (size_t)h->n_frames * HW * 3, rgb, (size_t)n * HW * 3, h->stream);
+        copy_in(h->depth.p + (size_t)h->n_frames * HW, depth, (size_t)n * HW * 2, h->stream);
+        copy_in(h->pose.p + (size_t)h->n_frames * 16, pose, (size_t)n * 16 * 8, h->stream);
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        h->n_frames += n;
+    });
+}
+
+int hmsg_finalize_map(hmsg_t* h) {
+    if (!h) return HMSG_ERR_INVALID;
+    return guard(h, [&] {
+        HMSG_REQUIRE(!h->map_ready, HMSG_ERR_INVALID, "map already finalised");
+        hmsg_build_map(h);
+    });
+}
+
+int64_t hmsg_map_size(const hmsg_t* h) { return h && h->map_ready ? h->V : -1; }
+int64_t hmsg_map_size_unfiltered(const hmsg_t* h) { return h && h->map_ready ? h->V0 : -1; }
+
+int hmsg_get_map_points(const hmsg_t* hc, double* xyz, double* rgb) {
+    hmsg_ctx* h = const_cast<hmsg_ctx*>(hc);
+    if (!h) return HMSG_ERR_INVALID;
+    return guard(h, [&] {
+        HMSG_REQUIRE(h->map_ready, HMSG_ERR_INVALID, "map not finalised");
+        if (xyz) HIP_TRY(hipMemcpy(xyz, h->pts.p, (size_t)h->V * 24, hipMemcpyDeviceToHost));
+        if (rgb) HIP_TRY(hipMemcpy(rgb, h->cols.p, (size_t)h->V * 24, hipMemcpyDeviceToHost));
+    });
+}
+
+int hmsg_add_frame_features(hmsg_t* h, int32_t first, int32_t n, int32_t M, const uint8_t* masks, const float* F_g,
+                            const float* F_masked, const float* F_crop) {
+    if (!h) return HMSG_ERR_INVALID;
+    return guard(h, [&] {
+        HMSG_REQUIRE(n >= 0 && masks && F_g && F_masked && F_crop, HMSG_ERR_INVALID, "hmsg_add_frame_features: null argument");
+        HMSG_REQUIRE(M > 0 && M <= h->cfg.max_masks, HMSG_ERR_INVALID, "M out of range (cfg.max_masks, <= 64)");
+        HMSG_REQUIRE(first == h->n_feat_frames, HMSG_ERR_INVALID, "frames must be handed over in order (first == #frames so far)");
+        HMSG_REQUIRE(first + n <= h->n_frames, HMSG_ERR_INVALID, "features for a frame without geometry");
+        HMSG_REQUIRE(h->M == 0 || h->M == M, HMSG_ERR_UNSUPPORTED, "M must be the same for all frames (pad with empty masks)");
+        h->M = M;
+        const size_t HW = (size_t)h->cfg.height * h->cfg.width;
+        const int D = h->cfg.feat_dim;
+        if (h->bits.n < (size_t)h->cfg.max_frames * HW) h->bits.alloc((size_t)h->cfg.max_frames * HW);
+        if (h->fp.n < (size_t)h->cfg.max_frames * M * D) h->fp.alloc((size_t)h->cfg.max_frames * M * D);
+        const bool dev = is_device_ptr(masks);
+        const int chunk = dev ? n : std::max(1, (int)(((size_t)512 << 20) / ((size_t)M * HW)));
+        DevBuf<unsigned char> st_m;
+        DevBuf<float> st_f;
+        for (int c0 = 0; c0 < n; c0 += chunk) {
+            int nc = std::min(chunk, n - c0);
+            const unsigned char* dm = masks + (size_t)c0 * M * HW;
+            const float *dg = F_g + (size_t)c0 * D, *dfm = F_masked + (size_t)c0 * M * D, *dfc = F_crop + (size_t)c0 * M * D;
+            if (!dev) {
+                st_m.ensure((size_t)nc * M * HW);
+                HIP_TRY(hipMemcpyAsync(st_m.p, dm, (size_t)nc * M * HW, hipMemcpyHostToDevice, h->stream));
+                dm = st_m.p;
+            }
+            if (!is_device_ptr(F_g) || !is_device_ptr(F_masked) || !is_device_ptr(F_crop)) {
+                st_f.ensure((size_t)nc * (2 * M + 1) * D);
+                float* g = st_f.p;
+                float* fm = g + (size_t)nc * D;
+                float* fc = fm + (size_t)nc * M * D;
+                copy_in(g, dg, (size_t)nc * D * 4, h->stream);
+                copy_in(fm, dfm, (size_t)nc * M * D * 4, h->stream);
+                copy_in(fc, dfc, (size_t)nc * M * D * 4, h->stream);
+                dg = g;
+                dfm = fm;
+                dfc = fc;
+            }
+            hmsg_bitset_and_fp(h, first + c0, nc, M, dm, dg, dfm, dfc);
+            HIP_TRY(hipStreamSynchronize(h->stream));
+        }
+        h->n_feat_frames += n;
+    });
+}
+
+int hmsg_fuse_frames(hmsg_t* h) {
+    if (!h) return HMSG_ERR_INVALID;
+    return guard(h, [&] { hmsg_fuse(h); });
+}
+
+int hmsg_get_map_feats(const hmsg_t* hc, float* feats, float* counter) {
+    hmsg_ctx* h = const_cast<hmsg_ctx*>(hc);
+    if (!h) return HMSG_ERR_INVALID;
+    return guard(h, [&] {
+        HMSG_REQUIRE(h->feats_final, HMSG_ERR_INVALID, "hmsg_fuse_frames not run");
+        if (feats) HIP_TRY(hipMemcpy(feats, h->feats.p, (size_t)h->V * h->cfg.feat_dim * 4, hipMemcpyDeviceToHost));
+        if (counter) {
+            std::vector<unsigned> c((size_t)h->V);
+            HIP_TRY(hipMemcpy(c.data(), h->cnt.p, (size_t)h->V * 4, hipMemcpyDeviceToHost));
+            for (long long i = 0; i < h->V; ++i) counter[i] = (float)c[i];
+        }
+    });
+}
+
+int hmsg_get_frame_nn(const hmsg_t* hc, int32_t frame, int32_t* idx) {
+    hmsg_ctx* h = const_cast<hmsg_ctx*>(hc);
+    if (!h) return HMSG_ERR_INVALID;
+    return guard(h, [&] {
+        HMSG_REQUIRE(frame >= 0 && frame < h->n_fused && idx, HMSG_ERR_INVALID, "frame not fused");
+        const size_t HW = (size_t)h->cfg.height * h->cfg.width;
+        HIP_TRY(hipMemcpy(idx, h->nn.p + (size_t)frame * HW, HW * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+int hmsg_get_frame_fp(const hmsg_t* hc, int32_t frame, float* f_p) {
+    hmsg_ctx* h = const_cast<hmsg_ctx*>(hc);
+    if (!h) return HMSG_ERR_INVALID;
+    return guard(h, [&] {
+        HMSG_REQUIRE(frame >= 0 && frame < h->n_feat_frames && f_p, HMSG_ERR_INVALID, "frame has no features");
+        size_t n = (size_t)h->M * h->cfg.feat_dim;
+        HIP_TRY(hipMemcpy(f_p, h->fp.p + (size_t)frame * n, n * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+int hmsg_get_frame_mask_sizes(const hmsg_t* hc, int32_t frame, int64_t* sizes) {
+    hmsg_ctx* h = const_cast<hmsg_ctx*>(hc);
+    if (!h) return HMSG_ERR_INVALID;
+    return guard(h, [&] {
+        HMSG_REQUIRE(frame >= 0 && frame < h->n_fused && sizes, HMSG_ERR_INVALID, "frame not fused");
+        for (int i = 0; i < h->M; ++i) {
+            size_t k = (size_t)frame * h->M + i;
+            sizes[i] = h->masks3d.off[k + 1] - h->masks3d.off[k];
+        }
+    });
+}
+
+int hmsg_get_frame_mask_points(const hmsg_t* hc, int32_t frame, double* xyz) {
+    hmsg_ctx* h = const_cast<hmsg_ctx*>(hc);
+    if (!h) return HMSG_ERR_INVALID;
+    return guard(h, [&] {
+        HMSG_REQUIRE(frame >= 0 && frame < h->n_fused && xyz, HMSG_ERR_INVALID, "frame not fused");
+        long long a = h->masks3d.off[(size_t)frame * h->M], b = h->masks3d.off[(size_t)(frame + 1) * h->M];
+        if (b > a) HIP_TRY(hipMemcpy(xyz, h->masks3d.pts.p + (size_t)a * 3, (size_t)(b - a) * 24, hipMemcpyDeviceToHost));
+    });
+}
+
+int hmsg_merge_instances(hmsg_t* h) {
+    if (!h) return HMSG_ERR_INVALID;
+    return guard(h, [&] { hmsg_merge(h); });
+}
+
+int64_t hmsg_num_instances(const hmsg_t* h) { return h && h->merged ? (int64_t)h->inst.off.size() - 1 : -1; }
+
+int hmsg_get_instance_sizes(const hmsg_t* hc, int64_t* sizes) {
+    hmsg_ctx* h = const_cast<hmsg_ctx*>(hc);
+    if (!h) return HMSG_ERR_INVALID;
+    return guard(h, [&] {
+        HMSG_REQUIRE(h->merged && sizes, HMSG_ERR_INVALID, "hmsg_merge_instances not run");
+        for (size_t i = 0; i + 1 < h->inst.off.size(); ++i) sizes[i] = h->inst.off[i + 1] - h->inst.off[i];
+    });
+}
+
+int hmsg_get_instance_points(const hmsg_t* hc, double* xyz) {
+    hmsg_ctx* h = const_cast<hmsg_ctx*>(hc);
+    if (!h) return HMSG_ERR_INVALID;
+    return guard(h, [&] {
+        HMSG_REQUIRE(h->merged && xyz, HMSG_ERR_INVALID, "hmsg_merge_instances not run");
+        if (h->inst.total) HIP_TRY(hipMemcpy(xyz, h->inst.pts.p, (size_t)h->inst.total * 24, hipMemcpyDeviceToHost));
+    });
+}
+
+int hmsg_pool_instances(hmsg_t* h) {
+    if (!h) return HMSG_ERR_INVALID;
+    return guard(h, [&] { hmsg_pool(h); });
+}
+
+int hmsg_get_instance_feats(const hmsg_t* hc, float* feats) {
+    hmsg_ctx* h = const_cast<hmsg_ctx*>(hc);
+    if (!h) return HMSG_ERR_INVALID;
+    return guard(h, [&] {
+        HMSG_REQUIRE(h->pooled && feats, HMSG_ERR_INVALID, "hmsg_pool_instances not run");
+        size_t n = (h->inst.off.size() - 1) * (size_t)h->cfg.feat_dim;
+        if (n) HIP_TRY(hipMemcpy(feats, h->inst_feats.p, n * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+}  // extern "C"

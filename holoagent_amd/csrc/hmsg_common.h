@@ -1,0 +1,202 @@
+// Shared state + device helpers of libhmsg (MI355X / gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/hmsg.h"
+
+#define HMSG_WAVE 64
+
+// ------------------------------------------------------------------ error plumbing
+struct hmsg_error {
+    int code;
+    std::string msg;
+};
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) throw hmsg_error{HMSG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)}; \
+    } while (0)
+#define HMSG_REQUIRE(cond, code, text) \
+    do {                               \
+        if (!(cond)) throw hmsg_error{code, text}; \
+    } while (0)
+#define HMSG_CHECK_LAUNCH() HIP_TRY(hipGetLastError())
+
+static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+// ------------------------------------------------------------------ device buffer (owned)
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    void alloc(size_t count) {
+        release();
+        if (count == 0) count = 1;
+        HIP_TRY(hipMalloc((void**)&p, count * sizeof(T)));
+        n = count;
+    }
+    void ensure(size_t count) {
+        if (count > n) alloc(count + count / 4);
+    }
+    void zero(hipStream_t s) { HIP_TRY(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+// ------------------------------------------------------------------ grid geometry (global voxel grid)
+// Linearisation: lin = (ix * NY + iy) * NZP + iz, NZP = NZ rounded up to 64 so a z-column starts on a
+// 64-bit word; slot of an occupied cell = rank[word] + popc(bits below) = its position in ascending
+// (ix, iy, iz) order (the canonical order of the oracle's voxel_down_sample).
+struct GridGeom {
+    double ox, oy, oz;   // voxel_min_bound = min_bound - vs/2  (Open3D VoxelDownSample)
+    double vs;
+    int nx, ny, nz, nzp; // nzp % 64 == 0
+    long long nwords;
+};
+
+struct CamK {
+    double fx, fy, cx, cy;
+};
+
+// ------------------------------------------------------------------ device helpers
+__device__ __forceinline__ unsigned long long enc_f64(double d) {
+    unsigned long long b = (unsigned long long)__double_as_longlong(d);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+static inline double dec_f64(unsigned long long e) {   // host side inverse of enc_f64
+    unsigned long long b = (e >> 63) ? (e & 0x7fffffffffffffffull) : ~e;
+    double d;
+    std::memcpy(&d, &b, 8);
+    return d;
+}
+
+// generic.py:111-124 + Open3D transform (generic.py:137): z = f32(depth)/f32(scale); X = (x-cx)*z/fx in
+// f64; world = ((X*T00 + Y*T01) + Z*T02) + T03, divided by the homogeneous w.  No FMA contraction.
+__device__ __forceinline__ bool backproject(unsigned short d, int x, int y, const CamK& k, float scale,
+                                            const double* __restrict__ T, double& wx, double& wy, double& wz) {
+    float z = __fdiv_rn((float)d, scale);
+    if (!(z > 0.0f)) return false;
+    double Z = (double)z;
+    double X = __ddiv_rn(__dmul_rn(__dsub_rn((double)x, k.cx), Z), k.fx);
+    double Y = __ddiv_rn(__dmul_rn(__dsub_rn((double)y, k.cy), Z), k.fy);
+    double a = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(X, T[0]), __dmul_rn(Y, T[1])), __dmul_rn(Z, T[2])), T[3]);
+    double b = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(X, T[4]), __dmul_rn(Y, T[5])), __dmul_rn(Z, T[6])), T[7]);
+    double c = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(X, T[8]), __dmul_rn(Y, T[9])), __dmul_rn(Z, T[10])), T[11]);
+    double w = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(X, T[12]), __dmul_rn(Y, T[13])), __dmul_rn(Z, T[14])), T[15]);
+    wx = __ddiv_rn(a, w);
+    wy = __ddiv_rn(b, w);
+    wz = __ddiv_rn(c, w);
+    return true;
+}
+
+__device__ __forceinline__ void cell_of(const GridGeom& g, double wx, double wy, double wz, int& ix, int& iy, int& iz) {
+    ix = (int)floor(__ddiv_rn(__dsub_rn(wx, g.ox), g.vs));
+    iy = (int)floor(__ddiv_rn(__dsub_rn(wy, g.oy), g.vs));
+    iz = (int)floor(__ddiv_rn(__dsub_rn(wz, g.oz), g.vs));
+}
+__device__ __forceinline__ long long lin_of(const GridGeom& g, int ix, int iy, int iz) {
+    return ((long long)ix * g.ny + iy) * g.nzp + iz;
+}
+
+__device__ __forceinline__ double wave_min_f64(double v) {
+    for (int o = 32; o > 0; o >>= 1) {
+        double t = __shfl_xor(v, o);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+    for (int o = 32; o > 0; o >>= 1) {
+        double t = __shfl_xor(v, o);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------ scene state
+struct MaskCloudSet {            // 3-D masks of all fused frames (generic.py:140-190 outputs)
+    DevBuf<double> pts;          // [total][3]
+    std::vector<long long> off;  // per (frame*M + i) offset into pts, size F*M + 1
+    long long total = 0;
+};
+
+struct InstanceSet {             // merged instances (graph.py:425-448)
+    DevBuf<double> pts;
+    std::vector<long long> off;
+    long long total = 0;
+};
+
+struct hmsg_ctx {
+    hmsg_config cfg;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int n_frames = 0;       // frames with geometry
+    int n_feat_frames = 0;  // frames with features handed over (prefix 0..n-1)
+    int n_fused = 0;        // frames processed by hmsg_fuse_frames
+    int M = 0;              // masks per frame (fixed per scene)
+    CamK cam;
+    double K[9];
+    bool have_K = false;
+    // resident frame store
+    DevBuf<unsigned char> rgb;     // [F][H][W][3]
+    DevBuf<unsigned short> depth;  // [F][H][W]
+    DevBuf<double> pose;           // [F][16]
+    DevBuf<unsigned long long> bits;  // [F][H][W] mask-membership bitset per pixel
+    DevBuf<float> fp;              // [F][M][D]   F_p
+    DevBuf<int> nn;                // [F][H][W]   NN index into the filtered cloud (-1 invalid)
+    // global voxel map
+    bool map_ready = false;
+    GridGeom grid;
+    long long V0 = 0;              // voxels before radius-outlier filtering
+    long long V = 0;               // filtered cloud size
+    DevBuf<unsigned long long> bitmap;  // occupancy of the FILTERED cloud
+    DevBuf<unsigned> rank;              // exclusive popcount prefix per word
+    DevBuf<double> pts;            // [V][3]
+    DevBuf<double> cols;           // [V][3]
+    DevBuf<float> sum;             // [V][D]
+    DevBuf<unsigned> cnt;          // [V]
+    bool feats_final = false;
+    DevBuf<float> feats;           // [V][D] = sum / counter
+    MaskCloudSet masks3d;
+    InstanceSet inst;
+    bool merged = false;
+    DevBuf<float> inst_feats;      // [N][D]
+    bool pooled = false;
+    // scratch
+    DevBuf<unsigned> scan_tmp;
+};
+
+// exclusive prefix sum of u32 (returns total via host sync when `total` != nullptr)
+void hmsg_scan_u32(const unsigned* in, unsigned* out, size_t n, hipStream_t s, DevBuf<unsigned>& tmp,
+                   unsigned long long* total);
+// popcount-prefix of a bitmap: rank[w] = number of set bits in words < w; returns total set bits
+unsigned long long hmsg_bitmap_rank(const unsigned long long* bitmap, unsigned* rank, size_t nwords, hipStream_t s,
+                                    DevBuf<unsigned>& tmp);
+
+void hmsg_build_map(hmsg_ctx* h);       // hmsg_map.hip
+void hmsg_fuse(hmsg_ctx* h);            // hmsg_fuse.hip
+void hmsg_merge(hmsg_ctx* h);           // hmsg_merge.hip
+void hmsg_pool(hmsg_ctx* h);            // hmsg_pool.hip

@@ -1,0 +1,427 @@
+// A1 + A2: RGB-D back-projection of every resident frame, voxel_down_sample into the global cloud,
+// remove_radius_outlier, and the occupancy-bitmap + rank index that replaces cKDTree.
+//
+// Reference: dataloader/generic.py:74-138 (create_pcd), graph/graph.py:339-364 (loop A, filtering,
+// tree build).  Open3D semantics restated in oracle/hmsg_oracle.py (o3d_voxel_down_sample,
+// o3d_remove_radius_outlier).
+//
+// MI355X design: all frames stay resident in HBM (depth u16 + rgb u8 = 1.5 MB/frame), so the global
+// min bound (which fixes Open3D's voxel grid origin) is one streaming reduction, and voxelisation is
+// "sort by counting": pass 1 marks an occupancy bitmap laid out (ix, iy, iz)-major, a popcount prefix
+// (rank) turns a cell into its slot in canonical order, pass 2 accumulates per-slot sums with integer
+// atomics (fixed-point offsets from the cell corner -> order-independent, bit-reproducible).
+#include "hmsg_common.h"
+
+#define FIX_SCALE 70368744177664.0 /* 2^46: 1.4e-14 m resolution */
+
+// ------------------------------------------------------------------------------------------ scans
+__global__ void k_scan_block(const unsigned* __restrict__ in, unsigned* __restrict__ out, unsigned* __restrict__ sums,
+                             size_t n) {
+    __shared__ unsigned wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    size_t base = ((size_t)blockIdx.x * 256 + tid) * 4;
+    unsigned v[4];
+    unsigned t = 0;
+    for (int i = 0; i < 4; ++i) {
+        v[i] = base + i < n ? in[base + i] : 0u;
+        t += v[i];
+    }
+    unsigned incl = t;   // inclusive wave scan
+    for (int o = 1; o < 64; o <<= 1) {
+        unsigned u = __shfl_up(incl, o);
+        if (lane >= o) incl += u;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    unsigned woff = 0;
+    for (int i = 0; i < w; ++i) woff += wsum[i];
+    unsigned excl = woff + incl - t;
+    for (int i = 0; i < 4; ++i) {
+        if (base + i < n) out[base + i] = excl;
+        excl += v[i];
+    }
+    if (tid == 255) sums[blockIdx.x] = woff + incl;
+}
+__global__ void k_scan_add(unsigned* __restrict__ out, const unsigned* __restrict__ offs, size_t n) {
+    size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    unsigned o = offs[blockIdx.x];
+    for (int i = 0; i < 4; ++i)
+        if (base + i < n) out[base + i] += o;
+}
+
+static void scan_rec(const unsigned* in, unsigned* out, size_t n, hipStream_t s, unsigned* tmp, size_t tmp_n) {
+    size_t nb = (n + 1023) / 1024;
+    HMSG_REQUIRE(nb <= tmp_n, HMSG_ERR_INVALID, "scan scratch too small");
+    hipLaunchKernelGGL(k_scan_block, dim3((unsigned)nb), dim3(256), 0, s, in, out, tmp, n);
+    HMSG_CHECK_LAUNCH();
+    if (nb > 1) {
+        scan_rec(tmp, tmp, nb, s, tmp + nb, tmp_n - nb);
+        hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(256), 0, s, out, (const unsigned*)tmp, n);
+        HMSG_CHECK_LAUNCH();
+    }
+}
+
+void hmsg_scan_u32(const unsigned* in, unsigned* out, size_t n, hipStream_t s, DevBuf<unsigned>& tmp,
+                   unsigned long long* total) {
+    if (n == 0) {
+        if (total) *total = 0;
+        return;
+    }
+    size_t need = (n + 1023) / 1024 * 2 + 64;
+    tmp.ensure(need);
+    unsigned last_in = 0, last_out = 0;
+    if (total) HIP_TRY(hipMemcpyAsync(&last_in, in + n - 1, 4, hipMemcpyDeviceToHost, s));
+    scan_rec(in, out, n, s, tmp.p, tmp.n);
+    if (total) {
+        HIP_TRY(hipMemcpyAsync(&last_out, out + n - 1, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        *total = (unsigned long long)last_in + last_out;
+    }
+}
+
+__global__ void k_popc_words(const unsigned long long* __restrict__ bm, unsigned* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (unsigned)__popcll(bm[i]);
+}
+
+unsigned long long hmsg_bitmap_rank(const unsigned long long* bitmap, unsigned* rank, size_t nwords, hipStream_t s,
+                                    DevBuf<unsigned>& tmp) {
+    hipLaunchKernelGGL(k_popc_words, dim3(cdiv(nwords, 256)), dim3(256), 0, s, bitmap, rank, nwords);
+    HMSG_CHECK_LAUNCH();
+    unsigned long long total = 0;
+    hmsg_scan_u32(rank, rank, nwords, s, tmp, &total);
+    return total;
+}
+
+// ------------------------------------------------------------------------------------------ bounds
+__global__ void k_bounds(const unsigned short* __restrict__ depth, const double* __restrict__ pose, CamK cam,
+                         float scale, int H, int W, int F, unsigned long long* __restrict__ out /*[6] enc min3,max3*/,
+                         unsigned long long* __restrict__ npts) {
+    const size_t HW = (size_t)H * W;
+    const size_t total = HW * F;
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    unsigned cnt = 0;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        int f = (int)(g / HW);
+        int p = (int)(g - (size_t)f * HW);
+        int y = p / W, x = p - y * W;
+        double w[3];
+        if (backproject(depth[g], x, y, cam, scale, pose + (size_t)f * 16, w[0], w[1], w[2])) {
+            for (int a = 0; a < 3; ++a) {
+                mn[a] = w[a] < mn[a] ? w[a] : mn[a];
+                mx[a] = w[a] > mx[a] ? w[a] : mx[a];
+            }
+            cnt++;
+        }
+    }
+    for (int a = 0; a < 3; ++a) {
+        mn[a] = wave_min_f64(mn[a]);
+        mx[a] = wave_max_f64(mx[a]);
+    }
+    int c = wave_sum_i32((int)cnt);
+    if ((threadIdx.x & 63) == 0) {
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&out[a], enc_f64(mn[a]));
+            atomicMax(&out[3 + a], enc_f64(mx[a]));
+        }
+        atomicAdd(npts, (unsigned long long)c);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ mark + accumulate
+__global__ void k_mark(const unsigned short* __restrict__ depth, const double* __restrict__ pose, CamK cam, float scale,
+                       int H, int W, int F, GridGeom g, unsigned long long* __restrict__ bitmap) {
+    const size_t HW = (size_t)H * W;
+    const size_t total = HW * F;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int f = (int)(i / HW);
+        int p = (int)(i - (size_t)f * HW);
+        int y = p / W, x = p - y * W;
+        double wx, wy, wz;
+        if (!backproject(depth[i], x, y, cam, scale, pose + (size_t)f * 16, wx, wy, wz)) continue;
+        int ix, iy, iz;
+        cell_of(g, wx, wy, wz, ix, iy, iz);
+        long long lin = lin_of(g, ix, iy, iz);
+        unsigned long long bit = 1ull << (lin & 63);
+        unsigned long long* wp = bitmap + (lin >> 6);
+        if (!(*wp & bit)) atomicOr(wp, bit);
+    }
+}
+
+struct VoxAcc {                 // per-slot accumulators (SoA)
+    long long* sx;
+    long long* sy;
+    long long* sz;
+    unsigned long long* sr;
+    unsigned long long* sg;
+    unsigned long long* sb;
+    unsigned* n;
+};
+
+__global__ void k_accum(const unsigned short* __restrict__ depth, const unsigned char* __restrict__ rgb,
+                        const double* __restrict__ pose, CamK cam, float scale, int H, int W, int F, GridGeom g,
+                        const unsigned long long* __restrict__ bitmap, const unsigned* __restrict__ rank, VoxAcc acc) {
+    const size_t HW = (size_t)H * W;
+    const size_t total = HW * F;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int f = (int)(i / HW);
+        int p = (int)(i - (size_t)f * HW);
+        int y = p / W, x = p - y * W;
+        double wx, wy, wz;
+        if (!backproject(depth[i], x, y, cam, scale, pose + (size_t)f * 16, wx, wy, wz)) continue;
+        int ix, iy, iz;
+        cell_of(g, wx, wy, wz, ix, iy, iz);
+        long long lin = lin_of(g, ix, iy, iz);
+        unsigned long long word = bitmap[lin >> 6];
+        unsigned slot = rank[lin >> 6] + (unsigned)__popcll(word & ((1ull << (lin & 63)) - 1ull));
+        double cx = __dadd_rn(g.ox, __dmul_rn((double)ix, g.vs));
+        double cy = __dadd_rn(g.oy, __dmul_rn((double)iy, g.vs));
+        double cz = __dadd_rn(g.oz, __dmul_rn((double)iz, g.vs));
+        long long qx = (long long)llrint((wx - cx) * FIX_SCALE);
+        long long qy = (long long)llrint((wy - cy) * FIX_SCALE);
+        long long qz = (long long)llrint((wz - cz) * FIX_SCALE);
+        atomicAdd((unsigned long long*)&acc.sx[slot], (unsigned long long)qx);
+        atomicAdd((unsigned long long*)&acc.sy[slot], (unsigned long long)qy);
+        atomicAdd((unsigned long long*)&acc.sz[slot], (unsigned long long)qz);
+        const unsigned char* c = rgb + i * 3;
+        atomicAdd(&acc.sr[slot], (unsigned long long)c[0]);
+        atomicAdd(&acc.sg[slot], (unsigned long long)c[1]);
+        atomicAdd(&acc.sb[slot], (unsigned long long)c[2]);
+        atomicAdd(&acc.n[slot], 1u);
+    }
+}
+
+// slot -> cell coordinates (one thread per bitmap word)
+__global__ void k_slot_cells(const unsigned long long* __restrict__ bitmap, const unsigned* __restrict__ rank,
+                             GridGeom g, int* __restrict__ cell /*[V][3]*/) {
+    long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= g.nwords) return;
+    unsigned long long bits = bitmap[w];
+    unsigned s = rank[w];
+    while (bits) {
+        int b = __ffsll(bits) - 1;
+        bits &= bits - 1;
+        long long lin = w * 64 + b;
+        int iz = (int)(lin % g.nzp);
+        long long r = lin / g.nzp;
+        int iy = (int)(r % g.ny);
+        int ix = (int)(r / g.ny);
+        cell[(size_t)s * 3 + 0] = ix;
+        cell[(size_t)s * 3 + 1] = iy;
+        cell[(size_t)s * 3 + 2] = iz;
+        ++s;
+    }
+}
+
+__global__ void k_finalize(VoxAcc acc, const int* __restrict__ cell, GridGeom g, long long V, double* __restrict__ pts,
+                           double* __restrict__ cols) {
+    long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= V) return;
+    double n = (double)acc.n[s];
+    double corner[3] = {__dadd_rn(g.ox, __dmul_rn((double)cell[s * 3 + 0], g.vs)),
+                        __dadd_rn(g.oy, __dmul_rn((double)cell[s * 3 + 1], g.vs)),
+                        __dadd_rn(g.oz, __dmul_rn((double)cell[s * 3 + 2], g.vs))};
+    pts[s * 3 + 0] = corner[0] + ((double)acc.sx[s] / n) / FIX_SCALE;
+    pts[s * 3 + 1] = corner[1] + ((double)acc.sy[s] / n) / FIX_SCALE;
+    pts[s * 3 + 2] = corner[2] + ((double)acc.sz[s] / n) / FIX_SCALE;
+    cols[s * 3 + 0] = ((double)acc.sr[s] / 255.0) / n;
+    cols[s * 3 + 1] = ((double)acc.sg[s] / 255.0) / n;
+    cols[s * 3 + 2] = ((double)acc.sb[s] / 255.0) / n;
+}
+
+// ------------------------------------------------------------------------------------------ radius outlier
+// Open3D RemoveRadiusOutliers: keep p iff #{q : |p-q| < radius} (incl. p) > nb_points.  One wave per
+// point; lanes sweep the (ix', iy') columns of the cube around p.  In a column the cells certainly
+// inside the ball are counted with popcounts of the bitmap words, only the cells that straddle the
+// sphere are tested point by point.
+__device__ __forceinline__ unsigned long long bits_range(int lo, int hi) {   // bits lo..hi inclusive within a word
+    if (hi < lo) return 0ull;
+    unsigned long long m = (hi >= 63) ? ~0ull : ((1ull << (hi + 1)) - 1ull);
+    return m & ~((1ull << lo) - 1ull);
+}
+
+__global__ void k_outlier(const double* __restrict__ pts, const int* __restrict__ cell, long long V, GridGeom g,
+                          const unsigned long long* __restrict__ bitmap, const unsigned* __restrict__ rank,
+                          double radius, int nb_points, unsigned* __restrict__ keep) {
+    const int lane = threadIdx.x & 63;
+    const long long s = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (s >= V) return;
+    const double px = pts[s * 3], py = pts[s * 3 + 1], pz = pts[s * 3 + 2];
+    const int cx = cell[s * 3], cy = cell[s * 3 + 1];
+    const int R = (int)ceil(radius / g.vs) + 1;
+    const int side = 2 * R + 1;
+    const double r2 = radius * radius;
+    const double slack = 1e-7;
+    int count = 0;
+    for (int c = lane; c < side * side; c += 64) {
+        int ix = cx - R + c / side, iy = cy - R + c % side;
+        if (ix < 0 || iy < 0 || ix >= g.nx || iy >= g.ny) continue;
+        double xlo = g.ox + ix * g.vs, xhi = xlo + g.vs, ylo = g.oy + iy * g.vs, yhi = ylo + g.vs;
+        double dxmin = fmax(0.0, fmax(xlo - px, px - xhi)), dxmax = fmax(fabs(px - xlo), fabs(px - xhi));
+        double dymin = fmax(0.0, fmax(ylo - py, py - yhi)), dymax = fmax(fabs(py - ylo), fabs(py - yhi));
+        dxmin = fmax(0.0, dxmin - slack);
+        dymin = fmax(0.0, dymin - slack);
+        dxmax += slack;
+        dymax += slack;
+        double rem_out = r2 - (dxmin * dxmin + dymin * dymin);
+        if (rem_out <= 0.0) continue;
+        double ho = sqrt(rem_out) + slack;
+        int zo0 = (int)floor((pz - ho - g.oz) / g.vs), zo1 = (int)floor((pz + ho - g.oz) / g.vs);
+        zo0 = zo0 < 0 ? 0 : zo0;
+        zo1 = zo1 >= g.nz ? g.nz - 1 : zo1;
+        if (zo1 < zo0) continue;
+        double rem_in = r2 - (dxmax * dxmax + dymax * dymax);
+        int zi0 = 1, zi1 = 0;   // empty
+        if (rem_in > 0.0) {
+            double hi_ = sqrt(rem_in) - slack;
+            if (hi_ > 0.0) {
+                zi0 = (int)ceil((pz - hi_ - g.oz) / g.vs);
+                zi1 = (int)floor((pz + hi_ - g.oz) / g.vs) - 1;
+                zi0 = zi0 < zo0 ? zo0 : zi0;
+                zi1 = zi1 > zo1 ? zo1 : zi1;
+            }
+        }
+        long long colw = ((long long)ix * g.ny + iy) * (g.nzp >> 6);
+        for (int w = zo0 >> 6; w <= zo1 >> 6; ++w) {
+            unsigned long long word = bitmap[colw + w];
+            if (!word) continue;
+            int b0 = w * 64;
+            unsigned long long outer = word & bits_range(zo0 - b0 < 0 ? 0 : zo0 - b0, zo1 - b0 > 63 ? 63 : zo1 - b0);
+            unsigned long long inner = 0ull;
+            if (zi1 >= zi0) inner = outer & bits_range(zi0 - b0 < 0 ? 0 : zi0 - b0, zi1 - b0 > 63 ? 63 : zi1 - b0);
+            count += __popcll(inner);
+            unsigned long long shell = outer & ~inner;
+            unsigned base = rank[colw + w];
+            while (shell) {
+                int b = __ffsll(shell) - 1;
+                shell &= shell - 1;
+                unsigned q = base + (unsigned)__popcll(word & ((1ull << b) - 1ull));
+                double dx = pts[(size_t)q * 3] - px, dy = pts[(size_t)q * 3 + 1] - py, dz = pts[(size_t)q * 3 + 2] - pz;
+                double d2 = dx * dx + dy * dy + dz * dz;
+                count += d2 < r2 ? 1 : 0;
+            }
+        }
+    }
+    count = wave_sum_i32(count);
+    if (lane == 0) keep[s] = count > nb_points ? 1u : 0u;
+}
+
+__global__ void k_compact(const unsigned* __restrict__ keep, const unsigned* __restrict__ newidx, long long V0,
+                          const double* __restrict__ pts0, const double* __restrict__ cols0, const int* __restrict__ cell,
+                          GridGeom g, double* __restrict__ pts, double* __restrict__ cols,
+                          unsigned long long* __restrict__ bitmap) {
+    long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= V0) return;
+    if (keep[s]) {
+        unsigned d = newidx[s];
+        for (int a = 0; a < 3; ++a) {
+            pts[(size_t)d * 3 + a] = pts0[s * 3 + a];
+            cols[(size_t)d * 3 + a] = cols0[s * 3 + a];
+        }
+    } else {
+        long long lin = lin_of(g, cell[s * 3], cell[s * 3 + 1], cell[s * 3 + 2]);
+        atomicAnd(&bitmap[lin >> 6], ~(1ull << (lin & 63)));
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host driver
+void hmsg_build_map(hmsg_ctx* h) {
+    const hmsg_config& c = h->cfg;
+    hipStream_t s = h->stream;
+    HMSG_REQUIRE(h->n_frames > 0, HMSG_ERR_INVALID, "hmsg_finalize_map: no frames added");
+    // pcd_denoise_dbscan(eps=0.01, min_points=100) (graph.py:352): with one point per voxel, at most 27
+    // points lie within eps <= voxel_size of any point, so with min_points > 27 there is no core point,
+    // no cluster, and the wrapper returns its input (graph_utils.py:853-880).
+    HMSG_REQUIRE(c.voxel_size >= 0.01, HMSG_ERR_UNSUPPORTED,
+                 "voxel_size < 0.01: the DBSCAN(0.01,100) of graph.py:352 is no longer a provable no-op");
+    const int H = c.height, W = c.width, F = h->n_frames;
+    const float scale = (float)c.depth_scale;
+    const size_t total = (size_t)H * W * F;
+    const unsigned nblk = (unsigned)std::min<size_t>(cdiv(total, 256), 256 * 8);
+
+    DevBuf<unsigned long long> d_b;
+    d_b.alloc(8);
+    unsigned long long init[8] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    HIP_TRY(hipMemcpyAsync(d_b.p, init, sizeof(init), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_bounds, dim3(nblk), dim3(256), 0, s, (const unsigned short*)h->depth.p,
+                       (const double*)h->pose.p, h->cam, scale, H, W, F, d_b.p, d_b.p + 6);
+    HMSG_CHECK_LAUNCH();
+    unsigned long long hb[8];
+    HIP_TRY(hipMemcpyAsync(hb, d_b.p, sizeof(hb), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HMSG_REQUIRE(hb[6] > 0, HMSG_ERR_INVALID, "no valid depth pixel in any frame");
+    double mn[3], mx[3];
+    for (int a = 0; a < 3; ++a) {
+        mn[a] = dec_f64(hb[a]);
+        mx[a] = dec_f64(hb[3 + a]);
+    }
+    GridGeom g;
+    g.vs = c.voxel_size;
+    g.ox = mn[0] - g.vs * 0.5;
+    g.oy = mn[1] - g.vs * 0.5;
+    g.oz = mn[2] - g.vs * 0.5;
+    g.nx = (int)floor((mx[0] - g.ox) / g.vs) + 2;
+    g.ny = (int)floor((mx[1] - g.oy) / g.vs) + 2;
+    g.nz = (int)floor((mx[2] - g.oz) / g.vs) + 2;
+    g.nzp = (g.nz + 63) / 64 * 64;
+    g.nwords = (long long)g.nx * g.ny * (g.nzp / 64);
+    HMSG_REQUIRE(g.nwords < (1ll << 31), HMSG_ERR_UNSUPPORTED, "scene bounding box too large for the dense occupancy bitmap");
+    h->grid = g;
+
+    h->bitmap.alloc((size_t)g.nwords);
+    h->rank.alloc((size_t)g.nwords);
+    h->bitmap.zero(s);
+    hipLaunchKernelGGL(k_mark, dim3(nblk), dim3(256), 0, s, (const unsigned short*)h->depth.p, (const double*)h->pose.p,
+                       h->cam, scale, H, W, F, g, h->bitmap.p);
+    HMSG_CHECK_LAUNCH();
+    unsigned long long V0 = hmsg_bitmap_rank(h->bitmap.p, h->rank.p, (size_t)g.nwords, s, h->scan_tmp);
+    h->V0 = (long long)V0;
+
+    DevBuf<long long> sxyz;
+    DevBuf<unsigned long long> srgb;
+    DevBuf<unsigned> sn;
+    sxyz.alloc(V0 * 3);
+    srgb.alloc(V0 * 3);
+    sn.alloc(V0);
+    sxyz.zero(s);
+    srgb.zero(s);
+    sn.zero(s);
+    VoxAcc acc{sxyz.p, sxyz.p + V0, sxyz.p + 2 * V0, srgb.p, srgb.p + V0, srgb.p + 2 * V0, sn.p};
+    hipLaunchKernelGGL(k_accum, dim3(nblk), dim3(256), 0, s, (const unsigned short*)h->depth.p,
+                       (const unsigned char*)h->rgb.p, (const double*)h->pose.p, h->cam, scale, H, W, F, g,
+                       (const unsigned long long*)h->bitmap.p, (const unsigned*)h->rank.p, acc);
+    HMSG_CHECK_LAUNCH();
+    DevBuf<int> cell;
+    cell.alloc(V0 * 3);
+    hipLaunchKernelGGL(k_slot_cells, dim3(cdiv((size_t)g.nwords, 256)), dim3(256), 0, s,
+                       (const unsigned long long*)h->bitmap.p, (const unsigned*)h->rank.p, g, cell.p);
+    HMSG_CHECK_LAUNCH();
+    DevBuf<double> pts0, cols0;
+    pts0.alloc(V0 * 3);
+    cols0.alloc(V0 * 3);
+    hipLaunchKernelGGL(k_finalize, dim3(cdiv(V0, 256)), dim3(256), 0, s, acc, (const int*)cell.p, g, (long long)V0,
+                       pts0.p, cols0.p);
+    HMSG_CHECK_LAUNCH();
+
+    // remove_radius_outlier (graph.py:355-358)
+    DevBuf<unsigned> keep, newidx;
+    keep.alloc(V0);
+    newidx.alloc(V0);
+    hipLaunchKernelGGL(k_outlier, dim3(cdiv(V0 * 64, 256)), dim3(256), 0, s, (const double*)pts0.p, (const int*)cell.p,
+                       (long long)V0, g, (const unsigned long long*)h->bitmap.p, (const unsigned*)h->rank.p,
+                       c.outlier_radius, c.outlier_nb_points, keep.p);
+    HMSG_CHECK_LAUNCH();
+    unsigned long long V = 0;
+    hmsg_scan_u32(keep.p, newidx.p, V0, s, h->scan_tmp, &V);
+    h->V = (long long)V;
+    h->pts.alloc(V * 3);
+    h->cols.alloc(V * 3);
+    hipLaunchKernelGGL(k_compact, dim3(cdiv(V0, 256)), dim3(256), 0, s, (const unsigned*)keep.p, (const unsigned*)newidx.p,
+                       (long long)V0, (const double*)pts0.p, (const double*)cols0.p, (const int*)cell.p, g, h->pts.p,
+                       h->cols.p, h->bitmap.p);
+    HMSG_CHECK_LAUNCH();
+    unsigned long long V2 = hmsg_bitmap_rank(h->bitmap.p, h->rank.p, (size_t)g.nwords, s, h->scan_tmp);
+    HMSG_REQUIRE(V2 == V, HMSG_ERR_INVALID, "internal: filtered bitmap population mismatch");
+    HIP_TRY(hipStreamSynchronize(s));
+    h->map_ready = true;
+}

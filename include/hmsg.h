@@ -1,0 +1,141 @@
+/*
+ * hmsg.h -- C ABI of the MI355X-native HMSG (Hierarchical Multi-modal Scene Graph) build + retrieval
+ * path.  This is the drop-in boundary for the hot path of HorizonRobotics/HoloAgent `fsr_vln`:
+ * the reference has no FFI today (its boundary is the Python class `Graph`,
+ * fsr_vln/memory/hmsg/graph/graph.py:77-219); each entry point below names the reference code it
+ * replaces.  INTEGRATION.md shows the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - every call returns 0 on success, <0 on error; hmsg_last_error(h) gives the message.
+ *   - input pointers may be host OR device (HIP) pointers; the library detects which
+ *     (hipPointerGetAttributes).  Output pointers are host pointers unless the name ends in `_dev`.
+ *   - one handle = one scene = one HIP device + stream.  A handle is not thread-safe; distinct
+ *     handles are independent.
+ *   - all state (frames, voxel map, feature map, instances) lives in HBM and is owned by the handle.
+ */
+#ifndef HMSG_H
+#define HMSG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hmsg_ctx hmsg_t;
+
+enum {
+    HMSG_OK = 0,
+    HMSG_ERR_INVALID = -1,     /* bad argument / call order */
+    HMSG_ERR_HIP = -2,         /* HIP runtime error */
+    HMSG_ERR_UNSUPPORTED = -3, /* configuration outside what this build implements */
+    HMSG_ERR_NOMEM = -4
+};
+
+enum { HMSG_MERGE_SEQUENTIAL = 0, HMSG_MERGE_HIERARCHICAL = 1 };
+
+/* Hydra `pipeline.*` / `main.*` keys of fsr_vln/config/semantic_scene_reconstruction_hm3d.yaml:1-39
+ * that the path reads, plus the constants the reference hard-codes in graph.py (named here so the
+ * oracle tests can vary them; defaults = the reference's literals). */
+typedef struct hmsg_config {
+    int32_t device_id;            /* HIP device ordinal */
+    int32_t feat_dim;             /* CLIP_DIM (utils/constants.py:3-7): 512 / 768 / 1024 */
+    int32_t height, width;        /* depth image size */
+    int32_t max_frames;           /* capacity of the resident frame store */
+    int32_t max_masks;            /* masks per frame upper bound (<= 64 in this build) */
+    double voxel_size;            /* pipeline.voxel_size */
+    double depth_scale;           /* dataset scale, 1000.0 (hm3dsem.py:40, horizon.py:38) */
+    double init_overlap_thresh;   /* pipeline.init_overlap_thresh */
+    double overlap_thresh_factor; /* pipeline.overlap_thresh_factor */
+    double iou_thresh;            /* pipeline.iou_thresh */
+    double clip_masked_weight;    /* pipeline.clip_masked_weight */
+    double max_mask_distance;     /* pipeline.max_mask_distance (filter_distance of create_3d_masks) */
+    int32_t merge_type;           /* pipeline.merge_type: HMSG_MERGE_* */
+    int32_t outlier_nb_points;    /* graph.py:355 literal 1000 */
+    double outlier_radius;        /* graph.py:356 literal 1.0 */
+    double pool_max_dist;         /* graph.py:460 literal 0.8 */
+    double feat_dbscan_eps;       /* graph.py:484 literal 0.01 */
+    int32_t feat_dbscan_min;      /* graph.py:484 literal 100 */
+    double merge_dbscan_eps;      /* graph_utils.py:678 literal 0.1 */
+    int32_t merge_dbscan_min;     /* graph_utils.py:678 literal 10 */
+    int32_t min_instance_points;  /* graph.py:447 literal 10 */
+} hmsg_config;
+
+/* Fill `cfg` with the reference defaults (hm3d yaml + graph.py literals). */
+void hmsg_default_config(hmsg_config* cfg);
+
+/* Graph.__init__ (graph.py:81-219) for the build pipeline: allocate the HBM-resident scene state. */
+int hmsg_create(const hmsg_config* cfg, hmsg_t** out);
+void hmsg_destroy(hmsg_t* h);
+const char* hmsg_last_error(const hmsg_t* h);
+const char* hmsg_version(void);
+
+/* ---- loop A of create_feature_map (graph.py:339-345): hand over posed RGB-D frames ------------
+ * rgb u8 [n][H][W][3], depth u16 [n][H][W] (millimetres), pose f64 [n][16] row-major camera-to-world,
+ * K f64 [9] row-major intrinsics (dataset[i] tuple contract, horizon.py:217-268). Frames are copied
+ * into the handle's resident frame store; frame ids are assigned consecutively from 0. */
+int hmsg_add_frames(hmsg_t* h, int32_t n, const uint8_t* rgb, const uint16_t* depth, const double* pose,
+                    const double* K);
+
+/* ---- A1+A2: create_pcd over all frames (generic.py:74-138) + voxel_down_sample + the (no-op)
+ * DBSCAN + remove_radius_outlier + the NN index that replaces cKDTree (graph.py:348-364). */
+int hmsg_finalize_map(hmsg_t* h);
+int64_t hmsg_map_size(const hmsg_t* h);              /* V = points of the filtered global cloud */
+int64_t hmsg_map_size_unfiltered(const hmsg_t* h);   /* voxels before remove_radius_outlier */
+int hmsg_get_map_points(const hmsg_t* h, double* xyz /*[V][3]*/, double* rgb /*[V][3] or NULL*/);
+
+/* ---- loop B (graph.py:373-411): per frame the encoder outputs consumed by
+ * extract_feats_per_pixel's fusion math (sam_clip_feats_extractor.py:159-191):
+ * masks u8 [n][M][H][W] (0/1), F_g f32 [n][D], F_masked f32 [n][M][D], F_crop f32 [n][M][D].
+ * Frames first_frame .. first_frame+n-1 must have been added; M <= cfg.max_masks. */
+int hmsg_add_frame_features(hmsg_t* h, int32_t first_frame, int32_t n, int32_t M, const uint8_t* masks,
+                            const float* F_g, const float* F_masked, const float* F_crop);
+
+/* A3+A4+A5 for every frame handed over so far: per-pixel feature fusion, NN snapping of frame and
+ * mask points, last-writer-wins accumulation into the voxel feature map, 3-D mask clouds
+ * (graph.py:380-415, generic.py:140-190). */
+int hmsg_fuse_frames(hmsg_t* h);
+int hmsg_get_map_feats(const hmsg_t* h, float* feats /*[V][D]*/, float* counter /*[V] or NULL*/);
+/* test/introspection: NN index of every pixel of a frame (-1 where depth == 0), i32 [H][W] */
+int hmsg_get_frame_nn(const hmsg_t* h, int32_t frame, int32_t* idx);
+/* test/introspection: F_p of a frame (sam_clip_feats_extractor.py:172-175), f32 [M][D] */
+int hmsg_get_frame_fp(const hmsg_t* h, int32_t frame, float* f_p);
+/* 3-D masks of a frame (create_3d_masks): sizes i64 [M] then points f64 [sum][3] */
+int hmsg_get_frame_mask_sizes(const hmsg_t* h, int32_t frame, int64_t* sizes);
+int hmsg_get_frame_mask_points(const hmsg_t* h, int32_t frame, double* xyz);
+
+/* ---- A6: seq_merge / hierarchical_merge (graph_utils.py:918-1038) + small-cloud drop
+ * (graph.py:445-448). */
+int hmsg_merge_instances(hmsg_t* h);
+int64_t hmsg_num_instances(const hmsg_t* h);
+int hmsg_get_instance_sizes(const hmsg_t* h, int64_t* sizes /*[N]*/);
+int hmsg_get_instance_points(const hmsg_t* h, double* xyz /*[sum][3]*/);
+
+/* ---- A7: per-instance feature pooling (graph.py:450-491, graph_utils.py:682-728). */
+int hmsg_pool_instances(hmsg_t* h);
+int hmsg_get_instance_feats(const hmsg_t* h, float* feats /*[N][D]*/);
+
+/* ---- A12: retrieval over a node table (graph.py:3056-3162 query_hmsg_object and the GEMV of
+ * query_hmsg_room / query_floor).  A table is N node embeddings (f64, as after load_hmsg_graph:
+ * object.py:88-89, or f32 right after build) with a parent (room) id per node. */
+typedef struct hmsg_index hmsg_index_t;
+int hmsg_index_create(int32_t device_id, int32_t dim, int64_t n, const void* emb, int32_t emb_is_f64,
+                      const int32_t* room_of_node, hmsg_index_t** out);
+void hmsg_index_destroy(hmsg_index_t* ix);
+const char* hmsg_index_last_error(const hmsg_index_t* ix);
+/* Q queries; query q has C text rows T[q][C][D] f32 (row `qid[q]` is the query itself, the others
+ * the negative prompts), searches the nodes whose room id is listed in rooms[room_off[q] ..
+ * room_off[q+1]) IN THAT ORDER (candidate order = room order then node order, graph.py:3099-3110),
+ * returns up to k node indices (-1 padded), their room ids and float64 scores sim[qid][node]. */
+int hmsg_query_objects(hmsg_index_t* ix, int32_t Q, int32_t C, const float* T, const int32_t* qid,
+                       const int32_t* room_off, const int32_t* rooms, int32_t k, int32_t use_negatives,
+                       int32_t* out_idx, int32_t* out_room, double* out_score);
+/* plain similarity S[Q][N] = T[Q][D] . E[N][D]^T in float64 (query_floor / query_hmsg_room GEMV) */
+int hmsg_similarity(hmsg_index_t* ix, int32_t Q, const float* T, double* S);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HMSG_H */

@@ -67,6 +67,15 @@ def o3d_voxel_down_sample(points: np.ndarray, colors: np.ndarray | None, voxel_s
     return out, outc, idx[first], origin
 
 
+def o3d_transform(points: np.ndarray, pose) -> np.ndarray:
+    """Open3D `PointCloud::Transform`: p' = (T [p,1])[:3] / (T [p,1])[3].  Evaluated element-wise, left to
+    right, without FMA (the same order the HIP kernels use) so results are bit-reproducible."""
+    T = np.asarray(pose, dtype=np.float64)
+    X, Y, Z = points[:, 0], points[:, 1], points[:, 2]
+    rows = [((X * T[r, 0] + Y * T[r, 1]) + Z * T[r, 2]) + T[r, 3] for r in range(4)]
+    return np.stack([rows[0] / rows[3], rows[1] / rows[3], rows[2] / rows[3]], axis=1)
+
+
 def _radius_pairs(points: np.ndarray, radius: float):
     """All i<j with ||p_i - p_j||^2 < radius^2 (nanoflann radius search is strict)."""
     tree = cKDTree(points)
@@ -140,6 +149,26 @@ def faiss_flat_l2_nn_sqdist(queries: np.ndarray, base: np.ndarray) -> np.ndarray
     return (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]   # float32
 
 
+NN_TIE = "scipy"   # "scipy": cKDTree's own (arbitrary) choice on exact distance ties, as the reference runs;
+                   # "lowest": canonical rule of the HIP path -- lowest index among candidates whose distance is
+                   # within 5e-13 (relative) of the minimum.  Ties are structural (adjacent pixels at equal depth
+                   # are equidistant from the pixel between them), so a rule is needed for reproducibility.
+
+
+def nn_query(tree: cKDTree, pts: np.ndarray):
+    """k=1 nearest neighbour, no distance cap (graph.py:409, generic.py:181, graph.py:458)."""
+    if NN_TIE == "scipy" or pts.shape[0] == 0:
+        return tree.query(pts, k=1, workers=-1)
+    k = min(4, tree.n)
+    d, i = tree.query(pts, k=k, workers=-1)
+    if k == 1:
+        return d, i
+    tied = d <= d[:, :1] * (1 + 5e-13)
+    cand = np.where(tied, i, np.iinfo(np.int64).max)
+    best = cand.min(axis=1)
+    return d[:, 0], best
+
+
 # --------------------------------------------------------------------------------------------------
 # A1: back-projection   (dataloader/generic.py:74-138)
 # --------------------------------------------------------------------------------------------------
@@ -172,11 +201,7 @@ def create_pcd(rgb, depth_u16, pose, K, scale=1000.0, mask_img=False, filter_dis
     cols = np.zeros((0, 3))
     if not mask_img:
         cols = rgb[m] / 255.0
-    T = np.asarray(pose, dtype=np.float64)
-    w = pts @ T[:3, :3].T + T[:3, 3]
-    den = pts @ T[3, :3] + T[3, 3]
-    w = w / den[:, None]
-    return w, cols, m
+    return o3d_transform(pts, pose), cols, m
 
 
 # --------------------------------------------------------------------------------------------------
@@ -254,7 +279,8 @@ def build_global_cloud(frames, voxel_size, outlier_nb=1000, outlier_radius=1.0):
     return p[keep], c[keep], dict(n_voxels=int(keys.shape[0]), origin=origin)
 
 
-def create_3d_masks(masks, depth_u16, cloud_pts, cloud_cols, tree, pose, K, voxel_size, filter_distance):
+def create_3d_masks(masks, depth_u16, cloud_pts, cloud_cols, tree, pose, K, voxel_size, filter_distance,
+                    nn_image=None):
     """generic.py:140-190: per mask, back-project the masked depth, snap every point to its nearest
     map point (k=1, no distance cap, duplicates kept), voxel_down_sample(voxel_size)."""
     out = []
@@ -263,7 +289,10 @@ def create_3d_masks(masks, depth_u16, cloud_pts, cloud_cols, tree, pose, K, voxe
         if p.shape[0] == 0:
             out.append((np.zeros((0, 3)), np.zeros((0, 3))))
             continue
-        _, idx = tree.query(p, k=1, workers=-1)
+        if nn_image is not None:      # test hook: reuse a given per-pixel NN map (tie-break independent)
+            idx = nn_image[(np.asarray(depth_u16) > 0) & masks[i]]
+        else:
+            _, idx = nn_query(tree, p)
         sp = cloud_pts[idx]
         sc = cloud_cols[idx]
         dp, dc, _, _ = o3d_voxel_down_sample(sp, sc, voxel_size)
@@ -403,7 +432,7 @@ def pool_instances(mask_pcds, cloud_pts, tree, full_feats, voxel_size, feat_dim,
     out = []
     for pts, cols in mask_pcds:
         dp, _, _, _ = o3d_voxel_down_sample(pts, cols, voxel_size)
-        dist, idx = tree.query(dp, k=1, workers=-1)
+        dist, idx = nn_query(tree, dp)
         valid = dist <= max_dist
         feats = np.nan_to_num(full_feats[idx[valid]])
         if feats.shape[0] == 0:
@@ -439,7 +468,7 @@ def create_feature_map(frames, cfg, keep_intermediates=False, stats=None):
         p, _, _ = create_pcd(fr["rgb"], fr["depth"], fr["pose"], fr["K"])
         frames_pcd.append(create_3d_masks(fr["masks"], fr["depth"], cloud_pts, cloud_cols, tree, fr["pose"],
                                           fr["K"], vs, cfg["max_mask_distance"]))
-        _, idx = tree.query(p, k=1, workers=-1)
+        _, idx = nn_query(tree, p)
         fuse_frame_into_map(sum_feats, counter, f2d, fr["depth"], idx)
         if keep_intermediates:
             nn_idx.append(idx)

@@ -49,10 +49,7 @@ class PointCloud:
 
     def transform(self, T):
         p = np.asarray(self.points, dtype=np.float64).reshape(-1, 3)
-        T = np.asarray(T, dtype=np.float64)
-        w = p @ T[:3, :3].T + T[:3, 3]
-        den = p @ T[3, :3] + T[3, 3]
-        self.points = w / den[:, None]
+        self.points = O.o3d_transform(p, T)
         return self
 
     def voxel_down_sample(self, voxel_size):

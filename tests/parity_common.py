@@ -1,0 +1,96 @@
+"""Shared body of the parity tests: drive the C ABI (include/hmsg.h) stage by stage and compare with the
+CPU oracle on the same seeded inputs.  Used with the real gfx950 library by the `-m gpu` tests and with
+the kernel-simulator build (tests/emu) by the CPU-side development tests."""
+import os
+
+import numpy as np
+from scipy.spatial import cKDTree
+
+from oracle import hmsg_oracle as O
+
+EMU_PATH = os.path.join(os.path.dirname(__file__), "emu", "libhmsg_emu.so")
+
+
+def stack_frames(frames):
+    return dict(
+        rgb=np.ascontiguousarray(np.stack([f["rgb"] for f in frames])),
+        depth=np.ascontiguousarray(np.stack([f["depth"] for f in frames])),
+        pose=np.ascontiguousarray(np.stack([f["pose"] for f in frames])),
+        K=np.ascontiguousarray(frames[0]["K"], dtype=np.float64),
+        masks=np.ascontiguousarray(np.stack([f["masks"] for f in frames]).astype(np.uint8)),
+        f_g=np.ascontiguousarray(np.stack([f["f_g"].reshape(-1) for f in frames]).astype(np.float32)),
+        f_masked=np.ascontiguousarray(np.stack([f["f_masked"] for f in frames]).astype(np.float32)),
+        f_crop=np.ascontiguousarray(np.stack([f["f_crop"] for f in frames]).astype(np.float32)))
+
+
+def make_scene(L, frames, cfg_over):
+    from holoagent_amd._lib import Scene
+    H, W = frames[0]["depth"].shape
+    M = frames[0]["masks"].shape[0]
+    over = dict(height=H, width=W, max_frames=len(frames), max_masks=max(M, 1))
+    over.update(cfg_over)
+    return Scene(lib_=L, **over)
+
+
+def check_map(sc, frames, cfg, oracle_cloud=None):
+    """A1 + A2: identical voxel set / order, centroids to 1e-9."""
+    S = stack_frames(frames)
+    sc.add_frames(S["rgb"], S["depth"], S["pose"], S["K"])
+    sc.finalize_map()
+    if oracle_cloud is None:
+        oracle_cloud = O.build_global_cloud(frames, cfg["voxel_size"], cfg.get("outlier_nb", 1000),
+                                            cfg.get("outlier_radius", 1.0))
+    ref_pts, ref_cols, info = oracle_cloud
+    assert sc.map_size_unfiltered() == info["n_voxels"]
+    assert sc.map_size() == ref_pts.shape[0]
+    pts, cols = sc.map_points(colors=True)
+    np.testing.assert_allclose(pts, ref_pts, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(cols, ref_cols, rtol=0, atol=1e-9)
+    return S, ref_pts, ref_cols
+
+
+def check_fuse(sc, frames, S, cfg, ref_pts, ref_cols, check_masks=True):
+    """A3 + A4 + A5: F_p to 3e-7, NN indices exact (up to exact distance ties), feature map within 1e-5
+    (fp16 knife edges allowed on a <1e-3 fraction), 3-D masks to 1e-9."""
+    D = cfg["feat_dim"]
+    n = len(frames)
+    half = n // 2
+    sc.add_frame_features(0, S["masks"][:half], S["f_g"][:half], S["f_masked"][:half], S["f_crop"][:half])
+    sc.add_frame_features(half, S["masks"][half:], S["f_g"][half:], S["f_masked"][half:], S["f_crop"][half:])
+    sc.fuse_frames()
+    tree = cKDTree(ref_pts)
+    V = ref_pts.shape[0]
+    counter = np.zeros((V, 1), np.float32)
+    sums = np.zeros((V, D), np.float32)
+    n_tie = 0
+    for i, fr in enumerate(frames):
+        f_p = O.fuse_mask_feats(fr["f_g"], fr["f_masked"], fr["f_crop"], cfg["clip_masked_weight"])
+        np.testing.assert_allclose(sc.frame_fp(i), f_p, rtol=0, atol=3e-7)
+        p, _, valid = O.create_pcd(fr["rgb"], fr["depth"], fr["pose"], fr["K"])
+        dist, idx = O.nn_query(tree, p)
+        got = sc.frame_nn(i)
+        assert (got[~valid] == -1).all()
+        g = got[valid]
+        bad = np.nonzero(g != idx)[0]
+        if bad.size:   # only exact distance ties may differ
+            d_g = np.linalg.norm(ref_pts[g[bad]] - p[bad], axis=1)
+            assert np.all(np.abs(d_g - dist[bad]) <= 1e-12), "NN mismatch beyond distance ties"
+            n_tie += bad.size
+        f2d = O.per_pixel_feats(fr["masks"], f_p)
+        O.fuse_frame_into_map(sums, counter, f2d, fr["depth"], g.astype(np.int64))
+        if check_masks:
+            ref_masks = O.create_3d_masks(fr["masks"], fr["depth"], ref_pts, ref_cols, tree, fr["pose"], fr["K"],
+                                          cfg["voxel_size"], cfg["max_mask_distance"], nn_image=got)
+            got_masks = sc.frame_masks3d(i)
+            for m, (rp, _rc) in enumerate(ref_masks):
+                assert got_masks[m].shape == rp.shape, (i, m, got_masks[m].shape, rp.shape)
+                np.testing.assert_allclose(got_masks[m], rp, rtol=0, atol=1e-9)
+    feats, cnt = sc.map_feats(counter=True)
+    np.testing.assert_array_equal(cnt, counter[:, 0])
+    c = counter.copy()
+    c[c == 0] = 1e-5
+    ref_feats = sums / c
+    d = np.abs(feats - ref_feats)
+    assert (d > 1e-6).mean() < 1e-3, (d > 1e-6).mean()
+    assert d.max() <= 2.0 ** -10
+    return ref_feats, n_tie
