@@ -8,6 +8,8 @@ from scipy.spatial import cKDTree
 
 from oracle import hmsg_oracle as O
 
+O.NN_TIE = "lowest"   # the HIP path's canonical NN tie rule (see oracle nn_query)
+
 EMU_PATH = os.path.join(os.path.dirname(__file__), "emu", "libhmsg_emu.so")
 
 

@@ -1,0 +1,40 @@
+"""Parity tests proper: the gfx950 HIP library driven through the C ABI against the CPU oracle."""
+import numpy as np
+import pytest
+
+from tests import golden_io as GI
+from tests import parity_common as PC
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    from holoagent_amd._lib import HmsgLib
+    return HmsgLib()          # raises if the HIP library is missing -- no fallback
+
+
+def test_map_and_fuse_golden_inputs(L):
+    z = GI.load("build_hier")
+    frames = GI.unpack_frames(z)
+    cfg = GI.unpack_cfg(z)
+    sc = PC.make_scene(L, frames, dict(feat_dim=cfg["feat_dim"]))
+    S, ref_pts, ref_cols = PC.check_map(sc, frames, cfg)
+    # the reference-produced cloud of the fixture is the same set too
+    np.testing.assert_allclose(ref_pts, z["ref_cloud"], rtol=0, atol=1e-12)
+    PC.check_fuse(sc, frames, S, cfg, ref_pts, ref_cols)
+    sc.close()
+
+
+def test_map_and_fuse_medium(L):
+    from holoagent_amd.synth import SceneSpec, SynthScene
+    spec = SceneSpec(seed=21, rooms_x=2, rooms_z=1, room_size=(4.0, 2.6, 3.5), objects_per_room=5, width=160,
+                     height=120, n_frames=70, n_masks=20, feat_dim=256)
+    scn = SynthScene(spec)
+    frames = [scn.frame(i) for i in range(spec.n_frames)]
+    cfg = dict(voxel_size=0.05, clip_masked_weight=0.4418, max_mask_distance=10000, feat_dim=256)
+    sc = PC.make_scene(L, frames, dict(feat_dim=256))
+    S, ref_pts, ref_cols = PC.check_map(sc, frames, cfg)
+    assert ref_pts.shape[0] > 1000
+    PC.check_fuse(sc, frames, S, cfg, ref_pts, ref_cols, check_masks=True)
+    sc.close()
