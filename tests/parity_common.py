@@ -8,8 +8,6 @@ from scipy.spatial import cKDTree
 
 from oracle import hmsg_oracle as O
 
-O.NN_TIE = "lowest"   # the HIP path's canonical NN tie rule (see oracle nn_query)
-
 EMU_PATH = os.path.join(os.path.dirname(__file__), "emu", "libhmsg_emu.so")
 
 
@@ -54,6 +52,14 @@ def check_map(sc, frames, cfg, oracle_cloud=None):
 def check_fuse(sc, frames, S, cfg, ref_pts, ref_cols, check_masks=True):
     """A3 + A4 + A5: F_p to 3e-7, NN indices exact (up to exact distance ties), feature map within 1e-5
     (fp16 knife edges allowed on a <1e-3 fraction), 3-D masks to 1e-9."""
+    O.NN_TIE = "lowest"   # the HIP path's canonical NN tie rule (see oracle nn_query)
+    try:
+        return _check_fuse(sc, frames, S, cfg, ref_pts, ref_cols, check_masks)
+    finally:
+        O.NN_TIE = "scipy"
+
+
+def _check_fuse(sc, frames, S, cfg, ref_pts, ref_cols, check_masks):
     D = cfg["feat_dim"]
     n = len(frames)
     half = n // 2
