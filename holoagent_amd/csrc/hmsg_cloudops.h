@@ -1,0 +1,47 @@
+// Segmented point-cloud primitives shared by the merge (A6), pooling (A7) and object (A10) stages:
+//   * exact DBSCAN of K independent clouds in one batch of launches (Open3D ClusterDBSCAN semantics +
+//     the keep-largest-cluster wrapper of graph_utils.py:827-880),
+//   * voxel_down_sample of K clouds (Open3D semantics, canonical order),
+//   * per-cloud uniform grids + "fraction of X within r of Y" counting (find_overlapping_ratio_faiss).
+#pragma once
+#include "hmsg_common.h"
+
+struct SegDesc {                 // one cloud of a batch, points at src[pt_base .. pt_base+n)
+    long long pt_base;
+    int n;
+    double mn[3], mx[3];         // AABB (host knows it: union of member boxes / reduction result)
+};
+
+struct DbscanResult {            // per segment
+    int n_out;
+    double mn[3], mx[3];
+    int changed;                 // 0: output == input (all points kept)
+};
+
+struct CloudOps {
+    hipStream_t s = nullptr;
+    DevBuf<unsigned> scan_tmp;
+    // scratch (grown on demand)
+    DevBuf<unsigned> cnt, start, cursor, ord, minidx, firstidx, size, flags, pos, rootmin;
+    DevBuf<int> parent, label, segid;
+    DevBuf<long long> cellid;
+    DevBuf<unsigned char> core;
+    DevBuf<unsigned long long> best, obounds;
+    DevBuf<int> winner, ocount;
+    DevBuf<char> geom;           // device copy of per-segment geometry tables
+    DevBuf<unsigned long long> vbitmap;
+    DevBuf<unsigned> vrank;
+    DevBuf<long long> vacc;
+    DevBuf<unsigned> vwgt;
+
+    // fill segs[k].mn / mx from the points (device reduction, one sync)
+    void bounds(const double* src, std::vector<SegDesc>& segs);
+    // keep-largest-cluster DBSCAN of every segment; outputs are written consecutively to `dst`
+    // (capacity >= total input points); returns total output points.
+    long long dbscan_keep_largest(const double* src, const std::vector<SegDesc>& segs, double eps, int min_points,
+                                  double* dst, std::vector<DbscanResult>& res);
+    // Open3D voxel_down_sample of every segment; outputs consecutively to dst (capacity >= total input
+    // points); out_n[k] = points of segment k.
+    long long voxel_down_sample(const double* src, const std::vector<SegDesc>& segs, double vs, double* dst,
+                                std::vector<int>& out_n);
+};

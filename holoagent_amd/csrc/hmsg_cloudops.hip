@@ -1,0 +1,588 @@
+// Segmented exact DBSCAN (keep-largest-cluster wrapper) and segmented voxel_down_sample.
+//
+// Reference semantics: Open3D 0.18 ClusterDBSCAN / VoxelDownSample as restated in
+// oracle/hmsg_oracle.py (o3d_cluster_dbscan, o3d_voxel_down_sample) and the wrapper
+// utils/graph_utils.py:827-880 (pcd_denoise_dbscan).
+//
+// DBSCAN design (grid-exact): cells of side eps/sqrt(3) -- any two points of one cell are neighbours, so
+// a cell holding >= min_points points is all-core without a single distance test, and core points of one
+// cell always share a cluster.  Clusters are found by a lock-free union-find over CORE CELLS (an edge
+// needs one witness pair of core points closer than eps, early exit), which makes the cost independent
+// of how many duplicates a heavily re-observed surface has piled up.  Cluster order (smallest core
+// index), border assignment (first = smallest-order reaching cluster) and the largest-cluster tie rule
+// (first label in point order) follow the reference exactly.
+#include "hmsg_cloudops.h"
+
+#include <algorithm>
+#include <cmath>
+
+struct DbSeg {
+    double ox, oy, oz, cs;
+    int nx, ny, nz, n;
+    long long cell_base, pt_base;
+};
+
+#define INF32 0xffffffffu
+
+__device__ __forceinline__ double dist2_f64(const double* __restrict__ a, const double* __restrict__ b) {
+    double dx = __dsub_rn(a[0], b[0]), dy = __dsub_rn(a[1], b[1]), dz = __dsub_rn(a[2], b[2]);
+    return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+}
+
+__global__ void k_db_segid(const DbSeg* __restrict__ segs, int K, int* __restrict__ segid) {
+    int k = blockIdx.y;
+    const DbSeg sg = segs[k];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < sg.n; i += gridDim.x * blockDim.x) segid[sg.pt_base + i] = k;
+}
+
+__global__ void k_db_cell(const double* __restrict__ pts, long long N, const int* __restrict__ segid,
+                          const DbSeg* __restrict__ segs, long long* __restrict__ cellid, unsigned* __restrict__ cnt) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const DbSeg sg = segs[segid[i]];
+    int ix = (int)floor((pts[i * 3] - sg.ox) / sg.cs), iy = (int)floor((pts[i * 3 + 1] - sg.oy) / sg.cs),
+        iz = (int)floor((pts[i * 3 + 2] - sg.oz) / sg.cs);
+    ix = ix < 0 ? 0 : (ix >= sg.nx ? sg.nx - 1 : ix);
+    iy = iy < 0 ? 0 : (iy >= sg.ny ? sg.ny - 1 : iy);
+    iz = iz < 0 ? 0 : (iz >= sg.nz ? sg.nz - 1 : iz);
+    long long c = sg.cell_base + ((long long)ix * sg.ny + iy) * sg.nz + iz;
+    cellid[i] = c;
+    atomicAdd(&cnt[c], 1u);
+}
+
+__global__ void k_db_fill(long long N, const long long* __restrict__ cellid, const unsigned* __restrict__ start,
+                          unsigned* __restrict__ cursor, unsigned* __restrict__ ord) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    long long c = cellid[i];
+    unsigned p = start[c] + atomicAdd(&cursor[c], 1u);
+    ord[p] = (unsigned)i;
+}
+
+__device__ __forceinline__ void cell_xyz(const DbSeg& sg, long long c, int& ix, int& iy, int& iz) {
+    long long l = c - sg.cell_base;
+    iz = (int)(l % sg.nz);
+    l /= sg.nz;
+    iy = (int)(l % sg.ny);
+    ix = (int)(l / sg.ny);
+}
+
+__global__ void k_db_core(const double* __restrict__ pts, long long N, const int* __restrict__ segid,
+                          const DbSeg* __restrict__ segs, const long long* __restrict__ cellid,
+                          const unsigned* __restrict__ cnt, const unsigned* __restrict__ start,
+                          const unsigned* __restrict__ ord, double eps2, int minpts, unsigned char* __restrict__ core,
+                          unsigned* __restrict__ minidx) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const DbSeg sg = segs[segid[i]];
+    long long c = cellid[i];
+    bool is_core = cnt[c] >= (unsigned)minpts;
+    if (!is_core) {
+        int ix, iy, iz, n = 0;
+        cell_xyz(sg, c, ix, iy, iz);
+        for (int dx = -2; dx <= 2 && n < minpts; ++dx)
+            for (int dy = -2; dy <= 2 && n < minpts; ++dy)
+                for (int dz = -2; dz <= 2 && n < minpts; ++dz) {
+                    int jx = ix + dx, jy = iy + dy, jz = iz + dz;
+                    if (jx < 0 || jy < 0 || jz < 0 || jx >= sg.nx || jy >= sg.ny || jz >= sg.nz) continue;
+                    long long c2 = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz + jz;
+                    unsigned s0 = start[c2], e0 = s0 + cnt[c2];
+                    for (unsigned k = s0; k < e0 && n < minpts; ++k)
+                        n += dist2_f64(pts + (size_t)ord[k] * 3, pts + (size_t)i * 3) < eps2 ? 1 : 0;
+                }
+        is_core = n >= minpts;
+    }
+    core[i] = is_core ? 1 : 0;
+    if (is_core) atomicMin(&minidx[c], (unsigned)(i - sg.pt_base));
+}
+
+__global__ void k_db_init_parent(long long NC, int* __restrict__ parent) {
+    long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < NC) parent[c] = (int)c;
+}
+
+// parent[] is updated by CAS from other workgroups while we walk it: read it with agent-scope atomic loads
+// (served by L2, never by this CU's non-coherent L1) or a retry loop could spin on a stale line.
+__device__ __forceinline__ int uf_find(int* parent, int x) {
+    int p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (p != x) {
+        x = p;
+        p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return x;
+}
+__device__ __forceinline__ void uf_union(int* parent, int a, int b) {
+    for (;;) {
+        a = uf_find(parent, a);
+        b = uf_find(parent, b);
+        if (a == b) return;
+        if (a < b) {
+            int t = a;
+            a = b;
+            b = t;
+        }                                   // a > b: hang the larger root under the smaller
+        if (atomicCAS(&parent[a], a, b) == a) return;
+    }
+}
+
+// pass 0: neighbour cells at Chebyshev distance 1; pass 1: distance 2 (skipped when already connected)
+__global__ void k_db_union(const double* __restrict__ pts, long long NC, const DbSeg* __restrict__ segs, int K,
+                           const unsigned* __restrict__ cnt, const unsigned* __restrict__ start,
+                           const unsigned* __restrict__ ord, const unsigned char* __restrict__ core,
+                           const unsigned* __restrict__ minidx, double eps2, int pass, int* __restrict__ parent) {
+    long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= NC) return;
+    if (minidx[c] == INF32) return;         // no core point in this cell
+    int lo = 0, hi = K - 1;                 // segment of the cell
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (segs[mid].cell_base <= c) lo = mid; else hi = mid - 1;
+    }
+    const DbSeg sg = segs[lo];
+    int ix, iy, iz;
+    cell_xyz(sg, c, ix, iy, iz);
+    const unsigned s0 = start[c], e0 = s0 + cnt[c];
+    for (int dx = -2; dx <= 2; ++dx)
+        for (int dy = -2; dy <= 2; ++dy)
+            for (int dz = -2; dz <= 2; ++dz) {
+                int cheb = max(abs(dx), max(abs(dy), abs(dz)));
+                if (cheb == 0 || (pass == 0 && cheb != 1) || (pass == 1 && cheb != 2)) continue;
+                int jx = ix + dx, jy = iy + dy, jz = iz + dz;
+                if (jx < 0 || jy < 0 || jz < 0 || jx >= sg.nx || jy >= sg.ny || jz >= sg.nz) continue;
+                long long c2 = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz + jz;
+                if (c2 <= c || minidx[c2] == INF32) continue;
+                if (uf_find(parent, (int)c) == uf_find(parent, (int)c2)) continue;
+                const unsigned s1 = start[c2], e1 = s1 + cnt[c2];
+                bool hit = false;
+                for (unsigned a = s0; a < e0 && !hit; ++a) {
+                    unsigned ia = ord[a];
+                    if (!core[ia]) continue;
+                    for (unsigned b = s1; b < e1; ++b) {
+                        unsigned ib = ord[b];
+                        if (core[ib] && dist2_f64(pts + (size_t)ia * 3, pts + (size_t)ib * 3) < eps2) {
+                            hit = true;
+                            break;
+                        }
+                    }
+                }
+                if (hit) uf_union(parent, (int)c, (int)c2);
+            }
+}
+
+__global__ void k_db_flatten(long long NC, const unsigned* __restrict__ minidx, int* __restrict__ parent) {
+    long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= NC || minidx[c] == INF32) return;
+    parent[c] = uf_find(parent, (int)c);     // roots never change after the union passes
+}
+
+// cluster order key: smallest core index of the cluster, kept at the root cell
+__global__ void k_db_rootmin(long long NC, const int* __restrict__ parent, const unsigned* __restrict__ minidx,
+                             unsigned* __restrict__ rootmin) {
+    long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= NC || minidx[c] == INF32) return;
+    atomicMin(&rootmin[parent[c]], minidx[c]);
+}
+
+__global__ void k_db_label(const double* __restrict__ pts, long long N, const int* __restrict__ segid,
+                           const DbSeg* __restrict__ segs, const long long* __restrict__ cellid,
+                           const unsigned* __restrict__ cnt, const unsigned* __restrict__ start,
+                           const unsigned* __restrict__ ord, const unsigned char* __restrict__ core,
+                           const int* __restrict__ parent, const unsigned* __restrict__ rootmin, double eps2,
+                           int* __restrict__ label, unsigned* __restrict__ size, unsigned* __restrict__ firstidx) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const DbSeg sg = segs[segid[i]];
+    long long c = cellid[i];
+    int lab = -1;
+    if (core[i]) {
+        lab = parent[c];
+    } else {
+        int ix, iy, iz;
+        cell_xyz(sg, c, ix, iy, iz);
+        unsigned bestkey = INF32;
+        for (int dx = -2; dx <= 2; ++dx)
+            for (int dy = -2; dy <= 2; ++dy)
+                for (int dz = -2; dz <= 2; ++dz) {
+                    int jx = ix + dx, jy = iy + dy, jz = iz + dz;
+                    if (jx < 0 || jy < 0 || jz < 0 || jx >= sg.nx || jy >= sg.ny || jz >= sg.nz) continue;
+                    long long c2 = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz + jz;
+                    unsigned n2 = cnt[c2];
+                    if (!n2) continue;
+                    unsigned s0 = start[c2];
+                    int r = -1;
+                    unsigned key = INF32;
+                    for (unsigned k = s0; k < s0 + n2; ++k) {
+                        unsigned j = ord[k];
+                        if (!core[j]) continue;
+                        if (r < 0) {
+                            r = parent[c2];
+                            key = rootmin[r];
+                            if (key >= bestkey) break;      // this cell's cluster cannot improve the choice
+                        }
+                        if (dist2_f64(pts + (size_t)j * 3, pts + (size_t)i * 3) < eps2) {
+                            bestkey = key;
+                            lab = r;
+                            break;
+                        }
+                    }
+                }
+    }
+    label[i] = lab;
+    if (lab >= 0) {
+        atomicAdd(&size[lab], 1u);
+        atomicMin(&firstidx[lab], (unsigned)(i - sg.pt_base));
+    }
+}
+
+__global__ void k_db_pick(long long NC, const DbSeg* __restrict__ segs, int K, const unsigned* __restrict__ size,
+                          const unsigned* __restrict__ firstidx, unsigned long long* __restrict__ best) {
+    long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= NC || size[c] == 0u) return;
+    int lo = 0, hi = K - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (segs[mid].cell_base <= c) lo = mid; else hi = mid - 1;
+    }
+    unsigned long long key = ((unsigned long long)size[c] << 32) | (unsigned long long)(INF32 - firstidx[c]);
+    atomicMax(&best[lo], key);
+}
+__global__ void k_db_winner(long long NC, const DbSeg* __restrict__ segs, int K, const unsigned* __restrict__ size,
+                            const unsigned* __restrict__ firstidx, const unsigned long long* __restrict__ best,
+                            int* __restrict__ winner) {
+    long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= NC || size[c] == 0u) return;
+    int lo = 0, hi = K - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (segs[mid].cell_base <= c) lo = mid; else hi = mid - 1;
+    }
+    unsigned long long key = ((unsigned long long)size[c] << 32) | (unsigned long long)(INF32 - firstidx[c]);
+    if (key == best[lo]) winner[lo] = (int)c;
+}
+
+// graph_utils.py:853-880: keep the largest cluster unless there is none or it has < 5 points
+__global__ void k_db_flags(long long N, const int* __restrict__ segid, const int* __restrict__ label,
+                           const int* __restrict__ winner, const unsigned* __restrict__ size, unsigned* __restrict__ flags) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    int w = winner[segid[i]];
+    bool keep = true;
+    if (w >= 0 && size[w] >= 5u) keep = label[i] == w;
+    flags[i] = keep ? 1u : 0u;
+}
+
+__global__ void k_db_scatter(const double* __restrict__ pts, long long N, const int* __restrict__ segid,
+                             const unsigned* __restrict__ flags, const unsigned* __restrict__ pos, double* __restrict__ dst,
+                             unsigned long long* __restrict__ obounds, int* __restrict__ ocount) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N || !flags[i]) return;
+    unsigned p = pos[i];
+    int k = segid[i];
+    for (int a = 0; a < 3; ++a) {
+        double v = pts[i * 3 + a];
+        dst[(size_t)p * 3 + a] = v;
+        unsigned long long e = enc_f64(v);
+        if (e < obounds[(size_t)k * 6 + a]) atomicMin(&obounds[(size_t)k * 6 + a], e);
+        if (e > obounds[(size_t)k * 6 + 3 + a]) atomicMax(&obounds[(size_t)k * 6 + 3 + a], e);
+    }
+    atomicAdd(&ocount[k], 1);
+}
+
+struct BdSeg {
+    long long pt_base;
+    int n, pad;
+};
+__global__ void k_seg_bounds(const double* __restrict__ pts, const BdSeg* __restrict__ segs, unsigned long long* __restrict__ ob) {
+    const BdSeg sg = segs[blockIdx.y];
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < sg.n; i += gridDim.x * blockDim.x)
+        for (int a = 0; a < 3; ++a) {
+            double v = pts[(size_t)(sg.pt_base + i) * 3 + a];
+            mn[a] = v < mn[a] ? v : mn[a];
+            mx[a] = v > mx[a] ? v : mx[a];
+        }
+    for (int a = 0; a < 3; ++a) {
+        mn[a] = wave_min_f64(mn[a]);
+        mx[a] = wave_max_f64(mx[a]);
+    }
+    if ((threadIdx.x & 63) == 0 && mn[0] <= mx[0])
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&ob[(size_t)blockIdx.y * 6 + a], enc_f64(mn[a]));
+            atomicMax(&ob[(size_t)blockIdx.y * 6 + 3 + a], enc_f64(mx[a]));
+        }
+}
+
+void CloudOps::bounds(const double* src, std::vector<SegDesc>& segs) {
+    const int K = (int)segs.size();
+    if (!K) return;
+    std::vector<BdSeg> hs(K);
+    std::vector<unsigned long long> hb((size_t)K * 6);
+    int maxn = 0;
+    for (int k = 0; k < K; ++k) {
+        hs[k] = BdSeg{segs[k].pt_base, segs[k].n, 0};
+        maxn = std::max(maxn, segs[k].n);
+        for (int a = 0; a < 6; ++a) hb[(size_t)k * 6 + a] = a < 3 ? ~0ull : 0ull;
+    }
+    geom.ensure((size_t)K * sizeof(BdSeg));
+    obounds.ensure((size_t)K * 6);
+    HIP_TRY(hipMemcpyAsync(geom.p, hs.data(), (size_t)K * sizeof(BdSeg), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(obounds.p, hb.data(), hb.size() * 8, hipMemcpyHostToDevice, s));
+    for (int k0 = 0; k0 < K; k0 += 32768) {
+        int nk = std::min(32768, K - k0);
+        hipLaunchKernelGGL(k_seg_bounds, dim3(std::max(1u, std::min(cdiv(maxn, 256), 64u)), nk), dim3(256), 0, s, src,
+                           (const BdSeg*)geom.p + k0, obounds.p + (size_t)k0 * 6);
+    }
+    HMSG_CHECK_LAUNCH();
+    HIP_TRY(hipMemcpyAsync(hb.data(), obounds.p, hb.size() * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int k = 0; k < K; ++k)
+        for (int a = 0; a < 3; ++a) {
+            segs[k].mn[a] = segs[k].n ? dec_f64(hb[(size_t)k * 6 + a]) : 0.0;
+            segs[k].mx[a] = segs[k].n ? dec_f64(hb[(size_t)k * 6 + 3 + a]) : 0.0;
+        }
+}
+
+long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<SegDesc>& segs, double eps, int min_points,
+                                        double* dst, std::vector<DbscanResult>& res) {
+    const int K = (int)segs.size();
+    res.assign(K, DbscanResult{});
+    if (K == 0) return 0;
+    const double cs = eps / std::sqrt(3.0) * (1.0 - 1e-7);
+    std::vector<DbSeg> hs(K);
+    long long NC = 0, N = 0;
+    long long span_lo = segs[0].pt_base, span_hi = segs[0].pt_base;
+    for (int k = 0; k < K; ++k) {
+        const SegDesc& sd = segs[k];
+        DbSeg& g = hs[k];
+        g.cs = cs;
+        g.n = sd.n;
+        g.pt_base = sd.pt_base;
+        g.cell_base = NC;
+        if (sd.n > 0) {
+            g.ox = sd.mn[0];
+            g.oy = sd.mn[1];
+            g.oz = sd.mn[2];
+            g.nx = (int)std::floor((sd.mx[0] - sd.mn[0]) / cs) + 1;
+            g.ny = (int)std::floor((sd.mx[1] - sd.mn[1]) / cs) + 1;
+            g.nz = (int)std::floor((sd.mx[2] - sd.mn[2]) / cs) + 1;
+        } else {
+            g.ox = g.oy = g.oz = 0;
+            g.nx = g.ny = g.nz = 1;
+        }
+        NC += (long long)g.nx * g.ny * g.nz;
+        N += sd.n;
+        span_lo = std::min(span_lo, sd.pt_base);
+        span_hi = std::max(span_hi, sd.pt_base + sd.n);
+    }
+    // segments must tile [0, N) of src (callers concatenate)
+    HMSG_REQUIRE(span_lo == 0 && span_hi == N, HMSG_ERR_INVALID, "dbscan: segments must tile the source buffer");
+    HMSG_REQUIRE(NC < (1ll << 31) && N < (1ll << 31), HMSG_ERR_UNSUPPORTED, "dbscan batch too large");
+    if (N == 0) return 0;
+    geom.ensure((size_t)K * sizeof(DbSeg));
+    HIP_TRY(hipMemcpyAsync(geom.p, hs.data(), (size_t)K * sizeof(DbSeg), hipMemcpyHostToDevice, s));
+    const DbSeg* dsegs = (const DbSeg*)geom.p;
+    segid.ensure(N); cellid.ensure(N); ord.ensure(N); core.ensure(N); label.ensure(N); flags.ensure(N); pos.ensure(N);
+    cnt.ensure(NC + 1); start.ensure(NC + 1); cursor.ensure(NC); minidx.ensure(NC); firstidx.ensure(NC); size.ensure(NC);
+    parent.ensure(NC);
+    rootmin.ensure(NC);
+    best.ensure(K); winner.ensure(K); obounds.ensure((size_t)K * 6); ocount.ensure(K);
+    HIP_TRY(hipMemsetAsync(cnt.p, 0, (size_t)(NC + 1) * 4, s));
+    HIP_TRY(hipMemsetAsync(cursor.p, 0, (size_t)NC * 4, s));
+    HIP_TRY(hipMemsetAsync(minidx.p, 0xff, (size_t)NC * 4, s));
+    HIP_TRY(hipMemsetAsync(firstidx.p, 0xff, (size_t)NC * 4, s));
+    HIP_TRY(hipMemsetAsync(rootmin.p, 0xff, (size_t)NC * 4, s));
+    HIP_TRY(hipMemsetAsync(size.p, 0, (size_t)NC * 4, s));
+    HIP_TRY(hipMemsetAsync(best.p, 0, (size_t)K * 8, s));
+    HIP_TRY(hipMemsetAsync(winner.p, 0xff, (size_t)K * 4, s));
+    HIP_TRY(hipMemsetAsync(ocount.p, 0, (size_t)K * 4, s));
+    std::vector<unsigned long long> hb((size_t)K * 6);
+    for (int k = 0; k < K; ++k)
+        for (int a = 0; a < 6; ++a) hb[(size_t)k * 6 + a] = a < 3 ? ~0ull : 0ull;
+    HIP_TRY(hipMemcpyAsync(obounds.p, hb.data(), hb.size() * 8, hipMemcpyHostToDevice, s));
+
+    const unsigned gN = cdiv(N, 256), gC = cdiv(NC, 256);
+    int maxn = 0;
+    for (auto& sd : segs) maxn = std::max(maxn, sd.n);
+    hipLaunchKernelGGL(k_db_segid, dim3(std::max(1u, std::min(cdiv(maxn, 256), 1024u)), K), dim3(256), 0, s, dsegs, K, segid.p);
+    hipLaunchKernelGGL(k_db_cell, dim3(gN), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, cellid.p, cnt.p);
+    HMSG_CHECK_LAUNCH();
+    hmsg_scan_u32(cnt.p, start.p, (size_t)NC, s, scan_tmp, nullptr);
+    hipLaunchKernelGGL(k_db_fill, dim3(gN), dim3(256), 0, s, N, (const long long*)cellid.p, (const unsigned*)start.p, cursor.p, ord.p);
+    hipLaunchKernelGGL(k_db_core, dim3(gN), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const long long*)cellid.p,
+                       (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p, eps * eps, min_points, core.p,
+                       minidx.p);
+    hipLaunchKernelGGL(k_db_init_parent, dim3(gC), dim3(256), 0, s, NC, parent.p);
+    for (int pass = 0; pass < 2; ++pass)
+        hipLaunchKernelGGL(k_db_union, dim3(gC), dim3(256), 0, s, src, NC, dsegs, K, (const unsigned*)cnt.p,
+                           (const unsigned*)start.p, (const unsigned*)ord.p, (const unsigned char*)core.p,
+                           (const unsigned*)minidx.p, eps * eps, pass, parent.p);
+    hipLaunchKernelGGL(k_db_flatten, dim3(gC), dim3(256), 0, s, NC, (const unsigned*)minidx.p, parent.p);
+    hipLaunchKernelGGL(k_db_rootmin, dim3(gC), dim3(256), 0, s, NC, (const int*)parent.p, (const unsigned*)minidx.p, rootmin.p);
+    hipLaunchKernelGGL(k_db_label, dim3(gN), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const long long*)cellid.p,
+                       (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p, (const unsigned char*)core.p,
+                       (const int*)parent.p, (const unsigned*)rootmin.p, eps * eps, label.p, size.p, firstidx.p);
+    hipLaunchKernelGGL(k_db_pick, dim3(gC), dim3(256), 0, s, NC, dsegs, K, (const unsigned*)size.p, (const unsigned*)firstidx.p, best.p);
+    hipLaunchKernelGGL(k_db_winner, dim3(gC), dim3(256), 0, s, NC, dsegs, K, (const unsigned*)size.p, (const unsigned*)firstidx.p,
+                       (const unsigned long long*)best.p, winner.p);
+    hipLaunchKernelGGL(k_db_flags, dim3(gN), dim3(256), 0, s, N, (const int*)segid.p, (const int*)label.p, (const int*)winner.p,
+                       (const unsigned*)size.p, flags.p);
+    HMSG_CHECK_LAUNCH();
+    hmsg_scan_u32(flags.p, pos.p, (size_t)N, s, scan_tmp, nullptr);
+    hipLaunchKernelGGL(k_db_scatter, dim3(gN), dim3(256), 0, s, src, N, (const int*)segid.p, (const unsigned*)flags.p,
+                       (const unsigned*)pos.p, dst, obounds.p, ocount.p);
+    HMSG_CHECK_LAUNCH();
+    std::vector<int> hc(K);
+    HIP_TRY(hipMemcpyAsync(hc.data(), ocount.p, (size_t)K * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(hb.data(), obounds.p, hb.size() * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    long long total = 0;
+    for (int k = 0; k < K; ++k) {
+        res[k].n_out = hc[k];
+        res[k].changed = hc[k] != segs[k].n;
+        for (int a = 0; a < 3; ++a) {
+            res[k].mn[a] = hc[k] ? dec_f64(hb[(size_t)k * 6 + a]) : 0.0;
+            res[k].mx[a] = hc[k] ? dec_f64(hb[(size_t)k * 6 + 3 + a]) : 0.0;
+        }
+        total += hc[k];
+    }
+    return total;
+}
+
+// ------------------------------------------------------------------------------------------ voxel_down_sample
+struct VxSeg {
+    double ox, oy, oz;
+    int nx, ny, nz, n;
+    long long word_base, pt_base;
+};
+#define VFIX 70368744177664.0 /* 2^46 (unit weights) */
+
+__device__ __forceinline__ long long vx_cell(const VxSeg& g, double vs, const double* __restrict__ p, int& ix, int& iy, int& iz) {
+    ix = (int)floor(__ddiv_rn(__dsub_rn(p[0], g.ox), vs));
+    iy = (int)floor(__ddiv_rn(__dsub_rn(p[1], g.oy), vs));
+    iz = (int)floor(__ddiv_rn(__dsub_rn(p[2], g.oz), vs));
+    return ((long long)ix * g.ny + iy) * g.nz + iz;
+}
+
+__global__ void k_vx_mark(const double* __restrict__ pts, const VxSeg* __restrict__ segs, double vs,
+                          unsigned long long* __restrict__ bitmap) {
+    const VxSeg g = segs[blockIdx.y];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += gridDim.x * blockDim.x) {
+        int ix, iy, iz;
+        long long lin = vx_cell(g, vs, pts + (size_t)(g.pt_base + i) * 3, ix, iy, iz);
+        atomicOr(&bitmap[g.word_base + (lin >> 6)], 1ull << (lin & 63));
+    }
+}
+__global__ void k_vx_accum(const double* __restrict__ pts, const VxSeg* __restrict__ segs, double vs,
+                           const unsigned long long* __restrict__ bitmap, const unsigned* __restrict__ rank,
+                           long long* __restrict__ acc /*[3][P]*/, long long P, unsigned* __restrict__ wgt) {
+    const VxSeg g = segs[blockIdx.y];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += gridDim.x * blockDim.x) {
+        const double* p = pts + (size_t)(g.pt_base + i) * 3;
+        int ix, iy, iz;
+        long long lin = vx_cell(g, vs, p, ix, iy, iz);
+        long long wd = g.word_base + (lin >> 6);
+        unsigned slot = rank[wd] + (unsigned)__popcll(bitmap[wd] & ((1ull << (lin & 63)) - 1ull));
+        double cx = __dadd_rn(g.ox, __dmul_rn((double)ix, vs)), cy = __dadd_rn(g.oy, __dmul_rn((double)iy, vs)),
+               cz = __dadd_rn(g.oz, __dmul_rn((double)iz, vs));
+        atomicAdd((unsigned long long*)&acc[slot], (unsigned long long)llrint((p[0] - cx) * VFIX));
+        atomicAdd((unsigned long long*)&acc[P + slot], (unsigned long long)llrint((p[1] - cy) * VFIX));
+        atomicAdd((unsigned long long*)&acc[2 * P + slot], (unsigned long long)llrint((p[2] - cz) * VFIX));
+        atomicAdd(&wgt[slot], 1u);
+    }
+}
+__global__ void k_vx_final(const unsigned long long* __restrict__ bitmap, const unsigned* __restrict__ rank, long long nwords,
+                           const VxSeg* __restrict__ segs, int K, double vs, const long long* __restrict__ acc, long long P,
+                           const unsigned* __restrict__ wgt, double* __restrict__ out) {
+    long long wd = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wd >= nwords) return;
+    unsigned long long bw = bitmap[wd];
+    if (!bw) return;
+    int lo = 0, hi = K - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (segs[mid].word_base <= wd) lo = mid; else hi = mid - 1;
+    }
+    const VxSeg g = segs[lo];
+    unsigned sidx = rank[wd];
+    while (bw) {
+        int b = __ffsll(bw) - 1;
+        bw &= bw - 1;
+        long long lin = (wd - g.word_base) * 64 + b;
+        int iz = (int)(lin % g.nz);
+        long long r = lin / g.nz;
+        int iy = (int)(r % g.ny), ix = (int)(r / g.ny);
+        double n = (double)wgt[sidx];
+        out[(size_t)sidx * 3 + 0] = __dadd_rn(g.ox, __dmul_rn((double)ix, vs)) + ((double)acc[sidx] / n) / VFIX;
+        out[(size_t)sidx * 3 + 1] = __dadd_rn(g.oy, __dmul_rn((double)iy, vs)) + ((double)acc[P + sidx] / n) / VFIX;
+        out[(size_t)sidx * 3 + 2] = __dadd_rn(g.oz, __dmul_rn((double)iz, vs)) + ((double)acc[2 * P + sidx] / n) / VFIX;
+        ++sidx;
+    }
+}
+__global__ void k_vx_gather(const unsigned* __restrict__ rank, const VxSeg* __restrict__ segs, int K, unsigned* __restrict__ out) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K) out[k] = segs[k].n ? rank[segs[k].word_base] : 0u;
+}
+
+long long CloudOps::voxel_down_sample(const double* src, const std::vector<SegDesc>& segs, double vs, double* dst,
+                                      std::vector<int>& out_n) {
+    const int K = (int)segs.size();
+    out_n.assign(K, 0);
+    if (K == 0) return 0;
+    std::vector<VxSeg> hs(K);
+    long long nwords = 0;
+    int maxn = 0;
+    for (int k = 0; k < K; ++k) {
+        const SegDesc& sd = segs[k];
+        VxSeg& g = hs[k];
+        g.n = sd.n;
+        g.pt_base = sd.pt_base;
+        g.word_base = nwords;
+        maxn = std::max(maxn, sd.n);
+        if (sd.n == 0) {
+            g.ox = g.oy = g.oz = 0;
+            g.nx = g.ny = g.nz = 0;
+            continue;
+        }
+        g.ox = sd.mn[0] - vs * 0.5;
+        g.oy = sd.mn[1] - vs * 0.5;
+        g.oz = sd.mn[2] - vs * 0.5;
+        g.nx = (int)std::floor((sd.mx[0] - g.ox) / vs) + 2;
+        g.ny = (int)std::floor((sd.mx[1] - g.oy) / vs) + 2;
+        g.nz = (int)std::floor((sd.mx[2] - g.oz) / vs) + 2;
+        nwords += ((long long)g.nx * g.ny * g.nz + 63) / 64;
+    }
+    if (nwords == 0) return 0;
+    HMSG_REQUIRE(nwords < (1ll << 31), HMSG_ERR_UNSUPPORTED, "voxel_down_sample batch too large");
+    geom.ensure((size_t)K * sizeof(VxSeg));
+    HIP_TRY(hipMemcpyAsync(geom.p, hs.data(), (size_t)K * sizeof(VxSeg), hipMemcpyHostToDevice, s));
+    const VxSeg* dsegs = (const VxSeg*)geom.p;
+    vbitmap.ensure((size_t)nwords);
+    vrank.ensure((size_t)nwords);
+    HIP_TRY(hipMemsetAsync(vbitmap.p, 0, (size_t)nwords * 8, s));
+    dim3 grid(std::max(1u, std::min(cdiv(maxn, 256), 2048u)), K);
+    hipLaunchKernelGGL(k_vx_mark, grid, dim3(256), 0, s, src, dsegs, vs, vbitmap.p);
+    HMSG_CHECK_LAUNCH();
+    long long P = (long long)hmsg_bitmap_rank(vbitmap.p, vrank.p, (size_t)nwords, s, scan_tmp);
+    vacc.ensure((size_t)P * 3);
+    vwgt.ensure((size_t)P);
+    HIP_TRY(hipMemsetAsync(vacc.p, 0, (size_t)P * 24, s));
+    HIP_TRY(hipMemsetAsync(vwgt.p, 0, (size_t)P * 4, s));
+    hipLaunchKernelGGL(k_vx_accum, grid, dim3(256), 0, s, src, dsegs, vs, (const unsigned long long*)vbitmap.p,
+                       (const unsigned*)vrank.p, vacc.p, P, vwgt.p);
+    hipLaunchKernelGGL(k_vx_final, dim3(cdiv((size_t)nwords, 256)), dim3(256), 0, s, (const unsigned long long*)vbitmap.p,
+                       (const unsigned*)vrank.p, nwords, dsegs, K, vs, (const long long*)vacc.p, P, (const unsigned*)vwgt.p, dst);
+    pos.ensure(K);
+    hipLaunchKernelGGL(k_vx_gather, dim3(cdiv(K, 256)), dim3(256), 0, s, (const unsigned*)vrank.p, dsegs, K, pos.p);
+    HMSG_CHECK_LAUNCH();
+    std::vector<unsigned> st(K);
+    HIP_TRY(hipMemcpyAsync(st.data(), pos.p, (size_t)K * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    // empty segments share the next segment's word_base -> rank there equals the next start
+    std::vector<long long> startv(K + 1, P);
+    for (int k = 0; k < K; ++k)
+        if (hs[k].n) startv[k] = st[k];
+    for (int k = K - 1; k >= 0; --k)
+        if (!hs[k].n) startv[k] = startv[k + 1];
+    for (int k = 0; k < K; ++k) out_n[k] = (int)(startv[k + 1] - startv[k]);
+    return P;
+}

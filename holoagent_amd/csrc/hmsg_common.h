@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -195,6 +196,20 @@ void hmsg_scan_u32(const unsigned* in, unsigned* out, size_t n, hipStream_t s, D
 // popcount-prefix of a bitmap: rank[w] = number of set bits in words < w; returns total set bits
 unsigned long long hmsg_bitmap_rank(const unsigned long long* bitmap, unsigned* rank, size_t nwords, hipStream_t s,
                                     DevBuf<unsigned>& tmp);
+
+// development aid: when HMSG_DEBUG_DUMP=<dir> is set, write a device array to <dir>/<name>.bin
+static inline void hmsg_dump(const char* name, const void* dev, size_t bytes, hipStream_t s) {
+    const char* dir = getenv("HMSG_DEBUG_DUMP");
+    if (!dir || !bytes) return;
+    std::vector<char> host(bytes);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(host.data(), dev, bytes, hipMemcpyDeviceToHost);
+    std::string path = std::string(dir) + "/" + name + ".bin";
+    if (FILE* f = fopen(path.c_str(), "wb")) {
+        fwrite(host.data(), 1, bytes, f);
+        fclose(f);
+    }
+}
 
 void hmsg_build_map(hmsg_ctx* h);       // hmsg_map.hip
 void hmsg_fuse(hmsg_ctx* h);            // hmsg_fuse.hip

@@ -1,2 +1,542 @@
-#include "hmsg_common.h"
-void hmsg_merge(hmsg_ctx* h) { throw hmsg_error{HMSG_ERR_UNSUPPORTED, "merge not built yet"}; }
+// A6: 3-D mask merging -- seq_merge / hierarchical_merge / merge_3d_masks
+// (fsr_vln/memory/hmsg/utils/graph_utils.py:620-679, 883-1038) and the small-cloud drop of
+// graph.py:445-448.
+//
+// What runs where
+//   device : per-cloud uniform grids, "fraction of X within r of Y" counting in float32
+//            (find_overlapping_ratio_faiss), concatenation of merged components, segmented exact DBSCAN
+//            (merge_point_clouds_list -> pcd_denoise_dbscan(eps 0.1, min 10)), AABBs.
+//   host   : AABB-IoU pair filter, threshold + connected components (tens..thousands of clouds), list
+//            bookkeeping.  The merge is a fold over frames (inherently sequential across steps); each
+//            step is two device->host syncs.
+//
+// Two EXACT shortcuts make a 1000-frame fold tractable (the reference re-does this work every step):
+//   (1) a cloud whose DBSCAN kept every point is a fixed point of pcd_denoise_dbscan, so singleton
+//       components that are unchanged are not re-clustered;
+//   (2) sequential merge: two clouds that were both inputs of the previous step and both survived it
+//       unchanged were separate components there, so their overlap is <= threshold again -- only pairs
+//       involving a new or changed cloud are evaluated.  (Hierarchical merge changes the threshold per
+//       level, so there overlap VALUES are cached per pair of unchanged clouds instead.)
+#include "hmsg_cloudops.h"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+#include <unordered_map>
+
+namespace {
+
+struct Cloud {
+    long long off = 0;      // into the point pool
+    int n = 0;
+    double mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+    bool fixed = false;     // pcd_denoise_dbscan(merge eps/min) is known to return it unchanged
+    bool fresh = true;      // new or changed since it last went through merge_3d_masks
+    unsigned long long uid = 0;
+    // overlap grid (cell side >= r): cellstart[ncell+1] (absolute positions) + cell-sorted float32 points
+    bool has_index = false;
+    long long ix_cell = 0;
+    int gd[3] = {0, 0, 0};
+};
+
+struct OvGrid {             // device view of one cloud for the overlap kernels
+    long long pt_off;       // f64 points in the pool
+    long long ix_cell;
+    int n, gx, gy, gz;
+    float mnx, mny, mnz, mxx, mxy, mxz;   // float32 AABB
+    double ox, oy, oz, cell;
+};
+
+struct OvTask {             // count points of grid[x] within r of grid[y]
+    int x, y;
+};
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ overlap index
+__device__ __forceinline__ long long ov_cell(const OvGrid& g, float x, float y, float z) {
+    int ix = (int)floor(((double)x - g.ox) / g.cell), iy = (int)floor(((double)y - g.oy) / g.cell),
+        iz = (int)floor(((double)z - g.oz) / g.cell);
+    ix = min(max(ix, 0), g.gx - 1);
+    iy = min(max(iy, 0), g.gy - 1);
+    iz = min(max(iz, 0), g.gz - 1);
+    return g.ix_cell + ((long long)ix * g.gy + iy) * g.gz + iz;
+}
+__global__ void k_ov_count(const double* __restrict__ pool, const OvGrid* __restrict__ gr, unsigned* __restrict__ cells) {
+    const OvGrid g = gr[blockIdx.y];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += gridDim.x * blockDim.x) {
+        const double* p = pool + (size_t)(g.pt_off + i) * 3;
+        atomicAdd(&cells[ov_cell(g, (float)p[0], (float)p[1], (float)p[2])], 1u);
+    }
+}
+__global__ void k_add_base(unsigned* __restrict__ v, long long n, unsigned base) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] += base;
+}
+__global__ void k_ov_fill(const double* __restrict__ pool, const OvGrid* __restrict__ gr, const unsigned* __restrict__ cells,
+                          unsigned* __restrict__ cursor, long long cursor_base, float* __restrict__ sorted) {
+    const OvGrid g = gr[blockIdx.y];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += gridDim.x * blockDim.x) {
+        const double* p = pool + (size_t)(g.pt_off + i) * 3;
+        float x = (float)p[0], y = (float)p[1], z = (float)p[2];
+        long long c = ov_cell(g, x, y, z);
+        unsigned pos = cells[c] + atomicAdd(&cursor[c - cursor_base], 1u);
+        sorted[(size_t)pos * 3] = x;
+        sorted[(size_t)pos * 3 + 1] = y;
+        sorted[(size_t)pos * 3 + 2] = z;
+    }
+}
+
+// find_overlapping_ratio_faiss (graph_utils.py:645-662): a point of X overlaps when its exact float32
+// nearest neighbour in Y is closer than r^2, i.e. when SOME y has (dx*dx + dy*dy) + dz*dz < r2 in float32.
+__global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __restrict__ gr, const OvTask* __restrict__ tasks,
+                           const unsigned* __restrict__ cells, const float* __restrict__ sorted, float r2, float r,
+                           unsigned* __restrict__ counts) {
+    const OvTask t = tasks[blockIdx.y];
+    const OvGrid X = gr[t.x], Y = gr[t.y];
+    unsigned local = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < X.n; i += gridDim.x * blockDim.x) {
+        const double* p = pool + (size_t)(X.pt_off + i) * 3;
+        float x = (float)p[0], y = (float)p[1], z = (float)p[2];
+        if (x < Y.mnx - r || x > Y.mxx + r || y < Y.mny - r || y > Y.mxy + r || z < Y.mnz - r || z > Y.mxz + r) continue;
+        int cx = (int)floor(((double)x - Y.ox) / Y.cell), cy = (int)floor(((double)y - Y.oy) / Y.cell),
+            cz = (int)floor(((double)z - Y.oz) / Y.cell);
+        bool hit = false;
+        for (int dx = -1; dx <= 1 && !hit; ++dx) {
+            int jx = cx + dx;
+            if (jx < 0 || jx >= Y.gx) continue;
+            for (int dy = -1; dy <= 1 && !hit; ++dy) {
+                int jy = cy + dy;
+                if (jy < 0 || jy >= Y.gy) continue;
+                int z0 = max(cz - 1, 0), z1 = min(cz + 1, Y.gz - 1);
+                if (z1 < z0) continue;
+                long long c0 = Y.ix_cell + ((long long)jx * Y.gy + jy) * Y.gz;
+                unsigned s0 = cells[c0 + z0], e0 = cells[c0 + z1 + 1];     // z-cells are contiguous
+                for (unsigned k = s0; k < e0; ++k) {
+                    float ddx = __fsub_rn(x, sorted[(size_t)k * 3]), ddy = __fsub_rn(y, sorted[(size_t)k * 3 + 1]),
+                          ddz = __fsub_rn(z, sorted[(size_t)k * 3 + 2]);
+                    float d2 = __fadd_rn(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)), __fmul_rn(ddz, ddz));
+                    if (d2 < r2) {
+                        hit = true;
+                        break;
+                    }
+                }
+            }
+        }
+        local += hit ? 1u : 0u;
+    }
+    if (local) atomicAdd(&counts[blockIdx.y], local);
+}
+
+struct CatSeg {
+    long long src, dst;
+    int n, pad;
+};
+__global__ void k_concat(const double* __restrict__ pool, const CatSeg* __restrict__ segs, double* __restrict__ dst) {
+    const CatSeg sg = segs[blockIdx.y];
+    const long long cnt = (long long)sg.n * 3;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (long long)gridDim.x * blockDim.x)
+        dst[sg.dst * 3 + i] = pool[sg.src * 3 + i];
+}
+
+// ------------------------------------------------------------------------------------------ host side
+namespace {
+
+double bbox_iou(const Cloud& a, const Cloud& b) {   // graph_utils.py:883-915; empty cloud -> (0,0,0) box
+    double ov = 1, va = 1, vb = 1;
+    for (int k = 0; k < 3; ++k) {
+        double omin = std::max(a.mn[k], b.mn[k]), omax = std::min(a.mx[k], b.mx[k]);
+        ov *= std::max(omax - omin, 0.0);
+        va *= a.mx[k] - a.mn[k];
+        vb *= b.mx[k] - b.mn[k];
+    }
+    return ov / (va + vb - ov);   // 0/0 -> NaN -> comparison false, like numpy
+}
+
+struct Merger {
+    hmsg_ctx* h = nullptr;
+    hipStream_t s = nullptr;
+    CloudOps ops;
+    DevBuf<double> pool;
+    long long pool_used = 0;        // points
+    DevBuf<unsigned> ix_cells;      // concatenated cellstart arrays (absolute positions into ix_pts)
+    long long ix_cells_used = 0;
+    DevBuf<float> ix_pts;           // concatenated cell-sorted float32 points
+    long long ix_pts_used = 0;      // points
+    DevBuf<double> concat;
+    DevBuf<OvGrid> d_grids;
+    DevBuf<OvTask> d_tasks;
+    DevBuf<unsigned> d_counts, d_cursor;
+    DevBuf<CatSeg> d_cat;
+    unsigned long long next_uid = 1;
+    std::unordered_map<unsigned long long, double> ratio_cache;   // hierarchical merge only
+    bool use_cache = false;
+    double radius = 0;              // 1.5 * voxel_size  (merge_3d_masks passes radius=1.5*radius)
+    double cell = 0;
+    double eps = 0.1;
+    int minpts = 10;
+    double iou_thresh = 0.05;
+
+    template <typename T>
+    void grow(DevBuf<T>& b, size_t used_elems, size_t need_elems) {
+        if (need_elems <= b.n) return;
+        DevBuf<T> nb;
+        nb.alloc(std::max(need_elems * 2, (size_t)1 << 18));
+        if (used_elems) HIP_TRY(hipMemcpyAsync(nb.p, b.p, used_elems * sizeof(T), hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        std::swap(nb.p, b.p);
+        std::swap(nb.n, b.n);
+    }
+
+    OvGrid grid_of(const Cloud& c) const {
+        OvGrid g;
+        g.pt_off = c.off;
+        g.ix_cell = c.ix_cell;
+        g.n = c.n;
+        g.gx = c.gd[0];
+        g.gy = c.gd[1];
+        g.gz = c.gd[2];
+        g.mnx = (float)c.mn[0]; g.mny = (float)c.mn[1]; g.mnz = (float)c.mn[2];
+        g.mxx = (float)c.mx[0]; g.mxy = (float)c.mx[1]; g.mxz = (float)c.mx[2];
+        // float32 rounding can move a coordinate slightly outside the f64 box: pad the origin
+        g.ox = (double)g.mnx - 1e-3;
+        g.oy = (double)g.mny - 1e-3;
+        g.oz = (double)g.mnz - 1e-3;
+        g.cell = cell;
+        return g;
+    }
+
+    // ---- overlap grids for the clouds that do not have one yet
+    void build_indices(std::vector<Cloud>& L) {
+        std::vector<int> todo;
+        long long ncell_new = 0, npts_new = 0;
+        int maxn = 0;
+        for (int i = 0; i < (int)L.size(); ++i) {
+            Cloud& c = L[i];
+            if (c.has_index || c.n == 0) continue;
+            for (int a = 0; a < 3; ++a)
+                c.gd[a] = (int)std::floor(((double)(float)c.mx[a] - (double)(float)c.mn[a] + 2e-3) / cell) + 1;
+            c.ix_cell = ix_cells_used + ncell_new;
+            ncell_new += (long long)c.gd[0] * c.gd[1] * c.gd[2] + 1;   // +1: end sentinel
+            npts_new += c.n;
+            maxn = std::max(maxn, c.n);
+            todo.push_back(i);
+        }
+        if (todo.empty()) return;
+        HMSG_REQUIRE(ix_cells_used + ncell_new < (1ll << 32) && ix_pts_used + npts_new < (1ll << 32), HMSG_ERR_UNSUPPORTED,
+                     "merge index exceeds 2^32 entries");
+        grow(ix_cells, (size_t)ix_cells_used, (size_t)(ix_cells_used + ncell_new));
+        grow(ix_pts, (size_t)ix_pts_used * 3, (size_t)(ix_pts_used + npts_new) * 3);
+        std::vector<OvGrid> g(todo.size());
+        for (size_t k = 0; k < todo.size(); ++k) g[k] = grid_of(L[todo[k]]);
+        d_grids.ensure(g.size());
+        HIP_TRY(hipMemcpyAsync(d_grids.p, g.data(), g.size() * sizeof(OvGrid), hipMemcpyHostToDevice, s));
+        unsigned* cells = ix_cells.p + ix_cells_used;
+        HIP_TRY(hipMemsetAsync(cells, 0, (size_t)ncell_new * 4, s));
+        dim3 grid(std::max(1u, std::min(cdiv(maxn, 256), 1024u)), (unsigned)todo.size());
+        hipLaunchKernelGGL(k_ov_count, grid, dim3(256), 0, s, (const double*)pool.p, (const OvGrid*)d_grids.p, ix_cells.p);
+        HMSG_CHECK_LAUNCH();
+        hmsg_scan_u32(cells, cells, (size_t)ncell_new, s, ops.scan_tmp, nullptr);
+        hipLaunchKernelGGL(k_add_base, dim3(cdiv((size_t)ncell_new, 256)), dim3(256), 0, s, cells, ncell_new, (unsigned)ix_pts_used);
+        d_cursor.ensure((size_t)ncell_new);
+        HIP_TRY(hipMemsetAsync(d_cursor.p, 0, (size_t)ncell_new * 4, s));
+        hipLaunchKernelGGL(k_ov_fill, grid, dim3(256), 0, s, (const double*)pool.p, (const OvGrid*)d_grids.p,
+                           (const unsigned*)ix_cells.p, d_cursor.p, ix_cells_used, ix_pts.p);
+        HMSG_CHECK_LAUNCH();
+        for (int i : todo) L[i].has_index = true;
+        ix_cells_used += ncell_new;
+        ix_pts_used += npts_new;
+    }
+
+    // ---- overlap ratios for a list of (i, j) pairs of L
+    void overlap_ratios(const std::vector<Cloud>& L, const std::vector<std::pair<int, int>>& pairs, std::vector<double>& ratio) {
+        ratio.assign(pairs.size(), 0.0);
+        if (pairs.empty()) return;
+        // compact table of the clouds involved
+        std::vector<int> slot(L.size(), -1);
+        std::vector<OvGrid> g;
+        std::vector<OvTask> tasks;
+        tasks.reserve(pairs.size() * 2);
+        int maxn = 0;
+        for (auto& pr : pairs) {
+            for (int v : {pr.first, pr.second})
+                if (slot[v] < 0) {
+                    slot[v] = (int)g.size();
+                    g.push_back(grid_of(L[v]));
+                    maxn = std::max(maxn, L[v].n);
+                }
+            tasks.push_back(OvTask{slot[pr.first], slot[pr.second]});
+            tasks.push_back(OvTask{slot[pr.second], slot[pr.first]});
+        }
+        d_grids.ensure(g.size());
+        d_tasks.ensure(tasks.size());
+        d_counts.ensure(tasks.size());
+        HIP_TRY(hipMemcpyAsync(d_grids.p, g.data(), g.size() * sizeof(OvGrid), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_tasks.p, tasks.data(), tasks.size() * sizeof(OvTask), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemsetAsync(d_counts.p, 0, tasks.size() * 4, s));
+        const float r = (float)radius;
+        const float r2 = (float)(radius * radius);   // `D < radius**2` with a float32 D (graph_utils.py:654-655)
+        const unsigned bx = std::max(1u, std::min(cdiv(maxn, 256), 64u));
+        for (size_t t0 = 0; t0 < tasks.size(); t0 += 32768) {
+            unsigned nt = (unsigned)std::min<size_t>(32768, tasks.size() - t0);
+            hipLaunchKernelGGL(k_ov_query, dim3(bx, nt), dim3(256), 0, s, (const double*)pool.p, (const OvGrid*)d_grids.p,
+                               (const OvTask*)(d_tasks.p + t0), (const unsigned*)ix_cells.p, (const float*)ix_pts.p, r2, r,
+                               d_counts.p + t0);
+        }
+        HMSG_CHECK_LAUNCH();
+        std::vector<unsigned> hc(tasks.size());
+        HIP_TRY(hipMemcpyAsync(hc.data(), d_counts.p, tasks.size() * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        for (size_t k = 0; k < pairs.size(); ++k) {
+            double a = (double)hc[2 * k] / (double)L[pairs[k].first].n;
+            double b = (double)hc[2 * k + 1] / (double)L[pairs[k].second].n;
+            ratio[k] = std::max(a, b);
+        }
+    }
+
+    // ---- merge_3d_masks (graph_utils.py:918-956)
+    std::vector<Cloud> merge_3d_masks(std::vector<Cloud> L, double th) {
+        const int n = (int)L.size();
+        if (n == 0) return L;
+        build_indices(L);
+        // 1. candidate pairs
+        std::vector<std::pair<int, int>> pairs;
+        std::vector<double> known;                 // cached ratios (hierarchical)
+        std::vector<std::pair<int, int>> known_pairs;
+        auto consider = [&](int i, int j) {
+            if (L[i].n == 0 || L[j].n == 0) return;   // find_overlapping_ratio_faiss returns 0 for empty clouds
+            if (!(bbox_iou(L[i], L[j]) > iou_thresh)) return;
+            if (use_cache && !L[i].fresh && !L[j].fresh) {
+                auto it = ratio_cache.find(L[i].uid * 0x100000000ull + L[j].uid);
+                if (it != ratio_cache.end()) {
+                    known_pairs.emplace_back(i, j);
+                    known.push_back(it->second);
+                    return;
+                }
+            }
+            pairs.emplace_back(i, j);
+        };
+        if (use_cache) {
+            for (int i = 0; i < n; ++i)
+                for (int j = i + 1; j < n; ++j) consider(i, j);
+        } else {
+            for (int i = 0; i < n; ++i)
+                for (int j = i + 1; j < n; ++j)
+                    if (L[i].fresh || L[j].fresh) consider(i, j);
+        }
+        std::vector<double> ratio;
+        overlap_ratios(L, pairs, ratio);
+        // 2. components of `overlap > th` (scipy connected_components labels by lowest member index)
+        std::vector<int> parent(n);
+        std::iota(parent.begin(), parent.end(), 0);
+        auto find = [&](int x) {
+            while (parent[x] != x) x = parent[x] = parent[parent[x]];
+            return x;
+        };
+        auto unite = [&](int a, int b) {
+            a = find(a);
+            b = find(b);
+            if (a != b) parent[std::max(a, b)] = std::min(a, b);
+        };
+        for (size_t k = 0; k < pairs.size(); ++k) {
+            if (use_cache) ratio_cache[L[pairs[k].first].uid * 0x100000000ull + L[pairs[k].second].uid] = ratio[k];
+            if (ratio[k] > th) unite(pairs[k].first, pairs[k].second);
+        }
+        for (size_t k = 0; k < known_pairs.size(); ++k)
+            if (known[k] > th) unite(known_pairs[k].first, known_pairs[k].second);
+        std::vector<std::vector<int>> comps;
+        std::vector<int> comp_of(n, -1);
+        for (int i = 0; i < n; ++i) {
+            int r = find(i);
+            if (comp_of[r] < 0) {
+                comp_of[r] = (int)comps.size();
+                comps.emplace_back();
+            }
+            comps[comp_of[r]].push_back(i);
+        }
+        // 3. merge_point_clouds_list per component: concat in index order + keep-largest DBSCAN
+        std::vector<int> seg_of_comp(comps.size(), -1);
+        std::vector<SegDesc> segs;
+        std::vector<CatSeg> cat;
+        long long cat_total = 0;
+        for (size_t c = 0; c < comps.size(); ++c) {
+            const auto& mem = comps[c];
+            if (mem.size() == 1 && (L[mem[0]].fixed || L[mem[0]].n == 0)) continue;   // exact shortcut (1)
+            SegDesc sd;
+            sd.pt_base = cat_total;
+            sd.n = 0;
+            bool any = false;
+            for (int i : mem) {
+                if (L[i].n == 0) continue;
+                cat.push_back(CatSeg{L[i].off, cat_total, L[i].n, 0});
+                cat_total += L[i].n;
+                sd.n += L[i].n;
+                for (int a = 0; a < 3; ++a) {
+                    sd.mn[a] = any ? std::min(sd.mn[a], L[i].mn[a]) : L[i].mn[a];
+                    sd.mx[a] = any ? std::max(sd.mx[a], L[i].mx[a]) : L[i].mx[a];
+                }
+                any = true;
+            }
+            seg_of_comp[c] = (int)segs.size();
+            segs.push_back(sd);
+        }
+        std::vector<DbscanResult> res;
+        long long out_base = pool_used;
+        if (!segs.empty() && cat_total > 0) {
+            concat.ensure((size_t)cat_total * 3);
+            d_cat.ensure(cat.size());
+            HIP_TRY(hipMemcpyAsync(d_cat.p, cat.data(), cat.size() * sizeof(CatSeg), hipMemcpyHostToDevice, s));
+            int maxn = 0;
+            for (auto& cs : cat) maxn = std::max(maxn, cs.n);
+            for (size_t c0 = 0; c0 < cat.size(); c0 += 32768) {
+                unsigned nc = (unsigned)std::min<size_t>(32768, cat.size() - c0);
+                hipLaunchKernelGGL(k_concat, dim3(std::max(1u, std::min(cdiv((size_t)maxn * 3, 256), 256u)), nc), dim3(256), 0, s,
+                                   (const double*)pool.p, (const CatSeg*)(d_cat.p + c0), concat.p);
+            }
+            HMSG_CHECK_LAUNCH();
+            grow(pool, (size_t)pool_used * 3, (size_t)(pool_used + cat_total) * 3);
+            ops.dbscan_keep_largest(concat.p, segs, eps, minpts, pool.p + (size_t)pool_used * 3, res);
+        } else {
+            res.assign(segs.size(), DbscanResult{});
+        }
+        // 4. new list in component order
+        std::vector<Cloud> out;
+        out.reserve(comps.size());
+        long long cursor = out_base;
+        for (size_t c = 0; c < comps.size(); ++c) {
+            const auto& mem = comps[c];
+            int sg = seg_of_comp[c];
+            if (sg < 0) {                       // untouched singleton
+                Cloud k = L[mem[0]];
+                k.fresh = false;
+                k.fixed = true;
+                out.push_back(k);
+                continue;
+            }
+            const DbscanResult& r = res[sg];
+            if (mem.size() == 1 && !r.changed) {   // DBSCAN kept every point: same cloud, now known fixed
+                Cloud k = L[mem[0]];
+                k.fresh = false;
+                k.fixed = true;
+                out.push_back(k);
+                cursor += r.n_out;              // its copy in the pool is simply unused
+                continue;
+            }
+            Cloud k;
+            k.off = cursor;
+            k.n = r.n_out;
+            for (int a = 0; a < 3; ++a) {
+                k.mn[a] = r.mn[a];
+                k.mx[a] = r.mx[a];
+            }
+            k.fixed = !r.changed;               // all points kept -> one closed cluster -> fixed point
+            k.fresh = true;
+            k.uid = next_uid++;
+            out.push_back(k);
+            cursor += r.n_out;
+        }
+        pool_used = cursor;
+        return out;
+    }
+};
+
+}  // namespace
+
+void hmsg_merge(hmsg_ctx* h) {
+    const hmsg_config& c = h->cfg;
+    HMSG_REQUIRE(h->feats_final && h->n_fused > 0, HMSG_ERR_INVALID, "hmsg_merge_instances: run hmsg_fuse_frames first");
+    HMSG_REQUIRE(!h->merged, HMSG_ERR_INVALID, "instances already merged");
+    Merger m;
+    m.h = h;
+    m.s = h->stream;
+    m.ops.s = h->stream;
+    m.radius = 1.5 * c.voxel_size;
+    m.cell = m.radius * (1.0 + 1e-3) + 2e-3;
+    m.eps = c.merge_dbscan_eps;
+    m.minpts = c.merge_dbscan_min;
+    m.iou_thresh = c.iou_thresh;
+    const int F = h->n_fused, M = h->M;
+    // the 3-D masks of all frames seed the pool (device to device)
+    const long long total = h->masks3d.total;
+    m.pool.alloc((size_t)std::max<long long>(total * 2, 1 << 16) * 3);
+    if (total) HIP_TRY(hipMemcpyAsync(m.pool.p, h->masks3d.pts.p, (size_t)total * 24, hipMemcpyDeviceToDevice, h->stream));
+    m.pool_used = total;
+    // AABBs of the frame masks (device reduction)
+    std::vector<SegDesc> msegs((size_t)F * M);
+    for (size_t id = 0; id < msegs.size(); ++id) {
+        msegs[id].pt_base = h->masks3d.off[id];
+        msegs[id].n = (int)(h->masks3d.off[id + 1] - h->masks3d.off[id]);
+    }
+    m.ops.bounds(m.pool.p, msegs);
+    std::vector<std::vector<Cloud>> frames(F);
+    for (int f = 0; f < F; ++f) {
+        frames[f].resize(M);
+        for (int i = 0; i < M; ++i) {
+            Cloud& k = frames[f][i];
+            const SegDesc& sd = msegs[(size_t)f * M + i];
+            k.off = sd.pt_base;
+            k.n = sd.n;
+            k.uid = m.next_uid++;
+            for (int a = 0; a < 3; ++a) {
+                k.mn[a] = sd.mn[a];
+                k.mx[a] = sd.mx[a];
+            }
+        }
+    }
+    std::vector<Cloud> result;
+    if (c.merge_type == HMSG_MERGE_HIERARCHICAL) {
+        // graph_utils.py:959-1012
+        m.use_cache = true;
+        double th = c.init_overlap_thresh;
+        std::vector<std::vector<Cloud>> lv = std::move(frames);
+        while (lv.size() > 1) {
+            std::vector<std::vector<Cloud>> nx;
+            for (size_t i = 0; i < lv.size(); i += 2) {
+                if (i == lv.size() - 1) {
+                    nx.push_back(std::move(lv[i]));
+                    break;
+                }
+                std::vector<Cloud> L = std::move(lv[i]);
+                L.insert(L.end(), lv[i + 1].begin(), lv[i + 1].end());
+                nx.push_back(m.merge_3d_masks(std::move(L), th));
+            }
+            lv = std::move(nx);
+            if (lv.size() > 1) th -= c.overlap_thresh_factor * (double)((long long)lv.size() - 2) / (double)std::max<long long>(1, (long long)lv.size() - 1);
+        }
+        result = m.merge_3d_masks(std::move(lv[0]), 0.75);
+    } else {
+        // graph_utils.py:1015-1038
+        std::vector<Cloud> G = std::move(frames[0]);
+        for (int f = 1; f < F; ++f) {
+            G.insert(G.end(), frames[f].begin(), frames[f].end());
+            G = m.merge_3d_masks(std::move(G), c.init_overlap_thresh);
+        }
+        result = m.merge_3d_masks(std::move(G), c.init_overlap_thresh);
+    }
+    // graph.py:445-448: drop clouds with < 10 points; compact the survivors into the handle
+    long long keep_total = 0;
+    std::vector<CatSeg> cat;
+    h->inst.off.assign(1, 0);
+    for (auto& k : result) {
+        if (k.n < c.min_instance_points) continue;
+        cat.push_back(CatSeg{k.off, keep_total, k.n, 0});
+        keep_total += k.n;
+        h->inst.off.push_back(keep_total);
+    }
+    h->inst.total = keep_total;
+    h->inst.pts.alloc((size_t)std::max<long long>(keep_total, 1) * 3);
+    if (!cat.empty()) {
+        m.d_cat.ensure(cat.size());
+        HIP_TRY(hipMemcpyAsync(m.d_cat.p, cat.data(), cat.size() * sizeof(CatSeg), hipMemcpyHostToDevice, h->stream));
+        int maxn = 0;
+        for (auto& cs : cat) maxn = std::max(maxn, cs.n);
+        for (size_t c0 = 0; c0 < cat.size(); c0 += 32768) {
+            unsigned nc = (unsigned)std::min<size_t>(32768, cat.size() - c0);
+            hipLaunchKernelGGL(k_concat, dim3(std::max(1u, std::min(cdiv((size_t)maxn * 3, 256), 256u)), nc), dim3(256), 0, h->stream,
+                               (const double*)m.pool.p, (const CatSeg*)(m.d_cat.p + c0), h->inst.pts.p);
+        }
+        HMSG_CHECK_LAUNCH();
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->merged = true;
+}

@@ -1,0 +1,92 @@
+// Exact nearest-neighbour search in the filtered global cloud (replaces scipy cKDTree.query(k=1) of
+// graph.py:409, generic.py:181, graph.py:458): ring expansion over the occupancy bitmap.
+#pragma once
+#include "hmsg_common.h"
+
+// ------------------------------------------------------------------------------------------ NN search
+struct NNBest {
+    double d2;
+    int idx;
+};
+__device__ __forceinline__ void nn_column(const GridGeom& g, const unsigned long long* __restrict__ bitmap,
+                                          const unsigned* __restrict__ rank, const double* __restrict__ pts, int ix, int iy,
+                                          int z0, int z1, double qx, double qy, double qz, NNBest& best) {
+    if (ix < 0 || iy < 0 || ix >= g.nx || iy >= g.ny) return;
+    z0 = z0 < 0 ? 0 : z0;
+    z1 = z1 >= g.nz ? g.nz - 1 : z1;
+    if (z1 < z0) return;
+    long long colw = ((long long)ix * g.ny + iy) * (g.nzp >> 6);
+    for (int w = z0 >> 6; w <= z1 >> 6; ++w) {
+        unsigned long long word = bitmap[colw + w];
+        if (!word) continue;
+        int b0 = w * 64;
+        int lo = z0 - b0 < 0 ? 0 : z0 - b0, hi = z1 - b0 > 63 ? 63 : z1 - b0;
+        unsigned long long m = (hi >= 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull)) & ~((1ull << lo) - 1ull);
+        unsigned long long sel = word & m;
+        if (!sel) continue;
+        unsigned base = rank[colw + w];
+        while (sel) {
+            int b = __ffsll(sel) - 1;
+            sel &= sel - 1;
+            int q = (int)(base + (unsigned)__popcll(word & ((1ull << b) - 1ull)));
+            double dx = __dsub_rn(pts[(size_t)q * 3], qx), dy = __dsub_rn(pts[(size_t)q * 3 + 1], qy),
+                   dz = __dsub_rn(pts[(size_t)q * 3 + 2], qz);
+            double d2 = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+            // canonical tie rule (oracle NN_TIE="lowest"): candidates whose squared distance is within 1e-9
+            // (relative) of the minimum are ties -> lowest index wins
+            if (d2 < best.d2 * (1.0 - 1e-9)) {
+                best.d2 = d2;
+                best.idx = q;
+            } else if (d2 <= best.d2 * (1.0 + 1e-9)) {
+                if (q < best.idx) best.idx = q;
+                if (d2 < best.d2) best.d2 = d2;
+            }
+        }
+    }
+}
+
+// Exact nearest cloud point of q (Euclidean, f64).  After ring r every cell of the cube [c-r, c+r]^3 has
+// been examined; a point outside the cube is at least `m` away, m = distance from q to the nearest cube
+// face that is not already the grid boundary, so the search stops once best < m.
+__device__ inline int nn_search(const GridGeom& g, const unsigned long long* __restrict__ bitmap, const unsigned* __restrict__ rank,
+                         const double* __restrict__ pts, double qx, double qy, double qz, double* out_d2 = nullptr) {
+    int cx, cy, cz;
+    cell_of(g, qx, qy, qz, cx, cy, cz);
+    cx = cx < 0 ? 0 : (cx >= g.nx ? g.nx - 1 : cx);
+    cy = cy < 0 ? 0 : (cy >= g.ny ? g.ny - 1 : cy);
+    cz = cz < 0 ? 0 : (cz >= g.nz ? g.nz - 1 : cz);
+    NNBest best{1e300, -1};
+    const int rmax = max(g.nx, max(g.ny, g.nz));
+    for (int r = 1; r <= rmax; ++r) {
+        if (r == 1) {
+            for (int dx = -1; dx <= 1; ++dx)
+                for (int dy = -1; dy <= 1; ++dy) nn_column(g, bitmap, rank, pts, cx + dx, cy + dy, cz - 1, cz + 1, qx, qy, qz, best);
+        } else {
+            for (int dx = -r; dx <= r; ++dx)
+                for (int dy = -r; dy <= r; ++dy) {
+                    bool rim = (dx == -r || dx == r || dy == -r || dy == r);
+                    if (rim) {
+                        nn_column(g, bitmap, rank, pts, cx + dx, cy + dy, cz - r, cz + r, qx, qy, qz, best);
+                    } else {
+                        nn_column(g, bitmap, rank, pts, cx + dx, cy + dy, cz - r, cz - r, qx, qy, qz, best);
+                        nn_column(g, bitmap, rank, pts, cx + dx, cy + dy, cz + r, cz + r, qx, qy, qz, best);
+                    }
+                }
+        }
+        // distance to the unexplored region
+        double m = 1e300;
+        bool open = false;
+        if (cx - r >= 0) { m = fmin(m, qx - (g.ox + (cx - r) * g.vs)); open = true; }
+        if (cx + r < g.nx - 1) { m = fmin(m, (g.ox + (cx + r + 1) * g.vs) - qx); open = true; }
+        if (cy - r >= 0) { m = fmin(m, qy - (g.oy + (cy - r) * g.vs)); open = true; }
+        if (cy + r < g.ny - 1) { m = fmin(m, (g.oy + (cy + r + 1) * g.vs) - qy); open = true; }
+        if (cz - r >= 0) { m = fmin(m, qz - (g.oz + (cz - r) * g.vs)); open = true; }
+        if (cz + r < g.nz - 1) { m = fmin(m, (g.oz + (cz + r + 1) * g.vs) - qz); open = true; }
+        if (!open) break;
+        m -= 1e-9;   // centroids sit inside their cell only up to rounding
+        if (best.idx >= 0 && m > 0.0 && best.d2 < m * m) break;
+    }
+    if (out_d2) *out_d2 = best.d2;
+    return best.idx;
+}
+

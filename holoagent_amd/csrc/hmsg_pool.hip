@@ -1,2 +1,400 @@
-#include "hmsg_common.h"
-void hmsg_pool(hmsg_ctx* h) { throw hmsg_error{HMSG_ERR_UNSUPPORTED, "pool not built yet"}; }
+// A7: per-instance feature pooling (fsr_vln/memory/hmsg/graph/graph.py:450-491) with
+// feats_denoise_dbscan (utils/graph_utils.py:682-728): for every merged instance
+//   voxel_down_sample -> nearest map voxel (dist <= 0.8) -> gather the voxel features -> cosine DBSCAN
+//   (eps 0.01, min_samples 100, sklearn semantics, SURVEY hazard 18) -> mean over the largest cluster.
+//
+// MI355X design: all instances are processed in ONE batch.  The n_i x n_i cosine matrices are never
+// stored as floats: a float32 MFMA (v_mfma_f32_32x32x2_f32 -- an exact fmaf chain, so the result does not
+// depend on tiling) kernel produces 32x32 tiles of X^.X^T, thresholds 1 - s <= eps in registers and writes
+// one adjacency BIT per pair plus per-row neighbour counts.  Core components, border assignment and the
+// largest-cluster choice then work on the bit matrix (n^2/8 bytes).  The final mean adds rows in index
+// order in float32, which is what np.mean(axis=0) does on a C-contiguous [n, D] array.
+#include "hmsg_cloudops.h"
+#include "hmsg_nn.h"
+
+#include <algorithm>
+#include <cmath>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct PoolSeg {            // one instance
+    long long row_base;     // first row in the concatenated feature matrix
+    long long bit_base;     // first u32 word of its adjacency bit matrix
+    int n;                  // rows (valid points)
+    int nw;                 // u32 words per row = ceil(n / 32)
+    long long tile_base;    // first 32x32 tile id
+    int nt;                 // tiles per side = ceil(n / 32)
+    int pad;
+};
+
+// ---- NN of the down-sampled instance points; keep dist <= max_dist (graph.py:458-460)
+__global__ void k_pool_nn(const double* __restrict__ q, long long N, GridGeom g, const unsigned long long* __restrict__ bitmap,
+                          const unsigned* __restrict__ rank, const double* __restrict__ pts, double max_dist,
+                          int* __restrict__ idx, unsigned* __restrict__ valid) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    double d2 = 0;
+    int v = nn_search(g, bitmap, rank, pts, q[i * 3], q[i * 3 + 1], q[i * 3 + 2], &d2);
+    idx[i] = v;
+    valid[i] = (v >= 0 && __dsqrt_rn(d2) <= max_dist) ? 1u : 0u;
+}
+
+// ---- gather + nan_to_num (graph.py:476-477) + row L2-normalised copy (sklearn cosine_distances)
+__global__ void k_pool_gather(const int* __restrict__ idx, const unsigned* __restrict__ valid, const unsigned* __restrict__ pos,
+                              long long N, const float* __restrict__ feats, int D, float* __restrict__ X, float* __restrict__ Xn) {
+    const int lane = threadIdx.x & 63;
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (i >= N || !valid[i]) return;
+    const float* src = feats + (size_t)idx[i] * D;
+    float* dx = X + (size_t)pos[i] * D;
+    float* dn = Xn + (size_t)pos[i] * D;
+    float n2 = 0.f;
+    for (int e = lane; e < D; e += 64) {
+        float v = src[e];
+        if (v != v) v = 0.f;                                   // nan -> 0
+        else if (v > 3.4028234663852886e38f) v = 3.4028234663852886e38f;    // +inf -> max
+        else if (v < -3.4028234663852886e38f) v = -3.4028234663852886e38f;  // -inf -> min
+        dx[e] = v;
+        n2 += v * v;
+    }
+    float nrm = __fsqrt_rn(wave_sum_f32(n2));
+    if (nrm == 0.f) nrm = 1.f;                                  // sklearn normalize: zero rows stay zero
+    for (int e = lane; e < D; e += 64) dn[e] = __fdiv_rn(dx[e], nrm);
+}
+
+// ---- Gram tiles on the matrix cores -> adjacency bits + neighbour counts
+// One wave per 32x32 tile.  K is consumed two columns per MFMA (32x32x2 f32): lane l feeds
+// A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; both come from X^ rows staged through LDS in 32-wide
+// K panels so global reads are coalesced.
+__global__ void __launch_bounds__(256) k_pool_gram(const float* __restrict__ Xn, int D, const PoolSeg* __restrict__ segs, int K,
+                                                   long long ntiles, float eps, unsigned* __restrict__ adj,
+                                                   unsigned* __restrict__ ncount) {
+    __shared__ float sa[4][32][33];
+    __shared__ float sb[4][32][33];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    long long tile = (long long)blockIdx.x * 4 + wv;
+    const bool active = tile < ntiles;
+    if (!active) tile = ntiles - 1;
+    int lo = 0, hi = K - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (segs[mid].tile_base <= tile) lo = mid; else hi = mid - 1;
+    }
+    const PoolSeg sg = segs[lo];
+    const long long t = tile - sg.tile_base;
+    const int ti = (int)(t / sg.nt), tj = (int)(t % sg.nt);
+    const int r0 = ti * 32, c0 = tj * 32;
+    f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* base = Xn + (size_t)sg.row_base * D;
+    for (int k0 = 0; k0 < D; k0 += 32) {
+        // stage 32 rows x 32 k of both operands: lane reads row lane>>1, 16 consecutive k
+        {
+            int rr = (lane >> 1), kk = (lane & 1) * 16;
+            int ra = r0 + rr, rb = c0 + rr;
+            for (int u = 0; u < 16; ++u) {
+                int k = k0 + kk + u;
+                sa[wv][rr][kk + u] = (ra < sg.n && k < D) ? base[(size_t)ra * D + k] : 0.f;
+                sb[wv][rr][kk + u] = (rb < sg.n && k < D) ? base[(size_t)rb * D + k] : 0.f;
+            }
+        }
+        __syncthreads();
+        for (int k = 0; k < 32; k += 2) {
+            float a = sa[wv][lane & 31][k + (lane >> 5)];
+            float b = sb[wv][lane & 31][k + (lane >> 5)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // epilogue: d = 1 - s, clipped to [0, 2], diagonal forced to 0; neighbour iff d <= eps
+    const int col = c0 + (lane & 31);
+    for (int r = 0; r < 16; ++r) {
+        int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float d = __fadd_rn(-acc[r], 1.0f);
+        d = fminf(fmaxf(d, 0.f), 2.f);
+        if (row == col) d = 0.f;
+        bool nb = active && row < sg.n && col < sg.n && d <= eps;
+        unsigned long long m = __ballot(nb);
+        if ((lane & 31) == 0 && active) {
+            unsigned word = (unsigned)(lane ? (m >> 32) : (m & 0xffffffffull));
+            if (row < sg.n && word) {
+                adj[sg.bit_base + (size_t)row * sg.nw + tj] = word;
+                atomicAdd(&ncount[sg.row_base + row], (unsigned)__popc(word));
+            }
+        }
+    }
+}
+
+// ---- label propagation over the adjacency bits (cores only): label = smallest core index reachable
+__global__ void k_pool_init(const unsigned* __restrict__ ncount, long long N, int minpts, int* __restrict__ label,
+                            const PoolSeg* __restrict__ segs, const int* __restrict__ seg_of_row) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const PoolSeg sg = segs[seg_of_row[i]];
+    label[i] = ncount[i] >= (unsigned)minpts ? (int)(i - sg.row_base) : -1;
+}
+__global__ void k_pool_prop(const unsigned* __restrict__ adj, const PoolSeg* __restrict__ segs, const int* __restrict__ seg_of_row,
+                            const unsigned* __restrict__ ncount, int minpts, long long N, int* __restrict__ label,
+                            int* __restrict__ changed) {
+    const int lane = threadIdx.x & 63;
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (i >= N) return;
+    if (ncount[i] < (unsigned)minpts) return;                 // wave-uniform
+    const PoolSeg sg = segs[seg_of_row[i]];
+    const unsigned* row = adj + sg.bit_base + (size_t)(i - sg.row_base) * sg.nw;
+    int best = label[i];
+    for (int w = lane; w < sg.nw; w += 64) {
+        unsigned bits = row[w];
+        while (bits) {
+            int b = __ffs(bits) - 1;
+            bits &= bits - 1;
+            long long j = sg.row_base + (long long)w * 32 + b;
+            if (ncount[j] >= (unsigned)minpts) {
+                int lj = __hip_atomic_load(&label[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                best = lj < best ? lj : best;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        int t = __shfl_xor(best, o);
+        best = t < best ? t : best;
+    }
+    if (lane == 0 && best < label[i]) {
+        atomicMin(&label[i], best);
+        *changed = 1;
+    }
+}
+// border points: smallest cluster label among adjacent cores; then sizes / first index per cluster
+__global__ void k_pool_border(const unsigned* __restrict__ adj, const PoolSeg* __restrict__ segs, const int* __restrict__ seg_of_row,
+                              const unsigned* __restrict__ ncount, int minpts, long long N, const int* __restrict__ label,
+                              int* __restrict__ final_label, unsigned* __restrict__ csize, unsigned* __restrict__ cfirst) {
+    const int lane = threadIdx.x & 63;
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (i >= N) return;
+    const PoolSeg sg = segs[seg_of_row[i]];
+    int best;
+    if (ncount[i] >= (unsigned)minpts) {
+        best = label[i];
+    } else {
+        best = 0x7fffffff;
+        const unsigned* row = adj + sg.bit_base + (size_t)(i - sg.row_base) * sg.nw;
+        for (int w = lane; w < sg.nw; w += 64) {
+            unsigned bits = row[w];
+            while (bits) {
+                int b = __ffs(bits) - 1;
+                bits &= bits - 1;
+                long long j = sg.row_base + (long long)w * 32 + b;
+                if (ncount[j] >= (unsigned)minpts) best = label[j] < best ? label[j] : best;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            int t = __shfl_xor(best, o);
+            best = t < best ? t : best;
+        }
+        if (best == 0x7fffffff) best = -1;
+    }
+    if (lane == 0) {
+        final_label[i] = best;
+        if (best >= 0) {
+            atomicAdd(&csize[sg.row_base + best], 1u);
+            atomicMin(&cfirst[sg.row_base + best], (unsigned)(i - sg.row_base));
+        }
+    }
+}
+__global__ void k_pool_pick(const PoolSeg* __restrict__ segs, const int* __restrict__ seg_of_row, long long N,
+                            const unsigned* __restrict__ csize, const unsigned* __restrict__ cfirst,
+                            unsigned long long* __restrict__ best) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N || csize[i] == 0u) return;
+    unsigned long long key = ((unsigned long long)csize[i] << 32) | (unsigned long long)(0xffffffffu - cfirst[i]);
+    atomicMax(&best[seg_of_row[i]], key);
+}
+// mean over the selected rows in index order (np.mean axis 0 = sequential float32 adds, then / n)
+__global__ void k_pool_mean(const float* __restrict__ X, int D, const PoolSeg* __restrict__ segs, int K,
+                            const int* __restrict__ final_label, const unsigned* __restrict__ csize,
+                            const unsigned* __restrict__ cfirst, const unsigned long long* __restrict__ best,
+                            float* __restrict__ out) {
+    const int k = blockIdx.y;
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    const PoolSeg sg = segs[k];
+    float* o = out + (size_t)k * D;
+    if (sg.n == 0) {                                          // graph.py:479-483 -> zeros(1, D)
+        o[d] = 0.f;
+        return;
+    }
+    int want = -2;                                            // -2: take all rows (no cluster)
+    unsigned long long key = best[k];
+    if (key) {
+        unsigned first = 0xffffffffu - (unsigned)(key & 0xffffffffull);
+        want = final_label[sg.row_base + first];
+    }
+    float acc = 0.f;
+    unsigned cnt = 0;
+    for (int r = 0; r < sg.n; ++r) {
+        if (want != -2 && final_label[sg.row_base + r] != want) continue;
+        acc = __fadd_rn(acc, X[(size_t)(sg.row_base + r) * D + d]);
+        ++cnt;
+    }
+    o[d] = cnt > 1 ? __fdiv_rn(acc, (float)cnt) : acc;
+}
+
+__global__ void k_pool_gather_u32(const unsigned* __restrict__ src, const long long* __restrict__ idx, int n,
+                                  unsigned* __restrict__ dst) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) dst[t] = src[idx[t]];
+}
+__global__ void k_seg_rows(const PoolSeg* __restrict__ segs, int* __restrict__ seg_of_row) {
+    const PoolSeg sg = segs[blockIdx.y];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < sg.n; i += gridDim.x * blockDim.x) seg_of_row[sg.row_base + i] = blockIdx.y;
+}
+
+void hmsg_pool(hmsg_ctx* h) {
+    const hmsg_config& c = h->cfg;
+    hipStream_t s = h->stream;
+    HMSG_REQUIRE(h->merged, HMSG_ERR_INVALID, "hmsg_pool_instances: run hmsg_merge_instances first");
+    const int K = (int)h->inst.off.size() - 1;
+    const int D = c.feat_dim;
+    h->inst_feats.alloc((size_t)std::max(K, 1) * D);
+    if (K == 0) {
+        h->pooled = true;
+        return;
+    }
+    CloudOps ops;
+    ops.s = s;
+    // (a) voxel_down_sample(voxel_size) of every instance (graph.py:456)
+    std::vector<SegDesc> segs(K);
+    for (int k = 0; k < K; ++k) {
+        segs[k].pt_base = h->inst.off[k];
+        segs[k].n = (int)(h->inst.off[k + 1] - h->inst.off[k]);
+    }
+    ops.bounds(h->inst.pts.p, segs);
+    DevBuf<double> ds;
+    ds.alloc((size_t)std::max<long long>(h->inst.total, 1) * 3);
+    std::vector<int> dn;
+    const long long P = ops.voxel_down_sample(h->inst.pts.p, segs, c.voxel_size, ds.p, dn);
+    // (b) nearest map voxel, dist <= 0.8
+    DevBuf<int> idx;
+    DevBuf<unsigned> valid, pos;
+    idx.alloc((size_t)std::max<long long>(P, 1));
+    valid.alloc((size_t)std::max<long long>(P, 1));
+    pos.alloc((size_t)std::max<long long>(P, 1));
+    if (P) {
+        hipLaunchKernelGGL(k_pool_nn, dim3(cdiv((size_t)P, 256)), dim3(256), 0, s, (const double*)ds.p, P, h->grid,
+                           (const unsigned long long*)h->bitmap.p, (const unsigned*)h->rank.p, (const double*)h->pts.p,
+                           c.pool_max_dist, idx.p, valid.p);
+        HMSG_CHECK_LAUNCH();
+    }
+    unsigned long long R = 0;   // total valid rows
+    if (P) hmsg_scan_u32(valid.p, pos.p, (size_t)P, s, ops.scan_tmp, &R);
+    // rows per instance = pos at the instance boundaries
+    std::vector<long long> pstart(K + 1, 0);
+    for (int k = 0; k < K; ++k) pstart[k + 1] = pstart[k] + dn[k];
+    std::vector<unsigned> hpos(K + 1, (unsigned)R);
+    {
+        DevBuf<long long> d_i;
+        DevBuf<unsigned> d_o;
+        std::vector<long long> q;
+        std::vector<int> which;
+        for (int k = 0; k < K; ++k)
+            if (pstart[k] < P) {
+                q.push_back(pstart[k]);
+                which.push_back(k);
+            }
+        if (!q.empty()) {
+            std::vector<unsigned> tmp(q.size());
+            d_i.alloc(q.size());
+            d_o.alloc(q.size());
+            HIP_TRY(hipMemcpyAsync(d_i.p, q.data(), q.size() * 8, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_pool_gather_u32, dim3(cdiv(q.size(), 256)), dim3(256), 0, s, (const unsigned*)pos.p,
+                               (const long long*)d_i.p, (int)q.size(), d_o.p);
+            HIP_TRY(hipMemcpyAsync(tmp.data(), d_o.p, q.size() * 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            for (size_t t = 0; t < q.size(); ++t) hpos[which[t]] = tmp[t];
+        }
+        for (int k = K - 1; k >= 0; --k)
+            if (pstart[k] >= P) hpos[k] = hpos[k + 1];
+    }
+    std::vector<PoolSeg> ps(K);
+    long long bitw = 0, tiles = 0;
+    int maxn = 0;
+    for (int k = 0; k < K; ++k) {
+        PoolSeg& g = ps[k];
+        g.row_base = hpos[k];
+        g.n = (int)(hpos[k + 1] - hpos[k]);
+        g.nw = (g.n + 31) / 32;
+        g.nt = g.nw;
+        g.bit_base = bitw;
+        g.tile_base = tiles;
+        g.pad = 0;
+        bitw += (long long)g.n * g.nw;
+        tiles += (long long)g.nt * g.nt;
+        maxn = std::max(maxn, g.n);
+    }
+    DevBuf<PoolSeg> d_ps;
+    d_ps.alloc(K);
+    HIP_TRY(hipMemcpyAsync(d_ps.p, ps.data(), (size_t)K * sizeof(PoolSeg), hipMemcpyHostToDevice, s));
+    DevBuf<float> X, Xn;
+    DevBuf<unsigned> adj, ncount, csize, cfirst;
+    DevBuf<int> label, flabel, seg_of_row, d_changed;
+    DevBuf<unsigned long long> best;
+    const size_t Rn = (size_t)std::max<unsigned long long>(R, 1);
+    X.alloc(Rn * D);
+    Xn.alloc(Rn * D);
+    adj.alloc((size_t)std::max<long long>(bitw, 1));
+    ncount.alloc(Rn);
+    csize.alloc(Rn);
+    cfirst.alloc(Rn);
+    label.alloc(Rn);
+    flabel.alloc(Rn);
+    seg_of_row.alloc(Rn);
+    d_changed.alloc(1);
+    best.alloc(K);
+    adj.zero(s);
+    ncount.zero(s);
+    csize.zero(s);
+    HIP_TRY(hipMemsetAsync(cfirst.p, 0xff, Rn * 4, s));
+    best.zero(s);
+    if (R) {
+        hipLaunchKernelGGL(k_pool_gather, dim3(cdiv((size_t)P * 64, 256)), dim3(256), 0, s, (const int*)idx.p,
+                           (const unsigned*)valid.p, (const unsigned*)pos.p, P, (const float*)h->feats.p, D, X.p, Xn.p);
+        hipLaunchKernelGGL(k_seg_rows, dim3(std::max(1u, std::min(cdiv(maxn, 256), 256u)), K), dim3(256), 0, s,
+                           (const PoolSeg*)d_ps.p, seg_of_row.p);
+        hipLaunchKernelGGL(k_pool_gram, dim3(cdiv((size_t)tiles, 4)), dim3(256), 0, s, (const float*)Xn.p, D,
+                           (const PoolSeg*)d_ps.p, K, tiles, (float)c.feat_dbscan_eps, adj.p, ncount.p);
+        hipLaunchKernelGGL(k_pool_init, dim3(cdiv((size_t)R, 256)), dim3(256), 0, s, (const unsigned*)ncount.p, (long long)R,
+                           c.feat_dbscan_min, label.p, (const PoolSeg*)d_ps.p, (const int*)seg_of_row.p);
+        HMSG_CHECK_LAUNCH();
+        for (int it = 0; it < 100000; ++it) {
+            HIP_TRY(hipMemsetAsync(d_changed.p, 0, 4, s));
+            for (int rep = 0; rep < 4; ++rep)
+                hipLaunchKernelGGL(k_pool_prop, dim3(cdiv((size_t)R * 64, 256)), dim3(256), 0, s, (const unsigned*)adj.p,
+                                   (const PoolSeg*)d_ps.p, (const int*)seg_of_row.p, (const unsigned*)ncount.p,
+                                   c.feat_dbscan_min, (long long)R, label.p, d_changed.p);
+            HMSG_CHECK_LAUNCH();
+            int ch = 0;
+            HIP_TRY(hipMemcpyAsync(&ch, d_changed.p, 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (!ch) break;
+        }
+        hipLaunchKernelGGL(k_pool_border, dim3(cdiv((size_t)R * 64, 256)), dim3(256), 0, s, (const unsigned*)adj.p,
+                           (const PoolSeg*)d_ps.p, (const int*)seg_of_row.p, (const unsigned*)ncount.p, c.feat_dbscan_min,
+                           (long long)R, (const int*)label.p, flabel.p, csize.p, cfirst.p);
+        hipLaunchKernelGGL(k_pool_pick, dim3(cdiv((size_t)R, 256)), dim3(256), 0, s, (const PoolSeg*)d_ps.p,
+                           (const int*)seg_of_row.p, (long long)R, (const unsigned*)csize.p, (const unsigned*)cfirst.p, best.p);
+        HMSG_CHECK_LAUNCH();
+    }
+    hmsg_dump("pool_ds", ds.p, (size_t)P * 24, s);
+    hmsg_dump("pool_idx", idx.p, (size_t)P * 4, s);
+    hmsg_dump("pool_valid", valid.p, (size_t)P * 4, s);
+    hmsg_dump("pool_ncount", ncount.p, (size_t)R * 4, s);
+    hmsg_dump("pool_flabel", flabel.p, (size_t)R * 4, s);
+    hmsg_dump("pool_label", label.p, (size_t)R * 4, s);
+    hmsg_dump("pool_segs", d_ps.p, (size_t)K * sizeof(PoolSeg), s);
+    hipLaunchKernelGGL(k_pool_mean, dim3(cdiv(D, 64), K), dim3(64), 0, s, (const float*)X.p, D, (const PoolSeg*)d_ps.p, K,
+                       (const int*)flabel.p, (const unsigned*)csize.p, (const unsigned*)cfirst.p,
+                       (const unsigned long long*)best.p, h->inst_feats.p);
+    HMSG_CHECK_LAUNCH();
+    HIP_TRY(hipStreamSynchronize(s));
+    h->pooled = true;
+}

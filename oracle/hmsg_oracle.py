@@ -151,7 +151,7 @@ def faiss_flat_l2_nn_sqdist(queries: np.ndarray, base: np.ndarray) -> np.ndarray
 
 NN_TIE = "scipy"   # "scipy": cKDTree's own (arbitrary) choice on exact distance ties, as the reference runs;
                    # "lowest": canonical rule of the HIP path -- lowest index among candidates whose distance is
-                   # within 5e-13 (relative) of the minimum.  Ties are structural (adjacent pixels at equal depth
+                   # within 5e-10 (relative) of the minimum.  Ties are structural (adjacent pixels at equal depth
                    # are equidistant from the pixel between them), so a rule is needed for reproducibility.
 
 
@@ -163,7 +163,7 @@ def nn_query(tree: cKDTree, pts: np.ndarray):
     d, i = tree.query(pts, k=k, workers=-1)
     if k == 1:
         return d, i
-    tied = d <= d[:, :1] * (1 + 5e-13)
+    tied = d <= d[:, :1] * (1 + 5e-10)
     cand = np.where(tied, i, np.iinfo(np.int64).max)
     best = cand.min(axis=1)
     return d[:, 0], best

@@ -22,6 +22,9 @@ using std::max;
 using std::min;
 
 #define HMSG_EMU_BUILD 1
+#ifndef __HIP_MEMORY_SCOPE_AGENT
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#endif
 #define __global__
 #define __device__
 #define __host__

@@ -102,3 +102,38 @@ def _check_fuse(sc, frames, S, cfg, ref_pts, ref_cols, check_masks):
     assert (d > 1e-6).mean() < 1e-3, (d > 1e-6).mean()
     assert d.max() <= 2.0 ** -10
     return ref_feats, n_tie
+
+
+def check_merge_pool(sc, frames, cfg, ref_pts, ref_feats):
+    """A6 + A7, stage-wise: the oracle merges the library's own 3-D masks (already checked against the
+    oracle's to 1e-9) and pools the library's own instances; instance point sets must agree exactly in
+    count/order and to 1e-9 in position, pooled features to 1e-5 (the north-star tolerance)."""
+    O.NN_TIE = "lowest"
+    try:
+        frames_pcd = []
+        for i in range(len(frames)):
+            frames_pcd.append([(p, np.zeros_like(p)) for p in sc.frame_masks3d(i)])
+        vs = cfg["voxel_size"]
+        if cfg.get("merge_type", "sequential") == "hierarchical":
+            ref = O.hierarchical_merge(frames_pcd, cfg["init_overlap_thresh"], cfg["overlap_thresh_factor"], vs,
+                                       cfg["iou_thresh"])
+        else:
+            ref = O.seq_merge(frames_pcd, cfg["init_overlap_thresh"], vs, cfg["iou_thresh"])
+        ref = [m for m in ref if m[0].shape[0] >= 10]
+        sc.merge_instances()
+        got = sc.instances()
+        assert len(got) == len(ref), (len(got), len(ref))
+        for k, (g, (r, _)) in enumerate(zip(got, ref)):
+            assert g.shape == r.shape, (k, g.shape, r.shape)
+            np.testing.assert_allclose(g, r, rtol=0, atol=1e-9)
+        sc.pool_instances()
+        feats = sc.instance_feats()
+        tree = cKDTree(ref_pts)
+        map_feats = sc.map_feats()
+        ref_pool = O.pool_instances([(g, np.zeros_like(g)) for g in got], ref_pts, tree, map_feats, vs, cfg["feat_dim"])
+        ref_pool = np.stack([np.asarray(f, np.float32).reshape(-1) for f in ref_pool]) if ref_pool else np.zeros((0, cfg["feat_dim"]))
+        assert feats.shape == ref_pool.shape
+        np.testing.assert_allclose(feats, ref_pool, rtol=0, atol=1e-5)
+        return got, feats
+    finally:
+        O.NN_TIE = "scipy"

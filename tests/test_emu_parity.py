@@ -28,3 +28,26 @@ def test_map_and_fuse_small(L):
     assert 0 < ref_pts.shape[0] < sc.map_size_unfiltered()
     PC.check_fuse(sc, frames, S, cfg, ref_pts, ref_cols)
     sc.close()
+
+
+@pytest.mark.parametrize("merge_type", ["sequential", "hierarchical"])
+def test_merge_and_pool_small(L, merge_type):
+    z = GI.load("build_hier")
+    frames = GI.unpack_frames(z)[:12]
+    cfg = GI.unpack_cfg(z)
+    cfg["outlier_nb"] = 300
+    cfg["merge_type"] = merge_type
+    sc = PC.make_scene(L, frames, dict(feat_dim=cfg["feat_dim"], outlier_nb_points=300,
+                                       merge_type=1 if merge_type == "hierarchical" else 0, feat_dbscan_min=20))
+    S, ref_pts, ref_cols = PC.check_map(sc, frames, cfg)
+    ref_feats, _ = PC.check_fuse(sc, frames, S, cfg, ref_pts, ref_cols, check_masks=False)
+    import oracle.hmsg_oracle as O
+    # smaller min_samples so the cosine DBSCAN actually forms clusters on this tiny scene
+    orig = O.feats_denoise_dbscan
+    O.feats_denoise_dbscan = lambda f, eps=0.01, min_points=100: orig(f, eps=0.01, min_points=20)
+    try:
+        got, feats = PC.check_merge_pool(sc, frames, cfg, ref_pts, ref_feats)
+    finally:
+        O.feats_denoise_dbscan = orig
+    assert len(got) > 3
+    sc.close()
