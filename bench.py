@@ -1,0 +1,274 @@
+#!/usr/bin/env python
+"""Headline benchmark: HMSG build (frames/s) + retrieval (queries/s) on synthetic posed RGB-D.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): one 1000-frame 640x480 scene per GPU, 32 masks/frame, 512-d
+features, build A1..A7 + node table + 1000 hierarchical object queries.  A "step" is one full pass of
+the hot path over that scene (reset -> frames -> map -> fuse -> merge -> pool -> index -> queries) with
+the inputs already resident in HBM.  N>1: one scene per rank (weak scaling), node tables all-gathered
+over RCCL for cross-scene retrieval, every rank answers Q/N of the queries on the global table.
+
+Prints ONE JSON line (rank 0): the driver contract + `roofline` (dominant kernel, HIP-event timed on
+the library's own stream) + `cpu_baseline` (the numpy/scipy/sklearn oracle on a bounded sample of the
+same frames, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def build_scene_inputs(L, spec, device, torch):
+    """Render the synthetic stream into HBM (bench utility kernel) and build the encoder-output tensors."""
+    import ctypes as C
+    from holoagent_amd.synth import SynthScene
+    scn = SynthScene(spec)
+    F, H, W, M, D = spec.n_frames, spec.height, spec.width, spec.n_masks, spec.feat_dim
+    poses = np.zeros((F, 16))
+    room_of = np.zeros(F, np.int32)
+    for i in range(F):
+        T, rid = scn.pose(i)
+        poses[i] = T.reshape(-1)
+        room_of[i] = rid
+    rooms = np.array([np.concatenate([lo, hi]) for lo, hi in scn.rooms])
+    # objects grouped by room (they are generated room by room)
+    obj = np.array([np.concatenate([lo, hi]) for _, lo, hi in scn.objects]).reshape(-1, 6)
+    obj_room = np.array([r for r, _, _ in scn.objects], np.int32)
+    off = np.zeros(len(scn.rooms) + 1, np.int32)
+    for r in obj_room:
+        off[r + 1] += 1
+    off = np.cumsum(off).astype(np.int32)
+    rgb = torch.empty((F, H, W, 3), dtype=torch.uint8, device=device)
+    depth = torch.empty((F, H, W), dtype=torch.int16, device=device)       # raw u16 storage
+    masks = torch.empty((F, M, H, W), dtype=torch.uint8, device=device)
+    ment = np.zeros((F, M), np.int32)
+    K = np.ascontiguousarray(scn.K, np.float64)
+    rc = L.c.hmsg_synth_render(device.index or 0, F, H, W, M, K.ctypes.data, poses.ctypes.data, room_of.ctypes.data,
+                               len(scn.rooms), np.ascontiguousarray(rooms).ctypes.data, len(scn.objects),
+                               np.ascontiguousarray(obj).ctypes.data, off.ctypes.data, spec.depth_noise_mm, spec.seed,
+                               rgb.data_ptr(), depth.data_ptr(), masks.data_ptr(), ment.ctypes.data)
+    assert rc == 0, "hmsg_synth_render failed"
+    rng = np.random.Generator(np.random.PCG64([spec.seed, 424242]))
+    u = scn.entity_feats[ment]                                              # [F, M, D]
+    f_masked = u + spec.feat_noise * rng.standard_normal(u.shape).astype(np.float32)
+    f_crop = u + spec.feat_noise * rng.standard_normal(u.shape).astype(np.float32)
+    f_masked /= np.linalg.norm(f_masked, axis=-1, keepdims=True)
+    f_crop /= np.linalg.norm(f_crop, axis=-1, keepdims=True)
+    f_g = u.mean(axis=1)
+    f_g /= np.linalg.norm(f_g, axis=-1, keepdims=True)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(device)
+    return dict(scene=scn, rgb=rgb, depth=depth, masks=masks, pose=np.ascontiguousarray(poses), K=K,
+                f_g=dev(f_g), f_masked=dev(f_masked), f_crop=dev(f_crop), rooms=rooms, obj_room=obj_room)
+
+
+def assign_rooms(boxes, rooms):
+    """instance -> room by AABB centre (the scene's rooms are given, SURVEY 8c: rooms are an input)."""
+    c = (boxes[:, :3] + boxes[:, 3:]) / 2
+    inside = (c[:, None, :] >= rooms[None, :, :3] - 1e-6) & (c[:, None, :] <= rooms[None, :, 3:] + 1e-6)
+    inside = inside.all(-1)
+    rid = inside.argmax(1)
+    none = ~inside.any(1)
+    if none.any():
+        rc = (rooms[:, :3] + rooms[:, 3:]) / 2
+        rid[none] = np.linalg.norm(c[none, None, :] - rc[None], axis=-1).argmin(1)
+    return rid.astype(np.int32)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=1000)
+    ap.add_argument("--queries", type=int, default=1000)
+    ap.add_argument("--feat-dim", type=int, default=512)
+    ap.add_argument("--topk", type=int, default=5)
+    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU-oracle baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from holoagent_amd._lib import HmsgLib, Scene, NodeIndex
+    from holoagent_amd.synth import SceneSpec
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == max(1, args.gpus) or world == 1, "launch with torch.distributed.run --nproc-per-node N"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    L = HmsgLib()                      # fails loudly without the HIP library
+
+    F, Q, D, k = args.frames, args.queries, args.feat_dim, args.topk
+    spec = SceneSpec(seed=1234 + rank, n_frames=F, feat_dim=D, n_masks=32)
+    inp = build_scene_inputs(L, spec, device, torch)
+    scn = inp["scene"]
+    text, q_ent = scn.text_table(Q)                               # [Q, 2, D] (query, negative)
+    n_rooms = len(scn.rooms)
+    ent_room = np.concatenate([inp["obj_room"], np.repeat(np.arange(n_rooms), 6)])
+    q_rooms = [[int(ent_room[e]), int((ent_room[e] + 1) % n_rooms)] for e in q_ent]   # label-mode room sets
+
+    sc = Scene(lib_=L, device_id=local, height=spec.height, width=spec.width, max_frames=F, max_masks=32, feat_dim=D)
+    sc.set_profiling(True)
+    stage = {}
+
+    def T(name, fn):
+        t0 = time.perf_counter()
+        r = fn()
+        stage[name] = stage.get(name, 0.0) + (time.perf_counter() - t0)
+        return r
+
+    state = {}
+
+    def step():
+        sc.reset()
+        T("add_frames", lambda: sc.add_frames(inp["rgb"], inp["depth"], inp["pose"], inp["K"]))
+        T("finalize_map", sc.finalize_map)
+        T("add_frame_features", lambda: sc.add_frame_features(0, inp["masks"], inp["f_g"], inp["f_masked"], inp["f_crop"]))
+        T("fuse_frames", sc.fuse_frames)
+        T("merge_instances", sc.merge_instances)
+        T("pool_instances", sc.pool_instances)
+
+        def assemble():
+            feats = sc.instance_feats().astype(np.float64)        # embeddings are f64 once stored (object.py:88-89)
+            rooms = assign_rooms(sc.instance_boxes(), inp["rooms"]) if feats.shape[0] else np.zeros(0, np.int32)
+            return feats, rooms
+        feats, rooms = T("assemble_nodes", assemble)
+        state["n_nodes_local"] = feats.shape[0]
+
+        def retrieve():
+            if world > 1:
+                # all-gather of the node tables (counts, then padded payload) -> global table on every rank
+                n_loc = torch.tensor([feats.shape[0]], device=device, dtype=torch.int64)
+                counts = [torch.zeros_like(n_loc) for _ in range(world)]
+                dist.all_gather(counts, n_loc)
+                counts = [int(c.item()) for c in counts]
+                nmax = max(max(counts), 1)
+                pay = torch.zeros((nmax, D + 1), device=device, dtype=torch.float64)
+                if feats.shape[0]:
+                    pay[: feats.shape[0], :D] = torch.from_numpy(feats).to(device)
+                    pay[: feats.shape[0], D] = torch.from_numpy((rooms + rank * n_rooms).astype(np.float64)).to(device)
+                allp = [torch.empty_like(pay) for _ in range(world)]
+                dist.all_gather(allp, pay)
+                tab = torch.cat([allp[r][: counts[r]] for r in range(world)]).cpu().numpy()
+                g_feats, g_rooms = np.ascontiguousarray(tab[:, :D]), tab[:, D].astype(np.int32)
+                qs = range(rank, Q, world)                       # this rank's share of the queries
+                rl = [[r + rank * n_rooms for r in q_rooms[q]] for q in qs]
+                tq = np.ascontiguousarray(text[list(qs)])
+            else:
+                g_feats, g_rooms, rl, tq = feats, rooms, q_rooms, text
+            if g_feats.shape[0] == 0:
+                return None
+            ix = NodeIndex(g_feats, g_rooms, device_id=local, lib_=L)
+            out = ix.query_objects(tq, np.zeros(len(rl), np.int32), rl, k)
+            ix.close()
+            return out
+        state["last"] = T("retrieval", retrieve)
+
+    for _ in range(args.warmup):
+        step()
+    stage.clear()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    prof = sc.profile()                                           # events of the LAST timed step
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    steps = max(args.steps, 1)
+    fps = world * F * steps / dt
+    retr_s = stage.get("retrieval", 0.0) / steps
+    qps = Q / retr_s if retr_s > 0 else None
+
+    # ---- roofline of the dominant kernel (algorithmic bytes per launch, DESIGN.md section "Kernels")
+    HW = spec.height * spec.width
+    M = spec.n_masks
+    V = sc.map_size()
+    per_frame_bytes = {
+        "k_nn_stamp": HW * (2 + 4 + 4) + 128,                     # depth in, NN index out, stamp atomic
+        "k_bitset": HW * (M + 8),                                 # M mask bytes in, one u64 out per pixel
+        "k_accum": HW * (2 + 3),                                  # depth + rgb in (accumulators: V0*56 B once)
+        "k_mcount": HW * (4 + 8) + HW * 4 * 2,                    # NN + bitset in, ~2 counter updates per pixel
+        "k_fuse": (V * 256) / 64.0,                               # stamps of V voxels per 64-frame launch (+ touched rows)
+    }
+    roof = None
+    if prof:
+        dom = max(prof.items(), key=lambda kv: kv[1][1])
+        name, (launches, total_ms) = dom
+        frames_per_launch = F / launches
+        alg = per_frame_bytes.get(name, 0.0) * frames_per_launch
+        avg_s = total_ms / launches / 1e3
+        achieved = alg / avg_s / 1e9 if avg_s > 0 else 0.0
+        roof = dict(kernel=name, bound="hbm", achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 6), traffic=None, launches=launches,
+                    avg_launch_ms=round(total_ms / launches, 4), algorithmic_bytes_per_launch=int(alg))
+
+    # ---- CPU baseline: the oracle on a bounded sample of the same frames (rank 0, N=1)
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_frames > 0:
+        from oracle import hmsg_oracle as O
+        n = min(args.cpu_frames, F)
+        h_rgb = inp["rgb"][:n].cpu().numpy()
+        h_depth = inp["depth"][:n].cpu().numpy().view(np.uint16)
+        h_masks = inp["masks"][:n].cpu().numpy().astype(bool)
+        fr = [dict(rgb=h_rgb[i], depth=h_depth[i], pose=inp["pose"][i].reshape(4, 4), K=inp["K"], masks=h_masks[i],
+                   f_g=inp["f_g"][i].cpu().numpy()[None], f_masked=inp["f_masked"][i].cpu().numpy(),
+                   f_crop=inp["f_crop"][i].cpu().numpy()) for i in range(n)]
+        cfg = dict(voxel_size=0.05, clip_masked_weight=0.4418, max_mask_distance=10000, init_overlap_thresh=0.75,
+                   overlap_thresh_factor=0.025, iou_thresh=0.05, merge_type="sequential", feat_dim=D)
+        t1 = time.perf_counter()
+        res = O.create_feature_map(fr, cfg)
+        feats = np.stack([np.asarray(f, np.float64).reshape(-1) for f in res["mask_feats"]]) if res["mask_feats"] else None
+        if feats is not None:
+            for q in range(min(Q, 100)):
+                O.query_object(text[q], 0, feats, k)
+        t_cpu = time.perf_counter() - t1
+        cpu = dict(value=round(n / t_cpu, 4), unit="frames/s", cores=os.cpu_count(), kind="port",
+                   sample="oracle create_feature_map + 100 queries on the first %d of the %d frames (640x480, D=%d, M=32)" % (n, F, D),
+                   seconds=round(t_cpu, 2))
+
+    if rank == 0:
+        last = state.get("last")
+        out = {
+            "metric": "HMSG frames/sec (build A1-A7 + node table + %d-query retrieval per %d-frame scene)" % (Q, F),
+            "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64 geometry / f32 features", "data": "synthetic",
+            "config": {"workload": "configs[1]: %d-frame single scene per GPU, 640x480 RGB-D, 32 masks/frame, %d-d features, "
+                                   "HMSG build + %d-query retrieval" % (F, D, Q),
+                       "frames": F, "queries": Q, "feat_dim": D, "masks": M, "parallelism": "scene-per-gpu x%d" % world},
+            "queries_per_sec": round(qps, 1) if qps else None,
+            "stage_ms_per_step": {k_: round(v / steps * 1e3, 2) for k_, v in stage.items()},
+            "map_voxels": V, "nodes_local": state.get("n_nodes_local"),
+            "kernels_ms_last_step": {k_: round(v[1], 3) for k_, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
+            "roofline": roof, "cpu_baseline": cpu,
+            "speedup_vs_cpu": round(fps / cpu["value"], 1) if cpu else None,
+        }
+        print(json.dumps(out))
+    sc.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

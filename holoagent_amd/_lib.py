@@ -40,6 +40,12 @@ _SIGS = {
     "hmsg_destroy": (None, [_P]),
     "hmsg_last_error": (C.c_char_p, [_P]),
     "hmsg_version": (C.c_char_p, []),
+    "hmsg_reset": (C.c_int, [_P]),
+    "hmsg_set_profiling": (C.c_int, [_P, C.c_int32]),
+    "hmsg_profile_count": (C.c_int32, [_P]),
+    "hmsg_profile_entry": (C.c_int, [_P, C.c_int32, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "hmsg_synth_render": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, _P,
+                                    C.c_int32, _P, _P, C.c_double, C.c_uint64, _P, _P, _P, _P]),
     "hmsg_add_frames": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P]),
     "hmsg_finalize_map": (C.c_int, [_P]),
     "hmsg_map_size": (C.c_int64, [_P]),
@@ -56,6 +62,7 @@ _SIGS = {
     "hmsg_num_instances": (C.c_int64, [_P]),
     "hmsg_get_instance_sizes": (C.c_int, [_P, _P]),
     "hmsg_get_instance_points": (C.c_int, [_P, _P]),
+    "hmsg_get_instance_boxes": (C.c_int, [_P, _P]),
     "hmsg_pool_instances": (C.c_int, [_P]),
     "hmsg_get_instance_feats": (C.c_int, [_P, _P]),
     "hmsg_index_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _P, C.c_int32, _P, C.POINTER(_P)]),
@@ -147,6 +154,23 @@ class Scene:
     def HW(self):
         return self.cfg.height * self.cfg.width
 
+    def reset(self):
+        self._ck(self.L.c.hmsg_reset(self.h))
+
+    def set_profiling(self, on: bool):
+        self._ck(self.L.c.hmsg_set_profiling(self.h, int(on)))
+
+    def profile(self):
+        """{kernel name: (launches, total_ms)} from the HIP-event brackets recorded since the last reset."""
+        out = {}
+        for i in range(int(self.L.c.hmsg_profile_count(self.h))):
+            name = C.create_string_buffer(64)
+            n = C.c_int64()
+            ms = C.c_double()
+            self._ck(self.L.c.hmsg_profile_entry(self.h, i, name, C.byref(n), C.byref(ms)))
+            out[name.value.decode()] = (int(n.value), float(ms.value))
+        return out
+
     # ---- build
     def add_frames(self, rgb, depth, pose, K):
         n = int(depth.shape[0])
@@ -214,6 +238,16 @@ class Scene:
             self._ck(self.L.c.hmsg_get_instance_points(self.h, _ptr(pts)))
         off = np.concatenate([[0], np.cumsum(sizes)])
         return [pts[off[i]:off[i + 1]] for i in range(n)]
+
+    def num_instances(self):
+        return int(self.L.c.hmsg_num_instances(self.h))
+
+    def instance_boxes(self):
+        n = self.num_instances()
+        out = np.empty((n, 6), np.float64)
+        if n:
+            self._ck(self.L.c.hmsg_get_instance_boxes(self.h, _ptr(out)))
+        return out
 
     def pool_instances(self):
         self._ck(self.L.c.hmsg_pool_instances(self.h))

@@ -112,6 +112,69 @@ void hmsg_destroy(hmsg_t* h) {
 
 const char* hmsg_last_error(const hmsg_t* h) { return h ? h->err.c_str() : "null handle"; }
 
+int hmsg_reset(hmsg_t* h) {
+    if (!h) return HMSG_ERR_INVALID;
+    return guard(h, [&] {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        h->n_frames = h->n_feat_frames = h->n_fused = 0;
+        h->M = 0;
+        h->have_K = false;
+        h->map_ready = h->feats_final = h->merged = h->pooled = false;
+        h->V = h->V0 = 0;
+        h->masks3d.off.clear();
+        h->masks3d.total = 0;
+        h->inst.off.clear();
+        h->inst.total = 0;
+        h->prof.clear();
+    });
+}
+
+int hmsg_set_profiling(hmsg_t* h, int32_t on) {
+    if (!h) return HMSG_ERR_INVALID;
+    h->prof.enabled = on != 0;
+    return HMSG_OK;
+}
+
+static void prof_aggregate(hmsg_ctx* h, std::vector<std::string>& names, std::vector<long long>& cnt, std::vector<double>& ms) {
+    (void)hipStreamSynchronize(h->stream);
+    for (auto& e : h->prof.ev) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, e.a, e.b) != hipSuccess) continue;
+        size_t k = 0;
+        for (; k < names.size(); ++k)
+            if (names[k] == e.name) break;
+        if (k == names.size()) {
+            names.push_back(e.name);
+            cnt.push_back(0);
+            ms.push_back(0.0);
+        }
+        cnt[k]++;
+        ms[k] += t;
+    }
+}
+
+int32_t hmsg_profile_count(hmsg_t* h) {
+    if (!h) return 0;
+    std::vector<std::string> n;
+    std::vector<long long> c;
+    std::vector<double> m;
+    prof_aggregate(h, n, c, m);
+    return (int32_t)n.size();
+}
+
+int hmsg_profile_entry(hmsg_t* h, int32_t i, char* name, int64_t* launches, double* total_ms) {
+    if (!h || !name || !launches || !total_ms) return HMSG_ERR_INVALID;
+    std::vector<std::string> n;
+    std::vector<long long> c;
+    std::vector<double> m;
+    prof_aggregate(h, n, c, m);
+    if (i < 0 || i >= (int32_t)n.size()) return HMSG_ERR_INVALID;
+    snprintf(name, 64, "%s", n[i].c_str());
+    *launches = c[i];
+    *total_ms = m[i];
+    return HMSG_OK;
+}
+
 int hmsg_add_frames(hmsg_t* h, int32_t n, const uint8_t* rgb, const uint16_t* depth, const double* pose, const double* K) {
     if (!h) return HMSG_ERR_INVALID;
     return guard(h, [&] {
@@ -288,6 +351,15 @@ int hmsg_get_instance_points(const hmsg_t* hc, double* xyz) {
     return guard(h, [&] {
         HMSG_REQUIRE(h->merged && xyz, HMSG_ERR_INVALID, "hmsg_merge_instances not run");
         if (h->inst.total) HIP_TRY(hipMemcpy(xyz, h->inst.pts.p, (size_t)h->inst.total * 24, hipMemcpyDeviceToHost));
+    });
+}
+
+int hmsg_get_instance_boxes(const hmsg_t* hc, double* boxes) {
+    hmsg_ctx* h = const_cast<hmsg_ctx*>(hc);
+    if (!h) return HMSG_ERR_INVALID;
+    return guard(h, [&] {
+        HMSG_REQUIRE(h->merged && boxes, HMSG_ERR_INVALID, "hmsg_merge_instances not run");
+        if (!h->inst.box.empty()) memcpy(boxes, h->inst.box.data(), h->inst.box.size() * 8);
     });
 }
 

@@ -147,10 +147,47 @@ struct MaskCloudSet {            // 3-D masks of all fused frames (generic.py:14
 struct InstanceSet {             // merged instances (graph.py:425-448)
     DevBuf<double> pts;
     std::vector<long long> off;
+    std::vector<double> box;     // [N][6] AABB (min xyz, max xyz)
     long long total = 0;
 };
 
+// live per-kernel timing with HIP events on the handle's own stream (bench.py roofline leg)
+struct ProfEntry {
+    std::string name;
+    hipEvent_t a, b;
+};
+struct Prof {
+    bool enabled = false;
+    std::vector<ProfEntry> ev;
+    void clear() {
+        for (auto& e : ev) {
+            (void)hipEventDestroy(e.a);
+            (void)hipEventDestroy(e.b);
+        }
+        ev.clear();
+    }
+};
+struct ProfScope {
+    Prof* p;
+    hipStream_t s;
+    size_t i = 0;
+    ProfScope(Prof& pr, hipStream_t st, const char* name) : p(pr.enabled ? &pr : nullptr), s(st) {
+        if (!p) return;
+        ProfEntry e;
+        e.name = name;
+        (void)hipEventCreate(&e.a);
+        (void)hipEventCreate(&e.b);
+        (void)hipEventRecord(e.a, s);
+        i = p->ev.size();
+        p->ev.push_back(e);
+    }
+    ~ProfScope() {
+        if (p) (void)hipEventRecord(p->ev[i].b, s);
+    }
+};
+
 struct hmsg_ctx {
+    Prof prof;
     hmsg_config cfg;
     hipStream_t stream = nullptr;
     std::string err;

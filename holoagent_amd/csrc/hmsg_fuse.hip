@@ -452,18 +452,27 @@ void hmsg_fuse(hmsg_ctx* h) {
     for (int fb0 = h->n_fused; fb0 < h->n_feat_frames; fb0 += FB) {
         const int nb = std::min(FB, h->n_feat_frames - fb0);
         stamp.zero(s);
-        hipLaunchKernelGGL(k_nn_stamp, dim3(cdiv(HW * nb, 256)), dim3(256), 0, s, (const unsigned short*)h->depth.p,
-                           (const double*)h->pose.p, h->cam, scale, H, W, fb0, nb, h->grid,
-                           (const unsigned long long*)h->bitmap.p, (const unsigned*)h->rank.p, (const double*)h->pts.p,
-                           h->nn.p, stamp.p);
+        {
+            ProfScope ps(h->prof, s, "k_nn_stamp");
+            hipLaunchKernelGGL(k_nn_stamp, dim3(cdiv(HW * nb, 256)), dim3(256), 0, s, (const unsigned short*)h->depth.p,
+                               (const double*)h->pose.p, h->cam, scale, H, W, fb0, nb, h->grid,
+                               (const unsigned long long*)h->bitmap.p, (const unsigned*)h->rank.p, (const double*)h->pts.p,
+                               h->nn.p, stamp.p);
+        }
         HMSG_CHECK_LAUNCH();
-        dispatch_fuse(h, stamp.p, fb0, nb);
+        {
+            ProfScope ps(h->prof, s, "k_fuse");
+            dispatch_fuse(h, stamp.p, fb0, nb);
+        }
         // ---- 3-D masks, Bm frames at a time
         for (int f0 = fb0; f0 < fb0 + nb; f0 += Bm) {
             const int nfr = std::min(Bm, fb0 + nb - f0);
             const int nmask = nfr * M;
-            hipLaunchKernelGGL(k_mcount, dim3(cdiv(HW * nfr, 256)), dim3(256), 0, s, (const int*)h->nn.p,
-                               (const unsigned long long*)h->bits.p, HW, f0, nfr, V, M, mcount.p);
+            {
+                ProfScope ps(h->prof, s, "k_mcount");
+                hipLaunchKernelGGL(k_mcount, dim3(cdiv(HW * nfr, 256)), dim3(256), 0, s, (const int*)h->nn.p,
+                                   (const unsigned long long*)h->bits.p, HW, f0, nfr, V, M, mcount.p);
+            }
             HMSG_CHECK_LAUNCH();
             HIP_TRY(hipMemsetAsync(d_nwin.p, 0, 4, s));
             hipLaunchKernelGGL(k_winners, dim3(cdiv(HW * nfr, 256)), dim3(256), 0, s, (const int*)h->nn.p,
@@ -581,8 +590,11 @@ void hmsg_bitset_and_fp(hmsg_ctx* h, int first, int n, int M, const unsigned cha
     const size_t HW = (size_t)h->cfg.height * h->cfg.width;
     const int D = h->cfg.feat_dim;
     const size_t chunks = (HW + 15) / 16;
-    hipLaunchKernelGGL(k_bitset, dim3(cdiv(chunks * n, 256)), dim3(256), 0, h->stream, d_masks, M, HW, n, (size_t)M * HW,
-                       h->bits.p + (size_t)first * HW);
+    {
+        ProfScope ps(h->prof, h->stream, "k_bitset");
+        hipLaunchKernelGGL(k_bitset, dim3(cdiv(chunks * n, 256)), dim3(256), 0, h->stream, d_masks, M, HW, n, (size_t)M * HW,
+                           h->bits.p + (size_t)first * HW);
+    }
     HMSG_CHECK_LAUNCH();
     const float wm = (float)h->cfg.clip_masked_weight, wc = (float)(1.0 - h->cfg.clip_masked_weight);
     hipLaunchKernelGGL(k_fp, dim3(n), dim3(256), 0, h->stream, d_fg, d_fm, d_fc, M, D, wm, wc,

@@ -387,9 +387,12 @@ void hmsg_build_map(hmsg_ctx* h) {
     srgb.zero(s);
     sn.zero(s);
     VoxAcc acc{sxyz.p, sxyz.p + V0, sxyz.p + 2 * V0, srgb.p, srgb.p + V0, srgb.p + 2 * V0, sn.p};
-    hipLaunchKernelGGL(k_accum, dim3(nblk), dim3(256), 0, s, (const unsigned short*)h->depth.p,
-                       (const unsigned char*)h->rgb.p, (const double*)h->pose.p, h->cam, scale, H, W, F, g,
-                       (const unsigned long long*)h->bitmap.p, (const unsigned*)h->rank.p, acc);
+    {
+        ProfScope ps(h->prof, s, "k_accum");
+        hipLaunchKernelGGL(k_accum, dim3(nblk), dim3(256), 0, s, (const unsigned short*)h->depth.p,
+                           (const unsigned char*)h->rgb.p, (const double*)h->pose.p, h->cam, scale, H, W, F, g,
+                           (const unsigned long long*)h->bitmap.p, (const unsigned*)h->rank.p, acc);
+    }
     HMSG_CHECK_LAUNCH();
     DevBuf<int> cell;
     cell.alloc(V0 * 3);

@@ -517,8 +517,11 @@ void hmsg_merge(hmsg_ctx* h) {
     long long keep_total = 0;
     std::vector<CatSeg> cat;
     h->inst.off.assign(1, 0);
+    h->inst.box.clear();
     for (auto& k : result) {
         if (k.n < c.min_instance_points) continue;
+        for (int a = 0; a < 3; ++a) h->inst.box.push_back(k.mn[a]);
+        for (int a = 0; a < 3; ++a) h->inst.box.push_back(k.mx[a]);
         cat.push_back(CatSeg{k.off, keep_total, k.n, 0});
         keep_total += k.n;
         h->inst.off.push_back(keep_total);

@@ -1,9 +1,379 @@
+// A12: text-query -> node retrieval over a resident node-embedding table.
+//
+// Reference: Graph.query_hmsg_object (fsr_vln/memory/hmsg/graph/graph.py:3056-3162), and the plain
+// similarity GEMVs of query_floor (:2231-2252) / query_hmsg_room (:3204-3272).
+//
+//   sim = T[C, D] . E[N', D]^T  (float32 text x float64 embeddings -> float64, graph.py:3127)
+//   plain top-k by sim[qid] (descending); with negative prompts: objects whose arg-max class (first max)
+//   is the query class, ordered by descending score; if there is none, the plain top-k (graph.py:3133-3151).
+//   Ties (unspecified in numpy's introsort) are broken by candidate position = room order, then node order.
+//
+// MI355X design: the table stays in HBM as float64; all Q x C text rows are scored against ALL nodes by
+// one f64-MFMA GEMM (v_mfma_f64_16x16x4_f64), then one workgroup per query walks its candidate rooms
+// (CSR room -> nodes) and keeps an exact top-k.
 #include "hmsg_common.h"
-struct hmsg_index { std::string err; };
-extern "C" {
-int hmsg_index_create(int32_t, int32_t, int64_t, const void*, int32_t, const int32_t*, hmsg_index_t** out) { if (out) *out = nullptr; return HMSG_ERR_UNSUPPORTED; }
-void hmsg_index_destroy(hmsg_index_t* ix) { delete ix; }
-const char* hmsg_index_last_error(const hmsg_index_t* ix) { return ix ? ix->err.c_str() : "null index"; }
-int hmsg_query_objects(hmsg_index_t*, int32_t, int32_t, const float*, const int32_t*, const int32_t*, const int32_t*, int32_t, int32_t, int32_t*, int32_t*, double*) { return HMSG_ERR_UNSUPPORTED; }
-int hmsg_similarity(hmsg_index_t*, int32_t, const float*, double*) { return HMSG_ERR_UNSUPPORTED; }
+
+#include <algorithm>
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+struct hmsg_index {
+    int device = 0;
+    int D = 0;
+    long long N = 0;
+    int n_rooms = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    DevBuf<double> E;            // [N][D]
+    DevBuf<int> room_of;         // [N]
+    DevBuf<int> room_off;        // [n_rooms + 1]   CSR room -> nodes (ascending node index)
+    DevBuf<int> room_nodes;      // [N]
+    std::vector<int> h_room_cnt;
+    DevBuf<double> T64, S;       // scratch: text rows in f64, similarity matrix
+    DevBuf<float> Tf;
+    DevBuf<int> d_qid, d_roff, d_rooms, d_oidx, d_oroom;
+    DevBuf<double> d_oscore;
+};
+
+__global__ void k_f32_to_f64(const float* __restrict__ a, double* __restrict__ b, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) b[i] = (double)a[i];
 }
+
+// S[M][N] = A[M][D] . B[N][D]^T, one wave per 16x16 tile.
+// v_mfma_f64_16x16x4_f64: lane l feeds A[i = l&15][k = l>>4], B[k = l>>4][j = l&15];
+// result reg r of lane l is C[row = (l>>4) + 4r][col = l&15].
+__global__ void __launch_bounds__(256) k_gemm_f64(const double* __restrict__ A, const double* __restrict__ B, int M, long long N,
+                                                  int D, double* __restrict__ S) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long tn = (N + 15) / 16;
+    long long tile = (long long)blockIdx.x * 4 + wv;
+    const long long ntiles = (long long)((M + 15) / 16) * tn;
+    const bool active = tile < ntiles;
+    if (!active) tile = ntiles - 1;
+    const int m0 = (int)(tile / tn) * 16;
+    const long long n0 = (tile % tn) * 16;
+    const int ar = m0 + (lane & 15);
+    const long long br = n0 + (lane & 15);
+    const double* ap = A + (size_t)(ar < M ? ar : M - 1) * D;
+    const double* bp = B + (size_t)(br < N ? br : N - 1) * D;
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    const int kq = lane >> 4;
+    for (int k0 = 0; k0 < D; k0 += 4) {
+        int k = k0 + kq;
+        double a = (k < D && ar < M) ? ap[k] : 0.0;
+        double b = (k < D && br < N) ? bp[k] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    if (!active) return;
+    const long long col = n0 + (lane & 15);
+    for (int r = 0; r < 4; ++r) {
+        int row = m0 + (lane >> 4) + 4 * r;
+        if (row < M && col < N) S[(size_t)row * N + col] = acc[r];
+    }
+}
+
+#define QK_MAX 64
+struct TopK {
+    double s[QK_MAX];
+    int pos[QK_MAX];
+    int node[QK_MAX];
+    int room[QK_MAX];
+    int n;
+};
+// (score desc, candidate position asc)
+__device__ __forceinline__ bool better(double s1, int p1, double s2, int p2) { return s1 > s2 || (s1 == s2 && p1 < p2); }
+
+// One workgroup per query.  Thread-private candidates are reduced through LDS by repeated arg-best
+// selection (k is small), which keeps the result exact and deterministic.
+__global__ void __launch_bounds__(256) k_query_topk(const double* __restrict__ S, long long N, int C, const int* __restrict__ qid,
+                                                    const int* __restrict__ q_room_off, const int* __restrict__ q_rooms,
+                                                    const int* __restrict__ room_off, const int* __restrict__ room_nodes,
+                                                    int n_rooms, int k, int use_neg, int* __restrict__ out_idx,
+                                                    int* __restrict__ out_room, double* __restrict__ out_score) {
+    __shared__ double sh_s[256];
+    __shared__ int sh_p[256];
+    __shared__ int sh_any;
+    __shared__ double last_s[2];
+    __shared__ int last_p[2];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int myq = qid[q];
+    const double* Sq = S + (size_t)q * C * N;
+    if (tid == 0) sh_any = 0;
+    __syncthreads();
+    // pass 0: does any candidate have arg-max class == query class?
+    if (use_neg) {
+        int pos0 = 0;
+        int any = 0;
+        for (int j = q_room_off[q]; j < q_room_off[q + 1]; ++j) {
+            int r = q_rooms[j];
+            if (r < 0 || r >= n_rooms) continue;
+            int b = room_off[r], e = room_off[r + 1];
+            for (int t = b + tid; t < e; t += 256) {
+                int node = room_nodes[t];
+                int cls = 0;
+                double mx = Sq[node];
+                for (int c = 1; c < C; ++c) {
+                    double v = Sq[(size_t)c * N + node];
+                    if (v > mx) {
+                        mx = v;
+                        cls = c;
+                    }
+                }
+                any |= (cls == myq);
+            }
+            pos0 += e - b;
+        }
+        if (any) sh_any = 1;
+    }
+    __syncthreads();
+    const bool filtered = use_neg && sh_any;
+    // k rounds of "best candidate worse than the previous pick"
+    if (tid == 0) {
+        last_s[0] = 1e308;
+        last_p[0] = -1;
+    }
+    __syncthreads();
+    for (int round = 0; round < k; ++round) {
+        const double ls = last_s[0];
+        const int lp = last_p[0];
+        double bs = -1e308;
+        int bp = 0x7fffffff;
+        int pos0 = 0;
+        for (int j = q_room_off[q]; j < q_room_off[q + 1]; ++j) {
+            int r = q_rooms[j];
+            if (r < 0 || r >= n_rooms) continue;
+            int b = room_off[r], e = room_off[r + 1];
+            for (int t = b + tid; t < e; t += 256) {
+                int node = room_nodes[t];
+                int pos = pos0 + (t - b);
+                double sc = Sq[(size_t)myq * N + node];
+                if (filtered) {
+                    int cls = 0;
+                    double mx = Sq[node];
+                    for (int c = 1; c < C; ++c) {
+                        double v = Sq[(size_t)c * N + node];
+                        if (v > mx) {
+                            mx = v;
+                            cls = c;
+                        }
+                    }
+                    if (cls != myq) continue;
+                }
+                // strictly after the previous pick in (score desc, pos asc) order
+                bool after = lp < 0 || sc < ls || (sc == ls && pos > lp);
+                if (after && better(sc, pos, bs, bp)) {
+                    bs = sc;
+                    bp = pos;
+                }
+            }
+            pos0 += e - b;
+        }
+        sh_s[tid] = bs;
+        sh_p[tid] = bp;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o && better(sh_s[tid + o], sh_p[tid + o], sh_s[tid], sh_p[tid])) {
+                sh_s[tid] = sh_s[tid + o];
+                sh_p[tid] = sh_p[tid + o];
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            int pos = sh_p[0];
+            int oi = -1, orr = -1;
+            double os = 0.0;
+            if (pos != 0x7fffffff) {
+                // position -> (room, node)
+                int pos0b = 0;
+                for (int j = q_room_off[q]; j < q_room_off[q + 1]; ++j) {
+                    int r = q_rooms[j];
+                    if (r < 0 || r >= n_rooms) continue;
+                    int cnt = room_off[r + 1] - room_off[r];
+                    if (pos < pos0b + cnt) {
+                        oi = room_nodes[room_off[r] + pos - pos0b];
+                        orr = r;
+                        break;
+                    }
+                    pos0b += cnt;
+                }
+                os = sh_s[0];
+            }
+            out_idx[(size_t)q * k + round] = oi;
+            out_room[(size_t)q * k + round] = orr;
+            out_score[(size_t)q * k + round] = os;
+            last_s[0] = sh_s[0];
+            last_p[0] = pos == 0x7fffffff ? 0x7ffffffe : pos;
+        }
+        __syncthreads();
+    }
+}
+
+namespace {
+template <typename F>
+int iguard(hmsg_index* ix, F&& fn) {
+    try {
+        HIP_TRY(hipSetDevice(ix->device));
+        fn();
+        return HMSG_OK;
+    } catch (const hmsg_error& e) {
+        ix->err = e.msg;
+        return e.code;
+    } catch (const std::exception& e) {
+        ix->err = e.what();
+        return HMSG_ERR_INVALID;
+    }
+}
+bool dev_ptr(const void* p) {
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof(a));
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice;
+}
+void gemm(hmsg_index* ix, const double* A, int M, double* S) {
+    long long tiles = (long long)((M + 15) / 16) * ((ix->N + 15) / 16);
+    hipLaunchKernelGGL(k_gemm_f64, dim3(cdiv((size_t)tiles, 4)), dim3(256), 0, ix->stream, A, (const double*)ix->E.p, M, ix->N,
+                       ix->D, S);
+    HMSG_CHECK_LAUNCH();
+}
+void text_to_f64(hmsg_index* ix, const float* T, size_t n) {
+    ix->T64.ensure(n);
+    const float* src = T;
+    if (!dev_ptr(T)) {
+        ix->Tf.ensure(n);
+        HIP_TRY(hipMemcpyAsync(ix->Tf.p, T, n * 4, hipMemcpyHostToDevice, ix->stream));
+        src = ix->Tf.p;
+    }
+    hipLaunchKernelGGL(k_f32_to_f64, dim3(cdiv(n, 256)), dim3(256), 0, ix->stream, src, ix->T64.p, n);
+    HMSG_CHECK_LAUNCH();
+}
+}  // namespace
+
+extern "C" {
+
+int hmsg_index_create(int32_t device_id, int32_t dim, int64_t n, const void* emb, int32_t emb_is_f64, const int32_t* room_of_node,
+                      hmsg_index_t** out) {
+    if (!out) return HMSG_ERR_INVALID;
+    *out = nullptr;
+    if (dim <= 0 || n <= 0 || !emb || !room_of_node) return HMSG_ERR_INVALID;
+    hmsg_index* ix = new hmsg_index();
+    ix->device = device_id;
+    ix->D = dim;
+    ix->N = n;
+    int rc = iguard(ix, [&] {
+        HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+        ix->E.alloc((size_t)n * dim);
+        const size_t cnt = (size_t)n * dim;
+        if (emb_is_f64) {
+            HIP_TRY(hipMemcpyAsync(ix->E.p, emb, cnt * 8, dev_ptr(emb) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ix->stream));
+        } else {
+            DevBuf<float> tmp;
+            tmp.alloc(cnt);
+            HIP_TRY(hipMemcpyAsync(tmp.p, emb, cnt * 4, dev_ptr(emb) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ix->stream));
+            hipLaunchKernelGGL(k_f32_to_f64, dim3(cdiv(cnt, 256)), dim3(256), 0, ix->stream, (const float*)tmp.p, ix->E.p, cnt);
+            HMSG_CHECK_LAUNCH();
+            HIP_TRY(hipStreamSynchronize(ix->stream));
+        }
+        std::vector<int> rooms((size_t)n);
+        if (dev_ptr(room_of_node)) {
+            HIP_TRY(hipMemcpy(rooms.data(), room_of_node, (size_t)n * 4, hipMemcpyDeviceToHost));
+        } else {
+            memcpy(rooms.data(), room_of_node, (size_t)n * 4);
+        }
+        int nr = 0;
+        for (int r : rooms) {
+            HMSG_REQUIRE(r >= 0, HMSG_ERR_INVALID, "negative room id");
+            nr = std::max(nr, r + 1);
+        }
+        ix->n_rooms = nr;
+        std::vector<int> off(nr + 1, 0), nodes((size_t)n);
+        for (int r : rooms) off[r + 1]++;
+        for (int r = 0; r < nr; ++r) off[r + 1] += off[r];
+        std::vector<int> cur(off.begin(), off.end() - 1);
+        for (long long i = 0; i < n; ++i) nodes[cur[rooms[i]]++] = (int)i;
+        ix->room_of.alloc((size_t)n);
+        ix->room_off.alloc(nr + 1);
+        ix->room_nodes.alloc((size_t)n);
+        HIP_TRY(hipMemcpyAsync(ix->room_of.p, rooms.data(), (size_t)n * 4, hipMemcpyHostToDevice, ix->stream));
+        HIP_TRY(hipMemcpyAsync(ix->room_off.p, off.data(), (size_t)(nr + 1) * 4, hipMemcpyHostToDevice, ix->stream));
+        HIP_TRY(hipMemcpyAsync(ix->room_nodes.p, nodes.data(), (size_t)n * 4, hipMemcpyHostToDevice, ix->stream));
+        HIP_TRY(hipStreamSynchronize(ix->stream));
+    });
+    if (rc != HMSG_OK) {
+        fprintf(stderr, "hmsg_index_create: %s\n", ix->err.c_str());
+        delete ix;
+        return rc;
+    }
+    *out = ix;
+    return HMSG_OK;
+}
+
+void hmsg_index_destroy(hmsg_index_t* ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    if (ix->stream) {
+        (void)hipStreamSynchronize(ix->stream);
+        (void)hipStreamDestroy(ix->stream);
+    }
+    delete ix;
+}
+
+const char* hmsg_index_last_error(const hmsg_index_t* ix) { return ix ? ix->err.c_str() : "null index"; }
+
+int hmsg_query_objects(hmsg_index_t* ix, int32_t Q, int32_t C, const float* T, const int32_t* qid, const int32_t* room_off,
+                       const int32_t* rooms, int32_t k, int32_t use_negatives, int32_t* out_idx, int32_t* out_room,
+                       double* out_score) {
+    if (!ix) return HMSG_ERR_INVALID;
+    return iguard(ix, [&] {
+        HMSG_REQUIRE(Q >= 0 && C >= 1 && T && qid && room_off && k >= 1 && out_idx && out_room && out_score, HMSG_ERR_INVALID,
+                     "hmsg_query_objects: bad argument");
+        if (Q == 0) return;
+        const size_t nT = (size_t)Q * C * ix->D;
+        text_to_f64(ix, T, nT);
+        ix->S.ensure((size_t)Q * C * ix->N);
+        gemm(ix, ix->T64.p, Q * C, ix->S.p);
+        std::vector<int> hoff(Q + 1);
+        if (dev_ptr(room_off)) {
+            HIP_TRY(hipMemcpy(hoff.data(), room_off, (size_t)(Q + 1) * 4, hipMemcpyDeviceToHost));
+        } else {
+            memcpy(hoff.data(), room_off, (size_t)(Q + 1) * 4);
+        }
+        const int nr = hoff[Q];
+        HMSG_REQUIRE(nr == 0 || rooms, HMSG_ERR_INVALID, "rooms list missing");
+        ix->d_qid.ensure(Q);
+        ix->d_roff.ensure(Q + 1);
+        ix->d_rooms.ensure(std::max(nr, 1));
+        ix->d_oidx.ensure((size_t)Q * k);
+        ix->d_oroom.ensure((size_t)Q * k);
+        ix->d_oscore.ensure((size_t)Q * k);
+        HIP_TRY(hipMemcpyAsync(ix->d_qid.p, qid, (size_t)Q * 4, dev_ptr(qid) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ix->stream));
+        HIP_TRY(hipMemcpyAsync(ix->d_roff.p, hoff.data(), (size_t)(Q + 1) * 4, hipMemcpyHostToDevice, ix->stream));
+        if (nr) HIP_TRY(hipMemcpyAsync(ix->d_rooms.p, rooms, (size_t)nr * 4, dev_ptr(rooms) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ix->stream));
+        hipLaunchKernelGGL(k_query_topk, dim3(Q), dim3(256), 0, ix->stream, (const double*)ix->S.p, ix->N, C, (const int*)ix->d_qid.p,
+                           (const int*)ix->d_roff.p, (const int*)ix->d_rooms.p, (const int*)ix->room_off.p,
+                           (const int*)ix->room_nodes.p, ix->n_rooms, k, use_negatives, ix->d_oidx.p, ix->d_oroom.p, ix->d_oscore.p);
+        HMSG_CHECK_LAUNCH();
+        HIP_TRY(hipMemcpyAsync(out_idx, ix->d_oidx.p, (size_t)Q * k * 4, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(hipMemcpyAsync(out_room, ix->d_oroom.p, (size_t)Q * k * 4, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(hipMemcpyAsync(out_score, ix->d_oscore.p, (size_t)Q * k * 8, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(hipStreamSynchronize(ix->stream));
+    });
+}
+
+int hmsg_similarity(hmsg_index_t* ix, int32_t Q, const float* T, double* S) {
+    if (!ix) return HMSG_ERR_INVALID;
+    return iguard(ix, [&] {
+        HMSG_REQUIRE(Q >= 0 && T && S, HMSG_ERR_INVALID, "hmsg_similarity: bad argument");
+        if (Q == 0) return;
+        text_to_f64(ix, T, (size_t)Q * ix->D);
+        ix->S.ensure((size_t)Q * ix->N);
+        gemm(ix, ix->T64.p, Q, ix->S.p);
+        HIP_TRY(hipMemcpyAsync(S, ix->S.p, (size_t)Q * ix->N * 8, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(hipStreamSynchronize(ix->stream));
+    });
+}
+
+}  // extern "C"

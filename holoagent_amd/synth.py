@@ -35,6 +35,7 @@ class SceneSpec:
     cam_height: float = 1.5
     depth_cut: float = 10.0
     feat_noise: float = 0.02
+    depth_noise_mm: float = 1.5      # sensor noise (std, mm) added before the u16 quantisation
 
 
 class SynthScene:
@@ -141,7 +142,8 @@ class SynthScene:
             hit = (tn < tf) & (tn > 0.05) & (tn < depth)
             depth = np.where(hit, tn, depth)
             ent = np.where(hit, oid, ent)
-        depth_mm = np.rint(depth * 1000.0)
+        rng_d = np.random.Generator(np.random.PCG64([self._rng_seed, 15485863, i]))
+        depth_mm = np.rint(depth * 1000.0 + spec.depth_noise_mm * rng_d.standard_normal(depth.shape))
         depth_mm[(depth > spec.depth_cut) | (depth_mm > 65535) | (depth_mm < 1)] = 0
         depth_u16 = depth_mm.astype(np.uint16)
         # colours: hash of the entity id

@@ -72,6 +72,25 @@ void hmsg_destroy(hmsg_t* h);
 const char* hmsg_last_error(const hmsg_t* h);
 const char* hmsg_version(void);
 
+/* Start a new scene on the same handle: state is cleared, the HBM allocations are kept (what a service
+ * that rebuilds maps repeatedly does; the reference constructs a new Graph per scene,
+ * application/semantic_scene_reconstrucion_offline/offline_mapping_create_hmsg_hm3d_benchmark.py:70-110). */
+int hmsg_reset(hmsg_t* h);
+
+/* Live kernel timing with HIP events on the handle's stream (measurement aid for bench.py): when on, the
+ * heavy kernels are bracketed by event pairs; hmsg_profile_entry aggregates them per kernel name. */
+int hmsg_set_profiling(hmsg_t* h, int32_t on);
+int32_t hmsg_profile_count(hmsg_t* h);   /* distinct kernel names recorded since the last reset */
+int hmsg_profile_entry(hmsg_t* h, int32_t i, char* name /*[64]*/, int64_t* launches, double* total_ms);
+
+/* Benchmark utility, not part of the path: render the synthetic posed RGB-D + mask stream of SURVEY 8d
+ * straight into device buffers (rgb u8 [n][H][W][3], depth u16 [n][H][W], masks u8 [n][M][H][W]);
+ * mask_entity (host, i32 [n][M]) tells which scene entity each mask shows. */
+int hmsg_synth_render(int32_t device_id, int32_t n_frames, int32_t H, int32_t W, int32_t M, const double* K,
+                      const double* poses, const int32_t* room_of_frame, int32_t n_rooms, const double* room_boxes,
+                      int32_t n_obj, const double* obj_boxes, const int32_t* room_obj_off, double depth_noise_mm,
+                      uint64_t seed, uint8_t* rgb_dev, uint16_t* depth_dev, uint8_t* masks_dev, int32_t* mask_entity_host);
+
 /* ---- loop A of create_feature_map (graph.py:339-345): hand over posed RGB-D frames ------------
  * rgb u8 [n][H][W][3], depth u16 [n][H][W] (millimetres), pose f64 [n][16] row-major camera-to-world,
  * K f64 [9] row-major intrinsics (dataset[i] tuple contract, horizon.py:217-268). Frames are copied
@@ -112,6 +131,7 @@ int hmsg_merge_instances(hmsg_t* h);
 int64_t hmsg_num_instances(const hmsg_t* h);
 int hmsg_get_instance_sizes(const hmsg_t* h, int64_t* sizes /*[N]*/);
 int hmsg_get_instance_points(const hmsg_t* h, double* xyz /*[sum][3]*/);
+int hmsg_get_instance_boxes(const hmsg_t* h, double* boxes /*[N][6]: AABB min xyz, max xyz*/);
 
 /* ---- A7: per-instance feature pooling (graph.py:450-491, graph_utils.py:682-728). */
 int hmsg_pool_instances(hmsg_t* h);

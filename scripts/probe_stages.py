@@ -25,3 +25,7 @@ T("add_frame_features", lambda: sc.add_frame_features(0, S["masks"], S["f_g"], S
 T("fuse_frames", sc.fuse_frames)
 nn = sc.frame_nn(F // 2)
 print("valid px", (nn >= 0).mean())
+T("merge_instances", sc.merge_instances)
+inst = sc.instances()
+print("instances", len(inst), "points", sum(len(i) for i in inst), "max", max(len(i) for i in inst))
+T("pool_instances", sc.pool_instances)

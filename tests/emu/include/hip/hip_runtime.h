@@ -364,6 +364,33 @@ static inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float 
     hipemu::wave_barrier();
     return d;
 }
+// f64 MFMA 16x16x4: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; C/D: col = lane&15, row = (lane>>4) + 4*reg
+typedef double hipemu_f64x4 __attribute__((ext_vector_type(4)));
+static inline hipemu_f64x4 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, hipemu_f64x4 c, int, int, int) {
+    hipemu::BlockState& s = hipemu::bs();
+    int tid = hipemu::lin_tid(), base = (tid / 64) * 64, lane = tid & 63;
+    uint64_t ra, rb;
+    memcpy(&ra, &a, 8);
+    memcpy(&rb, &b, 8);
+    s.xbuf[tid] = ra;
+    s.xbuf2[tid] = rb;
+    hipemu::wave_barrier();
+    hipemu_f64x4 d = c;
+    int col = lane & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = (lane >> 4) + 4 * r;
+        double acc = c[r];
+        for (int k = 0; k < 4; ++k) {
+            double av, bv;
+            memcpy(&av, &s.xbuf[base + row + 16 * k], 8);
+            memcpy(&bv, &s.xbuf2[base + col + 16 * k], 8);
+            acc = fma(av, bv, acc);
+        }
+        d[r] = acc;
+    }
+    hipemu::wave_barrier();
+    return d;
+}
 static inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hipemu_f32x4 c, int, int, int) {
     // A[l&15][k=l>>4], B[k=l>>4][l&15]; C/D: col = lane&15, row = (lane>>4)*4 + reg
     hipemu::BlockState& s = hipemu::bs();

@@ -137,3 +137,49 @@ def check_merge_pool(sc, frames, cfg, ref_pts, ref_feats):
         return got, feats
     finally:
         O.NN_TIE = "scipy"
+
+
+def check_query_golden(L):
+    """A12 against the fixture produced by the reference's own query_hmsg_object (tests/golden/query.npz):
+    retrieval indices bit-identical, scores to 1e-12."""
+    from holoagent_amd._lib import NodeIndex
+    from tests import golden_io as GI
+    z = GI.load("query")
+    words = [str(w) for w in z["table_words"]]
+    table = {w: z["table"][i] for i, w in enumerate(words)}
+    obj_emb, obj_room = z["obj_emb"], z["obj_room"]
+    room_floor = z["room_floor"]
+    R = len(room_floor)
+    k = z["ref_obj_idx"].shape[1]
+    ix = NodeIndex(obj_emb, obj_room, lib_=L)
+    floor_rooms = {f: [r for r in range(R) if room_floor[r] == f] for f in (0, 1)}
+    # the fixture's queries, batched per number of negatives
+    for nneg in (1, 2):
+        qs = [i for i, s in enumerate(z["qspec"]) if s[3] == nneg]
+        T, lists = [], []
+        for qi in qs:
+            q, rq, floor_id, _ = z["qspec"][qi]
+            rooms_list = list(range(R)) if floor_id == -1 else floor_rooms[floor_id]
+            rl = [int(v) for v in z["ref_rooms_label"][qi] if v >= 0]
+            lists.append([rooms_list[r] for r in rl])
+            negs = ["background"] if nneg == 1 else ["background", "wall"]
+            T.append(np.stack([table["thing%d" % q]] + [table[n] for n in negs]))
+        idx, room, score = ix.query_objects(np.stack(T), np.zeros(len(qs), np.int32), lists, k)
+        for j, qi in enumerate(qs):
+            ref = [int(v) for v in z["ref_obj_idx"][qi] if v >= 0]
+            got = [int(v) for v in idx[j] if v >= 0]
+            assert got == ref, (qi, got, ref)
+            np.testing.assert_allclose(score[j][: len(ref)], z["ref_obj_score"][qi][: len(ref)], rtol=0, atol=1e-12)
+            floor_id = z["qspec"][qi][2]
+            rooms_list = list(range(R)) if floor_id == -1 else floor_rooms[floor_id]
+            ref_room = [rooms_list[int(v)] for v in z["ref_obj_room"][qi] if v >= 0]
+            assert [int(v) for v in room[j][: len(ref)]] == ref_room
+    # query that IS one of the negative labels (graph.py:3082-3092): categories = negatives, qid = its index
+    T = np.stack([table["background"], table["wall"]])[None]
+    idx, room, score = ix.query_objects(T, np.array([1], np.int32), [list(range(R))], k)
+    assert [int(v) for v in idx[0] if v >= 0] == [int(v) for v in z["ref_neg_idx"]]
+    np.testing.assert_allclose(score[0][: len(z["ref_neg_score"])], z["ref_neg_score"], rtol=0, atol=1e-12)
+    # plain similarity (query_floor / query_hmsg_room GEMV)
+    S = ix.similarity(np.stack([table["thing3"], table["room1"]]))
+    np.testing.assert_allclose(S, np.dot(np.stack([table["thing3"], table["room1"]]), obj_emb.T), rtol=0, atol=1e-12)
+    ix.close()

@@ -51,3 +51,7 @@ def test_merge_and_pool_small(L, merge_type):
         O.feats_denoise_dbscan = orig
     assert len(got) > 3
     sc.close()
+
+
+def test_query_golden(L):
+    PC.check_query_golden(L)

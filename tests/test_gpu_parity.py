@@ -64,3 +64,27 @@ def test_full_build_against_oracle_and_reference_golden(L, name):
         assert same_pts >= 0.9 * n_ref
         assert close.sum() >= 0.9 * n_ref
     sc.close()
+
+
+def test_query_golden(L):
+    PC.check_query_golden(L)
+
+
+def test_query_random_large(L):
+    """1k queries x 5k nodes x D=512 against the numpy restatement (oracle.query_object)."""
+    from holoagent_amd._lib import NodeIndex
+    from oracle import hmsg_oracle as O
+    rng = np.random.Generator(np.random.PCG64(77))
+    N, D, R, Q, k = 5000, 512, 40, 1000, 5
+    emb = rng.standard_normal((N, D)) * 0.05
+    room = rng.integers(0, R, size=N).astype(np.int32)
+    T = rng.standard_normal((Q, 2, D)).astype(np.float32) * 0.05
+    lists = [sorted(rng.choice(R, size=int(rng.integers(1, 6)), replace=False).tolist()) for _ in range(Q)]
+    ix = NodeIndex(emb, room, lib_=L)
+    idx, rooms, score = ix.query_objects(T, np.zeros(Q, np.int32), lists, k)
+    for q in range(0, Q, 7):
+        cand = [o for r in lists[q] for o in np.nonzero(room == r)[0]]
+        top, sc = O.query_object(T[q], 0, emb[cand], k)
+        assert [cand[t] for t in top] == [int(v) for v in idx[q] if v >= 0]
+        np.testing.assert_allclose(score[q][: len(top)], sc, rtol=0, atol=1e-12)
+    ix.close()
