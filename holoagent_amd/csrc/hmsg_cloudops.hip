@@ -125,14 +125,25 @@ __device__ __forceinline__ void uf_union(int* parent, int a, int b) {
     }
 }
 
-// pass 0: neighbour cells at Chebyshev distance 1; pass 1: distance 2 (skipped when already connected)
-__global__ void k_db_union(const double* __restrict__ pts, long long NC, const DbSeg* __restrict__ segs, int K,
-                           const unsigned* __restrict__ cnt, const unsigned* __restrict__ start,
-                           const unsigned* __restrict__ ord, const unsigned char* __restrict__ core,
-                           const unsigned* __restrict__ minidx, double eps2, int pass, int* __restrict__ parent) {
+// compact list of the cells that hold at least one core point
+__global__ void k_db_corecells(long long NC, const unsigned* __restrict__ minidx, int* __restrict__ list, unsigned* __restrict__ n) {
     long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= NC) return;
-    if (minidx[c] == INF32) return;         // no core point in this cell
+    if (c >= NC || minidx[c] == INF32) return;
+    list[atomicAdd(n, 1u)] = (int)c;
+}
+
+// One WAVE per core cell, one LANE per neighbour cell (pass 0: Chebyshev distance 1, pass 1: distance 2,
+// skipped when the two cells are already connected).  An edge needs one witness pair of core points closer
+// than eps; the lane stops at the first one.
+__global__ void k_db_union(const double* __restrict__ pts, const int* __restrict__ corecells, const unsigned* __restrict__ ncore,
+                           const DbSeg* __restrict__ segs, int K, const unsigned* __restrict__ cnt,
+                           const unsigned* __restrict__ start, const unsigned* __restrict__ ord,
+                           const unsigned char* __restrict__ core, const unsigned* __restrict__ minidx, double eps2, int pass,
+                           int* __restrict__ parent) {
+    const int lane = threadIdx.x & 63;
+    const long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (w >= (long long)*ncore) return;
+    const long long c = corecells[w];
     int lo = 0, hi = K - 1;                 // segment of the cell
     while (lo < hi) {
         int mid = (lo + hi + 1) >> 1;
@@ -142,31 +153,30 @@ __global__ void k_db_union(const double* __restrict__ pts, long long NC, const D
     int ix, iy, iz;
     cell_xyz(sg, c, ix, iy, iz);
     const unsigned s0 = start[c], e0 = s0 + cnt[c];
-    for (int dx = -2; dx <= 2; ++dx)
-        for (int dy = -2; dy <= 2; ++dy)
-            for (int dz = -2; dz <= 2; ++dz) {
-                int cheb = max(abs(dx), max(abs(dy), abs(dz)));
-                if (cheb == 0 || (pass == 0 && cheb != 1) || (pass == 1 && cheb != 2)) continue;
-                int jx = ix + dx, jy = iy + dy, jz = iz + dz;
-                if (jx < 0 || jy < 0 || jz < 0 || jx >= sg.nx || jy >= sg.ny || jz >= sg.nz) continue;
-                long long c2 = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz + jz;
-                if (c2 <= c || minidx[c2] == INF32) continue;
-                if (uf_find(parent, (int)c) == uf_find(parent, (int)c2)) continue;
-                const unsigned s1 = start[c2], e1 = s1 + cnt[c2];
-                bool hit = false;
-                for (unsigned a = s0; a < e0 && !hit; ++a) {
-                    unsigned ia = ord[a];
-                    if (!core[ia]) continue;
-                    for (unsigned b = s1; b < e1; ++b) {
-                        unsigned ib = ord[b];
-                        if (core[ib] && dist2_f64(pts + (size_t)ia * 3, pts + (size_t)ib * 3) < eps2) {
-                            hit = true;
-                            break;
-                        }
-                    }
+    for (int o = lane; o < 125; o += 64) {
+        int dx = o / 25 - 2, dy = (o / 5) % 5 - 2, dz = o % 5 - 2;
+        int cheb = max(abs(dx), max(abs(dy), abs(dz)));
+        if (cheb == 0 || (pass == 0 && cheb != 1) || (pass == 1 && cheb != 2)) continue;
+        int jx = ix + dx, jy = iy + dy, jz = iz + dz;
+        if (jx < 0 || jy < 0 || jz < 0 || jx >= sg.nx || jy >= sg.ny || jz >= sg.nz) continue;
+        long long c2 = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz + jz;
+        if (c2 <= c || minidx[c2] == INF32) continue;
+        if (uf_find(parent, (int)c) == uf_find(parent, (int)c2)) continue;
+        const unsigned s1 = start[c2], e1 = s1 + cnt[c2];
+        bool hit = false;
+        for (unsigned a = s0; a < e0 && !hit; ++a) {
+            unsigned ia = ord[a];
+            if (!core[ia]) continue;
+            for (unsigned b = s1; b < e1; ++b) {
+                unsigned ib = ord[b];
+                if (core[ib] && dist2_f64(pts + (size_t)ia * 3, pts + (size_t)ib * 3) < eps2) {
+                    hit = true;
+                    break;
                 }
-                if (hit) uf_union(parent, (int)c, (int)c2);
             }
+        }
+        if (hit) uf_union(parent, (int)c, (int)c2);
+    }
 }
 
 __global__ void k_db_flatten(long long NC, const unsigned* __restrict__ minidx, int* __restrict__ parent) {
@@ -190,13 +200,14 @@ __global__ void k_db_label(const double* __restrict__ pts, long long N, const in
                            const int* __restrict__ parent, const unsigned* __restrict__ rootmin, double eps2,
                            int* __restrict__ label, unsigned* __restrict__ size, unsigned* __restrict__ firstidx) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+    const bool in_range = i < N;
+    if (!in_range) i = N - 1;                // keep the lane alive for the wave collectives below
     const DbSeg sg = segs[segid[i]];
     long long c = cellid[i];
     int lab = -1;
     if (core[i]) {
         lab = parent[c];
-    } else {
+    } else if (in_range) {
         int ix, iy, iz;
         cell_xyz(sg, c, ix, iy, iz);
         unsigned bestkey = INF32;
@@ -227,10 +238,20 @@ __global__ void k_db_label(const double* __restrict__ pts, long long N, const in
                     }
                 }
     }
-    label[i] = lab;
-    if (lab >= 0) {
-        atomicAdd(&size[lab], 1u);
-        atomicMin(&firstidx[lab], (unsigned)(i - sg.pt_base));
+    if (in_range) label[i] = lab;
+    // cluster sizes / first member index: one atomic per (wave, label) instead of one per point -- whole
+    // waves usually carry a single label, and per-point atomics on one address serialise.
+    const bool valid = in_range && lab >= 0;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+        int leader = __ffsll(todo) - 1;
+        int key = __shfl(lab, leader);
+        unsigned long long mine = __ballot(valid && lab == key);
+        if ((int)(threadIdx.x & 63) == leader) {
+            atomicAdd(&size[key], (unsigned)__popcll(mine));
+            atomicMin(&firstidx[key], (unsigned)(i - sg.pt_base));   // leader = lowest lane = smallest index of the group
+        }
+        todo &= ~mine;
     }
 }
 
@@ -275,17 +296,35 @@ __global__ void k_db_scatter(const double* __restrict__ pts, long long N, const 
                              const unsigned* __restrict__ flags, const unsigned* __restrict__ pos, double* __restrict__ dst,
                              unsigned long long* __restrict__ obounds, int* __restrict__ ocount) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N || !flags[i]) return;
-    unsigned p = pos[i];
-    int k = segid[i];
-    for (int a = 0; a < 3; ++a) {
-        double v = pts[i * 3 + a];
-        dst[(size_t)p * 3 + a] = v;
-        unsigned long long e = enc_f64(v);
-        if (e < obounds[(size_t)k * 6 + a]) atomicMin(&obounds[(size_t)k * 6 + a], e);
-        if (e > obounds[(size_t)k * 6 + 3 + a]) atomicMax(&obounds[(size_t)k * 6 + 3 + a], e);
+    const bool valid = i < N && flags[i];
+    if (i >= N) i = N - 1;
+    const int k = segid[i];
+    double v[3] = {pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]};
+    if (valid) {
+        unsigned p = pos[i];
+        for (int a = 0; a < 3; ++a) dst[(size_t)p * 3 + a] = v[a];
     }
-    atomicAdd(&ocount[k], 1);
+    // per-segment AABB and count, aggregated per (wave, segment)
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+        int leader = __ffsll(todo) - 1;
+        int key = __shfl(k, leader);
+        const bool mine_b = valid && k == key;
+        unsigned long long mine = __ballot(mine_b);
+        double mn[3], mx[3];
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = wave_min_f64(mine_b ? v[a] : 1e300);
+            mx[a] = wave_max_f64(mine_b ? v[a] : -1e300);
+        }
+        if ((int)(threadIdx.x & 63) == leader) {
+            for (int a = 0; a < 3; ++a) {
+                atomicMin(&obounds[(size_t)key * 6 + a], enc_f64(mn[a]));
+                atomicMax(&obounds[(size_t)key * 6 + 3 + a], enc_f64(mx[a]));
+            }
+            atomicAdd(&ocount[key], __popcll(mine));
+        }
+        todo &= ~mine;
+    }
 }
 
 struct BdSeg {
@@ -412,10 +451,19 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
                        (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p, eps * eps, min_points, core.p,
                        minidx.p);
     hipLaunchKernelGGL(k_db_init_parent, dim3(gC), dim3(256), 0, s, NC, parent.p);
-    for (int pass = 0; pass < 2; ++pass)
-        hipLaunchKernelGGL(k_db_union, dim3(gC), dim3(256), 0, s, src, NC, dsegs, K, (const unsigned*)cnt.p,
-                           (const unsigned*)start.p, (const unsigned*)ord.p, (const unsigned char*)core.p,
-                           (const unsigned*)minidx.p, eps * eps, pass, parent.p);
+    // core cells <= points: size the wave grid by min(NC, N), the kernel reads the exact count
+    const long long maxcore = std::min<long long>(NC, N);
+    label.ensure((size_t)std::max<long long>(maxcore, N));    // label[] doubles as the core-cell list until k_db_label
+    HIP_TRY(hipMemsetAsync(ocount.p, 0, 4, s));
+    hipLaunchKernelGGL(k_db_corecells, dim3(gC), dim3(256), 0, s, NC, (const unsigned*)minidx.p, label.p, (unsigned*)ocount.p);
+    for (int pass = 0; pass < 2; ++pass) {
+        hipLaunchKernelGGL(k_db_union, dim3(cdiv((size_t)maxcore * 64, 256)), dim3(256), 0, s, src, (const int*)label.p,
+                           (const unsigned*)ocount.p, dsegs, K, (const unsigned*)cnt.p, (const unsigned*)start.p,
+                           (const unsigned*)ord.p, (const unsigned char*)core.p, (const unsigned*)minidx.p, eps * eps, pass,
+                           parent.p);
+        if (pass == 0) hipLaunchKernelGGL(k_db_flatten, dim3(gC), dim3(256), 0, s, NC, (const unsigned*)minidx.p, parent.p);
+    }
+    HIP_TRY(hipMemsetAsync(ocount.p, 0, (size_t)K * 4, s));
     hipLaunchKernelGGL(k_db_flatten, dim3(gC), dim3(256), 0, s, NC, (const unsigned*)minidx.p, parent.p);
     hipLaunchKernelGGL(k_db_rootmin, dim3(gC), dim3(256), 0, s, NC, (const int*)parent.p, (const unsigned*)minidx.p, rootmin.p);
     hipLaunchKernelGGL(k_db_label, dim3(gN), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const long long*)cellid.p,

@@ -214,6 +214,11 @@ struct hmsg_ctx {
     DevBuf<unsigned> rank;              // exclusive popcount prefix per word
     DevBuf<double> pts;            // [V][3]
     DevBuf<double> cols;           // [V][3]
+    // NN candidate lists for the cells of voxels deleted by remove_radius_outlier (hmsg_nn.h)
+    DevBuf<unsigned long long> bitmap_rm;
+    DevBuf<unsigned> rank_rm, cand_off;
+    DevBuf<int> cand;
+    bool have_cand = false;
     DevBuf<float> sum;             // [V][D]
     DevBuf<unsigned> cnt;          // [V]
     bool feats_final = false;

@@ -119,9 +119,7 @@ __global__ void k_fp(const float* __restrict__ Fg, const float* __restrict__ Fm,
 #include "hmsg_nn.h"
 
 __global__ void k_nn_stamp(const unsigned short* __restrict__ depth, const double* __restrict__ pose, CamK cam, float scale,
-                           int H, int W, int f0, int nfr, GridGeom g, const unsigned long long* __restrict__ bitmap,
-                           const unsigned* __restrict__ rank, const double* __restrict__ pts, int* __restrict__ nn,
-                           unsigned* __restrict__ stamp /*[V][FB]*/) {
+                           int H, int W, int f0, int nfr, NNIndex I, int* __restrict__ nn, unsigned* __restrict__ stamp /*[V][FB]*/) {
     const size_t HW = (size_t)H * W;
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= HW * nfr) return;
@@ -132,7 +130,7 @@ __global__ void k_nn_stamp(const unsigned short* __restrict__ depth, const doubl
     double wx, wy, wz;
     int idx = -1;
     if (backproject(depth[(size_t)f * HW + p], x, y, cam, scale, pose + (size_t)f * 16, wx, wy, wz)) {
-        idx = nn_search(g, bitmap, rank, pts, wx, wy, wz);
+        idx = nn_search(I, wx, wy, wz);
         if (idx >= 0) atomicMax(&stamp[(size_t)idx * FB + fl], (unsigned)p + 1u);
     }
     nn[(size_t)f * HW + p] = idx;
@@ -455,9 +453,7 @@ void hmsg_fuse(hmsg_ctx* h) {
         {
             ProfScope ps(h->prof, s, "k_nn_stamp");
             hipLaunchKernelGGL(k_nn_stamp, dim3(cdiv(HW * nb, 256)), dim3(256), 0, s, (const unsigned short*)h->depth.p,
-                               (const double*)h->pose.p, h->cam, scale, H, W, fb0, nb, h->grid,
-                               (const unsigned long long*)h->bitmap.p, (const unsigned*)h->rank.p, (const double*)h->pts.p,
-                               h->nn.p, stamp.p);
+                               (const double*)h->pose.p, h->cam, scale, H, W, fb0, nb, hmsg_nn_index(h), h->nn.p, stamp.p);
         }
         HMSG_CHECK_LAUNCH();
         {

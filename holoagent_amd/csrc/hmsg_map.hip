@@ -12,6 +12,8 @@
 // atomics (fixed-point offsets from the cell corner -> order-independent, bit-reproducible).
 #include "hmsg_common.h"
 
+#include <algorithm>
+
 #define FIX_SCALE 70368744177664.0 /* 2^46: 1.4e-14 m resolution */
 
 // ------------------------------------------------------------------------------------------ scans
@@ -324,6 +326,121 @@ __global__ void k_compact(const unsigned* __restrict__ keep, const unsigned* __r
     }
 }
 
+// ------------------------------------------------------------------------------------------ NN candidate lists
+// (hmsg_nn.h) For every cell whose voxel was deleted: the cloud points that can be the nearest neighbour of
+// SOME query inside the cell = { p : mindist(p, cell) <= min_p' maxdist(p', cell) }.  One wave per cell.
+__global__ void k_rm_cells(const unsigned* __restrict__ keep, const unsigned* __restrict__ newidx, long long V0,
+                           const int* __restrict__ cell, GridGeom g, int* __restrict__ rmcell,
+                           unsigned long long* __restrict__ bitmap_rm) {
+    long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= V0 || keep[s]) return;
+    long long r = s - (long long)newidx[s];
+    for (int a = 0; a < 3; ++a) rmcell[r * 3 + a] = cell[s * 3 + a];
+    long long lin = lin_of(g, cell[s * 3], cell[s * 3 + 1], cell[s * 3 + 2]);
+    atomicOr(&bitmap_rm[lin >> 6], 1ull << (lin & 63));
+}
+
+template <typename F>
+__device__ __forceinline__ void ring_visit(const GridGeom& g, const unsigned long long* __restrict__ bitmap,
+                                           const unsigned* __restrict__ rank, int cx, int cy, int cz, int r, int lane, F&& f) {
+    const int side = 2 * r + 1;
+    for (int ci = lane; ci < side * side; ci += 64) {
+        int dx = ci / side - r, dy = ci % side - r;
+        int ix = cx + dx, iy = cy + dy;
+        if (ix < 0 || iy < 0 || ix >= g.nx || iy >= g.ny) continue;
+        bool rim = (dx == -r || dx == r || dy == -r || dy == r);
+        long long colw = ((long long)ix * g.ny + iy) * (g.nzp >> 6);
+        for (int part = 0; part < (rim ? 1 : 2); ++part) {
+            int z0 = rim ? cz - r : (part == 0 ? cz - r : cz + r);
+            int z1 = rim ? cz + r : z0;
+            z0 = z0 < 0 ? 0 : z0;
+            z1 = z1 >= g.nz ? g.nz - 1 : z1;
+            if (!rim && (z0 != z1 || (part == 0 ? cz - r < 0 : cz + r >= g.nz))) continue;
+            if (z1 < z0) continue;
+            for (int w = z0 >> 6; w <= z1 >> 6; ++w) {
+                unsigned long long word = bitmap[colw + w];
+                if (!word) continue;
+                int b0 = w * 64;
+                int lo = z0 - b0 < 0 ? 0 : z0 - b0, hi = z1 - b0 > 63 ? 63 : z1 - b0;
+                unsigned long long sel = word & (hi >= 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull)) & ~((1ull << lo) - 1ull);
+                unsigned base = rank[colw + w];
+                while (sel) {
+                    int b = __ffsll(sel) - 1;
+                    sel &= sel - 1;
+                    f((int)(base + (unsigned)__popcll(word & ((1ull << b) - 1ull))));
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void box_dists(const double* __restrict__ p, const double* lo, double vs, double& mn2, double& mx2) {
+    mn2 = 0.0;
+    mx2 = 0.0;
+    for (int a = 0; a < 3; ++a) {
+        double hi = lo[a] + vs;
+        double dmin = fmax(0.0, fmax(lo[a] - p[a], p[a] - hi));
+        double dmax = fmax(fabs(p[a] - lo[a]), fabs(p[a] - hi));
+        mn2 += dmin * dmin;
+        mx2 += dmax * dmax;
+    }
+}
+
+__global__ void k_cand(int mode, const int* __restrict__ rmcell, long long VR, GridGeom g,
+                       const unsigned long long* __restrict__ bitmap, const unsigned* __restrict__ rank,
+                       const double* __restrict__ pts, double* __restrict__ ub2_io, int* __restrict__ rend_io,
+                       unsigned* __restrict__ cnt, const unsigned* __restrict__ cand_off, int* __restrict__ cand,
+                       unsigned* __restrict__ cursor) {
+    const int lane = threadIdx.x & 63;
+    const long long r = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (r >= VR) return;
+    const int cx = rmcell[r * 3], cy = rmcell[r * 3 + 1], cz = rmcell[r * 3 + 2];
+    // the cell box, grown a hair: queries are assigned to cells by a rounded division
+    const double pad = 1e-9;
+    const double lo[3] = {g.ox + cx * g.vs - pad, g.oy + cy * g.vs - pad, g.oz + cz * g.vs - pad};
+    const double vs = g.vs + 2 * pad;
+    if (mode == 0) {
+        double ub2 = 1e300;
+        const int rmax = max(g.nx, max(g.ny, g.nz));
+        int rr = 1;
+        for (; rr <= rmax; ++rr) {
+            ring_visit(g, bitmap, rank, cx, cy, cz, rr, lane, [&](int q) {
+                double mn2, mx2;
+                box_dists(pts + (size_t)q * 3, lo, vs, mn2, mx2);
+                ub2 = mx2 < ub2 ? mx2 : ub2;
+            });
+            ub2 = wave_min_f64(ub2);
+            double reach = rr * g.vs - 1e-6;          // every unexplored point is at least this far from the cell
+            if (ub2 < 1e299 && reach > 0.0 && reach * reach > ub2) break;
+        }
+        if (rr > rmax) rr = rmax;
+        const double lim = ub2 * (1.0 + 1e-9) + 1e-12;
+        int n = 0;
+        for (int q = 1; q <= rr; ++q)
+            ring_visit(g, bitmap, rank, cx, cy, cz, q, lane, [&](int k) {
+                double mn2, mx2;
+                box_dists(pts + (size_t)k * 3, lo, vs, mn2, mx2);
+                n += mn2 <= lim ? 1 : 0;
+            });
+        n = wave_sum_i32(n);
+        if (lane == 0) {
+            ub2_io[r] = ub2;
+            rend_io[r] = rr;
+            cnt[r] = (unsigned)n;
+        }
+    } else {
+        const double lim = ub2_io[r] * (1.0 + 1e-9) + 1e-12;
+        const int rr = rend_io[r];
+        const unsigned base = cand_off[r];
+        for (int q = 1; q <= rr; ++q)
+            ring_visit(g, bitmap, rank, cx, cy, cz, q, lane, [&](int k) {
+                double mn2, mx2;
+                box_dists(pts + (size_t)k * 3, lo, vs, mn2, mx2);
+                if (mn2 <= lim) cand[base + atomicAdd(&cursor[r], 1u)] = k;
+            });
+    }
+}
+
 // ------------------------------------------------------------------------------------------ host driver
 void hmsg_build_map(hmsg_ctx* h) {
     const hmsg_config& c = h->cfg;
@@ -425,6 +542,45 @@ void hmsg_build_map(hmsg_ctx* h) {
     HMSG_CHECK_LAUNCH();
     unsigned long long V2 = hmsg_bitmap_rank(h->bitmap.p, h->rank.p, (size_t)g.nwords, s, h->scan_tmp);
     HMSG_REQUIRE(V2 == V, HMSG_ERR_INVALID, "internal: filtered bitmap population mismatch");
+    // NN candidate lists for the cells of the deleted voxels
+    const long long VR = (long long)V0 - (long long)V;
+    h->have_cand = false;
+    if (VR > 0 && V > 0) {
+        h->bitmap_rm.alloc((size_t)g.nwords);
+        h->rank_rm.alloc((size_t)g.nwords);
+        h->bitmap_rm.zero(s);
+        DevBuf<int> rmcell, rend;
+        DevBuf<double> ub2;
+        DevBuf<unsigned> ccnt, cursor;
+        rmcell.alloc((size_t)VR * 3);
+        rend.alloc((size_t)VR);
+        ub2.alloc((size_t)VR);
+        ccnt.alloc((size_t)VR + 1);
+        cursor.alloc((size_t)VR);
+        ccnt.zero(s);
+        cursor.zero(s);
+        hipLaunchKernelGGL(k_rm_cells, dim3(cdiv(V0, 256)), dim3(256), 0, s, (const unsigned*)keep.p, (const unsigned*)newidx.p,
+                           (long long)V0, (const int*)cell.p, g, rmcell.p, h->bitmap_rm.p);
+        HMSG_CHECK_LAUNCH();
+        unsigned long long nrm = hmsg_bitmap_rank(h->bitmap_rm.p, h->rank_rm.p, (size_t)g.nwords, s, h->scan_tmp);
+        HMSG_REQUIRE((long long)nrm == VR, HMSG_ERR_INVALID, "internal: removed-cell bitmap population mismatch");
+        h->cand_off.alloc((size_t)VR + 1);
+        {
+            ProfScope ps(h->prof, s, "k_cand");
+            hipLaunchKernelGGL(k_cand, dim3(cdiv((size_t)VR * 64, 256)), dim3(256), 0, s, 0, (const int*)rmcell.p, VR, g,
+                               (const unsigned long long*)h->bitmap.p, (const unsigned*)h->rank.p, (const double*)h->pts.p, ub2.p,
+                               rend.p, ccnt.p, (const unsigned*)nullptr, (int*)nullptr, (unsigned*)nullptr);
+        }
+        HMSG_CHECK_LAUNCH();
+        unsigned long long ncand = 0;
+        hmsg_scan_u32(ccnt.p, h->cand_off.p, (size_t)VR + 1, s, h->scan_tmp, &ncand);
+        h->cand.alloc((size_t)std::max<unsigned long long>(ncand, 1));
+        hipLaunchKernelGGL(k_cand, dim3(cdiv((size_t)VR * 64, 256)), dim3(256), 0, s, 1, (const int*)rmcell.p, VR, g,
+                           (const unsigned long long*)h->bitmap.p, (const unsigned*)h->rank.p, (const double*)h->pts.p, ub2.p,
+                           rend.p, ccnt.p, (const unsigned*)h->cand_off.p, h->cand.p, cursor.p);
+        HMSG_CHECK_LAUNCH();
+        h->have_cand = true;
+    }
     HIP_TRY(hipStreamSynchronize(s));
     h->map_ready = true;
 }

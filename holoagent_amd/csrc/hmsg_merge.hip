@@ -320,9 +320,14 @@ struct Merger {
             for (int i = 0; i < n; ++i)
                 for (int j = i + 1; j < n; ++j) consider(i, j);
         } else {
-            for (int i = 0; i < n; ++i)
-                for (int j = i + 1; j < n; ++j)
-                    if (L[i].fresh || L[j].fresh) consider(i, j);
+            // shortcut (2): only pairs with a fresh member; enumerate from the (few) fresh clouds
+            for (int i = 0; i < n; ++i) {
+                if (!L[i].fresh) continue;
+                for (int j = 0; j < n; ++j) {
+                    if (j == i || (L[j].fresh && j < i)) continue;
+                    consider(std::min(i, j), std::max(i, j));
+                }
+            }
         }
         std::vector<double> ratio;
         overlap_ratios(L, pairs, ratio);

@@ -28,13 +28,12 @@ struct PoolSeg {            // one instance
 };
 
 // ---- NN of the down-sampled instance points; keep dist <= max_dist (graph.py:458-460)
-__global__ void k_pool_nn(const double* __restrict__ q, long long N, GridGeom g, const unsigned long long* __restrict__ bitmap,
-                          const unsigned* __restrict__ rank, const double* __restrict__ pts, double max_dist,
-                          int* __restrict__ idx, unsigned* __restrict__ valid) {
+__global__ void k_pool_nn(const double* __restrict__ q, long long N, NNIndex I, double max_dist, int* __restrict__ idx,
+                          unsigned* __restrict__ valid) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     double d2 = 0;
-    int v = nn_search(g, bitmap, rank, pts, q[i * 3], q[i * 3 + 1], q[i * 3 + 2], &d2);
+    int v = nn_search(I, q[i * 3], q[i * 3 + 1], q[i * 3 + 2], &d2);
     idx[i] = v;
     valid[i] = (v >= 0 && __dsqrt_rn(d2) <= max_dist) ? 1u : 0u;
 }
@@ -280,8 +279,7 @@ void hmsg_pool(hmsg_ctx* h) {
     valid.alloc((size_t)std::max<long long>(P, 1));
     pos.alloc((size_t)std::max<long long>(P, 1));
     if (P) {
-        hipLaunchKernelGGL(k_pool_nn, dim3(cdiv((size_t)P, 256)), dim3(256), 0, s, (const double*)ds.p, P, h->grid,
-                           (const unsigned long long*)h->bitmap.p, (const unsigned*)h->rank.p, (const double*)h->pts.p,
+        hipLaunchKernelGGL(k_pool_nn, dim3(cdiv((size_t)P, 256)), dim3(256), 0, s, (const double*)ds.p, P, hmsg_nn_index(h),
                            c.pool_max_dist, idx.p, valid.p);
         HMSG_CHECK_LAUNCH();
     }
