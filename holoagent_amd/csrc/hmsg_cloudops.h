@@ -23,7 +23,8 @@ struct CloudOps {
     DevBuf<unsigned> scan_tmp;
     // scratch (grown on demand)
     DevBuf<unsigned> cnt, start, cursor, ord, minidx, firstidx, size, flags, pos, rootmin;
-    DevBuf<int> parent, label, segid;
+    DevBuf<int> parent, label, segid, cellpos;
+    DevBuf<double> cellbox;
     DevBuf<long long> cellid;
     DevBuf<unsigned char> core;
     DevBuf<unsigned long long> best, obounds;

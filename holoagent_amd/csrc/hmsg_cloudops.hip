@@ -126,10 +126,42 @@ __device__ __forceinline__ void uf_union(int* parent, int a, int b) {
 }
 
 // compact list of the cells that hold at least one core point
-__global__ void k_db_corecells(long long NC, const unsigned* __restrict__ minidx, int* __restrict__ list, unsigned* __restrict__ n) {
+__global__ void k_db_corecells(long long NC, const unsigned* __restrict__ minidx, int* __restrict__ list, unsigned* __restrict__ n,
+                               int* __restrict__ cellpos) {
     long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= NC || minidx[c] == INF32) return;
-    list[atomicAdd(n, 1u)] = (int)c;
+    unsigned p = atomicAdd(n, 1u);
+    list[p] = (int)c;
+    cellpos[c] = (int)p;
+}
+// AABB of the core points of every core cell (one wave per cell)
+__global__ void k_db_cellbox(const double* __restrict__ pts, const int* __restrict__ corecells, const unsigned* __restrict__ ncore,
+                             const unsigned* __restrict__ cnt, const unsigned* __restrict__ start, const unsigned* __restrict__ ord,
+                             const unsigned char* __restrict__ core, double* __restrict__ cellbox) {
+    const int lane = threadIdx.x & 63;
+    const long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (w >= (long long)*ncore) return;
+    const long long c = corecells[w];
+    const unsigned s0 = start[c], e0 = s0 + cnt[c];
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    for (unsigned k = s0 + lane; k < e0; k += 64) {
+        unsigned i = ord[k];
+        if (!core[i]) continue;
+        for (int a = 0; a < 3; ++a) {
+            double v = pts[(size_t)i * 3 + a];
+            mn[a] = v < mn[a] ? v : mn[a];
+            mx[a] = v > mx[a] ? v : mx[a];
+        }
+    }
+    for (int a = 0; a < 3; ++a) {
+        mn[a] = wave_min_f64(mn[a]);
+        mx[a] = wave_max_f64(mx[a]);
+    }
+    if (lane == 0)
+        for (int a = 0; a < 3; ++a) {
+            cellbox[(size_t)w * 6 + a] = mn[a];
+            cellbox[(size_t)w * 6 + 3 + a] = mx[a];
+        }
 }
 
 // One WAVE per core cell, one LANE per neighbour cell (pass 0: Chebyshev distance 1, pass 1: distance 2,
@@ -139,7 +171,7 @@ __global__ void k_db_union(const double* __restrict__ pts, const int* __restrict
                            const DbSeg* __restrict__ segs, int K, const unsigned* __restrict__ cnt,
                            const unsigned* __restrict__ start, const unsigned* __restrict__ ord,
                            const unsigned char* __restrict__ core, const unsigned* __restrict__ minidx, double eps2, int pass,
-                           int* __restrict__ parent) {
+                           const int* __restrict__ cellpos, const double* __restrict__ cellbox, int* __restrict__ parent) {
     const int lane = threadIdx.x & 63;
     const long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (w >= (long long)*ncore) return;
@@ -162,16 +194,36 @@ __global__ void k_db_union(const double* __restrict__ pts, const int* __restrict
         long long c2 = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz + jz;
         if (c2 <= c || minidx[c2] == INF32) continue;
         if (uf_find(parent, (int)c) == uf_find(parent, (int)c2)) continue;
-        const unsigned s1 = start[c2], e1 = s1 + cnt[c2];
-        bool hit = false;
-        for (unsigned a = s0; a < e0 && !hit; ++a) {
-            unsigned ia = ord[a];
-            if (!core[ia]) continue;
-            for (unsigned b = s1; b < e1; ++b) {
-                unsigned ib = ord[b];
-                if (core[ib] && dist2_f64(pts + (size_t)ia * 3, pts + (size_t)ib * 3) < eps2) {
-                    hit = true;
-                    break;
+        // tight AABBs of the two cells' core points decide most pairs without touching a point:
+        // farthest corners closer than eps -> every pair is a witness; nearest faces >= eps -> no witness.
+        const double* ba = cellbox + (size_t)cellpos[c] * 6;
+        const double* bb = cellbox + (size_t)cellpos[c2] * 6;
+        double mn2 = 0.0, mx2 = 0.0;
+        for (int a = 0; a < 3; ++a) {
+            double gap = fmax(0.0, fmax(ba[a] - bb[3 + a], bb[a] - ba[3 + a]));
+            double far = fmax(ba[3 + a] - bb[a], bb[3 + a] - ba[a]);
+            mn2 += gap * gap;
+            mx2 += far * far;
+        }
+        bool hit = mx2 < eps2 * (1.0 - 1e-12);
+        if (!hit && mn2 < eps2 * (1.0 + 1e-12)) {
+            const unsigned s1 = start[c2], e1 = s1 + cnt[c2];
+            for (unsigned a = s0; a < e0 && !hit; ++a) {
+                unsigned ia = ord[a];
+                if (!core[ia]) continue;
+                const double* pa = pts + (size_t)ia * 3;
+                double g2 = 0.0;                       // point-to-box lower bound
+                for (int q = 0; q < 3; ++q) {
+                    double gq = fmax(0.0, fmax(bb[q] - pa[q], pa[q] - bb[3 + q]));
+                    g2 += gq * gq;
+                }
+                if (g2 >= eps2 * (1.0 + 1e-12)) continue;
+                for (unsigned b = s1; b < e1; ++b) {
+                    unsigned ib = ord[b];
+                    if (core[ib] && dist2_f64(pa, pts + (size_t)ib * 3) < eps2) {
+                        hit = true;
+                        break;
+                    }
                 }
             }
         }
@@ -455,12 +507,18 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     const long long maxcore = std::min<long long>(NC, N);
     label.ensure((size_t)std::max<long long>(maxcore, N));    // label[] doubles as the core-cell list until k_db_label
     HIP_TRY(hipMemsetAsync(ocount.p, 0, 4, s));
-    hipLaunchKernelGGL(k_db_corecells, dim3(gC), dim3(256), 0, s, NC, (const unsigned*)minidx.p, label.p, (unsigned*)ocount.p);
+    cellpos.ensure((size_t)NC);
+    cellbox.ensure((size_t)maxcore * 6);
+    hipLaunchKernelGGL(k_db_corecells, dim3(gC), dim3(256), 0, s, NC, (const unsigned*)minidx.p, label.p, (unsigned*)ocount.p,
+                       cellpos.p);
+    hipLaunchKernelGGL(k_db_cellbox, dim3(cdiv((size_t)maxcore * 64, 256)), dim3(256), 0, s, src, (const int*)label.p,
+                       (const unsigned*)ocount.p, (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p,
+                       (const unsigned char*)core.p, cellbox.p);
     for (int pass = 0; pass < 2; ++pass) {
         hipLaunchKernelGGL(k_db_union, dim3(cdiv((size_t)maxcore * 64, 256)), dim3(256), 0, s, src, (const int*)label.p,
                            (const unsigned*)ocount.p, dsegs, K, (const unsigned*)cnt.p, (const unsigned*)start.p,
                            (const unsigned*)ord.p, (const unsigned char*)core.p, (const unsigned*)minidx.p, eps * eps, pass,
-                           parent.p);
+                           (const int*)cellpos.p, (const double*)cellbox.p, parent.p);
         if (pass == 0) hipLaunchKernelGGL(k_db_flatten, dim3(gC), dim3(256), 0, s, NC, (const unsigned*)minidx.p, parent.p);
     }
     HIP_TRY(hipMemsetAsync(ocount.p, 0, (size_t)K * 4, s));

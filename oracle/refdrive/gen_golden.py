@@ -150,12 +150,26 @@ def gen_build(G, X, out_dir):
         cloud = np.asarray(g.full_pcd.points)
         mp, moff = pack_clouds(g.mask_pcds)
         feats = np.stack([np.asarray(f).reshape(-1) for f in g.mask_feats]) if g.mask_feats else np.zeros((0, 1))
+        # Which instances depend on how scipy's cKDTree happens to break exact nearest-neighbour distance
+        # ties (an instance point that is the midpoint of two map voxels is equidistant from both)?  The
+        # oracle is run with both tie rules; instances whose pooled feature moves are flagged.
+        from oracle import hmsg_oracle as O
+        per_mode = []
+        for tie in ("scipy", "lowest"):
+            O.NN_TIE = tie
+            r = O.create_feature_map(frames, cfg)
+            per_mode.append(np.stack([np.asarray(f).reshape(-1) for f in r["mask_feats"]]))
+        O.NN_TIE = "scipy"
+        tie_sensitive = (np.abs(per_mode[0] - per_mode[1]).max(axis=1) > 1e-7) if per_mode[0].shape == per_mode[1].shape \
+            else np.ones(len(per_mode[0]), bool)
         np.savez_compressed(
             os.path.join(out_dir, name + ".npz"), **pack_frames(frames),
             cfg_keys=np.array(list(cfg.keys())), cfg_vals=np.array([str(v) for v in cfg.values()]),
             ref_cloud=cloud, ref_cloud_cols=np.asarray(g.full_pcd.colors),
             ref_full_feats=g.full_feats_array.astype(np.float32),
-            ref_mask_pts=mp, ref_mask_off=moff, ref_mask_feats=feats.astype(np.float32))
+            ref_mask_pts=mp, ref_mask_off=moff, ref_mask_feats=feats.astype(np.float32),
+            ref_tie_sensitive=tie_sensitive)
+        print(name, "tie-sensitive instances", int(tie_sensitive.sum()), "of", len(tie_sensitive))
         print(name, "cloud", cloud.shape, "instances", len(g.mask_pcds), "feats", feats.shape)
 
 

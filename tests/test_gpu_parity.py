@@ -51,18 +51,20 @@ def test_full_build_against_oracle_and_reference_golden(L, name):
     S, ref_pts, ref_cols = PC.check_map(sc, frames, cfg)
     ref_feats, n_tie = PC.check_fuse(sc, frames, S, cfg, ref_pts, ref_cols, check_masks=(name == "build_hier"))
     got, feats = PC.check_merge_pool(sc, frames, cfg, ref_pts, ref_feats)
-    # against the reference run (scipy's arbitrary NN tie-breaks differ from our canonical rule on a few
-    # structurally tied pixels, so a handful of instances may differ slightly; most must agree to 1e-5)
+    # against the REFERENCE run (tests/golden): identical instances; pooled features within 1e-5 for every
+    # instance that does not hinge on cKDTree's arbitrary choice between exactly equidistant map voxels
+    # (an instance point that is the midpoint of two voxels is equidistant from both; the fixture flags those
+    # instances, gen_golden.py).  Tie-sensitive instances are compared with the oracle's canonical rule above.
     off = z["ref_mask_off"]
     n_ref = len(off) - 1
-    assert abs(len(got) - n_ref) <= max(1, n_ref // 20)
-    if len(got) == n_ref:
-        same_pts = sum(1 for k in range(n_ref) if got[k].shape[0] == off[k + 1] - off[k] and
-                       np.allclose(got[k], z["ref_mask_pts"][off[k]:off[k + 1]], rtol=0, atol=1e-9))
-        close = np.abs(feats - z["ref_mask_feats"]).max(axis=1) <= 1e-5
-        print(name, "instances", n_ref, "identical point sets", same_pts, "features within 1e-5", int(close.sum()))
-        assert same_pts >= 0.9 * n_ref
-        assert close.sum() >= 0.9 * n_ref
+    assert len(got) == n_ref
+    for k in range(n_ref):
+        np.testing.assert_allclose(got[k], z["ref_mask_pts"][off[k]:off[k + 1]], rtol=0, atol=1e-9)
+    stable = ~z["ref_tie_sensitive"]
+    err = np.abs(feats - z["ref_mask_feats"]).max(axis=1)
+    print(name, "instances", n_ref, "tie-stable", int(stable.sum()), "max err on stable", float(err[stable].max()))
+    assert stable.sum() >= n_ref // 3
+    assert err[stable].max() <= 1e-5
     sc.close()
 
 
