@@ -150,23 +150,12 @@ def main():
 
         def retrieve():
             if world > 1:
-                # all-gather of the node tables (counts, then padded payload) -> global table on every rank
-                n_loc = torch.tensor([feats.shape[0]], device=device, dtype=torch.int64)
-                counts = [torch.zeros_like(n_loc) for _ in range(world)]
-                dist.all_gather(counts, n_loc)
-                counts = [int(c.item()) for c in counts]
-                nmax = max(max(counts), 1)
-                pay = torch.zeros((nmax, D + 1), device=device, dtype=torch.float64)
-                if feats.shape[0]:
-                    pay[: feats.shape[0], :D] = torch.from_numpy(feats).to(device)
-                    pay[: feats.shape[0], D] = torch.from_numpy((rooms + rank * n_rooms).astype(np.float64)).to(device)
-                allp = [torch.empty_like(pay) for _ in range(world)]
-                dist.all_gather(allp, pay)
-                tab = torch.cat([allp[r][: counts[r]] for r in range(world)]).cpu().numpy()
-                g_feats, g_rooms = np.ascontiguousarray(tab[:, :D]), tab[:, D].astype(np.int32)
-                qs = range(rank, Q, world)                       # this rank's share of the queries
-                rl = [[r + rank * n_rooms for r in q_rooms[q]] for q in qs]
-                tq = np.ascontiguousarray(text[list(qs)])
+                # all-gather of the node tables over RCCL -> global table on every rank (holoagent_amd/dist.py)
+                from holoagent_amd.dist import gather_node_tables, shard_queries
+                g_feats, g_rooms, _node_off, room_off = gather_node_tables(feats, rooms, n_rooms, device)
+                qs = shard_queries(Q, rank, world)               # this rank's share of the queries
+                rl = [[r + int(room_off[rank]) for r in q_rooms[q]] for q in qs]
+                tq = np.ascontiguousarray(text[qs])
             else:
                 g_feats, g_rooms, rl, tq = feats, rooms, q_rooms, text
             if g_feats.shape[0] == 0:

@@ -63,6 +63,7 @@ _SIGS = {
     "hmsg_get_instance_sizes": (C.c_int, [_P, _P]),
     "hmsg_get_instance_points": (C.c_int, [_P, _P]),
     "hmsg_get_instance_boxes": (C.c_int, [_P, _P]),
+    "hmsg_denoise_instances": (C.c_int, [_P, C.c_double, C.c_int32]),
     "hmsg_pool_instances": (C.c_int, [_P]),
     "hmsg_get_instance_feats": (C.c_int, [_P, _P]),
     "hmsg_index_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _P, C.c_int32, _P, C.POINTER(_P)]),
@@ -248,6 +249,9 @@ class Scene:
         if n:
             self._ck(self.L.c.hmsg_get_instance_boxes(self.h, _ptr(out)))
         return out
+
+    def denoise_instances(self, eps=0.05, min_points=10):
+        self._ck(self.L.c.hmsg_denoise_instances(self.h, float(eps), int(min_points)))
 
     def pool_instances(self):
         self._ck(self.L.c.hmsg_pool_instances(self.h))

@@ -354,6 +354,11 @@ int hmsg_get_instance_points(const hmsg_t* hc, double* xyz) {
     });
 }
 
+int hmsg_denoise_instances(hmsg_t* h, double eps, int32_t min_points) {
+    if (!h) return HMSG_ERR_INVALID;
+    return guard(h, [&] { hmsg_denoise_inst(h, eps, min_points); });
+}
+
 int hmsg_get_instance_boxes(const hmsg_t* hc, double* boxes) {
     hmsg_ctx* h = const_cast<hmsg_ctx*>(hc);
     if (!h) return HMSG_ERR_INVALID;

@@ -104,12 +104,14 @@ __global__ void k_db_init_parent(long long NC, int* __restrict__ parent) {
 // parent[] is updated by CAS from other workgroups while we walk it: read it with agent-scope atomic loads
 // (served by L2, never by this CU's non-coherent L1) or a retry loop could spin on a stale line.
 __device__ __forceinline__ int uf_find(int* parent, int x) {
-    int p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (p != x) {
+    for (;;) {
+        int p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p == x) return x;
+        int gp = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // path halving: any ancestor is a valid parent, so a racy store only shortens chains
+        if (gp != p) __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         x = p;
-        p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    return x;
 }
 __device__ __forceinline__ void uf_union(int* parent, int a, int b) {
     for (;;) {

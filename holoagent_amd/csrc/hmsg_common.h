@@ -256,4 +256,5 @@ static inline void hmsg_dump(const char* name, const void* dev, size_t bytes, hi
 void hmsg_build_map(hmsg_ctx* h);       // hmsg_map.hip
 void hmsg_fuse(hmsg_ctx* h);            // hmsg_fuse.hip
 void hmsg_merge(hmsg_ctx* h);           // hmsg_merge.hip
+void hmsg_denoise_inst(hmsg_ctx* h, double eps, int min_points);   // hmsg_merge.hip
 void hmsg_pool(hmsg_ctx* h);            // hmsg_pool.hip

@@ -548,3 +548,36 @@ void hmsg_merge(hmsg_ctx* h) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->merged = true;
 }
+
+// A10 first step (graph.py:1589-1591): every instance re-denoised with pcd_denoise_dbscan(eps, min_points),
+// in place (the pooled features were computed before, as in the reference).
+void hmsg_denoise_inst(hmsg_ctx* h, double eps, int min_points) {
+    HMSG_REQUIRE(h->merged, HMSG_ERR_INVALID, "hmsg_denoise_instances: run hmsg_merge_instances first");
+    const int K = (int)h->inst.off.size() - 1;
+    if (K <= 0 || h->inst.total == 0) return;
+    CloudOps ops;
+    ops.s = h->stream;
+    std::vector<SegDesc> segs(K);
+    for (int k = 0; k < K; ++k) {
+        segs[k].pt_base = h->inst.off[k];
+        segs[k].n = (int)(h->inst.off[k + 1] - h->inst.off[k]);
+    }
+    ops.bounds(h->inst.pts.p, segs);
+    DevBuf<double> out;
+    out.alloc((size_t)h->inst.total * 3);
+    std::vector<DbscanResult> res;
+    long long total = ops.dbscan_keep_largest(h->inst.pts.p, segs, eps, min_points, out.p, res);
+    std::swap(out.p, h->inst.pts.p);
+    std::swap(out.n, h->inst.pts.n);
+    h->inst.off.assign(1, 0);
+    h->inst.box.clear();
+    long long acc = 0;
+    for (int k = 0; k < K; ++k) {
+        acc += res[k].n_out;
+        h->inst.off.push_back(acc);
+        for (int a = 0; a < 3; ++a) h->inst.box.push_back(res[k].mn[a]);
+        for (int a = 0; a < 3; ++a) h->inst.box.push_back(res[k].mx[a]);
+    }
+    h->inst.total = total;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+}

@@ -1,0 +1,582 @@
+"""Host-side mirror of the reference's `Graph` (fsr_vln/memory/hmsg/graph/graph.py:77) on top of the C ABI.
+
+Same public surface as the reference for the mapping / retrieval path -- method names, argument meaning,
+return shapes, `print` + `return None` error convention -- so the reference apps
+(application/.../semantic_scene_reconstruction.py:109-127, visualize_query_graph_icra_*.py:179-265,
+nav_agent/.../goal_pose_publisher.py:75-221) run with a one-line import change.
+
+What runs where: everything between the encoders' outputs and the pooled instance embeddings, plus
+retrieval, runs in libhmsg (HIP).  This file only orchestrates, assembles the node objects (A8 floors,
+A10 object->room/view, A11 node/edge records + on-disk layout) and parses query triples.  Out of scope
+(SURVEY section 2): GPT/LLM parsing and slow reasoning, navigation graph, room segmentation by OpenCV
+watershed (rooms are an input: `set_rooms`), visualisation.
+
+Collaborators (the same the reference constructs in Graph.__init__, graph.py:98-219), injected so that no
+encoder package is needed to import this module:
+    dataset[i] -> (rgb PIL/array, depth u16 PIL/array, pose 4x4 f64, _, K 3x3)   (horizon.py:217-268)
+    encoders.extract(rgb_array) -> dict(masks bool [M,H,W], f_g [1,D], f_masked [M,D], f_crop [M,D])
+        = the encoder half of extract_feats_per_pixel (sam_clip_feats_extractor.py:117-158)
+    encoders.encode_text(list[str]) -> float32 [n, D] unit rows  (clip_utils.py:143-162)
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import List, Sequence
+
+import numpy as np
+from scipy.ndimage import gaussian_filter1d
+from scipy.signal import find_peaks
+from scipy.spatial import cKDTree
+
+from ._lib import HmsgLib, NodeIndex, Scene, lib as _default_lib
+
+CLIP_DIM = {"ViT-B-32": 512, "ViT-L-14": 768, "ViT-H-14": 1024}     # utils/constants.py:3-7
+TEXT_TEMPLATES = ["{}", "a photo of {} in the scene."]                 # clip_utils.py:262-265
+
+
+def _get(cfg, path, default=None):
+    cur = cfg
+    for k in path.split("."):
+        if cur is None:
+            return default
+        if isinstance(cur, dict):
+            cur = cur.get(k, None)
+        else:
+            cur = getattr(cur, k, None)
+    return default if cur is None else cur
+
+
+class _Pcd:
+    """Minimal stand-in for the o3d PointCloud attributes callers read (.points, get_center())."""
+
+    def __init__(self, pts=None):
+        self.points = np.zeros((0, 3)) if pts is None else np.asarray(pts, dtype=np.float64)
+
+    def get_center(self):
+        return self.points.mean(axis=0)
+
+    def is_empty(self):
+        return len(self.points) == 0
+
+
+def _write_ply(path, pts):
+    pts = np.asarray(pts, dtype=np.float64).reshape(-1, 3)
+    with open(path, "wb") as f:
+        f.write(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty double x\nproperty double y\n"
+                 "property double z\nend_header\n" % len(pts)).encode())
+        f.write(pts.astype("<f8").tobytes())
+
+
+def _read_ply(path):
+    with open(path, "rb") as f:
+        n, props = 0, []
+        while True:
+            line = f.readline().decode().strip()
+            if line.startswith("element vertex"):
+                n = int(line.split()[-1])
+            elif line.startswith("property"):
+                props.append(line.split()[1:])
+            elif line == "end_header":
+                break
+        dt = np.dtype([(p[1], {"double": "<f8", "float": "<f4", "uchar": "u1"}[p[0]]) for p in props])
+        arr = np.frombuffer(f.read(n * dt.itemsize), dtype=dt, count=n)
+    return np.stack([arr["x"], arr["y"], arr["z"]], axis=1).astype(np.float64)
+
+
+class Floor:   # graph/floor.py:10-67
+    def __init__(self, floor_id, name=None):
+        self.floor_id, self.name = floor_id, name
+        self.rooms, self.pcd, self.vertices = [], _Pcd(), np.zeros((8, 3))
+        self.floor_height = self.floor_zero_level = None
+
+    def add_room(self, room):
+        self.rooms.append(room)
+
+    def save(self, path):
+        _write_ply(os.path.join(path, str(self.floor_id) + ".ply"), self.pcd.points)
+        meta = dict(floor_id=self.floor_id, name=self.name, rooms=[r.room_id for r in self.rooms],
+                    vertices=np.asarray(self.vertices).tolist(), floor_height=self.floor_height,
+                    floor_zero_level=self.floor_zero_level)
+        json.dump(meta, open(os.path.join(path, str(self.floor_id) + ".json"), "w"))
+
+    def load(self, path):
+        self.pcd = _Pcd(_read_ply(os.path.join(path, str(self.floor_id) + ".ply")))
+        m = json.load(open(os.path.join(path, str(self.floor_id) + ".json")))
+        self.name, self.rooms, self.vertices = m["name"], m["rooms"], np.asarray(m["vertices"])
+        self.floor_height, self.floor_zero_level = m["floor_height"], m["floor_zero_level"]
+
+
+class Room:    # graph/room.py:15-60, 309-374
+    def __init__(self, room_id, floor_id, name=None):
+        self.room_id, self.floor_id, self.name = room_id, floor_id, name
+        self.objects, self.views, self.pcd, self.vertices = [], [], _Pcd(), np.zeros((0, 2))
+        self.embeddings, self.clip_embeddings, self.represent_images, self.sample_images = [], [], [], []
+        self.room_height = self.room_zero_level = None
+        self.object_counter = 0
+
+    def add_object(self, obj):
+        self.objects.append(obj)
+
+    def infer_room_type_from_view_embedding(self, default_room_types, text_feats):
+        """room.py:131-172: per view arg-max over room-type text features, majority vote, smallest type id on ties."""
+        if len(self.embeddings) == 0:
+            return None
+        votes = np.argmax(np.dot(np.stack(self.embeddings), np.asarray(text_feats).T), axis=1)
+        cnt = np.bincount(votes, minlength=len(default_room_types))
+        self.name = default_room_types[int(np.argmax(cnt))]
+        return self.name
+
+    def save(self, path):
+        _write_ply(os.path.join(path, str(self.room_id) + ".ply"), self.pcd.points)
+        meta = dict(room_id=self.room_id, name=self.name, floor_id=self.floor_id,
+                    objects=[o.object_id for o in self.objects],
+                    views=[v.view_id if hasattr(v, "view_id") else v for v in self.views],
+                    vertices=np.asarray(self.vertices).tolist(), room_height=self.room_height,
+                    room_zero_level=self.room_zero_level, embeddings=[np.asarray(e).tolist() for e in self.embeddings],
+                    represent_images=self.represent_images, sample_images=self.sample_images,
+                    clip_embeddings=[np.asarray(e).tolist() for e in self.clip_embeddings])
+        json.dump(meta, open(os.path.join(path, str(self.room_id) + ".json"), "w"))
+
+    def load_new(self, path):
+        self.pcd = _Pcd(_read_ply(os.path.join(path, str(self.room_id) + ".ply")))
+        m = json.load(open(os.path.join(path, str(self.room_id) + ".json")))
+        self.name, self.floor_id, self.vertices = m["name"], m["floor_id"], np.asarray(m["vertices"])
+        self.room_height, self.room_zero_level = m["room_height"], m["room_zero_level"]
+        self.embeddings = [np.asarray(i) for i in m["embeddings"]]
+        self.represent_images, self.sample_images = m["represent_images"], m["sample_images"]
+        self.clip_embeddings = [np.asarray(i) for i in m["clip_embeddings"]]
+        self.views = m["views"]
+
+
+class Object:  # graph/object.py:9-106
+    def __init__(self, object_id, room_id, name=None):
+        self.object_id, self.room_id, self.name = object_id, room_id, name
+        self.pcd, self.vertices, self.embedding = _Pcd(), None, None
+        self.view_ids, self.best_view_id = [], None
+
+    def save(self, path):
+        _write_ply(os.path.join(path, str(self.object_id) + ".ply"), self.pcd.points)
+        meta = dict(object_id=self.object_id, vertices=np.asarray(self.vertices).tolist(), room_id=self.room_id,
+                    name=self.name, embedding=self.embedding.tolist() if self.embedding is not None else "",
+                    view_ids=self.view_ids, best_view_id=self.best_view_id)
+        json.dump(meta, open(os.path.join(path, str(self.object_id) + ".json"), "w"))
+
+    def load_new(self, path):
+        self.pcd = _Pcd(_read_ply(os.path.join(path, str(self.object_id) + ".ply")))
+        m = json.load(open(os.path.join(path, str(self.object_id) + ".json")))
+        self.vertices, self.room_id, self.name = np.asarray(m["vertices"]), m["room_id"], m["name"]
+        self.embedding = np.asarray(m["embedding"]) if m["embedding"] != "" else None   # float64 after load (:88-89)
+        self.view_ids, self.best_view_id = m["view_ids"], m["best_view_id"]
+
+
+class View:    # graph/view.py:36-103
+    def __init__(self, view_id, room_id, img_id=None, name=None):
+        self.view_id, self.room_id, self.img_id, self.name = view_id, room_id, img_id, name
+        self.object_ids, self.text_discription, self.img_path = [], [], None
+
+    def save(self, path):
+        meta = dict(view_id=self.view_id, room_id=self.room_id, img_id=self.img_id, object_ids=self.object_ids,
+                    img_path=self.img_path, text_discription=self.text_discription)
+        json.dump(meta, open(os.path.join(path, str(self.view_id) + ".json"), "w"))
+
+    def load(self, path):
+        m = json.load(open(os.path.join(path, str(self.view_id) + ".json")))
+        self.room_id, self.img_id, self.object_ids = m["room_id"], m["img_id"], m["object_ids"]
+        self.img_path, self.text_discription = m.get("img_path"), m.get("text_discription", [])
+
+
+def check_object_in_view(img_w, img_h, K, cam_pose_inv, pts, min_visible_ratio=0.5, max_depth=10.0):
+    """utils/graph_utils.py:95-157."""
+    if pts.shape[0] == 0:
+        return False, np.inf
+    cam = (cam_pose_inv @ np.hstack([pts, np.ones((pts.shape[0], 1))]).T).T[:, :3]
+    cam = cam[cam[:, 2] > 0]
+    if cam.shape[0] == 0:
+        return False, np.inf
+    px = (K @ cam.T).T
+    px = px[:, :2] / px[:, 2:3]
+    inside = (px[:, 0] >= 0) & (px[:, 0] < img_w) & (px[:, 1] >= 0) & (px[:, 1] < img_h)
+    if not np.any(inside) or np.sum(inside) / pts.shape[0] < min_visible_ratio:
+        return False, np.inf
+    md = float(np.mean(cam[inside, 2]))
+    return (md <= max_depth), md
+
+
+def find_intersection_share(map_points, obj_points, radius=0.05):
+    """utils/graph_utils.py:160-189."""
+    if map_points.shape[0] == 0 or obj_points.shape[0] == 0:
+        return 0
+    _, idx = cKDTree(obj_points).query(map_points, k=1, distance_upper_bound=radius, p=2, workers=-1)
+    return int((idx != obj_points.shape[0]).sum()) / obj_points.shape[0]
+
+
+class Graph:
+    def __init__(self, cfg, dataset=None, encoders=None, lib: HmsgLib | None = None):
+        self.cfg = cfg
+        self.L = lib or _default_lib()
+        self.dataset, self.encoders = dataset, encoders
+        self.floors: List[Floor] = []
+        self.rooms: List[Room] = []
+        self.objects: List[Object] = []
+        self.views: List[View] = []
+        self.mask_pcds, self.mask_feats, self.full_feats_array = [], [], []
+        self.full_pcd = _Pcd()
+        clip_type = str(_get(cfg, "models.clip.type", "ViT-B/32")).replace("/", "-")
+        self.clip_feat_dim = int(_get(cfg, "models.clip.feat_dim", CLIP_DIM.get(clip_type, 512)))
+        self.build_mode = _get(cfg, "pipeline") is not None           # graph.py:166-168
+        self.scene: Scene | None = None
+        self._index: NodeIndex | None = None
+        self._text_cache = {}
+        self.graph_path = _get(cfg, "main.graph_path")
+        self._label_feats = None       # (text feats, class names) for identify_object
+
+    # ------------------------------------------------------------------ text features
+    def get_text_feats_multiple_templates(self, words: Sequence[str]) -> np.ndarray:
+        """clip_utils.py:257-349: mean over the 2 templates of unit vectors, NOT re-normalised."""
+        miss = [w for w in words if w not in self._text_cache]
+        if miss:
+            prompts = [t.format(w) for w in miss for t in TEXT_TEMPLATES]
+            f = np.asarray(self.encoders.encode_text(prompts), dtype=np.float32)
+            f = f.reshape(len(miss), len(TEXT_TEMPLATES), -1).mean(axis=1)
+            for w, v in zip(miss, f):
+                self._text_cache[w] = v
+        return np.stack([self._text_cache[w] for w in words]).astype(np.float32)
+
+    # ------------------------------------------------------------------ build: graph.py:262-491
+    def create_feature_map(self, save_path=None):
+        if self.dataset is None:
+            print("No dataset loaded")
+            return
+        p = lambda k, d=None: _get(self.cfg, "pipeline." + k, d)
+        skip = int(p("skip_frames", 1))
+        ids = list(range(0, len(self.dataset), skip))
+        first = self.dataset[ids[0]]
+        depth0 = np.asarray(first[1])
+        H, W = depth0.shape[:2]
+        merge = {"sequential": 0, "hierarchical": 1}[str(p("merge_type", "sequential"))]
+        self.scene = Scene(lib_=self.L, device_id=int(_get(self.cfg, "main.device_id", 0)), feat_dim=self.clip_feat_dim,
+                           height=H, width=W, max_frames=len(ids), max_masks=int(p("max_masks", 64)),
+                           voxel_size=float(p("voxel_size", 0.05)), init_overlap_thresh=float(p("init_overlap_thresh", 0.75)),
+                           overlap_thresh_factor=float(p("overlap_thresh_factor", 0.025)), iou_thresh=float(p("iou_thresh", 0.05)),
+                           clip_masked_weight=float(p("clip_masked_weight", 0.4418)),
+                           max_mask_distance=float(p("max_mask_distance", 10000)), merge_type=merge)
+        sc = self.scene
+        B = 32
+        self._poses, self._K = [], None
+        for b0 in range(0, len(ids), B):                                  # loop A (graph.py:339-345)
+            fr = [self.dataset[i] for i in ids[b0:b0 + B]]
+            rgb = np.ascontiguousarray(np.stack([np.asarray(f[0], dtype=np.uint8)[..., :3] for f in fr]))
+            dep = np.ascontiguousarray(np.stack([np.asarray(f[1]).astype(np.uint16) for f in fr]))
+            pose = np.ascontiguousarray(np.stack([np.asarray(f[2], dtype=np.float64) for f in fr]))
+            self._K = np.ascontiguousarray(np.asarray(fr[0][4], dtype=np.float64))
+            self._poses.extend(list(pose))
+            sc.add_frames(rgb, dep, pose, self._K)
+        sc.finalize_map()
+        self.full_pcd = _Pcd(sc.map_points())
+        M = None
+        n_done = 0
+        for b0 in range(0, len(ids), B):                                  # loop B (graph.py:373-411)
+            outs = [self.encoders.extract(np.asarray(self.dataset[i][0])) for i in ids[b0:b0 + B]]
+            M = M or max(o["masks"].shape[0] for o in outs)
+            def pad(a, rows):
+                out = np.zeros((rows,) + a.shape[1:], a.dtype)
+                out[: a.shape[0]] = a
+                return out
+            masks = np.ascontiguousarray(np.stack([pad(o["masks"].astype(np.uint8), M) for o in outs]))
+            fg = np.ascontiguousarray(np.stack([np.asarray(o["f_g"], np.float32).reshape(-1) for o in outs]))
+            fm = np.ascontiguousarray(np.stack([pad(np.asarray(o["f_masked"], np.float32), M) for o in outs]))
+            fc = np.ascontiguousarray(np.stack([pad(np.asarray(o["f_crop"], np.float32), M) for o in outs]))
+            sc.add_frame_features(n_done, masks, fg, fm, fc)
+            n_done += len(outs)
+        sc.fuse_frames()
+        self.full_feats_array = sc.map_feats()
+        sc.merge_instances()
+        sc.pool_instances()
+        self.mask_feats = list(sc.instance_feats())
+        self.mask_pcds = [_Pcd(x) for x in sc.instances()]
+        self._frame_ids = ids
+        assert len(self.mask_pcds) == len(self.mask_feats)
+
+    # ------------------------------------------------------------------ A8: graph.py:624-787
+    def segment_floors_manually(self, path=None):
+        pts = self.full_pcd.points          # already one point per 5 cm voxel (voxel_size 0.05)
+        y = pts[:, 1]
+        bins = int(np.abs(np.max(y) - np.min(y)) / 0.01)
+        hist = np.histogram(y, bins=bins)
+        smooth = gaussian_filter1d(hist[0], sigma=2)                       # int64 in, int64 out (hazard 17)
+        peaks, _ = find_peaks(smooth, distance=0.2 / 0.01, height=np.percentile(smooth, 90))
+        locs = hist[1][peaks]
+        # DBSCAN(eps=1, min_samples=1) on 1-D peak heights = chains of gaps <= 1 (graph.py:680-683)
+        order = np.argsort(locs)
+        labels = np.zeros(len(locs), dtype=int)
+        lab = 0
+        for a, b in zip(order[:-1], order[1:]):
+            if locs[b] - locs[a] > 1:
+                lab += 1
+            labels[b] = lab
+        # sklearn numbers clusters by first appearance in input order
+        remap, nxt = {}, 0
+        for l in labels:
+            if l not in remap:
+                remap[l] = nxt
+                nxt += 1
+        labels = np.array([remap[l] for l in labels], dtype=int)
+        n_lab = len(np.unique(labels))
+        clustered = []
+        for i in range(n_lab):
+            pk = peaks[labels == i]
+            take = 1 if (i == 0 or i == n_lab - 1) else 2
+            top = pk[np.argsort(smooth[pk])[-take:]].tolist()
+            clustered.extend(hist[1][t] for t in top)
+        clustered = np.sort(clustered)
+        adjusted = []
+        for i in range(len(clustered) - 1):
+            adjusted.append(clustered[i])
+            if clustered[i + 1] - clustered[i] >= 2.5:
+                adjusted.append(clustered[i + 1] - 0.2)
+        if len(clustered):
+            adjusted.append(clustered[-1])
+        floors = [[adjusted[i], adjusted[i + 1]] for i in range(len(adjusted) - 1)]
+        if not floors:
+            floors.append([float(hist[1].min()), float(hist[1].max())])
+        floors[0][0] = (floors[0][0] + np.min(y)) / 2
+        floors[-1][1] = np.max(y)
+        for i, (lo, hi) in enumerate(floors):
+            fl = Floor(str(i), name="floor_" + str(i))
+            sel = pts[(y >= lo) & (y <= hi)]
+            fl.pcd = _Pcd(sel)
+            if len(sel):
+                mn, mx = sel.min(0), sel.max(0)
+                ex = mx - mn     # Open3D AABB corner order
+                fl.vertices = np.array([mn, mn + [ex[0], 0, 0], mn + [0, ex[1], 0], mn + [0, 0, ex[2]], mx,
+                                        mn + [0, ex[1], ex[2]], mn + [ex[0], 0, ex[2]], mn + [ex[0], ex[1], 0]])
+                fl.floor_zero_level = float(np.min(sel[:, 1]))
+            else:
+                fl.floor_zero_level = float(lo)
+            fl.floor_height = float(hi - fl.floor_zero_level)
+            self.floors.append(fl)
+        return floors
+
+    # ------------------------------------------------------------------ A9 input
+    def set_rooms(self, rooms: Sequence[dict]):
+        """Rooms are an input (OpenCV watershed of graph.py:920-1189 is out of scope):
+        dict(floor=int, vertices=[[x,z]...], name=str|None, view_frames=[frame idx...], view_embeddings=[[D]...])."""
+        for spec in rooms:
+            fl = self.floors[spec["floor"]]
+            room = Room("%s_%d" % (fl.floor_id, len(fl.rooms)), fl.floor_id, name=spec.get("name"))
+            room.vertices = np.asarray(spec["vertices"], dtype=np.float64)
+            room.room_zero_level, room.room_height = fl.floor_zero_level, fl.floor_height
+            room.embeddings = [np.asarray(e) for e in spec.get("view_embeddings", [])]
+            for k, fidx in enumerate(spec.get("view_frames", [])):
+                v = View("%s_%d" % (room.room_id, len(self.views)), room.room_id, img_id=int(fidx))
+                room.views.append(v)
+                self.views.append(v)
+            fl.add_room(room)
+            self.rooms.append(room)
+
+    def set_label_feats(self, text_feats, classes):
+        self._label_feats = (np.asarray(text_feats, np.float32), list(classes))
+
+    # ------------------------------------------------------------------ A10: graph.py:1582-1736
+    def segment_hmsg_objects(self, save_dir=None):
+        if self.scene is not None:
+            self.scene.denoise_instances(0.05, 10)                          # graph.py:1589-1591 on device
+            self.mask_pcds = [_Pcd(x) for x in self.scene.instances()]
+        text_feats, classes = self._label_feats if self._label_feats is not None else (None, None)
+        names = None
+        if text_feats is not None and len(self.mask_feats):
+            emb = np.stack([np.asarray(f).reshape(-1) for f in self.mask_feats]).astype(np.float32)
+            ix = NodeIndex(np.ascontiguousarray(text_feats), np.zeros(len(classes), np.int32), lib_=self.L)
+            names = np.argmax(ix.similarity(emb), axis=1)                  # identify_object (graph.py:1441-1454)
+            ix.close()
+        margin = 0.2
+        for fl in self.floors:
+            for i, pcd in enumerate(self.mask_pcds):
+                pts = pcd.points
+                if len(pts) < 10:
+                    continue
+                if not (pts[:, 1].min() > fl.floor_zero_level - margin and
+                        pts[:, 1].max() < fl.floor_zero_level + fl.floor_height + margin):
+                    continue
+                if not fl.rooms:
+                    continue
+                xz = pts[:, [0, 2]]
+                assoc = [find_intersection_share(r.vertices, xz, 0.2) for r in fl.rooms]
+                if np.sum(assoc) == 0:
+                    assoc = [-np.linalg.norm(np.mean(r.vertices, axis=0) - np.mean(xz, axis=0)) for r in fl.rooms]
+                room = fl.rooms[int(np.argmax(assoc))]
+                obj = Object(room.room_id + "_" + str(room.object_counter), room.room_id)
+                room.object_counter += 1
+                obj.name = classes[int(names[i])] if names is not None else "object"
+                obj.pcd, obj.vertices, obj.embedding = pcd, xz, np.asarray(self.mask_feats[i]).reshape(-1)
+                best, best_d = None, float("inf")
+                for v in room.views:
+                    if self.dataset is None or v.img_id is None:
+                        continue
+                    img, _, pose, _, _ = self.dataset[v.img_id]
+                    a = np.asarray(img)
+                    ok, md = check_object_in_view(a.shape[1], a.shape[0], self._K, np.linalg.inv(pose), pts)
+                    if ok:
+                        obj.view_ids.append(v.view_id)
+                        v.object_ids.append(obj.object_id)
+                        v.text_discription.append(obj.name)
+                        if md < best_d:
+                            best_d, best = md, v.view_id
+                obj.best_view_id = best
+                room.add_object(obj)
+                self.objects.append(obj)
+        self._index = None
+
+    def build_hier_multimodal_scene_graph(self, save_path=None, rooms: Sequence[dict] | None = None):
+        """graph.py:2033-2076 (navigation graph omitted, rooms supplied)."""
+        self.segment_floors_manually(save_path)
+        if rooms is not None:
+            self.set_rooms(rooms)
+        self.segment_hmsg_objects(save_path)
+        if save_path is not None:
+            self.save_hmsg_graph(os.path.join(save_path, "graph"))
+
+    # ------------------------------------------------------------------ A11 persistence: graph.py:1801-1987
+    def save_hmsg_graph(self, path):
+        for sub, nodes in (("floors", self.floors), ("rooms", self.rooms), ("objects", self.objects), ("views", self.views)):
+            os.makedirs(os.path.join(path, sub), exist_ok=True)
+            for n in nodes:
+                n.save(os.path.join(path, sub))
+
+    def save_full_pcd(self, path):
+        os.makedirs(path, exist_ok=True)
+        _write_ply(os.path.join(path, "full_pcd.ply"), self.full_pcd.points)
+
+    def save_full_pcd_feats(self, path):
+        os.makedirs(path, exist_ok=True)
+        np.save(os.path.join(path, "mask_feats.npy"), np.stack([np.asarray(f).reshape(-1) for f in self.mask_feats]))
+        np.save(os.path.join(path, "full_feats.npy"), np.asarray(self.full_feats_array))
+
+    def save_masked_pcds(self, path, state="both"):
+        os.makedirs(os.path.join(path, "objects"), exist_ok=True)
+        for i, pcd in enumerate(self.mask_pcds):
+            _write_ply(os.path.join(path, "objects", "pcd_%d.ply" % i), pcd.points)
+
+    def load_hmsg_graph(self, path):
+        if not os.path.isdir(path):
+            print("graph not found in {}".format(path))
+            return None
+        self.graph_path = path
+        self.floors, self.rooms, self.objects, self.views = [], [], [], []
+        for f in sorted(x for x in os.listdir(os.path.join(path, "floors")) if x.endswith(".ply")):
+            fl = Floor(f.split(".")[0], name="floor_" + f.split(".")[0])
+            fl.load(os.path.join(path, "floors"))
+            self.floors.append(fl)
+        for f in sorted(x for x in os.listdir(os.path.join(path, "rooms")) if x.endswith(".ply")):   # lexicographic (:1931)
+            rid = f.split(".")[0]
+            room = Room(rid, rid.split("_")[0])
+            room.load_new(os.path.join(path, "rooms"))
+            self.rooms.append(room)
+            fl = self.floors[int(room.floor_id)]
+            if fl.rooms and isinstance(fl.rooms[0], str):
+                fl.rooms = []
+            fl.rooms.append(room)
+        for f in sorted(x for x in os.listdir(os.path.join(path, "objects")) if x.endswith(".ply")):
+            oid = f.split(".")[0]
+            room_id = "_".join(oid.split("_")[:2])
+            parent = next((r for r in self.rooms if r.room_id == room_id), None)
+            assert parent is not None, f"Couldn't find the room with room id {room_id}"
+            obj = Object(oid, room_id, name="object_" + oid)
+            obj.load_new(os.path.join(path, "objects"))
+            obj.room_id = room_id
+            self.objects.append(obj)
+            parent.add_object(obj)
+        for f in sorted(os.listdir(os.path.join(path, "views"))):
+            vid = f.split(".")[0]
+            v = View(vid, "_".join(vid.split("_")[:2]), name="view_" + vid)
+            v.load(os.path.join(path, "views"))
+            v.room_id = "_".join(vid.split("_")[:2])
+            self.views.append(v)
+        self._index = None
+        return self
+
+    load_graph = load_hmsg_graph
+
+    # ------------------------------------------------------------------ room names: graph.py:2129-2187
+    def generate_room_names(self, generate_method="view_embedding", default_room_types=None):
+        types = list(default_room_types or [])
+        tf = self.get_text_feats_multiple_templates(types)
+        for r in self.rooms:
+            r.infer_room_type_from_view_embedding(types, tf)
+
+    def set_room_names(self, room_names):
+        for r, n in zip(self.rooms, room_names):
+            r.name = n
+
+    # ------------------------------------------------------------------ A12 queries
+    def _node_index(self):
+        if self._index is None:
+            emb = np.stack([np.asarray(o.embedding, dtype=np.float64).reshape(-1) for o in self.objects])
+            rid = {r.room_id: i for i, r in enumerate(self.rooms)}
+            self._index = NodeIndex(emb, np.array([rid[o.room_id] for o in self.objects], np.int32), lib_=self.L)
+        return self._index
+
+    def query_floor(self, query, query_method="clip"):
+        """graph.py:2216-2257."""
+        order = np.argsort([f.floor_zero_level for f in self.floors])
+        try:
+            return order[int(query) - 1]
+        except BaseException:
+            t = self.get_text_feats_multiple_templates([query])
+            names = self.get_text_feats_multiple_templates(["floor " + str(i) for i in range(len(self.floors))])
+            return order[np.argsort(np.dot(t, names.T)[0])[::-1][0]]
+
+    def query_hmsg_room(self, query, floor_id=-1, query_method="view_embedding"):
+        """graph.py:3164-3272."""
+        valid = query is not None and query != "" and "unknown" not in query.lower()
+        t = self.get_text_feats_multiple_templates([query])
+        rooms = self.rooms if floor_id == -1 else self.floors[floor_id].rooms
+        if query_method == "label" and valid:
+            for r in rooms:
+                assert r.name is not None, "The name attribute for the room has not been generated"
+            sim = np.dot(t, self.get_text_feats_multiple_templates([r.name for r in rooms]).T)
+            order = np.argsort(sim[0])[::-1]
+            keep = [order[0]] + [i for i in order[1:] if np.abs(sim[0, i] - sim[0, order[0]]) < 1e-3]
+            ids = {rooms[i].room_id for i in keep}
+            return [i for i, r in enumerate(rooms) if r.room_id in ids]
+        sims = {}
+        for r in rooms:
+            sims[r.room_id] = np.max(np.dot(t, np.stack(r.embeddings).T))
+        ranked = {int(k.split("_")[-1]): v for k, v in sorted(sims.items(), key=lambda kv: kv[1], reverse=True)}
+        return list(ranked.keys())[: min(len(ranked), 5 if valid else 10)]
+
+    def query_hmsg_object(self, query, floor_id=-1, room_ids=[], query_method="clip", top_k=1, negative_prompt=[]):
+        """graph.py:3056-3162; the similarity GEMM, class arg-max and top-k run on the GPU."""
+        if query in negative_prompt:
+            qid, cats = negative_prompt.index(query), list(negative_prompt)
+        else:
+            qid, cats = 0, [query, *negative_prompt]
+        t = self.get_text_feats_multiple_templates(cats)
+        gl = {r.room_id: i for i, r in enumerate(self.rooms)}
+        if floor_id != -1:
+            rooms_global = [gl[self.floors[floor_id].rooms[i].room_id] for i in room_ids]
+        else:
+            rooms_global = list(room_ids)
+        idx, room, score = self._node_index().query_objects(t[None], np.array([qid], np.int32), [rooms_global], top_k,
+                                                            use_negatives=len(negative_prompt) > 0)
+        keep = idx[0] >= 0
+        back = {g: l for l, g in zip(room_ids, rooms_global)}
+        return [int(i) for i in idx[0][keep]], [back[int(r)] for r in room[0][keep]], [float(s) for s in score[0][keep]]
+
+    def query_hierarchy_protected_icra(self, query_instruction, top_k=1, use_gpt=False):
+        """graph.py:3483-3591 with the LLM parse replaced by a pre-parsed triple:
+        `query_instruction` = (floor_query | None, room_query, object_query)."""
+        floor_q, room_q, obj_q = query_instruction
+        negatives = ["wall"] if (room_q and "Exhibition" in room_q) else ["background"]
+        floor_id = self.query_floor(floor_q) if floor_q is not None else -1
+        room_ids = self.query_hmsg_room(room_q, floor_id=floor_id, query_method="label") if room_q is not None else []
+        obj_ids, room_ids2, scores = self.query_hmsg_object(obj_q, floor_id=floor_id, room_ids=room_ids, top_k=top_k,
+                                                            negative_prompt=negatives) if obj_q is not None else ([], [], [])
+        res = dict(room_query=room_q, object_query=obj_q, negative_labels=negatives, object_scores=scores,
+                   LLM_Parse_Time=0.0, FastMatching=0.0, ObjectInImageCheck=0.0, VLM_Rethinking=0.0, Re_Matching=0.0,
+                   Total_Time=0.0)
+        rooms = [self.floors[floor_id].rooms[k] for k in room_ids2] if floor_id != -1 else [self.rooms[k] for k in room_ids2]
+        return (self.floors[floor_id] if floor_id != -1 else None, rooms, [self.objects[i] for i in obj_ids], res)
+
+    query_hierarchy_protected = query_hierarchy_protected_icra

@@ -137,6 +137,10 @@ int hmsg_get_instance_boxes(const hmsg_t* h, double* boxes /*[N][6]: AABB min xy
 int hmsg_pool_instances(hmsg_t* h);
 int hmsg_get_instance_feats(const hmsg_t* h, float* feats /*[N][D]*/);
 
+/* ---- A10 first step: every instance through pcd_denoise_dbscan(eps=0.05, min_points=10)
+ * (graph.py:1589-1591), in place; call after hmsg_pool_instances like the reference does. */
+int hmsg_denoise_instances(hmsg_t* h, double eps, int32_t min_points);
+
 /* ---- A12: retrieval over a node table (graph.py:3056-3162 query_hmsg_object and the GEMV of
  * query_hmsg_room / query_floor).  A table is N node embeddings (f64, as after load_hmsg_graph:
  * object.py:88-89, or f32 right after build) with a parent (room) id per node. */

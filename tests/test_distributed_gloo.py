@@ -1,0 +1,72 @@
+"""N>1 path on CPU: 2 ranks (gloo) all-gather their node tables and answer their share of the queries on the
+global table; the union of the answers must equal the single-table answer bit for bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from tests import parity_common as PC
+
+pytestmark = pytest.mark.skipif(not os.path.exists(PC.EMU_PATH), reason="kernel simulator not built")
+
+
+def _tables(rank, D=24):
+    rng = np.random.Generator(np.random.PCG64(100 + rank))
+    n = 40 + 13 * rank
+    return rng.standard_normal((n, D)) * 0.1, rng.integers(0, 3, size=n).astype(np.int32), 3
+
+
+def _queries(D=24, Q=10):
+    rng = np.random.Generator(np.random.PCG64(7))
+    T = rng.standard_normal((Q, 2, D)).astype(np.float32)
+    lists = [sorted(rng.choice(6, size=2, replace=False).tolist()) for _ in range(Q)]
+    return T, lists
+
+
+def _worker(rank, world, port, out):
+    import torch.distributed as dist
+    from holoagent_amd._lib import HmsgLib, NodeIndex
+    from holoagent_amd.dist import gather_node_tables, shard_queries
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    feats, rooms, nr = _tables(rank)
+    g_feats, g_rooms, node_off, room_off = gather_node_tables(feats, rooms, nr)
+    T, lists = _queries()
+    mine = shard_queries(len(lists), rank, world)
+    ix = NodeIndex(g_feats, g_rooms, lib_=HmsgLib(PC.EMU_PATH))
+    idx, room, score = ix.query_objects(T[mine], np.zeros(len(mine), np.int32), [lists[q] for q in mine], 4)
+    ix.close()
+    np.savez(out % rank, idx=idx, score=score, mine=np.array(mine), node_off=node_off, n=g_feats.shape[0])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_allgather_retrieval(tmp_path):
+    import torch.multiprocessing as mp
+    from holoagent_amd._lib import HmsgLib, NodeIndex
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "r%d.npz")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    # single-table answer
+    tabs = [_tables(r) for r in range(2)]
+    feats = np.concatenate([t[0] for t in tabs])
+    rooms = np.concatenate([tabs[0][1], tabs[1][1] + 3]).astype(np.int32)
+    T, lists = _queries()
+    ix = NodeIndex(feats, rooms, lib_=HmsgLib(PC.EMU_PATH))
+    idx, room, score = ix.query_objects(T, np.zeros(len(lists), np.int32), lists, 4)
+    ix.close()
+    seen = set()
+    for r in range(2):
+        z = np.load(out % r)
+        assert int(z["n"]) == feats.shape[0]
+        assert list(z["node_off"]) == [0, tabs[0][0].shape[0], feats.shape[0]]
+        for j, q in enumerate(z["mine"]):
+            np.testing.assert_array_equal(z["idx"][j], idx[q])
+            np.testing.assert_array_equal(z["score"][j], score[q])
+            seen.add(int(q))
+    assert seen == set(range(len(lists)))

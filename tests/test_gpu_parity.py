@@ -90,3 +90,11 @@ def test_query_random_large(L):
         assert [cand[t] for t in top] == [int(v) for v in idx[q] if v >= 0]
         np.testing.assert_allclose(score[q][: len(top)], sc, rtol=0, atol=1e-12)
     ix.close()
+
+
+def test_graph_mirror_end_to_end(L, tmp_path):
+    """holoagent_amd.graph.Graph (mirror of the reference's Graph): build -> assemble -> save (reference layout)
+    -> load -> hierarchical query, on the GPU library."""
+    from tests.test_emu_parity import test_graph_end_to_end_tiny
+    test_graph_end_to_end_tiny.__wrapped__(L, tmp_path) if hasattr(test_graph_end_to_end_tiny, "__wrapped__") \
+        else test_graph_end_to_end_tiny(L, tmp_path)
