@@ -43,7 +43,8 @@ _SIGS = {
     "hmsg_reset": (C.c_int, [_P]),
     "hmsg_set_profiling": (C.c_int, [_P, C.c_int32]),
     "hmsg_profile_count": (C.c_int32, [_P]),
-    "hmsg_profile_entry": (C.c_int, [_P, C.c_int32, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "hmsg_profile_entry": (C.c_int, [_P, C.c_int32, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                     C.POINTER(C.c_double)]),
     "hmsg_synth_render": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, _P,
                                     C.c_int32, _P, _P, C.c_double, C.c_uint64, _P, _P, _P, _P]),
     "hmsg_add_frames": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P]),
@@ -162,14 +163,16 @@ class Scene:
         self._ck(self.L.c.hmsg_set_profiling(self.h, int(on)))
 
     def profile(self):
-        """{kernel name: (launches, total_ms)} from the HIP-event brackets recorded since the last reset."""
+        """{kernel name: (launches, total_ms, total algorithmic bytes or FLOP)} from the HIP-event brackets
+        recorded since the last reset."""
         out = {}
         for i in range(int(self.L.c.hmsg_profile_count(self.h))):
             name = C.create_string_buffer(64)
             n = C.c_int64()
             ms = C.c_double()
-            self._ck(self.L.c.hmsg_profile_entry(self.h, i, name, C.byref(n), C.byref(ms)))
-            out[name.value.decode()] = (int(n.value), float(ms.value))
+            wk = C.c_double()
+            self._ck(self.L.c.hmsg_profile_entry(self.h, i, name, C.byref(n), C.byref(ms), C.byref(wk)))
+            out[name.value.decode()] = (int(n.value), float(ms.value), float(wk.value))
         return out
 
     # ---- build

@@ -135,7 +135,8 @@ int hmsg_set_profiling(hmsg_t* h, int32_t on) {
     return HMSG_OK;
 }
 
-static void prof_aggregate(hmsg_ctx* h, std::vector<std::string>& names, std::vector<long long>& cnt, std::vector<double>& ms) {
+static void prof_aggregate(hmsg_ctx* h, std::vector<std::string>& names, std::vector<long long>& cnt, std::vector<double>& ms,
+                           std::vector<double>* work = nullptr) {
     (void)hipStreamSynchronize(h->stream);
     for (auto& e : h->prof.ev) {
         float t = 0.f;
@@ -147,9 +148,11 @@ static void prof_aggregate(hmsg_ctx* h, std::vector<std::string>& names, std::ve
             names.push_back(e.name);
             cnt.push_back(0);
             ms.push_back(0.0);
+            if (work) work->push_back(0.0);
         }
         cnt[k]++;
         ms[k] += t;
+        if (work) (*work)[k] += e.work;
     }
 }
 
@@ -162,16 +165,17 @@ int32_t hmsg_profile_count(hmsg_t* h) {
     return (int32_t)n.size();
 }
 
-int hmsg_profile_entry(hmsg_t* h, int32_t i, char* name, int64_t* launches, double* total_ms) {
+int hmsg_profile_entry(hmsg_t* h, int32_t i, char* name, int64_t* launches, double* total_ms, double* total_work) {
     if (!h || !name || !launches || !total_ms) return HMSG_ERR_INVALID;
     std::vector<std::string> n;
     std::vector<long long> c;
-    std::vector<double> m;
-    prof_aggregate(h, n, c, m);
+    std::vector<double> m, w;
+    prof_aggregate(h, n, c, m, &w);
     if (i < 0 || i >= (int32_t)n.size()) return HMSG_ERR_INVALID;
     snprintf(name, 64, "%s", n[i].c_str());
     *launches = c[i];
     *total_ms = m[i];
+    if (total_work) *total_work = w[i];
     return HMSG_OK;
 }
 

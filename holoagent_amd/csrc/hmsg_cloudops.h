@@ -20,10 +20,12 @@ struct DbscanResult {            // per segment
 
 struct CloudOps {
     hipStream_t s = nullptr;
+    Prof* prof = nullptr;        // optional live timing of the heavy kernels
     DevBuf<unsigned> scan_tmp;
     // scratch (grown on demand)
     DevBuf<unsigned> cnt, start, cursor, ord, minidx, firstidx, size, flags, pos, rootmin;
-    DevBuf<int> parent, label, segid, cellpos;
+    DevBuf<int> parent, label, segid, cellpos, corelist;
+    DevBuf<unsigned> d_ncore;
     DevBuf<double> cellbox;
     DevBuf<long long> cellid;
     DevBuf<unsigned char> core;

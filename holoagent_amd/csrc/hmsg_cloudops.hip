@@ -71,7 +71,8 @@ __global__ void k_db_core(const double* __restrict__ pts, long long N, const int
                           const DbSeg* __restrict__ segs, const long long* __restrict__ cellid,
                           const unsigned* __restrict__ cnt, const unsigned* __restrict__ start,
                           const unsigned* __restrict__ ord, double eps2, int minpts, unsigned char* __restrict__ core,
-                          unsigned* __restrict__ minidx) {
+                          unsigned* __restrict__ minidx, int* __restrict__ corecells, unsigned* __restrict__ ncore,
+                          int* __restrict__ cellpos, int* __restrict__ parent) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const DbSeg sg = segs[segid[i]];
@@ -93,12 +94,16 @@ __global__ void k_db_core(const double* __restrict__ pts, long long N, const int
         is_core = n >= minpts;
     }
     core[i] = is_core ? 1 : 0;
-    if (is_core) atomicMin(&minidx[c], (unsigned)(i - sg.pt_base));
-}
-
-__global__ void k_db_init_parent(long long NC, int* __restrict__ parent) {
-    long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < NC) parent[c] = (int)c;
+    if (is_core) {
+        // the first core point of a cell (it sees the initial INF) registers the cell in the compact list
+        unsigned old = atomicMin(&minidx[c], (unsigned)(i - sg.pt_base));
+        if (old == INF32) {
+            unsigned p = atomicAdd(ncore, 1u);
+            corecells[p] = (int)c;
+            cellpos[c] = (int)p;
+            parent[c] = (int)c;
+        }
+    }
 }
 
 // parent[] is updated by CAS from other workgroups while we walk it: read it with agent-scope atomic loads
@@ -127,22 +132,13 @@ __device__ __forceinline__ void uf_union(int* parent, int a, int b) {
     }
 }
 
-// compact list of the cells that hold at least one core point
-__global__ void k_db_corecells(long long NC, const unsigned* __restrict__ minidx, int* __restrict__ list, unsigned* __restrict__ n,
-                               int* __restrict__ cellpos) {
-    long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= NC || minidx[c] == INF32) return;
-    unsigned p = atomicAdd(n, 1u);
-    list[p] = (int)c;
-    cellpos[c] = (int)p;
-}
 // AABB of the core points of every core cell (one wave per cell)
 __global__ void k_db_cellbox(const double* __restrict__ pts, const int* __restrict__ corecells, const unsigned* __restrict__ ncore,
                              const unsigned* __restrict__ cnt, const unsigned* __restrict__ start, const unsigned* __restrict__ ord,
                              const unsigned char* __restrict__ core, double* __restrict__ cellbox) {
     const int lane = threadIdx.x & 63;
-    const long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (w >= (long long)*ncore) return;
+    const unsigned nwaves = (gridDim.x * blockDim.x) >> 6, ncells = *ncore;
+    for (unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < ncells; w += nwaves) {
     const long long c = corecells[w];
     const unsigned s0 = start[c], e0 = s0 + cnt[c];
     double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
@@ -164,6 +160,7 @@ __global__ void k_db_cellbox(const double* __restrict__ pts, const int* __restri
             cellbox[(size_t)w * 6 + a] = mn[a];
             cellbox[(size_t)w * 6 + 3 + a] = mx[a];
         }
+    }
 }
 
 // One WAVE per core cell, one LANE per neighbour cell (pass 0: Chebyshev distance 1, pass 1: distance 2,
@@ -175,8 +172,8 @@ __global__ void k_db_union(const double* __restrict__ pts, const int* __restrict
                            const unsigned char* __restrict__ core, const unsigned* __restrict__ minidx, double eps2, int pass,
                            const int* __restrict__ cellpos, const double* __restrict__ cellbox, int* __restrict__ parent) {
     const int lane = threadIdx.x & 63;
-    const long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (w >= (long long)*ncore) return;
+    const unsigned nwaves = (gridDim.x * blockDim.x) >> 6, ncells = *ncore;
+    for (unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < ncells; w += nwaves) {
     const long long c = corecells[w];
     int lo = 0, hi = K - 1;                 // segment of the cell
     while (lo < hi) {
@@ -190,7 +187,9 @@ __global__ void k_db_union(const double* __restrict__ pts, const int* __restrict
     for (int o = lane; o < 125; o += 64) {
         int dx = o / 25 - 2, dy = (o / 5) % 5 - 2, dz = o % 5 - 2;
         int cheb = max(abs(dx), max(abs(dy), abs(dz)));
-        if (cheb == 0 || (pass == 0 && cheb != 1) || (pass == 1 && cheb != 2)) continue;
+        // pass 0: every neighbour, AABB decisions only (no point scans); pass 1 / 2: Chebyshev distance 1 / 2,
+        // point scans for the pairs that are still unconnected
+        if (cheb == 0 || (pass == 1 && cheb != 1) || (pass == 2 && cheb != 2)) continue;
         int jx = ix + dx, jy = iy + dy, jz = iz + dz;
         if (jx < 0 || jy < 0 || jz < 0 || jx >= sg.nx || jy >= sg.ny || jz >= sg.nz) continue;
         long long c2 = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz + jz;
@@ -208,7 +207,7 @@ __global__ void k_db_union(const double* __restrict__ pts, const int* __restrict
             mx2 += far * far;
         }
         bool hit = mx2 < eps2 * (1.0 - 1e-12);
-        if (!hit && mn2 < eps2 * (1.0 + 1e-12)) {
+        if (!hit && pass > 0 && mn2 < eps2 * (1.0 + 1e-12)) {
             const unsigned s1 = start[c2], e1 = s1 + cnt[c2];
             for (unsigned a = s0; a < e0 && !hit; ++a) {
                 unsigned ia = ord[a];
@@ -231,20 +230,27 @@ __global__ void k_db_union(const double* __restrict__ pts, const int* __restrict
         }
         if (hit) uf_union(parent, (int)c, (int)c2);
     }
+    }
 }
 
-__global__ void k_db_flatten(long long NC, const unsigned* __restrict__ minidx, int* __restrict__ parent) {
-    long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= NC || minidx[c] == INF32) return;
-    parent[c] = uf_find(parent, (int)c);     // roots never change after the union passes
+// (the kernels below walk the compact core-cell list with a grid-stride loop: the list length is only
+//  known on the device, and launching one thread per grid cell would be dominated by empty cells)
+__global__ void k_db_flatten(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, int* __restrict__ parent) {
+    const unsigned n = *ncore;
+    for (unsigned w = blockIdx.x * blockDim.x + threadIdx.x; w < n; w += gridDim.x * blockDim.x) {
+        int c = corecells[w];
+        parent[c] = uf_find(parent, c);     // roots never change after the union passes
+    }
 }
 
 // cluster order key: smallest core index of the cluster, kept at the root cell
-__global__ void k_db_rootmin(long long NC, const int* __restrict__ parent, const unsigned* __restrict__ minidx,
-                             unsigned* __restrict__ rootmin) {
-    long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= NC || minidx[c] == INF32) return;
-    atomicMin(&rootmin[parent[c]], minidx[c]);
+__global__ void k_db_rootmin(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, const int* __restrict__ parent,
+                             const unsigned* __restrict__ minidx, unsigned* __restrict__ rootmin) {
+    const unsigned n = *ncore;
+    for (unsigned w = blockIdx.x * blockDim.x + threadIdx.x; w < n; w += gridDim.x * blockDim.x) {
+        int c = corecells[w];
+        atomicMin(&rootmin[parent[c]], minidx[c]);
+    }
 }
 
 __global__ void k_db_label(const double* __restrict__ pts, long long N, const int* __restrict__ segid,
@@ -309,30 +315,38 @@ __global__ void k_db_label(const double* __restrict__ pts, long long N, const in
     }
 }
 
-__global__ void k_db_pick(long long NC, const DbSeg* __restrict__ segs, int K, const unsigned* __restrict__ size,
-                          const unsigned* __restrict__ firstidx, unsigned long long* __restrict__ best) {
-    long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= NC || size[c] == 0u) return;
-    int lo = 0, hi = K - 1;
-    while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (segs[mid].cell_base <= c) lo = mid; else hi = mid - 1;
+// cluster roots are core cells: pick the largest cluster per segment (ties: first label in point order)
+__global__ void k_db_pick(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, const DbSeg* __restrict__ segs,
+                          int K, const unsigned* __restrict__ size, const unsigned* __restrict__ firstidx,
+                          unsigned long long* __restrict__ best) {
+    const unsigned n = *ncore;
+    for (unsigned w = blockIdx.x * blockDim.x + threadIdx.x; w < n; w += gridDim.x * blockDim.x) {
+        long long c = corecells[w];
+        if (size[c] == 0u) continue;
+        int lo = 0, hi = K - 1;
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (segs[mid].cell_base <= c) lo = mid; else hi = mid - 1;
+        }
+        unsigned long long key = ((unsigned long long)size[c] << 32) | (unsigned long long)(INF32 - firstidx[c]);
+        atomicMax(&best[lo], key);
     }
-    unsigned long long key = ((unsigned long long)size[c] << 32) | (unsigned long long)(INF32 - firstidx[c]);
-    atomicMax(&best[lo], key);
 }
-__global__ void k_db_winner(long long NC, const DbSeg* __restrict__ segs, int K, const unsigned* __restrict__ size,
-                            const unsigned* __restrict__ firstidx, const unsigned long long* __restrict__ best,
-                            int* __restrict__ winner) {
-    long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= NC || size[c] == 0u) return;
-    int lo = 0, hi = K - 1;
-    while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (segs[mid].cell_base <= c) lo = mid; else hi = mid - 1;
+__global__ void k_db_winner(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, const DbSeg* __restrict__ segs,
+                            int K, const unsigned* __restrict__ size, const unsigned* __restrict__ firstidx,
+                            const unsigned long long* __restrict__ best, int* __restrict__ winner) {
+    const unsigned n = *ncore;
+    for (unsigned w = blockIdx.x * blockDim.x + threadIdx.x; w < n; w += gridDim.x * blockDim.x) {
+        long long c = corecells[w];
+        if (size[c] == 0u) continue;
+        int lo = 0, hi = K - 1;
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (segs[mid].cell_base <= c) lo = mid; else hi = mid - 1;
+        }
+        unsigned long long key = ((unsigned long long)size[c] << 32) | (unsigned long long)(INF32 - firstidx[c]);
+        if (key == best[lo]) winner[lo] = (int)c;
     }
-    unsigned long long key = ((unsigned long long)size[c] << 32) | (unsigned long long)(INF32 - firstidx[c]);
-    if (key == best[lo]) winner[lo] = (int)c;
 }
 
 // graph_utils.py:853-880: keep the largest cluster unless there is none or it has < 5 points
@@ -501,43 +515,49 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     HMSG_CHECK_LAUNCH();
     hmsg_scan_u32(cnt.p, start.p, (size_t)NC, s, scan_tmp, nullptr);
     hipLaunchKernelGGL(k_db_fill, dim3(gN), dim3(256), 0, s, N, (const long long*)cellid.p, (const unsigned*)start.p, cursor.p, ord.p);
+    corelist.ensure((size_t)std::max<long long>(N, 1));
+    cellpos.ensure((size_t)NC);
+    cellbox.ensure((size_t)std::min<long long>(NC, N) * 6);
+    d_ncore.ensure(1);
+    HIP_TRY(hipMemsetAsync(d_ncore.p, 0, 4, s));
+    {
+    ProfScope ps(prof, s, "k_db_core", (double)N * 33.0);
     hipLaunchKernelGGL(k_db_core, dim3(gN), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const long long*)cellid.p,
                        (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p, eps * eps, min_points, core.p,
-                       minidx.p);
-    hipLaunchKernelGGL(k_db_init_parent, dim3(gC), dim3(256), 0, s, NC, parent.p);
-    // core cells <= points: size the wave grid by min(NC, N), the kernel reads the exact count
-    const long long maxcore = std::min<long long>(NC, N);
-    label.ensure((size_t)std::max<long long>(maxcore, N));    // label[] doubles as the core-cell list until k_db_label
-    HIP_TRY(hipMemsetAsync(ocount.p, 0, 4, s));
-    cellpos.ensure((size_t)NC);
-    cellbox.ensure((size_t)maxcore * 6);
-    hipLaunchKernelGGL(k_db_corecells, dim3(gC), dim3(256), 0, s, NC, (const unsigned*)minidx.p, label.p, (unsigned*)ocount.p,
-                       cellpos.p);
-    hipLaunchKernelGGL(k_db_cellbox, dim3(cdiv((size_t)maxcore * 64, 256)), dim3(256), 0, s, src, (const int*)label.p,
-                       (const unsigned*)ocount.p, (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p,
-                       (const unsigned char*)core.p, cellbox.p);
-    for (int pass = 0; pass < 2; ++pass) {
-        hipLaunchKernelGGL(k_db_union, dim3(cdiv((size_t)maxcore * 64, 256)), dim3(256), 0, s, src, (const int*)label.p,
-                           (const unsigned*)ocount.p, dsegs, K, (const unsigned*)cnt.p, (const unsigned*)start.p,
-                           (const unsigned*)ord.p, (const unsigned char*)core.p, (const unsigned*)minidx.p, eps * eps, pass,
-                           (const int*)cellpos.p, (const double*)cellbox.p, parent.p);
-        if (pass == 0) hipLaunchKernelGGL(k_db_flatten, dim3(gC), dim3(256), 0, s, NC, (const unsigned*)minidx.p, parent.p);
+                       minidx.p, corelist.p, d_ncore.p, cellpos.p, parent.p);
     }
-    HIP_TRY(hipMemsetAsync(ocount.p, 0, (size_t)K * 4, s));
-    hipLaunchKernelGGL(k_db_flatten, dim3(gC), dim3(256), 0, s, NC, (const unsigned*)minidx.p, parent.p);
-    hipLaunchKernelGGL(k_db_rootmin, dim3(gC), dim3(256), 0, s, NC, (const int*)parent.p, (const unsigned*)minidx.p, rootmin.p);
+    const unsigned gW = 2048;   // persistent grid (8 blocks per CU): waves / threads stride over the core-cell list
+    hipLaunchKernelGGL(k_db_cellbox, dim3(gW), dim3(256), 0, s, src, (const int*)corelist.p, (const unsigned*)d_ncore.p,
+                       (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p, (const unsigned char*)core.p,
+                       cellbox.p);
+    for (int pass = 0; pass < 3; ++pass) {
+        ProfScope ps(prof, s, "k_db_union", (double)N * 24.0);
+        hipLaunchKernelGGL(k_db_union, dim3(gW), dim3(256), 0, s, src, (const int*)corelist.p, (const unsigned*)d_ncore.p, dsegs, K,
+                           (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p, (const unsigned char*)core.p,
+                           (const unsigned*)minidx.p, eps * eps, pass, (const int*)cellpos.p, (const double*)cellbox.p, parent.p);
+        hipLaunchKernelGGL(k_db_flatten, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_ncore.p, parent.p);
+    }
+    hipLaunchKernelGGL(k_db_rootmin, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_ncore.p,
+                       (const int*)parent.p, (const unsigned*)minidx.p, rootmin.p);
+    {
+    ProfScope ps(prof, s, "k_db_label", (double)N * 28.0);
     hipLaunchKernelGGL(k_db_label, dim3(gN), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const long long*)cellid.p,
                        (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p, (const unsigned char*)core.p,
                        (const int*)parent.p, (const unsigned*)rootmin.p, eps * eps, label.p, size.p, firstidx.p);
-    hipLaunchKernelGGL(k_db_pick, dim3(gC), dim3(256), 0, s, NC, dsegs, K, (const unsigned*)size.p, (const unsigned*)firstidx.p, best.p);
-    hipLaunchKernelGGL(k_db_winner, dim3(gC), dim3(256), 0, s, NC, dsegs, K, (const unsigned*)size.p, (const unsigned*)firstidx.p,
-                       (const unsigned long long*)best.p, winner.p);
+    }
+    hipLaunchKernelGGL(k_db_pick, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_ncore.p, dsegs, K,
+                       (const unsigned*)size.p, (const unsigned*)firstidx.p, best.p);
+    hipLaunchKernelGGL(k_db_winner, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_ncore.p, dsegs, K,
+                       (const unsigned*)size.p, (const unsigned*)firstidx.p, (const unsigned long long*)best.p, winner.p);
     hipLaunchKernelGGL(k_db_flags, dim3(gN), dim3(256), 0, s, N, (const int*)segid.p, (const int*)label.p, (const int*)winner.p,
                        (const unsigned*)size.p, flags.p);
     HMSG_CHECK_LAUNCH();
     hmsg_scan_u32(flags.p, pos.p, (size_t)N, s, scan_tmp, nullptr);
+    {
+    ProfScope ps(prof, s, "k_db_scatter", (double)N * 56.0);
     hipLaunchKernelGGL(k_db_scatter, dim3(gN), dim3(256), 0, s, src, N, (const int*)segid.p, (const unsigned*)flags.p,
                        (const unsigned*)pos.p, dst, obounds.p, ocount.p);
+    }
     HMSG_CHECK_LAUNCH();
     std::vector<int> hc(K);
     HIP_TRY(hipMemcpyAsync(hc.data(), ocount.p, (size_t)K * 4, hipMemcpyDeviceToHost, s));

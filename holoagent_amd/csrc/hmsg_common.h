@@ -155,6 +155,7 @@ struct InstanceSet {             // merged instances (graph.py:425-448)
 struct ProfEntry {
     std::string name;
     hipEvent_t a, b;
+    double work;      // algorithmic bytes (or FLOP for the MFMA kernels) of this launch, DESIGN.md section 4
 };
 struct Prof {
     bool enabled = false;
@@ -171,10 +172,12 @@ struct ProfScope {
     Prof* p;
     hipStream_t s;
     size_t i = 0;
-    ProfScope(Prof& pr, hipStream_t st, const char* name) : p(pr.enabled ? &pr : nullptr), s(st) {
+    ProfScope(Prof& pr, hipStream_t st, const char* name, double work = 0.0) : ProfScope(&pr, st, name, work) {}
+    ProfScope(Prof* pr, hipStream_t st, const char* name, double work = 0.0) : p(pr && pr->enabled ? pr : nullptr), s(st) {
         if (!p) return;
         ProfEntry e;
         e.name = name;
+        e.work = work;
         (void)hipEventCreate(&e.a);
         (void)hipEventCreate(&e.b);
         (void)hipEventRecord(e.a, s);

@@ -451,13 +451,13 @@ void hmsg_fuse(hmsg_ctx* h) {
         const int nb = std::min(FB, h->n_feat_frames - fb0);
         stamp.zero(s);
         {
-            ProfScope ps(h->prof, s, "k_nn_stamp");
+            ProfScope ps(h->prof, s, "k_nn_stamp", (double)nb * ((double)HW * 10.0 + 128.0));
             hipLaunchKernelGGL(k_nn_stamp, dim3(cdiv(HW * nb, 256)), dim3(256), 0, s, (const unsigned short*)h->depth.p,
                                (const double*)h->pose.p, h->cam, scale, H, W, fb0, nb, hmsg_nn_index(h), h->nn.p, stamp.p);
         }
         HMSG_CHECK_LAUNCH();
         {
-            ProfScope ps(h->prof, s, "k_fuse");
+            ProfScope ps(h->prof, s, "k_fuse", (double)V * 256.0);
             dispatch_fuse(h, stamp.p, fb0, nb);
         }
         // ---- 3-D masks, Bm frames at a time
@@ -465,7 +465,7 @@ void hmsg_fuse(hmsg_ctx* h) {
             const int nfr = std::min(Bm, fb0 + nb - f0);
             const int nmask = nfr * M;
             {
-                ProfScope ps(h->prof, s, "k_mcount");
+                ProfScope ps(h->prof, s, "k_mcount", (double)nfr * (double)HW * 20.0);
                 hipLaunchKernelGGL(k_mcount, dim3(cdiv(HW * nfr, 256)), dim3(256), 0, s, (const int*)h->nn.p,
                                    (const unsigned long long*)h->bits.p, HW, f0, nfr, V, M, mcount.p);
             }
@@ -587,7 +587,7 @@ void hmsg_bitset_and_fp(hmsg_ctx* h, int first, int n, int M, const unsigned cha
     const int D = h->cfg.feat_dim;
     const size_t chunks = (HW + 15) / 16;
     {
-        ProfScope ps(h->prof, h->stream, "k_bitset");
+        ProfScope ps(h->prof, h->stream, "k_bitset", (double)n * (double)HW * (M + 8.0));
         hipLaunchKernelGGL(k_bitset, dim3(cdiv(chunks * n, 256)), dim3(256), 0, h->stream, d_masks, M, HW, n, (size_t)M * HW,
                            h->bits.p + (size_t)first * HW);
     }

@@ -505,7 +505,7 @@ void hmsg_build_map(hmsg_ctx* h) {
     sn.zero(s);
     VoxAcc acc{sxyz.p, sxyz.p + V0, sxyz.p + 2 * V0, srgb.p, srgb.p + V0, srgb.p + 2 * V0, sn.p};
     {
-        ProfScope ps(h->prof, s, "k_accum");
+        ProfScope ps(h->prof, s, "k_accum", (double)total * 5.0 + (double)V0 * 56.0);
         hipLaunchKernelGGL(k_accum, dim3(nblk), dim3(256), 0, s, (const unsigned short*)h->depth.p,
                            (const unsigned char*)h->rgb.p, (const double*)h->pose.p, h->cam, scale, H, W, F, g,
                            (const unsigned long long*)h->bitmap.p, (const unsigned*)h->rank.p, acc);

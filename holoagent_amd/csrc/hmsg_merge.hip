@@ -277,6 +277,9 @@ struct Merger {
         const float r = (float)radius;
         const float r2 = (float)(radius * radius);   // `D < radius**2` with a float32 D (graph_utils.py:654-655)
         const unsigned bx = std::max(1u, std::min(cdiv(maxn, 256), 64u));
+        double ov_work = 0;
+        for (auto& t : tasks) ov_work += 12.0 * g[t.x].n;
+        ProfScope ps(h->prof, s, "k_ov_query", ov_work);
         for (size_t t0 = 0; t0 < tasks.size(); t0 += 32768) {
             unsigned nt = (unsigned)std::min<size_t>(32768, tasks.size() - t0);
             hipLaunchKernelGGL(k_ov_query, dim3(bx, nt), dim3(256), 0, s, (const double*)pool.p, (const OvGrid*)d_grids.p,
@@ -455,6 +458,7 @@ void hmsg_merge(hmsg_ctx* h) {
     m.h = h;
     m.s = h->stream;
     m.ops.s = h->stream;
+    m.ops.prof = &h->prof;
     m.radius = 1.5 * c.voxel_size;
     m.cell = m.radius * (1.0 + 1e-3) + 2e-3;
     m.eps = c.merge_dbscan_eps;

@@ -358,8 +358,13 @@ void hmsg_pool(hmsg_ctx* h) {
                            (const unsigned*)valid.p, (const unsigned*)pos.p, P, (const float*)h->feats.p, D, X.p, Xn.p);
         hipLaunchKernelGGL(k_seg_rows, dim3(std::max(1u, std::min(cdiv(maxn, 256), 256u)), K), dim3(256), 0, s,
                            (const PoolSeg*)d_ps.p, seg_of_row.p);
-        hipLaunchKernelGGL(k_pool_gram, dim3(cdiv((size_t)tiles, 4)), dim3(256), 0, s, (const float*)Xn.p, D,
-                           (const PoolSeg*)d_ps.p, K, tiles, (float)c.feat_dbscan_eps, adj.p, ncount.p);
+        {
+            double flop = 0;
+            for (auto& g : ps) flop += 2.0 * (double)g.n * (double)g.n * D;
+            ProfScope psc(h->prof, s, "k_pool_gram", flop);
+            hipLaunchKernelGGL(k_pool_gram, dim3(cdiv((size_t)tiles, 4)), dim3(256), 0, s, (const float*)Xn.p, D,
+                               (const PoolSeg*)d_ps.p, K, tiles, (float)c.feat_dbscan_eps, adj.p, ncount.p);
+        }
         hipLaunchKernelGGL(k_pool_init, dim3(cdiv((size_t)R, 256)), dim3(256), 0, s, (const unsigned*)ncount.p, (long long)R,
                            c.feat_dbscan_min, label.p, (const PoolSeg*)d_ps.p, (const int*)seg_of_row.p);
         HMSG_CHECK_LAUNCH();

@@ -81,7 +81,8 @@ int hmsg_reset(hmsg_t* h);
  * heavy kernels are bracketed by event pairs; hmsg_profile_entry aggregates them per kernel name. */
 int hmsg_set_profiling(hmsg_t* h, int32_t on);
 int32_t hmsg_profile_count(hmsg_t* h);   /* distinct kernel names recorded since the last reset */
-int hmsg_profile_entry(hmsg_t* h, int32_t i, char* name /*[64]*/, int64_t* launches, double* total_ms);
+int hmsg_profile_entry(hmsg_t* h, int32_t i, char* name /*[64]*/, int64_t* launches, double* total_ms,
+                       double* total_work /* algorithmic bytes, or FLOP for the MFMA kernels; may be NULL */);
 
 /* Benchmark utility, not part of the path: render the synthetic posed RGB-D + mask stream of SURVEY 8d
  * straight into device buffers (rgb u8 [n][H][W][3], depth u16 [n][H][W], masks u8 [n][M][H][W]);
