@@ -94,7 +94,7 @@ __global__ void k_db_core(const double* __restrict__ pts, long long N, const int
         is_core = n >= minpts;
     }
     core[i] = is_core ? 1 : 0;
-    if (is_core) {
+    if (is_core && (unsigned)(i - sg.pt_base) < minidx[c]) {   // (stale read is only conservative)
         // the first core point of a cell (it sees the initial INF) registers the cell in the compact list
         unsigned old = atomicMin(&minidx[c], (unsigned)(i - sg.pt_base));
         if (old == INF32) {
@@ -118,10 +118,22 @@ __device__ __forceinline__ int uf_find(int* parent, int x) {
         x = p;
     }
 }
+// Cached variant: ordinary loads (may be served by this CU's L1, i.e. be STALE).  A stale parent is an older
+// ancestor, so whatever this returns is an ancestor of x: equal results for two cells still prove they are
+// connected; a stale "root" only makes the CAS in uf_union fail, which then retries with uf_find.
+// (Thousands of lanes ending their walk on the one hot root word through the L2 was the bottleneck.)
+__device__ __forceinline__ int uf_find_cached(const int* parent, int x) {
+    for (int hop = 0; hop < 64; ++hop) {
+        int p = parent[x];
+        if (p == x) return x;
+        x = p;
+    }
+    return x;
+}
 __device__ __forceinline__ void uf_union(int* parent, int a, int b) {
+    a = uf_find_cached(parent, a);
+    b = uf_find_cached(parent, b);
     for (;;) {
-        a = uf_find(parent, a);
-        b = uf_find(parent, b);
         if (a == b) return;
         if (a < b) {
             int t = a;
@@ -129,6 +141,8 @@ __device__ __forceinline__ void uf_union(int* parent, int a, int b) {
             b = t;
         }                                   // a > b: hang the larger root under the smaller
         if (atomicCAS(&parent[a], a, b) == a) return;
+        a = uf_find(parent, a);
+        b = uf_find(parent, b);
     }
 }
 
@@ -194,7 +208,7 @@ __global__ void k_db_union(const double* __restrict__ pts, const int* __restrict
         if (jx < 0 || jy < 0 || jz < 0 || jx >= sg.nx || jy >= sg.ny || jz >= sg.nz) continue;
         long long c2 = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz + jz;
         if (c2 <= c || minidx[c2] == INF32) continue;
-        if (uf_find(parent, (int)c) == uf_find(parent, (int)c2)) continue;
+        if (uf_find_cached(parent, (int)c) == uf_find_cached(parent, (int)c2)) continue;
         // tight AABBs of the two cells' core points decide most pairs without touching a point:
         // farthest corners closer than eps -> every pair is a witness; nearest faces >= eps -> no witness.
         const double* ba = cellbox + (size_t)cellpos[c] * 6;
@@ -247,9 +261,32 @@ __global__ void k_db_flatten(const int* __restrict__ corecells, const unsigned* 
 __global__ void k_db_rootmin(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, const int* __restrict__ parent,
                              const unsigned* __restrict__ minidx, unsigned* __restrict__ rootmin) {
     const unsigned n = *ncore;
-    for (unsigned w = blockIdx.x * blockDim.x + threadIdx.x; w < n; w += gridDim.x * blockDim.x) {
-        int c = corecells[w];
-        atomicMin(&rootmin[parent[c]], minidx[c]);
+    const unsigned stride = gridDim.x * blockDim.x;
+    // wave-uniform trip count; one atomic per (wave, root): a cluster's cells all target the same word
+    for (unsigned w0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); w0 < n; w0 += stride) {
+        unsigned w = w0 + (threadIdx.x & 63u);
+        const bool valid = w < n;
+        int root = -1;
+        unsigned mi = INF32;
+        if (valid) {
+            int c = corecells[w];
+            root = parent[c];
+            mi = minidx[c];
+        }
+        unsigned long long todo = __ballot(valid);
+        while (todo) {
+            int leader = __ffsll(todo) - 1;
+            int key = __shfl(root, leader);
+            const bool mine_b = valid && root == key;
+            unsigned long long mine = __ballot(mine_b);
+            unsigned v = mine_b ? mi : INF32;
+            for (int o = 32; o > 0; o >>= 1) {
+                unsigned t = __shfl_xor(v, o);
+                v = t < v ? t : v;
+            }
+            if ((int)(threadIdx.x & 63) == leader) atomicMin(&rootmin[key], v);
+            todo &= ~mine;
+        }
     }
 }
 
@@ -360,39 +397,18 @@ __global__ void k_db_flags(long long N, const int* __restrict__ segid, const int
     flags[i] = keep ? 1u : 0u;
 }
 
+// compaction of the kept points; the last point of every segment derives the segment's output count from
+// the scan (no per-point atomics).  AABBs of segments that lost points are reduced afterwards (host side).
 __global__ void k_db_scatter(const double* __restrict__ pts, long long N, const int* __restrict__ segid,
-                             const unsigned* __restrict__ flags, const unsigned* __restrict__ pos, double* __restrict__ dst,
-                             unsigned long long* __restrict__ obounds, int* __restrict__ ocount) {
+                             const DbSeg* __restrict__ segs, const unsigned* __restrict__ flags,
+                             const unsigned* __restrict__ pos, double* __restrict__ dst, int* __restrict__ ocount) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = i < N && flags[i];
-    if (i >= N) i = N - 1;
-    const int k = segid[i];
-    double v[3] = {pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]};
-    if (valid) {
-        unsigned p = pos[i];
-        for (int a = 0; a < 3; ++a) dst[(size_t)p * 3 + a] = v[a];
-    }
-    // per-segment AABB and count, aggregated per (wave, segment)
-    unsigned long long todo = __ballot(valid);
-    while (todo) {
-        int leader = __ffsll(todo) - 1;
-        int key = __shfl(k, leader);
-        const bool mine_b = valid && k == key;
-        unsigned long long mine = __ballot(mine_b);
-        double mn[3], mx[3];
-        for (int a = 0; a < 3; ++a) {
-            mn[a] = wave_min_f64(mine_b ? v[a] : 1e300);
-            mx[a] = wave_max_f64(mine_b ? v[a] : -1e300);
-        }
-        if ((int)(threadIdx.x & 63) == leader) {
-            for (int a = 0; a < 3; ++a) {
-                atomicMin(&obounds[(size_t)key * 6 + a], enc_f64(mn[a]));
-                atomicMax(&obounds[(size_t)key * 6 + 3 + a], enc_f64(mx[a]));
-            }
-            atomicAdd(&ocount[key], __popcll(mine));
-        }
-        todo &= ~mine;
-    }
+    if (i >= N) return;
+    const unsigned f = flags[i], p = pos[i];
+    if (f)
+        for (int a = 0; a < 3; ++a) dst[(size_t)p * 3 + a] = pts[i * 3 + a];
+    const DbSeg sg = segs[segid[i]];
+    if (i == sg.pt_base + sg.n - 1) ocount[segid[i]] = (int)(p + f - pos[sg.pt_base]);
 }
 
 struct BdSeg {
@@ -555,23 +571,39 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     hmsg_scan_u32(flags.p, pos.p, (size_t)N, s, scan_tmp, nullptr);
     {
     ProfScope ps(prof, s, "k_db_scatter", (double)N * 56.0);
-    hipLaunchKernelGGL(k_db_scatter, dim3(gN), dim3(256), 0, s, src, N, (const int*)segid.p, (const unsigned*)flags.p,
-                       (const unsigned*)pos.p, dst, obounds.p, ocount.p);
+    hipLaunchKernelGGL(k_db_scatter, dim3(gN), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const unsigned*)flags.p,
+                       (const unsigned*)pos.p, dst, ocount.p);
     }
     HMSG_CHECK_LAUNCH();
     std::vector<int> hc(K);
     HIP_TRY(hipMemcpyAsync(hc.data(), ocount.p, (size_t)K * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(hb.data(), obounds.p, hb.size() * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     long long total = 0;
+    std::vector<SegDesc> redo;          // segments that lost points: their AABB has to be re-reduced
+    std::vector<int> redo_k;
     for (int k = 0; k < K; ++k) {
         res[k].n_out = hc[k];
         res[k].changed = hc[k] != segs[k].n;
         for (int a = 0; a < 3; ++a) {
-            res[k].mn[a] = hc[k] ? dec_f64(hb[(size_t)k * 6 + a]) : 0.0;
-            res[k].mx[a] = hc[k] ? dec_f64(hb[(size_t)k * 6 + 3 + a]) : 0.0;
+            res[k].mn[a] = hc[k] ? segs[k].mn[a] : 0.0;     // unchanged: the input box is exact
+            res[k].mx[a] = hc[k] ? segs[k].mx[a] : 0.0;
+        }
+        if (res[k].changed && hc[k] > 0) {
+            SegDesc sd;
+            sd.pt_base = total;
+            sd.n = hc[k];
+            redo.push_back(sd);
+            redo_k.push_back(k);
         }
         total += hc[k];
+    }
+    if (!redo.empty()) {
+        bounds(dst, redo);
+        for (size_t j = 0; j < redo.size(); ++j)
+            for (int a = 0; a < 3; ++a) {
+                res[redo_k[j]].mn[a] = redo[j].mn[a];
+                res[redo_k[j]].mx[a] = redo[j].mx[a];
+            }
     }
     return total;
 }
