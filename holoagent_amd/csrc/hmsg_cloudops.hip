@@ -247,6 +247,97 @@ __global__ void k_db_union(const double* __restrict__ pts, const int* __restrict
     }
 }
 
+// Scan passes (pass 1: Chebyshev distance 1, pass 2: distance 2): for the neighbour pairs the AABBs could not
+// decide and that are still unconnected, look for ONE witness pair of core points closer than eps.  The whole
+// wave works on one pair: lanes take the points of c in turn (point-to-box pruned), each walks c2 with early
+// exit, and the wave stops at the first hit -- a heavily re-observed cell holds hundreds of points.
+__global__ void k_db_union_scan(const double* __restrict__ pts, const int* __restrict__ corecells,
+                                const unsigned* __restrict__ ncore, const DbSeg* __restrict__ segs, int K,
+                                const unsigned* __restrict__ cnt, const unsigned* __restrict__ start,
+                                const unsigned* __restrict__ ord, const unsigned char* __restrict__ core,
+                                const unsigned* __restrict__ minidx, double eps2, int pass, const int* __restrict__ cellpos,
+                                const double* __restrict__ cellbox, int* __restrict__ parent) {
+    const int lane = threadIdx.x & 63;
+    const unsigned nwaves = (gridDim.x * blockDim.x) >> 6, ncells = *ncore;
+    for (unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < ncells; w += nwaves) {
+        const long long c = corecells[w];
+        int lo = 0, hi = K - 1;
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (segs[mid].cell_base <= c) lo = mid; else hi = mid - 1;
+        }
+        const DbSeg sg = segs[lo];
+        int ix, iy, iz;
+        cell_xyz(sg, c, ix, iy, iz);
+        const unsigned s0 = start[c], e0 = s0 + cnt[c];
+        const double* ba = cellbox + (size_t)cellpos[c] * 6;
+        for (int round = 0; round < 2; ++round) {
+          // phase A: one lane per neighbour cell decides whether that pair needs a point scan at all
+          const int oo = round * 64 + lane;
+          bool need = false;
+          long long my_c2 = -1;
+          if (oo < 125) {
+              int dx = oo / 25 - 2, dy = (oo / 5) % 5 - 2, dz = oo % 5 - 2;
+              int cheb = max(abs(dx), max(abs(dy), abs(dz)));
+              int jx = ix + dx, jy = iy + dy, jz = iz + dz;
+              if (cheb == pass && jx >= 0 && jy >= 0 && jz >= 0 && jx < sg.nx && jy < sg.ny && jz < sg.nz) {
+                  long long cc = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz + jz;
+                  if (cc > c && minidx[cc] != INF32 && uf_find_cached(parent, (int)c) != uf_find_cached(parent, (int)cc)) {
+                      const double* bq = cellbox + (size_t)cellpos[cc] * 6;
+                      double mn2 = 0.0, mx2 = 0.0;
+                      for (int a = 0; a < 3; ++a) {
+                          double gap = fmax(0.0, fmax(ba[a] - bq[3 + a], bq[a] - ba[3 + a]));
+                          double far = fmax(ba[3 + a] - bq[a], bq[3 + a] - ba[a]);
+                          mn2 += gap * gap;
+                          mx2 += far * far;
+                      }
+                      // (mx2 < eps2: decided by the box pass; mn2 >= eps2: no witness possible)
+                      need = !(mx2 < eps2 * (1.0 - 1e-12)) && mn2 < eps2 * (1.0 + 1e-12);
+                      my_c2 = cc;
+                  }
+              }
+          }
+          unsigned long long todo = __ballot(need);
+          // phase B: the whole wave scans the pairs that need it, one after the other
+          while (todo) {
+            const int src_lane = __ffsll(todo) - 1;
+            todo &= todo - 1;
+            const long long c2 = __shfl(my_c2, src_lane);
+            const double* bb = cellbox + (size_t)cellpos[c2] * 6;
+            const unsigned s1 = start[c2], e1 = s1 + cnt[c2];
+            bool hit = false;
+            for (unsigned a0 = s0; a0 < e0; a0 += 64) {
+                unsigned a = a0 + lane;
+                if (a < e0) {
+                    unsigned ia = ord[a];
+                    if (core[ia]) {
+                        const double* pa = pts + (size_t)ia * 3;
+                        double g2 = 0.0;                       // point-to-box lower bound
+                        for (int q = 0; q < 3; ++q) {
+                            double gq = fmax(0.0, fmax(bb[q] - pa[q], pa[q] - bb[3 + q]));
+                            g2 += gq * gq;
+                        }
+                        if (g2 < eps2 * (1.0 + 1e-12))
+                            for (unsigned b = s1; b < e1; ++b) {
+                                unsigned ib = ord[b];
+                                if (core[ib] && dist2_f64(pa, pts + (size_t)ib * 3) < eps2) {
+                                    hit = true;
+                                    break;
+                                }
+                            }
+                    }
+                }
+                if (__any(hit)) {
+                    hit = true;
+                    break;
+                }
+            }
+            if (hit && lane == 0) uf_union(parent, (int)c, (int)c2);
+          }
+        }
+    }
+}
+
 // (the kernels below walk the compact core-cell list with a grid-stride loop: the list length is only
 //  known on the device, and launching one thread per grid cell would be dominated by empty cells)
 __global__ void k_db_flatten(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, int* __restrict__ parent) {
@@ -547,10 +638,17 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
                        (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p, (const unsigned char*)core.p,
                        cellbox.p);
     for (int pass = 0; pass < 3; ++pass) {
-        ProfScope ps(prof, s, "k_db_union", (double)N * 24.0);
-        hipLaunchKernelGGL(k_db_union, dim3(gW), dim3(256), 0, s, src, (const int*)corelist.p, (const unsigned*)d_ncore.p, dsegs, K,
-                           (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p, (const unsigned char*)core.p,
-                           (const unsigned*)minidx.p, eps * eps, pass, (const int*)cellpos.p, (const double*)cellbox.p, parent.p);
+        static const char* const pass_name[3] = {"k_db_union/box", "k_db_union/scan1", "k_db_union/scan2"};
+        ProfScope ps(prof, s, pass_name[pass], (double)N * 24.0);
+        if (pass == 0)
+            hipLaunchKernelGGL(k_db_union, dim3(gW), dim3(256), 0, s, src, (const int*)corelist.p, (const unsigned*)d_ncore.p, dsegs, K,
+                               (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p, (const unsigned char*)core.p,
+                               (const unsigned*)minidx.p, eps * eps, pass, (const int*)cellpos.p, (const double*)cellbox.p, parent.p);
+        else
+            hipLaunchKernelGGL(k_db_union_scan, dim3(gW), dim3(256), 0, s, src, (const int*)corelist.p, (const unsigned*)d_ncore.p,
+                               dsegs, K, (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p,
+                               (const unsigned char*)core.p, (const unsigned*)minidx.p, eps * eps, pass, (const int*)cellpos.p,
+                               (const double*)cellbox.p, parent.p);
         hipLaunchKernelGGL(k_db_flatten, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_ncore.p, parent.p);
     }
     hipLaunchKernelGGL(k_db_rootmin, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_ncore.p,

@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cmath>
 #include <numeric>
+#include <chrono>
 #include <unordered_map>
 
 namespace {
@@ -143,6 +144,10 @@ __global__ void k_concat(const double* __restrict__ pool, const CatSeg* __restri
 namespace {
 
 double bbox_iou(const Cloud& a, const Cloud& b) {   // graph_utils.py:883-915; empty cloud -> (0,0,0) box
+    // boxes disjoint along an axis: overlap volume 0 -> IoU 0 (or 0/0): never > iou_thresh (>= 0 by contract)
+    if (a.mx[0] <= b.mn[0] || b.mx[0] <= a.mn[0] || a.mx[1] <= b.mn[1] || b.mx[1] <= a.mn[1] || a.mx[2] <= b.mn[2] ||
+        b.mx[2] <= a.mn[2])
+        return 0.0;
     double ov = 1, va = 1, vb = 1;
     for (int k = 0; k < 3; ++k) {
         double omin = std::max(a.mn[k], b.mn[k]), omax = std::min(a.mx[k], b.mx[k]);
@@ -176,6 +181,7 @@ struct Merger {
     double eps = 0.1;
     int minpts = 10;
     double iou_thresh = 0.05;
+    double tphase[6] = {0, 0, 0, 0, 0, 0};   // host wall time per phase (HMSG_DEBUG_TIMING)
 
     template <typename T>
     void grow(DevBuf<T>& b, size_t used_elems, size_t need_elems) {
@@ -301,7 +307,15 @@ struct Merger {
     std::vector<Cloud> merge_3d_masks(std::vector<Cloud> L, double th) {
         const int n = (int)L.size();
         if (n == 0) return L;
+        auto tnow = [] { return std::chrono::steady_clock::now(); };
+        auto t0 = tnow();
+        auto lap = [&](int k) {
+            auto t1 = tnow();
+            tphase[k] += std::chrono::duration<double, std::milli>(t1 - t0).count();
+            t0 = t1;
+        };
         build_indices(L);
+        lap(0);
         // 1. candidate pairs
         std::vector<std::pair<int, int>> pairs;
         std::vector<double> known;                 // cached ratios (hierarchical)
@@ -324,16 +338,35 @@ struct Merger {
                 for (int j = i + 1; j < n; ++j) consider(i, j);
         } else {
             // shortcut (2): only pairs with a fresh member; enumerate from the (few) fresh clouds
+            // (AABBs in SoA form: the reject test -- boxes disjoint on some axis, overlap volume 0 -- is the hot loop)
+            std::vector<double> lo[3], hi[3];
+            std::vector<unsigned char> fr(n);
+            for (int a = 0; a < 3; ++a) {
+                lo[a].resize(n);
+                hi[a].resize(n);
+            }
+            for (int j = 0; j < n; ++j) {
+                fr[j] = L[j].fresh ? 1 : 0;
+                for (int a = 0; a < 3; ++a) {
+                    lo[a][j] = L[j].n ? L[j].mn[a] : 1e300;      // empty clouds never pair
+                    hi[a][j] = L[j].n ? L[j].mx[a] : -1e300;
+                }
+            }
             for (int i = 0; i < n; ++i) {
-                if (!L[i].fresh) continue;
+                if (!fr[i] || L[i].n == 0) continue;
+                const double l0 = lo[0][i], h0 = hi[0][i], l1 = lo[1][i], h1 = hi[1][i], l2 = lo[2][i], h2 = hi[2][i];
                 for (int j = 0; j < n; ++j) {
-                    if (j == i || (L[j].fresh && j < i)) continue;
+                    bool disjoint = (h0 <= lo[0][j]) | (hi[0][j] <= l0) | (h1 <= lo[1][j]) | (hi[1][j] <= l1) | (h2 <= lo[2][j]) |
+                                    (hi[2][j] <= l2);
+                    if (disjoint || j == i || (fr[j] && j < i)) continue;
                     consider(std::min(i, j), std::max(i, j));
                 }
             }
         }
         std::vector<double> ratio;
+        lap(1);
         overlap_ratios(L, pairs, ratio);
+        lap(2);
         // 2. components of `overlap > th` (scipy connected_components labels by lowest member index)
         std::vector<int> parent(n);
         std::iota(parent.begin(), parent.end(), 0);
@@ -403,7 +436,9 @@ struct Merger {
             }
             HMSG_CHECK_LAUNCH();
             grow(pool, (size_t)pool_used * 3, (size_t)(pool_used + cat_total) * 3);
+            lap(3);
             ops.dbscan_keep_largest(concat.p, segs, eps, minpts, pool.p + (size_t)pool_used * 3, res);
+            lap(4);
         } else {
             res.assign(segs.size(), DbscanResult{});
         }
@@ -444,6 +479,7 @@ struct Merger {
             cursor += r.n_out;
         }
         pool_used = cursor;
+        lap(5);
         return out;
     }
 };
@@ -464,6 +500,7 @@ void hmsg_merge(hmsg_ctx* h) {
     m.eps = c.merge_dbscan_eps;
     m.minpts = c.merge_dbscan_min;
     m.iou_thresh = c.iou_thresh;
+    HMSG_REQUIRE(c.iou_thresh >= 0.0, HMSG_ERR_UNSUPPORTED, "pipeline.iou_thresh must be >= 0");
     const int F = h->n_fused, M = h->M;
     // the 3-D masks of all frames seed the pool (device to device)
     const long long total = h->masks3d.total;
@@ -550,6 +587,9 @@ void hmsg_merge(hmsg_ctx* h) {
         HMSG_CHECK_LAUNCH();
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (getenv("HMSG_DEBUG_TIMING"))
+        fprintf(stderr, "[hmsg merge] index %.1f  pairs(host) %.1f  overlap %.1f  components+concat %.1f  dbscan %.1f  bookkeeping %.1f ms\n",
+                m.tphase[0], m.tphase[1], m.tphase[2], m.tphase[3], m.tphase[4], m.tphase[5]);
     h->merged = true;
 }
 
