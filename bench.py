@@ -120,6 +120,16 @@ def main():
     ent_room = np.concatenate([inp["obj_room"], np.repeat(np.arange(n_rooms), 6)])
     q_rooms = [[int(ent_room[e]), int((ent_room[e] + 1) % n_rooms)] for e in q_ent]   # label-mode room sets
 
+    from holoagent_amd.graph import Graph
+    # rooms are an input of the path: 2-D vertex grids at grid_resolution 0.05 like the reference's
+    room_specs = []
+    for lo6 in inp["rooms"]:
+        xs, zs = np.arange(lo6[0], lo6[3], 0.05), np.arange(lo6[2], lo6[5], 0.05)
+        room_specs.append(dict(floor=0, vertices=np.stack(np.meshgrid(xs, zs, indexing="ij"), -1).reshape(-1, 2)))
+    rng_l = np.random.Generator(np.random.PCG64(99))
+    label_feats = rng_l.standard_normal((205, D)).astype(np.float32)      # scannet200-sized label vocabulary
+    label_feats /= np.linalg.norm(label_feats, axis=1, keepdims=True)
+    label_names = ["label%d" % i for i in range(205)]
     sc = Scene(lib_=L, device_id=local, height=spec.height, width=spec.width, max_frames=F, max_masks=32, feat_dim=D)
     sc.set_profiling(True)
     stage = {}
@@ -142,10 +152,16 @@ def main():
         T("pool_instances", sc.pool_instances)
 
         def assemble():
-            feats = sc.instance_feats().astype(np.float64)        # embeddings are f64 once stored (object.py:88-89)
-            rooms = assign_rooms(sc.instance_boxes(), inp["rooms"]) if feats.shape[0] else np.zeros(0, np.int32)
+            # A8 floors, A10 objects (device: instance DBSCAN(0.05,10), object->room share, label GEMM), A11 node
+            # records -- holoagent_amd.graph.Graph, the mirror of the reference's Graph; rooms are an input.
+            g = Graph.from_scene(sc, lib=L)
+            g.set_label_feats(label_feats, label_names)
+            g.build_hier_multimodal_scene_graph(None, rooms=room_specs)
+            rid = {r.room_id: i for i, r in enumerate(g.rooms)}
+            feats = np.stack([o.embedding for o in g.objects]).astype(np.float64) if g.objects else np.zeros((0, D))
+            rooms = np.array([rid[o.room_id] for o in g.objects], np.int32)   # embeddings are f64 once stored (object.py:88-89)
             return feats, rooms
-        feats, rooms = T("assemble_nodes", assemble)
+        feats, rooms = T("assemble_graph", assemble)
         state["n_nodes_local"] = feats.shape[0]
 
         def retrieve():

@@ -65,6 +65,7 @@ _SIGS = {
     "hmsg_get_instance_points": (C.c_int, [_P, _P]),
     "hmsg_get_instance_boxes": (C.c_int, [_P, _P]),
     "hmsg_denoise_instances": (C.c_int, [_P, C.c_double, C.c_int32]),
+    "hmsg_instance_room_share": (C.c_int, [_P, C.c_int32, _P, _P, C.c_double, _P]),
     "hmsg_pool_instances": (C.c_int, [_P]),
     "hmsg_get_instance_feats": (C.c_int, [_P, _P]),
     "hmsg_index_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _P, C.c_int32, _P, C.POINTER(_P)]),
@@ -251,6 +252,17 @@ class Scene:
         out = np.empty((n, 6), np.float64)
         if n:
             self._ck(self.L.c.hmsg_get_instance_boxes(self.h, _ptr(out)))
+        return out
+
+    def instance_room_share(self, room_vertices, radius=0.2):
+        """room_vertices: list of [n_r, 2] (x, z) arrays -> share f64 [N, R] (find_intersection_share on device)."""
+        R = len(room_vertices)
+        off = np.zeros(R + 1, np.int64)
+        off[1:] = np.cumsum([len(v) for v in room_vertices])
+        verts = np.ascontiguousarray(np.concatenate([np.asarray(v, np.float64).reshape(-1, 2) for v in room_vertices])
+                                     if off[-1] else np.zeros((1, 2)), dtype=np.float64)
+        out = np.zeros((self.num_instances(), R), np.float64)
+        self._ck(self.L.c.hmsg_instance_room_share(self.h, R, _ptr(off), _ptr(verts), float(radius), _ptr(out)))
         return out
 
     def denoise_instances(self, eps=0.05, min_points=10):

@@ -363,6 +363,16 @@ int hmsg_denoise_instances(hmsg_t* h, double eps, int32_t min_points) {
     return guard(h, [&] { hmsg_denoise_inst(h, eps, min_points); });
 }
 
+int hmsg_instance_room_share(hmsg_t* h, int32_t n_rooms, const int64_t* vert_off, const double* verts_xz, double radius,
+                             double* share) {
+    if (!h) return HMSG_ERR_INVALID;
+    return guard(h, [&] {
+        HMSG_REQUIRE(n_rooms >= 0 && vert_off && verts_xz && share && radius > 0, HMSG_ERR_INVALID,
+                     "hmsg_instance_room_share: bad argument");
+        hmsg_room_share(h, n_rooms, (const long long*)vert_off, verts_xz, radius, share);
+    });
+}
+
 int hmsg_get_instance_boxes(const hmsg_t* hc, double* boxes) {
     hmsg_ctx* h = const_cast<hmsg_ctx*>(hc);
     if (!h) return HMSG_ERR_INVALID;

@@ -263,4 +263,6 @@ void hmsg_build_map(hmsg_ctx* h);       // hmsg_map.hip
 void hmsg_fuse(hmsg_ctx* h);            // hmsg_fuse.hip
 void hmsg_merge(hmsg_ctx* h);           // hmsg_merge.hip
 void hmsg_denoise_inst(hmsg_ctx* h, double eps, int min_points);   // hmsg_merge.hip
+void hmsg_room_share(hmsg_ctx* h, int R, const long long* vert_off, const double* verts_xz, double radius,
+                     double* share_out);                              // hmsg_merge.hip
 void hmsg_pool(hmsg_ctx* h);            // hmsg_pool.hip

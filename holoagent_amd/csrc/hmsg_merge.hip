@@ -625,3 +625,159 @@ void hmsg_denoise_inst(hmsg_ctx* h, double eps, int min_points) {
     h->inst.total = total;
     HIP_TRY(hipStreamSynchronize(h->stream));
 }
+
+// ------------------------------------------------------------------------------------------ A10: object -> room share
+// segment_hmsg_objects (graph.py:1634-1642) + find_intersection_share (utils/graph_utils.py:160-189): for an
+// object and a room, the number of room vertices (2-D, x/z) that have an object point within `radius`, divided
+// by the number of object points.  Device version: per-instance 2-D grids (cell = radius) over the instance's
+// (x, z) points, one task per (instance, room) whose boxes come within `radius`, float64 distances.
+struct ShGrid {
+    long long pt_off;        // instance points in inst.pts
+    long long cell_off;      // cellstart (ncell + 1) in the concatenated array
+    int n, gx, gz, pad;
+    double ox, oz, cell;
+};
+struct ShTask {
+    int inst, room;
+};
+__device__ __forceinline__ long long sh_cell(const ShGrid& g, double x, double z) {
+    int ix = (int)floor((x - g.ox) / g.cell), iz = (int)floor((z - g.oz) / g.cell);
+    ix = min(max(ix, 0), g.gx - 1);
+    iz = min(max(iz, 0), g.gz - 1);
+    return g.cell_off + (long long)ix * g.gz + iz;
+}
+__global__ void k_sh_count(const double* __restrict__ pts, const ShGrid* __restrict__ gr, unsigned* __restrict__ cells) {
+    const ShGrid g = gr[blockIdx.y];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += gridDim.x * blockDim.x) {
+        const double* p = pts + (size_t)(g.pt_off + i) * 3;
+        atomicAdd(&cells[sh_cell(g, p[0], p[2])], 1u);
+    }
+}
+__global__ void k_sh_fill(const double* __restrict__ pts, const ShGrid* __restrict__ gr, const unsigned* __restrict__ cells,
+                          unsigned* __restrict__ cursor, double* __restrict__ sorted /*[P][2]*/) {
+    const ShGrid g = gr[blockIdx.y];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += gridDim.x * blockDim.x) {
+        const double* p = pts + (size_t)(g.pt_off + i) * 3;
+        long long c = sh_cell(g, p[0], p[2]);
+        unsigned pos = cells[c] + atomicAdd(&cursor[c], 1u);
+        sorted[(size_t)pos * 2] = p[0];
+        sorted[(size_t)pos * 2 + 1] = p[2];
+    }
+}
+__global__ void k_sh_query(const ShGrid* __restrict__ gr, const ShTask* __restrict__ tasks, const long long* __restrict__ vert_off,
+                           const double* __restrict__ verts, const unsigned* __restrict__ cells, const double* __restrict__ sorted,
+                           double r2, unsigned* __restrict__ counts) {
+    const ShTask t = tasks[blockIdx.y];
+    const ShGrid g = gr[t.inst];
+    const long long v0 = vert_off[t.room], v1 = vert_off[t.room + 1];
+    unsigned local = 0;
+    for (long long v = v0 + blockIdx.x * blockDim.x + threadIdx.x; v < v1; v += (long long)gridDim.x * blockDim.x) {
+        const double x = verts[v * 2], z = verts[v * 2 + 1];
+        int cx = (int)floor((x - g.ox) / g.cell), cz = (int)floor((z - g.oz) / g.cell);
+        if (cx < -1 || cz < -1 || cx > g.gx || cz > g.gz) continue;
+        bool hit = false;
+        for (int dx = -1; dx <= 1 && !hit; ++dx) {
+            int jx = cx + dx;
+            if (jx < 0 || jx >= g.gx) continue;
+            int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.gz - 1);
+            if (z1 < z0) continue;
+            long long c0 = g.cell_off + (long long)jx * g.gz;
+            for (unsigned k = cells[c0 + z0]; k < cells[c0 + z1 + 1]; ++k) {
+                double ddx = __dsub_rn(sorted[(size_t)k * 2], x), ddz = __dsub_rn(sorted[(size_t)k * 2 + 1], z);
+                if (__dadd_rn(__dmul_rn(ddx, ddx), __dmul_rn(ddz, ddz)) < r2) {
+                    hit = true;
+                    break;
+                }
+            }
+        }
+        local += hit ? 1u : 0u;
+    }
+    if (local) atomicAdd(&counts[blockIdx.y], local);
+}
+
+void hmsg_room_share(hmsg_ctx* h, int R, const long long* vert_off, const double* verts_xz, double radius, double* share_out) {
+    HMSG_REQUIRE(h->merged, HMSG_ERR_INVALID, "hmsg_instance_room_share: run hmsg_merge_instances first");
+    hipStream_t s = h->stream;
+    const int N = (int)h->inst.off.size() - 1;
+    for (long long i = 0; i < (long long)N * R; ++i) share_out[i] = 0.0;
+    if (N <= 0 || R <= 0) return;
+    const double cell = radius * (1.0 + 1e-9);
+    // room vertex boxes (host)
+    std::vector<double> rb((size_t)R * 4);
+    for (int r = 0; r < R; ++r) {
+        double x0 = 1e300, x1 = -1e300, z0 = 1e300, z1 = -1e300;
+        for (long long v = vert_off[r]; v < vert_off[r + 1]; ++v) {
+            x0 = std::min(x0, verts_xz[v * 2]);
+            x1 = std::max(x1, verts_xz[v * 2]);
+            z0 = std::min(z0, verts_xz[v * 2 + 1]);
+            z1 = std::max(z1, verts_xz[v * 2 + 1]);
+        }
+        rb[(size_t)r * 4] = x0; rb[(size_t)r * 4 + 1] = x1; rb[(size_t)r * 4 + 2] = z0; rb[(size_t)r * 4 + 3] = z1;
+    }
+    std::vector<ShGrid> g(N);
+    std::vector<ShTask> tasks;
+    long long ncell = 0;
+    int maxn = 0;
+    for (int i = 0; i < N; ++i) {
+        ShGrid& q = g[i];
+        q.pt_off = h->inst.off[i];
+        q.n = (int)(h->inst.off[i + 1] - h->inst.off[i]);
+        q.cell = cell;
+        q.pad = 0;
+        q.cell_off = ncell;
+        const double* bx = &h->inst.box[(size_t)i * 6];
+        q.ox = bx[0] - 1e-9;
+        q.oz = bx[2] - 1e-9;
+        q.gx = q.n ? (int)std::floor((bx[3] - q.ox) / cell) + 1 : 1;
+        q.gz = q.n ? (int)std::floor((bx[5] - q.oz) / cell) + 1 : 1;
+        ncell += (long long)q.gx * q.gz + 1;
+        maxn = std::max(maxn, q.n);
+        if (!q.n) continue;
+        for (int r = 0; r < R; ++r)
+            if (!(rb[(size_t)r * 4] > bx[3] + radius || rb[(size_t)r * 4 + 1] < bx[0] - radius ||
+                  rb[(size_t)r * 4 + 2] > bx[5] + radius || rb[(size_t)r * 4 + 3] < bx[2] - radius))
+                tasks.push_back(ShTask{i, r});
+    }
+    if (tasks.empty()) return;
+    HMSG_REQUIRE(ncell < (1ll << 31), HMSG_ERR_UNSUPPORTED, "room-share grids too large");
+    DevBuf<ShGrid> d_g;
+    DevBuf<ShTask> d_t;
+    DevBuf<unsigned> cells, cursor, counts;
+    DevBuf<double> sorted, d_verts;
+    DevBuf<long long> d_voff;
+    DevBuf<unsigned> scan_tmp;
+    d_g.alloc(N);
+    d_t.alloc(tasks.size());
+    cells.alloc((size_t)ncell);
+    cursor.alloc((size_t)ncell);
+    counts.alloc(tasks.size());
+    sorted.alloc((size_t)std::max<long long>(h->inst.total, 1) * 2);
+    const long long nv = vert_off[R];
+    d_verts.alloc((size_t)std::max<long long>(nv, 1) * 2);
+    d_voff.alloc(R + 1);
+    HIP_TRY(hipMemcpyAsync(d_g.p, g.data(), (size_t)N * sizeof(ShGrid), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_t.p, tasks.data(), tasks.size() * sizeof(ShTask), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_verts.p, verts_xz, (size_t)nv * 16, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_voff.p, vert_off, (size_t)(R + 1) * 8, hipMemcpyHostToDevice, s));
+    cells.zero(s);
+    cursor.zero(s);
+    counts.zero(s);
+    dim3 grid(std::max(1u, std::min(cdiv(maxn, 256), 256u)), N);
+    hipLaunchKernelGGL(k_sh_count, grid, dim3(256), 0, s, (const double*)h->inst.pts.p, (const ShGrid*)d_g.p, cells.p);
+    HMSG_CHECK_LAUNCH();
+    hmsg_scan_u32(cells.p, cells.p, (size_t)ncell, s, scan_tmp, nullptr);
+    hipLaunchKernelGGL(k_sh_fill, grid, dim3(256), 0, s, (const double*)h->inst.pts.p, (const ShGrid*)d_g.p, (const unsigned*)cells.p,
+                       cursor.p, sorted.p);
+    for (size_t t0 = 0; t0 < tasks.size(); t0 += 32768) {
+        unsigned nt = (unsigned)std::min<size_t>(32768, tasks.size() - t0);
+        hipLaunchKernelGGL(k_sh_query, dim3(16, nt), dim3(256), 0, s, (const ShGrid*)d_g.p, (const ShTask*)(d_t.p + t0),
+                           (const long long*)d_voff.p, (const double*)d_verts.p, (const unsigned*)cells.p, (const double*)sorted.p,
+                           radius * radius, counts.p + t0);
+    }
+    HMSG_CHECK_LAUNCH();
+    std::vector<unsigned> hc(tasks.size());
+    HIP_TRY(hipMemcpyAsync(hc.data(), counts.p, tasks.size() * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (size_t k = 0; k < tasks.size(); ++k)
+        share_out[(size_t)tasks[k].inst * R + tasks[k].room] = (double)hc[k] / (double)g[tasks[k].inst].n;
+}

@@ -60,6 +60,37 @@ class _Pcd:
         return len(self.points) == 0
 
 
+class _InstanceStore:
+    """Instance clouds stay in HBM; the first access downloads all of them once."""
+
+    def __init__(self, scene):
+        self.scene = scene
+        self.sizes = np.empty((scene.num_instances(),), np.int64)
+        if len(self.sizes):
+            scene._ck(scene.L.c.hmsg_get_instance_sizes(scene.h, self.sizes.ctypes.data_as(__import__("ctypes").c_void_p)))
+        self._clouds = None
+
+    def get(self, i):
+        if self._clouds is None:
+            self._clouds = self.scene.instances()
+        return self._clouds[i]
+
+
+class _LazyPcd:
+    def __init__(self, store, i):
+        self._store, self._i = store, i
+
+    @property
+    def points(self):
+        return self._store.get(self._i)
+
+    def get_center(self):
+        return self.points.mean(axis=0)
+
+    def is_empty(self):
+        return int(self._store.sizes[self._i]) == 0
+
+
 def _write_ply(path, pts):
     pts = np.asarray(pts, dtype=np.float64).reshape(-1, 3)
     with open(path, "wb") as f:
@@ -157,7 +188,8 @@ class Object:  # graph/object.py:9-106
 
     def save(self, path):
         _write_ply(os.path.join(path, str(self.object_id) + ".ply"), self.pcd.points)
-        meta = dict(object_id=self.object_id, vertices=np.asarray(self.vertices).tolist(), room_id=self.room_id,
+        verts = self.vertices if self.vertices is not None else np.asarray(self.pcd.points)[:, [0, 2]]
+        meta = dict(object_id=self.object_id, vertices=np.asarray(verts).tolist(), room_id=self.room_id,
                     name=self.name, embedding=self.embedding.tolist() if self.embedding is not None else "",
                     view_ids=self.view_ids, best_view_id=self.best_view_id)
         json.dump(meta, open(os.path.join(path, str(self.object_id) + ".json"), "w"))
@@ -380,9 +412,12 @@ class Graph:
 
     # ------------------------------------------------------------------ A10: graph.py:1582-1736
     def segment_hmsg_objects(self, save_dir=None):
+        sizes = boxes = None
         if self.scene is not None:
             self.scene.denoise_instances(0.05, 10)                          # graph.py:1589-1591 on device
-            self.mask_pcds = [_Pcd(x) for x in self.scene.instances()]
+            store = _InstanceStore(self.scene)                               # points stay in HBM until somebody reads them
+            sizes, boxes = store.sizes, self.scene.instance_boxes()
+            self.mask_pcds = [_LazyPcd(store, i) for i in range(len(sizes))]
         text_feats, classes = self._label_feats if self._label_feats is not None else (None, None)
         names = None
         if text_feats is not None and len(self.mask_feats):
@@ -391,32 +426,43 @@ class Graph:
             names = np.argmax(ix.similarity(emb), axis=1)                  # identify_object (graph.py:1441-1454)
             ix.close()
         margin = 0.2
+        share = None
+        room_col = {}
+        if self.scene is not None and self.rooms:
+            # find_intersection_share for every (object, room) pair in one device pass (graph.py:1634-1642)
+            share = self.scene.instance_room_share([r.vertices for r in self.rooms], 0.2)
+            room_col = {r.room_id: k for k, r in enumerate(self.rooms)}
+        room_centre = {r.room_id: np.mean(r.vertices, axis=0) for r in self.rooms}
         for fl in self.floors:
             for i, pcd in enumerate(self.mask_pcds):
-                pts = pcd.points
-                if len(pts) < 10:
+                n_i = int(sizes[i]) if sizes is not None else len(pcd.points)
+                if n_i < 10:
                     continue
-                if not (pts[:, 1].min() > fl.floor_zero_level - margin and
-                        pts[:, 1].max() < fl.floor_zero_level + fl.floor_height + margin):
+                ymin, ymax = (boxes[i, 1], boxes[i, 4]) if boxes is not None else (pcd.points[:, 1].min(), pcd.points[:, 1].max())
+                if not (ymin > fl.floor_zero_level - margin and ymax < fl.floor_zero_level + fl.floor_height + margin):
                     continue
                 if not fl.rooms:
                     continue
-                xz = pts[:, [0, 2]]
-                assoc = [find_intersection_share(r.vertices, xz, 0.2) for r in fl.rooms]
+                if share is not None:
+                    assoc = [float(share[i, room_col[r.room_id]]) for r in fl.rooms]
+                else:
+                    assoc = [find_intersection_share(r.vertices, pcd.points[:, [0, 2]], 0.2) for r in fl.rooms]
                 if np.sum(assoc) == 0:
-                    assoc = [-np.linalg.norm(np.mean(r.vertices, axis=0) - np.mean(xz, axis=0)) for r in fl.rooms]
+                    c = np.mean(pcd.points[:, [0, 2]], axis=0)
+                    assoc = [-np.linalg.norm(room_centre[r.room_id] - c) for r in fl.rooms]
                 room = fl.rooms[int(np.argmax(assoc))]
                 obj = Object(room.room_id + "_" + str(room.object_counter), room.room_id)
                 room.object_counter += 1
                 obj.name = classes[int(names[i])] if names is not None else "object"
-                obj.pcd, obj.vertices, obj.embedding = pcd, xz, np.asarray(self.mask_feats[i]).reshape(-1)
+                obj.pcd, obj.embedding = pcd, np.asarray(self.mask_feats[i]).reshape(-1)
+                obj.vertices = None                                            # = points[:, [0, 2]], materialised on save
                 best, best_d = None, float("inf")
                 for v in room.views:
                     if self.dataset is None or v.img_id is None:
                         continue
                     img, _, pose, _, _ = self.dataset[v.img_id]
                     a = np.asarray(img)
-                    ok, md = check_object_in_view(a.shape[1], a.shape[0], self._K, np.linalg.inv(pose), pts)
+                    ok, md = check_object_in_view(a.shape[1], a.shape[0], self._K, np.linalg.inv(pose), pcd.points)
                     if ok:
                         obj.view_ids.append(v.view_id)
                         v.object_ids.append(obj.object_id)
@@ -580,3 +626,16 @@ class Graph:
         return (self.floors[floor_id] if floor_id != -1 else None, rooms, [self.objects[i] for i in obj_ids], res)
 
     query_hierarchy_protected = query_hierarchy_protected_icra
+
+    # ------------------------------------------------------------------ assembly on an already built Scene
+    @classmethod
+    def from_scene(cls, scene: Scene, cfg=None, encoders=None, lib: HmsgLib | None = None):
+        """Wrap a Scene whose A1..A7 stages already ran (bench.py / services that drive the C ABI directly):
+        the returned Graph can run build_hier_multimodal_scene_graph (A8, A10, A11) and the queries."""
+        g = cls(cfg or dict(main=dict(), models=dict(clip=dict(feat_dim=scene.cfg.feat_dim))), encoders=encoders,
+                lib=lib or scene.L)
+        g.scene = scene
+        g.full_pcd = _Pcd(scene.map_points())
+        g.mask_feats = list(scene.instance_feats())
+        g.mask_pcds = [None] * len(g.mask_feats)
+        return g

@@ -142,6 +142,12 @@ int hmsg_get_instance_feats(const hmsg_t* h, float* feats /*[N][D]*/);
  * (graph.py:1589-1591), in place; call after hmsg_pool_instances like the reference does. */
 int hmsg_denoise_instances(hmsg_t* h, double eps, int32_t min_points);
 
+/* A10 room association (graph.py:1634-1642, find_intersection_share graph_utils.py:160-189): for every
+ * instance i and room r, share[i][r] = #{room-r vertices (x,z) with an instance point within `radius` in the
+ * x/z plane} / #instance points.  verts_xz f64 [sum][2] (host), vert_off i64 [n_rooms+1], share f64 [N][n_rooms]. */
+int hmsg_instance_room_share(hmsg_t* h, int32_t n_rooms, const int64_t* vert_off, const double* verts_xz, double radius,
+                             double* share);
+
 /* ---- A12: retrieval over a node table (graph.py:3056-3162 query_hmsg_object and the GEMV of
  * query_hmsg_room / query_floor).  A table is N node embeddings (f64, as after load_hmsg_graph:
  * object.py:88-89, or f32 right after build) with a parent (room) id per node. */

@@ -79,6 +79,13 @@ def test_graph_end_to_end_tiny(L, tmp_path):
                   view_frames=[0, 3], view_embeddings=[enc.encode_text(["office"])[0], enc.encode_text(["kitchen"])[0]])]
     g.build_hier_multimodal_scene_graph(str(tmp_path), rooms=rooms)
     assert len(g.floors) >= 1
+    # A10 room association on the device == find_intersection_share (utils/graph_utils.py:160-189) on the host
+    from holoagent_amd.graph import find_intersection_share
+    share = g.scene.instance_room_share([r.vertices for r in g.rooms], 0.2)
+    for i, pts in enumerate(g.scene.instances()):
+        for k, r in enumerate(g.rooms):
+            ref = find_intersection_share(r.vertices, pts[:, [0, 2]], 0.2) if len(pts) else 0
+            assert abs(share[i, k] - ref) < 1e-12, (i, k, share[i, k], ref)
     g2 = Graph(dict(main=dict(), models=dict(clip=dict(feat_dim=32))), encoders=enc, lib=L)
     g2.load_hmsg_graph(str(tmp_path / "graph"))
     assert len(g2.objects) == len(g.objects) and len(g2.rooms) == 1
