@@ -22,8 +22,8 @@ struct PoolSeg {            // one instance
     long long bit_base;     // first u32 word of its adjacency bit matrix
     int n;                  // rows (valid points)
     int nw;                 // u32 words per row = ceil(n / 32)
-    long long tile_base;    // first 32x32 tile id
-    int nt;                 // tiles per side = ceil(n / 32)
+    long long tile_base;    // first 64x64 tile id (upper triangle, row-major)
+    int nt;                 // 64x64 tiles per side = ceil(n / 64)
     int pad;
 };
 
@@ -62,64 +62,87 @@ __global__ void k_pool_gather(const int* __restrict__ idx, const unsigned* __res
 }
 
 // ---- Gram tiles on the matrix cores -> adjacency bits + neighbour counts
-// One wave per 32x32 tile.  K is consumed two columns per MFMA (32x32x2 f32): lane l feeds
-// A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; both come from X^ rows staged through LDS in 32-wide
-// K panels so global reads are coalesced.
+// One 256-thread workgroup per 64x64 tile of X^ X^T of one instance, the four waves in a 2x2 arrangement
+// (32x32 accumulator each, v_mfma_f32_32x32x2_f32: lane l feeds A[i = l&31][k = l>>5], B[k = l>>5][j = l&31]).
+// The A and B row panels (64 rows x 32 k) are staged once per workgroup in LDS with 16-byte global loads and
+// shared by two waves each; rows are padded to 33 floats so the fragment reads are conflict free.
+// Only tiles with tj >= ti are computed (the matrix is symmetric): the mirrored adjacency words are built
+// from the same accumulators (a lane owns one column of its 32x32 tile = one mirrored row half).
 __global__ void __launch_bounds__(256) k_pool_gram(const float* __restrict__ Xn, int D, const PoolSeg* __restrict__ segs, int K,
-                                                   long long ntiles, float eps, unsigned* __restrict__ adj,
-                                                   unsigned* __restrict__ ncount) {
-    __shared__ float sa[4][32][33];
-    __shared__ float sb[4][32][33];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    long long tile = (long long)blockIdx.x * 4 + wv;
-    const bool active = tile < ntiles;
-    if (!active) tile = ntiles - 1;
+                                                   float eps, unsigned* __restrict__ adj, unsigned* __restrict__ ncount) {
+    __shared__ float sa[64][33];
+    __shared__ float sb[64][33];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wr = wv >> 1, wc = wv & 1;
+    const long long tile = blockIdx.x;
     int lo = 0, hi = K - 1;
     while (lo < hi) {
         int mid = (lo + hi + 1) >> 1;
         if (segs[mid].tile_base <= tile) lo = mid; else hi = mid - 1;
     }
     const PoolSeg sg = segs[lo];
-    const long long t = tile - sg.tile_base;
-    const int ti = (int)(t / sg.nt), tj = (int)(t % sg.nt);
-    const int r0 = ti * 32, c0 = tj * 32;
+    // upper-triangular tile index -> (ti, tj), ti <= tj
+    long long t = tile - sg.tile_base;
+    int ti = 0;
+    {
+        long long rowlen = sg.nt;
+        while (t >= rowlen) {
+            t -= rowlen;
+            --rowlen;
+            ++ti;
+        }
+    }
+    const int tj = ti + (int)t;
+    const int r0 = ti * 64, c0 = tj * 64;
     f32x16 acc;
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const float* base = Xn + (size_t)sg.row_base * D;
+    const int lrow = tid >> 2, lk = (tid & 3) * 8;          // this thread stages 8 consecutive k of one row
     for (int k0 = 0; k0 < D; k0 += 32) {
-        // stage 32 rows x 32 k of both operands: lane reads row lane>>1, 16 consecutive k
         {
-            int rr = (lane >> 1), kk = (lane & 1) * 16;
-            int ra = r0 + rr, rb = c0 + rr;
-            for (int u = 0; u < 16; ++u) {
-                int k = k0 + kk + u;
-                sa[wv][rr][kk + u] = (ra < sg.n && k < D) ? base[(size_t)ra * D + k] : 0.f;
-                sb[wv][rr][kk + u] = (rb < sg.n && k < D) ? base[(size_t)rb * D + k] : 0.f;
+            const int ra = r0 + lrow, rb = c0 + lrow;
+            for (int u = 0; u < 8; ++u) {
+                int k = k0 + lk + u;
+                sa[lrow][lk + u] = (ra < sg.n && k < D) ? base[(size_t)ra * D + k] : 0.f;
+                sb[lrow][lk + u] = (rb < sg.n && k < D) ? base[(size_t)rb * D + k] : 0.f;
             }
         }
         __syncthreads();
         for (int k = 0; k < 32; k += 2) {
-            float a = sa[wv][lane & 31][k + (lane >> 5)];
-            float b = sb[wv][lane & 31][k + (lane >> 5)];
+            float a = sa[wr * 32 + (lane & 31)][k + (lane >> 5)];
+            float b = sb[wc * 32 + (lane & 31)][k + (lane >> 5)];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
         __syncthreads();
     }
     // epilogue: d = 1 - s, clipped to [0, 2], diagonal forced to 0; neighbour iff d <= eps
-    const int col = c0 + (lane & 31);
+    const int rbase = r0 + wr * 32, cbase = c0 + wc * 32;
+    const int col = cbase + (lane & 31);
+    const bool diag_block = (ti == tj);
+    unsigned mirror = 0u;                                   // bits over rows rbase..rbase+31 for column `col`
     for (int r = 0; r < 16; ++r) {
-        int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int rloc = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int row = rbase + rloc;
         float d = __fadd_rn(-acc[r], 1.0f);
         d = fminf(fmaxf(d, 0.f), 2.f);
         if (row == col) d = 0.f;
-        bool nb = active && row < sg.n && col < sg.n && d <= eps;
+        const bool nb = row < sg.n && col < sg.n && d <= eps;
+        mirror |= (nb ? 1u : 0u) << rloc;
         unsigned long long m = __ballot(nb);
-        if ((lane & 31) == 0 && active) {
+        if ((lane & 31) == 0) {
             unsigned word = (unsigned)(lane ? (m >> 32) : (m & 0xffffffffull));
             if (row < sg.n && word) {
-                adj[sg.bit_base + (size_t)row * sg.nw + tj] = word;
+                adj[sg.bit_base + (size_t)row * sg.nw + (cbase >> 5)] = word;
                 atomicAdd(&ncount[sg.row_base + row], (unsigned)__popc(word));
             }
+        }
+    }
+    if (!diag_block) {
+        // mirrored 32x32 block: row `col`, word index rbase/32; the two lane halves hold disjoint row bits
+        unsigned other = __shfl_xor(mirror, 32);
+        unsigned word = mirror | other;
+        if (lane < 32 && col < sg.n && word) {
+            adj[sg.bit_base + (size_t)col * sg.nw + (rbase >> 5)] = word;
+            atomicAdd(&ncount[sg.row_base + col], (unsigned)__popc(word));
         }
     }
 }
@@ -321,12 +344,12 @@ void hmsg_pool(hmsg_ctx* h) {
         g.row_base = hpos[k];
         g.n = (int)(hpos[k + 1] - hpos[k]);
         g.nw = (g.n + 31) / 32;
-        g.nt = g.nw;
+        g.nt = (g.n + 63) / 64;
         g.bit_base = bitw;
         g.tile_base = tiles;
         g.pad = 0;
         bitw += (long long)g.n * g.nw;
-        tiles += (long long)g.nt * g.nt;
+        tiles += (long long)g.nt * (g.nt + 1) / 2;      // upper triangle of 64x64 tiles
         maxn = std::max(maxn, g.n);
     }
     DevBuf<PoolSeg> d_ps;
@@ -360,10 +383,10 @@ void hmsg_pool(hmsg_ctx* h) {
                            (const PoolSeg*)d_ps.p, seg_of_row.p);
         {
             double flop = 0;
-            for (auto& g : ps) flop += 2.0 * (double)g.n * (double)g.n * D;
+            for (auto& g : ps) flop += (double)g.n * ((double)g.n + 1.0) * D;   // unique pairs x 2 FLOP x D
             ProfScope psc(h->prof, s, "k_pool_gram", flop);
-            hipLaunchKernelGGL(k_pool_gram, dim3(cdiv((size_t)tiles, 4)), dim3(256), 0, s, (const float*)Xn.p, D,
-                               (const PoolSeg*)d_ps.p, K, tiles, (float)c.feat_dbscan_eps, adj.p, ncount.p);
+            hipLaunchKernelGGL(k_pool_gram, dim3((unsigned)tiles), dim3(256), 0, s, (const float*)Xn.p, D, (const PoolSeg*)d_ps.p, K,
+                               (float)c.feat_dbscan_eps, adj.p, ncount.p);
         }
         hipLaunchKernelGGL(k_pool_init, dim3(cdiv((size_t)R, 256)), dim3(256), 0, s, (const unsigned*)ncount.p, (long long)R,
                            c.feat_dbscan_min, label.p, (const PoolSeg*)d_ps.p, (const int*)seg_of_row.p);
