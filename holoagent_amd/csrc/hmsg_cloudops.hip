@@ -81,16 +81,21 @@ __global__ void k_db_core(const double* __restrict__ pts, long long N, const int
     if (!is_core) {
         int ix, iy, iz, n = 0;
         cell_xyz(sg, c, ix, iy, iz);
-        for (int dx = -2; dx <= 2 && n < minpts; ++dx)
-            for (int dy = -2; dy <= 2 && n < minpts; ++dy)
-                for (int dz = -2; dz <= 2 && n < minpts; ++dz) {
-                    int jx = ix + dx, jy = iy + dy, jz = iz + dz;
-                    if (jx < 0 || jy < 0 || jz < 0 || jx >= sg.nx || jy >= sg.ny || jz >= sg.nz) continue;
-                    long long c2 = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz + jz;
-                    unsigned s0 = start[c2], e0 = s0 + cnt[c2];
-                    for (unsigned k = s0; k < e0 && n < minpts; ++k)
-                        n += dist2_f64(pts + (size_t)ord[k] * 3, pts + (size_t)i * 3) < eps2 ? 1 : 0;
-                }
+        // the 5 z-cells of a (dx, dy) column are consecutive cell ids, so their points are ONE contiguous range
+        // of the cell-sorted order: 25 ranges instead of 125 cell probes
+        const int z0 = max(iz - 2, 0), z1 = min(iz + 2, sg.nz - 1);
+        for (int dx = -2; dx <= 2 && n < minpts; ++dx) {
+            int jx = ix + dx;
+            if (jx < 0 || jx >= sg.nx) continue;
+            for (int dy = -2; dy <= 2 && n < minpts; ++dy) {
+                int jy = iy + dy;
+                if (jy < 0 || jy >= sg.ny) continue;
+                long long cb = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz;
+                const unsigned e0 = start[cb + z1 + 1];
+                for (unsigned k = start[cb + z0]; k < e0 && n < minpts; ++k)
+                    n += dist2_f64(pts + (size_t)ord[k] * 3, pts + (size_t)i * 3) < eps2 ? 1 : 0;
+            }
+        }
         is_core = n >= minpts;
     }
     core[i] = is_core ? 1 : 0;
@@ -399,32 +404,28 @@ __global__ void k_db_label(const double* __restrict__ pts, long long N, const in
         int ix, iy, iz;
         cell_xyz(sg, c, ix, iy, iz);
         unsigned bestkey = INF32;
-        for (int dx = -2; dx <= 2; ++dx)
-            for (int dy = -2; dy <= 2; ++dy)
-                for (int dz = -2; dz <= 2; ++dz) {
-                    int jx = ix + dx, jy = iy + dy, jz = iz + dz;
-                    if (jx < 0 || jy < 0 || jz < 0 || jx >= sg.nx || jy >= sg.ny || jz >= sg.nz) continue;
-                    long long c2 = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz + jz;
-                    unsigned n2 = cnt[c2];
-                    if (!n2) continue;
-                    unsigned s0 = start[c2];
-                    int r = -1;
-                    unsigned key = INF32;
-                    for (unsigned k = s0; k < s0 + n2; ++k) {
-                        unsigned j = ord[k];
-                        if (!core[j]) continue;
-                        if (r < 0) {
-                            r = parent[c2];
-                            key = rootmin[r];
-                            if (key >= bestkey) break;      // this cell's cluster cannot improve the choice
-                        }
-                        if (dist2_f64(pts + (size_t)j * 3, pts + (size_t)i * 3) < eps2) {
-                            bestkey = key;
-                            lab = r;
-                            break;
-                        }
+        const int z0 = max(iz - 2, 0), z1 = min(iz + 2, sg.nz - 1);
+        for (int dx = -2; dx <= 2; ++dx) {
+            int jx = ix + dx;
+            if (jx < 0 || jx >= sg.nx) continue;
+            for (int dy = -2; dy <= 2; ++dy) {
+                int jy = iy + dy;
+                if (jy < 0 || jy >= sg.ny) continue;
+                long long cb = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz;
+                const unsigned e0 = start[cb + z1 + 1];
+                for (unsigned k = start[cb + z0]; k < e0; ++k) {
+                    unsigned j = ord[k];
+                    if (!core[j]) continue;
+                    int r = parent[cellid[j]];
+                    unsigned key = rootmin[r];
+                    if (key >= bestkey) continue;             // cannot improve the choice
+                    if (dist2_f64(pts + (size_t)j * 3, pts + (size_t)i * 3) < eps2) {
+                        bestkey = key;
+                        lab = r;
                     }
                 }
+            }
+        }
     }
     if (in_range) label[i] = lab;
     // cluster sizes / first member index: one atomic per (wave, label) instead of one per point -- whole
@@ -620,7 +621,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     hipLaunchKernelGGL(k_db_segid, dim3(std::max(1u, std::min(cdiv(maxn, 256), 1024u)), K), dim3(256), 0, s, dsegs, K, segid.p);
     hipLaunchKernelGGL(k_db_cell, dim3(gN), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, cellid.p, cnt.p);
     HMSG_CHECK_LAUNCH();
-    hmsg_scan_u32(cnt.p, start.p, (size_t)NC, s, scan_tmp, nullptr);
+    hmsg_scan_u32(cnt.p, start.p, (size_t)NC + 1, s, scan_tmp, nullptr);   // start[NC] = N (end sentinel)
     hipLaunchKernelGGL(k_db_fill, dim3(gN), dim3(256), 0, s, N, (const long long*)cellid.p, (const unsigned*)start.p, cursor.p, ord.p);
     corelist.ensure((size_t)std::max<long long>(N, 1));
     cellpos.ensure((size_t)NC);
