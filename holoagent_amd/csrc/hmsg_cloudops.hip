@@ -413,15 +413,22 @@ __global__ void k_db_label(const double* __restrict__ pts, long long N, const in
                 if (jy < 0 || jy >= sg.ny) continue;
                 long long cb = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz;
                 const unsigned e0 = start[cb + z1 + 1];
+                long long done_cell = -1;                      // cores of one cell share a cluster: decide a cell once
                 for (unsigned k = start[cb + z0]; k < e0; ++k) {
                     unsigned j = ord[k];
                     if (!core[j]) continue;
-                    int r = parent[cellid[j]];
+                    const long long cj = cellid[j];
+                    if (cj == done_cell) continue;
+                    int r = parent[cj];
                     unsigned key = rootmin[r];
-                    if (key >= bestkey) continue;             // cannot improve the choice
+                    if (key >= bestkey) {                      // cannot improve the choice
+                        done_cell = cj;
+                        continue;
+                    }
                     if (dist2_f64(pts + (size_t)j * 3, pts + (size_t)i * 3) < eps2) {
                         bestkey = key;
                         lab = r;
+                        done_cell = cj;
                     }
                 }
             }

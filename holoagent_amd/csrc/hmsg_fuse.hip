@@ -122,18 +122,23 @@ __global__ void k_nn_stamp(const unsigned short* __restrict__ depth, const doubl
                            int H, int W, int f0, int nfr, NNIndex I, int* __restrict__ nn, unsigned* __restrict__ stamp /*[V][FB]*/) {
     const size_t HW = (size_t)H * W;
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= HW * nfr) return;
+    const bool in_range = t < HW * nfr;
+    if (!in_range) t = HW * nfr - 1;
     int fl = (int)(t / HW);
     int p = (int)(t - (size_t)fl * HW);
     int f = f0 + fl;
     int y = p / W, x = p - y * W;
     double wx, wy, wz;
     int idx = -1;
-    if (backproject(depth[(size_t)f * HW + p], x, y, cam, scale, pose + (size_t)f * 16, wx, wy, wz)) {
+    if (in_range && backproject(depth[(size_t)f * HW + p], x, y, cam, scale, pose + (size_t)f * 16, wx, wy, wz))
         idx = nn_search(I, wx, wy, wz);
-        if (idx >= 0) atomicMax(&stamp[(size_t)idx * FB + fl], (unsigned)p + 1u);
-    }
-    nn[(size_t)f * HW + p] = idx;
+    if (in_range) nn[(size_t)f * HW + p] = idx;
+    // stamp = LARGEST pixel index per (voxel, frame): within a run of consecutive lanes snapping to the same
+    // voxel only the last lane can win, so only it pays for the atomic (runs are ~8 pixels long)
+    const int lane = threadIdx.x & 63;
+    long long key = in_range && idx >= 0 ? ((long long)idx << 8) | fl : -1 - lane;
+    long long nxt = __shfl_down(key, 1);
+    if (key >= 0 && (lane == 63 || nxt != key)) atomicMax(&stamp[(size_t)idx * FB + fl], (unsigned)p + 1u);
 }
 
 // ------------------------------------------------------------------------------------------ K_fuse (A5)
@@ -229,17 +234,32 @@ struct Winner {
 __global__ void k_mcount(const int* __restrict__ nn, const unsigned long long* __restrict__ bits, size_t HW, int f0, int nfr,
                          long long V, int M, unsigned* __restrict__ mcount /*[nfr][V][M]*/) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= HW * nfr) return;
+    const bool in_range = t < HW * nfr;
+    if (!in_range) t = HW * nfr - 1;
     int fl = (int)(t / HW);
     size_t g = (size_t)(f0 + fl) * HW + (t - (size_t)fl * HW);
-    int v = nn[g];
-    if (v < 0) return;
-    unsigned long long b = bits[g];
-    unsigned* row = mcount + ((size_t)fl * V + v) * M;
-    while (b) {
-        int i = __ffsll(b) - 1;
-        b &= b - 1;
-        atomicAdd(&row[i], 1u);
+    int v = in_range ? nn[g] : -1;
+    unsigned long long b = v >= 0 ? bits[g] : 0ull;
+    // runs of consecutive lanes with the same (frame, voxel, mask set): the last lane adds the run length
+    const int lane = threadIdx.x & 63;
+    long long k1 = v >= 0 ? ((long long)v << 8) | fl : -1 - lane;
+    long long p1 = __shfl_up(k1, 1);
+    unsigned long long pb = __shfl_up(b, 1);
+    const bool head = lane == 0 || p1 != k1 || pb != b;
+    unsigned long long heads = __ballot(head);
+    long long n1 = __shfl_down(k1, 1);
+    unsigned long long nb = __shfl_down(b, 1);
+    const bool tail = lane == 63 || n1 != k1 || nb != b;
+    if (v >= 0 && tail && b) {
+        unsigned long long below = heads & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull));
+        int start_lane = 63 - __clzll(below);
+        unsigned len = (unsigned)(lane - start_lane + 1);
+        unsigned* row = mcount + ((size_t)fl * V + v) * M;
+        while (b) {
+            int i = __ffsll(b) - 1;
+            b &= b - 1;
+            atomicAdd(&row[i], len);
+        }
     }
 }
 

@@ -160,36 +160,72 @@ struct VoxAcc {                 // per-slot accumulators (SoA)
     unsigned* n;
 };
 
+// Consecutive pixels of an image row mostly fall into the same voxel, and every global atomic costs a
+// 32-64 B memory transaction (measured: 60 GB of WRITE_SIZE for 307 M pixels with per-pixel atomics), so each
+// wave first adds up its runs of equal slots with a segmented scan; only the last lane of a run touches memory.
 __global__ void k_accum(const unsigned short* __restrict__ depth, const unsigned char* __restrict__ rgb,
                         const double* __restrict__ pose, CamK cam, float scale, int H, int W, int F, GridGeom g,
                         const unsigned long long* __restrict__ bitmap, const unsigned* __restrict__ rank, VoxAcc acc) {
     const size_t HW = (size_t)H * W;
     const size_t total = HW * F;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        int f = (int)(i / HW);
-        int p = (int)(i - (size_t)f * HW);
-        int y = p / W, x = p - y * W;
-        double wx, wy, wz;
-        if (!backproject(depth[i], x, y, cam, scale, pose + (size_t)f * 16, wx, wy, wz)) continue;
-        int ix, iy, iz;
-        cell_of(g, wx, wy, wz, ix, iy, iz);
-        long long lin = lin_of(g, ix, iy, iz);
-        unsigned long long word = bitmap[lin >> 6];
-        unsigned slot = rank[lin >> 6] + (unsigned)__popcll(word & ((1ull << (lin & 63)) - 1ull));
-        double cx = __dadd_rn(g.ox, __dmul_rn((double)ix, g.vs));
-        double cy = __dadd_rn(g.oy, __dmul_rn((double)iy, g.vs));
-        double cz = __dadd_rn(g.oz, __dmul_rn((double)iz, g.vs));
-        long long qx = (long long)llrint((wx - cx) * FIX_SCALE);
-        long long qy = (long long)llrint((wy - cy) * FIX_SCALE);
-        long long qz = (long long)llrint((wz - cz) * FIX_SCALE);
-        atomicAdd((unsigned long long*)&acc.sx[slot], (unsigned long long)qx);
-        atomicAdd((unsigned long long*)&acc.sy[slot], (unsigned long long)qy);
-        atomicAdd((unsigned long long*)&acc.sz[slot], (unsigned long long)qz);
-        const unsigned char* c = rgb + i * 3;
-        atomicAdd(&acc.sr[slot], (unsigned long long)c[0]);
-        atomicAdd(&acc.sg[slot], (unsigned long long)c[1]);
-        atomicAdd(&acc.sb[slot], (unsigned long long)c[2]);
-        atomicAdd(&acc.n[slot], 1u);
+    const int lane = threadIdx.x & 63;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    // wave-uniform trip count (the wave's first lane decides), so the shuffles below see all 64 lanes
+    for (size_t i0 = (size_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < total; i0 += stride) {
+        const size_t i = i0 + lane;
+        bool valid = i < total;
+        unsigned slot = 0xffffffffu;
+        long long qx = 0, qy = 0, qz = 0;
+        unsigned cr = 0, cg = 0, cb = 0, cn = 0;
+        if (valid) {
+            int f = (int)(i / HW);
+            int p = (int)(i - (size_t)f * HW);
+            int y = p / W, x = p - y * W;
+            double wx, wy, wz;
+            valid = backproject(depth[i], x, y, cam, scale, pose + (size_t)f * 16, wx, wy, wz);
+            if (valid) {
+                int ix, iy, iz;
+                cell_of(g, wx, wy, wz, ix, iy, iz);
+                long long lin = lin_of(g, ix, iy, iz);
+                unsigned long long word = bitmap[lin >> 6];
+                slot = rank[lin >> 6] + (unsigned)__popcll(word & ((1ull << (lin & 63)) - 1ull));
+                double cx = __dadd_rn(g.ox, __dmul_rn((double)ix, g.vs));
+                double cy = __dadd_rn(g.oy, __dmul_rn((double)iy, g.vs));
+                double cz = __dadd_rn(g.oz, __dmul_rn((double)iz, g.vs));
+                qx = (long long)llrint((wx - cx) * FIX_SCALE);
+                qy = (long long)llrint((wy - cy) * FIX_SCALE);
+                qz = (long long)llrint((wz - cz) * FIX_SCALE);
+                const unsigned char* c = rgb + i * 3;
+                cr = c[0];
+                cg = c[1];
+                cb = c[2];
+                cn = 1;
+            }
+        }
+        // segmented inclusive scan over runs of equal slot (integer sums: order-independent, exact)
+        unsigned prev = __shfl_up(slot, 1);
+        int flag = (lane == 0 || prev != slot) ? 1 : 0;
+        for (int d = 1; d < 64; d <<= 1) {
+            long long tx = __shfl_up(qx, d), ty = __shfl_up(qy, d), tz = __shfl_up(qz, d);
+            unsigned tr = __shfl_up(cr, d), tg = __shfl_up(cg, d), tb = __shfl_up(cb, d), tn = __shfl_up(cn, d);
+            int tf = __shfl_up(flag, d);
+            if (lane >= d && !flag) {
+                qx += tx; qy += ty; qz += tz;
+                cr += tr; cg += tg; cb += tb; cn += tn;
+                flag = tf;
+            }
+        }
+        unsigned nxt = __shfl_down(slot, 1);
+        const bool tail = lane == 63 || nxt != slot;
+        if (tail && slot != 0xffffffffu) {
+            atomicAdd((unsigned long long*)&acc.sx[slot], (unsigned long long)qx);
+            atomicAdd((unsigned long long*)&acc.sy[slot], (unsigned long long)qy);
+            atomicAdd((unsigned long long*)&acc.sz[slot], (unsigned long long)qz);
+            atomicAdd(&acc.sr[slot], (unsigned long long)cr);
+            atomicAdd(&acc.sg[slot], (unsigned long long)cg);
+            atomicAdd(&acc.sb[slot], (unsigned long long)cb);
+            atomicAdd(&acc.n[slot], cn);
+        }
     }
 }
 
