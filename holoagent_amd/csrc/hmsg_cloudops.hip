@@ -641,7 +641,16 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
                        (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p, eps * eps, min_points, core.p,
                        minidx.p, corelist.p, d_ncore.p, cellpos.p, parent.p);
     }
-    const unsigned gW = 2048;   // persistent grid (8 blocks per CU): waves / threads stride over the core-cell list
+    // persistent grid (8 blocks per CU): waves / threads stride over the core-cell list
+    static int n_cu = 0;
+    if (!n_cu) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        n_cu = std::max(1, prop.multiProcessorCount);
+    }
+    const unsigned gW = (unsigned)n_cu * 8u;
     hipLaunchKernelGGL(k_db_cellbox, dim3(gW), dim3(256), 0, s, src, (const int*)corelist.p, (const unsigned*)d_ncore.p,
                        (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p, (const unsigned char*)core.p,
                        cellbox.p);
