@@ -40,6 +40,7 @@ _SIGS = {
     "hmsg_destroy": (None, [_P]),
     "hmsg_last_error": (C.c_char_p, [_P]),
     "hmsg_version": (C.c_char_p, []),
+    "hmsg_release_cached_memory": (None, []),
     "hmsg_reset": (C.c_int, [_P]),
     "hmsg_set_profiling": (C.c_int, [_P, C.c_int32]),
     "hmsg_profile_count": (C.c_int32, [_P]),

@@ -112,6 +112,8 @@ void hmsg_destroy(hmsg_t* h) {
 
 const char* hmsg_last_error(const hmsg_t* h) { return h ? h->err.c_str() : "null handle"; }
 
+void hmsg_release_cached_memory(void) { dev_cache().trim(); }
+
 int hmsg_reset(hmsg_t* h) {
     if (!h) return HMSG_ERR_INVALID;
     return guard(h, [&] {

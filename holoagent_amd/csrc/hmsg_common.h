@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -33,25 +34,75 @@ struct hmsg_error {
 
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
+// ------------------------------------------------------------------ caching device allocator
+// hipMalloc / hipFree of the GB-sized scratch of one build cost hundreds of ms and synchronise the device, and
+// a service rebuilds scenes over and over: freed blocks are parked in a per-thread, per-device cache and handed
+// out again (first block of at least the requested size and at most twice it).  Safe because every C-ABI entry
+// point synchronises its stream before it returns and a handle is driven by one thread at a time.
+struct DevCache {
+    std::multimap<std::pair<int, size_t>, void*> free_;   // (device, bytes) -> block
+    // (no hipFree in a destructor: it would run at thread exit, possibly after the HIP runtime is gone)
+    void trim() {
+        for (auto& kv : free_) (void)hipFree(kv.second);
+        free_.clear();
+    }
+    void* get(int dev, size_t bytes, size_t* got) {
+        size_t gran = bytes < ((size_t)1 << 20) ? ((size_t)1 << 12) : ((size_t)1 << 21);
+        size_t want = (bytes + gran - 1) / gran * gran;
+        auto it = free_.lower_bound({dev, want});
+        if (it != free_.end() && it->first.first == dev && it->first.second <= want * 2) {
+            void* p = it->second;
+            *got = it->first.second;
+            free_.erase(it);
+            return p;
+        }
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {          // out of memory: drop the cache and retry once
+            for (auto& kv : free_) (void)hipFree(kv.second);
+            free_.clear();
+            e = hipMalloc(&p, want);
+        }
+        if (e != hipSuccess) throw hmsg_error{HMSG_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)};
+        *got = want;
+        return p;
+    }
+    void put(int dev, void* p, size_t bytes) { free_.insert({{dev, bytes}, p}); }
+};
+inline DevCache& dev_cache() {
+    static thread_local DevCache c;
+    return c;
+}
+
 // ------------------------------------------------------------------ device buffer (owned)
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    size_t cap_bytes = 0;
+    int dev = 0;
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) dev_cache().put(dev, p, cap_bytes);
         p = nullptr;
         n = 0;
+        cap_bytes = 0;
     }
     void alloc(size_t count) {
         release();
         if (count == 0) count = 1;
-        HIP_TRY(hipMalloc((void**)&p, count * sizeof(T)));
+        (void)hipGetDevice(&dev);
+        p = (T*)dev_cache().get(dev, count * sizeof(T), &cap_bytes);
         n = count;
+    }
+    void swap(DevBuf& o) {
+        std::swap(p, o.p);
+        std::swap(n, o.n);
+        std::swap(cap_bytes, o.cap_bytes);
+        std::swap(dev, o.dev);
     }
     void ensure(size_t count) {
         // scratch buffers: grow geometrically from a generous floor -- hipFree/hipMalloc synchronise the

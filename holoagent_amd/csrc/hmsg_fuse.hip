@@ -559,8 +559,7 @@ void hmsg_fuse(hmsg_ctx* h) {
                         HIP_TRY(hipMemcpyAsync(bigger.p, h->masks3d.pts.p, (size_t)h->masks3d.total * 24,
                                                hipMemcpyDeviceToDevice, s));
                     HIP_TRY(hipStreamSynchronize(s));
-                    std::swap(bigger.p, h->masks3d.pts.p);
-                    std::swap(bigger.n, h->masks3d.pts.n);
+                    bigger.swap(h->masks3d.pts);
                 }
                 hipLaunchKernelGGL(k_mfinal, dim3(cdiv((size_t)nwords, 256)), dim3(256), 0, s,
                                    (const unsigned long long*)mbitmap.p, (const unsigned*)mrank.p, nwords,

@@ -190,8 +190,7 @@ struct Merger {
         nb.alloc(std::max(need_elems * 2, (size_t)1 << 18));
         if (used_elems) HIP_TRY(hipMemcpyAsync(nb.p, b.p, used_elems * sizeof(T), hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipStreamSynchronize(s));
-        std::swap(nb.p, b.p);
-        std::swap(nb.n, b.n);
+        nb.swap(b);
     }
 
     OvGrid grid_of(const Cloud& c) const {
@@ -611,8 +610,7 @@ void hmsg_denoise_inst(hmsg_ctx* h, double eps, int min_points) {
     out.alloc((size_t)h->inst.total * 3);
     std::vector<DbscanResult> res;
     long long total = ops.dbscan_keep_largest(h->inst.pts.p, segs, eps, min_points, out.p, res);
-    std::swap(out.p, h->inst.pts.p);
-    std::swap(out.n, h->inst.pts.n);
+    out.swap(h->inst.pts);
     h->inst.off.assign(1, 0);
     h->inst.box.clear();
     long long acc = 0;

@@ -72,6 +72,10 @@ void hmsg_destroy(hmsg_t* h);
 const char* hmsg_last_error(const hmsg_t* h);
 const char* hmsg_version(void);
 
+/* The library parks freed device scratch in a per-thread cache (re-allocating GBs per scene costs hundreds of
+ * ms); this returns the calling thread's cached blocks to the driver. */
+void hmsg_release_cached_memory(void);
+
 /* Start a new scene on the same handle: state is cleared, the HBM allocations are kept (what a service
  * that rebuilds maps repeatedly does; the reference constructs a new Graph per scene,
  * application/semantic_scene_reconstrucion_offline/offline_mapping_create_hmsg_hm3d_benchmark.py:70-110). */
