@@ -227,6 +227,19 @@ def main():
                         frac=round(achieved / HBM_PEAK_GBS, 6), traffic=None, launches=launches,
                         avg_launch_ms=round(total_ms / launches, 4), algorithmic_bytes_per_launch=int(per_launch))
 
+    # HBM traffic of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of
+    # this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes) committed under profiles/
+    if roof is not None:
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+            key = {"k_db_union/box": "k_db_union", "k_db_union/scan1": "k_db_union_scan",
+                   "k_db_union/scan2": "k_db_union_scan"}.get(roof["kernel"], roof["kernel"])
+            if key in pmc:
+                roof["traffic"] = int(pmc[key]["hbm_bytes_per_launch"])
+                roof["traffic_source"] = "profiles/r01_pmc_traffic.json (offline PMC passes, same command)"
+        except Exception:
+            pass
+
     # ---- CPU baseline: the oracle on a bounded sample of the same frames (rank 0, N=1)
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:
