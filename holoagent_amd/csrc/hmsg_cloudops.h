@@ -16,6 +16,8 @@ struct DbscanResult {            // per segment
     int n_out;
     double mn[3], mx[3];
     int changed;                 // 0: output == input (all points kept)
+    int n_clusters;              // clusters DBSCAN found in the segment
+    int contested;               // some border point had cores of two clusters within eps (only looked for when n_clusters > 1)
 };
 
 struct CloudOps {
@@ -28,9 +30,12 @@ struct CloudOps {
     DevBuf<unsigned> d_ncore;
     DevBuf<double> cellbox;
     DevBuf<long long> cellid;
-    DevBuf<unsigned char> core;
+    DevBuf<unsigned char> core, score;     // core flag per point / per slot of the cell-sorted copy
+    DevBuf<double> spts;                   // cell-sorted copy of the batch's points
     DevBuf<unsigned long long> best, obounds;
-    DevBuf<int> winner, ocount;
+    DevBuf<unsigned> segmin, rep, active, kres, ccore;
+    DevBuf<int> actlist;
+    DevBuf<unsigned char> hasanchor;
     DevBuf<char> geom;           // device copy of per-segment geometry tables
     DevBuf<unsigned long long> vbitmap;
     DevBuf<unsigned> vrank;
@@ -41,8 +46,13 @@ struct CloudOps {
     void bounds(const double* src, std::vector<SegDesc>& segs);
     // keep-largest-cluster DBSCAN of every segment; outputs are written consecutively to `dst`
     // (capacity >= total input points); returns total output points.
+    // core0 (optional, one byte per input point): 1 = ANCHOR point -- a core point of a member cloud that is a
+    // known single-cluster fixed point of this very DBSCAN; at most one such member per segment.  Anchor points
+    // are core and mutually connected by construction, so they are neither counted nor re-connected; the
+    // result is identical to a run without the hint.  dst_core (optional): core flag of every output point.
     long long dbscan_keep_largest(const double* src, const std::vector<SegDesc>& segs, double eps, int min_points,
-                                  double* dst, std::vector<DbscanResult>& res);
+                                  double* dst, std::vector<DbscanResult>& res, const unsigned char* core0 = nullptr,
+                                  unsigned char* dst_core = nullptr);
     // Open3D voxel_down_sample of every segment; outputs consecutively to dst (capacity >= total input
     // points); out_n[k] = points of segment k.
     long long voxel_down_sample(const double* src, const std::vector<SegDesc>& segs, double vs, double* dst,

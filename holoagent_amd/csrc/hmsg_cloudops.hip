@@ -50,13 +50,51 @@ __global__ void k_db_cell(const double* __restrict__ pts, long long N, const int
     atomicAdd(&cnt[c], 1u);
 }
 
-__global__ void k_db_fill(long long N, const long long* __restrict__ cellid, const unsigned* __restrict__ start,
-                          unsigned* __restrict__ cursor, unsigned* __restrict__ ord) {
+// Cell-sorted COPY of the points (+ each point's slot): every neighbourhood scan below walks contiguous runs of
+// it.  Those scans are serial, latency-bound chains per lane (the kernel runs as long as its slowest lane), so
+// a candidate must cost one load, not the ord -> point -> flag chain of an index sort.
+__global__ void k_db_fill(const double* __restrict__ pts, long long N, const long long* __restrict__ cellid,
+                          const unsigned* __restrict__ start, unsigned* __restrict__ cursor, unsigned* __restrict__ rank,
+                          double* __restrict__ spts) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     long long c = cellid[i];
     unsigned p = start[c] + atomicAdd(&cursor[c], 1u);
-    ord[p] = (unsigned)i;
+    rank[i] = p;
+    for (int a = 0; a < 3; ++a) spts[(size_t)p * 3 + a] = pts[(size_t)i * 3 + a];
+}
+
+// number of points of the sorted run [s, e) closer than eps to p, counted until `need` are found; four
+// independent loads in flight per step
+__device__ __forceinline__ int count_within(const double* __restrict__ spts, unsigned s, unsigned e, const double* __restrict__ p,
+                                            double eps2, int have, int need) {
+    for (unsigned k = s; k < e && have < need; k += 4) {
+        double d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned kk = min(k + (unsigned)j, e - 1u);
+            d[j] = dist2_f64(spts + (size_t)kk * 3, p);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) have += (k + (unsigned)j < e && d[j] < eps2) ? 1 : 0;
+    }
+    return have;
+}
+// is some CORE point of the sorted run [s, e) closer than eps to p?
+__device__ __forceinline__ bool any_core_within(const double* __restrict__ spts, const unsigned char* __restrict__ score, unsigned s,
+                                                unsigned e, const double* __restrict__ p, double eps2) {
+    for (unsigned k = s; k < e; k += 4) {
+        bool h = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned kk = min(k + (unsigned)j, e - 1u);
+            const bool c = score[kk] != 0;
+            const double d = dist2_f64(spts + (size_t)kk * 3, p);
+            h = h || (k + (unsigned)j < e && c && d < eps2);
+        }
+        if (h) return true;
+    }
+    return false;
 }
 
 __device__ __forceinline__ void cell_xyz(const DbSeg& sg, long long c, int& ix, int& iy, int& iz) {
@@ -67,47 +105,153 @@ __device__ __forceinline__ void cell_xyz(const DbSeg& sg, long long c, int& ix, 
     ix = (int)(l / sg.ny);
 }
 
+// z-cell range [z0, z1] of grid column (jx, jy) that can hold a point within eps of p (conservative: the x/y
+// gaps to the column are shrunk by a slack far above the rounding of the cell arithmetic, and the z cells come
+// from the same monotone floor((z - oz) / cs) that k_db_cell bins points with).  false: nothing in reach.
+__device__ __forceinline__ bool column_zrange(const DbSeg& sg, const double* __restrict__ p, int jx, int jy, int iz,
+                                              double eps2, int& z0, int& z1) {
+    const double slack = 1e-9;
+    const double x0 = sg.ox + (double)jx * sg.cs, y0 = sg.oy + (double)jy * sg.cs;
+    const double gx = fmax(0.0, fmax(x0 - p[0], p[0] - (x0 + sg.cs)) - slack);
+    const double gy = fmax(0.0, fmax(y0 - p[1], p[1] - (y0 + sg.cs)) - slack);
+    const double rem = eps2 * (1.0 + 1e-9) - gx * gx - gy * gy;
+    if (rem <= 0.0) return false;
+    const double zr = sqrt(rem) + slack;
+    const int a = (int)floor((p[2] - zr - sg.oz) / sg.cs), b = (int)floor((p[2] + zr - sg.oz) / sg.cs);
+    z0 = max(max(iz - 2, 0), a);
+    z1 = min(min(iz + 2, sg.nz - 1), b);
+    return z0 <= z1;
+}
+
 __global__ void k_db_core(const double* __restrict__ pts, long long N, const int* __restrict__ segid,
                           const DbSeg* __restrict__ segs, const long long* __restrict__ cellid,
                           const unsigned* __restrict__ cnt, const unsigned* __restrict__ start,
-                          const unsigned* __restrict__ ord, double eps2, int minpts, unsigned char* __restrict__ core,
-                          unsigned* __restrict__ minidx, int* __restrict__ corecells, unsigned* __restrict__ ncore,
-                          int* __restrict__ cellpos, int* __restrict__ parent) {
+                          const unsigned* __restrict__ rank, const double* __restrict__ spts, unsigned char* __restrict__ score,
+                          double eps2, int minpts, unsigned char* __restrict__ core, unsigned* __restrict__ minidx, int* __restrict__ corecells, unsigned* __restrict__ ncore,
+                          int* __restrict__ cellpos, int* __restrict__ parent, const unsigned char* __restrict__ core0,
+                          unsigned char* __restrict__ hasanchor, unsigned* __restrict__ rep, unsigned* __restrict__ active,
+                          int* __restrict__ actlist, unsigned* __restrict__ nact) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const DbSeg sg = segs[segid[i]];
+    const bool in_range = i < N;
+    if (!in_range) i = N - 1;                // keep the lane alive for the wave collectives below
+    const int k_seg = segid[i];
+    const DbSeg sg = segs[k_seg];
     long long c = cellid[i];
-    bool is_core = cnt[c] >= (unsigned)minpts;
-    if (!is_core) {
+    // anchor points: core points of a member cloud that is a known single-cluster fixed point of this DBSCAN.
+    // More points only raise neighbour counts, so they stay core -- no counting needed.
+    const bool known = core0 != nullptr && core0[i] != 0;
+    bool is_core = known || cnt[c] >= (unsigned)minpts;
+    if (!is_core && in_range) {
         int ix, iy, iz, n = 0;
         cell_xyz(sg, c, ix, iy, iz);
         // the 5 z-cells of a (dx, dy) column are consecutive cell ids, so their points are ONE contiguous range
         // of the cell-sorted order: 25 ranges instead of 125 cell probes
-        const int z0 = max(iz - 2, 0), z1 = min(iz + 2, sg.nz - 1);
+        const double pi[3] = {pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2]};
         for (int dx = -2; dx <= 2 && n < minpts; ++dx) {
             int jx = ix + dx;
             if (jx < 0 || jx >= sg.nx) continue;
             for (int dy = -2; dy <= 2 && n < minpts; ++dy) {
                 int jy = iy + dy;
                 if (jy < 0 || jy >= sg.ny) continue;
+                int z0, z1;
+                if (!column_zrange(sg, pi, jx, jy, iz, eps2, z0, z1)) continue;
                 long long cb = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz;
-                const unsigned e0 = start[cb + z1 + 1];
-                for (unsigned k = start[cb + z0]; k < e0 && n < minpts; ++k)
-                    n += dist2_f64(pts + (size_t)ord[k] * 3, pts + (size_t)i * 3) < eps2 ? 1 : 0;
+                n = count_within(spts, start[cb + z0], start[cb + z1 + 1], pi, eps2, n, minpts);
             }
         }
         is_core = n >= minpts;
     }
-    core[i] = is_core ? 1 : 0;
-    if (is_core && (unsigned)(i - sg.pt_base) < minidx[c]) {   // (stale read is only conservative)
-        // the first core point of a cell (it sees the initial INF) registers the cell in the compact list
-        unsigned old = atomicMin(&minidx[c], (unsigned)(i - sg.pt_base));
-        if (old == INF32) {
-            unsigned p = atomicAdd(ncore, 1u);
+    is_core = is_core && in_range;
+    if (in_range) {
+        core[i] = is_core ? 1 : 0;
+        score[rank[i]] = is_core ? 1 : 0;
+    }
+    const int lane = threadIdx.x & 63;
+    // the first core point of a cell (it sees the initial INF) registers the cell in the compact list; list
+    // slots are handed out per wave (one atomic on the list counter per wave, not per cell)
+    bool reg = false;
+    if (is_core && (unsigned)(i - sg.pt_base) < minidx[c])     // (stale read is only conservative)
+        reg = atomicMin(&minidx[c], (unsigned)(i - sg.pt_base)) == INF32;
+    unsigned long long m = __ballot(reg);
+    if (m) {
+        const int leader = __ffsll(m) - 1;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(ncore, (unsigned)__popcll(m));
+        base = __shfl(base, leader);
+        if (reg) {
+            const unsigned p = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
             corecells[p] = (int)c;
             cellpos[c] = (int)p;
             parent[c] = (int)c;
         }
+    }
+    // cells holding anchor cores are all connected: k_db_anchor hangs them under the segment's lowest one
+    if (is_core && known && !hasanchor[c]) hasanchor[c] = 1;
+    // a core point that is not an anchor: the cell's connections have to be searched (active list)
+    bool act = false;
+    if (is_core && !known && !active[c]) act = atomicExch(&active[c], 1u) == 0u;
+    m = __ballot(act);
+    if (m) {
+        const int leader = __ffsll(m) - 1;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(nact, (unsigned)__popcll(m));
+        base = __shfl(base, leader);
+        if (act) actlist[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (int)c;
+    }
+}
+
+// lowest anchor cell of every segment (one atomic per (wave, segment))
+__global__ void k_db_anchor_min(const int* __restrict__ corecells, const unsigned* __restrict__ ncore,
+                                const DbSeg* __restrict__ segs, int K, const unsigned char* __restrict__ hasanchor,
+                                unsigned* __restrict__ rep) {
+    const unsigned n = *ncore;
+    const unsigned stride = gridDim.x * blockDim.x;
+    for (unsigned w0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); w0 < n; w0 += stride) {
+        const unsigned w = w0 + (threadIdx.x & 63u);
+        int seg = -1;
+        unsigned c = INF32;
+        if (w < n) {
+            c = (unsigned)corecells[w];
+            if (hasanchor[c]) {
+                int lo = 0, hi = K - 1;
+                while (lo < hi) {
+                    int mid = (lo + hi + 1) >> 1;
+                    if (segs[mid].cell_base <= (long long)c) lo = mid; else hi = mid - 1;
+                }
+                seg = lo;
+            }
+        }
+        unsigned long long todo = __ballot(seg >= 0);
+        while (todo) {
+            const int leader = __ffsll(todo) - 1;
+            const int key = __shfl(seg, leader);
+            const bool mine_b = seg == key;
+            const unsigned long long mine = __ballot(mine_b);
+            unsigned v = mine_b ? c : INF32;
+            for (int o = 32; o > 0; o >>= 1) {
+                unsigned t = __shfl_xor(v, o);
+                v = t < v ? t : v;
+            }
+            if ((int)(threadIdx.x & 63) == leader) atomicMin(&rep[key], v);
+            todo &= ~mine;
+        }
+    }
+}
+
+// anchor cells start out as one component (root = the lowest anchor cell of the segment)
+__global__ void k_db_anchor(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, const DbSeg* __restrict__ segs,
+                            int K, const unsigned char* __restrict__ hasanchor, const unsigned* __restrict__ rep,
+                            int* __restrict__ parent) {
+    const unsigned n = *ncore;
+    for (unsigned w = blockIdx.x * blockDim.x + threadIdx.x; w < n; w += gridDim.x * blockDim.x) {
+        const int c = corecells[w];
+        if (!hasanchor[c]) continue;
+        int lo = 0, hi = K - 1;
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (segs[mid].cell_base <= (long long)c) lo = mid; else hi = mid - 1;
+        }
+        parent[c] = (int)rep[lo];
     }
 }
 
@@ -154,16 +298,19 @@ __device__ __forceinline__ void uf_union(int* parent, int a, int b) {
 // AABB of the core points of every core cell (one wave per cell)
 __global__ void k_db_cellbox(const double* __restrict__ pts, const int* __restrict__ corecells, const unsigned* __restrict__ ncore,
                              const unsigned* __restrict__ cnt, const unsigned* __restrict__ start, const unsigned* __restrict__ ord,
-                             const unsigned char* __restrict__ core, double* __restrict__ cellbox) {
+                             const unsigned char* __restrict__ core, double* __restrict__ cellbox,
+                             unsigned* __restrict__ ccore) {
     const int lane = threadIdx.x & 63;
     const unsigned nwaves = (gridDim.x * blockDim.x) >> 6, ncells = *ncore;
     for (unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < ncells; w += nwaves) {
     const long long c = corecells[w];
     const unsigned s0 = start[c], e0 = s0 + cnt[c];
     double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    int ncorepts = 0;
     for (unsigned k = s0 + lane; k < e0; k += 64) {
-        unsigned i = ord[k];
+        unsigned i = k;                          // (pts / core: the cell-sorted copies)
         if (!core[i]) continue;
+        ++ncorepts;
         for (int a = 0; a < 3; ++a) {
             double v = pts[(size_t)i * 3 + a];
             mn[a] = v < mn[a] ? v : mn[a];
@@ -174,11 +321,14 @@ __global__ void k_db_cellbox(const double* __restrict__ pts, const int* __restri
         mn[a] = wave_min_f64(mn[a]);
         mx[a] = wave_max_f64(mx[a]);
     }
-    if (lane == 0)
+    ncorepts = wave_sum_i32(ncorepts);
+    if (lane == 0) {
         for (int a = 0; a < 3; ++a) {
             cellbox[(size_t)w * 6 + a] = mn[a];
             cellbox[(size_t)w * 6 + 3 + a] = mx[a];
         }
+        ccore[w] = (unsigned)ncorepts;           // core points of the cell (cluster sizes are summed per cell)
+    }
     }
 }
 
@@ -189,7 +339,10 @@ __global__ void k_db_union(const double* __restrict__ pts, const int* __restrict
                            const DbSeg* __restrict__ segs, int K, const unsigned* __restrict__ cnt,
                            const unsigned* __restrict__ start, const unsigned* __restrict__ ord,
                            const unsigned char* __restrict__ core, const unsigned* __restrict__ minidx, double eps2, int pass,
-                           const int* __restrict__ cellpos, const double* __restrict__ cellbox, int* __restrict__ parent) {
+                           const int* __restrict__ cellpos, const double* __restrict__ cellbox, int* __restrict__ parent,
+                           const unsigned* __restrict__ active) {
+    // (corecells / ncore: the ACTIVE core cells -- cells whose cores are all anchor points are pre-connected.  A pair
+    //  is handled from its active member; from the higher one when both are active.)
     const int lane = threadIdx.x & 63;
     const unsigned nwaves = (gridDim.x * blockDim.x) >> 6, ncells = *ncore;
     for (unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < ncells; w += nwaves) {
@@ -212,7 +365,7 @@ __global__ void k_db_union(const double* __restrict__ pts, const int* __restrict
         int jx = ix + dx, jy = iy + dy, jz = iz + dz;
         if (jx < 0 || jy < 0 || jz < 0 || jx >= sg.nx || jy >= sg.ny || jz >= sg.nz) continue;
         long long c2 = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz + jz;
-        if (c2 <= c || minidx[c2] == INF32) continue;
+        if (minidx[c2] == INF32 || (c2 < c && active[c2])) continue;
         if (uf_find_cached(parent, (int)c) == uf_find_cached(parent, (int)c2)) continue;
         // tight AABBs of the two cells' core points decide most pairs without touching a point:
         // farthest corners closer than eps -> every pair is a witness; nearest faces >= eps -> no witness.
@@ -229,7 +382,7 @@ __global__ void k_db_union(const double* __restrict__ pts, const int* __restrict
         if (!hit && pass > 0 && mn2 < eps2 * (1.0 + 1e-12)) {
             const unsigned s1 = start[c2], e1 = s1 + cnt[c2];
             for (unsigned a = s0; a < e0 && !hit; ++a) {
-                unsigned ia = ord[a];
+                unsigned ia = a;
                 if (!core[ia]) continue;
                 const double* pa = pts + (size_t)ia * 3;
                 double g2 = 0.0;                       // point-to-box lower bound
@@ -239,7 +392,7 @@ __global__ void k_db_union(const double* __restrict__ pts, const int* __restrict
                 }
                 if (g2 >= eps2 * (1.0 + 1e-12)) continue;
                 for (unsigned b = s1; b < e1; ++b) {
-                    unsigned ib = ord[b];
+                    unsigned ib = b;
                     if (core[ib] && dist2_f64(pa, pts + (size_t)ib * 3) < eps2) {
                         hit = true;
                         break;
@@ -261,7 +414,8 @@ __global__ void k_db_union_scan(const double* __restrict__ pts, const int* __res
                                 const unsigned* __restrict__ cnt, const unsigned* __restrict__ start,
                                 const unsigned* __restrict__ ord, const unsigned char* __restrict__ core,
                                 const unsigned* __restrict__ minidx, double eps2, int pass, const int* __restrict__ cellpos,
-                                const double* __restrict__ cellbox, int* __restrict__ parent) {
+                                const double* __restrict__ cellbox, int* __restrict__ parent,
+                                const unsigned* __restrict__ active) {
     const int lane = threadIdx.x & 63;
     const unsigned nwaves = (gridDim.x * blockDim.x) >> 6, ncells = *ncore;
     for (unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < ncells; w += nwaves) {
@@ -287,7 +441,7 @@ __global__ void k_db_union_scan(const double* __restrict__ pts, const int* __res
               int jx = ix + dx, jy = iy + dy, jz = iz + dz;
               if (cheb == pass && jx >= 0 && jy >= 0 && jz >= 0 && jx < sg.nx && jy < sg.ny && jz < sg.nz) {
                   long long cc = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz + jz;
-                  if (cc > c && minidx[cc] != INF32 && uf_find_cached(parent, (int)c) != uf_find_cached(parent, (int)cc)) {
+                  if (minidx[cc] != INF32 && (cc > c || !active[cc]) && uf_find_cached(parent, (int)c) != uf_find_cached(parent, (int)cc)) {
                       const double* bq = cellbox + (size_t)cellpos[cc] * 6;
                       double mn2 = 0.0, mx2 = 0.0;
                       for (int a = 0; a < 3; ++a) {
@@ -314,7 +468,7 @@ __global__ void k_db_union_scan(const double* __restrict__ pts, const int* __res
             for (unsigned a0 = s0; a0 < e0; a0 += 64) {
                 unsigned a = a0 + lane;
                 if (a < e0) {
-                    unsigned ia = ord[a];
+                    unsigned ia = a;
                     if (core[ia]) {
                         const double* pa = pts + (size_t)ia * 3;
                         double g2 = 0.0;                       // point-to-box lower bound
@@ -324,7 +478,7 @@ __global__ void k_db_union_scan(const double* __restrict__ pts, const int* __res
                         }
                         if (g2 < eps2 * (1.0 + 1e-12))
                             for (unsigned b = s1; b < e1; ++b) {
-                                unsigned ib = ord[b];
+                                unsigned ib = b;
                                 if (core[ib] && dist2_f64(pa, pts + (size_t)ib * 3) < eps2) {
                                     hit = true;
                                     break;
@@ -355,7 +509,9 @@ __global__ void k_db_flatten(const int* __restrict__ corecells, const unsigned* 
 
 // cluster order key: smallest core index of the cluster, kept at the root cell
 __global__ void k_db_rootmin(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, const int* __restrict__ parent,
-                             const unsigned* __restrict__ minidx, unsigned* __restrict__ rootmin) {
+                             const unsigned* __restrict__ minidx, unsigned* __restrict__ rootmin,
+                             const DbSeg* __restrict__ segs, int K, unsigned* __restrict__ segmin,
+                             unsigned* __restrict__ ncl, const unsigned* __restrict__ ccore, unsigned* __restrict__ size) {
     const unsigned n = *ncore;
     const unsigned stride = gridDim.x * blockDim.x;
     // wave-uniform trip count; one atomic per (wave, root): a cluster's cells all target the same word
@@ -363,11 +519,20 @@ __global__ void k_db_rootmin(const int* __restrict__ corecells, const unsigned* 
         unsigned w = w0 + (threadIdx.x & 63u);
         const bool valid = w < n;
         int root = -1;
-        unsigned mi = INF32;
+        unsigned mi = INF32, nc = 0;
         if (valid) {
             int c = corecells[w];
             root = parent[c];
             mi = minidx[c];
+            nc = ccore[w];
+            if (root == c) {                    // one root cell per cluster: clusters of the segment
+                int lo = 0, hi = K - 1;
+                while (lo < hi) {
+                    int mid = (lo + hi + 1) >> 1;
+                    if (segs[mid].cell_base <= (long long)c) lo = mid; else hi = mid - 1;
+                }
+                atomicAdd(&ncl[lo], 1u);
+            }
         }
         unsigned long long todo = __ballot(valid);
         while (todo) {
@@ -375,12 +540,24 @@ __global__ void k_db_rootmin(const int* __restrict__ corecells, const unsigned* 
             int key = __shfl(root, leader);
             const bool mine_b = valid && root == key;
             unsigned long long mine = __ballot(mine_b);
-            unsigned v = mine_b ? mi : INF32;
+            unsigned v = mine_b ? mi : INF32, sum = mine_b ? nc : 0u;
             for (int o = 32; o > 0; o >>= 1) {
                 unsigned t = __shfl_xor(v, o);
                 v = t < v ? t : v;
+                sum += __shfl_xor(sum, o);
             }
-            if ((int)(threadIdx.x & 63) == leader) atomicMin(&rootmin[key], v);
+            if ((int)(threadIdx.x & 63) == leader) {
+                atomicMin(&rootmin[key], v);
+                atomicAdd(&size[key], sum);      // core members; k_db_label adds the border points
+                // smallest key of the whole segment (= its first cluster): lets k_db_label stop at the first
+                // witness of that cluster
+                int lo = 0, hi = K - 1;
+                while (lo < hi) {
+                    int mid = (lo + hi + 1) >> 1;
+                    if (segs[mid].cell_base <= (long long)key) lo = mid; else hi = mid - 1;
+                }
+                if (v < segmin[lo]) atomicMin(&segmin[lo], v);
+            }
             todo &= ~mine;
         }
     }
@@ -388,10 +565,13 @@ __global__ void k_db_rootmin(const int* __restrict__ corecells, const unsigned* 
 
 __global__ void k_db_label(const double* __restrict__ pts, long long N, const int* __restrict__ segid,
                            const DbSeg* __restrict__ segs, const long long* __restrict__ cellid,
-                           const unsigned* __restrict__ cnt, const unsigned* __restrict__ start,
-                           const unsigned* __restrict__ ord, const unsigned char* __restrict__ core,
-                           const int* __restrict__ parent, const unsigned* __restrict__ rootmin, double eps2,
-                           int* __restrict__ label, unsigned* __restrict__ size, unsigned* __restrict__ firstidx) {
+                           const unsigned* __restrict__ minidx, const unsigned* __restrict__ start,
+                           const double* __restrict__ spts, const unsigned char* __restrict__ score,
+                           const unsigned char* __restrict__ core, const int* __restrict__ cellpos,
+                           const double* __restrict__ cellbox, const int* __restrict__ parent, const unsigned* __restrict__ rootmin,
+                           const unsigned* __restrict__ segmin, const unsigned* __restrict__ ncl, double eps2,
+                           int* __restrict__ label, unsigned* __restrict__ size, unsigned* __restrict__ firstidx,
+                           unsigned* __restrict__ contested) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = i < N;
     if (!in_range) i = N - 1;                // keep the lane alive for the wave collectives below
@@ -404,40 +584,53 @@ __global__ void k_db_label(const double* __restrict__ pts, long long N, const in
         int ix, iy, iz;
         cell_xyz(sg, c, ix, iy, iz);
         unsigned bestkey = INF32;
-        const int z0 = max(iz - 2, 0), z1 = min(iz + 2, sg.nz - 1);
-        for (int dx = -2; dx <= 2; ++dx) {
+        const unsigned firstkey = segmin[segid[i]];            // no cluster of the segment orders before this one
+        // With several clusters in the segment we also have to learn whether this border point is CONTESTED
+        // (cores of two clusters within eps): a contested point that ends up outside the kept cluster was a
+        // neighbour of its cores, so the kept cloud is not known to be a fixed point of the next pass.
+        bool settled = ncl[segid[i]] <= 1u;                    // nothing (more) to learn about contests
+        const double pi[3] = {pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2]};
+        for (int dx = -2; dx <= 2 && !(settled && bestkey == firstkey); ++dx) {
             int jx = ix + dx;
             if (jx < 0 || jx >= sg.nx) continue;
-            for (int dy = -2; dy <= 2; ++dy) {
+            for (int dy = -2; dy <= 2 && !(settled && bestkey == firstkey); ++dy) {
                 int jy = iy + dy;
                 if (jy < 0 || jy >= sg.ny) continue;
-                long long cb = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz;
-                const unsigned e0 = start[cb + z1 + 1];
-                long long done_cell = -1;                      // cores of one cell share a cluster: decide a cell once
-                for (unsigned k = start[cb + z0]; k < e0; ++k) {
-                    unsigned j = ord[k];
-                    if (!core[j]) continue;
-                    const long long cj = cellid[j];
-                    if (cj == done_cell) continue;
-                    int r = parent[cj];
-                    unsigned key = rootmin[r];
-                    if (key >= bestkey) {                      // cannot improve the choice
-                        done_cell = cj;
-                        continue;
+                int z0, z1;
+                if (!column_zrange(sg, pi, jx, jy, iz, eps2, z0, z1)) continue;
+                const long long cb = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz;
+                // cores of one cell share a cluster: a cell is decided once, by its cluster and its first witness
+                for (int jz = z0; jz <= z1 && !(settled && bestkey == firstkey); ++jz) {
+                    const long long c2 = cb + jz;
+                    if (minidx[c2] == INF32) continue;                       // no core point in the cell
+                    const int r = parent[c2];
+                    if (r == lab) continue;
+                    const unsigned key = rootmin[r];
+                    if (settled && key >= bestkey) continue;                 // nothing to learn from this cell
+                    const double* bb = cellbox + (size_t)cellpos[c2] * 6;    // tight box of its core points
+                    double g2 = 0.0;
+                    for (int q = 0; q < 3; ++q) {
+                        double gq = fmax(0.0, fmax(bb[q] - pi[q], pi[q] - bb[3 + q]));
+                        g2 += gq * gq;
                     }
-                    if (dist2_f64(pts + (size_t)j * 3, pts + (size_t)i * 3) < eps2) {
-                        bestkey = key;
-                        lab = r;
-                        done_cell = cj;
+                    if (g2 >= eps2 * (1.0 + 1e-12)) continue;
+                    if (any_core_within(spts, score, start[c2], start[c2 + 1], pi, eps2)) {
+                        if (lab >= 0) settled = true;                        // second cluster in reach: contested
+                        if (key < bestkey) {
+                            bestkey = key;
+                            lab = r;
+                        }
                     }
                 }
             }
         }
+        if (settled && ncl[segid[i]] > 1u && !contested[segid[i]]) contested[segid[i]] = 1u;
     }
     if (in_range) label[i] = lab;
     // cluster sizes / first member index: one atomic per (wave, label) instead of one per point -- whole
     // waves usually carry a single label, and per-point atomics on one address serialise.
-    const bool valid = in_range && lab >= 0;
+    // (core members were counted per cell by k_db_rootmin, and their smallest index is the cluster key)
+    const bool valid = in_range && lab >= 0 && !core[i];
     unsigned long long todo = __ballot(valid);
     while (todo) {
         int leader = __ffsll(todo) - 1;
@@ -454,7 +647,7 @@ __global__ void k_db_label(const double* __restrict__ pts, long long N, const in
 // cluster roots are core cells: pick the largest cluster per segment (ties: first label in point order)
 __global__ void k_db_pick(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, const DbSeg* __restrict__ segs,
                           int K, const unsigned* __restrict__ size, const unsigned* __restrict__ firstidx,
-                          unsigned long long* __restrict__ best) {
+                          const unsigned* __restrict__ rootmin, unsigned long long* __restrict__ best) {
     const unsigned n = *ncore;
     for (unsigned w = blockIdx.x * blockDim.x + threadIdx.x; w < n; w += gridDim.x * blockDim.x) {
         long long c = corecells[w];
@@ -464,50 +657,68 @@ __global__ void k_db_pick(const int* __restrict__ corecells, const unsigned* __r
             int mid = (lo + hi + 1) >> 1;
             if (segs[mid].cell_base <= c) lo = mid; else hi = mid - 1;
         }
-        unsigned long long key = ((unsigned long long)size[c] << 32) | (unsigned long long)(INF32 - firstidx[c]);
+        const unsigned first = min(firstidx[c], rootmin[c]);
+        unsigned long long key = ((unsigned long long)size[c] << 32) | (unsigned long long)(INF32 - first);
         atomicMax(&best[lo], key);
     }
 }
-__global__ void k_db_winner(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, const DbSeg* __restrict__ segs,
-                            int K, const unsigned* __restrict__ size, const unsigned* __restrict__ firstidx,
-                            const unsigned long long* __restrict__ best, int* __restrict__ winner) {
-    const unsigned n = *ncore;
-    for (unsigned w = blockIdx.x * blockDim.x + threadIdx.x; w < n; w += gridDim.x * blockDim.x) {
-        long long c = corecells[w];
-        if (size[c] == 0u) continue;
-        int lo = 0, hi = K - 1;
-        while (lo < hi) {
-            int mid = (lo + hi + 1) >> 1;
-            if (segs[mid].cell_base <= c) lo = mid; else hi = mid - 1;
-        }
-        unsigned long long key = ((unsigned long long)size[c] << 32) | (unsigned long long)(INF32 - firstidx[c]);
-        if (key == best[lo]) winner[lo] = (int)c;
-    }
-}
-
 // graph_utils.py:853-880: keep the largest cluster unless there is none or it has < 5 points
-__global__ void k_db_flags(long long N, const int* __restrict__ segid, const int* __restrict__ label,
-                           const int* __restrict__ winner, const unsigned* __restrict__ size, unsigned* __restrict__ flags) {
+// (best[k] = size << 32 | ~first member index of the segment's largest cluster, 0 if it has none: the winner's
+//  label is the label of that first member)
+__global__ void k_db_flags(long long N, const int* __restrict__ segid, const DbSeg* __restrict__ segs,
+                           const int* __restrict__ label, const unsigned long long* __restrict__ best,
+                           unsigned* __restrict__ flags) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    int w = winner[segid[i]];
+    const int k = segid[i];
+    const unsigned long long b = best[k];
     bool keep = true;
-    if (w >= 0 && size[w] >= 5u) keep = label[i] == w;
+    if ((unsigned)(b >> 32) >= 5u) keep = label[i] == label[segs[k].pt_base + (long long)(INF32 - (unsigned)(b & 0xffffffffull))];
     flags[i] = keep ? 1u : 0u;
 }
 
 // compaction of the kept points; the last point of every segment derives the segment's output count from
-// the scan (no per-point atomics).  AABBs of segments that lost points are reduced afterwards (host side).
+// the scan (no per-point atomics); the AABB of the kept points of every segment is reduced per wave (one set
+// of atomics per (wave, segment)) so that the host gets counts and boxes with ONE copy and no second pass.
 __global__ void k_db_scatter(const double* __restrict__ pts, long long N, const int* __restrict__ segid,
                              const DbSeg* __restrict__ segs, const unsigned* __restrict__ flags,
-                             const unsigned* __restrict__ pos, double* __restrict__ dst, int* __restrict__ ocount) {
+                             const unsigned* __restrict__ pos, double* __restrict__ dst, int* __restrict__ ocount,
+                             const unsigned char* __restrict__ core, unsigned char* __restrict__ dst_core,
+                             unsigned long long* __restrict__ obounds) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const unsigned f = flags[i], p = pos[i];
-    if (f)
-        for (int a = 0; a < 3; ++a) dst[(size_t)p * 3 + a] = pts[i * 3 + a];
-    const DbSeg sg = segs[segid[i]];
-    if (i == sg.pt_base + sg.n - 1) ocount[segid[i]] = (int)(p + f - pos[sg.pt_base]);
+    const bool in_range = i < N;
+    if (!in_range) i = N - 1;                // keep the lane alive for the wave collectives below
+    const unsigned f = in_range ? flags[i] : 0u, p = pos[i];
+    const int k = segid[i];
+    double v[3] = {0, 0, 0};
+    if (f) {
+        for (int a = 0; a < 3; ++a) {
+            v[a] = pts[i * 3 + a];
+            dst[(size_t)p * 3 + a] = v[a];
+        }
+        if (dst_core) dst_core[p] = core[i];
+    }
+    const DbSeg sg = segs[k];
+    if (in_range && i == sg.pt_base + sg.n - 1) ocount[k] = (int)(p + f - pos[sg.pt_base]);
+    unsigned long long todo = __ballot(f != 0u);
+    while (todo) {
+        const int leader = __ffsll(todo) - 1;
+        const int key = __shfl(k, leader);
+        const bool mine_b = f != 0u && k == key;
+        const unsigned long long mine = __ballot(mine_b);
+        for (int a = 0; a < 3; ++a) {
+            const double lo = wave_min_f64(mine_b ? v[a] : 1e300), hi = wave_max_f64(mine_b ? v[a] : -1e300);
+            if ((int)(threadIdx.x & 63) == leader) {
+                // most waves do not move the box: look (L2-coherent load) before paying for a same-address atomic
+                unsigned long long* qlo = &obounds[(size_t)key * 6 + a];
+                unsigned long long* qhi = &obounds[(size_t)key * 6 + 3 + a];
+                const unsigned long long elo = enc_f64(lo), ehi = enc_f64(hi);
+                if (elo < __hip_atomic_load(qlo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(qlo, elo);
+                if (ehi > __hip_atomic_load(qhi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(qhi, ehi);
+            }
+        }
+        todo &= ~mine;
+    }
 }
 
 struct BdSeg {
@@ -564,8 +775,43 @@ void CloudOps::bounds(const double* src, std::vector<SegDesc>& segs) {
         }
 }
 
+struct DbInit {
+    unsigned *cnt, *cursor, *minidx, *firstidx, *rootmin, *size, *active;
+    unsigned char* hasanchor;
+    unsigned long long* best;
+    int* ocount;
+    unsigned long long* obounds;
+    unsigned *ncl, *segmin, *rep, *contested, *counters;
+    long long NC;
+    int K;
+};
+__global__ void k_db_init(DbInit in) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= in.NC) in.cnt[i] = 0u;          // NC + 1 entries (scan sentinel)
+    if (i < in.NC) {
+        in.cursor[i] = 0u;
+        in.minidx[i] = INF32;
+        in.firstidx[i] = INF32;
+        in.rootmin[i] = INF32;
+        in.size[i] = 0u;
+        in.active[i] = 0u;
+        in.hasanchor[i] = 0;
+    }
+    if (i < in.K) {
+        in.best[i] = 0ull;
+        for (int a = 0; a < 6; ++a) in.obounds[(size_t)i * 6 + a] = a < 3 ? ~0ull : 0ull;
+        in.ocount[i] = 0;
+        in.ncl[i] = 0u;
+        in.segmin[i] = INF32;
+        in.rep[i] = INF32;
+        in.contested[i] = 0u;
+    }
+    if (i < 2) in.counters[i] = 0u;
+}
+
 long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<SegDesc>& segs, double eps, int min_points,
-                                        double* dst, std::vector<DbscanResult>& res) {
+                                        double* dst, std::vector<DbscanResult>& res, const unsigned char* core0,
+                                        unsigned char* dst_core) {
     const int K = (int)segs.size();
     res.assign(K, DbscanResult{});
     if (K == 0) return 0;
@@ -607,39 +853,47 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     cnt.ensure(NC + 1); start.ensure(NC + 1); cursor.ensure(NC); minidx.ensure(NC); firstidx.ensure(NC); size.ensure(NC);
     parent.ensure(NC);
     rootmin.ensure(NC);
-    best.ensure(K); winner.ensure(K); obounds.ensure((size_t)K * 6); ocount.ensure(K);
-    HIP_TRY(hipMemsetAsync(cnt.p, 0, (size_t)(NC + 1) * 4, s));
-    HIP_TRY(hipMemsetAsync(cursor.p, 0, (size_t)NC * 4, s));
-    HIP_TRY(hipMemsetAsync(minidx.p, 0xff, (size_t)NC * 4, s));
-    HIP_TRY(hipMemsetAsync(firstidx.p, 0xff, (size_t)NC * 4, s));
-    HIP_TRY(hipMemsetAsync(rootmin.p, 0xff, (size_t)NC * 4, s));
-    HIP_TRY(hipMemsetAsync(size.p, 0, (size_t)NC * 4, s));
-    HIP_TRY(hipMemsetAsync(best.p, 0, (size_t)K * 8, s));
-    HIP_TRY(hipMemsetAsync(winner.p, 0xff, (size_t)K * 4, s));
-    HIP_TRY(hipMemsetAsync(ocount.p, 0, (size_t)K * 4, s));
-    std::vector<unsigned long long> hb((size_t)K * 6);
-    for (int k = 0; k < K; ++k)
-        for (int a = 0; a < 6; ++a) hb[(size_t)k * 6 + a] = a < 3 ? ~0ull : 0ull;
-    HIP_TRY(hipMemcpyAsync(obounds.p, hb.data(), hb.size() * 8, hipMemcpyHostToDevice, s));
-
+    best.ensure(K);
+    segmin.ensure(K); rep.ensure(K);
+    kres.ensure((size_t)K * 16);            // per segment: n_out | n_clusters | contested | (pad) | 6 x u64 box
+    int* const d_ocount = (int*)kres.p;
+    unsigned* const d_ncl = kres.p + K;
+    unsigned* const d_contested = kres.p + 2 * (size_t)K;
+    unsigned long long* const d_obounds = (unsigned long long*)(kres.p + 4 * (size_t)K);
+    active.ensure(NC); hasanchor.ensure(NC);
+    corelist.ensure((size_t)std::max<long long>(N, 1));
+    actlist.ensure((size_t)std::max<long long>(N, 1));
+    cellpos.ensure((size_t)NC);
+    cellbox.ensure((size_t)std::min<long long>(NC, N) * 6);
+    ccore.ensure((size_t)std::min<long long>(NC, N));
+    d_ncore.ensure(2);                      // [0] core cells, [1] active core cells
     const unsigned gN = cdiv(N, 256), gC = cdiv(NC, 256);
+    {   // every per-cell / per-segment table initialised by one launch (was a dozen memsets per batch)
+        DbInit in;
+        in.cnt = cnt.p; in.cursor = cursor.p; in.minidx = minidx.p; in.firstidx = firstidx.p; in.rootmin = rootmin.p;
+        in.size = size.p; in.active = active.p; in.hasanchor = hasanchor.p;
+        in.best = best.p; in.obounds = d_obounds; in.ocount = d_ocount; in.ncl = d_ncl; in.segmin = segmin.p; in.rep = rep.p; in.contested = d_contested;
+        in.counters = d_ncore.p;
+        in.NC = NC; in.K = K;
+        hipLaunchKernelGGL(k_db_init, dim3(cdiv(NC + 1, 256)), dim3(256), 0, s, in);
+    }
     int maxn = 0;
     for (auto& sd : segs) maxn = std::max(maxn, sd.n);
     hipLaunchKernelGGL(k_db_segid, dim3(std::max(1u, std::min(cdiv(maxn, 256), 1024u)), K), dim3(256), 0, s, dsegs, K, segid.p);
     hipLaunchKernelGGL(k_db_cell, dim3(gN), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, cellid.p, cnt.p);
     HMSG_CHECK_LAUNCH();
     hmsg_scan_u32(cnt.p, start.p, (size_t)NC + 1, s, scan_tmp, nullptr);   // start[NC] = N (end sentinel)
-    hipLaunchKernelGGL(k_db_fill, dim3(gN), dim3(256), 0, s, N, (const long long*)cellid.p, (const unsigned*)start.p, cursor.p, ord.p);
-    corelist.ensure((size_t)std::max<long long>(N, 1));
-    cellpos.ensure((size_t)NC);
-    cellbox.ensure((size_t)std::min<long long>(NC, N) * 6);
-    d_ncore.ensure(1);
-    HIP_TRY(hipMemsetAsync(d_ncore.p, 0, 4, s));
+    spts.ensure((size_t)N * 3);
+    score.ensure(N);
+    hipLaunchKernelGGL(k_db_fill, dim3(gN), dim3(256), 0, s, src, N, (const long long*)cellid.p, (const unsigned*)start.p, cursor.p,
+                       ord.p, spts.p);       // ord: slot of every point in the cell-sorted copy
+    unsigned* d_nact = d_ncore.p + 1;
     {
     ProfScope ps(prof, s, "k_db_core", (double)N * 33.0);
     hipLaunchKernelGGL(k_db_core, dim3(gN), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const long long*)cellid.p,
-                       (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p, eps * eps, min_points, core.p,
-                       minidx.p, corelist.p, d_ncore.p, cellpos.p, parent.p);
+                       (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p, (const double*)spts.p, score.p,
+                       eps * eps, min_points, core.p, minidx.p, corelist.p, d_ncore.p, cellpos.p, parent.p, core0, hasanchor.p, rep.p, active.p, actlist.p,
+                       d_nact);
     }
     // persistent grid (8 blocks per CU): waves / threads stride over the core-cell list
     static int n_cu = 0;
@@ -651,74 +905,88 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
         n_cu = std::max(1, prop.multiProcessorCount);
     }
     const unsigned gW = (unsigned)n_cu * 8u;
-    hipLaunchKernelGGL(k_db_cellbox, dim3(gW), dim3(256), 0, s, src, (const int*)corelist.p, (const unsigned*)d_ncore.p,
-                       (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p, (const unsigned char*)core.p,
-                       cellbox.p);
+    hipLaunchKernelGGL(k_db_cellbox, dim3(gW), dim3(256), 0, s, (const double*)spts.p, (const int*)corelist.p,
+                       (const unsigned*)d_ncore.p, (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p,
+                       (const unsigned char*)score.p, cellbox.p, ccore.p);
+    if (core0) {
+        hipLaunchKernelGGL(k_db_anchor_min, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_ncore.p, dsegs, K,
+                           (const unsigned char*)hasanchor.p, rep.p);
+        hipLaunchKernelGGL(k_db_anchor, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_ncore.p, dsegs, K,
+                           (const unsigned char*)hasanchor.p, (const unsigned*)rep.p, parent.p);
+    }
     for (int pass = 0; pass < 3; ++pass) {
         static const char* const pass_name[3] = {"k_db_union/box", "k_db_union/scan1", "k_db_union/scan2"};
         ProfScope ps(prof, s, pass_name[pass], (double)N * 24.0);
         if (pass == 0)
-            hipLaunchKernelGGL(k_db_union, dim3(gW), dim3(256), 0, s, src, (const int*)corelist.p, (const unsigned*)d_ncore.p, dsegs, K,
-                               (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p, (const unsigned char*)core.p,
-                               (const unsigned*)minidx.p, eps * eps, pass, (const int*)cellpos.p, (const double*)cellbox.p, parent.p);
+            hipLaunchKernelGGL(k_db_union, dim3(gW), dim3(256), 0, s, (const double*)spts.p, (const int*)actlist.p,
+                               (const unsigned*)d_nact, dsegs, K,
+                               (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p, (const unsigned char*)score.p,
+                               (const unsigned*)minidx.p, eps * eps, pass, (const int*)cellpos.p, (const double*)cellbox.p, parent.p,
+                               (const unsigned*)active.p);
         else
-            hipLaunchKernelGGL(k_db_union_scan, dim3(gW), dim3(256), 0, s, src, (const int*)corelist.p, (const unsigned*)d_ncore.p,
+            hipLaunchKernelGGL(k_db_union_scan, dim3(gW), dim3(256), 0, s, (const double*)spts.p, (const int*)actlist.p,
+                               (const unsigned*)d_nact,
                                dsegs, K, (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p,
-                               (const unsigned char*)core.p, (const unsigned*)minidx.p, eps * eps, pass, (const int*)cellpos.p,
-                               (const double*)cellbox.p, parent.p);
+                               (const unsigned char*)score.p, (const unsigned*)minidx.p, eps * eps, pass, (const int*)cellpos.p,
+                               (const double*)cellbox.p, parent.p, (const unsigned*)active.p);
         hipLaunchKernelGGL(k_db_flatten, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_ncore.p, parent.p);
     }
     hipLaunchKernelGGL(k_db_rootmin, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_ncore.p,
-                       (const int*)parent.p, (const unsigned*)minidx.p, rootmin.p);
+                       (const int*)parent.p, (const unsigned*)minidx.p, rootmin.p, dsegs, K, segmin.p, d_ncl, (const unsigned*)ccore.p, size.p);
     {
     ProfScope ps(prof, s, "k_db_label", (double)N * 28.0);
     hipLaunchKernelGGL(k_db_label, dim3(gN), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const long long*)cellid.p,
-                       (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p, (const unsigned char*)core.p,
-                       (const int*)parent.p, (const unsigned*)rootmin.p, eps * eps, label.p, size.p, firstidx.p);
+                       (const unsigned*)minidx.p, (const unsigned*)start.p, (const double*)spts.p, (const unsigned char*)score.p,
+                       (const unsigned char*)core.p, (const int*)cellpos.p, (const double*)cellbox.p,
+                       (const int*)parent.p, (const unsigned*)rootmin.p, (const unsigned*)segmin.p, (const unsigned*)d_ncl, eps * eps,
+                       label.p, size.p, firstidx.p, d_contested);
     }
     hipLaunchKernelGGL(k_db_pick, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_ncore.p, dsegs, K,
-                       (const unsigned*)size.p, (const unsigned*)firstidx.p, best.p);
-    hipLaunchKernelGGL(k_db_winner, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_ncore.p, dsegs, K,
-                       (const unsigned*)size.p, (const unsigned*)firstidx.p, (const unsigned long long*)best.p, winner.p);
-    hipLaunchKernelGGL(k_db_flags, dim3(gN), dim3(256), 0, s, N, (const int*)segid.p, (const int*)label.p, (const int*)winner.p,
-                       (const unsigned*)size.p, flags.p);
+                       (const unsigned*)size.p, (const unsigned*)firstidx.p, (const unsigned*)rootmin.p, best.p);
+    hipLaunchKernelGGL(k_db_flags, dim3(gN), dim3(256), 0, s, N, (const int*)segid.p, dsegs, (const int*)label.p,
+                       (const unsigned long long*)best.p, flags.p);
     HMSG_CHECK_LAUNCH();
     hmsg_scan_u32(flags.p, pos.p, (size_t)N, s, scan_tmp, nullptr);
     {
     ProfScope ps(prof, s, "k_db_scatter", (double)N * 56.0);
     hipLaunchKernelGGL(k_db_scatter, dim3(gN), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const unsigned*)flags.p,
-                       (const unsigned*)pos.p, dst, ocount.p);
+                       (const unsigned*)pos.p, dst, d_ocount, (const unsigned char*)core.p, dst_core, d_obounds);
     }
     HMSG_CHECK_LAUNCH();
-    std::vector<int> hc(K);
-    HIP_TRY(hipMemcpyAsync(hc.data(), ocount.p, (size_t)K * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    long long total = 0;
-    std::vector<SegDesc> redo;          // segments that lost points: their AABB has to be re-reduced
-    std::vector<int> redo_k;
-    for (int k = 0; k < K; ++k) {
-        res[k].n_out = hc[k];
-        res[k].changed = hc[k] != segs[k].n;
-        for (int a = 0; a < 3; ++a) {
-            res[k].mn[a] = hc[k] ? segs[k].mn[a] : 0.0;     // unchanged: the input box is exact
-            res[k].mx[a] = hc[k] ? segs[k].mx[a] : 0.0;
+    {   // debug: HMSG_DEBUG_DBCALL=<n> dumps the n-th batch (inputs + per-point results) under HMSG_DEBUG_DUMP
+        static long long call_no = 0;
+        const char* want = getenv("HMSG_DEBUG_DBCALL");
+        const char* wantn = getenv("HMSG_DEBUG_DBMINN");     // ... or the first batch with at least that many points
+        static bool dumped = false;
+        if ((want && atoll(want) == call_no) || (wantn && !dumped && N >= atoll(wantn) && (dumped = true))) {
+            hmsg_dump("db_pts", src, (size_t)N * 24, s);
+            hmsg_dump("db_segs", geom.p, (size_t)K * sizeof(DbSeg), s);
+            hmsg_dump("db_core", core.p, (size_t)N, s);
+            hmsg_dump("db_label", label.p, (size_t)N * 4, s);
+            hmsg_dump("db_keep", flags.p, (size_t)N * 4, s);
+            hmsg_dump("db_cellid", cellid.p, (size_t)N * 8, s);
+            if (core0) hmsg_dump("db_core0", core0, (size_t)N, s);
         }
-        if (res[k].changed && hc[k] > 0) {
-            SegDesc sd;
-            sd.pt_base = total;
-            sd.n = hc[k];
-            redo.push_back(sd);
-            redo_k.push_back(k);
-        }
-        total += hc[k];
+        ++call_no;
     }
-    if (!redo.empty()) {
-        bounds(dst, redo);
-        for (size_t j = 0; j < redo.size(); ++j)
-            for (int a = 0; a < 3; ++a) {
-                res[redo_k[j]].mn[a] = redo[j].mn[a];
-                res[redo_k[j]].mx[a] = redo[j].mx[a];
-            }
+    // one copy brings back counts, cluster counts, contest flags and the boxes of the kept points
+    std::vector<unsigned> hres((size_t)K * 16);
+    HIP_TRY(hipMemcpyAsync(hres.data(), kres.p, hres.size() * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const unsigned long long* hb = reinterpret_cast<const unsigned long long*>(hres.data() + (size_t)K * 4);
+    long long total = 0;
+    for (int k = 0; k < K; ++k) {
+        const int n_out = (int)hres[k];
+        res[k].n_out = n_out;
+        res[k].changed = n_out != segs[k].n;
+        res[k].n_clusters = (int)hres[(size_t)K + k];
+        res[k].contested = (int)hres[(size_t)2 * K + k];
+        for (int a = 0; a < 3; ++a) {
+            // unchanged: the input box is exact (and maybe tighter bookkeeping upstream relies on it bit for bit)
+            res[k].mn[a] = !n_out ? 0.0 : (res[k].changed ? dec_f64(hb[(size_t)k * 6 + a]) : segs[k].mn[a]);
+            res[k].mx[a] = !n_out ? 0.0 : (res[k].changed ? dec_f64(hb[(size_t)k * 6 + 3 + a]) : segs[k].mx[a]);
+        }
+        total += n_out;
     }
     return total;
 }

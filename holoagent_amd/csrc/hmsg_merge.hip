@@ -33,6 +33,8 @@ struct Cloud {
     double mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
     bool fixed = false;     // pcd_denoise_dbscan(merge eps/min) is known to return it unchanged
     bool fresh = true;      // new or changed since it last went through merge_3d_masks
+    bool anchor = false;    // fixed AND one single cluster, with its core flags persisted next to the pool points:
+                            // usable as the pre-connected anchor of the next DBSCAN it takes part in
     unsigned long long uid = 0;
     // overlap grid (cell side >= r): cellstart[ncell+1] (absolute positions) + cell-sorted float32 points
     bool has_index = false;
@@ -88,6 +90,53 @@ __global__ void k_ov_fill(const double* __restrict__ pool, const OvGrid* __restr
     }
 }
 
+// one z-run of Y's cell-sorted points: is any of them closer than r to (x, y, z)?  (float32 arithmetic of
+// find_overlapping_ratio_faiss: (dx*dx + dy*dy) + dz*dz < r2)
+__device__ __forceinline__ bool ov_scan(const float* __restrict__ sorted, unsigned s0, unsigned e0, float x, float y, float z,
+                                        float r2) {
+    for (unsigned k = s0; k < e0; ++k) {
+        float ddx = __fsub_rn(x, sorted[(size_t)k * 3]), ddy = __fsub_rn(y, sorted[(size_t)k * 3 + 1]),
+              ddz = __fsub_rn(z, sorted[(size_t)k * 3 + 2]);
+        float d2 = __fadd_rn(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)), __fmul_rn(ddz, ddz));
+        if (d2 < r2) return true;
+    }
+    return false;
+}
+
+// does (x, y, z) have a point of Y closer than r?  The point's own cell is scanned first: tested pairs passed
+// the box filter, most points DO overlap, and on a surface that has piled up hundreds of re-observations per
+// cell the witness sits in the own cell -- scanning the 27 cells in grid order found it after thousands of
+// far candidates.
+__device__ __forceinline__ bool ov_hit(const OvGrid& Y, const unsigned* __restrict__ cells, const float* __restrict__ sorted,
+                                       float x, float y, float z, float r2, float r) {
+    if (x < Y.mnx - r || x > Y.mxx + r || y < Y.mny - r || y > Y.mxy + r || z < Y.mnz - r || z > Y.mxz + r) return false;
+    const int cx = (int)floor(((double)x - Y.ox) / Y.cell), cy = (int)floor(((double)y - Y.oy) / Y.cell),
+              cz = (int)floor(((double)z - Y.oz) / Y.cell);
+    const int z0 = max(cz - 1, 0), z1 = min(cz + 1, Y.gz - 1);
+    if (z1 < z0) return false;
+    const bool own = cx >= 0 && cx < Y.gx && cy >= 0 && cy < Y.gy && cz >= 0 && cz < Y.gz;
+    if (own) {
+        const long long c = Y.ix_cell + ((long long)cx * Y.gy + cy) * Y.gz + cz;
+        if (ov_scan(sorted, cells[c], cells[c + 1], x, y, z, r2)) return true;
+    }
+    for (int dx = -1; dx <= 1; ++dx) {
+        const int jx = cx + dx;
+        if (jx < 0 || jx >= Y.gx) continue;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int jy = cy + dy;
+            if (jy < 0 || jy >= Y.gy) continue;
+            const long long c0 = Y.ix_cell + ((long long)jx * Y.gy + jy) * Y.gz;   // z-cells are contiguous
+            if (own && dx == 0 && dy == 0) {                                       // own cell already done
+                if (ov_scan(sorted, cells[c0 + z0], cells[c0 + cz], x, y, z, r2)) return true;
+                if (ov_scan(sorted, cells[c0 + cz + 1], cells[c0 + z1 + 1], x, y, z, r2)) return true;
+            } else if (ov_scan(sorted, cells[c0 + z0], cells[c0 + z1 + 1], x, y, z, r2)) {
+                return true;
+            }
+        }
+    }
+    return false;
+}
+
 // find_overlapping_ratio_faiss (graph_utils.py:645-662): a point of X overlaps when its exact float32
 // nearest neighbour in Y is closer than r^2, i.e. when SOME y has (dx*dx + dy*dy) + dz*dz < r2 in float32.
 __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __restrict__ gr, const OvTask* __restrict__ tasks,
@@ -98,46 +147,25 @@ __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __rest
     unsigned local = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < X.n; i += gridDim.x * blockDim.x) {
         const double* p = pool + (size_t)(X.pt_off + i) * 3;
-        float x = (float)p[0], y = (float)p[1], z = (float)p[2];
-        if (x < Y.mnx - r || x > Y.mxx + r || y < Y.mny - r || y > Y.mxy + r || z < Y.mnz - r || z > Y.mxz + r) continue;
-        int cx = (int)floor(((double)x - Y.ox) / Y.cell), cy = (int)floor(((double)y - Y.oy) / Y.cell),
-            cz = (int)floor(((double)z - Y.oz) / Y.cell);
-        bool hit = false;
-        for (int dx = -1; dx <= 1 && !hit; ++dx) {
-            int jx = cx + dx;
-            if (jx < 0 || jx >= Y.gx) continue;
-            for (int dy = -1; dy <= 1 && !hit; ++dy) {
-                int jy = cy + dy;
-                if (jy < 0 || jy >= Y.gy) continue;
-                int z0 = max(cz - 1, 0), z1 = min(cz + 1, Y.gz - 1);
-                if (z1 < z0) continue;
-                long long c0 = Y.ix_cell + ((long long)jx * Y.gy + jy) * Y.gz;
-                unsigned s0 = cells[c0 + z0], e0 = cells[c0 + z1 + 1];     // z-cells are contiguous
-                for (unsigned k = s0; k < e0; ++k) {
-                    float ddx = __fsub_rn(x, sorted[(size_t)k * 3]), ddy = __fsub_rn(y, sorted[(size_t)k * 3 + 1]),
-                          ddz = __fsub_rn(z, sorted[(size_t)k * 3 + 2]);
-                    float d2 = __fadd_rn(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)), __fmul_rn(ddz, ddz));
-                    if (d2 < r2) {
-                        hit = true;
-                        break;
-                    }
-                }
-            }
-        }
-        local += hit ? 1u : 0u;
+        local += ov_hit(Y, cells, sorted, (float)p[0], (float)p[1], (float)p[2], r2, r) ? 1u : 0u;
     }
-    if (local) atomicAdd(&counts[blockIdx.y], local);
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(&counts[blockIdx.y], local);
 }
 
 struct CatSeg {
     long long src, dst;
-    int n, pad;
+    int n, anchor;          // anchor: copy the member's persisted core flags (else the flags are cleared)
 };
-__global__ void k_concat(const double* __restrict__ pool, const CatSeg* __restrict__ segs, double* __restrict__ dst) {
+__global__ void k_concat(const double* __restrict__ pool, const CatSeg* __restrict__ segs, double* __restrict__ dst,
+                         const unsigned char* __restrict__ poolcore, unsigned char* __restrict__ dstcore) {
     const CatSeg sg = segs[blockIdx.y];
     const long long cnt = (long long)sg.n * 3;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (long long)gridDim.x * blockDim.x)
         dst[sg.dst * 3 + i] = pool[sg.src * 3 + i];
+    if (dstcore)
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < sg.n; i += (long long)gridDim.x * blockDim.x)
+            dstcore[sg.dst + i] = sg.anchor ? poolcore[sg.src + i] : (unsigned char)0;
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -158,17 +186,33 @@ double bbox_iou(const Cloud& a, const Cloud& b) {   // graph_utils.py:883-915; e
     return ov / (va + vb - ov);   // 0/0 -> NaN -> comparison false, like numpy
 }
 
+struct IntSpan {
+    const int* b;
+    const int* e;
+    size_t size() const { return (size_t)(e - b); }
+    int operator[](size_t k) const { return b[k]; }
+    const int* begin() const { return b; }
+    const int* end() const { return e; }
+};
+struct CompList {               // components as CSR: members of component c = mem[off[c] .. off[c+1])
+    std::vector<int> off, mem;
+    size_t size() const { return off.empty() ? 0 : off.size() - 1; }
+    IntSpan operator[](size_t c) const { return IntSpan{mem.data() + off[c], mem.data() + off[c + 1]}; }
+};
+
 struct Merger {
     hmsg_ctx* h = nullptr;
     hipStream_t s = nullptr;
     CloudOps ops;
     DevBuf<double> pool;
+    DevBuf<unsigned char> poolcore; // core flag of every pool point (valid for `anchor` clouds)
     long long pool_used = 0;        // points
     DevBuf<unsigned> ix_cells;      // concatenated cellstart arrays (absolute positions into ix_pts)
     long long ix_cells_used = 0;
     DevBuf<float> ix_pts;           // concatenated cell-sorted float32 points
     long long ix_pts_used = 0;      // points
     DevBuf<double> concat;
+    DevBuf<unsigned char> concat_core;
     DevBuf<OvGrid> d_grids;
     DevBuf<OvTask> d_tasks;
     DevBuf<unsigned> d_counts, d_cursor;
@@ -176,6 +220,7 @@ struct Merger {
     unsigned long long next_uid = 1;
     std::unordered_map<unsigned long long, double> ratio_cache;   // hierarchical merge only
     bool use_cache = false;
+    bool use_anchor = true;         // HMSG_DEBUG_NOANCHOR: plain DBSCAN of every batch (tests compare the two)
     double radius = 0;              // 1.5 * voxel_size  (merge_3d_masks passes radius=1.5*radius)
     double cell = 0;
     double eps = 0.1;
@@ -339,7 +384,7 @@ struct Merger {
             // shortcut (2): only pairs with a fresh member; enumerate from the (few) fresh clouds
             // (AABBs in SoA form: the reject test -- boxes disjoint on some axis, overlap volume 0 -- is the hot loop)
             std::vector<double> lo[3], hi[3];
-            std::vector<unsigned char> fr(n);
+            std::vector<unsigned char> fr(n), cand((size_t)n + 8, 0);
             for (int a = 0; a < 3; ++a) {
                 lo[a].resize(n);
                 hi[a].resize(n);
@@ -354,11 +399,21 @@ struct Merger {
             for (int i = 0; i < n; ++i) {
                 if (!fr[i] || L[i].n == 0) continue;
                 const double l0 = lo[0][i], h0 = hi[0][i], l1 = lo[1][i], h1 = hi[1][i], l2 = lo[2][i], h2 = hi[2][i];
-                for (int j = 0; j < n; ++j) {
-                    bool disjoint = (h0 <= lo[0][j]) | (hi[0][j] <= l0) | (h1 <= lo[1][j]) | (hi[1][j] <= l1) | (h2 <= lo[2][j]) |
-                                    (hi[2][j] <= l2);
-                    if (disjoint || j == i || (fr[j] && j < i)) continue;
-                    consider(std::min(i, j), std::max(i, j));
+                // branch-free mask pass (vectorises), then a sparse walk over the few survivors
+                const double *lo0 = lo[0].data(), *lo1 = lo[1].data(), *lo2 = lo[2].data(), *hi0 = hi[0].data(),
+                             *hi1 = hi[1].data(), *hi2 = hi[2].data();
+                unsigned char* cm = cand.data();
+                for (int j = 0; j < n; ++j)
+                    cm[j] = (unsigned char)!((h0 <= lo0[j]) | (hi0[j] <= l0) | (h1 <= lo1[j]) | (hi1[j] <= l1) | (h2 <= lo2[j]) |
+                                             (hi2[j] <= l2));
+                for (int j0 = 0; j0 < n; j0 += 8) {
+                    unsigned long long w;
+                    std::memcpy(&w, cm + j0, 8);               // cand is padded to a multiple of 8
+                    if (!w) continue;
+                    for (int j = j0; j < std::min(j0 + 8, n); ++j) {
+                        if (!cm[j] || j == i || (fr[j] && j < i)) continue;
+                        consider(std::min(i, j), std::max(i, j));
+                    }
                 }
             }
         }
@@ -384,15 +439,22 @@ struct Merger {
         }
         for (size_t k = 0; k < known_pairs.size(); ++k)
             if (known[k] > th) unite(known_pairs[k].first, known_pairs[k].second);
-        std::vector<std::vector<int>> comps;
-        std::vector<int> comp_of(n, -1);
-        for (int i = 0; i < n; ++i) {
-            int r = find(i);
-            if (comp_of[r] < 0) {
-                comp_of[r] = (int)comps.size();
-                comps.emplace_back();
+        // (flat CSR: thousands of clouds per step, nearly all singletons -- no per-component allocations)
+        CompList comps;
+        {
+            std::vector<int> comp_of(n, -1), cid(n);
+            int nc = 0;
+            for (int i = 0; i < n; ++i) {
+                int r = find(i);
+                if (comp_of[r] < 0) comp_of[r] = nc++;      // roots are lowest members: components in index order
+                cid[i] = comp_of[r];
             }
-            comps[comp_of[r]].push_back(i);
+            comps.off.assign((size_t)nc + 1, 0);
+            for (int i = 0; i < n; ++i) ++comps.off[cid[i] + 1];
+            for (int c = 0; c < nc; ++c) comps.off[c + 1] += comps.off[c];
+            comps.mem.resize(n);
+            std::vector<int> cur(comps.off.begin(), comps.off.end() - 1);
+            for (int i = 0; i < n; ++i) comps.mem[cur[cid[i]]++] = i;
         }
         // 3. merge_point_clouds_list per component: concat in index order + keep-largest DBSCAN
         std::vector<int> seg_of_comp(comps.size(), -1);
@@ -406,9 +468,13 @@ struct Merger {
             sd.pt_base = cat_total;
             sd.n = 0;
             bool any = false;
+            int anchor_i = -1;                  // the largest member that can serve as the DBSCAN anchor
+            if (use_anchor)
+                for (int i : mem)
+                    if (L[i].anchor && (anchor_i < 0 || L[i].n > L[anchor_i].n)) anchor_i = i;
             for (int i : mem) {
                 if (L[i].n == 0) continue;
-                cat.push_back(CatSeg{L[i].off, cat_total, L[i].n, 0});
+                cat.push_back(CatSeg{L[i].off, cat_total, L[i].n, i == anchor_i ? 1 : 0});
                 cat_total += L[i].n;
                 sd.n += L[i].n;
                 for (int a = 0; a < 3; ++a) {
@@ -424,6 +490,7 @@ struct Merger {
         long long out_base = pool_used;
         if (!segs.empty() && cat_total > 0) {
             concat.ensure((size_t)cat_total * 3);
+            concat_core.ensure((size_t)cat_total);
             d_cat.ensure(cat.size());
             HIP_TRY(hipMemcpyAsync(d_cat.p, cat.data(), cat.size() * sizeof(CatSeg), hipMemcpyHostToDevice, s));
             int maxn = 0;
@@ -431,13 +498,43 @@ struct Merger {
             for (size_t c0 = 0; c0 < cat.size(); c0 += 32768) {
                 unsigned nc = (unsigned)std::min<size_t>(32768, cat.size() - c0);
                 hipLaunchKernelGGL(k_concat, dim3(std::max(1u, std::min(cdiv((size_t)maxn * 3, 256), 256u)), nc), dim3(256), 0, s,
-                                   (const double*)pool.p, (const CatSeg*)(d_cat.p + c0), concat.p);
+                                   (const double*)pool.p, (const CatSeg*)(d_cat.p + c0), concat.p,
+                                   (const unsigned char*)poolcore.p, use_anchor ? concat_core.p : nullptr);
             }
             HMSG_CHECK_LAUNCH();
             grow(pool, (size_t)pool_used * 3, (size_t)(pool_used + cat_total) * 3);
+            grow(poolcore, (size_t)pool_used, (size_t)(pool_used + cat_total));
             lap(3);
-            ops.dbscan_keep_largest(concat.p, segs, eps, minpts, pool.p + (size_t)pool_used * 3, res);
+            ops.dbscan_keep_largest(concat.p, segs, eps, minpts, pool.p + (size_t)pool_used * 3, res,
+                                    use_anchor ? (const unsigned char*)concat_core.p : nullptr, poolcore.p + pool_used);
             lap(4);
+            if (getenv("HMSG_DEBUG_MERGESTATS")) {
+                long long fixed_pts = 0, big_fixed = 0, removed = 0;
+                int nchanged = 0, multi = 0, multicl = 0, multicl_changed = 0;
+                long long multicl_pts = 0;
+                for (size_t c = 0; c < comps.size(); ++c) {
+                    if (seg_of_comp[c] < 0) continue;
+                    multi += comps[c].size() > 1;
+                    int best = 0;
+                    for (int i : comps[c])
+                        if (L[i].fixed) {
+                            fixed_pts += L[i].n;
+                            best = std::max(best, L[i].n);
+                        }
+                    big_fixed += best;
+                    const DbscanResult& r = res[seg_of_comp[c]];
+                    nchanged += r.changed;
+                    removed += segs[seg_of_comp[c]].n - r.n_out;
+                    if (r.n_clusters > 1) {
+                        ++multicl;
+                        multicl_pts += r.n_out;
+                        multicl_changed += r.changed;
+                    }
+                }
+                fprintf(stderr, "[mstat] clouds %d pairs %zu segs %zu multi %d N %lld fixed_pts %lld anchor_pts %lld changed %d removed %lld multicl %d multicl_changed %d multicl_pts %lld\n",
+                        n, pairs.size(), segs.size(), multi, cat_total, fixed_pts, big_fixed, nchanged, removed, multicl,
+                        multicl_changed, multicl_pts);
+            }
         } else {
             res.assign(segs.size(), DbscanResult{});
         }
@@ -460,8 +557,10 @@ struct Merger {
                 Cloud k = L[mem[0]];
                 k.fresh = false;
                 k.fixed = true;
+                k.off = cursor;                 // the identical copy DBSCAN just wrote: it carries the core flags
+                k.anchor = r.n_clusters == 1;
                 out.push_back(k);
-                cursor += r.n_out;              // its copy in the pool is simply unused
+                cursor += r.n_out;
                 continue;
             }
             Cloud k;
@@ -471,7 +570,15 @@ struct Merger {
                 k.mn[a] = r.mn[a];
                 k.mx[a] = r.mx[a];
             }
-            k.fixed = !r.changed;               // all points kept -> one closed cluster -> fixed point
+            // Fixed point of pcd_denoise_dbscan: all points kept, or no dropped point was an eps-neighbour of a
+            // core point of the kept cluster.  Neighbours of a core point are core (same cluster) or border, so
+            // the only dropped points that can be such neighbours are border points that cores of TWO clusters
+            // reach and that went to the other one ("contested"; impossible with a single cluster).  Without
+            // them, dropping the rest changes no kept core point's neighbour count: the core graph and every
+            // kept border point's witness survive, non-core points stay non-core, a second pass keeps everything
+            // ... and the core flags of the kept points are exactly the ones this pass computed.
+            k.fixed = !r.changed || r.n_clusters == 1 || (r.n_clusters > 1 && !r.contested);
+            k.anchor = k.fixed && r.n_clusters >= 1 && (r.changed || r.n_clusters == 1);
             k.fresh = true;
             k.uid = next_uid++;
             out.push_back(k);
@@ -504,6 +611,8 @@ void hmsg_merge(hmsg_ctx* h) {
     // the 3-D masks of all frames seed the pool (device to device)
     const long long total = h->masks3d.total;
     m.pool.alloc((size_t)std::max<long long>(total * 2, 1 << 16) * 3);
+    m.poolcore.alloc((size_t)std::max<long long>(total * 2, 1 << 16));
+    m.use_anchor = !getenv("HMSG_DEBUG_NOANCHOR");
     if (total) HIP_TRY(hipMemcpyAsync(m.pool.p, h->masks3d.pts.p, (size_t)total * 24, hipMemcpyDeviceToDevice, h->stream));
     m.pool_used = total;
     // AABBs of the frame masks (device reduction)
@@ -581,7 +690,8 @@ void hmsg_merge(hmsg_ctx* h) {
         for (size_t c0 = 0; c0 < cat.size(); c0 += 32768) {
             unsigned nc = (unsigned)std::min<size_t>(32768, cat.size() - c0);
             hipLaunchKernelGGL(k_concat, dim3(std::max(1u, std::min(cdiv((size_t)maxn * 3, 256), 256u)), nc), dim3(256), 0, h->stream,
-                               (const double*)m.pool.p, (const CatSeg*)(m.d_cat.p + c0), h->inst.pts.p);
+                               (const double*)m.pool.p, (const CatSeg*)(m.d_cat.p + c0), h->inst.pts.p,
+                               (const unsigned char*)nullptr, (unsigned char*)nullptr);
         }
         HMSG_CHECK_LAUNCH();
     }

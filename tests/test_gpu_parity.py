@@ -98,3 +98,38 @@ def test_graph_mirror_end_to_end(L, tmp_path):
     from tests.test_emu_parity import test_graph_end_to_end_tiny
     test_graph_end_to_end_tiny.__wrapped__(L, tmp_path) if hasattr(test_graph_end_to_end_tiny, "__wrapped__") \
         else test_graph_end_to_end_tiny(L, tmp_path)
+
+
+def test_merge_shortcuts_are_exact(L):
+    """The merge fold's accelerations (anchor DBSCAN, fixed-point skipping) must not
+    change a single point: the same scene merged with them disabled / forced gives bit-identical instances."""
+    import os
+    from holoagent_amd.synth import SceneSpec, SynthScene
+    spec = SceneSpec(seed=5, rooms_x=2, rooms_z=1, room_size=(4.0, 2.6, 3.5), objects_per_room=5, width=320,
+                     height=240, n_frames=120, n_masks=24, feat_dim=32)
+    scn = SynthScene(spec)
+    frames = [scn.frame(i) for i in range(spec.n_frames)]
+    S = PC.stack_frames(frames)
+    results = []
+    for env in ({}, {"HMSG_DEBUG_NOANCHOR": "1"}):
+        for k in ("HMSG_DEBUG_NOANCHOR",):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        try:
+            sc = PC.make_scene(L, frames, dict(feat_dim=32))
+            sc.add_frames(S["rgb"], S["depth"], S["pose"], S["K"])
+            sc.finalize_map()
+            sc.add_frame_features(0, S["masks"], S["f_g"], S["f_masked"], S["f_crop"])
+            sc.fuse_frames()
+            sc.merge_instances()
+            results.append([np.array(p) for p in sc.instances()])
+            sc.close()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    base = results[0]
+    assert len(base) > 10 and max(len(p) for p in base) > 4096
+    for other in results[1:]:
+        assert len(other) == len(base)
+        for a, b in zip(base, other):
+            assert a.shape == b.shape and np.array_equal(a, b)
