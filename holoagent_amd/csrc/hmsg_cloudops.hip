@@ -678,47 +678,75 @@ __global__ void k_db_flags(long long N, const int* __restrict__ segid, const DbS
 }
 
 // compaction of the kept points; the last point of every segment derives the segment's output count from
-// the scan (no per-point atomics); the AABB of the kept points of every segment is reduced per wave (one set
-// of atomics per (wave, segment)) so that the host gets counts and boxes with ONE copy and no second pass.
+// the scan (no per-point atomics).  The AABB of the kept points of every segment comes back with the counts
+// (one copy, no second pass): a persistent grid walks the points in contiguous chunks, every lane keeps a
+// running box for the segment it is in, and the wave flushes (one set of atomics per (wave, segment)) only
+// when some lane crosses into another segment and at the end -- thousands of waves hitting the same six
+// words of a dominant segment once per 64 points was the slowest thing in the batch.
+__device__ __forceinline__ void db_flush_boxes(bool have, int seg, const double* mn, const double* mx,
+                                               unsigned long long* __restrict__ obounds) {
+    unsigned long long todo = __ballot(have);
+    while (todo) {
+        const int leader = __ffsll(todo) - 1;
+        const int key = __shfl(seg, leader);
+        const bool mine_b = have && seg == key;
+        const unsigned long long mine = __ballot(mine_b);
+        for (int a = 0; a < 3; ++a) {
+            const double lo = wave_min_f64(mine_b ? mn[a] : 1e300), hi = wave_max_f64(mine_b ? mx[a] : -1e300);
+            if ((int)(threadIdx.x & 63) == leader) {
+                atomicMin(&obounds[(size_t)key * 6 + a], enc_f64(lo));
+                atomicMax(&obounds[(size_t)key * 6 + 3 + a], enc_f64(hi));
+            }
+        }
+        todo &= ~mine;
+    }
+}
 __global__ void k_db_scatter(const double* __restrict__ pts, long long N, const int* __restrict__ segid,
                              const DbSeg* __restrict__ segs, const unsigned* __restrict__ flags,
                              const unsigned* __restrict__ pos, double* __restrict__ dst, int* __restrict__ ocount,
                              const unsigned char* __restrict__ core, unsigned char* __restrict__ dst_core,
                              unsigned long long* __restrict__ obounds) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in_range = i < N;
-    if (!in_range) i = N - 1;                // keep the lane alive for the wave collectives below
-    const unsigned f = in_range ? flags[i] : 0u, p = pos[i];
-    const int k = segid[i];
-    double v[3] = {0, 0, 0};
-    if (f) {
-        for (int a = 0; a < 3; ++a) {
-            v[a] = pts[i * 3 + a];
-            dst[(size_t)p * 3 + a] = v[a];
+    const long long per_block = ((N + (long long)gridDim.x * blockDim.x - 1) / ((long long)gridDim.x * blockDim.x)) * blockDim.x;
+    const long long b0 = (long long)blockIdx.x * per_block, b1 = b0 + per_block < N ? b0 + per_block : N;
+    int cur = -1;                            // segment of the running box
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    for (long long base = b0; base < b1; base += blockDim.x) {      // block-uniform trip count
+        const long long i = base + threadIdx.x;
+        const bool in_range = i < b1;
+        unsigned f = 0u;
+        int k = cur;
+        double v[3] = {0, 0, 0};
+        if (in_range) {
+            f = flags[i];
+            k = segid[i];
+            const unsigned p = pos[i];
+            if (f) {
+                for (int a = 0; a < 3; ++a) {
+                    v[a] = pts[i * 3 + a];
+                    dst[(size_t)p * 3 + a] = v[a];
+                }
+                if (dst_core) dst_core[p] = core[i];
+            }
+            const DbSeg sg = segs[k];
+            if (i == sg.pt_base + sg.n - 1) ocount[k] = (int)(p + f - pos[sg.pt_base]);
         }
-        if (dst_core) dst_core[p] = core[i];
-    }
-    const DbSeg sg = segs[k];
-    if (in_range && i == sg.pt_base + sg.n - 1) ocount[k] = (int)(p + f - pos[sg.pt_base]);
-    unsigned long long todo = __ballot(f != 0u);
-    while (todo) {
-        const int leader = __ffsll(todo) - 1;
-        const int key = __shfl(k, leader);
-        const bool mine_b = f != 0u && k == key;
-        const unsigned long long mine = __ballot(mine_b);
-        for (int a = 0; a < 3; ++a) {
-            const double lo = wave_min_f64(mine_b ? v[a] : 1e300), hi = wave_max_f64(mine_b ? v[a] : -1e300);
-            if ((int)(threadIdx.x & 63) == leader) {
-                // most waves do not move the box: look (L2-coherent load) before paying for a same-address atomic
-                unsigned long long* qlo = &obounds[(size_t)key * 6 + a];
-                unsigned long long* qhi = &obounds[(size_t)key * 6 + 3 + a];
-                const unsigned long long elo = enc_f64(lo), ehi = enc_f64(hi);
-                if (elo < __hip_atomic_load(qlo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(qlo, elo);
-                if (ehi > __hip_atomic_load(qhi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(qhi, ehi);
+        if (__any(f != 0u && cur >= 0 && k != cur)) {               // somebody leaves its segment: flush all
+            db_flush_boxes(cur >= 0, cur, mn, mx, obounds);
+            cur = -1;
+            for (int a = 0; a < 3; ++a) {
+                mn[a] = 1e300;
+                mx[a] = -1e300;
             }
         }
-        todo &= ~mine;
+        if (f) {
+            cur = k;
+            for (int a = 0; a < 3; ++a) {
+                mn[a] = v[a] < mn[a] ? v[a] : mn[a];
+                mx[a] = v[a] > mx[a] ? v[a] : mx[a];
+            }
+        }
     }
+    db_flush_boxes(cur >= 0, cur, mn, mx, obounds);
 }
 
 struct BdSeg {
@@ -949,7 +977,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     hmsg_scan_u32(flags.p, pos.p, (size_t)N, s, scan_tmp, nullptr);
     {
     ProfScope ps(prof, s, "k_db_scatter", (double)N * 56.0);
-    hipLaunchKernelGGL(k_db_scatter, dim3(gN), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const unsigned*)flags.p,
+    hipLaunchKernelGGL(k_db_scatter, dim3(std::min(gN, (unsigned)n_cu * 2u)), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const unsigned*)flags.p,
                        (const unsigned*)pos.p, dst, d_ocount, (const unsigned char*)core.p, dst_core, d_obounds);
     }
     HMSG_CHECK_LAUNCH();

@@ -186,6 +186,31 @@ double bbox_iou(const Cloud& a, const Cloud& b) {   // graph_utils.py:883-915; e
     return ov / (va + vb - ov);   // 0/0 -> NaN -> comparison false, like numpy
 }
 
+// cm[j] = box j meets the query box q = {lo0, hi0, lo1, hi1, lo2, hi2} with positive extent on every axis
+// (thousands of boxes per fresh cloud per step: compiled for AVX2 when the host has it)
+#define HMSG_BOX_MASK_BODY                                                                                          \
+    for (int j = 0; j < n; ++j)                                                                                     \
+        cm[j] = (unsigned char)!((q[1] <= lo0[j]) | (hi0[j] <= q[0]) | (q[3] <= lo1[j]) | (hi1[j] <= q[2]) |        \
+                                 (q[5] <= lo2[j]) | (hi2[j] <= q[4]));
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+__attribute__((target("avx2"))) void box_mask_avx2(int n, const double* lo0, const double* hi0, const double* lo1,
+                                                   const double* hi1, const double* lo2, const double* hi2, const double* q,
+                                                   unsigned char* cm) {
+    HMSG_BOX_MASK_BODY
+}
+#endif
+void box_mask(int n, const double* lo0, const double* hi0, const double* lo1, const double* hi1, const double* lo2,
+              const double* hi2, const double* q, unsigned char* cm) {
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+    static const bool have_avx2 = __builtin_cpu_supports("avx2");
+    if (have_avx2) {
+        box_mask_avx2(n, lo0, hi0, lo1, hi1, lo2, hi2, q, cm);
+        return;
+    }
+#endif
+    HMSG_BOX_MASK_BODY
+}
+
 struct IntSpan {
     const int* b;
     const int* e;
@@ -399,13 +424,10 @@ struct Merger {
             for (int i = 0; i < n; ++i) {
                 if (!fr[i] || L[i].n == 0) continue;
                 const double l0 = lo[0][i], h0 = hi[0][i], l1 = lo[1][i], h1 = hi[1][i], l2 = lo[2][i], h2 = hi[2][i];
-                // branch-free mask pass (vectorises), then a sparse walk over the few survivors
-                const double *lo0 = lo[0].data(), *lo1 = lo[1].data(), *lo2 = lo[2].data(), *hi0 = hi[0].data(),
-                             *hi1 = hi[1].data(), *hi2 = hi[2].data();
+                // branch-free mask pass (vectorised), then a sparse walk over the few survivors
                 unsigned char* cm = cand.data();
-                for (int j = 0; j < n; ++j)
-                    cm[j] = (unsigned char)!((h0 <= lo0[j]) | (hi0[j] <= l0) | (h1 <= lo1[j]) | (hi1[j] <= l1) | (h2 <= lo2[j]) |
-                                             (hi2[j] <= l2));
+                const double q[6] = {l0, h0, l1, h1, l2, h2};
+                box_mask(n, lo[0].data(), hi[0].data(), lo[1].data(), hi[1].data(), lo[2].data(), hi[2].data(), q, cm);
                 for (int j0 = 0; j0 < n; j0 += 8) {
                     unsigned long long w;
                     std::memcpy(&w, cm + j0, 8);               // cand is padded to a multiple of 8
@@ -623,11 +645,15 @@ void hmsg_merge(hmsg_ctx* h) {
     }
     m.ops.bounds(m.pool.p, msegs);
     std::vector<std::vector<Cloud>> frames(F);
+    // Empty masks are left out: an empty cloud never pairs (find_overlapping_ratio_faiss returns 0 for it), so it
+    // stays a singleton through every step and is dropped by the min-points filter at the end (graph.py:445-448).
     for (int f = 0; f < F; ++f) {
-        frames[f].resize(M);
+        frames[f].reserve(M);
         for (int i = 0; i < M; ++i) {
-            Cloud& k = frames[f][i];
             const SegDesc& sd = msegs[(size_t)f * M + i];
+            if (sd.n == 0) continue;
+            frames[f].emplace_back();
+            Cloud& k = frames[f].back();
             k.off = sd.pt_base;
             k.n = sd.n;
             k.uid = m.next_uid++;
