@@ -167,37 +167,42 @@ __global__ void k_db_core(const double* __restrict__ pts, long long N, const int
         score[rank[i]] = is_core ? 1 : 0;
     }
     const int lane = threadIdx.x & 63;
-    // the first core point of a cell (it sees the initial INF) registers the cell in the compact list; list
-    // slots are handed out per wave (one atomic on the list counter per wave, not per cell)
+    // the first core point of a cell (it sees the initial INF) registers the cell in the compact list; a core
+    // point that is not an anchor puts its cell on the active list (its connections have to be searched).  List
+    // slots are handed out per BLOCK (waves take block-local offsets from LDS, one global atomic per block and
+    // list): the two counters share a cache line, and an atomic per wave on it was a third of this kernel.
+    __shared__ unsigned s_cnt[2], s_base[2];
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
     bool reg = false;
     if (is_core && (unsigned)(i - sg.pt_base) < minidx[c])     // (stale read is only conservative)
         reg = atomicMin(&minidx[c], (unsigned)(i - sg.pt_base)) == INF32;
-    unsigned long long m = __ballot(reg);
-    if (m) {
-        const int leader = __ffsll(m) - 1;
-        unsigned base = 0;
-        if (lane == leader) base = atomicAdd(ncore, (unsigned)__popcll(m));
-        base = __shfl(base, leader);
-        if (reg) {
-            const unsigned p = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-            corecells[p] = (int)c;
-            cellpos[c] = (int)p;
-            parent[c] = (int)c;
-        }
-    }
     // cells holding anchor cores are all connected: k_db_anchor hangs them under the segment's lowest one
     if (is_core && known && !hasanchor[c]) hasanchor[c] = 1;
-    // a core point that is not an anchor: the cell's connections have to be searched (active list)
     bool act = false;
     if (is_core && !known && !active[c]) act = atomicExch(&active[c], 1u) == 0u;
-    m = __ballot(act);
-    if (m) {
-        const int leader = __ffsll(m) - 1;
-        unsigned base = 0;
-        if (lane == leader) base = atomicAdd(nact, (unsigned)__popcll(m));
-        base = __shfl(base, leader);
-        if (act) actlist[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (int)c;
+    const unsigned long long m_reg = __ballot(reg), m_act = __ballot(act);
+    unsigned off_reg = 0, off_act = 0;
+    if (m_reg) {
+        const int leader = __ffsll(m_reg) - 1;
+        if (lane == leader) off_reg = atomicAdd(&s_cnt[0], (unsigned)__popcll(m_reg));
+        off_reg = __shfl(off_reg, leader) + (unsigned)__popcll(m_reg & ((1ull << lane) - 1ull));
     }
+    if (m_act) {
+        const int leader = __ffsll(m_act) - 1;
+        if (lane == leader) off_act = atomicAdd(&s_cnt[1], (unsigned)__popcll(m_act));
+        off_act = __shfl(off_act, leader) + (unsigned)__popcll(m_act & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(threadIdx.x == 0 ? ncore : nact, s_cnt[threadIdx.x]);
+    __syncthreads();
+    if (reg) {
+        const unsigned p = s_base[0] + off_reg;
+        corecells[p] = (int)c;
+        cellpos[c] = (int)p;
+        parent[c] = (int)c;
+    }
+    if (act) actlist[s_base[1] + off_act] = (int)c;
 }
 
 // lowest anchor cell of every segment (one atomic per (wave, segment))
@@ -667,7 +672,7 @@ __global__ void k_db_pick(const int* __restrict__ corecells, const unsigned* __r
 //  label is the label of that first member)
 __global__ void k_db_flags(long long N, const int* __restrict__ segid, const DbSeg* __restrict__ segs,
                            const int* __restrict__ label, const unsigned long long* __restrict__ best,
-                           unsigned* __restrict__ flags) {
+                           unsigned* __restrict__ flags, unsigned* __restrict__ dropped) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const int k = segid[i];
@@ -675,6 +680,7 @@ __global__ void k_db_flags(long long N, const int* __restrict__ segid, const DbS
     bool keep = true;
     if ((unsigned)(b >> 32) >= 5u) keep = label[i] == label[segs[k].pt_base + (long long)(INF32 - (unsigned)(b & 0xffffffffull))];
     flags[i] = keep ? 1u : 0u;
+    if (!keep && !dropped[k]) dropped[k] = 1u;      // the segment loses points: its box has to be re-reduced
 }
 
 // compaction of the kept points; the last point of every segment derives the segment's output count from
@@ -683,19 +689,32 @@ __global__ void k_db_flags(long long N, const int* __restrict__ segid, const DbS
 // running box for the segment it is in, and the wave flushes (one set of atomics per (wave, segment)) only
 // when some lane crosses into another segment and at the end -- thousands of waves hitting the same six
 // words of a dominant segment once per 64 points was the slowest thing in the batch.
+// (the block's first flushed segment is combined in LDS and reaches the global box once per block: a dominant
+//  segment otherwise draws a dozen same-line L2 atomics from every wave of the grid, which serialise)
 __device__ __forceinline__ void db_flush_boxes(bool have, int seg, const double* mn, const double* mx,
-                                               unsigned long long* __restrict__ obounds) {
+                                               unsigned long long* __restrict__ obounds, int* slot_seg,
+                                               unsigned long long* slot_box) {
     unsigned long long todo = __ballot(have);
     while (todo) {
         const int leader = __ffsll(todo) - 1;
         const int key = __shfl(seg, leader);
         const bool mine_b = have && seg == key;
         const unsigned long long mine = __ballot(mine_b);
+        bool in_lds = false;
+        if ((int)(threadIdx.x & 63) == leader) {
+            const int owner = atomicCAS(slot_seg, -1, key);
+            in_lds = owner == -1 || owner == key;
+        }
         for (int a = 0; a < 3; ++a) {
             const double lo = wave_min_f64(mine_b ? mn[a] : 1e300), hi = wave_max_f64(mine_b ? mx[a] : -1e300);
             if ((int)(threadIdx.x & 63) == leader) {
-                atomicMin(&obounds[(size_t)key * 6 + a], enc_f64(lo));
-                atomicMax(&obounds[(size_t)key * 6 + 3 + a], enc_f64(hi));
+                if (in_lds) {
+                    atomicMin(&slot_box[a], enc_f64(lo));
+                    atomicMax(&slot_box[3 + a], enc_f64(hi));
+                } else {
+                    atomicMin(&obounds[(size_t)key * 6 + a], enc_f64(lo));
+                    atomicMax(&obounds[(size_t)key * 6 + 3 + a], enc_f64(hi));
+                }
             }
         }
         todo &= ~mine;
@@ -705,7 +724,12 @@ __global__ void k_db_scatter(const double* __restrict__ pts, long long N, const 
                              const DbSeg* __restrict__ segs, const unsigned* __restrict__ flags,
                              const unsigned* __restrict__ pos, double* __restrict__ dst, int* __restrict__ ocount,
                              const unsigned char* __restrict__ core, unsigned char* __restrict__ dst_core,
-                             unsigned long long* __restrict__ obounds) {
+                             unsigned long long* __restrict__ obounds, const unsigned* __restrict__ dropped) {
+    __shared__ int slot_seg;
+    __shared__ unsigned long long slot_box[6];
+    if (threadIdx.x == 0) slot_seg = -1;
+    if (threadIdx.x < 6) slot_box[threadIdx.x] = threadIdx.x < 3 ? ~0ull : 0ull;
+    __syncthreads();
     const long long per_block = ((N + (long long)gridDim.x * blockDim.x - 1) / ((long long)gridDim.x * blockDim.x)) * blockDim.x;
     const long long b0 = (long long)blockIdx.x * per_block, b1 = b0 + per_block < N ? b0 + per_block : N;
     int cur = -1;                            // segment of the running box
@@ -730,8 +754,9 @@ __global__ void k_db_scatter(const double* __restrict__ pts, long long N, const 
             const DbSeg sg = segs[k];
             if (i == sg.pt_base + sg.n - 1) ocount[k] = (int)(p + f - pos[sg.pt_base]);
         }
+        if (f && !dropped[k]) f = 0u;                               // segment keeps every point: its input box stays exact
         if (__any(f != 0u && cur >= 0 && k != cur)) {               // somebody leaves its segment: flush all
-            db_flush_boxes(cur >= 0, cur, mn, mx, obounds);
+            db_flush_boxes(cur >= 0, cur, mn, mx, obounds, &slot_seg, slot_box);
             cur = -1;
             for (int a = 0; a < 3; ++a) {
                 mn[a] = 1e300;
@@ -746,7 +771,12 @@ __global__ void k_db_scatter(const double* __restrict__ pts, long long N, const 
             }
         }
     }
-    db_flush_boxes(cur >= 0, cur, mn, mx, obounds);
+    db_flush_boxes(cur >= 0, cur, mn, mx, obounds, &slot_seg, slot_box);
+    __syncthreads();
+    if (threadIdx.x < 6 && slot_seg >= 0) {
+        if (threadIdx.x < 3) atomicMin(&obounds[(size_t)slot_seg * 6 + threadIdx.x], slot_box[threadIdx.x]);
+        else atomicMax(&obounds[(size_t)slot_seg * 6 + threadIdx.x], slot_box[threadIdx.x]);
+    }
 }
 
 struct BdSeg {
@@ -809,7 +839,7 @@ struct DbInit {
     unsigned long long* best;
     int* ocount;
     unsigned long long* obounds;
-    unsigned *ncl, *segmin, *rep, *contested, *counters;
+    unsigned *ncl, *segmin, *rep, *contested, *dropped, *counters;
     long long NC;
     int K;
 };
@@ -833,6 +863,7 @@ __global__ void k_db_init(DbInit in) {
         in.segmin[i] = INF32;
         in.rep[i] = INF32;
         in.contested[i] = 0u;
+        in.dropped[i] = 0u;
     }
     if (i < 2) in.counters[i] = 0u;
 }
@@ -883,10 +914,11 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     rootmin.ensure(NC);
     best.ensure(K);
     segmin.ensure(K); rep.ensure(K);
-    kres.ensure((size_t)K * 16);            // per segment: n_out | n_clusters | contested | (pad) | 6 x u64 box
+    kres.ensure((size_t)K * 16);            // per segment: n_out | n_clusters | contested | dropped | 6 x u64 box
     int* const d_ocount = (int*)kres.p;
     unsigned* const d_ncl = kres.p + K;
     unsigned* const d_contested = kres.p + 2 * (size_t)K;
+    unsigned* const d_dropped = kres.p + 3 * (size_t)K;
     unsigned long long* const d_obounds = (unsigned long long*)(kres.p + 4 * (size_t)K);
     active.ensure(NC); hasanchor.ensure(NC);
     corelist.ensure((size_t)std::max<long long>(N, 1));
@@ -900,7 +932,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
         DbInit in;
         in.cnt = cnt.p; in.cursor = cursor.p; in.minidx = minidx.p; in.firstidx = firstidx.p; in.rootmin = rootmin.p;
         in.size = size.p; in.active = active.p; in.hasanchor = hasanchor.p;
-        in.best = best.p; in.obounds = d_obounds; in.ocount = d_ocount; in.ncl = d_ncl; in.segmin = segmin.p; in.rep = rep.p; in.contested = d_contested;
+        in.best = best.p; in.obounds = d_obounds; in.ocount = d_ocount; in.ncl = d_ncl; in.segmin = segmin.p; in.rep = rep.p; in.contested = d_contested; in.dropped = d_dropped;
         in.counters = d_ncore.p;
         in.NC = NC; in.K = K;
         hipLaunchKernelGGL(k_db_init, dim3(cdiv(NC + 1, 256)), dim3(256), 0, s, in);
@@ -972,13 +1004,13 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     hipLaunchKernelGGL(k_db_pick, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_ncore.p, dsegs, K,
                        (const unsigned*)size.p, (const unsigned*)firstidx.p, (const unsigned*)rootmin.p, best.p);
     hipLaunchKernelGGL(k_db_flags, dim3(gN), dim3(256), 0, s, N, (const int*)segid.p, dsegs, (const int*)label.p,
-                       (const unsigned long long*)best.p, flags.p);
+                       (const unsigned long long*)best.p, flags.p, d_dropped);
     HMSG_CHECK_LAUNCH();
     hmsg_scan_u32(flags.p, pos.p, (size_t)N, s, scan_tmp, nullptr);
     {
     ProfScope ps(prof, s, "k_db_scatter", (double)N * 56.0);
-    hipLaunchKernelGGL(k_db_scatter, dim3(std::min(gN, (unsigned)n_cu * 2u)), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const unsigned*)flags.p,
-                       (const unsigned*)pos.p, dst, d_ocount, (const unsigned char*)core.p, dst_core, d_obounds);
+    hipLaunchKernelGGL(k_db_scatter, dim3(std::min(gN, (unsigned)n_cu)), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const unsigned*)flags.p,
+                       (const unsigned*)pos.p, dst, d_ocount, (const unsigned char*)core.p, dst_core, d_obounds, (const unsigned*)d_dropped);
     }
     HMSG_CHECK_LAUNCH();
     {   // debug: HMSG_DEBUG_DBCALL=<n> dumps the n-th batch (inputs + per-point results) under HMSG_DEBUG_DUMP

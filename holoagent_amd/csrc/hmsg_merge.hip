@@ -94,11 +94,18 @@ __global__ void k_ov_fill(const double* __restrict__ pool, const OvGrid* __restr
 // find_overlapping_ratio_faiss: (dx*dx + dy*dy) + dz*dz < r2)
 __device__ __forceinline__ bool ov_scan(const float* __restrict__ sorted, unsigned s0, unsigned e0, float x, float y, float z,
                                         float r2) {
-    for (unsigned k = s0; k < e0; ++k) {
-        float ddx = __fsub_rn(x, sorted[(size_t)k * 3]), ddy = __fsub_rn(y, sorted[(size_t)k * 3 + 1]),
-              ddz = __fsub_rn(z, sorted[(size_t)k * 3 + 2]);
-        float d2 = __fadd_rn(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)), __fmul_rn(ddz, ddz));
-        if (d2 < r2) return true;
+    // four candidates per step with independent loads: the scan is a serial latency chain per lane
+    for (unsigned k = s0; k < e0; k += 4) {
+        bool h = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned kk = min(k + (unsigned)j, e0 - 1u);
+            float ddx = __fsub_rn(x, sorted[(size_t)kk * 3]), ddy = __fsub_rn(y, sorted[(size_t)kk * 3 + 1]),
+                  ddz = __fsub_rn(z, sorted[(size_t)kk * 3 + 2]);
+            float d2 = __fadd_rn(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)), __fmul_rn(ddz, ddz));
+            h = h || (k + (unsigned)j < e0 && d2 < r2);
+        }
+        if (h) return true;
     }
     return false;
 }
