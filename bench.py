@@ -232,8 +232,7 @@ def main():
     if roof is not None:
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-            key = {"k_db_union/box": "k_db_union", "k_db_union/scan1": "k_db_union_scan",
-                   "k_db_union/scan2": "k_db_union_scan"}.get(roof["kernel"], roof["kernel"])
+            key = {"k_db_union/box": "k_db_union", "k_db_union/scan": "k_db_union_scan"}.get(roof["kernel"], roof["kernel"])
             if key in pmc:
                 roof["traffic"] = int(pmc[key]["hbm_bytes_per_launch"])
                 roof["traffic_source"] = "profiles/r01_pmc_traffic.json (offline PMC passes, same command)"

@@ -123,6 +123,12 @@ __device__ __forceinline__ bool column_zrange(const DbSeg& sg, const double* __r
     return z0 <= z1;
 }
 
+// the 25 grid columns around a cell, nearest first: neighbour counts reach min_points, and border points find
+// their witness, after far fewer candidates than in raster order
+__device__ const signed char DB_COL[25][2] = {{0, 0},  {-1, 0}, {1, 0},  {0, -1},  {0, 1},  {-1, -1}, {-1, 1}, {1, -1}, {1, 1},
+                                              {-2, 0}, {2, 0},  {0, -2}, {0, 2},   {-2, -1}, {-2, 1}, {2, -1}, {2, 1},  {-1, -2},
+                                              {-1, 2}, {1, -2}, {1, 2},  {-2, -2}, {-2, 2},  {2, -2}, {2, 2}};
+
 __global__ void k_db_core(const double* __restrict__ pts, long long N, const int* __restrict__ segid,
                           const DbSeg* __restrict__ segs, const long long* __restrict__ cellid,
                           const unsigned* __restrict__ cnt, const unsigned* __restrict__ start,
@@ -147,17 +153,13 @@ __global__ void k_db_core(const double* __restrict__ pts, long long N, const int
         // the 5 z-cells of a (dx, dy) column are consecutive cell ids, so their points are ONE contiguous range
         // of the cell-sorted order: 25 ranges instead of 125 cell probes
         const double pi[3] = {pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2]};
-        for (int dx = -2; dx <= 2 && n < minpts; ++dx) {
-            int jx = ix + dx;
-            if (jx < 0 || jx >= sg.nx) continue;
-            for (int dy = -2; dy <= 2 && n < minpts; ++dy) {
-                int jy = iy + dy;
-                if (jy < 0 || jy >= sg.ny) continue;
-                int z0, z1;
-                if (!column_zrange(sg, pi, jx, jy, iz, eps2, z0, z1)) continue;
-                long long cb = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz;
-                n = count_within(spts, start[cb + z0], start[cb + z1 + 1], pi, eps2, n, minpts);
-            }
+        for (int col = 0; col < 25 && n < minpts; ++col) {
+            const int jx = ix + DB_COL[col][0], jy = iy + DB_COL[col][1];
+            if (jx < 0 || jx >= sg.nx || jy < 0 || jy >= sg.ny) continue;
+            int z0, z1;
+            if (!column_zrange(sg, pi, jx, jy, iz, eps2, z0, z1)) continue;
+            long long cb = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz;
+            n = count_within(spts, start[cb + z0], start[cb + z1 + 1], pi, eps2, n, minpts);
         }
         is_core = n >= minpts;
     }
@@ -337,76 +339,47 @@ __global__ void k_db_cellbox(const double* __restrict__ pts, const int* __restri
     }
 }
 
-// One WAVE per core cell, one LANE per neighbour cell (pass 0: Chebyshev distance 1, pass 1: distance 2,
-// skipped when the two cells are already connected).  An edge needs one witness pair of core points closer
-// than eps; the lane stops at the first one.
-__global__ void k_db_union(const double* __restrict__ pts, const int* __restrict__ corecells, const unsigned* __restrict__ ncore,
-                           const DbSeg* __restrict__ segs, int K, const unsigned* __restrict__ cnt,
-                           const unsigned* __restrict__ start, const unsigned* __restrict__ ord,
-                           const unsigned char* __restrict__ core, const unsigned* __restrict__ minidx, double eps2, int pass,
-                           const int* __restrict__ cellpos, const double* __restrict__ cellbox, int* __restrict__ parent,
-                           const unsigned* __restrict__ active) {
-    // (corecells / ncore: the ACTIVE core cells -- cells whose cores are all anchor points are pre-connected.  A pair
-    //  is handled from its active member; from the higher one when both are active.)
+// Box pass.  One WAVE per ACTIVE core cell (cells whose cores are all anchor points are pre-connected; a pair is
+// handled from its active member, from the higher one when both are active), one LANE per neighbour cell.  The
+// tight AABBs of the two cells' core points decide most pairs without touching a point: farthest corners closer
+// than eps -> every pair of core points is a witness -> union.  (Pairs the boxes cannot decide are left to
+// k_db_union_scan.)  Everything a lane needs about its neighbour is loaded up front: the lane is one serial
+// chain of L2 round trips, and the kernel lasts as long as the longest chain.
+__global__ void k_db_union(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, const DbSeg* __restrict__ segs,
+                           int K, const unsigned* __restrict__ minidx, double eps2, const int* __restrict__ cellpos,
+                           const double* __restrict__ cellbox, int* __restrict__ parent, const unsigned* __restrict__ active) {
     const int lane = threadIdx.x & 63;
     const unsigned nwaves = (gridDim.x * blockDim.x) >> 6, ncells = *ncore;
     for (unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < ncells; w += nwaves) {
-    const long long c = corecells[w];
-    int lo = 0, hi = K - 1;                 // segment of the cell
-    while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (segs[mid].cell_base <= c) lo = mid; else hi = mid - 1;
-    }
-    const DbSeg sg = segs[lo];
-    int ix, iy, iz;
-    cell_xyz(sg, c, ix, iy, iz);
-    const unsigned s0 = start[c], e0 = s0 + cnt[c];
-    for (int o = lane; o < 125; o += 64) {
-        int dx = o / 25 - 2, dy = (o / 5) % 5 - 2, dz = o % 5 - 2;
-        int cheb = max(abs(dx), max(abs(dy), abs(dz)));
-        // pass 0: every neighbour, AABB decisions only (no point scans); pass 1 / 2: Chebyshev distance 1 / 2,
-        // point scans for the pairs that are still unconnected
-        if (cheb == 0 || (pass == 1 && cheb != 1) || (pass == 2 && cheb != 2)) continue;
-        int jx = ix + dx, jy = iy + dy, jz = iz + dz;
-        if (jx < 0 || jy < 0 || jz < 0 || jx >= sg.nx || jy >= sg.ny || jz >= sg.nz) continue;
-        long long c2 = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz + jz;
-        if (minidx[c2] == INF32 || (c2 < c && active[c2])) continue;
-        if (uf_find_cached(parent, (int)c) == uf_find_cached(parent, (int)c2)) continue;
-        // tight AABBs of the two cells' core points decide most pairs without touching a point:
-        // farthest corners closer than eps -> every pair is a witness; nearest faces >= eps -> no witness.
-        const double* ba = cellbox + (size_t)cellpos[c] * 6;
-        const double* bb = cellbox + (size_t)cellpos[c2] * 6;
-        double mn2 = 0.0, mx2 = 0.0;
-        for (int a = 0; a < 3; ++a) {
-            double gap = fmax(0.0, fmax(ba[a] - bb[3 + a], bb[a] - ba[3 + a]));
-            double far = fmax(ba[3 + a] - bb[a], bb[3 + a] - ba[a]);
-            mn2 += gap * gap;
-            mx2 += far * far;
+        const long long c = corecells[w];
+        int lo = 0, hi = K - 1;                 // segment of the cell
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (segs[mid].cell_base <= c) lo = mid; else hi = mid - 1;
         }
-        bool hit = mx2 < eps2 * (1.0 - 1e-12);
-        if (!hit && pass > 0 && mn2 < eps2 * (1.0 + 1e-12)) {
-            const unsigned s1 = start[c2], e1 = s1 + cnt[c2];
-            for (unsigned a = s0; a < e0 && !hit; ++a) {
-                unsigned ia = a;
-                if (!core[ia]) continue;
-                const double* pa = pts + (size_t)ia * 3;
-                double g2 = 0.0;                       // point-to-box lower bound
-                for (int q = 0; q < 3; ++q) {
-                    double gq = fmax(0.0, fmax(bb[q] - pa[q], pa[q] - bb[3 + q]));
-                    g2 += gq * gq;
-                }
-                if (g2 >= eps2 * (1.0 + 1e-12)) continue;
-                for (unsigned b = s1; b < e1; ++b) {
-                    unsigned ib = b;
-                    if (core[ib] && dist2_f64(pa, pts + (size_t)ib * 3) < eps2) {
-                        hit = true;
-                        break;
-                    }
-                }
+        const DbSeg sg = segs[lo];
+        int ix, iy, iz;
+        cell_xyz(sg, c, ix, iy, iz);
+        const int rc = uf_find_cached(parent, (int)c);       // (may go stale: only costs a redundant uf_union)
+        double ba[6];
+        for (int a = 0; a < 6; ++a) ba[a] = cellbox[(size_t)cellpos[c] * 6 + a];
+        for (int o = lane; o < 125; o += 64) {
+            const int dx = o / 25 - 2, dy = (o / 5) % 5 - 2, dz = o % 5 - 2;
+            const int jx = ix + dx, jy = iy + dy, jz = iz + dz;
+            if (o == 62 || jx < 0 || jy < 0 || jz < 0 || jx >= sg.nx || jy >= sg.ny || jz >= sg.nz) continue;   // 62: the cell itself
+            const long long c2 = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz + jz;
+            const unsigned mi = minidx[c2], ac = active[c2];
+            const int p2 = parent[c2], cp2 = cellpos[c2];     // (garbage unless c2 is a core cell; not used then)
+            if (mi == INF32 || (c2 < c && ac)) continue;
+            if (uf_find_cached(parent, p2) == rc) continue;
+            const double* bb = cellbox + (size_t)cp2 * 6;
+            double mx2 = 0.0;
+            for (int a = 0; a < 3; ++a) {
+                double far = fmax(ba[3 + a] - bb[a], bb[3 + a] - ba[a]);
+                mx2 += far * far;
             }
+            if (mx2 < eps2 * (1.0 - 1e-12)) uf_union(parent, (int)c, (int)c2);
         }
-        if (hit) uf_union(parent, (int)c, (int)c2);
-    }
     }
 }
 
@@ -418,7 +391,7 @@ __global__ void k_db_union_scan(const double* __restrict__ pts, const int* __res
                                 const unsigned* __restrict__ ncore, const DbSeg* __restrict__ segs, int K,
                                 const unsigned* __restrict__ cnt, const unsigned* __restrict__ start,
                                 const unsigned* __restrict__ ord, const unsigned char* __restrict__ core,
-                                const unsigned* __restrict__ minidx, double eps2, int pass, const int* __restrict__ cellpos,
+                                const unsigned* __restrict__ minidx, double eps2, const int* __restrict__ cellpos,
                                 const double* __restrict__ cellbox, int* __restrict__ parent,
                                 const unsigned* __restrict__ active) {
     const int lane = threadIdx.x & 63;
@@ -435,6 +408,8 @@ __global__ void k_db_union_scan(const double* __restrict__ pts, const int* __res
         cell_xyz(sg, c, ix, iy, iz);
         const unsigned s0 = start[c], e0 = s0 + cnt[c];
         const double* ba = cellbox + (size_t)cellpos[c] * 6;
+        // Chebyshev distance 1 first (they connect most components), then distance 2
+        for (int pass = 1; pass <= 2; ++pass)
         for (int round = 0; round < 2; ++round) {
           // phase A: one lane per neighbour cell decides whether that pair needs a point scan at all
           const int oo = round * 64 + lane;
@@ -507,8 +482,17 @@ __global__ void k_db_union_scan(const double* __restrict__ pts, const int* __res
 __global__ void k_db_flatten(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, int* __restrict__ parent) {
     const unsigned n = *ncore;
     for (unsigned w = blockIdx.x * blockDim.x + threadIdx.x; w < n; w += gridDim.x * blockDim.x) {
-        int c = corecells[w];
-        parent[c] = uf_find(parent, c);     // roots never change after the union passes
+        const int c = corecells[w];
+        // read-only walk (roots never change after the union passes).  No path halving here: a halving store of
+        // one thread may land AFTER another thread has written the root into the same word and put an inner
+        // node back -- every parent[] must be a root when the kernel ends, labels are read straight from it.
+        int r = c;
+        for (;;) {
+            const int q = __hip_atomic_load(&parent[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (q == r) break;
+            r = q;
+        }
+        __hip_atomic_store(&parent[c], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -595,12 +579,10 @@ __global__ void k_db_label(const double* __restrict__ pts, long long N, const in
         // neighbour of its cores, so the kept cloud is not known to be a fixed point of the next pass.
         bool settled = ncl[segid[i]] <= 1u;                    // nothing (more) to learn about contests
         const double pi[3] = {pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2]};
-        for (int dx = -2; dx <= 2 && !(settled && bestkey == firstkey); ++dx) {
-            int jx = ix + dx;
-            if (jx < 0 || jx >= sg.nx) continue;
-            for (int dy = -2; dy <= 2 && !(settled && bestkey == firstkey); ++dy) {
-                int jy = iy + dy;
-                if (jy < 0 || jy >= sg.ny) continue;
+        for (int col = 0; col < 25 && !(settled && bestkey == firstkey); ++col) {
+            {
+                const int jx = ix + DB_COL[col][0], jy = iy + DB_COL[col][1];
+                if (jx < 0 || jx >= sg.nx || jy < 0 || jy >= sg.ny) continue;
                 int z0, z1;
                 if (!column_zrange(sg, pi, jx, jy, iz, eps2, z0, z1)) continue;
                 const long long cb = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz;
@@ -974,23 +956,20 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
         hipLaunchKernelGGL(k_db_anchor, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_ncore.p, dsegs, K,
                            (const unsigned char*)hasanchor.p, (const unsigned*)rep.p, parent.p);
     }
-    for (int pass = 0; pass < 3; ++pass) {
-        static const char* const pass_name[3] = {"k_db_union/box", "k_db_union/scan1", "k_db_union/scan2"};
-        ProfScope ps(prof, s, pass_name[pass], (double)N * 24.0);
-        if (pass == 0)
-            hipLaunchKernelGGL(k_db_union, dim3(gW), dim3(256), 0, s, (const double*)spts.p, (const int*)actlist.p,
-                               (const unsigned*)d_nact, dsegs, K,
-                               (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p, (const unsigned char*)score.p,
-                               (const unsigned*)minidx.p, eps * eps, pass, (const int*)cellpos.p, (const double*)cellbox.p, parent.p,
-                               (const unsigned*)active.p);
-        else
-            hipLaunchKernelGGL(k_db_union_scan, dim3(gW), dim3(256), 0, s, (const double*)spts.p, (const int*)actlist.p,
-                               (const unsigned*)d_nact,
-                               dsegs, K, (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p,
-                               (const unsigned char*)score.p, (const unsigned*)minidx.p, eps * eps, pass, (const int*)cellpos.p,
-                               (const double*)cellbox.p, parent.p, (const unsigned*)active.p);
-        hipLaunchKernelGGL(k_db_flatten, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_ncore.p, parent.p);
+    {
+        ProfScope ps(prof, s, "k_db_union/box", (double)N * 24.0);
+        hipLaunchKernelGGL(k_db_union, dim3(gW), dim3(256), 0, s, (const int*)actlist.p, (const unsigned*)d_nact, dsegs, K,
+                           (const unsigned*)minidx.p, eps * eps, (const int*)cellpos.p, (const double*)cellbox.p, parent.p,
+                           (const unsigned*)active.p);
     }
+    {
+        ProfScope ps(prof, s, "k_db_union/scan", (double)N * 24.0);
+        hipLaunchKernelGGL(k_db_union_scan, dim3(gW), dim3(256), 0, s, (const double*)spts.p, (const int*)actlist.p,
+                           (const unsigned*)d_nact, dsegs, K, (const unsigned*)cnt.p, (const unsigned*)start.p,
+                           (const unsigned*)ord.p, (const unsigned char*)score.p, (const unsigned*)minidx.p, eps * eps,
+                           (const int*)cellpos.p, (const double*)cellbox.p, parent.p, (const unsigned*)active.p);
+    }
+    hipLaunchKernelGGL(k_db_flatten, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_ncore.p, parent.p);
     hipLaunchKernelGGL(k_db_rootmin, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_ncore.p,
                        (const int*)parent.p, (const unsigned*)minidx.p, rootmin.p, dsegs, K, segmin.p, d_ncl, (const unsigned*)ccore.p, size.p);
     {
