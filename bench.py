@@ -22,6 +22,7 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+MFMA_KERNELS = ("k_pool_gram", "k_gemm_f64")
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -103,12 +104,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # HMSG_BENCH_FORCE_DIST=1 drives the RCCL code path (process group, all-gather of the node tables, max-over-ranks
+    # timing) even with a single rank: the multi-GPU launch is the driver's, this is how it is smoke-tested on one GPU
+    use_dist = world > 1 or bool(os.environ.get("HMSG_BENCH_FORCE_DIST"))
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
     assert world == max(1, args.gpus) or world == 1, "launch with torch.distributed.run --nproc-per-node N"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    if use_dist:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     L = HmsgLib()                      # fails loudly without the HIP library
 
     F, Q, D, k = args.frames, args.queries, args.feat_dim, args.topk
@@ -161,11 +168,17 @@ def main():
             feats = np.stack([o.embedding for o in g.objects]).astype(np.float64) if g.objects else np.zeros((0, D))
             rooms = np.array([rid[o.room_id] for o in g.objects], np.int32)   # embeddings are f64 once stored (object.py:88-89)
             return feats, rooms
-        feats, rooms = T("assemble_graph", assemble)
+        if os.environ.get("HMSG_BENCH_PROFILE_ASSEMBLE"):      # development aid: where the host-side stage spends its time
+            import cProfile, pstats
+            pr = cProfile.Profile()
+            feats, rooms = T("assemble_graph", lambda: pr.runcall(assemble))
+            pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(25)
+        else:
+            feats, rooms = T("assemble_graph", assemble)
         state["n_nodes_local"] = feats.shape[0]
 
         def retrieve():
-            if world > 1:
+            if use_dist:
                 # all-gather of the node tables over RCCL -> global table on every rank (holoagent_amd/dist.py)
                 from holoagent_amd.dist import gather_node_tables, shard_queries
                 g_feats, g_rooms, _node_off, room_off = gather_node_tables(feats, rooms, n_rooms, device)
@@ -185,18 +198,18 @@ def main():
     for _ in range(args.warmup):
         step()
     stage.clear()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     prof = sc.profile()                                           # events of the LAST timed step
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -216,7 +229,7 @@ def main():
         name, (launches, total_ms, work) = max(prof.items(), key=lambda kv: kv[1][1])
         avg_s = total_ms / launches / 1e3
         per_launch = work / launches
-        if name in ("k_pool_gram",):
+        if name in MFMA_KERNELS:
             achieved = per_launch / avg_s / 1e12 if avg_s > 0 else 0.0
             roof = dict(kernel=name, bound="mfma", achieved=round(achieved, 4), peak=157.3, unit="TFLOP/s",
                         frac=round(achieved / 157.3, 6), traffic=None, launches=launches,
@@ -277,12 +290,16 @@ def main():
             "stage_ms_per_step": {k_: round(v / steps * 1e3, 2) for k_, v in stage.items()},
             "map_voxels": V, "nodes_local": state.get("n_nodes_local"),
             "kernels_ms_last_step": {k_: round(v[1], 3) for k_, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
+            # algorithmic bytes (FLOP for the MFMA kernels) / measured time of every instrumented kernel
+            "kernels_achieved": {k_: [round(v[2] / (v[1] * 1e-3) / (1e12 if k_ in MFMA_KERNELS else 1e9), 2),
+                                      "TFLOP/s" if k_ in MFMA_KERNELS else "GB/s"]
+                                 for k_, v in sorted(prof.items(), key=lambda kv: -kv[1][1]) if v[1] > 0},
             "roofline": roof, "cpu_baseline": cpu,
             "speedup_vs_cpu": round(fps / cpu["value"], 1) if cpu else None,
         }
         print(json.dumps(out))
     sc.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -896,7 +896,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     rootmin.ensure(NC);
     best.ensure(K);
     segmin.ensure(K); rep.ensure(K);
-    kres.ensure((size_t)K * 16);            // per segment: n_out | n_clusters | contested | dropped | 6 x u64 box
+    kres.ensure((size_t)K * 16 + 2);            // per segment: n_out | n_clusters | contested | dropped | 6 x u64 box
     int* const d_ocount = (int*)kres.p;
     unsigned* const d_ncl = kres.p + K;
     unsigned* const d_contested = kres.p + 2 * (size_t)K;
@@ -908,14 +908,13 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     cellpos.ensure((size_t)NC);
     cellbox.ensure((size_t)std::min<long long>(NC, N) * 6);
     ccore.ensure((size_t)std::min<long long>(NC, N));
-    d_ncore.ensure(2);                      // [0] core cells, [1] active core cells
     const unsigned gN = cdiv(N, 256), gC = cdiv(NC, 256);
     {   // every per-cell / per-segment table initialised by one launch (was a dozen memsets per batch)
         DbInit in;
         in.cnt = cnt.p; in.cursor = cursor.p; in.minidx = minidx.p; in.firstidx = firstidx.p; in.rootmin = rootmin.p;
         in.size = size.p; in.active = active.p; in.hasanchor = hasanchor.p;
         in.best = best.p; in.obounds = d_obounds; in.ocount = d_ocount; in.ncl = d_ncl; in.segmin = segmin.p; in.rep = rep.p; in.contested = d_contested; in.dropped = d_dropped;
-        in.counters = d_ncore.p;
+        in.counters = kres.p + (size_t)K * 16;   // [0] core cells, [1] active core cells
         in.NC = NC; in.K = K;
         hipLaunchKernelGGL(k_db_init, dim3(cdiv(NC + 1, 256)), dim3(256), 0, s, in);
     }
@@ -929,12 +928,13 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     score.ensure(N);
     hipLaunchKernelGGL(k_db_fill, dim3(gN), dim3(256), 0, s, src, N, (const long long*)cellid.p, (const unsigned*)start.p, cursor.p,
                        ord.p, spts.p);       // ord: slot of every point in the cell-sorted copy
-    unsigned* d_nact = d_ncore.p + 1;
+    unsigned* const d_nc = kres.p + (size_t)K * 16;
+    unsigned* d_nact = d_nc + 1;
     {
     ProfScope ps(prof, s, "k_db_core", (double)N * 33.0);
     hipLaunchKernelGGL(k_db_core, dim3(gN), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const long long*)cellid.p,
                        (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p, (const double*)spts.p, score.p,
-                       eps * eps, min_points, core.p, minidx.p, corelist.p, d_ncore.p, cellpos.p, parent.p, core0, hasanchor.p, rep.p, active.p, actlist.p,
+                       eps * eps, min_points, core.p, minidx.p, corelist.p, d_nc, cellpos.p, parent.p, core0, hasanchor.p, rep.p, active.p, actlist.p,
                        d_nact);
     }
     // persistent grid (8 blocks per CU): waves / threads stride over the core-cell list
@@ -948,12 +948,12 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     }
     const unsigned gW = (unsigned)n_cu * 8u;
     hipLaunchKernelGGL(k_db_cellbox, dim3(gW), dim3(256), 0, s, (const double*)spts.p, (const int*)corelist.p,
-                       (const unsigned*)d_ncore.p, (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p,
+                       (const unsigned*)d_nc, (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p,
                        (const unsigned char*)score.p, cellbox.p, ccore.p);
     if (core0) {
-        hipLaunchKernelGGL(k_db_anchor_min, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_ncore.p, dsegs, K,
+        hipLaunchKernelGGL(k_db_anchor_min, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc, dsegs, K,
                            (const unsigned char*)hasanchor.p, rep.p);
-        hipLaunchKernelGGL(k_db_anchor, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_ncore.p, dsegs, K,
+        hipLaunchKernelGGL(k_db_anchor, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc, dsegs, K,
                            (const unsigned char*)hasanchor.p, (const unsigned*)rep.p, parent.p);
     }
     {
@@ -969,8 +969,8 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
                            (const unsigned*)ord.p, (const unsigned char*)score.p, (const unsigned*)minidx.p, eps * eps,
                            (const int*)cellpos.p, (const double*)cellbox.p, parent.p, (const unsigned*)active.p);
     }
-    hipLaunchKernelGGL(k_db_flatten, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_ncore.p, parent.p);
-    hipLaunchKernelGGL(k_db_rootmin, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_ncore.p,
+    hipLaunchKernelGGL(k_db_flatten, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc, parent.p);
+    hipLaunchKernelGGL(k_db_rootmin, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc,
                        (const int*)parent.p, (const unsigned*)minidx.p, rootmin.p, dsegs, K, segmin.p, d_ncl, (const unsigned*)ccore.p, size.p);
     {
     ProfScope ps(prof, s, "k_db_label", (double)N * 28.0);
@@ -980,7 +980,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
                        (const int*)parent.p, (const unsigned*)rootmin.p, (const unsigned*)segmin.p, (const unsigned*)d_ncl, eps * eps,
                        label.p, size.p, firstidx.p, d_contested);
     }
-    hipLaunchKernelGGL(k_db_pick, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_ncore.p, dsegs, K,
+    hipLaunchKernelGGL(k_db_pick, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc, dsegs, K,
                        (const unsigned*)size.p, (const unsigned*)firstidx.p, (const unsigned*)rootmin.p, best.p);
     hipLaunchKernelGGL(k_db_flags, dim3(gN), dim3(256), 0, s, N, (const int*)segid.p, dsegs, (const int*)label.p,
                        (const unsigned long long*)best.p, flags.p, d_dropped);
@@ -1009,10 +1009,15 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
         ++call_no;
     }
     // one copy brings back counts, cluster counts, contest flags and the boxes of the kept points
-    std::vector<unsigned> hres((size_t)K * 16);
+    std::vector<unsigned> hres((size_t)K * 16 + 2);
     HIP_TRY(hipMemcpyAsync(hres.data(), kres.p, hres.size() * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     const unsigned long long* hb = reinterpret_cast<const unsigned long long*>(hres.data() + (size_t)K * 4);
+    stat_calls += 1;
+    stat_points += N;
+    stat_cells += NC;
+    stat_core_cells += hres[(size_t)K * 16];
+    stat_active_cells += hres[(size_t)K * 16 + 1];
     long long total = 0;
     for (int k = 0; k < K; ++k) {
         const int n_out = (int)hres[k];

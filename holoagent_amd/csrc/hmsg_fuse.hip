@@ -266,14 +266,22 @@ __global__ void k_mcount(const int* __restrict__ nn, const unsigned long long* _
 __global__ void k_winners(const int* __restrict__ nn, const unsigned* __restrict__ stamp, size_t HW, int f0, int fb0, int nfr,
                           Winner* __restrict__ out, unsigned* __restrict__ n_out) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= HW * nfr) return;
-    int fl = (int)(t / HW);
-    int p = (int)(t - (size_t)fl * HW);
-    int v = nn[(size_t)(f0 + fl) * HW + p];
-    if (v < 0) return;
-    if (stamp[(size_t)v * FB + (f0 + fl - fb0)] != (unsigned)p + 1u) return;
-    unsigned pos = atomicAdd(n_out, 1u);
-    out[pos] = Winner{fl, p, v};
+    bool win = false;
+    int fl = 0, p = 0, v = -1;
+    if (t < HW * nfr) {
+        fl = (int)(t / HW);
+        p = (int)(t - (size_t)fl * HW);
+        v = nn[(size_t)(f0 + fl) * HW + p];
+        win = v >= 0 && stamp[(size_t)v * FB + (f0 + fl - fb0)] == (unsigned)p + 1u;
+    }
+    // list slots per wave (one atomic on the counter per wave, not per winning pixel)
+    const unsigned long long m = __ballot(win);
+    if (!m) return;
+    const int lane = threadIdx.x & 63, leader = __ffsll(m) - 1;
+    unsigned base = 0;
+    if (lane == leader) base = atomicAdd(n_out, (unsigned)__popcll(m));
+    base = __shfl(base, leader);
+    if (win) out[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = Winner{fl, p, v};
 }
 
 __global__ void k_mbounds(const Winner* __restrict__ win, unsigned nwin, long long V, int M, const unsigned* __restrict__ mcount,
@@ -439,9 +447,10 @@ void hmsg_fuse(hmsg_ctx* h) {
     if (h->nn.n < (size_t)c.max_frames * HW) h->nn.alloc((size_t)c.max_frames * HW);
     DevBuf<unsigned> stamp;
     stamp.alloc((size_t)std::max<long long>(V, 1) * FB);
-    // mask sub-batch size from a 1 GiB budget for the dense per-voxel mask counters
-    int Bm = 16;
-    while (Bm > 1 && (size_t)Bm * V * M * 4 > ((size_t)1 << 30)) Bm >>= 1;
+    // mask sub-batch size from an 8 GiB budget for the dense per-voxel mask counters (288 GB of HBM: a whole
+    // stamp batch at once for maps up to ~1M voxels; every sub-batch costs three host round trips)
+    int Bm = FB;
+    while (Bm > 1 && (size_t)Bm * V * M * 4 > ((size_t)8 << 30)) Bm >>= 1;
     DevBuf<unsigned> mcount;
     mcount.alloc((size_t)Bm * std::max<long long>(V, 1) * M);
     mcount.zero(s);

@@ -732,6 +732,10 @@ void hmsg_merge(hmsg_ctx* h) {
     if (getenv("HMSG_DEBUG_TIMING"))
         fprintf(stderr, "[hmsg merge] index %.1f  pairs(host) %.1f  overlap %.1f  components+concat %.1f  dbscan %.1f  bookkeeping %.1f ms\n",
                 m.tphase[0], m.tphase[1], m.tphase[2], m.tphase[3], m.tphase[4], m.tphase[5]);
+    if (getenv("HMSG_DEBUG_TIMING") && m.ops.stat_calls > 0)
+        fprintf(stderr, "[hmsg merge] dbscan batches %.0f: mean points %.0f  grid cells %.0f  core cells %.0f  active cells %.0f\n",
+                m.ops.stat_calls, m.ops.stat_points / m.ops.stat_calls, m.ops.stat_cells / m.ops.stat_calls,
+                m.ops.stat_core_cells / m.ops.stat_calls, m.ops.stat_active_cells / m.ops.stat_calls);
     h->merged = true;
 }
 
