@@ -263,25 +263,26 @@ __global__ void k_mcount(const int* __restrict__ nn, const unsigned long long* _
     }
 }
 
-__global__ void k_winners(const int* __restrict__ nn, const unsigned* __restrict__ stamp, size_t HW, int f0, int fb0, int nfr,
-                          Winner* __restrict__ out, unsigned* __restrict__ n_out) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool win = false;
-    int fl = 0, p = 0, v = -1;
-    if (t < HW * nfr) {
-        fl = (int)(t / HW);
-        p = (int)(t - (size_t)fl * HW);
-        v = nn[(size_t)(f0 + fl) * HW + p];
-        win = v >= 0 && stamp[(size_t)v * FB + (f0 + fl - fb0)] == (unsigned)p + 1u;
-    }
-    // list slots per wave (one atomic on the counter per wave, not per winning pixel)
+// The pixels that define the 3-D masks: for every (voxel, frame) the LAST pixel that snapped to the voxel
+// (create_3d_masks keeps one map point per voxel hit, weighted by its pixel count).  They are exactly the
+// non-zero stamps, so the list is read off the stamp table with coalesced loads -- testing every pixel against
+// its voxel's stamp was a random 4-byte gather per pixel.
+__global__ void k_winners(const unsigned* __restrict__ stamp, long long V, int j0, int nfr, Winner* __restrict__ out,
+                          unsigned* __restrict__ n_out) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // t = v * FB + j, rows padded to FB
+    const int j = (int)(t % FB);
+    const long long v = t / FB;
+    unsigned sv = 0u;
+    if (v < V && j >= j0 && j < j0 + nfr) sv = stamp[t];
+    const bool win = sv != 0u;
+    // list slots per wave (one atomic on the counter per wave)
     const unsigned long long m = __ballot(win);
     if (!m) return;
     const int lane = threadIdx.x & 63, leader = __ffsll(m) - 1;
     unsigned base = 0;
     if (lane == leader) base = atomicAdd(n_out, (unsigned)__popcll(m));
     base = __shfl(base, leader);
-    if (win) out[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = Winner{fl, p, v};
+    if (win) out[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = Winner{j - j0, (int)(sv - 1u), (int)v};
 }
 
 __global__ void k_mbounds(const Winner* __restrict__ win, unsigned nwin, long long V, int M, const unsigned* __restrict__ mcount,
@@ -500,8 +501,8 @@ void hmsg_fuse(hmsg_ctx* h) {
             }
             HMSG_CHECK_LAUNCH();
             HIP_TRY(hipMemsetAsync(d_nwin.p, 0, 4, s));
-            hipLaunchKernelGGL(k_winners, dim3(cdiv(HW * nfr, 256)), dim3(256), 0, s, (const int*)h->nn.p,
-                               (const unsigned*)stamp.p, HW, f0, fb0, nfr, win.p, d_nwin.p);
+            hipLaunchKernelGGL(k_winners, dim3(cdiv((size_t)V * FB, 256)), dim3(256), 0, s, (const unsigned*)stamp.p, V,
+                               f0 - fb0, nfr, win.p, d_nwin.p);
             HMSG_CHECK_LAUNCH();
             for (int i = 0; i < nmask; ++i)
                 for (int a = 0; a < 6; ++a) hb[(size_t)i * 6 + a] = a < 3 ? ~0ull : 0ull;

@@ -144,6 +144,7 @@ __device__ __forceinline__ bool ov_hit(const OvGrid& Y, const unsigned* __restri
     return false;
 }
 
+#define OV_CHUNK 512
 // find_overlapping_ratio_faiss (graph_utils.py:645-662): a point of X overlaps when its exact float32
 // nearest neighbour in Y is closer than r^2, i.e. when SOME y has (dx*dx + dy*dy) + dz*dz < r2 in float32.
 __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __restrict__ gr, const OvTask* __restrict__ tasks,
@@ -152,9 +153,15 @@ __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __rest
     const OvTask t = tasks[blockIdx.y];
     const OvGrid X = gr[t.x], Y = gr[t.y];
     unsigned local = 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < X.n; i += gridDim.x * blockDim.x) {
-        const double* p = pool + (size_t)(X.pt_off + i) * 3;
-        local += ov_hit(Y, cells, sorted, (float)p[0], (float)p[1], (float)p[2], r2, r) ? 1u : 0u;
+    // a block takes OV_CHUNK consecutive points per trip: every point is a serial chain of L2 round trips, so a
+    // million-point X must be spread over many blocks (gridDim.x is sized for the largest X of the launch; the
+    // blocks beyond a smaller X leave at once)
+    for (long long b0 = (long long)blockIdx.x * OV_CHUNK; b0 < X.n; b0 += (long long)gridDim.x * OV_CHUNK) {
+        const int b1 = (int)(b0 + OV_CHUNK < X.n ? b0 + OV_CHUNK : X.n);
+        for (int i = (int)b0 + (int)threadIdx.x; i < b1; i += blockDim.x) {
+            const double* p = pool + (size_t)(X.pt_off + i) * 3;
+            local += ov_hit(Y, cells, sorted, (float)p[0], (float)p[1], (float)p[2], r2, r) ? 1u : 0u;
+        }
     }
     for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(&counts[blockIdx.y], local);
@@ -358,7 +365,9 @@ struct Merger {
         HIP_TRY(hipMemsetAsync(d_counts.p, 0, tasks.size() * 4, s));
         const float r = (float)radius;
         const float r2 = (float)(radius * radius);   // `D < radius**2` with a float32 D (graph_utils.py:654-655)
-        const unsigned bx = std::max(1u, std::min(cdiv(maxn, 256), 64u));
+        // blocks per task: enough for the largest X at OV_CHUNK points per block, bounded by the launch size
+        const size_t tasks_per_launch = std::min<size_t>(32768, tasks.size());
+        const unsigned bx = std::max(1u, std::min(cdiv(maxn, OV_CHUNK), (unsigned)std::max<size_t>(64, ((size_t)1 << 19) / tasks_per_launch)));
         double ov_work = 0;
         for (auto& t : tasks) ov_work += 12.0 * g[t.x].n;
         ProfScope ps(h->prof, s, "k_ov_query", ov_work);
