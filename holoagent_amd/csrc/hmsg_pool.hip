@@ -149,22 +149,28 @@ __global__ void __launch_bounds__(256) k_pool_gram(const float* __restrict__ Xn,
 
 // ---- label propagation over the adjacency bits (cores only): label = smallest core index reachable
 __global__ void k_pool_init(const unsigned* __restrict__ ncount, long long N, int minpts, int* __restrict__ label,
-                            const PoolSeg* __restrict__ segs, const int* __restrict__ seg_of_row) {
+                            const PoolSeg* __restrict__ segs, const int* __restrict__ seg_of_row, int* __restrict__ seg_first) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    const PoolSeg sg = segs[seg_of_row[i]];
-    label[i] = ncount[i] >= (unsigned)minpts ? (int)(i - sg.row_base) : -1;
+    const int k = seg_of_row[i];
+    const PoolSeg sg = segs[k];
+    const bool is_core = ncount[i] >= (unsigned)minpts;
+    label[i] = is_core ? (int)(i - sg.row_base) : -1;
+    // lowest core row of the instance: a label that has reached it cannot drop further
+    if (is_core && (int)(i - sg.row_base) < seg_first[k]) atomicMin(&seg_first[k], (int)(i - sg.row_base));
 }
 __global__ void k_pool_prop(const unsigned* __restrict__ adj, const PoolSeg* __restrict__ segs, const int* __restrict__ seg_of_row,
                             const unsigned* __restrict__ ncount, int minpts, long long N, int* __restrict__ label,
-                            int* __restrict__ changed) {
+                            int* __restrict__ changed, const int* __restrict__ seg_first) {
     const int lane = threadIdx.x & 63;
     const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (i >= N) return;
     if (ncount[i] < (unsigned)minpts) return;                 // wave-uniform
-    const PoolSeg sg = segs[seg_of_row[i]];
-    const unsigned* row = adj + sg.bit_base + (size_t)(i - sg.row_base) * sg.nw;
+    const int k = seg_of_row[i];
     int best = label[i];
+    if (best == seg_first[k]) return;                         // already at the instance's lowest core row (wave-uniform)
+    const PoolSeg sg = segs[k];
+    const unsigned* row = adj + sg.bit_base + (size_t)(i - sg.row_base) * sg.nw;
     for (int w = lane; w < sg.nw; w += 64) {
         unsigned bits = row[w];
         while (bits) {
@@ -172,7 +178,9 @@ __global__ void k_pool_prop(const unsigned* __restrict__ adj, const PoolSeg* __r
             bits &= bits - 1;
             long long j = sg.row_base + (long long)w * 32 + b;
             if (ncount[j] >= (unsigned)minpts) {
-                int lj = __hip_atomic_load(&label[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // plain (L1-cacheable) load: a stale label is an older, larger one -- it only delays the drop to
+                // a later launch, and the host loop runs until a whole round changes nothing
+                const int lj = label[j];
                 best = lj < best ? lj : best;
             }
         }
@@ -357,7 +365,7 @@ void hmsg_pool(hmsg_ctx* h) {
     HIP_TRY(hipMemcpyAsync(d_ps.p, ps.data(), (size_t)K * sizeof(PoolSeg), hipMemcpyHostToDevice, s));
     DevBuf<float> X, Xn;
     DevBuf<unsigned> adj, ncount, csize, cfirst;
-    DevBuf<int> label, flabel, seg_of_row, d_changed;
+    DevBuf<int> label, flabel, seg_of_row, d_changed, seg_first;
     DevBuf<unsigned long long> best;
     const size_t Rn = (size_t)std::max<unsigned long long>(R, 1);
     X.alloc(Rn * D);
@@ -370,6 +378,8 @@ void hmsg_pool(hmsg_ctx* h) {
     flabel.alloc(Rn);
     seg_of_row.alloc(Rn);
     d_changed.alloc(1);
+    seg_first.alloc((size_t)std::max(K, 1));
+    HIP_TRY(hipMemsetAsync(seg_first.p, 0x7f, (size_t)std::max(K, 1) * 4, s));
     best.alloc(K);
     adj.zero(s);
     ncount.zero(s);
@@ -389,14 +399,14 @@ void hmsg_pool(hmsg_ctx* h) {
                                (float)c.feat_dbscan_eps, adj.p, ncount.p);
         }
         hipLaunchKernelGGL(k_pool_init, dim3(cdiv((size_t)R, 256)), dim3(256), 0, s, (const unsigned*)ncount.p, (long long)R,
-                           c.feat_dbscan_min, label.p, (const PoolSeg*)d_ps.p, (const int*)seg_of_row.p);
+                           c.feat_dbscan_min, label.p, (const PoolSeg*)d_ps.p, (const int*)seg_of_row.p, seg_first.p);
         HMSG_CHECK_LAUNCH();
         for (int it = 0; it < 100000; ++it) {
             HIP_TRY(hipMemsetAsync(d_changed.p, 0, 4, s));
             for (int rep = 0; rep < 4; ++rep)
                 hipLaunchKernelGGL(k_pool_prop, dim3(cdiv((size_t)R * 64, 256)), dim3(256), 0, s, (const unsigned*)adj.p,
                                    (const PoolSeg*)d_ps.p, (const int*)seg_of_row.p, (const unsigned*)ncount.p,
-                                   c.feat_dbscan_min, (long long)R, label.p, d_changed.p);
+                                   c.feat_dbscan_min, (long long)R, label.p, d_changed.p, (const int*)seg_first.p);
             HMSG_CHECK_LAUNCH();
             int ch = 0;
             HIP_TRY(hipMemcpyAsync(&ch, d_changed.p, 4, hipMemcpyDeviceToHost, s));
