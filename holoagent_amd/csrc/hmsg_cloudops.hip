@@ -29,17 +29,17 @@ __device__ __forceinline__ double dist2_f64(const double* __restrict__ a, const 
     return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
 }
 
-__global__ void k_db_segid(const DbSeg* __restrict__ segs, int K, int* __restrict__ segid) {
-    int k = blockIdx.y;
-    const DbSeg sg = segs[k];
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < sg.n; i += gridDim.x * blockDim.x) segid[sg.pt_base + i] = k;
-}
-
-__global__ void k_db_cell(const double* __restrict__ pts, long long N, const int* __restrict__ segid,
+__global__ void k_db_cell(const double* __restrict__ pts, long long N, int* __restrict__ segid, int K,
                           const DbSeg* __restrict__ segs, long long* __restrict__ cellid, unsigned* __restrict__ cnt) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    const DbSeg sg = segs[segid[i]];
+    int lo = 0, hi = K - 1;                 // segment of the point (segments tile [0, N) in order)
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (segs[mid].pt_base <= i) lo = mid; else hi = mid - 1;
+    }
+    segid[i] = lo;
+    const DbSeg sg = segs[lo];
     int ix = (int)floor((pts[i * 3] - sg.ox) / sg.cs), iy = (int)floor((pts[i * 3 + 1] - sg.oy) / sg.cs),
         iz = (int)floor((pts[i * 3 + 2] - sg.oz) / sg.cs);
     ix = ix < 0 ? 0 : (ix >= sg.nx ? sg.nx - 1 : ix);
@@ -479,25 +479,12 @@ __global__ void k_db_union_scan(const double* __restrict__ pts, const int* __res
 
 // (the kernels below walk the compact core-cell list with a grid-stride loop: the list length is only
 //  known on the device, and launching one thread per grid cell would be dominated by empty cells)
-__global__ void k_db_flatten(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, int* __restrict__ parent) {
-    const unsigned n = *ncore;
-    for (unsigned w = blockIdx.x * blockDim.x + threadIdx.x; w < n; w += gridDim.x * blockDim.x) {
-        const int c = corecells[w];
-        // read-only walk (roots never change after the union passes).  No path halving here: a halving store of
-        // one thread may land AFTER another thread has written the root into the same word and put an inner
-        // node back -- every parent[] must be a root when the kernel ends, labels are read straight from it.
-        int r = c;
-        for (;;) {
-            const int q = __hip_atomic_load(&parent[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (q == r) break;
-            r = q;
-        }
-        __hip_atomic_store(&parent[c], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-// cluster order key: smallest core index of the cluster, kept at the root cell
-__global__ void k_db_rootmin(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, const int* __restrict__ parent,
+// Final roots + per-cluster keys.  Every core cell looks its root up with a READ-ONLY walk (roots never change
+// after the union passes) and stores it: every parent[] must be a root when the kernel ends, labels are read
+// straight from it.  (No path halving here: a halving store of one thread may land after another thread has
+// written the root into the same word and put an inner node back.)  Then, per cluster: order key = smallest core
+// index (kept at the root cell), number of core members, number of clusters and smallest key per segment.
+__global__ void k_db_rootmin(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, int* __restrict__ parent,
                              const unsigned* __restrict__ minidx, unsigned* __restrict__ rootmin,
                              const DbSeg* __restrict__ segs, int K, unsigned* __restrict__ segmin,
                              unsigned* __restrict__ ncl, const unsigned* __restrict__ ccore, unsigned* __restrict__ size) {
@@ -511,7 +498,13 @@ __global__ void k_db_rootmin(const int* __restrict__ corecells, const unsigned* 
         unsigned mi = INF32, nc = 0;
         if (valid) {
             int c = corecells[w];
-            root = parent[c];
+            root = c;
+            for (;;) {
+                const int q = __hip_atomic_load(&parent[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (q == root) break;
+                root = q;
+            }
+            __hip_atomic_store(&parent[c], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             mi = minidx[c];
             nc = ccore[w];
             if (root == c) {                    // one root cell per cluster: clusters of the segment
@@ -920,8 +913,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     }
     int maxn = 0;
     for (auto& sd : segs) maxn = std::max(maxn, sd.n);
-    hipLaunchKernelGGL(k_db_segid, dim3(std::max(1u, std::min(cdiv(maxn, 256), 1024u)), K), dim3(256), 0, s, dsegs, K, segid.p);
-    hipLaunchKernelGGL(k_db_cell, dim3(gN), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, cellid.p, cnt.p);
+    hipLaunchKernelGGL(k_db_cell, dim3(gN), dim3(256), 0, s, src, N, segid.p, K, dsegs, cellid.p, cnt.p);
     HMSG_CHECK_LAUNCH();
     hmsg_scan_u32(cnt.p, start.p, (size_t)NC + 1, s, scan_tmp, nullptr);   // start[NC] = N (end sentinel)
     spts.ensure((size_t)N * 3);
@@ -969,9 +961,8 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
                            (const unsigned*)ord.p, (const unsigned char*)score.p, (const unsigned*)minidx.p, eps * eps,
                            (const int*)cellpos.p, (const double*)cellbox.p, parent.p, (const unsigned*)active.p);
     }
-    hipLaunchKernelGGL(k_db_flatten, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc, parent.p);
     hipLaunchKernelGGL(k_db_rootmin, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc,
-                       (const int*)parent.p, (const unsigned*)minidx.p, rootmin.p, dsegs, K, segmin.p, d_ncl, (const unsigned*)ccore.p, size.p);
+                       parent.p, (const unsigned*)minidx.p, rootmin.p, dsegs, K, segmin.p, d_ncl, (const unsigned*)ccore.p, size.p);
     {
     ProfScope ps(prof, s, "k_db_label", (double)N * 28.0);
     hipLaunchKernelGGL(k_db_label, dim3(gN), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const long long*)cellid.p,

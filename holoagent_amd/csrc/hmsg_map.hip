@@ -12,16 +12,29 @@
 // atomics (fixed-point offsets from the cell corner -> order-independent, bit-reproducible).
 #include "hmsg_common.h"
 
+#include <atomic>
+
 #include <algorithm>
 
 #define FIX_SCALE 70368744177664.0 /* 2^46: 1.4e-14 m resolution */
 
 // ------------------------------------------------------------------------------------------ scans
-__global__ void k_scan_block(const unsigned* __restrict__ in, unsigned* __restrict__ out, unsigned* __restrict__ sums,
-                             size_t n) {
+// Exclusive prefix sum of u32, ONE launch: tiles of 1024 elements, decoupled look-back.  Every tile publishes
+// its aggregate, then its inclusive prefix, in a 64-bit status word {epoch:30 | flag:2 | value:32}; a tile's
+// first wave looks back over its predecessors 64 at a time until it meets a published prefix.  Words carry the
+// epoch of the scan call, so the status table is never cleared (a stale word reads as "not ready").  Tiles are
+// numbered by blockIdx: workgroups are dispatched in index order, so every predecessor of a resident tile is
+// resident or finished and the spin cannot starve it.
+__device__ __forceinline__ unsigned long long scan_pack(unsigned epoch, unsigned flag, unsigned value) {
+    return ((unsigned long long)((epoch << 2) | flag) << 32) | (unsigned long long)value;
+}
+__global__ void k_scan_lookback(const unsigned* __restrict__ in, unsigned* __restrict__ out, size_t n,
+                                unsigned long long* __restrict__ state, unsigned epoch) {
     __shared__ unsigned wsum[4];
+    __shared__ unsigned s_prefix;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    size_t base = ((size_t)blockIdx.x * 256 + tid) * 4;
+    const long long tile = blockIdx.x;
+    const size_t base = ((size_t)tile * 256 + tid) * 4;
     unsigned v[4];
     unsigned t = 0;
     for (int i = 0; i < 4; ++i) {
@@ -37,29 +50,42 @@ __global__ void k_scan_block(const unsigned* __restrict__ in, unsigned* __restri
     __syncthreads();
     unsigned woff = 0;
     for (int i = 0; i < w; ++i) woff += wsum[i];
-    unsigned excl = woff + incl - t;
+    const unsigned agg = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (w == 0) {
+        if (lane == 0)
+            __hip_atomic_store(&state[tile], scan_pack(epoch, tile == 0 ? 2u : 1u, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned prefix = 0;
+        if (tile > 0) {
+            long long hi = tile - 1;                       // the window is tiles hi, hi-1, ..., hi-63
+            for (;;) {
+                const long long idx = hi - lane;
+                unsigned long long sw = scan_pack(epoch, 2u, 0u);        // before tile 0: prefix 0
+                if (idx >= 0) sw = __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned tag = (unsigned)(sw >> 32);
+                const unsigned flag = (tag >> 2) == (epoch & 0x3fffffffu) ? (tag & 3u) : 0u;
+                const unsigned long long has_prefix = __ballot(flag == 2u), not_ready = __ballot(flag == 0u);
+                unsigned long long take = ~0ull;                          // lanes whose value is added
+                if (has_prefix) {
+                    const int first = __ffsll(has_prefix) - 1;            // nearest published prefix
+                    take = first == 63 ? ~0ull : ((1ull << (first + 1)) - 1ull);
+                }
+                if (not_ready & take) continue;                           // a needed predecessor is not there yet
+                unsigned part = ((take >> lane) & 1ull) ? (unsigned)sw : 0u;
+                for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+                prefix += part;
+                if (has_prefix) break;
+                hi -= 64;
+            }
+            if (lane == 0)
+                __hip_atomic_store(&state[tile], scan_pack(epoch, 2u, prefix + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) s_prefix = prefix;
+    }
+    __syncthreads();
+    unsigned excl = s_prefix + woff + incl - t;
     for (int i = 0; i < 4; ++i) {
         if (base + i < n) out[base + i] = excl;
         excl += v[i];
-    }
-    if (tid == 255) sums[blockIdx.x] = woff + incl;
-}
-__global__ void k_scan_add(unsigned* __restrict__ out, const unsigned* __restrict__ offs, size_t n) {
-    size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    unsigned o = offs[blockIdx.x];
-    for (int i = 0; i < 4; ++i)
-        if (base + i < n) out[base + i] += o;
-}
-
-static void scan_rec(const unsigned* in, unsigned* out, size_t n, hipStream_t s, unsigned* tmp, size_t tmp_n) {
-    size_t nb = (n + 1023) / 1024;
-    HMSG_REQUIRE(nb <= tmp_n, HMSG_ERR_INVALID, "scan scratch too small");
-    hipLaunchKernelGGL(k_scan_block, dim3((unsigned)nb), dim3(256), 0, s, in, out, tmp, n);
-    HMSG_CHECK_LAUNCH();
-    if (nb > 1) {
-        scan_rec(tmp, tmp, nb, s, tmp + nb, tmp_n - nb);
-        hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(256), 0, s, out, (const unsigned*)tmp, n);
-        HMSG_CHECK_LAUNCH();
     }
 }
 
@@ -69,11 +95,18 @@ void hmsg_scan_u32(const unsigned* in, unsigned* out, size_t n, hipStream_t s, D
         if (total) *total = 0;
         return;
     }
-    size_t need = (n + 1023) / 1024 * 2 + 64;
-    tmp.ensure(need);
+    static std::atomic<unsigned> g_epoch{0};
+    const unsigned epoch = (g_epoch.fetch_add(1) + 1u) & 0x3fffffffu;
+    const size_t ntiles = (n + 1023) / 1024;
+    if (tmp.n < ntiles * 2 + 64) {                        // (status words are u64: two u32 slots each)
+        tmp.ensure(ntiles * 2 + 64);
+        HIP_TRY(hipMemsetAsync(tmp.p, 0, tmp.n * 4, s));  // fresh memory: no word may look like a current epoch
+    }
     unsigned last_in = 0, last_out = 0;
     if (total) HIP_TRY(hipMemcpyAsync(&last_in, in + n - 1, 4, hipMemcpyDeviceToHost, s));
-    scan_rec(in, out, n, s, tmp.p, tmp.n);
+    hipLaunchKernelGGL(k_scan_lookback, dim3((unsigned)ntiles), dim3(256), 0, s, in, out, n,
+                       reinterpret_cast<unsigned long long*>(tmp.p), epoch);
+    HMSG_CHECK_LAUNCH();
     if (total) {
         HIP_TRY(hipMemcpyAsync(&last_out, out + n - 1, 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));

@@ -38,12 +38,13 @@ struct Cloud {
     unsigned long long uid = 0;
     // overlap grid (cell side >= r): cellstart[ncell+1] (absolute positions) + cell-sorted float32 points
     bool has_index = false;
-    long long ix_cell = 0;
+    long long ix_cell = 0, ix_pt = 0;
     int gd[3] = {0, 0, 0};
 };
 
 struct OvGrid {             // device view of one cloud for the overlap kernels
     long long pt_off;       // f64 points in the pool
+    long long ix_pt;        // its cell-sorted float32 copy in ix_pts (cell starts are relative to it)
     long long ix_cell;
     int n, gx, gy, gz;
     float mnx, mny, mnz, mxx, mxy, mxz;   // float32 AABB
@@ -72,10 +73,6 @@ __global__ void k_ov_count(const double* __restrict__ pool, const OvGrid* __rest
         atomicAdd(&cells[ov_cell(g, (float)p[0], (float)p[1], (float)p[2])], 1u);
     }
 }
-__global__ void k_add_base(unsigned* __restrict__ v, long long n, unsigned base) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) v[i] += base;
-}
 __global__ void k_ov_fill(const double* __restrict__ pool, const OvGrid* __restrict__ gr, const unsigned* __restrict__ cells,
                           unsigned* __restrict__ cursor, long long cursor_base, float* __restrict__ sorted) {
     const OvGrid g = gr[blockIdx.y];
@@ -83,7 +80,7 @@ __global__ void k_ov_fill(const double* __restrict__ pool, const OvGrid* __restr
         const double* p = pool + (size_t)(g.pt_off + i) * 3;
         float x = (float)p[0], y = (float)p[1], z = (float)p[2];
         long long c = ov_cell(g, x, y, z);
-        unsigned pos = cells[c] + atomicAdd(&cursor[c - cursor_base], 1u);
+        size_t pos = (size_t)g.ix_pt + cells[c] + atomicAdd(&cursor[c - cursor_base], 1u);
         sorted[(size_t)pos * 3] = x;
         sorted[(size_t)pos * 3 + 1] = y;
         sorted[(size_t)pos * 3 + 2] = z;
@@ -124,7 +121,7 @@ __device__ __forceinline__ bool ov_hit(const OvGrid& Y, const unsigned* __restri
     const bool own = cx >= 0 && cx < Y.gx && cy >= 0 && cy < Y.gy && cz >= 0 && cz < Y.gz;
     if (own) {
         const long long c = Y.ix_cell + ((long long)cx * Y.gy + cy) * Y.gz + cz;
-        if (ov_scan(sorted, cells[c], cells[c + 1], x, y, z, r2)) return true;
+        if (ov_scan(sorted + (size_t)Y.ix_pt * 3, cells[c], cells[c + 1], x, y, z, r2)) return true;
     }
     for (int dx = -1; dx <= 1; ++dx) {
         const int jx = cx + dx;
@@ -134,9 +131,9 @@ __device__ __forceinline__ bool ov_hit(const OvGrid& Y, const unsigned* __restri
             if (jy < 0 || jy >= Y.gy) continue;
             const long long c0 = Y.ix_cell + ((long long)jx * Y.gy + jy) * Y.gz;   // z-cells are contiguous
             if (own && dx == 0 && dy == 0) {                                       // own cell already done
-                if (ov_scan(sorted, cells[c0 + z0], cells[c0 + cz], x, y, z, r2)) return true;
-                if (ov_scan(sorted, cells[c0 + cz + 1], cells[c0 + z1 + 1], x, y, z, r2)) return true;
-            } else if (ov_scan(sorted, cells[c0 + z0], cells[c0 + z1 + 1], x, y, z, r2)) {
+                if (ov_scan(sorted + (size_t)Y.ix_pt * 3, cells[c0 + z0], cells[c0 + cz], x, y, z, r2)) return true;
+                if (ov_scan(sorted + (size_t)Y.ix_pt * 3, cells[c0 + cz + 1], cells[c0 + z1 + 1], x, y, z, r2)) return true;
+            } else if (ov_scan(sorted + (size_t)Y.ix_pt * 3, cells[c0 + z0], cells[c0 + z1 + 1], x, y, z, r2)) {
                 return true;
             }
         }
@@ -281,6 +278,7 @@ struct Merger {
         OvGrid g;
         g.pt_off = c.off;
         g.ix_cell = c.ix_cell;
+        g.ix_pt = c.ix_pt;
         g.n = c.n;
         g.gx = c.gd[0];
         g.gy = c.gd[1];
@@ -306,6 +304,7 @@ struct Merger {
             for (int a = 0; a < 3; ++a)
                 c.gd[a] = (int)std::floor(((double)(float)c.mx[a] - (double)(float)c.mn[a] + 2e-3) / cell) + 1;
             c.ix_cell = ix_cells_used + ncell_new;
+            c.ix_pt = ix_pts_used;
             ncell_new += (long long)c.gd[0] * c.gd[1] * c.gd[2] + 1;   // +1: end sentinel
             npts_new += c.n;
             maxn = std::max(maxn, c.n);
@@ -326,7 +325,7 @@ struct Merger {
         hipLaunchKernelGGL(k_ov_count, grid, dim3(256), 0, s, (const double*)pool.p, (const OvGrid*)d_grids.p, ix_cells.p);
         HMSG_CHECK_LAUNCH();
         hmsg_scan_u32(cells, cells, (size_t)ncell_new, s, ops.scan_tmp, nullptr);
-        hipLaunchKernelGGL(k_add_base, dim3(cdiv((size_t)ncell_new, 256)), dim3(256), 0, s, cells, ncell_new, (unsigned)ix_pts_used);
+        // (cell starts stay relative to this batch's first sorted point: Cloud::ix_pt)
         d_cursor.ensure((size_t)ncell_new);
         HIP_TRY(hipMemsetAsync(d_cursor.p, 0, (size_t)ncell_new * 4, s));
         hipLaunchKernelGGL(k_ov_fill, grid, dim3(256), 0, s, (const double*)pool.p, (const OvGrid*)d_grids.p,
