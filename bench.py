@@ -161,9 +161,9 @@ def main():
         def assemble():
             # A8 floors, A10 objects (device: instance DBSCAN(0.05,10), object->room share, label GEMM), A11 node
             # records -- holoagent_amd.graph.Graph, the mirror of the reference's Graph; rooms are an input.
-            g = Graph.from_scene(sc, lib=L)
+            g = T("assemble/from_scene", lambda: Graph.from_scene(sc, lib=L))
             g.set_label_feats(label_feats, label_names)
-            g.build_hier_multimodal_scene_graph(None, rooms=room_specs)
+            T("assemble/build_hier", lambda: g.build_hier_multimodal_scene_graph(None, rooms=room_specs))
             rid = {r.room_id: i for i, r in enumerate(g.rooms)}
             feats = np.stack([o.embedding for o in g.objects]).astype(np.float64) if g.objects else np.zeros((0, D))
             rooms = np.array([rid[o.room_id] for o in g.objects], np.int32)   # embeddings are f64 once stored (object.py:88-89)

@@ -28,7 +28,7 @@ struct CloudOps {
     DevBuf<unsigned> scan_tmp;
     // scratch (grown on demand)
     DevBuf<unsigned> cnt, start, cursor, ord, minidx, firstidx, size, flags, pos, rootmin;
-    DevBuf<int> parent, label, segid, cellpos, corelist;
+    DevBuf<int> parent, label, segid, cellpos, corelist, cseg;
     DevBuf<double> cellbox;
     DevBuf<long long> cellid;
     DevBuf<unsigned char> core, score;     // core flag per point / per slot of the cell-sorted copy

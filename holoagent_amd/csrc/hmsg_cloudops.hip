@@ -136,7 +136,7 @@ __global__ void k_db_core(const double* __restrict__ pts, long long N, const int
                           double eps2, int minpts, unsigned char* __restrict__ core, unsigned* __restrict__ minidx, int* __restrict__ corecells, unsigned* __restrict__ ncore,
                           int* __restrict__ cellpos, int* __restrict__ parent, const unsigned char* __restrict__ core0,
                           unsigned char* __restrict__ hasanchor, unsigned* __restrict__ rep, unsigned* __restrict__ active,
-                          int* __restrict__ actlist, unsigned* __restrict__ nact) {
+                          int* __restrict__ actlist, unsigned* __restrict__ nact, int* __restrict__ cseg) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = i < N;
     if (!in_range) i = N - 1;                // keep the lane alive for the wave collectives below
@@ -203,13 +203,14 @@ __global__ void k_db_core(const double* __restrict__ pts, long long N, const int
         corecells[p] = (int)c;
         cellpos[c] = (int)p;
         parent[c] = (int)c;
+        cseg[c] = k_seg;
     }
     if (act) actlist[s_base[1] + off_act] = (int)c;
 }
 
 // lowest anchor cell of every segment (one atomic per (wave, segment))
 __global__ void k_db_anchor_min(const int* __restrict__ corecells, const unsigned* __restrict__ ncore,
-                                const DbSeg* __restrict__ segs, int K, const unsigned char* __restrict__ hasanchor,
+                                const int* __restrict__ cseg, const DbSeg* __restrict__ segs, int K, const unsigned char* __restrict__ hasanchor,
                                 unsigned* __restrict__ rep) {
     const unsigned n = *ncore;
     const unsigned stride = gridDim.x * blockDim.x;
@@ -220,11 +221,7 @@ __global__ void k_db_anchor_min(const int* __restrict__ corecells, const unsigne
         if (w < n) {
             c = (unsigned)corecells[w];
             if (hasanchor[c]) {
-                int lo = 0, hi = K - 1;
-                while (lo < hi) {
-                    int mid = (lo + hi + 1) >> 1;
-                    if (segs[mid].cell_base <= (long long)c) lo = mid; else hi = mid - 1;
-                }
+                const int lo = cseg[c];             // segment of the cell (written when the cell was registered)
                 seg = lo;
             }
         }
@@ -246,18 +243,14 @@ __global__ void k_db_anchor_min(const int* __restrict__ corecells, const unsigne
 }
 
 // anchor cells start out as one component (root = the lowest anchor cell of the segment)
-__global__ void k_db_anchor(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, const DbSeg* __restrict__ segs,
+__global__ void k_db_anchor(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, const int* __restrict__ cseg, const DbSeg* __restrict__ segs,
                             int K, const unsigned char* __restrict__ hasanchor, const unsigned* __restrict__ rep,
                             int* __restrict__ parent) {
     const unsigned n = *ncore;
     for (unsigned w = blockIdx.x * blockDim.x + threadIdx.x; w < n; w += gridDim.x * blockDim.x) {
         const int c = corecells[w];
         if (!hasanchor[c]) continue;
-        int lo = 0, hi = K - 1;
-        while (lo < hi) {
-            int mid = (lo + hi + 1) >> 1;
-            if (segs[mid].cell_base <= (long long)c) lo = mid; else hi = mid - 1;
-        }
+        const int lo = cseg[c];             // segment of the cell (written when the cell was registered)
         parent[c] = (int)rep[lo];
     }
 }
@@ -345,18 +338,14 @@ __global__ void k_db_cellbox(const double* __restrict__ pts, const int* __restri
 // than eps -> every pair of core points is a witness -> union.  (Pairs the boxes cannot decide are left to
 // k_db_union_scan.)  Everything a lane needs about its neighbour is loaded up front: the lane is one serial
 // chain of L2 round trips, and the kernel lasts as long as the longest chain.
-__global__ void k_db_union(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, const DbSeg* __restrict__ segs,
+__global__ void k_db_union(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, const int* __restrict__ cseg, const DbSeg* __restrict__ segs,
                            int K, const unsigned* __restrict__ minidx, double eps2, const int* __restrict__ cellpos,
                            const double* __restrict__ cellbox, int* __restrict__ parent, const unsigned* __restrict__ active) {
     const int lane = threadIdx.x & 63;
     const unsigned nwaves = (gridDim.x * blockDim.x) >> 6, ncells = *ncore;
     for (unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < ncells; w += nwaves) {
         const long long c = corecells[w];
-        int lo = 0, hi = K - 1;                 // segment of the cell
-        while (lo < hi) {
-            int mid = (lo + hi + 1) >> 1;
-            if (segs[mid].cell_base <= c) lo = mid; else hi = mid - 1;
-        }
+        const int lo = cseg[c];             // segment of the cell (written when the cell was registered)
         const DbSeg sg = segs[lo];
         int ix, iy, iz;
         cell_xyz(sg, c, ix, iy, iz);
@@ -388,7 +377,7 @@ __global__ void k_db_union(const int* __restrict__ corecells, const unsigned* __
 // wave works on one pair: lanes take the points of c in turn (point-to-box pruned), each walks c2 with early
 // exit, and the wave stops at the first hit -- a heavily re-observed cell holds hundreds of points.
 __global__ void k_db_union_scan(const double* __restrict__ pts, const int* __restrict__ corecells,
-                                const unsigned* __restrict__ ncore, const DbSeg* __restrict__ segs, int K,
+                                const unsigned* __restrict__ ncore, const int* __restrict__ cseg, const DbSeg* __restrict__ segs, int K,
                                 const unsigned* __restrict__ cnt, const unsigned* __restrict__ start,
                                 const unsigned* __restrict__ ord, const unsigned char* __restrict__ core,
                                 const unsigned* __restrict__ minidx, double eps2, const int* __restrict__ cellpos,
@@ -398,11 +387,7 @@ __global__ void k_db_union_scan(const double* __restrict__ pts, const int* __res
     const unsigned nwaves = (gridDim.x * blockDim.x) >> 6, ncells = *ncore;
     for (unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < ncells; w += nwaves) {
         const long long c = corecells[w];
-        int lo = 0, hi = K - 1;
-        while (lo < hi) {
-            int mid = (lo + hi + 1) >> 1;
-            if (segs[mid].cell_base <= c) lo = mid; else hi = mid - 1;
-        }
+        const int lo = cseg[c];             // segment of the cell (written when the cell was registered)
         const DbSeg sg = segs[lo];
         int ix, iy, iz;
         cell_xyz(sg, c, ix, iy, iz);
@@ -486,7 +471,7 @@ __global__ void k_db_union_scan(const double* __restrict__ pts, const int* __res
 // index (kept at the root cell), number of core members, number of clusters and smallest key per segment.
 __global__ void k_db_rootmin(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, int* __restrict__ parent,
                              const unsigned* __restrict__ minidx, unsigned* __restrict__ rootmin,
-                             const DbSeg* __restrict__ segs, int K, unsigned* __restrict__ segmin,
+                             const int* __restrict__ cseg, const DbSeg* __restrict__ segs, int K, unsigned* __restrict__ segmin,
                              unsigned* __restrict__ ncl, const unsigned* __restrict__ ccore, unsigned* __restrict__ size) {
     const unsigned n = *ncore;
     const unsigned stride = gridDim.x * blockDim.x;
@@ -508,11 +493,7 @@ __global__ void k_db_rootmin(const int* __restrict__ corecells, const unsigned* 
             mi = minidx[c];
             nc = ccore[w];
             if (root == c) {                    // one root cell per cluster: clusters of the segment
-                int lo = 0, hi = K - 1;
-                while (lo < hi) {
-                    int mid = (lo + hi + 1) >> 1;
-                    if (segs[mid].cell_base <= (long long)c) lo = mid; else hi = mid - 1;
-                }
+                const int lo = cseg[c];             // segment of the cell (written when the cell was registered)
                 atomicAdd(&ncl[lo], 1u);
             }
         }
@@ -533,11 +514,7 @@ __global__ void k_db_rootmin(const int* __restrict__ corecells, const unsigned* 
                 atomicAdd(&size[key], sum);      // core members; k_db_label adds the border points
                 // smallest key of the whole segment (= its first cluster): lets k_db_label stop at the first
                 // witness of that cluster
-                int lo = 0, hi = K - 1;
-                while (lo < hi) {
-                    int mid = (lo + hi + 1) >> 1;
-                    if (segs[mid].cell_base <= (long long)key) lo = mid; else hi = mid - 1;
-                }
+                const int lo = cseg[key];             // segment of the cell (written when the cell was registered)
                 if (v < segmin[lo]) atomicMin(&segmin[lo], v);
             }
             todo &= ~mine;
@@ -625,18 +602,14 @@ __global__ void k_db_label(const double* __restrict__ pts, long long N, const in
 }
 
 // cluster roots are core cells: pick the largest cluster per segment (ties: first label in point order)
-__global__ void k_db_pick(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, const DbSeg* __restrict__ segs,
+__global__ void k_db_pick(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, const int* __restrict__ cseg, const DbSeg* __restrict__ segs,
                           int K, const unsigned* __restrict__ size, const unsigned* __restrict__ firstidx,
                           const unsigned* __restrict__ rootmin, unsigned long long* __restrict__ best) {
     const unsigned n = *ncore;
     for (unsigned w = blockIdx.x * blockDim.x + threadIdx.x; w < n; w += gridDim.x * blockDim.x) {
         long long c = corecells[w];
         if (size[c] == 0u) continue;
-        int lo = 0, hi = K - 1;
-        while (lo < hi) {
-            int mid = (lo + hi + 1) >> 1;
-            if (segs[mid].cell_base <= c) lo = mid; else hi = mid - 1;
-        }
+        const int lo = cseg[c];             // segment of the cell (written when the cell was registered)
         const unsigned first = min(firstidx[c], rootmin[c]);
         unsigned long long key = ((unsigned long long)size[c] << 32) | (unsigned long long)(INF32 - first);
         atomicMax(&best[lo], key);
@@ -899,6 +872,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     corelist.ensure((size_t)std::max<long long>(N, 1));
     actlist.ensure((size_t)std::max<long long>(N, 1));
     cellpos.ensure((size_t)NC);
+    cseg.ensure((size_t)NC);
     cellbox.ensure((size_t)std::min<long long>(NC, N) * 6);
     ccore.ensure((size_t)std::min<long long>(NC, N));
     const unsigned gN = cdiv(N, 256), gC = cdiv(NC, 256);
@@ -927,7 +901,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     hipLaunchKernelGGL(k_db_core, dim3(gN), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const long long*)cellid.p,
                        (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p, (const double*)spts.p, score.p,
                        eps * eps, min_points, core.p, minidx.p, corelist.p, d_nc, cellpos.p, parent.p, core0, hasanchor.p, rep.p, active.p, actlist.p,
-                       d_nact);
+                       d_nact, cseg.p);
     }
     // persistent grid (8 blocks per CU): waves / threads stride over the core-cell list
     static int n_cu = 0;
@@ -943,26 +917,26 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
                        (const unsigned*)d_nc, (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p,
                        (const unsigned char*)score.p, cellbox.p, ccore.p);
     if (core0) {
-        hipLaunchKernelGGL(k_db_anchor_min, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc, dsegs, K,
+        hipLaunchKernelGGL(k_db_anchor_min, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc, (const int*)cseg.p, dsegs, K,
                            (const unsigned char*)hasanchor.p, rep.p);
-        hipLaunchKernelGGL(k_db_anchor, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc, dsegs, K,
+        hipLaunchKernelGGL(k_db_anchor, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc, (const int*)cseg.p, dsegs, K,
                            (const unsigned char*)hasanchor.p, (const unsigned*)rep.p, parent.p);
     }
     {
         ProfScope ps(prof, s, "k_db_union/box", (double)N * 24.0);
-        hipLaunchKernelGGL(k_db_union, dim3(gW), dim3(256), 0, s, (const int*)actlist.p, (const unsigned*)d_nact, dsegs, K,
+        hipLaunchKernelGGL(k_db_union, dim3(gW), dim3(256), 0, s, (const int*)actlist.p, (const unsigned*)d_nact, (const int*)cseg.p, dsegs, K,
                            (const unsigned*)minidx.p, eps * eps, (const int*)cellpos.p, (const double*)cellbox.p, parent.p,
                            (const unsigned*)active.p);
     }
     {
         ProfScope ps(prof, s, "k_db_union/scan", (double)N * 24.0);
         hipLaunchKernelGGL(k_db_union_scan, dim3(gW), dim3(256), 0, s, (const double*)spts.p, (const int*)actlist.p,
-                           (const unsigned*)d_nact, dsegs, K, (const unsigned*)cnt.p, (const unsigned*)start.p,
+                           (const unsigned*)d_nact, (const int*)cseg.p, dsegs, K, (const unsigned*)cnt.p, (const unsigned*)start.p,
                            (const unsigned*)ord.p, (const unsigned char*)score.p, (const unsigned*)minidx.p, eps * eps,
                            (const int*)cellpos.p, (const double*)cellbox.p, parent.p, (const unsigned*)active.p);
     }
     hipLaunchKernelGGL(k_db_rootmin, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc,
-                       parent.p, (const unsigned*)minidx.p, rootmin.p, dsegs, K, segmin.p, d_ncl, (const unsigned*)ccore.p, size.p);
+                       parent.p, (const unsigned*)minidx.p, rootmin.p, (const int*)cseg.p, dsegs, K, segmin.p, d_ncl, (const unsigned*)ccore.p, size.p);
     {
     ProfScope ps(prof, s, "k_db_label", (double)N * 28.0);
     hipLaunchKernelGGL(k_db_label, dim3(gN), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const long long*)cellid.p,
@@ -971,7 +945,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
                        (const int*)parent.p, (const unsigned*)rootmin.p, (const unsigned*)segmin.p, (const unsigned*)d_ncl, eps * eps,
                        label.p, size.p, firstidx.p, d_contested);
     }
-    hipLaunchKernelGGL(k_db_pick, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc, dsegs, K,
+    hipLaunchKernelGGL(k_db_pick, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc, (const int*)cseg.p, dsegs, K,
                        (const unsigned*)size.p, (const unsigned*)firstidx.p, (const unsigned*)rootmin.p, best.p);
     hipLaunchKernelGGL(k_db_flags, dim3(gN), dim3(256), 0, s, N, (const int*)segid.p, dsegs, (const int*)label.p,
                        (const unsigned long long*)best.p, flags.p, d_dropped);
