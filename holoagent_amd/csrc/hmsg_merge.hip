@@ -369,12 +369,14 @@ struct Merger {
         const unsigned bx = std::max(1u, std::min(cdiv(maxn, OV_CHUNK), (unsigned)std::max<size_t>(64, ((size_t)1 << 19) / tasks_per_launch)));
         double ov_work = 0;
         for (auto& t : tasks) ov_work += 12.0 * g[t.x].n;
-        ProfScope ps(h->prof, s, "k_ov_query", ov_work);
-        for (size_t t0 = 0; t0 < tasks.size(); t0 += 32768) {
-            unsigned nt = (unsigned)std::min<size_t>(32768, tasks.size() - t0);
-            hipLaunchKernelGGL(k_ov_query, dim3(bx, nt), dim3(256), 0, s, (const double*)pool.p, (const OvGrid*)d_grids.p,
-                               (const OvTask*)(d_tasks.p + t0), (const unsigned*)ix_cells.p, (const float*)ix_pts.p, r2, r,
-                               d_counts.p + t0);
+        {
+            ProfScope ps(h->prof, s, "k_ov_query", ov_work);   // (the kernel launches only: not the read-back below)
+            for (size_t t0 = 0; t0 < tasks.size(); t0 += 32768) {
+                unsigned nt = (unsigned)std::min<size_t>(32768, tasks.size() - t0);
+                hipLaunchKernelGGL(k_ov_query, dim3(bx, nt), dim3(256), 0, s, (const double*)pool.p, (const OvGrid*)d_grids.p,
+                                   (const OvTask*)(d_tasks.p + t0), (const unsigned*)ix_cells.p, (const float*)ix_pts.p, r2, r,
+                                   d_counts.p + t0);
+            }
         }
         HMSG_CHECK_LAUNCH();
         std::vector<unsigned> hc(tasks.size());

@@ -22,8 +22,8 @@ struct PoolSeg {            // one instance
     long long bit_base;     // first u32 word of its adjacency bit matrix
     int n;                  // rows (valid points)
     int nw;                 // u32 words per row = ceil(n / 32)
-    long long tile_base;    // first 64x64 tile id (upper triangle, row-major)
-    int nt;                 // 64x64 tiles per side = ceil(n / 64)
+    long long tile_base;    // first Gram tile id (upper triangle, row-major)
+    int nt;                 // Gram tiles per side = ceil(n / GRAM_T)
     int pad;
 };
 
@@ -62,16 +62,19 @@ __global__ void k_pool_gather(const int* __restrict__ idx, const unsigned* __res
 }
 
 // ---- Gram tiles on the matrix cores -> adjacency bits + neighbour counts
-// One 256-thread workgroup per 64x64 tile of X^ X^T of one instance, the four waves in a 2x2 arrangement
-// (32x32 accumulator each, v_mfma_f32_32x32x2_f32: lane l feeds A[i = l&31][k = l>>5], B[k = l>>5][j = l&31]).
-// The A and B row panels (64 rows x 32 k) are staged once per workgroup in LDS with 16-byte global loads and
-// shared by two waves each; rows are padded to 33 floats so the fragment reads are conflict free.
+// One 256-thread workgroup per 128x128 tile of X^ X^T of one instance, the four waves in a 2x2 arrangement, each
+// wave a 64x64 quadrant = 2x2 accumulators of 32x32 (v_mfma_f32_32x32x2_f32: lane l feeds A[i = l&31][k = l>>5],
+// B[k = l>>5][j = l&31]).  The A and B row panels (128 rows x 32 k) are staged once per workgroup in LDS with
+// 16-byte global loads; rows are padded to 33 floats so the fragment reads are conflict free.  A 128x128 tile
+// reads 2 x 128 x D floats for 128 x 128 x D multiply-adds -- half the L2/HBM traffic per FLOP of a 64x64 tile,
+// which is what bounded the kernel -- and four MFMAs share four LDS fragment reads.
 // Only tiles with tj >= ti are computed (the matrix is symmetric): the mirrored adjacency words are built
-// from the same accumulators (a lane owns one column of its 32x32 tile = one mirrored row half).
+// from the same accumulators (a lane owns one column of a 32x32 block = one mirrored row half).
+#define GRAM_T 128
 __global__ void __launch_bounds__(256) k_pool_gram(const float* __restrict__ Xn, int D, const PoolSeg* __restrict__ segs, int K,
                                                    float eps, unsigned* __restrict__ adj, unsigned* __restrict__ ncount) {
-    __shared__ float sa[64][33];
-    __shared__ float sb[64][33];
+    __shared__ float sa[GRAM_T][33];
+    __shared__ float sb[GRAM_T][33];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wr = wv >> 1, wc = wv & 1;
     const long long tile = blockIdx.x;
     int lo = 0, hi = K - 1;
@@ -92,59 +95,80 @@ __global__ void __launch_bounds__(256) k_pool_gram(const float* __restrict__ Xn,
         }
     }
     const int tj = ti + (int)t;
-    const int r0 = ti * 64, c0 = tj * 64;
-    f32x16 acc;
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int r0 = ti * GRAM_T, c0 = tj * GRAM_T;
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const float* base = Xn + (size_t)sg.row_base * D;
-    const int lrow = tid >> 2, lk = (tid & 3) * 8;          // this thread stages 8 consecutive k of one row
+    const int lrow = tid >> 1, lk = (tid & 1) * 16;         // this thread stages 16 consecutive k of one row
+    const bool vec_ok = (D & 3) == 0;                       // rows are 16-byte aligned
     for (int k0 = 0; k0 < D; k0 += 32) {
         {
             const int ra = r0 + lrow, rb = c0 + lrow;
-            for (int u = 0; u < 8; ++u) {
-                int k = k0 + lk + u;
-                sa[lrow][lk + u] = (ra < sg.n && k < D) ? base[(size_t)ra * D + k] : 0.f;
-                sb[lrow][lk + u] = (rb < sg.n && k < D) ? base[(size_t)rb * D + k] : 0.f;
+            if (vec_ok && k0 + lk + 16 <= D) {
+                const float4* pa = reinterpret_cast<const float4*>(base + (size_t)ra * D + k0 + lk);
+                const float4* pb = reinterpret_cast<const float4*>(base + (size_t)rb * D + k0 + lk);
+                for (int u = 0; u < 4; ++u) {
+                    const float4 va = ra < sg.n ? pa[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 vb = rb < sg.n ? pb[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    sa[lrow][lk + 4 * u] = va.x; sa[lrow][lk + 4 * u + 1] = va.y; sa[lrow][lk + 4 * u + 2] = va.z; sa[lrow][lk + 4 * u + 3] = va.w;
+                    sb[lrow][lk + 4 * u] = vb.x; sb[lrow][lk + 4 * u + 1] = vb.y; sb[lrow][lk + 4 * u + 2] = vb.z; sb[lrow][lk + 4 * u + 3] = vb.w;
+                }
+            } else {
+                for (int u = 0; u < 16; ++u) {
+                    int k = k0 + lk + u;
+                    sa[lrow][lk + u] = (ra < sg.n && k < D) ? base[(size_t)ra * D + k] : 0.f;
+                    sb[lrow][lk + u] = (rb < sg.n && k < D) ? base[(size_t)rb * D + k] : 0.f;
+                }
             }
         }
         __syncthreads();
         for (int k = 0; k < 32; k += 2) {
-            float a = sa[wr * 32 + (lane & 31)][k + (lane >> 5)];
-            float b = sb[wc * 32 + (lane & 31)][k + (lane >> 5)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            const int kk = k + (lane >> 5);
+            const float a0 = sa[wr * 64 + (lane & 31)][kk], a1 = sa[wr * 64 + 32 + (lane & 31)][kk];
+            const float b0 = sb[wc * 64 + (lane & 31)][kk], b1 = sb[wc * 64 + 32 + (lane & 31)][kk];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
         __syncthreads();
     }
-    // epilogue: d = 1 - s, clipped to [0, 2], diagonal forced to 0; neighbour iff d <= eps
-    const int rbase = r0 + wr * 32, cbase = c0 + wc * 32;
-    const int col = cbase + (lane & 31);
-    const bool diag_block = (ti == tj);
-    unsigned mirror = 0u;                                   // bits over rows rbase..rbase+31 for column `col`
-    for (int r = 0; r < 16; ++r) {
-        const int rloc = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int row = rbase + rloc;
-        float d = __fadd_rn(-acc[r], 1.0f);
-        d = fminf(fmaxf(d, 0.f), 2.f);
-        if (row == col) d = 0.f;
-        const bool nb = row < sg.n && col < sg.n && d <= eps;
-        mirror |= (nb ? 1u : 0u) << rloc;
-        unsigned long long m = __ballot(nb);
-        if ((lane & 31) == 0) {
-            unsigned word = (unsigned)(lane ? (m >> 32) : (m & 0xffffffffull));
-            if (row < sg.n && word) {
-                adj[sg.bit_base + (size_t)row * sg.nw + (cbase >> 5)] = word;
-                atomicAdd(&ncount[sg.row_base + row], (unsigned)__popc(word));
+    // epilogue per 32x32 block: d = 1 - s, clipped to [0, 2], diagonal forced to 0; neighbour iff d <= eps
+    const bool diag_tile = (ti == tj);                      // computed in full: no mirrored writes
+    for (int si = 0; si < 2; ++si)
+        for (int sj = 0; sj < 2; ++sj) {
+            const int rbase = r0 + wr * 64 + si * 32, cbase = c0 + wc * 64 + sj * 32;
+            const int col = cbase + (lane & 31);
+            unsigned mirror = 0u;                           // bits over rows rbase..rbase+31 for column `col`
+            for (int r = 0; r < 16; ++r) {
+                const int rloc = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int row = rbase + rloc;
+                float d = __fadd_rn(-acc[si][sj][r], 1.0f);
+                d = fminf(fmaxf(d, 0.f), 2.f);
+                if (row == col) d = 0.f;
+                const bool nb = row < sg.n && col < sg.n && d <= eps;
+                mirror |= (nb ? 1u : 0u) << rloc;
+                unsigned long long m = __ballot(nb);
+                if ((lane & 31) == 0) {
+                    unsigned word = (unsigned)(lane ? (m >> 32) : (m & 0xffffffffull));
+                    if (row < sg.n && word) {
+                        adj[sg.bit_base + (size_t)row * sg.nw + (cbase >> 5)] = word;
+                        atomicAdd(&ncount[sg.row_base + row], (unsigned)__popc(word));
+                    }
+                }
+            }
+            if (!diag_tile) {
+                // mirrored 32x32 block: row `col`, word index rbase/32; the two lane halves hold disjoint row bits
+                unsigned other = __shfl_xor(mirror, 32);
+                unsigned word = mirror | other;
+                if (lane < 32 && col < sg.n && word) {
+                    adj[sg.bit_base + (size_t)col * sg.nw + (rbase >> 5)] = word;
+                    atomicAdd(&ncount[sg.row_base + col], (unsigned)__popc(word));
+                }
             }
         }
-    }
-    if (!diag_block) {
-        // mirrored 32x32 block: row `col`, word index rbase/32; the two lane halves hold disjoint row bits
-        unsigned other = __shfl_xor(mirror, 32);
-        unsigned word = mirror | other;
-        if (lane < 32 && col < sg.n && word) {
-            adj[sg.bit_base + (size_t)col * sg.nw + (rbase >> 5)] = word;
-            atomicAdd(&ncount[sg.row_base + col], (unsigned)__popc(word));
-        }
-    }
 }
 
 // ---- label propagation over the adjacency bits (cores only): label = smallest core index reachable
@@ -352,12 +376,12 @@ void hmsg_pool(hmsg_ctx* h) {
         g.row_base = hpos[k];
         g.n = (int)(hpos[k + 1] - hpos[k]);
         g.nw = (g.n + 31) / 32;
-        g.nt = (g.n + 63) / 64;
+        g.nt = (g.n + GRAM_T - 1) / GRAM_T;
         g.bit_base = bitw;
         g.tile_base = tiles;
         g.pad = 0;
         bitw += (long long)g.n * g.nw;
-        tiles += (long long)g.nt * (g.nt + 1) / 2;      // upper triangle of 64x64 tiles
+        tiles += (long long)g.nt * (g.nt + 1) / 2;      // upper triangle of GRAM_T x GRAM_T tiles
         maxn = std::max(maxn, g.n);
     }
     DevBuf<PoolSeg> d_ps;
