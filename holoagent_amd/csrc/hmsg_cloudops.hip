@@ -136,7 +136,8 @@ __global__ void k_db_core(const double* __restrict__ pts, long long N, const int
                           double eps2, int minpts, unsigned char* __restrict__ core, unsigned* __restrict__ minidx, int* __restrict__ corecells, unsigned* __restrict__ ncore,
                           int* __restrict__ cellpos, int* __restrict__ parent, const unsigned char* __restrict__ core0,
                           unsigned char* __restrict__ hasanchor, unsigned* __restrict__ rep, unsigned* __restrict__ active,
-                          int* __restrict__ actlist, unsigned* __restrict__ nact, int* __restrict__ cseg) {
+                          int* __restrict__ actlist, unsigned* __restrict__ nact, int* __restrict__ cseg,
+                          unsigned* __restrict__ nclist) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = i < N;
     if (!in_range) i = N - 1;                // keep the lane alive for the wave collectives below
@@ -173,8 +174,8 @@ __global__ void k_db_core(const double* __restrict__ pts, long long N, const int
     // point that is not an anchor puts its cell on the active list (its connections have to be searched).  List
     // slots are handed out per BLOCK (waves take block-local offsets from LDS, one global atomic per block and
     // list): the two counters share a cache line, and an atomic per wave on it was a third of this kernel.
-    __shared__ unsigned s_cnt[2], s_base[2];
-    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0u;
+    __shared__ unsigned s_cnt[3], s_base[3];
+    if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
     bool reg = false;
     if (is_core && (unsigned)(i - sg.pt_base) < minidx[c])     // (stale read is only conservative)
@@ -183,8 +184,14 @@ __global__ void k_db_core(const double* __restrict__ pts, long long N, const int
     if (is_core && known && !hasanchor[c]) hasanchor[c] = 1;
     bool act = false;
     if (is_core && !known && !active[c]) act = atomicExch(&active[c], 1u) == 0u;
-    const unsigned long long m_reg = __ballot(reg), m_act = __ballot(act);
-    unsigned off_reg = 0, off_act = 0;
+    const bool ncp = in_range && !is_core;                     // non-core: the only points k_db_label has to visit
+    const unsigned long long m_reg = __ballot(reg), m_act = __ballot(act), m_ncp = __ballot(ncp);
+    unsigned off_reg = 0, off_act = 0, off_ncp = 0;
+    if (m_ncp) {
+        const int leader = __ffsll(m_ncp) - 1;
+        if (lane == leader) off_ncp = atomicAdd(&s_cnt[2], (unsigned)__popcll(m_ncp));
+        off_ncp = __shfl(off_ncp, leader) + (unsigned)__popcll(m_ncp & ((1ull << lane) - 1ull));
+    }
     if (m_reg) {
         const int leader = __ffsll(m_reg) - 1;
         if (lane == leader) off_reg = atomicAdd(&s_cnt[0], (unsigned)__popcll(m_reg));
@@ -196,7 +203,8 @@ __global__ void k_db_core(const double* __restrict__ pts, long long N, const int
         off_act = __shfl(off_act, leader) + (unsigned)__popcll(m_act & ((1ull << lane) - 1ull));
     }
     __syncthreads();
-    if (threadIdx.x < 2 && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(threadIdx.x == 0 ? ncore : nact, s_cnt[threadIdx.x]);
+    if (threadIdx.x < 3 && s_cnt[threadIdx.x])     // (the three counters are consecutive words: ncore, nact, n_noncore)
+        s_base[threadIdx.x] = atomicAdd(ncore + threadIdx.x, s_cnt[threadIdx.x]);
     __syncthreads();
     if (reg) {
         const unsigned p = s_base[0] + off_reg;
@@ -206,6 +214,7 @@ __global__ void k_db_core(const double* __restrict__ pts, long long N, const int
         cseg[c] = k_seg;
     }
     if (act) actlist[s_base[1] + off_act] = (int)c;
+    if (ncp) nclist[s_base[2] + off_ncp] = (unsigned)i;
 }
 
 // lowest anchor cell of every segment (one atomic per (wave, segment))
@@ -522,82 +531,77 @@ __global__ void k_db_rootmin(const int* __restrict__ corecells, const unsigned* 
     }
 }
 
-__global__ void k_db_label(const double* __restrict__ pts, long long N, const int* __restrict__ segid,
-                           const DbSeg* __restrict__ segs, const long long* __restrict__ cellid,
-                           const unsigned* __restrict__ minidx, const unsigned* __restrict__ start,
-                           const double* __restrict__ spts, const unsigned char* __restrict__ score,
-                           const unsigned char* __restrict__ core, const int* __restrict__ cellpos,
+__global__ void k_db_label(const double* __restrict__ pts, const int* __restrict__ segid, const DbSeg* __restrict__ segs,
+                           const long long* __restrict__ cellid, const unsigned* __restrict__ minidx,
+                           const unsigned* __restrict__ start, const double* __restrict__ spts,
+                           const unsigned char* __restrict__ score, const int* __restrict__ cellpos,
                            const double* __restrict__ cellbox, const int* __restrict__ parent, const unsigned* __restrict__ rootmin,
-                           const unsigned* __restrict__ segmin, const unsigned* __restrict__ ncl, double eps2,
-                           int* __restrict__ label, unsigned* __restrict__ size, unsigned* __restrict__ firstidx,
-                           unsigned* __restrict__ contested) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in_range = i < N;
-    if (!in_range) i = N - 1;                // keep the lane alive for the wave collectives below
-    const DbSeg sg = segs[segid[i]];
-    long long c = cellid[i];
-    int lab = -1;
-    if (core[i]) {
-        lab = parent[c];
-    } else if (in_range) {
+                           const unsigned* __restrict__ ncl, double eps2, int* __restrict__ label, unsigned* __restrict__ size,
+                           unsigned* __restrict__ firstidx, unsigned* __restrict__ contested, const unsigned* __restrict__ nclist,
+                           const unsigned* __restrict__ n_noncore) {
+    // Border search for the NON-CORE points only (compact list from k_db_core; a core point's label is simply the
+    // root of its cell, k_db_flags looks it up itself).  One WAVE per point, one LANE per neighbour cell (125 cells
+    // in two rounds): a lane decides its cell -- core cell? tight box of its core points in reach? a core point
+    // within eps? -- and the wave reduces to the cluster with the smallest order key (Open3D: the first cluster
+    // that reaches the point) and to "cores of two clusters in reach" (contested, see the merge stage).  A lane
+    // walking the 125 cells one after the other was the longest serial chain of the whole batch.
+    const int lane = threadIdx.x & 63;
+    const unsigned nn = *n_noncore;
+    const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (unsigned t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; t < nn; t += nwaves) {
+        const long long i = nclist[t];
+        const int k = segid[i];
+        const DbSeg sg = segs[k];
         int ix, iy, iz;
-        cell_xyz(sg, c, ix, iy, iz);
-        unsigned bestkey = INF32;
-        const unsigned firstkey = segmin[segid[i]];            // no cluster of the segment orders before this one
-        // With several clusters in the segment we also have to learn whether this border point is CONTESTED
-        // (cores of two clusters within eps): a contested point that ends up outside the kept cluster was a
-        // neighbour of its cores, so the kept cloud is not known to be a fixed point of the next pass.
-        bool settled = ncl[segid[i]] <= 1u;                    // nothing (more) to learn about contests
+        cell_xyz(sg, cellid[i], ix, iy, iz);
         const double pi[3] = {pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2]};
-        for (int col = 0; col < 25 && !(settled && bestkey == firstkey); ++col) {
-            {
-                const int jx = ix + DB_COL[col][0], jy = iy + DB_COL[col][1];
-                if (jx < 0 || jx >= sg.nx || jy < 0 || jy >= sg.ny) continue;
-                int z0, z1;
-                if (!column_zrange(sg, pi, jx, jy, iz, eps2, z0, z1)) continue;
-                const long long cb = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz;
-                // cores of one cell share a cluster: a cell is decided once, by its cluster and its first witness
-                for (int jz = z0; jz <= z1 && !(settled && bestkey == firstkey); ++jz) {
-                    const long long c2 = cb + jz;
-                    if (minidx[c2] == INF32) continue;                       // no core point in the cell
-                    const int r = parent[c2];
-                    if (r == lab) continue;
-                    const unsigned key = rootmin[r];
-                    if (settled && key >= bestkey) continue;                 // nothing to learn from this cell
-                    const double* bb = cellbox + (size_t)cellpos[c2] * 6;    // tight box of its core points
-                    double g2 = 0.0;
-                    for (int q = 0; q < 3; ++q) {
-                        double gq = fmax(0.0, fmax(bb[q] - pi[q], pi[q] - bb[3 + q]));
-                        g2 += gq * gq;
-                    }
-                    if (g2 >= eps2 * (1.0 + 1e-12)) continue;
-                    if (any_core_within(spts, score, start[c2], start[c2 + 1], pi, eps2)) {
-                        if (lab >= 0) settled = true;                        // second cluster in reach: contested
-                        if (key < bestkey) {
-                            bestkey = key;
-                            lab = r;
-                        }
-                    }
-                }
+        unsigned mykey = INF32;                 // best (smallest-key) cluster this lane found a witness of
+        int myr = -1;
+        bool mymulti = false;                   // ... and whether its two cells gave witnesses of different clusters
+        for (int round = 0; round < 2; ++round) {
+            const int o = round * 64 + lane;
+            if (o >= 125) continue;
+            const int jx = ix + o / 25 - 2, jy = iy + (o / 5) % 5 - 2, jz = iz + o % 5 - 2;
+            if (jx < 0 || jy < 0 || jz < 0 || jx >= sg.nx || jy >= sg.ny || jz >= sg.nz) continue;
+            const long long c2 = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz + jz;
+            if (minidx[c2] == INF32) continue;                               // no core point in the cell
+            const int r = parent[c2];
+            const unsigned key = rootmin[r];
+            const double* bb = cellbox + (size_t)cellpos[c2] * 6;            // tight box of its core points
+            double g2 = 0.0;
+            for (int q = 0; q < 3; ++q) {
+                double gq = fmax(0.0, fmax(bb[q] - pi[q], pi[q] - bb[3 + q]));
+                g2 += gq * gq;
+            }
+            if (g2 >= eps2 * (1.0 + 1e-12)) continue;
+            if (!any_core_within(spts, score, start[c2], start[c2 + 1], pi, eps2)) continue;
+            if (myr >= 0 && r != myr) mymulti = true;
+            if (key < mykey) {
+                mykey = key;
+                myr = r;
             }
         }
-        if (settled && ncl[segid[i]] > 1u && !contested[segid[i]]) contested[segid[i]] = 1u;
-    }
-    if (in_range) label[i] = lab;
-    // cluster sizes / first member index: one atomic per (wave, label) instead of one per point -- whole
-    // waves usually carry a single label, and per-point atomics on one address serialise.
-    // (core members were counted per cell by k_db_rootmin, and their smallest index is the cluster key)
-    const bool valid = in_range && lab >= 0 && !core[i];
-    unsigned long long todo = __ballot(valid);
-    while (todo) {
-        int leader = __ffsll(todo) - 1;
-        int key = __shfl(lab, leader);
-        unsigned long long mine = __ballot(valid && lab == key);
-        if ((int)(threadIdx.x & 63) == leader) {
-            atomicAdd(&size[key], (unsigned)__popcll(mine));
-            atomicMin(&firstidx[key], (unsigned)(i - sg.pt_base));   // leader = lowest lane = smallest index of the group
+        unsigned best = mykey;
+        for (int o = 32; o > 0; o >>= 1) {
+            unsigned u = __shfl_xor(best, o);
+            best = u < best ? u : best;
         }
-        todo &= ~mine;
+        int lab = -1;
+        bool contest = false;
+        if (best != INF32) {
+            const unsigned long long owners = __ballot(mykey == best);      // all of them hold the same cluster (keys are unique per cluster)
+            lab = __shfl(myr, __ffsll(owners) - 1);
+            contest = __any(mymulti || (myr >= 0 && myr != lab)) != 0;
+        }
+        if (lane == 0) {
+            label[i] = lab;
+            if (lab >= 0) {
+                // (core members were counted per cell by k_db_rootmin, and their smallest index is the cluster key)
+                atomicAdd(&size[lab], 1u);
+                atomicMin(&firstidx[lab], (unsigned)(i - sg.pt_base));
+                if (contest && ncl[k] > 1u && !contested[k]) contested[k] = 1u;
+            }
+        }
     }
 }
 
@@ -617,16 +621,23 @@ __global__ void k_db_pick(const int* __restrict__ corecells, const unsigned* __r
 }
 // graph_utils.py:853-880: keep the largest cluster unless there is none or it has < 5 points
 // (best[k] = size << 32 | ~first member index of the segment's largest cluster, 0 if it has none: the winner's
-//  label is the label of that first member)
+//  label is the label of that first member; a core point's label is the root of its cell, a non-core point's
+//  was written by k_db_label)
 __global__ void k_db_flags(long long N, const int* __restrict__ segid, const DbSeg* __restrict__ segs,
                            const int* __restrict__ label, const unsigned long long* __restrict__ best,
-                           unsigned* __restrict__ flags, unsigned* __restrict__ dropped) {
+                           unsigned* __restrict__ flags, unsigned* __restrict__ dropped, const unsigned char* __restrict__ core,
+                           const long long* __restrict__ cellid, const int* __restrict__ parent) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const int k = segid[i];
     const unsigned long long b = best[k];
     bool keep = true;
-    if ((unsigned)(b >> 32) >= 5u) keep = label[i] == label[segs[k].pt_base + (long long)(INF32 - (unsigned)(b & 0xffffffffull))];
+    if ((unsigned)(b >> 32) >= 5u) {
+        const long long fm = segs[k].pt_base + (long long)(INF32 - (unsigned)(b & 0xffffffffull));
+        const int wl = core[fm] ? parent[cellid[fm]] : label[fm];
+        const int my = core[i] ? parent[cellid[i]] : label[i];
+        keep = my == wl;
+    }
     flags[i] = keep ? 1u : 0u;
     if (!keep && !dropped[k]) dropped[k] = 1u;      // the segment loses points: its box has to be re-reduced
 }
@@ -813,7 +824,7 @@ __global__ void k_db_init(DbInit in) {
         in.contested[i] = 0u;
         in.dropped[i] = 0u;
     }
-    if (i < 2) in.counters[i] = 0u;
+    if (i < 3) in.counters[i] = 0u;
 }
 
 long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<SegDesc>& segs, double eps, int min_points,
@@ -862,7 +873,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     rootmin.ensure(NC);
     best.ensure(K);
     segmin.ensure(K); rep.ensure(K);
-    kres.ensure((size_t)K * 16 + 2);            // per segment: n_out | n_clusters | contested | dropped | 6 x u64 box
+    kres.ensure((size_t)K * 16 + 3);            // per segment: n_out | n_clusters | contested | dropped | 6 x u64 box
     int* const d_ocount = (int*)kres.p;
     unsigned* const d_ncl = kres.p + K;
     unsigned* const d_contested = kres.p + 2 * (size_t)K;
@@ -871,6 +882,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     active.ensure(NC); hasanchor.ensure(NC);
     corelist.ensure((size_t)std::max<long long>(N, 1));
     actlist.ensure((size_t)std::max<long long>(N, 1));
+    nclist.ensure((size_t)std::max<long long>(N, 1));
     cellpos.ensure((size_t)NC);
     cseg.ensure((size_t)NC);
     cellbox.ensure((size_t)std::min<long long>(NC, N) * 6);
@@ -901,7 +913,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     hipLaunchKernelGGL(k_db_core, dim3(gN), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const long long*)cellid.p,
                        (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p, (const double*)spts.p, score.p,
                        eps * eps, min_points, core.p, minidx.p, corelist.p, d_nc, cellpos.p, parent.p, core0, hasanchor.p, rep.p, active.p, actlist.p,
-                       d_nact, cseg.p);
+                       d_nact, cseg.p, nclist.p);
     }
     // persistent grid (8 blocks per CU): waves / threads stride over the core-cell list
     static int n_cu = 0;
@@ -939,16 +951,17 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
                        parent.p, (const unsigned*)minidx.p, rootmin.p, (const int*)cseg.p, dsegs, K, segmin.p, d_ncl, (const unsigned*)ccore.p, size.p);
     {
     ProfScope ps(prof, s, "k_db_label", (double)N * 28.0);
-    hipLaunchKernelGGL(k_db_label, dim3(gN), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const long long*)cellid.p,
-                       (const unsigned*)minidx.p, (const unsigned*)start.p, (const double*)spts.p, (const unsigned char*)score.p,
-                       (const unsigned char*)core.p, (const int*)cellpos.p, (const double*)cellbox.p,
-                       (const int*)parent.p, (const unsigned*)rootmin.p, (const unsigned*)segmin.p, (const unsigned*)d_ncl, eps * eps,
-                       label.p, size.p, firstidx.p, d_contested);
+    hipLaunchKernelGGL(k_db_label, dim3(std::min(gN, (unsigned)n_cu * 8u)), dim3(256), 0, s, src, (const int*)segid.p, dsegs,
+                       (const long long*)cellid.p, (const unsigned*)minidx.p, (const unsigned*)start.p, (const double*)spts.p,
+                       (const unsigned char*)score.p, (const int*)cellpos.p, (const double*)cellbox.p, (const int*)parent.p,
+                       (const unsigned*)rootmin.p, (const unsigned*)d_ncl, eps * eps, label.p, size.p, firstidx.p, d_contested,
+                       (const unsigned*)nclist.p, (const unsigned*)(d_nc + 2));
     }
     hipLaunchKernelGGL(k_db_pick, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc, (const int*)cseg.p, dsegs, K,
                        (const unsigned*)size.p, (const unsigned*)firstidx.p, (const unsigned*)rootmin.p, best.p);
     hipLaunchKernelGGL(k_db_flags, dim3(gN), dim3(256), 0, s, N, (const int*)segid.p, dsegs, (const int*)label.p,
-                       (const unsigned long long*)best.p, flags.p, d_dropped);
+                       (const unsigned long long*)best.p, flags.p, d_dropped, (const unsigned char*)core.p,
+                       (const long long*)cellid.p, (const int*)parent.p);
     HMSG_CHECK_LAUNCH();
     hmsg_scan_u32(flags.p, pos.p, (size_t)N, s, scan_tmp, nullptr);
     {
