@@ -11,6 +11,13 @@
 // of how many duplicates a heavily re-observed surface has piled up.  Cluster order (smallest core
 // index), border assignment (first = smallest-order reaching cluster) and the largest-cluster tie rule
 // (first label in point order) follow the reference exactly.
+//
+// Batch pipeline (one launch each): init tables -> bin points into cells -> scan -> cell-sorted copy -> core
+// flags + cell lists (k_db_core) -> per-cell boxes / core counts -> [anchor cells pre-connected] -> box pass and
+// witness scans over the ACTIVE cells -> roots, cluster keys and core sizes -> border points (wave per point)
+// -> largest cluster per segment -> keep flags -> scan -> compaction + boxes of the kept points.  The
+// neighbourhood kernels are serial chains of L2 round trips per lane: they work on a cell-SORTED COPY of the
+// points (one load per candidate), visit the nearest cells first and keep several loads in flight.
 #include "hmsg_cloudops.h"
 
 #include <algorithm>

@@ -10,13 +10,19 @@
 //            bookkeeping.  The merge is a fold over frames (inherently sequential across steps); each
 //            step is two device->host syncs.
 //
-// Two EXACT shortcuts make a 1000-frame fold tractable (the reference re-does this work every step):
-//   (1) a cloud whose DBSCAN kept every point is a fixed point of pcd_denoise_dbscan, so singleton
-//       components that are unchanged are not re-clustered;
+// EXACT shortcuts make a 1000-frame fold tractable (the reference re-does this work every step):
+//   (1) fixed points: a cloud whose DBSCAN kept every point -- or dropped only points that are not
+//       eps-neighbours of a kept core point (no "contested" border point, see k_db_label) -- is returned
+//       unchanged by pcd_denoise_dbscan, so unchanged singleton components are not re-clustered;
 //   (2) sequential merge: two clouds that were both inputs of the previous step and both survived it
 //       unchanged were separate components there, so their overlap is <= threshold again -- only pairs
 //       involving a new or changed cloud are evaluated.  (Hierarchical merge changes the threshold per
 //       level, so there overlap VALUES are cached per pair of unchanged clouds instead.)
+//   (3) anchors: the core flags of a fixed single-cluster cloud are persisted next to its pool points; when it
+//       takes part in a merge they are handed to the DBSCAN batch, which neither re-counts nor re-connects
+//       those points (CloudOps::dbscan_keep_largest, core0);
+//   (4) empty masks never pair and are dropped by the min-points filter at the end: they are left out.
+//   HMSG_DEBUG_NOANCHOR=1 disables (3) (tests compare the two folds bit for bit).
 #include "hmsg_cloudops.h"
 
 #include <algorithm>
