@@ -72,11 +72,15 @@ __device__ __forceinline__ long long ov_cell(const OvGrid& g, float x, float y, 
     iz = min(max(iz, 0), g.gz - 1);
     return g.ix_cell + ((long long)ix * g.gy + iy) * g.gz + iz;
 }
-__global__ void k_ov_count(const double* __restrict__ pool, const OvGrid* __restrict__ gr, unsigned* __restrict__ cells) {
+// (counts go to `cursor`, indexed relative to the batch's first cell; the scan turns them into cell starts in
+//  `cells`, and k_ov_fill hands a cell's slots out from its end by counting `cursor` back down -- the order of
+//  points inside a cell is irrelevant)
+__global__ void k_ov_count(const double* __restrict__ pool, const OvGrid* __restrict__ gr, unsigned* __restrict__ cursor,
+                           long long cursor_base) {
     const OvGrid g = gr[blockIdx.y];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += gridDim.x * blockDim.x) {
         const double* p = pool + (size_t)(g.pt_off + i) * 3;
-        atomicAdd(&cells[ov_cell(g, (float)p[0], (float)p[1], (float)p[2])], 1u);
+        atomicAdd(&cursor[ov_cell(g, (float)p[0], (float)p[1], (float)p[2]) - cursor_base], 1u);
     }
 }
 __global__ void k_ov_fill(const double* __restrict__ pool, const OvGrid* __restrict__ gr, const unsigned* __restrict__ cells,
@@ -86,7 +90,7 @@ __global__ void k_ov_fill(const double* __restrict__ pool, const OvGrid* __restr
         const double* p = pool + (size_t)(g.pt_off + i) * 3;
         float x = (float)p[0], y = (float)p[1], z = (float)p[2];
         long long c = ov_cell(g, x, y, z);
-        size_t pos = (size_t)g.ix_pt + cells[c] + atomicAdd(&cursor[c - cursor_base], 1u);
+        size_t pos = (size_t)g.ix_pt + cells[c] + (atomicSub(&cursor[c - cursor_base], 1u) - 1u);
         sorted[(size_t)pos * 3] = x;
         sorted[(size_t)pos * 3 + 1] = y;
         sorted[(size_t)pos * 3 + 2] = z;
@@ -326,14 +330,14 @@ struct Merger {
         d_grids.ensure(g.size());
         HIP_TRY(hipMemcpyAsync(d_grids.p, g.data(), g.size() * sizeof(OvGrid), hipMemcpyHostToDevice, s));
         unsigned* cells = ix_cells.p + ix_cells_used;
-        HIP_TRY(hipMemsetAsync(cells, 0, (size_t)ncell_new * 4, s));
-        dim3 grid(std::max(1u, std::min(cdiv(maxn, 256), 1024u)), (unsigned)todo.size());
-        hipLaunchKernelGGL(k_ov_count, grid, dim3(256), 0, s, (const double*)pool.p, (const OvGrid*)d_grids.p, ix_cells.p);
-        HMSG_CHECK_LAUNCH();
-        hmsg_scan_u32(cells, cells, (size_t)ncell_new, s, ops.scan_tmp, nullptr);
-        // (cell starts stay relative to this batch's first sorted point: Cloud::ix_pt)
         d_cursor.ensure((size_t)ncell_new);
         HIP_TRY(hipMemsetAsync(d_cursor.p, 0, (size_t)ncell_new * 4, s));
+        dim3 grid(std::max(1u, std::min(cdiv(maxn, 256), 1024u)), (unsigned)todo.size());
+        hipLaunchKernelGGL(k_ov_count, grid, dim3(256), 0, s, (const double*)pool.p, (const OvGrid*)d_grids.p, d_cursor.p,
+                           ix_cells_used);
+        HMSG_CHECK_LAUNCH();
+        // (cell starts stay relative to this batch's first sorted point: Cloud::ix_pt)
+        hmsg_scan_u32(d_cursor.p, cells, (size_t)ncell_new, s, ops.scan_tmp, nullptr);
         hipLaunchKernelGGL(k_ov_fill, grid, dim3(256), 0, s, (const double*)pool.p, (const OvGrid*)d_grids.p,
                            (const unsigned*)ix_cells.p, d_cursor.p, ix_cells_used, ix_pts.p);
         HMSG_CHECK_LAUNCH();
