@@ -133,21 +133,32 @@ __device__ __forceinline__ bool ov_hit(const OvGrid& Y, const unsigned* __restri
         const long long c = Y.ix_cell + ((long long)cx * Y.gy + cy) * Y.gz + cz;
         if (ov_scan(sorted + (size_t)Y.ix_pt * 3, cells[c], cells[c + 1], x, y, z, r2)) return true;
     }
-    for (int dx = -1; dx <= 1; ++dx) {
-        const int jx = cx + dx;
-        if (jx < 0 || jx >= Y.gx) continue;
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int jy = cy + dy;
-            if (jy < 0 || jy >= Y.gy) continue;
-            const long long c0 = Y.ix_cell + ((long long)jx * Y.gy + jy) * Y.gz;   // z-cells are contiguous
-            if (own && dx == 0 && dy == 0) {                                       // own cell already done
-                if (ov_scan(sorted + (size_t)Y.ix_pt * 3, cells[c0 + z0], cells[c0 + cz], x, y, z, r2)) return true;
-                if (ov_scan(sorted + (size_t)Y.ix_pt * 3, cells[c0 + cz + 1], cells[c0 + z1 + 1], x, y, z, r2)) return true;
-            } else if (ov_scan(sorted + (size_t)Y.ix_pt * 3, cells[c0 + z0], cells[c0 + z1 + 1], x, y, z, r2)) {
-                return true;
-            }
+    // a MISS has to rule out all 27 cells: fetch the candidate ranges of the 9 columns first (independent loads,
+    // one round trip), then scan them
+    unsigned rs[10], re[10];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const int jx = cx + q / 3 - 1, jy = cy + q % 3 - 1;
+        rs[q] = re[q] = 0u;
+        if (jx < 0 || jx >= Y.gx || jy < 0 || jy >= Y.gy) continue;
+        const long long c0 = Y.ix_cell + ((long long)jx * Y.gy + jy) * Y.gz;       // z-cells are contiguous
+        if (own && q == 4) {                                                       // own cell already done: below it ...
+            rs[q] = cells[c0 + z0];
+            re[q] = cells[c0 + cz];
+        } else {
+            rs[q] = cells[c0 + z0];
+            re[q] = cells[c0 + z1 + 1];
         }
     }
+    rs[9] = re[9] = 0u;
+    if (own) {                                                                     // ... and above it
+        const long long c0 = Y.ix_cell + ((long long)cx * Y.gy + cy) * Y.gz;
+        rs[9] = cells[c0 + cz + 1];
+        re[9] = cells[c0 + z1 + 1];
+    }
+#pragma unroll
+    for (int q = 0; q < 10; ++q)
+        if (ov_scan(sorted + (size_t)Y.ix_pt * 3, rs[q], re[q], x, y, z, r2)) return true;
     return false;
 }
 
