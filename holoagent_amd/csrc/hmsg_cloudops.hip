@@ -484,10 +484,10 @@ __global__ void k_db_union_scan(const double* __restrict__ pts, const int* __res
 // after the union passes) and stores it: every parent[] must be a root when the kernel ends, labels are read
 // straight from it.  (No path halving here: a halving store of one thread may land after another thread has
 // written the root into the same word and put an inner node back.)  Then, per cluster: order key = smallest core
-// index (kept at the root cell), number of core members, number of clusters and smallest key per segment.
+// index (kept at the root cell), number of core members, and the number of clusters per segment.
 __global__ void k_db_rootmin(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, int* __restrict__ parent,
                              const unsigned* __restrict__ minidx, unsigned* __restrict__ rootmin,
-                             const int* __restrict__ cseg, const DbSeg* __restrict__ segs, int K, unsigned* __restrict__ segmin,
+                             const int* __restrict__ cseg, const DbSeg* __restrict__ segs, int K,
                              unsigned* __restrict__ ncl, const unsigned* __restrict__ ccore, unsigned* __restrict__ size) {
     const unsigned n = *ncore;
     const unsigned stride = gridDim.x * blockDim.x;
@@ -528,10 +528,6 @@ __global__ void k_db_rootmin(const int* __restrict__ corecells, const unsigned* 
             if ((int)(threadIdx.x & 63) == leader) {
                 atomicMin(&rootmin[key], v);
                 atomicAdd(&size[key], sum);      // core members; k_db_label adds the border points
-                // smallest key of the whole segment (= its first cluster): lets k_db_label stop at the first
-                // witness of that cluster
-                const int lo = cseg[key];             // segment of the cell (written when the cell was registered)
-                if (v < segmin[lo]) atomicMin(&segmin[lo], v);
             }
             todo &= ~mine;
         }
@@ -805,7 +801,7 @@ struct DbInit {
     unsigned long long* best;
     int* ocount;
     unsigned long long* obounds;
-    unsigned *ncl, *segmin, *rep, *contested, *dropped, *counters;
+    unsigned *ncl, *rep, *contested, *dropped, *counters;
     long long NC;
     int K;
 };
@@ -826,7 +822,6 @@ __global__ void k_db_init(DbInit in) {
         for (int a = 0; a < 6; ++a) in.obounds[(size_t)i * 6 + a] = a < 3 ? ~0ull : 0ull;
         in.ocount[i] = 0;
         in.ncl[i] = 0u;
-        in.segmin[i] = INF32;
         in.rep[i] = INF32;
         in.contested[i] = 0u;
         in.dropped[i] = 0u;
@@ -879,7 +874,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     parent.ensure(NC);
     rootmin.ensure(NC);
     best.ensure(K);
-    segmin.ensure(K); rep.ensure(K);
+    rep.ensure(K);
     kres.ensure((size_t)K * 16 + 3);            // per segment: n_out | n_clusters | contested | dropped | 6 x u64 box
     int* const d_ocount = (int*)kres.p;
     unsigned* const d_ncl = kres.p + K;
@@ -899,7 +894,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
         DbInit in;
         in.cnt = cnt.p; in.cursor = cursor.p; in.minidx = minidx.p; in.firstidx = firstidx.p; in.rootmin = rootmin.p;
         in.size = size.p; in.active = active.p; in.hasanchor = hasanchor.p;
-        in.best = best.p; in.obounds = d_obounds; in.ocount = d_ocount; in.ncl = d_ncl; in.segmin = segmin.p; in.rep = rep.p; in.contested = d_contested; in.dropped = d_dropped;
+        in.best = best.p; in.obounds = d_obounds; in.ocount = d_ocount; in.ncl = d_ncl; in.rep = rep.p; in.contested = d_contested; in.dropped = d_dropped;
         in.counters = kres.p + (size_t)K * 16;   // [0] core cells, [1] active core cells
         in.NC = NC; in.K = K;
         hipLaunchKernelGGL(k_db_init, dim3(cdiv(NC + 1, 256)), dim3(256), 0, s, in);
@@ -955,7 +950,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
                            (const int*)cellpos.p, (const double*)cellbox.p, parent.p, (const unsigned*)active.p);
     }
     hipLaunchKernelGGL(k_db_rootmin, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc,
-                       parent.p, (const unsigned*)minidx.p, rootmin.p, (const int*)cseg.p, dsegs, K, segmin.p, d_ncl, (const unsigned*)ccore.p, size.p);
+                       parent.p, (const unsigned*)minidx.p, rootmin.p, (const int*)cseg.p, dsegs, K, d_ncl, (const unsigned*)ccore.p, size.p);
     {
     ProfScope ps(prof, s, "k_db_label", (double)N * 28.0);
     hipLaunchKernelGGL(k_db_label, dim3(std::min(gN, (unsigned)n_cu * 8u)), dim3(256), 0, s, src, (const int*)segid.p, dsegs,

@@ -68,16 +68,36 @@ def test_full_build_against_oracle_and_reference_golden(L, name):
     sc.close()
 
 
+def test_full_path_d1024(L):
+    """configs[2] shape (1024-d features, DINOv2 ViT-L width): A1..A7 stage-wise against the oracle on a small scene."""
+    from holoagent_amd.synth import SceneSpec, SynthScene
+    spec = SceneSpec(seed=33, rooms_x=1, rooms_z=1, room_size=(4.0, 2.6, 3.5), objects_per_room=5, width=160,
+                     height=120, n_frames=24, n_masks=16, feat_dim=1024)
+    scn = SynthScene(spec)
+    frames = [scn.frame(i) for i in range(spec.n_frames)]
+    cfg = dict(voxel_size=0.05, clip_masked_weight=0.4418, max_mask_distance=10000, feat_dim=1024,
+               init_overlap_thresh=0.75, overlap_thresh_factor=0.025, iou_thresh=0.05, merge_type="sequential",
+               outlier_nb=300)
+    sc = PC.make_scene(L, frames, dict(feat_dim=1024, outlier_nb_points=300))
+    S, ref_pts, ref_cols = PC.check_map(sc, frames, cfg)
+    ref_feats, _ = PC.check_fuse(sc, frames, S, cfg, ref_pts, ref_cols, check_masks=False)
+    got, feats = PC.check_merge_pool(sc, frames, cfg, ref_pts, ref_feats)
+    assert len(got) >= 3 and feats.shape[1] == 1024
+    sc.close()
+
+
 def test_query_golden(L):
     PC.check_query_golden(L)
 
 
-def test_query_random_large(L):
-    """1k queries x 5k nodes x D=512 against the numpy restatement (oracle.query_object)."""
+@pytest.mark.parametrize("D", [512, 1024])
+def test_query_random_large(L, D):
+    """1k queries x 5k nodes x D (CLIP ViT-B/32 width and configs[2]'s 1024) against the numpy restatement
+    (oracle.query_object)."""
     from holoagent_amd._lib import NodeIndex
     from oracle import hmsg_oracle as O
     rng = np.random.Generator(np.random.PCG64(77))
-    N, D, R, Q, k = 5000, 512, 40, 1000, 5
+    N, R, Q, k = 5000, 40, 1000, 5
     emb = rng.standard_normal((N, D)) * 0.05
     room = rng.integers(0, R, size=N).astype(np.int32)
     T = rng.standard_normal((Q, 2, D)).astype(np.float32) * 0.05
