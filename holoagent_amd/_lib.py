@@ -67,6 +67,7 @@ _SIGS = {
     "hmsg_get_instance_boxes": (C.c_int, [_P, _P]),
     "hmsg_denoise_instances": (C.c_int, [_P, C.c_double, C.c_int32]),
     "hmsg_instance_room_share": (C.c_int, [_P, C.c_int32, _P, _P, C.c_double, _P]),
+    "hmsg_voxel_down_sample": (C.c_int, [_P, _P, C.c_int64, C.c_double, _P, _P]),
     "hmsg_pool_instances": (C.c_int, [_P]),
     "hmsg_get_instance_feats": (C.c_int, [_P, _P]),
     "hmsg_index_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _P, C.c_int32, _P, C.POINTER(_P)]),
@@ -265,6 +266,14 @@ class Scene:
         out = np.zeros((self.num_instances(), R), np.float64)
         self._ck(self.L.c.hmsg_instance_room_share(self.h, R, _ptr(off), _ptr(verts), float(radius), _ptr(out)))
         return out
+
+    def voxel_down_sample(self, points, voxel_size):
+        """Open3D voxel_down_sample of an [n, 3] f64 cloud (canonical ascending voxel order) on the device."""
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        out = np.empty_like(pts)
+        n_out = C.c_int64(0)
+        self._ck(self.L.c.hmsg_voxel_down_sample(self.h, _ptr(pts), pts.shape[0], float(voxel_size), _ptr(out), C.byref(n_out)))
+        return out[: n_out.value].copy()
 
     def denoise_instances(self, eps=0.05, min_points=10):
         self._ck(self.L.c.hmsg_denoise_instances(self.h, float(eps), int(min_points)))

@@ -365,6 +365,14 @@ int hmsg_denoise_instances(hmsg_t* h, double eps, int32_t min_points) {
     return guard(h, [&] { hmsg_denoise_inst(h, eps, min_points); });
 }
 
+int hmsg_voxel_down_sample(hmsg_t* h, const double* points, int64_t n, double voxel_size, double* out_points, int64_t* out_n) {
+    if (!h) return HMSG_ERR_INVALID;
+    return guard(h, [&] {
+        HMSG_REQUIRE((points || n == 0) && out_points && out_n, HMSG_ERR_INVALID, "hmsg_voxel_down_sample: null argument");
+        *out_n = (int64_t)hmsg_voxel_ds(h, points, (long long)n, voxel_size, out_points);
+    });
+}
+
 int hmsg_instance_room_share(hmsg_t* h, int32_t n_rooms, const int64_t* vert_off, const double* verts_xz, double radius,
                              double* share) {
     if (!h) return HMSG_ERR_INVALID;

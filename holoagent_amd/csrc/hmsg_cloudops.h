@@ -41,7 +41,7 @@ struct CloudOps {
     DevBuf<unsigned long long> vbitmap;
     DevBuf<unsigned> vrank;
     DevBuf<long long> vacc;
-    DevBuf<unsigned> vwgt;
+    DevBuf<unsigned> vwgt, vany;
 
     // fill segs[k].mn / mx from the points (device reduction, one sync)
     void bounds(const double* src, std::vector<SegDesc>& segs);

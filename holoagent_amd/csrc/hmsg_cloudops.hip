@@ -1041,7 +1041,8 @@ __global__ void k_vx_mark(const double* __restrict__ pts, const VxSeg* __restric
 }
 __global__ void k_vx_accum(const double* __restrict__ pts, const VxSeg* __restrict__ segs, double vs,
                            const unsigned long long* __restrict__ bitmap, const unsigned* __restrict__ rank,
-                           long long* __restrict__ acc /*[3][P]*/, long long P, unsigned* __restrict__ wgt) {
+                           long long* __restrict__ acc /*[3][P]*/, long long P, unsigned* __restrict__ wgt,
+                           unsigned* __restrict__ anyidx) {
     const VxSeg g = segs[blockIdx.y];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += gridDim.x * blockDim.x) {
         const double* p = pts + (size_t)(g.pt_base + i) * 3;
@@ -1055,11 +1056,13 @@ __global__ void k_vx_accum(const double* __restrict__ pts, const VxSeg* __restri
         atomicAdd((unsigned long long*)&acc[P + slot], (unsigned long long)llrint((p[1] - cy) * VFIX));
         atomicAdd((unsigned long long*)&acc[2 * P + slot], (unsigned long long)llrint((p[2] - cz) * VFIX));
         atomicAdd(&wgt[slot], 1u);
+        anyidx[slot] = (unsigned)(g.pt_base + i);     // (only read for voxels that hold a single point)
     }
 }
 __global__ void k_vx_final(const unsigned long long* __restrict__ bitmap, const unsigned* __restrict__ rank, long long nwords,
                            const VxSeg* __restrict__ segs, int K, double vs, const long long* __restrict__ acc, long long P,
-                           const unsigned* __restrict__ wgt, double* __restrict__ out) {
+                           const unsigned* __restrict__ wgt, double* __restrict__ out, const double* __restrict__ pts,
+                           const unsigned* __restrict__ anyidx) {
     long long wd = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (wd >= nwords) return;
     unsigned long long bw = bitmap[wd];
@@ -1078,6 +1081,14 @@ __global__ void k_vx_final(const unsigned long long* __restrict__ bitmap, const 
         int iz = (int)(lin % g.nz);
         long long r = lin / g.nz;
         int iy = (int)(r % g.ny), ix = (int)(r / g.ny);
+        if (wgt[sidx] == 1u) {
+            // a voxel with one point returns that point bit for bit (sum / 1), as Open3D does -- callers compare
+            // against coordinates of the input (floor ranges start at the lowest re-sampled point)
+            const double* q = pts + (size_t)anyidx[sidx] * 3;
+            for (int a = 0; a < 3; ++a) out[(size_t)sidx * 3 + a] = q[a];
+            ++sidx;
+            continue;
+        }
         double n = (double)wgt[sidx];
         out[(size_t)sidx * 3 + 0] = __dadd_rn(g.ox, __dmul_rn((double)ix, vs)) + ((double)acc[sidx] / n) / VFIX;
         out[(size_t)sidx * 3 + 1] = __dadd_rn(g.oy, __dmul_rn((double)iy, vs)) + ((double)acc[P + sidx] / n) / VFIX;
@@ -1132,12 +1143,14 @@ long long CloudOps::voxel_down_sample(const double* src, const std::vector<SegDe
     long long P = (long long)hmsg_bitmap_rank(vbitmap.p, vrank.p, (size_t)nwords, s, scan_tmp);
     vacc.ensure((size_t)P * 3);
     vwgt.ensure((size_t)P);
+    vany.ensure((size_t)P);
     HIP_TRY(hipMemsetAsync(vacc.p, 0, (size_t)P * 24, s));
     HIP_TRY(hipMemsetAsync(vwgt.p, 0, (size_t)P * 4, s));
     hipLaunchKernelGGL(k_vx_accum, grid, dim3(256), 0, s, src, dsegs, vs, (const unsigned long long*)vbitmap.p,
-                       (const unsigned*)vrank.p, vacc.p, P, vwgt.p);
+                       (const unsigned*)vrank.p, vacc.p, P, vwgt.p, vany.p);
     hipLaunchKernelGGL(k_vx_final, dim3(cdiv((size_t)nwords, 256)), dim3(256), 0, s, (const unsigned long long*)vbitmap.p,
-                       (const unsigned*)vrank.p, nwords, dsegs, K, vs, (const long long*)vacc.p, P, (const unsigned*)vwgt.p, dst);
+                       (const unsigned*)vrank.p, nwords, dsegs, K, vs, (const long long*)vacc.p, P, (const unsigned*)vwgt.p, dst,
+                       src, (const unsigned*)vany.p);
     pos.ensure(K);
     hipLaunchKernelGGL(k_vx_gather, dim3(cdiv(K, 256)), dim3(256), 0, s, (const unsigned*)vrank.p, dsegs, K, pos.p);
     HMSG_CHECK_LAUNCH();

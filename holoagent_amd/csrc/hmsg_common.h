@@ -317,3 +317,4 @@ void hmsg_denoise_inst(hmsg_ctx* h, double eps, int min_points);   // hmsg_merge
 void hmsg_room_share(hmsg_ctx* h, int R, const long long* vert_off, const double* verts_xz, double radius,
                      double* share_out);                              // hmsg_merge.hip
 void hmsg_pool(hmsg_ctx* h);            // hmsg_pool.hip
+long long hmsg_voxel_ds(hmsg_ctx* h, const double* pts, long long n, double vs, double* out);   // hmsg_merge.hip

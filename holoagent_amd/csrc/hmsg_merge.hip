@@ -957,3 +957,32 @@ void hmsg_room_share(hmsg_ctx* h, int R, const long long* vert_off, const double
     for (size_t k = 0; k < tasks.size(); ++k)
         share_out[(size_t)tasks[k].inst * R + tasks[k].room] = (double)hc[k] / (double)g[tasks[k].inst].n;
 }
+
+// ------------------------------------------------------------------------------------------ A8 helper
+// Open3D voxel_down_sample of one caller-supplied cloud (segment_floors_manually re-samples the finished map at
+// 5 cm before it histograms the heights, graph.py:633): `pts` host or device, `out` host (capacity n points).
+long long hmsg_voxel_ds(hmsg_ctx* h, const double* pts, long long n, double vs, double* out) {
+    HMSG_REQUIRE(n >= 0 && n < (1ll << 31) && vs > 0, HMSG_ERR_INVALID, "hmsg_voxel_down_sample: bad argument");
+    if (n == 0) return 0;
+    hipStream_t s = h->stream;
+    DevBuf<double> src, dst;
+    src.alloc((size_t)n * 3);
+    dst.alloc((size_t)n * 3);
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof(a));
+    const bool on_dev = hipPointerGetAttributes(&a, pts) == hipSuccess && a.type == hipMemoryTypeDevice;
+    if (!on_dev) (void)hipGetLastError();
+    HIP_TRY(hipMemcpyAsync(src.p, pts, (size_t)n * 24, on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    CloudOps ops;
+    ops.s = s;
+    std::vector<SegDesc> segs(1);
+    segs[0].pt_base = 0;
+    segs[0].n = (int)n;
+    ops.bounds(src.p, segs);
+    std::vector<int> out_n;
+    const long long total = ops.voxel_down_sample(src.p, segs, vs, dst.p, out_n);
+    if (total) HIP_TRY(hipMemcpyAsync(out, dst.p, (size_t)total * 24, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return total;
+}
+

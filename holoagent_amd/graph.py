@@ -331,9 +331,24 @@ class Graph:
         assert len(self.mask_pcds) == len(self.mask_feats)
 
     # ------------------------------------------------------------------ A8: graph.py:624-787
+    def _voxel_down_sample(self, pts, voxel_size):
+        """Open3D voxel_down_sample on the device (a scratch handle when this Graph was not built from a scene)."""
+        if self.scene is not None:
+            return self.scene.voxel_down_sample(pts, voxel_size)
+        from ._lib import Scene
+        tmp = Scene(lib_=self.L, height=8, width=8, max_frames=1, max_masks=1, feat_dim=8)
+        try:
+            return tmp.voxel_down_sample(pts, voxel_size)
+        finally:
+            tmp.close()
+
     def segment_floors_manually(self, path=None):
-        pts = self.full_pcd.points          # already one point per 5 cm voxel (voxel_size 0.05)
-        y = pts[:, 1]
+        pts = self.full_pcd.points
+        # graph.py:633: the map is re-sampled at 5 cm first.  It already holds one centroid per 5 cm voxel, but of a
+        # grid with another origin (the new one hangs off the min bound of the FILTERED cloud), so neighbouring
+        # centroids can fall into one new voxel and get averaged -- the histogram is taken over that cloud.
+        down = self._voxel_down_sample(pts, 0.05)
+        y = down[:, 1]
         bins = int(np.abs(np.max(y) - np.min(y)) / 0.01)
         hist = np.histogram(y, bins=bins)
         smooth = gaussian_filter1d(hist[0], sigma=2)                       # int64 in, int64 out (hazard 17)
@@ -374,9 +389,10 @@ class Graph:
             floors.append([float(hist[1].min()), float(hist[1].max())])
         floors[0][0] = (floors[0][0] + np.min(y)) / 2
         floors[-1][1] = np.max(y)
+        yf = pts[:, 1]                      # the crop is taken from the full cloud (graph.py:769-775)
         for i, (lo, hi) in enumerate(floors):
             fl = Floor(str(i), name="floor_" + str(i))
-            sel = pts[(y >= lo) & (y <= hi)]
+            sel = pts[(yf >= lo) & (yf <= hi)]
             fl.pcd = _Pcd(sel)
             if len(sel):
                 mn, mx = sel.min(0), sel.max(0)

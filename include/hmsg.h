@@ -142,6 +142,13 @@ int hmsg_get_instance_boxes(const hmsg_t* h, double* boxes /*[N][6]: AABB min xy
 int hmsg_pool_instances(hmsg_t* h);
 int hmsg_get_instance_feats(const hmsg_t* h, float* feats /*[N][D]*/);
 
+/* ---- A8 helper: Open3D `PointCloud.voxel_down_sample(voxel_size)` of a caller-supplied cloud, output in ascending
+ * (ix, iy, iz) voxel order.  Replaces `self.full_pcd.voxel_down_sample(voxel_size=0.05)` at the top of
+ * segment_floors / segment_floors_manually (graph.py:496-497, 633), whose height histogram is taken over the
+ * re-sampled cloud.  `points` host or device [n][3]; `out_points` host, capacity n points; *out_n = points written. */
+int hmsg_voxel_down_sample(hmsg_t* h, const double* points, int64_t n, double voxel_size, double* out_points,
+                           int64_t* out_n);
+
 /* ---- A10 first step: every instance through pcd_denoise_dbscan(eps=0.05, min_points=10)
  * (graph.py:1589-1591), in place; call after hmsg_pool_instances like the reference does. */
 int hmsg_denoise_instances(hmsg_t* h, double eps, int32_t min_points);

@@ -14,9 +14,15 @@ from oracle import hmsg_oracle as O
 
 
 class _AABB:
-    def __init__(self, lo, hi):
-        self._lo = np.asarray(lo, dtype=np.float64)
-        self._hi = np.asarray(hi, dtype=np.float64)
+    def __init__(self, lo=None, hi=None, min_bound=None, max_bound=None):
+        self._lo = np.asarray(lo if lo is not None else min_bound, dtype=np.float64)
+        self._hi = np.asarray(hi if hi is not None else max_bound, dtype=np.float64)
+
+    def get_box_points(self):
+        # Open3D AxisAlignedBoundingBox::GetBoxPoints order
+        mn, ex = self._lo, self._hi - self._lo
+        return np.array([mn, mn + [ex[0], 0, 0], mn + [0, ex[1], 0], mn + [0, 0, ex[2]], self._hi,
+                         mn + [0, ex[1], ex[2]], mn + [ex[0], 0, ex[2]], mn + [ex[0], ex[1], 0]])
 
     def get_min_bound(self):
         return self._lo
@@ -81,6 +87,12 @@ class PointCloud:
         if p.shape[0] == 0:
             return _AABB(np.zeros(3), np.zeros(3))
         return _AABB(p.min(axis=0), p.max(axis=0))
+
+    def crop(self, box):
+        # GetPointIndicesWithinBoundingBox: min <= p <= max on every axis
+        p = np.asarray(self.points).reshape(-1, 3)
+        keep = np.all((p >= box.get_min_bound()) & (p <= box.get_max_bound()), axis=1)
+        return self.select_by_index(np.nonzero(keep)[0])
 
     def is_empty(self):
         return len(self.points) == 0

@@ -294,6 +294,66 @@ def gen_query(G, X, out_dir):
     print("query ok", out["ref_obj_idx"][:3])
 
 
+def synth_building_cloud(seed, floors):
+    """A voxel-grid-like cloud of a building: per storey a floor slab, a ceiling slab and four walls on a 5 cm
+    lattice with sub-voxel jitter (what full_pcd looks like after voxel_down_sample + outlier removal)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    pts = []
+    for y0, h, (sx, sz) in floors:
+        xs, zs = np.arange(0.0, sx, 0.05), np.arange(0.0, sz, 0.05)
+        gx, gz = np.meshgrid(xs, zs, indexing="ij")
+        for y in (y0, y0 + h):                                           # slabs
+            pts.append(np.stack([gx.ravel(), np.full(gx.size, y), gz.ravel()], 1))
+        ys = np.arange(y0, y0 + h, 0.05)
+        for x in (0.0, sx):                                              # walls
+            gy, gz2 = np.meshgrid(ys, zs, indexing="ij")
+            pts.append(np.stack([np.full(gy.size, x), gy.ravel(), gz2.ravel()], 1))
+        for z in (0.0, sz):
+            gy, gx2 = np.meshgrid(ys, xs, indexing="ij")
+            pts.append(np.stack([gx2.ravel(), gy.ravel(), np.full(gy.size, z)], 1))
+        # furniture-like clutter at mid height (keeps the histogram from being two clean spikes)
+        n = 1200
+        pts.append(np.stack([rng.uniform(0.3, sx - 0.3, n), rng.uniform(y0 + 0.3, y0 + 1.2, n),
+                             rng.uniform(0.3, sz - 0.3, n)], 1))
+    p = np.concatenate(pts) + rng.uniform(-0.02, 0.02, size=(sum(len(q) for q in pts), 3))
+    return p
+
+
+def gen_floors(G, X, out_dir):
+    """A8: the reference's Graph.segment_floors_manually (graph.py:624-787) on full clouds."""
+    o3d = sys.modules["open3d"]
+    cases = {
+        "one_storey": synth_building_cloud(11, [(0.0, 2.6, (3.0, 2.0))]),
+        "two_storeys": synth_building_cloud(12, [(0.0, 2.7, (3.0, 2.5)), (3.0, 2.6, (3.0, 2.5))]),
+        "three_storeys": synth_building_cloud(13, [(-0.2, 2.5, (2.5, 2.0)), (2.9, 2.6, (2.5, 2.0)), (6.1, 2.4, (2.5, 2.0))]),
+        "tall_gap": synth_building_cloud(14, [(0.0, 2.4, (2.5, 2.0)), (5.5, 2.4, (2.5, 2.0))]),
+    }
+    # ... and the cloud the reference built from frames in the build fixture
+    zb = np.load(os.path.join(out_dir, "build_hier.npz"), allow_pickle=True)
+    cases["fixture_scene"] = np.asarray(zb["ref_cloud"], dtype=np.float64)
+    out = {}
+    for name, pts in cases.items():
+        g = G.Graph.__new__(G.Graph)
+        g.cfg = AttrDict(main=AttrDict(save_path="/tmp/hmsg_golden_tmp"),
+                         pipeline=AttrDict(save_intermediate_results=False))
+        g.graph_tmp_folder = "/tmp/hmsg_golden_tmp"
+        g.floors = []
+        pc = o3d.geometry.PointCloud()
+        pc.points = pts.copy()
+        g.full_pcd = pc
+        ranges = g.segment_floors_manually(None)
+        if name != "fixture_scene":                      # (that cloud is already stored in build_hier.npz)
+            out[name + "_pts"] = pts
+        out[name + "_ranges"] = np.array(ranges, dtype=np.float64).reshape(-1, 2)
+        out[name + "_zero"] = np.array([f.floor_zero_level for f in g.floors], dtype=np.float64)
+        out[name + "_height"] = np.array([f.floor_height for f in g.floors], dtype=np.float64)
+        out[name + "_vertices"] = np.stack([np.asarray(f.vertices) for f in g.floors])
+        out[name + "_npts"] = np.array([len(np.asarray(f.pcd.points)) for f in g.floors], dtype=np.int64)
+        print(name, "floors", out[name + "_ranges"].tolist())
+    out["cases"] = np.array(list(cases.keys()))
+    np.savez_compressed(os.path.join(out_dir, "floors.npz"), **out)
+
+
 def main():
     out_dir = os.path.join(REPO, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
