@@ -208,9 +208,11 @@ class View:    # graph/view.py:36-103
         self.object_ids, self.text_discription, self.img_path = [], [], None
 
     def save(self, path):
-        meta = dict(view_id=self.view_id, room_id=self.room_id, img_id=self.img_id, object_ids=self.object_ids,
-                    img_path=self.img_path, text_discription=self.text_discription)
-        json.dump(meta, open(os.path.join(path, str(self.view_id) + ".json"), "w"))
+        plain = lambda x: int(x) if isinstance(x, np.integer) else x          # view.py:63-71: numpy ids -> int, text -> str
+        meta = dict(view_id=plain(self.view_id), room_id=plain(self.room_id), img_id=plain(self.img_id),
+                    object_ids=[plain(x) for x in self.object_ids], img_path=self.img_path,
+                    text_discription=[str(x) for x in self.text_discription])
+        json.dump(meta, open(os.path.join(path, str(self.view_id) + ".json"), "w", encoding="utf-8"))
 
     def load(self, path):
         m = json.load(open(os.path.join(path, str(self.view_id) + ".json")))

@@ -354,6 +354,154 @@ def gen_floors(G, X, out_dir):
     np.savez_compressed(os.path.join(out_dir, "floors.npz"), **out)
 
 
+def objects_case_inputs(zb):
+    """Rooms + label table used by the A10 fixture (also imported by the test that replays it)."""
+    cloud = np.asarray(zb["ref_cloud"], dtype=np.float64)
+    lo, hi = cloud.min(0), cloud.max(0)
+    xm = lo[0] + 0.55 * (hi[0] - lo[0])                                  # two rooms, split along x, 5 cm vertex grids
+    rooms = []
+    for x0, x1 in ((lo[0], xm), (xm, hi[0])):
+        xs, zs = np.arange(x0, x1, 0.05), np.arange(lo[2], hi[2], 0.05)
+        rooms.append(np.stack(np.meshgrid(xs, zs, indexing="ij"), -1).reshape(-1, 2))
+    D = int(np.asarray(zb["ref_mask_feats"]).shape[1])
+    rng = np.random.Generator(np.random.PCG64(2024))
+    text = rng.standard_normal((9, D)).astype(np.float32)
+    text /= np.linalg.norm(text, axis=1, keepdims=True)
+    classes = ["label%d" % i for i in range(9)]
+    return rooms, text, classes
+
+
+def gen_objects(G, X, out_dir):
+    """A10: the reference's Graph.segment_hmsg_objects (graph.py:1582-1736) on the instances the reference built in
+    the build_seq fixture, with two given rooms (rooms are an input of the path) and no views."""
+    o3d = sys.modules["open3d"]
+    from memory.hmsg.graph.room import Room
+    zb = np.load(os.path.join(out_dir, "build_seq.npz"), allow_pickle=True)
+    rooms, text, classes = objects_case_inputs(zb)
+    G.get_label_feats = lambda *a, **k: (text, classes)
+    g = G.Graph.__new__(G.Graph)
+    g.cfg = AttrDict(main=AttrDict(save_path="/tmp/hmsg_golden_tmp"),
+                     pipeline=AttrDict(save_intermediate_results=False, obj_labels="synthetic"))
+    g.graph_tmp_folder = "/tmp/hmsg_golden_tmp"
+    g.floors, g.rooms, g.objects, g.views = [], [], [], []
+    g.clip_model, g.clip_feat_dim = None, text.shape[1]
+    pc = o3d.geometry.PointCloud()
+    pc.points = np.asarray(zb["ref_cloud"], dtype=np.float64).copy()
+    g.full_pcd = pc
+    g.segment_floors_manually(None)
+    fl = g.floors[0]
+    for k, verts in enumerate(rooms):
+        r = Room("%s_%d" % (fl.floor_id, k), fl.floor_id)
+        r.vertices = verts
+        fl.add_room(r)
+        g.rooms.append(r)
+    off = zb["ref_mask_off"]
+    g.mask_pcds = []
+    for k in range(len(off) - 1):
+        m = o3d.geometry.PointCloud()
+        m.points = np.asarray(zb["ref_mask_pts"][off[k]:off[k + 1]], dtype=np.float64).copy()
+        m.colors = np.zeros_like(m.points)
+        g.mask_pcds.append(m)
+    g.mask_feats = [np.asarray(f) for f in zb["ref_mask_feats"]]
+
+    class DS:
+        def get_camera_intrinsics(self):
+            return np.asarray(zb["K"])
+    g.dataset = DS()
+    g.segment_hmsg_objects()
+    mask_of = []
+    for o in g.objects:                      # which instance became this object (the embedding is the instance's)
+        mask_of.append(next(i for i, f in enumerate(g.mask_feats) if f is o.embedding or np.array_equal(f, o.embedding)))
+    np.savez_compressed(
+        os.path.join(out_dir, "objects.npz"),
+        obj_mask=np.array(mask_of, np.int64),
+        obj_id=np.array([o.object_id for o in g.objects]),
+        obj_room=np.array([o.room_id for o in g.objects]),
+        obj_name=np.array([o.name for o in g.objects]),
+        obj_npts=np.array([len(np.asarray(o.pcd.points)) for o in g.objects], np.int64),
+        denoised_npts=np.array([len(np.asarray(m.points)) for m in g.mask_pcds], np.int64),
+        floor_zero=np.array([f.floor_zero_level for f in g.floors]), floor_height=np.array([f.floor_height for f in g.floors]))
+    print("objects", len(g.objects), "of", len(g.mask_pcds), "instances; rooms",
+          {r.room_id: len(r.objects) for r in g.rooms})
+
+
+def persist_case():
+    """A small graph (1 floor, 2 rooms, 3 objects, 2 views) described with plain data: the A11 fixture builds it
+    with the reference's classes, the test with the mirror's."""
+    rng = np.random.Generator(np.random.PCG64(5))
+    cloud = lambda n: rng.uniform(0.0, 2.0, size=(n, 3))
+    return dict(
+        floor=dict(floor_id="0", name="floor_0", pts=cloud(40), vertices=rng.uniform(0, 3, (8, 3)), height=2.6, zero=-0.02),
+        rooms=[dict(room_id="0_0", name="kitchen", pts=cloud(20), vertices=rng.uniform(0, 3, (30, 2)), height=2.6, zero=-0.02,
+                    embeddings=[rng.standard_normal(8), rng.standard_normal(8)], represent=[3, 7], sample=[1, 3, 7]),
+               dict(room_id="0_1", name=None, pts=cloud(10), vertices=rng.uniform(0, 3, (12, 2)), height=2.6, zero=-0.02,
+                    embeddings=[], represent=[], sample=[])],
+        objects=[dict(object_id="0_0_0", room="0_0", name="chair", pts=cloud(15), embedding=rng.standard_normal(8), views=["0_0_0"], best="0_0_0"),
+                 dict(object_id="0_0_1", room="0_0", name="table", pts=cloud(25), embedding=rng.standard_normal(8).astype(np.float32), views=[], best=None),
+                 dict(object_id="0_1_0", room="0_1", name="lamp", pts=cloud(12), embedding=None, views=["0_1_1"], best="0_1_1")],
+        views=[dict(view_id="0_0_0", room="0_0", img_id=np.int64(3), objects=["0_0_0"], text=["chair"], img_path="rgb/000003.png"),
+               dict(view_id="0_1_1", room="0_1", img_id=7, objects=["0_1_0"], text=["lamp"], img_path=None)])
+
+
+def build_persist_graph(case, Floor, Room, Object, View, make_pcd):
+    """Instantiate `case` with a set of node classes (the reference's or the mirror's); returns (floor, rooms, objects, views)."""
+    fl = Floor(case["floor"]["floor_id"], name=case["floor"]["name"])
+    fl.pcd, fl.vertices = make_pcd(case["floor"]["pts"]), np.asarray(case["floor"]["vertices"])
+    fl.floor_height, fl.floor_zero_level = case["floor"]["height"], case["floor"]["zero"]
+    views = {}
+    for v in case["views"]:
+        o = View(v["view_id"], v["room"], v["img_id"])
+        o.object_ids, o.text_discription, o.img_path = list(v["objects"]), list(v["text"]), v["img_path"]
+        views[v["view_id"]] = o
+    rooms = {}
+    for r in case["rooms"]:
+        o = Room(r["room_id"], fl.floor_id, name=r["name"])
+        o.pcd, o.vertices = make_pcd(r["pts"]), np.asarray(r["vertices"])
+        o.room_height, o.room_zero_level = r["height"], r["zero"]
+        o.embeddings = [np.asarray(e) for e in r["embeddings"]]
+        o.represent_images, o.sample_images = list(r["represent"]), list(r["sample"])
+        o.views = [v for v in views.values() if v.room_id == r["room_id"]]
+        fl.add_room(o)
+        rooms[r["room_id"]] = o
+    objects = []
+    for q in case["objects"]:
+        o = Object(q["object_id"], q["room"])
+        o.name, o.pcd, o.embedding = q["name"], make_pcd(q["pts"]), q["embedding"]
+        o.vertices = np.asarray(q["pts"])[:, [0, 2]]
+        o.view_ids, o.best_view_id = list(q["views"]), q["best"]
+        rooms[q["room"]].add_object(o)
+        objects.append(o)
+    return fl, list(rooms.values()), objects, list(views.values())
+
+
+def gen_persist(G, X, out_dir):
+    """A11: the JSON records the reference's own Floor / Room / Object / View .save() write (floor.py:33-51,
+    room.py:309-333, object.py:37-57, view.py:62-73) for a small graph."""
+    import json
+    import tempfile
+    o3d = sys.modules["open3d"]
+    from memory.hmsg.graph.floor import Floor
+    from memory.hmsg.graph.object import Object
+    from memory.hmsg.graph.room import Room
+    from memory.hmsg.graph.view import View
+
+    def make_pcd(p):
+        pc = o3d.geometry.PointCloud()
+        pc.points = np.asarray(p, dtype=np.float64)
+        return pc
+    fl, rooms, objects, views = build_persist_graph(persist_case(), Floor, Room, Object, View, make_pcd)
+    tmp = tempfile.mkdtemp()
+    records = {}
+    for kind, nodes in (("floors", [fl]), ("rooms", rooms), ("objects", objects), ("views", views)):
+        d = os.path.join(tmp, kind)
+        os.makedirs(d)
+        for n in nodes:
+            n.save(d)
+        records[kind] = {f: json.load(open(os.path.join(d, f))) for f in sorted(os.listdir(d)) if f.endswith(".json")}
+    json.dump(records, open(os.path.join(out_dir, "persist.json"), "w"), indent=0)
+    print("persist records", {k: sorted(v) for k, v in records.items()})
+
+
 def main():
     out_dir = os.path.join(REPO, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)

@@ -1,0 +1,49 @@
+"""A11 (persistence): the JSON records holoagent_amd.graph's Floor / Room / Object / View .save() write against
+the ones the REFERENCE's own classes wrote for the same small graph (tests/golden/persist.json, made by
+oracle/refdrive/gen_golden.py persist): same file names, same keys, same values -- a graph saved by either side
+loads on the other.  Also a save -> load round trip through the mirror."""
+import json
+import os
+
+import numpy as np
+
+from tests import golden_io as GI
+
+
+def _build():
+    from holoagent_amd.graph import Floor, Object, Room, View, _Pcd
+    from oracle.refdrive.gen_golden import build_persist_graph, persist_case
+    return build_persist_graph(persist_case(), Floor, Room, Object, View, lambda p: _Pcd(p))
+
+
+def test_saved_records_match_reference(tmp_path):
+    ref = json.load(open(os.path.join(GI.GOLDEN, "persist.json")))
+    fl, rooms, objects, views = _build()
+    for kind, nodes in (("floors", [fl]), ("rooms", rooms), ("objects", objects), ("views", views)):
+        d = tmp_path / kind
+        d.mkdir()
+        for n in nodes:
+            n.save(str(d))
+        got = {f: json.load(open(d / f)) for f in sorted(os.listdir(d)) if f.endswith(".json")}
+        assert sorted(got) == sorted(ref[kind]), kind
+        for f in got:
+            assert got[f] == ref[kind][f], (kind, f)
+        if kind != "views":                                   # every node with a cloud has its .ply next to the record
+            assert sorted(p for p in os.listdir(d) if p.endswith(".ply")) == [f[:-5] + ".ply" for f in sorted(got)]
+
+
+def test_round_trip(tmp_path):
+    from holoagent_amd.graph import Object, Room
+    fl, rooms, objects, views = _build()
+    for n in rooms + objects:
+        n.save(str(tmp_path))
+    r = Room(rooms[0].room_id, None)
+    r.load_new(str(tmp_path))
+    assert r.name == rooms[0].name and r.floor_id == rooms[0].floor_id
+    np.testing.assert_array_equal(r.vertices, rooms[0].vertices)
+    np.testing.assert_array_equal(r.pcd.points, rooms[0].pcd.points)
+    o = Object(objects[0].object_id, None)
+    o.load_new(str(tmp_path))
+    assert o.room_id == objects[0].room_id and o.name == objects[0].name and o.view_ids == objects[0].view_ids
+    np.testing.assert_array_equal(o.embedding, np.asarray(objects[0].embedding, np.float64))
+    np.testing.assert_array_equal(o.pcd.points, objects[0].pcd.points)
