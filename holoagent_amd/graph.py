@@ -152,7 +152,7 @@ class Room:    # graph/room.py:15-60, 309-374
     def infer_room_type_from_view_embedding(self, default_room_types, text_feats):
         """room.py:131-172: per view arg-max over room-type text features, majority vote, smallest type id on ties."""
         if len(self.embeddings) == 0:
-            return None
+            return "unknown room type"                                     # room.py:153-155 (the name is left as it was)
         votes = np.argmax(np.dot(np.stack(self.embeddings), np.asarray(text_feats).T), axis=1)
         cnt = np.bincount(votes, minlength=len(default_room_types))
         self.name = default_room_types[int(np.argmax(cnt))]

@@ -502,6 +502,29 @@ def gen_persist(G, X, out_dir):
     print("persist records", {k: sorted(v) for k, v in records.items()})
 
 
+def gen_roomnames(G, X, out_dir):
+    """A12 helper: Room.infer_room_type_from_view_embedding (room.py:131-172) -- per view arg-max over the room-type
+    text features, majority vote (np.unique order on ties), "unknown room type" without embeddings."""
+    import memory.hmsg.graph.room as R
+    rng = np.random.Generator(np.random.PCG64(31))
+    D, types = 16, ["kitchen", "office", "bedroom", "corridor", "bathroom"]
+    text = rng.standard_normal((len(types), D))
+    text /= np.linalg.norm(text, axis=1, keepdims=True)
+    R.get_text_feats_multiple_templates = lambda names, model, dim: text
+    embs, names = [], []
+    for k in (0, 1, 2, 5, 6, 9):
+        e = rng.standard_normal((k, D))
+        if k == 6:                      # a 3:3 tie between two types (lower type id wins through np.unique)
+            e = np.concatenate([np.tile(text[3], (3, 1)), np.tile(text[1], (3, 1))]) + 0.01 * rng.standard_normal((6, D))
+        room = R.Room("0_%d" % len(embs), "0")
+        room.embeddings = [v for v in e]
+        names.append(room.infer_room_type_from_view_embedding(types, None, D))
+        embs.append(e)
+    np.savez_compressed(os.path.join(out_dir, "roomnames.npz"), text=text, types=np.array(types), names=np.array(names),
+                        counts=np.array([len(e) for e in embs]), embs=np.concatenate(embs))
+    print("room names", names)
+
+
 def main():
     out_dir = os.path.join(REPO, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)

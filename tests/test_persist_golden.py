@@ -47,3 +47,16 @@ def test_round_trip(tmp_path):
     assert o.room_id == objects[0].room_id and o.name == objects[0].name and o.view_ids == objects[0].view_ids
     np.testing.assert_array_equal(o.embedding, np.asarray(objects[0].embedding, np.float64))
     np.testing.assert_array_equal(o.pcd.points, objects[0].pcd.points)
+
+
+def test_room_type_votes_match_reference():
+    """Room.infer_room_type_from_view_embedding against the reference's own (room.py:131-172; tests/golden/roomnames.npz):
+    per-view arg-max, majority vote with np.unique's tie order, "unknown room type" for a room without views."""
+    from holoagent_amd.graph import Room
+    z = GI.load("roomnames")
+    types = [str(t) for t in z["types"]]
+    off = np.concatenate([[0], np.cumsum(z["counts"])])
+    for k, ref in enumerate(z["names"]):
+        room = Room("0_%d" % k, "0")
+        room.embeddings = [e for e in z["embs"][off[k]:off[k + 1]]]
+        assert room.infer_room_type_from_view_embedding(types, z["text"]) == str(ref)
