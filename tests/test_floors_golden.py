@@ -39,3 +39,36 @@ def test_floors_match_reference_simulator():
 def test_floors_match_reference_gpu():
     from holoagent_amd._lib import HmsgLib
     _check(HmsgLib())
+
+
+def _check_vds(L):
+    """hmsg_voxel_down_sample against the oracle's Open3D restatement on a cloud whose grid spans many scan tiles:
+    same voxel set and order, centroids to 1e-12 (fixed-point sums), single-point voxels bit for bit."""
+    from holoagent_amd._lib import Scene
+    from oracle import hmsg_oracle as O
+    rng = np.random.Generator(np.random.PCG64(8))
+    pts = np.concatenate([rng.uniform(-4.0, 6.0, size=(60000, 3)),                 # sparse: mostly one point per voxel
+                          rng.normal(0.0, 0.15, size=(40000, 3)) + [1.0, 0.5, -2.0]])  # dense blob: many per voxel
+    sc = Scene(lib_=L, height=8, width=8, max_frames=1, max_masks=1, feat_dim=8)
+    got = sc.voxel_down_sample(pts, 0.05)
+    sc.close()
+    ref, _, _, _ = O.o3d_voxel_down_sample(pts, None, 0.05)
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12)
+    idx, _ = O.o3d_voxel_keys(pts, 0.05)
+    dims = idx.max(axis=0) + 1
+    _, counts = np.unique((idx[:, 0] * dims[1] + idx[:, 1]) * dims[2] + idx[:, 2], return_counts=True)   # canonical order
+    single = counts == 1
+    assert single.sum() > 1000 and (~single).sum() > 1000 and np.array_equal(got[single], ref[single])
+
+
+@pytest.mark.skipif(not os.path.exists(PC.EMU_PATH), reason="kernel simulator not built")
+def test_voxel_down_sample_simulator():
+    from holoagent_amd._lib import HmsgLib
+    _check_vds(HmsgLib(PC.EMU_PATH))
+
+
+@pytest.mark.gpu
+def test_voxel_down_sample_gpu():
+    from holoagent_amd._lib import HmsgLib
+    _check_vds(HmsgLib())
