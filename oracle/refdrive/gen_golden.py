@@ -290,8 +290,27 @@ def gen_query(G, X, out_dir):
     out.update(ref_obj_idx=np.array(res_idx), ref_obj_room=np.array(res_room), ref_obj_score=np.array(res_score),
                ref_rooms_label=np.array(res_rooms_label), ref_rooms_view=np.array(res_rooms_view),
                qspec=np.array(qspec), ref_neg_idx=np.array(oi), ref_neg_room=np.array(ri), ref_neg_score=np.array(sc))
+    # the driver (graph.py:3483-3591) with the LLM parse replaced by a fixed (floor, room, object) triple
+    triples = {
+        "go to thing3 in room2 on floor 2": ("2", "room2", "thing3"),
+        "find thing7 in room5": (None, "room5", "thing7"),
+        "thing11 in the Exhibition room1 on floor 1": ("1", "Exhibition room1", "thing11"),
+        "thing1 somewhere in room0 on floor 0": ("floor 0", "room0", "thing1"),
+    }
+    table["Exhibition room1"] = table["room1"]
+    G.parse_hier_query_use_prompt_insentence_parse_icra = lambda cfg, instr: triples[instr]
+    g.cfg = None
+    drv = []
+    for instr in triples:
+        fl, rooms, objs, res = g.query_hierarchy_protected_icra(instr, top_k=3, use_gpt=False)
+        drv.append(dict(instruction=instr, triple=list(triples[instr]), floor=None if fl is None else fl.floor_id,
+                        rooms=[r.room_id for r in rooms], objects=[o.object_id for o in objs],
+                        object_index=[g.objects.index(o) for o in objs], negative_labels=res["negative_labels"]))
+    import json
+    out["driver_json"] = np.array(json.dumps(drv))
     np.savez_compressed(os.path.join(out_dir, "query.npz"), **out)
     print("query ok", out["ref_obj_idx"][:3])
+    print("driver", drv)
 
 
 def synth_building_cloud(seed, floors):
