@@ -115,6 +115,31 @@ def _read_ply(path):
     return np.stack([arr["x"], arr["y"], arr["z"]], axis=1).astype(np.float64)
 
 
+def _box_points(pts):
+    """Open3D AxisAlignedBoundingBox::GetBoxPoints order of the AABB of `pts`."""
+    mn, mx = pts.min(0), pts.max(0)
+    ex = mx - mn
+    return np.array([mn, mn + [ex[0], 0, 0], mn + [0, ex[1], 0], mn + [0, 0, ex[2]], mx,
+                     mn + [0, ex[1], ex[2]], mn + [ex[0], 0, ex[2]], mn + [ex[0], ex[1], 0]])
+
+
+def find_overlapping_ratio_faiss(p1, p2, radius=0.02):
+    """utils/graph_utils.py:620-664 (faiss IndexFlatL2, k=1): fraction of points whose exact float32 nearest
+    neighbour in the other cloud is closer than radius (float32 `(dx*dx + dy*dy) + dz*dz < radius**2`), max over
+    both directions.  Host version for the few-hundred-point object clouds of Room.merge_objects."""
+    p1, p2 = np.asarray(getattr(p1, "points", p1)), np.asarray(getattr(p2, "points", p2))
+    if p1.shape[0] == 0 or p2.shape[0] == 0:
+        return 0
+    a, b = p1.astype(np.float32), p2.astype(np.float32)
+
+    def nn_d2(q, base):
+        _, nn = cKDTree(base.astype(np.float64)).query(q.astype(np.float64), k=1, workers=-1)
+        d = q - base[nn]
+        return (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+    r2 = np.float32(radius ** 2)
+    return np.max([np.sum(nn_d2(a, b) < r2) / a.shape[0], np.sum(nn_d2(b, a) < r2) / b.shape[0]])
+
+
 class Floor:   # graph/floor.py:10-67
     def __init__(self, floor_id, name=None):
         self.floor_id, self.name = floor_id, name
@@ -148,6 +173,50 @@ class Room:    # graph/room.py:15-60, 309-374
 
     def add_object(self, obj):
         self.objects.append(obj)
+
+    def merge_objects(self, overlap_threshold=0.01, radius=0.1):
+        """room.py:62-129: fuse same-name objects of the room whose clouds overlap, then re-number the objects.
+        Follows the reference step by step (including what its dictionary bookkeeping does with chains)."""
+        n = len(self.objects)
+        scores = np.zeros((n, n))
+        for i in range(n):
+            for j in range(i + 1, n):
+                if self.objects[i].name == self.objects[j].name:
+                    ov = find_overlapping_ratio_faiss(self.objects[i].pcd, self.objects[j].pcd, radius)
+                    if ov > overlap_threshold:
+                        scores[i, j] = scores[j, i] = ov
+        groups: dict = {}
+        merging = []
+        for i, j in zip(*np.where(scores > 0)):
+            i, j = int(i), int(j)
+            merging.extend([i, j])
+            if i not in groups and j not in groups:
+                groups.setdefault(i, []).append(j)
+            elif i in groups:
+                groups[i].append(j)
+            elif j in groups:
+                groups[j].append(i)
+        merging = set(merging)
+        for idx in range(n):
+            if idx not in merging:
+                groups.setdefault(idx, []).append(idx)
+        new_objects, counter = [], 0
+        for i, js in groups.items():
+            js = list(set(js))
+            if len(js) == 1:
+                jj = js[0]
+                obj = self.objects[i] if i == jj else self.objects[i] + self.objects[jj]
+                obj.object_id = self.room_id + "_" + str(counter)
+                new_objects.append(obj)
+                counter += 1
+            elif len(js) > 1:
+                obj = self.objects[i]
+                for jj in js:
+                    obj = obj + self.objects[jj]
+                    obj.object_id = self.room_id + "_" + str(counter)
+                new_objects.append(obj)
+                counter += 1
+        self.objects = new_objects
 
     def infer_room_type_from_view_embedding(self, default_room_types, text_feats):
         """room.py:131-172: per view arg-max over room-type text features, majority vote, smallest type id on ties."""
@@ -185,6 +254,18 @@ class Object:  # graph/object.py:9-106
         self.object_id, self.room_id, self.name = object_id, room_id, name
         self.pcd, self.vertices, self.embedding = _Pcd(), None, None
         self.view_ids, self.best_view_id = [], None
+
+    def __add__(self, other):
+        """object.py:93-103: an empty side yields the other object; otherwise the clouds are concatenated in place,
+        vertices become the 8 AABB corners and the embedding the mean of the two."""
+        if self.pcd.is_empty():
+            return other
+        if other.pcd.is_empty():
+            return self
+        self.pcd = _Pcd(np.concatenate([np.asarray(self.pcd.points).reshape(-1, 3), np.asarray(other.pcd.points).reshape(-1, 3)]))
+        self.vertices = _box_points(self.pcd.points)
+        self.embedding = np.mean([self.embedding, other.embedding], axis=0)
+        return self
 
     def save(self, path):
         _write_ply(os.path.join(path, str(self.object_id) + ".ply"), self.pcd.points)
@@ -498,6 +579,11 @@ class Graph:
         if rooms is not None:
             self.set_rooms(rooms)
         self.segment_hmsg_objects(save_path)
+        if _get(self.cfg, "pipeline.merge_objects_graph", False):          # graph.py:2053-2058 (false in every shipped config)
+            for room in self.rooms:
+                room.merge_objects()
+            self.objects = [o for room in self.rooms for o in room.objects]
+            self._index = None
         if save_path is not None:
             self.save_hmsg_graph(os.path.join(save_path, "graph"))
 

@@ -544,6 +544,47 @@ def gen_roomnames(G, X, out_dir):
     print("room names", names)
 
 
+def mergeobj_case():
+    """Objects of one room for Room.merge_objects (room.py:62-129): (name, points, embedding).  Boxes of 4 cm
+    lattice points; the x offsets decide which same-name objects overlap within 10 cm."""
+    rng = np.random.Generator(np.random.PCG64(77))
+
+    def box(x0, n=6):
+        g = np.stack(np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij"), -1).reshape(-1, 3) * 0.04
+        return g + [x0, 0.0, 0.0] + rng.uniform(-0.005, 0.005, size=g.shape)
+    specs = [("chair", box(0.00)), ("chair", box(0.15)), ("table", box(0.05)), ("chair", box(2.00)),
+             ("lamp", box(3.00)), ("lamp", box(3.12)), ("lamp", box(3.24)), ("shelf", np.zeros((0, 3))),
+             ("shelf", box(5.00)), ("table", box(6.00))]
+    return [(n, p, rng.standard_normal(8)) for n, p in specs]
+
+
+def gen_mergeobjects(G, X, out_dir):
+    """N2: the reference's Room.merge_objects (same-name fusion, room.py:62-129; Object.__add__ object.py:93-103)."""
+    o3d = sys.modules["open3d"]
+    from memory.hmsg.graph.object import Object
+    from memory.hmsg.graph.room import Room
+    room = Room("0_3", "0")
+    case = mergeobj_case()
+    for k, (name, pts, emb) in enumerate(case):
+        o = Object("0_3_%d" % k, "0_3")
+        o.name = name
+        pc = o3d.geometry.PointCloud()
+        pc.points = pts.copy()
+        o.pcd, o.embedding = pc, emb.copy()
+        o.vertices = pts[:, [0, 2]].copy()
+        room.add_object(o)
+    room.merge_objects()
+    out = dict(n=np.array(len(room.objects)), ids=np.array([o.object_id for o in room.objects]),
+               names=np.array([o.name for o in room.objects]),
+               npts=np.array([len(np.asarray(o.pcd.points)) for o in room.objects], np.int64),
+               emb=np.stack([np.asarray(o.embedding, np.float64) for o in room.objects]),
+               pts=np.concatenate([np.asarray(o.pcd.points).reshape(-1, 3) for o in room.objects]))
+    for k, o in enumerate(room.objects):
+        out["vertices_%d" % k] = np.asarray(o.vertices, np.float64)
+    np.savez_compressed(os.path.join(out_dir, "mergeobjects.npz"), **out)
+    print("merged", len(case), "->", len(room.objects), out["ids"].tolist(), out["names"].tolist(), out["npts"].tolist())
+
+
 def main():
     out_dir = os.path.join(REPO, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)

@@ -60,3 +60,26 @@ def test_room_type_votes_match_reference():
         room = Room("0_%d" % k, "0")
         room.embeddings = [e for e in z["embs"][off[k]:off[k + 1]]]
         assert room.infer_room_type_from_view_embedding(types, z["text"]) == str(ref)
+
+
+def test_merge_objects_matches_reference():
+    """Room.merge_objects (same-name fusion, optional post-pass of build_hier_multimodal_scene_graph) against the
+    reference's own room.py:62-129 / object.py:93-103 on ten objects with pairs, a chain, an empty cloud and
+    look-alikes of another name (tests/golden/mergeobjects.npz): ids, names, clouds, embeddings, vertices."""
+    from holoagent_amd.graph import Object, Room, _Pcd
+    from oracle.refdrive.gen_golden import mergeobj_case
+    z = GI.load("mergeobjects")
+    room = Room("0_3", "0")
+    for k, (name, pts, emb) in enumerate(mergeobj_case()):
+        o = Object("0_3_%d" % k, "0_3", name=name)
+        o.pcd, o.embedding, o.vertices = _Pcd(pts.copy()), emb.copy(), pts[:, [0, 2]].copy()
+        room.add_object(o)
+    room.merge_objects()
+    assert len(room.objects) == int(z["n"])
+    assert [o.object_id for o in room.objects] == [str(v) for v in z["ids"]]
+    assert [o.name for o in room.objects] == [str(v) for v in z["names"]]
+    assert [len(o.pcd.points) for o in room.objects] == z["npts"].tolist()
+    np.testing.assert_array_equal(np.concatenate([np.asarray(o.pcd.points).reshape(-1, 3) for o in room.objects]), z["pts"])
+    np.testing.assert_allclose(np.stack([np.asarray(o.embedding, np.float64) for o in room.objects]), z["emb"], rtol=0, atol=1e-15)
+    for k, o in enumerate(room.objects):
+        np.testing.assert_allclose(np.asarray(o.vertices, np.float64), z["vertices_%d" % k], rtol=0, atol=1e-15)
