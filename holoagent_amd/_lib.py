@@ -53,7 +53,8 @@ _SIGS = {
     "hmsg_map_size": (C.c_int64, [_P]),
     "hmsg_map_size_unfiltered": (C.c_int64, [_P]),
     "hmsg_get_map_points": (C.c_int, [_P, _P, _P]),
-    "hmsg_add_frame_features": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    "hmsg_add_frame_features": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
+    "hmsg_get_frame_num_masks": (C.c_int32, [_P, C.c_int32]),
     "hmsg_fuse_frames": (C.c_int, [_P]),
     "hmsg_get_map_feats": (C.c_int, [_P, _P, _P]),
     "hmsg_get_frame_nn": (C.c_int, [_P, C.c_int32, _P]),
@@ -75,6 +76,7 @@ _SIGS = {
     "hmsg_index_last_error": (C.c_char_p, [_P]),
     "hmsg_query_objects": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     "hmsg_similarity": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "hmsg_test_sort_pairs": (C.c_int, [_P, _P, C.c_int64, C.c_int32]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 
@@ -199,10 +201,16 @@ class Scene:
         self._ck(self.L.c.hmsg_get_map_points(self.h, _ptr(xyz), _ptr(rgb)))
         return (xyz, rgb) if colors else xyz
 
-    def add_frame_features(self, first, masks, f_g, f_masked, f_crop):
+    def add_frame_features(self, first, masks, f_g, f_masked, f_crop, n_masks=None):
+        """masks u8 [n, M, H, W], f_g [n, D], f_masked / f_crop [n, M, D]; n_masks i32 [n] = real masks per frame
+        (rows beyond it are padding), None = M for all."""
         n, M = int(f_masked.shape[0]), int(f_masked.shape[1])
-        self._ck(self.L.c.hmsg_add_frame_features(self.h, first, n, M, _ptr(masks), _ptr(f_g), _ptr(f_masked), _ptr(f_crop)))
-        self.M = M
+        nm = None if n_masks is None else np.ascontiguousarray(n_masks, dtype=np.int32)
+        self._ck(self.L.c.hmsg_add_frame_features(self.h, first, n, M, _ptr(masks), _ptr(f_g), _ptr(f_masked), _ptr(f_crop),
+                                                  _ptr(nm)))
+
+    def frame_num_masks(self, frame):
+        return int(self.L.c.hmsg_get_frame_num_masks(self.h, frame))
 
     def fuse_frames(self):
         self._ck(self.L.c.hmsg_fuse_frames(self.h))
@@ -220,18 +228,19 @@ class Scene:
         return idx
 
     def frame_fp(self, frame):
-        out = np.empty((self.M, self.cfg.feat_dim), np.float32)
+        out = np.empty((self.frame_num_masks(frame), self.cfg.feat_dim), np.float32)
         self._ck(self.L.c.hmsg_get_frame_fp(self.h, frame, _ptr(out)))
         return out
 
     def frame_masks3d(self, frame):
-        sizes = np.empty((self.M,), np.int64)
+        M = self.frame_num_masks(frame)
+        sizes = np.empty((M,), np.int64)
         self._ck(self.L.c.hmsg_get_frame_mask_sizes(self.h, frame, _ptr(sizes)))
         pts = np.empty((int(sizes.sum()), 3), np.float64)
         if pts.shape[0]:
             self._ck(self.L.c.hmsg_get_frame_mask_points(self.h, frame, _ptr(pts)))
         off = np.concatenate([[0], np.cumsum(sizes)])
-        return [pts[off[i]:off[i + 1]] for i in range(self.M)]
+        return [pts[off[i]:off[i + 1]] for i in range(M)]
 
     def merge_instances(self):
         self._ck(self.L.c.hmsg_merge_instances(self.h))

@@ -5,7 +5,7 @@
 #include <cstring>
 
 void hmsg_bitset_and_fp(hmsg_ctx* h, int first, int n, int M, const unsigned char* d_masks, const float* d_fg,
-                        const float* d_fm, const float* d_fc);   // hmsg_fuse.hip
+                        const float* d_fm, const float* d_fc, const int* d_nmask);   // hmsg_fuse.hip
 
 namespace {
 
@@ -53,7 +53,7 @@ void hmsg_default_config(hmsg_config* c) {
     c->height = 480;
     c->width = 640;
     c->max_frames = 1024;
-    c->max_masks = 64;
+    c->max_masks = 64;       /* up to 256 (SAM points_per_side=12 yields at most 144) */
     c->voxel_size = 0.05;
     c->depth_scale = 1000.0;
     c->init_overlap_thresh = 0.75;
@@ -76,10 +76,12 @@ int hmsg_create(const hmsg_config* cfg, hmsg_t** out) {
     if (!cfg || !out) return HMSG_ERR_INVALID;
     *out = nullptr;
     if (cfg->feat_dim <= 0 || cfg->height <= 0 || cfg->width <= 0 || cfg->max_frames <= 0 || cfg->voxel_size <= 0 ||
-        cfg->max_masks <= 0 || cfg->max_masks > 64)
+        cfg->max_masks <= 0 || cfg->max_masks > 256)
         return HMSG_ERR_INVALID;
     hmsg_ctx* h = new hmsg_ctx();
     h->cfg = *cfg;
+    h->NW = (cfg->max_masks + 63) / 64;
+    h->MS = h->NW * 64;
     int rc = guard(h, [&] {
         int ndev = 0;
         HIP_TRY(hipGetDeviceCount(&ndev));
@@ -119,7 +121,8 @@ int hmsg_reset(hmsg_t* h) {
     return guard(h, [&] {
         HIP_TRY(hipStreamSynchronize(h->stream));
         h->n_frames = h->n_feat_frames = h->n_fused = 0;
-        h->M = 0;
+        h->nmask.clear();
+        h->mask_first.clear();
         h->have_K = false;
         h->map_ready = h->feats_final = h->merged = h->pooled = false;
         h->V = h->V0 = 0;
@@ -229,19 +232,40 @@ int hmsg_get_map_points(const hmsg_t* hc, double* xyz, double* rgb) {
 }
 
 int hmsg_add_frame_features(hmsg_t* h, int32_t first, int32_t n, int32_t M, const uint8_t* masks, const float* F_g,
-                            const float* F_masked, const float* F_crop) {
+                            const float* F_masked, const float* F_crop, const int32_t* n_masks) {
     if (!h) return HMSG_ERR_INVALID;
     return guard(h, [&] {
-        HMSG_REQUIRE(n >= 0 && masks && F_g && F_masked && F_crop, HMSG_ERR_INVALID, "hmsg_add_frame_features: null argument");
-        HMSG_REQUIRE(M > 0 && M <= h->cfg.max_masks, HMSG_ERR_INVALID, "M out of range (cfg.max_masks, <= 64)");
+        HMSG_REQUIRE(n >= 0 && F_g, HMSG_ERR_INVALID, "hmsg_add_frame_features: null argument");
+        HMSG_REQUIRE(M >= 0 && M <= h->cfg.max_masks, HMSG_ERR_INVALID, "M out of range (cfg.max_masks, <= 256)");
+        HMSG_REQUIRE(M == 0 || (masks && F_masked && F_crop), HMSG_ERR_INVALID, "hmsg_add_frame_features: null argument");
         HMSG_REQUIRE(first == h->n_feat_frames, HMSG_ERR_INVALID, "frames must be handed over in order (first == #frames so far)");
         HMSG_REQUIRE(first + n <= h->n_frames, HMSG_ERR_INVALID, "features for a frame without geometry");
-        HMSG_REQUIRE(h->M == 0 || h->M == M, HMSG_ERR_UNSUPPORTED, "M must be the same for all frames (pad with empty masks)");
-        h->M = M;
+        if (n == 0) return;
         const size_t HW = (size_t)h->cfg.height * h->cfg.width;
         const int D = h->cfg.feat_dim;
-        if (h->bits.n < (size_t)h->cfg.max_frames * HW) h->bits.alloc((size_t)h->cfg.max_frames * HW);
-        if (h->fp.n < (size_t)h->cfg.max_frames * M * D) h->fp.alloc((size_t)h->cfg.max_frames * M * D);
+        const size_t NW = (size_t)h->NW, MS = (size_t)h->MS;
+        if (h->bits.n < (size_t)h->cfg.max_frames * HW * NW) h->bits.alloc((size_t)h->cfg.max_frames * HW * NW);
+        if (h->fp.n < (size_t)h->cfg.max_frames * MS * D) h->fp.alloc((size_t)h->cfg.max_frames * MS * D);
+        // per-frame mask counts (host copy kept: the 3-D mask store holds nmask[f] clouds for frame f)
+        std::vector<int> nm((size_t)n, M);
+        if (n_masks) {
+            if (is_device_ptr(n_masks)) {
+                HIP_TRY(hipMemcpy(nm.data(), n_masks, (size_t)n * 4, hipMemcpyDeviceToHost));
+            } else {
+                memcpy(nm.data(), n_masks, (size_t)n * 4);
+            }
+            for (int v : nm) HMSG_REQUIRE(v >= 0 && v <= M, HMSG_ERR_INVALID, "n_masks[f] must be in [0, M]");
+        }
+        DevBuf<int> d_nm;
+        d_nm.alloc((size_t)n);
+        HIP_TRY(hipMemcpyAsync(d_nm.p, nm.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+        if (M == 0) {   // no mask in any of these frames: empty bitsets, no F_p rows
+            HIP_TRY(hipMemsetAsync(h->bits.p + (size_t)first * HW * NW, 0, (size_t)n * HW * NW * 8, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            h->nmask.insert(h->nmask.end(), nm.begin(), nm.end());
+            h->n_feat_frames += n;
+            return;
+        }
         const bool dev = is_device_ptr(masks);
         const int chunk = dev ? n : std::max(1, (int)(((size_t)512 << 20) / ((size_t)M * HW)));
         DevBuf<unsigned char> st_m;
@@ -267,9 +291,10 @@ int hmsg_add_frame_features(hmsg_t* h, int32_t first, int32_t n, int32_t M, cons
                 dfm = fm;
                 dfc = fc;
             }
-            hmsg_bitset_and_fp(h, first + c0, nc, M, dm, dg, dfm, dfc);
+            hmsg_bitset_and_fp(h, first + c0, nc, M, dm, dg, dfm, dfc, d_nm.p + c0);
             HIP_TRY(hipStreamSynchronize(h->stream));
         }
+        h->nmask.insert(h->nmask.end(), nm.begin(), nm.end());
         h->n_feat_frames += n;
     });
 }
@@ -308,9 +333,13 @@ int hmsg_get_frame_fp(const hmsg_t* hc, int32_t frame, float* f_p) {
     if (!h) return HMSG_ERR_INVALID;
     return guard(h, [&] {
         HMSG_REQUIRE(frame >= 0 && frame < h->n_feat_frames && f_p, HMSG_ERR_INVALID, "frame has no features");
-        size_t n = (size_t)h->M * h->cfg.feat_dim;
-        HIP_TRY(hipMemcpy(f_p, h->fp.p + (size_t)frame * n, n * 4, hipMemcpyDeviceToHost));
+        const size_t D = (size_t)h->cfg.feat_dim, n = (size_t)h->nmask[frame] * D;
+        if (n) HIP_TRY(hipMemcpy(f_p, h->fp.p + (size_t)frame * h->MS * D, n * 4, hipMemcpyDeviceToHost));
     });
+}
+
+int32_t hmsg_get_frame_num_masks(const hmsg_t* h, int32_t frame) {
+    return (h && frame >= 0 && frame < h->n_feat_frames) ? h->nmask[frame] : -1;
 }
 
 int hmsg_get_frame_mask_sizes(const hmsg_t* hc, int32_t frame, int64_t* sizes) {
@@ -318,8 +347,8 @@ int hmsg_get_frame_mask_sizes(const hmsg_t* hc, int32_t frame, int64_t* sizes) {
     if (!h) return HMSG_ERR_INVALID;
     return guard(h, [&] {
         HMSG_REQUIRE(frame >= 0 && frame < h->n_fused && sizes, HMSG_ERR_INVALID, "frame not fused");
-        for (int i = 0; i < h->M; ++i) {
-            size_t k = (size_t)frame * h->M + i;
+        for (int i = 0; i < h->nmask[frame]; ++i) {
+            size_t k = (size_t)h->mask_first[frame] + i;
             sizes[i] = h->masks3d.off[k + 1] - h->masks3d.off[k];
         }
     });
@@ -330,7 +359,7 @@ int hmsg_get_frame_mask_points(const hmsg_t* hc, int32_t frame, double* xyz) {
     if (!h) return HMSG_ERR_INVALID;
     return guard(h, [&] {
         HMSG_REQUIRE(frame >= 0 && frame < h->n_fused && xyz, HMSG_ERR_INVALID, "frame not fused");
-        long long a = h->masks3d.off[(size_t)frame * h->M], b = h->masks3d.off[(size_t)(frame + 1) * h->M];
+        long long a = h->masks3d.off[(size_t)h->mask_first[frame]], b = h->masks3d.off[(size_t)h->mask_first[frame + 1]];
         if (b > a) HIP_TRY(hipMemcpy(xyz, h->masks3d.pts.p + (size_t)a * 3, (size_t)(b - a) * 24, hipMemcpyDeviceToHost));
     });
 }

@@ -40,8 +40,8 @@ struct CloudOps {
     DevBuf<char> geom;           // device copy of per-segment geometry tables
     DevBuf<unsigned long long> vbitmap;
     DevBuf<unsigned> vrank;
-    DevBuf<long long> vacc;
-    DevBuf<unsigned> vwgt, vany;
+    SortBufs vsort;              // ordered voxel sums: (slot, point index) records
+    DevBuf<unsigned> voff;
 
     // fill segs[k].mn / mx from the points (device reduction, one sync)
     void bounds(const double* src, std::vector<SegDesc>& segs);

@@ -1021,8 +1021,6 @@ struct VxSeg {
     int nx, ny, nz, n;
     long long word_base, pt_base;
 };
-#define VFIX 70368744177664.0 /* 2^46 (unit weights) */
-
 __device__ __forceinline__ long long vx_cell(const VxSeg& g, double vs, const double* __restrict__ p, int& ix, int& iy, int& iz) {
     ix = (int)floor(__ddiv_rn(__dsub_rn(p[0], g.ox), vs));
     iy = (int)floor(__ddiv_rn(__dsub_rn(p[1], g.oy), vs));
@@ -1039,62 +1037,38 @@ __global__ void k_vx_mark(const double* __restrict__ pts, const VxSeg* __restric
         atomicOr(&bitmap[g.word_base + (lin >> 6)], 1ull << (lin & 63));
     }
 }
-__global__ void k_vx_accum(const double* __restrict__ pts, const VxSeg* __restrict__ segs, double vs,
-                           const unsigned long long* __restrict__ bitmap, const unsigned* __restrict__ rank,
-                           long long* __restrict__ acc /*[3][P]*/, long long P, unsigned* __restrict__ wgt,
-                           unsigned* __restrict__ anyidx) {
+// sort key of every point = slot of its voxel (value = the point's index: the stable sort keeps input order)
+__global__ void k_vx_keys(const double* __restrict__ pts, const VxSeg* __restrict__ segs, double vs,
+                          const unsigned long long* __restrict__ bitmap, const unsigned* __restrict__ rank,
+                          unsigned* __restrict__ keys, unsigned long long* __restrict__ vals) {
     const VxSeg g = segs[blockIdx.y];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += gridDim.x * blockDim.x) {
         const double* p = pts + (size_t)(g.pt_base + i) * 3;
         int ix, iy, iz;
         long long lin = vx_cell(g, vs, p, ix, iy, iz);
         long long wd = g.word_base + (lin >> 6);
-        unsigned slot = rank[wd] + (unsigned)__popcll(bitmap[wd] & ((1ull << (lin & 63)) - 1ull));
-        double cx = __dadd_rn(g.ox, __dmul_rn((double)ix, vs)), cy = __dadd_rn(g.oy, __dmul_rn((double)iy, vs)),
-               cz = __dadd_rn(g.oz, __dmul_rn((double)iz, vs));
-        atomicAdd((unsigned long long*)&acc[slot], (unsigned long long)llrint((p[0] - cx) * VFIX));
-        atomicAdd((unsigned long long*)&acc[P + slot], (unsigned long long)llrint((p[1] - cy) * VFIX));
-        atomicAdd((unsigned long long*)&acc[2 * P + slot], (unsigned long long)llrint((p[2] - cz) * VFIX));
-        atomicAdd(&wgt[slot], 1u);
-        anyidx[slot] = (unsigned)(g.pt_base + i);     // (only read for voxels that hold a single point)
+        keys[g.pt_base + i] = rank[wd] + (unsigned)__popcll(bitmap[wd] & ((1ull << (lin & 63)) - 1ull));
+        vals[g.pt_base + i] = (unsigned long long)(g.pt_base + i);
     }
 }
-__global__ void k_vx_final(const unsigned long long* __restrict__ bitmap, const unsigned* __restrict__ rank, long long nwords,
-                           const VxSeg* __restrict__ segs, int K, double vs, const long long* __restrict__ acc, long long P,
-                           const unsigned* __restrict__ wgt, double* __restrict__ out, const double* __restrict__ pts,
-                           const unsigned* __restrict__ anyidx) {
-    long long wd = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (wd >= nwords) return;
-    unsigned long long bw = bitmap[wd];
-    if (!bw) return;
-    int lo = 0, hi = K - 1;
-    while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (segs[mid].word_base <= wd) lo = mid; else hi = mid - 1;
+// one lane per voxel: sequential float64 sum of its points in input order, / count (Open3D VoxelDownSample,
+// o3d_voxel_down_sample in the oracle)
+__global__ void k_vx_walk(const unsigned* __restrict__ off, const unsigned long long* __restrict__ idx, long long P,
+                          const double* __restrict__ pts, double* __restrict__ out) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= P) return;
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    const unsigned a = off[s], b = off[s + 1];
+    for (unsigned r = a; r < b; ++r) {
+        const double* p = pts + (size_t)idx[r] * 3;
+        sx = __dadd_rn(sx, p[0]);
+        sy = __dadd_rn(sy, p[1]);
+        sz = __dadd_rn(sz, p[2]);
     }
-    const VxSeg g = segs[lo];
-    unsigned sidx = rank[wd];
-    while (bw) {
-        int b = __ffsll(bw) - 1;
-        bw &= bw - 1;
-        long long lin = (wd - g.word_base) * 64 + b;
-        int iz = (int)(lin % g.nz);
-        long long r = lin / g.nz;
-        int iy = (int)(r % g.ny), ix = (int)(r / g.ny);
-        if (wgt[sidx] == 1u) {
-            // a voxel with one point returns that point bit for bit (sum / 1), as Open3D does -- callers compare
-            // against coordinates of the input (floor ranges start at the lowest re-sampled point)
-            const double* q = pts + (size_t)anyidx[sidx] * 3;
-            for (int a = 0; a < 3; ++a) out[(size_t)sidx * 3 + a] = q[a];
-            ++sidx;
-            continue;
-        }
-        double n = (double)wgt[sidx];
-        out[(size_t)sidx * 3 + 0] = __dadd_rn(g.ox, __dmul_rn((double)ix, vs)) + ((double)acc[sidx] / n) / VFIX;
-        out[(size_t)sidx * 3 + 1] = __dadd_rn(g.oy, __dmul_rn((double)iy, vs)) + ((double)acc[P + sidx] / n) / VFIX;
-        out[(size_t)sidx * 3 + 2] = __dadd_rn(g.oz, __dmul_rn((double)iz, vs)) + ((double)acc[2 * P + sidx] / n) / VFIX;
-        ++sidx;
-    }
+    const double n = (double)(b - a);
+    out[(size_t)s * 3 + 0] = __ddiv_rn(sx, n);
+    out[(size_t)s * 3 + 1] = __ddiv_rn(sy, n);
+    out[(size_t)s * 3 + 2] = __ddiv_rn(sz, n);
 }
 __global__ void k_vx_gather(const unsigned* __restrict__ rank, const VxSeg* __restrict__ segs, int K, unsigned* __restrict__ out) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1141,16 +1115,25 @@ long long CloudOps::voxel_down_sample(const double* src, const std::vector<SegDe
     hipLaunchKernelGGL(k_vx_mark, grid, dim3(256), 0, s, src, dsegs, vs, vbitmap.p);
     HMSG_CHECK_LAUNCH();
     long long P = (long long)hmsg_bitmap_rank(vbitmap.p, vrank.p, (size_t)nwords, s, scan_tmp);
-    vacc.ensure((size_t)P * 3);
-    vwgt.ensure((size_t)P);
-    vany.ensure((size_t)P);
-    HIP_TRY(hipMemsetAsync(vacc.p, 0, (size_t)P * 24, s));
-    HIP_TRY(hipMemsetAsync(vwgt.p, 0, (size_t)P * 4, s));
-    hipLaunchKernelGGL(k_vx_accum, grid, dim3(256), 0, s, src, dsegs, vs, (const unsigned long long*)vbitmap.p,
-                       (const unsigned*)vrank.p, vacc.p, P, vwgt.p, vany.p);
-    hipLaunchKernelGGL(k_vx_final, dim3(cdiv((size_t)nwords, 256)), dim3(256), 0, s, (const unsigned long long*)vbitmap.p,
-                       (const unsigned*)vrank.p, nwords, dsegs, K, vs, (const long long*)vacc.p, P, (const unsigned*)vwgt.p, dst,
-                       src, (const unsigned*)vany.p);
+    // (segments tile the source buffer: point index = position in src)
+    long long N = 0;
+    for (auto& sd : segs) N = std::max(N, sd.pt_base + sd.n);
+    HMSG_REQUIRE(N < (1ll << 32), HMSG_ERR_UNSUPPORTED, "voxel_down_sample batch too large");
+    vsort.keys.ensure((size_t)N);
+    vsort.vals.ensure((size_t)N);
+    // (gaps between segments, if any, must not reach the sort: callers pass tiling segments; checked here)
+    long long covered = 0;
+    for (auto& sd : segs) covered += sd.n;
+    HMSG_REQUIRE(covered == N, HMSG_ERR_INVALID, "voxel_down_sample: segments must tile the source buffer");
+    hipLaunchKernelGGL(k_vx_keys, grid, dim3(256), 0, s, src, dsegs, vs, (const unsigned long long*)vbitmap.p,
+                       (const unsigned*)vrank.p, vsort.keys.p, vsort.vals.p);
+    HMSG_CHECK_LAUNCH();
+    hmsg_sort_pairs(vsort, (size_t)N, bits_for((unsigned long long)P), s);
+    voff.ensure((size_t)P + 1);
+    hmsg_sort_segment_starts(vsort.res_keys, (size_t)N, voff.p, (unsigned)P, s);
+    hipLaunchKernelGGL(k_vx_walk, dim3(cdiv((size_t)P, 64)), dim3(64), 0, s, (const unsigned*)voff.p,
+                       (const unsigned long long*)vsort.res_vals, P, src, dst);
+    HMSG_CHECK_LAUNCH();
     pos.ensure(K);
     hipLaunchKernelGGL(k_vx_gather, dim3(cdiv(K, 256)), dim3(256), 0, s, (const unsigned*)vrank.p, dsegs, K, pos.p);
     HMSG_CHECK_LAUNCH();

@@ -194,7 +194,7 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 // ------------------------------------------------------------------ scene state
 struct MaskCloudSet {            // 3-D masks of all fused frames (generic.py:140-190 outputs)
     DevBuf<double> pts;          // [total][3]
-    std::vector<long long> off;  // per (frame*M + i) offset into pts, size F*M + 1
+    std::vector<long long> off;  // offset into pts per mask, masks of all frames in order (hmsg_ctx::mask_first), +1
     long long total = 0;
 };
 
@@ -251,7 +251,10 @@ struct hmsg_ctx {
     int n_frames = 0;       // frames with geometry
     int n_feat_frames = 0;  // frames with features handed over (prefix 0..n-1)
     int n_fused = 0;        // frames processed by hmsg_fuse_frames
-    int M = 0;              // masks per frame (fixed per scene)
+    int MS = 0;             // mask slots per frame = NW * 64 >= cfg.max_masks (stride of the F_p tables)
+    int NW = 0;             // 64-bit words of a pixel's mask-membership bitset
+    std::vector<int> nmask;            // masks of every frame with features (SAM returns a different count per frame)
+    std::vector<long long> mask_first; // first entry of frame f in masks3d.off (prefix sum of nmask over FUSED frames), +1
     CamK cam;
     double K[9];
     bool have_K = false;
@@ -259,8 +262,8 @@ struct hmsg_ctx {
     DevBuf<unsigned char> rgb;     // [F][H][W][3]
     DevBuf<unsigned short> depth;  // [F][H][W]
     DevBuf<double> pose;           // [F][16]
-    DevBuf<unsigned long long> bits;  // [F][H][W] mask-membership bitset per pixel
-    DevBuf<float> fp;              // [F][M][D]   F_p
+    DevBuf<unsigned long long> bits;  // [F][H][W][NW] mask-membership bitset per pixel
+    DevBuf<float> fp;              // [F][MS][D]  F_p
     DevBuf<int> nn;                // [F][H][W]   NN index into the filtered cloud (-1 invalid)
     // global voxel map
     bool map_ready = false;
@@ -295,6 +298,23 @@ void hmsg_scan_u32(const unsigned* in, unsigned* out, size_t n, hipStream_t s, D
 // popcount-prefix of a bitmap: rank[w] = number of set bits in words < w; returns total set bits
 unsigned long long hmsg_bitmap_rank(const unsigned long long* bitmap, unsigned* rank, size_t nwords, hipStream_t s,
                                     DevBuf<unsigned>& tmp);
+
+// stable radix sort of (u32 key, u64 value) pairs by the low key_bits bits (hmsg_sort.hip).  Fill keys / vals,
+// call hmsg_sort_pairs, read res_keys / res_vals (they point at whichever of the ping-pong buffers holds the result).
+struct SortBufs {
+    DevBuf<unsigned> keys, keys_alt, hist, scan_tmp;
+    DevBuf<unsigned long long> vals, vals_alt;
+    unsigned* res_keys = nullptr;
+    unsigned long long* res_vals = nullptr;
+};
+void hmsg_sort_pairs(SortBufs& b, size_t n, int key_bits, hipStream_t s);
+// off[k] = first position of key k in the sorted array (keys that occur), off[nkeys] = n
+void hmsg_sort_segment_starts(const unsigned* sorted_keys, size_t n, unsigned* off, unsigned nkeys, hipStream_t s);
+static inline int bits_for(unsigned long long n) {   // bits needed to hold values 0 .. n-1
+    int b = 1;
+    while (b < 63 && (1ull << b) < n) ++b;
+    return b;
+}
 
 // development aid: when HMSG_DEBUG_DUMP=<dir> is set, write a device array to <dir>/<name>.bin
 static inline void hmsg_dump(const char* name, const void* dev, size_t bytes, hipStream_t s) {

@@ -7,9 +7,11 @@
 //
 // MI355X design notes
 //  * The reference materialises a per-pixel fp16 feature image (315 MB/frame at D=512).  A pixel's
-//    feature depends only on WHICH masks cover it, so we keep a 64-bit mask-membership word per pixel
-//    and the M x D table F_p per frame, and rebuild the (fp16-rounded) row only for the one pixel per
-//    voxel per frame that torch's duplicate-index `+=` actually keeps (graph.py:410).
+//    feature depends only on WHICH masks cover it, so we keep a mask-membership bitset per pixel (NW 64-bit
+//    words, NW = ceil(max_masks / 64) <= 4) and the M x D table F_p per frame, and rebuild the (fp16-rounded)
+//    row only for the one pixel per voxel per frame that torch's duplicate-index `+=` actually keeps
+//    (graph.py:410).  SAM returns a different number of masks for every frame: the per-frame count bounds the
+//    softmax of sam_clip_feats_extractor.py:167-169 and the bitset.
 //  * Frames are processed 64 at a time.  stamp[v][j] = 1 + the largest pixel index of frame j (of the
 //    batch) whose nearest voxel is v: a wave then owns ONE voxel, ballots its 64 stamps and adds the
 //    frames' contributions in frame order in registers -- the same float32 addition order as the
@@ -17,6 +19,10 @@
 //    of one per frame.
 //  * Nearest voxel: ring expansion over the occupancy bitmap (z-columns are contiguous bits) with an
 //    exact termination bound; no distance cap (graph.py:409, generic.py:181).
+//  * 3-D masks (generic.py:181-188): the snapped map points of a mask, WITH their pixel multiplicity, go through
+//    Open3D's voxel_down_sample = per voxel a sequential float64 sum in pixel order.  Runs of pixels with the same
+//    (voxel, mask set) become records (mask-voxel slot, map voxel, length) in pixel order, a stable sort groups
+//    them by slot, one lane per slot replays the additions (hmsg_sort.hip explains why the order matters).
 #include "hmsg_common.h"
 
 #include <hip/hip_fp16.h>
@@ -28,49 +34,57 @@
 #define MFIX_SCALE 17592186044416.0  /* 2^44 fixed point for (pixel-count weighted) mask-cloud centroids */
 
 // ------------------------------------------------------------------------------------------ K_bitset
-// masks u8 [M][HW] of one frame -> bits u64 [HW]; 16 pixels per thread, 16-byte loads.
+// masks u8 [M][HW] of one frame -> bits u64 [HW][NW]; 16 pixels per thread, 16-byte loads.  Only the first
+// nmask[f] masks of a frame are real (the rest of the M rows is padding of the hand-over layout).
 __global__ void k_bitset(const unsigned char* __restrict__ masks, int M, size_t HW, int nfr, size_t mask_stride_frame,
-                         unsigned long long* __restrict__ bits) {
+                         const int* __restrict__ nmask, int NW, unsigned long long* __restrict__ bits) {
     const size_t chunks = (HW + 15) / 16;
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= chunks * nfr) return;
     int f = (int)(t / chunks);
     size_t p0 = (t - (size_t)f * chunks) * 16;
     const unsigned char* mf = masks + (size_t)f * mask_stride_frame;
-    unsigned long long b[16];
-    for (int j = 0; j < 16; ++j) b[j] = 0ull;
-    if (p0 + 16 <= HW && (HW & 15) == 0) {
-        for (int i = 0; i < M; ++i) {
-            uint4 v = *reinterpret_cast<const uint4*>(mf + (size_t)i * HW + p0);
-            unsigned w[4] = {v.x, v.y, v.z, v.w};
-            for (int j = 0; j < 16; ++j) {
-                unsigned byte = (w[j >> 2] >> ((j & 3) * 8)) & 0xffu;
-                b[j] |= (unsigned long long)(byte != 0) << i;
+    const int nm = min(nmask[f], M);
+    unsigned long long* o = bits + ((size_t)f * HW + p0) * NW;
+    for (int w = 0; w < NW; ++w) {
+        unsigned long long b[16];
+        for (int j = 0; j < 16; ++j) b[j] = 0ull;
+        const int i0 = w * 64, i1 = min(nm, i0 + 64);
+        if (p0 + 16 <= HW && (HW & 15) == 0) {
+            for (int i = i0; i < i1; ++i) {
+                uint4 v = *reinterpret_cast<const uint4*>(mf + (size_t)i * HW + p0);
+                unsigned wd[4] = {v.x, v.y, v.z, v.w};
+                for (int j = 0; j < 16; ++j) {
+                    unsigned byte = (wd[j >> 2] >> ((j & 3) * 8)) & 0xffu;
+                    b[j] |= (unsigned long long)(byte != 0) << (i - i0);
+                }
             }
+        } else {
+            for (int i = i0; i < i1; ++i)
+                for (int j = 0; j < 16 && p0 + j < HW; ++j) b[j] |= (unsigned long long)(mf[(size_t)i * HW + p0 + j] != 0) << (i - i0);
         }
-    } else {
-        for (int i = 0; i < M; ++i)
-            for (int j = 0; j < 16 && p0 + j < HW; ++j) b[j] |= (unsigned long long)(mf[(size_t)i * HW + p0 + j] != 0) << i;
+        for (int j = 0; j < 16 && p0 + j < HW; ++j) o[(size_t)j * NW + w] = b[j];
     }
-    unsigned long long* o = bits + (size_t)f * HW + p0;
-    for (int j = 0; j < 16 && p0 + j < HW; ++j) o[j] = b[j];
 }
 
 // ------------------------------------------------------------------------------------------ K_fp
-// sam_clip_feats_extractor.py:159-175.  One 256-thread block per frame; a wave per mask row.
+// sam_clip_feats_extractor.py:159-175.  One 256-thread block per frame; a wave per mask row.  The softmax runs
+// over the frame's OWN nm masks (:167-169); rows >= nm of the table are never referenced.
+#define HMSG_MAX_MASKS 256
 __global__ void k_fp(const float* __restrict__ Fg, const float* __restrict__ Fm, const float* __restrict__ Fc, int M, int D,
-                     float wm, float wc, float* __restrict__ Fp /*[nfr][M][D]*/) {
-    __shared__ float phi[64];
-    __shared__ float wsm[64];
+                     float wm, float wc, const int* __restrict__ nmask, int MS, float* __restrict__ Fp /*[nfr][MS][D]*/) {
+    __shared__ float phi[HMSG_MAX_MASKS];
+    __shared__ float wsm[HMSG_MAX_MASKS];
     const int f = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nm = min(nmask[f], M);
     const float* g = Fg + (size_t)f * D;
     float gn = 0.f;
     for (int e = lane; e < D; e += 64) gn += g[e] * g[e];
     gn = fmaxf(__fsqrt_rn(wave_sum_f32(gn)), 1e-6f);
-    for (int i = wv; i < M; i += 4) {
+    for (int i = wv; i < nm; i += 4) {
         const float* a = Fm + ((size_t)f * M + i) * D;
         const float* b = Fc + ((size_t)f * M + i) * D;
-        float* o = Fp + ((size_t)f * M + i) * D;
+        float* o = Fp + ((size_t)f * MS + i) * D;
         float n2 = 0.f;
         for (int e = lane; e < D; e += 64) {
             float v = __fadd_rn(__fmul_rn(wm, a[e]), __fmul_rn(wc, b[e]));
@@ -93,17 +107,17 @@ __global__ void k_fp(const float* __restrict__ Fg, const float* __restrict__ Fm,
     __syncthreads();
     if (threadIdx.x == 0) {
         float mx = -3.4e38f;
-        for (int i = 0; i < M; ++i) mx = fmaxf(mx, phi[i]);
+        for (int i = 0; i < nm; ++i) mx = fmaxf(mx, phi[i]);
         float s = 0.f;
-        for (int i = 0; i < M; ++i) {
+        for (int i = 0; i < nm; ++i) {
             wsm[i] = expf(phi[i] - mx);
             s += wsm[i];
         }
-        for (int i = 0; i < M; ++i) wsm[i] = __fdiv_rn(wsm[i], s);
+        for (int i = 0; i < nm; ++i) wsm[i] = __fdiv_rn(wsm[i], s);
     }
     __syncthreads();
-    for (int i = wv; i < M; i += 4) {
-        float* o = Fp + ((size_t)f * M + i) * D;
+    for (int i = wv; i < nm; i += 4) {
+        float* o = Fp + ((size_t)f * MS + i) * D;
         float w = wsm[i], w1 = __fsub_rn(1.0f, w);
         float n2 = 0.f;
         for (int e = lane; e < D; e += 64) {
@@ -145,7 +159,7 @@ __global__ void k_nn_stamp(const unsigned short* __restrict__ depth, const doubl
 // One wave per voxel.  graph.py:410-411 with torch's last-writer-wins semantics (SURVEY hazard 7): per
 // frame the voxel receives old + fp16(F_2D[p*]) for p* = its largest pixel index, counter += 1.
 template <int VEC, int NJ>
-__global__ void k_fuse(const unsigned* __restrict__ stamp, long long V, int f0, int nfr, int M, int D, size_t HW,
+__global__ void k_fuse(const unsigned* __restrict__ stamp, long long V, int f0, int nfr, int MS, int NW, int D, size_t HW,
                        const unsigned long long* __restrict__ bits, const float* __restrict__ Fp, float* __restrict__ sum,
                        unsigned* __restrict__ cnt) {
     const int lane = threadIdx.x & 63;
@@ -170,22 +184,24 @@ __global__ void k_fuse(const unsigned* __restrict__ stamp, long long V, int f0, 
         ++nfrm;
         unsigned p = __shfl(st, fl) - 1u;
         int f = f0 + fl;
-        unsigned long long b = bits[(size_t)f * HW + p];
-        const float* fpf = Fp + (size_t)f * M * D;
+        const float* fpf = Fp + (size_t)f * MS * D;
         float x[NJ * VEC];
 #pragma unroll
         for (int q = 0; q < NJ * VEC; ++q) x[q] = 0.f;
-        while (b) {
-            int i = __ffsll(b) - 1;
-            b &= b - 1;
-            const float* r = fpf + (size_t)i * D;
+        for (int w = 0; w < NW; ++w) {          // masks in index order (sam_clip_feats_extractor.py:183-187)
+            unsigned long long b = bits[((size_t)f * HW + p) * NW + w];
+            while (b) {
+                int i = w * 64 + __ffsll(b) - 1;
+                b &= b - 1;
+                const float* r = fpf + (size_t)i * D;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    int e = j * 64 * VEC + lane * VEC + k;
-                    if (e < D) x[j * VEC + k] = __fadd_rn(x[j * VEC + k], r[e]);
-                }
+                    for (int k = 0; k < VEC; ++k) {
+                        int e = j * 64 * VEC + lane * VEC + k;
+                        if (e < D) x[j * VEC + k] = __fadd_rn(x[j * VEC + k], r[e]);
+                    }
+            }
         }
         float n2 = 0.f;
 #pragma unroll
@@ -222,82 +238,89 @@ struct MaskGeom {           // per (frame, mask) local Open3D voxel grid of the 
     double ox, oy, oz;      // min_bound - vs/2
     int nx, ny, nz;
     int pad;
-    long long word_off;     // first bitmap word of this mask in the sub-batch bitmap
+    long long word_off;     // first bitmap word of this mask in the batch bitmap
 };
 
-struct Winner {
-    int f;   // frame index within the sub-batch
-    int p;
-    int v;
-};
+#define MCHUNK 4096         /* pixels per workgroup of the run kernels (record positions come from per-chunk counts) */
 
-__global__ void k_mcount(const int* __restrict__ nn, const unsigned long long* __restrict__ bits, size_t HW, int f0, int nfr,
-                         long long V, int M, unsigned* __restrict__ mcount /*[nfr][V][M]*/) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in_range = t < HW * nfr;
-    if (!in_range) t = HW * nfr - 1;
-    int fl = (int)(t / HW);
-    size_t g = (size_t)(f0 + fl) * HW + (t - (size_t)fl * HW);
-    int v = in_range ? nn[g] : -1;
-    unsigned long long b = v >= 0 ? bits[g] : 0ull;
-    // runs of consecutive lanes with the same (frame, voxel, mask set): the last lane adds the run length
+// A run = consecutive pixels of one image row, inside one 64-pixel wave slice, with the same nearest voxel and
+// the same mask set.  Every mask kernel below re-detects the runs from (nn, bits) with this routine, so they
+// all see the same runs; the lane holding a run's LAST pixel works for the run.
+struct MaskRun {
+    bool tail;              // this lane closes a run that has a voxel and at least one mask
+    int v, len;
+    unsigned long long b[4];
+    unsigned dsum;          // sum of the run's u16 depths (create_3d_masks' filter_distance test)
+};
+__device__ __forceinline__ MaskRun mask_run(const int* __restrict__ nn, const unsigned long long* __restrict__ bits,
+                                            const unsigned short* __restrict__ depth, int NW, int W, size_t g, bool in_range,
+                                            bool want_depth) {
+    MaskRun r;
     const int lane = threadIdx.x & 63;
-    long long k1 = v >= 0 ? ((long long)v << 8) | fl : -1 - lane;
-    long long p1 = __shfl_up(k1, 1);
-    unsigned long long pb = __shfl_up(b, 1);
-    const bool head = lane == 0 || p1 != k1 || pb != b;
-    unsigned long long heads = __ballot(head);
-    long long n1 = __shfl_down(k1, 1);
-    unsigned long long nb = __shfl_down(b, 1);
-    const bool tail = lane == 63 || n1 != k1 || nb != b;
-    if (v >= 0 && tail && b) {
-        unsigned long long below = heads & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull));
-        int start_lane = 63 - __clzll(below);
-        unsigned len = (unsigned)(lane - start_lane + 1);
-        unsigned* row = mcount + ((size_t)fl * V + v) * M;
-        while (b) {
-            int i = __ffsll(b) - 1;
-            b &= b - 1;
-            atomicAdd(&row[i], len);
-        }
+    r.v = in_range ? nn[g] : -1;
+    bool any = false;
+    for (int w = 0; w < 4; ++w) {
+        r.b[w] = (w < NW && r.v >= 0) ? bits[g * NW + w] : 0ull;
+        any = any || r.b[w] != 0ull;
     }
+    const int x = in_range ? (int)(g % (size_t)W) : 0;
+    const int pv = __shfl_up(r.v, 1);                  // (shuffles outside any short-circuit: all lanes take part)
+    bool head = lane == 0 || x == 0 || pv != r.v;
+    for (int w = 0; w < NW; ++w) {
+        const unsigned long long pb = __shfl_up(r.b[w], 1);
+        head = head || pb != r.b[w];
+    }
+    const unsigned long long heads = __ballot(head);
+    const int nhead = __shfl_down(head ? 1 : 0, 1);
+    const bool tail = lane == 63 || nhead != 0;
+    const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull));
+    const int start_lane = 63 - __clzll(below);
+    r.len = lane - start_lane + 1;
+    r.dsum = 0u;
+    if (want_depth) {
+        unsigned d = (in_range && r.v >= 0) ? (unsigned)depth[g] : 0u;
+        int flag = head ? 1 : 0;
+        for (int o = 1; o < 64; o <<= 1) {       // segmented inclusive scan (integer: exact)
+            unsigned td = __shfl_up(d, o);
+            int tf = __shfl_up(flag, o);
+            if (lane >= o && !flag) {
+                d += td;
+                flag = tf;
+            }
+        }
+        r.dsum = d;
+    }
+    r.tail = tail && r.v >= 0 && any;
+    return r;
 }
 
-// The pixels that define the 3-D masks: for every (voxel, frame) the LAST pixel that snapped to the voxel
-// (create_3d_masks keeps one map point per voxel hit, weighted by its pixel count).  They are exactly the
-// non-zero stamps, so the list is read off the stamp table with coalesced loads -- testing every pixel against
-// its voxel's stamp was a random 4-byte gather per pixel.
-__global__ void k_winners(const unsigned* __restrict__ stamp, long long V, int j0, int nfr, Winner* __restrict__ out,
-                          unsigned* __restrict__ n_out) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // t = v * FB + j, rows padded to FB
-    const int j = (int)(t % FB);
-    const long long v = t / FB;
-    unsigned sv = 0u;
-    if (v < V && j >= j0 && j < j0 + nfr) sv = stamp[t];
-    const bool win = sv != 0u;
-    // list slots per wave (one atomic on the counter per wave)
-    const unsigned long long m = __ballot(win);
-    if (!m) return;
-    const int lane = threadIdx.x & 63, leader = __ffsll(m) - 1;
-    unsigned base = 0;
-    if (lane == leader) base = atomicAdd(n_out, (unsigned)__popcll(m));
-    base = __shfl(base, leader);
-    if (win) out[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = Winner{j - j0, (int)(sv - 1u), (int)v};
-}
-
-__global__ void k_mbounds(const Winner* __restrict__ win, unsigned nwin, long long V, int M, const unsigned* __restrict__ mcount,
-                          const double* __restrict__ pts, unsigned long long* __restrict__ bounds /*[nfr*M][6]*/) {
-    unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nwin) return;
-    Winner w = win[t];
-    const unsigned* row = mcount + ((size_t)w.f * V + w.v) * M;
-    unsigned long long e[3] = {enc_f64(pts[(size_t)w.v * 3]), enc_f64(pts[(size_t)w.v * 3 + 1]), enc_f64(pts[(size_t)w.v * 3 + 2])};
-    for (int i = 0; i < M; ++i) {
-        if (!row[i]) continue;
-        unsigned long long* b = bounds + ((size_t)w.f * M + i) * 6;
-        for (int a = 0; a < 3; ++a) {
-            if (e[a] < b[a]) atomicMin(&b[a], e[a]);
-            if (e[a] > b[3 + a]) atomicMax(&b[3 + a], e[a]);
+// per (frame, mask): AABB of the snapped points, number of valid pixels and the sum of their depths
+__global__ void __launch_bounds__(256) k_mbounds(const int* __restrict__ nn, const unsigned long long* __restrict__ bits,
+                                                 const unsigned short* __restrict__ depth, size_t HW, int W, int f0, int nfr,
+                                                 int NW, int MS, const double* __restrict__ pts,
+                                                 unsigned long long* __restrict__ bounds /*[nfr*MS][6]*/,
+                                                 unsigned long long* __restrict__ dstat /*[nfr*MS][2]: depth sum, pixels*/) {
+    for (int it = 0; it < MCHUNK / 256; ++it) {
+        const size_t t = (size_t)blockIdx.x * MCHUNK + (size_t)it * 256 + threadIdx.x;
+        const bool in_range = t < HW * nfr;
+        const int fl = in_range ? (int)(t / HW) : 0;
+        const size_t g = (size_t)f0 * HW + t;
+        const MaskRun r = mask_run(nn, bits, depth, NW, W, g, in_range, true);
+        if (!r.tail) continue;
+        unsigned long long e[3] = {enc_f64(pts[(size_t)r.v * 3]), enc_f64(pts[(size_t)r.v * 3 + 1]), enc_f64(pts[(size_t)r.v * 3 + 2])};
+        for (int w = 0; w < NW; ++w) {
+            unsigned long long b = r.b[w];
+            while (b) {
+                const int i = w * 64 + __ffsll(b) - 1;
+                b &= b - 1;
+                unsigned long long* bd = bounds + ((size_t)fl * MS + i) * 6;
+                for (int a = 0; a < 3; ++a) {      // (stale reads only cost a redundant atomic)
+                    if (e[a] < bd[a]) atomicMin(&bd[a], e[a]);
+                    if (e[a] > bd[3 + a]) atomicMax(&bd[3 + a], e[a]);
+                }
+                atomicAdd(&dstat[((size_t)fl * MS + i) * 2], (unsigned long long)r.dsum);
+                atomicAdd(&dstat[((size_t)fl * MS + i) * 2 + 1], (unsigned long long)r.len);
+            }
         }
     }
 }
@@ -310,88 +333,128 @@ __device__ __forceinline__ long long mask_cell(const MaskGeom& mg, double vs, co
     return ((long long)ix * mg.ny + iy) * mg.nz + iz;
 }
 
-__global__ void k_mmark(const Winner* __restrict__ win, unsigned nwin, long long V, int M, const unsigned* __restrict__ mcount,
-                        const double* __restrict__ pts, const MaskGeom* __restrict__ geom, double vs,
-                        unsigned long long* __restrict__ mbitmap) {
-    unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nwin) return;
-    Winner w = win[t];
-    const unsigned* row = mcount + ((size_t)w.f * V + w.v) * M;
-    for (int i = 0; i < M; ++i) {
-        if (!row[i]) continue;
-        const MaskGeom mg = geom[(size_t)w.f * M + i];
-        int ix, iy, iz;
-        long long lin = mask_cell(mg, vs, pts + (size_t)w.v * 3, ix, iy, iz);
-        atomicOr(&mbitmap[mg.word_off + (lin >> 6)], 1ull << (lin & 63));
+// occupancy bitmaps of the per-mask Open3D grids + number of records every chunk will emit
+__global__ void __launch_bounds__(256) k_mmark(const int* __restrict__ nn, const unsigned long long* __restrict__ bits, size_t HW,
+                                               int W, int f0, int nfr, int NW, int MS, const double* __restrict__ pts,
+                                               const MaskGeom* __restrict__ geom, double vs,
+                                               unsigned long long* __restrict__ mbitmap, unsigned* __restrict__ chunk_recs) {
+    __shared__ unsigned s_n;
+    if (threadIdx.x == 0) s_n = 0u;
+    __syncthreads();
+    unsigned mine = 0;
+    for (int it = 0; it < MCHUNK / 256; ++it) {
+        const size_t t = (size_t)blockIdx.x * MCHUNK + (size_t)it * 256 + threadIdx.x;
+        const bool in_range = t < HW * nfr;
+        const int fl = in_range ? (int)(t / HW) : 0;
+        const size_t g = (size_t)f0 * HW + t;
+        const MaskRun r = mask_run(nn, bits, nullptr, NW, W, g, in_range, false);
+        if (!r.tail) continue;
+        for (int w = 0; w < NW; ++w) {
+            unsigned long long b = r.b[w];
+            while (b) {
+                const int i = w * 64 + __ffsll(b) - 1;
+                b &= b - 1;
+                const MaskGeom mg = geom[(size_t)fl * MS + i];
+                if (mg.nx == 0) continue;                       // mask rejected by filter_distance
+                int ix, iy, iz;
+                const long long lin = mask_cell(mg, vs, pts + (size_t)r.v * 3, ix, iy, iz);
+                unsigned long long* wp = mbitmap + mg.word_off + (lin >> 6);
+                const unsigned long long bit = 1ull << (lin & 63);
+                if (!(*wp & bit)) atomicOr(wp, bit);
+                ++mine;
+            }
+        }
+    }
+    mine = (unsigned)wave_sum_i32((int)mine);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_n, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_recs[blockIdx.x] = s_n;
+}
+
+// records (key = slot of the mask voxel, value = map voxel << 8 | run length) in pixel order
+__global__ void __launch_bounds__(256) k_memit(const int* __restrict__ nn, const unsigned long long* __restrict__ bits, size_t HW,
+                                               int W, int f0, int nfr, int NW, int MS, const double* __restrict__ pts,
+                                               const MaskGeom* __restrict__ geom, double vs,
+                                               const unsigned long long* __restrict__ mbitmap, const unsigned* __restrict__ mrank,
+                                               const unsigned* __restrict__ chunk_base, unsigned* __restrict__ keys,
+                                               unsigned long long* __restrict__ vals) {
+    __shared__ unsigned s_w[4];
+    __shared__ unsigned s_run;
+    if (threadIdx.x == 0) s_run = chunk_base[blockIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int it = 0; it < MCHUNK / 256; ++it) {
+        const size_t t = (size_t)blockIdx.x * MCHUNK + (size_t)it * 256 + threadIdx.x;
+        const bool in_range = t < HW * nfr;
+        const int fl = in_range ? (int)(t / HW) : 0;
+        const size_t g = (size_t)f0 * HW + t;
+        const MaskRun r = mask_run(nn, bits, nullptr, NW, W, g, in_range, false);
+        // records of this lane: its masks whose cloud was not rejected
+        unsigned nrec = 0;
+        if (r.tail)
+            for (int w = 0; w < NW; ++w) {
+                unsigned long long b = r.b[w];
+                while (b) {
+                    const int i = w * 64 + __ffsll(b) - 1;
+                    b &= b - 1;
+                    nrec += geom[(size_t)fl * MS + i].nx != 0 ? 1u : 0u;
+                }
+            }
+        unsigned incl = nrec;                       // inclusive wave scan
+        for (int o = 1; o < 64; o <<= 1) {
+            unsigned u = __shfl_up(incl, o);
+            if (lane >= o) incl += u;
+        }
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        unsigned pos = s_run + incl - nrec;
+        for (int q = 0; q < wv; ++q) pos += s_w[q];
+        if (nrec)
+            for (int w = 0; w < NW; ++w) {
+                unsigned long long b = r.b[w];
+                while (b) {
+                    const int i = w * 64 + __ffsll(b) - 1;
+                    b &= b - 1;
+                    const MaskGeom mg = geom[(size_t)fl * MS + i];
+                    if (mg.nx == 0) continue;
+                    int ix, iy, iz;
+                    const long long lin = mask_cell(mg, vs, pts + (size_t)r.v * 3, ix, iy, iz);
+                    const long long wd = mg.word_off + (lin >> 6);
+                    keys[pos] = mrank[wd] + (unsigned)__popcll(mbitmap[wd] & ((1ull << (lin & 63)) - 1ull));
+                    vals[pos] = ((unsigned long long)(unsigned)r.v << 8) | (unsigned long long)r.len;
+                    ++pos;
+                }
+            }
+        __syncthreads();
+        if (threadIdx.x == 0) s_run += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
     }
 }
 
-struct MaskAcc {
-    long long* sx;
-    long long* sy;
-    long long* sz;
-    unsigned long long* wgt;
-};
-
-__global__ void k_maccum(const Winner* __restrict__ win, unsigned nwin, long long V, int M, unsigned* __restrict__ mcount,
-                         const double* __restrict__ pts, const MaskGeom* __restrict__ geom, double vs,
-                         const unsigned long long* __restrict__ mbitmap, const unsigned* __restrict__ mrank, MaskAcc acc) {
-    unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nwin) return;
-    Winner w = win[t];
-    unsigned* row = mcount + ((size_t)w.f * V + w.v) * M;
-    const double* p = pts + (size_t)w.v * 3;
-    for (int i = 0; i < M; ++i) {
-        unsigned c = row[i];
-        if (!c) continue;
-        row[i] = 0u;   // leave the dense counter table clean for the next sub-batch
-        const MaskGeom mg = geom[(size_t)w.f * M + i];
-        int ix, iy, iz;
-        long long lin = mask_cell(mg, vs, p, ix, iy, iz);
-        long long wd = mg.word_off + (lin >> 6);
-        unsigned long long word = mbitmap[wd];
-        unsigned slot = mrank[wd] + (unsigned)__popcll(word & ((1ull << (lin & 63)) - 1ull));
-        double cx = __dadd_rn(mg.ox, __dmul_rn((double)ix, vs));
-        double cy = __dadd_rn(mg.oy, __dmul_rn((double)iy, vs));
-        double cz = __dadd_rn(mg.oz, __dmul_rn((double)iz, vs));
-        long long qx = (long long)llrint((p[0] - cx) * MFIX_SCALE) * (long long)c;
-        long long qy = (long long)llrint((p[1] - cy) * MFIX_SCALE) * (long long)c;
-        long long qz = (long long)llrint((p[2] - cz) * MFIX_SCALE) * (long long)c;
-        atomicAdd((unsigned long long*)&acc.sx[slot], (unsigned long long)qx);
-        atomicAdd((unsigned long long*)&acc.sy[slot], (unsigned long long)qy);
-        atomicAdd((unsigned long long*)&acc.sz[slot], (unsigned long long)qz);
-        atomicAdd(&acc.wgt[slot], (unsigned long long)c);
+// one lane per mask voxel: replay Open3D's accumulation -- sequential float64 sum of the snapped points in pixel
+// order, then / count (generic.py:188 -> o3d_voxel_down_sample)
+__global__ void k_mwalk(const unsigned* __restrict__ off, const unsigned long long* __restrict__ recs, long long npts,
+                        const double* __restrict__ pts, double* __restrict__ out) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= npts) return;
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    unsigned long long n = 0;
+    for (unsigned r = off[s]; r < off[s + 1]; ++r) {
+        const unsigned long long rec = recs[r];
+        const double* p = pts + (size_t)(rec >> 8) * 3;
+        const double px = p[0], py = p[1], pz = p[2];
+        const int len = (int)(rec & 255ull);
+        for (int j = 0; j < len; ++j) {
+            sx = __dadd_rn(sx, px);
+            sy = __dadd_rn(sy, py);
+            sz = __dadd_rn(sz, pz);
+        }
+        n += (unsigned long long)len;
     }
-}
-
-// one thread per bitmap word of the sub-batch: emit the points of its set bits
-__global__ void k_mfinal(const unsigned long long* __restrict__ mbitmap, const unsigned* __restrict__ mrank, long long nwords,
-                         const MaskGeom* __restrict__ geom, int nmasks, double vs, MaskAcc acc, double* __restrict__ out) {
-    long long wd = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (wd >= nwords) return;
-    unsigned long long bitsw = mbitmap[wd];
-    if (!bitsw) return;
-    int lo = 0, hi = nmasks - 1;   // last mask with word_off <= wd (empty masks share an offset: take the last)
-    while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (geom[mid].word_off <= wd) lo = mid; else hi = mid - 1;
-    }
-    const MaskGeom mg = geom[lo];
-    unsigned s = mrank[wd];
-    while (bitsw) {
-        int b = __ffsll(bitsw) - 1;
-        bitsw &= bitsw - 1;
-        long long lin = (wd - mg.word_off) * 64 + b;
-        int iz = (int)(lin % mg.nz);
-        long long r = lin / mg.nz;
-        int iy = (int)(r % mg.ny);
-        int ix = (int)(r / mg.ny);
-        double n = (double)acc.wgt[s];
-        out[(size_t)s * 3 + 0] = __dadd_rn(mg.ox, __dmul_rn((double)ix, vs)) + ((double)acc.sx[s] / n) / MFIX_SCALE;
-        out[(size_t)s * 3 + 1] = __dadd_rn(mg.oy, __dmul_rn((double)iy, vs)) + ((double)acc.sy[s] / n) / MFIX_SCALE;
-        out[(size_t)s * 3 + 2] = __dadd_rn(mg.oz, __dmul_rn((double)iz, vs)) + ((double)acc.sz[s] / n) / MFIX_SCALE;
-        ++s;
-    }
+    const double dn = (double)n;
+    out[(size_t)s * 3 + 0] = __ddiv_rn(sx, dn);
+    out[(size_t)s * 3 + 1] = __ddiv_rn(sy, dn);
+    out[(size_t)s * 3 + 2] = __ddiv_rn(sz, dn);
 }
 
 __global__ void k_gather_u32(const unsigned* __restrict__ src, const long long* __restrict__ idx, int n, unsigned* __restrict__ dst) {
@@ -404,7 +467,7 @@ template <int VEC, int NJ>
 static void launch_fuse(hmsg_ctx* h, const unsigned* stamp, int f0, int nfr) {
     const size_t HW = (size_t)h->cfg.height * h->cfg.width;
     hipLaunchKernelGGL((k_fuse<VEC, NJ>), dim3(cdiv((size_t)h->V * 64, 256)), dim3(256), 0, h->stream, stamp, h->V, f0, nfr,
-                       h->M, h->cfg.feat_dim, HW, (const unsigned long long*)h->bits.p, (const float*)h->fp.p, h->sum.p,
+                       h->MS, h->NW, h->cfg.feat_dim, HW, (const unsigned long long*)h->bits.p, (const float*)h->fp.p, h->sum.p,
                        h->cnt.p);
     HMSG_CHECK_LAUNCH();
 }
@@ -431,14 +494,10 @@ void hmsg_fuse(hmsg_ctx* h) {
     hipStream_t s = h->stream;
     HMSG_REQUIRE(h->map_ready, HMSG_ERR_INVALID, "hmsg_fuse_frames: call hmsg_finalize_map first");
     HMSG_REQUIRE(!h->feats_final || h->n_fused == h->n_feat_frames, HMSG_ERR_INVALID, "feature map already finalised");
-    const int H = c.height, W = c.width, D = c.feat_dim, M = h->M;
+    const int H = c.height, W = c.width, D = c.feat_dim, MS = h->MS, NW = h->NW;
     const size_t HW = (size_t)H * W;
     const long long V = h->V;
     const float scale = (float)c.depth_scale;
-    // create_3d_masks' filter_distance (generic.py:126-127): mean camera depth of a mask can never exceed
-    // the u16 depth range, so any threshold >= 65.536 m (the shipped 10000) never fires.
-    HMSG_REQUIRE(c.max_mask_distance * c.depth_scale >= 65536.0, HMSG_ERR_UNSUPPORTED,
-                 "max_mask_distance below the representable depth range is not implemented in this build");
     if (h->sum.n < (size_t)V * D || h->n_fused == 0) {
         h->sum.alloc((size_t)V * D);
         h->cnt.alloc((size_t)V);
@@ -448,34 +507,29 @@ void hmsg_fuse(hmsg_ctx* h) {
     if (h->nn.n < (size_t)c.max_frames * HW) h->nn.alloc((size_t)c.max_frames * HW);
     DevBuf<unsigned> stamp;
     stamp.alloc((size_t)std::max<long long>(V, 1) * FB);
-    // mask sub-batch size from an 8 GiB budget for the dense per-voxel mask counters (288 GB of HBM: a whole
-    // stamp batch at once for maps up to ~1M voxels; every sub-batch costs three host round trips)
-    int Bm = FB;
-    while (Bm > 1 && (size_t)Bm * V * M * 4 > ((size_t)8 << 30)) Bm >>= 1;
-    DevBuf<unsigned> mcount;
-    mcount.alloc((size_t)Bm * std::max<long long>(V, 1) * M);
-    mcount.zero(s);
-    DevBuf<Winner> win;
-    win.alloc((size_t)Bm * HW);
-    DevBuf<unsigned> d_nwin;
-    d_nwin.alloc(1);
-    DevBuf<unsigned long long> d_bounds;
-    d_bounds.alloc((size_t)Bm * M * 6);
+    const int nmask_max = FB * MS;
+    DevBuf<unsigned long long> d_bounds, d_dstat;
+    d_bounds.alloc((size_t)nmask_max * 6);
+    d_dstat.alloc((size_t)nmask_max * 2);
     DevBuf<MaskGeom> d_geom;
-    d_geom.alloc((size_t)Bm * M);
+    d_geom.alloc((size_t)nmask_max);
     DevBuf<unsigned long long> mbitmap;
-    DevBuf<unsigned> mrank;
-    DevBuf<long long> macc_xyz;
-    DevBuf<unsigned long long> macc_w;
+    DevBuf<unsigned> mrank, chunk_recs, rec_off;
     DevBuf<long long> d_offidx;
     DevBuf<unsigned> d_offval;
-    d_offidx.alloc((size_t)Bm * M);
-    d_offval.alloc((size_t)Bm * M);
-    std::vector<unsigned long long> hb((size_t)Bm * M * 6);
-    std::vector<MaskGeom> hg((size_t)Bm * M);
-    std::vector<long long> hoffidx((size_t)Bm * M);
-    std::vector<unsigned> hoffval((size_t)Bm * M);
+    d_offidx.alloc((size_t)nmask_max);
+    d_offval.alloc((size_t)nmask_max);
+    SortBufs sb;
+    std::vector<unsigned long long> hb((size_t)nmask_max * 6), hd((size_t)nmask_max * 2);
+    std::vector<MaskGeom> hg((size_t)nmask_max);
+    std::vector<long long> hoffidx((size_t)nmask_max);
+    std::vector<unsigned> hoffval((size_t)nmask_max);
     if (h->masks3d.off.empty()) h->masks3d.off.assign(1, 0);
+    if (h->mask_first.empty()) h->mask_first.assign(1, 0);
+    // create_3d_masks' filter_distance (generic.py:126-127): the mask is dropped when the mean camera depth of its
+    // valid pixels exceeds the threshold.  The mean is taken over the u16 depths (exact integer sum); the reference
+    // averages float32 metres, so a mask within ~1e-7 (relative) of the threshold can fall on the other side.
+    const double filt_mm = c.max_mask_distance * c.depth_scale;
 
     for (int fb0 = h->n_fused; fb0 < h->n_feat_frames; fb0 += FB) {
         const int nb = std::min(FB, h->n_feat_frames - fb0);
@@ -490,115 +544,127 @@ void hmsg_fuse(hmsg_ctx* h) {
             ProfScope ps(h->prof, s, "k_fuse", (double)V * 256.0);
             dispatch_fuse(h, stamp.p, fb0, nb);
         }
-        // ---- 3-D masks, Bm frames at a time
-        for (int f0 = fb0; f0 < fb0 + nb; f0 += Bm) {
-            const int nfr = std::min(Bm, fb0 + nb - f0);
-            const int nmask = nfr * M;
-            {
-                ProfScope ps(h->prof, s, "k_mcount", (double)nfr * (double)HW * 20.0);
-                hipLaunchKernelGGL(k_mcount, dim3(cdiv(HW * nfr, 256)), dim3(256), 0, s, (const int*)h->nn.p,
-                                   (const unsigned long long*)h->bits.p, HW, f0, nfr, V, M, mcount.p);
-            }
-            HMSG_CHECK_LAUNCH();
-            HIP_TRY(hipMemsetAsync(d_nwin.p, 0, 4, s));
-            hipLaunchKernelGGL(k_winners, dim3(cdiv((size_t)V * FB, 256)), dim3(256), 0, s, (const unsigned*)stamp.p, V,
-                               f0 - fb0, nfr, win.p, d_nwin.p);
-            HMSG_CHECK_LAUNCH();
-            for (int i = 0; i < nmask; ++i)
-                for (int a = 0; a < 6; ++a) hb[(size_t)i * 6 + a] = a < 3 ? ~0ull : 0ull;
-            HIP_TRY(hipMemcpyAsync(d_bounds.p, hb.data(), (size_t)nmask * 48, hipMemcpyHostToDevice, s));
-            unsigned nwin = 0;
-            HIP_TRY(hipMemcpyAsync(&nwin, d_nwin.p, 4, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            if (nwin) {
-                hipLaunchKernelGGL(k_mbounds, dim3(cdiv(nwin, 256)), dim3(256), 0, s, (const Winner*)win.p, nwin, V, M,
-                                   (const unsigned*)mcount.p, (const double*)h->pts.p, d_bounds.p);
-                HMSG_CHECK_LAUNCH();
-            }
-            HIP_TRY(hipMemcpyAsync(hb.data(), d_bounds.p, (size_t)nmask * 48, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            long long nwords = 0;
-            for (int i = 0; i < nmask; ++i) {
-                MaskGeom& mg = hg[i];
-                mg.word_off = nwords;
-                mg.pad = 0;
-                if (hb[(size_t)i * 6] == ~0ull) {   // no valid pixel in this mask
-                    mg.ox = mg.oy = mg.oz = 0.0;
-                    mg.nx = mg.ny = mg.nz = 0;
-                    continue;
-                }
-                double mn[3], mx[3];
-                for (int a = 0; a < 3; ++a) {
-                    mn[a] = dec_f64(hb[(size_t)i * 6 + a]);
-                    mx[a] = dec_f64(hb[(size_t)i * 6 + 3 + a]);
-                }
-                mg.ox = mn[0] - c.voxel_size * 0.5;
-                mg.oy = mn[1] - c.voxel_size * 0.5;
-                mg.oz = mn[2] - c.voxel_size * 0.5;
-                mg.nx = (int)std::floor((mx[0] - mg.ox) / c.voxel_size) + 2;
-                mg.ny = (int)std::floor((mx[1] - mg.oy) / c.voxel_size) + 2;
-                mg.nz = (int)std::floor((mx[2] - mg.oz) / c.voxel_size) + 2;
-                nwords += ((long long)mg.nx * mg.ny * mg.nz + 63) / 64;
-            }
-            long long npts = 0;
-            if (nwin && nwords) {
-                HIP_TRY(hipMemcpyAsync(d_geom.p, hg.data(), (size_t)nmask * sizeof(MaskGeom), hipMemcpyHostToDevice, s));
-                mbitmap.ensure((size_t)nwords);
-                mrank.ensure((size_t)nwords);
-                HIP_TRY(hipMemsetAsync(mbitmap.p, 0, (size_t)nwords * 8, s));
-                hipLaunchKernelGGL(k_mmark, dim3(cdiv(nwin, 256)), dim3(256), 0, s, (const Winner*)win.p, nwin, V, M,
-                                   (const unsigned*)mcount.p, (const double*)h->pts.p, (const MaskGeom*)d_geom.p,
-                                   c.voxel_size, mbitmap.p);
-                HMSG_CHECK_LAUNCH();
-                npts = (long long)hmsg_bitmap_rank(mbitmap.p, mrank.p, (size_t)nwords, s, h->scan_tmp);
-                macc_xyz.ensure((size_t)npts * 3);
-                macc_w.ensure((size_t)npts);
-                HIP_TRY(hipMemsetAsync(macc_xyz.p, 0, (size_t)npts * 3 * 8, s));
-                HIP_TRY(hipMemsetAsync(macc_w.p, 0, (size_t)npts * 8, s));
-                MaskAcc acc{macc_xyz.p, macc_xyz.p + npts, macc_xyz.p + 2 * npts, macc_w.p};
-                hipLaunchKernelGGL(k_maccum, dim3(cdiv(nwin, 256)), dim3(256), 0, s, (const Winner*)win.p, nwin, V, M,
-                                   mcount.p, (const double*)h->pts.p, (const MaskGeom*)d_geom.p, c.voxel_size,
-                                   (const unsigned long long*)mbitmap.p, (const unsigned*)mrank.p, acc);
-                HMSG_CHECK_LAUNCH();
-                // append to the resident mask-cloud store
-                size_t need = (size_t)(h->masks3d.total + npts) * 3;
-                if (need > h->masks3d.pts.n) {
-                    DevBuf<double> bigger;
-                    bigger.alloc(std::max(need * 2, (size_t)1 << 20));
-                    if (h->masks3d.total)
-                        HIP_TRY(hipMemcpyAsync(bigger.p, h->masks3d.pts.p, (size_t)h->masks3d.total * 24,
-                                               hipMemcpyDeviceToDevice, s));
-                    HIP_TRY(hipStreamSynchronize(s));
-                    bigger.swap(h->masks3d.pts);
-                }
-                hipLaunchKernelGGL(k_mfinal, dim3(cdiv((size_t)nwords, 256)), dim3(256), 0, s,
-                                   (const unsigned long long*)mbitmap.p, (const unsigned*)mrank.p, nwords,
-                                   (const MaskGeom*)d_geom.p, nmask, c.voxel_size, acc,
-                                   h->masks3d.pts.p + (size_t)h->masks3d.total * 3);
-                HMSG_CHECK_LAUNCH();
-                // per-mask point offsets = rank at the mask's first word
-                int ng = 0;
-                for (int i = 0; i < nmask; ++i)
-                    if (hg[i].nx) hoffidx[ng++] = hg[i].word_off;
-                HIP_TRY(hipMemcpyAsync(d_offidx.p, hoffidx.data(), (size_t)ng * 8, hipMemcpyHostToDevice, s));
-                hipLaunchKernelGGL(k_gather_u32, dim3(cdiv(ng, 256)), dim3(256), 0, s, (const unsigned*)mrank.p,
-                                   (const long long*)d_offidx.p, ng, d_offval.p);
-                HMSG_CHECK_LAUNCH();
-                HIP_TRY(hipMemcpyAsync(hoffval.data(), d_offval.p, (size_t)ng * 4, hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipStreamSynchronize(s));
-                // sizes: difference of consecutive starts (empty masks get 0)
-                std::vector<long long> start(nmask + 1, npts);
-                int k = 0;
-                for (int i = 0; i < nmask; ++i)
-                    if (hg[i].nx) start[i] = hoffval[k++];
-                for (int i = nmask - 1; i >= 0; --i)
-                    if (!hg[i].nx) start[i] = start[i + 1];
-                for (int i = 0; i < nmask; ++i) h->masks3d.off.push_back(h->masks3d.total + start[i + 1]);
-            } else {
-                for (int i = 0; i < nmask; ++i) h->masks3d.off.push_back(h->masks3d.total);
-            }
-            h->masks3d.total += npts;
+        // ---- 3-D masks of the batch
+        const int nmask = nb * MS;
+        const unsigned nchunks = cdiv(HW * nb, MCHUNK);
+        for (int i = 0; i < nmask; ++i)
+            for (int a = 0; a < 6; ++a) hb[(size_t)i * 6 + a] = a < 3 ? ~0ull : 0ull;
+        HIP_TRY(hipMemcpyAsync(d_bounds.p, hb.data(), (size_t)nmask * 48, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemsetAsync(d_dstat.p, 0, (size_t)nmask * 16, s));
+        {
+            ProfScope ps(h->prof, s, "k_mbounds", (double)nb * (double)HW * (6.0 + 8.0 * NW));
+            hipLaunchKernelGGL(k_mbounds, dim3(nchunks), dim3(256), 0, s, (const int*)h->nn.p, (const unsigned long long*)h->bits.p,
+                               (const unsigned short*)h->depth.p, HW, W, fb0, nb, NW, MS, (const double*)h->pts.p, d_bounds.p,
+                               d_dstat.p);
         }
+        HMSG_CHECK_LAUNCH();
+        HIP_TRY(hipMemcpyAsync(hb.data(), d_bounds.p, (size_t)nmask * 48, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(hd.data(), d_dstat.p, (size_t)nmask * 16, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        long long nwords = 0;
+        for (int i = 0; i < nmask; ++i) {
+            MaskGeom& mg = hg[i];
+            mg.word_off = nwords;
+            mg.pad = 0;
+            const bool none = hb[(size_t)i * 6] == ~0ull;   // no valid pixel in this mask
+            const bool far = !none && (double)hd[(size_t)i * 2] / (double)hd[(size_t)i * 2 + 1] > filt_mm;
+            if (none || far) {
+                mg.ox = mg.oy = mg.oz = 0.0;
+                mg.nx = mg.ny = mg.nz = 0;
+                continue;
+            }
+            double mn[3], mx[3];
+            for (int a = 0; a < 3; ++a) {
+                mn[a] = dec_f64(hb[(size_t)i * 6 + a]);
+                mx[a] = dec_f64(hb[(size_t)i * 6 + 3 + a]);
+            }
+            mg.ox = mn[0] - c.voxel_size * 0.5;
+            mg.oy = mn[1] - c.voxel_size * 0.5;
+            mg.oz = mn[2] - c.voxel_size * 0.5;
+            mg.nx = (int)std::floor((mx[0] - mg.ox) / c.voxel_size) + 2;
+            mg.ny = (int)std::floor((mx[1] - mg.oy) / c.voxel_size) + 2;
+            mg.nz = (int)std::floor((mx[2] - mg.oz) / c.voxel_size) + 2;
+            nwords += ((long long)mg.nx * mg.ny * mg.nz + 63) / 64;
+        }
+        long long npts = 0;
+        std::vector<long long> start(nmask + 1, 0);
+        if (nwords) {
+            HMSG_REQUIRE(nwords < (1ll << 31), HMSG_ERR_UNSUPPORTED, "mask grids of one frame batch exceed 2^31 words");
+            HIP_TRY(hipMemcpyAsync(d_geom.p, hg.data(), (size_t)nmask * sizeof(MaskGeom), hipMemcpyHostToDevice, s));
+            mbitmap.ensure((size_t)nwords);
+            mrank.ensure((size_t)nwords);
+            chunk_recs.ensure((size_t)nchunks + 1);
+            HIP_TRY(hipMemsetAsync(mbitmap.p, 0, (size_t)nwords * 8, s));
+            {
+                ProfScope ps(h->prof, s, "k_mmark", (double)nb * (double)HW * (4.0 + 8.0 * NW));
+                hipLaunchKernelGGL(k_mmark, dim3(nchunks), dim3(256), 0, s, (const int*)h->nn.p, (const unsigned long long*)h->bits.p,
+                                   HW, W, fb0, nb, NW, MS, (const double*)h->pts.p, (const MaskGeom*)d_geom.p, c.voxel_size,
+                                   mbitmap.p, chunk_recs.p);
+            }
+            HMSG_CHECK_LAUNCH();
+            npts = (long long)hmsg_bitmap_rank(mbitmap.p, mrank.p, (size_t)nwords, s, h->scan_tmp);
+            unsigned long long nrec = 0;
+            hmsg_scan_u32(chunk_recs.p, chunk_recs.p, (size_t)nchunks, s, h->scan_tmp, &nrec);
+            HMSG_REQUIRE(npts < (1ll << 32) && nrec < (1ull << 32), HMSG_ERR_UNSUPPORTED, "mask batch too large");
+            sb.keys.ensure((size_t)std::max<unsigned long long>(nrec, 1));
+            sb.vals.ensure((size_t)std::max<unsigned long long>(nrec, 1));
+            {
+                ProfScope ps(h->prof, s, "k_memit", (double)nb * (double)HW * (4.0 + 8.0 * NW) + (double)nrec * 12.0);
+                hipLaunchKernelGGL(k_memit, dim3(nchunks), dim3(256), 0, s, (const int*)h->nn.p, (const unsigned long long*)h->bits.p,
+                                   HW, W, fb0, nb, NW, MS, (const double*)h->pts.p, (const MaskGeom*)d_geom.p, c.voxel_size,
+                                   (const unsigned long long*)mbitmap.p, (const unsigned*)mrank.p, (const unsigned*)chunk_recs.p,
+                                   sb.keys.p, sb.vals.p);
+            }
+            HMSG_CHECK_LAUNCH();
+            {
+                ProfScope ps(h->prof, s, "sort_mask_recs", (double)nrec * 12.0 * 4.0);
+                hmsg_sort_pairs(sb, (size_t)nrec, bits_for((unsigned long long)npts), s);
+            }
+            rec_off.ensure((size_t)npts + 1);
+            hmsg_sort_segment_starts(sb.res_keys, (size_t)nrec, rec_off.p, (unsigned)npts, s);
+            // append to the resident mask-cloud store
+            size_t need = (size_t)(h->masks3d.total + npts) * 3;
+            if (need > h->masks3d.pts.n) {
+                DevBuf<double> bigger;
+                bigger.alloc(std::max(need * 2, (size_t)1 << 20));
+                if (h->masks3d.total)
+                    HIP_TRY(hipMemcpyAsync(bigger.p, h->masks3d.pts.p, (size_t)h->masks3d.total * 24, hipMemcpyDeviceToDevice, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                bigger.swap(h->masks3d.pts);
+            }
+            {
+                ProfScope ps(h->prof, s, "k_mwalk", (double)nrec * 8.0 + (double)npts * 32.0);
+                hipLaunchKernelGGL(k_mwalk, dim3(cdiv((size_t)npts, 64)), dim3(64), 0, s, (const unsigned*)rec_off.p,
+                                   (const unsigned long long*)sb.res_vals, npts, (const double*)h->pts.p,
+                                   h->masks3d.pts.p + (size_t)h->masks3d.total * 3);
+            }
+            HMSG_CHECK_LAUNCH();
+            // per-mask point offsets = rank at the mask's first word
+            int ng = 0;
+            for (int i = 0; i < nmask; ++i)
+                if (hg[i].nx) hoffidx[ng++] = hg[i].word_off;
+            HIP_TRY(hipMemcpyAsync(d_offidx.p, hoffidx.data(), (size_t)ng * 8, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_gather_u32, dim3(cdiv(ng, 256)), dim3(256), 0, s, (const unsigned*)mrank.p,
+                               (const long long*)d_offidx.p, ng, d_offval.p);
+            HMSG_CHECK_LAUNCH();
+            HIP_TRY(hipMemcpyAsync(hoffval.data(), d_offval.p, (size_t)ng * 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            // sizes: difference of consecutive starts (empty masks get 0)
+            start.assign(nmask + 1, npts);
+            int k = 0;
+            for (int i = 0; i < nmask; ++i)
+                if (hg[i].nx) start[i] = hoffval[k++];
+            for (int i = nmask - 1; i >= 0; --i)
+                if (!hg[i].nx) start[i] = start[i + 1];
+        }
+        // the store keeps the first nmask[f] masks of every frame
+        for (int fl = 0; fl < nb; ++fl) {
+            const int nm = h->nmask[(size_t)fb0 + fl];
+            for (int i = 0; i < nm; ++i) h->masks3d.off.push_back(h->masks3d.total + start[(size_t)fl * MS + i + 1]);
+            h->mask_first.push_back(h->mask_first.back() + nm);
+            // (slots nm .. MS-1 of the frame hold no pixel: their start equals the next one's, nothing is skipped)
+        }
+        h->masks3d.total += npts;
         h->n_fused = fb0 + nb;
     }
     h->feats.alloc((size_t)std::max<long long>(V, 1) * D);
@@ -611,18 +677,18 @@ void hmsg_fuse(hmsg_ctx* h) {
 
 // hand-over of the encoder outputs of frames [first, first+n): membership bitsets + F_p tables
 void hmsg_bitset_and_fp(hmsg_ctx* h, int first, int n, int M, const unsigned char* d_masks, const float* d_fg,
-                        const float* d_fm, const float* d_fc) {
+                        const float* d_fm, const float* d_fc, const int* d_nmask) {
     const size_t HW = (size_t)h->cfg.height * h->cfg.width;
     const int D = h->cfg.feat_dim;
     const size_t chunks = (HW + 15) / 16;
     {
-        ProfScope ps(h->prof, h->stream, "k_bitset", (double)n * (double)HW * (M + 8.0));
+        ProfScope ps(h->prof, h->stream, "k_bitset", (double)n * (double)HW * (M + 8.0 * h->NW));
         hipLaunchKernelGGL(k_bitset, dim3(cdiv(chunks * n, 256)), dim3(256), 0, h->stream, d_masks, M, HW, n, (size_t)M * HW,
-                           h->bits.p + (size_t)first * HW);
+                           d_nmask, h->NW, h->bits.p + (size_t)first * HW * h->NW);
     }
     HMSG_CHECK_LAUNCH();
     const float wm = (float)h->cfg.clip_masked_weight, wc = (float)(1.0 - h->cfg.clip_masked_weight);
-    hipLaunchKernelGGL(k_fp, dim3(n), dim3(256), 0, h->stream, d_fg, d_fm, d_fc, M, D, wm, wc,
-                       h->fp.p + (size_t)first * M * D);
+    hipLaunchKernelGGL(k_fp, dim3(n), dim3(256), 0, h->stream, d_fg, d_fm, d_fc, M, D, wm, wc, d_nmask, h->MS,
+                       h->fp.p + (size_t)first * h->MS * D);
     HMSG_CHECK_LAUNCH();
 }

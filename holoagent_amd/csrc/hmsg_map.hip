@@ -16,7 +16,6 @@
 
 #include <algorithm>
 
-#define FIX_SCALE 70368744177664.0 /* 2^46: 1.4e-14 m resolution */
 
 // ------------------------------------------------------------------------------------------ scans
 // Exclusive prefix sum of u32, ONE launch: tiles of 1024 elements, decoupled look-back.  Every tile publishes
@@ -183,51 +182,62 @@ __global__ void k_mark(const unsigned short* __restrict__ depth, const double* _
     }
 }
 
-struct VoxAcc {                 // per-slot accumulators (SoA)
-    long long* sx;
-    long long* sy;
-    long long* sz;
+struct VoxAcc {                 // per-slot colour / count accumulators (SoA)
     unsigned long long* sr;
     unsigned long long* sg;
     unsigned long long* sb;
     unsigned* n;
 };
 
-// Consecutive pixels of an image row mostly fall into the same voxel, and every global atomic costs a
-// 32-64 B memory transaction (measured: 60 GB of WRITE_SIZE for 307 M pixels with per-pixel atomics), so each
-// wave first adds up its runs of equal slots with a segmented scan; only the last lane of a run touches memory.
-__global__ void k_accum(const unsigned short* __restrict__ depth, const unsigned char* __restrict__ rgb,
-                        const double* __restrict__ pose, CamK cam, float scale, int H, int W, int F, GridGeom g,
-                        const unsigned long long* __restrict__ bitmap, const unsigned* __restrict__ rank, VoxAcc acc) {
+// ---- ordered voxel sums (A2) -------------------------------------------------------------------------------
+// Open3D's VoxelDownSample adds the points of a voxel in INPUT order (frame-major, pixel row-major here:
+// graph.py:339-348) in float64, and the nearest-neighbour decisions downstream hinge on the last bit of the
+// centroids, so the sums are taken in exactly that order:
+//   k_slots      pixel -> voxel slot (u32, kept for phase 2), colours / counts per run with integer atomics,
+//                number of runs per 4096-pixel chunk.  A run = consecutive pixels of one image row (inside one
+//                64-pixel wave slice) that fall into the same voxel (~8 pixels).
+//   k_emit_runs  run records (key = slot, value = first pixel << 8 | length) written in input order
+//   stable sort by slot (hmsg_sort.hip), segment starts
+//   k_accum_ordered  one lane per voxel walks its runs in order: back-project again, s += p, centroid = s / n
+#define RUN_CHUNK 4096
+__device__ __forceinline__ unsigned pixel_slot(const unsigned short* __restrict__ depth, const double* __restrict__ pose,
+                                               const CamK& cam, float scale, int W, size_t HW, size_t i, const GridGeom& g,
+                                               const unsigned long long* __restrict__ bitmap, const unsigned* __restrict__ rank) {
+    const int f = (int)(i / HW);
+    const int p = (int)(i - (size_t)f * HW);
+    const int y = p / W, x = p - y * W;
+    double wx, wy, wz;
+    if (!backproject(depth[i], x, y, cam, scale, pose + (size_t)f * 16, wx, wy, wz)) return 0xffffffffu;
+    int ix, iy, iz;
+    cell_of(g, wx, wy, wz, ix, iy, iz);
+    const long long lin = lin_of(g, ix, iy, iz);
+    const unsigned long long word = bitmap[lin >> 6];
+    return rank[lin >> 6] + (unsigned)__popcll(word & ((1ull << (lin & 63)) - 1ull));
+}
+
+__global__ void __launch_bounds__(256) k_slots(const unsigned short* __restrict__ depth, const unsigned char* __restrict__ rgb,
+                                               const double* __restrict__ pose, CamK cam, float scale, int H, int W, int F,
+                                               GridGeom g, const unsigned long long* __restrict__ bitmap,
+                                               const unsigned* __restrict__ rank, VoxAcc acc, unsigned* __restrict__ slots,
+                                               unsigned* __restrict__ chunk_runs) {
+    __shared__ unsigned s_runs;
+    if (threadIdx.x == 0) s_runs = 0u;
+    __syncthreads();
     const size_t HW = (size_t)H * W;
     const size_t total = HW * F;
     const int lane = threadIdx.x & 63;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    // wave-uniform trip count (the wave's first lane decides), so the shuffles below see all 64 lanes
-    for (size_t i0 = (size_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < total; i0 += stride) {
-        const size_t i = i0 + lane;
-        bool valid = i < total;
+    unsigned myruns = 0;
+    for (int it = 0; it < RUN_CHUNK / 256; ++it) {
+        const size_t i = (size_t)blockIdx.x * RUN_CHUNK + (size_t)it * 256 + threadIdx.x;
+        const bool in_range = i < total;
         unsigned slot = 0xffffffffu;
-        long long qx = 0, qy = 0, qz = 0;
         unsigned cr = 0, cg = 0, cb = 0, cn = 0;
-        if (valid) {
-            int f = (int)(i / HW);
-            int p = (int)(i - (size_t)f * HW);
-            int y = p / W, x = p - y * W;
-            double wx, wy, wz;
-            valid = backproject(depth[i], x, y, cam, scale, pose + (size_t)f * 16, wx, wy, wz);
-            if (valid) {
-                int ix, iy, iz;
-                cell_of(g, wx, wy, wz, ix, iy, iz);
-                long long lin = lin_of(g, ix, iy, iz);
-                unsigned long long word = bitmap[lin >> 6];
-                slot = rank[lin >> 6] + (unsigned)__popcll(word & ((1ull << (lin & 63)) - 1ull));
-                double cx = __dadd_rn(g.ox, __dmul_rn((double)ix, g.vs));
-                double cy = __dadd_rn(g.oy, __dmul_rn((double)iy, g.vs));
-                double cz = __dadd_rn(g.oz, __dmul_rn((double)iz, g.vs));
-                qx = (long long)llrint((wx - cx) * FIX_SCALE);
-                qy = (long long)llrint((wy - cy) * FIX_SCALE);
-                qz = (long long)llrint((wz - cz) * FIX_SCALE);
+        int x = 0;
+        if (in_range) {
+            slot = pixel_slot(depth, pose, cam, scale, W, HW, i, g, bitmap, rank);
+            slots[i] = slot;
+            x = (int)(i % (size_t)W);
+            if (slot != 0xffffffffu) {
                 const unsigned char* c = rgb + i * 3;
                 cr = c[0];
                 cg = c[1];
@@ -235,31 +245,99 @@ __global__ void k_accum(const unsigned short* __restrict__ depth, const unsigned
                 cn = 1;
             }
         }
-        // segmented inclusive scan over runs of equal slot (integer sums: order-independent, exact)
-        unsigned prev = __shfl_up(slot, 1);
-        int flag = (lane == 0 || prev != slot) ? 1 : 0;
+        // segmented inclusive scan over runs of equal slot within an image row (integer sums: exact in any order)
+        const unsigned prev = __shfl_up(slot, 1);
+        int flag = (lane == 0 || prev != slot || x == 0) ? 1 : 0;
+        const int head = flag;
         for (int d = 1; d < 64; d <<= 1) {
-            long long tx = __shfl_up(qx, d), ty = __shfl_up(qy, d), tz = __shfl_up(qz, d);
             unsigned tr = __shfl_up(cr, d), tg = __shfl_up(cg, d), tb = __shfl_up(cb, d), tn = __shfl_up(cn, d);
             int tf = __shfl_up(flag, d);
             if (lane >= d && !flag) {
-                qx += tx; qy += ty; qz += tz;
                 cr += tr; cg += tg; cb += tb; cn += tn;
                 flag = tf;
             }
         }
-        unsigned nxt = __shfl_down(slot, 1);
-        const bool tail = lane == 63 || nxt != slot;
+        const int nhead = __shfl_down(head, 1);
+        const bool tail = lane == 63 || nhead != 0;
         if (tail && slot != 0xffffffffu) {
-            atomicAdd((unsigned long long*)&acc.sx[slot], (unsigned long long)qx);
-            atomicAdd((unsigned long long*)&acc.sy[slot], (unsigned long long)qy);
-            atomicAdd((unsigned long long*)&acc.sz[slot], (unsigned long long)qz);
             atomicAdd(&acc.sr[slot], (unsigned long long)cr);
             atomicAdd(&acc.sg[slot], (unsigned long long)cg);
             atomicAdd(&acc.sb[slot], (unsigned long long)cb);
             atomicAdd(&acc.n[slot], cn);
+            ++myruns;
         }
     }
+    myruns = (unsigned)wave_sum_i32((int)myruns);
+    if (lane == 0 && myruns) atomicAdd(&s_runs, myruns);
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_runs[blockIdx.x] = s_runs;
+}
+
+__global__ void __launch_bounds__(256) k_emit_runs(const unsigned* __restrict__ slots, size_t total, int W,
+                                                   const unsigned* __restrict__ chunk_base, unsigned* __restrict__ keys,
+                                                   unsigned long long* __restrict__ vals) {
+    __shared__ unsigned s_w[4];
+    __shared__ unsigned s_run;
+    if (threadIdx.x == 0) s_run = chunk_base[blockIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int it = 0; it < RUN_CHUNK / 256; ++it) {
+        const size_t i = (size_t)blockIdx.x * RUN_CHUNK + (size_t)it * 256 + threadIdx.x;
+        const bool in_range = i < total;
+        const unsigned slot = in_range ? slots[i] : 0xffffffffu;
+        const int x = in_range ? (int)(i % (size_t)W) : 0;
+        const unsigned prev = __shfl_up(slot, 1);
+        const bool head = lane == 0 || prev != slot || x == 0;
+        const unsigned long long heads = __ballot(head);
+        const int nhead = __shfl_down(head ? 1 : 0, 1);
+        const bool tail = (lane == 63 || nhead != 0) && slot != 0xffffffffu;
+        const unsigned long long tails = __ballot(tail);
+        if (lane == 0) s_w[w] = (unsigned)__popcll(tails);
+        __syncthreads();
+        unsigned base = s_run;
+        for (int q = 0; q < w; ++q) base += s_w[q];
+        if (tail) {
+            const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull));
+            const int start_lane = 63 - __clzll(below);
+            const unsigned len = (unsigned)(lane - start_lane + 1);
+            const unsigned pos = base + (unsigned)__popcll(tails & ((1ull << lane) - 1ull));
+            keys[pos] = slot;
+            vals[pos] = ((unsigned long long)(i - (size_t)(lane - start_lane)) << 8) | (unsigned long long)len;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_run += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+}
+
+// centroid = (sequential float64 sum of the voxel's points in input order) / count  (o3d_voxel_down_sample)
+__global__ void k_accum_ordered(const unsigned short* __restrict__ depth, const double* __restrict__ pose, CamK cam, float scale,
+                                int W, size_t HW, long long V, const unsigned* __restrict__ off,
+                                const unsigned long long* __restrict__ runs, const unsigned* __restrict__ cnt,
+                                double* __restrict__ pts) {
+    const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    for (unsigned r = off[v]; r < off[v + 1]; ++r) {
+        const unsigned long long rec = runs[r];
+        const size_t i0 = (size_t)(rec >> 8);
+        const int len = (int)(rec & 255ull);
+        const int f = (int)(i0 / HW);
+        const int p = (int)(i0 - (size_t)f * HW);
+        const int y = p / W, x0 = p - y * W;
+        const double* T = pose + (size_t)f * 16;
+        for (int j = 0; j < len; ++j) {
+            double wx, wy, wz;
+            backproject(depth[i0 + j], x0 + j, y, cam, scale, T, wx, wy, wz);
+            sx = __dadd_rn(sx, wx);
+            sy = __dadd_rn(sy, wy);
+            sz = __dadd_rn(sz, wz);
+        }
+    }
+    const double n = (double)cnt[v];
+    pts[v * 3 + 0] = __ddiv_rn(sx, n);
+    pts[v * 3 + 1] = __ddiv_rn(sy, n);
+    pts[v * 3 + 2] = __ddiv_rn(sz, n);
 }
 
 // slot -> cell coordinates (one thread per bitmap word)
@@ -284,17 +362,10 @@ __global__ void k_slot_cells(const unsigned long long* __restrict__ bitmap, cons
     }
 }
 
-__global__ void k_finalize(VoxAcc acc, const int* __restrict__ cell, GridGeom g, long long V, double* __restrict__ pts,
-                           double* __restrict__ cols) {
+__global__ void k_finalize(VoxAcc acc, long long V, double* __restrict__ cols) {
     long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= V) return;
     double n = (double)acc.n[s];
-    double corner[3] = {__dadd_rn(g.ox, __dmul_rn((double)cell[s * 3 + 0], g.vs)),
-                        __dadd_rn(g.oy, __dmul_rn((double)cell[s * 3 + 1], g.vs)),
-                        __dadd_rn(g.oz, __dmul_rn((double)cell[s * 3 + 2], g.vs))};
-    pts[s * 3 + 0] = corner[0] + ((double)acc.sx[s] / n) / FIX_SCALE;
-    pts[s * 3 + 1] = corner[1] + ((double)acc.sy[s] / n) / FIX_SCALE;
-    pts[s * 3 + 2] = corner[2] + ((double)acc.sz[s] / n) / FIX_SCALE;
     cols[s * 3 + 0] = ((double)acc.sr[s] / 255.0) / n;
     cols[s * 3 + 1] = ((double)acc.sg[s] / 255.0) / n;
     cols[s * 3 + 2] = ((double)acc.sb[s] / 255.0) / n;
@@ -563,23 +634,38 @@ void hmsg_build_map(hmsg_ctx* h) {
     unsigned long long V0 = hmsg_bitmap_rank(h->bitmap.p, h->rank.p, (size_t)g.nwords, s, h->scan_tmp);
     h->V0 = (long long)V0;
 
-    DevBuf<long long> sxyz;
     DevBuf<unsigned long long> srgb;
-    DevBuf<unsigned> sn;
-    sxyz.alloc(V0 * 3);
+    DevBuf<unsigned> sn, slots, chunk_runs;
     srgb.alloc(V0 * 3);
     sn.alloc(V0);
-    sxyz.zero(s);
     srgb.zero(s);
     sn.zero(s);
-    VoxAcc acc{sxyz.p, sxyz.p + V0, sxyz.p + 2 * V0, srgb.p, srgb.p + V0, srgb.p + 2 * V0, sn.p};
+    slots.alloc(total);
+    const unsigned nchunks = cdiv(total, RUN_CHUNK);
+    chunk_runs.alloc((size_t)nchunks + 1);
+    VoxAcc acc{srgb.p, srgb.p + V0, srgb.p + 2 * V0, sn.p};
     {
-        ProfScope ps(h->prof, s, "k_accum", (double)total * 5.0 + (double)V0 * 56.0);
-        hipLaunchKernelGGL(k_accum, dim3(nblk), dim3(256), 0, s, (const unsigned short*)h->depth.p,
+        ProfScope ps(h->prof, s, "k_slots", (double)total * 9.0 + (double)V0 * 28.0);
+        hipLaunchKernelGGL(k_slots, dim3(nchunks), dim3(256), 0, s, (const unsigned short*)h->depth.p,
                            (const unsigned char*)h->rgb.p, (const double*)h->pose.p, h->cam, scale, H, W, F, g,
-                           (const unsigned long long*)h->bitmap.p, (const unsigned*)h->rank.p, acc);
+                           (const unsigned long long*)h->bitmap.p, (const unsigned*)h->rank.p, acc, slots.p, chunk_runs.p);
     }
     HMSG_CHECK_LAUNCH();
+    unsigned long long nruns = 0;
+    hmsg_scan_u32(chunk_runs.p, chunk_runs.p, (size_t)nchunks, s, h->scan_tmp, &nruns);
+    SortBufs sb;
+    sb.keys.alloc((size_t)std::max<unsigned long long>(nruns, 1));
+    sb.vals.alloc((size_t)std::max<unsigned long long>(nruns, 1));
+    hipLaunchKernelGGL(k_emit_runs, dim3(nchunks), dim3(256), 0, s, (const unsigned*)slots.p, total, W,
+                       (const unsigned*)chunk_runs.p, sb.keys.p, sb.vals.p);
+    HMSG_CHECK_LAUNCH();
+    {
+        ProfScope ps(h->prof, s, "sort_runs", (double)nruns * 12.0 * 4.0);
+        hmsg_sort_pairs(sb, (size_t)nruns, bits_for(V0), s);
+    }
+    DevBuf<unsigned> run_off;
+    run_off.alloc(V0 + 1);
+    hmsg_sort_segment_starts(sb.res_keys, (size_t)nruns, run_off.p, (unsigned)V0, s);
     DevBuf<int> cell;
     cell.alloc(V0 * 3);
     hipLaunchKernelGGL(k_slot_cells, dim3(cdiv((size_t)g.nwords, 256)), dim3(256), 0, s,
@@ -588,8 +674,13 @@ void hmsg_build_map(hmsg_ctx* h) {
     DevBuf<double> pts0, cols0;
     pts0.alloc(V0 * 3);
     cols0.alloc(V0 * 3);
-    hipLaunchKernelGGL(k_finalize, dim3(cdiv(V0, 256)), dim3(256), 0, s, acc, (const int*)cell.p, g, (long long)V0,
-                       pts0.p, cols0.p);
+    {
+        ProfScope ps(h->prof, s, "k_accum_ordered", (double)total * 2.0 + (double)nruns * 8.0 + (double)V0 * 32.0);
+        hipLaunchKernelGGL(k_accum_ordered, dim3(cdiv(V0, 64)), dim3(64), 0, s, (const unsigned short*)h->depth.p,
+                           (const double*)h->pose.p, h->cam, scale, W, (size_t)H * W, (long long)V0, (const unsigned*)run_off.p,
+                           (const unsigned long long*)sb.res_vals, (const unsigned*)sn.p, pts0.p);
+    }
+    hipLaunchKernelGGL(k_finalize, dim3(cdiv(V0, 256)), dim3(256), 0, s, acc, (long long)V0, cols0.p);
     HMSG_CHECK_LAUNCH();
 
     // remove_radius_outlier (graph.py:355-358)

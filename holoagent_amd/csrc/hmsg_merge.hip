@@ -667,7 +667,7 @@ void hmsg_merge(hmsg_ctx* h) {
     m.minpts = c.merge_dbscan_min;
     m.iou_thresh = c.iou_thresh;
     HMSG_REQUIRE(c.iou_thresh >= 0.0, HMSG_ERR_UNSUPPORTED, "pipeline.iou_thresh must be >= 0");
-    const int F = h->n_fused, M = h->M;
+    const int F = h->n_fused;
     // the 3-D masks of all frames seed the pool (device to device)
     const long long total = h->masks3d.total;
     m.pool.alloc((size_t)std::max<long long>(total * 2, 1 << 16) * 3);
@@ -676,7 +676,7 @@ void hmsg_merge(hmsg_ctx* h) {
     if (total) HIP_TRY(hipMemcpyAsync(m.pool.p, h->masks3d.pts.p, (size_t)total * 24, hipMemcpyDeviceToDevice, h->stream));
     m.pool_used = total;
     // AABBs of the frame masks (device reduction)
-    std::vector<SegDesc> msegs((size_t)F * M);
+    std::vector<SegDesc> msegs((size_t)h->mask_first[F]);
     for (size_t id = 0; id < msegs.size(); ++id) {
         msegs[id].pt_base = h->masks3d.off[id];
         msegs[id].n = (int)(h->masks3d.off[id + 1] - h->masks3d.off[id]);
@@ -686,9 +686,10 @@ void hmsg_merge(hmsg_ctx* h) {
     // Empty masks are left out: an empty cloud never pairs (find_overlapping_ratio_faiss returns 0 for it), so it
     // stays a singleton through every step and is dropped by the min-points filter at the end (graph.py:445-448).
     for (int f = 0; f < F; ++f) {
-        frames[f].reserve(M);
-        for (int i = 0; i < M; ++i) {
-            const SegDesc& sd = msegs[(size_t)f * M + i];
+        const int nm = (int)(h->mask_first[f + 1] - h->mask_first[f]);
+        frames[f].reserve(nm);
+        for (int i = 0; i < nm; ++i) {
+            const SegDesc& sd = msegs[(size_t)h->mask_first[f] + i];
             if (sd.n == 0) continue;
             frames[f].emplace_back();
             Cloud& k = frames[f].back();

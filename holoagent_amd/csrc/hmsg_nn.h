@@ -27,15 +27,14 @@ struct NNBest {
     int idx;
 };
 
-// canonical tie rule (oracle NN_TIE="lowest"): candidates whose squared distance is within 1e-9 (relative) of
-// the minimum are ties -> lowest index wins
+// Tie rule: the squared distance is evaluated exactly as scipy's cKDTree does for 3-D points
+// (sqeuclidean_distance_double: ((dx*dx) + dy*dy) + dz*dz in float64, no FMA), so a candidate that is closer by
+// even one ulp wins like it does there.  Only BIT-EQUAL distances are ties; they go to the lowest index
+// (oracle NN_TIE = "exact"; cKDTree's own choice among bit-equal candidates depends on its traversal order).
 __device__ __forceinline__ void nn_consider(NNBest& best, int q, double d2) {
-    if (d2 < best.d2 * (1.0 - 1e-9)) {
+    if (d2 < best.d2 || (d2 == best.d2 && q < best.idx)) {
         best.d2 = d2;
         best.idx = q;
-    } else if (d2 <= best.d2 * (1.0 + 1e-9)) {
-        if (q < best.idx) best.idx = q;
-        if (d2 < best.d2) best.d2 = d2;
     }
 }
 __device__ __forceinline__ double nn_dist2(const double* __restrict__ p, double qx, double qy, double qz) {

@@ -345,6 +345,7 @@ class Graph:
         self._text_cache = {}
         self.graph_path = _get(cfg, "main.graph_path")
         self._label_feats = None       # (text feats, class names) for identify_object
+        self._K, self._poses = None, []
 
     # ------------------------------------------------------------------ text features
     def get_text_feats_multiple_templates(self, words: Sequence[str]) -> np.ndarray:
@@ -371,7 +372,7 @@ class Graph:
         H, W = depth0.shape[:2]
         merge = {"sequential": 0, "hierarchical": 1}[str(p("merge_type", "sequential"))]
         self.scene = Scene(lib_=self.L, device_id=int(_get(self.cfg, "main.device_id", 0)), feat_dim=self.clip_feat_dim,
-                           height=H, width=W, max_frames=len(ids), max_masks=int(p("max_masks", 64)),
+                           height=H, width=W, max_frames=len(ids), max_masks=int(p("max_masks", 256)),
                            voxel_size=float(p("voxel_size", 0.05)), init_overlap_thresh=float(p("init_overlap_thresh", 0.75)),
                            overlap_thresh_factor=float(p("overlap_thresh_factor", 0.025)), iou_thresh=float(p("iou_thresh", 0.05)),
                            clip_masked_weight=float(p("clip_masked_weight", 0.4418)),
@@ -381,6 +382,8 @@ class Graph:
         self._poses, self._K = [], None
         for b0 in range(0, len(ids), B):                                  # loop A (graph.py:339-345)
             fr = [self.dataset[i] for i in ids[b0:b0 + B]]
+            fr = [(f[0].resize(f[1].size) if hasattr(f[0], "resize") and hasattr(f[0], "size") and f[0].size != f[1].size
+                   else f[0],) + tuple(f[1:]) for f in fr]               # graph.py:342-343
             rgb = np.ascontiguousarray(np.stack([np.asarray(f[0], dtype=np.uint8)[..., :3] for f in fr]))
             dep = np.ascontiguousarray(np.stack([np.asarray(f[1]).astype(np.uint16) for f in fr]))
             pose = np.ascontiguousarray(np.stack([np.asarray(f[2], dtype=np.float64) for f in fr]))
@@ -389,20 +392,29 @@ class Graph:
             sc.add_frames(rgb, dep, pose, self._K)
         sc.finalize_map()
         self.full_pcd = _Pcd(sc.map_points())
-        M = None
         n_done = 0
+        D = self.clip_feat_dim
         for b0 in range(0, len(ids), B):                                  # loop B (graph.py:373-411)
-            outs = [self.encoders.extract(np.asarray(self.dataset[i][0])) for i in ids[b0:b0 + B]]
-            M = M or max(o["masks"].shape[0] for o in outs)
-            def pad(a, rows):
-                out = np.zeros((rows,) + a.shape[1:], a.dtype)
-                out[: a.shape[0]] = a
+            outs = []
+            for i in ids[b0:b0 + B]:
+                rgb_i, depth_i = self.dataset[i][0], self.dataset[i][1]
+                if hasattr(rgb_i, "size") and hasattr(rgb_i, "resize") and rgb_i.size != depth_i.size:
+                    rgb_i = rgb_i.resize(depth_i.size)                     # graph.py:378-379
+                outs.append(self.encoders.extract(np.asarray(rgb_i)))
+            # SAM returns a different number of masks for every frame: rows are padded to the batch maximum and the
+            # real counts are handed over with them (sam_clip_feats_extractor.py:167-169 softmaxes over the frame's own)
+            n_masks = np.array([np.asarray(o["masks"]).shape[0] for o in outs], np.int32)
+            M = max(int(n_masks.max()), 1)
+
+            def pad(a, tail):
+                out = np.zeros((M,) + tail, a.dtype)
+                out[: a.shape[0]] = a.reshape((a.shape[0],) + tail)
                 return out
-            masks = np.ascontiguousarray(np.stack([pad(o["masks"].astype(np.uint8), M) for o in outs]))
+            masks = np.ascontiguousarray(np.stack([pad(np.asarray(o["masks"]).astype(np.uint8), (H, W)) for o in outs]))
             fg = np.ascontiguousarray(np.stack([np.asarray(o["f_g"], np.float32).reshape(-1) for o in outs]))
-            fm = np.ascontiguousarray(np.stack([pad(np.asarray(o["f_masked"], np.float32), M) for o in outs]))
-            fc = np.ascontiguousarray(np.stack([pad(np.asarray(o["f_crop"], np.float32), M) for o in outs]))
-            sc.add_frame_features(n_done, masks, fg, fm, fc)
+            fm = np.ascontiguousarray(np.stack([pad(np.asarray(o["f_masked"], np.float32), (D,)) for o in outs]))
+            fc = np.ascontiguousarray(np.stack([pad(np.asarray(o["f_crop"], np.float32), (D,)) for o in outs]))
+            sc.add_frame_features(n_done, masks, fg, fm, fc, n_masks)
             n_done += len(outs)
         sc.fuse_frames()
         self.full_feats_array = sc.map_feats()
@@ -561,7 +573,8 @@ class Graph:
                         continue
                     img, _, pose, _, _ = self.dataset[v.img_id]
                     a = np.asarray(img)
-                    ok, md = check_object_in_view(a.shape[1], a.shape[0], self._K, np.linalg.inv(pose), pcd.points)
+                    K = self._K if self._K is not None else np.asarray(self.dataset.get_camera_intrinsics())
+                    ok, md = check_object_in_view(a.shape[1], a.shape[0], K, np.linalg.inv(pose), pcd.points)
                     if ok:
                         obj.view_ids.append(v.view_id)
                         v.object_ids.append(obj.object_id)

@@ -44,7 +44,7 @@ typedef struct hmsg_config {
     int32_t feat_dim;             /* CLIP_DIM (utils/constants.py:3-7): 512 / 768 / 1024 */
     int32_t height, width;        /* depth image size */
     int32_t max_frames;           /* capacity of the resident frame store */
-    int32_t max_masks;            /* masks per frame upper bound (<= 64 in this build) */
+    int32_t max_masks;            /* masks per frame upper bound (<= 256; SAM at points_per_side=12 yields <= 144) */
     double voxel_size;            /* pipeline.voxel_size */
     double depth_scale;           /* dataset scale, 1000.0 (hm3dsem.py:40, horizon.py:38) */
     double init_overlap_thresh;   /* pipeline.init_overlap_thresh */
@@ -113,9 +113,16 @@ int hmsg_get_map_points(const hmsg_t* h, double* xyz /*[V][3]*/, double* rgb /*[
 /* ---- loop B (graph.py:373-411): per frame the encoder outputs consumed by
  * extract_feats_per_pixel's fusion math (sam_clip_feats_extractor.py:159-191):
  * masks u8 [n][M][H][W] (0/1), F_g f32 [n][D], F_masked f32 [n][M][D], F_crop f32 [n][M][D].
- * Frames first_frame .. first_frame+n-1 must have been added; M <= cfg.max_masks. */
+ * M is the row stride of this hand-over (M <= cfg.max_masks; it may differ from call to call); n_masks i32 [n]
+ * (host or device, NULL = M for every frame) is the number of masks SAM actually returned for each frame:
+ * rows >= n_masks[f] are padding and are ignored -- the softmax of sam_clip_feats_extractor.py:167-169 runs over
+ * the frame's own masks only.  A frame with 0 masks makes the reference raise (it unpacks a 3-tuple,
+ * :163-164); here such a frame contributes zero features (its touched voxels still count the frame, graph.py:411)
+ * and no 3-D mask.  Frames first_frame .. first_frame+n-1 must have been added. */
 int hmsg_add_frame_features(hmsg_t* h, int32_t first_frame, int32_t n, int32_t M, const uint8_t* masks,
-                            const float* F_g, const float* F_masked, const float* F_crop);
+                            const float* F_g, const float* F_masked, const float* F_crop, const int32_t* n_masks);
+/* masks SAM returned for a frame (= number of 3-D masks the frame contributes) */
+int32_t hmsg_get_frame_num_masks(const hmsg_t* h, int32_t frame);
 
 /* A3+A4+A5 for every frame handed over so far: per-pixel feature fusion, NN snapping of frame and
  * mask points, last-writer-wins accumulation into the voxel feature map, 3-D mask clouds
@@ -124,9 +131,9 @@ int hmsg_fuse_frames(hmsg_t* h);
 int hmsg_get_map_feats(const hmsg_t* h, float* feats /*[V][D]*/, float* counter /*[V] or NULL*/);
 /* test/introspection: NN index of every pixel of a frame (-1 where depth == 0), i32 [H][W] */
 int hmsg_get_frame_nn(const hmsg_t* h, int32_t frame, int32_t* idx);
-/* test/introspection: F_p of a frame (sam_clip_feats_extractor.py:172-175), f32 [M][D] */
+/* test/introspection: F_p of a frame (sam_clip_feats_extractor.py:172-175), f32 [n_masks(frame)][D] */
 int hmsg_get_frame_fp(const hmsg_t* h, int32_t frame, float* f_p);
-/* 3-D masks of a frame (create_3d_masks): sizes i64 [M] then points f64 [sum][3] */
+/* 3-D masks of a frame (create_3d_masks): sizes i64 [n_masks(frame)] then points f64 [sum][3] */
 int hmsg_get_frame_mask_sizes(const hmsg_t* h, int32_t frame, int64_t* sizes);
 int hmsg_get_frame_mask_points(const hmsg_t* h, int32_t frame, double* xyz);
 
@@ -176,6 +183,11 @@ int hmsg_query_objects(hmsg_index_t* ix, int32_t Q, int32_t C, const float* T, c
                        int32_t* out_idx, int32_t* out_room, double* out_score);
 /* plain similarity S[Q][N] = T[Q][D] . E[N][D]^T in float64 (query_floor / query_hmsg_room GEMV) */
 int hmsg_similarity(hmsg_index_t* ix, int32_t Q, const float* T, double* S);
+
+/* ---- diagnostics (tests only): the stable (key, value) radix sort every order-faithful voxel mean is built on
+ * (Open3D VoxelDownSample adds points in input order; graph.py:348, generic.py:188, graph.py:456).  Host arrays,
+ * sorted in place by the low key_bits bits of the key, equal keys keep their input order. */
+int hmsg_test_sort_pairs(uint32_t* keys, uint64_t* vals, int64_t n, int32_t key_bits);
 
 #ifdef __cplusplus
 }

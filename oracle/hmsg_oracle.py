@@ -134,7 +134,15 @@ def o3d_remove_radius_outlier(points: np.ndarray, nb_points: int, radius: float)
     if points.shape[0] == 0:
         return np.zeros(0, np.int64)
     tree = cKDTree(points)
+    # nanoflann's radius search (Open3D KDTreeFlann::SearchRadius) is STRICT, d^2 < r^2; scipy's ball query is
+    # inclusive.  The two counts differ only for points that have a neighbour within one ulp of the sphere: those
+    # are recounted by brute force.
     cnt = tree.query_ball_point(points, radius, return_length=True, workers=-1)
+    inner = tree.query_ball_point(points, np.nextafter(radius, 0.0), return_length=True, workers=-1)
+    for i in np.nonzero(cnt != inner)[0]:
+        d = points - points[i]
+        d2 = d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]
+        cnt[i] = int(np.sum(d2 < radius * radius))
     return np.nonzero(cnt > nb_points)[0]
 
 
@@ -149,20 +157,28 @@ def faiss_flat_l2_nn_sqdist(queries: np.ndarray, base: np.ndarray) -> np.ndarray
     return (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]   # float32
 
 
-NN_TIE = "scipy"   # "scipy": cKDTree's own (arbitrary) choice on exact distance ties, as the reference runs;
-                   # "lowest": canonical rule of the HIP path -- lowest index among candidates whose distance is
-                   # within 5e-10 (relative) of the minimum.  Ties are structural (adjacent pixels at equal depth
-                   # are equidistant from the pixel between them), so a rule is needed for reproducibility.
+NN_TIE = "scipy"   # "scipy": cKDTree's own choice among bit-equal distances (traversal order), as the reference runs;
+                   # "exact": the HIP path's rule -- the squared distance evaluated like cKDTree does
+                   #          (((dx*dx) + dy*dy) + dz*dz in float64), strict minimum, and only BIT-EQUAL distances are
+                   #          ties, which go to the lowest index.  Differs from "scipy" on bit-equal ties only (a point
+                   #          that is the exact midpoint of two map voxels);
+                   # "lowest": round 1's wide rule (candidates within 5e-10 relative are ties) -- kept for the record.
 
 
 def nn_query(tree: cKDTree, pts: np.ndarray):
     """k=1 nearest neighbour, no distance cap (graph.py:409, generic.py:181, graph.py:458)."""
     if NN_TIE == "scipy" or pts.shape[0] == 0:
         return tree.query(pts, k=1, workers=-1)
-    k = min(4, tree.n)
+    k = min(8 if NN_TIE == "exact" else 4, tree.n)
     d, i = tree.query(pts, k=k, workers=-1)
     if k == 1:
         return d, i
+    if NN_TIE == "exact":
+        diff = tree.data[i] - pts[:, None, :]
+        d2 = (diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1]) + diff[..., 2] * diff[..., 2]
+        m = d2.min(axis=1, keepdims=True)
+        cand = np.where(d2 == m, i, np.iinfo(np.int64).max)
+        return np.sqrt(m[:, 0]), cand.min(axis=1)
     tied = d <= d[:, :1] * (1 + 5e-10)
     cand = np.where(tied, i, np.iinfo(np.int64).max)
     best = cand.min(axis=1)
@@ -218,6 +234,8 @@ def fuse_mask_feats(f_g, f_masked, f_crop, masked_weight):
     """:159-175.  F_l = normalize(w_m F_masked + (1-w_m) F_crop); phi = cos(F_l, F_g) (eps 1e-6);
     w = softmax_M(phi); F_p = normalize(w F_g + (1-w) F_l).  All float32."""
     f_g = np.asarray(f_g, np.float32).reshape(1, -1)
+    if np.asarray(f_masked).shape[0] == 0:       # the reference raises here (:163-164 returns a 3-tuple); no F_p rows
+        return np.zeros((0, f_g.shape[1]), np.float32)
     # reference: numpy f32 arrays * python float -> stays float32 (numpy weak scalars)
     fused = (np.float32(masked_weight) * f_masked.astype(np.float32)
              + np.float32(1 - masked_weight) * f_crop.astype(np.float32)).astype(np.float32)

@@ -14,10 +14,12 @@ def unpack_frames(z):
     F, H, W = z["depth"].shape
     M = z["f_masked"].shape[1]
     masks = np.unpackbits(z["masks"], axis=-1)[..., :W].astype(bool)
+    nm = z["n_masks"] if "n_masks" in z.files else np.full(F, M)
     frames = []
     for i in range(F):
-        frames.append(dict(rgb=z["rgb"][i], depth=z["depth"][i], pose=z["pose"][i], K=z["K"], masks=masks[i],
-                           f_g=z["f_g"][i], f_masked=z["f_masked"][i], f_crop=z["f_crop"][i]))
+        m = int(nm[i])
+        frames.append(dict(rgb=z["rgb"][i], depth=z["depth"][i], pose=z["pose"][i], K=z["K"], masks=masks[i][:m],
+                           f_g=z["f_g"][i], f_masked=z["f_masked"][i][:m], f_crop=z["f_crop"][i][:m]))
     return frames
 
 

@@ -11,29 +11,40 @@ from oracle import hmsg_oracle as O
 EMU_PATH = os.path.join(os.path.dirname(__file__), "emu", "libhmsg_emu.so")
 
 
+def _pad(a, rows):
+    out = np.zeros((rows,) + a.shape[1:], a.dtype)
+    out[: a.shape[0]] = a
+    return out
+
+
 def stack_frames(frames):
+    """Hand-over layout of the C ABI: frames may hold different numbers of masks (SAM does); rows are padded to the
+    largest count and `n_masks` says how many are real."""
+    M = max(max(f["masks"].shape[0] for f in frames), 1)
+    D = frames[0]["f_g"].reshape(-1).shape[0]
     return dict(
         rgb=np.ascontiguousarray(np.stack([f["rgb"] for f in frames])),
         depth=np.ascontiguousarray(np.stack([f["depth"] for f in frames])),
         pose=np.ascontiguousarray(np.stack([f["pose"] for f in frames])),
         K=np.ascontiguousarray(frames[0]["K"], dtype=np.float64),
-        masks=np.ascontiguousarray(np.stack([f["masks"] for f in frames]).astype(np.uint8)),
+        masks=np.ascontiguousarray(np.stack([_pad(f["masks"].astype(np.uint8), M) for f in frames])),
         f_g=np.ascontiguousarray(np.stack([f["f_g"].reshape(-1) for f in frames]).astype(np.float32)),
-        f_masked=np.ascontiguousarray(np.stack([f["f_masked"] for f in frames]).astype(np.float32)),
-        f_crop=np.ascontiguousarray(np.stack([f["f_crop"] for f in frames]).astype(np.float32)))
+        f_masked=np.ascontiguousarray(np.stack([_pad(np.asarray(f["f_masked"], np.float32).reshape(-1, D), M) for f in frames])),
+        f_crop=np.ascontiguousarray(np.stack([_pad(np.asarray(f["f_crop"], np.float32).reshape(-1, D), M) for f in frames])),
+        n_masks=np.array([f["masks"].shape[0] for f in frames], np.int32))
 
 
 def make_scene(L, frames, cfg_over):
     from holoagent_amd._lib import Scene
     H, W = frames[0]["depth"].shape
-    M = frames[0]["masks"].shape[0]
+    M = max(f["masks"].shape[0] for f in frames)
     over = dict(height=H, width=W, max_frames=len(frames), max_masks=max(M, 1))
     over.update(cfg_over)
     return Scene(lib_=L, **over)
 
 
 def check_map(sc, frames, cfg, oracle_cloud=None):
-    """A1 + A2: identical voxel set / order, centroids to 1e-9."""
+    """A1 + A2: identical voxel set / order, centroids BIT-IDENTICAL (ordered float64 sums), colours to 1e-9."""
     S = stack_frames(frames)
     sc.add_frames(S["rgb"], S["depth"], S["pose"], S["K"])
     sc.finalize_map()
@@ -44,15 +55,15 @@ def check_map(sc, frames, cfg, oracle_cloud=None):
     assert sc.map_size_unfiltered() == info["n_voxels"]
     assert sc.map_size() == ref_pts.shape[0]
     pts, cols = sc.map_points(colors=True)
-    np.testing.assert_allclose(pts, ref_pts, rtol=0, atol=1e-9)
+    assert np.array_equal(pts, ref_pts), float(np.abs(pts - ref_pts).max())
     np.testing.assert_allclose(cols, ref_cols, rtol=0, atol=1e-9)
     return S, ref_pts, ref_cols
 
 
 def check_fuse(sc, frames, S, cfg, ref_pts, ref_cols, check_masks=True):
-    """A3 + A4 + A5: F_p to 3e-7, NN indices exact (up to exact distance ties), feature map within 1e-5
-    (fp16 knife edges allowed on a <1e-3 fraction), 3-D masks to 1e-9."""
-    O.NN_TIE = "lowest"   # the HIP path's canonical NN tie rule (see oracle nn_query)
+    """A3 + A4 + A5: F_p to 3e-7, NN indices identical, counters identical, feature map within 1e-6 (fp16 knife edges
+    allowed on a <1e-3 fraction, bounded by one fp16 ulp), 3-D masks BIT-IDENTICAL."""
+    O.NN_TIE = "exact"    # the HIP path's NN tie rule (see oracle nn_query)
     try:
         return _check_fuse(sc, frames, S, cfg, ref_pts, ref_cols, check_masks)
     finally:
@@ -63,15 +74,16 @@ def _check_fuse(sc, frames, S, cfg, ref_pts, ref_cols, check_masks):
     D = cfg["feat_dim"]
     n = len(frames)
     half = n // 2
-    sc.add_frame_features(0, S["masks"][:half], S["f_g"][:half], S["f_masked"][:half], S["f_crop"][:half])
-    sc.add_frame_features(half, S["masks"][half:], S["f_g"][half:], S["f_masked"][half:], S["f_crop"][half:])
+    for a, b in ((0, half), (half, n)):
+        if b > a:
+            sc.add_frame_features(a, S["masks"][a:b], S["f_g"][a:b], S["f_masked"][a:b], S["f_crop"][a:b], S["n_masks"][a:b])
     sc.fuse_frames()
     tree = cKDTree(ref_pts)
     V = ref_pts.shape[0]
     counter = np.zeros((V, 1), np.float32)
     sums = np.zeros((V, D), np.float32)
-    n_tie = 0
     for i, fr in enumerate(frames):
+        assert sc.frame_num_masks(i) == fr["masks"].shape[0]
         f_p = O.fuse_mask_feats(fr["f_g"], fr["f_masked"], fr["f_crop"], cfg["clip_masked_weight"])
         np.testing.assert_allclose(sc.frame_fp(i), f_p, rtol=0, atol=3e-7)
         p, _, valid = O.create_pcd(fr["rgb"], fr["depth"], fr["pose"], fr["K"])
@@ -79,20 +91,17 @@ def _check_fuse(sc, frames, S, cfg, ref_pts, ref_cols, check_masks):
         got = sc.frame_nn(i)
         assert (got[~valid] == -1).all()
         g = got[valid]
-        bad = np.nonzero(g != idx)[0]
-        if bad.size:   # only exact distance ties may differ
-            d_g = np.linalg.norm(ref_pts[g[bad]] - p[bad], axis=1)
-            assert np.all(np.abs(d_g - dist[bad]) <= 1e-12), "NN mismatch beyond distance ties"
-            n_tie += bad.size
-        f2d = O.per_pixel_feats(fr["masks"], f_p)
+        assert np.array_equal(g, idx), "NN index mismatch in frame %d: %d pixels" % (i, int((g != idx).sum()))
+        f2d = O.per_pixel_feats(fr["masks"], f_p) if fr["masks"].shape[0] else np.zeros((valid.size, D), np.float16)
         O.fuse_frame_into_map(sums, counter, f2d, fr["depth"], g.astype(np.int64))
         if check_masks:
             ref_masks = O.create_3d_masks(fr["masks"], fr["depth"], ref_pts, ref_cols, tree, fr["pose"], fr["K"],
-                                          cfg["voxel_size"], cfg["max_mask_distance"], nn_image=got)
+                                          cfg["voxel_size"], cfg["max_mask_distance"])
             got_masks = sc.frame_masks3d(i)
+            assert len(got_masks) == len(ref_masks)
             for m, (rp, _rc) in enumerate(ref_masks):
                 assert got_masks[m].shape == rp.shape, (i, m, got_masks[m].shape, rp.shape)
-                np.testing.assert_allclose(got_masks[m], rp, rtol=0, atol=1e-9)
+                assert np.array_equal(got_masks[m], rp), (i, m, float(np.abs(got_masks[m] - rp).max()))
     feats, cnt = sc.map_feats(counter=True)
     np.testing.assert_array_equal(cnt, counter[:, 0])
     c = counter.copy()
@@ -101,14 +110,14 @@ def _check_fuse(sc, frames, S, cfg, ref_pts, ref_cols, check_masks):
     d = np.abs(feats - ref_feats)
     assert (d > 1e-6).mean() < 1e-3, (d > 1e-6).mean()
     assert d.max() <= 2.0 ** -10
-    return ref_feats, n_tie
+    return ref_feats, 0
 
 
 def check_merge_pool(sc, frames, cfg, ref_pts, ref_feats):
-    """A6 + A7, stage-wise: the oracle merges the library's own 3-D masks (already checked against the
-    oracle's to 1e-9) and pools the library's own instances; instance point sets must agree exactly in
-    count/order and to 1e-9 in position, pooled features to 1e-5 (the north-star tolerance)."""
-    O.NN_TIE = "lowest"
+    """A6 + A7, stage-wise: the oracle merges the library's own 3-D masks (already checked bit for bit against the
+    oracle's) and pools the library's own instances; instance point sets must be BIT-IDENTICAL (count, order,
+    coordinates), pooled features within 1e-5 (the north-star tolerance)."""
+    O.NN_TIE = "exact"
     try:
         frames_pcd = []
         for i in range(len(frames)):
@@ -125,7 +134,7 @@ def check_merge_pool(sc, frames, cfg, ref_pts, ref_feats):
         assert len(got) == len(ref), (len(got), len(ref))
         for k, (g, (r, _)) in enumerate(zip(got, ref)):
             assert g.shape == r.shape, (k, g.shape, r.shape)
-            np.testing.assert_allclose(g, r, rtol=0, atol=1e-9)
+            assert np.array_equal(g, r), (k, float(np.abs(g - r).max()))
         sc.pool_instances()
         feats = sc.instance_feats()
         tree = cKDTree(ref_pts)
@@ -137,6 +146,31 @@ def check_merge_pool(sc, frames, cfg, ref_pts, ref_feats):
         return got, feats
     finally:
         O.NN_TIE = "scipy"
+
+
+def check_against_reference_run(name, z, sc, got, feats):
+    """The library's end result against what the REFERENCE's own create_feature_map produced (tests/golden):
+    identical map, identical instances (bit for bit), voxel features within fp16 knife edges, and pooled features
+    within 1e-5 for EVERY instance that does not hinge on a bit-equal nearest-neighbour tie (the fixture flags those:
+    an instance point that is the exact float64 midpoint of two map voxels is equidistant from both, and scipy's
+    cKDTree returns whichever its traversal meets first)."""
+    off = z["ref_mask_off"]
+    n_ref = len(off) - 1
+    assert len(got) == n_ref
+    for k in range(n_ref):
+        assert np.array_equal(got[k], z["ref_mask_pts"][off[k]:off[k + 1]]), k
+    mf = sc.map_feats()
+    d = np.abs(mf - z["ref_full_feats"])
+    frac_rows = float((d.max(axis=1) > 1e-6).mean())
+    hinge = z["ref_tie_sensitive"]
+    err = np.abs(feats - z["ref_mask_feats"]).max(axis=1)
+    ok = err <= 1e-5
+    print("%s: map rows off the reference run %.4f; instances %d, within 1e-5 of the reference run %d (%.1f %%), "
+          "hinging on a bit-equal NN tie %d, max err elsewhere %.3g"
+          % (name, frac_rows, n_ref, int(ok.sum()), 100.0 * ok.mean(), int(hinge.sum()), float(err[~hinge].max())))
+    assert (d > 1e-6).mean() < 2e-3 and d.max() < 2e-3
+    assert err[~hinge].max() <= 1e-5
+    return ok
 
 
 def check_query_golden(L):

@@ -1,0 +1,136 @@
+"""GPU parity at the sizes BASELINE.json's configs name: D = 512 / 768 with M = 32 at 640x480 against the oracle,
+and size-independent properties of the full configs[1] build (1000 frames) that the oracle cannot reach."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import parity_common as PC
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    from holoagent_amd._lib import HmsgLib
+    return HmsgLib()
+
+
+@pytest.mark.parametrize("D,n_frames,W,H", [(512, 20, 640, 480), (768, 10, 320, 240)])
+def test_build_at_config_shape_against_oracle(L, D, n_frames, W, H):
+    """configs[1]'s kernel instances (k_fuse<4,2> for D=512, <4,3> for 768; M = 32; 640x480) stage-wise against the oracle."""
+    from holoagent_amd.synth import SceneSpec, SynthScene
+    spec = SceneSpec(seed=61, rooms_x=1, rooms_z=1, room_size=(4.5, 2.8, 3.8), objects_per_room=6, width=W, height=H,
+                     n_frames=n_frames, n_masks=32, feat_dim=D, yaw_step_deg=18.0)
+    scn = SynthScene(spec)
+    frames = [scn.frame(i) for i in range(spec.n_frames)]
+    cfg = dict(voxel_size=0.05, clip_masked_weight=0.4418, max_mask_distance=10000, feat_dim=D, init_overlap_thresh=0.75,
+               overlap_thresh_factor=0.025, iou_thresh=0.05, merge_type="sequential")
+    sc = PC.make_scene(L, frames, dict(feat_dim=D))
+    S, ref_pts, ref_cols = PC.check_map(sc, frames, cfg)
+    assert ref_pts.shape[0] > 5000
+    ref_feats, _ = PC.check_fuse(sc, frames, S, cfg, ref_pts, ref_cols, check_masks=True)
+    got, feats = PC.check_merge_pool(sc, frames, cfg, ref_pts, ref_feats)
+    assert len(got) >= 5 and feats.shape[1] == D
+    sc.close()
+
+
+def test_filter_distance_drops_far_masks(L):
+    """pipeline.max_mask_distance as a real threshold (the yaml documents 6.4239): masks whose mean camera depth exceeds
+    it come back empty (generic.py:126-127), the others are untouched."""
+    from holoagent_amd.synth import SceneSpec, SynthScene
+    from oracle import hmsg_oracle as O
+    from scipy.spatial import cKDTree
+    spec = SceneSpec(seed=8, rooms_x=1, rooms_z=1, room_size=(5.0, 2.8, 4.0), objects_per_room=5, width=160, height=120,
+                     n_frames=8, n_masks=12, feat_dim=32)
+    scn = SynthScene(spec)
+    frames = [scn.frame(i) for i in range(spec.n_frames)]
+    thr = 2.2
+    cfg = dict(voxel_size=0.05, clip_masked_weight=0.4418, max_mask_distance=thr, feat_dim=32, outlier_nb=300)
+    sc = PC.make_scene(L, frames, dict(feat_dim=32, outlier_nb_points=300, max_mask_distance=thr))
+    S, ref_pts, ref_cols = PC.check_map(sc, frames, cfg)
+    PC.check_fuse(sc, frames, S, cfg, ref_pts, ref_cols, check_masks=True)
+    n_empty = sum(1 for i in range(len(frames)) for m in sc.frame_masks3d(i) if len(m) == 0)
+    n_all = sum(sc.frame_num_masks(i) for i in range(len(frames)))
+    assert 0 < n_empty < n_all
+    sc.close()
+
+
+def test_configs1_full_size_properties(L):
+    """The full configs[1] build (1000 frames, 640x480, M = 32, D = 512) on the device-rendered stream: properties that
+    hold for any input, checked at the size the oracle cannot reach."""
+    import torch
+    import bench
+    from holoagent_amd._lib import Scene, NodeIndex
+    from holoagent_amd.synth import SceneSpec
+    F, D, M = 1000, 512, 32
+    spec = SceneSpec(seed=1234, n_frames=F, feat_dim=D, n_masks=M)
+    device = torch.device("cuda", 0)
+    inp = bench.build_scene_inputs(L, spec, device, torch)
+    HW = spec.height * spec.width
+    results = []
+    for env in ({}, {"HMSG_DEBUG_NOANCHOR": "1"}):
+        os.environ.pop("HMSG_DEBUG_NOANCHOR", None)
+        os.environ.update(env)
+        try:
+            sc = Scene(lib_=L, height=spec.height, width=spec.width, max_frames=F, max_masks=M, feat_dim=D)
+            sc.add_frames(inp["rgb"], inp["depth"], inp["pose"], inp["K"])
+            sc.finalize_map()
+            sc.add_frame_features(0, inp["masks"], inp["f_g"], inp["f_masked"], inp["f_crop"])
+            sc.fuse_frames()
+            sc.merge_instances()
+            inst = sc.instances()
+            if not env:
+                V = sc.map_size()
+                pts = sc.map_points()
+                feats, counter = sc.map_feats(counter=True)
+                # (1) counter = number of frames that touched the voxel: sum over frames of the distinct nearest voxels
+                touched = 0
+                mask_rows = []
+                depth_h = inp["depth"].cpu().numpy().view(np.uint16)
+                for f in range(F):
+                    nn = sc.frame_nn(f)
+                    assert ((nn >= 0) == (depth_h[f] > 0)).all()
+                    u = np.unique(nn[nn >= 0])
+                    assert u.size == 0 or u[-1] < V
+                    touched += u.size
+                    if f % 50 == 0:
+                        mask_rows.append(np.concatenate(sc.frame_masks3d(f)))
+                assert int(counter.sum()) == touched
+                # (2) voxel features are means of unit-or-zero fp16 rows: norm <= 1 (+ rounding), zero where untouched
+                nrm = np.linalg.norm(feats, axis=1)
+                assert nrm.max() <= 1.0 + 1e-3 and np.all(nrm[counter == 0] == 0)
+                # (3) every 3-D mask point is a mean of map points of one 5 cm voxel: within the map's bounding box and
+                #     within sqrt(3) * 5 cm of a map point
+                from scipy.spatial import cKDTree
+                tree = cKDTree(pts)
+                mp = np.concatenate(mask_rows)
+                dmin, _ = tree.query(mp, k=1, workers=-1)
+                assert dmin.max() <= 0.05 * np.sqrt(3) + 1e-9
+                # (4) the fold only selects points: every instance point is one of the 3-D mask points (bit for bit)
+                allm = np.concatenate([np.concatenate(sc.frame_masks3d(f)) for f in range(F)])
+                keys = np.unique(np.ascontiguousarray(allm).view([("a", "V24")]).ravel())
+                ip = np.concatenate(inst)
+                ik = np.unique(np.ascontiguousarray(ip).view([("a", "V24")]).ravel())
+                assert np.isin(ik, keys).all() and len(ip) <= len(allm)
+                # (5) retrieval on the pooled table: indices and scores equal a float64 re-score on the host
+                sc.pool_instances()
+                emb = sc.instance_feats().astype(np.float64)
+                text, _ = inp["scene"].text_table(64)
+                ix = NodeIndex(emb, np.zeros(len(emb), np.int32), lib_=L)
+                idx, _, score = ix.query_objects(text, np.zeros(64, np.int32), [[0]] * 64, 5)
+                from oracle import hmsg_oracle as O
+                for q in range(64):
+                    top, s_ref = O.query_object(text[q], 0, emb, 5)
+                    assert [int(v) for v in idx[q] if v >= 0] == [int(t) for t in top]
+                    np.testing.assert_allclose(score[q][: len(top)], s_ref, rtol=0, atol=1e-12)
+                ix.close()
+            results.append(inst)
+            sc.close()
+        finally:
+            os.environ.pop("HMSG_DEBUG_NOANCHOR", None)
+    # (6) the merge fold's exact shortcuts change nothing at full size
+    a, b = results
+    assert len(a) == len(b) > 100
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and np.array_equal(x, y)

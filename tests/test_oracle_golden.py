@@ -29,13 +29,13 @@ def test_feats_dbscan_matches_reference(case):
     np.testing.assert_array_equal(out, z["ref_" + case])
 
 
-@pytest.mark.parametrize("name", ["build_seq", "build_hier"])
+@pytest.mark.parametrize("name", ["build_seq", "build_hier", "build_ragged"])
 def test_create_feature_map_matches_reference(name):
     z = GI.load(name)
     frames = GI.unpack_frames(z)
     cfg = GI.unpack_cfg(z)
     res = O.create_feature_map(frames, cfg)
-    np.testing.assert_allclose(res["cloud_pts"], z["ref_cloud"], rtol=0, atol=1e-12)
+    assert np.array_equal(res["cloud_pts"], z["ref_cloud"])
     ff, rf = res["full_feats"], z["ref_full_feats"]
     assert ff.shape == rf.shape
     d = np.abs(ff - rf)
@@ -43,7 +43,7 @@ def test_create_feature_map_matches_reference(name):
     off = z["ref_mask_off"]
     assert len(res["mask_pcds"]) == len(off) - 1
     for i, (p, _c) in enumerate(res["mask_pcds"]):
-        np.testing.assert_allclose(p, z["ref_mask_pts"][off[i]:off[i + 1]], rtol=0, atol=1e-12)
+        assert np.array_equal(p, z["ref_mask_pts"][off[i]:off[i + 1]])
     mf = np.stack([np.asarray(f).reshape(-1) for f in res["mask_feats"]])
     np.testing.assert_allclose(mf, z["ref_mask_feats"], rtol=0, atol=1e-5)
 

@@ -1,0 +1,35 @@
+"""Stable radix sort (hmsg_sort.hip) on the kernel simulator: equal keys keep their input order."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import parity_common as PC
+
+
+def check_sort(L, n, bits, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    hi = 1 << bits
+    # skewed keys: a few heavy keys + uniform tail, like voxel slots of a scanned surface
+    keys = np.where(rng.random(n) < 0.3, rng.integers(0, min(hi, 7), n), rng.integers(0, hi, n)).astype(np.uint32)
+    vals = np.arange(n, dtype=np.uint64) * np.uint64(3) + np.uint64(1)
+    k2, v2 = keys.copy(), vals.copy()
+    rc = L.c.hmsg_test_sort_pairs(k2.ctypes.data, v2.ctypes.data, n, bits)
+    assert rc == 0
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(k2, keys[order])
+    assert np.array_equal(v2, vals[order])
+
+
+@pytest.mark.skipif(not os.path.exists(PC.EMU_PATH), reason="kernel simulator not built")
+@pytest.mark.parametrize("n,bits", [(1, 5), (63, 3), (4096, 11), (4097, 12), (20000, 22), (9001, 25), (70000, 8)])
+def test_sort_emu(n, bits):
+    from holoagent_amd._lib import HmsgLib
+    check_sort(HmsgLib(PC.EMU_PATH), n, bits, 100 + n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,bits", [(1, 5), (4097, 12), (1 << 20, 22), (3_000_001, 23), (2_000_000, 32), (5_000_000, 8)])
+def test_sort_gpu(n, bits):
+    from holoagent_amd._lib import HmsgLib
+    check_sort(HmsgLib(), n, bits, 7 + n)
