@@ -294,17 +294,22 @@ __device__ __forceinline__ MaskRun mask_run(const int* __restrict__ nn, const un
     return r;
 }
 
-// per (frame, mask): AABB of the snapped points, number of valid pixels and the sum of their depths
+// per (frame, mask): AABB of the snapped points, number of valid pixels and the sum of their depths.
+// grid = (chunks per frame, frames): a workgroup stays inside one frame, combines in LDS (every run of a mask hits
+// the same eight words) and touches the global table once per mask it met.
 __global__ void __launch_bounds__(256) k_mbounds(const int* __restrict__ nn, const unsigned long long* __restrict__ bits,
-                                                 const unsigned short* __restrict__ depth, size_t HW, int W, int f0, int nfr,
+                                                 const unsigned short* __restrict__ depth, size_t HW, int W, int f0,
                                                  int NW, int MS, const double* __restrict__ pts,
                                                  unsigned long long* __restrict__ bounds /*[nfr*MS][6]*/,
                                                  unsigned long long* __restrict__ dstat /*[nfr*MS][2]: depth sum, pixels*/) {
+    __shared__ unsigned long long s_b[HMSG_MAX_MASKS][8];
+    for (int k = threadIdx.x; k < MS * 8; k += 256) s_b[k >> 3][k & 7] = (k & 7) < 3 ? ~0ull : 0ull;
+    __syncthreads();
+    const int fl = blockIdx.y;
     for (int it = 0; it < MCHUNK / 256; ++it) {
         const size_t t = (size_t)blockIdx.x * MCHUNK + (size_t)it * 256 + threadIdx.x;
-        const bool in_range = t < HW * nfr;
-        const int fl = in_range ? (int)(t / HW) : 0;
-        const size_t g = (size_t)f0 * HW + t;
+        const bool in_range = t < HW;
+        const size_t g = (size_t)(f0 + fl) * HW + (in_range ? t : 0);
         const MaskRun r = mask_run(nn, bits, depth, NW, W, g, in_range, true);
         if (!r.tail) continue;
         unsigned long long e[3] = {enc_f64(pts[(size_t)r.v * 3]), enc_f64(pts[(size_t)r.v * 3 + 1]), enc_f64(pts[(size_t)r.v * 3 + 2])};
@@ -313,15 +318,24 @@ __global__ void __launch_bounds__(256) k_mbounds(const int* __restrict__ nn, con
             while (b) {
                 const int i = w * 64 + __ffsll(b) - 1;
                 b &= b - 1;
-                unsigned long long* bd = bounds + ((size_t)fl * MS + i) * 6;
+                unsigned long long* bd = s_b[i];
                 for (int a = 0; a < 3; ++a) {      // (stale reads only cost a redundant atomic)
                     if (e[a] < bd[a]) atomicMin(&bd[a], e[a]);
                     if (e[a] > bd[3 + a]) atomicMax(&bd[3 + a], e[a]);
                 }
-                atomicAdd(&dstat[((size_t)fl * MS + i) * 2], (unsigned long long)r.dsum);
-                atomicAdd(&dstat[((size_t)fl * MS + i) * 2 + 1], (unsigned long long)r.len);
+                atomicAdd(&bd[6], (unsigned long long)r.dsum);
+                atomicAdd(&bd[7], (unsigned long long)r.len);
             }
         }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < MS * 8; k += 256) {
+        const int i = k >> 3, a = k & 7;
+        if (s_b[i][7] == 0ull) continue;
+        const size_t m = (size_t)fl * MS + i;
+        if (a < 3) atomicMin(&bounds[m * 6 + a], s_b[i][a]);
+        else if (a < 6) atomicMax(&bounds[m * 6 + a], s_b[i][a]);
+        else atomicAdd(&dstat[m * 2 + (a - 6)], s_b[i][a]);
     }
 }
 
@@ -335,18 +349,18 @@ __device__ __forceinline__ long long mask_cell(const MaskGeom& mg, double vs, co
 
 // occupancy bitmaps of the per-mask Open3D grids + number of records every chunk will emit
 __global__ void __launch_bounds__(256) k_mmark(const int* __restrict__ nn, const unsigned long long* __restrict__ bits, size_t HW,
-                                               int W, int f0, int nfr, int NW, int MS, const double* __restrict__ pts,
+                                               int W, int f0, int NW, int MS, const double* __restrict__ pts,
                                                const MaskGeom* __restrict__ geom, double vs,
                                                unsigned long long* __restrict__ mbitmap, unsigned* __restrict__ chunk_recs) {
     __shared__ unsigned s_n;
     if (threadIdx.x == 0) s_n = 0u;
     __syncthreads();
     unsigned mine = 0;
+    const int fl = blockIdx.y;
     for (int it = 0; it < MCHUNK / 256; ++it) {
         const size_t t = (size_t)blockIdx.x * MCHUNK + (size_t)it * 256 + threadIdx.x;
-        const bool in_range = t < HW * nfr;
-        const int fl = in_range ? (int)(t / HW) : 0;
-        const size_t g = (size_t)f0 * HW + t;
+        const bool in_range = t < HW;
+        const size_t g = (size_t)(f0 + fl) * HW + (in_range ? t : 0);
         const MaskRun r = mask_run(nn, bits, nullptr, NW, W, g, in_range, false);
         if (!r.tail) continue;
         for (int w = 0; w < NW; ++w) {
@@ -368,26 +382,26 @@ __global__ void __launch_bounds__(256) k_mmark(const int* __restrict__ nn, const
     mine = (unsigned)wave_sum_i32((int)mine);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_n, mine);
     __syncthreads();
-    if (threadIdx.x == 0) chunk_recs[blockIdx.x] = s_n;
+    if (threadIdx.x == 0) chunk_recs[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s_n;
 }
 
 // records (key = slot of the mask voxel, value = map voxel << 8 | run length) in pixel order
 __global__ void __launch_bounds__(256) k_memit(const int* __restrict__ nn, const unsigned long long* __restrict__ bits, size_t HW,
-                                               int W, int f0, int nfr, int NW, int MS, const double* __restrict__ pts,
+                                               int W, int f0, int NW, int MS, const double* __restrict__ pts,
                                                const MaskGeom* __restrict__ geom, double vs,
                                                const unsigned long long* __restrict__ mbitmap, const unsigned* __restrict__ mrank,
                                                const unsigned* __restrict__ chunk_base, unsigned* __restrict__ keys,
                                                unsigned long long* __restrict__ vals) {
     __shared__ unsigned s_w[4];
     __shared__ unsigned s_run;
-    if (threadIdx.x == 0) s_run = chunk_base[blockIdx.x];
+    if (threadIdx.x == 0) s_run = chunk_base[(size_t)blockIdx.y * gridDim.x + blockIdx.x];
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int fl = blockIdx.y;
     for (int it = 0; it < MCHUNK / 256; ++it) {
         const size_t t = (size_t)blockIdx.x * MCHUNK + (size_t)it * 256 + threadIdx.x;
-        const bool in_range = t < HW * nfr;
-        const int fl = in_range ? (int)(t / HW) : 0;
-        const size_t g = (size_t)f0 * HW + t;
+        const bool in_range = t < HW;
+        const size_t g = (size_t)(f0 + fl) * HW + (in_range ? t : 0);
         const MaskRun r = mask_run(nn, bits, nullptr, NW, W, g, in_range, false);
         // records of this lane: its masks whose cloud was not rejected
         unsigned nrec = 0;
@@ -444,11 +458,9 @@ __global__ void k_mwalk(const unsigned* __restrict__ off, const unsigned long lo
         const double* p = pts + (size_t)(rec >> 8) * 3;
         const double px = p[0], py = p[1], pz = p[2];
         const int len = (int)(rec & 255ull);
-        for (int j = 0; j < len; ++j) {
-            sx = __dadd_rn(sx, px);
-            sy = __dadd_rn(sy, py);
-            sz = __dadd_rn(sz, pz);
-        }
+        sx = repeat_add(sx, px, len);
+        sy = repeat_add(sy, py, len);
+        sz = repeat_add(sz, pz, len);
         n += (unsigned long long)len;
     }
     const double dn = (double)n;
@@ -546,15 +558,16 @@ void hmsg_fuse(hmsg_ctx* h) {
         }
         // ---- 3-D masks of the batch
         const int nmask = nb * MS;
-        const unsigned nchunks = cdiv(HW * nb, MCHUNK);
+        const unsigned cpf = cdiv(HW, MCHUNK);           // chunks per frame (a workgroup never straddles two frames)
+        const unsigned nchunks = cpf * (unsigned)nb;
         for (int i = 0; i < nmask; ++i)
             for (int a = 0; a < 6; ++a) hb[(size_t)i * 6 + a] = a < 3 ? ~0ull : 0ull;
         HIP_TRY(hipMemcpyAsync(d_bounds.p, hb.data(), (size_t)nmask * 48, hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemsetAsync(d_dstat.p, 0, (size_t)nmask * 16, s));
         {
             ProfScope ps(h->prof, s, "k_mbounds", (double)nb * (double)HW * (6.0 + 8.0 * NW));
-            hipLaunchKernelGGL(k_mbounds, dim3(nchunks), dim3(256), 0, s, (const int*)h->nn.p, (const unsigned long long*)h->bits.p,
-                               (const unsigned short*)h->depth.p, HW, W, fb0, nb, NW, MS, (const double*)h->pts.p, d_bounds.p,
+            hipLaunchKernelGGL(k_mbounds, dim3(cpf, nb), dim3(256), 0, s, (const int*)h->nn.p, (const unsigned long long*)h->bits.p,
+                               (const unsigned short*)h->depth.p, HW, W, fb0, NW, MS, (const double*)h->pts.p, d_bounds.p,
                                d_dstat.p);
         }
         HMSG_CHECK_LAUNCH();
@@ -597,8 +610,8 @@ void hmsg_fuse(hmsg_ctx* h) {
             HIP_TRY(hipMemsetAsync(mbitmap.p, 0, (size_t)nwords * 8, s));
             {
                 ProfScope ps(h->prof, s, "k_mmark", (double)nb * (double)HW * (4.0 + 8.0 * NW));
-                hipLaunchKernelGGL(k_mmark, dim3(nchunks), dim3(256), 0, s, (const int*)h->nn.p, (const unsigned long long*)h->bits.p,
-                                   HW, W, fb0, nb, NW, MS, (const double*)h->pts.p, (const MaskGeom*)d_geom.p, c.voxel_size,
+                hipLaunchKernelGGL(k_mmark, dim3(cpf, nb), dim3(256), 0, s, (const int*)h->nn.p, (const unsigned long long*)h->bits.p,
+                                   HW, W, fb0, NW, MS, (const double*)h->pts.p, (const MaskGeom*)d_geom.p, c.voxel_size,
                                    mbitmap.p, chunk_recs.p);
             }
             HMSG_CHECK_LAUNCH();
@@ -610,8 +623,8 @@ void hmsg_fuse(hmsg_ctx* h) {
             sb.vals.ensure((size_t)std::max<unsigned long long>(nrec, 1));
             {
                 ProfScope ps(h->prof, s, "k_memit", (double)nb * (double)HW * (4.0 + 8.0 * NW) + (double)nrec * 12.0);
-                hipLaunchKernelGGL(k_memit, dim3(nchunks), dim3(256), 0, s, (const int*)h->nn.p, (const unsigned long long*)h->bits.p,
-                                   HW, W, fb0, nb, NW, MS, (const double*)h->pts.p, (const MaskGeom*)d_geom.p, c.voxel_size,
+                hipLaunchKernelGGL(k_memit, dim3(cpf, nb), dim3(256), 0, s, (const int*)h->nn.p, (const unsigned long long*)h->bits.p,
+                                   HW, W, fb0, NW, MS, (const double*)h->pts.p, (const MaskGeom*)d_geom.p, c.voxel_size,
                                    (const unsigned long long*)mbitmap.p, (const unsigned*)mrank.p, (const unsigned*)chunk_recs.p,
                                    sb.keys.p, sb.vals.p);
             }

@@ -310,34 +310,47 @@ __global__ void __launch_bounds__(256) k_emit_runs(const unsigned* __restrict__ 
     }
 }
 
-// centroid = (sequential float64 sum of the voxel's points in input order) / count  (o3d_voxel_down_sample)
-__global__ void k_accum_ordered(const unsigned short* __restrict__ depth, const double* __restrict__ pose, CamK cam, float scale,
-                                int W, size_t HW, long long V, const unsigned* __restrict__ off,
-                                const unsigned long long* __restrict__ runs, const unsigned* __restrict__ cnt,
-                                double* __restrict__ pts) {
-    const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+// centroid = (sequential float64 sum of the voxel's points in input order) / count  (o3d_voxel_down_sample).
+// One WAVE per voxel: the additions are a serial chain by definition, but the back-projections that feed it are
+// not -- the lanes back-project the pixels of a run side by side and the wave then folds the points into the sum
+// in order with shuffles (uniform across lanes, so every lane holds the sum).
+__global__ void __launch_bounds__(256) k_accum_ordered(const unsigned short* __restrict__ depth, const double* __restrict__ pose,
+                                                       CamK cam, float scale, int W, size_t HW, long long V,
+                                                       const unsigned* __restrict__ off, const unsigned long long* __restrict__ runs,
+                                                       const unsigned* __restrict__ cnt, double* __restrict__ pts) {
+    const int lane = threadIdx.x & 63;
+    const long long v = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (v >= V) return;
     double sx = 0.0, sy = 0.0, sz = 0.0;
-    for (unsigned r = off[v]; r < off[v + 1]; ++r) {
-        const unsigned long long rec = runs[r];
-        const size_t i0 = (size_t)(rec >> 8);
-        const int len = (int)(rec & 255ull);
-        const int f = (int)(i0 / HW);
-        const int p = (int)(i0 - (size_t)f * HW);
-        const int y = p / W, x0 = p - y * W;
-        const double* T = pose + (size_t)f * 16;
-        for (int j = 0; j < len; ++j) {
-            double wx, wy, wz;
-            backproject(depth[i0 + j], x0 + j, y, cam, scale, T, wx, wy, wz);
-            sx = __dadd_rn(sx, wx);
-            sy = __dadd_rn(sy, wy);
-            sz = __dadd_rn(sz, wz);
+    const unsigned r0 = off[v], r1 = off[v + 1];
+    for (unsigned rb = r0; rb < r1; rb += 64) {
+        // this lane's run of the group of 64
+        const unsigned long long myrec = rb + lane < r1 ? runs[rb + lane] : 0ull;
+        const int nrun = (int)min(64u, r1 - rb);
+        for (int q = 0; q < nrun; ++q) {
+            const unsigned long long rec = __shfl(myrec, q);
+            const size_t i0 = (size_t)(rec >> 8);
+            const int len = (int)(rec & 255ull);
+            double wx = 0.0, wy = 0.0, wz = 0.0;
+            if (lane < len) {
+                const int f = (int)(i0 / HW);
+                const int p = (int)(i0 - (size_t)f * HW);
+                const int y = p / W, x0 = p - y * W;
+                backproject(depth[i0 + lane], x0 + lane, y, cam, scale, pose + (size_t)f * 16, wx, wy, wz);
+            }
+            for (int j = 0; j < len; ++j) {
+                sx = __dadd_rn(sx, __shfl(wx, j));
+                sy = __dadd_rn(sy, __shfl(wy, j));
+                sz = __dadd_rn(sz, __shfl(wz, j));
+            }
         }
     }
-    const double n = (double)cnt[v];
-    pts[v * 3 + 0] = __ddiv_rn(sx, n);
-    pts[v * 3 + 1] = __ddiv_rn(sy, n);
-    pts[v * 3 + 2] = __ddiv_rn(sz, n);
+    if (lane == 0) {
+        const double n = (double)cnt[v];
+        pts[v * 3 + 0] = __ddiv_rn(sx, n);
+        pts[v * 3 + 1] = __ddiv_rn(sy, n);
+        pts[v * 3 + 2] = __ddiv_rn(sz, n);
+    }
 }
 
 // slot -> cell coordinates (one thread per bitmap word)
@@ -676,7 +689,7 @@ void hmsg_build_map(hmsg_ctx* h) {
     cols0.alloc(V0 * 3);
     {
         ProfScope ps(h->prof, s, "k_accum_ordered", (double)total * 2.0 + (double)nruns * 8.0 + (double)V0 * 32.0);
-        hipLaunchKernelGGL(k_accum_ordered, dim3(cdiv(V0, 64)), dim3(64), 0, s, (const unsigned short*)h->depth.p,
+        hipLaunchKernelGGL(k_accum_ordered, dim3(cdiv(V0 * 64, 256)), dim3(256), 0, s, (const unsigned short*)h->depth.p,
                            (const double*)h->pose.p, h->cam, scale, W, (size_t)H * W, (long long)V0, (const unsigned*)run_off.p,
                            (const unsigned long long*)sb.res_vals, (const unsigned*)sn.p, pts0.p);
     }

@@ -10,3 +10,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+# torch ships its own HIP runtime; when libhmsg.so (linked against /opt/rocm) is loaded first, torch later finds
+# "No HIP GPUs".  Loading torch first makes both use one runtime, as bench.py does.
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    pass
