@@ -47,6 +47,17 @@ def _get(cfg, path, default=None):
     return default if cur is None else cur
 
 
+def _match_size(rgb, depth):
+    """graph.py:342-343 / 378-379: a PIL rgb image whose size differs from the depth image's is resized to it (the
+    iPhone loader delivers 1920x1440 colour with 256x192 depth); arrays pass through."""
+    if hasattr(rgb, "mode") and hasattr(depth, "mode") and rgb.size != depth.size:
+        return rgb.resize(depth.size)
+    if not hasattr(rgb, "mode"):
+        a, d = np.asarray(rgb), np.asarray(depth)
+        assert a.shape[:2] == d.shape[:2], "rgb and depth arrays must have the same height and width"
+    return rgb
+
+
 class _Pcd:
     """Minimal stand-in for the o3d PointCloud attributes callers read (.points, get_center())."""
 
@@ -382,8 +393,7 @@ class Graph:
         self._poses, self._K = [], None
         for b0 in range(0, len(ids), B):                                  # loop A (graph.py:339-345)
             fr = [self.dataset[i] for i in ids[b0:b0 + B]]
-            fr = [(f[0].resize(f[1].size) if hasattr(f[0], "resize") and hasattr(f[0], "size") and f[0].size != f[1].size
-                   else f[0],) + tuple(f[1:]) for f in fr]               # graph.py:342-343
+            fr = [(_match_size(f[0], f[1]),) + tuple(f[1:]) for f in fr]    # graph.py:342-343
             rgb = np.ascontiguousarray(np.stack([np.asarray(f[0], dtype=np.uint8)[..., :3] for f in fr]))
             dep = np.ascontiguousarray(np.stack([np.asarray(f[1]).astype(np.uint16) for f in fr]))
             pose = np.ascontiguousarray(np.stack([np.asarray(f[2], dtype=np.float64) for f in fr]))
@@ -397,9 +407,7 @@ class Graph:
         for b0 in range(0, len(ids), B):                                  # loop B (graph.py:373-411)
             outs = []
             for i in ids[b0:b0 + B]:
-                rgb_i, depth_i = self.dataset[i][0], self.dataset[i][1]
-                if hasattr(rgb_i, "size") and hasattr(rgb_i, "resize") and rgb_i.size != depth_i.size:
-                    rgb_i = rgb_i.resize(depth_i.size)                     # graph.py:378-379
+                rgb_i = _match_size(self.dataset[i][0], self.dataset[i][1])     # graph.py:378-379
                 outs.append(self.encoders.extract(np.asarray(rgb_i)))
             # SAM returns a different number of masks for every frame: rows are padded to the batch maximum and the
             # real counts are handed over with them (sam_clip_feats_extractor.py:167-169 softmaxes over the frame's own)
