@@ -96,6 +96,16 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU-oracle baseline sample (0 = skip)")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` (N > 1) without a launcher: become the launcher -- one process per GPU under
+    # torch.distributed.run on 127.0.0.1, same arguments; rank 0's JSON line is the output.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import subprocess
+        port = os.environ.get("MASTER_PORT", "29511")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(cmd, env=env))
+
     import torch
     import torch.distributed as dist
     from holoagent_amd._lib import HmsgLib, Scene, NodeIndex
@@ -111,7 +121,16 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-    assert world == max(1, args.gpus) or world == 1, "launch with torch.distributed.run --nproc-per-node N"
+    assert world == max(1, args.gpus), "WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus)
+    if os.environ.get("HMSG_BENCH_SPAWN_ONLY"):
+        # launch check without a GPU (tests/test_distributed_gloo.py): rendezvous over gloo, report the rank count
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"spawn_check": True, "n_gpus": world, "rank_sum": int(t.item())}))
+        dist.destroy_process_group()
+        return
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if use_dist:
@@ -209,7 +228,12 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     prof = sc.profile()                                           # events of the LAST timed step
+    per_rank_fps = [F * max(args.steps, 1) / dt]
     if use_dist:
+        mine = torch.tensor([dt], device=device, dtype=torch.float64)
+        allt = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allt, mine)
+        per_rank_fps = [F * max(args.steps, 1) / float(t.item()) for t in allt]
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -286,6 +310,8 @@ def main():
             "config": {"workload": "configs[1]: %d-frame single scene per GPU, 640x480 RGB-D, 32 masks/frame, %d-d features, "
                                    "HMSG build + %d-query retrieval" % (F, D, Q),
                        "frames": F, "queries": Q, "feat_dim": D, "masks": M, "parallelism": "scene-per-gpu x%d" % world},
+            "rccl_ranks": dist.get_world_size() if use_dist else 0,
+            "per_rank_frames_per_s": [round(v, 1) for v in per_rank_fps],
             "queries_per_sec": round(qps, 1) if qps else None,
             "stage_ms_per_step": {k_: round(v / steps * 1e3, 2) for k_, v in stage.items()},
             "map_voxels": V, "nodes_local": state.get("n_nodes_local"),

@@ -453,15 +453,44 @@ __global__ void k_mwalk(const unsigned* __restrict__ off, const unsigned long lo
     if (s >= npts) return;
     double sx = 0.0, sy = 0.0, sz = 0.0;
     unsigned long long n = 0;
-    for (unsigned r = off[s]; r < off[s + 1]; ++r) {
-        const unsigned long long rec = recs[r];
-        const double* p = pts + (size_t)(rec >> 8) * 3;
-        const double px = p[0], py = p[1], pz = p[2];
-        const int len = (int)(rec & 255ull);
-        sx = repeat_add(sx, px, len);
-        sy = repeat_add(sy, py, len);
-        sz = repeat_add(sz, pz, len);
-        n += (unsigned long long)len;
+    // consecutive records of one map voxel (the same voxel on successive image rows) are one repetition count;
+    // short counts are added one by one, long ones in closed form (repeat_add costs a 64-bit division)
+    unsigned cur_v = 0xffffffffu;
+    int cur_len = 0;
+    double px = 0.0, py = 0.0, pz = 0.0;
+    const unsigned r1 = off[s + 1];
+    for (unsigned r = off[s]; r <= r1; ++r) {
+        unsigned v = 0xffffffffu;
+        int len = 0;
+        if (r < r1) {
+            const unsigned long long rec = recs[r];
+            v = (unsigned)(rec >> 8);
+            len = (int)(rec & 255ull);
+        }
+        if (v == cur_v) {
+            cur_len += len;
+            continue;
+        }
+        if (cur_len >= 48) {
+            sx = repeat_add(sx, px, cur_len);
+            sy = repeat_add(sy, py, cur_len);
+            sz = repeat_add(sz, pz, cur_len);
+        } else {
+            for (int j = 0; j < cur_len; ++j) {
+                sx = __dadd_rn(sx, px);
+                sy = __dadd_rn(sy, py);
+                sz = __dadd_rn(sz, pz);
+            }
+        }
+        n += (unsigned long long)cur_len;
+        cur_v = v;
+        cur_len = len;
+        if (r < r1) {
+            const double* p = pts + (size_t)v * 3;
+            px = p[0];
+            py = p[1];
+            pz = p[2];
+        }
     }
     const double dn = (double)n;
     out[(size_t)s * 3 + 0] = __ddiv_rn(sx, dn);

@@ -70,3 +70,22 @@ def test_two_rank_allgather_retrieval(tmp_path):
             np.testing.assert_array_equal(z["score"][j], score[q])
             seen.add(int(q))
     assert seen == set(range(len(lists)))
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher re-executes itself under torch.distributed.run with one process
+    per GPU (checked here without GPUs: the ranks rendezvous over gloo and report the world size)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = dict(os.environ, HMSG_BENCH_SPAWN_ONLY="1", MASTER_PORT="29613")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["rank_sum"] == 3
