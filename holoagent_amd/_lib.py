@@ -51,6 +51,7 @@ _SIGS = {
     "hmsg_add_frames": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P]),
     "hmsg_finalize_map": (C.c_int, [_P]),
     "hmsg_map_size": (C.c_int64, [_P]),
+    "hmsg_num_tie_queries": (C.c_int64, [_P]),
     "hmsg_map_size_unfiltered": (C.c_int64, [_P]),
     "hmsg_get_map_points": (C.c_int, [_P, _P, _P]),
     "hmsg_add_frame_features": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
@@ -78,6 +79,7 @@ _SIGS = {
     "hmsg_similarity": (C.c_int, [_P, C.c_int32, _P, _P]),
     "hmsg_test_sort_pairs": (C.c_int, [_P, _P, C.c_int64, C.c_int32]),
     "hmsg_test_repeat_add": (C.c_int, [_P, _P, _P, _P, C.c_int64]),
+    "hmsg_test_ckdtree": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 
@@ -191,6 +193,9 @@ class Scene:
 
     def map_size(self):
         return int(self.L.c.hmsg_map_size(self.h))
+
+    def num_tie_queries(self):
+        return int(self.L.c.hmsg_num_tie_queries(self.h))
 
     def map_size_unfiltered(self):
         return int(self.L.c.hmsg_map_size_unfiltered(self.h))

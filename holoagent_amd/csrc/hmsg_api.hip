@@ -1,11 +1,67 @@
 // C ABI of libhmsg (see include/hmsg.h).  Thin: argument checks, host<->HBM staging, error capture.
 #include "hmsg_common.h"
+#include "hmsg_ckdtree.h"
+#include "hmsg_nn.h"
 
 #include <algorithm>
 #include <cstring>
 
 void hmsg_bitset_and_fp(hmsg_ctx* h, int first, int n, int M, const unsigned char* d_masks, const float* d_fg,
                         const float* d_fm, const float* d_fc, const int* d_nmask);   // hmsg_fuse.hip
+
+// ---- bit-equal nearest-neighbour ties: host side ----------------------------------------------------------------
+__global__ void k_nn_patch(const long long* __restrict__ qid, const int* __restrict__ val, unsigned n, int* __restrict__ target) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) target[qid[i]] = val[i];
+}
+
+void hmsg_kd_join(hmsg_ctx* h) {
+    if (h->kd_thread.joinable()) h->kd_thread.join();
+}
+
+void hmsg_kd_start(hmsg_ctx* h) {
+    hmsg_kd_join(h);
+    h->host_pts.resize((size_t)h->V * 3);
+    if (h->V) HIP_TRY(hipMemcpyAsync(h->host_pts.data(), h->pts.p, (size_t)h->V * 24, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->kd = std::make_shared<CKDTree>();
+    std::shared_ptr<CKDTree> kd = h->kd;
+    const double* pts = h->host_pts.data();
+    const long long V = h->V;
+    h->kd_thread = std::thread([kd, pts, V] { kd->build(pts, V); });
+}
+
+bool hmsg_resolve_ties(hmsg_ctx* h, TieBuf& tb, int* target) {
+    unsigned n = 0;
+    HIP_TRY(hipMemcpyAsync(&n, tb.count.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (n == 0) return true;
+    if (n > tb.cap) {                       // list overflowed: grow, the caller repeats the search
+        tb.cap = 0;
+        tb.prepare(h->stream, n + n / 2 + 1024);
+        return false;
+    }
+    std::vector<TieRec> recs(n);
+    HIP_TRY(hipMemcpy(recs.data(), tb.recs.p, (size_t)n * sizeof(TieRec), hipMemcpyDeviceToHost));
+    hmsg_kd_join(h);
+    std::vector<long long> q(n);
+    std::vector<int> v(n);
+    for (unsigned i = 0; i < n; ++i) {
+        const double x[3] = {recs[i].x, recs[i].y, recs[i].z};
+        q[i] = recs[i].qid;
+        v[i] = (int)h->kd->query1(x);
+    }
+    tb.pq.ensure(n);
+    tb.pv.ensure(n);
+    HIP_TRY(hipMemcpyAsync(tb.pq.p, q.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(tb.pv.p, v.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_nn_patch, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, (const long long*)tb.pq.p, (const int*)tb.pv.p, n,
+                       target);
+    HMSG_CHECK_LAUNCH();
+    HIP_TRY(hipStreamSynchronize(h->stream));     // (q / v are host temporaries)
+    h->n_tie_queries += n;
+    return true;
+}
 
 namespace {
 
@@ -104,6 +160,7 @@ int hmsg_create(const hmsg_config* cfg, hmsg_t** out) {
 
 void hmsg_destroy(hmsg_t* h) {
     if (!h) return;
+    hmsg_kd_join(h);
     (void)hipSetDevice(h->cfg.device_id);
     if (h->stream) {
         (void)hipStreamSynchronize(h->stream);
@@ -120,6 +177,8 @@ int hmsg_reset(hmsg_t* h) {
     if (!h) return HMSG_ERR_INVALID;
     return guard(h, [&] {
         HIP_TRY(hipStreamSynchronize(h->stream));
+        hmsg_kd_join(h);
+        h->n_tie_queries = 0;
         h->n_frames = h->n_feat_frames = h->n_fused = 0;
         h->nmask.clear();
         h->mask_first.clear();
@@ -218,6 +277,7 @@ int hmsg_finalize_map(hmsg_t* h) {
     });
 }
 
+int64_t hmsg_num_tie_queries(const hmsg_t* h) { return h ? h->n_tie_queries : -1; }
 int64_t hmsg_map_size(const hmsg_t* h) { return h && h->map_ready ? h->V : -1; }
 int64_t hmsg_map_size_unfiltered(const hmsg_t* h) { return h && h->map_ready ? h->V0 : -1; }
 
@@ -434,6 +494,19 @@ int hmsg_get_instance_feats(const hmsg_t* hc, float* feats) {
         size_t n = (h->inst.off.size() - 1) * (size_t)h->cfg.feat_dim;
         if (n) HIP_TRY(hipMemcpy(feats, h->inst_feats.p, n * 4, hipMemcpyDeviceToHost));
     });
+}
+
+// test hook: the host restatement of scipy's cKDTree (hmsg_ckdtree.h) -- index permutation after the build and
+// k = 1 answers; no GPU involved
+int hmsg_test_ckdtree(const double* pts, int64_t n, const double* queries, int64_t nq, int64_t* out_idx,
+                      int64_t* out_indices, int64_t* out_n_nodes) {
+    if (!pts || n < 0 || nq < 0) return HMSG_ERR_INVALID;
+    CKDTree t;
+    t.build(pts, n);
+    if (out_indices) memcpy(out_indices, t.indices.data(), (size_t)n * 8);
+    if (out_n_nodes) *out_n_nodes = (int64_t)t.nodes.size();
+    for (int64_t i = 0; i < nq; ++i) out_idx[i] = t.query1(queries + i * 3);
+    return HMSG_OK;
 }
 
 }  // extern "C"

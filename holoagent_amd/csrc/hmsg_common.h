@@ -9,6 +9,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -311,6 +313,12 @@ struct hmsg_ctx {
     DevBuf<unsigned> rank;              // exclusive popcount prefix per word
     DevBuf<double> pts;            // [V][3]
     DevBuf<double> cols;           // [V][3]
+    // host copy of the cloud + restated scipy cKDTree over it (hmsg_ckdtree.h): built on a side thread when the map
+    // is finalised, consulted only for bit-equal nearest-neighbour ties
+    std::vector<double> host_pts;
+    std::shared_ptr<struct CKDTree> kd;
+    std::thread kd_thread;
+    long long n_tie_queries = 0;   // (statistics)
     // NN candidate lists for the cells of voxels deleted by remove_radius_outlier (hmsg_nn.h)
     DevBuf<unsigned long long> bitmap_rm;
     DevBuf<unsigned> rank_rm, cand_off;
@@ -367,6 +375,8 @@ static inline void hmsg_dump(const char* name, const void* dev, size_t bytes, hi
     }
 }
 
+void hmsg_kd_start(hmsg_ctx* h);        // hmsg_api.hip: download the cloud, build the cKDTree restatement on a thread
+void hmsg_kd_join(hmsg_ctx* h);
 void hmsg_build_map(hmsg_ctx* h);       // hmsg_map.hip
 void hmsg_fuse(hmsg_ctx* h);            // hmsg_fuse.hip
 void hmsg_merge(hmsg_ctx* h);           // hmsg_merge.hip

@@ -132,25 +132,36 @@ __global__ void k_fp(const float* __restrict__ Fg, const float* __restrict__ Fm,
 
 #include "hmsg_nn.h"
 
-__global__ void k_nn_stamp(const unsigned short* __restrict__ depth, const double* __restrict__ pose, CamK cam, float scale,
-                           int H, int W, int f0, int nfr, NNIndex I, int* __restrict__ nn, unsigned* __restrict__ stamp /*[V][FB]*/) {
+__global__ void k_nn(const unsigned short* __restrict__ depth, const double* __restrict__ pose, CamK cam, float scale,
+                     int H, int W, int f0, int nfr, NNIndex I, int* __restrict__ nn, TieList ties) {
     const size_t HW = (size_t)H * W;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= HW * nfr) return;
+    const int fl = (int)(t / HW);
+    const int p = (int)(t - (size_t)fl * HW);
+    const int f = f0 + fl;
+    const int y = p / W, x = p - y * W;
+    double wx, wy, wz;
+    int idx = -1;
+    if (backproject(depth[(size_t)f * HW + p], x, y, cam, scale, pose + (size_t)f * 16, wx, wy, wz)) {
+        int ntie = 0;
+        idx = nn_search(I, wx, wy, wz, nullptr, &ntie);
+        if (ntie > 1) tie_push(ties, (long long)((size_t)f * HW + p), wx, wy, wz);
+    }
+    nn[(size_t)f * HW + p] = idx;
+}
+
+// stamp = 1 + the LARGEST pixel index per (voxel, frame): within a run of consecutive lanes snapping to the same
+// voxel only the last lane can win, so only it pays for the atomic (runs are ~8 pixels long)
+__global__ void k_stamp(const int* __restrict__ nn, size_t HW, int f0, int nfr, unsigned* __restrict__ stamp /*[V][FB]*/) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = t < HW * nfr;
     if (!in_range) t = HW * nfr - 1;
-    int fl = (int)(t / HW);
-    int p = (int)(t - (size_t)fl * HW);
-    int f = f0 + fl;
-    int y = p / W, x = p - y * W;
-    double wx, wy, wz;
-    int idx = -1;
-    if (in_range && backproject(depth[(size_t)f * HW + p], x, y, cam, scale, pose + (size_t)f * 16, wx, wy, wz))
-        idx = nn_search(I, wx, wy, wz);
-    if (in_range) nn[(size_t)f * HW + p] = idx;
-    // stamp = LARGEST pixel index per (voxel, frame): within a run of consecutive lanes snapping to the same
-    // voxel only the last lane can win, so only it pays for the atomic (runs are ~8 pixels long)
+    const int fl = (int)(t / HW);
+    const int p = (int)(t - (size_t)fl * HW);
+    const int idx = in_range ? nn[(size_t)(f0 + fl) * HW + p] : -1;
     const int lane = threadIdx.x & 63;
-    long long key = in_range && idx >= 0 ? ((long long)idx << 8) | fl : -1 - lane;
+    long long key = idx >= 0 ? ((long long)idx << 8) | fl : -1 - lane;
     long long nxt = __shfl_down(key, 1);
     if (key >= 0 && (lane == 63 || nxt != key)) atomicMax(&stamp[(size_t)idx * FB + fl], (unsigned)p + 1u);
 }
@@ -561,6 +572,7 @@ void hmsg_fuse(hmsg_ctx* h) {
     d_offidx.alloc((size_t)nmask_max);
     d_offval.alloc((size_t)nmask_max);
     SortBufs sb;
+    TieBuf ties;
     std::vector<unsigned long long> hb((size_t)nmask_max * 6), hd((size_t)nmask_max * 2);
     std::vector<MaskGeom> hg((size_t)nmask_max);
     std::vector<long long> hoffidx((size_t)nmask_max);
@@ -575,11 +587,17 @@ void hmsg_fuse(hmsg_ctx* h) {
     for (int fb0 = h->n_fused; fb0 < h->n_feat_frames; fb0 += FB) {
         const int nb = std::min(FB, h->n_feat_frames - fb0);
         stamp.zero(s);
-        {
-            ProfScope ps(h->prof, s, "k_nn_stamp", (double)nb * ((double)HW * 10.0 + 128.0));
-            hipLaunchKernelGGL(k_nn_stamp, dim3(cdiv(HW * nb, 256)), dim3(256), 0, s, (const unsigned short*)h->depth.p,
-                               (const double*)h->pose.p, h->cam, scale, H, W, fb0, nb, hmsg_nn_index(h), h->nn.p, stamp.p);
+        for (;;) {      // (repeated only when the tie list overflowed)
+            ties.prepare(s);
+            {
+                ProfScope ps(h->prof, s, "k_nn", (double)nb * ((double)HW * 6.0 + 128.0));
+                hipLaunchKernelGGL(k_nn, dim3(cdiv(HW * nb, 256)), dim3(256), 0, s, (const unsigned short*)h->depth.p,
+                                   (const double*)h->pose.p, h->cam, scale, H, W, fb0, nb, hmsg_nn_index(h), h->nn.p, ties.list());
+            }
+            HMSG_CHECK_LAUNCH();
+            if (hmsg_resolve_ties(h, ties, h->nn.p)) break;
         }
+        hipLaunchKernelGGL(k_stamp, dim3(cdiv(HW * nb, 256)), dim3(256), 0, s, (const int*)h->nn.p, HW, fb0, nb, stamp.p);
         HMSG_CHECK_LAUNCH();
         {
             ProfScope ps(h->prof, s, "k_fuse", (double)V * 256.0);

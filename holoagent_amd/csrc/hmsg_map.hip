@@ -755,5 +755,6 @@ void hmsg_build_map(hmsg_ctx* h) {
         h->have_cand = true;
     }
     HIP_TRY(hipStreamSynchronize(s));
+    hmsg_kd_start(h);
     h->map_ready = true;
 }

@@ -25,16 +25,37 @@ struct NNIndex {
 struct NNBest {
     double d2;
     int idx;
+    int ntie;      // candidates at exactly best.d2 (1 = unique minimum)
 };
 
-// Tie rule: the squared distance is evaluated exactly as scipy's cKDTree does for 3-D points
-// (sqeuclidean_distance_double: ((dx*dx) + dy*dy) + dz*dz in float64, no FMA), so a candidate that is closer by
-// even one ulp wins like it does there.  Only BIT-EQUAL distances are ties; they go to the lowest index
-// (oracle NN_TIE = "exact"; cKDTree's own choice among bit-equal candidates depends on its traversal order).
+// queries whose nearest neighbour is a BIT-EQUAL tie: the host answers them like scipy's cKDTree would
+// (hmsg_ckdtree.h) and k_nn_patch writes the answers back
+struct TieRec {
+    long long qid;          // position in the index array to patch
+    double x, y, z;
+};
+struct TieList {
+    unsigned* count;        // device counter (may run past cap: the batch is then redone with a larger buffer)
+    TieRec* recs;
+    unsigned cap;
+};
+__device__ __forceinline__ void tie_push(const TieList& t, long long qid, double x, double y, double z) {
+    const unsigned k = atomicAdd(t.count, 1u);
+    if (k < t.cap) t.recs[k] = TieRec{qid, x, y, z};
+}
+
+// The squared distance is evaluated exactly as scipy's cKDTree does for 3-D points (sqeuclidean_distance_double:
+// ((dx*dx) + dy*dy) + dz*dz in float64, no FMA), so a candidate that is closer by even one ulp wins like it does
+// there.  BIT-EQUAL distances are counted: the caller hands such queries to the host, which replays cKDTree's
+// traversal (the first candidate it meets wins there); until then the lowest index stands in.
 __device__ __forceinline__ void nn_consider(NNBest& best, int q, double d2) {
-    if (d2 < best.d2 || (d2 == best.d2 && q < best.idx)) {
+    if (d2 < best.d2) {
         best.d2 = d2;
         best.idx = q;
+        best.ntie = 1;
+    } else if (d2 == best.d2) {
+        ++best.ntie;
+        if (q < best.idx) best.idx = q;
     }
 }
 __device__ __forceinline__ double nn_dist2(const double* __restrict__ p, double qx, double qy, double qz) {
@@ -104,11 +125,12 @@ __device__ inline void nn_rings(const NNIndex& I, int cx, int cy, int cz, double
     }
 }
 
-__device__ inline int nn_search(const NNIndex& I, double qx, double qy, double qz, double* out_d2 = nullptr) {
+__device__ inline int nn_search(const NNIndex& I, double qx, double qy, double qz, double* out_d2 = nullptr,
+                                int* out_ntie = nullptr) {
     const GridGeom& g = I.g;
     int cx, cy, cz;
     cell_of(g, qx, qy, qz, cx, cy, cz);
-    NNBest best{1e300, -1};
+    NNBest best{1e300, -1, 0};
     const bool inside = cx >= 0 && cy >= 0 && cz >= 0 && cx < g.nx && cy < g.ny && cz < g.nz;
     bool done = false;
     if (inside && I.bitmap_rm) {
@@ -131,8 +153,29 @@ __device__ inline int nn_search(const NNIndex& I, double qx, double qy, double q
         nn_rings(I, cx, cy, cz, qx, qy, qz, best);
     }
     if (out_d2) *out_d2 = best.d2;
+    if (out_ntie) *out_ntie = best.ntie;
     return best.idx;
 }
+
+// host side of the tie hand-over (hmsg_api.hip): resolve the listed queries with the restated cKDTree, patch `target`
+struct TieBuf {
+    DevBuf<unsigned> count;
+    DevBuf<TieRec> recs;
+    DevBuf<long long> pq;
+    DevBuf<int> pv;
+    unsigned cap = 0;
+    void prepare(hipStream_t s, unsigned want_cap = 1u << 16) {
+        if (cap < want_cap) {
+            recs.alloc(want_cap);
+            cap = want_cap;
+        }
+        if (!count.p) count.alloc(1);
+        HIP_TRY(hipMemsetAsync(count.p, 0, 4, s));
+    }
+    TieList list() { return TieList{count.p, recs.p, cap}; }
+};
+// returns false when the list overflowed (cap was doubled: redo the search kernel and call again)
+bool hmsg_resolve_ties(hmsg_ctx* h, TieBuf& tb, int* target);
 
 static inline NNIndex hmsg_nn_index(const hmsg_ctx* h) {
     NNIndex I;

@@ -29,11 +29,13 @@ struct PoolSeg {            // one instance
 
 // ---- NN of the down-sampled instance points; keep dist <= max_dist (graph.py:458-460)
 __global__ void k_pool_nn(const double* __restrict__ q, long long N, NNIndex I, double max_dist, int* __restrict__ idx,
-                          unsigned* __restrict__ valid) {
+                          unsigned* __restrict__ valid, TieList ties) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     double d2 = 0;
-    int v = nn_search(I, q[i * 3], q[i * 3 + 1], q[i * 3 + 2], &d2);
+    int ntie = 0;
+    int v = nn_search(I, q[i * 3], q[i * 3 + 1], q[i * 3 + 2], &d2, &ntie);
+    if (ntie > 1) tie_push(ties, i, q[i * 3], q[i * 3 + 1], q[i * 3 + 2]);
     idx[i] = v;
     valid[i] = (v >= 0 && __dsqrt_rn(d2) <= max_dist) ? 1u : 0u;
 }
@@ -334,9 +336,14 @@ void hmsg_pool(hmsg_ctx* h) {
     valid.alloc((size_t)std::max<long long>(P, 1));
     pos.alloc((size_t)std::max<long long>(P, 1));
     if (P) {
-        hipLaunchKernelGGL(k_pool_nn, dim3(cdiv((size_t)P, 256)), dim3(256), 0, s, (const double*)ds.p, P, hmsg_nn_index(h),
-                           c.pool_max_dist, idx.p, valid.p);
-        HMSG_CHECK_LAUNCH();
+        TieBuf ties;
+        for (;;) {
+            ties.prepare(s);
+            hipLaunchKernelGGL(k_pool_nn, dim3(cdiv((size_t)P, 256)), dim3(256), 0, s, (const double*)ds.p, P, hmsg_nn_index(h),
+                               c.pool_max_dist, idx.p, valid.p, ties.list());
+            HMSG_CHECK_LAUNCH();
+            if (hmsg_resolve_ties(h, ties, idx.p)) break;     // bit-equal ties answered like cKDTree (hmsg_ckdtree.h)
+        }
     }
     unsigned long long R = 0;   // total valid rows
     if (P) hmsg_scan_u32(valid.p, pos.p, (size_t)P, s, ops.scan_tmp, &R);

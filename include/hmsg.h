@@ -107,6 +107,9 @@ int hmsg_add_frames(hmsg_t* h, int32_t n, const uint8_t* rgb, const uint16_t* de
  * DBSCAN + remove_radius_outlier + the NN index that replaces cKDTree (graph.py:348-364). */
 int hmsg_finalize_map(hmsg_t* h);
 int64_t hmsg_map_size(const hmsg_t* h);              /* V = points of the filtered global cloud */
+/* nearest-neighbour queries so far (graph.py:409, :458, generic.py:181) that were bit-equal distance ties and were
+ * answered by the host restatement of scipy's cKDTree traversal (statistics) */
+int64_t hmsg_num_tie_queries(const hmsg_t* h);
 int64_t hmsg_map_size_unfiltered(const hmsg_t* h);   /* voxels before remove_radius_outlier */
 int hmsg_get_map_points(const hmsg_t* h, double* xyz /*[V][3]*/, double* rgb /*[V][3] or NULL*/);
 
@@ -190,6 +193,10 @@ int hmsg_similarity(hmsg_index_t* ix, int32_t Q, const float* T, double* S);
 int hmsg_test_sort_pairs(uint32_t* keys, uint64_t* vals, int64_t n, int32_t key_bits);
 /* out[i] = s[i] after `len[i]` sequential float64 additions of p[i] (how Open3D accumulates a map point that many
  * pixels of a mask snapped to, generic.py:181-188), computed by the closed form the mask kernels use. */
+/* host restatement of scipy.spatial.cKDTree (the reference's NN index, graph.py:362-364): index permutation after the
+ * default build (out_indices i64 [n], may be NULL), node count, and query(x, k=1) answers for nq points. */
+int hmsg_test_ckdtree(const double* pts, int64_t n, const double* queries, int64_t nq, int64_t* out_idx,
+                      int64_t* out_indices, int64_t* out_n_nodes);
 int hmsg_test_repeat_add(const double* s, const double* p, const int32_t* len, double* out, int64_t n);
 
 #ifdef __cplusplus

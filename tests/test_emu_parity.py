@@ -51,6 +51,7 @@ def test_merge_and_pool_small(L, merge_type):
     finally:
         O.feats_denoise_dbscan = orig
     assert len(got) > 3
+    print("tie queries answered by the cKDTree replay:", sc.num_tie_queries())
     sc.close()
 
 
