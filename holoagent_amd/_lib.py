@@ -72,6 +72,7 @@ _SIGS = {
     "hmsg_voxel_down_sample": (C.c_int, [_P, _P, C.c_int64, C.c_double, _P, _P]),
     "hmsg_pool_instances": (C.c_int, [_P]),
     "hmsg_get_instance_feats": (C.c_int, [_P, _P]),
+    "hmsg_points_min_dist_2d": (C.c_int, [C.c_int32, C.c_int32, _P, _P, C.c_int64, _P, _P]),
     "hmsg_index_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _P, C.c_int32, _P, C.POINTER(_P)]),
     "hmsg_index_destroy": (None, [_P]),
     "hmsg_index_last_error": (C.c_char_p, [_P]),
@@ -302,6 +303,22 @@ class Scene:
         if n:
             self._ck(self.L.c.hmsg_get_instance_feats(self.h, _ptr(out)))
         return out
+
+
+def points_min_dist_2d(sets, queries, device_id=0, lib_: "HmsgLib | None" = None):
+    """out[q][s] = np.min(cdist([queries[q]], sets[s], "euclidean")) on the device (camera -> room assignment of
+    compute_room_embeddings, utils/graph_utils.py:244-291)."""
+    L = lib_ or lib()
+    off = np.zeros(len(sets) + 1, np.int64)
+    off[1:] = np.cumsum([len(s_) for s_ in sets])
+    pts = np.ascontiguousarray(np.concatenate([np.asarray(s_, np.float64).reshape(-1, 2) for s_ in sets])
+                               if off[-1] else np.zeros((1, 2)), dtype=np.float64)
+    q = np.ascontiguousarray(queries, dtype=np.float64).reshape(-1, 2)
+    out = np.full((len(q), len(sets)), np.inf)
+    rc = L.c.hmsg_points_min_dist_2d(device_id, len(sets), _ptr(off), _ptr(pts), len(q), _ptr(q), _ptr(out))
+    if rc != 0:
+        raise HmsgError(f"hmsg_points_min_dist_2d failed ({rc})")
+    return out
 
 
 class NodeIndex:

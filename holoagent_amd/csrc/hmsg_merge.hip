@@ -343,14 +343,17 @@ struct Merger {
         unsigned* cells = ix_cells.p + ix_cells_used;
         d_cursor.ensure((size_t)ncell_new);
         HIP_TRY(hipMemsetAsync(d_cursor.p, 0, (size_t)ncell_new * 4, s));
-        dim3 grid(std::max(1u, std::min(cdiv(maxn, 256), 1024u)), (unsigned)todo.size());
-        hipLaunchKernelGGL(k_ov_count, grid, dim3(256), 0, s, (const double*)pool.p, (const OvGrid*)d_grids.p, d_cursor.p,
-                           ix_cells_used);
+        const unsigned gx = std::max(1u, std::min(cdiv(maxn, 256), todo.size() > 4096 ? 16u : 1024u));
+        for (size_t t0 = 0; t0 < todo.size(); t0 += 32768)   // (gridDim.y limit)
+            hipLaunchKernelGGL(k_ov_count, dim3(gx, (unsigned)std::min<size_t>(32768, todo.size() - t0)), dim3(256), 0, s,
+                               (const double*)pool.p, (const OvGrid*)d_grids.p + t0, d_cursor.p, ix_cells_used);
         HMSG_CHECK_LAUNCH();
         // (cell starts stay relative to this batch's first sorted point: Cloud::ix_pt)
         hmsg_scan_u32(d_cursor.p, cells, (size_t)ncell_new, s, ops.scan_tmp, nullptr);
-        hipLaunchKernelGGL(k_ov_fill, grid, dim3(256), 0, s, (const double*)pool.p, (const OvGrid*)d_grids.p,
-                           (const unsigned*)ix_cells.p, d_cursor.p, ix_cells_used, ix_pts.p);
+        for (size_t t0 = 0; t0 < todo.size(); t0 += 32768)
+            hipLaunchKernelGGL(k_ov_fill, dim3(gx, (unsigned)std::min<size_t>(32768, todo.size() - t0)), dim3(256), 0, s,
+                               (const double*)pool.p, (const OvGrid*)d_grids.p + t0, (const unsigned*)ix_cells.p, d_cursor.p,
+                               ix_cells_used, ix_pts.p);
         HMSG_CHECK_LAUNCH();
         for (int i : todo) L[i].has_index = true;
         ix_cells_used += ncell_new;
@@ -702,6 +705,16 @@ void hmsg_merge(hmsg_ctx* h) {
             }
         }
     }
+    // overlap grids of ALL frame masks in one batch (they are inputs of the fold; only clouds that change during
+    // the fold get a new grid later)
+    {
+        std::vector<Cloud> all;
+        for (auto& fr : frames) all.insert(all.end(), fr.begin(), fr.end());
+        m.build_indices(all);
+        size_t k = 0;
+        for (auto& fr : frames)
+            for (auto& cl : fr) cl = all[k++];
+    }
     std::vector<Cloud> result;
     if (c.merge_type == HMSG_MERGE_HIERARCHICAL) {
         // graph_utils.py:959-1012
@@ -957,6 +970,61 @@ void hmsg_room_share(hmsg_ctx* h, int R, const long long* vert_off, const double
     HIP_TRY(hipStreamSynchronize(s));
     for (size_t k = 0; k < tasks.size(); ++k)
         share_out[(size_t)tasks[k].inst * R + tasks[k].room] = (double)hc[k] / (double)g[tasks[k].inst].n;
+}
+
+// ------------------------------------------------------------------------------------------ A9: camera -> room
+// compute_room_embeddings (utils/graph_utils.py:244-291): distance of a camera position (x, z) to a room =
+// np.min(cdist([pos], room_points, "euclidean")) = sqrt of the smallest dx*dx + dy*dy (float64, that order).
+// One workgroup per (query, set) pair.
+__global__ void __launch_bounds__(256) k_min_dist_2d(const long long* __restrict__ set_off, const double* __restrict__ pts, int n_sets,
+                                                     const double* __restrict__ q, double* __restrict__ out) {
+    __shared__ double s_m[4];
+    const int qi = blockIdx.y, si = blockIdx.x;
+    const double qx = q[(size_t)qi * 2], qy = q[(size_t)qi * 2 + 1];
+    double m = 1e308 * 10.0;     // +inf: an empty set answers inf like np.min would refuse to
+    for (long long k = set_off[si] + threadIdx.x; k < set_off[si + 1]; k += blockDim.x) {
+        const double dx = __dsub_rn(qx, pts[k * 2]), dy = __dsub_rn(qy, pts[k * 2 + 1]);
+        const double d2 = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
+        m = d2 < m ? d2 : m;
+    }
+    m = wave_min_f64(m);
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) m = s_m[w] < m ? s_m[w] : m;
+        out[(size_t)qi * n_sets + si] = __dsqrt_rn(m);
+    }
+}
+
+extern "C" int hmsg_points_min_dist_2d(int32_t device_id, int32_t n_sets, const int64_t* set_off, const double* pts_xy, int64_t n_q,
+                                       const double* q_xy, double* out) {
+    if (n_sets < 0 || n_q < 0 || !set_off || !out) return HMSG_ERR_INVALID;
+    if (n_sets == 0 || n_q == 0) return HMSG_OK;
+    try {
+        HIP_TRY(hipSetDevice(device_id));
+        const long long np = set_off[n_sets];
+        DevBuf<long long> d_off;
+        DevBuf<double> d_p, d_q, d_o;
+        d_off.alloc((size_t)n_sets + 1);
+        d_p.alloc((size_t)std::max<long long>(np, 1) * 2);
+        d_q.alloc((size_t)n_q * 2);
+        d_o.alloc((size_t)n_q * n_sets);
+        HIP_TRY(hipMemcpy(d_off.p, set_off, ((size_t)n_sets + 1) * 8, hipMemcpyHostToDevice));
+        if (np) HIP_TRY(hipMemcpy(d_p.p, pts_xy, (size_t)np * 16, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_q.p, q_xy, (size_t)n_q * 16, hipMemcpyHostToDevice));
+        for (long long q0 = 0; q0 < n_q; q0 += 32768) {
+            const unsigned nq = (unsigned)std::min<long long>(32768, n_q - q0);
+            hipLaunchKernelGGL(k_min_dist_2d, dim3((unsigned)n_sets, nq), dim3(256), 0, 0, (const long long*)d_off.p, (const double*)d_p.p,
+                               n_sets, (const double*)d_q.p + q0 * 2, d_o.p + q0 * n_sets);
+        }
+        HMSG_CHECK_LAUNCH();
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(out, d_o.p, (size_t)n_q * n_sets * 8, hipMemcpyDeviceToHost));
+        return HMSG_OK;
+    } catch (const hmsg_error& e) {
+        fprintf(stderr, "hmsg_points_min_dist_2d: %s\n", e.msg.c_str());
+        return e.code;
+    }
 }
 
 // ------------------------------------------------------------------------------------------ A8 helper

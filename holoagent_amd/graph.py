@@ -337,11 +337,100 @@ def find_intersection_share(map_points, obj_points, radius=0.05):
     return int((idx != obj_points.shape[0]).sum()) / obj_points.shape[0]
 
 
+def compute_room_embeddings(room_pcds, pose_list, emb_list, pcd_min, pcd_max, num_views=5, save_path=None, lib=None,
+                            device_id=0):
+    """utils/graph_utils.py:192-356.  Assign every image to the room whose cloud (projected to x/z) is nearest to the
+    camera position, provided the camera height lies inside the floor bounds; a room that got no image takes the
+    closest of the cameras OUTSIDE the floor bounds (sic, :267-291; image 0 when there is none); per room with at
+    least `num_views` images, KMeans(num_views, n_init=5, max_iter=100, random_state=0) over the image embeddings and
+    the member closest (dot product) to every centre.  The camera-to-room distances (F x R x room points) are
+    computed on the device (hmsg_points_min_dist_2d); KMeans is scikit-learn's, as in the reference.
+    Returns (repr_embs_list, repr_img_ids_list, room_id2img_id, room_clip_embeddings_list)."""
+    from collections import defaultdict
+    from sklearn.cluster import KMeans
+    from ._lib import points_min_dist_2d
+    flat = [np.stack([np.asarray(getattr(p, "points", p))[:, 0], np.asarray(getattr(p, "points", p))[:, 2]], axis=1)
+            for p in room_pcds]
+    room_id2img_id = defaultdict(list)
+    cam = np.array([[pose[0, 3], pose[2, 3]] for pose in pose_list], dtype=np.float64).reshape(-1, 2)
+    height = np.array([pose[1, 3] for pose in pose_list], dtype=np.float64)
+    dist = points_min_dist_2d(flat, cam, device_id=device_id, lib_=lib) if len(cam) and len(flat) else np.zeros((len(cam), len(flat)))
+    inside = ~((height < pcd_min[1]) | (height > pcd_max[1]))
+    for i in range(len(pose_list)):
+        if not inside[i]:
+            continue
+        room_id2img_id[int(np.argmin(dist[i]))].append(i)
+    for room_id in range(len(flat)):
+        if room_id not in room_id2img_id:
+            closest = np.where(inside, np.inf, dist[:, room_id]) if len(cam) else np.zeros(0)
+            room_id2img_id[room_id].append(int(np.argmin(closest)))
+    repr_img_ids_list, repr_embs_list, room_clip_embeddings_list = [], [], []
+    for room_id in range(len(flat)):
+        img_ids = room_id2img_id[room_id]
+        if len(img_ids) == 0:
+            repr_img_ids_list.append([])
+            repr_embs_list.append([])
+            continue
+        room_clip = np.squeeze(np.array([emb_list[i] for i in img_ids]), axis=1)
+        room_clip_embeddings_list.append(room_clip)
+        if len(img_ids) < num_views:
+            repr_img_ids_list.append(img_ids)
+            repr_embs_list.append([emb for emb in room_clip])
+            continue
+        kmeans = KMeans(n_clusters=num_views, max_iter=100, n_init=5, random_state=0).fit(room_clip)
+        labels, centers = kmeans.labels_, kmeans.cluster_centers_
+        repr_img_ids, repr_embs = [], []
+        for lab in np.unique(labels):
+            ids = np.where(labels == lab)[0]
+            cluster = room_clip[ids]
+            max_idx = int(np.argmax(np.dot(cluster, centers[lab])))
+            repr_img_ids.append(img_ids[ids[max_idx]])
+            repr_embs.append(cluster[max_idx])
+        repr_img_ids_list.append(repr_img_ids)
+        repr_embs_list.append(repr_embs)
+    return repr_embs_list, repr_img_ids_list, room_id2img_id, room_clip_embeddings_list
+
+
+def parse_hier_instruction(text):
+    """Stand-in for the reference's LLM parse (utils/llm_utils parse_hier_query_use_prompt_insentence_parse[_icra], out of
+    scope: SURVEY section 2): "<object> in [the] <room> on floor <n>" -> (floor | None, room, object).  Install a real
+    parser with `Graph.instruction_parser = callable`."""
+    import re
+    t = text.strip().rstrip(".")
+    floor = None
+    m = re.search(r"\s+on\s+(?:the\s+)?floor\s+(\w+)\s*$", t, flags=re.I) or re.search(r"\s+on\s+the\s+(\w+)\s+floor\s*$", t, flags=re.I)
+    if m:
+        floor, t = m.group(1), t[: m.start()]
+    m = re.search(r"\s+in\s+(?:the\s+)?(.+)$", t, flags=re.I)
+    room = "unknown"
+    if m:
+        room, t = m.group(1).strip(), t[: m.start()]
+    obj = re.sub(r"^(?:find|go to|navigate to|bring me to|take me to)\s+(?:the\s+|a\s+|an\s+)?", "", t.strip(), flags=re.I)
+    return floor, room, obj.strip()
+
+
+BACKGROUND_LABELS = ["background", "divider", "ledge", "pillar", "tape", "stairs", "door", "doors", "stair", "window", "glass",
+                     "railing", "glass doors", "whiteboard", "sliding door", "carpet", "ceiling", "curtain"]   # graph.py:3607-3625
+
+
 class Graph:
+    # str -> (floor_query | None, room_query, object_query); the reference asks an LLM (out of scope), see
+    # parse_hier_instruction.  collaborators: cfg -> (dataset, encoders), the part of Graph.__init__ (graph.py:98-219)
+    # that builds the dataset reader, SAM and CLIP from the Hydra keys; install the project's own factory to get the
+    # reference's `Graph(cfg)` call signature (INTEGRATION.md).
+    instruction_parser = staticmethod(parse_hier_instruction)
+    collaborators = None
+
     def __init__(self, cfg, dataset=None, encoders=None, lib: HmsgLib | None = None):
         self.cfg = cfg
         self.L = lib or _default_lib()
+        if dataset is None and encoders is None and Graph.collaborators is not None:
+            dataset, encoders = Graph.collaborators(cfg)
         self.dataset, self.encoders = dataset, encoders
+        import networkx as nx
+        self.graph = nx.Graph()                                        # graph.py:93
+        self.room_id2img_ids = {}
+        self._view_feats = []          # per processed frame the global CLIP feature F_g [1, D] (loop B hands it over)
         self.floors: List[Floor] = []
         self.rooms: List[Room] = []
         self.objects: List[Object] = []
@@ -423,6 +512,7 @@ class Graph:
             fm = np.ascontiguousarray(np.stack([pad(np.asarray(o["f_masked"], np.float32), (D,)) for o in outs]))
             fc = np.ascontiguousarray(np.stack([pad(np.asarray(o["f_crop"], np.float32), (D,)) for o in outs]))
             sc.add_frame_features(n_done, masks, fg, fm, fc, n_masks)
+            self._view_feats.extend(np.asarray(o["f_g"], np.float32).reshape(1, -1) for o in outs)
             n_done += len(outs)
         sc.fuse_frames()
         self.full_feats_array = sc.map_feats()
@@ -526,6 +616,82 @@ class Graph:
             fl.add_room(room)
             self.rooms.append(room)
 
+    def set_view_feats(self, feats):
+        """Global CLIP feature of every processed frame, [F, D] or list of [1, D] (graph.py:1119-1130 recomputes them
+        with get_img_feats; they are the F_g the per-pixel stage already received, so loop B keeps them)."""
+        self._view_feats = [np.asarray(f, np.float32).reshape(1, -1) for f in feats]
+
+    def _room_cloud(self, floor, floor_tree, room_m):
+        """graph.py:1086-1108: extrude the room's 2-D points over the floor's height in 5 cm steps, rotate into the map
+        frame (90 degrees about x, as scipy's Rotation gives it) and pick the floor points nearest to them."""
+        from scipy.spatial.transform import Rotation
+        z_levels = np.arange(floor.floor_zero_level, floor.floor_zero_level + floor.floor_height, 0.05).reshape(-1, 1)
+        z_levels *= -1
+        room_m3d = np.concatenate([np.hstack((room_m, np.ones((room_m.shape[0], 1)) * z)) for z in z_levels], axis=0)
+        T1 = np.eye(4)
+        T1[:3, :3] = Rotation.from_euler("x", 90, degrees=True).as_matrix()
+        X, Y, Z = room_m3d[:, 0], room_m3d[:, 1], room_m3d[:, 2]
+        rows = [((X * T1[r, 0] + Y * T1[r, 1]) + Z * T1[r, 2]) + T1[r, 3] for r in range(4)]      # Open3D transform
+        pts = np.stack([rows[0] / rows[3], rows[1] / rows[3], rows[2] / rows[3]], axis=1)
+        _, idx = floor_tree.query(pts, k=1, workers=-1)
+        mask = np.zeros(len(floor.pcd.points), bool)                      # Open3D select_by_index: unique, original order
+        mask[idx] = True
+        return _Pcd(np.asarray(floor.pcd.points)[mask])
+
+    def segment_hmsg_room(self, floor, path=None, room_2d_points=None, room_pcds=None):
+        """graph.py:920-1189 from the point where the rooms' 2-D regions exist: the OpenCV watershed that produces them
+        (:942-1071, graph_utils.py:391-487) is not restated, so `room_2d_points` -- one [n, 2]
+        array of (x, z) cell centres per room, what map_grid_to_point_cloud returns (:1084) -- is an input.  Everything
+        after it is mirrored: room clouds (:1086-1108), camera -> room assignment and KMeans(24) representative views
+        (compute_room_embeddings), Room nodes (:1147-1168) and one View node per (room, image) with the reference's id
+        scheme -- `<floor>_<room>_<k>` with k counting across the floor's rooms, View.room_id the per-floor room
+        INDEX (an int, :1176-1189)."""
+        if isinstance(floor, (int, np.integer)):
+            floor = self.floors[int(floor)]
+        if room_2d_points is None:
+            print("room regions are an input of this build (OpenCV watershed is not part of it)")
+            return None
+        skip = int(_get(self.cfg, "pipeline.skip_frames", 1))
+        floor_pts = np.asarray(floor.pcd.points)
+        if room_pcds is None:
+            tree = cKDTree(floor_pts)
+            room_pcds = [self._room_cloud(floor, tree, np.asarray(r, np.float64).reshape(-1, 2)) for r in room_2d_points]
+        ids = list(range(0, len(self.dataset), skip)) if self.dataset is not None else list(range(len(self._poses)))
+        pose_list = [np.asarray(self.dataset[i][2], np.float64) for i in ids] if self.dataset is not None else list(self._poses)
+        F_g_list = self._view_feats
+        if len(F_g_list) != len(pose_list) and self.encoders is not None and self.dataset is not None:
+            F_g_list = [np.asarray(self.encoders.extract(np.asarray(self.dataset[i][0]))["f_g"], np.float32).reshape(1, -1)
+                        for i in ids]
+        assert len(F_g_list) == len(pose_list), "one global feature per processed frame (set_view_feats)"
+        pcd_min, pcd_max = floor_pts.min(axis=0), floor_pts.max(axis=0)
+        repr_embs, repr_ids, room_id2img_id, room_clip = compute_room_embeddings(
+            room_pcds, pose_list, F_g_list, pcd_min, pcd_max, 24, path, lib=self.L,
+            device_id=int(_get(self.cfg, "main.device_id", 0)))
+        assert len(repr_embs) == len(room_2d_points) and len(room_id2img_id) == len(room_2d_points)
+        self.room_id2img_ids = room_id2img_id
+        for i in range(len(room_2d_points)):
+            room = Room(str(floor.floor_id) + "_" + str(i), floor.floor_id, name="room_" + str(i))
+            room.pcd = room_pcds[i] if hasattr(room_pcds[i], "points") else _Pcd(room_pcds[i])
+            room.vertices = np.asarray(room_2d_points[i], np.float64).reshape(-1, 2)
+            floor.add_room(room)
+            room.room_height, room.room_zero_level = floor.floor_height, floor.floor_zero_level
+            room.embeddings = repr_embs[i]
+            room.represent_images = [int(k * skip) for k in repr_ids[i]]
+            room.sample_images = [int(k * skip) for k in room_id2img_id[i]]
+            room.clip_embeddings = room_clip[i]
+            self.rooms.append(room)
+        view_index = 0
+        paths = getattr(self.dataset, "frameId2imgPath", None)
+        for room_id in range(len(room_id2img_id)):
+            for img_id in room_id2img_id[room_id]:
+                retarget = img_id * skip
+                view = View(str(floor.floor_id) + "_" + str(room_id) + "_" + str(view_index), room_id, retarget)
+                view.img_path = paths[retarget] if paths is not None else None
+                self.views.append(view)
+                view_index += 1
+                floor.rooms[room_id].views.append(view)
+        return room_pcds
+
     def set_label_feats(self, text_feats, classes):
         self._label_feats = (np.asarray(text_feats, np.float32), list(classes))
 
@@ -594,9 +760,14 @@ class Graph:
                 self.objects.append(obj)
         self._index = None
 
-    def build_hier_multimodal_scene_graph(self, save_path=None, rooms: Sequence[dict] | None = None):
-        """graph.py:2033-2076 (navigation graph omitted, rooms supplied)."""
+    def build_hier_multimodal_scene_graph(self, save_path=None, rooms: Sequence[dict] | None = None, room_regions=None):
+        """graph.py:2033-2076 (navigation graph omitted).  Rooms: `room_regions` = per floor a list of [n, 2] (x, z)
+        region point arrays -> the mirrored segment_hmsg_room (room clouds, room embeddings, View nodes); or `rooms` =
+        ready-made room specs (set_rooms)."""
         self.segment_floors_manually(save_path)
+        if room_regions is not None:
+            for fl, regions in zip(self.floors, room_regions):
+                self.segment_hmsg_room(fl, save_path, room_2d_points=regions)
         if rooms is not None:
             self.set_rooms(rooms)
         self.segment_hmsg_objects(save_path)
@@ -605,29 +776,133 @@ class Graph:
                 room.merge_objects()
             self.objects = [o for room in self.rooms for o in room.objects]
             self._index = None
+        self.create_graph_new()
         if save_path is not None:
             self.save_hmsg_graph(os.path.join(save_path, "graph"))
 
+    # ------------------------------------------------------------------ A11: graph.py:1752-1775
+    def create_graph_new(self):
+        """Building(0) - Floor - Room - Object, Room - View, View - Object.  As in the reference, `room.room_id ==
+        view.room_id` compares the room's string id with the int room index a freshly built View carries
+        (graph.py:1176-1189), so Room - View edges appear only after load_hmsg_graph."""
+        for floor in self.floors:
+            self.graph.add_node(floor, name="floor", type="floor")
+            self.graph.add_edge(0, floor)
+            for room in floor.rooms:
+                self.graph.add_node(room, name="room", type="room")
+                self.graph.add_edge(floor, room)
+                for obj in room.objects:
+                    self.graph.add_node(obj, name=obj.name, type="object")
+                    self.graph.add_edge(room, obj)
+        for view in self.views:
+            self.graph.add_node(view, name="view", type="view")
+            for floor in self.floors:
+                hit = False
+                for room in floor.rooms:
+                    if room.room_id == view.room_id:
+                        self.graph.add_edge(room, view)
+                        hit = True
+                        break
+                if hit:
+                    pass                         # (the reference's `break` leaves only the inner loop)
+            for obj in self.objects:
+                if obj.object_id in view.object_ids:
+                    self.graph.add_edge(view, obj)
+
     # ------------------------------------------------------------------ A11 persistence: graph.py:1801-1987
     def save_hmsg_graph(self, path):
-        for sub, nodes in (("floors", self.floors), ("rooms", self.rooms), ("objects", self.objects), ("views", self.views)):
+        """graph.py:1801-1824: every node OF THE GRAPH is written (create_graph_new must have run)."""
+        for sub in ("floors", "rooms", "objects", "views"):
             os.makedirs(os.path.join(path, sub), exist_ok=True)
-            for n in nodes:
-                n.save(os.path.join(path, sub))
+        for node in self.graph.nodes():
+            for cls, sub in ((Floor, "floors"), (Room, "rooms"), (Object, "objects"), (View, "views")):
+                if isinstance(node, cls):
+                    node.save(os.path.join(path, sub))
+
+    save_graph = save_hmsg_graph
 
     def save_full_pcd(self, path):
         os.makedirs(path, exist_ok=True)
         _write_ply(os.path.join(path, "full_pcd.ply"), self.full_pcd.points)
+        print("full pcd saved to disk in {}".format(path))
+
+    def load_full_pcd(self, path):
+        """graph.py:3782-3795."""
+        if not os.path.exists(path):
+            print("full pcd not found in {}".format(path))
+            return None
+        self.full_pcd = _Pcd(_read_ply(os.path.join(path, "full_pcd.ply")))
+        print("full pcd loaded from disk with shape {}".format(np.asarray(self.full_pcd.points).shape))
+        return self.full_pcd
 
     def save_full_pcd_feats(self, path):
+        """graph.py:3797-3830: instances without points are dropped, then mask_feats.pt / full_feats.pt (torch)."""
+        import torch
         os.makedirs(path, exist_ok=True)
-        np.save(os.path.join(path, "mask_feats.npy"), np.stack([np.asarray(f).reshape(-1) for f in self.mask_feats]))
-        np.save(os.path.join(path, "full_feats.npy"), np.asarray(self.full_feats_array))
+        keep = [(p, f) for p, f in zip(self.mask_pcds, self.mask_feats) if len(p.points) > 0]
+        self.mask_pcds, self.mask_feats = [k[0] for k in keep], [k[1] for k in keep]
+        if len(self.mask_feats) != 0:
+            self.mask_feats = np.array(self.mask_feats)
+            torch.save(torch.from_numpy(self.mask_feats), os.path.join(path, "mask_feats.pt"))
+        if len(self.full_feats_array) != 0:
+            torch.save(torch.from_numpy(np.asarray(self.full_feats_array)), os.path.join(path, "full_feats.pt"))
+        print("full pcd feats saved to disk in {}".format(path))
+
+    def load_full_pcd_feats(self, path, full_feats=False, normalize=True):
+        """graph.py:3832-3876."""
+        import torch
+        if not os.path.exists(path):
+            print("full pcd feats not found in {}".format(path))
+            return None
+        t = torch.load(os.path.join(path, "full_feats.pt" if full_feats else "mask_feats.pt")).float()
+        if normalize:
+            t = torch.nn.functional.normalize(t, p=2, dim=-1)
+        arr = t.cpu().numpy()
+        if full_feats:
+            self.full_feats_array = arr
+        else:
+            self.mask_feats = arr
+        print("full pcd feats loaded from disk with shape {}".format(arr.shape))
+        return arr
 
     def save_masked_pcds(self, path, state="both"):
-        os.makedirs(os.path.join(path, "objects"), exist_ok=True)
-        for i, pcd in enumerate(self.mask_pcds):
-            _write_ply(os.path.join(path, "objects", "pcd_%d.ply" % i), pcd.points)
+        """graph.py:3880-3942: instances with fewer than 10 points go first; objects/pcd_<i>.ply (+ masked_pcd.ply)."""
+        for i in reversed(range(len(self.mask_pcds))):
+            if len(self.mask_pcds[i].points) < 10:
+                self.mask_pcds.pop(i)
+                self.mask_feats = list(self.mask_feats)
+                self.mask_feats.pop(i)
+        os.makedirs(path, exist_ok=True)
+        objects_path = os.path.join(path, "objects")
+        if state in ("both", "objects"):
+            os.makedirs(objects_path, exist_ok=True)
+            for i, pcd in enumerate(self.mask_pcds):
+                _write_ply(os.path.join(objects_path, "pcd_%d.ply" % i), pcd.points)
+        if state in ("both", "full"):
+            allp = [np.asarray(p.points).reshape(-1, 3) for p in self.mask_pcds]
+            _write_ply(os.path.join(path, "masked_pcd.ply"), np.concatenate(allp) if allp else np.zeros((0, 3)))
+        print("masked pcds saved to disk in {}".format(path))
+
+    def load_masked_pcds_new(self, path):
+        """graph.py:3944-3990: needs the mask features first; features of missing clouds are deleted."""
+        if len(self.mask_feats) == 0:
+            print("load full pcd feats first")
+            return None
+        objects_path = os.path.join(path, "objects")
+        if not os.path.exists(objects_path):
+            print("masked pcds for objects not found in {}".format(path))
+            return None
+        self.mask_pcds, not_found = [], []
+        for i in range(len(os.listdir(objects_path))):
+            f = os.path.join(objects_path, "pcd_{}.ply".format(i))
+            if os.path.exists(f):
+                self.mask_pcds.append(_Pcd(_read_ply(f)))
+            else:
+                print("masked pcd {} not found in {}".format(i, path))
+                not_found.append(i)
+        not_found = [i for i in not_found if i < len(self.mask_feats)]
+        self.mask_feats = np.delete(self.mask_feats, not_found, axis=0)
+        return self.mask_pcds
 
     def load_hmsg_graph(self, path):
         if not os.path.isdir(path):
@@ -639,11 +914,15 @@ class Graph:
             fl = Floor(f.split(".")[0], name="floor_" + f.split(".")[0])
             fl.load(os.path.join(path, "floors"))
             self.floors.append(fl)
+            self.graph.add_node(fl, name="floor_" + f.split(".")[0], type="floor")
+            self.graph.add_edge(0, fl)
         for f in sorted(x for x in os.listdir(os.path.join(path, "rooms")) if x.endswith(".ply")):   # lexicographic (:1931)
             rid = f.split(".")[0]
             room = Room(rid, rid.split("_")[0])
             room.load_new(os.path.join(path, "rooms"))
             self.rooms.append(room)
+            self.graph.add_node(room, name="room_" + rid, type="room")
+            self.graph.add_edge(self.floors[int(rid.split("_")[0])], room)
             fl = self.floors[int(room.floor_id)]
             if fl.rooms and isinstance(fl.rooms[0], str):
                 fl.rooms = []
@@ -657,13 +936,19 @@ class Graph:
             obj.load_new(os.path.join(path, "objects"))
             obj.room_id = room_id
             self.objects.append(obj)
+            self.graph.add_node(obj, name="object_" + oid, type="object")
+            self.graph.add_edge(parent, obj)
             parent.add_object(obj)
         for f in sorted(os.listdir(os.path.join(path, "views"))):
             vid = f.split(".")[0]
             v = View(vid, "_".join(vid.split("_")[:2]), name="view_" + vid)
             v.load(os.path.join(path, "views"))
             v.room_id = "_".join(vid.split("_")[:2])
+            parent = next((r for r in self.rooms if r.room_id == v.room_id), None)
+            assert parent is not None, f"Couldn't find the room with room id {v.room_id}"
             self.views.append(v)
+            self.graph.add_node(v, name="view_" + vid, type="view")
+            self.graph.add_edge(parent, v)
         self._index = None
         return self
 
@@ -735,22 +1020,38 @@ class Graph:
         back = {g: l for l, g in zip(room_ids, rooms_global)}
         return [int(i) for i in idx[0][keep]], [back[int(r)] for r in room[0][keep]], [float(s) for s in score[0][keep]]
 
-    def query_hierarchy_protected_icra(self, query_instruction, top_k=1, use_gpt=False):
-        """graph.py:3483-3591 with the LLM parse replaced by a pre-parsed triple:
-        `query_instruction` = (floor_query | None, room_query, object_query)."""
-        floor_q, room_q, obj_q = query_instruction
-        negatives = ["wall"] if (room_q and "Exhibition" in room_q) else ["background"]
+    def _parse(self, query_instruction):
+        if isinstance(query_instruction, str):
+            return type(self).instruction_parser(query_instruction)
+        return tuple(query_instruction)                     # already parsed (floor | None, room, object)
+
+    def _hier_query(self, query_instruction, top_k, negatives, icra):
+        import time
+        t0 = time.time()
+        floor_q, room_q, obj_q = self._parse(query_instruction)
+        llm_parse_time = time.time() - t0
+        if icra and room_q and "Exhibition" in room_q:
+            negatives = ["wall"]
         floor_id = self.query_floor(floor_q) if floor_q is not None else -1
         room_ids = self.query_hmsg_room(room_q, floor_id=floor_id, query_method="label") if room_q is not None else []
         obj_ids, room_ids2, scores = self.query_hmsg_object(obj_q, floor_id=floor_id, room_ids=room_ids, top_k=top_k,
                                                             negative_prompt=negatives) if obj_q is not None else ([], [], [])
-        res = dict(room_query=room_q, object_query=obj_q, negative_labels=negatives, object_scores=scores,
-                   LLM_Parse_Time=0.0, FastMatching=0.0, ObjectInImageCheck=0.0, VLM_Rethinking=0.0, Re_Matching=0.0,
-                   Total_Time=0.0)
+        res = dict(room_query=room_q, object_query=obj_q, negative_labels=negatives, object_scores=scores)
+        if icra:
+            res.update(LLM_Parse_Time=llm_parse_time, FastMatching=0.0, ObjectInImageCheck=0.0, VLM_Rethinking=0.0,
+                       Re_Matching=0.0, Total_Time=0.0)
         rooms = [self.floors[floor_id].rooms[k] for k in room_ids2] if floor_id != -1 else [self.rooms[k] for k in room_ids2]
         return (self.floors[floor_id] if floor_id != -1 else None, rooms, [self.objects[i] for i in obj_ids], res)
 
-    query_hierarchy_protected = query_hierarchy_protected_icra
+    def query_hierarchy_protected_icra(self, query_instruction, top_k=1, use_gpt=False):
+        """graph.py:3483-3591: negatives ["background"] (["wall"] for an "Exhibition" room); `query_instruction` is the
+        sentence (parsed by Graph.instruction_parser, the reference asks an LLM) or an already parsed triple.  The
+        slow-reasoning branch (use_gpt) is out of scope."""
+        return self._hier_query(query_instruction, top_k, ["background"], icra=True)
+
+    def query_hierarchy_protected(self, query_instruction, top_k=1, use_gpt=False):
+        """graph.py:3593-3716: the long background-label list + monitor / wall / speaker as negatives."""
+        return self._hier_query(query_instruction, top_k, BACKGROUND_LABELS + ["monitor", "wall", "speaker"], icra=False)
 
     # ------------------------------------------------------------------ assembly on an already built Scene
     @classmethod

@@ -169,6 +169,13 @@ int hmsg_denoise_instances(hmsg_t* h, double eps, int32_t min_points);
 int hmsg_instance_room_share(hmsg_t* h, int32_t n_rooms, const int64_t* vert_off, const double* verts_xz, double radius,
                              double* share);
 
+/* ---- A9 camera -> room assignment of compute_room_embeddings (utils/graph_utils.py:244-291): out[q][s] =
+ * np.min(cdist([q], set s, "euclidean")) for n_q 2-D positions (camera x/z) against n_sets 2-D point sets (room
+ * clouds projected to x/z): pts_xy f64 [set_off[n_sets]][2], q_xy f64 [n_q][2], out f64 [n_q][n_sets] (inf for an empty
+ * set).  Host pointers. */
+int hmsg_points_min_dist_2d(int32_t device_id, int32_t n_sets, const int64_t* set_off, const double* pts_xy, int64_t n_q,
+                            const double* q_xy, double* out);
+
 /* ---- A12: retrieval over a node table (graph.py:3056-3162 query_hmsg_object and the GEMV of
  * query_hmsg_room / query_floor).  A table is N node embeddings (f64, as after load_hmsg_graph:
  * object.py:88-89, or f32 right after build) with a parent (room) id per node. */

@@ -75,11 +75,14 @@ class PointCloud:
         return self.select_by_index(ind), ind.tolist()
 
     def select_by_index(self, ind):
+        """Open3D PointCloud::SelectByIndex: a boolean mask over the points -- the selected points come back ONCE
+        each, in their original order, however often or in whatever order the index list names them."""
         out = PointCloud()
-        ind = np.asarray(ind, dtype=np.int64)
-        out.points = np.asarray(self.points)[ind]
+        mask = np.zeros(len(self.points), bool)
+        mask[np.asarray(ind, dtype=np.int64)] = True
+        out.points = np.asarray(self.points)[mask]
         if len(self.colors) == len(self.points):
-            out.colors = np.asarray(self.colors)[ind]
+            out.colors = np.asarray(self.colors)[mask]
         return out
 
     def get_axis_aligned_bounding_box(self):
@@ -104,12 +107,36 @@ class PointCloud:
         return len(self.points) > 0
 
 
+def _write_ply(path, pcd, *a, **k):
+    """o3d.io.write_point_cloud: binary little-endian PLY with double x / y / z (colours omitted: not on the path)."""
+    pts = np.asarray(pcd.points, dtype=np.float64).reshape(-1, 3)
+    with open(path, "wb") as f:
+        f.write(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty double x\nproperty double y\n"
+                 "property double z\nend_header\n" % len(pts)).encode())
+        f.write(pts.astype("<f8").tobytes())
+    return True
+
+
+def _read_ply(path, *a, **k):
+    out = PointCloud()
+    with open(path, "rb") as f:
+        n = 0
+        while True:
+            line = f.readline().decode().strip()
+            if line.startswith("element vertex"):
+                n = int(line.split()[-1])
+            elif line == "end_header":
+                break
+        out.points = np.frombuffer(f.read(n * 24), dtype="<f8").reshape(n, 3).copy()
+    return out
+
+
 def make_open3d():
     o3d = types.ModuleType("open3d")
     o3d.geometry = types.SimpleNamespace(PointCloud=PointCloud, AxisAlignedBoundingBox=_AABB)
     o3d.utility = types.SimpleNamespace(
         Vector3dVector=lambda a: np.array(a, dtype=np.float64).reshape(-1, 3))
-    o3d.io = types.SimpleNamespace(write_point_cloud=lambda *a, **k: True, read_point_cloud=None)
+    o3d.io = types.SimpleNamespace(write_point_cloud=_write_ply, read_point_cloud=_read_ply)
     o3d.visualization = types.SimpleNamespace()
     return o3d
 

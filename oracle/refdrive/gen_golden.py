@@ -32,6 +32,7 @@ def import_reference():
     import matplotlib
     matplotlib.use("Agg")
     import matplotlib.pyplot as plt
+    plt.switch_backend("Agg")                       # load a head-less backend, then pin it (navigation_graph.py:33 asks for TkAgg)
     plt.switch_backend = lambda *a, **k: None
     sys.path.insert(0, REF)
     import torch
@@ -616,6 +617,105 @@ def gen_mergeobjects(G, X, out_dir):
         out["vertices_%d" % k] = np.asarray(o.vertices, np.float64)
     np.savez_compressed(os.path.join(out_dir, "mergeobjects.npz"), **out)
     print("merged", len(case), "->", len(room.objects), out["ids"].tolist(), out["names"].tolist(), out["npts"].tolist())
+
+
+def roomemb_case():
+    """Rooms (x/z lattices lifted to clouds), camera poses and per-image CLIP features for compute_room_embeddings:
+    one room with more than 24 images (KMeans path), one with fewer, one that gets no camera inside the floor bounds
+    (forced assignment from the cameras OUTSIDE the bounds), cameras above / below the floor."""
+    rng = np.random.Generator(np.random.PCG64(2025))
+    D = 20
+
+    def room(x0, z0, w, h):
+        xs, zs = np.arange(x0, x0 + w, 0.25), np.arange(z0, z0 + h, 0.25)
+        g = np.stack(np.meshgrid(xs, zs, indexing="ij"), -1).reshape(-1, 2)
+        return np.stack([g[:, 0], rng.uniform(0.0, 2.5, len(g)), g[:, 1]], axis=1)
+    rooms = [room(0, 0, 4, 3), room(5, 0, 3, 3), room(0, 5, 2, 2), room(9, 9, 1, 1)]
+    poses, embs = [], []
+    centres = rng.standard_normal((6, D))
+
+    def cam(x, y, z, c):
+        T = np.eye(4)
+        T[:3, 3] = [x, y, z]
+        e = centres[c] + 0.15 * rng.standard_normal(D)
+        poses.append(T)
+        embs.append((e / np.linalg.norm(e)).astype(np.float32)[None, :])
+    for k in range(40):
+        cam(rng.uniform(0.2, 3.8), 1.5, rng.uniform(0.2, 2.8), k % 5)        # room 0: 40 images -> KMeans(24)
+    for k in range(7):
+        cam(rng.uniform(5.2, 7.8), 1.4, rng.uniform(0.2, 2.8), 5)            # room 1: 7 images
+    cam(1.0, 9.0, 6.0, 2)                                                      # above the floor: never assigned normally
+    cam(9.4, -3.0, 9.4, 3)                                                     # below the floor, next to room 3
+    for k in range(3):
+        cam(rng.uniform(0.2, 1.8), 1.6, rng.uniform(5.2, 6.8), 1)            # room 2
+    return rooms, poses, embs, np.array([-0.1, 0.0, -0.1]), np.array([10.0, 2.6, 10.0])
+
+
+def gen_roomemb(G, X, out_dir):
+    """A9: the reference's compute_room_embeddings (utils/graph_utils.py:192-356)."""
+    import tempfile
+    o3d = sys.modules["open3d"]
+    from memory.hmsg.utils.graph_utils import compute_room_embeddings
+    rooms, poses, embs, pmin, pmax = roomemb_case()
+    pcds = []
+    for r in rooms:
+        pc = o3d.geometry.PointCloud()
+        pc.points = r
+        pcds.append(pc)
+    repr_embs, repr_ids, r2i, clip = compute_room_embeddings(pcds, poses, embs, pmin, pmax, 24, tempfile.mkdtemp())
+    out = dict(n_rooms=np.array(len(rooms)))
+    for i in range(len(rooms)):
+        out["repr_ids_%d" % i] = np.array(repr_ids[i], np.int64)
+        out["repr_embs_%d" % i] = np.array(repr_embs[i], np.float32).reshape(len(repr_ids[i]), -1)
+        out["img_ids_%d" % i] = np.array(r2i[i], np.int64)
+        out["clip_%d" % i] = np.asarray(clip[i], np.float32)
+    np.savez_compressed(os.path.join(out_dir, "roomemb.npz"), **out)
+    print("roomemb", {i: (len(r2i[i]), len(repr_ids[i])) for i in range(len(rooms))})
+
+
+def gen_graphedges(G, X, out_dir):
+    """A11: edges of the reference's create_graph_new (graph.py:1752-1775) on a freshly built graph (View.room_id is the
+    int room index there, so no Room - View edge appears) and of load_hmsg_graph (:1892-1987) after saving it."""
+    import json
+    import tempfile
+    import networkx as nx
+    o3d = sys.modules["open3d"]
+    from memory.hmsg.graph.floor import Floor
+    from memory.hmsg.graph.object import Object
+    from memory.hmsg.graph.room import Room
+    from memory.hmsg.graph.view import View
+
+    def make_pcd(p):
+        pc = o3d.geometry.PointCloud()
+        pc.points = np.asarray(p, dtype=np.float64)
+        return pc
+
+    def node_key(n):
+        for cls, tag, attr in ((Floor, "floor", "floor_id"), (Room, "room", "room_id"), (Object, "object", "object_id"),
+                               (View, "view", "view_id")):
+            if isinstance(n, cls):
+                return "%s:%s" % (tag, getattr(n, attr))
+        return "root:%s" % n
+
+    def edges(g):
+        return sorted(sorted([node_key(a), node_key(b)]) for a, b in g.graph.edges())
+    fl, rooms, objects, views = build_persist_graph(persist_case(), Floor, Room, Object, View, make_pcd)
+    for v in views:                       # build time: the per-floor room INDEX (graph.py:1176-1183)
+        v.room_id = int(str(v.room_id).split("_")[-1])
+    g = G.Graph.__new__(G.Graph)
+    g.graph = nx.Graph()
+    g.floors, g.rooms, g.objects, g.views = [fl], rooms, objects, views
+    g.create_graph_new()
+    built = edges(g)
+    tmp = tempfile.mkdtemp()
+    g.save_hmsg_graph(tmp)
+    g2 = G.Graph.__new__(G.Graph)
+    g2.graph = nx.Graph()
+    g2.floors, g2.rooms, g2.objects, g2.views = [], [], [], []
+    g2.load_hmsg_graph(tmp)
+    json.dump(dict(built=built, loaded=edges(g2), object_order=[o.object_id for o in g2.objects],
+                   view_order=[v.view_id for v in g2.views]), open(os.path.join(out_dir, "graphedges.json"), "w"), indent=0)
+    print("graph edges: built", len(built), "loaded", len(edges(g2)))
 
 
 def main():
