@@ -76,6 +76,8 @@ _SIGS = {
     "hmsg_index_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _P, C.c_int32, _P, C.POINTER(_P)]),
     "hmsg_index_destroy": (None, [_P]),
     "hmsg_index_last_error": (C.c_char_p, [_P]),
+    "hmsg_index_set_profiling": (C.c_int, [_P, C.c_int32]),
+    "hmsg_index_profile": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "hmsg_query_objects": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     "hmsg_similarity": (C.c_int, [_P, C.c_int32, _P, _P]),
     "hmsg_test_sort_pairs": (C.c_int, [_P, _P, C.c_int64, C.c_int32]),
@@ -351,6 +353,15 @@ class NodeIndex:
     def _ck(self, rc):
         if rc != 0:
             raise HmsgError(f"[{rc}] " + self.L.c.hmsg_index_last_error(self.ix).decode())
+
+    def set_profiling(self, on=True):
+        self._ck(self.L.c.hmsg_index_set_profiling(self.ix, int(on)))
+
+    def profile(self):
+        """(launches, total ms, total FLOP) of the float64 MFMA similarity GEMM."""
+        n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
+        self._ck(self.L.c.hmsg_index_profile(self.ix, C.byref(n), C.byref(ms), C.byref(fl)))
+        return int(n.value), float(ms.value), float(fl.value)
 
     def query_objects(self, T, qid, room_lists, k, use_negatives=True):
         T = np.ascontiguousarray(T, dtype=np.float32)

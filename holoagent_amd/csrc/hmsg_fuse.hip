@@ -458,19 +458,39 @@ __global__ void __launch_bounds__(256) k_memit(const int* __restrict__ nn, const
 
 // one lane per mask voxel: replay Open3D's accumulation -- sequential float64 sum of the snapped points in pixel
 // order, then / count (generic.py:188 -> o3d_voxel_down_sample)
+// (one step of the replay: `len` more copies of point p)
+__device__ __forceinline__ void mwalk_add(double& sx, double& sy, double& sz, double px, double py, double pz, int len) {
+    // short counts are added one by one, long ones in closed form (repeat_add costs a 64-bit division)
+    if (len >= 48) {
+        sx = repeat_add(sx, px, len);
+        sy = repeat_add(sy, py, len);
+        sz = repeat_add(sz, pz, len);
+    } else {
+        for (int j = 0; j < len; ++j) {
+            sx = __dadd_rn(sx, px);
+            sy = __dadd_rn(sy, py);
+            sz = __dadd_rn(sz, pz);
+        }
+    }
+}
+#define MWALK_LONG 96       /* slots with at least this many records go to the wave-per-slot kernel */
 __global__ void k_mwalk(const unsigned* __restrict__ off, const unsigned long long* __restrict__ recs, long long npts,
-                        const double* __restrict__ pts, double* __restrict__ out) {
+                        const double* __restrict__ pts, double* __restrict__ out, unsigned* __restrict__ long_cnt,
+                        unsigned* __restrict__ long_list, unsigned long_thr) {
     const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= npts) return;
+    const unsigned r0 = off[s], r1 = off[s + 1];
+    if (r1 - r0 >= long_thr) {         // a voxel close to the camera: its chain of dependent loads would outlast the grid
+        long_list[atomicAdd(long_cnt, 1u)] = (unsigned)s;
+        return;
+    }
     double sx = 0.0, sy = 0.0, sz = 0.0;
     unsigned long long n = 0;
-    // consecutive records of one map voxel (the same voxel on successive image rows) are one repetition count;
-    // short counts are added one by one, long ones in closed form (repeat_add costs a 64-bit division)
+    // consecutive records of one map voxel (the same voxel on successive image rows) are one repetition count
     unsigned cur_v = 0xffffffffu;
     int cur_len = 0;
     double px = 0.0, py = 0.0, pz = 0.0;
-    const unsigned r1 = off[s + 1];
-    for (unsigned r = off[s]; r <= r1; ++r) {
+    for (unsigned r = r0; r <= r1; ++r) {
         unsigned v = 0xffffffffu;
         int len = 0;
         if (r < r1) {
@@ -482,17 +502,7 @@ __global__ void k_mwalk(const unsigned* __restrict__ off, const unsigned long lo
             cur_len += len;
             continue;
         }
-        if (cur_len >= 48) {
-            sx = repeat_add(sx, px, cur_len);
-            sy = repeat_add(sy, py, cur_len);
-            sz = repeat_add(sz, pz, cur_len);
-        } else {
-            for (int j = 0; j < cur_len; ++j) {
-                sx = __dadd_rn(sx, px);
-                sy = __dadd_rn(sy, py);
-                sz = __dadd_rn(sz, pz);
-            }
-        }
+        mwalk_add(sx, sy, sz, px, py, pz, cur_len);
         n += (unsigned long long)cur_len;
         cur_v = v;
         cur_len = len;
@@ -507,6 +517,63 @@ __global__ void k_mwalk(const unsigned* __restrict__ off, const unsigned long lo
     out[(size_t)s * 3 + 0] = __ddiv_rn(sx, dn);
     out[(size_t)s * 3 + 1] = __ddiv_rn(sy, dn);
     out[(size_t)s * 3 + 2] = __ddiv_rn(sz, dn);
+}
+// the long slots: one WAVE per slot, 64 records (and their map points) fetched side by side, then folded in
+// order with broadcasts -- the additions are the same serial chain, the loads no longer are
+__global__ void __launch_bounds__(256) k_mwalk_long(const unsigned* __restrict__ off, const unsigned long long* __restrict__ recs,
+                                                    const double* __restrict__ pts, double* __restrict__ out,
+                                                    const unsigned* __restrict__ long_cnt, const unsigned* __restrict__ long_list) {
+    const int lane = threadIdx.x & 63;
+    const unsigned nwaves = (gridDim.x * blockDim.x) >> 6, nlong = *long_cnt;
+    // (a wave operation on every path: the kernel simulator of tests/emu classifies a kernel by its first launch,
+    //  and the list is often empty then)
+    if (__ballot(1) == 0ull) return;
+    for (unsigned t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; t < nlong; t += nwaves) {
+        const unsigned s = long_list[t];
+        const unsigned r0 = off[s], r1 = off[s + 1];
+        double sx = 0.0, sy = 0.0, sz = 0.0;
+        unsigned long long n = 0;
+        unsigned cur_v = 0xffffffffu;
+        int cur_len = 0;
+        double cx = 0.0, cy = 0.0, cz = 0.0;
+        for (unsigned rb = r0; rb < r1; rb += 64) {
+            const unsigned long long rec = rb + lane < r1 ? recs[rb + lane] : 0ull;
+            const unsigned mv = (unsigned)(rec >> 8);
+            double px = 0.0, py = 0.0, pz = 0.0;
+            if (rb + lane < r1) {
+                const double* p = pts + (size_t)mv * 3;
+                px = p[0];
+                py = p[1];
+                pz = p[2];
+            }
+            const int nrec = (int)min(64u, r1 - rb);
+            for (int q = 0; q < nrec; ++q) {
+                const unsigned long long rq = __shfl(rec, q);
+                const unsigned v = (unsigned)(rq >> 8);
+                const int len = (int)(rq & 255ull);
+                const double qx = __shfl(px, q), qy = __shfl(py, q), qz = __shfl(pz, q);
+                if (v == cur_v) {
+                    cur_len += len;
+                    continue;
+                }
+                mwalk_add(sx, sy, sz, cx, cy, cz, cur_len);
+                n += (unsigned long long)cur_len;
+                cur_v = v;
+                cur_len = len;
+                cx = qx;
+                cy = qy;
+                cz = qz;
+            }
+        }
+        mwalk_add(sx, sy, sz, cx, cy, cz, cur_len);
+        n += (unsigned long long)cur_len;
+        if (lane == 0) {
+            const double dn = (double)n;
+            out[(size_t)s * 3 + 0] = __ddiv_rn(sx, dn);
+            out[(size_t)s * 3 + 1] = __ddiv_rn(sy, dn);
+            out[(size_t)s * 3 + 2] = __ddiv_rn(sz, dn);
+        }
+    }
 }
 
 __global__ void k_gather_u32(const unsigned* __restrict__ src, const long long* __restrict__ idx, int n, unsigned* __restrict__ dst) {
@@ -566,7 +633,7 @@ void hmsg_fuse(hmsg_ctx* h) {
     DevBuf<MaskGeom> d_geom;
     d_geom.alloc((size_t)nmask_max);
     DevBuf<unsigned long long> mbitmap;
-    DevBuf<unsigned> mrank, chunk_recs, rec_off;
+    DevBuf<unsigned> mrank, chunk_recs, rec_off, long_list;
     DevBuf<long long> d_offidx;
     DevBuf<unsigned> d_offval;
     d_offidx.alloc((size_t)nmask_max);
@@ -583,6 +650,8 @@ void hmsg_fuse(hmsg_ctx* h) {
     // valid pixels exceeds the threshold.  The mean is taken over the u16 depths (exact integer sum); the reference
     // averages float32 metres, so a mask within ~1e-7 (relative) of the threshold can fall on the other side.
     const double filt_mm = c.max_mask_distance * c.depth_scale;
+    // (HMSG_DEBUG_MWALK_LONG: tests push every slot through the wave-per-slot replay)
+    const unsigned long_thr = getenv("HMSG_DEBUG_MWALK_LONG") ? (unsigned)atoi(getenv("HMSG_DEBUG_MWALK_LONG")) : (unsigned)MWALK_LONG;
 
     for (int fb0 = h->n_fused; fb0 < h->n_feat_frames; fb0 += FB) {
         const int nb = std::min(FB, h->n_feat_frames - fb0);
@@ -694,9 +763,15 @@ void hmsg_fuse(hmsg_ctx* h) {
             }
             {
                 ProfScope ps(h->prof, s, "k_mwalk", (double)nrec * 8.0 + (double)npts * 32.0);
+                long_list.ensure((size_t)npts + 1);
+                HIP_TRY(hipMemsetAsync(long_list.p, 0, 4, s));                    // [0] = counter, the list follows
                 hipLaunchKernelGGL(k_mwalk, dim3(cdiv((size_t)npts, 64)), dim3(64), 0, s, (const unsigned*)rec_off.p,
                                    (const unsigned long long*)sb.res_vals, npts, (const double*)h->pts.p,
-                                   h->masks3d.pts.p + (size_t)h->masks3d.total * 3);
+                                   h->masks3d.pts.p + (size_t)h->masks3d.total * 3, long_list.p, long_list.p + 1, long_thr);
+                hipLaunchKernelGGL(k_mwalk_long, dim3(1024), dim3(256), 0, s, (const unsigned*)rec_off.p,
+                                   (const unsigned long long*)sb.res_vals, (const double*)h->pts.p,
+                                   h->masks3d.pts.p + (size_t)h->masks3d.total * 3, (const unsigned*)long_list.p,
+                                   (const unsigned*)(long_list.p + 1));
             }
             HMSG_CHECK_LAUNCH();
             // per-mask point offsets = rank at the mask's first word

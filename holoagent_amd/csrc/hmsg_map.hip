@@ -196,7 +196,7 @@ struct VoxAcc {                 // per-slot colour / count accumulators (SoA)
 //   k_slots      pixel -> voxel slot (u32, kept for phase 2), colours / counts per run with integer atomics,
 //                number of runs per 4096-pixel chunk.  A run = consecutive pixels of one image row (inside one
 //                64-pixel wave slice) that fall into the same voxel (~8 pixels).
-//   k_emit_runs  run records (key = slot, value = first pixel << 8 | length) written in input order
+//   k_emit_runs  run records (key = slot, value = frame << 32 | row << 20 | first column << 8 | length) in input order
 //   stable sort by slot (hmsg_sort.hip), segment starts
 //   k_accum_ordered  one lane per voxel walks its runs in order: back-project again, s += p, centroid = s / n
 #define RUN_CHUNK 4096
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(256) k_slots(const unsigned short* __restrict_
     if (threadIdx.x == 0) chunk_runs[blockIdx.x] = s_runs;
 }
 
-__global__ void __launch_bounds__(256) k_emit_runs(const unsigned* __restrict__ slots, size_t total, int W,
+__global__ void __launch_bounds__(256) k_emit_runs(const unsigned* __restrict__ slots, size_t total, int W, size_t HW,
                                                    const unsigned* __restrict__ chunk_base, unsigned* __restrict__ keys,
                                                    unsigned long long* __restrict__ vals) {
     __shared__ unsigned s_w[4];
@@ -302,7 +302,9 @@ __global__ void __launch_bounds__(256) k_emit_runs(const unsigned* __restrict__ 
             const unsigned len = (unsigned)(lane - start_lane + 1);
             const unsigned pos = base + (unsigned)__popcll(tails & ((1ull << lane) - 1ull));
             keys[pos] = slot;
-            vals[pos] = ((unsigned long long)(i - (size_t)(lane - start_lane)) << 8) | (unsigned long long)len;
+            const size_t i0 = i - (size_t)(lane - start_lane);
+            const unsigned long long f = i0 / HW, p = i0 - f * HW;
+            vals[pos] = (f << 32) | ((p / (unsigned)W) << 20) | ((p % (unsigned)W) << 8) | (unsigned long long)len;
         }
         __syncthreads();
         if (threadIdx.x == 0) s_run += s_w[0] + s_w[1] + s_w[2] + s_w[3];
@@ -312,8 +314,10 @@ __global__ void __launch_bounds__(256) k_emit_runs(const unsigned* __restrict__ 
 
 // centroid = (sequential float64 sum of the voxel's points in input order) / count  (o3d_voxel_down_sample).
 // One WAVE per voxel: the additions are a serial chain by definition, but the back-projections that feed it are
-// not -- the lanes back-project the pixels of a run side by side and the wave then folds the points into the sum
-// in order with shuffles (uniform across lanes, so every lane holds the sum).
+// not.  The wave takes as many consecutive runs as fit its 64 lanes (runs are ~8 pixels), every lane back-projects
+// one pixel, and the points are then folded into the sum in order with broadcasts (uniform across lanes, so every
+// lane holds the sum).  A voxel seen from close by has thousands of runs: packing them 64 pixels at a time keeps
+// that chain -- the kernel lasts as long as the longest one -- short.
 __global__ void __launch_bounds__(256) k_accum_ordered(const unsigned short* __restrict__ depth, const double* __restrict__ pose,
                                                        CamK cam, float scale, int W, size_t HW, long long V,
                                                        const unsigned* __restrict__ off, const unsigned long long* __restrict__ runs,
@@ -324,25 +328,47 @@ __global__ void __launch_bounds__(256) k_accum_ordered(const unsigned short* __r
     double sx = 0.0, sy = 0.0, sz = 0.0;
     const unsigned r0 = off[v], r1 = off[v + 1];
     for (unsigned rb = r0; rb < r1; rb += 64) {
-        // this lane's run of the group of 64
+        // lane q holds run rb + q of this group of 64 runs; inclusive prefix of the run lengths
         const unsigned long long myrec = rb + lane < r1 ? runs[rb + lane] : 0ull;
+        const int mylen = (int)(myrec & 255ull);
+        int incl = mylen;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(incl, o);
+            if (lane >= o) incl += u;
+        }
         const int nrun = (int)min(64u, r1 - rb);
-        for (int q = 0; q < nrun; ++q) {
-            const unsigned long long rec = __shfl(myrec, q);
-            const size_t i0 = (size_t)(rec >> 8);
-            const int len = (int)(rec & 255ull);
+        int q0 = 0;                                   // first run of the next pack
+        while (q0 < nrun) {
+            const int base = q0 ? __shfl(incl, q0 - 1) : 0;
+            // runs q0 .. q1-1 fit into 64 lanes (a run is at most 64 long, so at least one does)
+            const unsigned long long fits = __ballot(lane >= q0 && lane < nrun && incl - base <= 64);
+            const int q1 = q0 + __popcll(fits);
+            const int npix = __shfl(incl, q1 - 1) - base;
+            // lane L back-projects pixel L of the pack: find its run (uniform loop over the few runs of the pack)
             double wx = 0.0, wy = 0.0, wz = 0.0;
-            if (lane < len) {
-                const int f = (int)(i0 / HW);
-                const int p = (int)(i0 - (size_t)f * HW);
-                const int y = p / W, x0 = p - y * W;
-                backproject(depth[i0 + lane], x0 + lane, y, cam, scale, pose + (size_t)f * 16, wx, wy, wz);
+            unsigned long long rec = 0ull;
+            int start = 0;
+            for (int q = q0; q < q1; ++q) {
+                const unsigned long long rq = __shfl(myrec, q);
+                const int eq = __shfl(incl, q) - base;
+                const int sq = eq - (int)(rq & 255ull);
+                if (lane >= sq && lane < eq) {
+                    rec = rq;
+                    start = sq;
+                }
             }
-            for (int j = 0; j < len; ++j) {
+            if (lane < npix) {
+                const int f = (int)(rec >> 32);
+                const int y = (int)((rec >> 20) & 0xfffull), x0 = (int)((rec >> 8) & 0xfffull);
+                const int x = x0 + (lane - start);
+                backproject(depth[(size_t)f * HW + (size_t)y * W + x], x, y, cam, scale, pose + (size_t)f * 16, wx, wy, wz);
+            }
+            for (int j = 0; j < npix; ++j) {
                 sx = __dadd_rn(sx, __shfl(wx, j));
                 sy = __dadd_rn(sy, __shfl(wy, j));
                 sz = __dadd_rn(sz, __shfl(wz, j));
             }
+            q0 = q1;
         }
     }
     if (lane == 0) {
@@ -669,7 +695,8 @@ void hmsg_build_map(hmsg_ctx* h) {
     SortBufs sb;
     sb.keys.alloc((size_t)std::max<unsigned long long>(nruns, 1));
     sb.vals.alloc((size_t)std::max<unsigned long long>(nruns, 1));
-    hipLaunchKernelGGL(k_emit_runs, dim3(nchunks), dim3(256), 0, s, (const unsigned*)slots.p, total, W,
+    HMSG_REQUIRE(W < 4096 && H < 4096, HMSG_ERR_UNSUPPORTED, "image sides must be below 4096 pixels");
+    hipLaunchKernelGGL(k_emit_runs, dim3(nchunks), dim3(256), 0, s, (const unsigned*)slots.p, total, W, (size_t)H * W,
                        (const unsigned*)chunk_runs.p, sb.keys.p, sb.vals.p);
     HMSG_CHECK_LAUNCH();
     {

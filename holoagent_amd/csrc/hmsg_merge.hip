@@ -59,6 +59,8 @@ struct OvGrid {             // device view of one cloud for the overlap kernels
 
 struct OvTask {             // count points of grid[x] within r of grid[y]
     int x, y;
+    int dep_n;              // second-direction tasks: number of points of the pair's smaller cloud (see k_ov_query)
+    int pad;
 };
 
 }  // namespace
@@ -165,10 +167,14 @@ __device__ __forceinline__ bool ov_hit(const OvGrid& Y, const unsigned* __restri
 #define OV_CHUNK 512
 // find_overlapping_ratio_faiss (graph_utils.py:645-662): a point of X overlaps when its exact float32
 // nearest neighbour in Y is closer than r^2, i.e. when SOME y has (dx*dx + dy*dy) + dz*dz < r2 in float32.
+// dep_counts (optional): the pair's first direction (the SMALLER cloud against the larger) has already been counted;
+// when that ratio alone exceeds the threshold the pair merges whatever this direction gives -- max(a, b) > th --
+// so the scan of the larger cloud is skipped (sequential merge: only the decision is needed, not the value).
 __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __restrict__ gr, const OvTask* __restrict__ tasks,
                            const unsigned* __restrict__ cells, const float* __restrict__ sorted, float r2, float r,
-                           unsigned* __restrict__ counts) {
+                           unsigned* __restrict__ counts, const unsigned* __restrict__ dep_counts, double th) {
     const OvTask t = tasks[blockIdx.y];
+    if (dep_counts && (double)dep_counts[blockIdx.y] / (double)t.dep_n > th) return;
     const OvGrid X = gr[t.x], Y = gr[t.y];
     unsigned local = 0;
     // a block takes OV_CHUNK consecutive points per trip: every point is a serial chain of L2 round trips, so a
@@ -360,25 +366,31 @@ struct Merger {
         ix_pts_used += npts_new;
     }
 
-    // ---- overlap ratios for a list of (i, j) pairs of L
-    void overlap_ratios(const std::vector<Cloud>& L, const std::vector<std::pair<int, int>>& pairs, std::vector<double>& ratio) {
+    // ---- overlap ratios for a list of (i, j) pairs of L.  `decide_th` >= 0 (sequential merge): only `ratio > th`
+    // is needed downstream, so the pair's smaller cloud is counted first and the scan of the larger one is skipped on
+    // the device when the first ratio already exceeds the threshold (its entry then reports the first ratio).
+    void overlap_ratios(const std::vector<Cloud>& L, const std::vector<std::pair<int, int>>& pairs, std::vector<double>& ratio,
+                        double decide_th) {
         ratio.assign(pairs.size(), 0.0);
         if (pairs.empty()) return;
+        const size_t P = pairs.size();
         // compact table of the clouds involved
         std::vector<int> slot(L.size(), -1);
         std::vector<OvGrid> g;
-        std::vector<OvTask> tasks;
-        tasks.reserve(pairs.size() * 2);
-        int maxn = 0;
-        for (auto& pr : pairs) {
-            for (int v : {pr.first, pr.second})
+        std::vector<OvTask> tasks(P * 2);          // [0, P): smaller -> larger,  [P, 2P): larger -> smaller
+        int maxn1 = 0, maxn2 = 0;
+        for (size_t k = 0; k < P; ++k) {
+            int a = pairs[k].first, b = pairs[k].second;
+            for (int v : {a, b})
                 if (slot[v] < 0) {
                     slot[v] = (int)g.size();
                     g.push_back(grid_of(L[v]));
-                    maxn = std::max(maxn, L[v].n);
                 }
-            tasks.push_back(OvTask{slot[pr.first], slot[pr.second]});
-            tasks.push_back(OvTask{slot[pr.second], slot[pr.first]});
+            if (L[a].n > L[b].n) std::swap(a, b);  // a = the smaller cloud
+            tasks[k] = OvTask{slot[a], slot[b], 0, 0};
+            tasks[P + k] = OvTask{slot[b], slot[a], L[a].n, 0};
+            maxn1 = std::max(maxn1, L[a].n);
+            maxn2 = std::max(maxn2, L[b].n);
         }
         d_grids.ensure(g.size());
         d_tasks.ensure(tasks.size());
@@ -388,28 +400,31 @@ struct Merger {
         HIP_TRY(hipMemsetAsync(d_counts.p, 0, tasks.size() * 4, s));
         const float r = (float)radius;
         const float r2 = (float)(radius * radius);   // `D < radius**2` with a float32 D (graph_utils.py:654-655)
-        // blocks per task: enough for the largest X at OV_CHUNK points per block, bounded by the launch size
-        const size_t tasks_per_launch = std::min<size_t>(32768, tasks.size());
-        const unsigned bx = std::max(1u, std::min(cdiv(maxn, OV_CHUNK), (unsigned)std::max<size_t>(64, ((size_t)1 << 19) / tasks_per_launch)));
         double ov_work = 0;
         for (auto& t : tasks) ov_work += 12.0 * g[t.x].n;
         {
             ProfScope ps(h->prof, s, "k_ov_query", ov_work);   // (the kernel launches only: not the read-back below)
-            for (size_t t0 = 0; t0 < tasks.size(); t0 += 32768) {
-                unsigned nt = (unsigned)std::min<size_t>(32768, tasks.size() - t0);
-                hipLaunchKernelGGL(k_ov_query, dim3(bx, nt), dim3(256), 0, s, (const double*)pool.p, (const OvGrid*)d_grids.p,
-                                   (const OvTask*)(d_tasks.p + t0), (const unsigned*)ix_cells.p, (const float*)ix_pts.p, r2, r,
-                                   d_counts.p + t0);
+            for (int dir = 0; dir < 2; ++dir) {
+                const int maxn = dir ? maxn2 : maxn1;
+                for (size_t t0 = 0; t0 < P; t0 += 32768) {
+                    const unsigned nt = (unsigned)std::min<size_t>(32768, P - t0);
+                    // blocks per task: enough for the largest X at OV_CHUNK points per block, bounded by the launch size
+                    const unsigned bx = std::max(1u, std::min(cdiv(maxn, OV_CHUNK), (unsigned)std::max<size_t>(64, ((size_t)1 << 19) / nt)));
+                    const size_t o = (size_t)dir * P + t0;
+                    hipLaunchKernelGGL(k_ov_query, dim3(bx, nt), dim3(256), 0, s, (const double*)pool.p, (const OvGrid*)d_grids.p,
+                                       (const OvTask*)(d_tasks.p + o), (const unsigned*)ix_cells.p, (const float*)ix_pts.p, r2, r,
+                                       d_counts.p + o, (dir && decide_th >= 0.0) ? (const unsigned*)(d_counts.p + t0) : (const unsigned*)nullptr,
+                                       decide_th);
+                }
             }
         }
         HMSG_CHECK_LAUNCH();
         std::vector<unsigned> hc(tasks.size());
         HIP_TRY(hipMemcpyAsync(hc.data(), d_counts.p, tasks.size() * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        for (size_t k = 0; k < pairs.size(); ++k) {
-            double a = (double)hc[2 * k] / (double)L[pairs[k].first].n;
-            double b = (double)hc[2 * k + 1] / (double)L[pairs[k].second].n;
-            ratio[k] = std::max(a, b);
+        for (size_t k = 0; k < P; ++k) {
+            const int na = std::min(L[pairs[k].first].n, L[pairs[k].second].n), nb = std::max(L[pairs[k].first].n, L[pairs[k].second].n);
+            ratio[k] = std::max((double)hc[k] / (double)na, (double)hc[P + k] / (double)nb);
         }
     }
 
@@ -482,7 +497,7 @@ struct Merger {
         }
         std::vector<double> ratio;
         lap(1);
-        overlap_ratios(L, pairs, ratio);
+        overlap_ratios(L, pairs, ratio, use_cache ? -1.0 : th);
         lap(2);
         // 2. components of `overlap > th` (scipy connected_components labels by lowest member index)
         std::vector<int> parent(n);

@@ -33,6 +33,7 @@ struct hmsg_index {
     DevBuf<float> Tf;
     DevBuf<int> d_qid, d_roff, d_rooms, d_oidx, d_oroom;
     DevBuf<double> d_oscore;
+    Prof prof;                   // live timing of the GEMM (hmsg_index_set_profiling)
 };
 
 __global__ void k_f32_to_f64(const float* __restrict__ a, double* __restrict__ b, size_t n) {
@@ -71,6 +72,74 @@ __global__ void __launch_bounds__(256) k_gemm_f64(const double* __restrict__ A, 
         int row = m0 + (lane >> 4) + 4 * r;
         if (row < M && col < N) S[(size_t)row * N + col] = acc[r];
     }
+}
+
+// Tiled version for the batched query path: a 256-thread workgroup owns a 128x128 tile of S, the four waves a
+// 2x2 arrangement of 64x64 quadrants = 4x4 accumulators of 16x16 (64 result registers per lane).  Per 16-wide k
+// step the workgroup stages a 128x16 panel of A and of B in LDS (k-major, one 64-byte global load per thread and
+// matrix, double-buffered: the loads of step t+1 are in flight while the 64 MFMAs of step t run), and every wave
+// reads 4 + 4 fragments for 16 MFMAs.  128x128x16 multiply-adds per 32 KB staged = 16 FLOP per byte of L2 traffic
+// (the one-wave-per-tile kernel above moves 1 byte per FLOP and has no reuse at all).
+#define GT 128
+#define GK 16
+#define GPAD 2
+__global__ void __launch_bounds__(256) k_gemm_f64_tiled(const double* __restrict__ A, const double* __restrict__ B, int M,
+                                                        long long N, int D, double* __restrict__ S) {
+    __shared__ double sa[2][GK][GT + GPAD];
+    __shared__ double sb[2][GK][GT + GPAD];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wr = wv >> 1, wc = wv & 1;
+    const long long tn = (N + GT - 1) / GT;
+    const int m0 = (int)(blockIdx.x / tn) * GT;
+    const long long n0 = (long long)(blockIdx.x % tn) * GT;
+    // staging: thread t loads 8 consecutive k of row t>>1 (64 bytes) of each matrix
+    const int lrow = tid >> 1, lk = (tid & 1) * 8;
+    const int ar = m0 + lrow < M ? m0 + lrow : M - 1;
+    const long long br = n0 + lrow < N ? n0 + lrow : N - 1;
+    const double* ap = A + (size_t)ar * D;
+    const double* bp = B + (size_t)br * D;
+    f64x4 acc[4][4];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+    double ra[8], rb[8];
+    auto load = [&](int k0) {
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + lk + u;
+            ra[u] = k < D ? ap[k] : 0.0;
+            rb[u] = k < D ? bp[k] : 0.0;
+        }
+    };
+    auto stage = [&](int buf) {
+        for (int u = 0; u < 8; ++u) {
+            sa[buf][lk + u][lrow] = ra[u];
+            sb[buf][lk + u][lrow] = rb[u];
+        }
+    };
+    load(0);
+    stage(0);
+    __syncthreads();
+    const int nk = (D + GK - 1) / GK;
+    const int kq = lane >> 4, li = lane & 15;
+    for (int t = 0; t < nk; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nk) load((t + 1) * GK);
+        for (int k = 0; k < GK; k += 4) {
+            double fa[4], fb[4];
+            for (int i = 0; i < 4; ++i) fa[i] = sa[buf][k + kq][wr * 64 + i * 16 + li];
+            for (int j = 0; j < 4; ++j) fb[j] = sb[buf][k + kq][wc * 64 + j * 16 + li];
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < nk) stage(buf ^ 1);
+        __syncthreads();
+    }
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            const long long col = n0 + wc * 64 + j * 16 + li;
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wr * 64 + i * 16 + kq + 4 * r;
+                if (row < M && col < N) S[(size_t)row * N + col] = acc[i][j][r];
+            }
+        }
 }
 
 #define QK_MAX 64
@@ -234,6 +303,13 @@ bool dev_ptr(const void* p) {
     return a.type == hipMemoryTypeDevice;
 }
 void gemm(hmsg_index* ix, const double* A, int M, double* S) {
+    if (M >= 64 && ix->N >= 64) {
+        const long long tiles = (long long)((M + GT - 1) / GT) * ((ix->N + GT - 1) / GT);
+        ProfScope ps(ix->prof, ix->stream, "k_gemm_f64", 2.0 * (double)M * (double)ix->N * (double)ix->D);
+        hipLaunchKernelGGL(k_gemm_f64_tiled, dim3((unsigned)tiles), dim3(256), 0, ix->stream, A, (const double*)ix->E.p, M, ix->N, ix->D, S);
+        HMSG_CHECK_LAUNCH();
+        return;
+    }
     long long tiles = (long long)((M + 15) / 16) * ((ix->N + 15) / 16);
     hipLaunchKernelGGL(k_gemm_f64, dim3(cdiv((size_t)tiles, 4)), dim3(256), 0, ix->stream, A, (const double*)ix->E.p, M, ix->N,
                        ix->D, S);
@@ -318,10 +394,32 @@ void hmsg_index_destroy(hmsg_index_t* ix) {
         (void)hipStreamSynchronize(ix->stream);
         (void)hipStreamDestroy(ix->stream);
     }
+    ix->prof.clear();
     delete ix;
 }
 
 const char* hmsg_index_last_error(const hmsg_index_t* ix) { return ix ? ix->err.c_str() : "null index"; }
+
+int hmsg_index_set_profiling(hmsg_index_t* ix, int32_t on) {
+    if (!ix) return HMSG_ERR_INVALID;
+    ix->prof.enabled = on != 0;
+    return HMSG_OK;
+}
+// launches, total milliseconds and total FLOP of the similarity GEMM since the index was created
+int hmsg_index_profile(hmsg_index_t* ix, int64_t* launches, double* total_ms, double* total_flop) {
+    if (!ix || !launches || !total_ms || !total_flop) return HMSG_ERR_INVALID;
+    (void)hipStreamSynchronize(ix->stream);
+    *launches = 0;
+    *total_ms = *total_flop = 0.0;
+    for (auto& e : ix->prof.ev) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, e.a, e.b) != hipSuccess) continue;
+        ++*launches;
+        *total_ms += t;
+        *total_flop += e.work;
+    }
+    return HMSG_OK;
+}
 
 int hmsg_query_objects(hmsg_index_t* ix, int32_t Q, int32_t C, const float* T, const int32_t* qid, const int32_t* room_off,
                        const int32_t* rooms, int32_t k, int32_t use_negatives, int32_t* out_idx, int32_t* out_room,

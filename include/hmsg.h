@@ -184,6 +184,9 @@ int hmsg_index_create(int32_t device_id, int32_t dim, int64_t n, const void* emb
                       const int32_t* room_of_node, hmsg_index_t** out);
 void hmsg_index_destroy(hmsg_index_t* ix);
 const char* hmsg_index_last_error(const hmsg_index_t* ix);
+/* live HIP-event timing of the similarity GEMM on the index's stream (measurement aid for bench.py) */
+int hmsg_index_set_profiling(hmsg_index_t* ix, int32_t on);
+int hmsg_index_profile(hmsg_index_t* ix, int64_t* launches, double* total_ms, double* total_flop);
 /* Q queries; query q has C text rows T[q][C][D] f32 (row `qid[q]` is the query itself, the others
  * the negative prompts), searches the nodes whose room id is listed in rooms[room_off[q] ..
  * room_off[q+1]) IN THAT ORDER (candidate order = room order then node order, graph.py:3099-3110),

@@ -30,6 +30,22 @@ def test_map_and_fuse_small(L):
     sc.close()
 
 
+def test_mask_walk_long_slot_path(L):
+    """The wave-per-slot replay of long mask voxels (k_mwalk_long) forced on every slot: still bit-identical."""
+    z = GI.load("build_ragged")
+    frames = GI.unpack_frames(z)[:5]
+    cfg = GI.unpack_cfg(z)
+    cfg["outlier_nb"] = 300
+    os.environ["HMSG_DEBUG_MWALK_LONG"] = "2"
+    try:
+        sc = PC.make_scene(L, frames, dict(feat_dim=cfg["feat_dim"], outlier_nb_points=300))
+        S, ref_pts, ref_cols = PC.check_map(sc, frames, cfg)
+        PC.check_fuse(sc, frames, S, cfg, ref_pts, ref_cols)
+        sc.close()
+    finally:
+        os.environ.pop("HMSG_DEBUG_MWALK_LONG", None)
+
+
 @pytest.mark.skipif(not os.environ.get("HMSG_EMU_SLOW"), reason="slow on the simulator (minutes); covered on the GPU")
 @pytest.mark.parametrize("merge_type", ["sequential", "hierarchical"])
 def test_merge_and_pool_small(L, merge_type):
@@ -97,3 +113,26 @@ def test_graph_end_to_end_tiny(L, tmp_path):
         top, sc = O.query_object(T, 0, emb, 3)
         assert [g2.objects[i].object_id for i in top] == [o.object_id for o in objs]
         np.testing.assert_allclose(res["object_scores"], sc, rtol=0, atol=1e-12)
+
+
+def test_query_tiled_gemm_small(L):
+    """The 128x128-tile float64 MFMA GEMM of the batched query path (ragged edges in M, N and D) against the numpy
+    restatement."""
+    from holoagent_amd._lib import NodeIndex
+    from oracle import hmsg_oracle as O
+    rng = np.random.Generator(np.random.PCG64(3))
+    N, R, Q, D, k = 203, 5, 71, 27, 4
+    emb = rng.standard_normal((N, D)) * 0.1
+    room = rng.integers(0, R, size=N).astype(np.int32)
+    T = rng.standard_normal((Q, 2, D)).astype(np.float32) * 0.1
+    lists = [sorted(rng.choice(R, size=int(rng.integers(1, 4)), replace=False).tolist()) for _ in range(Q)]
+    ix = NodeIndex(emb, room, lib_=L)
+    idx, rooms, score = ix.query_objects(T, np.zeros(Q, np.int32), lists, k)
+    for q in range(Q):
+        cand = [o for r in lists[q] for o in np.nonzero(room == r)[0]]
+        top, sc = O.query_object(T[q], 0, emb[cand], k)
+        assert [cand[t] for t in top] == [int(v) for v in idx[q] if v >= 0]
+        np.testing.assert_allclose(score[q][: len(top)], sc, rtol=0, atol=1e-12)
+    S = ix.similarity(T[:, 0, :])
+    np.testing.assert_allclose(S, np.dot(T[:, 0, :].astype(np.float64), emb.T), rtol=0, atol=1e-12)
+    ix.close()
