@@ -208,7 +208,9 @@ def main():
                 g_feats, g_rooms, rl, tq = feats, rooms, q_rooms, text
             if g_feats.shape[0] == 0:
                 return None
-            ix = NodeIndex(g_feats, g_rooms, device_id=local, lib_=L)
+            # one GPU: the index is gathered on the device from the node table (hmsg_index_from_nodes); N GPUs: from
+            # the all-gathered global table
+            ix = sc.index_from_nodes() if not use_dist else NodeIndex(g_feats, g_rooms, device_id=local, lib_=L)
             ix.set_profiling(True)
             out = ix.query_objects(tq, np.zeros(len(rl), np.int32), rl, k)
             state["gemm"] = ix.profile()                       # (launches, ms, FLOP) of the float64 MFMA GEMM

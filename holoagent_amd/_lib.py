@@ -29,6 +29,11 @@ class HmsgConfig(C.Structure):
     ]
 
 
+class HmsgNode(C.Structure):          # include/hmsg.h: hmsg_node
+    _fields_ = [("instance", C.c_int32), ("floor", C.c_int32), ("room", C.c_int32), ("counter", C.c_int32),
+                ("label", C.c_int32), ("n_points", C.c_int64)]
+
+
 class HmsgError(RuntimeError):
     pass
 
@@ -72,6 +77,10 @@ _SIGS = {
     "hmsg_voxel_down_sample": (C.c_int, [_P, _P, C.c_int64, C.c_double, _P, _P]),
     "hmsg_pool_instances": (C.c_int, [_P]),
     "hmsg_get_instance_feats": (C.c_int, [_P, _P]),
+    "hmsg_build_object_nodes": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P, _P, _P, C.c_int32, _P]),
+    "hmsg_num_nodes": (C.c_int64, [_P]),
+    "hmsg_get_nodes": (C.c_int, [_P, _P, _P]),
+    "hmsg_index_from_nodes": (C.c_int, [_P, C.POINTER(_P)]),
     "hmsg_points_min_dist_2d": (C.c_int, [C.c_int32, C.c_int32, _P, _P, C.c_int64, _P, _P]),
     "hmsg_index_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _P, C.c_int32, _P, C.POINTER(_P)]),
     "hmsg_index_destroy": (None, [_P]),
@@ -285,6 +294,38 @@ class Scene:
         self._ck(self.L.c.hmsg_instance_room_share(self.h, R, _ptr(off), _ptr(verts), float(radius), _ptr(out)))
         return out
 
+    def build_object_nodes(self, floor_zero, floor_height, room_floor, room_vertices, label_feats=None):
+        """A10 on the device (segment_hmsg_objects, graph.py:1582-1736, minus the per-view visibility test): returns the
+        node records (numpy structured array: instance, floor, room, counter, label, n_points)."""
+        nf, R = len(floor_zero), len(room_vertices)
+        fz = np.ascontiguousarray(floor_zero, np.float64)
+        fh = np.ascontiguousarray(floor_height, np.float64)
+        rf = np.ascontiguousarray(room_floor, np.int32)
+        off = np.zeros(R + 1, np.int64)
+        off[1:] = np.cumsum([len(v) for v in room_vertices])
+        verts = np.ascontiguousarray(np.concatenate([np.asarray(v, np.float64).reshape(-1, 2) for v in room_vertices])
+                                     if off[-1] else np.zeros((1, 2)), dtype=np.float64)
+        lf = None if label_feats is None else np.ascontiguousarray(label_feats, np.float32)
+        self._ck(self.L.c.hmsg_build_object_nodes(self.h, nf, _ptr(fz), _ptr(fh), R, _ptr(rf), _ptr(off), _ptr(verts),
+                                                  0 if lf is None else lf.shape[0], _ptr(lf)))
+        return self.nodes()
+
+    def nodes(self, embeddings=False):
+        n = int(self.L.c.hmsg_num_nodes(self.h))
+        rec = (HmsgNode * max(n, 1))()
+        emb = np.empty((n, self.cfg.feat_dim), np.float32) if embeddings else None
+        if n:
+            self._ck(self.L.c.hmsg_get_nodes(self.h, C.cast(rec, _P), _ptr(emb)))
+        out = np.array([(r.instance, r.floor, r.room, r.counter, r.label, r.n_points) for r in rec[:n]],
+                       dtype=[("instance", "i4"), ("floor", "i4"), ("room", "i4"), ("counter", "i4"), ("label", "i4"), ("n_points", "i8")])
+        return (out, emb) if embeddings else out
+
+    def index_from_nodes(self):
+        """Resident retrieval index over the node table, gathered on the device."""
+        ix = _P()
+        self._ck(self.L.c.hmsg_index_from_nodes(self.h, C.byref(ix)))
+        return NodeIndex._wrap(self.L, ix, int(self.L.c.hmsg_num_nodes(self.h)), self.cfg.feat_dim)
+
     def voxel_down_sample(self, points, voxel_size):
         """Open3D voxel_down_sample of an [n, 3] f64 cloud (canonical ascending voxel order) on the device."""
         pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
@@ -338,6 +379,12 @@ class NodeIndex:
         if rc != 0:
             raise HmsgError(f"hmsg_index_create failed ({rc})")
         self.ix = ix
+
+    @classmethod
+    def _wrap(cls, L, ix, n, d):
+        self = cls.__new__(cls)
+        self.L, self.ix, self.N, self.D = L, ix, n, d
+        return self
 
     def close(self):
         if getattr(self, "ix", None):

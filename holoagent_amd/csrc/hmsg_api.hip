@@ -183,7 +183,8 @@ int hmsg_reset(hmsg_t* h) {
         h->nmask.clear();
         h->mask_first.clear();
         h->have_K = false;
-        h->map_ready = h->feats_final = h->merged = h->pooled = false;
+        h->map_ready = h->feats_final = h->merged = h->pooled = h->inst_denoised = false;
+        h->nodes.clear();
         h->V = h->V0 = 0;
         h->masks3d.off.clear();
         h->masks3d.total = 0;
@@ -451,7 +452,10 @@ int hmsg_get_instance_points(const hmsg_t* hc, double* xyz) {
 
 int hmsg_denoise_instances(hmsg_t* h, double eps, int32_t min_points) {
     if (!h) return HMSG_ERR_INVALID;
-    return guard(h, [&] { hmsg_denoise_inst(h, eps, min_points); });
+    return guard(h, [&] {
+        hmsg_denoise_inst(h, eps, min_points);
+        if (eps == 0.05 && min_points == 10) h->inst_denoised = true;
+    });
 }
 
 int hmsg_voxel_down_sample(hmsg_t* h, const double* points, int64_t n, double voxel_size, double* out_points, int64_t* out_n) {

@@ -214,8 +214,10 @@ __device__ __forceinline__ double repeat_add(double s, double p, int len) {
                 const unsigned long long d = iq + (qf > 0.5 ? 1ull : 0ull);
                 const unsigned long long top = (1ull << 53) - 1ull;
                 if (S + iq <= top) {                         // (each step needs S + q < 2^53 before it)
-                    unsigned long long k = (top - iq - S) / d + 1ull;
-                    if (k > (unsigned long long)len) k = (unsigned long long)len;
+                    // all `len` steps stay in the binade when S + (len-1)*d + iq <= top (the usual case: no division)
+                    unsigned long long k = (unsigned long long)len;
+                    const unsigned long long room = top - iq - S;
+                    if (__umul64hi(k - 1ull, d) != 0ull || (k - 1ull) * d > room) k = room / d + 1ull;
                     S += k * d;
                     const double r = ldexp((double)S, e - 1075);
                     s = s < 0.0 ? -r : r;
@@ -228,6 +230,14 @@ __device__ __forceinline__ double repeat_add(double s, double p, int len) {
         --len;
     }
     return s;
+}
+
+// value of lane `src` (wave-uniform) as a scalar broadcast: v_readlane, not an LDS permute
+__device__ __forceinline__ double wave_bcast_f64(double v, int src) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)b >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
 // ------------------------------------------------------------------ scene state
@@ -333,6 +343,9 @@ struct hmsg_ctx {
     bool merged = false;
     DevBuf<float> inst_feats;      // [N][D]
     bool pooled = false;
+    bool inst_denoised = false;    // the per-object pcd_denoise_dbscan(0.05, 10) of graph.py:1589-1591 has run
+    std::vector<hmsg_node> nodes;  // object nodes (hmsg_build_object_nodes)
+    std::vector<int> node_label;   // per instance: arg-max label (-1 without a vocabulary)
     // scratch
     DevBuf<unsigned> scan_tmp;
 };

@@ -460,8 +460,8 @@ __global__ void __launch_bounds__(256) k_memit(const int* __restrict__ nn, const
 // order, then / count (generic.py:188 -> o3d_voxel_down_sample)
 // (one step of the replay: `len` more copies of point p)
 __device__ __forceinline__ void mwalk_add(double& sx, double& sy, double& sz, double px, double py, double pz, int len) {
-    // short counts are added one by one, long ones in closed form (repeat_add costs a 64-bit division)
-    if (len >= 48) {
+    // short counts are added one by one, longer ones in closed form
+    if (len >= 16) {
         sx = repeat_add(sx, px, len);
         sy = repeat_add(sy, py, len);
         sz = repeat_add(sz, pz, len);
@@ -473,17 +473,25 @@ __device__ __forceinline__ void mwalk_add(double& sx, double& sy, double& sz, do
         }
     }
 }
-#define MWALK_LONG 96       /* slots with at least this many records go to the wave-per-slot kernel */
+#define MWALK_LONG 64       /* slots with at least this many records go to the wave-per-slot kernel */
 __global__ void k_mwalk(const unsigned* __restrict__ off, const unsigned long long* __restrict__ recs, long long npts,
                         const double* __restrict__ pts, double* __restrict__ out, unsigned* __restrict__ long_cnt,
                         unsigned* __restrict__ long_list, unsigned long_thr) {
     const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= npts) return;
-    const unsigned r0 = off[s], r1 = off[s + 1];
-    if (r1 - r0 >= long_thr) {         // a voxel close to the camera: its chain of dependent loads would outlast the grid
-        long_list[atomicAdd(long_cnt, 1u)] = (unsigned)s;
-        return;
+    const bool live = s < npts;
+    const unsigned r0 = live ? off[s] : 0u, r1 = live ? off[s + 1] : 0u;
+    // a voxel close to the camera: its chain of dependent loads would outlast the grid -> wave-per-slot kernel.
+    // (list slots per wave: one atomic on the counter per wave, not per slot)
+    const bool is_long = live && r1 - r0 >= long_thr;
+    const unsigned long long lm = __ballot(is_long);
+    if (lm) {
+        const int lane = threadIdx.x & 63, leader = __ffsll(lm) - 1;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(long_cnt, (unsigned)__popcll(lm));
+        base = __shfl(base, leader);
+        if (is_long) long_list[base + (unsigned)__popcll(lm & ((1ull << lane) - 1ull))] = (unsigned)s;
     }
+    if (!live || is_long) return;
     double sx = 0.0, sy = 0.0, sz = 0.0;
     unsigned long long n = 0;
     // consecutive records of one map voxel (the same voxel on successive image rows) are one repetition count
@@ -548,10 +556,9 @@ __global__ void __launch_bounds__(256) k_mwalk_long(const unsigned* __restrict__
             }
             const int nrec = (int)min(64u, r1 - rb);
             for (int q = 0; q < nrec; ++q) {
-                const unsigned long long rq = __shfl(rec, q);
-                const unsigned v = (unsigned)(rq >> 8);
-                const int len = (int)(rq & 255ull);
-                const double qx = __shfl(px, q), qy = __shfl(py, q), qz = __shfl(pz, q);
+                const unsigned v = (unsigned)__builtin_amdgcn_readlane((int)mv, q);
+                const int len = __builtin_amdgcn_readlane((int)(rec & 255ull), q);
+                const double qx = wave_bcast_f64(px, q), qy = wave_bcast_f64(py, q), qz = wave_bcast_f64(pz, q);
                 if (v == cur_v) {
                     cur_len += len;
                     continue;
@@ -765,15 +772,22 @@ void hmsg_fuse(hmsg_ctx* h) {
                 ProfScope ps(h->prof, s, "k_mwalk", (double)nrec * 8.0 + (double)npts * 32.0);
                 long_list.ensure((size_t)npts + 1);
                 HIP_TRY(hipMemsetAsync(long_list.p, 0, 4, s));                    // [0] = counter, the list follows
-                hipLaunchKernelGGL(k_mwalk, dim3(cdiv((size_t)npts, 64)), dim3(64), 0, s, (const unsigned*)rec_off.p,
+                hipLaunchKernelGGL(k_mwalk, dim3(cdiv((size_t)npts, 256)), dim3(256), 0, s, (const unsigned*)rec_off.p,
                                    (const unsigned long long*)sb.res_vals, npts, (const double*)h->pts.p,
                                    h->masks3d.pts.p + (size_t)h->masks3d.total * 3, long_list.p, long_list.p + 1, long_thr);
-                hipLaunchKernelGGL(k_mwalk_long, dim3(1024), dim3(256), 0, s, (const unsigned*)rec_off.p,
+                hipLaunchKernelGGL(k_mwalk_long, dim3(2048), dim3(256), 0, s, (const unsigned*)rec_off.p,
                                    (const unsigned long long*)sb.res_vals, (const double*)h->pts.p,
                                    h->masks3d.pts.p + (size_t)h->masks3d.total * 3, (const unsigned*)long_list.p,
                                    (const unsigned*)(long_list.p + 1));
             }
             HMSG_CHECK_LAUNCH();
+            if (getenv("HMSG_DEBUG_TIMING")) {
+                unsigned nl = 0;
+                HIP_TRY(hipMemcpyAsync(&nl, long_list.p, 4, hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                fprintf(stderr, "[hmsg fuse] batch at frame %d: mask voxels %lld  records %llu  long slots %u  bitmap words %lld\n", fb0,
+                        npts, nrec, nl, nwords);
+            }
             // per-mask point offsets = rank at the mask's first word
             int ng = 0;
             for (int i = 0; i < nmask; ++i)

@@ -364,9 +364,9 @@ __global__ void __launch_bounds__(256) k_accum_ordered(const unsigned short* __r
                 backproject(depth[(size_t)f * HW + (size_t)y * W + x], x, y, cam, scale, pose + (size_t)f * 16, wx, wy, wz);
             }
             for (int j = 0; j < npix; ++j) {
-                sx = __dadd_rn(sx, __shfl(wx, j));
-                sy = __dadd_rn(sy, __shfl(wy, j));
-                sz = __dadd_rn(sz, __shfl(wz, j));
+                sx = __dadd_rn(sx, wave_bcast_f64(wx, j));
+                sy = __dadd_rn(sy, wave_bcast_f64(wy, j));
+                sz = __dadd_rn(sz, wave_bcast_f64(wz, j));
             }
             q0 = q1;
         }

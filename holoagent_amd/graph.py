@@ -697,68 +697,67 @@ class Graph:
 
     # ------------------------------------------------------------------ A10: graph.py:1582-1736
     def segment_hmsg_objects(self, save_dir=None):
-        sizes = boxes = None
-        if self.scene is not None:
-            self.scene.denoise_instances(0.05, 10)                          # graph.py:1589-1591 on device
-            store = _InstanceStore(self.scene)                               # points stay in HBM until somebody reads them
-            sizes, boxes = store.sizes, self.scene.instance_boxes()
-            self.mask_pcds = [_LazyPcd(store, i) for i in range(len(sizes))]
+        """graph.py:1582-1736.  With a resident scene the object -> floor / room / label assignment runs behind the C
+        ABI (hmsg_build_object_nodes: per-object DBSCAN, find_intersection_share, label GEMM on the device); the
+        per-view visibility test (check_object_in_view) needs the dataset's images and stays here."""
         text_feats, classes = self._label_feats if self._label_feats is not None else (None, None)
+        if self.scene is not None:
+            nodes = self.scene.build_object_nodes([f.floor_zero_level for f in self.floors], [f.floor_height for f in self.floors],
+                                                  [int(r.floor_id) for r in self.rooms], [r.vertices for r in self.rooms], text_feats)
+            store = _InstanceStore(self.scene)                               # points stay in HBM until somebody reads them
+            self.mask_pcds = [_LazyPcd(store, i) for i in range(len(store.sizes))]
+            picks = [(int(n["instance"]), self.rooms[int(n["room"])], int(n["label"])) for n in nodes]
+        else:
+            picks = self._assign_objects_host(text_feats)
+        for i, room, label in picks:
+            pcd = self.mask_pcds[i]
+            obj = Object(room.room_id + "_" + str(room.object_counter), room.room_id)
+            room.object_counter += 1
+            obj.name = classes[label] if (classes is not None and label >= 0) else "object"
+            obj.pcd, obj.embedding = pcd, np.asarray(self.mask_feats[i]).reshape(-1)
+            obj.vertices = None                                            # = points[:, [0, 2]], materialised on save
+            best, best_d = None, float("inf")
+            for v in room.views:
+                if self.dataset is None or v.img_id is None:
+                    continue
+                img, _, pose, _, _ = self.dataset[v.img_id]
+                a = np.asarray(img)
+                K = self._K if self._K is not None else np.asarray(self.dataset.get_camera_intrinsics())
+                ok, md = check_object_in_view(a.shape[1], a.shape[0], K, np.linalg.inv(pose), pcd.points)
+                if ok:
+                    obj.view_ids.append(v.view_id)
+                    v.object_ids.append(obj.object_id)
+                    v.text_discription.append(obj.name)
+                    if md < best_d:
+                        best_d, best = md, v.view_id
+            obj.best_view_id = best
+            room.add_object(obj)
+            self.objects.append(obj)
+        self._index = None
+
+    def _assign_objects_host(self, text_feats):
+        """The same assignment for a Graph without a resident scene (clouds loaded from disk): numpy / scipy."""
         names = None
         if text_feats is not None and len(self.mask_feats):
             emb = np.stack([np.asarray(f).reshape(-1) for f in self.mask_feats]).astype(np.float32)
-            ix = NodeIndex(np.ascontiguousarray(text_feats), np.zeros(len(classes), np.int32), lib_=self.L)
-            names = np.argmax(ix.similarity(emb), axis=1)                  # identify_object (graph.py:1441-1454)
-            ix.close()
-        margin = 0.2
-        share = None
-        room_col = {}
-        if self.scene is not None and self.rooms:
-            # find_intersection_share for every (object, room) pair in one device pass (graph.py:1634-1642)
-            share = self.scene.instance_room_share([r.vertices for r in self.rooms], 0.2)
-            room_col = {r.room_id: k for k, r in enumerate(self.rooms)}
+            names = np.argmax(np.dot(emb.astype(np.float64), np.asarray(text_feats, np.float64).T), axis=1)
+        margin, picks = 0.2, []
         room_centre = {r.room_id: np.mean(r.vertices, axis=0) for r in self.rooms}
         for fl in self.floors:
             for i, pcd in enumerate(self.mask_pcds):
-                n_i = int(sizes[i]) if sizes is not None else len(pcd.points)
-                if n_i < 10:
+                pts = np.asarray(pcd.points)
+                if len(pts) < 10:
                     continue
-                ymin, ymax = (boxes[i, 1], boxes[i, 4]) if boxes is not None else (pcd.points[:, 1].min(), pcd.points[:, 1].max())
-                if not (ymin > fl.floor_zero_level - margin and ymax < fl.floor_zero_level + fl.floor_height + margin):
+                if not (pts[:, 1].min() > fl.floor_zero_level - margin and pts[:, 1].max() < fl.floor_zero_level + fl.floor_height + margin):
                     continue
                 if not fl.rooms:
                     continue
-                if share is not None:
-                    assoc = [float(share[i, room_col[r.room_id]]) for r in fl.rooms]
-                else:
-                    assoc = [find_intersection_share(r.vertices, pcd.points[:, [0, 2]], 0.2) for r in fl.rooms]
+                assoc = [find_intersection_share(r.vertices, pts[:, [0, 2]], 0.2) for r in fl.rooms]
                 if np.sum(assoc) == 0:
-                    c = np.mean(pcd.points[:, [0, 2]], axis=0)
+                    c = np.mean(pts[:, [0, 2]], axis=0)
                     assoc = [-np.linalg.norm(room_centre[r.room_id] - c) for r in fl.rooms]
-                room = fl.rooms[int(np.argmax(assoc))]
-                obj = Object(room.room_id + "_" + str(room.object_counter), room.room_id)
-                room.object_counter += 1
-                obj.name = classes[int(names[i])] if names is not None else "object"
-                obj.pcd, obj.embedding = pcd, np.asarray(self.mask_feats[i]).reshape(-1)
-                obj.vertices = None                                            # = points[:, [0, 2]], materialised on save
-                best, best_d = None, float("inf")
-                for v in room.views:
-                    if self.dataset is None or v.img_id is None:
-                        continue
-                    img, _, pose, _, _ = self.dataset[v.img_id]
-                    a = np.asarray(img)
-                    K = self._K if self._K is not None else np.asarray(self.dataset.get_camera_intrinsics())
-                    ok, md = check_object_in_view(a.shape[1], a.shape[0], K, np.linalg.inv(pose), pcd.points)
-                    if ok:
-                        obj.view_ids.append(v.view_id)
-                        v.object_ids.append(obj.object_id)
-                        v.text_discription.append(obj.name)
-                        if md < best_d:
-                            best_d, best = md, v.view_id
-                obj.best_view_id = best
-                room.add_object(obj)
-                self.objects.append(obj)
-        self._index = None
+                picks.append((i, fl.rooms[int(np.argmax(assoc))], int(names[i]) if names is not None else -1))
+        return picks
 
     def build_hier_multimodal_scene_graph(self, save_path=None, rooms: Sequence[dict] | None = None, room_regions=None):
         """graph.py:2033-2076 (navigation graph omitted).  Rooms: `room_regions` = per floor a list of [n, 2] (x, z)

@@ -169,6 +169,27 @@ int hmsg_denoise_instances(hmsg_t* h, double eps, int32_t min_points);
 int hmsg_instance_room_share(hmsg_t* h, int32_t n_rooms, const int64_t* vert_off, const double* verts_xz, double radius,
                              double* share);
 
+/* ---- A10 + node table: segment_hmsg_objects (graph.py:1582-1736) without the per-view visibility test, which needs the
+ * dataset's images and stays with the caller.  Runs the per-object pcd_denoise_dbscan(0.05, 10) if it has not run yet,
+ * assigns every instance with at least 10 points to each floor whose [zero - 0.2, zero + height + 0.2] contains its
+ * y-extent and, there, to the room with the largest find_intersection_share (fallback: nearest room centre), labels
+ * it with the arg-max of emb . label_feats^T (identify_object) and numbers it per room.  Nodes come out in the
+ * reference's creation order (floors outer, instances inner).  floor_zero / floor_height f64 [n_floors];
+ * room_floor i32 [n_rooms]; vert_off i64 [n_rooms + 1]; verts_xz f64 [sum][2]; label_feats f32 [n_labels][D] or NULL. */
+typedef struct hmsg_node {
+    int32_t instance;      /* index into the instance list (hmsg_get_instance_*) */
+    int32_t floor, room;   /* room = index into the caller's room list: object id "<room_id>_<counter>" */
+    int32_t counter;
+    int32_t label;         /* -1 without a vocabulary */
+    int64_t n_points;
+} hmsg_node;
+int hmsg_build_object_nodes(hmsg_t* h, int32_t n_floors, const double* floor_zero, const double* floor_height, int32_t n_rooms,
+                            const int32_t* room_floor, const int64_t* vert_off, const double* verts_xz, int32_t n_labels,
+                            const float* label_feats);
+int64_t hmsg_num_nodes(const hmsg_t* h);
+/* nodes [hmsg_num_nodes] and/or their embeddings f32 [N][D] (either may be NULL) */
+int hmsg_get_nodes(const hmsg_t* h, hmsg_node* nodes, float* embeddings);
+
 /* ---- A9 camera -> room assignment of compute_room_embeddings (utils/graph_utils.py:244-291): out[q][s] =
  * np.min(cdist([q], set s, "euclidean")) for n_q 2-D positions (camera x/z) against n_sets 2-D point sets (room
  * clouds projected to x/z): pts_xy f64 [set_off[n_sets]][2], q_xy f64 [n_q][2], out f64 [n_q][n_sets] (inf for an empty
@@ -182,6 +203,8 @@ int hmsg_points_min_dist_2d(int32_t device_id, int32_t n_sets, const int64_t* se
 typedef struct hmsg_index hmsg_index_t;
 int hmsg_index_create(int32_t device_id, int32_t dim, int64_t n, const void* emb, int32_t emb_is_f64,
                       const int32_t* room_of_node, hmsg_index_t** out);
+/* the node table of a built scene as a resident index (embeddings gathered on the device, parent = node.room) */
+int hmsg_index_from_nodes(hmsg_t* h, hmsg_index_t** out);
 void hmsg_index_destroy(hmsg_index_t* ix);
 const char* hmsg_index_last_error(const hmsg_index_t* ix);
 /* live HIP-event timing of the similarity GEMM on the index's stream (measurement aid for bench.py) */

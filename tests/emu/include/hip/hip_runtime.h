@@ -348,6 +348,8 @@ static inline unsigned long long __ballot(int pred) {
     hipemu::wave_barrier();
     return m;
 }
+static inline int __builtin_amdgcn_readlane(int v, int src) { return hipemu::exchange(v, src); }
+static inline unsigned long long __umul64hi(unsigned long long a, unsigned long long b) { return (unsigned long long)(((unsigned __int128)a * b) >> 64); }
 static inline int __any(int p) { return __ballot(p) != 0; }
 static inline int __all(int p) { return __ballot(!p) == 0; }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }

@@ -103,6 +103,19 @@ def test_graph_end_to_end_tiny(L, tmp_path):
         for k, r in enumerate(g.rooms):
             ref = find_intersection_share(r.vertices, pts[:, [0, 2]], 0.2) if len(pts) else 0
             assert abs(share[i, k] - ref) < 1e-12, (i, k, share[i, k], ref)
+    # the node table behind the C ABI (hmsg_get_nodes / hmsg_index_from_nodes) is the object list
+    nodes, emb = g.scene.nodes(embeddings=True)
+    assert len(nodes) == len(g.objects)
+    for n, e, o in zip(nodes, emb, g.objects):
+        assert o.object_id == "%s_%d" % (g.rooms[int(n["room"])].room_id, int(n["counter"]))
+        np.testing.assert_array_equal(e, np.asarray(o.embedding, np.float32))
+    if len(nodes):
+        ixn = g.scene.index_from_nodes()
+        Tq = g.get_text_feats_multiple_templates(["chair", "background"])[None]
+        a = ixn.query_objects(Tq, np.zeros(1, np.int32), [[0]], 3)
+        b = g._node_index().query_objects(Tq, np.zeros(1, np.int32), [[0]], 3)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])
+        ixn.close()
     g2 = Graph(dict(main=dict(), models=dict(clip=dict(feat_dim=32))), encoders=enc, lib=L)
     g2.load_hmsg_graph(str(tmp_path / "graph"))
     assert len(g2.objects) == len(g.objects) and len(g2.rooms) == 1
