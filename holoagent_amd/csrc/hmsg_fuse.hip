@@ -457,129 +457,60 @@ __global__ void __launch_bounds__(256) k_memit(const int* __restrict__ nn, const
 }
 
 // one lane per mask voxel: replay Open3D's accumulation -- sequential float64 sum of the snapped points in pixel
-// order, then / count (generic.py:188 -> o3d_voxel_down_sample)
-// (one step of the replay: `len` more copies of point p)
-__device__ __forceinline__ void mwalk_add(double& sx, double& sy, double& sz, double px, double py, double pz, int len) {
-    // short counts are added one by one, longer ones in closed form
-    if (len >= 16) {
-        sx = repeat_add(sx, px, len);
-        sy = repeat_add(sy, py, len);
-        sz = repeat_add(sz, pz, len);
-    } else {
-        for (int j = 0; j < len; ++j) {
+// order, then / count (generic.py:188 -> o3d_voxel_down_sample).
+// A workgroup owns 256 consecutive voxels, whose records are one contiguous range of the sorted record array.  The
+// records and the map points they name are fetched cooperatively (coalesced, all in flight at once) into LDS, a
+// chunk at a time; every lane then consumes its voxel's records from LDS in a FLATTENED loop -- one addition per
+// trip, a lane that runs out of repetitions picks up its next record -- so a wave runs as long as its busiest
+// voxel's pixel count, not (records x longest repetition), and no lane ever waits on a dependent global load.
+#define MW_CHUNK 1024
+__global__ void __launch_bounds__(256) k_mwalk(const unsigned* __restrict__ off, const unsigned long long* __restrict__ recs,
+                                               long long npts, const double* __restrict__ pts, double* __restrict__ out) {
+    __shared__ double s_p[MW_CHUNK][3];
+    __shared__ unsigned char s_len[MW_CHUNK];
+    const long long s0 = (long long)blockIdx.x * 256, s = s0 + threadIdx.x;
+    const bool live = s < npts;
+    const unsigned r1 = live ? off[s + 1] : 0u;
+    unsigned r = live ? off[s] : 0u;
+    const unsigned blk_r0 = off[s0], blk_r1 = off[s0 + 256 < npts ? s0 + 256 : npts];
+    double sx = 0.0, sy = 0.0, sz = 0.0, px = 0.0, py = 0.0, pz = 0.0;
+    unsigned long long n = 0;
+    int rem = 0;
+    for (unsigned c0 = blk_r0; c0 < blk_r1; c0 += MW_CHUNK) {
+        const unsigned c1 = c0 + MW_CHUNK < blk_r1 ? c0 + MW_CHUNK : blk_r1;
+        for (unsigned k = c0 + threadIdx.x; k < c1; k += 256) {
+            const unsigned long long rec = recs[k];
+            const double* p = pts + (size_t)(rec >> 8) * 3;
+            s_len[k - c0] = (unsigned char)(rec & 255ull);
+            s_p[k - c0][0] = p[0];
+            s_p[k - c0][1] = p[1];
+            s_p[k - c0][2] = p[2];
+        }
+        __syncthreads();
+        const unsigned e = r1 < c1 ? r1 : c1;        // this lane's records inside the chunk: [r, e)
+        for (;;) {
+            if (rem == 0) {
+                if (r >= e) break;
+                const unsigned i = r - c0;
+                rem = (int)s_len[i];
+                px = s_p[i][0];
+                py = s_p[i][1];
+                pz = s_p[i][2];
+                n += (unsigned long long)rem;
+                ++r;
+            }
             sx = __dadd_rn(sx, px);
             sy = __dadd_rn(sy, py);
             sz = __dadd_rn(sz, pz);
+            --rem;
         }
+        __syncthreads();
     }
-}
-#define MWALK_LONG 64       /* slots with at least this many records go to the wave-per-slot kernel */
-__global__ void k_mwalk(const unsigned* __restrict__ off, const unsigned long long* __restrict__ recs, long long npts,
-                        const double* __restrict__ pts, double* __restrict__ out, unsigned* __restrict__ long_cnt,
-                        unsigned* __restrict__ long_list, unsigned long_thr) {
-    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = s < npts;
-    const unsigned r0 = live ? off[s] : 0u, r1 = live ? off[s + 1] : 0u;
-    // a voxel close to the camera: its chain of dependent loads would outlast the grid -> wave-per-slot kernel.
-    // (list slots per wave: one atomic on the counter per wave, not per slot)
-    const bool is_long = live && r1 - r0 >= long_thr;
-    const unsigned long long lm = __ballot(is_long);
-    if (lm) {
-        const int lane = threadIdx.x & 63, leader = __ffsll(lm) - 1;
-        unsigned base = 0;
-        if (lane == leader) base = atomicAdd(long_cnt, (unsigned)__popcll(lm));
-        base = __shfl(base, leader);
-        if (is_long) long_list[base + (unsigned)__popcll(lm & ((1ull << lane) - 1ull))] = (unsigned)s;
-    }
-    if (!live || is_long) return;
-    double sx = 0.0, sy = 0.0, sz = 0.0;
-    unsigned long long n = 0;
-    // consecutive records of one map voxel (the same voxel on successive image rows) are one repetition count
-    unsigned cur_v = 0xffffffffu;
-    int cur_len = 0;
-    double px = 0.0, py = 0.0, pz = 0.0;
-    for (unsigned r = r0; r <= r1; ++r) {
-        unsigned v = 0xffffffffu;
-        int len = 0;
-        if (r < r1) {
-            const unsigned long long rec = recs[r];
-            v = (unsigned)(rec >> 8);
-            len = (int)(rec & 255ull);
-        }
-        if (v == cur_v) {
-            cur_len += len;
-            continue;
-        }
-        mwalk_add(sx, sy, sz, px, py, pz, cur_len);
-        n += (unsigned long long)cur_len;
-        cur_v = v;
-        cur_len = len;
-        if (r < r1) {
-            const double* p = pts + (size_t)v * 3;
-            px = p[0];
-            py = p[1];
-            pz = p[2];
-        }
-    }
-    const double dn = (double)n;
-    out[(size_t)s * 3 + 0] = __ddiv_rn(sx, dn);
-    out[(size_t)s * 3 + 1] = __ddiv_rn(sy, dn);
-    out[(size_t)s * 3 + 2] = __ddiv_rn(sz, dn);
-}
-// the long slots: one WAVE per slot, 64 records (and their map points) fetched side by side, then folded in
-// order with broadcasts -- the additions are the same serial chain, the loads no longer are
-__global__ void __launch_bounds__(256) k_mwalk_long(const unsigned* __restrict__ off, const unsigned long long* __restrict__ recs,
-                                                    const double* __restrict__ pts, double* __restrict__ out,
-                                                    const unsigned* __restrict__ long_cnt, const unsigned* __restrict__ long_list) {
-    const int lane = threadIdx.x & 63;
-    const unsigned nwaves = (gridDim.x * blockDim.x) >> 6, nlong = *long_cnt;
-    // (a wave operation on every path: the kernel simulator of tests/emu classifies a kernel by its first launch,
-    //  and the list is often empty then)
-    if (__ballot(1) == 0ull) return;
-    for (unsigned t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; t < nlong; t += nwaves) {
-        const unsigned s = long_list[t];
-        const unsigned r0 = off[s], r1 = off[s + 1];
-        double sx = 0.0, sy = 0.0, sz = 0.0;
-        unsigned long long n = 0;
-        unsigned cur_v = 0xffffffffu;
-        int cur_len = 0;
-        double cx = 0.0, cy = 0.0, cz = 0.0;
-        for (unsigned rb = r0; rb < r1; rb += 64) {
-            const unsigned long long rec = rb + lane < r1 ? recs[rb + lane] : 0ull;
-            const unsigned mv = (unsigned)(rec >> 8);
-            double px = 0.0, py = 0.0, pz = 0.0;
-            if (rb + lane < r1) {
-                const double* p = pts + (size_t)mv * 3;
-                px = p[0];
-                py = p[1];
-                pz = p[2];
-            }
-            const int nrec = (int)min(64u, r1 - rb);
-            for (int q = 0; q < nrec; ++q) {
-                const unsigned v = (unsigned)__builtin_amdgcn_readlane((int)mv, q);
-                const int len = __builtin_amdgcn_readlane((int)(rec & 255ull), q);
-                const double qx = wave_bcast_f64(px, q), qy = wave_bcast_f64(py, q), qz = wave_bcast_f64(pz, q);
-                if (v == cur_v) {
-                    cur_len += len;
-                    continue;
-                }
-                mwalk_add(sx, sy, sz, cx, cy, cz, cur_len);
-                n += (unsigned long long)cur_len;
-                cur_v = v;
-                cur_len = len;
-                cx = qx;
-                cy = qy;
-                cz = qz;
-            }
-        }
-        mwalk_add(sx, sy, sz, cx, cy, cz, cur_len);
-        n += (unsigned long long)cur_len;
-        if (lane == 0) {
-            const double dn = (double)n;
-            out[(size_t)s * 3 + 0] = __ddiv_rn(sx, dn);
-            out[(size_t)s * 3 + 1] = __ddiv_rn(sy, dn);
-            out[(size_t)s * 3 + 2] = __ddiv_rn(sz, dn);
-        }
+    if (live) {
+        const double dn = (double)n;
+        out[(size_t)s * 3 + 0] = __ddiv_rn(sx, dn);
+        out[(size_t)s * 3 + 1] = __ddiv_rn(sy, dn);
+        out[(size_t)s * 3 + 2] = __ddiv_rn(sz, dn);
     }
 }
 
@@ -640,7 +571,7 @@ void hmsg_fuse(hmsg_ctx* h) {
     DevBuf<MaskGeom> d_geom;
     d_geom.alloc((size_t)nmask_max);
     DevBuf<unsigned long long> mbitmap;
-    DevBuf<unsigned> mrank, chunk_recs, rec_off, long_list;
+    DevBuf<unsigned> mrank, chunk_recs, rec_off;
     DevBuf<long long> d_offidx;
     DevBuf<unsigned> d_offval;
     d_offidx.alloc((size_t)nmask_max);
@@ -657,8 +588,6 @@ void hmsg_fuse(hmsg_ctx* h) {
     // valid pixels exceeds the threshold.  The mean is taken over the u16 depths (exact integer sum); the reference
     // averages float32 metres, so a mask within ~1e-7 (relative) of the threshold can fall on the other side.
     const double filt_mm = c.max_mask_distance * c.depth_scale;
-    // (HMSG_DEBUG_MWALK_LONG: tests push every slot through the wave-per-slot replay)
-    const unsigned long_thr = getenv("HMSG_DEBUG_MWALK_LONG") ? (unsigned)atoi(getenv("HMSG_DEBUG_MWALK_LONG")) : (unsigned)MWALK_LONG;
 
     for (int fb0 = h->n_fused; fb0 < h->n_feat_frames; fb0 += FB) {
         const int nb = std::min(FB, h->n_feat_frames - fb0);
@@ -770,24 +699,13 @@ void hmsg_fuse(hmsg_ctx* h) {
             }
             {
                 ProfScope ps(h->prof, s, "k_mwalk", (double)nrec * 8.0 + (double)npts * 32.0);
-                long_list.ensure((size_t)npts + 1);
-                HIP_TRY(hipMemsetAsync(long_list.p, 0, 4, s));                    // [0] = counter, the list follows
                 hipLaunchKernelGGL(k_mwalk, dim3(cdiv((size_t)npts, 256)), dim3(256), 0, s, (const unsigned*)rec_off.p,
                                    (const unsigned long long*)sb.res_vals, npts, (const double*)h->pts.p,
-                                   h->masks3d.pts.p + (size_t)h->masks3d.total * 3, long_list.p, long_list.p + 1, long_thr);
-                hipLaunchKernelGGL(k_mwalk_long, dim3(2048), dim3(256), 0, s, (const unsigned*)rec_off.p,
-                                   (const unsigned long long*)sb.res_vals, (const double*)h->pts.p,
-                                   h->masks3d.pts.p + (size_t)h->masks3d.total * 3, (const unsigned*)long_list.p,
-                                   (const unsigned*)(long_list.p + 1));
+                                   h->masks3d.pts.p + (size_t)h->masks3d.total * 3);
             }
             HMSG_CHECK_LAUNCH();
-            if (getenv("HMSG_DEBUG_TIMING")) {
-                unsigned nl = 0;
-                HIP_TRY(hipMemcpyAsync(&nl, long_list.p, 4, hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipStreamSynchronize(s));
-                fprintf(stderr, "[hmsg fuse] batch at frame %d: mask voxels %lld  records %llu  long slots %u  bitmap words %lld\n", fb0,
-                        npts, nrec, nl, nwords);
-            }
+            if (getenv("HMSG_DEBUG_TIMING"))
+                fprintf(stderr, "[hmsg fuse] batch at frame %d: mask voxels %lld  records %llu  bitmap words %lld\n", fb0, npts, nrec, nwords);
             // per-mask point offsets = rank at the mask's first word
             int ng = 0;
             for (int i = 0; i < nmask; ++i)

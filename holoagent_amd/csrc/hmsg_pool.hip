@@ -220,6 +220,22 @@ __global__ void k_pool_prop(const unsigned* __restrict__ adj, const PoolSeg* __r
         *changed = 1;
     }
 }
+// pointer jumping between propagation rounds: a core row's label is the (relative) index of a core row of the same
+// component that is not larger than its own, so label[label[i]] is one too -- following the chain to its end makes
+// the propagation converge in O(log diameter) rounds instead of O(diameter).  (Races only read older, larger labels.)
+__global__ void k_pool_jump(const PoolSeg* __restrict__ segs, const int* __restrict__ seg_of_row, const unsigned* __restrict__ ncount,
+                            int minpts, long long N, int* __restrict__ label) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N || ncount[i] < (unsigned)minpts) return;
+    const long long base = segs[seg_of_row[i]].row_base;
+    int l = label[i];
+    for (int hop = 0; hop < 64; ++hop) {
+        const int p = label[base + l];
+        if (p >= l) break;
+        l = p;
+    }
+    if (l < label[i]) atomicMin(&label[i], l);
+}
 // border points: smallest cluster label among adjacent cores; then sizes / first index per cluster
 __global__ void k_pool_border(const unsigned* __restrict__ adj, const PoolSeg* __restrict__ segs, const int* __restrict__ seg_of_row,
                               const unsigned* __restrict__ ncount, int minpts, long long N, const int* __restrict__ label,
@@ -434,10 +450,13 @@ void hmsg_pool(hmsg_ctx* h) {
         HMSG_CHECK_LAUNCH();
         for (int it = 0; it < 100000; ++it) {
             HIP_TRY(hipMemsetAsync(d_changed.p, 0, 4, s));
-            for (int rep = 0; rep < 4; ++rep)
+            for (int rep = 0; rep < 2; ++rep) {
                 hipLaunchKernelGGL(k_pool_prop, dim3(cdiv((size_t)R * 64, 256)), dim3(256), 0, s, (const unsigned*)adj.p,
                                    (const PoolSeg*)d_ps.p, (const int*)seg_of_row.p, (const unsigned*)ncount.p,
                                    c.feat_dbscan_min, (long long)R, label.p, d_changed.p, (const int*)seg_first.p);
+                hipLaunchKernelGGL(k_pool_jump, dim3(cdiv((size_t)R, 256)), dim3(256), 0, s, (const PoolSeg*)d_ps.p,
+                                   (const int*)seg_of_row.p, (const unsigned*)ncount.p, c.feat_dbscan_min, (long long)R, label.p);
+            }
             HMSG_CHECK_LAUNCH();
             int ch = 0;
             HIP_TRY(hipMemcpyAsync(&ch, d_changed.p, 4, hipMemcpyDeviceToHost, s));
