@@ -90,6 +90,7 @@ _SIGS = {
     "hmsg_query_objects": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     "hmsg_similarity": (C.c_int, [_P, C.c_int32, _P, _P]),
     "hmsg_test_sort_pairs": (C.c_int, [_P, _P, C.c_int64, C.c_int32]),
+    "hmsg_test_repeat_add": (C.c_int, [_P, _P, _P, _P, C.c_int64]),
     "hmsg_test_ckdtree": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)

@@ -912,8 +912,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     unsigned* d_nact = d_nc + 1;
     {
     ProfScope ps(prof, s, "k_db_core", (double)N * 33.0);
-    // (1024-thread workgroups: the three list counters share one cache line and every workgroup adds to them once)
-    hipLaunchKernelGGL(k_db_core, dim3(cdiv(N, 1024)), dim3(1024), 0, s, src, N, (const int*)segid.p, dsegs, (const long long*)cellid.p,
+    hipLaunchKernelGGL(k_db_core, dim3(gN), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const long long*)cellid.p,
                        (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p, (const double*)spts.p, score.p,
                        eps * eps, min_points, core.p, minidx.p, corelist.p, d_nc, cellpos.p, parent.p, core0, hasanchor.p, rep.p, active.p, actlist.p,
                        d_nact, cseg.p, nclist.p);

@@ -193,6 +193,45 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
     return v;
 }
 
+// s <- fl(s + p), `len` times, in closed form.  While s stays inside one binade [2^e, 2^(e+1)) its ulp u is fixed,
+// s is a multiple of u and p = q*u: every addition rounds S + q (S = s/u) to the nearest integer, i.e. adds the
+// same integer d = round(q) -- unless q sits exactly on .5 (round-half-even then depends on S: stepped) or the sum
+// leaves the binade (stepped across).  A mask voxel holds the SAME snapped map point hundreds of times
+// (generic.py:181-188), and Open3D adds them one by one; this replays those additions bit for bit in O(binades).
+__device__ __forceinline__ double repeat_add(double s, double p, int len) {
+    while (len > 0) {
+        const double as = fabs(s), ap = fabs(p);
+        if (ap == 0.0) return __dadd_rn(s, p);
+        const long long bs = __double_as_longlong(as);
+        const int e = (int)(bs >> 52);                       // biased exponent (sign bit cleared)
+        if (as >= ap && ((s < 0.0) == (p < 0.0)) && e >= 1 && e < 2046) {
+            unsigned long long S = ((unsigned long long)bs & 0xfffffffffffffull) | (1ull << 52);
+            const double q = ldexp(ap, 1075 - e);            // p in units of ulp(s): exact, < 2^53
+            if (q < 0.5) return s;                           // p below half an ulp: s never moves
+            const double qi = floor(q), qf = q - qi;
+            if (qf != 0.5) {
+                const unsigned long long iq = (unsigned long long)qi;
+                const unsigned long long d = iq + (qf > 0.5 ? 1ull : 0ull);
+                const unsigned long long top = (1ull << 53) - 1ull;
+                if (S + iq <= top) {                         // (each step needs S + q < 2^53 before it)
+                    // all `len` steps stay in the binade when S + (len-1)*d + iq <= top (the usual case: no division)
+                    unsigned long long k = (unsigned long long)len;
+                    const unsigned long long room = top - iq - S;
+                    if (__umul64hi(k - 1ull, d) != 0ull || (k - 1ull) * d > room) k = room / d + 1ull;
+                    S += k * d;
+                    const double r = ldexp((double)S, e - 1075);
+                    s = s < 0.0 ? -r : r;
+                    len -= (int)k;
+                    continue;
+                }
+            }
+        }
+        s = __dadd_rn(s, p);
+        --len;
+    }
+    return s;
+}
+
 // value of lane `src` (wave-uniform) as a scalar broadcast: v_readlane, not an LDS permute
 __device__ __forceinline__ double wave_bcast_f64(double v, int src) {
     const long long b = __double_as_longlong(v);

@@ -463,15 +463,34 @@ __global__ void __launch_bounds__(256) k_memit(const int* __restrict__ nn, const
 // chunk at a time; every lane then consumes its voxel's records from LDS in a FLATTENED loop -- one addition per
 // trip, a lane that runs out of repetitions picks up its next record -- so a wave runs as long as its busiest
 // voxel's pixel count, not (records x longest repetition), and no lane ever waits on a dependent global load.
+// Long repetitions of one point are added in closed form (repeat_add).
 #define MW_CHUNK 1024
 __global__ void __launch_bounds__(256) k_mwalk(const unsigned* __restrict__ off, const unsigned long long* __restrict__ recs,
-                                               long long npts, const double* __restrict__ pts, double* __restrict__ out) {
+                                               long long npts, const double* __restrict__ pts, double* __restrict__ out,
+                                               unsigned* __restrict__ heavy_cnt, unsigned* __restrict__ heavy_list, unsigned heavy_thr) {
     __shared__ double s_p[MW_CHUNK][3];
+    __shared__ unsigned s_v[MW_CHUNK];
     __shared__ unsigned char s_len[MW_CHUNK];
     const long long s0 = (long long)blockIdx.x * 256, s = s0 + threadIdx.x;
-    const bool live = s < npts;
+    bool live = s < npts;
     const unsigned r1 = live ? off[s + 1] : 0u;
     unsigned r = live ? off[s] : 0u;
+    {   // voxels with many records (thousands of pixels of a deleted region snap to the few surviving voxels next to
+        // it, SURVEY hazard 15) go to the wave-per-voxel kernel; list slots per wave, one atomic on the counter
+        const bool heavy = live && r1 - r >= heavy_thr;
+        const unsigned long long hm = __ballot(heavy);
+        if (hm) {
+            const int lane = threadIdx.x & 63, leader = __ffsll(hm) - 1;
+            unsigned base = 0;
+            if (lane == leader) base = atomicAdd(heavy_cnt, (unsigned)__popcll(hm));
+            base = __shfl(base, leader);
+            if (heavy) heavy_list[base + (unsigned)__popcll(hm & ((1ull << lane) - 1ull))] = (unsigned)s;
+        }
+        if (heavy) {
+            live = false;
+            r = r1;
+        }
+    }
     const unsigned blk_r0 = off[s0], blk_r1 = off[s0 + 256 < npts ? s0 + 256 : npts];
     double sx = 0.0, sy = 0.0, sz = 0.0, px = 0.0, py = 0.0, pz = 0.0;
     unsigned long long n = 0;
@@ -482,6 +501,7 @@ __global__ void __launch_bounds__(256) k_mwalk(const unsigned* __restrict__ off,
             const unsigned long long rec = recs[k];
             const double* p = pts + (size_t)(rec >> 8) * 3;
             s_len[k - c0] = (unsigned char)(rec & 255ull);
+            s_v[k - c0] = (unsigned)(rec >> 8);
             s_p[k - c0][0] = p[0];
             s_p[k - c0][1] = p[1];
             s_p[k - c0][2] = p[2];
@@ -496,8 +516,19 @@ __global__ void __launch_bounds__(256) k_mwalk(const unsigned* __restrict__ off,
                 px = s_p[i][0];
                 py = s_p[i][1];
                 pz = s_p[i][2];
-                n += (unsigned long long)rem;
                 ++r;
+                // following records of the SAME map point (the voxel on the next image rows) extend the repetition;
+                // a long one -- thousands of pixels of a deleted region all snap to the one surviving voxel next to
+                // it (SURVEY hazard 15) -- is added in closed form
+                while (r < e && s_v[r - c0] == s_v[i]) rem += (int)s_len[r++ - c0];
+                n += (unsigned long long)rem;
+                if (rem >= 256) {
+                    sx = repeat_add(sx, px, rem);
+                    sy = repeat_add(sy, py, rem);
+                    sz = repeat_add(sz, pz, rem);
+                    rem = 0;
+                    continue;
+                }
             }
             sx = __dadd_rn(sx, px);
             sy = __dadd_rn(sy, py);
@@ -511,6 +542,89 @@ __global__ void __launch_bounds__(256) k_mwalk(const unsigned* __restrict__ off,
         out[(size_t)s * 3 + 0] = __ddiv_rn(sx, dn);
         out[(size_t)s * 3 + 1] = __ddiv_rn(sy, dn);
         out[(size_t)s * 3 + 2] = __ddiv_rn(sz, dn);
+    }
+}
+
+// The heavy voxels: one WAVE per voxel, 64 records side by side.  While the running sum s stays inside one binade
+// its ulp u is fixed and every addition of a point p adds the same integer d(p) = round(p / u) to S = s / u (see
+// repeat_add): the order of the additions no longer matters, so the lanes compute len * d(p) for their records, a
+// prefix sum finds how many records fit before S would leave the binade (or a record needs care: round-half-even
+// tie, opposite sign, p larger than s), those are added in ONE step, and the record that did not fit is replayed
+// exactly by repeat_add.  A sum crosses ~20 binades in its life, so a voxel with thousands of records costs a few
+// dozen rounds.
+__global__ void __launch_bounds__(256) k_mwalk_heavy(const unsigned* __restrict__ off, const unsigned long long* __restrict__ recs,
+                                                     const double* __restrict__ pts, double* __restrict__ out,
+                                                     const unsigned* __restrict__ heavy_cnt, const unsigned* __restrict__ heavy_list) {
+    const int lane = threadIdx.x & 63;
+    const unsigned nwaves = (gridDim.x * blockDim.x) >> 6, nheavy = *heavy_cnt;
+    // (a wave operation on every path: the kernel simulator of tests/emu classifies a kernel by its first launch)
+    if (__ballot(1) == 0ull) return;
+    const unsigned long long top = (1ull << 53) - 1ull;
+    for (unsigned t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; t < nheavy; t += nwaves) {
+        const unsigned slot = heavy_list[t];
+        const unsigned r0 = off[slot], r1 = off[slot + 1];
+        double res[3];
+        unsigned long long n = 0;
+        for (int c = 0; c < 3; ++c) {
+            double s = 0.0;
+            for (unsigned rb = r0; rb < r1; rb += 64) {
+                const int cnt = (int)min(64u, r1 - rb);
+                const unsigned long long rec = lane < cnt ? recs[rb + lane] : 0ull;
+                const int len = (int)(rec & 255ull);
+                const double p = lane < cnt ? pts[(size_t)(rec >> 8) * 3 + c] : 0.0;
+                if (c == 0) {
+                    int tl = len;
+                    for (int o = 32; o > 0; o >>= 1) tl += __shfl_xor(tl, o);
+                    n += (unsigned long long)tl;
+                }
+                int j0 = 0;
+                while (j0 < cnt) {
+                    // state of the running sum
+                    const double as = fabs(s);
+                    const long long bs = __double_as_longlong(as);
+                    const int e = (int)(bs >> 52);
+                    const unsigned long long S = ((unsigned long long)bs & 0xfffffffffffffull) | (1ull << 52);
+                    const bool st_ok = e >= 1 && e < 2046;
+                    // this lane's record against it
+                    const double ap = fabs(p);
+                    bool ok = st_ok && lane >= j0 && lane < cnt && as >= ap && (ap == 0.0 || (p < 0.0) == (s < 0.0));
+                    unsigned long long d = 0ull, iq = 0ull;
+                    if (ok && ap != 0.0) {
+                        const double q = ldexp(ap, 1075 - e);
+                        if (q >= 0.5) {
+                            const double qi = floor(q), qf = q - qi;
+                            iq = (unsigned long long)qi;
+                            d = iq + (qf > 0.5 ? 1ull : 0ull);
+                            ok = qf != 0.5 && d < (1ull << 44);
+                        }
+                    }
+                    const unsigned long long inc = ok ? (unsigned long long)len * d : 0ull;
+                    unsigned long long pre = inc;                    // inclusive prefix over the lanes
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const unsigned long long u = __shfl_up(pre, o);
+                        if (lane >= o) pre += u;
+                    }
+                    const bool fits = ok && S + pre - d + iq <= top;
+                    const unsigned long long todo = ((cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull)) >> j0) << j0;
+                    const unsigned long long bad = ~__ballot(fits) & todo;
+                    const int f = bad ? __ffsll(bad) - 1 : cnt;      // first record that is not added in bulk
+                    if (f > j0) {
+                        const unsigned long long add = __shfl(pre, f - 1);
+                        const double rr = ldexp((double)(S + add), e - 1075);
+                        s = s < 0.0 ? -rr : rr;
+                    }
+                    if (f < cnt) s = repeat_add(s, wave_bcast_f64(p, f), __builtin_amdgcn_readlane(len, f));
+                    j0 = f + 1;
+                }
+            }
+            res[c] = s;
+        }
+        if (lane == 0) {
+            const double dn = (double)n;
+            out[(size_t)slot * 3 + 0] = __ddiv_rn(res[0], dn);
+            out[(size_t)slot * 3 + 1] = __ddiv_rn(res[1], dn);
+            out[(size_t)slot * 3 + 2] = __ddiv_rn(res[2], dn);
+        }
     }
 }
 
@@ -571,7 +685,9 @@ void hmsg_fuse(hmsg_ctx* h) {
     DevBuf<MaskGeom> d_geom;
     d_geom.alloc((size_t)nmask_max);
     DevBuf<unsigned long long> mbitmap;
-    DevBuf<unsigned> mrank, chunk_recs, rec_off;
+    DevBuf<unsigned> mrank, chunk_recs, rec_off, heavy;
+    // (HMSG_DEBUG_MWALK_HEAVY: tests push every voxel through the wave-per-voxel replay)
+    const unsigned heavy_thr = getenv("HMSG_DEBUG_MWALK_HEAVY") ? (unsigned)atoi(getenv("HMSG_DEBUG_MWALK_HEAVY")) : 32u;
     DevBuf<long long> d_offidx;
     DevBuf<unsigned> d_offval;
     d_offidx.alloc((size_t)nmask_max);
@@ -699,9 +815,15 @@ void hmsg_fuse(hmsg_ctx* h) {
             }
             {
                 ProfScope ps(h->prof, s, "k_mwalk", (double)nrec * 8.0 + (double)npts * 32.0);
+                heavy.ensure((size_t)npts + 1);
+                HIP_TRY(hipMemsetAsync(heavy.p, 0, 4, s));                        // [0] = counter, the list follows
                 hipLaunchKernelGGL(k_mwalk, dim3(cdiv((size_t)npts, 256)), dim3(256), 0, s, (const unsigned*)rec_off.p,
                                    (const unsigned long long*)sb.res_vals, npts, (const double*)h->pts.p,
-                                   h->masks3d.pts.p + (size_t)h->masks3d.total * 3);
+                                   h->masks3d.pts.p + (size_t)h->masks3d.total * 3, heavy.p, heavy.p + 1, heavy_thr);
+                hipLaunchKernelGGL(k_mwalk_heavy, dim3(2048), dim3(256), 0, s, (const unsigned*)rec_off.p,
+                                   (const unsigned long long*)sb.res_vals, (const double*)h->pts.p,
+                                   h->masks3d.pts.p + (size_t)h->masks3d.total * 3, (const unsigned*)heavy.p,
+                                   (const unsigned*)(heavy.p + 1));
             }
             HMSG_CHECK_LAUNCH();
             if (getenv("HMSG_DEBUG_TIMING"))

@@ -155,3 +155,30 @@ extern "C" int hmsg_test_sort_pairs(uint32_t* keys, uint64_t* vals, int64_t n, i
         return e.code;
     }
 }
+
+// ---- test hook: repeat_add (hmsg_common.h) against the plain loop it replaces ------------------------------
+__global__ void k_test_repeat_add(const double* __restrict__ s, const double* __restrict__ p, const int* __restrict__ len,
+                                  double* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = repeat_add(s[i], p[i], len[i]);
+}
+extern "C" int hmsg_test_repeat_add(const double* s, const double* p, const int32_t* len, double* out, int64_t n) {
+    try {
+        if (n <= 0) return HMSG_OK;
+        DevBuf<double> ds, dp, dout;
+        DevBuf<int> dl;
+        ds.alloc((size_t)n); dp.alloc((size_t)n); dout.alloc((size_t)n); dl.alloc((size_t)n);
+        HIP_TRY(hipMemcpy(ds.p, s, (size_t)n * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dp.p, p, (size_t)n * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dl.p, len, (size_t)n * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_test_repeat_add, dim3(cdiv((size_t)n, 256)), dim3(256), 0, 0, (const double*)ds.p, (const double*)dp.p,
+                           (const int*)dl.p, dout.p, (long long)n);
+        HMSG_CHECK_LAUNCH();
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+        return HMSG_OK;
+    } catch (const hmsg_error& e) {
+        fprintf(stderr, "hmsg_test_repeat_add: %s\n", e.msg.c_str());
+        return e.code;
+    }
+}

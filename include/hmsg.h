@@ -224,6 +224,10 @@ int hmsg_similarity(hmsg_index_t* ix, int32_t Q, const float* T, double* S);
  * (Open3D VoxelDownSample adds points in input order; graph.py:348, generic.py:188, graph.py:456).  Host arrays,
  * sorted in place by the low key_bits bits of the key, equal keys keep their input order. */
 int hmsg_test_sort_pairs(uint32_t* keys, uint64_t* vals, int64_t n, int32_t key_bits);
+/* out[i] = s[i] after `len[i]` sequential float64 additions of p[i] (how Open3D accumulates a map point that many
+ * pixels of a mask snapped to, generic.py:181-188), computed by the closed form the mask kernels use for long
+ * repetitions. */
+int hmsg_test_repeat_add(const double* s, const double* p, const int32_t* len, double* out, int64_t n);
 /* host restatement of scipy.spatial.cKDTree (the reference's NN index, graph.py:362-364; used to answer bit-equal
  * nearest-neighbour ties like scipy does): index permutation after the default build (out_indices i64 [n], may be
  * NULL), node count, and query(x, k=1) answers for nq points. */

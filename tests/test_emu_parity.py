@@ -30,6 +30,23 @@ def test_map_and_fuse_small(L):
     sc.close()
 
 
+def test_mask_walk_heavy_voxel_path(L):
+    """The wave-per-voxel replay of heavy mask voxels (k_mwalk_heavy: bulk integer additions inside a binade) forced
+    on every voxel: still bit-identical."""
+    z = GI.load("build_ragged")
+    frames = GI.unpack_frames(z)[:5]
+    cfg = GI.unpack_cfg(z)
+    cfg["outlier_nb"] = 300
+    os.environ["HMSG_DEBUG_MWALK_HEAVY"] = "1"
+    try:
+        sc = PC.make_scene(L, frames, dict(feat_dim=cfg["feat_dim"], outlier_nb_points=300))
+        S, ref_pts, ref_cols = PC.check_map(sc, frames, cfg)
+        PC.check_fuse(sc, frames, S, cfg, ref_pts, ref_cols)
+        sc.close()
+    finally:
+        os.environ.pop("HMSG_DEBUG_MWALK_HEAVY", None)
+
+
 @pytest.mark.skipif(not os.environ.get("HMSG_EMU_SLOW"), reason="slow on the simulator (minutes); covered on the GPU")
 @pytest.mark.parametrize("merge_type", ["sequential", "hierarchical"])
 def test_merge_and_pool_small(L, merge_type):

@@ -33,3 +33,35 @@ def test_sort_emu(n, bits):
 def test_sort_gpu(n, bits):
     from holoagent_amd._lib import HmsgLib
     check_sort(HmsgLib(), n, bits, 7 + n)
+
+
+def check_repeat_add(L, seed, n):
+    """repeat_add (closed form of `len` sequential float64 additions of the same value) == the plain loop, bit for bit."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    p = rng.uniform(-20, 20, n)
+    p[: n // 8] = np.ldexp(rng.integers(1, 1 << 20, n // 8).astype(np.float64), rng.integers(-30, 4, n // 8))   # few bits: ties
+    k = rng.integers(0, 3000, n)
+    s = p * k * rng.uniform(0.999, 1.001, n)          # a running sum of about k copies
+    s[::7] = 0.0
+    s[3::11] = rng.uniform(-5, 5, len(s[3::11]))      # unrelated start values (sign changes, |s| < |p|)
+    ln = rng.integers(0, 256, n).astype(np.int32)
+    ln[::13] = rng.integers(256, 5000, len(ln[::13]))
+    ref = s.copy()
+    for j in range(int(ln.max())):
+        m = ln > j
+        ref[m] = ref[m] + p[m]
+    out = np.empty(n)
+    assert L.c.hmsg_test_repeat_add(s.ctypes.data, p.ctypes.data, ln.ctypes.data, out.ctypes.data, n) == 0
+    assert np.array_equal(out.view(np.int64), ref.view(np.int64)), int((out != ref).sum())
+
+
+@pytest.mark.skipif(not os.path.exists(PC.EMU_PATH), reason="kernel simulator not built")
+def test_repeat_add_emu():
+    from holoagent_amd._lib import HmsgLib
+    check_repeat_add(HmsgLib(PC.EMU_PATH), 5, 20000)
+
+
+@pytest.mark.gpu
+def test_repeat_add_gpu():
+    from holoagent_amd._lib import HmsgLib
+    check_repeat_add(HmsgLib(), 6, 400000)
