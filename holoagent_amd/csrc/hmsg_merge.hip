@@ -48,7 +48,21 @@ struct Cloud {
     int gd[3] = {0, 0, 0};
 };
 
+// Work lists: the per-cloud kernels below get ONE workgroup per chunk of a cloud (blk0 = first workgroup of the
+// entry, a prefix sum the host fills in; a workgroup finds its entry by binary search).  A 2-D grid sized for the
+// largest cloud of a launch would start ~10^5 workgroups per fold step that find nothing to do.
+template <typename T>
+__device__ __forceinline__ int find_entry(const T* __restrict__ e, int n, unsigned blk) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((unsigned)e[mid].blk0 <= blk) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
 struct OvGrid {             // device view of one cloud for the overlap kernels
+    int blk0, pad0;         // first workgroup of this cloud in k_ov_count / k_ov_fill (work list)
     long long pt_off;       // f64 points in the pool
     long long ix_pt;        // its cell-sorted float32 copy in ix_pts (cell starts are relative to it)
     long long ix_cell;
@@ -60,7 +74,7 @@ struct OvGrid {             // device view of one cloud for the overlap kernels
 struct OvTask {             // count points of grid[x] within r of grid[y]
     int x, y;
     int dep_n;              // second-direction tasks: number of points of the pair's smaller cloud (see k_ov_query)
-    int pad;
+    int blk0;               // first workgroup of this task (work list)
 };
 
 }  // namespace
@@ -77,18 +91,21 @@ __device__ __forceinline__ long long ov_cell(const OvGrid& g, float x, float y, 
 // (counts go to `cursor`, indexed relative to the batch's first cell; the scan turns them into cell starts in
 //  `cells`, and k_ov_fill hands a cell's slots out from its end by counting `cursor` back down -- the order of
 //  points inside a cell is irrelevant)
-__global__ void k_ov_count(const double* __restrict__ pool, const OvGrid* __restrict__ gr, unsigned* __restrict__ cursor,
+#define OVI_CHUNK 2048      /* points per workgroup of the index kernels */
+__global__ void k_ov_count(const double* __restrict__ pool, const OvGrid* __restrict__ gr, int ngr, unsigned* __restrict__ cursor,
                            long long cursor_base) {
-    const OvGrid g = gr[blockIdx.y];
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += gridDim.x * blockDim.x) {
+    const OvGrid g = gr[find_entry(gr, ngr, blockIdx.x)];
+    const int i0 = (int)(blockIdx.x - (unsigned)g.blk0) * OVI_CHUNK, i1 = min(g.n, i0 + OVI_CHUNK);
+    for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
         const double* p = pool + (size_t)(g.pt_off + i) * 3;
         atomicAdd(&cursor[ov_cell(g, (float)p[0], (float)p[1], (float)p[2]) - cursor_base], 1u);
     }
 }
-__global__ void k_ov_fill(const double* __restrict__ pool, const OvGrid* __restrict__ gr, const unsigned* __restrict__ cells,
+__global__ void k_ov_fill(const double* __restrict__ pool, const OvGrid* __restrict__ gr, int ngr, const unsigned* __restrict__ cells,
                           unsigned* __restrict__ cursor, long long cursor_base, float* __restrict__ sorted) {
-    const OvGrid g = gr[blockIdx.y];
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += gridDim.x * blockDim.x) {
+    const OvGrid g = gr[find_entry(gr, ngr, blockIdx.x)];
+    const int i0 = (int)(blockIdx.x - (unsigned)g.blk0) * OVI_CHUNK, i1 = min(g.n, i0 + OVI_CHUNK);
+    for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
         const double* p = pool + (size_t)(g.pt_off + i) * 3;
         float x = (float)p[0], y = (float)p[1], z = (float)p[2];
         long long c = ov_cell(g, x, y, z);
@@ -172,37 +189,39 @@ __device__ __forceinline__ bool ov_hit(const OvGrid& Y, const unsigned* __restri
 // so the scan of the larger cloud is skipped (sequential merge: only the decision is needed, not the value).
 __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __restrict__ gr, const OvTask* __restrict__ tasks,
                            const unsigned* __restrict__ cells, const float* __restrict__ sorted, float r2, float r,
-                           unsigned* __restrict__ counts, const unsigned* __restrict__ dep_counts, double th) {
-    const OvTask t = tasks[blockIdx.y];
-    if (dep_counts && (double)dep_counts[blockIdx.y] / (double)t.dep_n > th) return;
+                           int ntasks, unsigned* __restrict__ counts, const unsigned* __restrict__ dep_counts, double th) {
+    const int ti = find_entry(tasks, ntasks, blockIdx.x);
+    const OvTask t = tasks[ti];
+    if (dep_counts && (double)dep_counts[ti] / (double)t.dep_n > th) return;
     const OvGrid X = gr[t.x], Y = gr[t.y];
     unsigned local = 0;
-    // a block takes OV_CHUNK consecutive points per trip: every point is a serial chain of L2 round trips, so a
-    // million-point X must be spread over many blocks (gridDim.x is sized for the largest X of the launch; the
-    // blocks beyond a smaller X leave at once)
-    for (long long b0 = (long long)blockIdx.x * OV_CHUNK; b0 < X.n; b0 += (long long)gridDim.x * OV_CHUNK) {
-        const int b1 = (int)(b0 + OV_CHUNK < X.n ? b0 + OV_CHUNK : X.n);
-        for (int i = (int)b0 + (int)threadIdx.x; i < b1; i += blockDim.x) {
+    // a workgroup takes OV_CHUNK consecutive points: every point is a serial chain of L2 round trips, so a
+    // million-point X is spread over many workgroups (work list: exactly ceil(n / OV_CHUNK) of them per task)
+    {
+        const int b0 = (int)(blockIdx.x - (unsigned)t.blk0) * OV_CHUNK;
+        const int b1 = b0 + OV_CHUNK < X.n ? b0 + OV_CHUNK : X.n;
+        for (int i = b0 + (int)threadIdx.x; i < b1; i += blockDim.x) {
             const double* p = pool + (size_t)(X.pt_off + i) * 3;
             local += ov_hit(Y, cells, sorted, (float)p[0], (float)p[1], (float)p[2], r2, r) ? 1u : 0u;
         }
     }
     for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(&counts[blockIdx.y], local);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(&counts[ti], local);
 }
 
 struct CatSeg {
     long long src, dst;
     int n, anchor;          // anchor: copy the member's persisted core flags (else the flags are cleared)
+    int blk0, pad;          // first workgroup of this segment (work list)
 };
-__global__ void k_concat(const double* __restrict__ pool, const CatSeg* __restrict__ segs, double* __restrict__ dst,
+#define CAT_CHUNK 4096      /* points per workgroup of k_concat */
+__global__ void k_concat(const double* __restrict__ pool, const CatSeg* __restrict__ segs, int nsegs, double* __restrict__ dst,
                          const unsigned char* __restrict__ poolcore, unsigned char* __restrict__ dstcore) {
-    const CatSeg sg = segs[blockIdx.y];
-    const long long cnt = (long long)sg.n * 3;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (long long)gridDim.x * blockDim.x)
-        dst[sg.dst * 3 + i] = pool[sg.src * 3 + i];
+    const CatSeg sg = segs[find_entry(segs, nsegs, blockIdx.x)];
+    const long long p0 = (long long)(blockIdx.x - (unsigned)sg.blk0) * CAT_CHUNK, p1 = min((long long)sg.n, p0 + CAT_CHUNK);
+    for (long long i = p0 * 3 + threadIdx.x; i < p1 * 3; i += blockDim.x) dst[sg.dst * 3 + i] = pool[sg.src * 3 + i];
     if (dstcore)
-        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < sg.n; i += (long long)gridDim.x * blockDim.x)
+        for (long long i = p0 + threadIdx.x; i < p1; i += blockDim.x)
             dstcore[sg.dst + i] = sg.anchor ? poolcore[sg.src + i] : (unsigned char)0;
 }
 
@@ -303,6 +322,7 @@ struct Merger {
 
     OvGrid grid_of(const Cloud& c) const {
         OvGrid g;
+        g.blk0 = g.pad0 = 0;
         g.pt_off = c.off;
         g.ix_cell = c.ix_cell;
         g.ix_pt = c.ix_pt;
@@ -343,23 +363,24 @@ struct Merger {
         grow(ix_cells, (size_t)ix_cells_used, (size_t)(ix_cells_used + ncell_new));
         grow(ix_pts, (size_t)ix_pts_used * 3, (size_t)(ix_pts_used + npts_new) * 3);
         std::vector<OvGrid> g(todo.size());
-        for (size_t k = 0; k < todo.size(); ++k) g[k] = grid_of(L[todo[k]]);
+        unsigned nblk = 0;
+        for (size_t k = 0; k < todo.size(); ++k) {
+            g[k] = grid_of(L[todo[k]]);
+            g[k].blk0 = (int)nblk;
+            nblk += cdiv((size_t)g[k].n, OVI_CHUNK);
+        }
         d_grids.ensure(g.size());
         HIP_TRY(hipMemcpyAsync(d_grids.p, g.data(), g.size() * sizeof(OvGrid), hipMemcpyHostToDevice, s));
         unsigned* cells = ix_cells.p + ix_cells_used;
         d_cursor.ensure((size_t)ncell_new);
         HIP_TRY(hipMemsetAsync(d_cursor.p, 0, (size_t)ncell_new * 4, s));
-        const unsigned gx = std::max(1u, std::min(cdiv(maxn, 256), todo.size() > 4096 ? 16u : 1024u));
-        for (size_t t0 = 0; t0 < todo.size(); t0 += 32768)   // (gridDim.y limit)
-            hipLaunchKernelGGL(k_ov_count, dim3(gx, (unsigned)std::min<size_t>(32768, todo.size() - t0)), dim3(256), 0, s,
-                               (const double*)pool.p, (const OvGrid*)d_grids.p + t0, d_cursor.p, ix_cells_used);
+        hipLaunchKernelGGL(k_ov_count, dim3(nblk), dim3(256), 0, s, (const double*)pool.p, (const OvGrid*)d_grids.p, (int)g.size(),
+                           d_cursor.p, ix_cells_used);
         HMSG_CHECK_LAUNCH();
         // (cell starts stay relative to this batch's first sorted point: Cloud::ix_pt)
         hmsg_scan_u32(d_cursor.p, cells, (size_t)ncell_new, s, ops.scan_tmp, nullptr);
-        for (size_t t0 = 0; t0 < todo.size(); t0 += 32768)
-            hipLaunchKernelGGL(k_ov_fill, dim3(gx, (unsigned)std::min<size_t>(32768, todo.size() - t0)), dim3(256), 0, s,
-                               (const double*)pool.p, (const OvGrid*)d_grids.p + t0, (const unsigned*)ix_cells.p, d_cursor.p,
-                               ix_cells_used, ix_pts.p);
+        hipLaunchKernelGGL(k_ov_fill, dim3(nblk), dim3(256), 0, s, (const double*)pool.p, (const OvGrid*)d_grids.p, (int)g.size(),
+                           (const unsigned*)ix_cells.p, d_cursor.p, ix_cells_used, ix_pts.p);
         HMSG_CHECK_LAUNCH();
         for (int i : todo) L[i].has_index = true;
         ix_cells_used += ncell_new;
@@ -378,7 +399,7 @@ struct Merger {
         std::vector<int> slot(L.size(), -1);
         std::vector<OvGrid> g;
         std::vector<OvTask> tasks(P * 2);          // [0, P): smaller -> larger,  [P, 2P): larger -> smaller
-        int maxn1 = 0, maxn2 = 0;
+        unsigned nblk1 = 0, nblk2 = 0;          // workgroups of the two directions (work lists)
         for (size_t k = 0; k < P; ++k) {
             int a = pairs[k].first, b = pairs[k].second;
             for (int v : {a, b})
@@ -387,10 +408,10 @@ struct Merger {
                     g.push_back(grid_of(L[v]));
                 }
             if (L[a].n > L[b].n) std::swap(a, b);  // a = the smaller cloud
-            tasks[k] = OvTask{slot[a], slot[b], 0, 0};
-            tasks[P + k] = OvTask{slot[b], slot[a], L[a].n, 0};
-            maxn1 = std::max(maxn1, L[a].n);
-            maxn2 = std::max(maxn2, L[b].n);
+            tasks[k] = OvTask{slot[a], slot[b], 0, (int)nblk1};
+            tasks[P + k] = OvTask{slot[b], slot[a], L[a].n, (int)nblk2};
+            nblk1 += cdiv((size_t)L[a].n, OV_CHUNK);
+            nblk2 += cdiv((size_t)L[b].n, OV_CHUNK);
         }
         d_grids.ensure(g.size());
         d_tasks.ensure(tasks.size());
@@ -405,17 +426,13 @@ struct Merger {
         {
             ProfScope ps(h->prof, s, "k_ov_query", ov_work);   // (the kernel launches only: not the read-back below)
             for (int dir = 0; dir < 2; ++dir) {
-                const int maxn = dir ? maxn2 : maxn1;
-                for (size_t t0 = 0; t0 < P; t0 += 32768) {
-                    const unsigned nt = (unsigned)std::min<size_t>(32768, P - t0);
-                    // blocks per task: enough for the largest X at OV_CHUNK points per block, bounded by the launch size
-                    const unsigned bx = std::max(1u, std::min(cdiv(maxn, OV_CHUNK), (unsigned)std::max<size_t>(64, ((size_t)1 << 19) / nt)));
-                    const size_t o = (size_t)dir * P + t0;
-                    hipLaunchKernelGGL(k_ov_query, dim3(bx, nt), dim3(256), 0, s, (const double*)pool.p, (const OvGrid*)d_grids.p,
-                                       (const OvTask*)(d_tasks.p + o), (const unsigned*)ix_cells.p, (const float*)ix_pts.p, r2, r,
-                                       d_counts.p + o, (dir && decide_th >= 0.0) ? (const unsigned*)(d_counts.p + t0) : (const unsigned*)nullptr,
-                                       decide_th);
-                }
+                const unsigned nb = dir ? nblk2 : nblk1;
+                if (!nb) continue;
+                const size_t o = (size_t)dir * P;
+                hipLaunchKernelGGL(k_ov_query, dim3(nb), dim3(256), 0, s, (const double*)pool.p, (const OvGrid*)d_grids.p,
+                                   (const OvTask*)(d_tasks.p + o), (const unsigned*)ix_cells.p, (const float*)ix_pts.p, r2, r, (int)P,
+                                   d_counts.p + o, (dir && decide_th >= 0.0) ? (const unsigned*)d_counts.p : (const unsigned*)nullptr,
+                                   decide_th);
             }
         }
         HMSG_CHECK_LAUNCH();
@@ -539,6 +556,7 @@ struct Merger {
         std::vector<SegDesc> segs;
         std::vector<CatSeg> cat;
         long long cat_total = 0;
+        unsigned cat_blocks = 0;
         for (size_t c = 0; c < comps.size(); ++c) {
             const auto& mem = comps[c];
             if (mem.size() == 1 && (L[mem[0]].fixed || L[mem[0]].n == 0)) continue;   // exact shortcut (1)
@@ -552,7 +570,8 @@ struct Merger {
                     if (L[i].anchor && (anchor_i < 0 || L[i].n > L[anchor_i].n)) anchor_i = i;
             for (int i : mem) {
                 if (L[i].n == 0) continue;
-                cat.push_back(CatSeg{L[i].off, cat_total, L[i].n, i == anchor_i ? 1 : 0});
+                cat.push_back(CatSeg{L[i].off, cat_total, L[i].n, i == anchor_i ? 1 : 0, (int)cat_blocks, 0});
+                cat_blocks += cdiv((size_t)L[i].n, CAT_CHUNK);
                 cat_total += L[i].n;
                 sd.n += L[i].n;
                 for (int a = 0; a < 3; ++a) {
@@ -571,14 +590,8 @@ struct Merger {
             concat_core.ensure((size_t)cat_total);
             d_cat.ensure(cat.size());
             HIP_TRY(hipMemcpyAsync(d_cat.p, cat.data(), cat.size() * sizeof(CatSeg), hipMemcpyHostToDevice, s));
-            int maxn = 0;
-            for (auto& cs : cat) maxn = std::max(maxn, cs.n);
-            for (size_t c0 = 0; c0 < cat.size(); c0 += 32768) {
-                unsigned nc = (unsigned)std::min<size_t>(32768, cat.size() - c0);
-                hipLaunchKernelGGL(k_concat, dim3(std::max(1u, std::min(cdiv((size_t)maxn * 3, 256), 256u)), nc), dim3(256), 0, s,
-                                   (const double*)pool.p, (const CatSeg*)(d_cat.p + c0), concat.p,
-                                   (const unsigned char*)poolcore.p, use_anchor ? concat_core.p : nullptr);
-            }
+            hipLaunchKernelGGL(k_concat, dim3(cat_blocks), dim3(256), 0, s, (const double*)pool.p, (const CatSeg*)d_cat.p, (int)cat.size(),
+                               concat.p, (const unsigned char*)poolcore.p, use_anchor ? concat_core.p : nullptr);
             HMSG_CHECK_LAUNCH();
             grow(pool, (size_t)pool_used * 3, (size_t)(pool_used + cat_total) * 3);
             grow(poolcore, (size_t)pool_used, (size_t)(pool_used + cat_total));
@@ -762,6 +775,7 @@ void hmsg_merge(hmsg_ctx* h) {
     }
     // graph.py:445-448: drop clouds with < 10 points; compact the survivors into the handle
     long long keep_total = 0;
+    unsigned cat_blocks = 0;
     std::vector<CatSeg> cat;
     h->inst.off.assign(1, 0);
     h->inst.box.clear();
@@ -769,7 +783,8 @@ void hmsg_merge(hmsg_ctx* h) {
         if (k.n < c.min_instance_points) continue;
         for (int a = 0; a < 3; ++a) h->inst.box.push_back(k.mn[a]);
         for (int a = 0; a < 3; ++a) h->inst.box.push_back(k.mx[a]);
-        cat.push_back(CatSeg{k.off, keep_total, k.n, 0});
+        cat.push_back(CatSeg{k.off, keep_total, k.n, 0, (int)cat_blocks, 0});
+        cat_blocks += cdiv((size_t)k.n, CAT_CHUNK);
         keep_total += k.n;
         h->inst.off.push_back(keep_total);
     }
@@ -778,14 +793,9 @@ void hmsg_merge(hmsg_ctx* h) {
     if (!cat.empty()) {
         m.d_cat.ensure(cat.size());
         HIP_TRY(hipMemcpyAsync(m.d_cat.p, cat.data(), cat.size() * sizeof(CatSeg), hipMemcpyHostToDevice, h->stream));
-        int maxn = 0;
-        for (auto& cs : cat) maxn = std::max(maxn, cs.n);
-        for (size_t c0 = 0; c0 < cat.size(); c0 += 32768) {
-            unsigned nc = (unsigned)std::min<size_t>(32768, cat.size() - c0);
-            hipLaunchKernelGGL(k_concat, dim3(std::max(1u, std::min(cdiv((size_t)maxn * 3, 256), 256u)), nc), dim3(256), 0, h->stream,
-                               (const double*)m.pool.p, (const CatSeg*)(m.d_cat.p + c0), h->inst.pts.p,
-                               (const unsigned char*)nullptr, (unsigned char*)nullptr);
-        }
+        if (cat_blocks)
+            hipLaunchKernelGGL(k_concat, dim3(cat_blocks), dim3(256), 0, h->stream, (const double*)m.pool.p, (const CatSeg*)m.d_cat.p,
+                               (int)cat.size(), h->inst.pts.p, (const unsigned char*)nullptr, (unsigned char*)nullptr);
         HMSG_CHECK_LAUNCH();
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
