@@ -40,6 +40,8 @@ struct CloudOps {
     DevBuf<char> geom;           // device copy of per-segment geometry tables
     DevBuf<unsigned long long> vbitmap;
     DevBuf<unsigned> vrank;
+    PinnedBuf<unsigned> h_res;   // per-segment results of a DBSCAN batch (pinned: read back every fold step)
+    SpinWait spin;
     SortBufs vsort;              // ordered voxel sums: (slot, point index) records
     DevBuf<unsigned> voff;
 

@@ -989,10 +989,11 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
         ++call_no;
     }
     // one copy brings back counts, cluster counts, contest flags and the boxes of the kept points
-    std::vector<unsigned> hres((size_t)K * 16 + 2);
-    HIP_TRY(hipMemcpyAsync(hres.data(), kres.p, hres.size() * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    const unsigned long long* hb = reinterpret_cast<const unsigned long long*>(hres.data() + (size_t)K * 4);
+    h_res.ensure((size_t)K * 16 + 2);
+    unsigned* hres = h_res.p;
+    HIP_TRY(hipMemcpyAsync(hres, kres.p, ((size_t)K * 16 + 2) * 4, hipMemcpyDeviceToHost, s));
+    spin.wait(s);
+    const unsigned long long* hb = reinterpret_cast<const unsigned long long*>(hres + (size_t)K * 4);
     stat_calls += 1;
     stat_points += N;
     stat_cells += NC;

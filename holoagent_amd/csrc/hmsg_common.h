@@ -115,6 +115,44 @@ struct DevBuf {
     size_t bytes() const { return n * sizeof(T); }
 };
 
+// ------------------------------------------------------------------ pinned host buffer + low-latency wait
+// The merge fold reads a few hundred bytes back twice per step.  A pageable destination makes the copy a blocking
+// staged transfer and hipStreamSynchronize parks the thread (tens of microseconds to wake up, a thousand times per
+// scene): results land in pinned memory and the host spins on an event instead.
+template <typename T>
+struct PinnedBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    ~PinnedBuf() {
+        if (p) (void)hipHostFree(p);
+    }
+    void ensure(size_t count) {
+        if (count <= n) return;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        n = std::max<size_t>(count * 2, 256);
+        HIP_TRY(hipHostMalloc((void**)&p, n * sizeof(T), hipHostMallocDefault));
+    }
+};
+struct SpinWait {
+    hipEvent_t ev = nullptr;
+    ~SpinWait() {
+        if (ev) (void)hipEventDestroy(ev);
+    }
+    void wait(hipStream_t s) {
+        if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ev, s));
+        for (;;) {
+            const hipError_t e = hipEventQuery(ev);
+            if (e == hipSuccess) return;
+            if (e != hipErrorNotReady) HIP_TRY(e);
+        }
+    }
+};
+
 // ------------------------------------------------------------------ grid geometry (global voxel grid)
 // Linearisation: lin = (ix * NY + iy) * NZP + iz, NZP = NZ rounded up to 64 so a z-column starts on a
 // 64-bit word; slot of an occupied cell = rank[word] + popc(bits below) = its position in ascending

@@ -299,6 +299,8 @@ struct Merger {
     DevBuf<OvTask> d_tasks;
     DevBuf<unsigned> d_counts, d_cursor;
     DevBuf<CatSeg> d_cat;
+    PinnedBuf<unsigned> h_counts;
+    SpinWait spin;
     unsigned long long next_uid = 1;
     std::unordered_map<unsigned long long, double> ratio_cache;   // hierarchical merge only
     bool use_cache = false;
@@ -436,9 +438,10 @@ struct Merger {
             }
         }
         HMSG_CHECK_LAUNCH();
-        std::vector<unsigned> hc(tasks.size());
-        HIP_TRY(hipMemcpyAsync(hc.data(), d_counts.p, tasks.size() * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        h_counts.ensure(tasks.size());
+        unsigned* hc = h_counts.p;
+        HIP_TRY(hipMemcpyAsync(hc, d_counts.p, tasks.size() * 4, hipMemcpyDeviceToHost, s));
+        spin.wait(s);
         for (size_t k = 0; k < P; ++k) {
             const int na = std::min(L[pairs[k].first].n, L[pairs[k].second].n), nb = std::max(L[pairs[k].first].n, L[pairs[k].second].n);
             ratio[k] = std::max((double)hc[k] / (double)na, (double)hc[P + k] / (double)nb);

@@ -296,6 +296,9 @@ struct hipDeviceProp_t { int multiProcessorCount; char name[64]; size_t totalGlo
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : 2; }
 template <typename T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+#define hipHostMallocDefault 0
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = malloc(n ? n : 1); return *p ? hipSuccess : 2; }
+static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = 0) { if (n) memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemset(void* d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }
@@ -321,6 +324,10 @@ static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipEmuEvent{0}
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = 0) { e->t = hipemu_now(); return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+#define hipErrorNotReady 600
+#define hipEventDisableTiming 2
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new hipEmuEvent{0}; return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
 
 template <typename... KArgs, typename... Args>
