@@ -68,6 +68,9 @@ _SIGS = {
     "hmsg_get_frame_mask_sizes": (C.c_int, [_P, C.c_int32, _P]),
     "hmsg_get_frame_mask_points": (C.c_int, [_P, C.c_int32, _P]),
     "hmsg_merge_instances": (C.c_int, [_P]),
+    "hmsg_set_frame_window": (C.c_int, [_P, C.c_int32]),
+    "hmsg_merge_tree_local": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "hmsg_merge_tree_join": (C.c_int, [_P, C.c_int32, _P, _P, C.c_double, C.c_int32]),
     "hmsg_num_instances": (C.c_int64, [_P]),
     "hmsg_get_instance_sizes": (C.c_int, [_P, _P]),
     "hmsg_get_instance_points": (C.c_int, [_P, _P]),
@@ -262,6 +265,22 @@ class Scene:
 
     def merge_instances(self):
         self._ck(self.L.c.hmsg_merge_instances(self.h))
+
+    def set_frame_window(self, first_frame):
+        self._ck(self.L.c.hmsg_set_frame_window(self.h, int(first_frame)))
+
+    def merge_tree_local(self, total_frames):
+        """-> (threshold of the next level, lists at that level, index of this handle's list)"""
+        th, n, i = C.c_double(), C.c_int64(), C.c_int64()
+        self._ck(self.L.c.hmsg_merge_tree_local(self.h, int(total_frames), C.byref(th), C.byref(n), C.byref(i)))
+        return float(th.value), int(n.value), int(i.value)
+
+    def merge_tree_join(self, clouds, th, final_pass):
+        """clouds: list of [n, 3] f64 arrays of the partner handle (may be empty)."""
+        sizes = np.array([len(c) for c in clouds], np.int64)
+        pts = np.ascontiguousarray(np.concatenate(clouds) if len(clouds) and sizes.sum() else np.zeros((0, 3)), np.float64)
+        self._ck(self.L.c.hmsg_merge_tree_join(self.h, len(clouds), _ptr(sizes) if len(clouds) else None,
+                                               _ptr(pts) if len(pts) else None, float(th), int(bool(final_pass))))
 
     def instances(self):
         n = int(self.L.c.hmsg_num_instances(self.h))

@@ -183,7 +183,8 @@ int hmsg_reset(hmsg_t* h) {
         h->nmask.clear();
         h->mask_first.clear();
         h->have_K = false;
-        h->map_ready = h->feats_final = h->merged = h->pooled = h->inst_denoised = false;
+        h->map_ready = h->feats_final = h->merged = h->pooled = h->inst_denoised = h->tree_partial = false;
+        h->frame_window = 0;
         h->nodes.clear();
         h->V = h->V0 = 0;
         h->masks3d.off.clear();
@@ -360,6 +361,36 @@ int hmsg_add_frame_features(hmsg_t* h, int32_t first, int32_t n, int32_t M, cons
     });
 }
 
+int hmsg_set_frame_window(hmsg_t* h, int32_t first_frame) {
+    if (!h) return HMSG_ERR_INVALID;
+    return guard(h, [&] {
+        HMSG_REQUIRE(h->map_ready, HMSG_ERR_INVALID, "hmsg_set_frame_window: call hmsg_finalize_map first");
+        HMSG_REQUIRE(h->n_feat_frames == 0 && h->n_fused == 0, HMSG_ERR_INVALID, "hmsg_set_frame_window: features already handed over");
+        HMSG_REQUIRE(first_frame >= 0 && first_frame <= h->n_frames, HMSG_ERR_INVALID, "hmsg_set_frame_window: frame out of range");
+        h->frame_window = first_frame;
+        h->n_feat_frames = h->n_fused = first_frame;
+        h->nmask.assign((size_t)first_frame, 0);
+        h->mask_first.assign((size_t)first_frame + 1, 0);
+        h->masks3d.off.assign(1, 0);
+        h->masks3d.total = 0;
+    });
+}
+
+int hmsg_merge_tree_local(hmsg_t* h, int32_t total_frames, double* th_next, int64_t* lists_now, int64_t* my_index) {
+    if (!h || !th_next || !lists_now || !my_index) return HMSG_ERR_INVALID;
+    return guard(h, [&] {
+        long long l = 0, i = 0;
+        hmsg_merge_tree_local_impl(h, total_frames, th_next, &l, &i);
+        *lists_now = l;
+        *my_index = i;
+    });
+}
+
+int hmsg_merge_tree_join(hmsg_t* h, int32_t n_ext, const int64_t* ext_sizes, const double* ext_points, double th, int32_t final_pass) {
+    if (!h) return HMSG_ERR_INVALID;
+    return guard(h, [&] { hmsg_merge_tree_join_impl(h, n_ext, (const long long*)ext_sizes, ext_points, th, final_pass); });
+}
+
 int hmsg_fuse_frames(hmsg_t* h) {
     if (!h) return HMSG_ERR_INVALID;
     return guard(h, [&] { hmsg_fuse(h); });
@@ -430,13 +461,13 @@ int hmsg_merge_instances(hmsg_t* h) {
     return guard(h, [&] { hmsg_merge(h); });
 }
 
-int64_t hmsg_num_instances(const hmsg_t* h) { return h && h->merged ? (int64_t)h->inst.off.size() - 1 : -1; }
+int64_t hmsg_num_instances(const hmsg_t* h) { return h && (h->merged || h->tree_partial) ? (int64_t)h->inst.off.size() - 1 : -1; }
 
 int hmsg_get_instance_sizes(const hmsg_t* hc, int64_t* sizes) {
     hmsg_ctx* h = const_cast<hmsg_ctx*>(hc);
     if (!h) return HMSG_ERR_INVALID;
     return guard(h, [&] {
-        HMSG_REQUIRE(h->merged && sizes, HMSG_ERR_INVALID, "hmsg_merge_instances not run");
+        HMSG_REQUIRE((h->merged || h->tree_partial) && sizes, HMSG_ERR_INVALID, "hmsg_merge_instances not run");
         for (size_t i = 0; i + 1 < h->inst.off.size(); ++i) sizes[i] = h->inst.off[i + 1] - h->inst.off[i];
     });
 }
@@ -445,7 +476,7 @@ int hmsg_get_instance_points(const hmsg_t* hc, double* xyz) {
     hmsg_ctx* h = const_cast<hmsg_ctx*>(hc);
     if (!h) return HMSG_ERR_INVALID;
     return guard(h, [&] {
-        HMSG_REQUIRE(h->merged && xyz, HMSG_ERR_INVALID, "hmsg_merge_instances not run");
+        HMSG_REQUIRE((h->merged || h->tree_partial) && xyz, HMSG_ERR_INVALID, "hmsg_merge_instances not run");
         if (h->inst.total) HIP_TRY(hipMemcpy(xyz, h->inst.pts.p, (size_t)h->inst.total * 24, hipMemcpyDeviceToHost));
     });
 }

@@ -379,6 +379,8 @@ struct hmsg_ctx {
     MaskCloudSet masks3d;
     InstanceSet inst;
     bool merged = false;
+    int frame_window = 0;          // first frame with features (hmsg_set_frame_window: this handle owns a frame range)
+    bool tree_partial = false;     // inst holds an unfinished list of the sharded hierarchical merge tree
     DevBuf<float> inst_feats;      // [N][D]
     bool pooled = false;
     bool inst_denoised = false;    // the per-object pcd_denoise_dbscan(0.05, 10) of graph.py:1589-1591 has run
@@ -431,6 +433,8 @@ void hmsg_kd_join(hmsg_ctx* h);
 void hmsg_build_map(hmsg_ctx* h);       // hmsg_map.hip
 void hmsg_fuse(hmsg_ctx* h);            // hmsg_fuse.hip
 void hmsg_merge(hmsg_ctx* h);           // hmsg_merge.hip
+void hmsg_merge_tree_local_impl(hmsg_ctx* h, int total_frames, double* th_next, long long* lists_now, long long* my_index);
+void hmsg_merge_tree_join_impl(hmsg_ctx* h, int n_ext, const long long* ext_sizes, const double* ext_pts, double th, int final_pass);
 void hmsg_denoise_inst(hmsg_ctx* h, double eps, int min_points);   // hmsg_merge.hip
 void hmsg_room_share(hmsg_ctx* h, int R, const long long* vert_off, const double* verts_xz, double radius,
                      double* share_out);                              // hmsg_merge.hip

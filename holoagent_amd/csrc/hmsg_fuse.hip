@@ -669,7 +669,7 @@ void hmsg_fuse(hmsg_ctx* h) {
     const size_t HW = (size_t)H * W;
     const long long V = h->V;
     const float scale = (float)c.depth_scale;
-    if (h->sum.n < (size_t)V * D || h->n_fused == 0) {
+    if (h->sum.n < (size_t)V * D || h->n_fused == h->frame_window) {
         h->sum.alloc((size_t)V * D);
         h->cnt.alloc((size_t)V);
         h->sum.zero(s);

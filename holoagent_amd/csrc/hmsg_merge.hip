@@ -686,11 +686,10 @@ struct Merger {
 
 }  // namespace
 
-void hmsg_merge(hmsg_ctx* h) {
+namespace {
+
+void merger_init(Merger& m, hmsg_ctx* h) {
     const hmsg_config& c = h->cfg;
-    HMSG_REQUIRE(h->feats_final && h->n_fused > 0, HMSG_ERR_INVALID, "hmsg_merge_instances: run hmsg_fuse_frames first");
-    HMSG_REQUIRE(!h->merged, HMSG_ERR_INVALID, "instances already merged");
-    Merger m;
     m.h = h;
     m.s = h->stream;
     m.ops.s = h->stream;
@@ -700,13 +699,16 @@ void hmsg_merge(hmsg_ctx* h) {
     m.eps = c.merge_dbscan_eps;
     m.minpts = c.merge_dbscan_min;
     m.iou_thresh = c.iou_thresh;
+    m.use_anchor = !getenv("HMSG_DEBUG_NOANCHOR");
     HMSG_REQUIRE(c.iou_thresh >= 0.0, HMSG_ERR_UNSUPPORTED, "pipeline.iou_thresh must be >= 0");
+}
+
+// the frames' 3-D masks as per-frame cloud lists over a pool seeded with them (frames first .. n_fused-1)
+std::vector<std::vector<Cloud>> seed_frames(Merger& m, hmsg_ctx* h, int first) {
     const int F = h->n_fused;
-    // the 3-D masks of all frames seed the pool (device to device)
     const long long total = h->masks3d.total;
     m.pool.alloc((size_t)std::max<long long>(total * 2, 1 << 16) * 3);
     m.poolcore.alloc((size_t)std::max<long long>(total * 2, 1 << 16));
-    m.use_anchor = !getenv("HMSG_DEBUG_NOANCHOR");
     if (total) HIP_TRY(hipMemcpyAsync(m.pool.p, h->masks3d.pts.p, (size_t)total * 24, hipMemcpyDeviceToDevice, h->stream));
     m.pool_used = total;
     // AABBs of the frame masks (device reduction)
@@ -716,17 +718,18 @@ void hmsg_merge(hmsg_ctx* h) {
         msegs[id].n = (int)(h->masks3d.off[id + 1] - h->masks3d.off[id]);
     }
     m.ops.bounds(m.pool.p, msegs);
-    std::vector<std::vector<Cloud>> frames(F);
+    std::vector<std::vector<Cloud>> frames((size_t)(F - first));
     // Empty masks are left out: an empty cloud never pairs (find_overlapping_ratio_faiss returns 0 for it), so it
     // stays a singleton through every step and is dropped by the min-points filter at the end (graph.py:445-448).
-    for (int f = 0; f < F; ++f) {
+    for (int f = first; f < F; ++f) {
         const int nm = (int)(h->mask_first[f + 1] - h->mask_first[f]);
-        frames[f].reserve(nm);
+        auto& fr = frames[(size_t)(f - first)];
+        fr.reserve(nm);
         for (int i = 0; i < nm; ++i) {
             const SegDesc& sd = msegs[(size_t)h->mask_first[f] + i];
             if (sd.n == 0) continue;
-            frames[f].emplace_back();
-            Cloud& k = frames[f].back();
+            fr.emplace_back();
+            Cloud& k = fr.back();
             k.off = sd.pt_base;
             k.n = sd.n;
             k.uid = m.next_uid++;
@@ -738,14 +741,62 @@ void hmsg_merge(hmsg_ctx* h) {
     }
     // overlap grids of ALL frame masks in one batch (they are inputs of the fold; only clouds that change during
     // the fold get a new grid later)
-    {
-        std::vector<Cloud> all;
-        for (auto& fr : frames) all.insert(all.end(), fr.begin(), fr.end());
-        m.build_indices(all);
-        size_t k = 0;
-        for (auto& fr : frames)
-            for (auto& cl : fr) cl = all[k++];
+    std::vector<Cloud> all;
+    for (auto& fr : frames) all.insert(all.end(), fr.begin(), fr.end());
+    m.build_indices(all);
+    size_t k = 0;
+    for (auto& fr : frames)
+        for (auto& cl : fr) cl = all[k++];
+    return frames;
+}
+
+// compact the clouds of `result` with at least `min_points` points into the handle's instance list
+void store_instances(Merger& m, hmsg_ctx* h, const std::vector<Cloud>& result, int min_points) {
+    long long keep_total = 0;
+    unsigned cat_blocks = 0;
+    std::vector<CatSeg> cat;
+    h->inst.off.assign(1, 0);
+    h->inst.box.clear();
+    for (auto& k : result) {
+        if (k.n < min_points) continue;
+        for (int a = 0; a < 3; ++a) h->inst.box.push_back(k.mn[a]);
+        for (int a = 0; a < 3; ++a) h->inst.box.push_back(k.mx[a]);
+        cat.push_back(CatSeg{k.off, keep_total, k.n, 0, (int)cat_blocks, 0});
+        cat_blocks += cdiv((size_t)k.n, CAT_CHUNK);
+        keep_total += k.n;
+        h->inst.off.push_back(keep_total);
     }
+    h->inst.total = keep_total;
+    DevBuf<double> fresh;                     // (the pool may alias the handle's current instance buffer: tree join)
+    fresh.alloc((size_t)std::max<long long>(keep_total, 1) * 3);
+    if (!cat.empty()) {
+        m.d_cat.ensure(cat.size());
+        HIP_TRY(hipMemcpyAsync(m.d_cat.p, cat.data(), cat.size() * sizeof(CatSeg), hipMemcpyHostToDevice, h->stream));
+        if (cat_blocks)
+            hipLaunchKernelGGL(k_concat, dim3(cat_blocks), dim3(256), 0, h->stream, (const double*)m.pool.p, (const CatSeg*)m.d_cat.p,
+                               (int)cat.size(), fresh.p, (const unsigned char*)nullptr, (unsigned char*)nullptr);
+        HMSG_CHECK_LAUNCH();
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    fresh.swap(h->inst.pts);
+}
+
+// threshold after a level that left `lists` lists (graph_utils.py:1001-1003)
+double next_level_threshold(double th, double factor, long long lists) {
+    return th - factor * (double)(lists - 2) / (double)std::max<long long>(1, lists - 1);
+}
+
+}  // namespace
+
+void hmsg_merge(hmsg_ctx* h) {
+    const hmsg_config& c = h->cfg;
+    HMSG_REQUIRE(h->feats_final && h->n_fused > 0, HMSG_ERR_INVALID, "hmsg_merge_instances: run hmsg_fuse_frames first");
+    HMSG_REQUIRE(!h->merged, HMSG_ERR_INVALID, "instances already merged");
+    HMSG_REQUIRE(h->frame_window == 0, HMSG_ERR_INVALID, "hmsg_merge_instances on a frame window: use hmsg_merge_tree_local / _join");
+    Merger m;
+    merger_init(m, h);
+    std::vector<std::vector<Cloud>> frames = seed_frames(m, h, 0);
+    const int F = h->n_fused;
     std::vector<Cloud> result;
     if (c.merge_type == HMSG_MERGE_HIERARCHICAL) {
         // graph_utils.py:959-1012
@@ -764,7 +815,7 @@ void hmsg_merge(hmsg_ctx* h) {
                 nx.push_back(m.merge_3d_masks(std::move(L), th));
             }
             lv = std::move(nx);
-            if (lv.size() > 1) th -= c.overlap_thresh_factor * (double)((long long)lv.size() - 2) / (double)std::max<long long>(1, (long long)lv.size() - 1);
+            if (lv.size() > 1) th = next_level_threshold(th, c.overlap_thresh_factor, (long long)lv.size());
         }
         result = m.merge_3d_masks(std::move(lv[0]), 0.75);
     } else {
@@ -777,31 +828,7 @@ void hmsg_merge(hmsg_ctx* h) {
         result = m.merge_3d_masks(std::move(G), c.init_overlap_thresh);
     }
     // graph.py:445-448: drop clouds with < 10 points; compact the survivors into the handle
-    long long keep_total = 0;
-    unsigned cat_blocks = 0;
-    std::vector<CatSeg> cat;
-    h->inst.off.assign(1, 0);
-    h->inst.box.clear();
-    for (auto& k : result) {
-        if (k.n < c.min_instance_points) continue;
-        for (int a = 0; a < 3; ++a) h->inst.box.push_back(k.mn[a]);
-        for (int a = 0; a < 3; ++a) h->inst.box.push_back(k.mx[a]);
-        cat.push_back(CatSeg{k.off, keep_total, k.n, 0, (int)cat_blocks, 0});
-        cat_blocks += cdiv((size_t)k.n, CAT_CHUNK);
-        keep_total += k.n;
-        h->inst.off.push_back(keep_total);
-    }
-    h->inst.total = keep_total;
-    h->inst.pts.alloc((size_t)std::max<long long>(keep_total, 1) * 3);
-    if (!cat.empty()) {
-        m.d_cat.ensure(cat.size());
-        HIP_TRY(hipMemcpyAsync(m.d_cat.p, cat.data(), cat.size() * sizeof(CatSeg), hipMemcpyHostToDevice, h->stream));
-        if (cat_blocks)
-            hipLaunchKernelGGL(k_concat, dim3(cat_blocks), dim3(256), 0, h->stream, (const double*)m.pool.p, (const CatSeg*)m.d_cat.p,
-                               (int)cat.size(), h->inst.pts.p, (const unsigned char*)nullptr, (unsigned char*)nullptr);
-        HMSG_CHECK_LAUNCH();
-    }
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    store_instances(m, h, result, c.min_instance_points);
     if (getenv("HMSG_DEBUG_TIMING"))
         fprintf(stderr, "[hmsg merge] index %.1f  pairs(host) %.1f  overlap %.1f  components+concat %.1f  dbscan %.1f  bookkeeping %.1f ms\n",
                 m.tphase[0], m.tphase[1], m.tphase[2], m.tphase[3], m.tphase[4], m.tphase[5]);
@@ -810,6 +837,102 @@ void hmsg_merge(hmsg_ctx* h) {
                 m.ops.stat_calls, m.ops.stat_points / m.ops.stat_calls, m.ops.stat_cells / m.ops.stat_calls,
                 m.ops.stat_core_cells / m.ops.stat_calls, m.ops.stat_active_cells / m.ops.stat_calls);
     h->merged = true;
+}
+
+// ---- hierarchical_merge (graph_utils.py:989-1012) sharded over the frames --------------------------
+// The merge tree pairs ADJACENT lists level by level, so a handle that holds the frames [first, first + n) of an
+// episode of `total_frames` frames -- first a multiple of a power of two >= n -- owns a whole subtree: it reduces its
+// frames with the thresholds the GLOBAL tree has at those levels and stops when its list's partner lives on another
+// handle.  hmsg_merge_tree_join then plays one cross-handle level: [mine ++ theirs] through merge_3d_masks, and on the
+// last level the final pass (threshold 0.75, :1007-1011) and the small-cloud drop of graph.py:445-448.
+void hmsg_merge_tree_local_impl(hmsg_ctx* h, int total_frames, double* th_next, long long* lists_now, long long* my_index) {
+    const hmsg_config& c = h->cfg;
+    HMSG_REQUIRE(h->feats_final && h->n_fused > h->frame_window, HMSG_ERR_INVALID, "hmsg_merge_tree_local: run hmsg_fuse_frames first");
+    HMSG_REQUIRE(!h->merged, HMSG_ERR_INVALID, "instances already merged");
+    HMSG_REQUIRE(total_frames >= h->n_fused, HMSG_ERR_INVALID, "hmsg_merge_tree_local: total_frames smaller than the window's end");
+    Merger m;
+    merger_init(m, h);
+    m.use_cache = true;
+    std::vector<std::vector<Cloud>> lv = seed_frames(m, h, h->frame_window);
+    double th = c.init_overlap_thresh;
+    long long lists = total_frames, off = h->frame_window;     // global list count / global index of my first list
+    while (lists > 1) {
+        const long long n = (long long)lv.size();
+        // local level: my lists pair among themselves (an odd last one only when it is the global last list)
+        if ((off & 1) || ((n & 1) && off + n < lists)) break;
+        std::vector<std::vector<Cloud>> nx;
+        for (size_t i = 0; i < lv.size(); i += 2) {
+            if (i == lv.size() - 1) {
+                nx.push_back(std::move(lv[i]));
+                break;
+            }
+            std::vector<Cloud> L = std::move(lv[i]);
+            L.insert(L.end(), lv[i + 1].begin(), lv[i + 1].end());
+            nx.push_back(m.merge_3d_masks(std::move(L), th));
+        }
+        lv = std::move(nx);
+        off >>= 1;
+        lists = (lists + 1) / 2;
+        if (lists > 1) th = next_level_threshold(th, c.overlap_thresh_factor, lists);
+    }
+    HMSG_REQUIRE(lv.size() == 1, HMSG_ERR_UNSUPPORTED,
+                 "hmsg_merge_tree_local: the frame window is not a subtree of the merge tree (first frame must be a multiple of a "
+                 "power of two >= the window length)");
+    store_instances(m, h, lv[0], 0);
+    *th_next = th;
+    *lists_now = lists;
+    *my_index = off;
+    h->tree_partial = true;
+}
+
+void hmsg_merge_tree_join_impl(hmsg_ctx* h, int n_ext, const long long* ext_sizes, const double* ext_pts, double th, int final_pass) {
+    const hmsg_config& c = h->cfg;
+    HMSG_REQUIRE(h->tree_partial, HMSG_ERR_INVALID, "hmsg_merge_tree_join: run hmsg_merge_tree_local first");
+    HMSG_REQUIRE(n_ext >= 0 && (n_ext == 0 || (ext_sizes && ext_pts)), HMSG_ERR_INVALID, "hmsg_merge_tree_join: bad argument");
+    Merger m;
+    merger_init(m, h);
+    m.use_cache = true;
+    long long ext_total = 0;
+    for (int k = 0; k < n_ext; ++k) ext_total += ext_sizes[k];
+    const long long own = h->inst.total, total = own + ext_total;
+    m.pool.alloc((size_t)std::max<long long>(total * 2, 1 << 16) * 3);
+    m.poolcore.alloc((size_t)std::max<long long>(total * 2, 1 << 16));
+    if (own) HIP_TRY(hipMemcpyAsync(m.pool.p, h->inst.pts.p, (size_t)own * 24, hipMemcpyDeviceToDevice, h->stream));
+    if (ext_total) HIP_TRY(hipMemcpyAsync(m.pool.p + (size_t)own * 3, ext_pts, (size_t)ext_total * 24, hipMemcpyHostToDevice, h->stream));
+    m.pool_used = total;
+    const int n_own = (int)h->inst.off.size() - 1;
+    std::vector<SegDesc> segs((size_t)(n_own + n_ext));
+    for (int k = 0; k < n_own; ++k) {
+        segs[(size_t)k].pt_base = h->inst.off[(size_t)k];
+        segs[(size_t)k].n = (int)(h->inst.off[(size_t)k + 1] - h->inst.off[(size_t)k]);
+    }
+    long long at = own;
+    for (int k = 0; k < n_ext; ++k) {
+        segs[(size_t)(n_own + k)].pt_base = at;
+        segs[(size_t)(n_own + k)].n = (int)ext_sizes[k];
+        at += ext_sizes[k];
+    }
+    m.ops.bounds(m.pool.p, segs);
+    std::vector<Cloud> L;                      // [my list ++ the partner's list]: I hold the even-indexed list of the pair
+    for (auto& sd : segs) {
+        if (sd.n == 0) continue;
+        Cloud k;
+        k.off = sd.pt_base;
+        k.n = sd.n;
+        k.uid = m.next_uid++;
+        for (int a = 0; a < 3; ++a) {
+            k.mn[a] = sd.mn[a];
+            k.mx[a] = sd.mx[a];
+        }
+        L.push_back(k);
+    }
+    std::vector<Cloud> result = n_ext > 0 ? m.merge_3d_masks(std::move(L), th) : std::move(L);
+    if (final_pass) result = m.merge_3d_masks(std::move(result), 0.75);
+    store_instances(m, h, result, final_pass ? c.min_instance_points : 0);
+    if (final_pass) {
+        h->merged = true;
+        h->tree_partial = false;
+    }
 }
 
 // A10 first step (graph.py:1589-1591): every instance re-denoised with pcd_denoise_dbscan(eps, min_points),

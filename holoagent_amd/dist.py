@@ -37,3 +37,56 @@ def gather_node_tables(feats: np.ndarray, rooms: np.ndarray, n_rooms_local: int,
 def shard_queries(n_queries: int, rank: int, world: int):
     """Round-robin share of the query batch for this rank."""
     return list(range(rank, n_queries, world))
+
+
+def sharded_hierarchical_merge(scene, total_frames, overlap_thresh_factor=0.025, group=None):
+    """hierarchical_merge (graph_utils.py:989-1012) of ONE episode whose frames are spread over the ranks:
+    rank r holds the frame window [r * chunk, (r + 1) * chunk) with chunk a power of two (scene.set_frame_window), has
+    fused its own frames, and calls this.  Rank-local tree levels first, then log2(ranks) cross-rank levels in which
+    the odd list of every pair travels to the rank holding the even one (point clouds, over torch.distributed send /
+    recv: RCCL on the GPUs, gloo in the CPU test); rank 0 ends with the instances of the whole episode, bit-identical
+    to a single-process hmsg_merge_instances.  Returns True on the rank that holds the result."""
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
+    th, lists, idx = scene.merge_tree_local(total_frames)
+    stride = 1                                   # ranks between the owners of adjacent lists at this level
+    active = True
+    if lists == 1:                               # one rank held every frame
+        scene.merge_tree_join([], th, final_pass=True)
+        return True
+    while lists > 1:
+        nxt = (lists + 1) // 2
+        if active:
+            if idx % 2 == 0:
+                if idx + 1 < lists:
+                    src = rank + stride
+                    meta = torch.zeros(1, dtype=torch.int64)
+                    dist.recv(meta, src=src, group=group)
+                    sizes = torch.zeros(int(meta.item()), dtype=torch.int64)
+                    if len(sizes):
+                        dist.recv(sizes, src=src, group=group)
+                    pts = torch.zeros((int(sizes.sum().item()), 3), dtype=torch.float64)
+                    if len(pts):
+                        dist.recv(pts, src=src, group=group)
+                    off = np.concatenate([[0], np.cumsum(sizes.numpy())])
+                    clouds = [pts.numpy()[off[k]:off[k + 1]] for k in range(len(sizes))]
+                    scene.merge_tree_join(clouds, th, final_pass=(nxt == 1))
+                # (an even list without a partner is carried to the next level unchanged)
+            else:
+                dst = rank - stride
+                clouds = scene.instances()
+                sizes = torch.tensor([len(c) for c in clouds], dtype=torch.int64)
+                dist.send(torch.tensor([len(clouds)], dtype=torch.int64), dst=dst, group=group)
+                if len(clouds):
+                    dist.send(sizes, dst=dst, group=group)
+                pts = torch.from_numpy(np.ascontiguousarray(np.concatenate(clouds) if len(clouds) else np.zeros((0, 3))))
+                if len(pts):
+                    dist.send(pts, dst=dst, group=group)
+                active = False
+        idx //= 2
+        stride *= 2
+        lists = nxt
+        if lists > 1:
+            th -= overlap_thresh_factor * (lists - 2) / max(1, lists - 1)
+    return active

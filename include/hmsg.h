@@ -148,6 +148,26 @@ int hmsg_get_instance_sizes(const hmsg_t* h, int64_t* sizes /*[N]*/);
 int hmsg_get_instance_points(const hmsg_t* h, double* xyz /*[sum][3]*/);
 int hmsg_get_instance_boxes(const hmsg_t* h, double* boxes /*[N][6]: AABB min xyz, max xyz*/);
 
+/* ---- hierarchical_merge (graph_utils.py:989-1012) sharded over the frames of ONE episode: every handle
+ * holds the whole map (all frames' geometry) but the features / masks of its own frame range only.
+ *   hmsg_set_frame_window  after hmsg_finalize_map, before any feature: this handle's frames start at first_frame
+ *                          (frame indices stay global; hmsg_add_frame_features continues from first_frame).
+ *   hmsg_merge_tree_local  the levels of the merge tree that lie inside the window, with the thresholds the global tree
+ *                          over total_frames frames has there.  first_frame must be a multiple of a power of two >= the
+ *                          window length.  Leaves the unfinished list as the handle's instances (hmsg_get_instance_*),
+ *                          reports the threshold of the next level, the number of lists at that level and this list's
+ *                          index among them.
+ *   hmsg_merge_tree_join   one cross-handle level on the handle that holds the even-indexed list: merge_3d_masks over
+ *                          [mine ++ the partner's clouds] (host arrays: sizes i64 [n_ext], points f64 [sum][3]) at
+ *                          threshold th; final_pass != 0 also runs the last pass (threshold 0.75, :1007-1011) and the
+ *                          small-cloud drop (graph.py:445-448), after which hmsg_pool_instances may follow.
+ *                          n_ext == 0 with final_pass: a single handle held every frame.
+ * The result is bit-identical to hmsg_merge_instances over all frames (tests/test_distributed_gloo.py). */
+int hmsg_set_frame_window(hmsg_t* h, int32_t first_frame);
+int hmsg_merge_tree_local(hmsg_t* h, int32_t total_frames, double* th_next, int64_t* lists_now, int64_t* my_index);
+int hmsg_merge_tree_join(hmsg_t* h, int32_t n_ext, const int64_t* ext_sizes, const double* ext_points, double th,
+                         int32_t final_pass);
+
 /* ---- A7: per-instance feature pooling (graph.py:450-491, graph_utils.py:682-728). */
 int hmsg_pool_instances(hmsg_t* h);
 int hmsg_get_instance_feats(const hmsg_t* h, float* feats /*[N][D]*/);

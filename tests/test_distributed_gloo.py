@@ -89,3 +89,68 @@ def test_bench_spawns_its_own_ranks():
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["rank_sum"] == 3
+
+
+# ---- config 5 building block: the hierarchical merge tree of ONE episode sharded over the ranks ---------------------
+def _episode(n_frames=8):
+    from holoagent_amd.synth import SceneSpec, SynthScene
+    spec = SceneSpec(seed=11, rooms_x=1, rooms_z=1, room_size=(3.6, 2.5, 3.2), objects_per_room=4, width=96, height=72,
+                     n_frames=n_frames, n_masks=8, feat_dim=16, yaw_step_deg=25.0)
+    scn = SynthScene(spec)
+    return [scn.frame(i) for i in range(n_frames)]
+
+
+def _build(L, frames, window=None):
+    """Scene with the whole map; features / masks of frames[window] only (all frames when None)."""
+    S = PC.stack_frames(frames)
+    sc = PC.make_scene(L, frames, dict(feat_dim=16, merge_type=1, outlier_nb_points=200))
+    sc.add_frames(S["rgb"], S["depth"], S["pose"], S["K"])
+    sc.finalize_map()
+    a, b = window if window is not None else (0, len(frames))
+    if window is not None:
+        sc.set_frame_window(a)
+    sc.add_frame_features(a, S["masks"][a:b], S["f_g"][a:b], S["f_masked"][a:b], S["f_crop"][a:b], S["n_masks"][a:b])
+    sc.fuse_frames()
+    return sc
+
+
+def _merge_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from holoagent_amd._lib import HmsgLib
+    from holoagent_amd.dist import sharded_hierarchical_merge
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames = _episode()
+    chunk = len(frames) // world
+    sc = _build(HmsgLib(PC.EMU_PATH), frames, (rank * chunk, (rank + 1) * chunk))
+    holds = sharded_hierarchical_merge(sc, len(frames))
+    assert holds == (rank == 0)
+    if rank == 0:
+        inst = sc.instances()
+        np.savez(out, sizes=np.array([len(c) for c in inst]), pts=np.concatenate(inst) if inst else np.zeros((0, 3)))
+    dist.barrier()
+    sc.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, pytest.param(4, marks=pytest.mark.skipif(not os.environ.get("HMSG_EMU_SLOW"),
+                                                                                reason="another minute on the simulator"))])
+def test_sharded_hierarchical_merge_equals_single_process(tmp_path, world):
+    """Frames of one episode split over the ranks, rank-local tree levels + cross-rank joins (torch.distributed send /
+    recv) == hmsg_merge_instances over all frames in one process, bit for bit."""
+    import torch.multiprocessing as mp
+    from holoagent_amd._lib import HmsgLib
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "merged.npz")
+    mp.spawn(_merge_worker, args=(world, port, out), nprocs=world, join=True)
+    sc = _build(HmsgLib(PC.EMU_PATH), _episode())
+    sc.merge_instances()
+    ref = sc.instances()
+    sc.close()
+    z = np.load(out)
+    assert len(ref) > 3 and z["sizes"].tolist() == [len(c) for c in ref]
+    assert np.array_equal(z["pts"], np.concatenate(ref))
