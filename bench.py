@@ -278,7 +278,9 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))["kernels"]
             key = {"k_db_union/box": "k_db_union", "k_db_union/scan": "k_db_union_scan"}.get(roof["kernel"], roof["kernel"])
             if key in pmc:
-                roof["traffic"] = int(pmc[key]["hbm_bytes_per_launch"])
+                # (a timed "launch" of k_ov_query is the pair of launches of one fold step: scale by the dispatch counts)
+                per = max(1.0, pmc[key]["dispatches"] / max(roof["launches"], 1)) if key == "k_ov_query" else 1.0
+                roof["traffic"] = int(pmc[key]["hbm_bytes_per_launch"] * per)
                 roof["traffic_source"] = "profiles/r02_pmc_traffic.json (offline PMC passes, same command)"
         except Exception:
             pass

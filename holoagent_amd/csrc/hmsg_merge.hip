@@ -91,7 +91,7 @@ __device__ __forceinline__ long long ov_cell(const OvGrid& g, float x, float y, 
 // (counts go to `cursor`, indexed relative to the batch's first cell; the scan turns them into cell starts in
 //  `cells`, and k_ov_fill hands a cell's slots out from its end by counting `cursor` back down -- the order of
 //  points inside a cell is irrelevant)
-#define OVI_CHUNK 2048      /* points per workgroup of the index kernels */
+#define OVI_CHUNK 512      /* points per workgroup of the index kernels */
 __global__ void k_ov_count(const double* __restrict__ pool, const OvGrid* __restrict__ gr, int ngr, unsigned* __restrict__ cursor,
                            long long cursor_base) {
     const OvGrid g = gr[find_entry(gr, ngr, blockIdx.x)];
@@ -214,7 +214,7 @@ struct CatSeg {
     int n, anchor;          // anchor: copy the member's persisted core flags (else the flags are cleared)
     int blk0, pad;          // first workgroup of this segment (work list)
 };
-#define CAT_CHUNK 4096      /* points per workgroup of k_concat */
+#define CAT_CHUNK 512      /* points per workgroup of k_concat */
 __global__ void k_concat(const double* __restrict__ pool, const CatSeg* __restrict__ segs, int nsegs, double* __restrict__ dst,
                          const unsigned char* __restrict__ poolcore, unsigned char* __restrict__ dstcore) {
     const CatSeg sg = segs[find_entry(segs, nsegs, blockIdx.x)];
@@ -423,10 +423,9 @@ struct Merger {
         HIP_TRY(hipMemsetAsync(d_counts.p, 0, tasks.size() * 4, s));
         const float r = (float)radius;
         const float r2 = (float)(radius * radius);   // `D < radius**2` with a float32 D (graph_utils.py:654-655)
-        double ov_work = 0;
-        for (auto& t : tasks) ov_work += 12.0 * g[t.x].n;
+        const size_t prof_idx = h->prof.ev.size();          // (algorithmic bytes are filled in after the read-back)
         {
-            ProfScope ps(h->prof, s, "k_ov_query", ov_work);   // (the kernel launches only: not the read-back below)
+            ProfScope ps(h->prof, s, "k_ov_query", 0.0);       // (the kernel launches only: not the read-back below)
             for (int dir = 0; dir < 2; ++dir) {
                 const unsigned nb = dir ? nblk2 : nblk1;
                 if (!nb) continue;
@@ -442,10 +441,14 @@ struct Merger {
         unsigned* hc = h_counts.p;
         HIP_TRY(hipMemcpyAsync(hc, d_counts.p, tasks.size() * 4, hipMemcpyDeviceToHost, s));
         spin.wait(s);
+        double ov_work = 0;                                  // 12 B per point of every scan the decision needed
         for (size_t k = 0; k < P; ++k) {
             const int na = std::min(L[pairs[k].first].n, L[pairs[k].second].n), nb = std::max(L[pairs[k].first].n, L[pairs[k].second].n);
             ratio[k] = std::max((double)hc[k] / (double)na, (double)hc[P + k] / (double)nb);
+            ov_work += 12.0 * na;
+            if (!(decide_th >= 0.0 && (double)hc[k] / (double)na > decide_th)) ov_work += 12.0 * nb;
         }
+        if (h->prof.enabled && prof_idx < h->prof.ev.size()) h->prof.ev[prof_idx].work = ov_work;
     }
 
     // ---- merge_3d_masks (graph_utils.py:918-956)
