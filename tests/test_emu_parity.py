@@ -34,7 +34,7 @@ def test_mask_walk_heavy_voxel_path(L):
     """The wave-per-voxel replay of heavy mask voxels (k_mwalk_heavy: bulk integer additions inside a binade) forced
     on every voxel: still bit-identical."""
     z = GI.load("build_ragged")
-    frames = GI.unpack_frames(z)[:5]
+    frames = GI.unpack_frames(z)[:3]
     cfg = GI.unpack_cfg(z)
     cfg["outlier_nb"] = 300
     os.environ["HMSG_DEBUG_MWALK_HEAVY"] = "1"
