@@ -63,6 +63,8 @@ _SIGS = {
     "hmsg_get_frame_num_masks": (C.c_int32, [_P, C.c_int32]),
     "hmsg_fuse_frames": (C.c_int, [_P]),
     "hmsg_get_map_feats": (C.c_int, [_P, _P, _P]),
+    "hmsg_get_feature_sums": (C.c_int, [_P, _P, _P]),
+    "hmsg_set_feature_sums": (C.c_int, [_P, _P, _P]),
     "hmsg_get_frame_nn": (C.c_int, [_P, C.c_int32, _P]),
     "hmsg_get_frame_fp": (C.c_int, [_P, C.c_int32, _P]),
     "hmsg_get_frame_mask_sizes": (C.c_int, [_P, C.c_int32, _P]),
@@ -242,6 +244,16 @@ class Scene:
         c = np.empty((V,), np.float32) if counter else None
         self._ck(self.L.c.hmsg_get_map_feats(self.h, _ptr(f), _ptr(c)))
         return (f, c) if counter else f
+
+    def feature_sums(self):
+        V, D = self.map_size(), self.cfg.feat_dim
+        s_, c = np.empty((V, D), np.float32), np.empty((V,), np.uint32)
+        self._ck(self.L.c.hmsg_get_feature_sums(self.h, _ptr(s_), _ptr(c)))
+        return s_, c
+
+    def set_feature_sums(self, sums, counter):
+        self._ck(self.L.c.hmsg_set_feature_sums(self.h, _ptr(np.ascontiguousarray(sums, np.float32)),
+                                                _ptr(np.ascontiguousarray(counter, np.uint32))))
 
     def frame_nn(self, frame):
         idx = np.empty((self.cfg.height, self.cfg.width), np.int32)

@@ -410,6 +410,43 @@ int hmsg_get_map_feats(const hmsg_t* hc, float* feats, float* counter) {
     });
 }
 
+// graph.py:413-415 again after the sums changed
+__global__ void k_feats_refresh(const float* __restrict__ sum, const unsigned* __restrict__ cnt, long long V, int D,
+                                float* __restrict__ feats) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)V * D) return;
+    unsigned c = cnt[t / D];
+    float d = c == 0u ? 1e-5f : (float)c;
+    feats[t] = __fdiv_rn(sum[t], d);
+}
+
+int hmsg_get_feature_sums(const hmsg_t* hc, float* sum, uint32_t* counter) {
+    hmsg_ctx* h = const_cast<hmsg_ctx*>(hc);
+    if (!h) return HMSG_ERR_INVALID;
+    return guard(h, [&] {
+        HMSG_REQUIRE(h->feats_final, HMSG_ERR_INVALID, "hmsg_fuse_frames not run");
+        const size_t n = (size_t)h->V * h->cfg.feat_dim;
+        if (sum && n) HIP_TRY(hipMemcpy(sum, h->sum.p, n * 4, is_device_ptr(sum) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+        if (counter && h->V)
+            HIP_TRY(hipMemcpy(counter, h->cnt.p, (size_t)h->V * 4, is_device_ptr(counter) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    });
+}
+
+int hmsg_set_feature_sums(hmsg_t* h, const float* sum, const uint32_t* counter) {
+    if (!h) return HMSG_ERR_INVALID;
+    return guard(h, [&] {
+        HMSG_REQUIRE(h->feats_final && sum && counter, HMSG_ERR_INVALID, "hmsg_set_feature_sums: run hmsg_fuse_frames first");
+        HMSG_REQUIRE(!h->pooled, HMSG_ERR_INVALID, "hmsg_set_feature_sums after hmsg_pool_instances");
+        const size_t n = (size_t)h->V * h->cfg.feat_dim;
+        copy_in(h->sum.p, sum, n * 4, h->stream);
+        copy_in(h->cnt.p, counter, (size_t)h->V * 4, h->stream);
+        if (n) hipLaunchKernelGGL(k_feats_refresh, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, (const float*)h->sum.p,
+                                  (const unsigned*)h->cnt.p, (long long)h->V, h->cfg.feat_dim, h->feats.p);
+        HMSG_CHECK_LAUNCH();
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    });
+}
+
 int hmsg_get_frame_nn(const hmsg_t* hc, int32_t frame, int32_t* idx) {
     hmsg_ctx* h = const_cast<hmsg_ctx*>(hc);
     if (!h) return HMSG_ERR_INVALID;

@@ -90,3 +90,18 @@ def sharded_hierarchical_merge(scene, total_frames, overlap_thresh_factor=0.025,
         if lists > 1:
             th -= overlap_thresh_factor * (lists - 2) / max(1, lists - 1)
     return active
+
+
+def allreduce_feature_sums(scene, group=None, device=None):
+    """One episode fused in disjoint frame windows: sum the per-voxel feature sums and frame counters of
+    all ranks (all-reduce of V * (D + 1) * 4 bytes over RCCL / gloo) and install the result on every rank.  Counters
+    are exact; the float32 sums agree with a single-process build up to summation order (<= 1e-5)."""
+    import torch
+    import torch.distributed as dist
+    sums, cnt = scene.feature_sums()
+    dev = device if device is not None else torch.device("cpu")
+    ts = torch.from_numpy(sums).to(dev)
+    tc = torch.from_numpy(cnt.astype(np.int64)).to(dev)
+    dist.all_reduce(ts, group=group)
+    dist.all_reduce(tc, group=group)
+    scene.set_feature_sums(ts.cpu().numpy(), tc.cpu().numpy().astype(np.uint32))

@@ -132,6 +132,12 @@ int32_t hmsg_get_frame_num_masks(const hmsg_t* h, int32_t frame);
  * (graph.py:380-415, generic.py:140-190). */
 int hmsg_fuse_frames(hmsg_t* h);
 int hmsg_get_map_feats(const hmsg_t* h, float* feats /*[V][D]*/, float* counter /*[V] or NULL*/);
+/* The per-voxel feature sums behind hmsg_get_map_feats (graph.py:410-411): sum f32 [V][D], counter u32 [V] (host or
+ * device pointers; either may be NULL on get).  Handles that fused disjoint frame windows of ONE episode (same map)
+ * all-reduce them and install the result; feats = sum / counter is recomputed (graph.py:413-415).  Frame
+ * contributions add commutatively, so the reduced map equals the single-handle one up to float32 summation order. */
+int hmsg_get_feature_sums(const hmsg_t* h, float* sum, uint32_t* counter);
+int hmsg_set_feature_sums(hmsg_t* h, const float* sum, const uint32_t* counter);
 /* test/introspection: NN index of every pixel of a frame (-1 where depth == 0), i32 [H][W] */
 int hmsg_get_frame_nn(const hmsg_t* h, int32_t frame, int32_t* idx);
 /* test/introspection: F_p of a frame (sam_clip_feats_extractor.py:172-175), f32 [n_masks(frame)][D] */

@@ -124,11 +124,16 @@ def _merge_worker(rank, world, port, out):
     frames = _episode()
     chunk = len(frames) // world
     sc = _build(HmsgLib(PC.EMU_PATH), frames, (rank * chunk, (rank + 1) * chunk))
+    from holoagent_amd.dist import allreduce_feature_sums
+    allreduce_feature_sums(sc)                       # every rank now holds the whole episode's voxel features
     holds = sharded_hierarchical_merge(sc, len(frames))
     assert holds == (rank == 0)
     if rank == 0:
         inst = sc.instances()
-        np.savez(out, sizes=np.array([len(c) for c in inst]), pts=np.concatenate(inst) if inst else np.zeros((0, 3)))
+        sc.pool_instances()
+        feats, counter = sc.map_feats(counter=True)
+        np.savez(out, sizes=np.array([len(c) for c in inst]), pts=np.concatenate(inst) if inst else np.zeros((0, 3)),
+                 map_feats=feats, counter=counter, pooled=sc.instance_feats())
     dist.barrier()
     sc.close()
     dist.destroy_process_group()
@@ -137,8 +142,9 @@ def _merge_worker(rank, world, port, out):
 @pytest.mark.parametrize("world", [2, pytest.param(4, marks=pytest.mark.skipif(not os.environ.get("HMSG_EMU_SLOW"),
                                                                                 reason="another minute on the simulator"))])
 def test_sharded_hierarchical_merge_equals_single_process(tmp_path, world):
-    """Frames of one episode split over the ranks, rank-local tree levels + cross-rank joins (torch.distributed send /
-    recv) == hmsg_merge_instances over all frames in one process, bit for bit."""
+    """Frames of one episode split over the ranks: all-reduce of the voxel feature sums, rank-local merge-tree levels +
+    cross-rank joins (torch.distributed send / recv), pooling on the root == one process over all frames (instances bit
+    for bit, features within 1e-5)."""
     import torch.multiprocessing as mp
     from holoagent_amd._lib import HmsgLib
     s = socket.socket()
@@ -150,7 +156,15 @@ def test_sharded_hierarchical_merge_equals_single_process(tmp_path, world):
     sc = _build(HmsgLib(PC.EMU_PATH), _episode())
     sc.merge_instances()
     ref = sc.instances()
+    sc.pool_instances()
+    ref_feats, ref_counter = sc.map_feats(counter=True)
+    ref_pooled = sc.instance_feats()
     sc.close()
     z = np.load(out)
     assert len(ref) > 3 and z["sizes"].tolist() == [len(c) for c in ref]
     assert np.array_equal(z["pts"], np.concatenate(ref))
+    # voxel features all-reduced over the ranks: counters exact, float32 sums up to summation order; pooled features
+    # of the episode within the north-star tolerance
+    assert np.array_equal(z["counter"], ref_counter)
+    np.testing.assert_allclose(z["map_feats"], ref_feats, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(z["pooled"], ref_pooled, rtol=0, atol=1e-5)
