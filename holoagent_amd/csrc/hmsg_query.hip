@@ -6,7 +6,11 @@
 //   sim = T[C, D] . E[N', D]^T  (float32 text x float64 embeddings -> float64, graph.py:3127)
 //   plain top-k by sim[qid] (descending); with negative prompts: objects whose arg-max class (first max)
 //   is the query class, ordered by descending score; if there is none, the plain top-k (graph.py:3133-3151).
-//   Ties (unspecified in numpy's introsort) are broken by candidate position = room order, then node order.
+//   Exact score ties (bit-equal scores: duplicate embeddings) are broken by candidate position = room order, then
+//   node order.  That is what np.argsort(-score) of the negative-prompt path gives for them; the plain path's
+//   np.argsort(sim)[::-1] has no defined order for equal keys (numpy's default sort is not stable: for three
+//   duplicates it returned 5, 0, 2 in tests/test_emu_parity.py::test_query_exact_score_ties), so only the SET of tied
+//   nodes and their scores can be compared there.
 //
 // MI355X design: the table stays in HBM as float64; all Q x C text rows are scored against ALL nodes by
 // one f64-MFMA GEMM (v_mfma_f64_16x16x4_f64), then one workgroup per query walks its candidate rooms

@@ -1019,6 +1019,28 @@ class Graph:
         back = {g: l for l, g in zip(room_ids, rooms_global)}
         return [int(i) for i in idx[0][keep]], [back[int(r)] for r in room[0][keep]], [float(s) for s in score[0][keep]]
 
+    def rank_goal_views(self, object_query, rooms_list, top_k=24):
+        """The view search of the slow path (graph.py:2864-2897): similarity of the object query to the CLIP embedding of
+        EVERY sampled image of the candidate rooms, arg-max and the top-24 (np.argsort(sims)[-k:][::-1]).  The similarity
+        matrix comes from the device (float64 MFMA GEMM); the ordering is numpy's.  Returns (best image id, top image
+        ids, similarities)."""
+        img_ids, embs = [], []
+        for room in rooms_list:
+            assert len(room.sample_images) == len(room.clip_embeddings), \
+                f"Number of images ({len(room.sample_images)}) != embeddings ({len(room.clip_embeddings)})"
+            img_ids.extend(room.sample_images)
+            embs.extend(np.asarray(e).reshape(-1) for e in room.clip_embeddings)
+        if not img_ids:
+            return None, [], np.zeros(0)
+        t = self.get_text_feats_multiple_templates([object_query])
+        table = np.ascontiguousarray(np.stack(embs), dtype=np.float64)
+        ix = NodeIndex(table, np.zeros(len(table), np.int32), lib_=self.L)
+        sims = ix.similarity(t[:1])[0]
+        ix.close()
+        k = min(top_k, sims.shape[0])
+        top_idx = np.argsort(sims)[-k:][::-1]
+        return img_ids[int(np.argmax(sims))], [img_ids[int(i)] for i in top_idx], sims
+
     def _parse(self, query_instruction):
         if isinstance(query_instruction, str):
             return type(self).instruction_parser(query_instruction)

@@ -150,3 +150,30 @@ def test_query_tiled_gemm_small(L):
     S = ix.similarity(T[:, 0, :])
     np.testing.assert_allclose(S, np.dot(T[:, 0, :].astype(np.float64), emb.T), rtol=0, atol=1e-12)
     ix.close()
+
+
+def test_query_exact_score_ties(L):
+    """Duplicate embeddings give bit-equal scores.  The negative-prompt path orders them like np.argsort(-score) (the
+    earlier candidate first, graph.py:3147-3150).  The plain path's np.argsort(sim)[::-1] (:3133) has no defined order
+    for equal keys (numpy's default sort is not stable), so there the scores and the set of nodes per score are compared;
+    the library lists tied nodes by candidate position."""
+    from holoagent_amd._lib import NodeIndex
+    from oracle import hmsg_oracle as O
+    rng = np.random.Generator(np.random.PCG64(12))
+    D = 12
+    base = rng.standard_normal((5, D))
+    emb = base[[0, 1, 0, 2, 1, 0, 3, 4, 2]]                       # 9 nodes, rows 0/2/5, 1/4 and 3/8 are duplicates
+    room = np.zeros(len(emb), np.int32)
+    T = np.stack([base[0] + 0.01 * rng.standard_normal(D), -base[0]]).astype(np.float32)[None]
+    ix = NodeIndex(emb, room, lib_=L)
+    idx, _, score = ix.query_objects(T, np.zeros(1, np.int32), [[0]], 6, use_negatives=True)
+    top, sc = O.query_object(T[0], 0, emb, 6, has_negatives=True)
+    assert [int(v) for v in idx[0] if v >= 0] == [int(t) for t in top]
+    np.testing.assert_array_equal(score[0][: len(top)], sc)
+    idx, _, score = ix.query_objects(T, np.zeros(1, np.int32), [[0]], 6, use_negatives=False)
+    top, sc = O.query_object(T[0], 0, emb, 6, has_negatives=False)
+    np.testing.assert_array_equal(score[0], sc)
+    for v in np.unique(sc):
+        assert sorted(int(i) for i in idx[0][score[0] == v]) == sorted(int(t) for t in top[sc == v])
+    assert [int(i) for i in idx[0][:3]] == [0, 2, 5]             # tied nodes in candidate order
+    ix.close()

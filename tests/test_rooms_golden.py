@@ -147,6 +147,13 @@ def test_graph_build_with_room_regions(tmp_path):
     g2 = Graph(dict(main=dict(), models=dict(clip=dict(feat_dim=32))), encoders=enc, lib=L)
     g2.load_hmsg_graph(str(tmp_path / "graph"))
     assert len(rv(g2)) == len(g.views) and len(g2.objects) == len(g.objects)
+    # slow-path view search (graph.py:2864-2897): top views of the candidate rooms for an object query
+    best, top, sims = g2.rank_goal_views("chair", g2.rooms, top_k=24)
+    allv = [i for r in g2.rooms for i in r.sample_images]
+    ref = np.dot(g2.get_text_feats_multiple_templates(["chair"])[0].astype(np.float64),
+                 np.stack([np.asarray(e, np.float64).reshape(-1) for r in g2.rooms for e in r.clip_embeddings]).T)
+    np.testing.assert_allclose(sims, ref, rtol=0, atol=1e-12)
+    assert best == allv[int(np.argmax(ref))] and top == [allv[int(i)] for i in np.argsort(ref)[-min(24, len(ref)):][::-1]]
     g2.generate_room_names(default_room_types=["office", "kitchen"])
     fl, rooms, objs, res = g2.query_hierarchy_protected_icra("find the chair in the %s" % g2.rooms[0].name, top_k=2)
     assert res["object_query"] == "chair" and len(objs) <= 2
