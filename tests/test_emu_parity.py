@@ -170,8 +170,8 @@ def test_query_exact_score_ties(L):
     top, sc = O.query_object(T[0], 0, emb, 6, has_negatives=True)
     assert [int(v) for v in idx[0] if v >= 0] == [int(t) for t in top]
     np.testing.assert_array_equal(score[0][: len(top)], sc)
-    idx, _, score = ix.query_objects(T, np.zeros(1, np.int32), [[0]], 6, use_negatives=False)
-    top, sc = O.query_object(T[0], 0, emb, 6, has_negatives=False)
+    idx, _, score = ix.query_objects(T, np.zeros(1, np.int32), [[0]], 9, use_negatives=False)      # (all nodes: no tie
+    top, sc = O.query_object(T[0], 0, emb, 9, has_negatives=False)                               #  is cut by k)
     np.testing.assert_array_equal(score[0], sc)
     for v in np.unique(sc):
         assert sorted(int(i) for i in idx[0][score[0] == v]) == sorted(int(t) for t in top[sc == v])
