@@ -62,8 +62,7 @@ __device__ __forceinline__ int find_entry(const T* __restrict__ e, int n, unsign
 }
 
 struct OvGrid {             // device view of one cloud for the overlap kernels
-    int blk0;               // first workgroup of this cloud in k_ov_count / k_ov_fill (work list)
-    int use_core;           // the cloud is an anchor: its persisted core flags go into the index (k_absorb)
+    int blk0, pad0;         // first workgroup of this cloud in k_ov_count / k_ov_fill (work list)
     long long pt_off;       // f64 points in the pool
     long long ix_pt;        // its cell-sorted float32 copy in ix_pts (cell starts are relative to it)
     long long ix_cell;
@@ -93,7 +92,6 @@ __device__ __forceinline__ long long ov_cell(const OvGrid& g, float x, float y, 
 //  `cells`, and k_ov_fill hands a cell's slots out from its end by counting `cursor` back down -- the order of
 //  points inside a cell is irrelevant)
 #define OVI_CHUNK 512      /* points per workgroup of the index kernels */
-#define OV_CHUNK 512       /* points per workgroup of the overlap / absorb queries */
 __global__ void k_ov_count(const double* __restrict__ pool, const OvGrid* __restrict__ gr, int ngr, unsigned* __restrict__ cursor,
                            long long cursor_base) {
     const OvGrid g = gr[find_entry(gr, ngr, blockIdx.x)];
@@ -104,8 +102,7 @@ __global__ void k_ov_count(const double* __restrict__ pool, const OvGrid* __rest
     }
 }
 __global__ void k_ov_fill(const double* __restrict__ pool, const OvGrid* __restrict__ gr, int ngr, const unsigned* __restrict__ cells,
-                          unsigned* __restrict__ cursor, long long cursor_base, float* __restrict__ sorted,
-                          const unsigned char* __restrict__ poolcore, unsigned char* __restrict__ sorted_core) {
+                          unsigned* __restrict__ cursor, long long cursor_base, float* __restrict__ sorted) {
     const OvGrid g = gr[find_entry(gr, ngr, blockIdx.x)];
     const int i0 = (int)(blockIdx.x - (unsigned)g.blk0) * OVI_CHUNK, i1 = min(g.n, i0 + OVI_CHUNK);
     for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
@@ -116,58 +113,7 @@ __global__ void k_ov_fill(const double* __restrict__ pool, const OvGrid* __restr
         sorted[(size_t)pos * 3] = x;
         sorted[(size_t)pos * 3 + 1] = y;
         sorted[(size_t)pos * 3 + 2] = z;
-        sorted_core[pos] = g.use_core ? poolcore[g.pt_off + i] : (unsigned char)0;
     }
-}
-
-// ---- exact "absorb" test (sequential and hierarchical merge alike) ------------------------------------------------
-// Component {A, B...} with A an anchor -- a fixed single-cluster cloud whose persisted flags mark points that ARE core
-// -- and A the FIRST member.  If every point b of the other members has a flagged point of A closer than eps, then
-// merge_point_clouds_list returns the plain concatenation: A's cores stay core and connected (cluster C_A, which holds
-// the lowest core index of the concatenation, so it has the smallest cluster key); b is either core -- then it is
-// eps-connected to an A core, i.e. in C_A -- or a border point reached by C_A, which wins every contest; nothing is
-// left for a second cluster or for noise, and keep-largest keeps everything.  The DBSCAN batch of such a component is
-// skipped.  The test runs on the float32 index of A with a margin (eps - 1e-3) that covers the float32 rounding, so a
-// pass is a proof; a point that fails it merely sends the component down the ordinary path.
-__global__ void k_absorb(const double* __restrict__ pool, const OvGrid* __restrict__ gr, const OvTask* __restrict__ tasks, int ntasks,
-                         const unsigned* __restrict__ cells, const float* __restrict__ sorted,
-                         const unsigned char* __restrict__ sorted_core, float thr2, float reach, unsigned* __restrict__ fails) {
-    const int ti = find_entry(tasks, ntasks, blockIdx.x);
-    const OvTask t = tasks[ti];
-    const OvGrid X = gr[t.x], Y = gr[t.y];        // X = the absorbed cloud B, Y = the anchor A
-    unsigned local = 0;
-    const int b0 = (int)(blockIdx.x - (unsigned)t.blk0) * OV_CHUNK;
-    const int b1 = b0 + OV_CHUNK < X.n ? b0 + OV_CHUNK : X.n;
-    const float* sp = sorted + (size_t)Y.ix_pt * 3;
-    const unsigned char* sc = sorted_core + Y.ix_pt;
-    for (int i = b0 + (int)threadIdx.x; i < b1; i += blockDim.x) {
-        const double* p = pool + (size_t)(X.pt_off + i) * 3;
-        const float x = (float)p[0], y = (float)p[1], z = (float)p[2];
-        bool hit = false;
-        if (!(x < Y.mnx - reach || x > Y.mxx + reach || y < Y.mny - reach || y > Y.mxy + reach || z < Y.mnz - reach || z > Y.mxz + reach)) {
-            const int cx = (int)floor(((double)x - Y.ox) / Y.cell), cy = (int)floor(((double)y - Y.oy) / Y.cell),
-                      cz = (int)floor(((double)z - Y.oz) / Y.cell);
-            const int z0 = max(cz - 2, 0), z1 = min(cz + 2, Y.gz - 1);
-            // own column first, then the other 24 (eps < 2 cells)
-            for (int q = 0; q < 25 && !hit && z0 <= z1; ++q) {
-                const int o = q == 0 ? 12 : (q <= 12 ? q - 1 : q);
-                const int jx = cx + o / 5 - 2, jy = cy + o % 5 - 2;
-                if (jx < 0 || jx >= Y.gx || jy < 0 || jy >= Y.gy) continue;
-                const long long c0 = Y.ix_cell + ((long long)jx * Y.gy + jy) * Y.gz;
-                for (unsigned k = cells[c0 + z0]; k < cells[c0 + z1 + 1]; ++k) {
-                    if (!sc[k]) continue;
-                    const float dx = x - sp[(size_t)k * 3], dy = y - sp[(size_t)k * 3 + 1], dz = z - sp[(size_t)k * 3 + 2];
-                    if (dx * dx + dy * dy + dz * dz < thr2) {
-                        hit = true;
-                        break;
-                    }
-                }
-            }
-        }
-        local += hit ? 0u : 1u;
-    }
-    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(&fails[ti], local);
 }
 
 // one z-run of Y's cell-sorted points: is any of them closer than r to (x, y, z)?  (float32 arithmetic of
@@ -235,6 +181,7 @@ __device__ __forceinline__ bool ov_hit(const OvGrid& Y, const unsigned* __restri
     return false;
 }
 
+#define OV_CHUNK 512
 // find_overlapping_ratio_faiss (graph_utils.py:645-662): a point of X overlaps when its exact float32
 // nearest neighbour in Y is closer than r^2, i.e. when SOME y has (dx*dx + dy*dy) + dz*dz < r2 in float32.
 // dep_counts (optional): the pair's first direction (the SMALLER cloud against the larger) has already been counted;
@@ -345,14 +292,13 @@ struct Merger {
     DevBuf<unsigned> ix_cells;      // concatenated cellstart arrays (absolute positions into ix_pts)
     long long ix_cells_used = 0;
     DevBuf<float> ix_pts;           // concatenated cell-sorted float32 points
-    DevBuf<unsigned char> ix_core;  // ... and, for anchors, their persisted core flags in the same order
     long long ix_pts_used = 0;      // points
     DevBuf<double> concat;
     DevBuf<unsigned char> concat_core;
     DevBuf<OvGrid> d_grids;
     DevBuf<OvTask> d_tasks;
     DevBuf<unsigned> d_counts, d_cursor;
-    DevBuf<CatSeg> d_cat, d_cat2;
+    DevBuf<CatSeg> d_cat;
     PinnedBuf<unsigned> h_counts;
     SpinWait spin;
     unsigned long long next_uid = 1;
@@ -365,7 +311,6 @@ struct Merger {
     int minpts = 10;
     double iou_thresh = 0.05;
     double tphase[6] = {0, 0, 0, 0, 0, 0};   // host wall time per phase (HMSG_DEBUG_TIMING)
-    long long n_absorbed = 0, n_batched = 0; // components that took the absorb shortcut / went through the DBSCAN batch
 
     template <typename T>
     void grow(DevBuf<T>& b, size_t used_elems, size_t need_elems) {
@@ -379,8 +324,7 @@ struct Merger {
 
     OvGrid grid_of(const Cloud& c) const {
         OvGrid g;
-        g.blk0 = 0;
-        g.use_core = (c.anchor && use_anchor) ? 1 : 0;
+        g.blk0 = g.pad0 = 0;
         g.pt_off = c.off;
         g.ix_cell = c.ix_cell;
         g.ix_pt = c.ix_pt;
@@ -420,7 +364,6 @@ struct Merger {
                      "merge index exceeds 2^32 entries");
         grow(ix_cells, (size_t)ix_cells_used, (size_t)(ix_cells_used + ncell_new));
         grow(ix_pts, (size_t)ix_pts_used * 3, (size_t)(ix_pts_used + npts_new) * 3);
-        grow(ix_core, (size_t)ix_pts_used, (size_t)(ix_pts_used + npts_new));
         std::vector<OvGrid> g(todo.size());
         unsigned nblk = 0;
         for (size_t k = 0; k < todo.size(); ++k) {
@@ -439,8 +382,7 @@ struct Merger {
         // (cell starts stay relative to this batch's first sorted point: Cloud::ix_pt)
         hmsg_scan_u32(d_cursor.p, cells, (size_t)ncell_new, s, ops.scan_tmp, nullptr);
         hipLaunchKernelGGL(k_ov_fill, dim3(nblk), dim3(256), 0, s, (const double*)pool.p, (const OvGrid*)d_grids.p, (int)g.size(),
-                           (const unsigned*)ix_cells.p, d_cursor.p, ix_cells_used, ix_pts.p, (const unsigned char*)poolcore.p,
-                           ix_core.p);
+                           (const unsigned*)ix_cells.p, d_cursor.p, ix_cells_used, ix_pts.p);
         HMSG_CHECK_LAUNCH();
         for (int i : todo) L[i].has_index = true;
         ix_cells_used += ncell_new;
@@ -450,12 +392,9 @@ struct Merger {
     // ---- overlap ratios for a list of (i, j) pairs of L.  `decide_th` >= 0 (sequential merge): only `ratio > th`
     // is needed downstream, so the pair's smaller cloud is counted first and the scan of the larger one is skipped on
     // the device when the first ratio already exceeds the threshold (its entry then reports the first ratio).
-    // `absorb` (optional): per pair the number of points of the pair's non-anchor member that have NO flagged anchor
-    // point within eps (k_absorb); -1 where the pair is not (anchor first, non-anchor second).
     void overlap_ratios(const std::vector<Cloud>& L, const std::vector<std::pair<int, int>>& pairs, std::vector<double>& ratio,
-                        double decide_th, std::vector<long long>* absorb = nullptr) {
+                        double decide_th) {
         ratio.assign(pairs.size(), 0.0);
-        if (absorb) absorb->assign(pairs.size(), -1);
         if (pairs.empty()) return;
         const size_t P = pairs.size();
         // compact table of the clouds involved
@@ -476,17 +415,6 @@ struct Merger {
             nblk1 += cdiv((size_t)L[a].n, OV_CHUNK);
             nblk2 += cdiv((size_t)L[b].n, OV_CHUNK);
         }
-        // absorb tasks: pairs (anchor with the lower index, non-anchor)
-        std::vector<size_t> ab_pair;
-        unsigned nblk3 = 0;
-        if (absorb && use_anchor)
-            for (size_t k = 0; k < P; ++k) {
-                const int a = pairs[k].first, b = pairs[k].second;     // a < b
-                if (!L[a].anchor || L[b].anchor) continue;
-                ab_pair.push_back(k);
-                tasks.push_back(OvTask{slot[b], slot[a], 0, (int)nblk3});
-                nblk3 += cdiv((size_t)L[b].n, OV_CHUNK);
-            }
         d_grids.ensure(g.size());
         d_tasks.ensure(tasks.size());
         d_counts.ensure(tasks.size());
@@ -508,12 +436,6 @@ struct Merger {
                                    decide_th);
             }
         }
-        if (nblk3) {
-            const float reach = (float)eps, thr = (float)(eps - 1e-3);
-            hipLaunchKernelGGL(k_absorb, dim3(nblk3), dim3(256), 0, s, (const double*)pool.p, (const OvGrid*)d_grids.p,
-                               (const OvTask*)(d_tasks.p + 2 * P), (int)ab_pair.size(), (const unsigned*)ix_cells.p,
-                               (const float*)ix_pts.p, (const unsigned char*)ix_core.p, thr * thr, reach, d_counts.p + 2 * P);
-        }
         HMSG_CHECK_LAUNCH();
         h_counts.ensure(tasks.size());
         unsigned* hc = h_counts.p;
@@ -527,7 +449,6 @@ struct Merger {
             if (!(decide_th >= 0.0 && (double)hc[k] / (double)na > decide_th)) ov_work += 12.0 * nb;
         }
         if (h->prof.enabled && prof_idx < h->prof.ev.size()) h->prof.ev[prof_idx].work = ov_work;
-        for (size_t q = 0; q < ab_pair.size(); ++q) (*absorb)[ab_pair[q]] = (long long)hc[2 * P + q];
     }
 
     // ---- merge_3d_masks (graph_utils.py:918-956)
@@ -598,14 +519,9 @@ struct Merger {
             }
         }
         std::vector<double> ratio;
-        std::vector<long long> absorb;
         lap(1);
-        overlap_ratios(L, pairs, ratio, use_cache ? -1.0 : th, &absorb);
+        overlap_ratios(L, pairs, ratio, use_cache ? -1.0 : th);
         lap(2);
-        // absorbable[j]: cloud j passed the absorb test against anchor `absorbed_by[j]`
-        std::vector<int> absorbed_by(n, -1);
-        for (size_t k = 0; k < pairs.size(); ++k)
-            if (absorb[k] == 0 && absorbed_by[pairs[k].second] < 0) absorbed_by[pairs[k].second] = pairs[k].first;
         // 2. components of `overlap > th` (scipy connected_components labels by lowest member index)
         std::vector<int> parent(n);
         std::iota(parent.begin(), parent.end(), 0);
@@ -642,30 +558,14 @@ struct Merger {
             for (int i = 0; i < n; ++i) comps.mem[cur[cid[i]]++] = i;
         }
         // 3. merge_point_clouds_list per component: concat in index order + keep-largest DBSCAN
-        std::vector<int> seg_of_comp(comps.size(), -1);      // -1 untouched, -2 absorbed (plain concatenation)
+        std::vector<int> seg_of_comp(comps.size(), -1);
         std::vector<SegDesc> segs;
-        std::vector<CatSeg> cat, cat_direct;
-        long long cat_total = 0, direct_total = 0;
-        unsigned cat_blocks = 0, direct_blocks = 0;
+        std::vector<CatSeg> cat;
+        long long cat_total = 0;
+        unsigned cat_blocks = 0;
         for (size_t c = 0; c < comps.size(); ++c) {
             const auto& mem = comps[c];
             if (mem.size() == 1 && (L[mem[0]].fixed || L[mem[0]].n == 0)) continue;   // exact shortcut (1)
-            if (use_anchor && mem.size() > 1 && L[mem[0]].anchor) {                  // exact shortcut (5): see k_absorb
-                bool all = true;
-                for (size_t q = 1; q < mem.size() && all; ++q) all = L[mem[q]].n == 0 || absorbed_by[mem[q]] == mem[0];
-                if (all) {
-                    for (int i : mem) {
-                        if (L[i].n == 0) continue;
-                        cat_direct.push_back(CatSeg{L[i].off, pool_used + direct_total, L[i].n, i == mem[0] ? 1 : 0, (int)direct_blocks, 0});
-                        direct_blocks += cdiv((size_t)L[i].n, CAT_CHUNK);
-                        direct_total += L[i].n;
-                    }
-                    seg_of_comp[c] = -2;
-                    ++n_absorbed;
-                    continue;
-                }
-            }
-            ++n_batched;
             SegDesc sd;
             sd.pt_base = cat_total;
             sd.n = 0;
@@ -690,19 +590,6 @@ struct Merger {
             segs.push_back(sd);
         }
         std::vector<DbscanResult> res;
-        const long long direct_base = pool_used;
-        if (direct_total > 0) {
-            // the absorbed components: members copied straight to the end of the pool (the anchor with its flags, the
-            // others with flag 0 = "not known to be core", which later batches simply re-count)
-            grow(pool, (size_t)pool_used * 3, (size_t)(pool_used + direct_total + cat_total) * 3);
-            grow(poolcore, (size_t)pool_used, (size_t)(pool_used + direct_total + cat_total));
-            d_cat2.ensure(cat_direct.size());
-            HIP_TRY(hipMemcpyAsync(d_cat2.p, cat_direct.data(), cat_direct.size() * sizeof(CatSeg), hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(k_concat, dim3(direct_blocks), dim3(256), 0, s, (const double*)pool.p, (const CatSeg*)d_cat2.p,
-                               (int)cat_direct.size(), pool.p, (const unsigned char*)poolcore.p, poolcore.p);
-            HMSG_CHECK_LAUNCH();
-            pool_used += direct_total;
-        }
         long long out_base = pool_used;
         if (!segs.empty() && cat_total > 0) {
             concat.ensure((size_t)cat_total * 3);
@@ -751,32 +638,10 @@ struct Merger {
         // 4. new list in component order
         std::vector<Cloud> out;
         out.reserve(comps.size());
-        long long cursor = out_base, dcursor = direct_base;
+        long long cursor = out_base;
         for (size_t c = 0; c < comps.size(); ++c) {
             const auto& mem = comps[c];
             int sg = seg_of_comp[c];
-            if (sg == -2) {                     // absorbed: the concatenation, one cluster, every point kept
-                Cloud k;
-                k.off = dcursor;
-                k.n = 0;
-                bool any = false;
-                for (int i : mem) {
-                    if (L[i].n == 0) continue;
-                    k.n += L[i].n;
-                    for (int a = 0; a < 3; ++a) {
-                        k.mn[a] = any ? std::min(k.mn[a], L[i].mn[a]) : L[i].mn[a];
-                        k.mx[a] = any ? std::max(k.mx[a], L[i].mx[a]) : L[i].mx[a];
-                    }
-                    any = true;
-                }
-                dcursor += k.n;
-                k.fixed = true;
-                k.anchor = true;
-                k.fresh = true;
-                k.uid = next_uid++;
-                out.push_back(k);
-                continue;
-            }
             if (sg < 0) {                       // untouched singleton
                 Cloud k = L[mem[0]];
                 k.fresh = false;
@@ -971,10 +836,9 @@ void hmsg_merge(hmsg_ctx* h) {
         fprintf(stderr, "[hmsg merge] index %.1f  pairs(host) %.1f  overlap %.1f  components+concat %.1f  dbscan %.1f  bookkeeping %.1f ms\n",
                 m.tphase[0], m.tphase[1], m.tphase[2], m.tphase[3], m.tphase[4], m.tphase[5]);
     if (getenv("HMSG_DEBUG_TIMING") && m.ops.stat_calls > 0)
-        fprintf(stderr, "[hmsg merge] dbscan batches %.0f: mean points %.0f  grid cells %.0f  core cells %.0f  active cells %.0f; "
-                        "components absorbed %lld, batched %lld\n",
+        fprintf(stderr, "[hmsg merge] dbscan batches %.0f: mean points %.0f  grid cells %.0f  core cells %.0f  active cells %.0f\n",
                 m.ops.stat_calls, m.ops.stat_points / m.ops.stat_calls, m.ops.stat_cells / m.ops.stat_calls,
-                m.ops.stat_core_cells / m.ops.stat_calls, m.ops.stat_active_cells / m.ops.stat_calls, m.n_absorbed, m.n_batched);
+                m.ops.stat_core_cells / m.ops.stat_calls, m.ops.stat_active_cells / m.ops.stat_calls);
     h->merged = true;
 }
 
