@@ -34,6 +34,12 @@ class HmsgNode(C.Structure):          # include/hmsg.h: hmsg_node
                 ("label", C.c_int32), ("n_points", C.c_int64)]
 
 
+class HmsgDepthParams(C.Structure):    # include/hmsg.h: hmsg_depth_params
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("image_scale", C.c_int32), ("fx", C.c_double),
+                ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("voxel_size", C.c_double),
+                ("depth_factor", C.c_double)]
+
+
 class HmsgError(RuntimeError):
     pass
 
@@ -87,6 +93,7 @@ _SIGS = {
     "hmsg_get_nodes": (C.c_int, [_P, _P, _P]),
     "hmsg_index_from_nodes": (C.c_int, [_P, C.POINTER(_P)]),
     "hmsg_points_min_dist_2d": (C.c_int, [C.c_int32, C.c_int32, _P, _P, C.c_int64, _P, _P]),
+    "hmsg_lidar_depth": (C.c_int, [C.c_int32, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "hmsg_index_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _P, C.c_int32, _P, C.POINTER(_P)]),
     "hmsg_index_destroy": (None, [_P]),
     "hmsg_index_last_error": (C.c_char_p, [_P]),
@@ -393,6 +400,36 @@ def points_min_dist_2d(sets, queries, device_id=0, lib_: "HmsgLib | None" = None
     if rc != 0:
         raise HmsgError(f"hmsg_points_min_dist_2d failed ({rc})")
     return out
+
+
+def lidar_depth(clouds, poses, intrinsics, width, height, voxel_size=0.02, depth_factor=1000.0, image_scale=1,
+                want_state=False, device_id=0, lib_: "HmsgLib | None" = None):
+    """LiDAR local maps -> occlusion-aware uint16 depth images on the device (include/hmsg.h: hmsg_lidar_depth; the
+    reference's generate_depth.py process_frame per frame).  `clouds`: one [n_f, 3] float64 array per frame; `poses`:
+    [F, 3, 4] world -> camera [R | t], or None when the clouds already hold (u, v, z) rows; `intrinsics`: 3x3 K.
+    Returns (depth [F, H, W] uint16, stats [F, 4] int64, state per input point or None, device milliseconds)."""
+    L = lib_ or lib()
+    F = len(clouds)
+    off = np.zeros(F + 1, np.int64)
+    off[1:] = np.cumsum([len(c) for c in clouds])
+    pts = np.ascontiguousarray(np.concatenate([np.asarray(c, np.float64).reshape(-1, 3) for c in clouds])
+                               if off[-1] else np.zeros((1, 3)), dtype=np.float64)
+    K = np.asarray(intrinsics, np.float64)
+    prm = HmsgDepthParams(int(width), int(height), int(image_scale), K[0, 0], K[1, 1], K[0, 2], K[1, 2], float(voxel_size),
+                          float(depth_factor))
+    T = None
+    if poses is not None:
+        P = np.asarray(poses, np.float64).reshape(F, 3, 4)
+        T = np.ascontiguousarray(np.concatenate([P[:, :, :3].reshape(F, 9), P[:, :, 3]], axis=1))
+    depth = np.zeros((F, int(height), int(width)), np.uint16)
+    stats = np.zeros((F, 4), np.int64)
+    state = np.zeros(max(int(off[-1]), 1), np.uint8) if want_state else None
+    ms = C.c_double(0.0)
+    rc = L.c.hmsg_lidar_depth(device_id, C.byref(prm), F, _ptr(pts), _ptr(off), _ptr(T) if T is not None else None,
+                              _ptr(depth), _ptr(state) if state is not None else None, _ptr(stats), C.byref(ms))
+    if rc != 0:
+        raise HmsgError(f"hmsg_lidar_depth failed ({rc})")
+    return depth, stats, (state[:int(off[-1])] if state is not None else None), ms.value
 
 
 class NodeIndex:

@@ -223,6 +223,34 @@ int hmsg_get_nodes(const hmsg_t* h, hmsg_node* nodes, float* embeddings);
 int hmsg_points_min_dist_2d(int32_t device_id, int32_t n_sets, const int64_t* set_off, const double* pts_xy, int64_t n_q,
                             const double* q_xy, double* out);
 
+/* ---- N3 (the step right before the path): LiDAR keyframe clouds -> occlusion-aware uint16 depth images.  Replaces
+ * nav_agent/humble_localization_nav2/lio_mapping_loc/scripts/generate_depth.py process_frame (:612-659) per frame:
+ * voxel_down_sample (:626-629), project_points (:366-396), whether_occluded_deoccfast (:125-205: z-buffer at rounded
+ * pixels against a float32 buffer in point order, fb / z, cv2.dilate(rect max(1, 4 / image_scale), iterations 4),
+ * np.int16, cv2.filterSpeckles(0, 1000, 1), |fb / z - disparity| >= 3) and generate_occ_depth (:399-474: last point
+ * in input order wins its truncated pixel, uint16(float32(z * depth_factor))).  Host pointers.
+ *   points     f64 [cloud_off[n_frames]][3]: frame f owns rows cloud_off[f] .. cloud_off[f+1]
+ *   poses      f64 [n_frames][12]: world -> camera rotation (row-major 3x3) then translation; NULL: `points` are
+ *              already (u, v, z) rows = generate_occ_depth's own inputs (points_image[0], points_image[1],
+ *              points_camera[2]) and no projection / culling is done
+ *   depth_out  u16 [n_frames][height][width]
+ *   state_out  optional u8 per input point: 0 visible, 1 occluded, 2 culled by the projection; only without
+ *              down-sampling (voxel_size <= 0), HMSG_ERR_INVALID otherwise
+ *   stats_out  optional i64 [n_frames][4]: points after down-sampling, projected into the image, visible, depth
+ *              pixels written
+ *   device_ms  optional: HIP-event time of the device work (transfers excluded)
+ * Down-sampled voxels are visited in ascending (ix, iy, iz) order (Open3D's order is its hash map's); a cloud whose
+ * bounding box holds more than 2^37 voxels is HMSG_ERR_UNSUPPORTED. */
+typedef struct {
+    int32_t width, height, image_scale;
+    double fx, fy, cx, cy;
+    double voxel_size;      /* <= 0: no down-sampling */
+    double depth_factor;    /* 1000 in the reference */
+} hmsg_depth_params;
+int hmsg_lidar_depth(int32_t device_id, const hmsg_depth_params* prm, int32_t n_frames, const double* points,
+                     const int64_t* cloud_off, const double* poses, uint16_t* depth_out, uint8_t* state_out,
+                     int64_t* stats_out, double* device_ms);
+
 /* ---- A12: retrieval over a node table (graph.py:3056-3162 query_hmsg_object and the GEMV of
  * query_hmsg_room / query_floor).  A table is N node embeddings (f64, as after load_hmsg_graph:
  * object.py:88-89, or f32 right after build) with a parent (room) id per node. */

@@ -159,3 +159,39 @@ def make_faiss():
     f = types.ModuleType("faiss")
     f.IndexFlatL2 = IndexFlatL2
     return f
+
+
+# ---- OpenCV stand-in for nav_agent/.../lio_mapping_loc/scripts/generate_depth.py (row N3) ---------------------------
+def make_cv2(captured):
+    """The calls generate_depth.py:125-205, 399-474 makes.  dilate / filterSpeckles are the restatements of
+    oracle/lidar_depth_oracle.py (OpenCV is absent here: that part stays unpinned); imwrite stores the array in
+    `captured[path]`; the overlay drawing calls are no-ops."""
+    import types
+
+    import numpy as np
+
+    from oracle import lidar_depth_oracle as LO
+    m = types.ModuleType("cv2")
+    m.MORPH_RECT = 0
+    m.COLORMAP_JET = 2
+    m.getStructuringElement = lambda shape, ksize: np.ones((ksize[1], ksize[0]), np.uint8)
+
+    def dilate(src, element, iterations=1):
+        assert element.shape[0] == element.shape[1] and element.all()
+        return LO.dilate_rect(src, element.shape[0], iterations)
+
+    def filterSpeckles(img, newVal, maxSpeckleSize, maxDiff):
+        LO.filter_speckles(img, newVal, maxSpeckleSize, maxDiff)
+        return img, None
+
+    def imwrite(path, arr):
+        captured[path] = np.array(arr)
+        return True
+
+    m.dilate = dilate
+    m.filterSpeckles = filterSpeckles
+    m.imwrite = imwrite
+    m.circle = lambda *a, **k: None
+    m.applyColorMap = lambda gray, cmap: np.zeros(gray.shape + (3,), np.uint8)
+    m.imread = lambda *a, **k: None
+    return m
