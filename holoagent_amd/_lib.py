@@ -94,6 +94,7 @@ _SIGS = {
     "hmsg_index_from_nodes": (C.c_int, [_P, C.POINTER(_P)]),
     "hmsg_points_min_dist_2d": (C.c_int, [C.c_int32, C.c_int32, _P, _P, C.c_int64, _P, _P]),
     "hmsg_lidar_depth": (C.c_int, [C.c_int32, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "hmsg_crop_resize_batch": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, C.c_double, C.c_int32, _P, _P, _P]),
     "hmsg_index_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _P, C.c_int32, _P, C.POINTER(_P)]),
     "hmsg_index_destroy": (None, [_P]),
     "hmsg_index_last_error": (C.c_char_p, [_P]),
@@ -430,6 +431,26 @@ def lidar_depth(clouds, poses, intrinsics, width, height, voxel_size=0.02, depth
     if rc != 0:
         raise HmsgError(f"hmsg_lidar_depth failed ({rc})")
     return depth, stats, (state[:int(off[-1])] if state is not None else None), ms.value
+
+
+def crop_all_bounding_boxs(image, masks, bbox_margin=0, size=512, plain=True, masked=True, device_id=0,
+                           lib_: "HmsgLib | None" = None):
+    """Both crop sets of one frame on the device (include/hmsg.h: hmsg_crop_resize_batch; utils/sam_utils.py:119-147 as
+    called by sam_clip_feats_extractor.py:148-151).  `masks`: SAM records (dicts with "segmentation" and "bbox" XYWH).
+    Returns (plain [M, S, S, 3] uint8 or None, masked [M, S, S, 3] uint8 or None)."""
+    L = lib_ or lib()
+    image = np.ascontiguousarray(image, dtype=np.uint8)
+    H, W = image.shape[:2]
+    M = len(masks)
+    bbox = np.ascontiguousarray([m["bbox"] for m in masks], dtype=np.float64).reshape(M, 4)
+    segs = np.ascontiguousarray(np.stack([m["segmentation"] for m in masks]).astype(np.uint8)) if (masked and M) else None
+    o_plain = np.zeros((M, size, size, 3), np.uint8) if plain else None
+    o_masked = np.zeros((M, size, size, 3), np.uint8) if masked else None
+    rc = L.c.hmsg_crop_resize_batch(device_id, H, W, _ptr(image), M, _ptr(segs), _ptr(bbox), float(bbox_margin), int(size),
+                                    _ptr(o_plain), _ptr(o_masked), None)
+    if rc != 0:
+        raise HmsgError(f"hmsg_crop_resize_batch failed ({rc})")
+    return o_plain, o_masked
 
 
 class NodeIndex:

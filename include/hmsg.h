@@ -251,6 +251,18 @@ int hmsg_lidar_depth(int32_t device_id, const hmsg_depth_params* prm, int32_t n_
                      const int64_t* cloud_off, const double* poses, uint16_t* depth_out, uint8_t* state_out,
                      int64_t* stats_out, double* device_ms);
 
+/* ---- N4 (encoder side of the path): crop_all_bounding_boxs (memory/hmsg/utils/sam_utils.py:119-147) for BOTH variants
+ * the extractor asks for per frame (perception/models/sam_clip_feats_extractor.py:148-151) in one launch:
+ *   out_plain[m]  = cv2.resize(crop_bbox(image, bbox[m], bbox_margin), (S, S))      (sam_utils.py:58-81, 167-183)
+ *   out_masked[m] = cv2.resize(crop_image(image, mask m), (S, S))                    (:150-164, no margin)
+ * image u8 [H][W][3]; segs u8 [M][H][W] (non-zero = inside; needed for out_masked); bbox f64 [M][4] XYWH (host);
+ * out_* u8 [M][S][S][3] (either may be NULL); S = out_size, a multiple of 4 (512 in the reference).  image / segs /
+ * out_* may be host or device pointers.  cv2.resize = INTER_LINEAR, OpenCV's 8-bit fixed-point arithmetic.  A mask whose
+ * crop is empty is HMSG_ERR_INVALID (cv2.resize raises on it).  device_ms (optional): HIP-event time of the launch. */
+int hmsg_crop_resize_batch(int32_t device_id, int32_t H, int32_t W, const uint8_t* image, int32_t M, const uint8_t* segs,
+                           const double* bbox, double bbox_margin, int32_t out_size, uint8_t* out_plain, uint8_t* out_masked,
+                           double* device_ms);
+
 /* ---- A12: retrieval over a node table (graph.py:3056-3162 query_hmsg_object and the GEMV of
  * query_hmsg_room / query_floor).  A table is N node embeddings (f64, as after load_hmsg_graph:
  * object.py:88-89, or f32 right after build) with a parent (room) id per node. */
