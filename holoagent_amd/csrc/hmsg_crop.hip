@@ -31,58 +31,80 @@ __device__ __forceinline__ int coef_short(float w) {   // saturate_cast<short>(w
     return (int)fminf(fmaxf(v, -32768.0f), 32767.0f);
 }
 
+#define CROP_ROWS 16      // output rows per workgroup: the column coefficients of a thread's 4 pixels are reused for all of them
+
 __global__ void __launch_bounds__(256) k_crop_resize(const unsigned char* __restrict__ image, const unsigned char* __restrict__ segs,
                                                      int H, int W, const CropRect* __restrict__ rects, int S,
                                                      unsigned char* __restrict__ out_plain, unsigned char* __restrict__ out_masked) {
     const CropRect r = rects[blockIdx.y];
-    const int quads = S / 4;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= quads * S) return;
-    const int dy = t / quads, dx0 = (t % quads) * 4;
-    const double scale_x = __ddiv_rn(1.0, __ddiv_rn((double)S, (double)r.w)), scale_y = __ddiv_rn(1.0, __ddiv_rn((double)S, (double)r.h));
-    int sy;
-    float fy;
-    lin_coef(dy, scale_y, sy, fy);
-    const int b0 = coef_short(__fsub_rn(1.0f, fy)), b1 = coef_short(fy);
-    const int y0 = r.y0 + min(max(sy, 0), r.h - 1), y1 = r.y0 + min(max(sy + 1, 0), r.h - 1);
-    const unsigned char* seg = r.mask >= 0 ? segs + (size_t)r.mask * H * W : nullptr;
-    unsigned px[3] = {0u, 0u, 0u};          // 12 output bytes
-    for (int j = 0; j < 4; ++j) {
-        int sx;
-        float fx;
-        lin_coef(dx0 + j, scale_x, sx, fx);
-        if (sx < 0) {
-            sx = 0;
-            fx = 0.0f;
-        }
-        if (sx >= r.w - 1) {
-            sx = r.w - 1;
-            fx = 0.0f;
-        }
-        const int a0 = coef_short(__fsub_rn(1.0f, fx)), a1 = coef_short(fx);
-        const int xa = r.x0 + sx, xb = r.x0 + min(sx + 1, r.w - 1);
-        const size_t p00 = (size_t)y0 * W + xa, p01 = (size_t)y0 * W + xb, p10 = (size_t)y1 * W + xa, p11 = (size_t)y1 * W + xb;
-        int m00 = 1, m01 = 1, m10 = 1, m11 = 1;
-        if (seg) {
-            m00 = seg[p00] != 0;
-            m01 = seg[p01] != 0;
-            m10 = seg[p10] != 0;
-            m11 = seg[p11] != 0;
-        }
-        for (int c = 0; c < 3; ++c) {
-            const int r0 = (m00 ? image[p00 * 3 + c] : 0) * a0 + (m01 ? image[p01 * 3 + c] : 0) * a1;
-            const int r1 = (m10 ? image[p10 * 3 + c] : 0) * a0 + (m11 ? image[p11 * 3 + c] : 0) * a1;
-            int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-            v = min(max(v, 0), 255);
-            const int byte = j * 3 + c;
-            px[byte >> 2] |= (unsigned)v << ((byte & 3) * 8);
-        }
+    const int quads = S / 4, row0 = blockIdx.x * CROP_ROWS;
+    __shared__ int s_y0[CROP_ROWS], s_y1[CROP_ROWS], s_b0[CROP_ROWS], s_b1[CROP_ROWS];
+    if (threadIdx.x < CROP_ROWS && row0 + (int)threadIdx.x < S) {
+        const double scale_y = __ddiv_rn(1.0, __ddiv_rn((double)S, (double)r.h));
+        int sy;
+        float fy;
+        lin_coef(row0 + threadIdx.x, scale_y, sy, fy);
+        s_b0[threadIdx.x] = coef_short(__fsub_rn(1.0f, fy));
+        s_b1[threadIdx.x] = coef_short(fy);
+        s_y0[threadIdx.x] = r.y0 + min(max(sy, 0), r.h - 1);       // rows are clamped one by one, weights untouched
+        s_y1[threadIdx.x] = r.y0 + min(max(sy + 1, 0), r.h - 1);
     }
-    unsigned char* dst = (r.variant ? out_masked : out_plain) + ((size_t)r.out * S + dy) * S * 3 + (size_t)dx0 * 3;
-    unsigned* d32 = (unsigned*)dst;         // (S multiple of 4 -> 12-byte groups start on 4-byte boundaries)
-    d32[0] = px[0];
-    d32[1] = px[1];
-    d32[2] = px[2];
+    __syncthreads();
+    const double scale_x = __ddiv_rn(1.0, __ddiv_rn((double)S, (double)r.w));
+    const unsigned char* seg = r.mask >= 0 ? segs + (size_t)r.mask * H * W : nullptr;
+    unsigned char* out = (r.variant ? out_masked : out_plain) + (size_t)r.out * S * S * 3;
+    const int rows = min(CROP_ROWS, S - row0);
+    int last_q = -1, xa[4], xb[4], a0[4], a1[4];
+    for (int item = threadIdx.x; item < rows * quads; item += 256) {
+        const int rl = item / quads, q = item - rl * quads;
+        if (q != last_q) {
+            last_q = q;
+            for (int j = 0; j < 4; ++j) {
+                int sx;
+                float fx;
+                lin_coef(q * 4 + j, scale_x, sx, fx);
+                if (sx < 0) {
+                    sx = 0;
+                    fx = 0.0f;
+                }
+                if (sx >= r.w - 1) {
+                    sx = r.w - 1;
+                    fx = 0.0f;
+                }
+                a0[j] = coef_short(__fsub_rn(1.0f, fx));
+                a1[j] = coef_short(fx);
+                xa[j] = r.x0 + sx;
+                xb[j] = r.x0 + min(sx + 1, r.w - 1);
+            }
+        }
+        const int b0 = s_b0[rl], b1 = s_b1[rl];
+        const size_t o0 = (size_t)s_y0[rl] * W, o1 = (size_t)s_y1[rl] * W;
+        unsigned px[3] = {0u, 0u, 0u};          // 12 output bytes
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const size_t p00 = o0 + xa[j], p01 = o0 + xb[j], p10 = o1 + xa[j], p11 = o1 + xb[j];
+            bool m00 = true, m01 = true, m10 = true, m11 = true;
+            if (seg) {
+                m00 = seg[p00] != 0;
+                m01 = seg[p01] != 0;
+                m10 = seg[p10] != 0;
+                m11 = seg[p11] != 0;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int r0 = (m00 ? image[p00 * 3 + c] : 0) * a0[j] + (m01 ? image[p01 * 3 + c] : 0) * a1[j];
+                const int r1 = (m10 ? image[p10 * 3 + c] : 0) * a0[j] + (m11 ? image[p11 * 3 + c] : 0) * a1[j];
+                int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+                v = min(max(v, 0), 255);
+                const int byte = j * 3 + c;
+                px[byte >> 2] |= (unsigned)v << ((byte & 3) * 8);
+            }
+        }
+        unsigned* d32 = (unsigned*)(out + ((size_t)(row0 + rl) * S + (size_t)q * 4) * 3);   // (12-byte groups: 4-byte aligned)
+        d32[0] = px[0];
+        d32[1] = px[1];
+        d32[2] = px[2];
+    }
 }
 
 bool crop_is_device_ptr(const void* p) {
@@ -181,7 +203,7 @@ extern "C" int hmsg_crop_resize_batch(int32_t device_id, int32_t H, int32_t W, c
             d_rects.alloc(rects.size());
             HIP_TRY(hipMemcpyAsync(d_rects.p, rects.data(), rects.size() * sizeof(CropRect), hipMemcpyHostToDevice, s));
             HIP_TRY(hipEventRecord(ev0, s));
-            hipLaunchKernelGGL(k_crop_resize, dim3(cdiv(S * S / 4, 256), (unsigned)rects.size()), dim3(256), 0, s, p_img, p_seg, H, W,
+            hipLaunchKernelGGL(k_crop_resize, dim3(cdiv(S, CROP_ROWS), (unsigned)rects.size()), dim3(256), 0, s, p_img, p_seg, H, W,
                                (const CropRect*)d_rects.p, out_size, p_plain, p_masked);
             HMSG_CHECK_LAUNCH();
             HIP_TRY(hipEventRecord(ev1, s));

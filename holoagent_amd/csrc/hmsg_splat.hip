@@ -11,9 +11,10 @@
 //                          are replayed in input order (stable radix sort by pixel, one lane per pixel run)
 //   k_sp_dilate_h / _v     cv2.dilate(rect k, iterations 4) = one max filter over [-4a, 4 (k - 1 - a)], a = k / 2;
 //                          the vertical pass also does the int16 cast and seeds the union-find
-//   k_sp_cc_union / _size / _apply   cv2.filterSpeckles(0, 1000, 1): connected components of the 4-neighbour graph
-//                          "both non-zero and |a - b| <= 1" (symmetric, so independent of scan order), lock-free
-//                          union-find over pixels, components of <= 1000 pixels zeroed
+//   k_sp_cc_init / _union / _size / _apply   cv2.filterSpeckles(0, 1000, 1): connected components of the 4-neighbour
+//                          graph "both non-zero and |a - b| <= 1" (symmetric, so independent of scan order): lock-free
+//                          union-find over pixels seeded with per-wave row runs, only the links that transitivity
+//                          does not already give are united; components of <= 1000 pixels zeroed
 //   k_sp_flags             per point: occluded if the pixel is empty or |fb / z - disparity| >= 3; the visible ones
 //                          race for their TRUNCATED pixel with atomicMax(point index) = numpy's last-writer-wins
 //   k_sp_depth             depth = uint16(float32(z * depth_factor)) of the winner
@@ -136,9 +137,8 @@ __global__ void k_sp_dilate_h(const float* __restrict__ src, float* __restrict__
     for (int q = max(0, x - lo); q <= min(W - 1, x + hi); ++q) m = fmaxf(m, row[q]);
     dst[p] = m;
 }
-// vertical pass + np.int16 cast + union-find seeds
-__global__ void k_sp_dilate_v(const float* __restrict__ src, int W, int H, long long npix, int lo, int hi, short* __restrict__ s16,
-                              int* __restrict__ parent) {
+// vertical pass + np.int16 cast
+__global__ void k_sp_dilate_v(const float* __restrict__ src, int W, int H, long long npix, int lo, int hi, short* __restrict__ s16) {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npix) return;
     const long long hw = (long long)W * H;
@@ -150,7 +150,6 @@ __global__ void k_sp_dilate_v(const float* __restrict__ src, int W, int H, long 
     // float32 -> int16 like the C cast numpy performs (through a wider integer, wrapping)
     const short d = (short)(long long)truncf(m);
     s16[p] = d;
-    parent[p] = d != 0 ? (int)p : -1;
 }
 
 __device__ __forceinline__ int sp_find(int* parent, int x) {
@@ -175,6 +174,23 @@ __device__ __forceinline__ void sp_union(int* parent, int a, int b) {
         if (atomicCAS(&parent[a], a, b) == a) return;
     }
 }
+__device__ __forceinline__ bool sp_linked(int a, int b) { return a != 0 && b != 0 && abs(a - b) <= SP_MAX_DIFF; }
+
+// Seeds: every live pixel starts under the first pixel of its horizontal run INSIDE ITS WAVE (64 consecutive pixels;
+// a run never crosses a row start because "linked to the left" is false at x = 0), so the horizontal links of a flat
+// region cost one union per wave instead of one per pixel.
+__global__ void __launch_bounds__(256) k_sp_cc_init(const short* __restrict__ s16, int W, long long npix, int* __restrict__ parent) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = p < npix;
+    const int d = live ? s16[p] : 0;
+    const bool cl = d != 0 && (p % W) > 0 && sp_linked(d, s16[p - 1]);
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = __ballot(!cl) & ((2ull << lane) - 1ull);      // run starts at or before this lane
+    const int start = below ? 63 - __clzll(below) : 0;
+    if (live) parent[p] = d != 0 ? (int)(p - (lane - start)) : -1;
+}
+// Links: wave-boundary horizontal links, and the vertical links that are not implied by the square to their left
+// ((x-1,y)~(x,y), (x-1,y)~(x-1,y+1) and (x-1,y+1)~(x,y+1) already connect (x,y) with (x,y+1)).
 __global__ void k_sp_cc_union(const short* __restrict__ s16, int W, int H, long long npix, int* __restrict__ parent) {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npix) return;
@@ -182,27 +198,28 @@ __global__ void k_sp_cc_union(const short* __restrict__ s16, int W, int H, long 
     if (d == 0) return;
     const long long inf = p % ((long long)W * H);
     const int x = (int)(inf % W), y = (int)(inf / W);
-    if (x + 1 < W) {
-        const int e = s16[p + 1];
-        if (e != 0 && abs(d - e) <= SP_MAX_DIFF) sp_union(parent, (int)p, (int)p + 1);
-    }
+    const int dl = x > 0 ? s16[p - 1] : 0;
+    const bool cl = sp_linked(d, dl);
+    if (cl && (p & 63) == 0) sp_union(parent, (int)p, (int)p - 1);
     if (y + 1 < H) {
-        const int e = s16[p + W];
-        if (e != 0 && abs(d - e) <= SP_MAX_DIFF) sp_union(parent, (int)p, (int)p + W);
+        const int dd = s16[p + W];
+        if (sp_linked(d, dd)) {
+            const int dld = x > 0 ? s16[p + W - 1] : 0;
+            const bool implied = cl && sp_linked(dl, dld) && sp_linked(dld, dd);
+            if (!implied) sp_union(parent, (int)p, (int)p + W);
+        }
     }
 }
 __global__ void k_sp_cc_size(int* __restrict__ parent, long long npix, unsigned* __restrict__ size) {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npix || parent[p] < 0) return;
-    const int r = sp_find(parent, (int)p);
-    parent[p] = r;
-    atomicAdd(&size[r], 1u);
+    atomicAdd(&size[sp_find(parent, (int)p)], 1u);
 }
-__global__ void k_sp_cc_apply(const int* __restrict__ parent, const unsigned* __restrict__ size, long long npix, short* __restrict__ s16) {
+// (the root is looked up again: a path-halving store of another lane may have moved parent[p] to ANY ancestor)
+__global__ void k_sp_cc_apply(int* __restrict__ parent, const unsigned* __restrict__ size, long long npix, short* __restrict__ s16) {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= npix) return;
-    const int r = parent[p];
-    if (r >= 0 && size[r] <= SP_MAX_SPECKLE) s16[p] = 0;
+    if (p >= npix || parent[p] < 0) return;
+    if (size[sp_find(parent, (int)p)] <= SP_MAX_SPECKLE) s16[p] = 0;
 }
 
 __global__ void __launch_bounds__(256) k_sp_flags(const double* __restrict__ uvz, const long long* __restrict__ off, SpGeom g,
@@ -380,10 +397,11 @@ extern "C" int hmsg_lidar_depth(int32_t device_id, const hmsg_depth_params* prm,
                     HMSG_CHECK_LAUNCH();
                 }
                 hipLaunchKernelGGL(k_sp_dilate_h, dim3(pblk), dim3(256), 0, s, (const float*)d_inv.p, d_tmp.p, W, (long long)F * H, lo, hi);
-                hipLaunchKernelGGL(k_sp_dilate_v, dim3(pblk), dim3(256), 0, s, (const float*)d_tmp.p, W, H, npix, lo, hi, d_s16.p, d_parent.p);
+                hipLaunchKernelGGL(k_sp_dilate_v, dim3(pblk), dim3(256), 0, s, (const float*)d_tmp.p, W, H, npix, lo, hi, d_s16.p);
+                hipLaunchKernelGGL(k_sp_cc_init, dim3(pblk), dim3(256), 0, s, (const short*)d_s16.p, W, npix, d_parent.p);
                 hipLaunchKernelGGL(k_sp_cc_union, dim3(pblk), dim3(256), 0, s, (const short*)d_s16.p, W, H, npix, d_parent.p);
                 hipLaunchKernelGGL(k_sp_cc_size, dim3(pblk), dim3(256), 0, s, d_parent.p, npix, d_size.p);
-                hipLaunchKernelGGL(k_sp_cc_apply, dim3(pblk), dim3(256), 0, s, (const int*)d_parent.p, (const unsigned*)d_size.p, npix, d_s16.p);
+                hipLaunchKernelGGL(k_sp_cc_apply, dim3(pblk), dim3(256), 0, s, d_parent.p, (const unsigned*)d_size.p, npix, d_s16.p);
                 HMSG_CHECK_LAUNCH();
                 if (N > 0) {
                     hipLaunchKernelGGL(k_sp_flags, dim3(cdiv((size_t)N, 256)), dim3(256), 0, s, (const double*)d_uvz.p,

@@ -695,11 +695,27 @@ class Graph:
     def set_label_feats(self, text_feats, classes):
         self._label_feats = (np.asarray(text_feats, np.float32), list(classes))
 
+    def load_label_feats(self, obj_labels=None, label_dir=None):
+        """The vocabulary segment_hmsg_objects names objects with (graph.py:1592-1597 get_label_feats): by name
+        (cfg.pipeline.obj_labels; CSV sets are read from `label_dir` = cfg.pipeline.label_dir, the reference's
+        memory/hmsg/labels) or a list of class names; features come from the 2-template text encoder or the cached
+        text_feats_*.npy next to the CSV."""
+        from .label_feats import get_label_feats
+        obj_labels = obj_labels if obj_labels is not None else _get(self.cfg, "pipeline.obj_labels")
+        label_dir = label_dir if label_dir is not None else _get(self.cfg, "pipeline.label_dir")
+        text_feats, classes = get_label_feats(self.get_text_feats_multiple_templates, obj_labels, label_dir)
+        self.set_label_feats(text_feats, classes)
+        return text_feats, classes
+
     # ------------------------------------------------------------------ A10: graph.py:1582-1736
     def segment_hmsg_objects(self, save_dir=None):
         """graph.py:1582-1736.  With a resident scene the object -> floor / room / label assignment runs behind the C
         ABI (hmsg_build_object_nodes: per-object DBSCAN, find_intersection_share, label GEMM on the device); the
         per-view visibility test (check_object_in_view) needs the dataset's images and stays here."""
+        want = _get(self.cfg, "pipeline.obj_labels")
+        if self._label_feats is None and self.encoders is not None and want is not None and (
+                not isinstance(want, str) or _get(self.cfg, "pipeline.label_dir") is not None):
+            self.load_label_feats()
         text_feats, classes = self._label_feats if self._label_feats is not None else (None, None)
         if self.scene is not None:
             nodes = self.scene.build_object_nodes([f.floor_zero_level for f in self.floors], [f.floor_height for f in self.floors],

@@ -101,7 +101,7 @@ def check_batch_against_oracle(L, W, H, n, frames, vs):
         if vs <= 0 and len(clouds[f]):
             st = state[sum(len(c) for c in clouds[:f]):][:len(clouds[f])]
             assert int((st != 2).sum()) == pi.shape[1] and np.array_equal(st[st != 2] == 1, flags)
-    assert (depth[1] == 0).all() and (depth[0] > 0).sum() > 0.1 * W * H
+    assert (depth[1] == 0).all() and (depth[0] > 0).sum() > 0.05 * W * H
     return ms
 
 
