@@ -40,6 +40,12 @@ class HmsgDepthParams(C.Structure):    # include/hmsg.h: hmsg_depth_params
                 ("depth_factor", C.c_double)]
 
 
+class HmsgObjectRecord(C.Structure):   # include/hmsg.h: hmsg_object_record
+    _fields_ = [("instance", C.c_int32), ("file_stem", C.c_char_p), ("object_id_json", C.c_char_p),
+                ("room_id_json", C.c_char_p), ("name_json", C.c_char_p), ("view_ids_json", C.c_char_p),
+                ("best_view_id_json", C.c_char_p)]
+
+
 class HmsgError(RuntimeError):
     pass
 
@@ -95,6 +101,8 @@ _SIGS = {
     "hmsg_points_min_dist_2d": (C.c_int, [C.c_int32, C.c_int32, _P, _P, C.c_int64, _P, _P]),
     "hmsg_lidar_depth": (C.c_int, [C.c_int32, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "hmsg_crop_resize_batch": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, C.c_double, C.c_int32, _P, _P, _P]),
+    "hmsg_save_objects": (C.c_int, [_P, C.c_char_p, C.c_int64, _P, C.c_int32]),
+    "hmsg_test_format_doubles": (C.c_int64, [_P, C.c_int64, _P, C.c_int64]),
     "hmsg_index_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _P, C.c_int32, _P, C.POINTER(_P)]),
     "hmsg_index_destroy": (None, [_P]),
     "hmsg_index_last_error": (C.c_char_p, [_P]),
@@ -358,6 +366,24 @@ class Scene:
         out = np.array([(r.instance, r.floor, r.room, r.counter, r.label, r.n_points) for r in rec[:n]],
                        dtype=[("instance", "i4"), ("floor", "i4"), ("room", "i4"), ("counter", "i4"), ("label", "i4"), ("n_points", "i8")])
         return (out, emb) if embeddings else out
+
+    def save_objects(self, directory, records, n_threads=0):
+        """Bulk writer of the object level (include/hmsg.h: hmsg_save_objects; Object.save object.py:37-57).  `records`:
+        dicts with instance, object_id, room_id, name, view_ids, best_view_id (JSON-encoded here, numbers and clouds by
+        the library)."""
+        import json
+        n = len(records)
+        arr = (HmsgObjectRecord * max(n, 1))()
+        plain = lambda x: x.item() if isinstance(x, np.generic) else x
+        for a, r in zip(arr, records):
+            a.instance = int(r["instance"])
+            a.file_stem = str(r["object_id"]).encode()
+            a.object_id_json = json.dumps(plain(r["object_id"])).encode()
+            a.room_id_json = json.dumps(plain(r["room_id"])).encode()
+            a.name_json = json.dumps(plain(r["name"])).encode()
+            a.view_ids_json = json.dumps([plain(v) for v in r["view_ids"]]).encode()
+            a.best_view_id_json = json.dumps(plain(r["best_view_id"])).encode()
+        self._ck(self.L.c.hmsg_save_objects(self.h, str(directory).encode(), n, C.cast(arr, _P), int(n_threads)))
 
     def index_from_nodes(self):
         """Resident retrieval index over the node table, gathered on the device."""

@@ -1,0 +1,209 @@
+// Row N2: the object level of the on-disk HMSG format written at speed.
+// Reference: memory/hmsg/graph/object.py:37-57 (Object.save: <object_id>.ply through o3d.io.write_point_cloud and
+// <object_id>.json through json.dump of {object_id, vertices, room_id, name, embedding, view_ids, best_view_id}), driven
+// per node by graph.py:1801-1824 save_hmsg_graph.  A 1000-frame scene has ~15 000 objects; their records hold ~3*10^7
+// numbers that Python turns into text one float at a time.  Here the instance clouds and pooled features are read back
+// from HBM once and a pool of host threads formats and writes the files.
+//
+// The text is byte-for-byte what json.dump produces: keys in the reference's order, ", " / ": " separators, and every
+// number printed like Python's float.__repr__ (shortest digits that round-trip -- std::to_chars gives the same digits --
+// laid out with Python's rule: fixed notation while -4 <= exponent < 16, else d.ddde+XX).  Strings come from the caller
+// already JSON-encoded (it owns the ids, names and view lists); only numbers are produced here.
+#include "hmsg_common.h"
+
+#include <atomic>
+#include <charconv>
+#include <thread>
+
+namespace {
+
+// Python repr(float) into out (at most 25 bytes), returns the end
+char* py_repr(char* out, double v) {
+    if (v != v) {
+        memcpy(out, "NaN", 3);
+        return out + 3;
+    }
+    if (v == __builtin_inf() || v == -__builtin_inf()) {
+        const char* t = v > 0 ? "Infinity" : "-Infinity";
+        const size_t n = strlen(t);
+        memcpy(out, t, n);
+        return out + n;
+    }
+    char buf[40];
+    auto res = std::to_chars(buf, buf + sizeof(buf), v, std::chars_format::scientific);
+    // buf = [-]d[.ddd]e[+-]XX
+    char* p = buf;
+    if (*p == '-') *out++ = *p++;
+    char digits[24];
+    int nd = 0;
+    while (p < res.ptr && *p != 'e') {
+        if (*p != '.') digits[nd++] = *p;
+        ++p;
+    }
+    int e10 = 0;
+    {
+        ++p;                                   // 'e'
+        const bool neg = *p == '-';
+        ++p;
+        while (p < res.ptr) e10 = e10 * 10 + (*p++ - '0');
+        if (neg) e10 = -e10;
+    }
+    const int decpt = e10 + 1;                 // position of the decimal point relative to the digit string
+    if (decpt > -4 && decpt <= 16) {
+        if (decpt <= 0) {
+            *out++ = '0';
+            *out++ = '.';
+            for (int i = 0; i < -decpt; ++i) *out++ = '0';
+            memcpy(out, digits, (size_t)nd);
+            out += nd;
+        } else if (decpt >= nd) {
+            memcpy(out, digits, (size_t)nd);
+            out += nd;
+            for (int i = nd; i < decpt; ++i) *out++ = '0';
+            *out++ = '.';
+            *out++ = '0';
+        } else {
+            memcpy(out, digits, (size_t)decpt);
+            out += decpt;
+            *out++ = '.';
+            memcpy(out, digits + decpt, (size_t)(nd - decpt));
+            out += nd - decpt;
+        }
+    } else {
+        *out++ = digits[0];
+        if (nd > 1) {
+            *out++ = '.';
+            memcpy(out, digits + 1, (size_t)(nd - 1));
+            out += nd - 1;
+        }
+        *out++ = 'e';
+        int e = decpt - 1;
+        *out++ = e < 0 ? '-' : '+';
+        if (e < 0) e = -e;
+        char eb[8];
+        int ne = 0;
+        do {
+            eb[ne++] = (char)('0' + e % 10);
+            e /= 10;
+        } while (e);
+        if (ne < 2) eb[ne++] = '0';
+        while (ne) *out++ = eb[--ne];
+    }
+    return out;
+}
+
+bool write_file(const std::string& path, const char* data, size_t n) {
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    const bool ok = fwrite(data, 1, n, f) == n;
+    return (fclose(f) == 0) && ok;
+}
+
+}  // namespace
+
+extern "C" int hmsg_save_objects(hmsg_t* hc, const char* dir, int64_t n, const hmsg_object_record* recs, int32_t n_threads) {
+    hmsg_ctx* h = hc;
+    if (!h || !dir || n < 0 || (n > 0 && !recs)) return HMSG_ERR_INVALID;
+    try {
+        HMSG_REQUIRE((h->merged || h->tree_partial) && h->pooled, HMSG_ERR_INVALID, "hmsg_save_objects: instances are not merged and pooled");
+        const int64_t NI = (int64_t)h->inst.off.size() - 1;
+        const int D = h->cfg.feat_dim;
+        for (int64_t i = 0; i < n; ++i)
+            HMSG_REQUIRE(recs[i].instance >= 0 && recs[i].instance < NI && recs[i].file_stem && recs[i].object_id_json &&
+                             recs[i].room_id_json && recs[i].name_json && recs[i].view_ids_json && recs[i].best_view_id_json,
+                         HMSG_ERR_INVALID, "hmsg_save_objects: bad record");
+        if (n == 0) return HMSG_OK;
+        HIP_TRY(hipSetDevice(h->cfg.device_id));
+        std::vector<double> pts((size_t)std::max<long long>(h->inst.total, 1) * 3);
+        std::vector<float> feats((size_t)NI * D);
+        if (h->inst.total) HIP_TRY(hipMemcpy(pts.data(), h->inst.pts.p, (size_t)h->inst.total * 24, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(feats.data(), h->inst_feats.p, feats.size() * 4, hipMemcpyDeviceToHost));
+        int nt = n_threads > 0 ? n_threads : (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+        nt = (int)std::min<int64_t>(nt, n);
+        std::atomic<int64_t> next{0};
+        std::atomic<int> failed{0};
+        const std::string base = std::string(dir) + "/";
+        auto work = [&]() {
+            std::string js;
+            std::vector<char> ply;
+            for (;;) {
+                const int64_t i = next.fetch_add(1);
+                if (i >= n || failed.load()) return;
+                const hmsg_object_record& r = recs[i];
+                const long long a = h->inst.off[(size_t)r.instance], b = h->inst.off[(size_t)r.instance + 1];
+                const double* P = pts.data() + a * 3;
+                const long long np = b - a;
+                // ---- <stem>.ply: binary little-endian, double x y z (a colourless Open3D cloud)
+                char hdr[160];
+                const int hl = snprintf(hdr, sizeof(hdr),
+                                        "ply\nformat binary_little_endian 1.0\nelement vertex %lld\nproperty double x\nproperty double y\n"
+                                        "property double z\nend_header\n", np);
+                ply.resize((size_t)hl + (size_t)np * 24);
+                memcpy(ply.data(), hdr, (size_t)hl);
+                if (np) memcpy(ply.data() + hl, P, (size_t)np * 24);
+                if (!write_file(base + r.file_stem + ".ply", ply.data(), ply.size())) {
+                    failed.store(1);
+                    return;
+                }
+                // ---- <stem>.json (object.py:46-56 key order)
+                js.clear();
+                js.reserve((size_t)np * 44 + (size_t)D * 24 + 256);
+                js += "{\"object_id\": ";
+                js += r.object_id_json;
+                js += ", \"vertices\": [";
+                char num[32];
+                for (long long k = 0; k < np; ++k) {          // vertices = points[:, [0, 2]] (graph.py:1715)
+                    if (k) js += ", ";
+                    js += '[';
+                    js.append(num, (size_t)(py_repr(num, P[k * 3]) - num));
+                    js += ", ";
+                    js.append(num, (size_t)(py_repr(num, P[k * 3 + 2]) - num));
+                    js += ']';
+                }
+                js += "], \"room_id\": ";
+                js += r.room_id_json;
+                js += ", \"name\": ";
+                js += r.name_json;
+                js += ", \"embedding\": [";
+                const float* E = feats.data() + (size_t)r.instance * D;
+                for (int k = 0; k < D; ++k) {
+                    if (k) js += ", ";
+                    js.append(num, (size_t)(py_repr(num, (double)E[k]) - num));
+                }
+                js += "], \"view_ids\": ";
+                js += r.view_ids_json;
+                js += ", \"best_view_id\": ";
+                js += r.best_view_id_json;
+                js += '}';
+                if (!write_file(base + r.file_stem + ".json", js.data(), js.size())) {
+                    failed.store(1);
+                    return;
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+        work();
+        for (auto& t : pool) t.join();
+        HMSG_REQUIRE(!failed.load(), HMSG_ERR_INVALID, std::string("hmsg_save_objects: cannot write into ") + dir);
+        return HMSG_OK;
+    } catch (const hmsg_error& e) {
+        h->err = e.msg;
+        return e.code;
+    } catch (const std::exception& e) {
+        h->err = e.what();
+        return HMSG_ERR_INVALID;
+    }
+}
+
+// test hook: Python-repr formatting of doubles, newline separated (tests/test_persist_golden.py compares with repr())
+extern "C" int64_t hmsg_test_format_doubles(const double* v, int64_t n, char* out, int64_t cap) {
+    int64_t used = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (used + 34 > cap) return -1;
+        char* e = py_repr(out + used, v[i]);
+        *e++ = '\n';
+        used = e - out;
+    }
+    return used;
+}

@@ -731,6 +731,7 @@ class Graph:
             room.object_counter += 1
             obj.name = classes[label] if (classes is not None and label >= 0) else "object"
             obj.pcd, obj.embedding = pcd, np.asarray(self.mask_feats[i]).reshape(-1)
+            obj._instance = i if isinstance(pcd, _LazyPcd) else None       # (save_hmsg_graph: bulk writer)
             obj.vertices = None                                            # = points[:, [0, 2]], materialised on save
             best, best_d = None, float("inf")
             for v in room.views:
@@ -829,10 +830,20 @@ class Graph:
         """graph.py:1801-1824: every node OF THE GRAPH is written (create_graph_new must have run)."""
         for sub in ("floors", "rooms", "objects", "views"):
             os.makedirs(os.path.join(path, sub), exist_ok=True)
+        bulk = []
         for node in self.graph.nodes():
+            # objects whose cloud and embedding still live in HBM (built by segment_hmsg_objects, untouched since) go
+            # through the library's multi-threaded writer; everything else is written node by node
+            if isinstance(node, Object) and self.scene is not None and getattr(node, "_instance", None) is not None \
+                    and isinstance(node.pcd, _LazyPcd) and node.vertices is None:
+                bulk.append(dict(instance=node._instance, object_id=node.object_id, room_id=node.room_id, name=node.name,
+                                 view_ids=node.view_ids, best_view_id=node.best_view_id))
+                continue
             for cls, sub in ((Floor, "floors"), (Room, "rooms"), (Object, "objects"), (View, "views")):
                 if isinstance(node, cls):
                     node.save(os.path.join(path, sub))
+        if bulk:
+            self.scene.save_objects(os.path.join(path, "objects"), bulk)
 
     save_graph = save_hmsg_graph
 

@@ -216,6 +216,26 @@ int64_t hmsg_num_nodes(const hmsg_t* h);
 /* nodes [hmsg_num_nodes] and/or their embeddings f32 [N][D] (either may be NULL) */
 int hmsg_get_nodes(const hmsg_t* h, hmsg_node* nodes, float* embeddings);
 
+/* ---- N2: the object level of the on-disk format written at speed.  Replaces Object.save (memory/hmsg/graph/object.py:
+ * 37-57) as driven per node by save_hmsg_graph (graph.py:1801-1824): for every record <dir>/<file_stem>.ply (binary
+ * little-endian double x y z of the instance cloud) and <dir>/<file_stem>.json = json.dump of {"object_id", "vertices"
+ * (= points[:, [0, 2]], graph.py:1715), "room_id", "name", "embedding" (pooled feature), "view_ids", "best_view_id"} in
+ * that order, numbers printed like Python's float repr.  The *_json fields are JSON text supplied by the caller (a
+ * quoted string, a list, null ...) and are copied verbatim.  Clouds and features are read back from HBM once;
+ * n_threads host threads format and write (<= 0: one per core, at most 32). */
+typedef struct {
+    int32_t instance;               /* index into the instance list (hmsg_node.instance) */
+    const char* file_stem;          /* str(object_id) */
+    const char* object_id_json;
+    const char* room_id_json;
+    const char* name_json;
+    const char* view_ids_json;
+    const char* best_view_id_json;
+} hmsg_object_record;
+int hmsg_save_objects(hmsg_t* h, const char* dir, int64_t n, const hmsg_object_record* recs, int32_t n_threads);
+/* test hook: Python-repr text of n doubles, newline separated, into out[cap]; returns bytes written or -1 */
+int64_t hmsg_test_format_doubles(const double* v, int64_t n, char* out, int64_t cap);
+
 /* ---- A9 camera -> room assignment of compute_room_embeddings (utils/graph_utils.py:244-291): out[q][s] =
  * np.min(cdist([q], set s, "euclidean")) for n_q 2-D positions (camera x/z) against n_sets 2-D point sets (room
  * clouds projected to x/z): pts_xy f64 [set_off[n_sets]][2], q_xy f64 [n_q][2], out f64 [n_q][n_sets] (inf for an empty

@@ -117,6 +117,17 @@ def test_graph_end_to_end_tiny(L, tmp_path):
         b = g._node_index().query_objects(Tq, np.zeros(1, np.int32), [[0]], 3)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])
         ixn.close()
+    # N2: the objects were written by the library's bulk writer (hmsg_save_objects): byte-identical with Object.save
+    import os
+    ref_dir = tmp_path / "objects_py"
+    ref_dir.mkdir()
+    for o in g.objects:
+        assert o._instance is not None
+        o.save(str(ref_dir))
+    names = sorted(os.listdir(ref_dir))
+    assert len(names) == 2 * len(g.objects) and names == sorted(os.listdir(tmp_path / "graph" / "objects"))
+    for f in names:
+        assert open(ref_dir / f, "rb").read() == open(tmp_path / "graph" / "objects" / f, "rb").read(), f
     g2 = Graph(dict(main=dict(), models=dict(clip=dict(feat_dim=32))), encoders=enc, lib=L)
     g2.load_hmsg_graph(str(tmp_path / "graph"))
     assert len(g2.objects) == len(g.objects) and len(g2.rooms) == 1

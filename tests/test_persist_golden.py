@@ -83,3 +83,34 @@ def test_merge_objects_matches_reference():
     np.testing.assert_allclose(np.stack([np.asarray(o.embedding, np.float64) for o in room.objects]), z["emb"], rtol=0, atol=1e-15)
     for k, o in enumerate(room.objects):
         np.testing.assert_allclose(np.asarray(o.vertices, np.float64), z["vertices_%d" % k], rtol=0, atol=1e-15)
+
+
+def test_library_prints_floats_like_python_repr():
+    """hmsg_save_objects writes JSON numbers itself: its formatter must equal float.__repr__ (what json.dump uses)."""
+    import ctypes as C
+    import os
+
+    import pytest
+
+    from tests import parity_common as PC
+    if not os.path.exists(PC.EMU_PATH):
+        pytest.skip("kernel simulator not built")
+    from holoagent_amd._lib import HmsgLib
+    L = HmsgLib(PC.EMU_PATH)
+    rng = np.random.Generator(np.random.PCG64(2))
+    vals = np.concatenate([
+        rng.integers(0, 2 ** 64, 20000, dtype=np.uint64).view(np.float64),            # every exponent, NaNs included
+        rng.standard_normal(20000), rng.standard_normal(5000).astype(np.float32).astype(np.float64),
+        10.0 ** rng.integers(-30, 30, 3000) * rng.integers(1, 1000, 3000),
+        np.array([0.0, -0.0, 1.0, -1.0, 0.1, 1e-4, 9.999e-5, 1e-5, 1e15, 1e16, 9999999999999998.0, 1e17, 123456789012345680.0,
+                  5e-324, 1.7976931348623157e308, np.inf, -np.inf, np.nan, 1e22, 1e23, 2.5, 100.0, 0.001, 1234.5678])])
+    vals = np.ascontiguousarray(vals)
+    buf = C.create_string_buffer(len(vals) * 34)
+    n = L.c.hmsg_test_format_doubles(vals.ctypes.data_as(C.c_void_p), len(vals), buf, len(buf))
+    assert n > 0
+    got = buf.raw[:n].decode().split("\n")[:-1]
+    import json
+    want = [json.dumps(float(v)) for v in vals]
+    assert len(got) == len(want)
+    bad = [(g, w) for g, w in zip(got, want) if g != w]
+    assert not bad, bad[:5]
