@@ -54,6 +54,7 @@ __global__ void __launch_bounds__(256) k_crop_resize(const unsigned char* __rest
     const unsigned char* seg = r.mask >= 0 ? segs + (size_t)r.mask * H * W : nullptr;
     unsigned char* out = (r.variant ? out_masked : out_plain) + (size_t)r.out * S * S * 3;
     const int rows = min(CROP_ROWS, S - row0);
+    const size_t img_bytes = (size_t)H * W * 3;
     int last_q = -1, xa[4], xb[4], a0[4], a1[4];
     for (int item = threadIdx.x; item < rows * quads; item += 256) {
         const int rl = item / quads, q = item - rl * quads;
@@ -82,18 +83,41 @@ __global__ void __launch_bounds__(256) k_crop_resize(const unsigned char* __rest
         unsigned px[3] = {0u, 0u, 0u};          // 12 output bytes
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const size_t p00 = o0 + xa[j], p01 = o0 + xb[j], p10 = o1 + xa[j], p11 = o1 + xb[j];
-            bool m00 = true, m01 = true, m10 = true, m11 = true;
+            const size_t p0 = o0 + xa[j], p1 = o1 + xa[j];
+            // the two taps of a row are neighbouring pixels (6 bytes): ONE unaligned 8-byte load per row instead of six
+            // byte loads (the L1 request rate, not HBM, bounds this kernel); the last pixels of the image, and the
+            // clamped right edge where both taps are the same pixel, take the byte path
+            unsigned long long w0, w1;
+            const bool pair = xb[j] == xa[j] + 1;
+            if (pair && p0 * 3 + 8 <= img_bytes && p1 * 3 + 8 <= img_bytes) {
+                __builtin_memcpy(&w0, image + p0 * 3, 8);
+                __builtin_memcpy(&w1, image + p1 * 3, 8);
+            } else {
+                const size_t q0 = o0 + xb[j], q1 = o1 + xb[j];
+                w0 = w1 = 0ull;
+                for (int c = 0; c < 3; ++c) {
+                    w0 |= (unsigned long long)image[p0 * 3 + c] << (8 * c) | (unsigned long long)image[q0 * 3 + c] << (8 * (c + 3));
+                    w1 |= (unsigned long long)image[p1 * 3 + c] << (8 * c) | (unsigned long long)image[q1 * 3 + c] << (8 * (c + 3));
+                }
+            }
             if (seg) {
-                m00 = seg[p00] != 0;
-                m01 = seg[p01] != 0;
-                m10 = seg[p10] != 0;
-                m11 = seg[p11] != 0;
+                unsigned short m0, m1;                       // the two taps' mask bytes (neighbours when `pair`)
+                if (pair) {
+                    __builtin_memcpy(&m0, seg + p0, 2);
+                    __builtin_memcpy(&m1, seg + p1, 2);
+                } else {
+                    m0 = (unsigned short)(seg[p0] | (seg[o0 + xb[j]] << 8));
+                    m1 = (unsigned short)(seg[p1] | (seg[o1 + xb[j]] << 8));
+                }
+                if (!(m0 & 0xff)) w0 &= ~0xffffffull;
+                if (!(m0 >> 8)) w0 &= ~0xffffff000000ull;
+                if (!(m1 & 0xff)) w1 &= ~0xffffffull;
+                if (!(m1 >> 8)) w1 &= ~0xffffff000000ull;
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const int r0 = (m00 ? image[p00 * 3 + c] : 0) * a0[j] + (m01 ? image[p01 * 3 + c] : 0) * a1[j];
-                const int r1 = (m10 ? image[p10 * 3 + c] : 0) * a0[j] + (m11 ? image[p11 * 3 + c] : 0) * a1[j];
+                const int r0 = (int)((w0 >> (8 * c)) & 0xff) * a0[j] + (int)((w0 >> (8 * (c + 3))) & 0xff) * a1[j];
+                const int r1 = (int)((w1 >> (8 * c)) & 0xff) * a0[j] + (int)((w1 >> (8 * (c + 3))) & 0xff) * a1[j];
                 int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
                 v = min(max(v, 0), 255);
                 const int byte = j * 3 + c;

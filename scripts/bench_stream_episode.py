@@ -1,0 +1,156 @@
+"""BASELINE.json configs[4] on ONE GPU: a long 1280x720 episode STREAMED through the C ABI in chunks.
+
+The raw masks of such an episode (10 000 frames x 32 masks x 0.92 MB = 295 GB) never fit in HBM at once, and need not:
+`hmsg_add_frames` appends geometry chunk by chunk and `hmsg_add_frame_features` turns each chunk's masks into the
+resident per-pixel bitsets (8 B per pixel and frame) and F_p rows right away, so only one chunk of raw masks exists at
+any time.  After the last chunk: map, fusion, merge, pooling, graph assembly, retrieval -- the same calls as bench.py.
+
+    python scripts/bench_stream_episode.py --frames 2000 --chunk 100           # one JSON line
+    python scripts/bench_stream_episode.py --emu --frames 6 --chunk 4 --width 64 --height 48 --feat-dim 16   # CPU dry run
+
+The synthetic renderer (bench utility kernel) stands in for the sensor + SAM + CLIP; its time is reported separately and
+is not part of frames/s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=2000)
+    ap.add_argument("--chunk", type=int, default=100)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--feat-dim", type=int, default=512)
+    ap.add_argument("--masks", type=int, default=32)
+    ap.add_argument("--queries", type=int, default=1000)
+    ap.add_argument("--emu", action="store_true", help="kernel simulator + numpy buffers (API dry run without a GPU)")
+    a = ap.parse_args()
+    F, H, W, M, D = a.frames, a.height, a.width, a.masks, a.feat_dim
+    if a.emu:
+        from tests import parity_common as PC
+        from holoagent_amd._lib import HmsgLib, Scene
+        L = HmsgLib(PC.EMU_PATH)
+        torch = None
+    else:
+        import torch
+        from holoagent_amd._lib import HmsgLib, Scene
+        L = HmsgLib()
+        torch.cuda.set_device(0)
+    from holoagent_amd.synth import SceneSpec, SynthScene
+    spec = SceneSpec(seed=1234, n_frames=F, feat_dim=D, n_masks=M, width=W, height=H)
+    scn = SynthScene(spec)
+    poses = np.zeros((F, 16))
+    room_of = np.zeros(F, np.int32)
+    for i in range(F):
+        T, rid = scn.pose(i)
+        poses[i] = T.reshape(-1)
+        room_of[i] = rid
+    rooms = np.ascontiguousarray([np.concatenate([lo, hi]) for lo, hi in scn.rooms])
+    obj = np.ascontiguousarray(np.array([np.concatenate([lo, hi]) for _, lo, hi in scn.objects]).reshape(-1, 6))
+    obj_room = np.array([r for r, _, _ in scn.objects], np.int32)
+    off = np.zeros(len(scn.rooms) + 1, np.int32)
+    for r in obj_room:
+        off[r + 1] += 1
+    off = np.ascontiguousarray(np.cumsum(off).astype(np.int32))
+    K = np.ascontiguousarray(scn.K, np.float64)
+    C = min(a.chunk, F)
+    if a.emu:
+        rgb = np.empty((C, H, W, 3), np.uint8)
+        depth = np.empty((C, H, W), np.uint16)
+        masks = np.empty((C, M, H, W), np.uint8)
+        ptr = lambda t: t.ctypes.data
+        dev = lambda x: np.ascontiguousarray(x, np.float32)
+        sync = lambda: None
+    else:
+        device = torch.device("cuda", 0)
+        rgb = torch.empty((C, H, W, 3), dtype=torch.uint8, device=device)
+        depth = torch.empty((C, H, W), dtype=torch.int16, device=device)
+        masks = torch.empty((C, M, H, W), dtype=torch.uint8, device=device)
+        ptr = lambda t: t.data_ptr()
+        dev = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(device)
+        sync = torch.cuda.synchronize
+    sc = Scene(lib_=L, device_id=0, height=H, width=W, max_frames=F, max_masks=M, feat_dim=D)
+    stage = {}
+
+    def T(name, fn):
+        sync()
+        t0 = time.perf_counter()
+        r = fn()
+        sync()
+        stage[name] = stage.get(name, 0.0) + (time.perf_counter() - t0)
+        return r
+
+    rng = np.random.Generator(np.random.PCG64([spec.seed, 424242]))
+    for c0 in range(0, F, C):
+        n = min(C, F - c0)
+        ment = np.zeros((n, M), np.int32)
+
+        def render():
+            rc = L.c.hmsg_synth_render(0, n, H, W, M, K.ctypes.data, np.ascontiguousarray(poses[c0:c0 + n]).ctypes.data,
+                                       np.ascontiguousarray(room_of[c0:c0 + n]).ctypes.data, len(scn.rooms), rooms.ctypes.data,
+                                       len(scn.objects), obj.ctypes.data, off.ctypes.data, spec.depth_noise_mm,
+                                       spec.seed + 7919 * (c0 // C), ptr(rgb), ptr(depth), ptr(masks), ment.ctypes.data)
+            assert rc == 0, "hmsg_synth_render failed"
+        T("source/render (not counted)", render)
+
+        def feats():
+            u = scn.entity_feats[ment]
+            fm = u + spec.feat_noise * rng.standard_normal(u.shape).astype(np.float32)
+            fc = u + spec.feat_noise * rng.standard_normal(u.shape).astype(np.float32)
+            fm /= np.linalg.norm(fm, axis=-1, keepdims=True)
+            fc /= np.linalg.norm(fc, axis=-1, keepdims=True)
+            fg = u.mean(axis=1)
+            fg /= np.linalg.norm(fg, axis=-1, keepdims=True)
+            return dev(fg), dev(fm), dev(fc)
+        fg, fm, fc = T("source/features (not counted)", feats)
+        T("add_frames", lambda: sc.add_frames(rgb[:n], depth[:n], np.ascontiguousarray(poses[c0:c0 + n]), K))
+        T("add_frame_features", lambda: sc.add_frame_features(c0, masks[:n], fg, fm, fc))
+    T("finalize_map", sc.finalize_map)
+    T("fuse_frames", sc.fuse_frames)
+    T("merge_instances", sc.merge_instances)
+    T("pool_instances", sc.pool_instances)
+    from holoagent_amd.graph import Graph
+    room_specs = []
+    for lo6 in rooms:
+        xs, zs = np.arange(lo6[0], lo6[3], 0.05), np.arange(lo6[2], lo6[5], 0.05)
+        room_specs.append(dict(floor=0, vertices=np.stack(np.meshgrid(xs, zs, indexing="ij"), -1).reshape(-1, 2)))
+
+    def assemble():
+        g = Graph.from_scene(sc, lib=L)
+        g.build_hier_multimodal_scene_graph(None, rooms=room_specs)
+        return g
+    g = T("assemble_graph", assemble)
+    text, q_ent = scn.text_table(a.queries)
+    n_rooms = len(scn.rooms)
+    ent_room = np.concatenate([obj_room, np.repeat(np.arange(n_rooms), 6)])
+    q_rooms = [[int(ent_room[e]), int((ent_room[e] + 1) % n_rooms)] for e in q_ent]
+
+    def retrieve():
+        if not g.objects:
+            return None
+        ix = sc.index_from_nodes()
+        out = ix.query_objects(text, np.zeros(len(q_rooms), np.int32), q_rooms, 5)
+        ix.close()
+        return out
+    T("retrieval", retrieve)
+    counted = sum(v for k, v in stage.items() if "not counted" not in k)
+    print(json.dumps({"metric": "HMSG frames/sec, one episode streamed in chunks (configs[4] shape on one GPU)",
+                      "value": round(F / counted, 3), "unit": "frames/s", "frames": F, "image": [W, H], "chunk": C, "masks": M,
+                      "feat_dim": D, "seconds": round(counted, 3), "stage_seconds": {k: round(v, 4) for k, v in stage.items()},
+                      "map_voxels": int(sc.map_size()), "instances": int(sc.num_instances()), "objects": len(g.objects),
+                      "tie_queries": int(sc.num_tie_queries()),
+                      "resident_GB": round(F * H * W * (3 + 2 + 8 + 4) / 1e9, 2), "raw_masks_GB_never_resident": round(F * M * H * W / 1e9, 2)}))
+    sc.close()
+
+
+if __name__ == "__main__":
+    main()
