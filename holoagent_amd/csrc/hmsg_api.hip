@@ -96,6 +96,21 @@ int guard(hmsg_ctx* h, F&& fn) {
     }
 }
 
+// A long episode's frame store (colour, depth, mask bitsets, nearest-voxel indices: 17 B per pixel and frame, 157 GB for
+// 10 000 frames at 1280x720) is dead weight once every frame is fused: nothing after the fusion reads it, and the merge
+// needs the room.  Small stores stay (a service that rebuilds scenes reuses them).
+void release_frame_store_if_large(hmsg_ctx* h) {
+    const size_t bytes = h->rgb.bytes() + h->depth.bytes() + h->bits.bytes() + h->nn.bytes();
+    if (bytes < ((size_t)32 << 30) || h->n_fused < h->n_feat_frames) return;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->rgb.release();
+    h->depth.release();
+    h->bits.release();
+    h->nn.release();
+    dev_cache().trim();
+    h->frames_released = true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -180,6 +195,12 @@ int hmsg_reset(hmsg_t* h) {
         hmsg_kd_join(h);
         h->n_tie_queries = 0;
         h->n_frames = h->n_feat_frames = h->n_fused = 0;
+        if (h->frames_released) {              // (hmsg_merge_instances gave a very large frame store back)
+            const size_t HW = (size_t)h->cfg.height * h->cfg.width;
+            h->rgb.alloc(HW * 3 * h->cfg.max_frames);
+            h->depth.alloc(HW * h->cfg.max_frames);
+            h->frames_released = false;
+        }
         h->nmask.clear();
         h->mask_first.clear();
         h->have_K = false;
@@ -251,6 +272,7 @@ int hmsg_add_frames(hmsg_t* h, int32_t n, const uint8_t* rgb, const uint16_t* de
         HMSG_REQUIRE(n >= 0 && rgb && depth && pose && K, HMSG_ERR_INVALID, "hmsg_add_frames: null argument");
         HMSG_REQUIRE(!h->map_ready, HMSG_ERR_INVALID, "hmsg_add_frames after hmsg_finalize_map");
         HMSG_REQUIRE(h->n_frames + n <= h->cfg.max_frames, HMSG_ERR_INVALID, "frame store full (cfg.max_frames)");
+        HMSG_REQUIRE(!h->frames_released, HMSG_ERR_INVALID, "hmsg_add_frames: the frame store was released (hmsg_reset first)");
         double Kh[9];
         if (is_device_ptr(K)) {
             HIP_TRY(hipMemcpy(Kh, K, sizeof(Kh), hipMemcpyDeviceToHost));
@@ -302,6 +324,7 @@ int hmsg_add_frame_features(hmsg_t* h, int32_t first, int32_t n, int32_t M, cons
         HMSG_REQUIRE(M == 0 || (masks && F_masked && F_crop), HMSG_ERR_INVALID, "hmsg_add_frame_features: null argument");
         HMSG_REQUIRE(first == h->n_feat_frames, HMSG_ERR_INVALID, "frames must be handed over in order (first == #frames so far)");
         HMSG_REQUIRE(first + n <= h->n_frames, HMSG_ERR_INVALID, "features for a frame without geometry");
+        HMSG_REQUIRE(!h->frames_released, HMSG_ERR_INVALID, "hmsg_add_frame_features: the frame store was released (hmsg_reset first)");
         if (n == 0) return;
         const size_t HW = (size_t)h->cfg.height * h->cfg.width;
         const int D = h->cfg.feat_dim;
@@ -380,6 +403,7 @@ int hmsg_merge_tree_local(hmsg_t* h, int32_t total_frames, double* th_next, int6
     if (!h || !th_next || !lists_now || !my_index) return HMSG_ERR_INVALID;
     return guard(h, [&] {
         long long l = 0, i = 0;
+        release_frame_store_if_large(h);
         hmsg_merge_tree_local_impl(h, total_frames, th_next, &l, &i);
         *lists_now = l;
         *my_index = i;
@@ -495,7 +519,10 @@ int hmsg_get_frame_mask_points(const hmsg_t* hc, int32_t frame, double* xyz) {
 
 int hmsg_merge_instances(hmsg_t* h) {
     if (!h) return HMSG_ERR_INVALID;
-    return guard(h, [&] { hmsg_merge(h); });
+    return guard(h, [&] {
+        release_frame_store_if_large(h);
+        hmsg_merge(h);
+    });
 }
 
 int64_t hmsg_num_instances(const hmsg_t* h) { return h && (h->merged || h->tree_partial) ? (int64_t)h->inst.off.size() - 1 : -1; }

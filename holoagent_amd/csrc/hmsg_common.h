@@ -61,9 +61,16 @@ struct DevCache {
         void* p = nullptr;
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) {          // out of memory: drop the cache and retry once
+            (void)hipGetLastError();    // (the failed call must not surface at the next launch check)
+            size_t parked = 0, fr = 0, tot = 0;
+            for (auto& kv : free_) parked += kv.first.second;
+            (void)hipMemGetInfo(&fr, &tot);
+            fprintf(stderr, "[hmsg alloc] %.1f MB did not fit (device free %.1f of %.1f GB): returning %.1f GB of parked blocks\n",
+                    want / 1048576.0, fr / 1073741824.0, tot / 1073741824.0, parked / 1073741824.0);
             for (auto& kv : free_) (void)hipFree(kv.second);
             free_.clear();
             e = hipMalloc(&p, want);
+            if (e != hipSuccess) (void)hipGetLastError();
         }
         if (e != hipSuccess) throw hmsg_error{HMSG_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)};
         *got = want;
@@ -381,6 +388,7 @@ struct hmsg_ctx {
     bool merged = false;
     int frame_window = 0;          // first frame with features (hmsg_set_frame_window: this handle owns a frame range)
     bool tree_partial = false;     // inst holds an unfinished list of the sharded hierarchical merge tree
+    bool frames_released = false;  // the (very large) frame store was given back before the merge (hmsg_api.hip)
     DevBuf<float> inst_feats;      // [N][D]
     bool pooled = false;
     bool inst_denoised = false;    // the per-object pcd_denoise_dbscan(0.05, 10) of graph.py:1589-1591 has run

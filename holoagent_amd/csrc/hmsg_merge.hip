@@ -360,8 +360,9 @@ struct Merger {
             todo.push_back(i);
         }
         if (todo.empty()) return;
-        HMSG_REQUIRE(ix_cells_used + ncell_new < (1ll << 32) && ix_pts_used + npts_new < (1ll << 32), HMSG_ERR_UNSUPPORTED,
-                     "merge index exceeds 2^32 entries");
+        // (arena offsets are 64-bit; cell starts are relative to the batch's first sorted point, so only a BATCH is bounded)
+        HMSG_REQUIRE(ncell_new < (1ll << 32) && npts_new < (1ll << 32), HMSG_ERR_UNSUPPORTED,
+                     "one batch of overlap grids exceeds 2^32 entries");
         grow(ix_cells, (size_t)ix_cells_used, (size_t)(ix_cells_used + ncell_new));
         grow(ix_pts, (size_t)ix_pts_used * 3, (size_t)(ix_pts_used + npts_new) * 3);
         std::vector<OvGrid> g(todo.size());
@@ -388,6 +389,68 @@ struct Merger {
         ix_cells_used += ncell_new;
         ix_pts_used += npts_new;
     }
+
+    // ---- overlap grids of the frame masks of frames [a, b) in one batch (inputs of the fold: built ahead, a window at a
+    // time, so that a very long episode neither exceeds a batch nor holds grids of frames that are hours away)
+    void prebuild(std::vector<std::vector<Cloud>>& frames, size_t a, size_t b) {
+        b = std::min(b, frames.size());
+        std::vector<Cloud> all;
+        for (size_t f = a; f < b; ++f) all.insert(all.end(), frames[f].begin(), frames[f].end());
+        build_indices(all);
+        size_t k = 0;
+        for (size_t f = a; f < b; ++f)
+            for (auto& cl : frames[f]) cl = all[k++];
+    }
+
+    // ---- The point pool and the grid arenas are append-only: every fold step adds its merged clouds and their grids,
+    // and what they replace stays behind.  Fine for 10^3 frames (a few GB); a 10^4-frame episode would leave ~70 GB of
+    // dead points and > 2^32 dead cells.  collect() moves the LIVE clouds (the global list + the frames still to come)
+    // to a fresh pool and drops every grid; grids come back through prebuild / build_indices.  Results do not change.
+    bool needs_collect() const {
+        return pool_used > (long long)gc_pool_points || ix_cells_used > (long long)gc_index_entries || ix_pts_used > (long long)gc_index_entries;
+    }
+    void collect(std::vector<Cloud>& G, std::vector<std::vector<Cloud>>& frames, size_t f_next) {
+        long long live = 0;
+        unsigned blocks = 0;
+        std::vector<CatSeg> cat;
+        auto add = [&](Cloud& c) {
+            cat.push_back(CatSeg{c.off, live, c.n, c.anchor ? 1 : 0, (int)blocks, 0});
+            blocks += cdiv((size_t)c.n, CAT_CHUNK);
+            c.off = live;
+            live += c.n;
+            c.has_index = false;
+        };
+        for (auto& c : G) add(c);
+        for (size_t f = f_next; f < frames.size(); ++f)
+            for (auto& c : frames[f]) add(c);
+        DevBuf<double> np;
+        DevBuf<unsigned char> nc;
+        np.alloc((size_t)std::max<long long>(live + live / 2, 1 << 16) * 3);
+        nc.alloc((size_t)std::max<long long>(live + live / 2, 1 << 16));
+        if (!cat.empty()) {
+            d_cat.ensure(cat.size());
+            HIP_TRY(hipMemcpyAsync(d_cat.p, cat.data(), cat.size() * sizeof(CatSeg), hipMemcpyHostToDevice, s));
+            if (blocks)
+                hipLaunchKernelGGL(k_concat, dim3(blocks), dim3(256), 0, s, (const double*)pool.p, (const CatSeg*)d_cat.p, (int)cat.size(),
+                                   np.p, (const unsigned char*)poolcore.p, nc.p);
+            HMSG_CHECK_LAUNCH();
+        }
+        HIP_TRY(hipStreamSynchronize(s));
+        pool.swap(np);
+        poolcore.swap(nc);
+        np.release();
+        nc.release();
+        ix_cells.release();
+        ix_pts.release();
+        dev_cache().trim();              // give the dead arenas back to the device
+        pool_used = live;
+        ix_cells_used = ix_pts_used = 0;
+        ++n_collects;
+    }
+    size_t gc_pool_points = (size_t)12 << 27;        // 1.6 * 10^9 points = 39 GB
+    size_t gc_index_entries = (size_t)3 << 30;       // grid cells / sorted points
+    int n_collects = 0;
+    static constexpr size_t PREBUILD_WINDOW = 1024;  // frames
 
     // ---- overlap ratios for a list of (i, j) pairs of L.  `decide_th` >= 0 (sequential merge): only `ratio > th`
     // is needed downstream, so the pair's smaller cloud is counted first and the scan of the larger one is skipped on
@@ -744,12 +807,11 @@ std::vector<std::vector<Cloud>> seed_frames(Merger& m, hmsg_ctx* h, int first) {
     }
     // overlap grids of ALL frame masks in one batch (they are inputs of the fold; only clouds that change during
     // the fold get a new grid later)
-    std::vector<Cloud> all;
-    for (auto& fr : frames) all.insert(all.end(), fr.begin(), fr.end());
-    m.build_indices(all);
-    size_t k = 0;
-    for (auto& fr : frames)
-        for (auto& cl : fr) cl = all[k++];
+    if (h->cfg.merge_type == HMSG_MERGE_HIERARCHICAL || first != 0) {
+        for (size_t a = 0; a < frames.size(); a += Merger::PREBUILD_WINDOW) m.prebuild(frames, a, a + Merger::PREBUILD_WINDOW);
+    } else {
+        m.prebuild(frames, 0, Merger::PREBUILD_WINDOW);      // (the fold builds the later windows when it gets there)
+    }
     return frames;
 }
 
@@ -824,8 +886,16 @@ void hmsg_merge(hmsg_ctx* h) {
     } else {
         // graph_utils.py:1015-1038
         std::vector<Cloud> G = std::move(frames[0]);
+        if (const char* e = getenv("HMSG_DEBUG_GC_POINTS")) m.gc_pool_points = (size_t)atoll(e);   // (tests: force collections)
         for (int f = 1; f < F; ++f) {
+            if (m.needs_collect()) {
+                m.collect(G, frames, (size_t)f);
+                m.prebuild(frames, (size_t)f, (size_t)f + Merger::PREBUILD_WINDOW - (size_t)f % Merger::PREBUILD_WINDOW);
+            } else if ((size_t)f % Merger::PREBUILD_WINDOW == 0) {
+                m.prebuild(frames, (size_t)f, (size_t)f + Merger::PREBUILD_WINDOW);
+            }
             G.insert(G.end(), frames[f].begin(), frames[f].end());
+            std::vector<Cloud>().swap(frames[f]);
             G = m.merge_3d_masks(std::move(G), c.init_overlap_thresh);
         }
         result = m.merge_3d_masks(std::move(G), c.init_overlap_thresh);
@@ -835,6 +905,8 @@ void hmsg_merge(hmsg_ctx* h) {
     if (getenv("HMSG_DEBUG_TIMING"))
         fprintf(stderr, "[hmsg merge] index %.1f  pairs(host) %.1f  overlap %.1f  components+concat %.1f  dbscan %.1f  bookkeeping %.1f ms\n",
                 m.tphase[0], m.tphase[1], m.tphase[2], m.tphase[3], m.tphase[4], m.tphase[5]);
+    if (getenv("HMSG_DEBUG_TIMING") && m.n_collects)
+        fprintf(stderr, "[hmsg merge] %d collections of the point pool / grid arenas\n", m.n_collects);
     if (getenv("HMSG_DEBUG_TIMING") && m.ops.stat_calls > 0)
         fprintf(stderr, "[hmsg merge] dbscan batches %.0f: mean points %.0f  grid cells %.0f  core cells %.0f  active cells %.0f\n",
                 m.ops.stat_calls, m.ops.stat_points / m.ops.stat_calls, m.ops.stat_cells / m.ops.stat_calls,
