@@ -423,10 +423,13 @@ struct Merger {
         for (auto& c : G) add(c);
         for (size_t f = f_next; f < frames.size(); ++f)
             for (auto& c : frames[f]) add(c);
+        // the fresh pool has room for everything up to the next collection, so the pool stops growing; the old one is
+        // parked in the allocator's cache and comes back at the next collection (two pools ping-pong, no hipMalloc)
         DevBuf<double> np;
         DevBuf<unsigned char> nc;
-        np.alloc((size_t)std::max<long long>(live + live / 2, 1 << 16) * 3);
-        nc.alloc((size_t)std::max<long long>(live + live / 2, 1 << 16));
+        const size_t cap = std::max<size_t>((size_t)live + (size_t)live / 2, gc_pool_points + ((size_t)1 << 27));
+        np.alloc(cap * 3);
+        nc.alloc(cap);
         if (!cat.empty()) {
             d_cat.ensure(cat.size());
             HIP_TRY(hipMemcpyAsync(d_cat.p, cat.data(), cat.size() * sizeof(CatSeg), hipMemcpyHostToDevice, s));
@@ -440,15 +443,12 @@ struct Merger {
         poolcore.swap(nc);
         np.release();
         nc.release();
-        ix_cells.release();
-        ix_pts.release();
-        dev_cache().trim();              // give the dead arenas back to the device
-        pool_used = live;
+        pool_used = live;                // (the grid arenas keep their buffers: only their fill level is reset)
         ix_cells_used = ix_pts_used = 0;
         ++n_collects;
     }
-    size_t gc_pool_points = (size_t)12 << 27;        // 1.6 * 10^9 points = 39 GB
-    size_t gc_index_entries = (size_t)3 << 30;       // grid cells / sorted points
+    size_t gc_pool_points = (size_t)1 << 30;         // 1.07 * 10^9 points = 26 GB
+    size_t gc_index_entries = (size_t)1 << 31;       // grid cells (8 GB) / sorted points (26 GB)
     int n_collects = 0;
     static constexpr size_t PREBUILD_WINDOW = 1024;  // frames
 
