@@ -424,44 +424,62 @@ def objects_case_inputs(zb):
     return rooms, text, classes
 
 
+OBJECT_VIEW_FRAMES = [[0, 7, 14], [21, 28, 35]]       # frames whose poses become the views of the two rooms (objects_views)
+
+
 def gen_objects(G, X, out_dir):
     """A10: the reference's Graph.segment_hmsg_objects (graph.py:1582-1736) on the instances the reference built in
-    the build_seq fixture, with two given rooms (rooms are an input of the path) and no views."""
+    the build_seq fixture, with two given rooms (rooms are an input of the path): once without views (objects.npz) and
+    once with three views per room taken from the fixture's camera poses (objects_views.npz: the view <-> object
+    topology and best_view_id of :1706-1733)."""
     o3d = sys.modules["open3d"]
     from memory.hmsg.graph.room import Room
+    from memory.hmsg.graph.view import View
     zb = np.load(os.path.join(out_dir, "build_seq.npz"), allow_pickle=True)
     rooms, text, classes = objects_case_inputs(zb)
     G.get_label_feats = lambda *a, **k: (text, classes)
-    g = G.Graph.__new__(G.Graph)
-    g.cfg = AttrDict(main=AttrDict(save_path="/tmp/hmsg_golden_tmp"),
-                     pipeline=AttrDict(save_intermediate_results=False, obj_labels="synthetic"))
-    g.graph_tmp_folder = "/tmp/hmsg_golden_tmp"
-    g.floors, g.rooms, g.objects, g.views = [], [], [], []
-    g.clip_model, g.clip_feat_dim = None, text.shape[1]
-    pc = o3d.geometry.PointCloud()
-    pc.points = np.asarray(zb["ref_cloud"], dtype=np.float64).copy()
-    g.full_pcd = pc
-    g.segment_floors_manually(None)
-    fl = g.floors[0]
-    for k, verts in enumerate(rooms):
-        r = Room("%s_%d" % (fl.floor_id, k), fl.floor_id)
-        r.vertices = verts
-        fl.add_room(r)
-        g.rooms.append(r)
-    off = zb["ref_mask_off"]
-    g.mask_pcds = []
-    for k in range(len(off) - 1):
-        m = o3d.geometry.PointCloud()
-        m.points = np.asarray(zb["ref_mask_pts"][off[k]:off[k + 1]], dtype=np.float64).copy()
-        m.colors = np.zeros_like(m.points)
-        g.mask_pcds.append(m)
-    g.mask_feats = [np.asarray(f) for f in zb["ref_mask_feats"]]
 
-    class DS:
-        def get_camera_intrinsics(self):
-            return np.asarray(zb["K"])
-    g.dataset = DS()
-    g.segment_hmsg_objects()
+    def run(with_views):
+        g = G.Graph.__new__(G.Graph)
+        g.cfg = AttrDict(main=AttrDict(save_path="/tmp/hmsg_golden_tmp"),
+                         pipeline=AttrDict(save_intermediate_results=False, obj_labels="synthetic"))
+        g.graph_tmp_folder = "/tmp/hmsg_golden_tmp"
+        g.floors, g.rooms, g.objects, g.views = [], [], [], []
+        g.clip_model, g.clip_feat_dim = None, text.shape[1]
+        pc = o3d.geometry.PointCloud()
+        pc.points = np.asarray(zb["ref_cloud"], dtype=np.float64).copy()
+        g.full_pcd = pc
+        g.segment_floors_manually(None)
+        fl = g.floors[0]
+        for k, verts in enumerate(rooms):
+            r = Room("%s_%d" % (fl.floor_id, k), fl.floor_id)
+            r.vertices = verts
+            if with_views:
+                for fidx in OBJECT_VIEW_FRAMES[k]:
+                    v = View("%s_%d" % (r.room_id, len(g.views)), r.room_id, fidx)
+                    r.views.append(v)
+                    g.views.append(v)
+            fl.add_room(r)
+            g.rooms.append(r)
+        off = zb["ref_mask_off"]
+        g.mask_pcds = []
+        for k in range(len(off) - 1):
+            m = o3d.geometry.PointCloud()
+            m.points = np.asarray(zb["ref_mask_pts"][off[k]:off[k + 1]], dtype=np.float64).copy()
+            m.colors = np.zeros_like(m.points)
+            g.mask_pcds.append(m)
+        g.mask_feats = [np.asarray(f) for f in zb["ref_mask_feats"]]
+
+        class DS:
+            def get_camera_intrinsics(self):
+                return np.asarray(zb["K"])
+
+            def __getitem__(self, i):
+                return np.asarray(zb["rgb"][i]), None, np.asarray(zb["pose"][i]), None, None
+        g.dataset = DS()
+        g.segment_hmsg_objects()
+        return g
+    g = run(False)
     mask_of = []
     for o in g.objects:                      # which instance became this object (the embedding is the instance's)
         mask_of.append(next(i for i, f in enumerate(g.mask_feats) if f is o.embedding or np.array_equal(f, o.embedding)))
@@ -476,6 +494,17 @@ def gen_objects(G, X, out_dir):
         floor_zero=np.array([f.floor_zero_level for f in g.floors]), floor_height=np.array([f.floor_height for f in g.floors]))
     print("objects", len(g.objects), "of", len(g.mask_pcds), "instances; rooms",
           {r.room_id: len(r.objects) for r in g.rooms})
+    import json
+    gv = run(True)
+    assert [o.object_id for o in gv.objects] == [o.object_id for o in g.objects]
+    rec = dict(view_frames=OBJECT_VIEW_FRAMES,
+               views=[dict(view_id=v.view_id, room_id=v.room_id, img_id=int(v.img_id), object_ids=list(v.object_ids),
+                           text_discription=[str(t) for t in v.text_discription]) for v in gv.views],
+               objects=[dict(object_id=o.object_id, view_ids=list(o.view_ids), best_view_id=o.best_view_id) for o in gv.objects])
+    with open(os.path.join(out_dir, "objects_views.json"), "w") as f:
+        json.dump(rec, f)
+    print("objects_views:", sum(len(v["object_ids"]) for v in rec["views"]), "view-object links,",
+          sum(o["best_view_id"] is not None for o in rec["objects"]), "objects with a best view")
 
 
 def persist_case():

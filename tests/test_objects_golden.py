@@ -46,6 +46,28 @@ def _check(L):
     bad = [k for k in range(len(ref)) if stable[mask[k]] and got[k] != ref[k]]
     assert not bad, bad
     assert sum(bool(stable[m]) for m in mask) >= len(ref) // 3
+    # the view <-> object topology of graph.py:1706-1733 (check_object_in_view over the parent room's views, best view =
+    # smallest mean depth) against the reference run with three views per room (tests/golden/objects_views.json)
+    import json
+    zv = json.load(open(os.path.join(GI.GOLDEN, "objects_views.json")))
+
+    class DS:
+        def get_camera_intrinsics(self):
+            return np.asarray(z["K"])
+
+        def __getitem__(self, i):
+            return np.asarray(z["rgb"][i]), None, np.asarray(z["pose"][i]), None, None
+    g2 = Graph.from_scene(sc, lib=L)
+    g2.dataset = DS()
+    g2.segment_floors_manually(None)
+    g2.set_rooms([dict(floor=0, vertices=v, view_frames=zv["view_frames"][k]) for k, v in enumerate(rooms)])
+    g2.set_label_feats(text, classes)
+    g2.segment_hmsg_objects()
+    assert [(o.object_id, list(o.view_ids), o.best_view_id) for o in g2.objects] == \
+        [(o["object_id"], o["view_ids"], o["best_view_id"]) for o in zv["objects"]]
+    assert [(v.view_id, v.room_id, int(v.img_id), list(v.object_ids)) for v in g2.views] == \
+        [(v["view_id"], v["room_id"], v["img_id"], v["object_ids"]) for v in zv["views"]]
+    assert sum(len(v.object_ids) for v in g2.views) > 10
     sc.close()
 
 
