@@ -60,15 +60,31 @@ __global__ void k_db_cell(const double* __restrict__ pts, long long N, int* __re
 // Cell-sorted COPY of the points (+ each point's slot): every neighbourhood scan below walks contiguous runs of
 // it.  Those scans are serial, latency-bound chains per lane (the kernel runs as long as its slowest lane), so
 // a candidate must cost one load, not the ord -> point -> flag chain of an index sort.
+// It also lists the points whose core status needs a neighbour COUNT (not an anchor core, cell holds fewer than
+// min_points): k_db_count gives each of them a whole wave.
 __global__ void k_db_fill(const double* __restrict__ pts, long long N, const long long* __restrict__ cellid,
                           const unsigned* __restrict__ start, unsigned* __restrict__ cursor, unsigned* __restrict__ rank,
-                          double* __restrict__ spts) {
+                          double* __restrict__ spts, const unsigned char* __restrict__ core0, int minpts,
+                          unsigned* __restrict__ needy, unsigned* __restrict__ n_needy) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    long long c = cellid[i];
-    unsigned p = start[c] + atomicAdd(&cursor[c], 1u);
-    rank[i] = p;
-    for (int a = 0; a < 3; ++a) spts[(size_t)p * 3 + a] = pts[(size_t)i * 3 + a];
+    const bool live = i < N;
+    bool need = false;
+    if (live) {
+        long long c = cellid[i];
+        const unsigned s0 = start[c];
+        unsigned p = s0 + atomicAdd(&cursor[c], 1u);
+        rank[i] = p;
+        for (int a = 0; a < 3; ++a) spts[(size_t)p * 3 + a] = pts[(size_t)i * 3 + a];
+        need = !(core0 != nullptr && core0[i] != 0) && start[c + 1] - s0 < (unsigned)minpts;
+    }
+    const unsigned long long m = __ballot(need);
+    if (m) {
+        const int lane = threadIdx.x & 63, leader = __ffsll(m) - 1;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(n_needy, (unsigned)__popcll(m));
+        base = __shfl(base, leader);
+        if (need) needy[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (unsigned)i;
+    }
 }
 
 // number of points of the sorted run [s, e) closer than eps to p, counted until `need` are found; four
@@ -136,6 +152,60 @@ __device__ const signed char DB_COL[25][2] = {{0, 0},  {-1, 0}, {1, 0},  {0, -1}
                                               {-2, 0}, {2, 0},  {0, -2}, {0, 2},   {-2, -1}, {-2, 1}, {2, -1}, {2, 1},  {-1, -2},
                                               {-1, 2}, {1, -2}, {1, 2},  {-2, -2}, {-2, 2},  {2, -2}, {2, 2}};
 
+// Neighbour counts of the listed points, one WAVE per point: the 25 grid columns around the point's cell are 25
+// contiguous ranges of the cell-sorted copy; lanes 0..24 look their range up side by side, the ranges are laid end
+// to end (wave prefix sum) and the 64 lanes test 64 candidates per trip -- a handful of L2 round trips per point instead
+// of the ~75 of one lane walking the columns one after the other.  core[i] = (neighbours within eps, the point itself
+// included, >= min_points), the same predicate as before.
+__global__ void __launch_bounds__(256) k_db_count(const double* __restrict__ pts, const int* __restrict__ segid,
+                                                  const DbSeg* __restrict__ segs, const long long* __restrict__ cellid,
+                                                  const unsigned* __restrict__ start, const double* __restrict__ spts, double eps2,
+                                                  int minpts, const unsigned* __restrict__ needy,
+                                                  const unsigned* __restrict__ n_needy, unsigned char* __restrict__ core) {
+    const int lane = threadIdx.x & 63;
+    (void)__ballot(1);                                       // (keeps the kernel simulator's launch classification stable)
+    const unsigned nwaves = (gridDim.x * blockDim.x) >> 6, n = *n_needy;
+    for (unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
+        const long long i = needy[w];
+        const DbSeg sg = segs[segid[i]];
+        int ix, iy, iz;
+        cell_xyz(sg, cellid[i], ix, iy, iz);
+        const double pi[3] = {pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2]};
+        unsigned s0 = 0, len = 0;
+        if (lane < 25) {
+            const int jx = ix + DB_COL[lane][0], jy = iy + DB_COL[lane][1];
+            int z0, z1;
+            if (jx >= 0 && jx < sg.nx && jy >= 0 && jy < sg.ny && column_zrange(sg, pi, jx, jy, iz, eps2, z0, z1)) {
+                const long long cb = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz;
+                s0 = start[cb + z0];
+                len = start[cb + z1 + 1] - s0;
+            }
+        }
+        unsigned incl = len;                                  // inclusive prefix sum over the lanes
+        for (int d = 1; d < 32; d <<= 1) {
+            const unsigned up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        const unsigned total = __shfl(incl, 24);
+        int have = 0;
+        for (unsigned t0 = 0; t0 < total && have < minpts; t0 += 64) {
+            const unsigned t = t0 + lane;
+            int lo = 0, hi = 24;                              // column of candidate t: first lane with incl > t
+            for (int it = 0; it < 5; ++it) {
+                const int mid = (lo + hi) >> 1;
+                const unsigned v = __shfl(incl, mid);
+                if (v > t) hi = mid; else lo = mid + 1;
+            }
+            const int col = min(lo, 24);
+            const unsigned c_incl = __shfl(incl, col), c_len = __shfl(len, col), c_s0 = __shfl(s0, col);
+            bool hit = false;
+            if (t < total) hit = dist2_f64(spts + (size_t)(c_s0 + (t - (c_incl - c_len))) * 3, pi) < eps2;
+            have += __popcll(__ballot(hit));
+        }
+        if (lane == 0) core[i] = have >= minpts ? 1 : 0;
+    }
+}
+
 __global__ void k_db_core(const double* __restrict__ pts, long long N, const int* __restrict__ segid,
                           const DbSeg* __restrict__ segs, const long long* __restrict__ cellid,
                           const unsigned* __restrict__ cnt, const unsigned* __restrict__ start,
@@ -155,22 +225,7 @@ __global__ void k_db_core(const double* __restrict__ pts, long long N, const int
     // More points only raise neighbour counts, so they stay core -- no counting needed.
     const bool known = core0 != nullptr && core0[i] != 0;
     bool is_core = known || cnt[c] >= (unsigned)minpts;
-    if (!is_core && in_range) {
-        int ix, iy, iz, n = 0;
-        cell_xyz(sg, c, ix, iy, iz);
-        // the 5 z-cells of a (dx, dy) column are consecutive cell ids, so their points are ONE contiguous range
-        // of the cell-sorted order: 25 ranges instead of 125 cell probes
-        const double pi[3] = {pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2]};
-        for (int col = 0; col < 25 && n < minpts; ++col) {
-            const int jx = ix + DB_COL[col][0], jy = iy + DB_COL[col][1];
-            if (jx < 0 || jx >= sg.nx || jy < 0 || jy >= sg.ny) continue;
-            int z0, z1;
-            if (!column_zrange(sg, pi, jx, jy, iz, eps2, z0, z1)) continue;
-            long long cb = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz;
-            n = count_within(spts, start[cb + z0], start[cb + z1 + 1], pi, eps2, n, minpts);
-        }
-        is_core = n >= minpts;
-    }
+    if (!is_core && in_range) is_core = core[i] != 0;        // counted by k_db_count (the points k_db_fill listed)
     is_core = is_core && in_range;
     if (in_range) {
         core[i] = is_core ? 1 : 0;
@@ -359,6 +414,8 @@ __global__ void k_db_union(const int* __restrict__ corecells, const unsigned* __
                            const double* __restrict__ cellbox, int* __restrict__ parent, const unsigned* __restrict__ active) {
     const int lane = threadIdx.x & 63;
     const unsigned nwaves = (gridDim.x * blockDim.x) >> 6, ncells = *ncore;
+    // (two waves per cell, 64 neighbour cells each, was tried: 40 -> 48 us per step -- the per-wave preamble and the
+    //  contention on the roots cost more than the second trip through the lane's chain)
     for (unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < ncells; w += nwaves) {
         const long long c = corecells[w];
         const int lo = cseg[c];             // segment of the cell (written when the cell was registered)
@@ -826,7 +883,7 @@ __global__ void k_db_init(DbInit in) {
         in.contested[i] = 0u;
         in.dropped[i] = 0u;
     }
-    if (i < 3) in.counters[i] = 0u;
+    if (i < 4) in.counters[i] = 0u;
 }
 
 long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<SegDesc>& segs, double eps, int min_points,
@@ -875,7 +932,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     rootmin.ensure(NC);
     best.ensure(K);
     rep.ensure(K);
-    kres.ensure((size_t)K * 16 + 3);            // per segment: n_out | n_clusters | contested | dropped | 6 x u64 box
+    kres.ensure((size_t)K * 16 + 4);            // per segment: n_out | n_clusters | contested | dropped | 6 x u64 box
     int* const d_ocount = (int*)kres.p;
     unsigned* const d_ncl = kres.p + K;
     unsigned* const d_contested = kres.p + 2 * (size_t)K;
@@ -906,18 +963,11 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     hmsg_scan_u32(cnt.p, start.p, (size_t)NC + 1, s, scan_tmp, nullptr);   // start[NC] = N (end sentinel)
     spts.ensure((size_t)N * 3);
     score.ensure(N);
-    hipLaunchKernelGGL(k_db_fill, dim3(gN), dim3(256), 0, s, src, N, (const long long*)cellid.p, (const unsigned*)start.p, cursor.p,
-                       ord.p, spts.p);       // ord: slot of every point in the cell-sorted copy
     unsigned* const d_nc = kres.p + (size_t)K * 16;
     unsigned* d_nact = d_nc + 1;
-    {
-    ProfScope ps(prof, s, "k_db_core", (double)N * 33.0);
-    hipLaunchKernelGGL(k_db_core, dim3(gN), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const long long*)cellid.p,
-                       (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p, (const double*)spts.p, score.p,
-                       eps * eps, min_points, core.p, minidx.p, corelist.p, d_nc, cellpos.p, parent.p, core0, hasanchor.p, rep.p, active.p, actlist.p,
-                       d_nact, cseg.p, nclist.p);
-    }
-    // persistent grid (8 blocks per CU): waves / threads stride over the core-cell list
+    needy.ensure((size_t)std::max<long long>(N, 1));
+    hipLaunchKernelGGL(k_db_fill, dim3(gN), dim3(256), 0, s, src, N, (const long long*)cellid.p, (const unsigned*)start.p, cursor.p,
+                       ord.p, spts.p, core0, min_points, needy.p, d_nc + 3);       // ord: slot of every point in the cell-sorted copy
     static int n_cu = 0;
     if (!n_cu) {
         hipDeviceProp_t prop;
@@ -926,6 +976,17 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
         HIP_TRY(hipGetDeviceProperties(&prop, dev));
         n_cu = std::max(1, prop.multiProcessorCount);
     }
+    {
+    ProfScope ps(prof, s, "k_db_core", (double)N * 33.0);    // (k_db_count + k_db_core: one timed unit)
+    hipLaunchKernelGGL(k_db_count, dim3((unsigned)n_cu * 8u), dim3(256), 0, s, src, (const int*)segid.p, dsegs, (const long long*)cellid.p,
+                       (const unsigned*)start.p, (const double*)spts.p, eps * eps, min_points, (const unsigned*)needy.p,
+                       (const unsigned*)(d_nc + 3), core.p);
+    hipLaunchKernelGGL(k_db_core, dim3(gN), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const long long*)cellid.p,
+                       (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p, (const double*)spts.p, score.p,
+                       eps * eps, min_points, core.p, minidx.p, corelist.p, d_nc, cellpos.p, parent.p, core0, hasanchor.p, rep.p, active.p, actlist.p,
+                       d_nact, cseg.p, nclist.p);
+    }
+    // persistent grid (8 blocks per CU): waves / threads stride over the core-cell list
     const unsigned gW = (unsigned)n_cu * 8u;
     hipLaunchKernelGGL(k_db_cellbox, dim3(gW), dim3(256), 0, s, (const double*)spts.p, (const int*)corelist.p,
                        (const unsigned*)d_nc, (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p,

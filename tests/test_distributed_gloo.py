@@ -103,7 +103,7 @@ def _episode(n_frames=8):
 def _build(L, frames, window=None):
     """Scene with the whole map; features / masks of frames[window] only (all frames when None)."""
     S = PC.stack_frames(frames)
-    sc = PC.make_scene(L, frames, dict(feat_dim=16, merge_type=1, outlier_nb_points=200))
+    sc = PC.make_scene(L, frames, dict(feat_dim=16, merge_type=1, outlier_nb_points=20, outlier_radius=0.3))
     sc.add_frames(S["rgb"], S["depth"], S["pose"], S["K"])
     sc.finalize_map()
     a, b = window if window is not None else (0, len(frames))

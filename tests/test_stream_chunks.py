@@ -13,7 +13,7 @@ pytestmark = pytest.mark.skipif(not os.path.exists(PC.EMU_PATH), reason="kernel 
 
 def _run(L, frames, chunk):
     S = PC.stack_frames(frames)
-    sc = PC.make_scene(L, frames, dict(feat_dim=16, merge_type=0, outlier_nb_points=200))
+    sc = PC.make_scene(L, frames, dict(feat_dim=16, merge_type=0, outlier_nb_points=20, outlier_radius=0.3))
     n = len(frames)
     for a in range(0, n, chunk):
         b = min(n, a + chunk)
