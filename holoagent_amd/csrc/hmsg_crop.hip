@@ -11,6 +11,8 @@
 // The launch is bound by the HBM WRITE of the crops: 2 M S^2 3 bytes per frame (50 MB at M = 32, S = 512).
 #include "hmsg_common.h"
 
+#include <cmath>
+
 namespace {
 
 struct CropRect {
@@ -175,8 +177,10 @@ extern "C" int hmsg_crop_resize_batch(int32_t device_id, int32_t H, int32_t W, c
                     y = 0;
                 }
             }
-            const long long xi = (long long)x, yi = (long long)y, wi = (long long)w, hi = (long long)h;   // int(): toward zero
             CropRect r{0, 0, 0, 0, v ? m : -1, m, v, 0};
+            const bool finite = std::fabs(x) < 1e15 && std::fabs(y) < 1e15 && std::fabs(w) < 1e15 && std::fabs(h) < 1e15;   // (NaN fails)
+            const long long xi = finite ? (long long)x : -1, yi = finite ? (long long)y : -1, wi = finite ? (long long)w : 0,
+                            hi = finite ? (long long)h : 0;                                                // int(): toward zero
             if (xi >= 0 && yi >= 0 && wi > 0 && hi > 0) {
                 clip_slice(xi, wi, W, r.x0, r.w);
                 clip_slice(yi, hi, H, r.y0, r.h);

@@ -446,6 +446,8 @@ struct Merger {
         pool_used = live;                // (the grid arenas keep their buffers: only their fill level is reset)
         ix_cells_used = ix_pts_used = 0;
         ++n_collects;
+        // an episode whose LIVE clouds alone pass the threshold must not collect on every frame
+        gc_pool_points = std::max(gc_pool_points, (size_t)live * 2);
     }
     size_t gc_pool_points = (size_t)1 << 30;         // 1.07 * 10^9 points = 26 GB
     size_t gc_index_entries = (size_t)1 << 31;       // grid cells (8 GB) / sorted points (26 GB)
