@@ -30,6 +30,34 @@ def test_map_and_fuse_small(L):
     sc.close()
 
 
+def test_four_word_mask_bitsets(L):
+    """Up to 256 masks per frame (4-word bitsets per pixel, NW = 4): frames whose masks are re-cut into 150-200 small
+    overlapping patches; map, per-pixel fusion and the 3-D masks still equal the oracle."""
+    z = GI.load("build_hier")
+    frames = GI.unpack_frames(z)[:3]
+    cfg = GI.unpack_cfg(z)
+    cfg["outlier_nb"] = 300
+    rng = np.random.Generator(np.random.PCG64(77))
+    D = cfg["feat_dim"]
+    for k, f in enumerate(frames):
+        H, W = f["depth"].shape
+        M = 150 + 25 * k                                  # 150, 175, 200: three and four 64-bit words
+        masks = np.zeros((M, H, W), bool)
+        for m in range(M):
+            h, w = int(rng.integers(3, H // 3)), int(rng.integers(3, W // 3))
+            y, x = int(rng.integers(0, H - h)), int(rng.integers(0, W - w))
+            masks[m, y:y + h, x:x + w] = True
+        unit = lambda a: (a / np.linalg.norm(a, axis=-1, keepdims=True)).astype(np.float32)
+        f["masks"] = masks
+        f["f_masked"] = unit(rng.standard_normal((M, D)))
+        f["f_crop"] = unit(rng.standard_normal((M, D)))
+    sc = PC.make_scene(L, frames, dict(feat_dim=D, outlier_nb_points=300))
+    assert sc.cfg.max_masks == 200
+    S, ref_pts, ref_cols = PC.check_map(sc, frames, cfg)
+    PC.check_fuse(sc, frames, S, cfg, ref_pts, ref_cols)
+    sc.close()
+
+
 def test_mask_walk_heavy_voxel_path(L):
     """The wave-per-voxel replay of heavy mask voxels (k_mwalk_heavy: bulk integer additions inside a binade) forced
     on every voxel: still bit-identical."""
