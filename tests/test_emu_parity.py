@@ -58,6 +58,26 @@ def test_four_word_mask_bitsets(L):
     sc.close()
 
 
+def test_frames_without_masks_or_depth(L):
+    """Edge inputs inside an episode: a frame SAM found nothing in (zero masks) and a frame without a single valid depth
+    pixel; the build goes through and map, fusion and 3-D masks equal the oracle."""
+    z = GI.load("build_hier")
+    frames = GI.unpack_frames(z)[:5]
+    cfg = GI.unpack_cfg(z)
+    cfg["outlier_nb"] = 300
+    D = cfg["feat_dim"]
+    H, W = frames[0]["depth"].shape
+    frames[1]["masks"] = np.zeros((0, H, W), bool)
+    frames[1]["f_masked"] = np.zeros((0, D), np.float32)
+    frames[1]["f_crop"] = np.zeros((0, D), np.float32)
+    frames[3]["depth"] = np.zeros_like(frames[3]["depth"])
+    sc = PC.make_scene(L, frames, dict(feat_dim=D, outlier_nb_points=300))
+    S, ref_pts, ref_cols = PC.check_map(sc, frames, cfg)
+    PC.check_fuse(sc, frames, S, cfg, ref_pts, ref_cols)
+    assert sc.frame_num_masks(1) == 0 and all(len(m) == 0 for m in sc.frame_masks3d(3))
+    sc.close()
+
+
 def test_mask_walk_heavy_voxel_path(L):
     """The wave-per-voxel replay of heavy mask voxels (k_mwalk_heavy: bulk integer additions inside a binade) forced
     on every voxel: still bit-identical."""
