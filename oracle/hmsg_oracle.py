@@ -146,13 +146,22 @@ def o3d_remove_radius_outlier(points: np.ndarray, nb_points: int, radius: float)
     return np.nonzero(cnt > nb_points)[0]
 
 
+def _workers(n_queries: int) -> int:
+    """cKDTree worker threads: all cores for big query sets, a few for medium ones, one for small ones (scipy starts a
+    thread per worker and call -- on a 256-thread host that start-up dwarfs a query of a few thousand points; results do
+    not depend on it)."""
+    if n_queries > 200000:
+        return -1
+    return 16 if n_queries > 1500 else 1
+
+
 def faiss_flat_l2_nn_sqdist(queries: np.ndarray, base: np.ndarray) -> np.ndarray:
     """faiss `IndexFlatL2.search(k=1)` distances: exact brute-force squared L2 on float32 data.
     Call site graph_utils.py:645-652."""
     q = queries.astype(np.float32)
     b = base.astype(np.float32)
     tree = cKDTree(b.astype(np.float64))
-    _, nn = tree.query(q.astype(np.float64), k=1, workers=-1)
+    _, nn = tree.query(q.astype(np.float64), k=1, workers=_workers(len(q)))
     d = q - b[nn]
     return (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]   # float32
 
@@ -168,9 +177,9 @@ NN_TIE = "scipy"   # "scipy": cKDTree's own choice among bit-equal distances (tr
 def nn_query(tree: cKDTree, pts: np.ndarray):
     """k=1 nearest neighbour, no distance cap (graph.py:409, generic.py:181, graph.py:458)."""
     if NN_TIE == "scipy" or pts.shape[0] == 0:
-        return tree.query(pts, k=1, workers=-1)
+        return tree.query(pts, k=1, workers=_workers(len(pts)))
     k = min(8 if NN_TIE == "exact" else 4, tree.n)
-    d, i = tree.query(pts, k=k, workers=-1)
+    d, i = tree.query(pts, k=k, workers=_workers(len(pts)))
     if k == 1:
         return d, i
     if NN_TIE == "exact":
