@@ -92,9 +92,9 @@ def test_bench_spawns_its_own_ranks():
 
 
 # ---- config 5 building block: the hierarchical merge tree of ONE episode sharded over the ranks ---------------------
-def _episode(n_frames=8):
+def _episode(n_frames=4):
     from holoagent_amd.synth import SceneSpec, SynthScene
-    spec = SceneSpec(seed=11, rooms_x=1, rooms_z=1, room_size=(3.6, 2.5, 3.2), objects_per_room=4, width=80, height=60,
+    spec = SceneSpec(seed=11, rooms_x=1, rooms_z=1, room_size=(3.6, 2.5, 3.2), objects_per_room=4, width=64, height=48,
                      n_frames=n_frames, n_masks=8, feat_dim=16, yaw_step_deg=25.0)
     scn = SynthScene(spec)
     return [scn.frame(i) for i in range(n_frames)]
