@@ -134,3 +134,45 @@ def test_configs1_full_size_properties(L):
     assert len(a) == len(b) > 100
     for x, y in zip(a, b):
         assert x.shape == y.shape and np.array_equal(x, y)
+
+
+def test_many_masks_and_edge_frames_against_oracle(L):
+    """Three- and four-word mask bitsets (150-200 masks per frame), a frame without masks and a frame without valid depth,
+    on the real device against the oracle (the simulator variants live in tests/test_emu_parity.py)."""
+    from tests import golden_io as GI
+    from tests.test_emu_parity import test_four_word_mask_bitsets, test_frames_without_masks_or_depth
+    assert GI.load("build_hier") is not None
+    test_four_word_mask_bitsets(L)
+    test_frames_without_masks_or_depth(L)
+
+
+def test_fold_collector_is_exact_on_device(L):
+    """Merger::collect (compaction of the fold's point pool, grid arenas reset; used by very long episodes) forced after
+    every frame on a 60-frame device-rendered stream: instances identical to the plain fold, bit for bit."""
+    import torch
+    import bench
+    from holoagent_amd._lib import Scene
+    from holoagent_amd.synth import SceneSpec
+    F, D, M = 60, 64, 32
+    spec = SceneSpec(seed=77, n_frames=F, feat_dim=D, n_masks=M, width=320, height=240)
+    inp = bench.build_scene_inputs(L, spec, torch.device("cuda", 0), torch)
+    out = []
+    for env in ({}, {"HMSG_DEBUG_GC_POINTS": "1"}):
+        os.environ.pop("HMSG_DEBUG_GC_POINTS", None)
+        os.environ.update(env)
+        try:
+            sc = Scene(lib_=L, height=spec.height, width=spec.width, max_frames=F, max_masks=M, feat_dim=D)
+            for a in range(0, F, 25):                                   # chunked hand-over, like the streaming driver
+                b = min(F, a + 25)
+                sc.add_frames(inp["rgb"][a:b], inp["depth"][a:b], inp["pose"][a:b], inp["K"])
+                sc.add_frame_features(a, inp["masks"][a:b], inp["f_g"][a:b], inp["f_masked"][a:b], inp["f_crop"][a:b])
+            sc.finalize_map()
+            sc.fuse_frames()
+            sc.merge_instances()
+            out.append(sc.instances())
+            sc.close()
+        finally:
+            os.environ.pop("HMSG_DEBUG_GC_POINTS", None)
+    assert len(out[0]) == len(out[1]) > 10
+    for x, y in zip(out[0], out[1]):
+        assert np.array_equal(x, y)
