@@ -103,6 +103,7 @@ _SIGS = {
     "hmsg_crop_resize_batch": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, C.c_double, C.c_int32, _P, _P, _P]),
     "hmsg_save_objects": (C.c_int, [_P, C.c_char_p, C.c_int64, _P, C.c_int32]),
     "hmsg_test_format_doubles": (C.c_int64, [_P, C.c_int64, _P, C.c_int64]),
+    "hmsg_index_load_objects": (C.c_int, [C.c_int32, C.c_char_p, C.c_int64, _P, _P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int32)]),
     "hmsg_index_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _P, C.c_int32, _P, C.POINTER(_P)]),
     "hmsg_index_destroy": (None, [_P]),
     "hmsg_index_last_error": (C.c_char_p, [_P]),
@@ -494,6 +495,21 @@ class NodeIndex:
         if rc != 0:
             raise HmsgError(f"hmsg_index_create failed ({rc})")
         self.ix = ix
+
+    @classmethod
+    def load_objects(cls, directory, stems, room_of_node, device_id=0, n_threads=0, lib_: "HmsgLib | None" = None):
+        """The object table of a saved graph (objects/<stem>.json, "embedding" arrays as float64) straight into a resident
+        index (include/hmsg.h: hmsg_index_load_objects)."""
+        L = lib_ or lib()
+        n = len(stems)
+        arr = (C.c_char_p * max(n, 1))(*[str(s_).encode() for s_ in stems])
+        rooms = np.ascontiguousarray(room_of_node, dtype=np.int32)
+        ix, d = _P(), C.c_int32(0)
+        rc = L.c.hmsg_index_load_objects(device_id, str(directory).encode(), n, C.cast(arr, _P), _ptr(rooms), int(n_threads),
+                                         C.byref(ix), C.byref(d))
+        if rc != 0:
+            raise HmsgError(f"hmsg_index_load_objects failed ({rc})")
+        return cls._wrap(L, ix, n, int(d.value))
 
     @classmethod
     def _wrap(cls, L, ix, n, d):

@@ -196,6 +196,106 @@ extern "C" int hmsg_save_objects(hmsg_t* hc, const char* dir, int64_t n, const h
     }
 }
 
+// ---- load side: the object table of a saved graph straight into a retrieval index
+// (object.py:75-91: metadata["embedding"] -> np.array, float64; graph.py:1892-1987 load_hmsg_graph walks the objects/
+//  directory).  The caller lists the objects (file stems, in table order) and their rooms; host threads read
+//  <dir>/<stem>.json, find the "embedding" array and parse its numbers with strtod (correctly rounded: the value Python's
+//  json module yields); the table goes to hmsg_index_create as float64.
+namespace {
+
+// parses a JSON array of numbers starting at p (which points at '['); returns false on anything else
+bool parse_number_array(const char* p, const char* end, std::vector<double>& out) {
+    if (p >= end || *p != '[') return false;
+    ++p;
+    for (;;) {
+        while (p < end && (*p == ' ' || *p == ',' || *p == '\n' || *p == '\t' || *p == '\r')) ++p;
+        if (p >= end) return false;
+        if (*p == ']') return true;
+        if (!strncmp(p, "NaN", 3)) {
+            out.push_back(__builtin_nan(""));
+            p += 3;
+        } else if (!strncmp(p, "Infinity", 8)) {
+            out.push_back(__builtin_inf());
+            p += 8;
+        } else if (!strncmp(p, "-Infinity", 9)) {
+            out.push_back(-__builtin_inf());
+            p += 9;
+        } else {
+            char* q = nullptr;
+            const double v = strtod(p, &q);
+            if (q == p) return false;
+            out.push_back(v);
+            p = q;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int hmsg_index_load_objects(int32_t device_id, const char* dir, int64_t n, const char* const* stems,
+                                       const int32_t* room_of_node, int32_t n_threads, hmsg_index_t** out, int32_t* feat_dim) {
+    if (!dir || n <= 0 || !stems || !room_of_node || !out) return HMSG_ERR_INVALID;
+    *out = nullptr;
+    std::vector<std::vector<double>> rows((size_t)n);
+    std::atomic<int64_t> next{0};
+    std::atomic<int> failed{0};
+    const std::string base = std::string(dir) + "/";
+    auto work = [&]() {
+        std::string text;
+        for (;;) {
+            const int64_t i = next.fetch_add(1);
+            if (i >= n || failed.load()) return;
+            FILE* f = stems[i] ? fopen((base + stems[i] + ".json").c_str(), "rb") : nullptr;
+            if (!f) {
+                failed.store(1);
+                return;
+            }
+            fseek(f, 0, SEEK_END);
+            const long len = ftell(f);
+            fseek(f, 0, SEEK_SET);
+            text.resize((size_t)std::max<long>(len, 0));
+            const bool ok = len >= 0 && fread(&text[0], 1, (size_t)len, f) == (size_t)len;
+            fclose(f);
+            // (the key cannot occur inside another value: ids, names and view lists are the only strings of a record)
+            const size_t k = ok ? text.find("\"embedding\":") : std::string::npos;
+            if (k == std::string::npos) {
+                failed.store(2);
+                return;
+            }
+            const char* p = text.data() + k + 12;
+            const char* end = text.data() + text.size();
+            while (p < end && *p == ' ') ++p;
+            if (!parse_number_array(p, end, rows[(size_t)i])) {     // "" (an object saved without an embedding) lands here
+                failed.store(2);
+                return;
+            }
+        }
+    };
+    int nt = n_threads > 0 ? n_threads : (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+    nt = (int)std::min<int64_t>(nt, n);
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    if (failed.load()) {
+        fprintf(stderr, "hmsg_index_load_objects: %s under %s\n",
+                failed.load() == 1 ? "an object record cannot be opened" : "an object record has no numeric \"embedding\" array", dir);
+        return HMSG_ERR_INVALID;
+    }
+    const size_t D = rows[0].size();
+    if (D == 0) return HMSG_ERR_INVALID;
+    std::vector<double> table((size_t)n * D);
+    for (int64_t i = 0; i < n; ++i) {
+        if (rows[(size_t)i].size() != D) {
+            fprintf(stderr, "hmsg_index_load_objects: embeddings of different lengths (%zu and %zu)\n", D, rows[(size_t)i].size());
+            return HMSG_ERR_INVALID;
+        }
+        memcpy(&table[(size_t)i * D], rows[(size_t)i].data(), D * 8);
+    }
+    if (feat_dim) *feat_dim = (int32_t)D;
+    return hmsg_index_create(device_id, (int32_t)D, n, table.data(), 1, room_of_node, out);
+}
+
 // test hook: Python-repr formatting of doubles, newline separated (tests/test_persist_golden.py compares with repr())
 extern "C" int64_t hmsg_test_format_doubles(const double* v, int64_t n, char* out, int64_t cap) {
     int64_t used = 0;

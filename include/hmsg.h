@@ -233,6 +233,13 @@ typedef struct {
     const char* best_view_id_json;
 } hmsg_object_record;
 int hmsg_save_objects(hmsg_t* h, const char* dir, int64_t n, const hmsg_object_record* recs, int32_t n_threads);
+/* N2, load side: the object table of a saved graph straight into a retrieval index.  For every stem <dir>/<stem>.json is
+ * read and its "embedding" array parsed as float64 (object.py:75-91 load; graph.py:1892-1987 load_hmsg_graph), rows in
+ * the order given; room_of_node as for hmsg_index_create (declared below).  feat_dim (optional) receives the row length.
+ * HMSG_ERR_INVALID when a record is missing, has no numeric embedding (saved as "") or the lengths differ. */
+struct hmsg_index;
+int hmsg_index_load_objects(int32_t device_id, const char* dir, int64_t n, const char* const* stems,
+                            const int32_t* room_of_node, int32_t n_threads, struct hmsg_index** out, int32_t* feat_dim);
 /* test hook: Python-repr text of n doubles, newline separated, into out[cap]; returns bytes written or -1 */
 int64_t hmsg_test_format_doubles(const double* v, int64_t n, char* out, int64_t cap);
 

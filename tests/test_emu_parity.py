@@ -180,6 +180,19 @@ def test_graph_end_to_end_tiny(L, tmp_path):
     g2.load_hmsg_graph(str(tmp_path / "graph"))
     assert len(g2.objects) == len(g.objects) and len(g2.rooms) == 1
     if g2.objects:
+        # N2, load side: the saved object records parsed by the library straight into a resident index
+        from holoagent_amd._lib import HmsgError, NodeIndex
+        rid = {r.room_id: i for i, r in enumerate(g2.rooms)}
+        ixl = NodeIndex.load_objects(str(tmp_path / "graph" / "objects"), [o.object_id for o in g2.objects],
+                                     [rid[o.room_id] for o in g2.objects], lib_=L)
+        assert (ixl.N, ixl.D) == (len(g2.objects), 32)
+        Tq = g2.get_text_feats_multiple_templates(["chair", "background"])[None]
+        a = ixl.query_objects(Tq, np.zeros(1, np.int32), [[0]], 3)
+        b = g2._node_index().query_objects(Tq, np.zeros(1, np.int32), [[0]], 3)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])
+        ixl.close()
+        with pytest.raises(HmsgError):
+            NodeIndex.load_objects(str(tmp_path / "graph" / "objects"), ["no_such_object"], [0], lib_=L)
         fl, rooms2, objs, res = g2.query_hierarchy_protected_icra((None, "office", "chair"), top_k=3)
         emb = np.stack([o.embedding for o in g2.objects])
         T = g2.get_text_feats_multiple_templates(["chair", "background"])
