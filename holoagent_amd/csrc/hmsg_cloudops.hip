@@ -1211,3 +1211,53 @@ long long CloudOps::voxel_down_sample(const double* src, const std::vector<SegDe
     for (int k = 0; k < K; ++k) out_n[k] = (int)(startv[k + 1] - startv[k]);
     return P;
 }
+
+// ---- test hook (include/hmsg.h: hmsg_test_dbscan): the segmented keep-largest DBSCAN on caller-supplied clouds ------
+extern "C" int hmsg_test_dbscan(const double* pts, int32_t K, const int64_t* sizes, double eps, int32_t min_points,
+                                const uint8_t* core0, double* out_pts, int64_t* out_sizes, uint8_t* out_core, int32_t* out_info) {
+    if (K < 0 || (K > 0 && (!sizes || !out_sizes)) || eps <= 0 || min_points <= 0) return HMSG_ERR_INVALID;
+    hipStream_t s = nullptr;
+    int rc = HMSG_OK;
+    try {
+        HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        {
+            CloudOps ops;
+            ops.s = s;
+            std::vector<SegDesc> segs((size_t)K);
+            long long N = 0;
+            for (int k = 0; k < K; ++k) {
+                segs[k].pt_base = N;
+                segs[k].n = (int)sizes[k];
+                N += sizes[k];
+            }
+            DevBuf<double> d_src, d_dst;
+            DevBuf<unsigned char> d_c0, d_oc;
+            d_src.alloc((size_t)std::max<long long>(N, 1) * 3);
+            d_dst.alloc((size_t)std::max<long long>(N, 1) * 3);
+            d_c0.alloc((size_t)std::max<long long>(N, 1));
+            d_oc.alloc((size_t)std::max<long long>(N, 1));
+            if (N) HIP_TRY(hipMemcpyAsync(d_src.p, pts, (size_t)N * 24, hipMemcpyHostToDevice, s));
+            if (N && core0) HIP_TRY(hipMemcpyAsync(d_c0.p, core0, (size_t)N, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            ops.bounds(d_src.p, segs);
+            std::vector<DbscanResult> res;
+            const long long total = ops.dbscan_keep_largest(d_src.p, segs, eps, min_points, d_dst.p, res, core0 ? d_c0.p : nullptr, d_oc.p);
+            if (total && out_pts) HIP_TRY(hipMemcpyAsync(out_pts, d_dst.p, (size_t)total * 24, hipMemcpyDeviceToHost, s));
+            if (total && out_core) HIP_TRY(hipMemcpyAsync(out_core, d_oc.p, (size_t)total, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            for (int k = 0; k < K; ++k) {
+                out_sizes[k] = res[(size_t)k].n_out;
+                if (out_info) {
+                    out_info[k * 3] = res[(size_t)k].changed;
+                    out_info[k * 3 + 1] = res[(size_t)k].n_clusters;
+                    out_info[k * 3 + 2] = res[(size_t)k].contested;
+                }
+            }
+        }
+    } catch (const hmsg_error& e) {
+        fprintf(stderr, "hmsg_test_dbscan: %s\n", e.msg.c_str());
+        rc = e.code;
+    }
+    if (s) (void)hipStreamDestroy(s);
+    return rc;
+}

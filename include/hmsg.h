@@ -240,6 +240,12 @@ int hmsg_save_objects(hmsg_t* h, const char* dir, int64_t n, const hmsg_object_r
 struct hmsg_index;
 int hmsg_index_load_objects(int32_t device_id, const char* dir, int64_t n, const char* const* stems,
                             const int32_t* room_of_node, int32_t n_threads, struct hmsg_index** out, int32_t* feat_dim);
+/* test hook: the segmented keep-largest DBSCAN (pcd_denoise_dbscan, graph_utils.py:827-880) on K caller-supplied clouds
+ * (sizes[k] points each, concatenated in pts; host pointers).  core0 (optional, one byte per point): anchor hint as the
+ * merge fold passes it.  out_pts (capacity = all points), out_sizes [K], out_core (core flag per kept point), out_info
+ * [K][3] = changed, clusters found, contested. */
+int hmsg_test_dbscan(const double* pts, int32_t K, const int64_t* sizes, double eps, int32_t min_points, const uint8_t* core0,
+                     double* out_pts, int64_t* out_sizes, uint8_t* out_core, int32_t* out_info);
 /* test hook: Python-repr text of n doubles, newline separated, into out[cap]; returns bytes written or -1 */
 int64_t hmsg_test_format_doubles(const double* v, int64_t n, char* out, int64_t cap);
 
