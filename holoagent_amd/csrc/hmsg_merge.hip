@@ -296,10 +296,14 @@ struct Merger {
     DevBuf<double> concat;
     DevBuf<unsigned char> concat_core;
     DevBuf<OvGrid> d_grids;
-    DevBuf<OvTask> d_tasks;
-    DevBuf<unsigned> d_counts, d_cursor;
+    DevBuf<unsigned> d_cursor;
     DevBuf<CatSeg> d_cat;
     PinnedBuf<unsigned> h_counts;
+    // one packed upload per overlap step: [grids | tasks | zeroed counts], staged in pinned memory (the previous step's
+    // copy has completed: every overlap step ends with a wait on the stream)
+    PinnedBuf<char> h_ovpack;
+    DevBuf<char> d_ovpack;
+    size_t cursor_clean = 0;        // entries of d_cursor known to be zero (k_ov_fill counts every cell back down to zero)
     SpinWait spin;
     unsigned long long next_uid = 1;
     std::unordered_map<unsigned long long, double> ratio_cache;   // hierarchical merge only
@@ -375,8 +379,15 @@ struct Merger {
         d_grids.ensure(g.size());
         HIP_TRY(hipMemcpyAsync(d_grids.p, g.data(), g.size() * sizeof(OvGrid), hipMemcpyHostToDevice, s));
         unsigned* cells = ix_cells.p + ix_cells_used;
-        d_cursor.ensure((size_t)ncell_new);
-        HIP_TRY(hipMemsetAsync(d_cursor.p, 0, (size_t)ncell_new * 4, s));
+        {   // the cursor is zero whenever k_ov_fill has run over what k_ov_count counted: only fresh memory is cleared
+            const unsigned* before = d_cursor.p;
+            d_cursor.ensure((size_t)ncell_new);
+            if (d_cursor.p != before) cursor_clean = 0;
+            if (cursor_clean < (size_t)ncell_new) {
+                HIP_TRY(hipMemsetAsync(d_cursor.p, 0, d_cursor.n * 4, s));
+                cursor_clean = d_cursor.n;
+            }
+        }
         hipLaunchKernelGGL(k_ov_count, dim3(nblk), dim3(256), 0, s, (const double*)pool.p, (const OvGrid*)d_grids.p, (int)g.size(),
                            d_cursor.p, ix_cells_used);
         HMSG_CHECK_LAUNCH();
@@ -480,12 +491,17 @@ struct Merger {
             nblk1 += cdiv((size_t)L[a].n, OV_CHUNK);
             nblk2 += cdiv((size_t)L[b].n, OV_CHUNK);
         }
-        d_grids.ensure(g.size());
-        d_tasks.ensure(tasks.size());
-        d_counts.ensure(tasks.size());
-        HIP_TRY(hipMemcpyAsync(d_grids.p, g.data(), g.size() * sizeof(OvGrid), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(d_tasks.p, tasks.data(), tasks.size() * sizeof(OvTask), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemsetAsync(d_counts.p, 0, tasks.size() * 4, s));
+        const size_t off_t = (g.size() * sizeof(OvGrid) + 15) & ~(size_t)15, off_c = off_t + tasks.size() * sizeof(OvTask),
+                     pack = off_c + tasks.size() * 4;
+        h_ovpack.ensure(pack);
+        d_ovpack.ensure(pack);
+        memcpy(h_ovpack.p, g.data(), g.size() * sizeof(OvGrid));
+        memcpy(h_ovpack.p + off_t, tasks.data(), tasks.size() * sizeof(OvTask));
+        memset(h_ovpack.p + off_c, 0, tasks.size() * 4);
+        HIP_TRY(hipMemcpyAsync(d_ovpack.p, h_ovpack.p, pack, hipMemcpyHostToDevice, s));
+        const OvGrid* const dg = (const OvGrid*)d_ovpack.p;
+        const OvTask* const dt = (const OvTask*)(d_ovpack.p + off_t);
+        unsigned* const dc = (unsigned*)(d_ovpack.p + off_c);
         const float r = (float)radius;
         const float r2 = (float)(radius * radius);   // `D < radius**2` with a float32 D (graph_utils.py:654-655)
         const size_t prof_idx = h->prof.ev.size();          // (algorithmic bytes are filled in after the read-back)
@@ -495,16 +511,15 @@ struct Merger {
                 const unsigned nb = dir ? nblk2 : nblk1;
                 if (!nb) continue;
                 const size_t o = (size_t)dir * P;
-                hipLaunchKernelGGL(k_ov_query, dim3(nb), dim3(256), 0, s, (const double*)pool.p, (const OvGrid*)d_grids.p,
-                                   (const OvTask*)(d_tasks.p + o), (const unsigned*)ix_cells.p, (const float*)ix_pts.p, r2, r, (int)P,
-                                   d_counts.p + o, (dir && decide_th >= 0.0) ? (const unsigned*)d_counts.p : (const unsigned*)nullptr,
-                                   decide_th);
+                hipLaunchKernelGGL(k_ov_query, dim3(nb), dim3(256), 0, s, (const double*)pool.p, dg, dt + o,
+                                   (const unsigned*)ix_cells.p, (const float*)ix_pts.p, r2, r, (int)P, dc + o,
+                                   (dir && decide_th >= 0.0) ? (const unsigned*)dc : (const unsigned*)nullptr, decide_th);
             }
         }
         HMSG_CHECK_LAUNCH();
         h_counts.ensure(tasks.size());
         unsigned* hc = h_counts.p;
-        HIP_TRY(hipMemcpyAsync(hc, d_counts.p, tasks.size() * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(hc, dc, tasks.size() * 4, hipMemcpyDeviceToHost, s));
         spin.wait(s);
         double ov_work = 0;                                  // 12 B per point of every scan the decision needed
         for (size_t k = 0; k < P; ++k) {
