@@ -163,7 +163,6 @@ __global__ void __launch_bounds__(256) k_db_count(const double* __restrict__ pts
                                                   int minpts, const unsigned* __restrict__ needy,
                                                   const unsigned* __restrict__ n_needy, unsigned char* __restrict__ core) {
     const int lane = threadIdx.x & 63;
-    (void)__ballot(1);                                       // (keeps the kernel simulator's launch classification stable)
     const unsigned nwaves = (gridDim.x * blockDim.x) >> 6, n = *n_needy;
     for (unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
         const long long i = needy[w];
@@ -283,7 +282,6 @@ __global__ void k_db_core(const double* __restrict__ pts, long long N, const int
 __global__ void k_db_anchor_min(const int* __restrict__ corecells, const unsigned* __restrict__ ncore,
                                 const int* __restrict__ cseg, const DbSeg* __restrict__ segs, int K, const unsigned char* __restrict__ hasanchor,
                                 unsigned* __restrict__ rep) {
-    (void)__ballot(1);      // (simulator: wave collectives below sit in loops over device-side counts)
     const unsigned n = *ncore;
     const unsigned stride = gridDim.x * blockDim.x;
     for (unsigned w0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); w0 < n; w0 += stride) {
@@ -372,7 +370,6 @@ __global__ void k_db_cellbox(const double* __restrict__ pts, const int* __restri
                              const unsigned* __restrict__ cnt, const unsigned* __restrict__ start, const unsigned* __restrict__ ord,
                              const unsigned char* __restrict__ core, double* __restrict__ cellbox,
                              unsigned* __restrict__ ccore) {
-    (void)__ballot(1);      // (simulator: wave collectives below sit in loops over device-side counts)
     const int lane = threadIdx.x & 63;
     const unsigned nwaves = (gridDim.x * blockDim.x) >> 6, ncells = *ncore;
     for (unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < ncells; w += nwaves) {
@@ -458,7 +455,6 @@ __global__ void k_db_union_scan(const double* __restrict__ pts, const int* __res
                                 const unsigned* __restrict__ minidx, double eps2, const int* __restrict__ cellpos,
                                 const double* __restrict__ cellbox, int* __restrict__ parent,
                                 const unsigned* __restrict__ active) {
-    (void)__ballot(1);      // (simulator: wave collectives below sit in loops over device-side counts)
     const int lane = threadIdx.x & 63;
     const unsigned nwaves = (gridDim.x * blockDim.x) >> 6, ncells = *ncore;
     for (unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < ncells; w += nwaves) {
@@ -549,7 +545,6 @@ __global__ void k_db_rootmin(const int* __restrict__ corecells, const unsigned* 
                              const unsigned* __restrict__ minidx, unsigned* __restrict__ rootmin,
                              const int* __restrict__ cseg, const DbSeg* __restrict__ segs, int K,
                              unsigned* __restrict__ ncl, const unsigned* __restrict__ ccore, unsigned* __restrict__ size) {
-    (void)__ballot(1);      // (simulator: wave collectives below sit in loops over device-side counts)
     const unsigned n = *ncore;
     const unsigned stride = gridDim.x * blockDim.x;
     // wave-uniform trip count; one atomic per (wave, root): a cluster's cells all target the same word
@@ -603,7 +598,6 @@ __global__ void k_db_label(const double* __restrict__ pts, const int* __restrict
                            const unsigned* __restrict__ ncl, double eps2, int* __restrict__ label, unsigned* __restrict__ size,
                            unsigned* __restrict__ firstidx, unsigned* __restrict__ contested, const unsigned* __restrict__ nclist,
                            const unsigned* __restrict__ n_noncore) {
-    (void)__ballot(1);      // (simulator: wave collectives below sit in loops over device-side counts)
     // Border search for the NON-CORE points only (compact list from k_db_core; a core point's label is simply the
     // root of its cell, k_db_flags looks it up itself).  One WAVE per point, one LANE per neighbour cell (125 cells
     // in two rounds): a lane decides its cell -- core cell? tight box of its core points in reach? a core point

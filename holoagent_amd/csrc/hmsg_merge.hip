@@ -39,11 +39,15 @@ struct Cloud {
     double mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
     bool fixed = false;     // pcd_denoise_dbscan(merge eps/min) is known to return it unchanged
     bool fresh = true;      // new or changed since it last went through merge_3d_masks
+    bool raw = false;       // a frame mask that has not been through a DBSCAN yet (statistics only)
     bool anchor = false;    // fixed AND one single cluster, with its core flags persisted next to the pool points:
                             // usable as the pre-connected anchor of the next DBSCAN it takes part in
     unsigned long long uid = 0;
+    unsigned id = 0;        // incremental fold: cloud id in the persistent index
+    int cap = 0;            // incremental fold: room of the cloud's pool region (points)
     // overlap grid (cell side >= r): cellstart[ncell+1] (absolute positions) + cell-sorted float32 points
     bool has_index = false;
+    bool has_index_before = false;   // (statistics)
     long long ix_cell = 0, ix_pt = 0;
     int gd[3] = {0, 0, 0};
 };
@@ -315,6 +319,17 @@ struct Merger {
     int minpts = 10;
     double iou_thresh = 0.05;
     double tphase[6] = {0, 0, 0, 0, 0, 0};   // host wall time per phase (HMSG_DEBUG_TIMING)
+    // HMSG_DEBUG_MERGESTATS: what a fold step is made of (sums over the fold)
+    struct Stats {
+        double steps = 0, clouds = 0, fresh_raw = 0, fresh_g = 0, pairs_raw = 0, pairs_g = 0;
+        double scan1_raw = 0, scan2_raw = 0, scan1_g = 0, scan2_g = 0;      // points scanned, by direction and pair class
+        double idx_pts = 0;                                                 // points (re)indexed
+        // components that go through DBSCAN, by class: 0 singleton raw, 1 singleton non-fixed, 2 anchor first + raw rest
+        // (|A| > |B|), 3 anchor first + any rest (|A| > |B|), 4 other
+        double ccount[5] = {0, 0, 0, 0, 0}, cpts[5] = {0, 0, 0, 0, 0}, cB[5] = {0, 0, 0, 0, 0}, cmem[5] = {0, 0, 0, 0, 0};
+        double cchanged[5] = {0, 0, 0, 0, 0}, cmulti[5] = {0, 0, 0, 0, 0}, ccontested[5] = {0, 0, 0, 0, 0}, cnonfixed[5] = {0, 0, 0, 0, 0};
+    } st;
+    bool want_stats = false;
 
     template <typename T>
     void grow(DevBuf<T>& b, size_t used_elems, size_t need_elems) {
@@ -469,8 +484,9 @@ struct Merger {
     // is needed downstream, so the pair's smaller cloud is counted first and the scan of the larger one is skipped on
     // the device when the first ratio already exceeds the threshold (its entry then reports the first ratio).
     void overlap_ratios(const std::vector<Cloud>& L, const std::vector<std::pair<int, int>>& pairs, std::vector<double>& ratio,
-                        double decide_th) {
+                        double decide_th, std::vector<unsigned char>* second_ran = nullptr) {
         ratio.assign(pairs.size(), 0.0);
+        if (second_ran) second_ran->assign(pairs.size(), 0);
         if (pairs.empty()) return;
         const size_t P = pairs.size();
         // compact table of the clouds involved
@@ -526,28 +542,19 @@ struct Merger {
             const int na = std::min(L[pairs[k].first].n, L[pairs[k].second].n), nb = std::max(L[pairs[k].first].n, L[pairs[k].second].n);
             ratio[k] = std::max((double)hc[k] / (double)na, (double)hc[P + k] / (double)nb);
             ov_work += 12.0 * na;
-            if (!(decide_th >= 0.0 && (double)hc[k] / (double)na > decide_th)) ov_work += 12.0 * nb;
+            if (!(decide_th >= 0.0 && (double)hc[k] / (double)na > decide_th)) {
+                ov_work += 12.0 * nb;
+                if (second_ran) (*second_ran)[k] = 1;
+            }
         }
         if (h->prof.enabled && prof_idx < h->prof.ev.size()) h->prof.ev[prof_idx].work = ov_work;
     }
 
-    // ---- merge_3d_masks (graph_utils.py:918-956)
-    std::vector<Cloud> merge_3d_masks(std::vector<Cloud> L, double th) {
+    // ---- candidate pairs of merge_3d_masks (graph_utils.py:937-941): AABB IoU above the threshold; sequential merge:
+    // only pairs with a new or changed member (shortcut 2); hierarchical merge: cached ratios of unchanged pairs
+    void find_pairs(const std::vector<Cloud>& L, std::vector<std::pair<int, int>>& pairs, std::vector<double>& known,
+                    std::vector<std::pair<int, int>>& known_pairs) {
         const int n = (int)L.size();
-        if (n == 0) return L;
-        auto tnow = [] { return std::chrono::steady_clock::now(); };
-        auto t0 = tnow();
-        auto lap = [&](int k) {
-            auto t1 = tnow();
-            tphase[k] += std::chrono::duration<double, std::milli>(t1 - t0).count();
-            t0 = t1;
-        };
-        build_indices(L);
-        lap(0);
-        // 1. candidate pairs
-        std::vector<std::pair<int, int>> pairs;
-        std::vector<double> known;                 // cached ratios (hierarchical)
-        std::vector<std::pair<int, int>> known_pairs;
         auto consider = [&](int i, int j) {
             if (L[i].n == 0 || L[j].n == 0) return;   // find_overlapping_ratio_faiss returns 0 for empty clouds
             if (!(bbox_iou(L[i], L[j]) > iou_thresh)) return;
@@ -598,11 +605,13 @@ struct Merger {
                 }
             }
         }
-        std::vector<double> ratio;
-        lap(1);
-        overlap_ratios(L, pairs, ratio, use_cache ? -1.0 : th);
-        lap(2);
-        // 2. components of `overlap > th` (scipy connected_components labels by lowest member index)
+    }
+
+    // ---- components of `overlap > th` (scipy connected_components labels by lowest member index)
+    void make_components(const std::vector<Cloud>& L, const std::vector<std::pair<int, int>>& pairs, const std::vector<double>& ratio,
+                         const std::vector<std::pair<int, int>>& known_pairs, const std::vector<double>& known, double th,
+                         CompList& comps) {
+        const int n = (int)L.size();
         std::vector<int> parent(n);
         std::iota(parent.begin(), parent.end(), 0);
         auto find = [&](int x) {
@@ -621,7 +630,6 @@ struct Merger {
         for (size_t k = 0; k < known_pairs.size(); ++k)
             if (known[k] > th) unite(known_pairs[k].first, known_pairs[k].second);
         // (flat CSR: thousands of clouds per step, nearly all singletons -- no per-component allocations)
-        CompList comps;
         {
             std::vector<int> comp_of(n, -1), cid(n);
             int nc = 0;
@@ -637,6 +645,53 @@ struct Merger {
             std::vector<int> cur(comps.off.begin(), comps.off.end() - 1);
             for (int i = 0; i < n; ++i) comps.mem[cur[cid[i]]++] = i;
         }
+    }
+
+    // ---- merge_3d_masks (graph_utils.py:918-956)
+    std::vector<Cloud> merge_3d_masks(std::vector<Cloud> L, double th) {
+        const int n = (int)L.size();
+        if (n == 0) return L;
+        auto tnow = [] { return std::chrono::steady_clock::now(); };
+        auto t0 = tnow();
+        auto lap = [&](int k) {
+            auto t1 = tnow();
+            tphase[k] += std::chrono::duration<double, std::milli>(t1 - t0).count();
+            t0 = t1;
+        };
+        if (want_stats)
+            for (auto& c : L) c.has_index_before = c.has_index;
+        build_indices(L);
+        lap(0);
+        // 1. candidate pairs
+        std::vector<std::pair<int, int>> pairs;
+        std::vector<double> known;                 // cached ratios (hierarchical)
+        std::vector<std::pair<int, int>> known_pairs;
+        find_pairs(L, pairs, known, known_pairs);
+        std::vector<double> ratio;
+        lap(1);
+        std::vector<unsigned char> second_ran;
+        overlap_ratios(L, pairs, ratio, use_cache ? -1.0 : th, want_stats ? &second_ran : nullptr);
+        lap(2);
+        if (want_stats) {
+            st.steps += 1;
+            st.clouds += n;
+            for (int i = 0; i < n; ++i) {
+                if (L[i].fresh && L[i].raw) st.fresh_raw += 1;
+                if (L[i].fresh && !L[i].raw) st.fresh_g += 1;
+                if (!L[i].has_index_before) st.idx_pts += L[i].n;
+            }
+            for (size_t k = 0; k < pairs.size(); ++k) {
+                const Cloud &a = L[pairs[k].first], &b = L[pairs[k].second];
+                const bool g = (a.fresh && !a.raw) || (b.fresh && !b.raw);       // a changed G cloud is involved
+                const double n1 = std::min(a.n, b.n), n2 = second_ran[k] ? std::max(a.n, b.n) : 0;
+                (g ? st.pairs_g : st.pairs_raw) += 1;
+                (g ? st.scan1_g : st.scan1_raw) += n1;
+                (g ? st.scan2_g : st.scan2_raw) += n2;
+            }
+        }
+        // 2. components of `overlap > th`
+        CompList comps;
+        make_components(L, pairs, ratio, known_pairs, known, th, comps);
         // 3. merge_point_clouds_list per component: concat in index order + keep-largest DBSCAN
         std::vector<int> seg_of_comp(comps.size(), -1);
         std::vector<SegDesc> segs;
@@ -685,7 +740,36 @@ struct Merger {
             ops.dbscan_keep_largest(concat.p, segs, eps, minpts, pool.p + (size_t)pool_used * 3, res,
                                     use_anchor ? (const unsigned char*)concat_core.p : nullptr, poolcore.p + pool_used);
             lap(4);
-            if (getenv("HMSG_DEBUG_MERGESTATS")) {
+            if (want_stats) {
+                for (size_t c = 0; c < comps.size(); ++c) {
+                    if (seg_of_comp[c] < 0) continue;
+                    const auto& mem = comps[c];
+                    const DbscanResult& r = res[seg_of_comp[c]];
+                    long long tot = 0, rest = 0;
+                    bool rest_raw = true;
+                    for (size_t q = 0; q < mem.size(); ++q) {
+                        tot += L[mem[q]].n;
+                        if (q) {
+                            rest += L[mem[q]].n;
+                            rest_raw = rest_raw && L[mem[q]].raw;
+                        }
+                    }
+                    int cls;
+                    if (mem.size() == 1) cls = L[mem[0]].raw ? 0 : 1;
+                    else if (L[mem[0]].anchor && L[mem[0]].n > rest) cls = rest_raw ? 2 : 3;
+                    else cls = 4;
+                    st.ccount[cls] += 1;
+                    st.cpts[cls] += tot;
+                    st.cB[cls] += mem.size() == 1 ? tot : rest;
+                    st.cmem[cls] += mem.size();
+                    st.cchanged[cls] += r.changed;
+                    st.cmulti[cls] += r.n_clusters > 1;
+                    st.ccontested[cls] += r.contested != 0;
+                    const bool fx = !r.changed || r.n_clusters == 1 || (r.n_clusters > 1 && !r.contested);
+                    st.cnonfixed[cls] += !fx;
+                }
+            }
+            if (getenv("HMSG_DEBUG_MERGESTATS_STEP")) {
                 long long fixed_pts = 0, big_fixed = 0, removed = 0;
                 int nchanged = 0, multi = 0, multicl = 0, multicl_changed = 0;
                 long long multicl_pts = 0;
@@ -734,6 +818,7 @@ struct Merger {
                 Cloud k = L[mem[0]];
                 k.fresh = false;
                 k.fixed = true;
+                k.raw = false;
                 k.off = cursor;                 // the identical copy DBSCAN just wrote: it carries the core flags
                 k.anchor = r.n_clusters == 1;
                 out.push_back(k);
@@ -769,6 +854,8 @@ struct Merger {
 
 }  // namespace
 
+#include "hmsg_fold.inl"
+
 namespace {
 
 void merger_init(Merger& m, hmsg_ctx* h) {
@@ -783,11 +870,12 @@ void merger_init(Merger& m, hmsg_ctx* h) {
     m.minpts = c.merge_dbscan_min;
     m.iou_thresh = c.iou_thresh;
     m.use_anchor = !getenv("HMSG_DEBUG_NOANCHOR");
+    m.want_stats = getenv("HMSG_DEBUG_MERGESTATS") != nullptr;
     HMSG_REQUIRE(c.iou_thresh >= 0.0, HMSG_ERR_UNSUPPORTED, "pipeline.iou_thresh must be >= 0");
 }
 
 // the frames' 3-D masks as per-frame cloud lists over a pool seeded with them (frames first .. n_fused-1)
-std::vector<std::vector<Cloud>> seed_frames(Merger& m, hmsg_ctx* h, int first) {
+std::vector<std::vector<Cloud>> seed_frames(Merger& m, hmsg_ctx* h, int first, bool legacy_grids = true) {
     const int F = h->n_fused;
     const long long total = h->masks3d.total;
     m.pool.alloc((size_t)std::max<long long>(total * 2, 1 << 16) * 3);
@@ -815,6 +903,7 @@ std::vector<std::vector<Cloud>> seed_frames(Merger& m, hmsg_ctx* h, int first) {
             Cloud& k = fr.back();
             k.off = sd.pt_base;
             k.n = sd.n;
+            k.raw = true;
             k.uid = m.next_uid++;
             for (int a = 0; a < 3; ++a) {
                 k.mn[a] = sd.mn[a];
@@ -824,6 +913,7 @@ std::vector<std::vector<Cloud>> seed_frames(Merger& m, hmsg_ctx* h, int first) {
     }
     // overlap grids of ALL frame masks in one batch (they are inputs of the fold; only clouds that change during
     // the fold get a new grid later)
+    if (!legacy_grids) return frames;
     if (h->cfg.merge_type == HMSG_MERGE_HIERARCHICAL || first != 0) {
         for (size_t a = 0; a < frames.size(); a += Merger::PREBUILD_WINDOW) m.prebuild(frames, a, a + Merger::PREBUILD_WINDOW);
     } else {
@@ -870,11 +960,67 @@ double next_level_threshold(double th, double factor, long long lists) {
 
 }  // namespace
 
+// seq_merge (graph_utils.py:1015-1038) as the incremental fold of hmsg_fold.inl.  false: configuration outside what the
+// fold index supports (the caller runs the batch fold).
+static bool hmsg_fold_sequential(hmsg_ctx* h) {
+    const hmsg_config& c = h->cfg;
+    Folder m;
+    merger_init(m, h);
+    const double cs = m.eps / std::sqrt(3.0) * (1.0 - 1e-7);
+    if (!(m.radius + 1e-4 < 1.9 * cs) || h->masks3d.total >= (1ll << 30)) return false;
+    std::vector<std::vector<Cloud>> frames = seed_frames(m, h, 0, false);
+    const int F = h->n_fused;
+    // lattice over the box of all masks; every mask indexed under its own id, in one batch
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    std::vector<FInsSeg> segs;
+    long long n_masks = 0;
+    for (auto& fr : frames)
+        for (auto& k : fr) {
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = std::min(lo[a], k.mn[a]);
+                hi[a] = std::max(hi[a], k.mx[a]);
+            }
+            if (m.next_id >= (1u << 24)) return false;
+            k.id = m.next_id++;
+            k.cap = k.n;
+            segs.push_back(FInsSeg{k.off, k.id, k.n, 0, 0, 0, 0});
+            ++n_masks;
+        }
+    if (n_masks == 0) {
+        store_instances(m, h, std::vector<Cloud>(), c.min_instance_points);
+        h->merged = true;
+        return true;
+    }
+    m.index_init(h->masks3d.total, n_masks, lo, hi);
+    m.index_bulk(segs);
+    std::vector<Cloud> G = std::move(frames[0]);
+    for (int f = 1; f < F; ++f) {
+        G.insert(G.end(), frames[(size_t)f].begin(), frames[(size_t)f].end());
+        std::vector<Cloud>().swap(frames[(size_t)f]);
+        G = m.fold_step(std::move(G), c.init_overlap_thresh);
+    }
+    std::vector<Cloud> result = m.fold_step(std::move(G), c.init_overlap_thresh);
+    store_instances(m, h, result, c.min_instance_points);
+    if (getenv("HMSG_DEBUG_TIMING")) {
+        fprintf(stderr, "[hmsg fold] pairs(host) %.1f  overlap %.1f  tables %.1f  step kernels %.1f  bookkeeping %.1f ms\n", m.tphase[1],
+                m.tphase[2], m.tphase[3], m.tphase[4], m.tphase[5]);
+        fprintf(stderr, "[hmsg fold] steps %.0f  components: anchor %.0f  plain %.0f  batch %.0f   active points %.0f  relocated %.0f   ids %u\n",
+                m.fstat[0], m.fstat[1], m.fstat[2], m.fstat[3], m.fstat[4], m.fstat[5], m.next_id);
+        unsigned cnt[FC_N];
+        HIP_TRY(hipMemcpy(cnt, m.ix_counters.p, sizeof(cnt), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[hmsg fold] index: %u of %u bricks, %u of %u records, hash %u slots\n", cnt[FC_BRICKS], m.ix.brick_cap, cnt[FC_RECS],
+                m.ix.rec_cap, m.ix.hmask + 1);
+    }
+    h->merged = true;
+    return true;
+}
+
 void hmsg_merge(hmsg_ctx* h) {
     const hmsg_config& c = h->cfg;
     HMSG_REQUIRE(h->feats_final && h->n_fused > 0, HMSG_ERR_INVALID, "hmsg_merge_instances: run hmsg_fuse_frames first");
     HMSG_REQUIRE(!h->merged, HMSG_ERR_INVALID, "instances already merged");
     HMSG_REQUIRE(h->frame_window == 0, HMSG_ERR_INVALID, "hmsg_merge_instances on a frame window: use hmsg_merge_tree_local / _join");
+    if (c.merge_type != HMSG_MERGE_HIERARCHICAL && !getenv("HMSG_FOLD_LEGACY") && hmsg_fold_sequential(h)) return;
     Merger m;
     merger_init(m, h);
     std::vector<std::vector<Cloud>> frames = seed_frames(m, h, 0);
@@ -922,6 +1068,19 @@ void hmsg_merge(hmsg_ctx* h) {
     if (getenv("HMSG_DEBUG_TIMING"))
         fprintf(stderr, "[hmsg merge] index %.1f  pairs(host) %.1f  overlap %.1f  components+concat %.1f  dbscan %.1f  bookkeeping %.1f ms\n",
                 m.tphase[0], m.tphase[1], m.tphase[2], m.tphase[3], m.tphase[4], m.tphase[5]);
+    if (m.want_stats) {
+        const auto& t = m.st;
+        const double S = std::max(1.0, t.steps);
+        fprintf(stderr, "[mstat] steps %.0f  per step: clouds %.1f  fresh raw %.1f  fresh G %.1f  indexed pts %.0f\n", t.steps, t.clouds / S,
+                t.fresh_raw / S, t.fresh_g / S, t.idx_pts / S);
+        fprintf(stderr, "[mstat] pairs/step raw %.1f (scan1 %.0f scan2 %.0f pts)   G-fresh %.1f (scan1 %.0f scan2 %.0f pts)\n", t.pairs_raw / S,
+                t.scan1_raw / S, t.scan2_raw / S, t.pairs_g / S, t.scan1_g / S, t.scan2_g / S);
+        const char* nm[5] = {"singleton raw", "singleton non-fixed", "anchor+raw", "anchor+any", "other"};
+        for (int c = 0; c < 5; ++c)
+            fprintf(stderr, "[mstat] dbscan class %-20s comps/step %.2f  pts/step %.0f  B pts/step %.0f  members %.2f  changed %.0f multi %.0f contested %.0f nonfixed %.0f (totals)\n",
+                    nm[c], t.ccount[c] / S, t.cpts[c] / S, t.cB[c] / S, t.ccount[c] ? t.cmem[c] / t.ccount[c] : 0.0, t.cchanged[c],
+                    t.cmulti[c], t.ccontested[c], t.cnonfixed[c]);
+    }
     if (getenv("HMSG_DEBUG_TIMING") && m.n_collects)
         fprintf(stderr, "[hmsg merge] %d collections of the point pool / grid arenas\n", m.n_collects);
     if (getenv("HMSG_DEBUG_TIMING") && m.ops.stat_calls > 0)

@@ -198,7 +198,9 @@ void run_grid(const void* key, dim3 grid, dim3 block, size_t shmem, F body) {
     g_bs = &state;
     BlockState& s = state;
     KernelInfo& ki = kinfo()[key];
-    bool fiber_mode = !ki.seen || ki.needs_fiber;
+    // every launch runs its threads as fibers: a kernel without collectives finishes each thread on its first switch
+    // (two register swaps per thread), and no kernel can be mis-classified because its first launch skipped a loop
+    bool fiber_mode = true;
     int n = block.x * block.y * block.z;
     s.n = n;
     s.fiber_mode = fiber_mode;
