@@ -8,21 +8,22 @@
 // eps of them:
 //
 //   * ONE persistent spatial index for every live cloud, on a FIXED global lattice of cells of side eps/sqrt(3)
-//     (two points of one cell are always neighbours): hash (cloud id, 4x4x4-cell brick) -> brick = 64 cell
-//     descriptors -> per-cell record block (point copy + index inside the cloud + core flag) that grows by
+//     (two points of one cell are always neighbours): hash (cloud id, 4x4x4-cell brick) -> brick = occupancy masks +
+//     64 cell descriptors -> per-cell record block (point copy + index inside the cloud + core flag) that grows by
 //     doubling.  Frame masks are indexed in bulk before the fold; a step appends the kept points.
 //     The same index answers the float32 overlap test of find_overlapping_ratio_faiss (graph_utils.py:620-662).
-//   * a component {members in list order} whose first member A is an ANCHOR (a fixed point of this very DBSCAN
-//     with one cluster: every point kept, exact core flags known) and larger than the rest together keeps A
-//     INACTIVE: its cores stay core and stay connected (one super-node C_A), A comes first in the concatenation so
-//     C_A has the smallest cluster id and wins every contested border point, all of A is kept.  Only the other
-//     members' points are ACTIVE: neighbour counts (against all members' indices), re-counts of the anchor's
-//     non-core points that have an active point within eps, connections of active cores (lock-free union-find
-//     over active points + C_A), labels of active non-core points, cluster sizes / keep-largest, and the kept
-//     active points are APPENDED behind A in place (capacity slack in the pool; A is never copied or re-binned).
+//   * ANCHORS.  A cloud that is a fixed point of this very DBSCAN with one cluster (every point kept, exact core
+//     flags known) keeps its cores core (more points only raise counts) and mutually connected: in a component they
+//     are ONE node of the union-find.  When the component's first member A is such a cloud and larger than the rest
+//     together it is not even looked at: A comes first in the concatenation, so its cluster has the smallest id and
+//     wins every contested border point, all of A is kept, and only the OTHER members' points are ACTIVE --
+//     neighbour counts (against all members' indices), re-counts of the anchor's non-core points that have an
+//     active point within eps, connections of active cores (lock-free union-find over active points + one node per
+//     anchor), labels of active non-core points, cluster sizes / keep-largest -- and the kept active points are
+//     APPENDED behind A in place (capacity slack in the pool; A is never copied or re-binned).
 //     (oracle/incremental_dbscan_proto.py states this step in numpy; tests/test_incremental_proto.py checks it
 //      against the batch DBSCAN.)
-//   * components without a usable anchor run the same kernels with every member active (no super-node);
+//   * components without a usable first anchor run the same kernels with every member active;
 //     the few large ones (a big cloud that is not a fixed point) go through the batch kernels.
 // Everything is exact: tests/test_fold_incremental.py and the GPU suite compare this fold with the batch fold
 // (HMSG_FOLD_LEGACY=1) bit for bit.
@@ -46,8 +47,10 @@ struct FCell {               // one lattice cell of one cloud
     unsigned pad0, pad1;
 };
 struct FBrick {
-    unsigned long long occ;  // cells with cnt > 0 (bit = lx*16 + ly*4 + lz)
-    unsigned long long pad[7];
+    unsigned long long occ;  // cells with records (bit = lx*16 + ly*4 + lz)
+    unsigned long long cm;   // cells with a record flagged F_CORE
+    unsigned long long ncm;  // cells with a record not flagged F_CORE
+    unsigned long long pad[5];
     FCell c[64];
 };
 struct FIndexDev {           // by value to every kernel
@@ -58,10 +61,11 @@ struct FIndexDev {           // by value to every kernel
     unsigned brick_cap;
     FRec* recs;
     unsigned rec_cap;
-    unsigned* counters;      // [0] bricks used  [1] records used  [2] error bits  [3] cells touched by the insertion in flight
+    unsigned* counters;
     double ox, oy, oz, cs;   // lattice
 };
-enum { FC_BRICKS = 0, FC_RECS = 1, FC_ERR = 2, FC_TOUCHED_CELLS = 3, FC_TOUCHED_RECS = 4, FC_ROOTS = 5, FC_N = 8 };
+enum { FC_BRICKS = 0, FC_RECS = 1, FC_ERR = 2, FC_TOUCHED_CELLS = 3, FC_TOUCHED_RECS = 4, FC_ROOTS = 5, FC_L_COUNT = 6, FC_L_TOUCH = 7,
+       FC_L_LINK0 = 8, FC_L_LINK = 9, FC_L_LABEL = 10, FC_N = 16 };
 enum { FERR_BRICKS = 1, FERR_RECS = 2, FERR_TOUCHED = 4, FERR_WINNER = 8, FERR_HASH = 16 };
 
 __device__ __forceinline__ unsigned long long f_key(unsigned id, int bx, int by, int bz) {
@@ -81,6 +85,7 @@ __device__ __forceinline__ void f_cell_of(const FIndexDev& ix, double x, double 
     cy = (int)floor(__ddiv_rn(__dsub_rn(y, ix.oy), ix.cs));
     cz = (int)floor(__ddiv_rn(__dsub_rn(z, ix.oz), ix.cs));
 }
+__device__ __forceinline__ unsigned f_local(int cx, int cy, int cz) { return (unsigned)(((cx & 3) << 4) | ((cy & 3) << 2) | (cz & 3)); }
 __device__ __forceinline__ unsigned f_find(const FIndexDev& ix, unsigned long long key) {
     unsigned h = f_hash(key) & ix.hmask;
     for (;;) {
@@ -136,6 +141,18 @@ __device__ __forceinline__ double f_dist2(double ax, double ay, double az, doubl
     const double dx = __dsub_rn(ax, bx), dy = __dsub_rn(ay, by), dz = __dsub_rn(az, bz);
     return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
 }
+// slot of this lane among the lanes of its wave that pass `want`, on a shared counter: ONE atomic per wave
+// (call from wave-uniform code)
+__device__ __forceinline__ unsigned f_wave_slot(bool want, unsigned* counter) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long m = __ballot(want);
+    if (!m) return 0u;
+    const int leader = __ffsll(m) - 1;
+    unsigned base = 0u;
+    if (lane == leader) base = atomicAdd(counter, (unsigned)__popcll(m));
+    base = __shfl(base, leader);
+    return base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+}
 
 // ---------------------------------------------------------------------------------------------- insertion
 // Points to insert are pool segments (bulk: the frame masks, outputs of the batch path) or the kept active points of
@@ -152,7 +169,7 @@ struct FInsArgs {
     const FInsSeg* segs;     // bulk mode
     int nsegs;
     unsigned nitems;
-    // step mode (segs == nullptr): item t = active point t, inserted when keep[t]
+    // step mode (segs == nullptr): item t = active slot t, inserted when keep[t]
     const unsigned* keep;
     const unsigned* dst;     // pool index the step's emit wrote the point to
     const unsigned* item_id;
@@ -196,55 +213,92 @@ __device__ __forceinline__ FItem f_item(const FInsArgs& a, unsigned i) {
     }
     return it;
 }
-__device__ __forceinline__ void f_reserve(const FIndexDev& ix, const FInsArgs& a, unsigned i, unsigned id, double x, double y, double z) {
-    int cx, cy, cz;
-    f_cell_of(ix, x, y, z, cx, cy, cz);
-    const unsigned b = f_find_or_insert(ix, f_key(id, cx >> 2, cy >> 2, cz >> 2));
-    const unsigned local = (unsigned)(((cx & 3) << 4) | ((cy & 3) << 2) | (cz & 3));
-    const unsigned cr = b * 64u + local;
-    const unsigned s = atomicAdd(&ix.bricks[b].c[local].pend, 1u);
-    a.cellref[i] = cr;
-    a.slot[i] = s;
-    if (s == 0u) a.touched[atomicAdd(&ix.counters[FC_TOUCHED_CELLS], 1u)] = cr;
+// reserve a slot for item i (all lanes call; `valid` lanes insert)
+__device__ __forceinline__ void f_reserve(const FIndexDev& ix, const FInsArgs& a, bool valid, unsigned i, unsigned id, double x, double y,
+                                          double z) {
+    bool fresh = false;
+    unsigned cr = 0u;
+    if (valid) {
+        int cx, cy, cz;
+        f_cell_of(ix, x, y, z, cx, cy, cz);
+        const unsigned b = f_find_or_insert(ix, f_key(id, cx >> 2, cy >> 2, cz >> 2));
+        const unsigned local = f_local(cx, cy, cz);
+        cr = b * 64u + local;
+        const unsigned s = atomicAdd(&ix.bricks[b].c[local].pend, 1u);
+        a.cellref[i] = cr;
+        a.slot[i] = s;
+        fresh = s == 0u;
+    }
+    const unsigned q = f_wave_slot(fresh, &ix.counters[FC_TOUCHED_CELLS]);
+    if (fresh) a.touched[q] = cr;
 }
 __global__ void k_ix_reserve(FIndexDev ix, FInsArgs a) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     const FItem it = f_item(a, i);
-    if (!it.valid) return;
-    f_reserve(ix, a, i, it.id, a.pool[it.p * 3], a.pool[it.p * 3 + 1], a.pool[it.p * 3 + 2]);
+    double x = 0, y = 0, z = 0;
+    if (it.valid) {
+        x = a.pool[it.p * 3];
+        y = a.pool[it.p * 3 + 1];
+        z = a.pool[it.p * 3 + 2];
+    }
+    f_reserve(ix, a, it.valid, i, it.id, x, y, z);
 }
-// one wave per touched cell: make room (blocks double), fix the counts
+// one LANE per touched cell: make room (first block: exactly what is asked for -- a frame mask never grows; later
+// blocks double), fix the counts.  One allocation atomic per wave; blocks that move are copied by the whole wave.
 __global__ void k_ix_grow(FIndexDev ix, const unsigned* __restrict__ touched) {
     const int lane = threadIdx.x & 63;
-    const unsigned nwaves = (gridDim.x * blockDim.x) >> 6, n = ix.counters[FC_TOUCHED_CELLS];
-    for (unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
-        const unsigned cr = touched[w];
-        FBrick& br = ix.bricks[cr >> 6];
-        FCell& c = br.c[cr & 63u];
-        const unsigned cnt = c.cnt, need = cnt + c.pend, cap = c.cap, optr = c.ptr;
-        unsigned nptr = optr;
-        if (need > cap) {
-            // first block: exactly what is asked for (a frame mask never grows); later blocks double
-            unsigned nc = cap == 0u ? need : max(2u * cap, need);
+    const unsigned n = ix.counters[FC_TOUCHED_CELLS];
+    const unsigned stride = gridDim.x * blockDim.x;
+    for (unsigned i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {
+        const unsigned i = i0 + (unsigned)lane;
+        const bool valid = i < n;
+        unsigned cr = 0u, cnt = 0u, need = 0u, cap = 0u, optr = 0u, nc = 0u;
+        if (valid) {
+            cr = touched[i];
+            const FCell& c = ix.bricks[cr >> 6].c[cr & 63u];
+            cnt = c.cnt;
+            need = cnt + c.pend;
+            cap = c.cap;
+            optr = c.ptr;
+            if (need > cap) nc = cap == 0u ? need : max(2u * cap, need);
+        }
+        unsigned incl = nc;
+        for (int s = 1; s < 64; s <<= 1) {
+            const unsigned up = __shfl_up(incl, s);
+            if (lane >= s) incl += up;
+        }
+        const unsigned total = __shfl(incl, 63);
+        unsigned base = 0u;
+        if (total) {
             if (lane == 0) {
-                nptr = atomicAdd(&ix.counters[FC_RECS], nc);
-                if ((unsigned long long)nptr + nc > ix.rec_cap) {
+                base = atomicAdd(&ix.counters[FC_RECS], total);
+                if ((unsigned long long)base + total > ix.rec_cap) {
                     atomicOr(&ix.counters[FC_ERR], (unsigned)FERR_RECS);
-                    nptr = 0u;
+                    base = 0u;
                 }
             }
-            nptr = __shfl(nptr, 0);
-            for (unsigned k = lane; k < cnt; k += 64u) ix.recs[nptr + k] = ix.recs[optr + k];
-            if (lane == 0) {
+            base = __shfl(base, 0);
+        }
+        const unsigned nptr = nc ? base + (incl - nc) : optr;
+        unsigned long long movers = __ballot(nc != 0u && cnt != 0u);
+        while (movers) {
+            const int l = __ffsll(movers) - 1;
+            movers &= movers - 1ull;
+            const unsigned src = __shfl(optr, l), dstp = __shfl(nptr, l), m = __shfl(cnt, l);
+            for (unsigned k = (unsigned)lane; k < m; k += 64u) ix.recs[dstp + k] = ix.recs[src + k];
+        }
+        if (valid) {
+            FBrick& br = ix.bricks[cr >> 6];
+            FCell& c = br.c[cr & 63u];
+            if (nc) {
                 c.ptr = nptr;
                 c.cap = nc;
             }
-        }
-        if (lane == 0) {
             c.base = cnt;
             c.cnt = need;
             c.pend = 0u;
-            atomicOr(&br.occ, 1ull << (cr & 63u));
+            const unsigned long long bit = 1ull << (cr & 63u);
+            if (!(br.occ & bit)) atomicOr(&br.occ, bit);
         }
     }
 }
@@ -254,7 +308,8 @@ __global__ void k_ix_write(FIndexDev ix, FInsArgs a) {
     const FItem it = f_item(a, i);
     if (!it.valid) return;
     const unsigned cr = a.cellref[i];
-    FCell& c = ix.bricks[cr >> 6].c[cr & 63u];
+    FBrick& br = ix.bricks[cr >> 6];
+    FCell& c = br.c[cr & 63u];
     FRec r;
     r.x = a.pool[it.p * 3];
     r.y = a.pool[it.p * 3 + 1];
@@ -262,7 +317,11 @@ __global__ void k_ix_write(FIndexDev ix, FInsArgs a) {
     r.lidx = it.lidx;
     r.flags = it.core ? F_CORE : 0u;
     ix.recs[c.ptr + c.base + a.slot[i]] = r;
-    if (it.core) atomicAdd(&c.ncore, 1u);
+    const unsigned long long bit = 1ull << (cr & 63u);
+    if (it.core) {
+        atomicAdd(&c.ncore, 1u);
+        if (!(br.cm & bit)) atomicOr(&br.cm, bit);
+    } else if (!(br.ncm & bit)) atomicOr(&br.ncm, bit);
 }
 
 // ---------------------------------------------------------------------------------------------- wave traversal
@@ -281,6 +340,10 @@ __device__ __forceinline__ unsigned long long f_window_mask(int bx, int by, int 
                 if (my >> y & 1u) m |= (unsigned long long)mz << ((x << 4) | (y << 2));
     return m;
 }
+__device__ __forceinline__ int f_nth_bit(unsigned long long m, unsigned r) {
+    for (unsigned i = 0; i < r; ++i) m &= m - 1ull;
+    return __ffsll(m) - 1;
+}
 // squared distance from p to the cube of cell (cx, cy, cz): nearest / farthest corner (a point of the cell can sit a
 // rounding error outside the nominal cube: callers compare with a margin)
 __device__ __forceinline__ void f_cube_dist(const FIndexDev& ix, const double* p, int cx, int cy, int cz, double& dmin2, double& dmax2) {
@@ -296,71 +359,96 @@ __device__ __forceinline__ void f_cube_dist(const FIndexDev& ix, const double* p
         dmax2 += far * far;
     }
 }
+__device__ __forceinline__ unsigned f_wave_incl_scan(unsigned v) {
+    const int lane = threadIdx.x & 63;
+    for (int s = 1; s < 64; s <<= 1) {
+        const unsigned up = __shfl_up(v, s);
+        if (lane >= s) v += up;
+    }
+    return v;
+}
+// first lane whose inclusive sum exceeds t (per-lane t)
+__device__ __forceinline__ int f_wave_search(unsigned incl, unsigned t) {
+    int a = 0, b = 63;
+    for (int it = 0; it < 6; ++it) {
+        const int mid = (a + b) >> 1;
+        const unsigned v = __shfl(incl, mid);
+        if (v > t) b = mid; else a = mid + 1;
+    }
+    return min(a, 63);
+}
 
+enum { FSEL_SKIP = 0, FSEL_ALL = 1, FSEL_CORE = 2, FSEL_NONCORE = 3 };
 // Wave-uniform walk over the cells of the clouds ids[0..k) inside the cell window [lo, hi] (at most 2 bricks per axis:
-// hi - lo <= 4) and over the records of the cells `cellfn` selects:
-//   cellfn(have_cell, j, cx, cy, cz, desc, cellref) -> records of this lane's cell to scan (0: none), called by ALL lanes
-//       (one lane per cell of the current brick; have_cell false on idle lanes) -- it may use wave collectives;
-//   recfn(valid, j, cell_lane, rec, rec_index) called by all lanes once per trip of 64 records (cell_lane = the lane
-//       whose cell the record belongs to);
-//   stop() wave-uniform: end the walk.
-template <class CellFn, class RecFn, class StopFn>
-__device__ __forceinline__ void f_walk(const FIndexDev& ix, const unsigned* __restrict__ ids, int k, const int* lo, const int* hi,
-                                       CellFn cellfn, RecFn recfn, StopFn stop) {
+// hi - lo <= 4) and over the records of the cells `cellfn` selects.  The candidate cells of all clouds are compacted
+// over the lanes (one lane per cell, 64 per round), their records laid end to end (64 per trip):
+//   sel(j) -> FSEL_*: which cells of cloud j are candidates (all occupied / with core records / with non-core records);
+//   cellfn(have, j, cx, cy, cz, desc, cellref) -> records of this lane's cell to scan (0: none); called by ALL lanes
+//       (have false on idle lanes) -- it may use wave collectives;
+//   recfn(valid, j, cell_lane, rec, rec_index): all lanes, once per trip (cell_lane = the lane whose cell the record is in);
+//   stop(): wave-uniform, ends the walk.
+//   budget > 0: a round takes only as many candidate cells as hold `budget` records (at least one) and re-offers the
+//       rest to cellfn in the next round -- a witness found in one heavy cell then lets cellfn drop its neighbours;
+//       cellfn must be free of side effects.
+template <class SelFn, class CellFn, class RecFn, class StopFn>
+__device__ __forceinline__ void f_walk(const FIndexDev& ix, const unsigned* __restrict__ ids, int k, const int* lo, const int* hi, SelFn sel,
+                                       CellFn cellfn, RecFn recfn, StopFn stop, unsigned budget = 0u) {
     const int lane = threadIdx.x & 63;
     const int b0x = lo[0] >> 2, b0y = lo[1] >> 2, b0z = lo[2] >> 2;
     for (int g = 0; g < k; g += 8) {
-        // probe: lane = (member, brick corner)
+        // probe: lane = (cloud, brick corner)
         const int j_l = g + (lane >> 3);
         unsigned bi = F_NONE;
         unsigned long long cand = 0ull;
-        int bx = 0, by = 0, bz = 0;
         if (j_l < k) {
-            bx = b0x + ((lane >> 2) & 1);
-            by = b0y + ((lane >> 1) & 1);
-            bz = b0z + (lane & 1);
-            if (bx * 4 <= hi[0] && by * 4 <= hi[1] && bz * 4 <= hi[2]) {
+            const int kind = sel(j_l);
+            const int bx = b0x + ((lane >> 2) & 1), by = b0y + ((lane >> 1) & 1), bz = b0z + (lane & 1);
+            if (kind != FSEL_SKIP && bx * 4 <= hi[0] && by * 4 <= hi[1] && bz * 4 <= hi[2]) {
                 bi = f_find(ix, f_key(ids[j_l], bx, by, bz));
-                if (bi != F_NONE) cand = ix.bricks[bi].occ & f_window_mask(bx, by, bz, lo, hi);
+                if (bi != F_NONE) {
+                    const FBrick& br = ix.bricks[bi];
+                    const unsigned long long m = kind == FSEL_ALL ? br.occ : (kind == FSEL_CORE ? br.cm : br.ncm);
+                    cand = m & f_window_mask(bx, by, bz, lo, hi);
+                }
             }
         }
-        unsigned long long owners = __ballot(cand != 0ull);
-        while (owners) {
-            const int o = __ffsll(owners) - 1;
-            owners &= owners - 1ull;
-            const unsigned bi_o = __shfl(bi, o);
-            const unsigned long long cand_o = __shfl(cand, o);
-            const int j_o = g + (o >> 3);
-            const int bx_o = b0x + ((o >> 2) & 1), by_o = b0y + ((o >> 1) & 1), bz_o = b0z + (o & 1);
-            const bool have = (cand_o >> lane) & 1ull;
+        const unsigned np = (unsigned)__popcll(cand);
+        const unsigned cincl = f_wave_incl_scan(np);
+        const unsigned ctotal = __shfl(cincl, 63);
+        for (unsigned c0 = 0, took = 64u; c0 < ctotal; c0 += took) {
+            const unsigned ci = c0 + (unsigned)lane;
+            const bool have = ci < ctotal;
+            const int o = f_wave_search(cincl, ci);                  // the probing lane that owns candidate ci
+            const unsigned o_incl = __shfl(cincl, o), o_np = __shfl(np, o), o_bi = __shfl(bi, o);
+            const unsigned long long o_cand = __shfl(cand, o);
+            const int bit = have ? f_nth_bit(o_cand, ci - (o_incl - o_np)) : 0;
+            const int j = g + (o >> 3);
+            const int cx = (b0x + ((o >> 2) & 1)) * 4 + (bit >> 4), cy = (b0y + ((o >> 1) & 1)) * 4 + ((bit >> 2) & 3),
+                      cz = (b0z + (o & 1)) * 4 + (bit & 3);
             FCell d;
             d.ptr = d.cnt = d.cap = d.ncore = d.pend = d.base = d.pad0 = d.pad1 = 0u;
-            if (have) d = ix.bricks[bi_o].c[lane];
-            const int cx = bx_o * 4 + (lane >> 4), cy = by_o * 4 + ((lane >> 2) & 3), cz = bz_o * 4 + (lane & 3);
-            const unsigned n = cellfn(have, j_o, cx, cy, cz, d, bi_o * 64u + (unsigned)lane);
-            unsigned incl = n;                                   // records laid end to end over the lanes' cells
-            for (int s = 1; s < 64; s <<= 1) {
-                const unsigned up = __shfl_up(incl, s);
-                if (lane >= s) incl += up;
+            if (have) d = ix.bricks[o_bi].c[bit];
+            unsigned n = cellfn(have, j, cx, cy, cz, d, o_bi * 64u + (unsigned)bit);
+            unsigned rincl = f_wave_incl_scan(n);
+            took = 64u;
+            if (budget) {
+                took = max(1u, (unsigned)__popcll(__ballot(rincl <= budget)));
+                if ((unsigned)lane >= took) n = 0u;
+                rincl = min(rincl, __shfl(rincl, (int)took - 1));
             }
-            const unsigned total = __shfl(incl, 63);
-            for (unsigned t0 = 0; t0 < total; t0 += 64u) {
+            const unsigned rtotal = __shfl(rincl, 63);
+            for (unsigned t0 = 0; t0 < rtotal; t0 += 64u) {
                 const unsigned t = t0 + (unsigned)lane;
-                int a = 0, b = 63;                               // first lane whose inclusive sum exceeds t
-                for (int it = 0; it < 6; ++it) {
-                    const int mid = (a + b) >> 1;
-                    const unsigned v = __shfl(incl, mid);
-                    if (v > t) b = mid; else a = mid + 1;
-                }
-                const int cl = min(a, 63);
-                const unsigned c_incl = __shfl(incl, cl), c_n = __shfl(n, cl), c_ptr = __shfl(d.ptr, cl);
-                const bool valid = t < total;
+                const int cl = f_wave_search(rincl, t);
+                const unsigned c_incl = __shfl(rincl, cl), c_n = __shfl(n, cl), c_ptr = __shfl(d.ptr, cl);
+                const int c_j = __shfl(j, cl);
+                const bool valid = t < rtotal;
                 const unsigned ri = valid ? c_ptr + (t - (c_incl - c_n)) : 0u;
                 FRec r;
                 r.x = r.y = r.z = 0.0;
                 r.lidx = r.flags = 0u;
                 if (valid) r = ix.recs[ri];
-                recfn(valid, j_o, cl, r, ri);
+                recfn(valid, c_j, cl, r, ri);
                 if (stop()) return;
             }
             if (stop()) return;
@@ -381,9 +469,23 @@ struct FOvTask {             // count the points of cloud x that have a point of
     int blk0;
 };
 #define FOV_CHUNK 512
+// is any record of [ptr, ptr + cnt) closer than r to (x, y, z) in float32?  four independent loads per step
+__device__ __forceinline__ bool f_ov_scan(const FRec* __restrict__ recs, unsigned ptr, unsigned cnt, float x, float y, float z, float r2) {
+    for (unsigned k = 0; k < cnt; k += 4u) {
+        bool h = false;
+#pragma unroll
+        for (unsigned q = 0; q < 4u; ++q) {
+            const FRec& rc = recs[ptr + min(k + q, cnt - 1u)];
+            const float ddx = __fsub_rn(x, (float)rc.x), ddy = __fsub_rn(y, (float)rc.y), ddz = __fsub_rn(z, (float)rc.z);
+            h = h || __fadd_rn(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)), __fmul_rn(ddz, ddz)) < r2;
+        }
+        if (h) return true;
+    }
+    return false;
+}
 // find_overlapping_ratio_faiss (graph_utils.py:645-662): float32 (dx*dx + dy*dy) + dz*dz < r2 against the exact
-// nearest neighbour == against SOME point.  Lanes test their point against the first records of its own cell (on a
-// re-observed surface the witness sits there); the points that found none are walked by the whole wave, one by one.
+// nearest neighbour == against SOME point.  One lane per point of X: its own cell of Y first (on a re-observed
+// surface the witness sits there), then the other cells within reach, brick by brick.
 __global__ void __launch_bounds__(256) k_f_overlap(FIndexDev ix, const double* __restrict__ pool, const FOvCloud* __restrict__ cl,
                                                    const FOvTask* __restrict__ tasks, int ntasks, float r2, float r,
                                                    unsigned* __restrict__ counts, const unsigned* __restrict__ dep_counts, double th) {
@@ -391,94 +493,77 @@ __global__ void __launch_bounds__(256) k_f_overlap(FIndexDev ix, const double* _
     const FOvTask tk = tasks[ti];
     if (dep_counts && (double)dep_counts[ti] / (double)tk.dep_n > th) return;
     const FOvCloud X = cl[tk.x], Y = cl[tk.y];
-    const int lane = threadIdx.x & 63;
     const int b0 = (int)(blockIdx.x - (unsigned)tk.blk0) * FOV_CHUNK;
     const int b1 = b0 + FOV_CHUNK < X.n ? b0 + FOV_CHUNK : X.n;
     const double reach = (double)r + 1e-4;                     // float32 rounding of the coordinates is ~1e-6 m
+    const double o[3] = {ix.ox, ix.oy, ix.oz};
     unsigned local = 0;
-    for (int i0 = b0; i0 < b1; i0 += (int)blockDim.x) {        // block-uniform trip count
-        const int i = i0 + (int)threadIdx.x;
-        double p[3] = {0, 0, 0};
-        bool open = false;                                      // still undecided
-        if (i < b1) {
-            const double* q = pool + (size_t)(X.off + i) * 3;
-            p[0] = q[0];
-            p[1] = q[1];
-            p[2] = q[2];
-            const float x = (float)p[0], y = (float)p[1], z = (float)p[2];
-            open = !(x < Y.mn[0] - r || x > Y.mx[0] + r || y < Y.mn[1] - r || y > Y.mx[1] + r || z < Y.mn[2] - r || z > Y.mx[2] + r);
+    for (int i = b0 + (int)threadIdx.x; i < b1; i += (int)blockDim.x) {
+        const double* q = pool + (size_t)(X.off + i) * 3;
+        const double p[3] = {q[0], q[1], q[2]};
+        const float x = (float)p[0], y = (float)p[1], z = (float)p[2];
+        if (x < Y.mn[0] - r || x > Y.mx[0] + r || y < Y.mn[1] - r || y > Y.mx[1] + r || z < Y.mn[2] - r || z > Y.mx[2] + r) continue;
+        int c[3], lo[3], hi[3];
+        f_cell_of(ix, p[0], p[1], p[2], c[0], c[1], c[2]);
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = (int)floor((p[a] - reach - o[a]) / ix.cs);
+            hi[a] = (int)floor((p[a] + reach - o[a]) / ix.cs);
         }
-        int cx = 0, cy = 0, cz = 0;
-        if (open) {
-            f_cell_of(ix, p[0], p[1], p[2], cx, cy, cz);
-            const unsigned b = f_find(ix, f_key(Y.id, cx >> 2, cy >> 2, cz >> 2));
-            if (b != F_NONE) {
-                const FCell& c = ix.bricks[b].c[((cx & 3) << 4) | ((cy & 3) << 2) | (cz & 3)];
-                const unsigned ptr = c.ptr, m = min(c.cnt, 4u);
-                const float x = (float)p[0], y = (float)p[1], z = (float)p[2];
-                bool h = false;
-                for (unsigned k = 0; k < m; ++k) {
-                    const FRec& rc = ix.recs[ptr + k];
-                    const float ddx = __fsub_rn(x, (float)rc.x), ddy = __fsub_rn(y, (float)rc.y), ddz = __fsub_rn(z, (float)rc.z);
-                    h = h || __fadd_rn(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)), __fmul_rn(ddz, ddz)) < r2;
-                }
-                if (h) {
-                    ++local;
-                    open = false;
+        const int b0x = lo[0] >> 2, b0y = lo[1] >> 2, b0z = lo[2] >> 2;
+        const int own = (((c[0] >> 2) - b0x) << 2) | (((c[1] >> 2) - b0y) << 1) | ((c[2] >> 2) - b0z);
+        bool hit = false;
+        for (int qq = 0; qq < 8 && !hit; ++qq) {
+            const int corner = qq ^ own;                       // the point's own brick first
+            const int bx = b0x + ((corner >> 2) & 1), by = b0y + ((corner >> 1) & 1), bz = b0z + (corner & 1);
+            if (bx * 4 > hi[0] || by * 4 > hi[1] || bz * 4 > hi[2]) continue;
+            const unsigned b = f_find(ix, f_key(Y.id, bx, by, bz));
+            if (b == F_NONE) continue;
+            const FBrick& br = ix.bricks[b];
+            unsigned long long m = br.occ & f_window_mask(bx, by, bz, lo, hi);
+            if (qq == 0) {                                     // ... and in it the own cell
+                const unsigned ob = f_local(c[0], c[1], c[2]);
+                if (m >> ob & 1ull) {
+                    m &= ~(1ull << ob);
+                    hit = f_ov_scan(ix.recs, br.c[ob].ptr, br.c[ob].cnt, x, y, z, r2);
                 }
             }
-        }
-        unsigned long long todo = __ballot(open);
-        while (todo) {
-            const int src = __ffsll(todo) - 1;
-            todo &= todo - 1ull;
-            const double q[3] = {__shfl(p[0], src), __shfl(p[1], src), __shfl(p[2], src)};
-            const float x = (float)q[0], y = (float)q[1], z = (float)q[2];
-            int lo[3], hi[3];
-            const double o[3] = {ix.ox, ix.oy, ix.oz};
-            for (int a = 0; a < 3; ++a) {
-                lo[a] = (int)floor((q[a] - reach - o[a]) / ix.cs);
-                hi[a] = (int)floor((q[a] + reach - o[a]) / ix.cs);
+            while (m && !hit) {
+                const int bit = __ffsll(m) - 1;
+                m &= m - 1ull;
+                double dmin2, dmax2;
+                f_cube_dist(ix, p, bx * 4 + (bit >> 4), by * 4 + ((bit >> 2) & 3), bz * 4 + (bit & 3), dmin2, dmax2);
+                if (dmin2 > reach * reach) continue;
+                hit = f_ov_scan(ix.recs, br.c[bit].ptr, br.c[bit].cnt, x, y, z, r2);
             }
-            bool hit = false;
-            f_walk(ix, &cl[tk.y].id, 1, lo, hi,
-                   [&](bool have, int, int ccx, int ccy, int ccz, const FCell& d, unsigned) -> unsigned {
-                       if (!have) return 0u;
-                       double dmin2, dmax2;
-                       f_cube_dist(ix, q, ccx, ccy, ccz, dmin2, dmax2);
-                       return dmin2 > reach * reach ? 0u : d.cnt;
-                   },
-                   [&](bool valid, int, int, const FRec& rc, unsigned) {
-                       bool h = false;
-                       if (valid) {
-                           const float ddx = __fsub_rn(x, (float)rc.x), ddy = __fsub_rn(y, (float)rc.y), ddz = __fsub_rn(z, (float)rc.z);
-                           h = __fadd_rn(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)), __fmul_rn(ddz, ddz)) < r2;
-                       }
-                       if (__any(h)) hit = true;
-                   },
-                   [&]() { return hit; });
-            if (hit && lane == src) ++local;
         }
+        local += hit ? 1u : 0u;
     }
-    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
-    if (lane == 0 && local) atomicAdd(&counts[ti], local);
+    for (int s = 32; s > 0; s >>= 1) local += __shfl_xor(local, s);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(&counts[ti], local);
 }
 
 // ---------------------------------------------------------------------------------------------- the fold step
+// Active slots: per component, per active member in list order, ONE slot for the member's anchor node followed by one
+// slot per point -- slot order = concatenation order, and Open3D numbers clusters by their smallest core index, so
+// "smallest node of the cluster" (the union-find's roots) orders clusters exactly like the reference.  (The anchor
+// node of a member stands for all its own core points: no other cluster can have its first core inside that member.)
 struct FMem {                // one member cloud of a component
     long long off;
     unsigned id;
     int n;
-    unsigned t0;             // first active point (F_NONE: the inactive anchor)
-    unsigned pad;
+    unsigned t0;             // slot of the member's anchor node, its points follow (F_NONE: the inactive first anchor)
+    unsigned am;             // anchor member: exact core flags in the pool / the records, one cluster
+    double mn[3], mx[3];     // AABB
 };
 struct FComp {
     int m0, nm;              // members [m0, m0 + nm) of the member table, in list order
     int has_anchor;          // member m0 is an inactive anchor
     unsigned anchor_n;
-    unsigned t0, nt;         // active points [t0, t0 + nt): the other members' points in concatenation order
+    unsigned t0, nt;         // active slots [t0, t0 + nt)
+    unsigned n_active;       // active points (nt minus the members' node slots)
     unsigned out_id;         // cloud id the kept active points are indexed under
     unsigned out_lidx0;      // index inside the output cloud of the first kept active point (anchor: |A|)
+    unsigned pad;
     long long out_off;       // pool position of the first kept active point
 };
 struct FRes {                // per component, read back
@@ -493,13 +578,13 @@ struct FStep {               // by value to the step kernels
     const FMem* mems;
     const unsigned* mem_ids; // ids of all members, parallel to mems (contiguous per component)
     int ncomp;
-    unsigned T;              // active points
+    unsigned T;              // active slots
     double* pool;
     unsigned char* poolcore;
-    unsigned char* acore;    // [T]
-    int* parent;             // [ncomp + T]: node c < ncomp = the anchor cluster of component c, ncomp + t = active point t
+    unsigned char* acore;    // [T] core flag of the slot's point in this DBSCAN
+    int* parent;             // [ncomp + T]: node c < ncomp = the first anchor's cluster of component c, ncomp + t = slot t
     unsigned* size;          // [ncomp + T] cluster sizes (at the roots)
-    unsigned* first;         // [ncomp + T] 1 + first member (active index) of the cluster; 0 for an anchor cluster
+    unsigned* first;         // [ncomp + T] 1 + first member (slot) of the cluster; 0 for a first anchor's cluster
     int* lab;                // [T] root of the point's cluster, -1 noise
     unsigned* keep;          // [T]
     unsigned* pos;           // [T] exclusive scan of keep
@@ -511,7 +596,8 @@ struct FStep {               // by value to the step kernels
     FTouched* touched;
     unsigned touched_cap;
     unsigned* roots;         // [ncomp + T]
-    double eps2;
+    unsigned *list_count, *list_touch, *list_link0, *list_link, *list_label;   // [T] slots that need a walk
+    double eps, eps2;
     int minpts;
 };
 __device__ __forceinline__ int f_comp_of(const FStep& st, unsigned t) {
@@ -522,7 +608,7 @@ __device__ __forceinline__ int f_comp_of(const FStep& st, unsigned t) {
     }
     return lo;
 }
-// member of component c that holds active point t (members are laid out in order; the anchor has t0 = F_NONE)
+// member of component c that holds slot t (members are laid out in order; the inactive anchor has t0 = F_NONE)
 __device__ __forceinline__ int f_mem_of(const FStep& st, const FComp& c, unsigned t) {
     int lo = c.m0 + (c.has_anchor ? 1 : 0), hi = c.m0 + c.nm - 1;
     while (lo < hi) {
@@ -562,45 +648,198 @@ __device__ __forceinline__ int f_uf_root_ro(const int* parent, int x) {      // 
         x = p;
     }
 }
+// what a slot is: its component, member, point; `own` = a core point of an anchor member (stands in the member's node)
+struct FSlot {
+    int ci, mi;
+    bool is_node, own;
+    double p[3];
+    long long pi;            // pool index
+};
+__device__ __forceinline__ FSlot f_slot(const FStep& st, unsigned t) {
+    FSlot s;
+    s.ci = f_comp_of(st, t);
+    const FComp& c = st.comps[s.ci];
+    s.mi = f_mem_of(st, c, t);
+    const FMem& m = st.mems[s.mi];
+    s.is_node = t == m.t0;
+    s.own = false;
+    s.pi = 0;
+    s.p[0] = s.p[1] = s.p[2] = 0.0;
+    if (!s.is_node) {
+        s.pi = m.off + (long long)(t - m.t0 - 1u);
+        s.p[0] = st.pool[(size_t)s.pi * 3];
+        s.p[1] = st.pool[(size_t)s.pi * 3 + 1];
+        s.p[2] = st.pool[(size_t)s.pi * 3 + 2];
+        s.own = m.am && st.poolcore[s.pi];
+    }
+    return s;
+}
+// node of a record of member `m` (its anchor node for the own core points of an anchor member)
+__device__ __forceinline__ int f_rec_node(const FStep& st, const FMem& m, const FRec& rc) {
+    return st.ncomp + (int)((m.am && (rc.flags & F_CORE)) ? m.t0 : m.t0 + 1u + rc.lidx);
+}
 
-// (1) the anchor's non-core points that have an active point within eps: the only anchor points whose core status
-//     can change.  Also initialises the per-component nodes.
-__global__ void __launch_bounds__(256) k_f_touch(FIndexDev ix, FStep st) {
+// The step kernels come in pairs: a THREAD per slot settles what a single lane can (most active points re-observe an
+// anchored surface: a look at one cell descriptor decides them; a point of an anchor member that is farther than eps
+// from every other member keeps its status) and lists the slots that need a walk over a neighbourhood; a WAVE per
+// listed slot then does the walks, spread over the whole device.
+#define FB 256
+__device__ __forceinline__ void f_list_push(unsigned* counter, unsigned* list, bool want, unsigned t) {   // wave-uniform call
+    const unsigned q = f_wave_slot(want, counter);
+    if (want) list[q] = t;
+}
+// cluster bookkeeping, one set of atomics per (wave, cluster): lanes with `on` add their point to cluster r (size,
+// first member).  true on the lane that saw the cluster's size leave zero: it registers the root.
+__device__ __forceinline__ bool f_account(const FStep& st, bool on, int r, unsigned t) {
     const int lane = threadIdx.x & 63;
-    const unsigned gt = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gt < (unsigned)st.ncomp) {
-        const FComp c = st.comps[gt];
-        st.parent[gt] = (int)gt;
-        st.size[gt] = c.has_anchor ? c.anchor_n : 0u;
-        st.first[gt] = c.has_anchor ? 0u : 0xffffffffu;
-        st.best[gt] = 0ull;
+    bool reg = false;
+    unsigned long long todo = __ballot(on);
+    while (todo) {
+        const int l = __ffsll(todo) - 1;
+        const int key = __shfl(r, l);
+        const bool mine = on && r == key;
+        const unsigned long long same = __ballot(mine);
+        unsigned f = mine ? t + 1u : 0xffffffffu;
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned u = __shfl_xor(f, o);
+            f = u < f ? u : f;
+        }
+        if (lane == l) {
+            atomicMin(&st.first[key], f);
+            reg = atomicAdd(&st.size[key], (unsigned)__popcll(same)) == 0u;
+        }
+        todo &= ~same;
+    }
+    return reg;
+}
+__device__ __forceinline__ void f_register_root(const FIndexDev& ix, const FStep& st, int ci, int r) {
+    atomicAdd(&st.res[ci].ncl, 1u);
+    st.roots[atomicAdd(&ix.counters[FC_ROOTS], 1u)] = (unsigned)r;
+}
+// number of core records of cloud `id` in the cell of p (0: none / no such cell)
+__device__ __forceinline__ unsigned f_own_cell_ncore(const FIndexDev& ix, unsigned id, int cx, int cy, int cz) {
+    const unsigned b = f_find(ix, f_key(id, cx >> 2, cy >> 2, cz >> 2));
+    return b == F_NONE ? 0u : ix.bricks[b].c[f_local(cx, cy, cz)].ncore;
+}
+// is p within `d` of the box of some member of component c other than member `jme`?
+__device__ __forceinline__ bool f_near_other(const FStep& st, const FComp& c, int jme, const double* p, double d) {
+    for (int j = 0; j < c.nm; ++j) {
+        if (j == jme) continue;
+        const FMem& m = st.mems[c.m0 + j];
+        if (p[0] >= m.mn[0] - d && p[0] <= m.mx[0] + d && p[1] >= m.mn[1] - d && p[1] <= m.mx[1] + d && p[2] >= m.mn[2] - d &&
+            p[2] <= m.mx[2] + d)
+            return true;
+    }
+    return false;
+}
+// A core slot's connections, as far as one lane can settle them (true: settled).
+//   * in the first anchor's cluster already (an anchor member's node joins once for all its own core points), or in one
+//     cell with a core point of the first anchor: connected without a distance test, and done -- see k_f_link;
+//   * an own core point of an anchor member farther than 2 eps from every other member: no foreign point within eps,
+//     and no point of its own member that a foreign point could have promoted.
+__device__ __forceinline__ bool f_link_pre(const FIndexDev& ix, const FStep& st, const FSlot& sl, unsigned t) {
+    const FComp& c = st.comps[sl.ci];
+    const int me = st.ncomp + (int)(sl.own ? st.mems[sl.mi].t0 : t);
+    if (c.has_anchor) {
+        if (f_uf_find(st.parent, me) == sl.ci) return true;
+        int cx, cy, cz;
+        f_cell_of(ix, sl.p[0], sl.p[1], sl.p[2], cx, cy, cz);
+        if (f_own_cell_ncore(ix, st.mem_ids[c.m0], cx, cy, cz)) {
+            f_uf_union(st.parent, me, sl.ci);
+            return true;
+        }
+    }
+    return sl.own && !f_near_other(st, c, sl.mi - c.m0, sl.p, 2.0 * st.eps + 1e-6);
+}
+
+// (1) per slot: core flags a lane can decide -- own core points of an anchor member stay core; a point of an anchor
+//     member farther than eps from every other member keeps its count; a cell that holds min_points points of the
+//     component makes its points core without a distance test -- the rest is listed for k_f_count; points with a
+//     cell of the first anchor that holds non-core records in reach are listed for k_f_touch.  Initialises the nodes.
+__global__ void __launch_bounds__(FB) k_f_pre(FIndexDev ix, FStep st) {
+    const unsigned t = blockIdx.x * FB + threadIdx.x;
+    if (t < (unsigned)st.ncomp) {
+        const FComp c = st.comps[t];
+        st.parent[t] = (int)t;
+        st.size[t] = c.has_anchor ? c.anchor_n : 0u;
+        st.first[t] = c.has_anchor ? 0u : 0xffffffffu;
+        st.best[t] = 0ull;
         FRes r;
         r.n_kept = 0u;
         r.ncl = c.has_anchor ? 1u : 0u;
         r.contested = r.pad = 0u;
         for (int a = 0; a < 6; ++a) r.box[a] = a < 3 ? ~0ull : 0ull;
-        st.res[gt] = r;
-        if (c.has_anchor) st.roots[atomicAdd(&ix.counters[FC_ROOTS], 1u)] = gt;
+        st.res[t] = r;
+        if (c.has_anchor) st.roots[atomicAdd(&ix.counters[FC_ROOTS], 1u)] = t;
     }
-    const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (unsigned t = gt >> 6; t < st.T; t += nwaves) {
+    bool want_count = false, want_touch = false, want_link = false;
+    if (t < st.T) {
+        st.parent[st.ncomp + t] = st.ncomp + (int)t;         // (before any union can name the node)
+        st.size[st.ncomp + t] = 0u;
+        st.first[st.ncomp + t] = 0xffffffffu;
+        st.lab[t] = -1;
+    }
+    // (connections start in k_f_count: every node has to be initialised before the first union)
+    if (t < st.T) {
+        const FSlot sl = f_slot(st, t);
+        bool core = sl.own;
+        if (!sl.is_node && !sl.own) {
+            const FComp& c = st.comps[sl.ci];
+            const FMem& m = st.mems[sl.mi];
+            if (!m.am || f_near_other(st, c, sl.mi - c.m0, sl.p, st.eps + 1e-6)) {
+                int cx, cy, cz;
+                f_cell_of(ix, sl.p[0], sl.p[1], sl.p[2], cx, cy, cz);
+                unsigned have = 0u;
+                for (int j = 0; j < c.nm && have < (unsigned)st.minpts; ++j) {
+                    const unsigned b = f_find(ix, f_key(st.mem_ids[c.m0 + j], cx >> 2, cy >> 2, cz >> 2));
+                    if (b != F_NONE) have += ix.bricks[b].c[f_local(cx, cy, cz)].cnt;
+                }
+                core = have >= (unsigned)st.minpts;
+                want_count = !core;
+            }
+        }
+        st.acore[t] = core ? 1 : 0;
+        want_link = core;
+        if (!sl.is_node && st.comps[sl.ci].has_anchor) {
+            const FComp& c = st.comps[sl.ci];
+            int cx, cy, cz;
+            f_cell_of(ix, sl.p[0], sl.p[1], sl.p[2], cx, cy, cz);
+            const int lo[3] = {cx - 2, cy - 2, cz - 2}, hi[3] = {cx + 2, cy + 2, cz + 2};
+            const unsigned aid = st.mem_ids[c.m0];
+            for (int q = 0; q < 8 && !want_touch; ++q) {
+                const int bx = (lo[0] >> 2) + ((q >> 2) & 1), by = (lo[1] >> 2) + ((q >> 1) & 1), bz = (lo[2] >> 2) + (q & 1);
+                const unsigned b = f_find(ix, f_key(aid, bx, by, bz));
+                if (b != F_NONE && (ix.bricks[b].ncm & f_window_mask(bx, by, bz, lo, hi))) want_touch = true;
+            }
+        }
+    }
+    f_list_push(&ix.counters[FC_L_COUNT], st.list_count, want_count, t);
+    f_list_push(&ix.counters[FC_L_TOUCH], st.list_touch, want_touch, t);
+    f_list_push(&ix.counters[FC_L_LINK0], st.list_link0, want_link, t);
+}
+
+// (2) the first anchor's non-core points that have an active point within eps: the only points of it whose core
+//     status can change
+__global__ void __launch_bounds__(256) k_f_touch(FIndexDev ix, FStep st) {
+    const unsigned n = ix.counters[FC_L_TOUCH];
+    const unsigned nw = (gridDim.x * blockDim.x) >> 6;
+    for (unsigned i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n; i += nw) {
+        const unsigned t = st.list_touch[i];
         const int ci = f_comp_of(st, t);
         const FComp c = st.comps[ci];
-        if (!c.has_anchor) continue;
-        const FMem m = st.mems[f_mem_of(st, c, t)];
-        const size_t pi = (size_t)(m.off + (t - m.t0)) * 3;
-        const double p[3] = {st.pool[pi], st.pool[pi + 1], st.pool[pi + 2]};
+        const FSlot sl = f_slot(st, t);
+        const double* p = sl.p;
         int cx, cy, cz;
         f_cell_of(ix, p[0], p[1], p[2], cx, cy, cz);
         const int lo[3] = {cx - 2, cy - 2, cz - 2}, hi[3] = {cx + 2, cy + 2, cz + 2};
-        f_walk(ix, st.mem_ids + c.m0, 1, lo, hi,
+        f_walk(ix, st.mem_ids + c.m0, 1, lo, hi, [&](int) { return (int)FSEL_NONCORE; },
                [&](bool have, int, int ccx, int ccy, int ccz, const FCell& d, unsigned) -> unsigned {
                    if (!have || d.ncore >= d.cnt) return 0u;
                    double dmin2, dmax2;
                    f_cube_dist(ix, p, ccx, ccy, ccz, dmin2, dmax2);
                    return dmin2 >= st.eps2 * (1.0 + 1e-9) + 1e-12 ? 0u : d.cnt;
                },
-               [&](bool valid, int, int cl, const FRec& rc, unsigned ri) {
+               [&](bool valid, int, int, const FRec& rc, unsigned ri) {
                    if (!valid || (rc.flags & F_CORE) || !(f_dist2(rc.x, rc.y, rc.z, p[0], p[1], p[2]) < st.eps2)) return;
                    const unsigned old = atomicOr(&ix.recs[ri].flags, F_TOUCHED);
                    if (old & F_TOUCHED) return;
@@ -614,7 +853,7 @@ __global__ void __launch_bounds__(256) k_f_touch(FIndexDev ix, FStep st) {
                    const unsigned b = f_find(ix, f_key(st.mem_ids[c.m0], rx >> 2, ry >> 2, rz >> 2));
                    FTouched tr;
                    tr.rec = ri;
-                   tr.cellref = b * 64u + (unsigned)(((rx & 3) << 4) | ((ry & 3) << 2) | (rz & 3));
+                   tr.cellref = b * 64u + f_local(rx, ry, rz);
                    tr.comp = (unsigned)ci;
                    tr.pad = 0u;
                    st.touched[q] = tr;
@@ -635,13 +874,13 @@ __device__ __forceinline__ bool f_is_core(const FIndexDev& ix, const FStep& st, 
         unsigned n = 0;
         if (j0 + lane < c.nm) {
             const unsigned b = f_find(ix, f_key(ids[j0 + lane], cx >> 2, cy >> 2, cz >> 2));
-            if (b != F_NONE) n = ix.bricks[b].c[((cx & 3) << 4) | ((cy & 3) << 2) | (cz & 3)].cnt;
+            if (b != F_NONE) n = ix.bricks[b].c[f_local(cx, cy, cz)].cnt;
         }
         have += wave_sum_i32((int)n);
     }
     if (have >= st.minpts) return true;
     const int lo[3] = {cx - 2, cy - 2, cz - 2}, hi[3] = {cx + 2, cy + 2, cz + 2};
-    f_walk(ix, ids, c.nm, lo, hi,
+    f_walk(ix, ids, c.nm, lo, hi, [&](int) { return (int)FSEL_ALL; },
            [&](bool hv, int, int ccx, int ccy, int ccz, const FCell& d, unsigned) -> unsigned {
                unsigned scan = 0u, sure = 0u;
                if (hv && !(ccx == cx && ccy == cy && ccz == cz)) {
@@ -661,41 +900,59 @@ __device__ __forceinline__ bool f_is_core(const FIndexDev& ix, const FStep& st, 
     return have >= st.minpts;
 }
 
-// (2) core flags of the active points; re-count (and promotion) of the touched anchor points
-__global__ void __launch_bounds__(256) k_f_count(FIndexDev ix, FStep st) {
+// (3) neighbour counts of the listed points; re-count and promotion of the touched points of the first anchors; and
+//     (thread per entry) the lane-level part of the connections of the points k_f_pre found core
+__global__ void __launch_bounds__(256) k_f_count(FIndexDev ix, FStep st, unsigned link_blocks) {
     const int lane = threadIdx.x & 63;
-    const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
-    const unsigned n_touched = min(ix.counters[FC_TOUCHED_RECS], st.touched_cap);
-    for (unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < st.T + n_touched; w += nwaves) {
-        if (w < st.T) {
-            const FComp c = st.comps[f_comp_of(st, w)];
-            const FMem m = st.mems[f_mem_of(st, c, w)];
-            const size_t pi = (size_t)(m.off + (w - m.t0)) * 3;
-            const double p[3] = {st.pool[pi], st.pool[pi + 1], st.pool[pi + 2]};
-            const bool core = f_is_core(ix, st, c, p);
-            if (lane == 0) {
-                st.acore[w] = core ? 1 : 0;
-                st.parent[st.ncomp + w] = st.ncomp + (int)w;
-                st.size[st.ncomp + w] = 0u;
-                st.first[st.ncomp + w] = 0xffffffffu;
-                st.lab[w] = -1;
+    if (blockIdx.x < link_blocks) {
+        const unsigned n = ix.counters[FC_L_LINK0];
+        for (unsigned i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += link_blocks * blockDim.x) {
+            const unsigned i = i0 + (unsigned)lane;
+            bool hard = false;
+            unsigned t = 0u;
+            if (i < n) {
+                t = st.list_link0[i];
+                hard = !f_link_pre(ix, st, f_slot(st, t), t);
             }
+            f_list_push(&ix.counters[FC_L_LINK], st.list_link, hard, t);
+        }
+        return;
+    }
+    const unsigned n_count = ix.counters[FC_L_COUNT];
+    const unsigned n_touched = min(ix.counters[FC_TOUCHED_RECS], st.touched_cap);
+    const unsigned nw = ((gridDim.x - link_blocks) * blockDim.x) >> 6;
+    for (unsigned w = ((blockIdx.x - link_blocks) * blockDim.x + threadIdx.x) >> 6; w < n_count + n_touched; w += nw) {
+        if (w < n_count) {
+            const unsigned t = st.list_count[w];
+            const FSlot sl = f_slot(st, t);
+            const bool core = f_is_core(ix, st, st.comps[sl.ci], sl.p);
+            bool hard = false;
+            if (core && lane == 0) {
+                st.acore[t] = 1;
+                hard = !f_link_pre(ix, st, sl, t);
+            }
+            f_list_push(&ix.counters[FC_L_LINK], st.list_link, hard, t);
         } else {
-            const FTouched tr = st.touched[w - st.T];
+            const FTouched tr = st.touched[w - n_count];
             const FComp c = st.comps[tr.comp];
             const FRec rc = ix.recs[tr.rec];
             const double p[3] = {rc.x, rc.y, rc.z};
             const bool core = f_is_core(ix, st, c, p);
-            if (core && lane == 0) {                             // promoted: a border point of the anchor cluster becomes core
+            if (core && lane == 0) {                             // promoted: a border point of the anchor's cluster becomes core
                 atomicOr(&ix.recs[tr.rec].flags, F_CORE);
-                atomicAdd(&ix.bricks[tr.cellref >> 6].c[tr.cellref & 63u].ncore, 1u);
+                FBrick& br = ix.bricks[tr.cellref >> 6];
+                FCell& cell = br.c[tr.cellref & 63u];
+                const unsigned long long bit = 1ull << (tr.cellref & 63u);
+                const unsigned nc = atomicAdd(&cell.ncore, 1u) + 1u;
+                if (!(br.cm & bit)) atomicOr(&br.cm, bit);
+                if (nc >= cell.cnt) atomicAnd(&br.ncm, ~bit);
                 st.poolcore[st.mems[c.m0].off + rc.lidx] = 1;
             }
         }
     }
 }
 
-// one union per (trip, cell) with a witness: `hit` lanes of the same cell elect their lowest lane
+// one action per (trip, cell) with a witness: `hit` lanes of the same cell elect their lowest lane
 template <class Fn>
 __device__ __forceinline__ void f_per_cell_leader(bool hit, int cell_lane, Fn fn) {
     const int lane = threadIdx.x & 63;
@@ -709,136 +966,193 @@ __device__ __forceinline__ void f_per_cell_leader(bool hit, int cell_lane, Fn fn
     }
 }
 
-// (3) connections of the active core points: to the anchor cluster (any anchor core within eps) and to each other.
-//     Every core point looks for ONE witness per neighbouring (cloud, cell): core points of one cell are always connected.
+// (4) connections of the listed core points.  Every edge of the eps-graph on core points has to be found from ONE
+//     of its ends:
+//       * a core point with a core point of the first anchor within eps joins the anchor's cluster and is done (an
+//         edge between two such points is irrelevant; any other neighbour finds this point from its side);
+//       * every other core point walks ALL its neighbourhood: core points of one cell are always connected, so one
+//         witness per (cloud, cell) is enough; the own core points of an anchor member are one node, so one witness
+//         per anchor member is enough -- plus its points promoted in this step, which are not flagged in their
+//         records and sit in cells with non-core records (also looked for in the walker's own member).
 __global__ void __launch_bounds__(256) k_f_link(FIndexDev ix, FStep st) {
     const int lane = threadIdx.x & 63;
-    const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (unsigned t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; t < st.T; t += nwaves) {
-        if (!st.acore[t]) continue;
-        const int ci = f_comp_of(st, t);
+    const unsigned n = ix.counters[FC_L_LINK];
+    const unsigned nw = (gridDim.x * blockDim.x) >> 6;
+    for (unsigned i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n; i += nw) {
+        const unsigned t = st.list_link[i];
+        const FSlot sl = f_slot(st, t);
+        const int ci = sl.ci;
         const FComp c = st.comps[ci];
-        const int mi = f_mem_of(st, c, t);
-        const FMem m = st.mems[mi];
-        const size_t pi = (size_t)(m.off + (t - m.t0)) * 3;
-        const double p[3] = {st.pool[pi], st.pool[pi + 1], st.pool[pi + 2]};
+        const FMem mm = st.mems[sl.mi];
+        const int jme = sl.mi - c.m0;
+        const double* p = sl.p;
         int cx, cy, cz;
         f_cell_of(ix, p[0], p[1], p[2], cx, cy, cz);
         const int lo[3] = {cx - 2, cy - 2, cz - 2}, hi[3] = {cx + 2, cy + 2, cz + 2};
-        const int me = st.ncomp + (int)t;
-        bool in_anchor = false;                                  // wave-uniform: already connected to the anchor cluster
-        f_walk(ix, st.mem_ids + c.m0, c.nm, lo, hi,
-               [&](bool hv, int j, int ccx, int ccy, int ccz, const FCell& d, unsigned) -> unsigned {
-                   const bool anch = c.has_anchor && j == 0;
-                   unsigned scan = 0u;
-                   bool own_anchor = false;
-                   if (hv && !(anch && (in_anchor || d.ncore == 0u))) {
-                       if (anch && ccx == cx && ccy == cy && ccz == cz) own_anchor = true;     // same cell: within eps
-                       else {
-                           double dmin2, dmax2;
-                           f_cube_dist(ix, p, ccx, ccy, ccz, dmin2, dmax2);
-                           if (!(dmin2 >= st.eps2 * (1.0 + 1e-9) + 1e-12)) scan = d.cnt;
-                       }
-                   }
-                   if (__any(own_anchor)) {
-                       if (lane == 0) f_uf_union(st.parent, me, ci);
-                       in_anchor = true;
-                       if (anch) scan = 0u;
-                   }
-                   return scan;
-               },
-               [&](bool valid, int j, int cl, const FRec& rc, unsigned) {
-                   const bool anch = c.has_anchor && j == 0;
-                   bool hit = false;
-                   int node = ci;
-                   if (valid && f_dist2(rc.x, rc.y, rc.z, p[0], p[1], p[2]) < st.eps2) {
-                       if (anch) hit = !in_anchor && (rc.flags & F_CORE);
-                       else {
-                           const unsigned q = st.mems[c.m0 + j].t0 + rc.lidx;
-                           hit = q != t && st.acore[q];
-                           node = st.ncomp + (int)q;
-                       }
-                   }
-                   f_per_cell_leader(hit, cl, [&]() { f_uf_union(st.parent, me, node); });
-                   if (anch && __any(hit)) in_anchor = true;
-               },
-               [&]() { return false; });
-    }
-}
-
-// (4) cluster bookkeeping of the core points, labels of the non-core points (the reaching cluster with the smallest
-//     root = Open3D's first cluster; cores of two clusters in reach = contested), contest check of the touched
-//     anchor points that stayed non-core.
-__global__ void __launch_bounds__(256) k_f_label(FIndexDev ix, FStep st) {
-    const int lane = threadIdx.x & 63;
-    const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
-    const unsigned n_touched = min(ix.counters[FC_TOUCHED_RECS], st.touched_cap);
-    for (unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < st.T + n_touched; w += nwaves) {
-        const bool is_active = w < st.T;
-        int ci;
-        double p[3];
-        unsigned self = F_NONE;
-        if (is_active) {
-            ci = f_comp_of(st, w);
-            const FComp c0 = st.comps[ci];
-            const FMem m = st.mems[f_mem_of(st, c0, w)];
-            const size_t pi = (size_t)(m.off + (w - m.t0)) * 3;
-            p[0] = st.pool[pi];
-            p[1] = st.pool[pi + 1];
-            p[2] = st.pool[pi + 2];
-            self = w;
-            if (st.acore[w]) {
-                if (lane == 0) {
-                    const int r = f_uf_root_ro(st.parent, st.ncomp + (int)w);
-                    st.lab[w] = r;
-                    atomicAdd(&st.size[r], 1u);
-                    atomicMin(&st.first[r], w + 1u);
-                    if (r == st.ncomp + (int)w) {
-                        atomicAdd(&st.res[ci].ncl, 1u);
-                        st.roots[atomicAdd(&ix.counters[FC_ROOTS], 1u)] = (unsigned)r;
-                    }
-                }
+        const int me = st.ncomp + (int)(sl.own ? mm.t0 : t);
+        if (c.has_anchor) {                                      // the first core point of the anchor within eps
+            bool in_anchor = false;
+            f_walk(ix, st.mem_ids + c.m0, 1, lo, hi, [&](int) { return (int)FSEL_CORE; },
+                   [&](bool hv, int, int ccx, int ccy, int ccz, const FCell& d, unsigned) -> unsigned {
+                       if (!hv || d.ncore == 0u) return 0u;
+                       double dmin2, dmax2;
+                       f_cube_dist(ix, p, ccx, ccy, ccz, dmin2, dmax2);
+                       return dmin2 >= st.eps2 * (1.0 + 1e-9) + 1e-12 ? 0u : d.cnt;
+                   },
+                   [&](bool valid, int, int, const FRec& rc, unsigned) {
+                       const bool hit = valid && (rc.flags & F_CORE) && f_dist2(rc.x, rc.y, rc.z, p[0], p[1], p[2]) < st.eps2;
+                       if (__any(hit)) in_anchor = true;
+                   },
+                   [&]() { return in_anchor; }, 128u);
+            if (in_anchor) {
+                if (lane == 0) f_uf_union(st.parent, me, ci);
                 continue;
             }
-        } else {
-            const FTouched tr = st.touched[w - st.T];
-            ci = (int)tr.comp;
-            const FRec rc = ix.recs[tr.rec];
-            if (lane == 0) atomicAnd(&ix.recs[tr.rec].flags, ~F_TOUCHED);
-            if (rc.flags & F_CORE) continue;                     // promoted by k_f_count
-            p[0] = rc.x;
-            p[1] = rc.y;
-            p[2] = rc.z;
         }
-        const FComp c = st.comps[ci];
-        int cx, cy, cz;
-        f_cell_of(ix, p[0], p[1], p[2], cx, cy, cz);
-        const int lo[3] = {cx - 2, cy - 2, cz - 2}, hi[3] = {cx + 2, cy + 2, cz + 2};
-        int best = 0x7fffffff;                                   // per lane: smallest root it saw a witness of
-        bool multi = false;                                      // ... and whether it saw two different ones
-        bool got_anchor = !is_active;                            // a touched anchor point is a border point of the anchor cluster
-        if (!is_active) best = ci;
-        f_walk(ix, st.mem_ids + c.m0, c.nm, lo, hi,
-               [&](bool hv, int j, int ccx, int ccy, int ccz, const FCell& d, unsigned) -> unsigned {
-                   const bool anch = c.has_anchor && j == 0;
-                   if (!hv || (anch && (got_anchor || d.ncore == 0u))) return 0u;
+        const int j0 = c.has_anchor ? 1 : 0;
+        unsigned long long done_am = 0ull;                       // anchor members (first 64 of the walk) with a witness
+        if (sl.own && jme - j0 < 64) done_am |= 1ull << (jme - j0);   // (its own member's node is the walker itself)
+        f_walk(ix, st.mem_ids + c.m0 + j0, c.nm - j0, lo, hi,
+               [&](int jj) { return (sl.own && jj + j0 == jme) ? (int)FSEL_NONCORE : (int)FSEL_ALL; },
+               [&](bool hv, int jj, int ccx, int ccy, int ccz, const FCell& d, unsigned) -> unsigned {
+                   if (!hv) return 0u;
+                   if (jj < 64 && (done_am >> jj & 1ull) && d.ncore >= d.cnt) return 0u;
                    double dmin2, dmax2;
                    f_cube_dist(ix, p, ccx, ccy, ccz, dmin2, dmax2);
                    return dmin2 >= st.eps2 * (1.0 + 1e-9) + 1e-12 ? 0u : d.cnt;
                },
-               [&](bool valid, int j, int, const FRec& rc, unsigned) {
-                   const bool anch = c.has_anchor && j == 0;
-                   bool hit = false;
+               [&](bool valid, int jj, int cl, const FRec& rc, unsigned) {
+                   bool hit = false, am_hit = false;
+                   int node = ci;
+                   if (valid && f_dist2(rc.x, rc.y, rc.z, p[0], p[1], p[2]) < st.eps2) {
+                       const FMem& m = st.mems[c.m0 + j0 + jj];
+                       node = f_rec_node(st, m, rc);
+                       const unsigned q = m.t0 + 1u + rc.lidx;
+                       hit = q != t && (st.acore[q] != 0);
+                       am_hit = hit && m.am && (rc.flags & F_CORE);
+                       if (am_hit && jj < 64 && (done_am >> jj & 1ull)) hit = false;      // (that node is connected already)
+                       if (am_hit && jj >= 64 && sl.own && jj + j0 == jme) hit = false;
+                   }
+                   f_per_cell_leader(hit, cl, [&]() { f_uf_union(st.parent, me, node); });
+                   unsigned long long am_todo = __ballot(am_hit && jj < 64);
+                   while (am_todo) {
+                       const int l = __ffsll(am_todo) - 1;
+                       am_todo &= am_todo - 1ull;
+                       done_am |= 1ull << __shfl(jj, l);
+                   }
+               },
+               [&]() { return false; }, 128u);
+    }
+}
+
+// (5) clusters of the core points: root, size, first member; the first member registers the root
+__global__ void __launch_bounds__(FB) k_f_acct(FIndexDev ix, FStep st) {
+    const unsigned t = blockIdx.x * FB + threadIdx.x;
+    bool on = false;
+    int r = -1, ci = 0;
+    if (t < st.T && st.acore[t]) {
+        const FSlot sl = f_slot(st, t);
+        ci = sl.ci;
+        r = f_uf_root_ro(st.parent, st.ncomp + (int)(sl.own ? st.mems[sl.mi].t0 : t));
+        st.lab[t] = r;
+        on = true;
+    }
+    if (f_account(st, on, r, t) && r >= st.ncomp) f_register_root(ix, st, ci, r);
+}
+
+// (6) labels of the non-core points (the reaching cluster with the smallest root = Open3D's first cluster; cores of
+//     two clusters in reach = contested).  What a lane can settle: no cluster at all -> noise; a non-core point of an
+//     anchor member farther than 2 eps from every other member is a border point of its member's cluster and of no
+//     other; in a component with ONE cluster, every border point of an anchor (member) and every point in one cell
+//     with a core point of the first anchor belongs to it.  The rest is listed for k_f_label.
+__global__ void __launch_bounds__(FB) k_f_labelpre(FIndexDev ix, FStep st) {
+    const unsigned t = blockIdx.x * FB + threadIdx.x;
+    bool hard = false, on = false;
+    int r = -1;
+    if (t < st.T && !st.acore[t]) {
+        const FSlot sl = f_slot(st, t);
+        if (!sl.is_node) {
+            const FComp& c = st.comps[sl.ci];
+            const FMem& m = st.mems[sl.mi];
+            const unsigned ncl = st.res[sl.ci].ncl;
+            if (ncl != 0u) {
+                if (m.am && (ncl == 1u || !f_near_other(st, c, sl.mi - c.m0, sl.p, 2.0 * st.eps + 1e-6)))
+                    r = f_uf_root_ro(st.parent, st.ncomp + (int)m.t0);
+                else if (ncl == 1u && c.has_anchor) {
+                    int cx, cy, cz;
+                    f_cell_of(ix, sl.p[0], sl.p[1], sl.p[2], cx, cy, cz);
+                    if (f_own_cell_ncore(ix, st.mem_ids[c.m0], cx, cy, cz)) r = sl.ci;
+                }
+                on = r >= 0;
+                if (on) st.lab[t] = r;
+                hard = !on;
+            }
+        }
+    }
+    f_account(st, on, r, t);                                     // (the cluster exists already: nothing to register)
+    f_list_push(&ix.counters[FC_L_LABEL], st.list_label, hard, t);
+}
+__device__ __forceinline__ void f_label_walk(const FIndexDev& ix, const FStep& st, int ci, const double* p, unsigned self, int jme, bool skip_own_member,
+                                             int best0, bool got_anchor0, bool one_cluster, int& wbest_out, bool& contest_out) {
+    const int lane = threadIdx.x & 63;
+    const FComp c = st.comps[ci];
+    int cx, cy, cz;
+    f_cell_of(ix, p[0], p[1], p[2], cx, cy, cz);
+    const int lo[3] = {cx - 2, cy - 2, cz - 2}, hi[3] = {cx + 2, cy + 2, cz + 2};
+    int best = best0;                                            // per lane: smallest root it saw a witness of
+    bool multi = false;                                          // this lane saw witnesses of two different clusters
+    bool got_anchor = got_anchor0;                               // the first anchor's cluster is known to reach the point
+    bool any_hit = best0 != 0x7fffffff;
+    if (c.has_anchor && !got_anchor) {
+        // does the first anchor's cluster reach the point?  a core point in the point's own cell is within eps;
+        // else the first witness ends the search
+        unsigned nc = 0u;
+        if (lane == 0) nc = f_own_cell_ncore(ix, st.mem_ids[c.m0], cx, cy, cz);
+        got_anchor = __shfl(nc, 0) != 0u;
+        if (!got_anchor)
+            f_walk(ix, st.mem_ids + c.m0, 1, lo, hi, [&](int) { return (int)FSEL_CORE; },
+                   [&](bool hv, int, int ccx, int ccy, int ccz, const FCell& d, unsigned) -> unsigned {
+                       if (!hv || d.ncore == 0u) return 0u;
+                       double dmin2, dmax2;
+                       f_cube_dist(ix, p, ccx, ccy, ccz, dmin2, dmax2);
+                       return dmin2 >= st.eps2 * (1.0 + 1e-9) + 1e-12 ? 0u : d.cnt;
+                   },
+                   [&](bool valid, int, int, const FRec& rc, unsigned) {
+                       const bool hit = valid && (rc.flags & F_CORE) && f_dist2(rc.x, rc.y, rc.z, p[0], p[1], p[2]) < st.eps2;
+                       if (__any(hit)) got_anchor = true;
+                   },
+                   [&]() { return got_anchor; }, 128u);
+        if (got_anchor) {
+            if (best != 0x7fffffff && best != ci) multi = true;
+            best = ci;                                           // (the smallest root there is)
+            any_hit = true;
+        }
+    }
+    if (!(one_cluster && any_hit)) {
+        // the other members: every core point within eps counts; the own core points of an anchor member are one
+        // cluster (one witness is enough, the rest of its all-core cells is skipped)
+        const int j0 = c.has_anchor ? 1 : 0;
+        unsigned long long seen_am = 0ull;                       // anchor members (first 64 of the walk) an own core point has been seen of
+        f_walk(ix, st.mem_ids + c.m0 + j0, c.nm - j0, lo, hi,
+               [&](int jj) { return (skip_own_member && jj + j0 == jme) ? (int)FSEL_SKIP : (int)FSEL_ALL; },
+               [&](bool hv, int jj, int ccx, int ccy, int ccz, const FCell& d, unsigned) -> unsigned {
+                   if (!hv) return 0u;
+                   if (jj < 64 && (seen_am >> jj & 1ull) && d.ncore >= d.cnt) return 0u;
+                   double dmin2, dmax2;
+                   f_cube_dist(ix, p, ccx, ccy, ccz, dmin2, dmax2);
+                   return dmin2 >= st.eps2 * (1.0 + 1e-9) + 1e-12 ? 0u : d.cnt;
+               },
+               [&](bool valid, int jj, int, const FRec& rc, unsigned) {
+                   bool hit = false, am_hit = false;
                    int r = -1;
                    if (valid && f_dist2(rc.x, rc.y, rc.z, p[0], p[1], p[2]) < st.eps2) {
-                       if (anch) {
-                           hit = (rc.flags & F_CORE) != 0u;
-                           r = ci;
-                       } else {
-                           const unsigned q = st.mems[c.m0 + j].t0 + rc.lidx;
-                           if (q != self && st.acore[q]) {
+                       const FMem& m = st.mems[c.m0 + j0 + jj];
+                       const unsigned q = m.t0 + 1u + rc.lidx;
+                       if (q != self && st.acore[q]) {
+                           am_hit = m.am && (rc.flags & F_CORE);
+                           if (!(am_hit && jj < 64 && (seen_am >> jj & 1ull))) {       // (that cluster is accounted for)
                                hit = true;
-                               r = f_uf_root_ro(st.parent, st.ncomp + (int)q);
+                               r = f_uf_root_ro(st.parent, f_rec_node(st, m, rc));
                            }
                        }
                    }
@@ -846,25 +1160,58 @@ __global__ void __launch_bounds__(256) k_f_label(FIndexDev ix, FStep st) {
                        if (best != 0x7fffffff && r != best) multi = true;
                        if (r < best) best = r;
                    }
-                   if (anch && __any(hit)) got_anchor = true;
+                   if (__any(hit)) any_hit = true;
+                   unsigned long long am_todo = __ballot(am_hit && jj < 64);
+                   while (am_todo) {
+                       const int l = __ffsll(am_todo) - 1;
+                       am_todo &= am_todo - 1ull;
+                       seen_am |= 1ull << __shfl(jj, l);
+                   }
                },
-               [&]() { return false; });
-        int wbest = best;
-        for (int o = 32; o > 0; o >>= 1) {
-            const int u = __shfl_xor(wbest, o);
-            wbest = u < wbest ? u : wbest;
+               [&]() { return one_cluster && any_hit; }, 128u);
+    }
+    int wbest = best;
+    for (int o = 32; o > 0; o >>= 1) {
+        const int u = __shfl_xor(wbest, o);
+        wbest = u < wbest ? u : wbest;
+    }
+    wbest_out = wbest;
+    contest_out = __any(multi || (best != 0x7fffffff && best != wbest)) != 0;
+}
+// (7) labels of the listed points; contest check of the touched points of the first anchors that stayed non-core
+__global__ void __launch_bounds__(256) k_f_label(FIndexDev ix, FStep st) {
+    const int lane = threadIdx.x & 63;
+    const unsigned n_label = ix.counters[FC_L_LABEL];
+    const unsigned n_touched = min(ix.counters[FC_TOUCHED_RECS], st.touched_cap);
+    const unsigned nw = (gridDim.x * blockDim.x) >> 6;
+    for (unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n_label + n_touched; w += nw) {
+        if (w >= n_label) {
+            const FTouched tr = st.touched[w - n_label];
+            const int ci = (int)tr.comp;
+            const FRec rc = ix.recs[tr.rec];
+            if (lane == 0) atomicAnd(&ix.recs[tr.rec].flags, ~F_TOUCHED);
+            if ((rc.flags & F_CORE) || st.res[ci].ncl <= 1u) continue;     // promoted by k_f_count / no second cluster
+            const double p[3] = {rc.x, rc.y, rc.z};
+            int wbest;
+            bool contest;
+            f_label_walk(ix, st, ci, p, F_NONE, -1, false, ci, true, false, wbest, contest);    // a border point of the first anchor's cluster
+            if (contest && lane == 0 && !st.res[ci].contested) st.res[ci].contested = 1u;
+            continue;
         }
-        const bool contest = __any(multi || (best != 0x7fffffff && best != wbest)) != 0;
+        const unsigned t = st.list_label[w];
+        const FSlot sl = f_slot(st, t);
+        const FMem& mm = st.mems[sl.mi];
+        int best0 = 0x7fffffff;
+        if (mm.am) best0 = f_uf_root_ro(st.parent, st.ncomp + (int)mm.t0);       // a border point of its member's one cluster
+        int wbest;
+        bool contest;
+        f_label_walk(ix, st, sl.ci, sl.p, t, sl.mi - st.comps[sl.ci].m0, mm.am != 0u, best0, false, st.res[sl.ci].ncl == 1u, wbest, contest);
+        const bool on = wbest != 0x7fffffff;
         if (lane == 0) {
-            if (is_active) {
-                st.lab[w] = wbest == 0x7fffffff ? -1 : wbest;
-                if (wbest != 0x7fffffff) {
-                    atomicAdd(&st.size[wbest], 1u);
-                    atomicMin(&st.first[wbest], w + 1u);
-                }
-            }
-            if (contest && !st.res[ci].contested) st.res[ci].contested = 1u;
+            st.lab[t] = on ? wbest : -1;
+            if (contest && !st.res[sl.ci].contested) st.res[sl.ci].contested = 1u;
         }
+        f_account(st, on && lane == 0, wbest, t);
     }
 }
 
@@ -885,21 +1232,28 @@ __global__ void k_f_keep(FIndexDev ix, FStep st) {
     if (t == 0u) {                                               // (the lists of this step have been consumed)
         ix.counters[FC_ROOTS] = 0u;
         ix.counters[FC_TOUCHED_RECS] = 0u;
+        ix.counters[FC_L_COUNT] = ix.counters[FC_L_TOUCH] = ix.counters[FC_L_LINK0] = ix.counters[FC_L_LINK] = ix.counters[FC_L_LABEL] = 0u;
     }
     if (t >= st.T) return;
     const int ci = f_comp_of(st, t);
+    const FComp& c = st.comps[ci];
+    const FMem& m = st.mems[f_mem_of(st, c, t)];
+    if (t == m.t0) {
+        st.keep[t] = 0u;
+        return;
+    }
     const unsigned long long b = st.best[ci];
     bool keep = true;
     if ((unsigned)(b >> 32) >= 5u) {
         const unsigned f = 0xffffffffu - (unsigned)(b & 0xffffffffull);
         const int win = f == 0u ? ci : st.lab[f - 1u];
         keep = st.lab[t] == win;
-        if (st.comps[ci].has_anchor && win != ci) atomicOr(&ix.counters[FC_ERR], (unsigned)FERR_WINNER);
+        if (c.has_anchor && win != ci) atomicOr(&ix.counters[FC_ERR], (unsigned)FERR_WINNER);
     }
     st.keep[t] = keep ? 1u : 0u;
 }
-// (7) the kept active points go behind the anchor (or to the component's new cloud), their box and count come back,
-//     and their index slots are reserved
+// (7) the kept active points go behind the first anchor (or to the component's new cloud), their box and count come
+//     back, and their index slots are reserved
 __global__ void __launch_bounds__(256) k_f_emit(FIndexDev ix, FStep st, FInsArgs ins) {
     const int lane = threadIdx.x & 63;
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -907,6 +1261,7 @@ __global__ void __launch_bounds__(256) k_f_emit(FIndexDev ix, FStep st, FInsArgs
     int ci = -1;
     bool kp = false;
     double v[3] = {0, 0, 0};
+    unsigned out_id = 0u;
     if (in) {
         ci = f_comp_of(st, t);
         const FComp c = st.comps[ci];
@@ -914,7 +1269,7 @@ __global__ void __launch_bounds__(256) k_f_emit(FIndexDev ix, FStep st, FInsArgs
         const unsigned k = st.pos[t] - st.pos[c.t0];
         if (kp) {
             const FMem m = st.mems[f_mem_of(st, c, t)];
-            const size_t pi = (size_t)(m.off + (t - m.t0)) * 3;
+            const size_t pi = (size_t)(m.off + (long long)(t - m.t0 - 1u)) * 3;
             const long long d = c.out_off + (long long)k;
             for (int a = 0; a < 3; ++a) {
                 v[a] = st.pool[pi + a];
@@ -924,10 +1279,11 @@ __global__ void __launch_bounds__(256) k_f_emit(FIndexDev ix, FStep st, FInsArgs
             st.dst[t] = (unsigned)d;
             st.item_id[t] = c.out_id;
             st.item_lidx[t] = c.out_lidx0 + k;
-            f_reserve(ix, ins, t, c.out_id, v[0], v[1], v[2]);
+            out_id = c.out_id;
         }
         if (t == c.t0 + c.nt - 1u) st.res[ci].n_kept = k + (kp ? 1u : 0u);
     }
+    f_reserve(ix, ins, kp, t, out_id, v[0], v[1], v[2]);
     // boxes: one set of atomics per (wave, component)
     unsigned long long todo = __ballot(kp);
     while (todo) {
@@ -964,7 +1320,7 @@ struct Folder : Merger {
     PinnedBuf<char> h_pack;
     DevBuf<unsigned char> acore;
     DevBuf<int> parent, lab;
-    DevBuf<unsigned> size, first, keep, pos, dst, item_id, item_lidx, roots, cellref, slot, touched_cells;
+    DevBuf<unsigned> size, first, keep, pos, dst, item_id, item_lidx, roots, cellref, slot, touched_cells, lists;
     DevBuf<unsigned long long> best;
     DevBuf<FRes> d_res;
     DevBuf<FTouched> touched;
@@ -1221,17 +1577,22 @@ struct Folder : Merger {
                 m.off = cl.off;
                 m.id = cl.id;
                 m.n = cl.n;
-                m.pad = 0;
+                m.am = (use_anchor && cl.anchor && minpts >= 5) ? 1u : 0u;
+                for (int a = 0; a < 3; ++a) {
+                    m.mn[a] = cl.mn[a];
+                    m.mx[a] = cl.mx[a];
+                }
                 if (anch && k == 0) m.t0 = F_NONE;
                 else {
-                    m.t0 = T;
-                    T += (unsigned)cl.n;
+                    m.t0 = T;                               // the member's node slot, then its points
+                    T += (unsigned)cl.n + 1u;
                 }
                 fm.push_back(m);
                 fids.push_back(cl.id);
             }
             q.nm = (int)fm.size() - q.m0;
             q.nt = T - q.t0;
+            q.n_active = (unsigned)active;
             fc.push_back(q);
             fstat[anch ? 1 : 2] += 1;
             fstat[4] += (double)active;
@@ -1243,8 +1604,8 @@ struct Folder : Merger {
             FComp& q = fc[(size_t)comp_slot[c]];
             if (q.has_anchor) {
                 Cloud& A = L[comps[c][0]];
-                if ((long long)A.n + q.nt > A.cap) {
-                    const long long ncap = 2 * ((long long)A.n + q.nt);
+                if ((long long)A.n + q.n_active > A.cap) {
+                    const long long ncap = 2 * ((long long)A.n + q.n_active);
                     const long long noff = pool_alloc(ncap);
                     reloc.push_back(CatSeg{A.off, noff, A.n, 1, (int)reloc_blocks, 0});
                     reloc_blocks += cdiv((size_t)A.n, CAT_CHUNK);
@@ -1260,7 +1621,7 @@ struct Folder : Merger {
                 HMSG_REQUIRE(next_id < (1u << 24), HMSG_ERR_UNSUPPORTED, "merge: fold index ran out of cloud ids");
                 q.out_id = next_id++;
                 q.out_lidx0 = 0;
-                q.out_off = pool_alloc(2ll * q.nt);
+                q.out_off = pool_alloc(2ll * q.n_active);
             }
         }
         if (!reloc.empty()) {
@@ -1322,6 +1683,13 @@ struct Folder : Merger {
             st.touched = touched.p;
             st.touched_cap = TOUCHED_CAP;
             st.roots = roots.p;
+            lists.ensure((size_t)T * 5);
+            st.list_count = lists.p;
+            st.list_touch = lists.p + T;
+            st.list_link0 = lists.p + 2 * (size_t)T;
+            st.list_link = lists.p + 3 * (size_t)T;
+            st.list_label = lists.p + 4 * (size_t)T;
+            st.eps = eps;
             st.eps2 = eps * eps;
             st.minpts = minpts;
             FInsArgs ins;
@@ -1336,12 +1704,15 @@ struct Folder : Merger {
             ins.cellref = cellref.p;
             ins.slot = slot.p;
             ins.touched = touched_cells.p;
-            const unsigned gW = std::max(cdiv((size_t)std::max<unsigned>(T, (unsigned)NCOMP) * 64, 256), 1u);     // a wave per active point
+            const unsigned gS = std::max(cdiv(std::max<unsigned>(T, (unsigned)NCOMP), FB), 1u);   // a thread per slot
+            const unsigned gW = std::max(1u, std::min(cdiv((size_t)T * 64, 256), (unsigned)n_cu * 8u)); // a wave per listed slot (grid-stride)
+            const unsigned gL = std::max(1u, std::min(gS, 64u));
             const unsigned gT = cdiv(std::max<unsigned>(T, 1u), 256);
             {
                 ProfScope ps(h->prof, s, "k_f_count", (double)T * 24.0);
+                hipLaunchKernelGGL(k_f_pre, dim3(gS), dim3(FB), 0, s, ix, st);
                 hipLaunchKernelGGL(k_f_touch, dim3(gW), dim3(256), 0, s, ix, st);
-                hipLaunchKernelGGL(k_f_count, dim3(gW), dim3(256), 0, s, ix, st);
+                hipLaunchKernelGGL(k_f_count, dim3(gL + gW), dim3(256), 0, s, ix, st, gL);
             }
             {
                 ProfScope ps(h->prof, s, "k_f_link", (double)T * 24.0);
@@ -1349,6 +1720,8 @@ struct Folder : Merger {
             }
             {
                 ProfScope ps(h->prof, s, "k_f_label", (double)T * 24.0);
+                hipLaunchKernelGGL(k_f_acct, dim3(gS), dim3(FB), 0, s, ix, st);
+                hipLaunchKernelGGL(k_f_labelpre, dim3(gS), dim3(FB), 0, s, ix, st);
                 hipLaunchKernelGGL(k_f_label, dim3(gW), dim3(256), 0, s, ix, st);
             }
             hipLaunchKernelGGL(k_f_pick, dim3(std::max(1u, std::min(gT, 64u))), dim3(256), 0, s, ix, st);
@@ -1356,7 +1729,7 @@ struct Folder : Merger {
             HMSG_CHECK_LAUNCH();
             hmsg_scan_u32(keep.p, pos.p, (size_t)T, s, ops.scan_tmp, nullptr);
             hipLaunchKernelGGL(k_f_emit, dim3(gT), dim3(256), 0, s, ix, st, ins);
-            hipLaunchKernelGGL(k_ix_grow, dim3(std::min(gW, (unsigned)n_cu * 16u)), dim3(256), 0, s, ix, (const unsigned*)touched_cells.p);
+            hipLaunchKernelGGL(k_ix_grow, dim3(std::min(gT, (unsigned)n_cu * 4u)), dim3(256), 0, s, ix, (const unsigned*)touched_cells.p);
             hipLaunchKernelGGL(k_ix_write, dim3(gT), dim3(256), 0, s, ix, ins);
             HMSG_CHECK_LAUNCH();
             const size_t rb = (size_t)NCOMP * sizeof(FRes);
@@ -1433,7 +1806,7 @@ struct Folder : Merger {
             }
             const FComp& q = fc[(size_t)comp_slot[c]];
             const FRes& r = hres[comp_slot[c]];
-            const bool changed = r.n_kept != q.nt;
+            const bool changed = r.n_kept != q.n_active;
             double bmn[3] = {0, 0, 0}, bmx[3] = {0, 0, 0};
             if (r.n_kept)
                 for (int a = 0; a < 3; ++a) {
@@ -1468,7 +1841,7 @@ struct Folder : Merger {
                 settle(k, changed, r.ncl, r.contested != 0);
             }
             k.off = q.out_off;
-            k.cap = (int)std::min<long long>(2ll * q.nt, 0x7fffffff);
+            k.cap = (int)std::min<long long>(2ll * q.n_active, 0x7fffffff);
             k.id = q.out_id;
             out.push_back(k);
         }
