@@ -65,7 +65,7 @@ struct FIndexDev {           // by value to every kernel
     double ox, oy, oz, cs;   // lattice
 };
 enum { FC_BRICKS = 0, FC_RECS = 1, FC_ERR = 2, FC_TOUCHED_CELLS = 3, FC_TOUCHED_RECS = 4, FC_ROOTS = 5, FC_L_COUNT = 6, FC_L_TOUCH = 7,
-       FC_L_LINK0 = 8, FC_L_LINK = 9, FC_L_LABEL = 10, FC_N = 16 };
+       FC_L_LINK0 = 8, FC_L_LINK = 9, FC_L_LABEL = 10, FC_L_LINK2 = 24, FC_STAT = 11 /* 5 running totals of the lists */, FC_DBG = 16, FC_N = 32 };
 enum { FERR_BRICKS = 1, FERR_RECS = 2, FERR_TOUCHED = 4, FERR_WINNER = 8, FERR_HASH = 16 };
 
 __device__ __forceinline__ unsigned long long f_key(unsigned id, int bx, int by, int bz) {
@@ -596,9 +596,11 @@ struct FStep {               // by value to the step kernels
     FTouched* touched;
     unsigned touched_cap;
     unsigned* roots;         // [ncomp + T]
-    unsigned *list_count, *list_touch, *list_link0, *list_link, *list_label;   // [T] slots that need a walk
+    unsigned *list_count, *list_touch, *list_link0, *list_link, *list_link2, *list_label;   // [T] slots that need a walk
+    unsigned short* slot_ci;  // [T] component of the slot (written by k_f_pre)
+    int* slot_mi;            // [T] member of the slot
     double eps, eps2;
-    int minpts;
+    int minpts, debug;
 };
 __device__ __forceinline__ int f_comp_of(const FStep& st, unsigned t) {
     int lo = 0, hi = st.ncomp - 1;
@@ -655,11 +657,19 @@ struct FSlot {
     double p[3];
     long long pi;            // pool index
 };
+template <bool SEARCH = false>
 __device__ __forceinline__ FSlot f_slot(const FStep& st, unsigned t) {
     FSlot s;
-    s.ci = f_comp_of(st, t);
+    if (SEARCH) {
+        s.ci = f_comp_of(st, t);
+        s.mi = f_mem_of(st, st.comps[s.ci], t);
+        st.slot_ci[t] = (unsigned short)s.ci;
+        st.slot_mi[t] = s.mi;
+    } else {
+        s.ci = (int)st.slot_ci[t];
+        s.mi = st.slot_mi[t];
+    }
     const FComp& c = st.comps[s.ci];
-    s.mi = f_mem_of(st, c, t);
     const FMem& m = st.mems[s.mi];
     s.is_node = t == m.t0;
     s.own = false;
@@ -732,24 +742,68 @@ __device__ __forceinline__ bool f_near_other(const FStep& st, const FComp& c, in
     }
     return false;
 }
-// A core slot's connections, as far as one lane can settle them (true: settled).
-//   * in the first anchor's cluster already (an anchor member's node joins once for all its own core points), or in one
-//     cell with a core point of the first anchor: connected without a distance test, and done -- see k_f_link;
-//   * an own core point of an anchor member farther than 2 eps from every other member: no foreign point within eps,
-//     and no point of its own member that a foreign point could have promoted.
+// Connections of the active core points.  Every edge of the eps-graph on core points has to be found from ONE of
+// its ends; the own core points of an anchor (member) are one node, so one witness per anchor (member) is enough:
+//   (i)   an edge to the first anchor's cluster: looked for by every point that is not in that cluster yet;
+//   (ii)  an edge to the node of an anchor member: looked for by every point whose cluster does not hold that node yet;
+//   (iii) an edge between two points that are not own core points of an anchor member (frame mask points, points
+//         promoted in this step -- not flagged in their records): looked for by BOTH ends, except that a point of
+//         the first anchor's cluster need not look (the other end does, or is in that cluster as well).
+// An own core point of an anchor member never looks for (iii): the other end does.
+// f_link_pre: what one lane can do before the walks -- a point in one cell with a core point of an anchor (member) is
+// connected to it without a distance test; an own core point farther than eps from every other member has no edge
+// to find (true: settled).
 __device__ __forceinline__ bool f_link_pre(const FIndexDev& ix, const FStep& st, const FSlot& sl, unsigned t) {
     const FComp& c = st.comps[sl.ci];
     const int me = st.ncomp + (int)(sl.own ? st.mems[sl.mi].t0 : t);
-    if (c.has_anchor) {
-        if (f_uf_find(st.parent, me) == sl.ci) return true;
-        int cx, cy, cz;
-        f_cell_of(ix, sl.p[0], sl.p[1], sl.p[2], cx, cy, cz);
-        if (f_own_cell_ncore(ix, st.mem_ids[c.m0], cx, cy, cz)) {
-            f_uf_union(st.parent, me, sl.ci);
-            return true;
+    int cx, cy, cz;
+    f_cell_of(ix, sl.p[0], sl.p[1], sl.p[2], cx, cy, cz);
+    if (sl.own && !f_near_other(st, c, sl.mi - c.m0, sl.p, st.eps + 1e-6)) return true;
+    if (c.has_anchor && f_uf_find(st.parent, me) != sl.ci && f_own_cell_ncore(ix, st.mem_ids[c.m0], cx, cy, cz)) f_uf_union(st.parent, me, sl.ci);
+    for (int j = c.has_anchor ? 1 : 0; j < c.nm; ++j) {
+        const FMem& m = st.mems[c.m0 + j];
+        if (!m.am || c.m0 + j == sl.mi) continue;
+        const double d = 1e-6;
+        if (sl.p[0] < m.mn[0] - d || sl.p[0] > m.mx[0] + d || sl.p[1] < m.mn[1] - d || sl.p[1] > m.mx[1] + d || sl.p[2] < m.mn[2] - d ||
+            sl.p[2] > m.mx[2] + d)
+            continue;
+        if (f_own_cell_ncore(ix, m.id, cx, cy, cz)) f_uf_union(st.parent, me, st.ncomp + (int)m.t0);
+    }
+    return false;
+}
+// f_link_pre2: once those unions are all done -- which of (i), (ii), (iii) is still open for the slot (0: settled).
+enum { FL_ANCHOR = 1, FL_MEMBERS = 2, FL_ALL = 4 };
+__device__ __forceinline__ unsigned f_link_pre2(const FIndexDev& ix, const FStep& st, const FSlot& sl, unsigned t) {
+    const FComp& c = st.comps[sl.ci];
+    const int me = st.ncomp + (int)(sl.own ? st.mems[sl.mi].t0 : t);
+    const int r = f_uf_find(st.parent, me);
+    const bool in_anchor = c.has_anchor && r == sl.ci;
+    unsigned need = 0u;
+    if (!sl.own && !in_anchor) need |= FL_ALL;
+    int cx, cy, cz;
+    f_cell_of(ix, sl.p[0], sl.p[1], sl.p[2], cx, cy, cz);
+    const int lo[3] = {cx - 2, cy - 2, cz - 2}, hi[3] = {cx + 2, cy + 2, cz + 2};
+    const double d = st.eps + 1e-6;
+    for (int j = 0; j < c.nm; ++j) {
+        const FMem& m = st.mems[c.m0 + j];
+        if (c.m0 + j == sl.mi) continue;
+        const bool first_anchor = c.has_anchor && j == 0;
+        if (!first_anchor && !m.am) continue;
+        if (sl.p[0] < m.mn[0] - d || sl.p[0] > m.mx[0] + d || sl.p[1] < m.mn[1] - d || sl.p[1] > m.mx[1] + d || sl.p[2] < m.mn[2] - d ||
+            sl.p[2] > m.mx[2] + d)
+            continue;
+        if (first_anchor ? in_anchor : f_uf_find(st.parent, st.ncomp + (int)m.t0) == r) continue;
+        // a cell of it with core records in the window may hold the witness
+        for (int q = 0; q < 8; ++q) {
+            const int bx = (lo[0] >> 2) + ((q >> 2) & 1), by = (lo[1] >> 2) + ((q >> 1) & 1), bz = (lo[2] >> 2) + (q & 1);
+            const unsigned b = f_find(ix, f_key(m.id, bx, by, bz));
+            if (b != F_NONE && (ix.bricks[b].cm & f_window_mask(bx, by, bz, lo, hi))) {
+                need |= first_anchor ? FL_ANCHOR : FL_MEMBERS;
+                break;
+            }
         }
     }
-    return sl.own && !f_near_other(st, c, sl.mi - c.m0, sl.p, 2.0 * st.eps + 1e-6);
+    return need;
 }
 
 // (1) per slot: core flags a lane can decide -- own core points of an anchor member stay core; a point of an anchor
@@ -781,7 +835,7 @@ __global__ void __launch_bounds__(FB) k_f_pre(FIndexDev ix, FStep st) {
     }
     // (connections start in k_f_count: every node has to be initialised before the first union)
     if (t < st.T) {
-        const FSlot sl = f_slot(st, t);
+        const FSlot sl = f_slot<true>(st, t);
         bool core = sl.own;
         if (!sl.is_node && !sl.own) {
             const FComp& c = st.comps[sl.ci];
@@ -825,7 +879,7 @@ __global__ void __launch_bounds__(256) k_f_touch(FIndexDev ix, FStep st) {
     const unsigned nw = (gridDim.x * blockDim.x) >> 6;
     for (unsigned i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n; i += nw) {
         const unsigned t = st.list_touch[i];
-        const int ci = f_comp_of(st, t);
+        const int ci = (int)st.slot_ci[t];
         const FComp c = st.comps[ci];
         const FSlot sl = f_slot(st, t);
         const double* p = sl.p;
@@ -912,7 +966,9 @@ __global__ void __launch_bounds__(256) k_f_count(FIndexDev ix, FStep st, unsigne
             unsigned t = 0u;
             if (i < n) {
                 t = st.list_link0[i];
-                hard = !f_link_pre(ix, st, f_slot(st, t), t);
+                const FSlot sl = f_slot(st, t);
+                if (!sl.own && st.mems[sl.mi].am) atomicAdd(&st.res[sl.ci].pad, 1u);      // a point of an anchor member promoted in this step
+                hard = !f_link_pre(ix, st, sl, t);
             }
             f_list_push(&ix.counters[FC_L_LINK], st.list_link, hard, t);
         }
@@ -929,6 +985,7 @@ __global__ void __launch_bounds__(256) k_f_count(FIndexDev ix, FStep st, unsigne
             bool hard = false;
             if (core && lane == 0) {
                 st.acore[t] = 1;
+                if (st.mems[sl.mi].am) atomicAdd(&st.res[sl.ci].pad, 1u);
                 hard = !f_link_pre(ix, st, sl, t);
             }
             f_list_push(&ix.counters[FC_L_LINK], st.list_link, hard, t);
@@ -966,31 +1023,44 @@ __device__ __forceinline__ void f_per_cell_leader(bool hit, int cell_lane, Fn fn
     }
 }
 
-// (4) connections of the listed core points.  Every edge of the eps-graph on core points has to be found from ONE
-//     of its ends:
-//       * a core point with a core point of the first anchor within eps joins the anchor's cluster and is done (an
-//         edge between two such points is irrelevant; any other neighbour finds this point from its side);
-//       * every other core point walks ALL its neighbourhood: core points of one cell are always connected, so one
-//         witness per (cloud, cell) is enough; the own core points of an anchor member are one node, so one witness
-//         per anchor member is enough -- plus its points promoted in this step, which are not flagged in their
-//         records and sit in cells with non-core records (also looked for in the walker's own member).
-__global__ void __launch_bounds__(256) k_f_link(FIndexDev ix, FStep st) {
+// (3b) the listed core points once more, now that every lane-level union is done
+__global__ void __launch_bounds__(256) k_f_linkpre2(FIndexDev ix, FStep st) {
     const int lane = threadIdx.x & 63;
     const unsigned n = ix.counters[FC_L_LINK];
+    for (unsigned i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += gridDim.x * blockDim.x) {
+        const unsigned i = i0 + (unsigned)lane;
+        bool hard = false;
+        unsigned t = 0u;
+        if (i < n) {
+            t = st.list_link[i];
+            const unsigned need = f_link_pre2(ix, st, f_slot(st, t), t);
+            st.pos[t] = need;                                    // (scratch until the scan of the keep flags)
+            hard = need != 0u;
+        }
+        f_list_push(&ix.counters[FC_L_LINK2], st.list_link2, hard, t);
+    }
+}
+
+// (4) the walks of the listed core points: whatever of (i), (ii), (iii) k_f_linkpre2 left open
+__global__ void __launch_bounds__(256) k_f_link(FIndexDev ix, FStep st) {
+    const int lane = threadIdx.x & 63;
+    const unsigned n = ix.counters[FC_L_LINK2];
     const unsigned nw = (gridDim.x * blockDim.x) >> 6;
     for (unsigned i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n; i += nw) {
-        const unsigned t = st.list_link[i];
+        const unsigned t = st.list_link2[i];
         const FSlot sl = f_slot(st, t);
         const int ci = sl.ci;
         const FComp c = st.comps[ci];
         const FMem mm = st.mems[sl.mi];
         const int jme = sl.mi - c.m0;
+        if (st.debug && lane == 0) atomicAdd(&ix.counters[FC_DBG + (c.has_anchor ? 0 : 4) + (sl.own ? 0 : (mm.am ? 1 : 2))], 1u);
         const double* p = sl.p;
         int cx, cy, cz;
         f_cell_of(ix, p[0], p[1], p[2], cx, cy, cz);
         const int lo[3] = {cx - 2, cy - 2, cz - 2}, hi[3] = {cx + 2, cy + 2, cz + 2};
         const int me = st.ncomp + (int)(sl.own ? mm.t0 : t);
-        if (c.has_anchor) {                                      // the first core point of the anchor within eps
+        const unsigned need = st.pos[t];
+        if (need & FL_ANCHOR) {                                  // (i): the first core point of the anchor within eps
             bool in_anchor = false;
             f_walk(ix, st.mem_ids + c.m0, 1, lo, hi, [&](int) { return (int)FSEL_CORE; },
                    [&](bool hv, int, int ccx, int ccy, int ccz, const FCell& d, unsigned) -> unsigned {
@@ -1006,17 +1076,25 @@ __global__ void __launch_bounds__(256) k_f_link(FIndexDev ix, FStep st) {
                    [&]() { return in_anchor; }, 128u);
             if (in_anchor) {
                 if (lane == 0) f_uf_union(st.parent, me, ci);
-                continue;
+                if (!sl.own) continue;                           // (iii) is the other ends' now; (ii) stays open for an anchor member's node
             }
         }
+        if (!(need & (FL_MEMBERS | FL_ALL))) continue;
+        // (ii) + (iii).  all: every core point within eps that is not an own core point of an anchor member, one
+        // witness per anchor member; else only the witnesses.
+        const bool all = (need & FL_ALL) != 0u;
         const int j0 = c.has_anchor ? 1 : 0;
         unsigned long long done_am = 0ull;                       // anchor members (first 64 of the walk) with a witness
         if (sl.own && jme - j0 < 64) done_am |= 1ull << (jme - j0);   // (its own member's node is the walker itself)
         f_walk(ix, st.mem_ids + c.m0 + j0, c.nm - j0, lo, hi,
-               [&](int jj) { return (sl.own && jj + j0 == jme) ? (int)FSEL_NONCORE : (int)FSEL_ALL; },
+               [&](int jj) {
+                   const bool am = st.mems[c.m0 + j0 + jj].am != 0u;
+                   if (all) return (sl.own && jj + j0 == jme) ? (int)FSEL_SKIP : (int)FSEL_ALL;
+                   return (am && jj + j0 != jme) ? (int)FSEL_CORE : (int)FSEL_SKIP;
+               },
                [&](bool hv, int jj, int ccx, int ccy, int ccz, const FCell& d, unsigned) -> unsigned {
                    if (!hv) return 0u;
-                   if (jj < 64 && (done_am >> jj & 1ull) && d.ncore >= d.cnt) return 0u;
+                   if (jj < 64 && (done_am >> jj & 1ull) && (!all || d.ncore >= d.cnt)) return 0u;
                    double dmin2, dmax2;
                    f_cube_dist(ix, p, ccx, ccy, ccz, dmin2, dmax2);
                    return dmin2 >= st.eps2 * (1.0 + 1e-9) + 1e-12 ? 0u : d.cnt;
@@ -1028,8 +1106,9 @@ __global__ void __launch_bounds__(256) k_f_link(FIndexDev ix, FStep st) {
                        const FMem& m = st.mems[c.m0 + j0 + jj];
                        node = f_rec_node(st, m, rc);
                        const unsigned q = m.t0 + 1u + rc.lidx;
-                       hit = q != t && (st.acore[q] != 0);
-                       am_hit = hit && m.am && (rc.flags & F_CORE);
+                       am_hit = m.am && (rc.flags & F_CORE);
+                       hit = q != t && (st.acore[q] != 0) && (all || am_hit);
+                       am_hit = am_hit && hit;
                        if (am_hit && jj < 64 && (done_am >> jj & 1ull)) hit = false;      // (that node is connected already)
                        if (am_hit && jj >= 64 && sl.own && jj + j0 == jme) hit = false;
                    }
@@ -1222,7 +1301,7 @@ __global__ void k_f_pick(FIndexDev ix, FStep st) {
         const unsigned r = st.roots[i];
         const unsigned sz = st.size[r];
         if (!sz) continue;
-        const int ci = r < (unsigned)st.ncomp ? (int)r : f_comp_of(st, r - (unsigned)st.ncomp);
+        const int ci = r < (unsigned)st.ncomp ? (int)r : (int)st.slot_ci[r - (unsigned)st.ncomp];
         atomicMax(&st.best[ci], ((unsigned long long)sz << 32) | (unsigned long long)(0xffffffffu - st.first[r]));
     }
 }
@@ -1230,14 +1309,19 @@ __global__ void k_f_pick(FIndexDev ix, FStep st) {
 __global__ void k_f_keep(FIndexDev ix, FStep st) {
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0u) {                                               // (the lists of this step have been consumed)
+        ix.counters[FC_STAT] += ix.counters[FC_L_COUNT];
+        ix.counters[FC_STAT + 1] += ix.counters[FC_L_TOUCH];
+        ix.counters[FC_STAT + 2] += ix.counters[FC_L_LINK2];
+        ix.counters[FC_STAT + 3] += ix.counters[FC_L_LABEL];
+        ix.counters[FC_STAT + 4] += ix.counters[FC_TOUCHED_RECS];
         ix.counters[FC_ROOTS] = 0u;
         ix.counters[FC_TOUCHED_RECS] = 0u;
-        ix.counters[FC_L_COUNT] = ix.counters[FC_L_TOUCH] = ix.counters[FC_L_LINK0] = ix.counters[FC_L_LINK] = ix.counters[FC_L_LABEL] = 0u;
+        ix.counters[FC_L_COUNT] = ix.counters[FC_L_TOUCH] = ix.counters[FC_L_LINK0] = ix.counters[FC_L_LINK] = ix.counters[FC_L_LINK2] = ix.counters[FC_L_LABEL] = 0u;
     }
     if (t >= st.T) return;
-    const int ci = f_comp_of(st, t);
+    const int ci = (int)st.slot_ci[t];
     const FComp& c = st.comps[ci];
-    const FMem& m = st.mems[f_mem_of(st, c, t)];
+    const FMem& m = st.mems[st.slot_mi[t]];
     if (t == m.t0) {
         st.keep[t] = 0u;
         return;
@@ -1263,12 +1347,12 @@ __global__ void __launch_bounds__(256) k_f_emit(FIndexDev ix, FStep st, FInsArgs
     double v[3] = {0, 0, 0};
     unsigned out_id = 0u;
     if (in) {
-        ci = f_comp_of(st, t);
+        ci = (int)st.slot_ci[t];
         const FComp c = st.comps[ci];
         kp = st.keep[t] != 0u;
         const unsigned k = st.pos[t] - st.pos[c.t0];
         if (kp) {
-            const FMem m = st.mems[f_mem_of(st, c, t)];
+            const FMem m = st.mems[st.slot_mi[t]];
             const size_t pi = (size_t)(m.off + (long long)(t - m.t0 - 1u)) * 3;
             const long long d = c.out_off + (long long)k;
             for (int a = 0; a < 3; ++a) {
@@ -1319,7 +1403,8 @@ struct Folder : Merger {
     DevBuf<char> d_pack;             // [comps | mems | ids]
     PinnedBuf<char> h_pack;
     DevBuf<unsigned char> acore;
-    DevBuf<int> parent, lab;
+    DevBuf<int> parent, lab, slot_mi;
+    DevBuf<unsigned short> slot_ci;
     DevBuf<unsigned> size, first, keep, pos, dst, item_id, item_lidx, roots, cellref, slot, touched_cells, lists;
     DevBuf<unsigned long long> best;
     DevBuf<FRes> d_res;
@@ -1635,6 +1720,7 @@ struct Folder : Merger {
         lap(3);
         // ---- the step kernels
         const int NCOMP = (int)fc.size();
+        HMSG_REQUIRE(NCOMP < 65536, HMSG_ERR_UNSUPPORTED, "merge: more than 65535 components in one fold step");
         FRes* hres = nullptr;
         if (NCOMP) {
             const size_t off_m = (fc.size() * sizeof(FComp) + 15) & ~(size_t)15, off_i = off_m + ((fm.size() * sizeof(FMem) + 15) & ~(size_t)15),
@@ -1683,13 +1769,19 @@ struct Folder : Merger {
             st.touched = touched.p;
             st.touched_cap = TOUCHED_CAP;
             st.roots = roots.p;
-            lists.ensure((size_t)T * 5);
+            lists.ensure((size_t)T * 6);
+            slot_ci.ensure(T);
+            slot_mi.ensure(T);
+            st.slot_ci = slot_ci.p;
+            st.slot_mi = slot_mi.p;
+            st.list_link2 = lists.p + 5 * (size_t)T;
             st.list_count = lists.p;
             st.list_touch = lists.p + T;
             st.list_link0 = lists.p + 2 * (size_t)T;
             st.list_link = lists.p + 3 * (size_t)T;
             st.list_label = lists.p + 4 * (size_t)T;
             st.eps = eps;
+            st.debug = getenv("HMSG_DEBUG_TIMING") ? 1 : 0;
             st.eps2 = eps * eps;
             st.minpts = minpts;
             FInsArgs ins;
@@ -1716,6 +1808,7 @@ struct Folder : Merger {
             }
             {
                 ProfScope ps(h->prof, s, "k_f_link", (double)T * 24.0);
+                hipLaunchKernelGGL(k_f_linkpre2, dim3(gL), dim3(256), 0, s, ix, st);
                 hipLaunchKernelGGL(k_f_link, dim3(gW), dim3(256), 0, s, ix, st);
             }
             {

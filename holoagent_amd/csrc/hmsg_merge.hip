@@ -1010,6 +1010,10 @@ static bool hmsg_fold_sequential(hmsg_ctx* h) {
         HIP_TRY(hipMemcpy(cnt, m.ix_counters.p, sizeof(cnt), hipMemcpyDeviceToHost));
         fprintf(stderr, "[hmsg fold] index: %u of %u bricks, %u of %u records, hash %u slots\n", cnt[FC_BRICKS], m.ix.brick_cap, cnt[FC_RECS],
                 m.ix.rec_cap, m.ix.hmask + 1);
+        fprintf(stderr, "[hmsg fold] walks: count %u  touch %u  link %u  label %u   touched anchor points %u\n", cnt[FC_STAT], cnt[FC_STAT + 1],
+                cnt[FC_STAT + 2], cnt[FC_STAT + 3], cnt[FC_STAT + 4]);
+        fprintf(stderr, "[hmsg fold] link walks: anchor comps own %u promoted %u raw %u | plain comps own %u promoted %u raw %u\n", cnt[FC_DBG], cnt[FC_DBG + 1],
+                cnt[FC_DBG + 2], cnt[FC_DBG + 4], cnt[FC_DBG + 5], cnt[FC_DBG + 6]);
     }
     h->merged = true;
     return true;
