@@ -44,13 +44,14 @@ struct FCell {               // one lattice cell of one cloud
     unsigned cnt, cap;
     unsigned ncore;          // records flagged F_CORE
     unsigned pend, base;     // insertion in flight: reserved slots / first slot of this batch
-    unsigned pad0, pad1;
+    unsigned long long sub;  // which of the cell's 4x4x4 sub-cells hold a record (bit = sx*16 + sy*4 + sz)
 };
 struct FBrick {
     unsigned long long occ;  // cells with records (bit = lx*16 + ly*4 + lz)
     unsigned long long cm;   // cells with a record flagged F_CORE
     unsigned long long ncm;  // cells with a record not flagged F_CORE
-    unsigned long long pad[5];
+    unsigned long long pm;   // step scratch: cells of an anchor member with a point promoted in this step (not flagged in its record)
+    unsigned long long pad[4];
     FCell c[64];
 };
 struct FIndexDev {           // by value to every kernel
@@ -65,7 +66,7 @@ struct FIndexDev {           // by value to every kernel
     double ox, oy, oz, cs;   // lattice
 };
 enum { FC_BRICKS = 0, FC_RECS = 1, FC_ERR = 2, FC_TOUCHED_CELLS = 3, FC_TOUCHED_RECS = 4, FC_ROOTS = 5, FC_L_COUNT = 6, FC_L_TOUCH = 7,
-       FC_L_LINK0 = 8, FC_L_LINK = 9, FC_L_LABEL = 10, FC_L_LINK2 = 24, FC_STAT = 11 /* 5 running totals of the lists */, FC_DBG = 16, FC_N = 32 };
+       FC_L_LINK0 = 8, FC_L_LINK = 9, FC_L_LABEL = 10, FC_L_LINK2 = 24, FC_DIRTY = 25, FC_STAT = 11 /* 5 running totals of the lists */, FC_DBG = 32, FC_N = 64 };
 enum { FERR_BRICKS = 1, FERR_RECS = 2, FERR_TOUCHED = 4, FERR_WINNER = 8, FERR_HASH = 16 };
 
 __device__ __forceinline__ unsigned long long f_key(unsigned id, int bx, int by, int bz) {
@@ -152,6 +153,21 @@ __device__ __forceinline__ unsigned f_wave_slot(bool want, unsigned* counter) {
     if (lane == leader) base = atomicAdd(counter, (unsigned)__popcll(m));
     base = __shfl(base, leader);
     return base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+}
+
+// sub-cell of a point inside its cell (a quarter of the cell side per axis)
+__device__ __forceinline__ unsigned long long f_sub_bit(const FIndexDev& ix, double x, double y, double z) {
+    int cx, cy, cz;
+    f_cell_of(ix, x, y, z, cx, cy, cz);
+    const double q[3] = {x, y, z}, o[3] = {ix.ox, ix.oy, ix.oz};
+    const int c[3] = {cx, cy, cz};
+    int sidx = 0;
+    for (int a = 0; a < 3; ++a) {
+        int sa = (int)floor((q[a] - (o[a] + (double)c[a] * ix.cs)) / (ix.cs * 0.25));
+        sa = sa < 0 ? 0 : (sa > 3 ? 3 : sa);
+        sidx = sidx * 4 + sa;
+    }
+    return 1ull << sidx;
 }
 
 // ---------------------------------------------------------------------------------------------- insertion
@@ -317,6 +333,10 @@ __global__ void k_ix_write(FIndexDev ix, FInsArgs a) {
     r.lidx = it.lidx;
     r.flags = it.core ? F_CORE : 0u;
     ix.recs[c.ptr + c.base + a.slot[i]] = r;
+    {
+        const unsigned long long sb = f_sub_bit(ix, r.x, r.y, r.z);
+        if (!(c.sub & sb)) atomicOr(&c.sub, sb);
+    }
     const unsigned long long bit = 1ull << (cr & 63u);
     if (it.core) {
         atomicAdd(&c.ncore, 1u);
@@ -359,6 +379,26 @@ __device__ __forceinline__ void f_cube_dist(const FIndexDev& ix, const double* p
         dmax2 += far * far;
     }
 }
+// can a record of the cell be within sqrt(lim2) of p at all?  (nearest corner of the OCCUPIED sub-cells, with a margin of
+// a thousandth of a sub-cell for the rounding of the binning)
+__device__ __forceinline__ bool f_sub_reach(const FIndexDev& ix, const double* p, int cx, int cy, int cz, unsigned long long sub, double lim2) {
+    const double o[3] = {ix.ox + (double)cx * ix.cs, ix.oy + (double)cy * ix.cs, ix.oz + (double)cz * ix.cs};
+    const double ss = ix.cs * 0.25, mg = ss * 1e-3;
+    // per axis: squared gap to each of the 4 slabs
+    double g[3][4];
+    for (int a = 0; a < 3; ++a)
+        for (int k = 0; k < 4; ++k) {
+            const double lo = o[a] + (double)k * ss - mg, hi = lo + ss + 2.0 * mg;
+            const double gap = fmax(0.0, fmax(lo - p[a], p[a] - hi));
+            g[a][k] = gap * gap;
+        }
+    while (sub) {
+        const int b = __ffsll(sub) - 1;
+        sub &= sub - 1ull;
+        if (g[0][b >> 4] + g[1][(b >> 2) & 3] + g[2][b & 3] < lim2) return true;
+    }
+    return false;
+}
 __device__ __forceinline__ unsigned f_wave_incl_scan(unsigned v) {
     const int lane = threadIdx.x & 63;
     for (int s = 1; s < 64; s <<= 1) {
@@ -378,7 +418,7 @@ __device__ __forceinline__ int f_wave_search(unsigned incl, unsigned t) {
     return min(a, 63);
 }
 
-enum { FSEL_SKIP = 0, FSEL_ALL = 1, FSEL_CORE = 2, FSEL_NONCORE = 3 };
+enum { FSEL_SKIP = 0, FSEL_ALL = 1, FSEL_CORE = 2, FSEL_NONCORE = 3, FSEL_CORE_PROM = 4, FSEL_PROM = 5 };
 // Wave-uniform walk over the cells of the clouds ids[0..k) inside the cell window [lo, hi] (at most 2 bricks per axis:
 // hi - lo <= 4) and over the records of the cells `cellfn` selects.  The candidate cells of all clouds are compacted
 // over the lanes (one lane per cell, 64 per round), their records laid end to end (64 per trip):
@@ -390,9 +430,12 @@ enum { FSEL_SKIP = 0, FSEL_ALL = 1, FSEL_CORE = 2, FSEL_NONCORE = 3 };
 //   budget > 0: a round takes only as many candidate cells as hold `budget` records (at least one) and re-offers the
 //       rest to cellfn in the next round -- a witness found in one heavy cell then lets cellfn drop its neighbours;
 //       cellfn must be free of side effects.
+struct FWalkStat {            // development aid: what a walk did (wave-uniform counters)
+    unsigned groups, rounds, trips, cells, recs;
+};
 template <class SelFn, class CellFn, class RecFn, class StopFn>
 __device__ __forceinline__ void f_walk(const FIndexDev& ix, const unsigned* __restrict__ ids, int k, const int* lo, const int* hi, SelFn sel,
-                                       CellFn cellfn, RecFn recfn, StopFn stop, unsigned budget = 0u) {
+                                       CellFn cellfn, RecFn recfn, StopFn stop, unsigned budget = 0u, FWalkStat* ws = nullptr) {
     const int lane = threadIdx.x & 63;
     const int b0x = lo[0] >> 2, b0y = lo[1] >> 2, b0z = lo[2] >> 2;
     for (int g = 0; g < k; g += 8) {
@@ -407,7 +450,7 @@ __device__ __forceinline__ void f_walk(const FIndexDev& ix, const unsigned* __re
                 bi = f_find(ix, f_key(ids[j_l], bx, by, bz));
                 if (bi != F_NONE) {
                     const FBrick& br = ix.bricks[bi];
-                    const unsigned long long m = kind == FSEL_ALL ? br.occ : (kind == FSEL_CORE ? br.cm : br.ncm);
+                    const unsigned long long m = kind == FSEL_ALL ? br.occ : (kind == FSEL_CORE ? br.cm : (kind == FSEL_NONCORE ? br.ncm : (kind == FSEL_PROM ? br.pm : (br.cm | br.pm))));
                     cand = m & f_window_mask(bx, by, bz, lo, hi);
                 }
             }
@@ -415,6 +458,10 @@ __device__ __forceinline__ void f_walk(const FIndexDev& ix, const unsigned* __re
         const unsigned np = (unsigned)__popcll(cand);
         const unsigned cincl = f_wave_incl_scan(np);
         const unsigned ctotal = __shfl(cincl, 63);
+        if (ws) {
+            ws->groups += 1u;
+            ws->cells += ctotal;
+        }
         for (unsigned c0 = 0, took = 64u; c0 < ctotal; c0 += took) {
             const unsigned ci = c0 + (unsigned)lane;
             const bool have = ci < ctotal;
@@ -426,7 +473,8 @@ __device__ __forceinline__ void f_walk(const FIndexDev& ix, const unsigned* __re
             const int cx = (b0x + ((o >> 2) & 1)) * 4 + (bit >> 4), cy = (b0y + ((o >> 1) & 1)) * 4 + ((bit >> 2) & 3),
                       cz = (b0z + (o & 1)) * 4 + (bit & 3);
             FCell d;
-            d.ptr = d.cnt = d.cap = d.ncore = d.pend = d.base = d.pad0 = d.pad1 = 0u;
+            d.ptr = d.cnt = d.cap = d.ncore = d.pend = d.base = 0u;
+            d.sub = 0ull;
             if (have) d = ix.bricks[o_bi].c[bit];
             unsigned n = cellfn(have, j, cx, cy, cz, d, o_bi * 64u + (unsigned)bit);
             unsigned rincl = f_wave_incl_scan(n);
@@ -437,6 +485,11 @@ __device__ __forceinline__ void f_walk(const FIndexDev& ix, const unsigned* __re
                 rincl = min(rincl, __shfl(rincl, (int)took - 1));
             }
             const unsigned rtotal = __shfl(rincl, 63);
+            if (ws) {
+                ws->rounds += 1u;
+                ws->recs += rtotal;
+                ws->trips += (rtotal + 63u) >> 6;
+            }
             for (unsigned t0 = 0; t0 < rtotal; t0 += 64u) {
                 const unsigned t = t0 + (unsigned)lane;
                 const int cl = f_wave_search(rincl, t);
@@ -533,6 +586,7 @@ __global__ void __launch_bounds__(256) k_f_overlap(FIndexDev ix, const double* _
                 double dmin2, dmax2;
                 f_cube_dist(ix, p, bx * 4 + (bit >> 4), by * 4 + ((bit >> 2) & 3), bz * 4 + (bit & 3), dmin2, dmax2);
                 if (dmin2 > reach * reach) continue;
+                if (br.c[bit].cnt >= 8u && !f_sub_reach(ix, p, bx * 4 + (bit >> 4), by * 4 + ((bit >> 2) & 3), bz * 4 + (bit & 3), br.c[bit].sub, reach * reach)) continue;
                 hit = f_ov_scan(ix.recs, br.c[bit].ptr, br.c[bit].cnt, x, y, z, r2);
             }
         }
@@ -597,10 +651,13 @@ struct FStep {               // by value to the step kernels
     unsigned touched_cap;
     unsigned* roots;         // [ncomp + T]
     unsigned *list_count, *list_touch, *list_link0, *list_link, *list_link2, *list_label;   // [T] slots that need a walk
+    unsigned* dirty;         // bricks with a promoted-point mask to clear
+    unsigned dirty_cap;
     unsigned short* slot_ci;  // [T] component of the slot (written by k_f_pre)
     int* slot_mi;            // [T] member of the slot
     double eps, eps2;
     int minpts, debug;
+    unsigned long long* dbgbuf;   // development aid: per listed link slot, what its walk did
 };
 __device__ __forceinline__ int f_comp_of(const FStep& st, unsigned t) {
     int lo = 0, hi = st.ncomp - 1;
@@ -619,18 +676,19 @@ __device__ __forceinline__ int f_mem_of(const FStep& st, const FComp& c, unsigne
     }
     return lo;
 }
-__device__ __forceinline__ int f_uf_find(int* parent, int x) {
+__device__ __forceinline__ int f_uf_find(int* parent, int x, unsigned* hops = nullptr) {
     for (;;) {
         const int p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (hops) ++*hops;
         if (p == x) return x;
         const int gp = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (gp != p) __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // halving: any ancestor is valid
         x = p;
     }
 }
-__device__ __forceinline__ void f_uf_union(int* parent, int a, int b) {
-    a = f_uf_find(parent, a);
-    b = f_uf_find(parent, b);
+__device__ __forceinline__ void f_uf_union(int* parent, int a, int b, unsigned* hops = nullptr) {
+    a = f_uf_find(parent, a, hops);
+    b = f_uf_find(parent, b, hops);
     for (;;) {
         if (a == b) return;
         if (a < b) {
@@ -639,9 +697,21 @@ __device__ __forceinline__ void f_uf_union(int* parent, int a, int b) {
             b = t;
         }                                   // a > b: the larger root goes under the smaller (roots = smallest node of the cluster)
         if (atomicCAS(&parent[a], a, b) == a) return;
-        a = f_uf_find(parent, a);
-        b = f_uf_find(parent, b);
+        if (hops) *hops += 1000u;           // (a failed CAS)
+        a = f_uf_find(parent, a, hops);
+        b = f_uf_find(parent, b, hops);
     }
+}
+// Ordinary loads (may be served by this CU's L1, i.e. be STALE): a stale parent is an older ancestor, so the result is
+// an ancestor of x -- equal results for two nodes still prove that they are connected, unequal ones only cost a real
+// union.  (Thousands of walkers ending their walks on one hot root word through the L2 is the bottleneck otherwise.)
+__device__ __forceinline__ int f_uf_find_cached(const int* parent, int x) {
+    for (int hop = 0; hop < 64; ++hop) {
+        const int p = parent[x];
+        if (p == x) return x;
+        x = p;
+    }
+    return x;
 }
 __device__ __forceinline__ int f_uf_root_ro(const int* parent, int x) {      // read-only walk (no unions in flight)
     for (;;) {
@@ -688,6 +758,21 @@ __device__ __forceinline__ FSlot f_slot(const FStep& st, unsigned t) {
 __device__ __forceinline__ int f_rec_node(const FStep& st, const FMem& m, const FRec& rc) {
     return st.ncomp + (int)((m.am && (rc.flags & F_CORE)) ? m.t0 : m.t0 + 1u + rc.lidx);
 }
+
+// development aid (HMSG_DEBUG_TIMING): 100 MHz ticks a wave spends on an item -> [0] sum, [1] max, [2] items
+struct FDbgTimer {
+    unsigned* c;
+    unsigned long long t0;
+    __device__ FDbgTimer(int on, unsigned* counters) : c(on ? counters : nullptr), t0(on ? wall_clock64() : 0ull) {}
+    __device__ ~FDbgTimer() {
+        if (c && (threadIdx.x & 63) == 0) {
+            const unsigned dt = (unsigned)(wall_clock64() - t0);
+            atomicAdd(&c[0], dt);
+            atomicMax(&c[1], dt);
+            atomicAdd(&c[2], 1u);
+        }
+    }
+};
 
 // The step kernels come in pairs: a THREAD per slot settles what a single lane can (most active points re-observe an
 // anchored surface: a look at one cell descriptor decides them; a point of an anchor member that is farther than eps
@@ -742,6 +827,22 @@ __device__ __forceinline__ bool f_near_other(const FStep& st, const FComp& c, in
     }
     return false;
 }
+// a point of an anchor member became core in this step: its record does not say so, its cell does
+__device__ __forceinline__ void f_mark_promoted(const FIndexDev& ix, const FStep& st, const FSlot& sl) {
+    int cx, cy, cz;
+    f_cell_of(ix, sl.p[0], sl.p[1], sl.p[2], cx, cy, cz);
+    const unsigned b = f_find(ix, f_key(st.mems[sl.mi].id, cx >> 2, cy >> 2, cz >> 2));
+    if (b == F_NONE) return;
+    const unsigned long long bit = 1ull << f_local(cx, cy, cz);
+    if (ix.bricks[b].pm & bit) return;
+    const unsigned long long old = atomicOr(&ix.bricks[b].pm, bit);
+    if (old == 0ull) {
+        const unsigned q = atomicAdd(&ix.counters[FC_DIRTY], 1u);
+        if (q < st.dirty_cap) st.dirty[q] = b;
+        else atomicOr(&ix.counters[FC_ERR], (unsigned)FERR_TOUCHED);
+    }
+}
+
 // Connections of the active core points.  Every edge of the eps-graph on core points has to be found from ONE of
 // its ends; the own core points of an anchor (member) are one node, so one witness per anchor (member) is enough:
 //   (i)   an edge to the first anchor's cluster: looked for by every point that is not in that cluster yet;
@@ -759,7 +860,7 @@ __device__ __forceinline__ bool f_link_pre(const FIndexDev& ix, const FStep& st,
     int cx, cy, cz;
     f_cell_of(ix, sl.p[0], sl.p[1], sl.p[2], cx, cy, cz);
     if (sl.own && !f_near_other(st, c, sl.mi - c.m0, sl.p, st.eps + 1e-6)) return true;
-    if (c.has_anchor && f_uf_find(st.parent, me) != sl.ci && f_own_cell_ncore(ix, st.mem_ids[c.m0], cx, cy, cz)) f_uf_union(st.parent, me, sl.ci);
+    if (c.has_anchor && f_uf_find_cached(st.parent, me) != sl.ci && f_own_cell_ncore(ix, st.mem_ids[c.m0], cx, cy, cz)) f_uf_union(st.parent, me, sl.ci);
     for (int j = c.has_anchor ? 1 : 0; j < c.nm; ++j) {
         const FMem& m = st.mems[c.m0 + j];
         if (!m.am || c.m0 + j == sl.mi) continue;
@@ -767,7 +868,8 @@ __device__ __forceinline__ bool f_link_pre(const FIndexDev& ix, const FStep& st,
         if (sl.p[0] < m.mn[0] - d || sl.p[0] > m.mx[0] + d || sl.p[1] < m.mn[1] - d || sl.p[1] > m.mx[1] + d || sl.p[2] < m.mn[2] - d ||
             sl.p[2] > m.mx[2] + d)
             continue;
-        if (f_own_cell_ncore(ix, m.id, cx, cy, cz)) f_uf_union(st.parent, me, st.ncomp + (int)m.t0);
+        if (f_own_cell_ncore(ix, m.id, cx, cy, cz) && f_uf_find_cached(st.parent, me) != f_uf_find_cached(st.parent, st.ncomp + (int)m.t0))
+            f_uf_union(st.parent, me, st.ncomp + (int)m.t0);
     }
     return false;
 }
@@ -776,7 +878,7 @@ enum { FL_ANCHOR = 1, FL_MEMBERS = 2, FL_ALL = 4 };
 __device__ __forceinline__ unsigned f_link_pre2(const FIndexDev& ix, const FStep& st, const FSlot& sl, unsigned t) {
     const FComp& c = st.comps[sl.ci];
     const int me = st.ncomp + (int)(sl.own ? st.mems[sl.mi].t0 : t);
-    const int r = f_uf_find(st.parent, me);
+    const int r = f_uf_root_ro(st.parent, me);                   // (no union in flight in this launch)
     const bool in_anchor = c.has_anchor && r == sl.ci;
     unsigned need = 0u;
     if (!sl.own && !in_anchor) need |= FL_ALL;
@@ -792,7 +894,7 @@ __device__ __forceinline__ unsigned f_link_pre2(const FIndexDev& ix, const FStep
         if (sl.p[0] < m.mn[0] - d || sl.p[0] > m.mx[0] + d || sl.p[1] < m.mn[1] - d || sl.p[1] > m.mx[1] + d || sl.p[2] < m.mn[2] - d ||
             sl.p[2] > m.mx[2] + d)
             continue;
-        if (first_anchor ? in_anchor : f_uf_find(st.parent, st.ncomp + (int)m.t0) == r) continue;
+        if (first_anchor ? in_anchor : f_uf_root_ro(st.parent, st.ncomp + (int)m.t0) == r) continue;
         // a cell of it with core records in the window may hold the witness
         for (int q = 0; q < 8; ++q) {
             const int bx = (lo[0] >> 2) + ((q >> 2) & 1), by = (lo[1] >> 2) + ((q >> 1) & 1), bz = (lo[2] >> 2) + (q & 1);
@@ -891,7 +993,8 @@ __global__ void __launch_bounds__(256) k_f_touch(FIndexDev ix, FStep st) {
                    if (!have || d.ncore >= d.cnt) return 0u;
                    double dmin2, dmax2;
                    f_cube_dist(ix, p, ccx, ccy, ccz, dmin2, dmax2);
-                   return dmin2 >= st.eps2 * (1.0 + 1e-9) + 1e-12 ? 0u : d.cnt;
+                   if (dmin2 >= st.eps2 * (1.0 + 1e-9) + 1e-12) return 0u;
+                   return (d.cnt >= 8u && !f_sub_reach(ix, p, ccx, ccy, ccz, d.sub, st.eps2 * (1.0 + 1e-9) + 1e-12)) ? 0u : d.cnt;
                },
                [&](bool valid, int, int, const FRec& rc, unsigned ri) {
                    if (!valid || (rc.flags & F_CORE) || !(f_dist2(rc.x, rc.y, rc.z, p[0], p[1], p[2]) < st.eps2)) return;
@@ -941,7 +1044,9 @@ __device__ __forceinline__ bool f_is_core(const FIndexDev& ix, const FStep& st, 
                    double dmin2, dmax2;
                    f_cube_dist(ix, p, ccx, ccy, ccz, dmin2, dmax2);
                    if (dmax2 < st.eps2 * (1.0 - 1e-9) - 1e-12) sure = d.cnt;             // the whole cell is in reach
-                   else if (!(dmin2 >= st.eps2 * (1.0 + 1e-9) + 1e-12)) scan = d.cnt;
+                   else if (!(dmin2 >= st.eps2 * (1.0 + 1e-9) + 1e-12) &&
+                            !(d.cnt >= 8u && !f_sub_reach(ix, p, ccx, ccy, ccz, d.sub, st.eps2 * (1.0 + 1e-9) + 1e-12)))
+                       scan = d.cnt;
                }
                have += wave_sum_i32((int)sure);
                return scan;
@@ -967,7 +1072,7 @@ __global__ void __launch_bounds__(256) k_f_count(FIndexDev ix, FStep st, unsigne
             if (i < n) {
                 t = st.list_link0[i];
                 const FSlot sl = f_slot(st, t);
-                if (!sl.own && st.mems[sl.mi].am) atomicAdd(&st.res[sl.ci].pad, 1u);      // a point of an anchor member promoted in this step
+                if (!sl.own && st.mems[sl.mi].am) f_mark_promoted(ix, st, sl);            // a point of an anchor member promoted in this step
                 hard = !f_link_pre(ix, st, sl, t);
             }
             f_list_push(&ix.counters[FC_L_LINK], st.list_link, hard, t);
@@ -985,7 +1090,7 @@ __global__ void __launch_bounds__(256) k_f_count(FIndexDev ix, FStep st, unsigne
             bool hard = false;
             if (core && lane == 0) {
                 st.acore[t] = 1;
-                if (st.mems[sl.mi].am) atomicAdd(&st.res[sl.ci].pad, 1u);
+                if (st.mems[sl.mi].am) f_mark_promoted(ix, st, sl);
                 hard = !f_link_pre(ix, st, sl, t);
             }
             f_list_push(&ix.counters[FC_L_LINK], st.list_link, hard, t);
@@ -1053,13 +1158,15 @@ __global__ void __launch_bounds__(256) k_f_link(FIndexDev ix, FStep st) {
         const FComp c = st.comps[ci];
         const FMem mm = st.mems[sl.mi];
         const int jme = sl.mi - c.m0;
-        if (st.debug && lane == 0) atomicAdd(&ix.counters[FC_DBG + (c.has_anchor ? 0 : 4) + (sl.own ? 0 : (mm.am ? 1 : 2))], 1u);
+        if (st.debug && lane == 0 && (t & 15u) == 0u) atomicAdd(&ix.counters[FC_DBG + (c.has_anchor ? 0 : 4) + (sl.own ? 0 : (mm.am ? 1 : 2))], 16u);
         const double* p = sl.p;
         int cx, cy, cz;
         f_cell_of(ix, p[0], p[1], p[2], cx, cy, cz);
         const int lo[3] = {cx - 2, cy - 2, cz - 2}, hi[3] = {cx + 2, cy + 2, cz + 2};
         const int me = st.ncomp + (int)(sl.own ? mm.t0 : t);
         const unsigned need = st.pos[t];
+        FWalkStat wst = {0u, 0u, 0u, 0u, 0u};
+        const unsigned long long dbg_t0 = st.dbgbuf ? wall_clock64() : 0ull;
         if (need & FL_ANCHOR) {                                  // (i): the first core point of the anchor within eps
             bool in_anchor = false;
             f_walk(ix, st.mem_ids + c.m0, 1, lo, hi, [&](int) { return (int)FSEL_CORE; },
@@ -1067,13 +1174,14 @@ __global__ void __launch_bounds__(256) k_f_link(FIndexDev ix, FStep st) {
                        if (!hv || d.ncore == 0u) return 0u;
                        double dmin2, dmax2;
                        f_cube_dist(ix, p, ccx, ccy, ccz, dmin2, dmax2);
-                       return dmin2 >= st.eps2 * (1.0 + 1e-9) + 1e-12 ? 0u : d.cnt;
+                       if (dmin2 >= st.eps2 * (1.0 + 1e-9) + 1e-12) return 0u;
+                   return (d.cnt >= 8u && !f_sub_reach(ix, p, ccx, ccy, ccz, d.sub, st.eps2 * (1.0 + 1e-9) + 1e-12)) ? 0u : d.cnt;
                    },
                    [&](bool valid, int, int, const FRec& rc, unsigned) {
                        const bool hit = valid && (rc.flags & F_CORE) && f_dist2(rc.x, rc.y, rc.z, p[0], p[1], p[2]) < st.eps2;
                        if (__any(hit)) in_anchor = true;
                    },
-                   [&]() { return in_anchor; }, 128u);
+                   [&]() { return in_anchor; }, 128u, st.dbgbuf ? &wst : nullptr);
             if (in_anchor) {
                 if (lane == 0) f_uf_union(st.parent, me, ci);
                 if (!sl.own) continue;                           // (iii) is the other ends' now; (ii) stays open for an anchor member's node
@@ -1086,18 +1194,26 @@ __global__ void __launch_bounds__(256) k_f_link(FIndexDev ix, FStep st) {
         const int j0 = c.has_anchor ? 1 : 0;
         unsigned long long done_am = 0ull;                       // anchor members (first 64 of the walk) with a witness
         if (sl.own && jme - j0 < 64) done_am |= 1ull << (jme - j0);   // (its own member's node is the walker itself)
+        {   // ... or whose node is in the walker's cluster already (a lane per member)
+            const int myroot = f_uf_find_cached(st.parent, me);
+            bool same = false;
+            if (lane < c.nm - j0 && st.mems[c.m0 + j0 + lane].am) same = f_uf_find_cached(st.parent, st.ncomp + (int)st.mems[c.m0 + j0 + lane].t0) == myroot;
+            done_am |= __ballot(same);
+        }
         f_walk(ix, st.mem_ids + c.m0 + j0, c.nm - j0, lo, hi,
                [&](int jj) {
                    const bool am = st.mems[c.m0 + j0 + jj].am != 0u;
-                   if (all) return (sl.own && jj + j0 == jme) ? (int)FSEL_SKIP : (int)FSEL_ALL;
+                   if (all) return (sl.own && jj + j0 == jme) ? (int)FSEL_SKIP : (am ? (int)FSEL_CORE_PROM : (int)FSEL_ALL);
                    return (am && jj + j0 != jme) ? (int)FSEL_CORE : (int)FSEL_SKIP;
                },
-               [&](bool hv, int jj, int ccx, int ccy, int ccz, const FCell& d, unsigned) -> unsigned {
+               [&](bool hv, int jj, int ccx, int ccy, int ccz, const FCell& d, unsigned cr) -> unsigned {
                    if (!hv) return 0u;
-                   if (jj < 64 && (done_am >> jj & 1ull) && (!all || d.ncore >= d.cnt)) return 0u;
+                   // an anchor member with a witness: only its cells with a point promoted in this step are still of interest
+                   if (jj < 64 && (done_am >> jj & 1ull) && (!all || !(ix.bricks[cr >> 6].pm >> (cr & 63u) & 1ull))) return 0u;
                    double dmin2, dmax2;
                    f_cube_dist(ix, p, ccx, ccy, ccz, dmin2, dmax2);
-                   return dmin2 >= st.eps2 * (1.0 + 1e-9) + 1e-12 ? 0u : d.cnt;
+                   if (dmin2 >= st.eps2 * (1.0 + 1e-9) + 1e-12) return 0u;
+                   return (d.cnt >= 8u && !f_sub_reach(ix, p, ccx, ccy, ccz, d.sub, st.eps2 * (1.0 + 1e-9) + 1e-12)) ? 0u : d.cnt;
                },
                [&](bool valid, int jj, int cl, const FRec& rc, unsigned) {
                    bool hit = false, am_hit = false;
@@ -1112,7 +1228,23 @@ __global__ void __launch_bounds__(256) k_f_link(FIndexDev ix, FStep st) {
                        if (am_hit && jj < 64 && (done_am >> jj & 1ull)) hit = false;      // (that node is connected already)
                        if (am_hit && jj >= 64 && sl.own && jj + j0 == jme) hit = false;
                    }
-                   f_per_cell_leader(hit, cl, [&]() { f_uf_union(st.parent, me, node); });
+                   // the hit lanes look their witnesses' roots up side by side; one union per distinct root
+                   // The hit lanes look their witnesses' roots up side by side; every root that is not the smallest of
+                   // them (and of the walker's own) is hooked under that one directly, each lane its own word -- a star,
+                   // not a chain of unions.  A root that moved in the meantime goes through the general union.
+                   const int wr = hit ? f_uf_find_cached(st.parent, node) : 0x7fffffff;
+                   const int mr = f_uf_find_cached(st.parent, me);
+                   int m = min(wr, mr);
+                   for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
+                   if (hit && wr != m) {
+                       const int old = atomicCAS(&st.parent[wr], wr, m);
+                       if (old != wr && old != m) f_uf_union(st.parent, wr, m);
+                   }
+                   const bool any_hit = __any(hit) != 0;
+                   if (lane == 0 && mr != m && any_hit) {
+                       const int old = atomicCAS(&st.parent[mr], mr, m);
+                       if (old != mr && old != m) f_uf_union(st.parent, mr, m);
+                   }
                    unsigned long long am_todo = __ballot(am_hit && jj < 64);
                    while (am_todo) {
                        const int l = __ffsll(am_todo) - 1;
@@ -1120,7 +1252,13 @@ __global__ void __launch_bounds__(256) k_f_link(FIndexDev ix, FStep st) {
                        done_am |= 1ull << __shfl(jj, l);
                    }
                },
-               [&]() { return false; }, 128u);
+               [&]() { return false; }, 128u, st.dbgbuf ? &wst : nullptr);
+        if (st.dbgbuf && lane == 0) {
+            unsigned long long* o = st.dbgbuf + (size_t)i * 2;
+            o[0] = ((wall_clock64() - dbg_t0) << 32) | ((unsigned long long)min(wst.recs, 0xfffffu) << 12) | ((unsigned long long)min(wst.trips, 0xfffu));
+            o[1] = ((unsigned long long)min(wst.cells, 0xffffu) << 48) | ((unsigned long long)min(wst.rounds, 0xffu) << 40) | ((unsigned long long)min(wst.groups, 0xffu) << 32) |
+                   ((unsigned long long)min(c.nm, 255) << 24) | ((unsigned long long)need << 16) | ((unsigned long long)(sl.own ? 1 : 0) << 8) | (unsigned long long)(mm.am ? 1 : 0);
+        }
     }
 }
 
@@ -1194,7 +1332,8 @@ __device__ __forceinline__ void f_label_walk(const FIndexDev& ix, const FStep& s
                        if (!hv || d.ncore == 0u) return 0u;
                        double dmin2, dmax2;
                        f_cube_dist(ix, p, ccx, ccy, ccz, dmin2, dmax2);
-                       return dmin2 >= st.eps2 * (1.0 + 1e-9) + 1e-12 ? 0u : d.cnt;
+                       if (dmin2 >= st.eps2 * (1.0 + 1e-9) + 1e-12) return 0u;
+                   return (d.cnt >= 8u && !f_sub_reach(ix, p, ccx, ccy, ccz, d.sub, st.eps2 * (1.0 + 1e-9) + 1e-12)) ? 0u : d.cnt;
                    },
                    [&](bool valid, int, int, const FRec& rc, unsigned) {
                        const bool hit = valid && (rc.flags & F_CORE) && f_dist2(rc.x, rc.y, rc.z, p[0], p[1], p[2]) < st.eps2;
@@ -1213,13 +1352,17 @@ __device__ __forceinline__ void f_label_walk(const FIndexDev& ix, const FStep& s
         const int j0 = c.has_anchor ? 1 : 0;
         unsigned long long seen_am = 0ull;                       // anchor members (first 64 of the walk) an own core point has been seen of
         f_walk(ix, st.mem_ids + c.m0 + j0, c.nm - j0, lo, hi,
-               [&](int jj) { return (skip_own_member && jj + j0 == jme) ? (int)FSEL_SKIP : (int)FSEL_ALL; },
-               [&](bool hv, int jj, int ccx, int ccy, int ccz, const FCell& d, unsigned) -> unsigned {
+               [&](int jj) {
+                   if (skip_own_member && jj + j0 == jme) return (int)FSEL_SKIP;
+                   return st.mems[c.m0 + j0 + jj].am ? (int)FSEL_CORE_PROM : (int)FSEL_ALL;
+               },
+               [&](bool hv, int jj, int ccx, int ccy, int ccz, const FCell& d, unsigned cr) -> unsigned {
                    if (!hv) return 0u;
-                   if (jj < 64 && (seen_am >> jj & 1ull) && d.ncore >= d.cnt) return 0u;
+                   if (jj < 64 && (seen_am >> jj & 1ull) && !(ix.bricks[cr >> 6].pm >> (cr & 63u) & 1ull)) return 0u;
                    double dmin2, dmax2;
                    f_cube_dist(ix, p, ccx, ccy, ccz, dmin2, dmax2);
-                   return dmin2 >= st.eps2 * (1.0 + 1e-9) + 1e-12 ? 0u : d.cnt;
+                   if (dmin2 >= st.eps2 * (1.0 + 1e-9) + 1e-12) return 0u;
+                   return (d.cnt >= 8u && !f_sub_reach(ix, p, ccx, ccy, ccz, d.sub, st.eps2 * (1.0 + 1e-9) + 1e-12)) ? 0u : d.cnt;
                },
                [&](bool valid, int jj, int, const FRec& rc, unsigned) {
                    bool hit = false, am_hit = false;
@@ -1318,6 +1461,10 @@ __global__ void k_f_keep(FIndexDev ix, FStep st) {
         ix.counters[FC_TOUCHED_RECS] = 0u;
         ix.counters[FC_L_COUNT] = ix.counters[FC_L_TOUCH] = ix.counters[FC_L_LINK0] = ix.counters[FC_L_LINK] = ix.counters[FC_L_LINK2] = ix.counters[FC_L_LABEL] = 0u;
     }
+    {   // the promoted-point masks of this step
+        const unsigned nd = min(ix.counters[FC_DIRTY], st.dirty_cap);
+        for (unsigned i = t; i < nd; i += gridDim.x * blockDim.x) ix.bricks[st.dirty[i]].pm = 0ull;
+    }
     if (t >= st.T) return;
     const int ci = (int)st.slot_ci[t];
     const FComp& c = st.comps[ci];
@@ -1341,6 +1488,7 @@ __global__ void k_f_keep(FIndexDev ix, FStep st) {
 __global__ void __launch_bounds__(256) k_f_emit(FIndexDev ix, FStep st, FInsArgs ins) {
     const int lane = threadIdx.x & 63;
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0u) ix.counters[FC_DIRTY] = 0u;                    // (k_f_keep has cleared the masks)
     const bool in = t < st.T;
     int ci = -1;
     bool kp = false;
@@ -1404,6 +1552,8 @@ struct Folder : Merger {
     PinnedBuf<char> h_pack;
     DevBuf<unsigned char> acore;
     DevBuf<int> parent, lab, slot_mi;
+    DevBuf<unsigned> dirty;
+    DevBuf<unsigned long long> dbgbuf;
     DevBuf<unsigned short> slot_ci;
     DevBuf<unsigned> size, first, keep, pos, dst, item_id, item_lidx, roots, cellref, slot, touched_cells, lists;
     DevBuf<unsigned long long> best;
@@ -1772,6 +1922,9 @@ struct Folder : Merger {
             lists.ensure((size_t)T * 6);
             slot_ci.ensure(T);
             slot_mi.ensure(T);
+            dirty.ensure(1u << 20);
+            st.dirty = dirty.p;
+            st.dirty_cap = 1u << 20;
             st.slot_ci = slot_ci.p;
             st.slot_mi = slot_mi.p;
             st.list_link2 = lists.p + 5 * (size_t)T;
@@ -1782,6 +1935,13 @@ struct Folder : Merger {
             st.list_label = lists.p + 4 * (size_t)T;
             st.eps = eps;
             st.debug = getenv("HMSG_DEBUG_TIMING") ? 1 : 0;
+            st.dbgbuf = nullptr;
+            const bool dump_step = getenv("HMSG_DEBUG_LINKSTEP") && (int)fstat[0] == atoi(getenv("HMSG_DEBUG_LINKSTEP"));
+            if (dump_step) {
+                dbgbuf.ensure((size_t)T * 2);
+                HIP_TRY(hipMemsetAsync(dbgbuf.p, 0, (size_t)T * 16, s));
+                st.dbgbuf = dbgbuf.p;
+            }
             st.eps2 = eps * eps;
             st.minpts = minpts;
             FInsArgs ins;
@@ -1831,6 +1991,25 @@ struct Folder : Merger {
             HIP_TRY(hipMemcpyAsync(h_res.p + rb, ix_counters.p, FC_N * 4, hipMemcpyDeviceToHost, s));
             if (segs.empty()) spin.wait(s);
             hres = (FRes*)h_res.p;
+            if (st.dbgbuf) {
+                std::vector<unsigned long long> hb((size_t)T * 2);
+                HIP_TRY(hipStreamSynchronize(s));
+                HIP_TRY(hipMemcpy(hb.data(), dbgbuf.p, (size_t)T * 16, hipMemcpyDeviceToHost));
+                std::vector<std::pair<unsigned long long, unsigned long long>> v;
+                for (unsigned i = 0; i < T; ++i)
+                    if (hb[(size_t)i * 2]) v.emplace_back(hb[(size_t)i * 2], hb[(size_t)i * 2 + 1]);
+                std::sort(v.begin(), v.end());
+                fprintf(stderr, "[fold dbg] step %d: %zu link walks of %u slots, %d components\n", (int)fstat[0], v.size(), T, NCOMP);
+                for (size_t q = 0; q < v.size(); q += std::max<size_t>(1, v.size() / 24)) {
+                    const unsigned long long a = v[q].first, b = v[q].second;
+                    fprintf(stderr, "[fold dbg]  rank %5zu: %7.1f us  recs %llu trips %llu cells %llu rounds %llu groups %llu members %llu need %llu own %llu am %llu\n", q,
+                            (a >> 32) * 0.01, (a >> 12) & 0xfffff, a & 0xfff, b >> 48, (b >> 40) & 0xff, (b >> 32) & 0xff, (b >> 24) & 0xff, (b >> 16) & 0xff,
+                            (b >> 8) & 1, b & 1);
+                }
+                const unsigned long long a = v.empty() ? 0 : v.back().first, b = v.empty() ? 0 : v.back().second;
+                fprintf(stderr, "[fold dbg]  slowest    : %7.1f us  recs %llu trips %llu cells %llu rounds %llu groups %llu members %llu need %llu own %llu am %llu\n",
+                        (a >> 32) * 0.01, (a >> 12) & 0xfffff, a & 0xfff, b >> 48, (b >> 40) & 0xff, (b >> 32) & 0xff, (b >> 24) & 0xff, (b >> 16) & 0xff, (b >> 8) & 1, b & 1);
+            }
         }
         // ---- the batch path for the few large components without an anchor
         std::vector<DbscanResult> res;

@@ -48,6 +48,7 @@ struct int4 { int x, y, z, w; };
 static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
 static inline uint2 make_uint2(unsigned a, unsigned b) { return uint2{a, b}; }
 
+static inline double hipemu_now();
 namespace hipemu {
 inline thread_local uint3e t_idx, b_idx;
 inline thread_local dim3 b_dim, g_dim;
@@ -359,6 +360,7 @@ static inline unsigned long long __ballot(int pred) {
 }
 static inline int __builtin_amdgcn_readlane(int v, int src) { return hipemu::exchange(v, src); }
 static inline unsigned long long __umul64hi(unsigned long long a, unsigned long long b) { return (unsigned long long)(((unsigned __int128)a * b) >> 64); }
+static inline unsigned long long wall_clock64() { return (unsigned long long)(hipemu_now() * 1e5); }   // 100 MHz ticks
 static inline int __any(int p) { return __ballot(p) != 0; }
 static inline int __all(int p) { return __ballot(!p) == 0; }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
