@@ -101,7 +101,8 @@ int guard(hmsg_ctx* h, F&& fn) {
 // needs the room.  Small stores stay (a service that rebuilds scenes reuses them).
 void release_frame_store_if_large(hmsg_ctx* h) {
     const size_t bytes = h->rgb.bytes() + h->depth.bytes() + h->bits.bytes() + h->nn.bytes();
-    if (bytes < ((size_t)32 << 30) || h->n_fused < h->n_feat_frames) return;
+    // (handing 60 GB back to the driver costs seconds: only when the merge could not fit next to it)
+    if (bytes < ((size_t)96 << 30) || h->n_fused < h->n_feat_frames) return;
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->rgb.release();
     h->depth.release();

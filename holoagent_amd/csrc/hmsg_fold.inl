@@ -54,9 +54,12 @@ struct FBrick {
     unsigned long long pad[4];
     FCell c[64];
 };
+struct __attribute__((aligned(16))) FHashEnt {   // key and brick number come with ONE 16-byte load
+    unsigned long long key;
+    unsigned val, pad;
+};
 struct FIndexDev {           // by value to every kernel
-    unsigned long long* keys;
-    unsigned* vals;
+    FHashEnt* tab;
     unsigned hmask;
     FBrick* bricks;
     unsigned brick_cap;
@@ -90,9 +93,9 @@ __device__ __forceinline__ unsigned f_local(int cx, int cy, int cz) { return (un
 __device__ __forceinline__ unsigned f_find(const FIndexDev& ix, unsigned long long key) {
     unsigned h = f_hash(key) & ix.hmask;
     for (;;) {
-        const unsigned long long k = ix.keys[h];
-        if (k == key) return ix.vals[h];
-        if (k == F_EMPTY) return F_NONE;
+        const FHashEnt e = ix.tab[h];
+        if (e.key == key) return e.val;
+        if (e.key == F_EMPTY) return F_NONE;
         h = (h + 1u) & ix.hmask;
     }
 }
@@ -104,10 +107,10 @@ __device__ __forceinline__ unsigned f_find_or_insert(const FIndexDev& ix, unsign
     unsigned res = F_NONE, wait_slot = F_NONE;
     bool done = false;
     for (unsigned probe = 0; !done; ++probe) {
-        unsigned long long k = __hip_atomic_load(&ix.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long k = __hip_atomic_load(&ix.tab[h].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bool won = false;
         if (k == F_EMPTY) {
-            const unsigned long long old = atomicCAS(&ix.keys[h], F_EMPTY, key);
+            const unsigned long long old = atomicCAS(&ix.tab[h].key, F_EMPTY, key);
             won = old == F_EMPTY;
             k = won ? key : old;
         }
@@ -117,7 +120,7 @@ __device__ __forceinline__ unsigned f_find_or_insert(const FIndexDev& ix, unsign
                 atomicOr(&ix.counters[FC_ERR], (unsigned)FERR_BRICKS);
                 b = 0u;
             }
-            __hip_atomic_store(&ix.vals[h], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ix.tab[h].val, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             res = b;
             done = true;
         } else if (k == key) {
@@ -133,7 +136,7 @@ __device__ __forceinline__ unsigned f_find_or_insert(const FIndexDev& ix, unsign
         }
     }
     if (wait_slot != F_NONE)
-        do res = __hip_atomic_load(&ix.vals[wait_slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        do res = __hip_atomic_load(&ix.tab[wait_slot].val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while (res == F_NONE);
     return res;
 }
@@ -430,6 +433,9 @@ enum { FSEL_SKIP = 0, FSEL_ALL = 1, FSEL_CORE = 2, FSEL_NONCORE = 3, FSEL_CORE_P
 //   budget > 0: a round takes only as many candidate cells as hold `budget` records (at least one) and re-offers the
 //       rest to cellfn in the next round -- a witness found in one heavy cell then lets cellfn drop its neighbours;
 //       cellfn must be free of side effects.
+#ifndef F_WALK_STATS
+#define F_WALK_STATS 0      /* development aid: per-walk statistics (HMSG_DEBUG_LINKSTEP / HMSG_DEBUG_COUNTSTEP) */
+#endif
 struct FWalkStat {            // development aid: what a walk did (wave-uniform counters)
     unsigned groups, rounds, trips, cells, recs;
 };
@@ -458,7 +464,7 @@ __device__ __forceinline__ void f_walk(const FIndexDev& ix, const unsigned* __re
         const unsigned np = (unsigned)__popcll(cand);
         const unsigned cincl = f_wave_incl_scan(np);
         const unsigned ctotal = __shfl(cincl, 63);
-        if (ws) {
+        if (F_WALK_STATS && ws) {
             ws->groups += 1u;
             ws->cells += ctotal;
         }
@@ -485,7 +491,7 @@ __device__ __forceinline__ void f_walk(const FIndexDev& ix, const unsigned* __re
                 rincl = min(rincl, __shfl(rincl, (int)took - 1));
             }
             const unsigned rtotal = __shfl(rincl, 63);
-            if (ws) {
+            if (F_WALK_STATS && ws) {
                 ws->rounds += 1u;
                 ws->recs += rtotal;
                 ws->trips += (rtotal + 63u) >> 6;
@@ -627,6 +633,7 @@ struct FRes {                // per component, read back
 struct FTouched {
     unsigned rec, cellref, comp, pad;
 };
+struct FSlotRec;
 struct FStep {               // by value to the step kernels
     const FComp* comps;
     const FMem* mems;
@@ -653,8 +660,7 @@ struct FStep {               // by value to the step kernels
     unsigned *list_count, *list_touch, *list_link0, *list_link, *list_link2, *list_label;   // [T] slots that need a walk
     unsigned* dirty;         // bricks with a promoted-point mask to clear
     unsigned dirty_cap;
-    unsigned short* slot_ci;  // [T] component of the slot (written by k_f_pre)
-    int* slot_mi;            // [T] member of the slot
+    struct FSlotRec* slotrec; // [T] written by k_f_pre
     double eps, eps2;
     int minpts, debug;
     unsigned long long* dbgbuf;   // development aid: per listed link slot, what its walk did
@@ -725,33 +731,67 @@ struct FSlot {
     int ci, mi;
     bool is_node, own;
     double p[3];
-    long long pi;            // pool index
 };
-template <bool SEARCH = false>
+struct __attribute__((aligned(32))) FSlotRec {   // what k_f_pre found out about a slot: one 32-byte load for every later kernel
+    double p[3];
+    int mi;
+    unsigned short ci;
+    unsigned char is_node, own;
+};
 __device__ __forceinline__ FSlot f_slot(const FStep& st, unsigned t) {
+    const FSlotRec r = st.slotrec[t];
     FSlot s;
-    if (SEARCH) {
-        s.ci = f_comp_of(st, t);
-        s.mi = f_mem_of(st, st.comps[s.ci], t);
-        st.slot_ci[t] = (unsigned short)s.ci;
-        st.slot_mi[t] = s.mi;
-    } else {
-        s.ci = (int)st.slot_ci[t];
-        s.mi = st.slot_mi[t];
+    s.ci = (int)r.ci;
+    s.mi = r.mi;
+    s.is_node = r.is_node != 0;
+    s.own = r.own != 0;
+    s.p[0] = r.p[0];
+    s.p[1] = r.p[1];
+    s.p[2] = r.p[2];
+    return s;
+}
+// first pass: the slot's component and member by binary search over the t0 tables (in LDS when they fit: lds_c / lds_m)
+#define F_LDS_COMPS 256
+#define F_LDS_MEMS 1024
+__device__ __forceinline__ FSlot f_slot_search(const FStep& st, unsigned t, const unsigned* lds_c, const unsigned* lds_m) {
+    FSlot s;
+    {
+        int lo = 0, hi = st.ncomp - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if ((lds_c ? lds_c[mid] : st.comps[mid].t0) <= t) lo = mid; else hi = mid - 1;
+        }
+        s.ci = lo;
     }
     const FComp& c = st.comps[s.ci];
+    {
+        int lo = c.m0 + (c.has_anchor ? 1 : 0), hi = c.m0 + c.nm - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if ((lds_m ? lds_m[mid] : st.mems[mid].t0) <= t) lo = mid; else hi = mid - 1;
+        }
+        s.mi = lo;
+    }
     const FMem& m = st.mems[s.mi];
     s.is_node = t == m.t0;
     s.own = false;
-    s.pi = 0;
     s.p[0] = s.p[1] = s.p[2] = 0.0;
     if (!s.is_node) {
-        s.pi = m.off + (long long)(t - m.t0 - 1u);
-        s.p[0] = st.pool[(size_t)s.pi * 3];
-        s.p[1] = st.pool[(size_t)s.pi * 3 + 1];
-        s.p[2] = st.pool[(size_t)s.pi * 3 + 2];
-        s.own = m.am && st.poolcore[s.pi];
+        const long long pi = m.off + (long long)(t - m.t0 - 1u);
+        s.p[0] = st.pool[(size_t)pi * 3];
+        s.p[1] = st.pool[(size_t)pi * 3 + 1];
+        s.p[2] = st.pool[(size_t)pi * 3 + 2];
+        s.own = m.am && st.poolcore[pi];
     }
+    FSlotRec r;
+    r.p[0] = s.p[0];
+    r.p[1] = s.p[1];
+    r.p[2] = s.p[2];
+    r.mi = s.mi;
+    r.ci = (unsigned short)s.ci;
+    r.is_node = s.is_node ? 1 : 0;
+    r.own = s.own ? 1 : 0;
+    st.slotrec[t] = r;
     return s;
 }
 // node of a record of member `m` (its anchor node for the own core points of an anchor member)
@@ -912,7 +952,14 @@ __device__ __forceinline__ unsigned f_link_pre2(const FIndexDev& ix, const FStep
 //     member farther than eps from every other member keeps its count; a cell that holds min_points points of the
 //     component makes its points core without a distance test -- the rest is listed for k_f_count; points with a
 //     cell of the first anchor that holds non-core records in reach are listed for k_f_touch.  Initialises the nodes.
-__global__ void __launch_bounds__(FB) k_f_pre(FIndexDev ix, FStep st) {
+__global__ void __launch_bounds__(FB) k_f_pre(FIndexDev ix, FStep st, int nmem) {
+    __shared__ unsigned s_ct0[F_LDS_COMPS], s_mt0[F_LDS_MEMS];
+    const bool lds = st.ncomp <= F_LDS_COMPS && nmem <= F_LDS_MEMS;
+    if (lds) {
+        for (int i = threadIdx.x; i < st.ncomp; i += FB) s_ct0[i] = st.comps[i].t0;
+        for (int i = threadIdx.x; i < nmem; i += FB) s_mt0[i] = st.mems[i].t0;
+    }
+    __syncthreads();
     const unsigned t = blockIdx.x * FB + threadIdx.x;
     if (t < (unsigned)st.ncomp) {
         const FComp c = st.comps[t];
@@ -937,7 +984,7 @@ __global__ void __launch_bounds__(FB) k_f_pre(FIndexDev ix, FStep st) {
     }
     // (connections start in k_f_count: every node has to be initialised before the first union)
     if (t < st.T) {
-        const FSlot sl = f_slot<true>(st, t);
+        const FSlot sl = f_slot_search(st, t, lds ? s_ct0 : nullptr, lds ? s_mt0 : nullptr);
         bool core = sl.own;
         if (!sl.is_node && !sl.own) {
             const FComp& c = st.comps[sl.ci];
@@ -981,9 +1028,9 @@ __global__ void __launch_bounds__(256) k_f_touch(FIndexDev ix, FStep st) {
     const unsigned nw = (gridDim.x * blockDim.x) >> 6;
     for (unsigned i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n; i += nw) {
         const unsigned t = st.list_touch[i];
-        const int ci = (int)st.slot_ci[t];
-        const FComp c = st.comps[ci];
         const FSlot sl = f_slot(st, t);
+        const int ci = sl.ci;
+        const FComp c = st.comps[ci];
         const double* p = sl.p;
         int cx, cy, cz;
         f_cell_of(ix, p[0], p[1], p[2], cx, cy, cz);
@@ -1020,7 +1067,7 @@ __global__ void __launch_bounds__(256) k_f_touch(FIndexDev ix, FStep st) {
 }
 
 // neighbours of p within eps over all members of a component (p's own record included), counted until `minpts`
-__device__ __forceinline__ bool f_is_core(const FIndexDev& ix, const FStep& st, const FComp& c, const double* p) {
+__device__ __forceinline__ bool f_is_core(const FIndexDev& ix, const FStep& st, const FComp& c, const double* p, FWalkStat* ws = nullptr) {
     const int lane = threadIdx.x & 63;
     int cx, cy, cz;
     f_cell_of(ix, p[0], p[1], p[2], cx, cy, cz);
@@ -1055,30 +1102,30 @@ __device__ __forceinline__ bool f_is_core(const FIndexDev& ix, const FStep& st, 
                const bool h = valid && f_dist2(rc.x, rc.y, rc.z, p[0], p[1], p[2]) < st.eps2;
                have += __popcll(__ballot(h));
            },
-           [&]() { return have >= st.minpts; });
+           [&]() { return have >= st.minpts; }, 0u, ws);
     return have >= st.minpts;
 }
 
 // (3) neighbour counts of the listed points; re-count and promotion of the touched points of the first anchors; and
 //     (thread per entry) the lane-level part of the connections of the points k_f_pre found core
+__global__ void __launch_bounds__(256) k_f_linkpre1(FIndexDev ix, FStep st) {
+    const int lane = threadIdx.x & 63;
+    const unsigned n = ix.counters[FC_L_LINK0];
+    for (unsigned i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += gridDim.x * blockDim.x) {
+        const unsigned i = i0 + (unsigned)lane;
+        bool hard = false;
+        unsigned t = 0u;
+        if (i < n) {
+            t = st.list_link0[i];
+            const FSlot sl = f_slot(st, t);
+            if (!sl.own && st.mems[sl.mi].am) f_mark_promoted(ix, st, sl);            // a point of an anchor member promoted in this step
+            hard = !f_link_pre(ix, st, sl, t);
+        }
+        f_list_push(&ix.counters[FC_L_LINK], st.list_link, hard, t);
+    }
+}
 __global__ void __launch_bounds__(256) k_f_count(FIndexDev ix, FStep st, unsigned link_blocks) {
     const int lane = threadIdx.x & 63;
-    if (blockIdx.x < link_blocks) {
-        const unsigned n = ix.counters[FC_L_LINK0];
-        for (unsigned i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += link_blocks * blockDim.x) {
-            const unsigned i = i0 + (unsigned)lane;
-            bool hard = false;
-            unsigned t = 0u;
-            if (i < n) {
-                t = st.list_link0[i];
-                const FSlot sl = f_slot(st, t);
-                if (!sl.own && st.mems[sl.mi].am) f_mark_promoted(ix, st, sl);            // a point of an anchor member promoted in this step
-                hard = !f_link_pre(ix, st, sl, t);
-            }
-            f_list_push(&ix.counters[FC_L_LINK], st.list_link, hard, t);
-        }
-        return;
-    }
     const unsigned n_count = ix.counters[FC_L_COUNT];
     const unsigned n_touched = min(ix.counters[FC_TOUCHED_RECS], st.touched_cap);
     const unsigned nw = ((gridDim.x - link_blocks) * blockDim.x) >> 6;
@@ -1086,7 +1133,17 @@ __global__ void __launch_bounds__(256) k_f_count(FIndexDev ix, FStep st, unsigne
         if (w < n_count) {
             const unsigned t = st.list_count[w];
             const FSlot sl = f_slot(st, t);
-            const bool core = f_is_core(ix, st, st.comps[sl.ci], sl.p);
+            FWalkStat wst = {0u, 0u, 0u, 0u, 0u};
+            const bool dbg = F_WALK_STATS && st.dbgbuf != nullptr && st.debug == 2;
+            const unsigned long long dbg_t0 = dbg ? wall_clock64() : 0ull;
+            const bool core = f_is_core(ix, st, st.comps[sl.ci], sl.p, dbg ? &wst : nullptr);
+            if (dbg && lane == 0) {
+                unsigned long long* o = st.dbgbuf + (size_t)w * 2;
+                o[0] = ((wall_clock64() - dbg_t0) << 32) | ((unsigned long long)min(wst.recs, 0xfffffu) << 12) | ((unsigned long long)min(wst.trips, 0xfffu));
+                o[1] = ((unsigned long long)min(wst.cells, 0xffffu) << 48) | ((unsigned long long)min(wst.rounds, 0xffu) << 40) | ((unsigned long long)min(wst.groups, 0xffu) << 32) |
+                       ((unsigned long long)min(st.comps[sl.ci].nm, 255) << 24) | ((unsigned long long)(st.comps[sl.ci].has_anchor ? 1 : 0) << 16) | ((unsigned long long)(core ? 1 : 0) << 8) |
+                       (unsigned long long)(st.mems[sl.mi].am ? 1 : 0);
+            }
             bool hard = false;
             if (core && lane == 0) {
                 st.acore[t] = 1;
@@ -1166,7 +1223,7 @@ __global__ void __launch_bounds__(256) k_f_link(FIndexDev ix, FStep st) {
         const int me = st.ncomp + (int)(sl.own ? mm.t0 : t);
         const unsigned need = st.pos[t];
         FWalkStat wst = {0u, 0u, 0u, 0u, 0u};
-        const unsigned long long dbg_t0 = st.dbgbuf ? wall_clock64() : 0ull;
+        const unsigned long long dbg_t0 = (F_WALK_STATS && st.dbgbuf) ? wall_clock64() : 0ull;
         if (need & FL_ANCHOR) {                                  // (i): the first core point of the anchor within eps
             bool in_anchor = false;
             f_walk(ix, st.mem_ids + c.m0, 1, lo, hi, [&](int) { return (int)FSEL_CORE; },
@@ -1181,7 +1238,7 @@ __global__ void __launch_bounds__(256) k_f_link(FIndexDev ix, FStep st) {
                        const bool hit = valid && (rc.flags & F_CORE) && f_dist2(rc.x, rc.y, rc.z, p[0], p[1], p[2]) < st.eps2;
                        if (__any(hit)) in_anchor = true;
                    },
-                   [&]() { return in_anchor; }, 128u, st.dbgbuf ? &wst : nullptr);
+                   [&]() { return in_anchor; }, 128u, (F_WALK_STATS && st.dbgbuf) ? &wst : nullptr);
             if (in_anchor) {
                 if (lane == 0) f_uf_union(st.parent, me, ci);
                 if (!sl.own) continue;                           // (iii) is the other ends' now; (ii) stays open for an anchor member's node
@@ -1252,8 +1309,8 @@ __global__ void __launch_bounds__(256) k_f_link(FIndexDev ix, FStep st) {
                        done_am |= 1ull << __shfl(jj, l);
                    }
                },
-               [&]() { return false; }, 128u, st.dbgbuf ? &wst : nullptr);
-        if (st.dbgbuf && lane == 0) {
+               [&]() { return false; }, 128u, (F_WALK_STATS && st.dbgbuf) ? &wst : nullptr);
+        if (F_WALK_STATS && st.dbgbuf && st.debug != 2 && lane == 0) {
             unsigned long long* o = st.dbgbuf + (size_t)i * 2;
             o[0] = ((wall_clock64() - dbg_t0) << 32) | ((unsigned long long)min(wst.recs, 0xfffffu) << 12) | ((unsigned long long)min(wst.trips, 0xfffu));
             o[1] = ((unsigned long long)min(wst.cells, 0xffffu) << 48) | ((unsigned long long)min(wst.rounds, 0xffu) << 40) | ((unsigned long long)min(wst.groups, 0xffu) << 32) |
@@ -1444,7 +1501,7 @@ __global__ void k_f_pick(FIndexDev ix, FStep st) {
         const unsigned r = st.roots[i];
         const unsigned sz = st.size[r];
         if (!sz) continue;
-        const int ci = r < (unsigned)st.ncomp ? (int)r : (int)st.slot_ci[r - (unsigned)st.ncomp];
+        const int ci = r < (unsigned)st.ncomp ? (int)r : (int)st.slotrec[r - (unsigned)st.ncomp].ci;
         atomicMax(&st.best[ci], ((unsigned long long)sz << 32) | (unsigned long long)(0xffffffffu - st.first[r]));
     }
 }
@@ -1466,10 +1523,10 @@ __global__ void k_f_keep(FIndexDev ix, FStep st) {
         for (unsigned i = t; i < nd; i += gridDim.x * blockDim.x) ix.bricks[st.dirty[i]].pm = 0ull;
     }
     if (t >= st.T) return;
-    const int ci = (int)st.slot_ci[t];
+    const FSlotRec sr = st.slotrec[t];
+    const int ci = (int)sr.ci;
     const FComp& c = st.comps[ci];
-    const FMem& m = st.mems[st.slot_mi[t]];
-    if (t == m.t0) {
+    if (sr.is_node) {
         st.keep[t] = 0u;
         return;
     }
@@ -1495,16 +1552,15 @@ __global__ void __launch_bounds__(256) k_f_emit(FIndexDev ix, FStep st, FInsArgs
     double v[3] = {0, 0, 0};
     unsigned out_id = 0u;
     if (in) {
-        ci = (int)st.slot_ci[t];
+        const FSlotRec sr = st.slotrec[t];
+        ci = (int)sr.ci;
         const FComp c = st.comps[ci];
         kp = st.keep[t] != 0u;
         const unsigned k = st.pos[t] - st.pos[c.t0];
         if (kp) {
-            const FMem m = st.mems[st.slot_mi[t]];
-            const size_t pi = (size_t)(m.off + (long long)(t - m.t0 - 1u)) * 3;
             const long long d = c.out_off + (long long)k;
             for (int a = 0; a < 3; ++a) {
-                v[a] = st.pool[pi + a];
+                v[a] = sr.p[a];
                 st.pool[(size_t)d * 3 + a] = v[a];
             }
             st.poolcore[d] = st.acore[t];
@@ -1541,8 +1597,8 @@ namespace {
 
 struct Folder : Merger {
     // the persistent index
-    DevBuf<unsigned long long> ix_keys;
-    DevBuf<unsigned> ix_vals, ix_counters;
+    DevBuf<FHashEnt> ix_tab;
+    DevBuf<unsigned> ix_counters;
     DevBuf<FBrick> ix_bricks;
     DevBuf<FRec> ix_recs;
     FIndexDev ix;
@@ -1551,16 +1607,18 @@ struct Folder : Merger {
     DevBuf<char> d_pack;             // [comps | mems | ids]
     PinnedBuf<char> h_pack;
     DevBuf<unsigned char> acore;
-    DevBuf<int> parent, lab, slot_mi;
+    DevBuf<int> parent, lab;
+    DevBuf<FSlotRec> slotrec;
     DevBuf<unsigned> dirty;
     DevBuf<unsigned long long> dbgbuf;
-    DevBuf<unsigned short> slot_ci;
     DevBuf<unsigned> size, first, keep, pos, dst, item_id, item_lidx, roots, cellref, slot, touched_cells, lists;
     DevBuf<unsigned long long> best;
     DevBuf<FRes> d_res;
     DevBuf<FTouched> touched;
     PinnedBuf<char> h_res;           // [FRes x ncomp | counters]
     DevBuf<FInsSeg> d_insseg;
+    DevBuf<CatSeg> d_reloc;
+    PinnedBuf<CatSeg> h_reloc;
     DevBuf<char> d_ovtab;            // overlap step: [clouds | tasks | counts]
     PinnedBuf<char> h_ovtab;
     int n_cu = 0;
@@ -1583,17 +1641,14 @@ struct Folder : Merger {
         size_t H = 1 << 16;
         while (H < brick_cap * 4) H <<= 1;
         const size_t rec_cap = std::min<size_t>((size_t)total_points * 16 + ((size_t)1 << 20), 0xfffffff0u);
-        ix_keys.alloc(H);
-        ix_vals.alloc(H);
+        ix_tab.alloc(H);
         ix_bricks.alloc(brick_cap);
         ix_recs.alloc(rec_cap);
         ix_counters.alloc(FC_N);
-        HIP_TRY(hipMemsetAsync(ix_keys.p, 0xff, H * 8, s));
-        HIP_TRY(hipMemsetAsync(ix_vals.p, 0xff, H * 4, s));
+        HIP_TRY(hipMemsetAsync(ix_tab.p, 0xff, H * sizeof(FHashEnt), s));
         HIP_TRY(hipMemsetAsync(ix_bricks.p, 0, brick_cap * sizeof(FBrick), s));
         HIP_TRY(hipMemsetAsync(ix_counters.p, 0, FC_N * 4, s));
-        ix.keys = ix_keys.p;
-        ix.vals = ix_vals.p;
+        ix.tab = ix_tab.p;
         ix.hmask = (unsigned)(H - 1);
         ix.bricks = ix_bricks.p;
         ix.brick_cap = (unsigned)brick_cap;
@@ -1860,12 +1915,14 @@ struct Folder : Merger {
             }
         }
         if (!reloc.empty()) {
-            d_cat.ensure(reloc.size());
-            HIP_TRY(hipMemcpyAsync(d_cat.p, reloc.data(), reloc.size() * sizeof(CatSeg), hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(k_concat, dim3(reloc_blocks), dim3(256), 0, s, (const double*)pool.p, (const CatSeg*)d_cat.p, (int)reloc.size(),
+            // (own staging buffers: no wait -- the previous step's copy has completed, every step ends with one)
+            h_reloc.ensure(reloc.size());
+            d_reloc.ensure(reloc.size());
+            memcpy(h_reloc.p, reloc.data(), reloc.size() * sizeof(CatSeg));
+            HIP_TRY(hipMemcpyAsync(d_reloc.p, h_reloc.p, reloc.size() * sizeof(CatSeg), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_concat, dim3(reloc_blocks), dim3(256), 0, s, (const double*)pool.p, (const CatSeg*)d_reloc.p, (int)reloc.size(),
                                pool.p, (const unsigned char*)poolcore.p, poolcore.p);
             HMSG_CHECK_LAUNCH();
-            HIP_TRY(hipStreamSynchronize(s));                    // (d_cat / reloc are reused below)
         }
         lap(3);
         // ---- the step kernels
@@ -1920,13 +1977,11 @@ struct Folder : Merger {
             st.touched_cap = TOUCHED_CAP;
             st.roots = roots.p;
             lists.ensure((size_t)T * 6);
-            slot_ci.ensure(T);
-            slot_mi.ensure(T);
+            slotrec.ensure(T);
             dirty.ensure(1u << 20);
             st.dirty = dirty.p;
             st.dirty_cap = 1u << 20;
-            st.slot_ci = slot_ci.p;
-            st.slot_mi = slot_mi.p;
+            st.slotrec = slotrec.p;
             st.list_link2 = lists.p + 5 * (size_t)T;
             st.list_count = lists.p;
             st.list_touch = lists.p + T;
@@ -1936,7 +1991,11 @@ struct Folder : Merger {
             st.eps = eps;
             st.debug = getenv("HMSG_DEBUG_TIMING") ? 1 : 0;
             st.dbgbuf = nullptr;
-            const bool dump_step = getenv("HMSG_DEBUG_LINKSTEP") && (int)fstat[0] == atoi(getenv("HMSG_DEBUG_LINKSTEP"));
+            bool dump_step = getenv("HMSG_DEBUG_LINKSTEP") && (int)fstat[0] == atoi(getenv("HMSG_DEBUG_LINKSTEP"));
+            if (getenv("HMSG_DEBUG_COUNTSTEP") && (int)fstat[0] == atoi(getenv("HMSG_DEBUG_COUNTSTEP"))) {
+                dump_step = true;
+                st.debug = 2;
+            }
             if (dump_step) {
                 dbgbuf.ensure((size_t)T * 2);
                 HIP_TRY(hipMemsetAsync(dbgbuf.p, 0, (size_t)T * 16, s));
@@ -1962,9 +2021,10 @@ struct Folder : Merger {
             const unsigned gT = cdiv(std::max<unsigned>(T, 1u), 256);
             {
                 ProfScope ps(h->prof, s, "k_f_count", (double)T * 24.0);
-                hipLaunchKernelGGL(k_f_pre, dim3(gS), dim3(FB), 0, s, ix, st);
+                hipLaunchKernelGGL(k_f_pre, dim3(gS), dim3(FB), 0, s, ix, st, (int)fm.size());
                 hipLaunchKernelGGL(k_f_touch, dim3(gW), dim3(256), 0, s, ix, st);
-                hipLaunchKernelGGL(k_f_count, dim3(gL + gW), dim3(256), 0, s, ix, st, gL);
+                hipLaunchKernelGGL(k_f_count, dim3(gW), dim3(256), 0, s, ix, st, 0u);
+                hipLaunchKernelGGL(k_f_linkpre1, dim3(gL), dim3(256), 0, s, ix, st);
             }
             {
                 ProfScope ps(h->prof, s, "k_f_link", (double)T * 24.0);

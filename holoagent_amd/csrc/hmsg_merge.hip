@@ -875,11 +875,11 @@ void merger_init(Merger& m, hmsg_ctx* h) {
 }
 
 // the frames' 3-D masks as per-frame cloud lists over a pool seeded with them (frames first .. n_fused-1)
-std::vector<std::vector<Cloud>> seed_frames(Merger& m, hmsg_ctx* h, int first, bool legacy_grids = true) {
+std::vector<std::vector<Cloud>> seed_frames(Merger& m, hmsg_ctx* h, int first, bool legacy_grids = true, long long pool_factor = 2) {
     const int F = h->n_fused;
     const long long total = h->masks3d.total;
-    m.pool.alloc((size_t)std::max<long long>(total * 2, 1 << 16) * 3);
-    m.poolcore.alloc((size_t)std::max<long long>(total * 2, 1 << 16));
+    m.pool.alloc((size_t)std::max<long long>(total * pool_factor, 1 << 16) * 3);
+    m.poolcore.alloc((size_t)std::max<long long>(total * pool_factor, 1 << 16));
     if (total) HIP_TRY(hipMemcpyAsync(m.pool.p, h->masks3d.pts.p, (size_t)total * 24, hipMemcpyDeviceToDevice, h->stream));
     m.pool_used = total;
     // AABBs of the frame masks (device reduction)
@@ -968,7 +968,19 @@ static bool hmsg_fold_sequential(hmsg_ctx* h) {
     merger_init(m, h);
     const double cs = m.eps / std::sqrt(3.0) * (1.0 - 1e-7);
     if (!(m.radius + 1e-4 < 1.9 * cs) || h->masks3d.total >= (1ll << 30)) return false;
-    std::vector<std::vector<Cloud>> frames = seed_frames(m, h, 0, false);
+    auto tp0 = std::chrono::steady_clock::now();
+    auto tlap = [&]() {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        auto t1 = std::chrono::steady_clock::now();
+        const double ms = std::chrono::duration<double, std::milli>(t1 - tp0).count();
+        tp0 = t1;
+        return ms;
+    };
+    const bool timing = getenv("HMSG_DEBUG_TIMING") != nullptr;
+    // (the fold's clouds keep room to grow and are relocated when they outgrow it: ~8 pool points per mask point over a
+    //  1000-frame scene -- allocated once, growing a multi-GB buffer costs a fresh hipMalloc and a copy)
+    std::vector<std::vector<Cloud>> frames = seed_frames(m, h, 0, false, 12);
+    const double t_seed = timing ? tlap() : 0.0;
     const int F = h->n_fused;
     // lattice over the box of all masks; every mask indexed under its own id, in one batch
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
@@ -992,7 +1004,10 @@ static bool hmsg_fold_sequential(hmsg_ctx* h) {
         return true;
     }
     m.index_init(h->masks3d.total, n_masks, lo, hi);
+    const double t_init = timing ? tlap() : 0.0;
     m.index_bulk(segs);
+    const double t_bulk = timing ? tlap() : 0.0;
+    if (timing) fprintf(stderr, "[hmsg fold] setup: seed %.1f  index arenas %.1f  bulk index of the frame masks %.1f ms\n", t_seed, t_init, t_bulk);
     std::vector<Cloud> G = std::move(frames[0]);
     for (int f = 1; f < F; ++f) {
         G.insert(G.end(), frames[(size_t)f].begin(), frames[(size_t)f].end());
@@ -1010,6 +1025,7 @@ static bool hmsg_fold_sequential(hmsg_ctx* h) {
         HIP_TRY(hipMemcpy(cnt, m.ix_counters.p, sizeof(cnt), hipMemcpyDeviceToHost));
         fprintf(stderr, "[hmsg fold] index: %u of %u bricks, %u of %u records, hash %u slots\n", cnt[FC_BRICKS], m.ix.brick_cap, cnt[FC_RECS],
                 m.ix.rec_cap, m.ix.hmask + 1);
+        fprintf(stderr, "[hmsg fold] point pool: %lld points in use (%.2f GB), %lld in the frame masks\n", m.pool_used, m.pool_used * 25e-9, (long long)h->masks3d.total);
         fprintf(stderr, "[hmsg fold] walks: count %u  touch %u  link %u  label %u   touched anchor points %u\n", cnt[FC_STAT], cnt[FC_STAT + 1],
                 cnt[FC_STAT + 2], cnt[FC_STAT + 3], cnt[FC_STAT + 4]);
         fprintf(stderr, "[hmsg fold] link walks: anchor comps own %u promoted %u raw %u | plain comps own %u promoted %u raw %u\n", cnt[FC_DBG], cnt[FC_DBG + 1],
