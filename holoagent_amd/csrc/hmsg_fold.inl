@@ -819,6 +819,7 @@ struct FDbgTimer {
 // from every other member keeps its status) and lists the slots that need a walk over a neighbourhood; a WAVE per
 // listed slot then does the walks, spread over the whole device.
 #define FB 256
+#define FWB 1024     /* threads of a walk kernel's workgroup: the dispatcher starts ~20 workgroups per microsecond, so few fat ones */
 __device__ __forceinline__ void f_list_push(unsigned* counter, unsigned* list, bool want, unsigned t) {   // wave-uniform call
     const unsigned q = f_wave_slot(want, counter);
     if (want) list[q] = t;
@@ -1023,7 +1024,7 @@ __global__ void __launch_bounds__(FB) k_f_pre(FIndexDev ix, FStep st, int nmem) 
 
 // (2) the first anchor's non-core points that have an active point within eps: the only points of it whose core
 //     status can change
-__global__ void __launch_bounds__(256) k_f_touch(FIndexDev ix, FStep st) {
+__global__ void __launch_bounds__(FWB) k_f_touch(FIndexDev ix, FStep st) {
     const unsigned n = ix.counters[FC_L_TOUCH];
     const unsigned nw = (gridDim.x * blockDim.x) >> 6;
     for (unsigned i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n; i += nw) {
@@ -1124,7 +1125,7 @@ __global__ void __launch_bounds__(256) k_f_linkpre1(FIndexDev ix, FStep st) {
         f_list_push(&ix.counters[FC_L_LINK], st.list_link, hard, t);
     }
 }
-__global__ void __launch_bounds__(256) k_f_count(FIndexDev ix, FStep st, unsigned link_blocks) {
+__global__ void __launch_bounds__(FWB) k_f_count(FIndexDev ix, FStep st, unsigned link_blocks) {
     const int lane = threadIdx.x & 63;
     const unsigned n_count = ix.counters[FC_L_COUNT];
     const unsigned n_touched = min(ix.counters[FC_TOUCHED_RECS], st.touched_cap);
@@ -1144,13 +1145,9 @@ __global__ void __launch_bounds__(256) k_f_count(FIndexDev ix, FStep st, unsigne
                        ((unsigned long long)min(st.comps[sl.ci].nm, 255) << 24) | ((unsigned long long)(st.comps[sl.ci].has_anchor ? 1 : 0) << 16) | ((unsigned long long)(core ? 1 : 0) << 8) |
                        (unsigned long long)(st.mems[sl.mi].am ? 1 : 0);
             }
-            bool hard = false;
-            if (core && lane == 0) {
-                st.acore[t] = 1;
-                if (st.mems[sl.mi].am) f_mark_promoted(ix, st, sl);
-                hard = !f_link_pre(ix, st, sl, t);
-            }
-            f_list_push(&ix.counters[FC_L_LINK], st.list_link, hard, t);
+            // (its connections start in k_f_linkpre1, a thread per core point: not on one lane of this wave)
+            if (core && lane == 0) st.acore[t] = 1;
+            f_list_push(&ix.counters[FC_L_LINK0], st.list_link0, core && lane == 0, t);
         } else {
             const FTouched tr = st.touched[w - n_count];
             const FComp c = st.comps[tr.comp];
@@ -1204,7 +1201,7 @@ __global__ void __launch_bounds__(256) k_f_linkpre2(FIndexDev ix, FStep st) {
 }
 
 // (4) the walks of the listed core points: whatever of (i), (ii), (iii) k_f_linkpre2 left open
-__global__ void __launch_bounds__(256) k_f_link(FIndexDev ix, FStep st) {
+__global__ void __launch_bounds__(FWB) k_f_link(FIndexDev ix, FStep st) {
     const int lane = threadIdx.x & 63;
     const unsigned n = ix.counters[FC_L_LINK2];
     const unsigned nw = (gridDim.x * blockDim.x) >> 6;
@@ -1458,7 +1455,7 @@ __device__ __forceinline__ void f_label_walk(const FIndexDev& ix, const FStep& s
     contest_out = __any(multi || (best != 0x7fffffff && best != wbest)) != 0;
 }
 // (7) labels of the listed points; contest check of the touched points of the first anchors that stayed non-core
-__global__ void __launch_bounds__(256) k_f_label(FIndexDev ix, FStep st) {
+__global__ void __launch_bounds__(FWB) k_f_label(FIndexDev ix, FStep st) {
     const int lane = threadIdx.x & 63;
     const unsigned n_label = ix.counters[FC_L_LABEL];
     const unsigned n_touched = min(ix.counters[FC_TOUCHED_RECS], st.touched_cap);
@@ -2016,26 +2013,27 @@ struct Folder : Merger {
             ins.slot = slot.p;
             ins.touched = touched_cells.p;
             const unsigned gS = std::max(cdiv(std::max<unsigned>(T, (unsigned)NCOMP), FB), 1u);   // a thread per slot
-            const unsigned gW = std::max(1u, std::min(cdiv((size_t)T * 64, 256), (unsigned)n_cu * 8u)); // a wave per listed slot (grid-stride)
+            const unsigned gWmul = getenv("HMSG_DEBUG_GW") ? (unsigned)atoi(getenv("HMSG_DEBUG_GW")) : 2u;
+            const unsigned gW = std::max(1u, std::min(cdiv((size_t)T * 64, FWB), (unsigned)n_cu * gWmul)); // a wave per listed slot (grid-stride)
             const unsigned gL = std::max(1u, std::min(gS, 64u));
             const unsigned gT = cdiv(std::max<unsigned>(T, 1u), 256);
             {
                 ProfScope ps(h->prof, s, "k_f_count", (double)T * 24.0);
                 hipLaunchKernelGGL(k_f_pre, dim3(gS), dim3(FB), 0, s, ix, st, (int)fm.size());
-                hipLaunchKernelGGL(k_f_touch, dim3(gW), dim3(256), 0, s, ix, st);
-                hipLaunchKernelGGL(k_f_count, dim3(gW), dim3(256), 0, s, ix, st, 0u);
+                hipLaunchKernelGGL(k_f_touch, dim3(gW), dim3(FWB), 0, s, ix, st);
+                hipLaunchKernelGGL(k_f_count, dim3(gW), dim3(FWB), 0, s, ix, st, 0u);
                 hipLaunchKernelGGL(k_f_linkpre1, dim3(gL), dim3(256), 0, s, ix, st);
             }
             {
                 ProfScope ps(h->prof, s, "k_f_link", (double)T * 24.0);
                 hipLaunchKernelGGL(k_f_linkpre2, dim3(gL), dim3(256), 0, s, ix, st);
-                hipLaunchKernelGGL(k_f_link, dim3(gW), dim3(256), 0, s, ix, st);
+                hipLaunchKernelGGL(k_f_link, dim3(gW), dim3(FWB), 0, s, ix, st);
             }
             {
                 ProfScope ps(h->prof, s, "k_f_label", (double)T * 24.0);
                 hipLaunchKernelGGL(k_f_acct, dim3(gS), dim3(FB), 0, s, ix, st);
                 hipLaunchKernelGGL(k_f_labelpre, dim3(gS), dim3(FB), 0, s, ix, st);
-                hipLaunchKernelGGL(k_f_label, dim3(gW), dim3(256), 0, s, ix, st);
+                hipLaunchKernelGGL(k_f_label, dim3(gW), dim3(FWB), 0, s, ix, st);
             }
             hipLaunchKernelGGL(k_f_pick, dim3(std::max(1u, std::min(gT, 64u))), dim3(256), 0, s, ix, st);
             hipLaunchKernelGGL(k_f_keep, dim3(gT), dim3(256), 0, s, ix, st);
