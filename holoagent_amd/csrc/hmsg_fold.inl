@@ -1619,6 +1619,7 @@ struct Folder : Merger {
     DevBuf<char> d_ovtab;            // overlap step: [clouds | tasks | counts]
     PinnedBuf<char> h_ovtab;
     int n_cu = 0;
+    double stat_points_seen = 0;     // (batch fold: points of the DBSCAN batches before the last step)
     long long big_active = 1 << 16;  // components without an anchor and more active points than this use the batch kernels
     double fstat[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // steps, comps (anchor), comps (plain), comps (batch), active points, relocated points, touched
     static constexpr unsigned TOUCHED_CAP = 1u << 20;

@@ -960,79 +960,55 @@ double next_level_threshold(double th, double factor, long long lists) {
 
 }  // namespace
 
-// seq_merge (graph_utils.py:1015-1038) as the incremental fold of hmsg_fold.inl.  false: configuration outside what the
-// fold index supports (the caller runs the batch fold).
-static bool hmsg_fold_sequential(hmsg_ctx* h) {
-    const hmsg_config& c = h->cfg;
-    Folder m;
-    merger_init(m, h);
+// Switch a sequential fold to the incremental fold of hmsg_fold.inl: the live clouds (the instance list G and the masks
+// of the frames still to come) move to a fresh pool with room to grow, get an id each and are indexed in one batch.
+// false: configuration outside what the fold index supports (the batch fold carries on).
+static bool fold_begin(Folder& m, hmsg_ctx* h, std::vector<Cloud>& G, std::vector<std::vector<Cloud>>& frames, size_t f_next) {
     const double cs = m.eps / std::sqrt(3.0) * (1.0 - 1e-7);
-    if (!(m.radius + 1e-4 < 1.9 * cs) || h->masks3d.total >= (1ll << 30)) return false;
-    auto tp0 = std::chrono::steady_clock::now();
-    auto tlap = [&]() {
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        auto t1 = std::chrono::steady_clock::now();
-        const double ms = std::chrono::duration<double, std::milli>(t1 - tp0).count();
-        tp0 = t1;
-        return ms;
-    };
-    const bool timing = getenv("HMSG_DEBUG_TIMING") != nullptr;
+    if (!(m.radius + 1e-4 < 1.9 * cs)) return false;
+    long long live = 0, n_clouds = 0;
+    for (auto& k : G) live += k.n, ++n_clouds;
+    for (size_t f = f_next; f < frames.size(); ++f)
+        for (auto& k : frames[f]) live += k.n, ++n_clouds;
+    if (n_clouds == 0 || live >= (1ll << 28) || n_clouds >= (1ll << 23)) return false;
     // (the fold's clouds keep room to grow and are relocated when they outgrow it: ~8 pool points per mask point over a
     //  1000-frame scene -- allocated once, growing a multi-GB buffer costs a fresh hipMalloc and a copy)
-    std::vector<std::vector<Cloud>> frames = seed_frames(m, h, 0, false, 12);
-    const double t_seed = timing ? tlap() : 0.0;
-    const int F = h->n_fused;
-    // lattice over the box of all masks; every mask indexed under its own id, in one batch
+    const size_t keep_gc = m.gc_pool_points;
+    m.gc_pool_points = (size_t)live * 11;
+    m.collect(G, frames, f_next);
+    m.gc_pool_points = keep_gc;
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     std::vector<FInsSeg> segs;
-    long long n_masks = 0;
-    for (auto& fr : frames)
-        for (auto& k : fr) {
-            for (int a = 0; a < 3; ++a) {
-                lo[a] = std::min(lo[a], k.mn[a]);
-                hi[a] = std::max(hi[a], k.mx[a]);
-            }
-            if (m.next_id >= (1u << 24)) return false;
-            k.id = m.next_id++;
-            k.cap = k.n;
-            segs.push_back(FInsSeg{k.off, k.id, k.n, 0, 0, 0, 0});
-            ++n_masks;
+    auto take = [&](Cloud& k) {
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], k.mn[a]);
+            hi[a] = std::max(hi[a], k.mx[a]);
         }
-    if (n_masks == 0) {
-        store_instances(m, h, std::vector<Cloud>(), c.min_instance_points);
-        h->merged = true;
-        return true;
-    }
-    m.index_init(h->masks3d.total, n_masks, lo, hi);
-    const double t_init = timing ? tlap() : 0.0;
+        k.id = m.next_id++;
+        k.cap = k.n;
+        segs.push_back(FInsSeg{k.off, k.id, k.n, 0, 0, k.anchor ? 1 : 0, 0});
+    };
+    for (auto& k : G) take(k);
+    for (size_t f = f_next; f < frames.size(); ++f)
+        for (auto& k : frames[f]) take(k);
+    m.index_init(live, n_clouds, lo, hi);
     m.index_bulk(segs);
-    const double t_bulk = timing ? tlap() : 0.0;
-    if (timing) fprintf(stderr, "[hmsg fold] setup: seed %.1f  index arenas %.1f  bulk index of the frame masks %.1f ms\n", t_seed, t_init, t_bulk);
-    std::vector<Cloud> G = std::move(frames[0]);
-    for (int f = 1; f < F; ++f) {
-        G.insert(G.end(), frames[(size_t)f].begin(), frames[(size_t)f].end());
-        std::vector<Cloud>().swap(frames[(size_t)f]);
-        G = m.fold_step(std::move(G), c.init_overlap_thresh);
-    }
-    std::vector<Cloud> result = m.fold_step(std::move(G), c.init_overlap_thresh);
-    store_instances(m, h, result, c.min_instance_points);
-    if (getenv("HMSG_DEBUG_TIMING")) {
-        fprintf(stderr, "[hmsg fold] pairs(host) %.1f  overlap %.1f  tables %.1f  step kernels %.1f  bookkeeping %.1f ms\n", m.tphase[1],
-                m.tphase[2], m.tphase[3], m.tphase[4], m.tphase[5]);
-        fprintf(stderr, "[hmsg fold] steps %.0f  components: anchor %.0f  plain %.0f  batch %.0f   active points %.0f  relocated %.0f   ids %u\n",
-                m.fstat[0], m.fstat[1], m.fstat[2], m.fstat[3], m.fstat[4], m.fstat[5], m.next_id);
-        unsigned cnt[FC_N];
-        HIP_TRY(hipMemcpy(cnt, m.ix_counters.p, sizeof(cnt), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[hmsg fold] index: %u of %u bricks, %u of %u records, hash %u slots\n", cnt[FC_BRICKS], m.ix.brick_cap, cnt[FC_RECS],
-                m.ix.rec_cap, m.ix.hmask + 1);
-        fprintf(stderr, "[hmsg fold] point pool: %lld points in use (%.2f GB), %lld in the frame masks\n", m.pool_used, m.pool_used * 25e-9, (long long)h->masks3d.total);
-        fprintf(stderr, "[hmsg fold] walks: count %u  touch %u  link %u  label %u   touched anchor points %u\n", cnt[FC_STAT], cnt[FC_STAT + 1],
-                cnt[FC_STAT + 2], cnt[FC_STAT + 3], cnt[FC_STAT + 4]);
-        fprintf(stderr, "[hmsg fold] link walks: anchor comps own %u promoted %u raw %u | plain comps own %u promoted %u raw %u\n", cnt[FC_DBG], cnt[FC_DBG + 1],
-                cnt[FC_DBG + 2], cnt[FC_DBG + 4], cnt[FC_DBG + 5], cnt[FC_DBG + 6]);
-    }
-    h->merged = true;
     return true;
+}
+static void fold_report(Folder& m, hmsg_ctx* h) {
+    fprintf(stderr, "[hmsg fold] pairs(host) %.1f  overlap %.1f  tables %.1f  step kernels %.1f  bookkeeping %.1f ms\n", m.tphase[1],
+            m.tphase[2], m.tphase[3], m.tphase[4], m.tphase[5]);
+    fprintf(stderr, "[hmsg fold] steps %.0f  components: anchor %.0f  plain %.0f  batch %.0f   active points %.0f  relocated %.0f   ids %u\n",
+            m.fstat[0], m.fstat[1], m.fstat[2], m.fstat[3], m.fstat[4], m.fstat[5], m.next_id);
+    unsigned cnt[FC_N];
+    HIP_TRY(hipMemcpy(cnt, m.ix_counters.p, sizeof(cnt), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[hmsg fold] index: %u of %u bricks, %u of %u records, hash %u slots\n", cnt[FC_BRICKS], m.ix.brick_cap, cnt[FC_RECS],
+            m.ix.rec_cap, m.ix.hmask + 1);
+    fprintf(stderr, "[hmsg fold] point pool: %lld points in use (%.2f GB), %lld in the frame masks\n", m.pool_used, m.pool_used * 25e-9, (long long)h->masks3d.total);
+    fprintf(stderr, "[hmsg fold] walks: count %u  touch %u  link %u  label %u   touched anchor points %u\n", cnt[FC_STAT], cnt[FC_STAT + 1],
+            cnt[FC_STAT + 2], cnt[FC_STAT + 3], cnt[FC_STAT + 4]);
+    fprintf(stderr, "[hmsg fold] link walks: anchor comps own %u promoted %u raw %u | plain comps own %u promoted %u raw %u\n", cnt[FC_DBG], cnt[FC_DBG + 1],
+            cnt[FC_DBG + 2], cnt[FC_DBG + 4], cnt[FC_DBG + 5], cnt[FC_DBG + 6]);
 }
 
 void hmsg_merge(hmsg_ctx* h) {
@@ -1040,8 +1016,7 @@ void hmsg_merge(hmsg_ctx* h) {
     HMSG_REQUIRE(h->feats_final && h->n_fused > 0, HMSG_ERR_INVALID, "hmsg_merge_instances: run hmsg_fuse_frames first");
     HMSG_REQUIRE(!h->merged, HMSG_ERR_INVALID, "instances already merged");
     HMSG_REQUIRE(h->frame_window == 0, HMSG_ERR_INVALID, "hmsg_merge_instances on a frame window: use hmsg_merge_tree_local / _join");
-    if (c.merge_type != HMSG_MERGE_HIERARCHICAL && !getenv("HMSG_FOLD_LEGACY") && hmsg_fold_sequential(h)) return;
-    Merger m;
+    Folder m;
     merger_init(m, h);
     std::vector<std::vector<Cloud>> frames = seed_frames(m, h, 0);
     const int F = h->n_fused;
@@ -1067,10 +1042,36 @@ void hmsg_merge(hmsg_ctx* h) {
         }
         result = m.merge_3d_masks(std::move(lv[0]), 0.75);
     } else {
-        // graph_utils.py:1015-1038
+        // graph_utils.py:1015-1038.  The BATCH fold (re-cluster every touched cloud in full each step) is the cheaper one
+        // while the clouds are small; its step grows with the clouds, the INCREMENTAL fold's (hmsg_fold.inl) with the new
+        // points only: the fold switches over when the batches' running mean passes `switch_points` points.
+        //   HMSG_FOLD_LEGACY=1: batch fold throughout;  HMSG_FOLD_INCREMENTAL=1: incremental from the first step;
+        //   HMSG_FOLD_SWITCH=<points>: the threshold (default 600000: ~0.55 ms per step either way on an MI355X).  The instances are identical either way.
         std::vector<Cloud> G = std::move(frames[0]);
         if (const char* e = getenv("HMSG_DEBUG_GC_POINTS")) m.gc_pool_points = (size_t)atoll(e);   // (tests: force collections)
+        const bool never = getenv("HMSG_FOLD_LEGACY") != nullptr;
+        double switch_points = getenv("HMSG_FOLD_INCREMENTAL") ? 0.0 : 600000.0;
+        if (const char* e = getenv("HMSG_FOLD_SWITCH")) switch_points = atof(e);
+        bool incremental = false;
+        int f_switch = -1;
+        double batch_mean = 0.0;
         for (int f = 1; f < F; ++f) {
+            if (!incremental && !never) {
+                // (a single step's batch jumps around: the running mean over ~64 steps decides)
+                const double last_batch = m.ops.stat_points - m.stat_points_seen;
+                m.stat_points_seen = m.ops.stat_points;
+                batch_mean += (last_batch - batch_mean) / 64.0;
+                if ((switch_points <= 0.0 || batch_mean > switch_points) && fold_begin(m, h, G, frames, (size_t)f)) {
+                    incremental = true;
+                    f_switch = f;
+                }
+            }
+            if (incremental) {
+                G.insert(G.end(), frames[(size_t)f].begin(), frames[(size_t)f].end());
+                std::vector<Cloud>().swap(frames[(size_t)f]);
+                G = m.fold_step(std::move(G), c.init_overlap_thresh);
+                continue;
+            }
             if (m.needs_collect()) {
                 m.collect(G, frames, (size_t)f);
                 m.prebuild(frames, (size_t)f, (size_t)f + Merger::PREBUILD_WINDOW - (size_t)f % Merger::PREBUILD_WINDOW);
@@ -1081,7 +1082,11 @@ void hmsg_merge(hmsg_ctx* h) {
             std::vector<Cloud>().swap(frames[f]);
             G = m.merge_3d_masks(std::move(G), c.init_overlap_thresh);
         }
-        result = m.merge_3d_masks(std::move(G), c.init_overlap_thresh);
+        result = incremental ? m.fold_step(std::move(G), c.init_overlap_thresh) : m.merge_3d_masks(std::move(G), c.init_overlap_thresh);
+        if (getenv("HMSG_DEBUG_TIMING") && incremental) {
+            fprintf(stderr, "[hmsg merge] incremental fold from frame %d of %d\n", f_switch, F);
+            fold_report(m, h);
+        }
     }
     // graph.py:445-448: drop clouds with < 10 points; compact the survivors into the handle
     store_instances(m, h, result, c.min_instance_points);

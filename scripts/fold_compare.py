@@ -20,11 +20,15 @@ spec = SceneSpec(seed=seed, rooms_x=1, rooms_z=1, room_size=(3.6, 2.5, 3.2), obj
 scn = SynthScene(spec)
 frames = [scn.frame(i) for i in range(F)]
 
-def run(legacy):
-    if legacy:
+def run(mode):
+    for k in ("HMSG_FOLD_LEGACY", "HMSG_FOLD_INCREMENTAL", "HMSG_FOLD_SWITCH"):
+        os.environ.pop(k, None)
+    if mode == "legacy":
         os.environ["HMSG_FOLD_LEGACY"] = "1"
+    elif mode == "incremental":
+        os.environ["HMSG_FOLD_INCREMENTAL"] = "1"
     else:
-        os.environ.pop("HMSG_FOLD_LEGACY", None)
+        os.environ["HMSG_FOLD_SWITCH"] = str(mode)
     sc = PC.make_scene(L, frames, dict(feat_dim=16, outlier_nb_points=200, feat_dbscan_min=20))
     S = PC.stack_frames(frames)
     sc.add_frames(S["rgb"], S["depth"], S["pose"], S["K"])
@@ -38,12 +42,15 @@ def run(legacy):
     sc.close()
     return inst, dt
 
-a, ta = run(True)
-b, tb = run(False)
-print("legacy %d instances (%.2fs)   fold %d instances (%.2fs)" % (len(a), ta, len(b), tb))
-ok = len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))
-if not ok:
-    print("sizes legacy", [len(x) for x in a])
-    print("sizes fold  ", [len(x) for x in b])
-print("IDENTICAL" if ok else "DIFFERENT")
+a, ta = run("legacy")
+ok = True
+for mode in ("incremental", 6000):
+    b, tb = run(mode)
+    same = len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))
+    print("batch fold %d instances (%.2fs)   %s: %d instances (%.2fs)  %s" % (len(a), ta, "incremental fold" if mode == "incremental" else "switch at %d points" % mode,
+                                                                          len(b), tb, "IDENTICAL" if same else "DIFFERENT"))
+    if not same:
+        print("sizes batch", [len(x) for x in a])
+        print("sizes other", [len(x) for x in b])
+    ok = ok and same
 sys.exit(0 if ok else 1)
