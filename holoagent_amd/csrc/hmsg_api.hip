@@ -103,12 +103,13 @@ void release_frame_store_if_large(hmsg_ctx* h) {
     const size_t bytes = h->rgb.bytes() + h->depth.bytes() + h->bits.bytes() + h->nn.bytes();
     // (handing 60 GB back to the driver costs seconds: only when the merge could not fit next to it)
     if (bytes < ((size_t)96 << 30) || h->n_fused < h->n_feat_frames) return;
+    // (parked in the allocator's cache, not handed back to the driver: hipFree of 150 GB takes seconds; the merge's
+    //  arenas re-use the blocks that fit, and the cache frees the rest when an allocation does not fit)
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->rgb.release();
     h->depth.release();
     h->bits.release();
     h->nn.release();
-    dev_cache().trim();
     h->frames_released = true;
 }
 
@@ -477,6 +478,7 @@ int hmsg_get_frame_nn(const hmsg_t* hc, int32_t frame, int32_t* idx) {
     if (!h) return HMSG_ERR_INVALID;
     return guard(h, [&] {
         HMSG_REQUIRE(frame >= 0 && frame < h->n_fused && idx, HMSG_ERR_INVALID, "frame not fused");
+        HMSG_REQUIRE(!h->frames_released, HMSG_ERR_INVALID, "hmsg_get_frame_nn: the frame store was released by the merge (very long episode)");
         const size_t HW = (size_t)h->cfg.height * h->cfg.width;
         HIP_TRY(hipMemcpy(idx, h->nn.p + (size_t)frame * HW, HW * 4, hipMemcpyDeviceToHost));
     });

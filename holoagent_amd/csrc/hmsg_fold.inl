@@ -1638,7 +1638,7 @@ struct Folder : Merger {
         const size_t brick_cap = (size_t)(total_points / 5 + n_masks * 8 + 4096);
         size_t H = 1 << 16;
         while (H < brick_cap * 4) H <<= 1;
-        const size_t rec_cap = std::min<size_t>((size_t)total_points * 16 + ((size_t)1 << 20), 0xfffffff0u);
+        const size_t rec_cap = std::min<size_t>((size_t)total_points * 20 + ((size_t)1 << 20), 0xfffffff0u);
         ix_tab.alloc(H);
         ix_bricks.alloc(brick_cap);
         ix_recs.alloc(rec_cap);

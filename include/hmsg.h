@@ -138,7 +138,8 @@ int hmsg_get_map_feats(const hmsg_t* h, float* feats /*[V][D]*/, float* counter 
  * contributions add commutatively, so the reduced map equals the single-handle one up to float32 summation order. */
 int hmsg_get_feature_sums(const hmsg_t* h, float* sum, uint32_t* counter);
 int hmsg_set_feature_sums(hmsg_t* h, const float* sum, const uint32_t* counter);
-/* test/introspection: NN index of every pixel of a frame (-1 where depth == 0), i32 [H][W] */
+/* test/introspection: NN index of every pixel of a frame (-1 where depth == 0), i32 [H][W].  HMSG_ERR_INVALID after
+ * hmsg_merge_instances on an episode whose frame store exceeded 96 GB (the merge hands that store back). */
 int hmsg_get_frame_nn(const hmsg_t* h, int32_t frame, int32_t* idx);
 /* test/introspection: F_p of a frame (sam_clip_feats_extractor.py:172-175), f32 [n_masks(frame)][D] */
 int hmsg_get_frame_fp(const hmsg_t* h, int32_t frame, float* f_p);
