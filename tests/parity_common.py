@@ -165,7 +165,9 @@ def check_against_reference_run(name, z, sc, got, feats):
     print("%s: map rows off the reference run %.4f; instances %d, within 1e-5 of the reference run %d (%.1f %%), "
           "hinging on a bit-equal NN tie %d (tie queries answered by the cKDTree replay: %d), max err %.3g"
           % (name, frac_rows, n_ref, int(ok.sum()), 100.0 * ok.mean(), int(hinge.sum()), sc.num_tie_queries(), float(err.max())))
-    assert (d > 1e-6).mean() < 2e-3 and d.max() < 2e-3
+    # (an element on an fp16 rounding boundary of the per-pixel feature can differ by ONE fp16 ulp, 2^-10 at most: the row
+    #  norm is a wave reduction here and a vectorised torch reduction in the reference)
+    assert (d > 1e-6).mean() < 2e-3 and d.max() <= 2.0 ** -10, (float((d > 1e-6).mean()), float(d.max()))
     assert err.max() <= 1e-5, (int((~ok).sum()), float(err.max()))
     assert sc.num_tie_queries() > 0
     return ok

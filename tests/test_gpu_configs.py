@@ -136,6 +136,48 @@ def test_configs1_full_size_properties(L):
         assert x.shape == y.shape and np.array_equal(x, y)
 
 
+def test_episode_shape_1280x720_three_floors_against_oracle(L):
+    """configs[4]'s shape: 1280x720 frames of a three-storey scene (three one-floor scenes stacked 3.4 m apart), 12 frames,
+    32 masks -- map, fusion, 3-D masks, sequential merge and pooling stage-wise against the oracle (bit-identical clouds,
+    pooled features within 1e-5), with the incremental fold forced from the first step as well, and the floor
+    segmentation of the mirror (graph.py:624-787) has to find the three floors."""
+    from holoagent_amd.synth import SceneSpec, SynthScene
+    from holoagent_amd.graph import Graph
+    D, W, H, per_floor, storey = 32, 1280, 720, 4, 3.4
+    frames = []
+    for fl in range(3):
+        spec = SceneSpec(seed=90 + fl, rooms_x=1, rooms_z=1, room_size=(4.6, 2.8, 4.0), objects_per_room=5, width=W, height=H,
+                         n_frames=per_floor, n_masks=32, feat_dim=D, yaw_step_deg=24.0)
+        scn = SynthScene(spec)
+        for i in range(per_floor):
+            fr = scn.frame(i)
+            fr["pose"] = np.array(fr["pose"], np.float64)
+            fr["pose"][1, 3] += fl * storey                  # up = +y
+            frames.append(fr)
+    cfg = dict(voxel_size=0.05, clip_masked_weight=0.4418, max_mask_distance=10000, feat_dim=D, init_overlap_thresh=0.75,
+               overlap_thresh_factor=0.025, iou_thresh=0.05, merge_type="sequential", outlier_nb=400)
+    for env in ({}, {"HMSG_FOLD_INCREMENTAL": "1"}):
+        os.environ.pop("HMSG_FOLD_INCREMENTAL", None)
+        os.environ.update(env)
+        try:
+            sc = PC.make_scene(L, frames, dict(feat_dim=D, outlier_nb_points=400))
+            S, ref_pts, ref_cols = PC.check_map(sc, frames, cfg)
+            assert ref_pts.shape[0] > 20000
+            assert ref_pts[:, 1].max() - ref_pts[:, 1].min() > 2 * storey
+            ref_feats, _ = PC.check_fuse(sc, frames, S, cfg, ref_pts, ref_cols, check_masks=True)
+            got, feats = PC.check_merge_pool(sc, frames, cfg, ref_pts, ref_feats)
+            assert len(got) >= 12
+            if not env:
+                g = Graph.from_scene(sc, lib=L)
+                ranges = g.segment_floors_manually(None)
+                assert len(g.floors) == 3, ranges
+                zero = sorted(f.floor_zero_level for f in g.floors)
+                assert abs((zero[1] - zero[0]) - storey) < 0.15 and abs((zero[2] - zero[1]) - storey) < 0.15, zero
+            sc.close()
+        finally:
+            os.environ.pop("HMSG_FOLD_INCREMENTAL", None)
+
+
 def test_many_masks_and_edge_frames_against_oracle(L):
     """Three- and four-word mask bitsets (150-200 masks per frame), a frame without masks and a frame without valid depth,
     on the real device against the oracle (the simulator variants live in tests/test_emu_parity.py)."""

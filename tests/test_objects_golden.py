@@ -36,16 +36,12 @@ def _check(L):
     assert [o.object_id for o in g.objects] == [str(v) for v in zo["obj_id"]]
     assert [o.room_id for o in g.objects] == [str(v) for v in zo["obj_room"]]
     assert [len(o.pcd.points) for o in g.objects] == zo["obj_npts"].tolist()
-    # label names: argmax of <pooled feature, label feature>; pooled features of instances that hinge on an exact
-    # nearest-neighbour tie differ from the reference run by a swapped voxel row, so names are
-    # compared on the tie-stable instances
-    stable = ~z["ref_tie_sensitive"]
+    # label names: argmax of <pooled feature, label feature> (graph.py:1441-1454) -- on EVERY object: the pooled features
+    # are within 1e-5 of the reference run's for every instance, bit-equal nearest-neighbour ties included
     got = [o.name for o in g.objects]
     ref = [str(v) for v in zo["obj_name"]]
-    mask = zo["obj_mask"]
-    bad = [k for k in range(len(ref)) if stable[mask[k]] and got[k] != ref[k]]
+    bad = [(k, got[k], ref[k]) for k in range(len(ref)) if got[k] != ref[k]]
     assert not bad, bad
-    assert sum(bool(stable[m]) for m in mask) >= len(ref) // 3
     # the view <-> object topology of graph.py:1706-1733 (check_object_in_view over the parent room's views, best view =
     # smallest mean depth) against the reference run with three views per room (tests/golden/objects_views.json)
     import json
