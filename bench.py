@@ -94,6 +94,13 @@ def main():
     ap.add_argument("--feat-dim", type=int, default=512)
     ap.add_argument("--topk", type=int, default=5)
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU-oracle baseline sample (0 = skip)")
+    ap.add_argument("--mode", choices=("scene", "episode"), default="scene",
+                    help="scene: one scene per GPU, node tables all-gathered (configs[1]/[3], weak scaling); episode: ONE "
+                         "episode of --frames frames sharded over the GPUs -- frame windows per rank, all-reduce of the voxel "
+                         "feature sums, hierarchical merge tree with cross-rank joins, pooling + retrieval on the root "
+                         "(configs[4], strong scaling)")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
     args = ap.parse_args()
 
     # `python bench.py --gpus N` (N > 1) without a launcher: become the launcher -- one process per GPU under
@@ -138,7 +145,9 @@ def main():
     L = HmsgLib()                      # fails loudly without the HIP library
 
     F, Q, D, k = args.frames, args.queries, args.feat_dim, args.topk
-    spec = SceneSpec(seed=1234 + rank, n_frames=F, feat_dim=D, n_masks=32)
+    episode = args.mode == "episode"
+    # (episode mode: every rank sees the same episode -- same seed; scene mode: a scene per rank)
+    spec = SceneSpec(seed=1234 + (0 if episode else rank), n_frames=F, feat_dim=D, n_masks=32, width=args.width, height=args.height)
     inp = build_scene_inputs(L, spec, device, torch)
     scn = inp["scene"]
     text, q_ent = scn.text_table(Q)                               # [Q, 2, D] (query, negative)
@@ -156,8 +165,16 @@ def main():
     label_feats = rng_l.standard_normal((205, D)).astype(np.float32)      # scannet200-sized label vocabulary
     label_feats /= np.linalg.norm(label_feats, axis=1, keepdims=True)
     label_names = ["label%d" % i for i in range(205)]
-    sc = Scene(lib_=L, device_id=local, height=spec.height, width=spec.width, max_frames=F, max_masks=32, feat_dim=D)
+    sc = Scene(lib_=L, device_id=local, height=spec.height, width=spec.width, max_frames=F, max_masks=32, feat_dim=D,
+               merge_type=1 if episode else 0)
     sc.set_profiling(True)
+    # episode mode: rank r owns the frame window [r * chunk, (r + 1) * chunk), chunk a power of two (a subtree of the merge tree)
+    chunk = 1
+    while chunk * world < F:
+        chunk *= 2
+    win = (min(F, rank * chunk), min(F, (rank + 1) * chunk))
+    if episode:
+        assert (world - 1) * chunk < F, "--frames too small for %d ranks" % world
     stage = {}
 
     def T(name, fn):
@@ -168,7 +185,49 @@ def main():
 
     state = {}
 
+    def step_episode():
+        """configs[4]: every rank holds the whole map (all frames' geometry: replicated, the order-faithful float64 voxel
+        sums are not associative) and the features / masks of its own frame window; voxel feature sums all-reduced over
+        RCCL, merge tree sharded (hmsg_merge_tree_local + cross-rank joins, HBM to HBM), the root pools, assembles, answers."""
+        from holoagent_amd.dist import allreduce_feature_sums, sharded_hierarchical_merge
+        sc.reset()
+        T("add_frames", lambda: sc.add_frames(inp["rgb"], inp["depth"], inp["pose"], inp["K"]))
+        T("finalize_map", sc.finalize_map)
+        a, b = win
+        sc.set_frame_window(a)
+        T("add_frame_features", lambda: sc.add_frame_features(a, inp["masks"][a:b], inp["f_g"][a:b], inp["f_masked"][a:b], inp["f_crop"][a:b]))
+        T("fuse_frames", sc.fuse_frames)
+        if use_dist:
+            T("allreduce_feature_sums", lambda: allreduce_feature_sums(sc, device=device))
+            holds = T("merge_tree", lambda: sharded_hierarchical_merge(sc, F, device=device))
+        else:
+            def whole():
+                th, lists, idx = sc.merge_tree_local(F)
+                assert lists == 1 and idx == 0
+                sc.merge_tree_join([], th, final_pass=True)
+                return True
+            holds = T("merge_tree", whole)
+        state["last"] = None
+        state["n_nodes_local"] = 0
+        if holds:
+            T("pool_instances", sc.pool_instances)
+            g = T("assemble/from_scene", lambda: Graph.from_scene(sc, lib=L))
+            g.set_label_feats(label_feats, label_names)
+            T("assemble/build_hier", lambda: g.build_hier_multimodal_scene_graph(None, rooms=room_specs))
+            state["n_nodes_local"] = len(g.objects)
+            if g.objects:
+                def retrieve():
+                    ix = sc.index_from_nodes()
+                    ix.set_profiling(True)
+                    out = ix.query_objects(text, np.zeros(len(q_rooms), np.int32), q_rooms, k)
+                    state["gemm"] = ix.profile()
+                    ix.close()
+                    return out
+                state["last"] = T("retrieval", retrieve)
+
     def step():
+        if episode:
+            return step_episode()
         sc.reset()
         T("add_frames", lambda: sc.add_frames(inp["rgb"], inp["depth"], inp["pose"], inp["K"]))
         T("finalize_map", sc.finalize_map)
@@ -244,7 +303,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     steps = max(args.steps, 1)
-    fps = world * F * steps / dt
+    fps = (1 if episode else world) * F * steps / dt          # (episode mode: ONE episode of F frames over all ranks)
     retr_s = stage.get("retrieval", 0.0) / steps
     qps = Q / retr_s if retr_s > 0 else None
 
@@ -320,14 +379,21 @@ def main():
     if rank == 0:
         last = state.get("last")
         out = {
-            "metric": "HMSG frames/sec (build A1-A11 + %d-query retrieval per %d-frame scene; frames, masks and encoder "
-                      "features already resident in HBM, encoders bypassed)" % (Q, F),
+            "metric": "HMSG frames/sec (%s: map A1-A2, fusion A3-A5, merge A6, pooling A7, floors A8, objects A10 and graph "
+                      "assembly A11 with the rooms' 2-D regions given and without views -- A9's room embeddings / View nodes are "
+                      "not in the timed step -- plus %d object-level retrieval queries (A12) per %d-frame %s; frames, masks and "
+                      "encoder features already resident in HBM, encoders bypassed)"
+                      % ("one episode sharded over the GPUs" if episode else "one scene per GPU", Q, F, "episode" if episode else "scene"),
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if episode else "weak", "vs_baseline": None,
             "dtype": "f64 geometry / f32 features", "data": "synthetic",
-            "config": {"workload": "configs[1]: %d-frame single scene per GPU, 640x480 RGB-D, 32 masks/frame, %d-d features, "
-                                   "HMSG build + %d-query retrieval" % (F, D, Q),
-                       "frames": F, "queries": Q, "feat_dim": D, "masks": M, "parallelism": "scene-per-gpu x%d" % world},
+            "config": {"workload": ("configs[4] shape: ONE %d-frame episode, %dx%d RGB-D, 32 masks/frame, %d-d features, hierarchical "
+                                    "merge tree sharded over the ranks, HMSG build + %d-query retrieval on the root" % (F, spec.width, spec.height, D, Q))
+                       if episode else
+                       ("configs[1]: %d-frame single scene per GPU, %dx%d RGB-D, 32 masks/frame, %d-d features, "
+                        "HMSG build + %d-query retrieval" % (F, spec.width, spec.height, D, Q)),
+                       "frames": F, "queries": Q, "feat_dim": D, "masks": M,
+                       "parallelism": ("episode-sharded x%d (frame windows of %d)" % (world, chunk)) if episode else "scene-per-gpu x%d" % world},
             "rccl_ranks": dist.get_world_size() if use_dist else 0,
             "per_rank_frames_per_s": [round(v, 1) for v in per_rank_fps],
             "queries_per_sec": round(qps, 1) if qps else None,

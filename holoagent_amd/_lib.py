@@ -312,6 +312,33 @@ class Scene:
         self._ck(self.L.c.hmsg_merge_tree_join(self.h, len(clouds), _ptr(sizes) if len(clouds) else None,
                                                _ptr(pts) if len(pts) else None, float(th), int(bool(final_pass))))
 
+    def merge_tree_join_raw(self, sizes, points, th, final_pass):
+        """Same, the partner's clouds as one block: sizes i64 [n] (host), points [sum, 3] f64 -- a numpy array or a torch
+        tensor on the host or ON THE DEVICE (e.g. what an RCCL recv just filled)."""
+        sizes = np.ascontiguousarray(sizes, np.int64)
+        total = int(sizes.sum())
+        self._ck(self.L.c.hmsg_merge_tree_join(self.h, len(sizes), _ptr(sizes) if len(sizes) else None,
+                                               _ptr(points) if total else None, float(th), int(bool(final_pass))))
+
+    def instance_sizes(self):
+        n = int(self.L.c.hmsg_num_instances(self.h))
+        sizes = np.empty((n,), np.int64)
+        if n:
+            self._ck(self.L.c.hmsg_get_instance_sizes(self.h, _ptr(sizes)))
+        return sizes
+
+    def instance_points_into(self, out):
+        """Instance points into a caller-supplied [sum, 3] f64 buffer (numpy array, or torch tensor on host or device)."""
+        self._ck(self.L.c.hmsg_get_instance_points(self.h, _ptr(out)))
+
+    def feature_sums_into(self, sums, counter):
+        """Per-voxel feature sums f32 [V, D] and frame counters u32 [V] into caller-supplied buffers (host or device)."""
+        self._ck(self.L.c.hmsg_get_feature_sums(self.h, _ptr(sums), _ptr(counter)))
+
+    def set_feature_sums_from(self, sums, counter):
+        """Install feature sums / counters from caller-supplied buffers (host or device) without a detour over numpy."""
+        self._ck(self.L.c.hmsg_set_feature_sums(self.h, _ptr(sums), _ptr(counter)))
+
     def instances(self):
         n = int(self.L.c.hmsg_num_instances(self.h))
         sizes = np.empty((n,), np.int64)

@@ -544,7 +544,8 @@ int hmsg_get_instance_points(const hmsg_t* hc, double* xyz) {
     if (!h) return HMSG_ERR_INVALID;
     return guard(h, [&] {
         HMSG_REQUIRE((h->merged || h->tree_partial) && xyz, HMSG_ERR_INVALID, "hmsg_merge_instances not run");
-        if (h->inst.total) HIP_TRY(hipMemcpy(xyz, h->inst.pts.p, (size_t)h->inst.total * 24, hipMemcpyDeviceToHost));
+        if (h->inst.total)
+            HIP_TRY(hipMemcpy(xyz, h->inst.pts.p, (size_t)h->inst.total * 24, is_device_ptr(xyz) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
     });
 }
 

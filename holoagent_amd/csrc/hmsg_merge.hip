@@ -1134,8 +1134,10 @@ void hmsg_merge_tree_local_impl(hmsg_ctx* h, int total_frames, double* th_next, 
     long long lists = total_frames, off = h->frame_window;     // global list count / global index of my first list
     while (lists > 1) {
         const long long n = (long long)lv.size();
-        // local level: my lists pair among themselves (an odd last one only when it is the global last list)
-        if ((off & 1) || ((n & 1) && off + n < lists)) break;
+        // local level: my lists pair among themselves (an odd last one only when it is the global last list).  A single
+        // list has nobody to pair with here: whether it is carried up or meets a partner is the cross-handle levels'
+        // business (every handle then stops at a level the others can work out, whatever the window lengths).
+        if (n == 1 || (off & 1) || ((n & 1) && off + n < lists)) break;
         std::vector<std::vector<Cloud>> nx;
         for (size_t i = 0; i < lv.size(); i += 2) {
             if (i == lv.size() - 1) {
@@ -1174,7 +1176,13 @@ void hmsg_merge_tree_join_impl(hmsg_ctx* h, int n_ext, const long long* ext_size
     m.pool.alloc((size_t)std::max<long long>(total * 2, 1 << 16) * 3);
     m.poolcore.alloc((size_t)std::max<long long>(total * 2, 1 << 16));
     if (own) HIP_TRY(hipMemcpyAsync(m.pool.p, h->inst.pts.p, (size_t)own * 24, hipMemcpyDeviceToDevice, h->stream));
-    if (ext_total) HIP_TRY(hipMemcpyAsync(m.pool.p + (size_t)own * 3, ext_pts, (size_t)ext_total * 24, hipMemcpyHostToDevice, h->stream));
+    if (ext_total) {                               // (the partner's clouds: host memory, or device memory straight from a collective)
+        hipPointerAttribute_t pa;
+        memset(&pa, 0, sizeof(pa));
+        const bool on_dev = hipPointerGetAttributes(&pa, ext_pts) == hipSuccess && pa.type == hipMemoryTypeDevice;
+        if (!on_dev) (void)hipGetLastError();
+        HIP_TRY(hipMemcpyAsync(m.pool.p + (size_t)own * 3, ext_pts, (size_t)ext_total * 24, on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    }
     m.pool_used = total;
     const int n_own = (int)h->inst.off.size() - 1;
     std::vector<SegDesc> segs((size_t)(n_own + n_ext));

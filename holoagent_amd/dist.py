@@ -8,7 +8,7 @@ from __future__ import annotations
 import numpy as np
 
 
-def gather_node_tables(feats: np.ndarray, rooms: np.ndarray, n_rooms_local: int, device=None):
+def gather_node_tables(feats, rooms: np.ndarray, n_rooms_local: int, device=None):
     """feats f64 [n, D], rooms i32 [n] (local room ids) -> (global feats [N, D], global room ids [N],
     node offsets per rank [world+1], room offsets per rank [world+1])."""
     import torch
@@ -26,7 +26,9 @@ def gather_node_tables(feats: np.ndarray, rooms: np.ndarray, n_rooms_local: int,
     nmax = max(max(counts), 1)
     pay = torch.zeros((nmax, D + 1), dtype=torch.float64, device=dev)
     if feats.shape[0]:
-        pay[: feats.shape[0], :D] = torch.from_numpy(np.ascontiguousarray(feats, np.float64)).to(dev)
+        # (feats: numpy, or a torch tensor already on the device -- no detour over the host then)
+        pay[: feats.shape[0], :D] = (feats.to(dev, torch.float64) if hasattr(feats, "data_ptr")
+                                     else torch.from_numpy(np.ascontiguousarray(feats, np.float64)).to(dev))
         pay[: feats.shape[0], D] = torch.from_numpy((rooms.astype(np.int64) + room_off[rank]).astype(np.float64)).to(dev)
     allp = [torch.empty_like(pay) for _ in range(world)]
     dist.all_gather(allp, pay)
@@ -39,69 +41,110 @@ def shard_queries(n_queries: int, rank: int, world: int):
     return list(range(rank, n_queries, world))
 
 
-def sharded_hierarchical_merge(scene, total_frames, overlap_thresh_factor=0.025, group=None):
+def _next_threshold(th, factor, lists):
+    """threshold after a level that left `lists` lists (graph_utils.py:1001-1003)"""
+    return th - factor * (lists - 2) / max(1, lists - 1) if lists > 1 else th
+
+
+def sharded_hierarchical_merge(scene, total_frames, overlap_thresh_factor=0.025, group=None, device=None):
     """hierarchical_merge (graph_utils.py:989-1012) of ONE episode whose frames are spread over the ranks:
-    rank r holds the frame window [r * chunk, (r + 1) * chunk) with chunk a power of two (scene.set_frame_window), has
-    fused its own frames, and calls this.  Rank-local tree levels first, then log2(ranks) cross-rank levels in which
-    the odd list of every pair travels to the rank holding the even one (point clouds, over torch.distributed send /
-    recv: RCCL on the GPUs, gloo in the CPU test); rank 0 ends with the instances of the whole episode, bit-identical
-    to a single-process hmsg_merge_instances.  Returns True on the rank that holds the result."""
+    rank r holds a frame window that is a subtree of the merge tree (first frame a multiple of a power of two >= the
+    window length: scene.set_frame_window; equal power-of-two chunks with a shorter last one qualify), has fused its own
+    frames, and calls this.
+
+    1. rank-local tree levels (hmsg_merge_tree_local): every rank ends with ONE list and reports the level it stopped at;
+    2. the ranks agree on the level (all-gather of (lists, index)): a rank that stopped lower holds the last, unpaired
+       list of its level and carries it up unchanged, as merge_adjacent_frames does with an odd last list;
+    3. cross-rank levels: the owner of list 2k+1 sends its clouds to the owner of list 2k, which merges [mine ++ theirs]
+       (hmsg_merge_tree_join); an unpaired last list stays where it is.  Owners are tracked per list, so any number of
+       ranks works (3, 5, 6, ... not only powers of two).
+
+    `device`: where the exchanged tensors live -- None / cpu with the gloo backend (CPU tests), the rank's GPU with the
+    nccl backend (RCCL: send / recv need device tensors; the clouds then go from HBM to HBM, hmsg_merge_tree_join reads
+    the receive buffer in place).  The root (rank 0) ends with the instances of the whole episode, bit-identical to a
+    single-process hmsg_merge_instances.  Returns True on the rank that holds the result."""
     import torch
     import torch.distributed as dist
-    rank = dist.get_rank(group)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    dev = device if device is not None else torch.device("cpu")
     th, lists, idx = scene.merge_tree_local(total_frames)
-    stride = 1                                   # ranks between the owners of adjacent lists at this level
-    active = True
+    meta = torch.tensor([lists, idx], dtype=torch.int64, device=dev)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    state = [(int(m[0].item()), int(m[1].item())) for m in metas]
+    target = min(l for l, _ in state)
+    owner = {}                                   # list index at the common level -> rank
+    for r, (l, i) in enumerate(state):
+        t = th if r == rank else None
+        while l > target:
+            if not (i == l - 1 and l % 2 == 1):
+                raise ValueError("sharded_hierarchical_merge: rank %d's frame window is not a subtree of the merge tree "
+                                 "(list %d of %d cannot be carried up)" % (r, i, l))
+            i //= 2
+            l = (l + 1) // 2
+            if t is not None:
+                t = _next_threshold(t, overlap_thresh_factor, l)
+        if i in owner:
+            raise ValueError("sharded_hierarchical_merge: ranks %d and %d both hold list %d" % (owner[i], r, i))
+        owner[i] = r
+        if r == rank:
+            th, lists, idx = t, l, i
+    if sorted(owner) != list(range(lists)):
+        raise ValueError("sharded_hierarchical_merge: the ranks hold lists %s of %d" % (sorted(owner), lists))
     if lists == 1:                               # one rank held every frame
-        scene.merge_tree_join([], th, final_pass=True)
-        return True
+        if owner[0] == rank:
+            scene.merge_tree_join([], th, final_pass=True)
+        return owner[0] == rank
+    active = True
     while lists > 1:
         nxt = (lists + 1) // 2
-        if active:
-            if idx % 2 == 0:
-                if idx + 1 < lists:
-                    src = rank + stride
-                    meta = torch.zeros(1, dtype=torch.int64)
-                    dist.recv(meta, src=src, group=group)
-                    sizes = torch.zeros(int(meta.item()), dtype=torch.int64)
-                    if len(sizes):
-                        dist.recv(sizes, src=src, group=group)
-                    pts = torch.zeros((int(sizes.sum().item()), 3), dtype=torch.float64)
-                    if len(pts):
-                        dist.recv(pts, src=src, group=group)
-                    off = np.concatenate([[0], np.cumsum(sizes.numpy())])
-                    clouds = [pts.numpy()[off[k]:off[k + 1]] for k in range(len(sizes))]
-                    scene.merge_tree_join(clouds, th, final_pass=(nxt == 1))
-                # (an even list without a partner is carried to the next level unchanged)
-            else:
-                dst = rank - stride
-                clouds = scene.instances()
-                sizes = torch.tensor([len(c) for c in clouds], dtype=torch.int64)
-                dist.send(torch.tensor([len(clouds)], dtype=torch.int64), dst=dst, group=group)
-                if len(clouds):
-                    dist.send(sizes, dst=dst, group=group)
-                pts = torch.from_numpy(np.ascontiguousarray(np.concatenate(clouds) if len(clouds) else np.zeros((0, 3))))
-                if len(pts):
+        if active and idx % 2 == 1:              # my list is the odd one of its pair: it travels
+            dst = owner[idx - 1]
+            sizes = scene.instance_sizes()
+            dist.send(torch.tensor([len(sizes)], dtype=torch.int64, device=dev), dst=dst, group=group)
+            if len(sizes):
+                dist.send(torch.from_numpy(sizes).to(dev), dst=dst, group=group)
+                total = int(sizes.sum())
+                if total:
+                    pts = torch.empty((total, 3), dtype=torch.float64, device=dev)
+                    scene.instance_points_into(pts)          # HBM -> HBM when dev is the GPU
                     dist.send(pts, dst=dst, group=group)
-                active = False
+            active = False
+        elif active and idx + 1 < lists:         # I hold the even one: merge [mine ++ theirs]
+            src = owner[idx + 1]
+            n = torch.zeros(1, dtype=torch.int64, device=dev)
+            dist.recv(n, src=src, group=group)
+            sizes = torch.zeros(int(n.item()), dtype=torch.int64, device=dev)
+            pts = None
+            if len(sizes):
+                dist.recv(sizes, src=src, group=group)
+                total = int(sizes.sum().item())
+                if total:
+                    pts = torch.empty((total, 3), dtype=torch.float64, device=dev)
+                    dist.recv(pts, src=src, group=group)
+            scene.merge_tree_join_raw(sizes.cpu().numpy(), pts, th, final_pass=(nxt == 1))
+        # (an even list without a partner is carried to the next level unchanged)
+        owner = {k // 2: r for k, r in owner.items() if k % 2 == 0}
         idx //= 2
-        stride *= 2
         lists = nxt
-        if lists > 1:
-            th -= overlap_thresh_factor * (lists - 2) / max(1, lists - 1)
+        th = _next_threshold(th, overlap_thresh_factor, lists)
     return active
 
 
 def allreduce_feature_sums(scene, group=None, device=None):
     """One episode fused in disjoint frame windows: sum the per-voxel feature sums and frame counters of
     all ranks (all-reduce of V * (D + 1) * 4 bytes over RCCL / gloo) and install the result on every rank.  Counters
-    are exact; the float32 sums agree with a single-process build up to summation order (<= 1e-5)."""
+    are exact; the float32 sums agree with a single-process build up to summation order (<= 1e-5).
+    With `device` = the rank's GPU the buffers never leave HBM: the library copies its sums into the collective's
+    tensors and reads the reduced ones back by device pointer."""
     import torch
     import torch.distributed as dist
-    sums, cnt = scene.feature_sums()
     dev = device if device is not None else torch.device("cpu")
-    ts = torch.from_numpy(sums).to(dev)
-    tc = torch.from_numpy(cnt.astype(np.int64)).to(dev)
+    V, D = scene.map_size(), scene.cfg.feat_dim
+    ts = torch.empty((V, D), dtype=torch.float32, device=dev)
+    tc32 = torch.empty((V,), dtype=torch.int32, device=dev)      # (the library's counters are u32; int32 views them bit for bit)
+    scene.feature_sums_into(ts, tc32)
+    tc = tc32.to(torch.int64)
     dist.all_reduce(ts, group=group)
     dist.all_reduce(tc, group=group)
-    scene.set_feature_sums(ts.cpu().numpy(), tc.cpu().numpy().astype(np.uint32))
+    scene.set_feature_sums_from(ts, tc.to(torch.int32).contiguous())

@@ -152,7 +152,7 @@ int hmsg_get_frame_mask_points(const hmsg_t* h, int32_t frame, double* xyz);
 int hmsg_merge_instances(hmsg_t* h);
 int64_t hmsg_num_instances(const hmsg_t* h);
 int hmsg_get_instance_sizes(const hmsg_t* h, int64_t* sizes /*[N]*/);
-int hmsg_get_instance_points(const hmsg_t* h, double* xyz /*[sum][3]*/);
+int hmsg_get_instance_points(const hmsg_t* h, double* xyz /*[sum][3], host or device*/);
 int hmsg_get_instance_boxes(const hmsg_t* h, double* boxes /*[N][6]: AABB min xyz, max xyz*/);
 
 /* ---- hierarchical_merge (graph_utils.py:989-1012) sharded over the frames of ONE episode: every handle
@@ -165,7 +165,8 @@ int hmsg_get_instance_boxes(const hmsg_t* h, double* boxes /*[N][6]: AABB min xy
  *                          reports the threshold of the next level, the number of lists at that level and this list's
  *                          index among them.
  *   hmsg_merge_tree_join   one cross-handle level on the handle that holds the even-indexed list: merge_3d_masks over
- *                          [mine ++ the partner's clouds] (host arrays: sizes i64 [n_ext], points f64 [sum][3]) at
+ *                          [mine ++ the partner's clouds] (sizes i64 [n_ext] on the host, points f64 [sum][3] on the host
+ *                          or on the device -- e.g. the receive buffer of an RCCL collective) at
  *                          threshold th; final_pass != 0 also runs the last pass (threshold 0.75, :1007-1011) and the
  *                          small-cloud drop (graph.py:445-448), after which hmsg_pool_instances may follow.
  *                          n_ext == 0 with final_pass: a single handle held every frame.

@@ -114,16 +114,15 @@ def _build(L, frames, window=None):
     return sc
 
 
-def _merge_worker(rank, world, port, out):
+def _merge_worker(rank, world, port, out, n_frames, chunk):
     import torch.distributed as dist
     from holoagent_amd._lib import HmsgLib
     from holoagent_amd.dist import sharded_hierarchical_merge
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    frames = _episode()
-    chunk = len(frames) // world
-    sc = _build(HmsgLib(PC.EMU_PATH), frames, (rank * chunk, (rank + 1) * chunk))
+    frames = _episode(n_frames)
+    sc = _build(HmsgLib(PC.EMU_PATH), frames, (rank * chunk, min(n_frames, (rank + 1) * chunk)))
     from holoagent_amd.dist import allreduce_feature_sums
     allreduce_feature_sums(sc)                       # every rank now holds the whole episode's voxel features
     holds = sharded_hierarchical_merge(sc, len(frames))
@@ -139,9 +138,13 @@ def _merge_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, pytest.param(4, marks=pytest.mark.skipif(not os.environ.get("HMSG_EMU_SLOW"),
-                                                                                reason="another minute on the simulator"))])
-def test_sharded_hierarchical_merge_equals_single_process(tmp_path, world):
+# (world, frames, frames per rank): two even ranks; THREE ranks with a shorter last window (the last rank stops its local
+# tree two levels below the others and is carried up); four ranks on request
+@pytest.mark.parametrize("world,n_frames,chunk", [
+    (2, 4, 2), (3, 5, 2),
+    pytest.param(4, 4, 1, marks=pytest.mark.skipif(not os.environ.get("HMSG_EMU_SLOW"), reason="another minute on the simulator")),
+    pytest.param(3, 10, 4, marks=pytest.mark.skipif(not os.environ.get("HMSG_EMU_SLOW"), reason="minutes on the simulator"))])
+def test_sharded_hierarchical_merge_equals_single_process(tmp_path, world, n_frames, chunk):
     """Frames of one episode split over the ranks: all-reduce of the voxel feature sums, rank-local merge-tree levels +
     cross-rank joins (torch.distributed send / recv), pooling on the root == one process over all frames (instances bit
     for bit, features within 1e-5)."""
@@ -152,8 +155,8 @@ def test_sharded_hierarchical_merge_equals_single_process(tmp_path, world):
     port = s.getsockname()[1]
     s.close()
     out = str(tmp_path / "merged.npz")
-    mp.spawn(_merge_worker, args=(world, port, out), nprocs=world, join=True)
-    sc = _build(HmsgLib(PC.EMU_PATH), _episode())
+    mp.spawn(_merge_worker, args=(world, port, out, n_frames, chunk), nprocs=world, join=True)
+    sc = _build(HmsgLib(PC.EMU_PATH), _episode(n_frames))
     sc.merge_instances()
     ref = sc.instances()
     sc.pool_instances()
@@ -168,3 +171,42 @@ def test_sharded_hierarchical_merge_equals_single_process(tmp_path, world):
     assert np.array_equal(z["counter"], ref_counter)
     np.testing.assert_allclose(z["map_feats"], ref_feats, rtol=0, atol=1e-5)
     np.testing.assert_allclose(z["pooled"], ref_pooled, rtol=0, atol=1e-5)
+
+
+def test_tree_schedule_pairs_every_rank_layout():
+    """The send / recv schedule of sharded_hierarchical_merge, simulated without processes for every (ranks, frames per
+    rank, total) with power-of-two chunks and a shorter last window: each level's sends match its receives, exactly one
+    rank ends up with the result, and the number of joins equals ranks - 1."""
+    def local(total, first, n):
+        lists, off = total, first
+        while lists > 1:
+            if n == 1 or (off & 1) or ((n & 1) and off + n < lists):
+                break
+            n = (n + 1) // 2
+            off >>= 1
+            lists = (lists + 1) // 2
+        return lists, off
+    for chunk in (1, 2, 4, 8):
+        for world in range(1, 9):
+            for total in range((world - 1) * chunk + 1, world * chunk + 1):
+                state = [local(total, r * chunk, min(total, (r + 1) * chunk) - r * chunk) for r in range(world)]
+                target = min(l for l, _ in state)
+                owner = {}
+                for r, (l, i) in enumerate(state):
+                    while l > target:
+                        assert i == l - 1 and l % 2 == 1, (chunk, world, total, r)
+                        i //= 2
+                        l = (l + 1) // 2
+                    assert i not in owner
+                    owner[i] = r
+                lists = target
+                assert sorted(owner) == list(range(lists)), (chunk, world, total)
+                joins = 0
+                while lists > 1:
+                    sends = {owner[k - 1]: owner[k] for k in owner if k % 2 == 1}
+                    recvs = {owner[k]: owner[k + 1] for k in owner if k % 2 == 0 and k + 1 < lists}
+                    assert sends == recvs
+                    joins += len(sends)
+                    owner = {k // 2: r for k, r in owner.items() if k % 2 == 0}
+                    lists = (lists + 1) // 2
+                assert joins == world - 1 and owner == {0: 0}

@@ -220,3 +220,23 @@ def test_fold_collector_is_exact_on_device(L):
     assert len(out[0]) == len(out[1]) > 10
     for x, y in zip(out[0], out[1]):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("mode", ["scene", "episode"])
+def test_bench_rccl_path_with_one_rank(mode):
+    """bench.py's multi-GPU code paths executed on the one GPU of this box (HMSG_BENCH_FORCE_DIST=1: process group on
+    the nccl backend = RCCL, device tensors in the collectives): scene mode (all-gather of the node tables) and episode
+    mode (all-reduce of the voxel feature sums, sharded merge tree, root-side pooling / retrieval).  The 8-GPU runs are
+    the driver's; this keeps the RCCL code from rotting."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = dict(os.environ, HMSG_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--frames", "96",
+                          "--queries", "64", "--cpu-frames", "0", "--mode", mode], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["rccl_ranks"] == 1 and rec["n_gpus"] == 1 and rec["value"] > 0
+    assert rec["scaling"] == ("strong" if mode == "episode" else "weak")
+    assert rec["nodes_local"] > 5 and rec["queries_per_sec"] > 0
