@@ -153,7 +153,12 @@ def main():
     text, q_ent = scn.text_table(Q)                               # [Q, 2, D] (query, negative)
     n_rooms = len(scn.rooms)
     ent_room = np.concatenate([inp["obj_room"], np.repeat(np.arange(n_rooms), 6)])
-    q_rooms = [[int(ent_room[e]), int((ent_room[e] + 1) % n_rooms)] for e in q_ent]   # label-mode room sets
+    q_rooms = [[int(ent_room[e]), int((ent_room[e] + 1) % n_rooms)] for e in q_ent]   # (multi-GPU leg: room sets handed in)
+    # room names stand in for CLIP text embeddings of "room<i>": random unit rows; a query names its entity's room
+    rng_r = np.random.Generator(np.random.PCG64(4242))
+    room_name_feats = rng_r.standard_normal((n_rooms, D))
+    room_name_feats /= np.linalg.norm(room_name_feats, axis=1, keepdims=True)
+    room_text = np.ascontiguousarray(room_name_feats[ent_room[q_ent]], np.float32)
 
     from holoagent_amd.graph import Graph
     # rooms are an input of the path: 2-D vertex grids at grid_resolution 0.05 like the reference's
@@ -219,10 +224,12 @@ def main():
                 def retrieve():
                     ix = sc.index_from_nodes()
                     ix.set_profiling(True)
-                    out = ix.query_objects(text, np.zeros(len(q_rooms), np.int32), q_rooms, k)
+                    ix.set_hierarchy([list(range(n_rooms))], room_name_feats, [np.zeros((0, D))] * n_rooms, list(range(n_rooms)))
+                    sel, idx, room, score = ix.query_hier(text, np.zeros(len(text), np.int32), room_text, np.zeros(len(text), np.int32),
+                                                          np.ones(len(text), np.int32), k)
                     state["gemm"] = ix.profile()
                     ix.close()
-                    return out
+                    return idx, room, score
                 state["last"] = T("retrieval", retrieve)
 
     def step():
@@ -267,9 +274,21 @@ def main():
                 g_feats, g_rooms, rl, tq = feats, rooms, q_rooms, text
             if g_feats.shape[0] == 0:
                 return None
-            # one GPU: the index is gathered on the device from the node table (hmsg_index_from_nodes); N GPUs: from
-            # the all-gathered global table
-            ix = sc.index_from_nodes() if not use_dist else NodeIndex(g_feats, g_rooms, device_id=local, lib_=L)
+            # one GPU: the index is gathered on the device from the node table (hmsg_index_from_nodes) and the queries run
+            # coarse to fine ON THE DEVICE (hmsg_query_hier): floor 0 -> room by its name (label mode: the rooms within
+            # 1e-3 of the best name similarity) -> objects of those rooms with one negative prompt -- no room list is
+            # handed in.  N GPUs: object-level queries on the all-gathered global table with the rooms' global ids.
+            if not use_dist:
+                ix = sc.index_from_nodes()
+                ix.set_profiling(True)
+                ix.set_hierarchy([list(range(n_rooms))], room_name_feats, [np.zeros((0, D))] * n_rooms, list(range(n_rooms)))
+                sel, idx, room, score = ix.query_hier(tq, np.zeros(len(tq), np.int32), room_text, np.zeros(len(tq), np.int32),
+                                                      np.ones(len(tq), np.int32), k)
+                state["gemm"] = ix.profile()
+                state["rooms_hit"] = float(np.mean([int(ent_room[e]) in s_ for e, s_ in zip(q_ent, sel)]))
+                ix.close()
+                return idx, room, score
+            ix = NodeIndex(g_feats, g_rooms, device_id=local, lib_=L)
             ix.set_profiling(True)
             out = ix.query_objects(tq, np.zeros(len(rl), np.int32), rl, k)
             state["gemm"] = ix.profile()                       # (launches, ms, FLOP) of the float64 MFMA GEMM
@@ -381,7 +400,8 @@ def main():
         out = {
             "metric": "HMSG frames/sec (%s: map A1-A2, fusion A3-A5, merge A6, pooling A7, floors A8, objects A10 and graph "
                       "assembly A11 with the rooms' 2-D regions given and without views -- A9's room embeddings / View nodes are "
-                      "not in the timed step -- plus %d object-level retrieval queries (A12) per %d-frame %s; frames, masks and "
+                      "not in the timed step -- plus %d coarse-to-fine retrieval queries (A12: floor -> room by its name -> objects with a "
+                      "negative prompt, every stage on the device; object level only in the multi-GPU scene mode) per %d-frame %s; frames, masks and "
                       "encoder features already resident in HBM, encoders bypassed)"
                       % ("one episode sharded over the GPUs" if episode else "one scene per GPU", Q, F, "episode" if episode else "scene"),
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -397,6 +417,7 @@ def main():
             "rccl_ranks": dist.get_world_size() if use_dist else 0,
             "per_rank_frames_per_s": [round(v, 1) for v in per_rank_fps],
             "queries_per_sec": round(qps, 1) if qps else None,
+            "retrieval_room_stage_hit_rate": state.get("rooms_hit"),
             "stage_ms_per_step": {k_: round(v / steps * 1e3, 2) for k_, v in stage.items()},
             "map_voxels": V, "nodes_local": state.get("n_nodes_local"),
             "kernels_ms_last_step": {k_: round(v[1], 3) for k_, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},

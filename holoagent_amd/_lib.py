@@ -112,6 +112,8 @@ _SIGS = {
     "hmsg_index_profile": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "hmsg_query_objects": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     "hmsg_similarity": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "hmsg_index_set_hierarchy": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P]),
+    "hmsg_query_hier": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     "hmsg_test_sort_pairs": (C.c_int, [_P, _P, C.c_int64, C.c_int32]),
     "hmsg_test_repeat_add": (C.c_int, [_P, _P, _P, _P, C.c_int64]),
     "hmsg_test_ckdtree": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P]),
@@ -568,6 +570,42 @@ class NodeIndex:
         n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
         self._ck(self.L.c.hmsg_index_profile(self.ix, C.byref(n), C.byref(ms), C.byref(fl)))
         return int(n.value), float(ms.value), float(fl.value)
+
+    def set_hierarchy(self, floor_rooms, room_name_emb, room_view_embs, room_keys):
+        """floor_rooms: per floor the room ids in floors[f].rooms order; room_name_emb f64 [R, D] (or None);
+        room_view_embs: per room an [n_v, D] array (room.embeddings); room_keys: per room int(room_id.split("_")[-1])."""
+        R = len(room_view_embs)
+        foff = np.zeros(len(floor_rooms) + 1, np.int32)
+        foff[1:] = np.cumsum([len(r) for r in floor_rooms])
+        fr = np.ascontiguousarray(np.concatenate([np.asarray(r, np.int32) for r in floor_rooms]) if foff[-1] else np.zeros(0, np.int32), np.int32)
+        voff = np.zeros(R + 1, np.int64)
+        voff[1:] = np.cumsum([len(v) for v in room_view_embs])
+        views = np.ascontiguousarray(np.concatenate([np.asarray(v, np.float64).reshape(-1, self.D) for v in room_view_embs])
+                                     if voff[-1] else np.zeros((0, self.D)), np.float64)
+        names = None if room_name_emb is None else np.ascontiguousarray(room_name_emb, np.float64)
+        keys = np.ascontiguousarray(room_keys, np.int32)
+        self._ck(self.L.c.hmsg_index_set_hierarchy(self.ix, R, len(floor_rooms), _ptr(foff), _ptr(fr), _ptr(names), _ptr(voff),
+                                                   _ptr(views), _ptr(keys)))
+        self._n_rooms = R
+
+    def query_hier(self, T_obj, qid, T_room, floor_id, room_mode, k, use_negatives=True, max_rooms=None):
+        """floor -> room(s) -> objects on the device (include/hmsg.h: hmsg_query_hier).  Returns (rooms per query as
+        query_hmsg_room reports them, idx [Q, k], room [Q, k] (global ids), score [Q, k])."""
+        T_obj = np.ascontiguousarray(T_obj, dtype=np.float32)
+        Q, Cn, D = T_obj.shape
+        T_room = None if T_room is None else np.ascontiguousarray(T_room, dtype=np.float32)
+        qid = np.ascontiguousarray(qid, dtype=np.int32)
+        floor_id = np.ascontiguousarray(floor_id, dtype=np.int32)
+        room_mode = np.ascontiguousarray(room_mode, dtype=np.int32)
+        RM = int(max_rooms or max(self._n_rooms, 10))
+        sel = np.empty((Q, RM), np.int32)
+        nsel = np.empty((Q,), np.int32)
+        idx = np.empty((Q, k), np.int32)
+        room = np.empty((Q, k), np.int32)
+        score = np.empty((Q, k), np.float64)
+        self._ck(self.L.c.hmsg_query_hier(self.ix, Q, Cn, _ptr(T_obj), _ptr(qid), _ptr(T_room), _ptr(floor_id), _ptr(room_mode), k,
+                                          int(use_negatives), RM, _ptr(sel), _ptr(nsel), _ptr(idx), _ptr(room), _ptr(score)))
+        return [sel[q, : nsel[q]].tolist() for q in range(Q)], idx, room, score
 
     def query_objects(self, T, qid, room_lists, k, use_negatives=True):
         T = np.ascontiguousarray(T, dtype=np.float32)

@@ -37,6 +37,20 @@ struct hmsg_index {
     DevBuf<float> Tf;
     DevBuf<int> d_qid, d_roff, d_rooms, d_oidx, d_oroom;
     DevBuf<double> d_oscore;
+    // the hierarchy above the nodes (hmsg_index_set_hierarchy): floors -> rooms, room name / view embeddings
+    bool have_hier = false;
+    int n_floors = 0, h_rooms = 0;
+    long long n_views = 0;
+    DevBuf<double> room_name_emb;   // [n_rooms][D]  CLIP text embedding of the room's name (label mode)
+    DevBuf<double> view_emb;        // [n_views][D]  room.embeddings (view mode)
+    DevBuf<int> view_off;           // [n_rooms + 1]
+    DevBuf<int> room_key;           // [n_rooms]     int(room_id.split("_")[-1]): what the view mode returns
+    DevBuf<int> floor_room_off;     // [n_floors + 1]
+    DevBuf<int> floor_rooms;        // rooms of floor f in floors[f].rooms order (global room ids)
+    DevBuf<double> S_room, S_view;  // scratch
+    DevBuf<float> Tr;
+    DevBuf<double> Tr64;
+    DevBuf<int> d_floor, d_mode, d_sel, d_nsel, d_err;
     Prof prof;                   // live timing of the GEMM (hmsg_index_set_profiling)
 };
 
@@ -282,6 +296,104 @@ __global__ void __launch_bounds__(256) k_query_topk(const double* __restrict__ S
     }
 }
 
+// query_hmsg_room (graph.py:3164-3272), one workgroup per query.  rooms_list = self.rooms (floor -1) or floors[f].rooms.
+//   mode 1 (label, :3204-3232): similarity of the room text with every room NAME of the list; every room within 1e-3 of
+//        the best one, in list order; the numbers returned are positions in rooms_list.
+//   mode 2 / 3 (view embeddings, :3247-3272): per room the largest similarity over its view embeddings; rooms sorted by
+//        it, descending (Python's sorted: stable, ties keep the list order); the first 5 (mode 2) or 10 (mode 3); the
+//        numbers returned are int(room_id.split("_")[-1]) -- which the caller then uses as positions in rooms_list.
+//   mode 0: no room stage (every room of the list, in order).
+// The selected numbers go to sel[q][0 .. nsel[q]); the object stage searches rooms_list[number] in that order
+// (query_hmsg_object :3099-3110); a number that is no position of rooms_list raises IndexError there: err[q] = 1.
+__global__ void __launch_bounds__(256) k_room_select(int n_rooms, int n_floors, const double* __restrict__ S_room,
+                                                     const double* __restrict__ S_view, long long n_views,
+                                                     const int* __restrict__ view_off, const int* __restrict__ room_key,
+                                                     const int* __restrict__ floor_room_off, const int* __restrict__ floor_rooms,
+                                                     const int* __restrict__ floor_id, const int* __restrict__ mode, int max_sel,
+                                                     int* __restrict__ sel, int* __restrict__ nsel, int* __restrict__ q_rooms,
+                                                     int* __restrict__ err) {
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int f = floor_id[q], m = mode[q];
+    __shared__ int s_bad;
+    if (tid == 0) s_bad = (f >= n_floors) ? 1 : 0;
+    __syncthreads();
+    const int L = f < 0 ? n_rooms : (s_bad ? 0 : floor_room_off[f + 1] - floor_room_off[f]);
+    auto room_at = [&](int i) { return f < 0 ? i : floor_rooms[floor_room_off[f] + i]; };
+    __shared__ double s_red[256];
+    int* my_sel = sel + (size_t)q * max_sel;
+    if (m == 1) {
+        double best = -1e308;
+        for (int i = tid; i < L; i += 256) best = fmax(best, S_room[(size_t)q * n_rooms + room_at(i)]);
+        s_red[tid] = best;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) s_red[tid] = fmax(s_red[tid], s_red[tid + o]);
+            __syncthreads();
+        }
+        best = s_red[0];
+        if (tid == 0) {                                         // (a handful of rooms: in list order)
+            int n = 0;
+            for (int i = 0; i < L && n < max_sel; ++i)
+                if (fabs(S_room[(size_t)q * n_rooms + room_at(i)] - best) < 1e-3) my_sel[n++] = i;
+            nsel[q] = n;
+        }
+    } else if (m == 2 || m == 3) {
+        // per room: max over its views (np.argmax takes the first maximum; only the value matters here)
+        __shared__ double s_max[1024];
+        __shared__ unsigned char s_taken[1024];
+        const int Lc = min(L, 1024);
+        for (int i = tid; i < Lc; i += 256) {
+            const int r = room_at(i);
+            double mx = -1e308;
+            for (int v = view_off[r]; v < view_off[r + 1]; ++v) mx = fmax(mx, S_view[(size_t)q * n_views + v]);
+            s_max[i] = mx;
+            s_taken[i] = 0;
+            if (view_off[r + 1] == view_off[r]) s_bad = 1;      // np.stack([]) raises
+        }
+        __syncthreads();
+        if (tid == 0) {
+            if (L > 1024) s_bad = 1;
+            const int want = min(Lc, m == 2 ? 5 : 10);
+            int n = 0;
+            for (; n < want && n < max_sel; ++n) {              // selection sort of the top few, first index wins ties
+                int bi = -1;
+                double bv = -1e308;
+                for (int i = 0; i < Lc; ++i)
+                    if (!s_taken[i] && (bi < 0 || s_max[i] > bv)) {
+                        bi = i;
+                        bv = s_max[i];
+                    }
+                s_taken[bi] = 1;
+                my_sel[n] = room_key[room_at(bi)];
+            }
+            nsel[q] = n;
+        }
+    } else if (tid == 0) {
+        int n = 0;
+        for (int i = 0; i < L && n < max_sel; ++i) my_sel[n++] = i;
+        nsel[q] = n;
+    }
+    __syncthreads();
+    // positions of rooms_list -> room ids for the object stage
+    if (tid == 0) {
+        const int n = nsel[q];
+        for (int j = 0; j < max_sel; ++j) {
+            int r = -1;
+            if (j < n) {
+                const int pos = my_sel[j];
+                if (pos < 0 || pos >= L) s_bad = 1;
+                else r = room_at(pos);
+            }
+            q_rooms[(size_t)q * max_sel + j] = r;
+        }
+        err[q] = s_bad;
+    }
+}
+__global__ void k_fill_offsets(int* off, int n, int stride) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n) off[i] = i * stride;
+}
+
 namespace {
 template <typename F>
 int iguard(hmsg_index* ix, F&& fn) {
@@ -306,17 +418,21 @@ bool dev_ptr(const void* p) {
     }
     return a.type == hipMemoryTypeDevice;
 }
-void gemm(hmsg_index* ix, const double* A, int M, double* S) {
-    if (M >= 64 && ix->N >= 64) {
-        const long long tiles = (long long)((M + GT - 1) / GT) * ((ix->N + GT - 1) / GT);
-        ProfScope ps(ix->prof, ix->stream, "k_gemm_f64", 2.0 * (double)M * (double)ix->N * (double)ix->D);
-        hipLaunchKernelGGL(k_gemm_f64_tiled, dim3((unsigned)tiles), dim3(256), 0, ix->stream, A, (const double*)ix->E.p, M, ix->N, ix->D, S);
+// S[M][N] = A[M][D] . B[N][D]^T  (B = the node table unless given)
+void gemm(hmsg_index* ix, const double* A, int M, double* S, const double* B = nullptr, long long N = -1) {
+    if (!B) {
+        B = ix->E.p;
+        N = ix->N;
+    }
+    if (M >= 64 && N >= 64) {
+        const long long tiles = (long long)((M + GT - 1) / GT) * ((N + GT - 1) / GT);
+        ProfScope ps(ix->prof, ix->stream, "k_gemm_f64", 2.0 * (double)M * (double)N * (double)ix->D);
+        hipLaunchKernelGGL(k_gemm_f64_tiled, dim3((unsigned)tiles), dim3(256), 0, ix->stream, A, B, M, N, ix->D, S);
         HMSG_CHECK_LAUNCH();
         return;
     }
-    long long tiles = (long long)((M + 15) / 16) * ((ix->N + 15) / 16);
-    hipLaunchKernelGGL(k_gemm_f64, dim3(cdiv((size_t)tiles, 4)), dim3(256), 0, ix->stream, A, (const double*)ix->E.p, M, ix->N,
-                       ix->D, S);
+    long long tiles = (long long)((M + 15) / 16) * ((N + 15) / 16);
+    hipLaunchKernelGGL(k_gemm_f64, dim3(cdiv((size_t)tiles, 4)), dim3(256), 0, ix->stream, A, B, M, N, ix->D, S);
     HMSG_CHECK_LAUNCH();
 }
 void text_to_f64(hmsg_index* ix, const float* T, size_t n) {
@@ -462,6 +578,129 @@ int hmsg_query_objects(hmsg_index_t* ix, int32_t Q, int32_t C, const float* T, c
         HIP_TRY(hipMemcpyAsync(out_room, ix->d_oroom.p, (size_t)Q * k * 4, hipMemcpyDeviceToHost, ix->stream));
         HIP_TRY(hipMemcpyAsync(out_score, ix->d_oscore.p, (size_t)Q * k * 8, hipMemcpyDeviceToHost, ix->stream));
         HIP_TRY(hipStreamSynchronize(ix->stream));
+    });
+}
+
+int hmsg_index_set_hierarchy(hmsg_index_t* ix, int32_t n_rooms, int32_t n_floors, const int32_t* floor_room_off, const int32_t* floor_rooms,
+                             const double* room_name_emb, const int64_t* view_off, const double* view_emb, const int32_t* room_key) {
+    if (!ix) return HMSG_ERR_INVALID;
+    return iguard(ix, [&] {
+        const int R = n_rooms;                   // (rooms without objects included: >= the largest room id of a node + 1)
+        HMSG_REQUIRE(R >= ix->n_rooms && n_floors >= 0 && (n_floors == 0 || (floor_room_off && floor_rooms)) && view_off && room_key,
+                     HMSG_ERR_INVALID, "hmsg_index_set_hierarchy: bad argument");
+        ix->h_rooms = R;
+        for (int f = 0; f < n_floors; ++f)
+            for (int j = floor_room_off[f]; j < floor_room_off[f + 1]; ++j)
+                HMSG_REQUIRE(floor_rooms[j] >= 0 && floor_rooms[j] < R, HMSG_ERR_INVALID, "hmsg_index_set_hierarchy: room id out of range");
+        const long long NV = view_off[R];
+        HMSG_REQUIRE(NV >= 0 && NV < (1ll << 31) && (NV == 0 || view_emb), HMSG_ERR_INVALID, "hmsg_index_set_hierarchy: bad view table");
+        ix->n_floors = n_floors;
+        ix->n_views = NV;
+        std::vector<int> voff((size_t)R + 1);
+        for (int r = 0; r <= R; ++r) voff[(size_t)r] = (int)view_off[r];
+        ix->view_off.alloc((size_t)R + 1);
+        ix->room_key.alloc((size_t)std::max(R, 1));
+        ix->floor_room_off.alloc((size_t)n_floors + 1);
+        const int nfr = n_floors ? floor_room_off[n_floors] : 0;
+        ix->floor_rooms.alloc((size_t)std::max(nfr, 1));
+        HIP_TRY(hipMemcpyAsync(ix->view_off.p, voff.data(), ((size_t)R + 1) * 4, hipMemcpyHostToDevice, ix->stream));
+        HIP_TRY(hipMemcpyAsync(ix->room_key.p, room_key, (size_t)R * 4, hipMemcpyHostToDevice, ix->stream));
+        std::vector<int> zero(1, 0);
+        HIP_TRY(hipMemcpyAsync(ix->floor_room_off.p, n_floors ? floor_room_off : zero.data(), ((size_t)n_floors + 1) * 4, hipMemcpyHostToDevice, ix->stream));
+        if (nfr) HIP_TRY(hipMemcpyAsync(ix->floor_rooms.p, floor_rooms, (size_t)nfr * 4, hipMemcpyHostToDevice, ix->stream));
+        if (room_name_emb) {
+            ix->room_name_emb.alloc((size_t)std::max(R, 1) * ix->D);
+            HIP_TRY(hipMemcpyAsync(ix->room_name_emb.p, room_name_emb, (size_t)R * ix->D * 8, dev_ptr(room_name_emb) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ix->stream));
+        } else {
+            ix->room_name_emb.release();
+        }
+        ix->view_emb.alloc((size_t)std::max<long long>(NV, 1) * ix->D);
+        if (NV) HIP_TRY(hipMemcpyAsync(ix->view_emb.p, view_emb, (size_t)NV * ix->D * 8, dev_ptr(view_emb) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ix->stream));
+        HIP_TRY(hipStreamSynchronize(ix->stream));
+        ix->have_hier = true;
+    });
+}
+
+int hmsg_query_hier(hmsg_index_t* ix, int32_t Q, int32_t C, const float* T_obj, const int32_t* qid, const float* T_room,
+                    const int32_t* floor_id, const int32_t* room_mode, int32_t k, int32_t use_negatives, int32_t max_rooms,
+                    int32_t* out_sel, int32_t* out_nsel, int32_t* out_idx, int32_t* out_room, double* out_score) {
+    if (!ix) return HMSG_ERR_INVALID;
+    return iguard(ix, [&] {
+        HMSG_REQUIRE(ix->have_hier, HMSG_ERR_INVALID, "hmsg_query_hier: hmsg_index_set_hierarchy first");
+        HMSG_REQUIRE(Q >= 0 && C >= 1 && T_obj && qid && floor_id && room_mode && k >= 1 && max_rooms >= 1 && out_sel && out_nsel && out_idx &&
+                         out_room && out_score,
+                     HMSG_ERR_INVALID, "hmsg_query_hier: bad argument");
+        if (Q == 0) return;
+        const int R = ix->h_rooms;
+        std::vector<int> hm((size_t)Q), hf((size_t)Q);
+        memcpy(hm.data(), room_mode, (size_t)Q * 4);
+        memcpy(hf.data(), floor_id, (size_t)Q * 4);
+        bool need_label = false, need_view = false;
+        for (int q = 0; q < Q; ++q) {
+            HMSG_REQUIRE(hm[q] >= 0 && hm[q] <= 3 && hf[q] >= -1 && hf[q] < ix->n_floors, HMSG_ERR_INVALID, "hmsg_query_hier: bad floor id / room mode");
+            need_label |= hm[q] == 1;
+            need_view |= hm[q] >= 2;
+        }
+        HMSG_REQUIRE(!(need_label || need_view) || T_room, HMSG_ERR_INVALID, "hmsg_query_hier: room text rows missing");
+        HMSG_REQUIRE(!need_label || ix->room_name_emb.p, HMSG_ERR_INVALID, "hmsg_query_hier: label mode without room name embeddings");
+        // room stage: similarities of the room text with the room names / the view embeddings (float64 MFMA GEMM)
+        ix->S_room.ensure((size_t)Q * std::max(R, 1));
+        ix->S_view.ensure((size_t)Q * std::max<long long>(ix->n_views, 1));
+        if (need_label || need_view) {
+            const size_t nT = (size_t)Q * ix->D;
+            ix->Tr64.ensure(nT);
+            const float* src = T_room;
+            if (!dev_ptr(T_room)) {
+                ix->Tr.ensure(nT);
+                HIP_TRY(hipMemcpyAsync(ix->Tr.p, T_room, nT * 4, hipMemcpyHostToDevice, ix->stream));
+                src = ix->Tr.p;
+            }
+            hipLaunchKernelGGL(k_f32_to_f64, dim3(cdiv(nT, 256)), dim3(256), 0, ix->stream, src, ix->Tr64.p, nT);
+            HMSG_CHECK_LAUNCH();
+            if (need_label) gemm(ix, ix->Tr64.p, Q, ix->S_room.p, ix->room_name_emb.p, R);
+            if (need_view && ix->n_views) gemm(ix, ix->Tr64.p, Q, ix->S_view.p, ix->view_emb.p, ix->n_views);
+        }
+        ix->d_floor.ensure(Q);
+        ix->d_mode.ensure(Q);
+        ix->d_sel.ensure((size_t)Q * max_rooms);
+        ix->d_nsel.ensure(Q);
+        ix->d_err.ensure(Q);
+        ix->d_rooms.ensure((size_t)Q * max_rooms);
+        ix->d_roff.ensure((size_t)Q + 1);
+        HIP_TRY(hipMemcpyAsync(ix->d_floor.p, hf.data(), (size_t)Q * 4, hipMemcpyHostToDevice, ix->stream));
+        HIP_TRY(hipMemcpyAsync(ix->d_mode.p, hm.data(), (size_t)Q * 4, hipMemcpyHostToDevice, ix->stream));
+        hipLaunchKernelGGL(k_room_select, dim3(Q), dim3(256), 0, ix->stream, R, ix->n_floors, (const double*)ix->S_room.p,
+                           (const double*)ix->S_view.p, ix->n_views, (const int*)ix->view_off.p, (const int*)ix->room_key.p,
+                           (const int*)ix->floor_room_off.p, (const int*)ix->floor_rooms.p, (const int*)ix->d_floor.p,
+                           (const int*)ix->d_mode.p, max_rooms, ix->d_sel.p, ix->d_nsel.p, ix->d_rooms.p, ix->d_err.p);
+        hipLaunchKernelGGL(k_fill_offsets, dim3(cdiv((size_t)Q + 1, 256)), dim3(256), 0, ix->stream, ix->d_roff.p, Q, max_rooms);
+        HMSG_CHECK_LAUNCH();
+        // object stage on the rooms the room stage picked, in that order
+        const size_t nT = (size_t)Q * C * ix->D;
+        text_to_f64(ix, T_obj, nT);
+        ix->S.ensure((size_t)Q * C * ix->N);
+        gemm(ix, ix->T64.p, Q * C, ix->S.p);
+        ix->d_qid.ensure(Q);
+        ix->d_oidx.ensure((size_t)Q * k);
+        ix->d_oroom.ensure((size_t)Q * k);
+        ix->d_oscore.ensure((size_t)Q * k);
+        HIP_TRY(hipMemcpyAsync(ix->d_qid.p, qid, (size_t)Q * 4, dev_ptr(qid) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ix->stream));
+        hipLaunchKernelGGL(k_query_topk, dim3(Q), dim3(256), 0, ix->stream, (const double*)ix->S.p, ix->N, C, (const int*)ix->d_qid.p,
+                           (const int*)ix->d_roff.p, (const int*)ix->d_rooms.p, (const int*)ix->room_off.p,
+                           (const int*)ix->room_nodes.p, ix->n_rooms, k, use_negatives, ix->d_oidx.p, ix->d_oroom.p, ix->d_oscore.p);
+        HMSG_CHECK_LAUNCH();
+        std::vector<int> herr((size_t)Q);
+        HIP_TRY(hipMemcpyAsync(out_sel, ix->d_sel.p, (size_t)Q * max_rooms * 4, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(hipMemcpyAsync(out_nsel, ix->d_nsel.p, (size_t)Q * 4, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(hipMemcpyAsync(herr.data(), ix->d_err.p, (size_t)Q * 4, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(hipMemcpyAsync(out_idx, ix->d_oidx.p, (size_t)Q * k * 4, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(hipMemcpyAsync(out_room, ix->d_oroom.p, (size_t)Q * k * 4, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(hipMemcpyAsync(out_score, ix->d_oscore.p, (size_t)Q * k * 8, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(hipStreamSynchronize(ix->stream));
+        for (int q = 0; q < Q; ++q)
+            HMSG_REQUIRE(!herr[(size_t)q], HMSG_ERR_INVALID,
+                         "hmsg_query_hier: a query's room stage failed like the reference would (a room without view embeddings, or a "
+                         "view-mode room number that is no position of the floor's room list)");
     });
 }
 

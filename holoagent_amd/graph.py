@@ -1081,15 +1081,61 @@ class Graph:
         if icra and room_q and "Exhibition" in room_q:
             negatives = ["wall"]
         floor_id = self.query_floor(floor_q) if floor_q is not None else -1
-        room_ids = self.query_hmsg_room(room_q, floor_id=floor_id, query_method="label") if room_q is not None else []
-        obj_ids, room_ids2, scores = self.query_hmsg_object(obj_q, floor_id=floor_id, room_ids=room_ids, top_k=top_k,
-                                                            negative_prompt=negatives) if obj_q is not None else ([], [], [])
+        if room_q is not None and obj_q is not None:
+            # room stage + object stage on the device in one call (include/hmsg.h: hmsg_query_hier)
+            (room_ids, obj_ids, room_ids2, scores), = self.query_hierarchy_batch([(floor_id, room_q, obj_q, negatives)], top_k)
+        else:
+            room_ids = self.query_hmsg_room(room_q, floor_id=floor_id, query_method="label") if room_q is not None else []
+            obj_ids, room_ids2, scores = self.query_hmsg_object(obj_q, floor_id=floor_id, room_ids=room_ids, top_k=top_k,
+                                                                negative_prompt=negatives) if obj_q is not None else ([], [], [])
         res = dict(room_query=room_q, object_query=obj_q, negative_labels=negatives, object_scores=scores)
         if icra:
             res.update(LLM_Parse_Time=llm_parse_time, FastMatching=0.0, ObjectInImageCheck=0.0, VLM_Rethinking=0.0,
                        Re_Matching=0.0, Total_Time=0.0)
         rooms = [self.floors[floor_id].rooms[k] for k in room_ids2] if floor_id != -1 else [self.rooms[k] for k in room_ids2]
         return (self.floors[floor_id] if floor_id != -1 else None, rooms, [self.objects[i] for i in obj_ids], res)
+
+    def _hier_index(self):
+        """the node index with the levels above it resident (room name / view embeddings, floors -> rooms)"""
+        ix = self._node_index()
+        if not getattr(self, "_hier_ready", False):
+            gl = {r.room_id: i for i, r in enumerate(self.rooms)}
+            named = all(getattr(r, "name", None) is not None for r in self.rooms)
+            names = self.get_text_feats_multiple_templates([r.name for r in self.rooms]) if named and self.rooms else None
+            views = [np.stack(r.embeddings) if len(getattr(r, "embeddings", []) or []) else np.zeros((0, ix.D)) for r in self.rooms]
+            ix.set_hierarchy([[gl[r.room_id] for r in f.rooms] for f in self.floors], names, views,
+                             [int(str(r.room_id).split("_")[-1]) for r in self.rooms])
+            self._hier_ready = True
+        return ix
+
+    def query_hierarchy_batch(self, queries, top_k=1):
+        """queries: (floor_id, room_query, object_query, negative_prompt) tuples -> per query (room numbers as
+        query_hmsg_room(..., "label") returns them, object indices, their room numbers, scores) -- graph.py:3538-3568 for a
+        whole batch, floor -> room -> object on the device.  Queries are grouped by the number of text rows."""
+        ix = self._hier_index()
+        out = [None] * len(queries)
+        groups = {}
+        for n, (floor_id, room_q, obj_q, negs) in enumerate(queries):
+            if obj_q in negs:
+                qid, cats = negs.index(obj_q), list(negs)
+            else:
+                qid, cats = 0, [obj_q, *negs]
+            groups.setdefault((len(cats), len(negs) > 0), []).append((n, floor_id, room_q, qid, cats))
+        for (_, use_neg), items in groups.items():
+            T = np.stack([self.get_text_feats_multiple_templates(cats) for _, _, _, _, cats in items])
+            Tr = np.stack([self.get_text_feats_multiple_templates([room_q])[0] for _, _, room_q, _, _ in items])
+            fl = np.array([f for _, f, _, _, _ in items], np.int32)
+            valid = [rq is not None and rq != "" and "unknown" not in rq.lower() for _, _, rq, _, _ in items]
+            mode = np.array([1 if v else 3 for v in valid], np.int32)       # an invalid room text falls into the view branch (top 10)
+            sel, idx, room, score = ix.query_hier(T, np.array([q for _, _, _, q, _ in items], np.int32), Tr, fl, mode, top_k,
+                                                  use_negatives=use_neg)
+            for j, (n, floor_id, _, _, _) in enumerate(items):
+                rooms_list = list(range(len(self.rooms))) if floor_id == -1 else \
+                    [next(i for i, r in enumerate(self.rooms) if r.room_id == fr.room_id) for fr in self.floors[floor_id].rooms]
+                back = {rooms_list[p]: p for p in sel[j]}
+                keep = idx[j] >= 0
+                out[n] = (sel[j], [int(i) for i in idx[j][keep]], [back[int(r)] for r in room[j][keep]], [float(v) for v in score[j][keep]])
+        return out
 
     def query_hierarchy_protected_icra(self, query_instruction, top_k=1, use_gpt=False):
         """graph.py:3483-3591: negatives ["background"] (["wall"] for an "Exhibition" room); `query_instruction` is the

@@ -318,6 +318,29 @@ int hmsg_index_profile(hmsg_index_t* ix, int64_t* launches, double* total_ms, do
 int hmsg_query_objects(hmsg_index_t* ix, int32_t Q, int32_t C, const float* T, const int32_t* qid,
                        const int32_t* room_off, const int32_t* rooms, int32_t k, int32_t use_negatives,
                        int32_t* out_idx, int32_t* out_room, double* out_score);
+/* ---- the coarse-to-fine query behind the drivers query_hierarchy_protected{,_icra} (graph.py:3483-3716): floor ->
+ * room(s) -> objects, batched, every stage on the device.
+ *   hmsg_index_set_hierarchy  makes the levels above the nodes resident: n_rooms rooms (rooms without objects count), the rooms of every floor in floors[f].rooms
+ *        order (CSR floor_room_off [n_floors + 1] / floor_rooms; room ids as in room_of_node, where self.rooms order =
+ *        ascending id), per room the CLIP embedding of its NAME (room_name_emb f64 [R][D]; NULL: no label mode), its
+ *        view embeddings room.embeddings (CSR view_off i64 [R + 1] / view_emb f64 [NV][D]) and room_key[r] =
+ *        int(room_id.split("_")[-1]), the number the view mode reports (graph.py:3254-3262).
+ *   hmsg_query_hier  per query: floor_id (-1 = all rooms; resolve query_floor :2216-2257 on the host or with
+ *        hmsg_similarity), the room text row T_room[q][D] and room_mode[q]:
+ *          0  no room stage: every room of the floor's list;
+ *          1  query_hmsg_room(..., "label") (:3204-3232): rooms whose name similarity is within 1e-3 of the best;
+ *          2 / 3  the view-embedding branch (:3247-3272): the 5 (valid room text) / 10 best rooms by their best view;
+ *        then query_hmsg_object (:3056-3162) over those rooms IN THAT ORDER with the C text rows T_obj[q] (row qid[q] the
+ *        query, the others negative prompts).  out_sel [Q][max_rooms] / out_nsel [Q]: the numbers query_hmsg_room
+ *        returns (positions in the floor's room list; in view mode the room keys, which the reference then uses AS
+ *        positions); out_idx / out_room / out_score [Q][k] as hmsg_query_objects (room = global room id).
+ *        HMSG_ERR_INVALID where the reference raises (a room without view embeddings in view mode; a key that is no
+ *        position of the list). */
+int hmsg_index_set_hierarchy(hmsg_index_t* ix, int32_t n_rooms, int32_t n_floors, const int32_t* floor_room_off, const int32_t* floor_rooms,
+                             const double* room_name_emb, const int64_t* view_off, const double* view_emb, const int32_t* room_key);
+int hmsg_query_hier(hmsg_index_t* ix, int32_t Q, int32_t C, const float* T_obj, const int32_t* qid, const float* T_room,
+                    const int32_t* floor_id, const int32_t* room_mode, int32_t k, int32_t use_negatives, int32_t max_rooms,
+                    int32_t* out_sel, int32_t* out_nsel, int32_t* out_idx, int32_t* out_room, double* out_score);
 /* plain similarity S[Q][N] = T[Q][D] . E[N][D]^T in float64 (query_floor / query_hmsg_room GEMV) */
 int hmsg_similarity(hmsg_index_t* ix, int32_t Q, const float* T, double* S);
 

@@ -213,6 +213,35 @@ def check_query_golden(L):
     idx, room, score = ix.query_objects(T, np.array([1], np.int32), [list(range(R))], k)
     assert [int(v) for v in idx[0] if v >= 0] == [int(v) for v in z["ref_neg_idx"]]
     np.testing.assert_allclose(score[0][: len(z["ref_neg_score"])], z["ref_neg_score"], rtol=0, atol=1e-12)
+    # the whole coarse-to-fine query on the device (hmsg_query_hier): floors -> rooms (label mode: the reference's own
+    # query_hmsg_room results; view mode likewise) -> objects, against the same reference-made fixture
+    room_name_emb = np.stack([table[str(n)] for n in z["room_name"]]).astype(np.float64)
+    voff = z["room_view_off"]
+    views = [z["room_view_emb"][voff[r]:voff[r + 1]] for r in range(R)]
+    keys, cnt = [], {0: 0, 1: 0}
+    for r in range(R):                                       # room_id = "<floor>_<position on the floor>"
+        keys.append(cnt[int(room_floor[r])])
+        cnt[int(room_floor[r])] += 1
+    ix.set_hierarchy([floor_rooms[0], floor_rooms[1]], room_name_emb, views, keys)
+    for nneg in (1, 2):
+        qs = [i for i, s in enumerate(z["qspec"]) if s[3] == nneg]
+        negs = ["background"] if nneg == 1 else ["background", "wall"]
+        T = np.stack([np.stack([table["thing%d" % z["qspec"][qi][0]]] + [table[n] for n in negs]) for qi in qs])
+        Tr = np.stack([table["room%d" % z["qspec"][qi][1]] for qi in qs])
+        fl = np.array([z["qspec"][qi][2] for qi in qs], np.int32)
+        rooms_sel, idx, room, score = ix.query_hier(T, np.zeros(len(qs), np.int32), Tr, fl, np.ones(len(qs), np.int32), k)
+        for j, qi in enumerate(qs):
+            assert rooms_sel[j] == [int(v) for v in z["ref_rooms_label"][qi] if v >= 0], (qi, rooms_sel[j])
+            ref = [int(v) for v in z["ref_obj_idx"][qi] if v >= 0]
+            assert [int(v) for v in idx[j] if v >= 0] == ref, (qi, idx[j], ref)
+            np.testing.assert_allclose(score[j][: len(ref)], z["ref_obj_score"][qi][: len(ref)], rtol=0, atol=1e-12)
+            rooms_list = list(range(R)) if fl[j] == -1 else floor_rooms[int(fl[j])]
+            assert [int(v) for v in room[j][: len(ref)]] == [rooms_list[int(v)] for v in z["ref_obj_room"][qi] if v >= 0]
+        # the view-embedding branch of query_hmsg_room (top 5 room keys by their best view)
+        ok = [j for j, qi in enumerate(qs) if fl[j] != -1]       # (with floor -1 the keys are no positions: the reference's quirk)
+        rooms_v, _, _, _ = ix.query_hier(T[ok], np.zeros(len(ok), np.int32), Tr[ok], fl[ok], np.full(len(ok), 2, np.int32), k)
+        for jj, j in enumerate(ok):
+            assert rooms_v[jj] == [int(v) for v in z["ref_rooms_view"][qs[j]] if v >= 0][:5], (qs[j], rooms_v[jj])
     # plain similarity (query_floor / query_hmsg_room GEMV)
     S = ix.similarity(np.stack([table["thing3"], table["room1"]]))
     np.testing.assert_allclose(S, np.dot(np.stack([table["thing3"], table["room1"]]), obj_emb.T), rtol=0, atol=1e-12)
