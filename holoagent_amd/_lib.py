@@ -98,6 +98,7 @@ _SIGS = {
     "hmsg_num_nodes": (C.c_int64, [_P]),
     "hmsg_get_nodes": (C.c_int, [_P, _P, _P]),
     "hmsg_index_from_nodes": (C.c_int, [_P, C.POINTER(_P)]),
+    "hmsg_room_clouds": (C.c_int, [_P, C.c_double, C.c_double, _P, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "hmsg_points_min_dist_2d": (C.c_int, [C.c_int32, C.c_int32, _P, _P, C.c_int64, _P, _P]),
     "hmsg_lidar_depth": (C.c_int, [C.c_int32, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "hmsg_crop_resize_batch": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, C.c_double, C.c_int32, _P, _P, _P]),
@@ -415,6 +416,23 @@ class Scene:
             a.view_ids_json = json.dumps([plain(v) for v in r["view_ids"]]).encode()
             a.best_view_id_json = json.dumps(plain(r["best_view_id"])).encode()
         self._ck(self.L.c.hmsg_save_objects(self.h, str(directory).encode(), n, C.cast(arr, _P), int(n_threads)))
+
+    def room_clouds(self, y_lo, y_hi, T, z_levels, room_xz):
+        """segment_hmsg_room's room clouds on the device (include/hmsg.h: hmsg_room_clouds): room_xz = list of [n, 2] arrays;
+        returns (per room the ascending indices into the floor cloud, size of the floor cloud)."""
+        T = np.ascontiguousarray(T, np.float64).reshape(16)
+        z = np.ascontiguousarray(z_levels, np.float64).reshape(-1)
+        off = np.zeros(len(room_xz) + 1, np.int64)
+        off[1:] = np.cumsum([len(r) for r in room_xz])
+        xz = np.ascontiguousarray(np.concatenate([np.asarray(r, np.float64).reshape(-1, 2) for r in room_xz]) if off[-1] else np.zeros((0, 2)))
+        sizes = np.zeros(len(room_xz), np.int64)
+        nf = C.c_int64(0)
+        cap = int(len(room_xz)) * max(int(self.map_size()), 1)
+        out = np.empty(cap, np.int32)
+        self._ck(self.L.c.hmsg_room_clouds(self.h, float(y_lo), float(y_hi), _ptr(T), len(z), _ptr(z), len(room_xz), _ptr(off), _ptr(xz),
+                                           _ptr(sizes), _ptr(out), cap, C.byref(nf)))
+        o = np.concatenate([[0], np.cumsum(sizes)])
+        return [out[o[r]:o[r + 1]].copy() for r in range(len(room_xz))], int(nf.value)
 
     def index_from_nodes(self):
         """Resident retrieval index over the node table, gathered on the device."""

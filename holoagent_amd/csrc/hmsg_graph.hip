@@ -10,6 +10,8 @@
 // label = arg-max over the label text features of emb . text^T (identify_object, :1441-1454, float64 MFMA GEMM);
 // object id = (room, running counter of that room) (:1696-1700).
 #include "hmsg_common.h"
+#include "hmsg_nn.h"
+#include "hmsg_ckdtree.h"
 
 #include <cmath>
 
@@ -179,3 +181,162 @@ int hmsg_index_from_nodes(hmsg_t* h, hmsg_index_t** out) {
 }
 
 }  // extern "C"
+
+
+// ------------------------------------------------------------------------------------------ A9: room clouds
+// segment_hmsg_room (graph.py:1086-1108): the (x, z) cell centres of a room's 2-D region are extruded over the storey's
+// height in 5 cm steps, turned into the map frame (pcd.transform(T1), T1 = Rotation.from_euler("x", 90) as scipy
+// gives it: cos(90 deg) is 6.1e-17 there, not 0, so the matrix comes from the caller) and each of those points picks its
+// nearest neighbour in the FLOOR cloud = full_pcd.crop(y in [y_lo, y_hi]) (:769-775; cKDTree.query(k = 1), "very slow"
+// says the reference's comment: 10^5..10^6 queries per room); the room cloud is floor_pcd.select_by_index(idx): the
+// picked points, each once, in the floor cloud's order.  Device: a thread per extruded point, exact nearest neighbour
+// among the map points of the storey (ring expansion over the map's occupancy grid, hmsg_nn.h); queries whose two
+// nearest candidates are at BIT-EQUAL distance go to the host, which replays scipy's cKDTree built over the floor cloud.
+struct RoomTie {
+    int room;
+    double x, y, z;
+};
+__global__ void k_floor_mask(const double* __restrict__ pts, long long V, double y_lo, double y_hi, unsigned char* __restrict__ ok,
+                             unsigned* __restrict__ okw) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V) return;
+    const double y = pts[i * 3 + 1];
+    const bool in = y >= y_lo && y <= y_hi;                  // Open3D crop: both bounds inclusive
+    ok[i] = in ? 1 : 0;
+    okw[i] = in ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256) k_room_nn(NNIndex I, const unsigned char* __restrict__ ok, const unsigned* __restrict__ floor_rank,
+                                                 long long NF, const double* __restrict__ T, int n_levels, const double* __restrict__ z_levels,
+                                                 int n_rooms, const long long* __restrict__ room_off, const double* __restrict__ room_xz,
+                                                 unsigned char* __restrict__ mark, unsigned* __restrict__ n_ties, RoomTie* __restrict__ ties,
+                                                 unsigned tie_cap) {
+    const long long total_cells = room_off[n_rooms];
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= total_cells * n_levels) return;
+    // extruded points are laid out level by level (np.concatenate over z_levels, :1094-1098): order is irrelevant here
+    const long long cell = q % total_cells;
+    const int lvl = (int)(q / total_cells);
+    int lo = 0, hi = n_rooms - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (room_off[mid] <= cell) lo = mid; else hi = mid - 1;
+    }
+    const double X = room_xz[cell * 2], Y = room_xz[cell * 2 + 1], Z = z_levels[lvl];
+    // Open3D transform: ((X*T0 + Y*T1) + Z*T2) + T3 per row, divided by the homogeneous row; no FMA
+    double r[4];
+    for (int k = 0; k < 4; ++k)
+        r[k] = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(X, T[k * 4]), __dmul_rn(Y, T[k * 4 + 1])), __dmul_rn(Z, T[k * 4 + 2])), T[k * 4 + 3]);
+    const double px = __ddiv_rn(r[0], r[3]), py = __ddiv_rn(r[1], r[3]), pz = __ddiv_rn(r[2], r[3]);
+    int ntie = 0;
+    const int idx = nn_search_subset(I, ok, px, py, pz, &ntie);
+    if (idx < 0) return;
+    if (ntie > 1) {
+        const unsigned k = atomicAdd(n_ties, 1u);
+        if (k < tie_cap) ties[k] = RoomTie{lo, px, py, pz};
+        return;
+    }
+    mark[(size_t)lo * NF + floor_rank[idx]] = 1;
+}
+
+extern "C" int hmsg_room_clouds(hmsg_t* h, double y_lo, double y_hi, const double* T, int32_t n_levels, const double* z_levels,
+                                int32_t n_rooms, const int64_t* room_off, const double* room_xz, int64_t* out_sizes,
+                                int32_t* out_index, int64_t out_capacity, int64_t* n_floor_points) {
+    if (!h) return HMSG_ERR_INVALID;
+    try {
+        HIP_TRY(hipSetDevice(h->cfg.device_id));
+        HMSG_REQUIRE(h->map_ready && T && n_levels >= 0 && (n_levels == 0 || z_levels) && n_rooms >= 0 && room_off && out_sizes && n_floor_points,
+                     HMSG_ERR_INVALID, "hmsg_room_clouds: bad argument (finalize the map first)");
+        hipStream_t s = h->stream;
+        const long long V = h->V, cells = room_off[n_rooms];
+        HMSG_REQUIRE(cells == 0 || room_xz, HMSG_ERR_INVALID, "hmsg_room_clouds: room points missing");
+        DevBuf<unsigned char> ok;
+        DevBuf<unsigned> okw, frank;
+        ok.alloc((size_t)std::max<long long>(V, 1));
+        okw.alloc((size_t)std::max<long long>(V, 1));
+        frank.alloc((size_t)std::max<long long>(V, 1));
+        unsigned long long NFu = 0;
+        if (V) {
+            hipLaunchKernelGGL(k_floor_mask, dim3(cdiv((size_t)V, 256)), dim3(256), 0, s, (const double*)h->pts.p, V, y_lo, y_hi, ok.p, okw.p);
+            HMSG_CHECK_LAUNCH();
+            hmsg_scan_u32(okw.p, frank.p, (size_t)V, s, h->scan_tmp, &NFu);
+        }
+        const long long NF = (long long)NFu;
+        *n_floor_points = NF;
+        for (int r = 0; r < n_rooms; ++r) out_sizes[r] = 0;
+        if (NF == 0 || cells == 0 || n_levels == 0 || n_rooms == 0) return HMSG_OK;
+        HMSG_REQUIRE((long long)n_rooms * NF < (1ll << 33), HMSG_ERR_UNSUPPORTED, "hmsg_room_clouds: too many rooms x floor points");
+        DevBuf<double> dT, dz, dxz;
+        DevBuf<long long> doff;
+        DevBuf<unsigned char> mark;
+        DevBuf<unsigned> nt;
+        DevBuf<RoomTie> ties;
+        const unsigned tie_cap = 1u << 20;
+        dT.alloc(16);
+        dz.alloc((size_t)n_levels);
+        dxz.alloc((size_t)cells * 2);
+        doff.alloc((size_t)n_rooms + 1);
+        mark.alloc((size_t)n_rooms * NF);
+        nt.alloc(1);
+        ties.alloc(tie_cap);
+        std::vector<long long> hoff((size_t)n_rooms + 1);
+        for (int r = 0; r <= n_rooms; ++r) hoff[(size_t)r] = room_off[r];
+        HIP_TRY(hipMemcpyAsync(dT.p, T, 128, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(dz.p, z_levels, (size_t)n_levels * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(dxz.p, room_xz, (size_t)cells * 16, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(doff.p, hoff.data(), hoff.size() * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemsetAsync(mark.p, 0, (size_t)n_rooms * NF, s));
+        HIP_TRY(hipMemsetAsync(nt.p, 0, 4, s));
+        NNIndex I = hmsg_nn_index(h);
+        const long long nq = cells * n_levels;
+        hipLaunchKernelGGL(k_room_nn, dim3(cdiv((size_t)nq, 256)), dim3(256), 0, s, I, (const unsigned char*)ok.p, (const unsigned*)frank.p, NF,
+                           (const double*)dT.p, n_levels, (const double*)dz.p, n_rooms, (const long long*)doff.p, (const double*)dxz.p, mark.p, nt.p,
+                           ties.p, tie_cap);
+        HMSG_CHECK_LAUNCH();
+        std::vector<unsigned char> hmark((size_t)n_rooms * NF);
+        unsigned n_t = 0;
+        HIP_TRY(hipMemcpyAsync(hmark.data(), mark.p, hmark.size(), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(&n_t, nt.p, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        HMSG_REQUIRE(n_t <= tie_cap, HMSG_ERR_UNSUPPORTED, "hmsg_room_clouds: more than 2^20 bit-equal nearest-neighbour ties");
+        if (n_t) {
+            // scipy's answer for the tied queries: the restated cKDTree over the floor cloud (crop order)
+            hmsg_kd_join(h);
+            std::vector<double> fpts((size_t)NF * 3);
+            {
+                std::vector<unsigned char> hok((size_t)V);
+                HIP_TRY(hipMemcpy(hok.data(), ok.p, (size_t)V, hipMemcpyDeviceToHost));
+                size_t k = 0;
+                for (long long i = 0; i < V; ++i)
+                    if (hok[(size_t)i]) {
+                        for (int a = 0; a < 3; ++a) fpts[k * 3 + a] = h->host_pts[(size_t)i * 3 + a];
+                        ++k;
+                    }
+            }
+            CKDTree tree;
+            tree.build(fpts.data(), NF);
+            std::vector<RoomTie> ht(n_t);
+            HIP_TRY(hipMemcpy(ht.data(), ties.p, (size_t)n_t * sizeof(RoomTie), hipMemcpyDeviceToHost));
+            for (auto& t : ht) {
+                const double x[3] = {t.x, t.y, t.z};
+                hmark[(size_t)t.room * NF + (size_t)tree.query1(x)] = 1;
+            }
+            h->n_tie_queries += n_t;
+        }
+        long long total = 0;
+        for (int r = 0; r < n_rooms; ++r) {
+            long long n = 0;
+            for (long long i = 0; i < NF; ++i)
+                if (hmark[(size_t)r * NF + i]) {
+                    if (out_index && total + n < out_capacity) out_index[total + n] = (int32_t)i;
+                    ++n;
+                }
+            out_sizes[r] = n;
+            total += n;
+        }
+        HMSG_REQUIRE(!out_index || total <= out_capacity, HMSG_ERR_INVALID, "hmsg_room_clouds: out_index too small (sum of out_sizes needed)");
+        return HMSG_OK;
+    } catch (const hmsg_error& e) {
+        h->err = e.msg;
+        return e.code;
+    }
+}

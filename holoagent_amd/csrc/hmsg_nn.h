@@ -63,9 +63,12 @@ __device__ __forceinline__ double nn_dist2(const double* __restrict__ p, double 
     return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
 }
 
+// `ok` (optional, one byte per cloud point): only points with ok[q] != 0 take part (nearest neighbour inside a SUBSET of
+// the cloud, e.g. one storey: graph.py:769-775 crops the floor cloud from the map, :1105 searches in it)
 __device__ __forceinline__ void nn_column(const GridGeom& g, const unsigned long long* __restrict__ bitmap,
                                           const unsigned* __restrict__ rank, const double* __restrict__ pts, int ix, int iy,
-                                          int z0, int z1, double qx, double qy, double qz, NNBest& best) {
+                                          int z0, int z1, double qx, double qy, double qz, NNBest& best,
+                                          const unsigned char* __restrict__ ok = nullptr) {
     if (ix < 0 || iy < 0 || ix >= g.nx || iy >= g.ny) return;
     z0 = z0 < 0 ? 0 : z0;
     z1 = z1 >= g.nz ? g.nz - 1 : z1;
@@ -84,6 +87,7 @@ __device__ __forceinline__ void nn_column(const GridGeom& g, const unsigned long
             int b = __ffsll(sel) - 1;
             sel &= sel - 1;
             int q = (int)(base + (unsigned)__popcll(word & ((1ull << b) - 1ull)));
+            if (ok && !ok[q]) continue;
             nn_consider(best, q, nn_dist2(pts + (size_t)q * 3, qx, qy, qz));
         }
     }
@@ -92,22 +96,23 @@ __device__ __forceinline__ void nn_column(const GridGeom& g, const unsigned long
 // Ring expansion.  After ring r every cell of the cube [c-r, c+r]^3 has been examined; a point outside the
 // cube is at least `m` away, m = distance from q to the nearest cube face that still has cells beyond it,
 // so the search stops once best < m.
-__device__ inline void nn_rings(const NNIndex& I, int cx, int cy, int cz, double qx, double qy, double qz, NNBest& best) {
+__device__ inline void nn_rings(const NNIndex& I, int cx, int cy, int cz, double qx, double qy, double qz, NNBest& best,
+                                const unsigned char* __restrict__ ok = nullptr) {
     const GridGeom& g = I.g;
     const int rmax = max(g.nx, max(g.ny, g.nz));
     for (int r = 1; r <= rmax; ++r) {
         if (r == 1) {
             for (int dx = -1; dx <= 1; ++dx)
-                for (int dy = -1; dy <= 1; ++dy) nn_column(g, I.bitmap, I.rank, I.pts, cx + dx, cy + dy, cz - 1, cz + 1, qx, qy, qz, best);
+                for (int dy = -1; dy <= 1; ++dy) nn_column(g, I.bitmap, I.rank, I.pts, cx + dx, cy + dy, cz - 1, cz + 1, qx, qy, qz, best, ok);
         } else {
             for (int dx = -r; dx <= r; ++dx)
                 for (int dy = -r; dy <= r; ++dy) {
                     bool rim = (dx == -r || dx == r || dy == -r || dy == r);
                     if (rim) {
-                        nn_column(g, I.bitmap, I.rank, I.pts, cx + dx, cy + dy, cz - r, cz + r, qx, qy, qz, best);
+                        nn_column(g, I.bitmap, I.rank, I.pts, cx + dx, cy + dy, cz - r, cz + r, qx, qy, qz, best, ok);
                     } else {
-                        nn_column(g, I.bitmap, I.rank, I.pts, cx + dx, cy + dy, cz - r, cz - r, qx, qy, qz, best);
-                        nn_column(g, I.bitmap, I.rank, I.pts, cx + dx, cy + dy, cz + r, cz + r, qx, qy, qz, best);
+                        nn_column(g, I.bitmap, I.rank, I.pts, cx + dx, cy + dy, cz - r, cz - r, qx, qy, qz, best, ok);
+                        nn_column(g, I.bitmap, I.rank, I.pts, cx + dx, cy + dy, cz + r, cz + r, qx, qy, qz, best, ok);
                     }
                 }
         }
@@ -123,6 +128,22 @@ __device__ inline void nn_rings(const NNIndex& I, int cx, int cy, int cz, double
         m -= 1e-9;   // centroids sit inside their cell only up to rounding
         if (best.idx >= 0 && m > 0.0 && best.d2 < m * m) break;
     }
+}
+
+// nearest neighbour among the points with ok[q] != 0 (ring expansion only: the candidate lists of deleted voxels are
+// exact for the WHOLE cloud, not for a subset)
+__device__ inline int nn_search_subset(const NNIndex& I, const unsigned char* __restrict__ ok, double qx, double qy, double qz,
+                                       int* out_ntie) {
+    const GridGeom& g = I.g;
+    int cx, cy, cz;
+    cell_of(g, qx, qy, qz, cx, cy, cz);
+    NNBest best{1e300, -1, 0};
+    cx = cx < 0 ? 0 : (cx >= g.nx ? g.nx - 1 : cx);
+    cy = cy < 0 ? 0 : (cy >= g.ny ? g.ny - 1 : cy);
+    cz = cz < 0 ? 0 : (cz >= g.nz ? g.nz - 1 : cz);
+    nn_rings(I, cx, cy, cz, qx, qy, qz, best, ok);
+    if (out_ntie) *out_ntie = best.ntie;
+    return best.idx;
 }
 
 __device__ inline int nn_search(const NNIndex& I, double qx, double qy, double qz, double* out_d2 = nullptr,

@@ -133,11 +133,11 @@ extern "C" int hmsg_save_objects(hmsg_t* hc, const char* dir, int64_t n, const h
                 const long long a = h->inst.off[(size_t)r.instance], b = h->inst.off[(size_t)r.instance + 1];
                 const double* P = pts.data() + a * 3;
                 const long long np = b - a;
-                // ---- <stem>.ply: binary little-endian, double x y z (a colourless Open3D cloud)
-                char hdr[160];
+                // ---- <stem>.ply: binary little-endian, double x y z (a colourless Open3D cloud, Open3D's header comment line)
+                char hdr[200];
                 const int hl = snprintf(hdr, sizeof(hdr),
-                                        "ply\nformat binary_little_endian 1.0\nelement vertex %lld\nproperty double x\nproperty double y\n"
-                                        "property double z\nend_header\n", np);
+                                        "ply\nformat binary_little_endian 1.0\ncomment Created by Open3D\nelement vertex %lld\nproperty double x\n"
+                                        "property double y\nproperty double z\nend_header\n", np);
                 ply.resize((size_t)hl + (size_t)np * 24);
                 memcpy(ply.data(), hdr, (size_t)hl);
                 if (np) memcpy(ply.data() + hl, P, (size_t)np * 24);

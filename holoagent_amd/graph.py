@@ -105,8 +105,9 @@ class _LazyPcd:
 def _write_ply(path, pts):
     pts = np.asarray(pts, dtype=np.float64).reshape(-1, 3)
     with open(path, "wb") as f:
-        f.write(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty double x\nproperty double y\n"
-                 "property double z\nend_header\n" % len(pts)).encode())
+        # (header as Open3D 0.18's write_point_cloud emits it for a cloud without colours / normals, comment line included)
+        f.write(("ply\nformat binary_little_endian 1.0\ncomment Created by Open3D\nelement vertex %d\nproperty double x\n"
+                 "property double y\nproperty double z\nend_header\n" % len(pts)).encode())
         f.write(pts.astype("<f8").tobytes())
 
 
@@ -587,6 +588,7 @@ class Graph:
             fl = Floor(str(i), name="floor_" + str(i))
             sel = pts[(yf >= lo) & (yf <= hi)]
             fl.pcd = _Pcd(sel)
+            fl._crop = (float(lo), float(hi))     # the slab of the map this cloud is (room clouds on the device: hmsg_room_clouds)
             if len(sel):
                 mn, mx = sel.min(0), sel.max(0)
                 ex = mx - mn     # Open3D AABB corner order
@@ -621,15 +623,22 @@ class Graph:
         with get_img_feats; they are the F_g the per-pixel stage already received, so loop B keeps them)."""
         self._view_feats = [np.asarray(f, np.float32).reshape(1, -1) for f in feats]
 
-    def _room_cloud(self, floor, floor_tree, room_m):
-        """graph.py:1086-1108: extrude the room's 2-D points over the floor's height in 5 cm steps, rotate into the map
-        frame (90 degrees about x, as scipy's Rotation gives it) and pick the floor points nearest to them."""
+    @staticmethod
+    def _room_extrusion(floor):
+        """graph.py:1088-1103: the z levels of the extrusion (5 cm steps over the storey, negated) and T1 = the 90 degree turn
+        about x as scipy's Rotation gives it (cos(90 deg) = 6.1e-17, not 0)."""
         from scipy.spatial.transform import Rotation
         z_levels = np.arange(floor.floor_zero_level, floor.floor_zero_level + floor.floor_height, 0.05).reshape(-1, 1)
         z_levels *= -1
-        room_m3d = np.concatenate([np.hstack((room_m, np.ones((room_m.shape[0], 1)) * z)) for z in z_levels], axis=0)
         T1 = np.eye(4)
         T1[:3, :3] = Rotation.from_euler("x", 90, degrees=True).as_matrix()
+        return z_levels, T1
+
+    def _room_cloud(self, floor, floor_tree, room_m):
+        """graph.py:1086-1108 on the host (a Graph without a resident scene): extrude the room's 2-D points over the floor's
+        height in 5 cm steps, rotate into the map frame and pick the floor points nearest to them."""
+        z_levels, T1 = self._room_extrusion(floor)
+        room_m3d = np.concatenate([np.hstack((room_m, np.ones((room_m.shape[0], 1)) * z)) for z in z_levels], axis=0)
         X, Y, Z = room_m3d[:, 0], room_m3d[:, 1], room_m3d[:, 2]
         rows = [((X * T1[r, 0] + Y * T1[r, 1]) + Z * T1[r, 2]) + T1[r, 3] for r in range(4)]      # Open3D transform
         pts = np.stack([rows[0] / rows[3], rows[1] / rows[3], rows[2] / rows[3]], axis=1)
@@ -637,6 +646,19 @@ class Graph:
         mask = np.zeros(len(floor.pcd.points), bool)                      # Open3D select_by_index: unique, original order
         mask[idx] = True
         return _Pcd(np.asarray(floor.pcd.points)[mask])
+
+    def _room_clouds_device(self, floor, room_2d_points):
+        """The same for all rooms of a storey at once behind the C ABI (hmsg_room_clouds): nearest neighbours on the GPU,
+        bit-equal ties by the restated cKDTree.  None when the floor cloud is not a slab of the resident map."""
+        crop = getattr(floor, "_crop", None)
+        if self.scene is None or crop is None:
+            return None
+        z_levels, T1 = self._room_extrusion(floor)
+        sel, nf = self.scene.room_clouds(crop[0], crop[1], T1, z_levels, room_2d_points)
+        fp = np.asarray(floor.pcd.points)
+        if nf != len(fp):
+            return None
+        return [_Pcd(fp[i]) for i in sel]
 
     def segment_hmsg_room(self, floor, path=None, room_2d_points=None, room_pcds=None):
         """graph.py:920-1189 from the point where the rooms' 2-D regions exist: the OpenCV watershed that produces them
@@ -653,6 +675,8 @@ class Graph:
             return None
         skip = int(_get(self.cfg, "pipeline.skip_frames", 1))
         floor_pts = np.asarray(floor.pcd.points)
+        if room_pcds is None:
+            room_pcds = self._room_clouds_device(floor, [np.asarray(r, np.float64).reshape(-1, 2) for r in room_2d_points])
         if room_pcds is None:
             tree = cKDTree(floor_pts)
             room_pcds = [self._room_cloud(floor, tree, np.asarray(r, np.float64).reshape(-1, 2)) for r in room_2d_points]

@@ -215,12 +215,27 @@ int hmsg_build_object_nodes(hmsg_t* h, int32_t n_floors, const double* floor_zer
                             const int32_t* room_floor, const int64_t* vert_off, const double* verts_xz, int32_t n_labels,
                             const float* label_feats);
 int64_t hmsg_num_nodes(const hmsg_t* h);
+
+/* ---- A9: the room clouds of segment_hmsg_room (graph.py:1086-1108).  For every room the (x, z) cell centres of its 2-D
+ * region (room_xz f64 [sum][2], CSR room_off i64 [n_rooms + 1]: what map_grid_to_point_cloud returns, :1084) are
+ * extruded over z_levels (np.arange(zero, zero + height, 0.05) * -1, :1088-1092), transformed by T (row-major 4x4, the
+ * reference's T1: Rotation.from_euler("x", 90) as scipy gives it) and every extruded point picks its nearest neighbour
+ * in the FLOOR cloud = the map points with y in [y_lo, y_hi] (full_pcd.crop, :769-775; cKDTree.query(k = 1) in the
+ * reference, bit-equal ties answered by the restated cKDTree over that cloud).  A room's cloud is
+ * floor_pcd.select_by_index(idx): out_index (i32, capacity out_capacity) receives, room after room, the ascending indices
+ * INTO THE FLOOR CLOUD (= rank among the map points inside the slab, map order); out_sizes [n_rooms] their counts;
+ * n_floor_points the size of the floor cloud.  out_index may be NULL to ask for the sizes only. */
+int hmsg_room_clouds(hmsg_t* h, double y_lo, double y_hi, const double* T, int32_t n_levels, const double* z_levels,
+                     int32_t n_rooms, const int64_t* room_off, const double* room_xz, int64_t* out_sizes,
+                     int32_t* out_index, int64_t out_capacity, int64_t* n_floor_points);
 /* nodes [hmsg_num_nodes] and/or their embeddings f32 [N][D] (either may be NULL) */
 int hmsg_get_nodes(const hmsg_t* h, hmsg_node* nodes, float* embeddings);
 
 /* ---- N2: the object level of the on-disk format written at speed.  Replaces Object.save (memory/hmsg/graph/object.py:
  * 37-57) as driven per node by save_hmsg_graph (graph.py:1801-1824): for every record <dir>/<file_stem>.ply (binary
- * little-endian double x y z of the instance cloud) and <dir>/<file_stem>.json = json.dump of {"object_id", "vertices"
+ * little-endian double x y z of the instance cloud under the header Open3D 0.18 writes for a cloud without colours, its
+ * "comment Created by Open3D" line included; the reference's objects also carry colours, which this path does not keep) and
+ * <dir>/<file_stem>.json = json.dump of {"object_id", "vertices"
  * (= points[:, [0, 2]], graph.py:1715), "room_id", "name", "embedding" (pooled feature), "view_ids", "best_view_id"} in
  * that order, numbers printed like Python's float repr.  The *_json fields are JSON text supplied by the caller (a
  * quoted string, a list, null ...) and are copied verbatim.  Clouds and features are read back from HBM once;
@@ -238,7 +253,9 @@ int hmsg_save_objects(hmsg_t* h, const char* dir, int64_t n, const hmsg_object_r
 /* N2, load side: the object table of a saved graph straight into a retrieval index.  For every stem <dir>/<stem>.json is
  * read and its "embedding" array parsed as float64 (object.py:75-91 load; graph.py:1892-1987 load_hmsg_graph), rows in
  * the order given; room_of_node as for hmsg_index_create (declared below).  feat_dim (optional) receives the row length.
- * HMSG_ERR_INVALID when a record is missing, has no numeric embedding (saved as "") or the lengths differ. */
+ * HMSG_ERR_INVALID when a record is missing, has no numeric embedding (saved as "") or the lengths differ.  (Object.load
+ * accepts a record saved without an embedding and leaves embedding = None; such a node cannot be scored, and skipping it
+ * would shift every node index after it, so the index refuses the whole table instead.) */
 struct hmsg_index;
 int hmsg_index_load_objects(int32_t device_id, const char* dir, int64_t n, const char* const* stems,
                             const int32_t* room_of_node, int32_t n_threads, struct hmsg_index** out, int32_t* feat_dim);
