@@ -99,6 +99,8 @@ _SIGS = {
     "hmsg_get_nodes": (C.c_int, [_P, _P, _P]),
     "hmsg_index_from_nodes": (C.c_int, [_P, C.POINTER(_P)]),
     "hmsg_room_clouds": (C.c_int, [_P, C.c_double, C.c_double, _P, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "hmsg_segment_rooms": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P, C.c_int64, C.POINTER(C.c_int32),
+                                     C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P]),
     "hmsg_points_min_dist_2d": (C.c_int, [C.c_int32, C.c_int32, _P, _P, C.c_int64, _P, _P]),
     "hmsg_lidar_depth": (C.c_int, [C.c_int32, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "hmsg_crop_resize_batch": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, C.c_double, C.c_int32, _P, _P, _P]),
@@ -433,6 +435,16 @@ class Scene:
                                            _ptr(sizes), _ptr(out), cap, C.byref(nf)))
         o = np.concatenate([[0], np.cumsum(sizes)])
         return [out[o[r]:o[r + 1]].copy() for r in range(len(room_xz))], int(nf.value)
+
+    def segment_rooms(self, y_lo, y_hi, zero_level, height, resolution):
+        """N1 on the device (include/hmsg.h: hmsg_segment_rooms) -> (markers i32 [rows, cols], n_rooms, xz_min [2])."""
+        rows, cols, nr = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        xz = np.zeros(2, np.float64)
+        a = (self.h, float(y_lo), float(y_hi), float(zero_level), float(height), float(resolution))
+        self._ck(self.L.c.hmsg_segment_rooms(*a, None, 0, C.byref(rows), C.byref(cols), C.byref(nr), _ptr(xz)))
+        m = np.empty((rows.value, cols.value), np.int32)
+        self._ck(self.L.c.hmsg_segment_rooms(*a, _ptr(m), m.size, C.byref(rows), C.byref(cols), C.byref(nr), _ptr(xz)))
+        return m, int(nr.value), xz
 
     def index_from_nodes(self):
         """Resident retrieval index over the node table, gathered on the device."""

@@ -660,18 +660,38 @@ class Graph:
             return None
         return [_Pcd(fp[i]) for i in sel]
 
+    def _room_regions_device(self, floor):
+        """graph.py:942-1084: the storey's rooms as lists of (x, z) cell centres -- histograms, blur / threshold /
+        closings, distance transform, seeds and the watershed on the device (hmsg_segment_rooms; OpenCV restated, see
+        oracle/rooms_oracle.py), then map_grid_to_point_cloud (graph_utils.py:359-388) per room.  None when the floor
+        cloud is not a slab of the resident map."""
+        crop = getattr(floor, "_crop", None)
+        if self.scene is None or crop is None:
+            return None
+        res = float(_get(self.cfg, "pipeline.grid_resolution", 0.05))
+        markers, n_rooms, xz_min = self.scene.segment_rooms(crop[0], crop[1], floor.floor_zero_level, floor.floor_height, res)
+        self.room_markers = getattr(self, "room_markers", {})
+        self.room_markers[floor.floor_id] = markers
+        out = []
+        for i in range(n_rooms):
+            y_cells, x_cells = np.where(markers == i + 1)
+            out.append(np.column_stack(((x_cells - 10.5) * res + xz_min[0], (y_cells - 10.5) * res + xz_min[1])))
+        return out
+
     def segment_hmsg_room(self, floor, path=None, room_2d_points=None, room_pcds=None):
-        """graph.py:920-1189 from the point where the rooms' 2-D regions exist: the OpenCV watershed that produces them
-        (:942-1071, graph_utils.py:391-487) is not restated, so `room_2d_points` -- one [n, 2]
-        array of (x, z) cell centres per room, what map_grid_to_point_cloud returns (:1084) -- is an input.  Everything
-        after it is mirrored: room clouds (:1086-1108), camera -> room assignment and KMeans(24) representative views
+        """graph.py:920-1189.  The rooms' 2-D regions (:942-1084, graph_utils.py:391-487: numpy + OpenCV in the
+        reference) come from the device restatement (_room_regions_device; parity statistical) unless
+        `room_2d_points` -- one [n, 2] array of (x, z) cell centres per room, what map_grid_to_point_cloud returns
+        (:1084) -- is handed in.  Everything after it is mirrored exactly: room clouds (:1086-1108), camera -> room assignment and KMeans(24) representative views
         (compute_room_embeddings), Room nodes (:1147-1168) and one View node per (room, image) with the reference's id
         scheme -- `<floor>_<room>_<k>` with k counting across the floor's rooms, View.room_id the per-floor room
         INDEX (an int, :1176-1189)."""
         if isinstance(floor, (int, np.integer)):
             floor = self.floors[int(floor)]
         if room_2d_points is None:
-            print("room regions are an input of this build (OpenCV watershed is not part of it)")
+            room_2d_points = self._room_regions_device(floor)
+        if room_2d_points is None:
+            print("no room regions: the floor cloud is not a slab of the resident map (pass room_2d_points)")
             return None
         skip = int(_get(self.cfg, "pipeline.skip_frames", 1))
         floor_pts = np.asarray(floor.pcd.points)
@@ -801,13 +821,16 @@ class Graph:
         return picks
 
     def build_hier_multimodal_scene_graph(self, save_path=None, rooms: Sequence[dict] | None = None, room_regions=None):
-        """graph.py:2033-2076 (navigation graph omitted).  Rooms: `room_regions` = per floor a list of [n, 2] (x, z)
-        region point arrays -> the mirrored segment_hmsg_room (room clouds, room embeddings, View nodes); or `rooms` =
-        ready-made room specs (set_rooms)."""
+        """graph.py:2033-2076 (navigation graph omitted).  Rooms: by default segment_hmsg_room per floor with the
+        device room segmentation; `room_regions` = per floor a list of [n, 2] (x, z) region point arrays -> the same
+        from the regions on (room clouds, room embeddings, View nodes); or `rooms` = ready-made room specs (set_rooms)."""
         self.segment_floors_manually(save_path)
         if room_regions is not None:
             for fl, regions in zip(self.floors, room_regions):
                 self.segment_hmsg_room(fl, save_path, room_2d_points=regions)
+        elif rooms is None and self.scene is not None:
+            for fl in self.floors:                                         # graph.py:2044-2046
+                self.segment_hmsg_room(fl, save_path)
         if rooms is not None:
             self.set_rooms(rooms)
         self.segment_hmsg_objects(save_path)

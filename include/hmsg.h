@@ -228,6 +228,18 @@ int64_t hmsg_num_nodes(const hmsg_t* h);
 int hmsg_room_clouds(hmsg_t* h, double y_lo, double y_hi, const double* T, int32_t n_levels, const double* z_levels,
                      int32_t n_rooms, const int64_t* room_off, const double* room_xz, int64_t* out_sizes,
                      int32_t* out_index, int64_t out_capacity, int64_t* n_floor_points);
+/* ---- N1: the rooms of one storey as a label image -- segment_hmsg_room up to room_vertices (graph.py:942-1071) and
+ * distance_transform (graph_utils.py:391-487), every image step a kernel (the reference: numpy + OpenCV on the host).
+ * The storey's cloud is the map points with y in [y_lo, y_hi] (as hmsg_room_clouds); zero_level / height are the
+ * floor's, resolution = pipeline.grid_resolution.  out_markers i32 [rows][cols] (capacity in elements; host or device
+ * memory): room i is markers == i + 1 for i < n_rooms, n_rooms + 1 the outside, -1 watershed lines and the image
+ * border.  map_grid_to_point_cloud (graph_utils.py:359-388) of a cell (row, col): x = (col - 10.5) * resolution +
+ * xz_min[0], z = (row - 10.5) * resolution + xz_min[1].  out_markers NULL asks for rows / cols / xz_min only.
+ * OpenCV is restated from its documented semantics (oracle/rooms_oracle.py says where that is not pixel-exact):
+ * parity with the reference is statistical here, unlike the rest of the path. */
+int hmsg_segment_rooms(hmsg_t* h, double y_lo, double y_hi, double zero_level, double height, double resolution,
+                       int32_t* out_markers, int64_t capacity, int32_t* out_rows, int32_t* out_cols, int32_t* out_n_rooms,
+                       double* out_xz_min);
 /* nodes [hmsg_num_nodes] and/or their embeddings f32 [N][D] (either may be NULL) */
 int hmsg_get_nodes(const hmsg_t* h, hmsg_node* nodes, float* embeddings);
 

@@ -1,0 +1,211 @@
+"""TEST INFRASTRUCTURE -- CPU restatement of the room segmentation (N1): Graph.segment_hmsg_room up to the rooms' 2-D regions
+(fsr_vln/memory/hmsg/graph/graph.py:942-1084) and distance_transform (fsr_vln/memory/hmsg/utils/graph_utils.py:391-487).
+
+PARITY UNPINNED.  Every image operation there is OpenCV 4.8 (`opencv-python-headless 4.8.1.78`, environment.yaml:31;
+un-vendored, absent from this image): cv2.normalize, GaussianBlur, threshold (binary / Otsu), copyMakeBorder,
+morphologyEx(MORPH_CLOSE), findContours + drawContours(filled), distanceTransform(DIST_L2, DIST_MASK_PRECISE),
+contourArea, circle, watershed.  They are restated here from their documented semantics; where OpenCV's result depends
+on implementation detail the restatement picks the documented mathematics and says so:
+
+  * GaussianBlur on 8-bit images: OpenCV evaluates a fixed-point kernel; here the float kernel (getGaussianKernel's
+    closed form), BORDER_REFLECT_101, rounded to nearest.  Differences of one grey level near a threshold can flip a pixel.
+  * findContours(RETR_EXTERNAL) + drawContours(..., -1, 255, FILLED): the union of the filled outer contours = every
+    8-connected foreground component with its holes filled.
+  * contourArea of an external contour: area of the polygon through the centres of the component's boundary pixels;
+    by Pick's theorem = pixels - boundary_pixels / 2 - 1 for a simply connected blob (used for the seed size filter).
+  * watershed: OpenCV floods from the markers with a priority queue keyed by the colour difference to the labelled
+    neighbour (0 inside free space and inside walls, 255 across a wall edge), FIFO inside a priority, 4-neighbours,
+    watershed lines where two labels meet.  Restated layer-synchronously: in every round an unlabelled pixel with
+    labelled 4-neighbours of its OWN colour takes their label (two different labels -> -1); when that stops, the rounds
+    continue across colour edges.  Pixel-exact agreement with OpenCV's FIFO order is not claimed (boundary pixels).
+
+The HIP path (holoagent_amd/csrc/hmsg_rooms.hip) implements the same restatement; tests compare it with this module
+exactly and check size-independent properties (labels partition the free space, every seed keeps its label, box rooms
+give one region each).  Imported only by tests."""
+from __future__ import annotations
+
+import numpy as np
+from scipy import ndimage
+
+
+def _normalize_minmax_u8(a):
+    """cv2.normalize(a, a, 0, 255, NORM_MINMAX).astype(np.uint8): scale = 255 * (1 / (max - min)), shift = -min * scale,
+    a * scale + shift in double; then truncation toward zero."""
+    a = np.asarray(a, np.float64)
+    lo, hi = a.min(), a.max()
+    scale = 255.0 * (1.0 / (hi - lo)) if hi > lo else 0.0
+    return (a * scale + (0.0 - lo * scale)).astype(np.uint8)
+
+
+def _gauss_kernel(ksize, sigma):
+    x = np.arange(ksize, dtype=np.float64) - (ksize - 1) / 2.0
+    k = np.exp(-(x * x) / (2.0 * sigma * sigma))
+    return k / k.sum()
+
+
+def _blur_u8(img, kx, ky, sigma):
+    """GaussianBlur(img, (kx, ky), sigma) on uint8, BORDER_REFLECT_101, rounded to nearest."""
+    a = img.astype(np.float64)
+    if kx > 1:
+        a = ndimage.correlate1d(a, _gauss_kernel(kx, sigma), axis=1, mode="mirror")
+    if ky > 1:
+        a = ndimage.correlate1d(a, _gauss_kernel(ky, sigma), axis=0, mode="mirror")
+    return np.clip(np.floor(a + 0.5), 0, 255).astype(np.uint8)
+
+
+def _pad10(img):
+    return np.pad(img, 10, mode="constant", constant_values=0)
+
+
+def _close(img, shape, size, iterations):
+    """morphologyEx(MORPH_CLOSE): `iterations` dilations then as many erosions; outside the image counts as background
+    for the dilation and as foreground for the erosion (OpenCV's default border value)."""
+    if shape == "cross":
+        st = np.zeros((size, size), bool)
+        st[size // 2, :] = True
+        st[:, size // 2] = True
+    else:
+        st = np.ones((size, size), bool)
+    a = img > 0
+    a = ndimage.binary_dilation(a, structure=st, iterations=iterations, border_value=0)
+    a = ndimage.binary_erosion(a, structure=st, iterations=iterations, border_value=1)
+    return np.where(a, 255, 0).astype(np.uint8)
+
+
+def _fill_external(img):
+    """findContours(RETR_EXTERNAL) + drawContours(filled): foreground components (8-connected) with their holes filled
+    = everything that is not background connected (4-connected) to the image border."""
+    fg = img > 0
+    bg_lab, _ = ndimage.label(~fg, structure=ndimage.generate_binary_structure(2, 1))
+    edge = np.unique(np.concatenate([bg_lab[0], bg_lab[-1], bg_lab[:, 0], bg_lab[:, -1]]))
+    outside = np.isin(bg_lab, edge[edge > 0])
+    return np.where(~outside, 255, 0).astype(np.uint8)
+
+
+def _hist2d(a, b, bins):
+    """np.histogram2d(a, b, bins=(na, nb)) (the reference's own call)."""
+    h, _, _ = np.histogram2d(a, b, bins=bins)
+    return h
+
+
+def _otsu(img):
+    """cv2.threshold(..., THRESH_OTSU): the threshold maximising the between-class variance (first maximum)."""
+    hist = np.bincount(img.ravel(), minlength=256).astype(np.float64)
+    total = hist.sum()
+    mu_total = (hist * np.arange(256)).sum() / total
+    best_t, best_v, q1, mu1_sum = 0, -1.0, 0.0, 0.0
+    for t in range(256):
+        q1 += hist[t]
+        mu1_sum += t * hist[t]
+        if q1 == 0 or q1 == total:
+            continue
+        mu1 = mu1_sum / q1
+        mu2 = (mu_total * total - mu1_sum) / (total - q1)
+        v = q1 * (total - q1) * (mu1 - mu2) ** 2
+        if v > best_v:
+            best_v, best_t = v, t
+    return best_t
+
+
+def full_map_of_floor(floor_pts, zero_level, height, resolution):
+    """graph.py:942-1062: the wall / outside map of one storey.  Returns (full_map uint8 [rows, cols], pcd_2d min (x, z))."""
+    xyz = np.asarray(floor_pts, np.float64)
+    xyz_full = xyz[xyz[:, 1] < zero_level + height - 0.2][:, [0, 2]]
+    xyz = xyz[xyz[:, 1] < zero_level + height - 0.3]
+    xyz = xyz[xyz[:, 1] >= zero_level + 0.3]
+    pcd_2d = xyz[:, [0, 2]]
+    gs = (int(np.max(pcd_2d[:, 0]) - np.min(pcd_2d[:, 0])) + 1, int(np.max(pcd_2d[:, 1]) - np.min(pcd_2d[:, 1])) + 1)
+    nb = (int(gs[0] // resolution), int(gs[1] // resolution))
+    nb = (nb[1] + 1, nb[0] + 1)
+    hist = _normalize_minmax_u8(_hist2d(pcd_2d[:, 1], pcd_2d[:, 0], nb))
+    hist = _blur_u8(hist, 5, 5, 1.0)
+    walls = np.where(hist > 0.25 * np.max(hist), 255, 0).astype(np.uint8)
+    walls = _close(_pad10(walls), "cross", 3, 1)
+    hist_full = _normalize_minmax_u8(_hist2d(xyz_full[:, 1], xyz_full[:, 0], nb))
+    hist_full = _blur_u8(hist_full, 21, 21, 2.0)
+    outside = np.where(hist_full > 0, 255, 0).astype(np.uint8)
+    outside = _close(_pad10(outside), "rect", 5, 3)
+    outside = _fill_external(outside)
+    full = np.bitwise_or(walls, np.bitwise_not(outside))
+    full = _close(full, "rect", 3, 2)
+    return full, pcd_2d.min(axis=0)
+
+
+def _edt(free):
+    """cv2.distanceTransform(bw, DIST_L2, DIST_MASK_PRECISE): exact Euclidean distance of every non-zero pixel to the
+    nearest zero pixel (float32)."""
+    return ndimage.distance_transform_edt(free).astype(np.float32)
+
+
+def _seed_components(binary, min_area):
+    """external contours with contourArea > min_area, in OpenCV's order (findContours scans from the top-left; its
+    contour list is in REVERSE discovery order for RETR_EXTERNAL): label image with seeds 1..R."""
+    F = _fill_external(binary) > 0                   # outer contours only: holes (and whatever sits in them) belong to the blob
+    lab, n = ndimage.label(F, structure=np.ones((3, 3), bool))
+    inner = ndimage.binary_erosion(F, structure=np.ones((3, 3), bool), border_value=0)
+    keep = []
+    for i in range(1, n + 1):
+        m = lab == i
+        area = int(m.sum()) - int((m & ~inner).sum()) / 2.0 - 1.0     # polygon through the boundary pixel centres (Pick)
+        if area > min_area:
+            keep.append(m)
+    keep = keep[::-1]
+    seeds = np.zeros(binary.shape, np.int32)
+    for k, m in enumerate(keep):
+        seeds[m] = k + 1
+    return seeds, len(keep)
+
+
+def watershed_sync(colour, markers):
+    """The layer-synchronous restatement of cv2.watershed on a one-channel image (see the module header)."""
+    m = markers.copy()
+    m[0, :] = m[-1, :] = m[:, 0] = m[:, -1] = -1
+    H, W = m.shape
+    for same_colour in (True, False):
+        while True:
+            lab = np.zeros((4, H, W), np.int32)
+            ok = np.zeros((4, H, W), bool)
+            for k, (dy, dx) in enumerate(((-1, 0), (1, 0), (0, -1), (0, 1))):
+                src = np.zeros((H, W), np.int32)
+                csrc = np.full((H, W), -1, np.int32)
+                ys, xs = slice(max(dy, 0), H + min(dy, 0)), slice(max(dx, 0), W + min(dx, 0))
+                yd, xd = slice(max(-dy, 0), H + min(-dy, 0)), slice(max(-dx, 0), W + min(-dx, 0))
+                src[yd, xd] = m[ys, xs]
+                csrc[yd, xd] = colour[ys, xs]
+                lab[k] = src
+                ok[k] = (src > 0) & ((csrc == colour) | (not same_colour))
+            lo = np.where(ok, lab, np.iinfo(np.int32).max).min(axis=0)
+            hi = np.where(ok, lab, 0).max(axis=0)
+            todo = (m == 0) & ok.any(axis=0)
+            if not todo.any():
+                break
+            m[todo] = np.where(lo[todo] == hi[todo], lo[todo], -1)
+    return m
+
+
+def distance_transform(full_map, resolution):
+    """graph_utils.py:391-487 -> (markers int32 [rows, cols], number of rooms)."""
+    bw = np.bitwise_not(full_map)
+    dist = _edt(bw > 0)
+    lo, hi = float(dist.min()), float(dist.max())
+    if hi > lo:                                  # cv2.normalize on float32: double scale / shift, applied in float32
+        sc = 255.0 * (1.0 / (hi - lo))
+        d8 = (dist * np.float32(sc) + np.float32(0.0 - lo * sc)).astype(np.float32).astype(np.uint8)
+    else:
+        d8 = np.zeros(dist.shape, np.uint8)
+    blur = _blur_u8(d8, 11, 1, 10.0)
+    t = _otsu(blur)
+    binary = np.where(blur > t, 255, 0).astype(np.uint8)
+    seeds, R = _seed_components(binary, (0.5 / resolution) ** 2)
+    markers = seeds.copy()
+    yy, xx = np.ogrid[:markers.shape[0], :markers.shape[1]]
+    markers[(yy - 3) ** 2 + (xx - 3) ** 2 <= 1] = R + 1       # cv2.circle(markers, (3, 3), 1, R + 1, -1)
+    return watershed_sync(full_map.astype(np.int32), markers), R
+
+
+def segment_rooms(floor_pts, zero_level, height, resolution):
+    """-> (markers, n_rooms, xz_min): room i is markers == i + 1; map_grid_to_point_cloud (graph_utils.py:359-388) turns its
+    cells into (x, z) points: ((col, row) - 10.5) * resolution + xz_min."""
+    full, xz_min = full_map_of_floor(floor_pts, zero_level, height, resolution)
+    markers, R = distance_transform(full, resolution)
+    return markers, R, xz_min
