@@ -99,6 +99,7 @@ _SIGS = {
     "hmsg_get_nodes": (C.c_int, [_P, _P, _P]),
     "hmsg_index_from_nodes": (C.c_int, [_P, C.POINTER(_P)]),
     "hmsg_room_clouds": (C.c_int, [_P, C.c_double, C.c_double, _P, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "hmsg_segment_floors": (C.c_int, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),
     "hmsg_segment_rooms": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P, C.c_int64, C.POINTER(C.c_int32),
                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P]),
     "hmsg_points_min_dist_2d": (C.c_int, [C.c_int32, C.c_int32, _P, _P, C.c_int64, _P, _P]),
@@ -435,6 +436,16 @@ class Scene:
                                            _ptr(sizes), _ptr(out), cap, C.byref(nf)))
         o = np.concatenate([[0], np.cumsum(sizes)])
         return [out[o[r]:o[r + 1]].copy() for r in range(len(room_xz))], int(nf.value)
+
+    def segment_floors(self):
+        """A8 behind the C ABI (include/hmsg.h: hmsg_segment_floors) -> list of dicts (y_lo, y_hi, zero_level, height,
+        bbox_min, bbox_max, n_points)."""
+        n = C.c_int32(0)
+        self._ck(self.L.c.hmsg_segment_floors(self.h, None, 0, C.byref(n)))
+        rec = np.zeros((max(n.value, 1), 11), np.float64)          # hmsg_floor: 10 doubles + one int64
+        self._ck(self.L.c.hmsg_segment_floors(self.h, _ptr(rec), n.value, C.byref(n)))
+        return [dict(y_lo=r[0], y_hi=r[1], zero_level=r[2], height=r[3], bbox_min=r[4:7].copy(), bbox_max=r[7:10].copy(),
+                     n_points=int(r[10:11].view(np.int64)[0])) for r in rec[:n.value]]
 
     def segment_rooms(self, y_lo, y_hi, zero_level, height, resolution):
         """N1 on the device (include/hmsg.h: hmsg_segment_rooms) -> (markers i32 [rows, cols], n_rooms, xz_min [2])."""

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/hmsg.h"
+#include "../../include/hmsg_test.h"
 
 #define HMSG_WAVE 64
 
@@ -33,6 +34,24 @@ struct hmsg_error {
         if (!(cond)) throw hmsg_error{code, text}; \
     } while (0)
 #define HMSG_CHECK_LAUNCH() HIP_TRY(hipGetLastError())
+
+// np.sum of a short float64 array as numpy adds it (pairwise_sum below its 128-element block: eight running sums over
+// the leading multiple of 8, combined as a tree, then the tail in order) -- kernel weights are normalised by such a sum
+static inline double np_sum_f64(const double* a, size_t n) {
+    if (n < 8) {
+        double r = 0.0;          // (numpy starts from a[0]; adding it to 0.0 first is exact)
+        for (size_t i = 0; i < n; ++i) r += a[i];
+        return r;
+    }
+    double r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    size_t i = 8;
+    for (; i + 8 <= n; i += 8)
+        for (int j = 0; j < 8; ++j) r[j] += a[i + (size_t)j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
 
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 

@@ -406,12 +406,11 @@ struct Img {
 
 void gauss_weights(int ksize, double sigma, std::vector<double>& w) {
     w.resize((size_t)ksize);
-    double sum = 0;
     for (int i = 0; i < ksize; ++i) {
         const double x = (double)i - (double)(ksize - 1) / 2.0;
         w[(size_t)i] = std::exp(-(x * x) / (2.0 * sigma * sigma));
-        sum += w[(size_t)i];
     }
+    const double sum = np_sum_f64(w.data(), w.size());       // (the oracle normalises with np.sum)
     for (auto& v : w) v /= sum;
 }
 

@@ -88,14 +88,6 @@ int32_t hmsg_profile_count(hmsg_t* h);   /* distinct kernel names recorded since
 int hmsg_profile_entry(hmsg_t* h, int32_t i, char* name /*[64]*/, int64_t* launches, double* total_ms,
                        double* total_work /* algorithmic bytes, or FLOP for the MFMA kernels; may be NULL */);
 
-/* Benchmark utility, not part of the path: render the synthetic posed RGB-D + mask stream of SURVEY 8d
- * straight into device buffers (rgb u8 [n][H][W][3], depth u16 [n][H][W], masks u8 [n][M][H][W]);
- * mask_entity (host, i32 [n][M]) tells which scene entity each mask shows. */
-int hmsg_synth_render(int32_t device_id, int32_t n_frames, int32_t H, int32_t W, int32_t M, const double* K,
-                      const double* poses, const int32_t* room_of_frame, int32_t n_rooms, const double* room_boxes,
-                      int32_t n_obj, const double* obj_boxes, const int32_t* room_obj_off, double depth_noise_mm,
-                      uint64_t seed, uint8_t* rgb_dev, uint16_t* depth_dev, uint8_t* masks_dev, int32_t* mask_entity_host);
-
 /* ---- loop A of create_feature_map (graph.py:339-345): hand over posed RGB-D frames ------------
  * rgb u8 [n][H][W][3], depth u16 [n][H][W] (millimetres), pose f64 [n][16] row-major camera-to-world,
  * K f64 [9] row-major intrinsics (dataset[i] tuple contract, horizon.py:217-268). Frames are copied
@@ -179,6 +171,21 @@ int hmsg_merge_tree_join(hmsg_t* h, int32_t n_ext, const int64_t* ext_sizes, con
 /* ---- A7: per-instance feature pooling (graph.py:450-491, graph_utils.py:682-728). */
 int hmsg_pool_instances(hmsg_t* h);
 int hmsg_get_instance_feats(const hmsg_t* h, float* feats /*[N][D]*/);
+
+/* ---- A8: the storeys of the map -- Graph.segment_floors_manually (graph.py:624-787): the map re-sampled at 5 cm, the
+ * height histogram at 1 cm (device), gaussian_filter1d(sigma = 2) on the int64 counts, find_peaks(distance = 20 bins,
+ * height = 90th percentile), the 1-D DBSCAN(eps = 1 m) chaining of the peaks and the reference's pick / adjust rules
+ * (numpy / scipy restated in C++ on the host: a few hundred bins), then per storey the crop of the full map by
+ * y in [y_lo, y_hi] (both inclusive): point count, axis-aligned box, zero_level = lowest y in the crop, height = y_hi -
+ * zero_level (:769-787).  [y_lo, y_hi] is the slab hmsg_segment_rooms / hmsg_room_clouds take.  capacity 0 asks for
+ * the count only. */
+typedef struct hmsg_floor {
+    double y_lo, y_hi;
+    double zero_level, height;
+    double bbox_min[3], bbox_max[3];
+    int64_t n_points;
+} hmsg_floor;
+int hmsg_segment_floors(hmsg_t* h, hmsg_floor* out, int32_t capacity, int32_t* n_floors);
 
 /* ---- A8 helper: Open3D `PointCloud.voxel_down_sample(voxel_size)` of a caller-supplied cloud, output in ascending
  * (ix, iy, iz) voxel order.  Replaces `self.full_pcd.voxel_down_sample(voxel_size=0.05)` at the top of
@@ -271,14 +278,6 @@ int hmsg_save_objects(hmsg_t* h, const char* dir, int64_t n, const hmsg_object_r
 struct hmsg_index;
 int hmsg_index_load_objects(int32_t device_id, const char* dir, int64_t n, const char* const* stems,
                             const int32_t* room_of_node, int32_t n_threads, struct hmsg_index** out, int32_t* feat_dim);
-/* test hook: the segmented keep-largest DBSCAN (pcd_denoise_dbscan, graph_utils.py:827-880) on K caller-supplied clouds
- * (sizes[k] points each, concatenated in pts; host pointers).  core0 (optional, one byte per point): anchor hint as the
- * merge fold passes it.  out_pts (capacity = all points), out_sizes [K], out_core (core flag per kept point), out_info
- * [K][3] = changed, clusters found, contested. */
-int hmsg_test_dbscan(const double* pts, int32_t K, const int64_t* sizes, double eps, int32_t min_points, const uint8_t* core0,
-                     double* out_pts, int64_t* out_sizes, uint8_t* out_core, int32_t* out_info);
-/* test hook: Python-repr text of n doubles, newline separated, into out[cap]; returns bytes written or -1 */
-int64_t hmsg_test_format_doubles(const double* v, int64_t n, char* out, int64_t cap);
 
 /* ---- A9 camera -> room assignment of compute_room_embeddings (utils/graph_utils.py:244-291): out[q][s] =
  * np.min(cdist([q], set s, "euclidean")) for n_q 2-D positions (camera x/z) against n_sets 2-D point sets (room
@@ -373,19 +372,6 @@ int hmsg_query_hier(hmsg_index_t* ix, int32_t Q, int32_t C, const float* T_obj, 
 /* plain similarity S[Q][N] = T[Q][D] . E[N][D]^T in float64 (query_floor / query_hmsg_room GEMV) */
 int hmsg_similarity(hmsg_index_t* ix, int32_t Q, const float* T, double* S);
 
-/* ---- diagnostics (tests only): the stable (key, value) radix sort every order-faithful voxel mean is built on
- * (Open3D VoxelDownSample adds points in input order; graph.py:348, generic.py:188, graph.py:456).  Host arrays,
- * sorted in place by the low key_bits bits of the key, equal keys keep their input order. */
-int hmsg_test_sort_pairs(uint32_t* keys, uint64_t* vals, int64_t n, int32_t key_bits);
-/* out[i] = s[i] after `len[i]` sequential float64 additions of p[i] (how Open3D accumulates a map point that many
- * pixels of a mask snapped to, generic.py:181-188), computed by the closed form the mask kernels use for long
- * repetitions. */
-int hmsg_test_repeat_add(const double* s, const double* p, const int32_t* len, double* out, int64_t n);
-/* host restatement of scipy.spatial.cKDTree (the reference's NN index, graph.py:362-364; used to answer bit-equal
- * nearest-neighbour ties like scipy does): index permutation after the default build (out_indices i64 [n], may be
- * NULL), node count, and query(x, k=1) answers for nq points. */
-int hmsg_test_ckdtree(const double* pts, int64_t n, const double* queries, int64_t nq, int64_t* out_idx,
-                      int64_t* out_indices, int64_t* out_n_nodes);
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,6 @@
-"""The C-ABI library loads (no GPU needed) and exports every function include/hmsg.h declares; the product
-loader refuses to run without it (no CPU fallback)."""
+"""The C-ABI library loads (no GPU needed) and exports every function include/hmsg.h (the boundary) and
+include/hmsg_test.h (test hooks, the bench renderer) declare; the product loader refuses to run without it (no CPU
+fallback); a C++ host compiles against hmsg.h alone and drives the path through it."""
 import ctypes
 import os
 import re
@@ -9,10 +10,19 @@ import pytest
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-def declared_functions():
-    src = open(os.path.join(ROOT, "include", "hmsg.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(hmsg_[a-z0-9_]+)\s*\(", src)))
+def declared_functions(headers=("hmsg.h", "hmsg_test.h")):
+    names = set()
+    for h in headers:
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(hmsg_[a-z0-9_]+)\s*\(", src))
+    return sorted(names)
+
+
+def test_the_boundary_header_holds_no_test_hooks():
+    names = declared_functions(("hmsg.h",))
+    assert not [n for n in names if n.startswith("hmsg_test_") or n == "hmsg_synth_render"]
+    assert "hmsg_test_dbscan" in declared_functions(("hmsg_test.h",))
 
 
 def test_library_exports_every_declared_symbol():

@@ -1,0 +1,41 @@
+"""A8 behind the C ABI: hmsg_segment_floors (device histogram + scipy / numpy restated in C++) == the Python mirror
+Graph.segment_floors_manually, which calls scipy.ndimage.gaussian_filter1d, scipy.signal.find_peaks and np.percentile
+themselves (graph.py:624-787) -- slabs, zero levels, heights, boxes and point counts, bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import parity_common as PC
+from tests.test_rooms_segmentation import _two_storey_scene
+
+
+def check_floors(L):
+    from holoagent_amd.graph import Graph, _Pcd
+    sc, _ = _two_storey_scene(L, n_frames=8)
+    g = Graph(dict(main=dict(), models=dict(clip=dict(feat_dim=16))), lib=L)
+    g.scene = sc
+    g.full_pcd = _Pcd(sc.map_points())
+    slabs = g.segment_floors_manually(None)
+    got = sc.segment_floors()
+    assert len(got) == len(slabs) == len(g.floors) and len(got) >= 2
+    for f, fl, (lo, hi) in zip(got, g.floors, slabs):
+        assert f["y_lo"] == lo and f["y_hi"] == hi, (f, lo, hi)
+        pts = np.asarray(fl.pcd.points)
+        assert f["n_points"] == len(pts)
+        assert f["zero_level"] == fl.floor_zero_level and f["height"] == fl.floor_height
+        if len(pts):
+            assert np.array_equal(f["bbox_min"], pts.min(0)) and np.array_equal(f["bbox_max"], pts.max(0))
+    sc.close()
+
+
+@pytest.mark.skipif(not os.path.exists(PC.EMU_PATH), reason="kernel simulator not built")
+def test_segment_floors_cabi_equals_mirror_emu():
+    from holoagent_amd._lib import HmsgLib
+    check_floors(HmsgLib(PC.EMU_PATH))
+
+
+@pytest.mark.gpu
+def test_segment_floors_cabi_equals_mirror_gpu():
+    from holoagent_amd._lib import HmsgLib
+    check_floors(HmsgLib())
