@@ -312,8 +312,8 @@ int hmsg_get_map_points(const hmsg_t* hc, double* xyz, double* rgb) {
     if (!h) return HMSG_ERR_INVALID;
     return guard(h, [&] {
         HMSG_REQUIRE(h->map_ready, HMSG_ERR_INVALID, "map not finalised");
-        if (xyz) HIP_TRY(hipMemcpy(xyz, h->pts.p, (size_t)h->V * 24, hipMemcpyDeviceToHost));
-        if (rgb) HIP_TRY(hipMemcpy(rgb, h->cols.p, (size_t)h->V * 24, hipMemcpyDeviceToHost));
+        if (xyz) d2h_bounce(xyz, h->pts.p, (size_t)h->V * 24);
+        if (rgb) d2h_bounce(rgb, h->cols.p, (size_t)h->V * 24);
     });
 }
 
@@ -427,7 +427,7 @@ int hmsg_get_map_feats(const hmsg_t* hc, float* feats, float* counter) {
     if (!h) return HMSG_ERR_INVALID;
     return guard(h, [&] {
         HMSG_REQUIRE(h->feats_final, HMSG_ERR_INVALID, "hmsg_fuse_frames not run");
-        if (feats) HIP_TRY(hipMemcpy(feats, h->feats.p, (size_t)h->V * h->cfg.feat_dim * 4, hipMemcpyDeviceToHost));
+        if (feats) d2h_bounce(feats, h->feats.p, (size_t)h->V * h->cfg.feat_dim * 4);
         if (counter) {
             std::vector<unsigned> c((size_t)h->V);
             HIP_TRY(hipMemcpy(c.data(), h->cnt.p, (size_t)h->V * 4, hipMemcpyDeviceToHost));
@@ -516,7 +516,7 @@ int hmsg_get_frame_mask_points(const hmsg_t* hc, int32_t frame, double* xyz) {
     return guard(h, [&] {
         HMSG_REQUIRE(frame >= 0 && frame < h->n_fused && xyz, HMSG_ERR_INVALID, "frame not fused");
         long long a = h->masks3d.off[(size_t)h->mask_first[frame]], b = h->masks3d.off[(size_t)h->mask_first[frame + 1]];
-        if (b > a) HIP_TRY(hipMemcpy(xyz, h->masks3d.pts.p + (size_t)a * 3, (size_t)(b - a) * 24, hipMemcpyDeviceToHost));
+        if (b > a) d2h_bounce(xyz, h->masks3d.pts.p + (size_t)a * 3, (size_t)(b - a) * 24);
     });
 }
 
@@ -544,8 +544,12 @@ int hmsg_get_instance_points(const hmsg_t* hc, double* xyz) {
     if (!h) return HMSG_ERR_INVALID;
     return guard(h, [&] {
         HMSG_REQUIRE((h->merged || h->tree_partial) && xyz, HMSG_ERR_INVALID, "hmsg_merge_instances not run");
-        if (h->inst.total)
-            HIP_TRY(hipMemcpy(xyz, h->inst.pts.p, (size_t)h->inst.total * 24, is_device_ptr(xyz) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+        if (h->inst.total) {
+            if (is_device_ptr(xyz))
+                HIP_TRY(hipMemcpy(xyz, h->inst.pts.p, (size_t)h->inst.total * 24, hipMemcpyDeviceToDevice));
+            else
+                d2h_bounce(xyz, h->inst.pts.p, (size_t)h->inst.total * 24);
+        }
     });
 }
 
@@ -595,7 +599,7 @@ int hmsg_get_instance_feats(const hmsg_t* hc, float* feats) {
     return guard(h, [&] {
         HMSG_REQUIRE(h->pooled && feats, HMSG_ERR_INVALID, "hmsg_pool_instances not run");
         size_t n = (h->inst.off.size() - 1) * (size_t)h->cfg.feat_dim;
-        if (n) HIP_TRY(hipMemcpy(feats, h->inst_feats.p, n * 4, hipMemcpyDeviceToHost));
+        if (n) d2h_bounce(feats, h->inst_feats.p, n * 4);
     });
 }
 

@@ -71,6 +71,25 @@ class _Pcd:
         return len(self.points) == 0
 
 
+class _LazyFn:
+    """A cloud that stays in HBM until somebody reads `.points` (the map of a resident scene, a storey's slab of it)."""
+
+    def __init__(self, fetch, n=None):
+        self._fetch, self._pts, self._n = fetch, None, n
+
+    @property
+    def points(self):
+        if self._pts is None:
+            self._pts = np.asarray(self._fetch(), dtype=np.float64)
+        return self._pts
+
+    def get_center(self):
+        return self.points.mean(axis=0)
+
+    def is_empty(self):
+        return (len(self.points) if self._n is None else self._n) == 0
+
+
 class _InstanceStore:
     """Instance clouds stay in HBM; the first access downloads all of them once."""
 
@@ -491,7 +510,7 @@ class Graph:
             self._poses.extend(list(pose))
             sc.add_frames(rgb, dep, pose, self._K)
         sc.finalize_map()
-        self.full_pcd = _Pcd(sc.map_points())
+        self.full_pcd = _LazyFn(sc.map_points, sc.map_size())           # stays in HBM until read
         n_done = 0
         D = self.clip_feat_dim
         for b0 in range(0, len(ids), B):                                  # loop B (graph.py:373-411)
@@ -537,6 +556,34 @@ class Graph:
             tmp.close()
 
     def segment_floors_manually(self, path=None):
+        """graph.py:624-787.  With a resident scene the whole step runs behind the C ABI (hmsg_segment_floors: the
+        re-sampling and the height histogram on the device, scipy's filter / peak rules restated in C++), the map never
+        leaves HBM and a storey's cloud is fetched only when somebody reads it; `_segment_floors_host` is the numpy /
+        scipy mirror used for clouds loaded from disk (tests/test_floors_cabi.py: the two agree bit for bit)."""
+        if self.scene is None or not isinstance(self.full_pcd, _LazyFn):     # (a cloud somebody set or loaded from disk)
+            return self._segment_floors_host(path)
+        floors = []
+        for i, f in enumerate(self.scene.segment_floors()):
+            lo, hi = float(f["y_lo"]), float(f["y_hi"])
+            fl = Floor(str(i), name="floor_" + str(i))
+
+            def crop(lo=lo, hi=hi):
+                pts = self.full_pcd.points
+                return pts[(pts[:, 1] >= lo) & (pts[:, 1] <= hi)]
+            fl.pcd = _LazyFn(crop, int(f["n_points"]))
+            fl._crop = (lo, hi)
+            if f["n_points"]:
+                mn, mx = np.asarray(f["bbox_min"]), np.asarray(f["bbox_max"])
+                ex = mx - mn
+                fl.vertices = np.array([mn, mn + [ex[0], 0, 0], mn + [0, ex[1], 0], mn + [0, 0, ex[2]], mx,
+                                        mn + [0, ex[1], ex[2]], mn + [ex[0], 0, ex[2]], mn + [ex[0], ex[1], 0]])
+            fl.floor_zero_level = float(f["zero_level"])
+            fl.floor_height = float(f["height"])
+            self.floors.append(fl)
+            floors.append([lo, hi])
+        return floors
+
+    def _segment_floors_host(self, path=None):
         pts = self.full_pcd.points
         # graph.py:633: the map is re-sampled at 5 cm first.  It already holds one centroid per 5 cm voxel, but of a
         # grid with another origin (the new one hangs off the min bound of the FILTERED cloud), so neighbouring
@@ -1202,7 +1249,7 @@ class Graph:
         g = cls(cfg or dict(main=dict(), models=dict(clip=dict(feat_dim=scene.cfg.feat_dim))), encoders=encoders,
                 lib=lib or scene.L)
         g.scene = scene
-        g.full_pcd = _Pcd(scene.map_points())
+        g.full_pcd = _LazyFn(scene.map_points, scene.map_size())     # stays in HBM until read
         g.mask_feats = list(scene.instance_feats())
         g.mask_pcds = [None] * len(g.mask_feats)
         return g

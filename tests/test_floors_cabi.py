@@ -16,7 +16,7 @@ def check_floors(L):
     g = Graph(dict(main=dict(), models=dict(clip=dict(feat_dim=16))), lib=L)
     g.scene = sc
     g.full_pcd = _Pcd(sc.map_points())
-    slabs = g.segment_floors_manually(None)
+    slabs = g._segment_floors_host(None)
     got = sc.segment_floors()
     assert len(got) == len(slabs) == len(g.floors) and len(got) >= 2
     for f, fl, (lo, hi) in zip(got, g.floors, slabs):
