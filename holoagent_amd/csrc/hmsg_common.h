@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -79,7 +80,12 @@ struct DevCache {
             return p;
         }
         void* p = nullptr;
+        const bool timing = want >= ((size_t)1 << 28) && getenv("HMSG_DEBUG_TIMING") != nullptr;
+        const auto t_a = std::chrono::steady_clock::now();
         hipError_t e = hipMalloc(&p, want);
+        if (timing)
+            fprintf(stderr, "[hmsg alloc] hipMalloc of %.1f GB: %.1f ms\n", want / 1073741824.0,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_a).count());
         if (e != hipSuccess) {          // out of memory: drop the cache and retry once
             (void)hipGetLastError();    // (the failed call must not surface at the next launch check)
             size_t parked = 0, fr = 0, tot = 0;
@@ -87,9 +93,15 @@ struct DevCache {
             (void)hipMemGetInfo(&fr, &tot);
             fprintf(stderr, "[hmsg alloc] %.1f MB did not fit (device free %.1f of %.1f GB): returning %.1f GB of parked blocks\n",
                     want / 1048576.0, fr / 1073741824.0, tot / 1073741824.0, parked / 1073741824.0);
+            const auto t_b = std::chrono::steady_clock::now();
             for (auto& kv : free_) (void)hipFree(kv.second);
             free_.clear();
+            const auto t_c = std::chrono::steady_clock::now();
             e = hipMalloc(&p, want);
+            if (timing)
+                fprintf(stderr, "[hmsg alloc] hipFree of the parked blocks: %.1f ms, hipMalloc: %.1f ms\n",
+                        std::chrono::duration<double, std::milli>(t_c - t_b).count(),
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_c).count());
             if (e != hipSuccess) (void)hipGetLastError();
         }
         if (e != hipSuccess) throw hmsg_error{HMSG_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)};
