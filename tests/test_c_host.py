@@ -1,0 +1,104 @@
+"""The drop-in boundary from C: tests/host_c/hmsg_host.c is compiled with gcc as strict C99 against include/hmsg.h ALONE
+(and the header is parsed as C++11 too), linked with the library, run on a small scene, and its answers are compared bit
+for bit with the same calls made through the Python binding.  CPU: against the kernel simulator build of the same
+sources; -m gpu: against libhmsg.so on the MI355X."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import parity_common as PC
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "host_c", "hmsg_host.c")
+INC = os.path.join(ROOT, "include")
+LIB = os.path.join(ROOT, "holoagent_amd", "libhmsg.so")
+
+
+def _build(lib_path, out):
+    d = os.path.dirname(lib_path)
+    cmd = ["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-O1", "-I", INC, SRC, "-o", out, lib_path,
+           "-Wl,-rpath," + d, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"]
+    subprocess.run(cmd, check=True, capture_output=True)
+    return out
+
+
+def _scene():
+    from holoagent_amd.synth import SceneSpec, SynthScene
+    spec = SceneSpec(seed=11, rooms_x=1, rooms_z=1, room_size=(3.6, 2.5, 3.2), objects_per_room=4, width=64, height=48,
+                     n_frames=6, n_masks=5, feat_dim=16)
+    sc = SynthScene(spec)
+    frames = [sc.frame(i) for i in range(spec.n_frames)]
+    text, _ = sc.text_table(5)
+    return spec, frames, np.ascontiguousarray(text, np.float32)
+
+
+def _run(lib_path, tmp_path):
+    from holoagent_amd._lib import HmsgLib
+    spec, frames, text = _scene()
+    S = PC.stack_frames(frames)
+    F, (H, W), M, D, Q, k = len(frames), frames[0]["depth"].shape, S["masks"].shape[1], spec.feat_dim, text.shape[0], 3
+    over = dict(feat_dim=D, outlier_nb_points=60, feat_dbscan_min=8)
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        np.array([F, H, W, M, D, Q, k, over["outlier_nb_points"], over["feat_dbscan_min"]], np.int32).tofile(f)
+        for a, t in ((S["K"], np.float64), (S["rgb"], np.uint8), (S["depth"], np.uint16), (S["pose"], np.float64),
+                     (S["masks"], np.uint8), (S["n_masks"], np.int32), (S["f_g"], np.float32), (S["f_masked"], np.float32),
+                     (S["f_crop"], np.float32), (text, np.float32)):
+            np.ascontiguousarray(a, t).tofile(f)
+    exe = _build(lib_path, str(tmp_path / "hmsg_host"))
+    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = open(fout, "rb").read()
+    V, N, n_floors, n_nodes = np.frombuffer(raw, np.int64, 4)
+    o = 32
+    sizes = np.frombuffer(raw, np.int64, N, o); o += 8 * N
+    feats = np.frombuffer(raw, np.float32, N * D, o).reshape(N, D); o += 4 * N * D
+    idx = np.frombuffer(raw, np.int32, Q * k, o).reshape(Q, k); o += 4 * Q * k
+    score = np.frombuffer(raw, np.float64, Q * k, o).reshape(Q, k)
+    # the same calls through the Python binding
+    L = HmsgLib(lib_path)
+    sc = PC.make_scene(L, frames, over)
+    sc.add_frames(S["rgb"], S["depth"], S["pose"], S["K"])
+    sc.finalize_map()
+    sc.add_frame_features(0, S["masks"], S["f_g"], S["f_masked"], S["f_crop"], S["n_masks"])
+    sc.fuse_frames()
+    sc.merge_instances()
+    sc.pool_instances()
+    assert V == sc.map_size() and N == sc.num_instances() and N >= 3
+    assert np.array_equal(sizes, [len(c) for c in sc.instances()])
+    assert np.array_equal(feats, sc.instance_feats())
+    fl = sc.segment_floors()
+    assert n_floors == len(fl) >= 1
+    box = np.array([[-100.0, -100.0], [100.0, -100.0], [100.0, 100.0], [-100.0, 100.0]])
+    nodes = sc.build_object_nodes([f["zero_level"] for f in fl], [f["height"] for f in fl], [0], [box], None)
+    assert n_nodes == len(nodes) >= 1
+    ix = sc.index_from_nodes()
+    idx2, _, score2 = ix.query_objects(text, np.zeros(Q, np.int32), [[0]] * Q, k)
+    assert np.array_equal(idx, idx2) and np.array_equal(score, score2)
+    ix.close()
+    sc.close()
+
+
+def test_header_is_plain_c_and_cxx(tmp_path):
+    """include/hmsg.h on its own: strict C99 and C++11 front ends, no torch / HIP types in the signatures."""
+    src = tmp_path / "t.c"
+    src.write_text('#include "hmsg.h"\nint main(void) { hmsg_config c; hmsg_default_config(&c); return c.feat_dim < 0; }\n')
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", INC, str(src)], check=True)
+    subprocess.run(["g++", "-std=c++11", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c++", "-I", INC, str(src)],
+                   check=True)
+    import re
+    code = re.sub(r"/\*.*?\*/", "", open(os.path.join(INC, "hmsg.h")).read(), flags=re.S)      # declarations only
+    assert "torch" not in code and "hipStream" not in code and "at::" not in code and "#include <hip" not in code
+
+
+@pytest.mark.skipif(not os.path.exists(PC.EMU_PATH), reason="kernel simulator not built")
+def test_c_host_equals_binding_emu(tmp_path):
+    _run(PC.EMU_PATH, tmp_path)
+
+
+@pytest.mark.gpu
+def test_c_host_equals_binding_gpu(tmp_path):
+    _run(LIB, tmp_path)
