@@ -111,6 +111,8 @@ void release_frame_store_if_large(hmsg_ctx* h) {
     h->bits.release();
     h->nn.release();
     h->frames_released = true;
+    // (a fold running on its worker thread allocates from its own cache: hand the parked blocks back to the driver)
+    if (h->fold_pipe) dev_cache().trim();
 }
 
 }  // namespace
@@ -179,6 +181,11 @@ void hmsg_destroy(hmsg_t* h) {
     if (!h) return;
     hmsg_kd_join(h);
     (void)hipSetDevice(h->cfg.device_id);
+    try {
+        hmsg_fold_pipe_abort(h);
+    } catch (...) {
+    }
+    h->fold_cache.trim();
     if (h->stream) {
         (void)hipStreamSynchronize(h->stream);
         (void)hipStreamDestroy(h->stream);
@@ -195,6 +202,7 @@ int hmsg_reset(hmsg_t* h) {
     return guard(h, [&] {
         HIP_TRY(hipStreamSynchronize(h->stream));
         hmsg_kd_join(h);
+        hmsg_fold_pipe_abort(h);
         h->n_tie_queries = 0;
         h->n_frames = h->n_feat_frames = h->n_fused = 0;
         if (h->frames_released) {              // (hmsg_merge_instances gave a very large frame store back)
@@ -405,6 +413,7 @@ int hmsg_merge_tree_local(hmsg_t* h, int32_t total_frames, double* th_next, int6
     if (!h || !th_next || !lists_now || !my_index) return HMSG_ERR_INVALID;
     return guard(h, [&] {
         long long l = 0, i = 0;
+        hmsg_fold_pipe_abort(h);
         release_frame_store_if_large(h);
         hmsg_merge_tree_local_impl(h, total_frames, th_next, &l, &i);
         *lists_now = l;

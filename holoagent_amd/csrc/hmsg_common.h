@@ -442,6 +442,10 @@ struct hmsg_ctx {
     bool frames_released = false;  // the (very large) frame store was given back before the merge (hmsg_api.hip)
     DevBuf<float> inst_feats;      // [N][D]
     bool pooled = false;
+    // the sequential fold running beside the fusion on a worker thread (hmsg_merge.hip: FoldPipe)
+    std::shared_ptr<struct FoldPipe> fold_pipe;
+    int fold_pipe_frames = 0;      // frames handed to it so far
+    DevCache fold_cache;           // the worker's allocator cache between scenes (its thread-local one while it runs)
     bool inst_denoised = false;    // the per-object pcd_denoise_dbscan(0.05, 10) of graph.py:1589-1591 has run
     std::vector<hmsg_node> nodes;  // object nodes (hmsg_build_object_nodes)
     std::vector<int> node_label;   // per instance: arg-max label (-1 without a vocabulary)
@@ -492,6 +496,8 @@ void hmsg_kd_join(hmsg_ctx* h);
 void hmsg_build_map(hmsg_ctx* h);       // hmsg_map.hip
 void hmsg_fuse(hmsg_ctx* h);            // hmsg_fuse.hip
 void hmsg_merge(hmsg_ctx* h);           // hmsg_merge.hip
+void hmsg_fold_pipe_feed(hmsg_ctx* h, int f0, int nfr);   // hmsg_merge.hip: masks of frames [f0, f0 + nfr) are complete
+void hmsg_fold_pipe_abort(hmsg_ctx* h);                  // hmsg_merge.hip
 void hmsg_merge_tree_local_impl(hmsg_ctx* h, int total_frames, double* th_next, long long* lists_now, long long* my_index);
 void hmsg_merge_tree_join_impl(hmsg_ctx* h, int n_ext, const long long* ext_sizes, const double* ext_pts, double th, int final_pass);
 void hmsg_denoise_inst(hmsg_ctx* h, double eps, int min_points);   // hmsg_merge.hip

@@ -1749,9 +1749,9 @@ struct Folder : Merger {
         unsigned* const dc = (unsigned*)(d_ovtab.p + off_c);
         const float r = (float)radius;
         const float r2 = (float)(radius * radius);
-        const size_t prof_idx = h->prof.ev.size();
+        const size_t prof_idx = ops.prof->ev.size();
         {
-            ProfScope ps(h->prof, s, "k_f_overlap", 0.0);
+            ProfScope ps(ops.prof, s, "k_f_overlap", 0.0);
             for (int dir = 0; dir < 2; ++dir) {
                 const unsigned nb = dir ? nblk2 : nblk1;
                 if (!nb) continue;
@@ -1772,7 +1772,7 @@ struct Folder : Merger {
             ov_work += 12.0 * na;
             if (!(decide_th >= 0.0 && (double)hc[k] / (double)na > decide_th)) ov_work += 12.0 * nb;
         }
-        if (h->prof.enabled && prof_idx < h->prof.ev.size()) h->prof.ev[prof_idx].work = ov_work;
+        if (ops.prof->enabled && prof_idx < ops.prof->ev.size()) ops.prof->ev[prof_idx].work = ov_work;
     }
 
     long long pool_alloc(long long cap) {
@@ -2019,19 +2019,19 @@ struct Folder : Merger {
             const unsigned gL = std::max(1u, std::min(gS, 64u));
             const unsigned gT = cdiv(std::max<unsigned>(T, 1u), 256);
             {
-                ProfScope ps(h->prof, s, "k_f_count", (double)T * 24.0);
+                ProfScope ps(ops.prof, s, "k_f_count", (double)T * 24.0);
                 hipLaunchKernelGGL(k_f_pre, dim3(gS), dim3(FB), 0, s, ix, st, (int)fm.size());
                 hipLaunchKernelGGL(k_f_touch, dim3(gW), dim3(FWB), 0, s, ix, st);
                 hipLaunchKernelGGL(k_f_count, dim3(gW), dim3(FWB), 0, s, ix, st, 0u);
                 hipLaunchKernelGGL(k_f_linkpre1, dim3(gL), dim3(256), 0, s, ix, st);
             }
             {
-                ProfScope ps(h->prof, s, "k_f_link", (double)T * 24.0);
+                ProfScope ps(ops.prof, s, "k_f_link", (double)T * 24.0);
                 hipLaunchKernelGGL(k_f_linkpre2, dim3(gL), dim3(256), 0, s, ix, st);
                 hipLaunchKernelGGL(k_f_link, dim3(gW), dim3(FWB), 0, s, ix, st);
             }
             {
-                ProfScope ps(h->prof, s, "k_f_label", (double)T * 24.0);
+                ProfScope ps(ops.prof, s, "k_f_label", (double)T * 24.0);
                 hipLaunchKernelGGL(k_f_acct, dim3(gS), dim3(FB), 0, s, ix, st);
                 hipLaunchKernelGGL(k_f_labelpre, dim3(gS), dim3(FB), 0, s, ix, st);
                 hipLaunchKernelGGL(k_f_label, dim3(gW), dim3(FWB), 0, s, ix, st);

@@ -855,6 +855,7 @@ void hmsg_fuse(hmsg_ctx* h) {
         }
         h->masks3d.total += npts;
         h->n_fused = fb0 + nb;
+        hmsg_fold_pipe_feed(h, fb0, nb);           // the sequential fold starts on these frames right away (FoldPipe)
     }
     h->feats.alloc((size_t)std::max<long long>(V, 1) * D);
     hipLaunchKernelGGL(k_feats_final, dim3(cdiv((size_t)V * D, 256)), dim3(256), 0, s, (const float*)h->sum.p,

@@ -30,6 +30,10 @@
 #include <numeric>
 #include <chrono>
 #include <unordered_map>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 
 namespace {
 
@@ -520,9 +524,9 @@ struct Merger {
         unsigned* const dc = (unsigned*)(d_ovpack.p + off_c);
         const float r = (float)radius;
         const float r2 = (float)(radius * radius);   // `D < radius**2` with a float32 D (graph_utils.py:654-655)
-        const size_t prof_idx = h->prof.ev.size();          // (algorithmic bytes are filled in after the read-back)
+        const size_t prof_idx = ops.prof->ev.size();        // (algorithmic bytes are filled in after the read-back)
         {
-            ProfScope ps(h->prof, s, "k_ov_query", 0.0);       // (the kernel launches only: not the read-back below)
+            ProfScope ps(ops.prof, s, "k_ov_query", 0.0);       // (the kernel launches only: not the read-back below)
             for (int dir = 0; dir < 2; ++dir) {
                 const unsigned nb = dir ? nblk2 : nblk1;
                 if (!nb) continue;
@@ -547,7 +551,7 @@ struct Merger {
                 if (second_ran) (*second_ran)[k] = 1;
             }
         }
-        if (h->prof.enabled && prof_idx < h->prof.ev.size()) h->prof.ev[prof_idx].work = ov_work;
+        if (ops.prof->enabled && prof_idx < ops.prof->ev.size()) ops.prof->ev[prof_idx].work = ov_work;
     }
 
     // ---- candidate pairs of merge_3d_masks (graph_utils.py:937-941): AABB IoU above the threshold; sequential merge:
@@ -943,13 +947,13 @@ void store_instances(Merger& m, hmsg_ctx* h, const std::vector<Cloud>& result, i
     fresh.alloc((size_t)std::max<long long>(keep_total, 1) * 3);
     if (!cat.empty()) {
         m.d_cat.ensure(cat.size());
-        HIP_TRY(hipMemcpyAsync(m.d_cat.p, cat.data(), cat.size() * sizeof(CatSeg), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(m.d_cat.p, cat.data(), cat.size() * sizeof(CatSeg), hipMemcpyHostToDevice, m.s));
         if (cat_blocks)
-            hipLaunchKernelGGL(k_concat, dim3(cat_blocks), dim3(256), 0, h->stream, (const double*)m.pool.p, (const CatSeg*)m.d_cat.p,
+            hipLaunchKernelGGL(k_concat, dim3(cat_blocks), dim3(256), 0, m.s, (const double*)m.pool.p, (const CatSeg*)m.d_cat.p,
                                (int)cat.size(), fresh.p, (const unsigned char*)nullptr, (unsigned char*)nullptr);
         HMSG_CHECK_LAUNCH();
     }
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipStreamSynchronize(m.s));
     fresh.swap(h->inst.pts);
 }
 
@@ -1011,17 +1015,329 @@ static void fold_report(Folder& m, hmsg_ctx* h) {
             cnt[FC_DBG + 2], cnt[FC_DBG + 4], cnt[FC_DBG + 5], cnt[FC_DBG + 6]);
 }
 
+static void merge_report(Folder& m) {
+    if (getenv("HMSG_DEBUG_TIMING"))
+        fprintf(stderr, "[hmsg merge] index %.1f  pairs(host) %.1f  overlap %.1f  components+concat %.1f  dbscan %.1f  bookkeeping %.1f ms\n",
+                m.tphase[0], m.tphase[1], m.tphase[2], m.tphase[3], m.tphase[4], m.tphase[5]);
+    if (m.want_stats) {
+        const auto& t = m.st;
+        const double S = std::max(1.0, t.steps);
+        fprintf(stderr, "[mstat] steps %.0f  per step: clouds %.1f  fresh raw %.1f  fresh G %.1f  indexed pts %.0f\n", t.steps, t.clouds / S,
+                t.fresh_raw / S, t.fresh_g / S, t.idx_pts / S);
+        fprintf(stderr, "[mstat] pairs/step raw %.1f (scan1 %.0f scan2 %.0f pts)   G-fresh %.1f (scan1 %.0f scan2 %.0f pts)\n", t.pairs_raw / S,
+                t.scan1_raw / S, t.scan2_raw / S, t.pairs_g / S, t.scan1_g / S, t.scan2_g / S);
+        const char* nmc[5] = {"singleton raw", "singleton non-fixed", "anchor+raw", "anchor+any", "other"};
+        for (int c = 0; c < 5; ++c)
+            fprintf(stderr, "[mstat] dbscan class %-20s comps/step %.2f  pts/step %.0f  B pts/step %.0f  members %.2f  changed %.0f multi %.0f contested %.0f nonfixed %.0f (totals)\n",
+                    nmc[c], t.ccount[c] / S, t.cpts[c] / S, t.cB[c] / S, t.ccount[c] ? t.cmem[c] / t.ccount[c] : 0.0, t.cchanged[c],
+                    t.cmulti[c], t.ccontested[c], t.cnonfixed[c]);
+    }
+    if (getenv("HMSG_DEBUG_TIMING") && m.n_collects)
+        fprintf(stderr, "[hmsg merge] %d collections of the point pool / grid arenas\n", m.n_collects);
+    if (getenv("HMSG_DEBUG_TIMING") && m.ops.stat_calls > 0)
+        fprintf(stderr, "[hmsg merge] dbscan batches %.0f: mean points %.0f  grid cells %.0f  core cells %.0f  active cells %.0f\n",
+                m.ops.stat_calls, m.ops.stat_points / m.ops.stat_calls, m.ops.stat_cells / m.ops.stat_calls,
+                m.ops.stat_core_cells / m.ops.stat_calls, m.ops.stat_active_cells / m.ops.stat_calls);
+}
+
+// ---- The sequential fold (graph_utils.py:1015-1038) as a RESUMABLE object: frames are handed in as their 3-D masks
+// become available, step() folds the next one.  hmsg_merge drives it in one go; the pipelined path (FoldPipe below)
+// drives it from a worker thread while hmsg_fuse_frames is still producing masks.
+//   The BATCH fold (re-cluster every touched cloud in full each step) is the cheaper one while the clouds are small; its
+//   step grows with the clouds, the INCREMENTAL fold's (hmsg_fold.inl) with the new points only: the fold switches over
+//   when the batches' running mean passes `switch_points` points -- and only once every frame has arrived, because the
+//   switch indexes the masks of the frames still to come.
+//     HMSG_FOLD_LEGACY=1: batch fold throughout;  HMSG_FOLD_INCREMENTAL=1: incremental from the first step;
+//     HMSG_FOLD_SWITCH=<points>: the threshold (default 600000: ~0.55 ms per step either way on an MI355X).
+//   The instances are identical either way.
+struct SeqFold {
+    Folder m;
+    hmsg_ctx* h = nullptr;
+    std::vector<std::vector<Cloud>> frames;    // frame f's non-empty masks (emptied when the frame is folded)
+    size_t f_next = 0;                         // next frame to fold
+    size_t prebuilt_upto = 0;                  // frames below it have their overlap grids (unless a collection dropped them)
+    std::vector<Cloud> G;
+    bool incremental = false, never = false;
+    int f_switch = -1;
+    double batch_mean = 0.0, switch_points = 600000.0;
+
+    void init(hmsg_ctx* hh, hipStream_t stream, Prof* prof) {
+        h = hh;
+        merger_init(m, h);
+        m.s = stream;
+        m.ops.s = stream;
+        m.ops.prof = prof;
+        if (const char* e = getenv("HMSG_DEBUG_GC_POINTS")) m.gc_pool_points = (size_t)atoll(e);   // (tests: force collections)
+        never = getenv("HMSG_FOLD_LEGACY") != nullptr;
+        switch_points = getenv("HMSG_FOLD_INCREMENTAL") ? 0.0 : 600000.0;
+        if (const char* e = getenv("HMSG_FOLD_SWITCH")) switch_points = atof(e);
+    }
+    // the 3-D masks of `nm.size()` more frames: npts points at src (device; complete on the fold's stream or synchronised),
+    // off[i] .. off[i + 1] = points of mask i (relative to src), nm[f] = masks of frame f.  reserve: pool room per point.
+    void ingest(const double* src, long long npts, const long long* off, const std::vector<int>& nm, long long reserve) {
+        if (m.pool.n == 0) {
+            m.pool.alloc((size_t)std::max<long long>(npts * reserve, 1 << 16) * 3);
+            m.poolcore.alloc((size_t)std::max<long long>(npts * reserve, 1 << 16));
+        } else {
+            m.grow(m.pool, (size_t)m.pool_used * 3, (size_t)(m.pool_used + npts) * 3);
+            m.grow(m.poolcore, (size_t)m.pool_used, (size_t)(m.pool_used + npts));
+        }
+        const long long base = m.pool_used;
+        if (npts) HIP_TRY(hipMemcpyAsync(m.pool.p + (size_t)base * 3, src, (size_t)npts * 24, hipMemcpyDeviceToDevice, m.s));
+        m.pool_used += npts;
+        size_t nmask = 0;
+        for (int v : nm) nmask += (size_t)v;
+        std::vector<SegDesc> msegs(nmask);
+        for (size_t id = 0; id < nmask; ++id) {
+            msegs[id].pt_base = base + (off[id] - off[0]);
+            msegs[id].n = (int)(off[id + 1] - off[id]);
+        }
+        m.ops.bounds(m.pool.p, msegs);           // AABBs of the masks (device reduction)
+        // Empty masks are left out: an empty cloud never pairs (find_overlapping_ratio_faiss returns 0 for it), so it
+        // stays a singleton through every step and is dropped by the min-points filter at the end (graph.py:445-448).
+        size_t id = 0;
+        for (int v : nm) {
+            frames.emplace_back();
+            auto& fr = frames.back();
+            fr.reserve((size_t)v);
+            for (int i = 0; i < v; ++i, ++id) {
+                const SegDesc& sd = msegs[id];
+                if (sd.n == 0) continue;
+                fr.emplace_back();
+                Cloud& k = fr.back();
+                k.off = sd.pt_base;
+                k.n = sd.n;
+                k.raw = true;
+                k.uid = m.next_uid++;
+                for (int a = 0; a < 3; ++a) {
+                    k.mn[a] = sd.mn[a];
+                    k.mx[a] = sd.mx[a];
+                }
+            }
+        }
+    }
+    bool pending() const { return f_next < frames.size(); }
+    // fold the next frame; input_complete: no further ingest() will follow
+    void step(bool input_complete) {
+        const hmsg_config& c = h->cfg;
+        const size_t f = f_next++;
+        if (f == 0) {
+            G = std::move(frames[0]);
+            std::vector<Cloud>().swap(frames[0]);
+            return;
+        }
+        if (!incremental && !never) {
+            // (a single step's batch jumps around: the running mean over ~64 steps decides)
+            const double last_batch = m.ops.stat_points - m.stat_points_seen;
+            m.stat_points_seen = m.ops.stat_points;
+            batch_mean += (last_batch - batch_mean) / 64.0;
+            if (input_complete && (switch_points <= 0.0 || batch_mean > switch_points) && fold_begin(m, h, G, frames, f)) {
+                incremental = true;
+                f_switch = (int)f;
+            }
+        }
+        if (incremental) {
+            G.insert(G.end(), frames[f].begin(), frames[f].end());
+            std::vector<Cloud>().swap(frames[f]);
+            G = m.fold_step(std::move(G), c.init_overlap_thresh);
+            return;
+        }
+        // overlap grids of the frame masks are built ahead, a window at a time (inputs of the fold: only clouds that
+        // change during the fold get a new grid later); a collection of the pool drops every grid
+        if (m.needs_collect()) {
+            m.collect(G, frames, f);
+            prebuilt_upto = f;
+        }
+        if (f >= prebuilt_upto) {
+            const size_t b = std::min(frames.size(), f + Merger::PREBUILD_WINDOW);
+            m.prebuild(frames, f, b);
+            prebuilt_upto = b;
+        }
+        G.insert(G.end(), frames[f].begin(), frames[f].end());
+        std::vector<Cloud>().swap(frames[f]);
+        G = m.merge_3d_masks(std::move(G), c.init_overlap_thresh);
+    }
+    // the last pass (graph_utils.py:1033-1037), the small-cloud drop (graph.py:445-448), instances into the handle
+    void finish() {
+        const hmsg_config& c = h->cfg;
+        std::vector<Cloud> result = incremental ? m.fold_step(std::move(G), c.init_overlap_thresh) : m.merge_3d_masks(std::move(G), c.init_overlap_thresh);
+        if (getenv("HMSG_DEBUG_TIMING") && incremental) {
+            fprintf(stderr, "[hmsg merge] incremental fold from frame %d of %zu\n", f_switch, frames.size());
+            fold_report(m, h);
+        }
+        store_instances(m, h, result, c.min_instance_points);
+        merge_report(m);
+    }
+};
+
+// ---- The fold runs BESIDE the fusion.  seq_merge consumes the frames' 3-D masks in frame order, hmsg_fuse_frames
+// produces them 64 frames at a time, and the fold is a chain of ~25 small latency-bound launches per frame that leaves
+// the GPU almost empty -- so a worker thread with its own (high-priority) stream starts folding as soon as the first
+// batch of masks exists, while the fusion's wide streaming kernels keep filling the chip.  hmsg_merge_instances then only
+// waits for the rest.  Same sequence of merge_3d_masks calls, same instances (tests/test_fold_pipeline.py);
+// HMSG_FOLD_NOPIPE=1 runs the fold inside hmsg_merge_instances as before.
+// The worker has its own thread-local allocator cache (no block ever moves between the two streams while in flight), its
+// own timing list, and owns every buffer of the fold; it gets each batch as a private copy of the batch's mask points.
+struct FoldPipe {
+    struct Batch {
+        DevBuf<double> pts;
+        long long npts = 0;
+        std::vector<long long> off;
+        std::vector<int> nm;
+    };
+    hmsg_ctx* h = nullptr;
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::unique_ptr<Batch>> q;
+    bool closed = false, aborted = false, failed = false;
+    hmsg_error err{HMSG_OK, ""};
+    Prof prof;
+    std::vector<std::unique_ptr<Batch>> spent;   // consumed batches: their buffers go back through the thread that made them
+
+    void run() {
+        hipStream_t s = nullptr;
+        // the fold's scratch lives in a cache of its own that stays with the handle from scene to scene (a service
+        // rebuilds scenes over and over: only the first fold pays for its hipMallocs), apart from the calling thread's
+        dev_cache().free_.swap(h->fold_cache.free_);
+        try {
+            HIP_TRY(hipSetDevice(h->cfg.device_id));
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            if (getenv("HMSG_DEBUG_PIPE_NOPRIO")) HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+            else HIP_TRY(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi));
+            {
+                SeqFold sf;
+                sf.init(h, s, &prof);
+                for (;;) {
+                    std::unique_ptr<Batch> b;
+                    bool have = false, done = false, complete = false;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        if (!sf.pending()) cv.wait(lk, [&] { return !q.empty() || closed || aborted; });
+                        if (aborted) break;
+                        if (!q.empty()) {
+                            b = std::move(q.front());
+                            q.pop_front();
+                            have = true;
+                        }
+                        complete = closed && q.empty();
+                        done = complete && !have && !sf.pending();
+                    }
+                    if (have) {
+                        sf.ingest(b->pts.p, b->npts, b->off.data(), b->nm, 64);
+                        HIP_TRY(hipStreamSynchronize(s));
+                        std::lock_guard<std::mutex> lk(mu);
+                        spent.push_back(std::move(b));
+                        continue;
+                    }
+                    if (done) {
+                        if (!sf.frames.empty()) sf.finish();
+                        break;
+                    }
+                    sf.step(complete);
+                }
+                HIP_TRY(hipStreamSynchronize(s));
+            }
+        } catch (const hmsg_error& e) {
+            failed = true;
+            err = e;
+        } catch (const std::exception& e) {
+            failed = true;
+            err = hmsg_error{HMSG_ERR_HIP, e.what()};
+        }
+        if (s) {
+            (void)hipStreamSynchronize(s);
+            (void)hipStreamDestroy(s);
+        }
+        h->fold_cache.free_.swap(dev_cache().free_);
+    }
+    void push(std::unique_ptr<Batch> b) {
+        std::vector<std::unique_ptr<Batch>> done;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            q.push_back(std::move(b));
+            done.swap(spent);
+        }
+        cv.notify_one();
+    }
+    // stop == false: let the worker fold everything it was given and store the instances
+    void join(bool stop) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            closed = true;
+            aborted = aborted || stop;
+        }
+        cv.notify_one();
+        if (th.joinable()) th.join();
+        spent.clear();
+        q.clear();
+    }
+};
+
+static bool fold_pipe_wanted(const hmsg_ctx* h) {
+    return h->cfg.merge_type != HMSG_MERGE_HIERARCHICAL && h->frame_window == 0 && !getenv("HMSG_FOLD_NOPIPE") &&
+           !getenv("HMSG_FOLD_INCREMENTAL") && !getenv("HMSG_FOLD_SWITCH") && !getenv("HMSG_DEBUG_GC_POINTS");
+}
+
+// hmsg_fuse_frames finished a batch: frames [f0, f0 + nfr) have their 3-D masks (stream synchronised)
+void hmsg_fold_pipe_feed(hmsg_ctx* h, int f0, int nfr) {
+    if (h->merged || !fold_pipe_wanted(h)) return;
+    if (!h->fold_pipe) {
+        if (f0 != 0) return;                     // (fused before without a pipe: the fold runs in hmsg_merge_instances)
+        h->fold_pipe = std::make_shared<FoldPipe>();
+        h->fold_pipe->h = h;
+        h->fold_pipe->prof.enabled = h->prof.enabled;
+        FoldPipe* fp = h->fold_pipe.get();
+        fp->th = std::thread([fp] { fp->run(); });
+    }
+    std::unique_ptr<FoldPipe::Batch> bp(new FoldPipe::Batch());
+    FoldPipe::Batch& b = *bp;
+    const size_t m0 = (size_t)h->mask_first[(size_t)f0], m1 = (size_t)h->mask_first[(size_t)f0 + nfr];
+    b.off.assign(h->masks3d.off.begin() + (long)m0, h->masks3d.off.begin() + (long)m1 + 1);
+    for (int f = f0; f < f0 + nfr; ++f) b.nm.push_back((int)(h->mask_first[(size_t)f + 1] - h->mask_first[(size_t)f]));
+    b.npts = b.off.back() - b.off.front();
+    b.pts.alloc((size_t)std::max<long long>(b.npts, 1) * 3);
+    if (b.npts) {
+        HIP_TRY(hipMemcpyAsync(b.pts.p, h->masks3d.pts.p + (size_t)b.off.front() * 3, (size_t)b.npts * 24, hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    h->fold_pipe_frames = f0 + nfr;
+    h->fold_pipe->push(std::move(bp));
+}
+
+// any call that invalidates a running pipe (reset, destroy, frame windows, the merge tree)
+void hmsg_fold_pipe_abort(hmsg_ctx* h) {
+    if (!h->fold_pipe) return;
+    h->fold_pipe->join(true);
+    h->fold_pipe->prof.clear();
+    h->fold_pipe.reset();
+    h->fold_pipe_frames = 0;
+}
+
 void hmsg_merge(hmsg_ctx* h) {
     const hmsg_config& c = h->cfg;
     HMSG_REQUIRE(h->feats_final && h->n_fused > 0, HMSG_ERR_INVALID, "hmsg_merge_instances: run hmsg_fuse_frames first");
     HMSG_REQUIRE(!h->merged, HMSG_ERR_INVALID, "instances already merged");
     HMSG_REQUIRE(h->frame_window == 0, HMSG_ERR_INVALID, "hmsg_merge_instances on a frame window: use hmsg_merge_tree_local / _join");
-    Folder m;
-    merger_init(m, h);
-    std::vector<std::vector<Cloud>> frames = seed_frames(m, h, 0);
     const int F = h->n_fused;
-    std::vector<Cloud> result;
+    if (h->fold_pipe && h->fold_pipe_frames == F && fold_pipe_wanted(h)) {
+        // the fold has been running beside the fusion: wait for the rest
+        std::shared_ptr<FoldPipe> fp = h->fold_pipe;
+        fp->join(false);
+        h->fold_pipe.reset();
+        h->fold_pipe_frames = 0;
+        for (auto& e : fp->prof.ev) h->prof.ev.push_back(e);      // (events stay valid across threads)
+        fp->prof.ev.clear();
+        if (fp->failed) throw fp->err;
+        h->merged = true;
+        return;
+    }
+    hmsg_fold_pipe_abort(h);
     if (c.merge_type == HMSG_MERGE_HIERARCHICAL) {
+        Folder m;
+        merger_init(m, h);
+        std::vector<std::vector<Cloud>> frames = seed_frames(m, h, 0);
         // graph_utils.py:959-1012
         m.use_cache = true;
         double th = c.init_overlap_thresh;
@@ -1040,78 +1356,19 @@ void hmsg_merge(hmsg_ctx* h) {
             lv = std::move(nx);
             if (lv.size() > 1) th = next_level_threshold(th, c.overlap_thresh_factor, (long long)lv.size());
         }
-        result = m.merge_3d_masks(std::move(lv[0]), 0.75);
+        std::vector<Cloud> result = m.merge_3d_masks(std::move(lv[0]), 0.75);
+        // graph.py:445-448: drop clouds with < 10 points; compact the survivors into the handle
+        store_instances(m, h, result, c.min_instance_points);
+        merge_report(m);
     } else {
-        // graph_utils.py:1015-1038.  The BATCH fold (re-cluster every touched cloud in full each step) is the cheaper one
-        // while the clouds are small; its step grows with the clouds, the INCREMENTAL fold's (hmsg_fold.inl) with the new
-        // points only: the fold switches over when the batches' running mean passes `switch_points` points.
-        //   HMSG_FOLD_LEGACY=1: batch fold throughout;  HMSG_FOLD_INCREMENTAL=1: incremental from the first step;
-        //   HMSG_FOLD_SWITCH=<points>: the threshold (default 600000: ~0.55 ms per step either way on an MI355X).  The instances are identical either way.
-        std::vector<Cloud> G = std::move(frames[0]);
-        if (const char* e = getenv("HMSG_DEBUG_GC_POINTS")) m.gc_pool_points = (size_t)atoll(e);   // (tests: force collections)
-        const bool never = getenv("HMSG_FOLD_LEGACY") != nullptr;
-        double switch_points = getenv("HMSG_FOLD_INCREMENTAL") ? 0.0 : 600000.0;
-        if (const char* e = getenv("HMSG_FOLD_SWITCH")) switch_points = atof(e);
-        bool incremental = false;
-        int f_switch = -1;
-        double batch_mean = 0.0;
-        for (int f = 1; f < F; ++f) {
-            if (!incremental && !never) {
-                // (a single step's batch jumps around: the running mean over ~64 steps decides)
-                const double last_batch = m.ops.stat_points - m.stat_points_seen;
-                m.stat_points_seen = m.ops.stat_points;
-                batch_mean += (last_batch - batch_mean) / 64.0;
-                if ((switch_points <= 0.0 || batch_mean > switch_points) && fold_begin(m, h, G, frames, (size_t)f)) {
-                    incremental = true;
-                    f_switch = f;
-                }
-            }
-            if (incremental) {
-                G.insert(G.end(), frames[(size_t)f].begin(), frames[(size_t)f].end());
-                std::vector<Cloud>().swap(frames[(size_t)f]);
-                G = m.fold_step(std::move(G), c.init_overlap_thresh);
-                continue;
-            }
-            if (m.needs_collect()) {
-                m.collect(G, frames, (size_t)f);
-                m.prebuild(frames, (size_t)f, (size_t)f + Merger::PREBUILD_WINDOW - (size_t)f % Merger::PREBUILD_WINDOW);
-            } else if ((size_t)f % Merger::PREBUILD_WINDOW == 0) {
-                m.prebuild(frames, (size_t)f, (size_t)f + Merger::PREBUILD_WINDOW);
-            }
-            G.insert(G.end(), frames[f].begin(), frames[f].end());
-            std::vector<Cloud>().swap(frames[f]);
-            G = m.merge_3d_masks(std::move(G), c.init_overlap_thresh);
-        }
-        result = incremental ? m.fold_step(std::move(G), c.init_overlap_thresh) : m.merge_3d_masks(std::move(G), c.init_overlap_thresh);
-        if (getenv("HMSG_DEBUG_TIMING") && incremental) {
-            fprintf(stderr, "[hmsg merge] incremental fold from frame %d of %d\n", f_switch, F);
-            fold_report(m, h);
-        }
+        SeqFold sf;
+        sf.init(h, h->stream, &h->prof);
+        std::vector<int> nm((size_t)F);
+        for (int f = 0; f < F; ++f) nm[(size_t)f] = (int)(h->mask_first[(size_t)f + 1] - h->mask_first[(size_t)f]);
+        sf.ingest(h->masks3d.pts.p, h->masks3d.total, h->masks3d.off.data(), nm, 2);
+        while (sf.pending()) sf.step(true);
+        sf.finish();
     }
-    // graph.py:445-448: drop clouds with < 10 points; compact the survivors into the handle
-    store_instances(m, h, result, c.min_instance_points);
-    if (getenv("HMSG_DEBUG_TIMING"))
-        fprintf(stderr, "[hmsg merge] index %.1f  pairs(host) %.1f  overlap %.1f  components+concat %.1f  dbscan %.1f  bookkeeping %.1f ms\n",
-                m.tphase[0], m.tphase[1], m.tphase[2], m.tphase[3], m.tphase[4], m.tphase[5]);
-    if (m.want_stats) {
-        const auto& t = m.st;
-        const double S = std::max(1.0, t.steps);
-        fprintf(stderr, "[mstat] steps %.0f  per step: clouds %.1f  fresh raw %.1f  fresh G %.1f  indexed pts %.0f\n", t.steps, t.clouds / S,
-                t.fresh_raw / S, t.fresh_g / S, t.idx_pts / S);
-        fprintf(stderr, "[mstat] pairs/step raw %.1f (scan1 %.0f scan2 %.0f pts)   G-fresh %.1f (scan1 %.0f scan2 %.0f pts)\n", t.pairs_raw / S,
-                t.scan1_raw / S, t.scan2_raw / S, t.pairs_g / S, t.scan1_g / S, t.scan2_g / S);
-        const char* nm[5] = {"singleton raw", "singleton non-fixed", "anchor+raw", "anchor+any", "other"};
-        for (int c = 0; c < 5; ++c)
-            fprintf(stderr, "[mstat] dbscan class %-20s comps/step %.2f  pts/step %.0f  B pts/step %.0f  members %.2f  changed %.0f multi %.0f contested %.0f nonfixed %.0f (totals)\n",
-                    nm[c], t.ccount[c] / S, t.cpts[c] / S, t.cB[c] / S, t.ccount[c] ? t.cmem[c] / t.ccount[c] : 0.0, t.cchanged[c],
-                    t.cmulti[c], t.ccontested[c], t.cnonfixed[c]);
-    }
-    if (getenv("HMSG_DEBUG_TIMING") && m.n_collects)
-        fprintf(stderr, "[hmsg merge] %d collections of the point pool / grid arenas\n", m.n_collects);
-    if (getenv("HMSG_DEBUG_TIMING") && m.ops.stat_calls > 0)
-        fprintf(stderr, "[hmsg merge] dbscan batches %.0f: mean points %.0f  grid cells %.0f  core cells %.0f  active cells %.0f\n",
-                m.ops.stat_calls, m.ops.stat_points / m.ops.stat_calls, m.ops.stat_cells / m.ops.stat_calls,
-                m.ops.stat_core_cells / m.ops.stat_calls, m.ops.stat_active_cells / m.ops.stat_calls);
     h->merged = true;
 }
 

@@ -14,7 +14,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <dlfcn.h>
 #include <map>
+#include <mutex>
 #include <tuple>
 #include <utility>
 #include <vector>
@@ -97,9 +100,12 @@ struct BlockState {
     unsigned sync_gen = 0;
     // per-wave
     std::vector<int> w_arrived;
+    std::vector<int> w_live;        // fibers of the wave that have not finished
+    int b_live = 0;
     std::vector<unsigned> w_gen;
     std::vector<uint64_t> xbuf;     // n entries
     std::vector<uint64_t> xbuf2;
+    std::vector<unsigned> xtag, xtag2;   // barrier count of the wave when the entry was written (2n entries, like xbuf)
     std::vector<char> dyn_shared;
 };
 inline thread_local BlockState* g_bs = nullptr;
@@ -122,17 +128,10 @@ inline void need_fiber(const char* what) {
         abort();
     }
 }
-inline int live_in_block() {
-    int c = 0;
-    for (auto& f : bs().fibers) c += !f.done;
-    return c;
-}
-inline int live_in_wave(int w) {
-    BlockState& s = bs();
-    int c = 0;
-    for (int i = w * 64; i < std::min(s.n, w * 64 + 64); ++i) c += !s.fibers[i].done;
-    return c;
-}
+// (live counts are kept incrementally: a Fiber holds a ucontext_t, so walking 64 `done` flags per barrier call touched
+//  64 cache lines -- the simulated collectives were what made the CPU test suite slow)
+inline int live_in_block() { return bs().b_live; }
+inline int live_in_wave(int w) { return bs().w_live[(size_t)w]; }
 inline void block_barrier() {
     need_fiber("__syncthreads");
     BlockState& s = bs();
@@ -157,6 +156,9 @@ inline void recheck_barriers() {
     for (size_t w = 0; w < s.w_arrived.size(); ++w)
         if (s.w_arrived[w] > 0 && s.w_arrived[w] >= live_in_wave((int)w)) { s.w_arrived[w] = 0; s.w_gen[w]++; }
 }
+// One barrier per collective: the values go through two buffers used in turn (parity of the wave's barrier count at
+// entry -- every lane of a wave has passed the same number of barriers when it enters a collective, and a lane can be
+// at most one collective ahead of the slowest one, which still reads the other buffer).
 template <typename T>
 inline T exchange(T v, int src_lane) {
     static_assert(sizeof(T) <= 8, "shuffle of >8 bytes");
@@ -165,19 +167,44 @@ inline T exchange(T v, int src_lane) {
     int base = (tid / 64) * 64;
     uint64_t raw = 0;
     memcpy(&raw, &v, sizeof(T));
-    s.xbuf[tid] = raw;
+    // (an entry counts only if its lane wrote it in THIS collective: lanes that sit at another call site, i.e. are
+    //  inactive here, or have exited, are skipped -- reading an inactive lane is undefined on the hardware, here it yields
+    //  the own value)
+    const unsigned gen = s.w_gen[(size_t)(tid / 64)];
+    const size_t par = (size_t)(gen & 1u) * (size_t)s.n;
+    uint64_t* buf = s.xbuf.data() + par;
+    unsigned* tag = s.xtag.data() + par;
+    buf[tid] = raw;
+    tag[tid] = gen;
     wave_barrier();
     int src = base + (src_lane & 63);
-    uint64_t got = (src < s.n && !s.fibers[src].done) ? s.xbuf[src] : raw;
-    wave_barrier();
+    uint64_t got = (src < s.n && tag[src] == gen) ? buf[src] : raw;   // (the source may have EXITED since: no `done` test)
     T out;
     memcpy(&out, &got, sizeof(T));
     return out;
 }
-struct KernelInfo { bool seen = false; bool needs_fiber = true; };
+struct KernelInfo { bool seen = false; bool needs_fiber = true; double ms = 0; double threads = 0; long launches = 0; };
 inline std::map<const void*, KernelInfo>& kinfo() {
     static std::map<const void*, KernelInfo> m;
     return m;
+}
+inline bool emu_profile() {
+    static const bool on = [] {
+        const bool v = getenv("HIPEMU_PROFILE") != nullptr;
+        if (v) atexit([] {
+            std::vector<std::pair<double, const void*>> v2;
+            for (auto& kv : kinfo()) v2.push_back({kv.second.ms, kv.first});
+            std::sort(v2.begin(), v2.end());
+            for (size_t i = v2.size(); i-- > 0 && v2.size() - i <= 25;) {
+                const KernelInfo& k = kinfo()[v2[i].second];
+                Dl_info di;
+                const char* nm = dladdr(v2[i].second, &di) && di.dli_sname ? di.dli_sname : "?";
+                fprintf(stderr, "[hipemu] %-48.48s launches %7ld  threads %12.0f  %9.1f ms\n", nm, k.launches, k.threads, k.ms);
+            }
+        });
+        return v;
+    }();
+    return on;
 }
 template <typename F>
 struct Thunk {
@@ -186,6 +213,8 @@ struct Thunk {
         (*fn)();
         BlockState& s = bs();
         s.fibers[s.cur].done = true;
+        s.b_live--;
+        s.w_live[(size_t)(s.cur / 64)]--;
         to_scheduler();               // never resumed
         abort();
     }
@@ -198,7 +227,14 @@ void run_grid(const void* key, dim3 grid, dim3 block, size_t shmem, F body) {
     static thread_local BlockState state;
     g_bs = &state;
     BlockState& s = state;
-    KernelInfo& ki = kinfo()[key];
+    const double t_start = emu_profile() ? hipemu_now() : 0.0;
+    KernelInfo* kip;
+    {   // (host threads launch side by side: the fold worker of hmsg_merge.hip)
+        static std::mutex kmu;
+        std::lock_guard<std::mutex> lk(kmu);
+        kip = &kinfo()[key];
+    }
+    KernelInfo& ki = *kip;
     // every launch runs its threads as fibers: a kernel without collectives finishes each thread on its first switch
     // (two register swaps per thread), and no kernel can be mis-classified because its first launch skipped a loop
     bool fiber_mode = true;
@@ -218,8 +254,10 @@ void run_grid(const void* key, dim3 grid, dim3 block, size_t shmem, F body) {
         }
         s.w_arrived.assign((n + 63) / 64, 0);
         s.w_gen.assign((n + 63) / 64, 0);
-        s.xbuf.assign(n, 0);
-        s.xbuf2.assign(n, 0);
+        s.xbuf.assign(2 * (size_t)n, 0);
+        s.xbuf2.assign(2 * (size_t)n, 0);
+        s.xtag.assign(2 * (size_t)n, 0xffffffffu);
+        s.xtag2.assign(2 * (size_t)n, 0xffffffffu);
     }
     Thunk<F>::fn = &body;
     for (unsigned bz = 0; bz < grid.z; ++bz)
@@ -259,6 +297,9 @@ void run_grid(const void* key, dim3 grid, dim3 block, size_t shmem, F body) {
 #endif
                 }
                 for (int t = n; t < (int)s.fibers.size(); ++t) s.fibers[t].done = true;
+                s.b_live = n;
+                s.w_live.assign((size_t)(n + 63) / 64, 0);
+                for (int w = 0; w < (n + 63) / 64; ++w) s.w_live[(size_t)w] = std::min(64, n - w * 64);
                 int remaining = n;
                 while (remaining > 0) {
                     for (int t = 0; t < n; ++t) {
@@ -277,6 +318,11 @@ void run_grid(const void* key, dim3 grid, dim3 block, size_t shmem, F body) {
             }
     if (!ki.seen) { ki.seen = true; ki.needs_fiber = s.used_collective; }
     else if (s.used_collective) ki.needs_fiber = true;
+    if (emu_profile()) {          // HIPEMU_PROFILE=1: where the simulated kernels spend the test suite's time
+        ki.ms += hipemu_now() - t_start;
+        ki.threads += (double)n * grid.x * grid.y * grid.z;
+        ki.launches += 1;
+    }
 }
 }  // namespace hipemu
 
@@ -309,6 +355,8 @@ static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = 
 static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
 #define hipStreamNonBlocking 1
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 0; *greatest = 0; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
@@ -350,12 +398,16 @@ template <typename T> static inline T __shfl_up(T v, unsigned d, int = 64) { int
 static inline unsigned long long __ballot(int pred) {
     hipemu::BlockState& s = hipemu::bs();
     int tid = hipemu::lin_tid(), base = (tid / 64) * 64;
-    s.xbuf2[tid] = pred ? 1 : 0;
+    const unsigned gen = s.w_gen[(size_t)(tid / 64)];
+    const size_t par = (size_t)(gen & 1u) * (size_t)s.n;
+    uint64_t* buf = s.xbuf2.data() + par;
+    unsigned* tag = s.xtag2.data() + par;
+    buf[tid] = pred ? 1 : 0;
+    tag[tid] = gen;
     hipemu::wave_barrier();
     unsigned long long m = 0;
     for (int l = 0; l < 64 && base + l < s.n; ++l)
-        if (!s.fibers[base + l].done && s.xbuf2[base + l]) m |= 1ull << l;
-    hipemu::wave_barrier();
+        if (tag[base + l] == gen && buf[base + l]) m |= 1ull << l;
     return m;
 }
 static inline int __builtin_amdgcn_readlane(int v, int src) { return hipemu::exchange(v, src); }
@@ -411,7 +463,11 @@ typedef float hipemu_f32x4 __attribute__((ext_vector_type(4)));
 static inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, hipemu_f32x16 c, int, int, int) {
     hipemu::BlockState& s = hipemu::bs();
     int tid = hipemu::lin_tid(), base = (tid / 64) * 64, lane = tid & 63;
-    s.xbuf[tid] = (uint64_t)__float_as_uint(a) | ((uint64_t)__float_as_uint(b) << 32);
+    const size_t par = (size_t)(s.w_gen[(size_t)(tid / 64)] & 1u) * (size_t)s.n;   // (see hipemu::exchange)
+    uint64_t* xb = s.xbuf.data() + par;
+    uint64_t* xb2 = s.xbuf2.data() + par;
+    (void)xb2;
+    xb[tid] = (uint64_t)__float_as_uint(a) | ((uint64_t)__float_as_uint(b) << 32);
     hipemu::wave_barrier();
     hipemu_f32x16 d = c;
     int col = lane & 31;
@@ -419,13 +475,12 @@ static inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float 
         int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         float acc = c[r];
         for (int k = 0; k < 2; ++k) {
-            float av = __uint_as_float((unsigned)(s.xbuf[base + row + 32 * k] & 0xffffffffu));
-            float bv = __uint_as_float((unsigned)(s.xbuf[base + col + 32 * k] >> 32));
+            float av = __uint_as_float((unsigned)(xb[base + row + 32 * k] & 0xffffffffu));
+            float bv = __uint_as_float((unsigned)(xb[base + col + 32 * k] >> 32));
             acc = fmaf(av, bv, acc);
         }
         d[r] = acc;
     }
-    hipemu::wave_barrier();
     return d;
 }
 // f64 MFMA 16x16x4: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; C/D: col = lane&15, row = (lane>>4) + 4*reg
@@ -433,11 +488,15 @@ typedef double hipemu_f64x4 __attribute__((ext_vector_type(4)));
 static inline hipemu_f64x4 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, hipemu_f64x4 c, int, int, int) {
     hipemu::BlockState& s = hipemu::bs();
     int tid = hipemu::lin_tid(), base = (tid / 64) * 64, lane = tid & 63;
+    const size_t par = (size_t)(s.w_gen[(size_t)(tid / 64)] & 1u) * (size_t)s.n;   // (see hipemu::exchange)
+    uint64_t* xb = s.xbuf.data() + par;
+    uint64_t* xb2 = s.xbuf2.data() + par;
+    (void)xb2;
     uint64_t ra, rb;
     memcpy(&ra, &a, 8);
     memcpy(&rb, &b, 8);
-    s.xbuf[tid] = ra;
-    s.xbuf2[tid] = rb;
+    xb[tid] = ra;
+    xb2[tid] = rb;
     hipemu::wave_barrier();
     hipemu_f64x4 d = c;
     int col = lane & 15;
@@ -446,20 +505,23 @@ static inline hipemu_f64x4 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double
         double acc = c[r];
         for (int k = 0; k < 4; ++k) {
             double av, bv;
-            memcpy(&av, &s.xbuf[base + row + 16 * k], 8);
-            memcpy(&bv, &s.xbuf2[base + col + 16 * k], 8);
+            memcpy(&av, &xb[base + row + 16 * k], 8);
+            memcpy(&bv, &xb2[base + col + 16 * k], 8);
             acc = fma(av, bv, acc);
         }
         d[r] = acc;
     }
-    hipemu::wave_barrier();
     return d;
 }
 static inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hipemu_f32x4 c, int, int, int) {
     // A[l&15][k=l>>4], B[k=l>>4][l&15]; C/D: col = lane&15, row = (lane>>4)*4 + reg
     hipemu::BlockState& s = hipemu::bs();
     int tid = hipemu::lin_tid(), base = (tid / 64) * 64, lane = tid & 63;
-    s.xbuf[tid] = (uint64_t)__float_as_uint(a) | ((uint64_t)__float_as_uint(b) << 32);
+    const size_t par = (size_t)(s.w_gen[(size_t)(tid / 64)] & 1u) * (size_t)s.n;   // (see hipemu::exchange)
+    uint64_t* xb = s.xbuf.data() + par;
+    uint64_t* xb2 = s.xbuf2.data() + par;
+    (void)xb2;
+    xb[tid] = (uint64_t)__float_as_uint(a) | ((uint64_t)__float_as_uint(b) << 32);
     hipemu::wave_barrier();
     hipemu_f32x4 d = c;
     int col = lane & 15;
@@ -467,12 +529,11 @@ static inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b
         int row = (lane >> 4) * 4 + r;
         float acc = c[r];
         for (int k = 0; k < 4; ++k) {
-            float av = __uint_as_float((unsigned)(s.xbuf[base + row + 16 * k] & 0xffffffffu));
-            float bv = __uint_as_float((unsigned)(s.xbuf[base + col + 16 * k] >> 32));
+            float av = __uint_as_float((unsigned)(xb[base + row + 16 * k] & 0xffffffffu));
+            float bv = __uint_as_float((unsigned)(xb[base + col + 16 * k] >> 32));
             acc = fmaf(av, bv, acc);
         }
         d[r] = acc;
     }
-    hipemu::wave_barrier();
     return d;
 }

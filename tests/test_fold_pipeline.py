@@ -1,0 +1,113 @@
+"""The sequential fold running BESIDE the fusion (hmsg_merge.hip: FoldPipe -- a worker thread with its own stream
+starts folding the frames' 3-D masks while hmsg_fuse_frames is still producing them) against the fold run inside
+hmsg_merge_instances (HMSG_FOLD_NOPIPE=1): the same sequence of merge_3d_masks calls (graph_utils.py:1015-1038), so
+the instances have to be the same clouds, point for point, in the same order; a handle can be reset or destroyed
+while its worker is still folding."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from tests import parity_common as PC
+
+
+def _digest(inst):
+    h = hashlib.sha1()
+    for a in inst:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return len(inst), sum(len(a) for a in inst), h.hexdigest()
+
+
+def _host_scene(L, frames, feat_dim, nopipe, split=False):
+    os.environ.pop("HMSG_FOLD_NOPIPE", None)
+    if nopipe:
+        os.environ["HMSG_FOLD_NOPIPE"] = "1"
+    try:
+        sc = PC.make_scene(L, frames, dict(feat_dim=feat_dim, outlier_nb_points=60, feat_dbscan_min=8))
+        S = PC.stack_frames(frames)
+        sc.add_frames(S["rgb"], S["depth"], S["pose"], S["K"])
+        sc.finalize_map()
+        n = len(frames)
+        cuts = [0, n // 2, n] if split else [0, n]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            sc.add_frame_features(a, S["masks"][a:b], S["f_g"][a:b], S["f_masked"][a:b], S["f_crop"][a:b], S["n_masks"][a:b])
+        sc.fuse_frames()
+        sc.merge_instances()
+        sc.pool_instances()
+        inst, feats = sc.instances(), sc.instance_feats()
+        sc.close()
+        return inst, feats
+    finally:
+        os.environ.pop("HMSG_FOLD_NOPIPE", None)
+
+
+@pytest.mark.skipif(not os.path.exists(PC.EMU_PATH), reason="kernel simulator not built")
+def test_pipelined_fold_equals_fold_in_merge_on_the_simulator():
+    from holoagent_amd._lib import HmsgLib
+    from holoagent_amd.synth import SceneSpec, SynthScene
+    L = HmsgLib(PC.EMU_PATH)
+    spec = SceneSpec(seed=5, rooms_x=1, rooms_z=1, room_size=(3.6, 2.5, 3.2), objects_per_room=4, width=64, height=48,
+                     n_frames=6, n_masks=5, feat_dim=16)
+    scn = SynthScene(spec)
+    frames = [scn.frame(i) for i in range(spec.n_frames)]
+    ref, ref_f = _host_scene(L, frames, 16, nopipe=True)
+    assert len(ref) >= 3
+    got, got_f = _host_scene(L, frames, 16, nopipe=False, split=True)
+    assert len(got) == len(ref) and all(np.array_equal(a, b) for a, b in zip(got, ref))
+    assert np.array_equal(got_f, ref_f)
+    # a handle that is reset / destroyed while its worker still has frames to fold
+    sc = PC.make_scene(L, frames, dict(feat_dim=16, outlier_nb_points=60, feat_dbscan_min=8))
+    S = PC.stack_frames(frames)
+    sc.add_frames(S["rgb"], S["depth"], S["pose"], S["K"])
+    sc.finalize_map()
+    sc.add_frame_features(0, S["masks"], S["f_g"], S["f_masked"], S["f_crop"], S["n_masks"])
+    sc.fuse_frames()
+    sc.reset()
+    sc.add_frames(S["rgb"], S["depth"], S["pose"], S["K"])
+    sc.finalize_map()
+    sc.add_frame_features(0, S["masks"], S["f_g"], S["f_masked"], S["f_crop"], S["n_masks"])
+    sc.fuse_frames()
+    sc.close()
+
+
+def _device_scene(L, spec, inp, nopipe, chunks=1):
+    from holoagent_amd._lib import Scene
+    os.environ.pop("HMSG_FOLD_NOPIPE", None)
+    if nopipe:
+        os.environ["HMSG_FOLD_NOPIPE"] = "1"
+    try:
+        sc = Scene(lib_=L, height=spec.height, width=spec.width, max_frames=spec.n_frames, max_masks=spec.n_masks, feat_dim=spec.feat_dim)
+        sc.add_frames(inp["rgb"], inp["depth"], inp["pose"], inp["K"])
+        sc.finalize_map()
+        F = spec.n_frames
+        cuts = [round(i * F / chunks) for i in range(chunks + 1)]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            sc.add_frame_features(a, inp["masks"][a:b], inp["f_g"][a:b], inp["f_masked"][a:b], inp["f_crop"][a:b])
+        sc.fuse_frames()
+        sc.merge_instances()
+        sc.pool_instances()
+        d = _digest(sc.instances()), hashlib.sha1(np.ascontiguousarray(sc.instance_feats()).tobytes()).hexdigest()
+        sc.close()
+        return d
+    finally:
+        os.environ.pop("HMSG_FOLD_NOPIPE", None)
+
+
+@pytest.mark.gpu
+def test_pipelined_fold_equals_fold_in_merge_on_the_gpu():
+    """configs[1]'s scene (device-rendered, 640x480, 32 masks per frame), 300 frames = 5 fusion batches: the fold beside
+    the fusion (features handed over in one piece, and in three), and the fold inside hmsg_merge_instances -- same instances (SHA-1
+    of the coordinates), same pooled features."""
+    import torch
+    import bench
+    from holoagent_amd._lib import HmsgLib
+    from holoagent_amd.synth import SceneSpec
+    L = HmsgLib()
+    spec = SceneSpec(seed=1234, n_frames=300, feat_dim=64, n_masks=32)
+    inp = bench.build_scene_inputs(L, spec, torch.device("cuda", 0), torch)
+    ref = _device_scene(L, spec, inp, nopipe=True)
+    assert ref[0][0] > 50
+    assert _device_scene(L, spec, inp, nopipe=False) == ref
+    assert _device_scene(L, spec, inp, nopipe=False, chunks=3) == ref
+    assert _device_scene(L, spec, inp, nopipe=False) == ref          # (handles re-use the allocator cache of both threads)
