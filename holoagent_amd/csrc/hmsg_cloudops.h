@@ -41,6 +41,7 @@ struct CloudOps {
     DevBuf<unsigned long long> vbitmap;
     DevBuf<unsigned> vrank;
     PinnedBuf<unsigned> h_res;   // per-segment results of a DBSCAN batch (pinned: read back every fold step)
+    PinnedBuf<char> h_geom;      // staging of the DBSCAN batch geometry table (uploaded every fold step)
     SpinWait spin;
     SortBufs vsort;              // ordered voxel sums: (slot, point index) records
     DevBuf<unsigned> voff;

@@ -923,7 +923,9 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     HMSG_REQUIRE(NC < (1ll << 31) && N < (1ll << 31), HMSG_ERR_UNSUPPORTED, "dbscan batch too large");
     if (N == 0) return 0;
     geom.ensure((size_t)K * sizeof(DbSeg));
-    HIP_TRY(hipMemcpyAsync(geom.p, hs.data(), (size_t)K * sizeof(DbSeg), hipMemcpyHostToDevice, s));
+    h_geom.ensure((size_t)K * sizeof(DbSeg));          // (pinned staging; the previous batch ended with a wait on the stream)
+    memcpy(h_geom.p, hs.data(), (size_t)K * sizeof(DbSeg));
+    HIP_TRY(hipMemcpyAsync(geom.p, h_geom.p, (size_t)K * sizeof(DbSeg), hipMemcpyHostToDevice, s));
     const DbSeg* dsegs = (const DbSeg*)geom.p;
     segid.ensure(N); cellid.ensure(N); ord.ensure(N); core.ensure(N); label.ensure(N); flags.ensure(N); pos.ensure(N);
     cnt.ensure(NC + 1); start.ensure(NC + 1); cursor.ensure(NC); minidx.ensure(NC); firstidx.ensure(NC); size.ensure(NC);

@@ -1919,7 +1919,7 @@ struct Folder : Merger {
             memcpy(h_reloc.p, reloc.data(), reloc.size() * sizeof(CatSeg));
             HIP_TRY(hipMemcpyAsync(d_reloc.p, h_reloc.p, reloc.size() * sizeof(CatSeg), hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(k_concat, dim3(reloc_blocks), dim3(256), 0, s, (const double*)pool.p, (const CatSeg*)d_reloc.p, (int)reloc.size(),
-                               pool.p, (const unsigned char*)poolcore.p, poolcore.p);
+                               pool.p, (const unsigned char*)poolcore.p, poolcore.p, CAT_CHUNK);
             HMSG_CHECK_LAUNCH();
         }
         lap(3);
@@ -2078,7 +2078,7 @@ struct Folder : Merger {
             d_cat.ensure(cat.size());
             HIP_TRY(hipMemcpyAsync(d_cat.p, cat.data(), cat.size() * sizeof(CatSeg), hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(k_concat, dim3(cat_blocks), dim3(256), 0, s, (const double*)pool.p, (const CatSeg*)d_cat.p, (int)cat.size(),
-                               concat.p, (const unsigned char*)nullptr, (unsigned char*)nullptr);
+                               concat.p, (const unsigned char*)nullptr, (unsigned char*)nullptr, CAT_CHUNK);
             HMSG_CHECK_LAUNCH();
             batch_base = pool_alloc(cat_total);
             ops.dbscan_keep_largest(concat.p, segs, eps, minpts, pool.p + (size_t)batch_base * 3, res, nullptr, poolcore.p + batch_base);

@@ -99,20 +99,20 @@ __device__ __forceinline__ long long ov_cell(const OvGrid& g, float x, float y, 
 // (counts go to `cursor`, indexed relative to the batch's first cell; the scan turns them into cell starts in
 //  `cells`, and k_ov_fill hands a cell's slots out from its end by counting `cursor` back down -- the order of
 //  points inside a cell is irrelevant)
-#define OVI_CHUNK 512      /* points per workgroup of the index kernels */
+static const int OVI_CHUNK = 512;      /* points per workgroup of the index kernels */
 __global__ void k_ov_count(const double* __restrict__ pool, const OvGrid* __restrict__ gr, int ngr, unsigned* __restrict__ cursor,
-                           long long cursor_base) {
+                           long long cursor_base, int chunk) {
     const OvGrid g = gr[find_entry(gr, ngr, blockIdx.x)];
-    const int i0 = (int)(blockIdx.x - (unsigned)g.blk0) * OVI_CHUNK, i1 = min(g.n, i0 + OVI_CHUNK);
+    const int i0 = (int)(blockIdx.x - (unsigned)g.blk0) * chunk, i1 = min(g.n, i0 + chunk);
     for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
         const double* p = pool + (size_t)(g.pt_off + i) * 3;
         atomicAdd(&cursor[ov_cell(g, (float)p[0], (float)p[1], (float)p[2]) - cursor_base], 1u);
     }
 }
 __global__ void k_ov_fill(const double* __restrict__ pool, const OvGrid* __restrict__ gr, int ngr, const unsigned* __restrict__ cells,
-                          unsigned* __restrict__ cursor, long long cursor_base, float* __restrict__ sorted) {
+                          unsigned* __restrict__ cursor, long long cursor_base, float* __restrict__ sorted, int chunk) {
     const OvGrid g = gr[find_entry(gr, ngr, blockIdx.x)];
-    const int i0 = (int)(blockIdx.x - (unsigned)g.blk0) * OVI_CHUNK, i1 = min(g.n, i0 + OVI_CHUNK);
+    const int i0 = (int)(blockIdx.x - (unsigned)g.blk0) * chunk, i1 = min(g.n, i0 + chunk);
     for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
         const double* p = pool + (size_t)(g.pt_off + i) * 3;
         float x = (float)p[0], y = (float)p[1], z = (float)p[2];
@@ -189,7 +189,7 @@ __device__ __forceinline__ bool ov_hit(const OvGrid& Y, const unsigned* __restri
     return false;
 }
 
-#define OV_CHUNK 512
+static const int OV_CHUNK = 256;       /* points per workgroup of the overlap scans (128 .. 512 measured within 3 us of each other) */
 // find_overlapping_ratio_faiss (graph_utils.py:645-662): a point of X overlaps when its exact float32
 // nearest neighbour in Y is closer than r^2, i.e. when SOME y has (dx*dx + dy*dy) + dz*dz < r2 in float32.
 // dep_counts (optional): the pair's first direction (the SMALLER cloud against the larger) has already been counted;
@@ -197,7 +197,7 @@ __device__ __forceinline__ bool ov_hit(const OvGrid& Y, const unsigned* __restri
 // so the scan of the larger cloud is skipped (sequential merge: only the decision is needed, not the value).
 __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __restrict__ gr, const OvTask* __restrict__ tasks,
                            const unsigned* __restrict__ cells, const float* __restrict__ sorted, float r2, float r,
-                           int ntasks, unsigned* __restrict__ counts, const unsigned* __restrict__ dep_counts, double th) {
+                           int ntasks, unsigned* __restrict__ counts, const unsigned* __restrict__ dep_counts, double th, int chunk) {
     const int ti = find_entry(tasks, ntasks, blockIdx.x);
     const OvTask t = tasks[ti];
     if (dep_counts && (double)dep_counts[ti] / (double)t.dep_n > th) return;
@@ -206,8 +206,8 @@ __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __rest
     // a workgroup takes OV_CHUNK consecutive points: every point is a serial chain of L2 round trips, so a
     // million-point X is spread over many workgroups (work list: exactly ceil(n / OV_CHUNK) of them per task)
     {
-        const int b0 = (int)(blockIdx.x - (unsigned)t.blk0) * OV_CHUNK;
-        const int b1 = b0 + OV_CHUNK < X.n ? b0 + OV_CHUNK : X.n;
+        const int b0 = (int)(blockIdx.x - (unsigned)t.blk0) * chunk;
+        const int b1 = b0 + chunk < X.n ? b0 + chunk : X.n;
         for (int i = b0 + (int)threadIdx.x; i < b1; i += blockDim.x) {
             const double* p = pool + (size_t)(X.pt_off + i) * 3;
             local += ov_hit(Y, cells, sorted, (float)p[0], (float)p[1], (float)p[2], r2, r) ? 1u : 0u;
@@ -222,11 +222,11 @@ struct CatSeg {
     int n, anchor;          // anchor: copy the member's persisted core flags (else the flags are cleared)
     int blk0, pad;          // first workgroup of this segment (work list)
 };
-#define CAT_CHUNK 512      /* points per workgroup of k_concat */
+static const int CAT_CHUNK = 512;      /* points per workgroup of k_concat */
 __global__ void k_concat(const double* __restrict__ pool, const CatSeg* __restrict__ segs, int nsegs, double* __restrict__ dst,
-                         const unsigned char* __restrict__ poolcore, unsigned char* __restrict__ dstcore) {
+                         const unsigned char* __restrict__ poolcore, unsigned char* __restrict__ dstcore, int chunk) {
     const CatSeg sg = segs[find_entry(segs, nsegs, blockIdx.x)];
-    const long long p0 = (long long)(blockIdx.x - (unsigned)sg.blk0) * CAT_CHUNK, p1 = min((long long)sg.n, p0 + CAT_CHUNK);
+    const long long p0 = (long long)(blockIdx.x - (unsigned)sg.blk0) * chunk, p1 = min((long long)sg.n, p0 + chunk);
     for (long long i = p0 * 3 + threadIdx.x; i < p1 * 3; i += blockDim.x) dst[sg.dst * 3 + i] = pool[sg.src * 3 + i];
     if (dstcore)
         for (long long i = p0 + threadIdx.x; i < p1; i += blockDim.x)
@@ -304,6 +304,8 @@ struct Merger {
     DevBuf<double> concat;
     DevBuf<unsigned char> concat_core;
     DevBuf<OvGrid> d_grids;
+    PinnedBuf<OvGrid> h_grids;
+    PinnedBuf<CatSeg> h_cat;
     DevBuf<unsigned> d_cursor;
     DevBuf<CatSeg> d_cat;
     PinnedBuf<unsigned> h_counts;
@@ -396,7 +398,11 @@ struct Merger {
             nblk += cdiv((size_t)g[k].n, OVI_CHUNK);
         }
         d_grids.ensure(g.size());
-        HIP_TRY(hipMemcpyAsync(d_grids.p, g.data(), g.size() * sizeof(OvGrid), hipMemcpyHostToDevice, s));
+        // (pinned staging: an async copy from pageable memory is staged by the runtime, ~3x the host time per call;
+        //  the previous use has completed -- every step and every prebuild ends with a wait on the stream)
+        h_grids.ensure(g.size());
+        memcpy(h_grids.p, g.data(), g.size() * sizeof(OvGrid));
+        HIP_TRY(hipMemcpyAsync(d_grids.p, h_grids.p, g.size() * sizeof(OvGrid), hipMemcpyHostToDevice, s));
         unsigned* cells = ix_cells.p + ix_cells_used;
         {   // the cursor is zero whenever k_ov_fill has run over what k_ov_count counted: only fresh memory is cleared
             const unsigned* before = d_cursor.p;
@@ -408,12 +414,12 @@ struct Merger {
             }
         }
         hipLaunchKernelGGL(k_ov_count, dim3(nblk), dim3(256), 0, s, (const double*)pool.p, (const OvGrid*)d_grids.p, (int)g.size(),
-                           d_cursor.p, ix_cells_used);
+                           d_cursor.p, ix_cells_used, OVI_CHUNK);
         HMSG_CHECK_LAUNCH();
         // (cell starts stay relative to this batch's first sorted point: Cloud::ix_pt)
         hmsg_scan_u32(d_cursor.p, cells, (size_t)ncell_new, s, ops.scan_tmp, nullptr);
         hipLaunchKernelGGL(k_ov_fill, dim3(nblk), dim3(256), 0, s, (const double*)pool.p, (const OvGrid*)d_grids.p, (int)g.size(),
-                           (const unsigned*)ix_cells.p, d_cursor.p, ix_cells_used, ix_pts.p);
+                           (const unsigned*)ix_cells.p, d_cursor.p, ix_cells_used, ix_pts.p, OVI_CHUNK);
         HMSG_CHECK_LAUNCH();
         for (int i : todo) L[i].has_index = true;
         ix_cells_used += ncell_new;
@@ -427,6 +433,7 @@ struct Merger {
         std::vector<Cloud> all;
         for (size_t f = a; f < b; ++f) all.insert(all.end(), frames[f].begin(), frames[f].end());
         build_indices(all);
+        spin.wait(s);                       // (h_grids is re-used by the next call)
         size_t k = 0;
         for (size_t f = a; f < b; ++f)
             for (auto& cl : frames[f]) cl = all[k++];
@@ -465,7 +472,7 @@ struct Merger {
             HIP_TRY(hipMemcpyAsync(d_cat.p, cat.data(), cat.size() * sizeof(CatSeg), hipMemcpyHostToDevice, s));
             if (blocks)
                 hipLaunchKernelGGL(k_concat, dim3(blocks), dim3(256), 0, s, (const double*)pool.p, (const CatSeg*)d_cat.p, (int)cat.size(),
-                                   np.p, (const unsigned char*)poolcore.p, nc.p);
+                                   np.p, (const unsigned char*)poolcore.p, nc.p, CAT_CHUNK);
             HMSG_CHECK_LAUNCH();
         }
         HIP_TRY(hipStreamSynchronize(s));
@@ -482,7 +489,7 @@ struct Merger {
     size_t gc_pool_points = (size_t)1 << 30;         // 1.07 * 10^9 points = 26 GB
     size_t gc_index_entries = (size_t)1 << 31;       // grid cells (8 GB) / sorted points (26 GB)
     int n_collects = 0;
-    static constexpr size_t PREBUILD_WINDOW = 1024;  // frames
+    static constexpr size_t PREBUILD_WINDOW = 64;    // frames (one fusion batch; measured: the overlap scans of a 1000-frame fold take 90 ms with 64-frame windows, 110 ms with one 1024-frame window)
 
     // ---- overlap ratios for a list of (i, j) pairs of L.  `decide_th` >= 0 (sequential merge): only `ratio > th`
     // is needed downstream, so the pair's smaller cloud is counted first and the scan of the larger one is skipped on
@@ -533,7 +540,7 @@ struct Merger {
                 const size_t o = (size_t)dir * P;
                 hipLaunchKernelGGL(k_ov_query, dim3(nb), dim3(256), 0, s, (const double*)pool.p, dg, dt + o,
                                    (const unsigned*)ix_cells.p, (const float*)ix_pts.p, r2, r, (int)P, dc + o,
-                                   (dir && decide_th >= 0.0) ? (const unsigned*)dc : (const unsigned*)nullptr, decide_th);
+                                   (dir && decide_th >= 0.0) ? (const unsigned*)dc : (const unsigned*)nullptr, decide_th, OV_CHUNK);
             }
         }
         HMSG_CHECK_LAUNCH();
@@ -734,9 +741,11 @@ struct Merger {
             concat.ensure((size_t)cat_total * 3);
             concat_core.ensure((size_t)cat_total);
             d_cat.ensure(cat.size());
-            HIP_TRY(hipMemcpyAsync(d_cat.p, cat.data(), cat.size() * sizeof(CatSeg), hipMemcpyHostToDevice, s));
+            h_cat.ensure(cat.size());
+            memcpy(h_cat.p, cat.data(), cat.size() * sizeof(CatSeg));
+            HIP_TRY(hipMemcpyAsync(d_cat.p, h_cat.p, cat.size() * sizeof(CatSeg), hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(k_concat, dim3(cat_blocks), dim3(256), 0, s, (const double*)pool.p, (const CatSeg*)d_cat.p, (int)cat.size(),
-                               concat.p, (const unsigned char*)poolcore.p, use_anchor ? concat_core.p : nullptr);
+                               concat.p, (const unsigned char*)poolcore.p, use_anchor ? concat_core.p : nullptr, CAT_CHUNK);
             HMSG_CHECK_LAUNCH();
             grow(pool, (size_t)pool_used * 3, (size_t)(pool_used + cat_total) * 3);
             grow(poolcore, (size_t)pool_used, (size_t)(pool_used + cat_total));
@@ -950,7 +959,7 @@ void store_instances(Merger& m, hmsg_ctx* h, const std::vector<Cloud>& result, i
         HIP_TRY(hipMemcpyAsync(m.d_cat.p, cat.data(), cat.size() * sizeof(CatSeg), hipMemcpyHostToDevice, m.s));
         if (cat_blocks)
             hipLaunchKernelGGL(k_concat, dim3(cat_blocks), dim3(256), 0, m.s, (const double*)m.pool.p, (const CatSeg*)m.d_cat.p,
-                               (int)cat.size(), fresh.p, (const unsigned char*)nullptr, (unsigned char*)nullptr);
+                               (int)cat.size(), fresh.p, (const unsigned char*)nullptr, (unsigned char*)nullptr, CAT_CHUNK);
         HMSG_CHECK_LAUNCH();
     }
     HIP_TRY(hipStreamSynchronize(m.s));
@@ -1276,6 +1285,10 @@ struct FoldPipe {
 };
 
 static bool fold_pipe_wanted(const hmsg_ctx* h) {
+    // (not beside a very large frame store -- the 157 GB of a 10 000-frame 1280x720 episode: the fold's arenas then come
+    //  from fresh hipMallocs of tens of GB, each of which waits for the other thread's device work and stalls it in turn;
+    //  measured 18.7 s instead of 15.5 s for that episode.  Such a store is handed back before the merge instead.)
+    if (h->rgb.bytes() + h->depth.bytes() + h->bits.bytes() + h->nn.bytes() >= ((size_t)96 << 30)) return false;
     return h->cfg.merge_type != HMSG_MERGE_HIERARCHICAL && h->frame_window == 0 && !getenv("HMSG_FOLD_NOPIPE") &&
            !getenv("HMSG_FOLD_INCREMENTAL") && !getenv("HMSG_FOLD_SWITCH") && !getenv("HMSG_DEBUG_GC_POINTS");
 }
@@ -1289,7 +1302,7 @@ void hmsg_fold_pipe_feed(hmsg_ctx* h, int f0, int nfr) {
         h->fold_pipe->h = h;
         h->fold_pipe->prof.enabled = h->prof.enabled;
         FoldPipe* fp = h->fold_pipe.get();
-        fp->th = std::thread([fp] { fp->run(); });
+        if (!getenv("HMSG_DEBUG_PIPE_LATE")) fp->th = std::thread([fp] { fp->run(); });
     }
     std::unique_ptr<FoldPipe::Batch> bp(new FoldPipe::Batch());
     FoldPipe::Batch& b = *bp;
@@ -1324,6 +1337,10 @@ void hmsg_merge(hmsg_ctx* h) {
     if (h->fold_pipe && h->fold_pipe_frames == F && fold_pipe_wanted(h)) {
         // the fold has been running beside the fusion: wait for the rest
         std::shared_ptr<FoldPipe> fp = h->fold_pipe;
+        if (getenv("HMSG_DEBUG_PIPE_LATE")) {
+            FoldPipe* q = fp.get();
+            q->th = std::thread([q] { q->run(); });
+        }
         fp->join(false);
         h->fold_pipe.reset();
         h->fold_pipe_frames = 0;
