@@ -353,13 +353,15 @@ def main():
     # this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes) committed under profiles/
     if roof is not None:
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))["kernels"]
+            import glob
+            pmc_path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))[-1]   # newest round
+            pmc = json.load(open(pmc_path))["kernels"]
             key = {"k_db_union/box": "k_db_union", "k_db_union/scan": "k_db_union_scan"}.get(roof["kernel"], roof["kernel"])
             if key in pmc:
                 # (a timed "launch" of k_ov_query is the pair of launches of one fold step: scale by the dispatch counts)
                 per = max(1.0, pmc[key]["dispatches"] / max(roof["launches"], 1)) if key == "k_ov_query" else 1.0
                 roof["traffic"] = int(pmc[key]["hbm_bytes_per_launch"] * per)
-                roof["traffic_source"] = "profiles/r02_pmc_traffic.json (offline PMC passes, same command)"
+                roof["traffic_source"] = "profiles/%s (offline PMC passes, same command)" % os.path.basename(pmc_path)
         except Exception:
             pass
 
@@ -415,6 +417,9 @@ def main():
                        "frames": F, "queries": Q, "feat_dim": D, "masks": M,
                        "parallelism": ("episode-sharded x%d (frame windows of %d)" % (world, chunk)) if episode else "scene-per-gpu x%d" % world},
             "rccl_ranks": dist.get_world_size() if use_dist else 0,
+            # (scene mode: the sequential fold of A6 starts on a worker thread while hmsg_fuse_frames is still producing
+            #  3-D masks, so part of the merge is inside the fuse_frames stage time; HMSG_FOLD_NOPIPE=1 separates them)
+            "fold_beside_fusion": (not episode) and not os.environ.get("HMSG_FOLD_NOPIPE"),
             "per_rank_frames_per_s": [round(v, 1) for v in per_rank_fps],
             "queries_per_sec": round(qps, 1) if qps else None,
             "retrieval_room_stage_hit_rate": state.get("rooms_hit"),
@@ -428,10 +433,18 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
             "speedup_vs_cpu": round(fps / cpu["value"], 1) if cpu else None,
         }
-        print(json.dumps(out))
     sc.close()
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line goes out LAST: RCCL writes its version banner through C stdio, which would otherwise be flushed
+        # behind it at exit
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
