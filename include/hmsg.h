@@ -208,7 +208,10 @@ int hmsg_instance_room_share(hmsg_t* h, int32_t n_rooms, const int64_t* vert_off
  * dataset's images and stays with the caller.  Runs the per-object pcd_denoise_dbscan(0.05, 10) if it has not run yet,
  * assigns every instance with at least 10 points to each floor whose [zero - 0.2, zero + height + 0.2] contains its
  * y-extent and, there, to the room with the largest find_intersection_share (fallback: nearest room centre), labels
- * it with the arg-max of emb . label_feats^T (identify_object) and numbers it per room.  Nodes come out in the
+ * it with the arg-max of emb . label_feats^T (identify_object, graph.py:1441-1454) and numbers it per room.  The scores are
+ * float32 inputs multiplied and summed in FLOAT64 (exact products, one rounding per sum); the reference's np.dot stays in
+ * float32 with BLAS's summation order, so two classes within ~1e-7 of each other could swap -- none does on the
+ * reference-made fixture (every object name is compared, tests/test_objects_golden.py).  Nodes come out in the
  * reference's creation order (floors outer, instances inner).  floor_zero / floor_height f64 [n_floors];
  * room_floor i32 [n_rooms]; vert_off i64 [n_rooms + 1]; verts_xz f64 [sum][2]; label_feats f32 [n_labels][D] or NULL. */
 typedef struct hmsg_node {
