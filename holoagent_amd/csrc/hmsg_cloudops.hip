@@ -1036,8 +1036,8 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     HMSG_CHECK_LAUNCH();
     {   // debug: HMSG_DEBUG_DBCALL=<n> dumps the n-th batch (inputs + per-point results) under HMSG_DEBUG_DUMP
         static long long call_no = 0;
-        const char* want = getenv("HMSG_DEBUG_DBCALL");
-        const char* wantn = getenv("HMSG_DEBUG_DBMINN");     // ... or the first batch with at least that many points
+        static const char* const want = getenv("HMSG_DEBUG_DBCALL");      // (read once: batches may run on a worker thread)
+        static const char* const wantn = getenv("HMSG_DEBUG_DBMINN");     // ... or the first batch with at least that many points
         static bool dumped = false;
         if ((want && atoll(want) == call_no) || (wantn && !dumped && N >= atoll(wantn) && (dumped = true))) {
             hmsg_dump("db_pts", src, (size_t)N * 24, s);

@@ -782,7 +782,8 @@ struct Merger {
                     st.cnonfixed[cls] += !fx;
                 }
             }
-            if (getenv("HMSG_DEBUG_MERGESTATS_STEP")) {
+            static const bool stats_step = getenv("HMSG_DEBUG_MERGESTATS_STEP") != nullptr;   // (read once: the fold may run on a worker thread)
+            if (stats_step) {
                 long long fixed_pts = 0, big_fixed = 0, removed = 0;
                 int nchanged = 0, multi = 0, multicl = 0, multicl_changed = 0;
                 long long multicl_pts = 0;
@@ -1213,8 +1214,7 @@ struct FoldPipe {
             HIP_TRY(hipSetDevice(h->cfg.device_id));
             int lo = 0, hi = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-            if (getenv("HMSG_DEBUG_PIPE_NOPRIO")) HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-            else HIP_TRY(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi));
+            HIP_TRY(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi));
             {
                 SeqFold sf;
                 sf.init(h, s, &prof);
@@ -1254,6 +1254,9 @@ struct FoldPipe {
         } catch (const std::exception& e) {
             failed = true;
             err = hmsg_error{HMSG_ERR_HIP, e.what()};
+        } catch (...) {
+            failed = true;
+            err = hmsg_error{HMSG_ERR_HIP, "merge fold worker: unknown exception"};
         }
         if (s) {
             (void)hipStreamSynchronize(s);
@@ -1302,7 +1305,7 @@ void hmsg_fold_pipe_feed(hmsg_ctx* h, int f0, int nfr) {
         h->fold_pipe->h = h;
         h->fold_pipe->prof.enabled = h->prof.enabled;
         FoldPipe* fp = h->fold_pipe.get();
-        if (!getenv("HMSG_DEBUG_PIPE_LATE")) fp->th = std::thread([fp] { fp->run(); });
+        fp->th = std::thread([fp] { fp->run(); });
     }
     std::unique_ptr<FoldPipe::Batch> bp(new FoldPipe::Batch());
     FoldPipe::Batch& b = *bp;
@@ -1337,10 +1340,6 @@ void hmsg_merge(hmsg_ctx* h) {
     if (h->fold_pipe && h->fold_pipe_frames == F && fold_pipe_wanted(h)) {
         // the fold has been running beside the fusion: wait for the rest
         std::shared_ptr<FoldPipe> fp = h->fold_pipe;
-        if (getenv("HMSG_DEBUG_PIPE_LATE")) {
-            FoldPipe* q = fp.get();
-            q->th = std::thread([q] { q->run(); });
-        }
         fp->join(false);
         h->fold_pipe.reset();
         h->fold_pipe_frames = 0;
