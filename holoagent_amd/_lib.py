@@ -107,6 +107,7 @@ _SIGS = {
     "hmsg_crop_resize_batch": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, C.c_double, C.c_int32, _P, _P, _P]),
     "hmsg_save_objects": (C.c_int, [_P, C.c_char_p, C.c_int64, _P, C.c_int32]),
     "hmsg_test_format_doubles": (C.c_int64, [_P, C.c_int64, _P, C.c_int64]),
+    "hmsg_test_allocator_carving": (C.c_int, [C.c_int32, C.c_int32]),
     "hmsg_test_dbscan": (C.c_int, [_P, C.c_int32, _P, C.c_double, C.c_int32, _P, _P, _P, _P, _P]),
     "hmsg_index_load_objects": (C.c_int, [C.c_int32, C.c_char_p, C.c_int64, _P, _P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int32)]),
     "hmsg_index_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _P, C.c_int32, _P, C.POINTER(_P)]),

@@ -99,10 +99,34 @@ int guard(hmsg_ctx* h, F&& fn) {
 // A long episode's frame store (colour, depth, mask bitsets, nearest-voxel indices: 17 B per pixel and frame, 157 GB for
 // 10 000 frames at 1280x720) is dead weight once every frame is fused: nothing after the fusion reads it, and the merge
 // needs the room.  Small stores stay (a service that rebuilds scenes reuses them).
+// The frame store of a handle: colour + depth at creation, mask bitsets and nearest-voxel indices when they are first
+// needed -- four blocks; or, when all four together pass 96 GB (a long episode), ONE block with the four as views into
+// it: handed back before the merge it is a single parked block that the merge's arenas are carved from (DevCache).
+static const size_t FRAME_STORE_LARGE = (size_t)96 << 30;
+void alloc_frame_store(hmsg_ctx* h) {
+    const size_t HW = (size_t)h->cfg.height * h->cfg.width, F = (size_t)h->cfg.max_frames, NW = (size_t)h->NW;
+    const size_t b_rgb = HW * 3 * F, b_depth = HW * 2 * F, b_bits = HW * NW * 8 * F, b_nn = HW * 4 * F;
+    auto up = [](size_t v) { return (v + ((size_t)1 << 21) - 1) & ~(((size_t)1 << 21) - 1); };
+    if (b_rgb + b_depth + b_bits + b_nn >= FRAME_STORE_LARGE) {
+        h->frame_arena.alloc(up(b_rgb) + up(b_depth) + up(b_bits) + up(b_nn));
+        unsigned char* p = h->frame_arena.p;
+        h->rgb.view(p, HW * 3 * F);
+        p += up(b_rgb);
+        h->depth.view((unsigned short*)p, HW * F);
+        p += up(b_depth);
+        h->bits.view((unsigned long long*)p, HW * NW * F);
+        p += up(b_bits);
+        h->nn.view((int*)p, HW * F);
+    } else {
+        h->rgb.alloc(HW * 3 * F);
+        h->depth.alloc(HW * F);
+    }
+}
+
 void release_frame_store_if_large(hmsg_ctx* h) {
     const size_t bytes = h->rgb.bytes() + h->depth.bytes() + h->bits.bytes() + h->nn.bytes();
     // (handing 60 GB back to the driver costs seconds: only when the merge could not fit next to it)
-    if (bytes < ((size_t)96 << 30) || h->n_fused < h->n_feat_frames) return;
+    if (bytes < FRAME_STORE_LARGE || h->n_fused < h->n_feat_frames) return;
     // (parked in the allocator's cache, not handed back to the driver: hipFree of 150 GB takes seconds; the merge's
     //  arenas re-use the blocks that fit, and the cache frees the rest when an allocation does not fit)
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -110,6 +134,7 @@ void release_frame_store_if_large(hmsg_ctx* h) {
     h->depth.release();
     h->bits.release();
     h->nn.release();
+    h->frame_arena.release();      // (arena mode: the four were views, this parks the one block)
     h->frames_released = true;
     // (a fold running on its worker thread allocates from its own cache: hand the parked blocks back to the driver)
     if (h->fold_pipe) dev_cache().trim();
@@ -163,9 +188,7 @@ int hmsg_create(const hmsg_config* cfg, hmsg_t** out) {
         HMSG_REQUIRE(cfg->device_id >= 0 && cfg->device_id < ndev, HMSG_ERR_INVALID, "device_id out of range");
         HIP_TRY(hipSetDevice(cfg->device_id));
         HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-        const size_t HW = (size_t)cfg->height * cfg->width;
-        h->rgb.alloc(HW * 3 * cfg->max_frames);
-        h->depth.alloc(HW * cfg->max_frames);
+        alloc_frame_store(h);
         h->pose.alloc((size_t)16 * cfg->max_frames);
     });
     if (rc != HMSG_OK) {
@@ -206,9 +229,7 @@ int hmsg_reset(hmsg_t* h) {
         h->n_tie_queries = 0;
         h->n_frames = h->n_feat_frames = h->n_fused = 0;
         if (h->frames_released) {              // (hmsg_merge_instances gave a very large frame store back)
-            const size_t HW = (size_t)h->cfg.height * h->cfg.width;
-            h->rgb.alloc(HW * 3 * h->cfg.max_frames);
-            h->depth.alloc(HW * h->cfg.max_frames);
+            alloc_frame_store(h);
             h->frames_released = false;
         }
         h->nmask.clear();

@@ -64,20 +64,95 @@ static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) 
 // point synchronises its stream before it returns and a handle is driven by one thread at a time.
 struct DevCache {
     std::multimap<std::pair<int, size_t>, void*> free_;   // (device, bytes) -> block
+    // Carving: a very large parked block (the frame store of a long episode, handed back before the merge) can be cut
+    // into pieces for large requests instead of going back to the driver -- a fresh hipMalloc costs ~28 ms per GB on this
+    // stack (49 GB: 1.4 s, measured), and the merge of a 10 000-frame episode asks for ~120 GB of arenas.  Only while
+    // `allow_carve` is set (the caller guarantees that everything it carves is released again before the big block is
+    // wanted back).  A piece can be parked and handed out like any block; it is never hipFree'd on its own: when every
+    // piece of a root is parked again they are merged back into the root.
+    struct Root {
+        size_t bytes = 0;
+        int dev = 0;
+    };
+    std::map<void*, Root> roots_;          // split blocks by base address
+    std::map<void*, void*> piece_root_;    // piece base -> root base (parked or handed out)
+    bool allow_carve = false;
+    // merge the pieces of every root whose pieces are ALL parked back into one block
+    void coalesce() {
+        if (roots_.empty()) return;
+        std::map<void*, size_t> parked;    // root -> parked bytes
+        for (auto& kv : free_) {
+            auto it = piece_root_.find(kv.second);
+            if (it != piece_root_.end()) parked[it->second] += kv.first.second;
+        }
+        for (auto it = roots_.begin(); it != roots_.end();) {
+            void* root = it->first;
+            if (parked[root] != it->second.bytes) {
+                ++it;
+                continue;
+            }
+            for (auto f = free_.begin(); f != free_.end();) {
+                auto pr = piece_root_.find(f->second);
+                if (pr != piece_root_.end() && pr->second == root) {
+                    piece_root_.erase(pr);
+                    f = free_.erase(f);
+                } else {
+                    ++f;
+                }
+            }
+            free_.insert({{it->second.dev, it->second.bytes}, root});
+            it = roots_.erase(it);
+        }
+    }
     // (no hipFree in a destructor: it would run at thread exit, possibly after the HIP runtime is gone)
     void trim() {
-        for (auto& kv : free_) (void)hipFree(kv.second);
-        free_.clear();
+        coalesce();
+        for (auto it = free_.begin(); it != free_.end();) {
+            if (piece_root_.count(it->second)) {       // a piece whose siblings are still in use: stays parked
+                ++it;
+                continue;
+            }
+            (void)hipFree(it->second);
+            it = free_.erase(it);
+        }
     }
     void* get(int dev, size_t bytes, size_t* got) {
         size_t gran = bytes < ((size_t)1 << 20) ? ((size_t)1 << 12) : ((size_t)1 << 21);
         size_t want = (bytes + gran - 1) / gran * gran;
+        if (!roots_.empty() && want >= ((size_t)1 << 28)) coalesce();     // (a cut-up block that is whole again)
         auto it = free_.lower_bound({dev, want});
         if (it != free_.end() && it->first.first == dev && it->first.second <= want * 2) {
             void* p = it->second;
             *got = it->first.second;
             free_.erase(it);
             return p;
+        }
+        if (allow_carve && want >= ((size_t)1 << 28)) {
+            coalesce();
+            // the largest parked block of this device
+            auto big = free_.end();
+            for (auto f = free_.begin(); f != free_.end(); ++f)
+                if (f->first.first == dev && f->first.second >= want &&
+                    (f->first.second >= ((size_t)8 << 30) || piece_root_.count(f->second)) &&
+                    (big == free_.end() || f->first.second > big->first.second))
+                    big = f;         // (only blocks of 8 GB and more are cut up -- and what is left of them)
+            if (big != free_.end()) {
+                void* base = big->second;
+                const size_t total = big->first.second;
+                free_.erase(big);
+                void* root = base;
+                auto pr = piece_root_.find(base);
+                if (pr != piece_root_.end()) root = pr->second;
+                else roots_[root] = Root{total, dev};
+                piece_root_[base] = root;
+                if (total > want) {
+                    void* rest = (char*)base + want;
+                    piece_root_[rest] = root;
+                    free_.insert({{dev, total - want}, rest});
+                }
+                *got = want;
+                return base;
+            }
         }
         void* p = nullptr;
         const bool timing = want >= ((size_t)1 << 28) && getenv("HMSG_DEBUG_TIMING") != nullptr;
@@ -94,8 +169,7 @@ struct DevCache {
             fprintf(stderr, "[hmsg alloc] %.1f MB did not fit (device free %.1f of %.1f GB): returning %.1f GB of parked blocks\n",
                     want / 1048576.0, fr / 1073741824.0, tot / 1073741824.0, parked / 1073741824.0);
             const auto t_b = std::chrono::steady_clock::now();
-            for (auto& kv : free_) (void)hipFree(kv.second);
-            free_.clear();
+            trim();
             const auto t_c = std::chrono::steady_clock::now();
             e = hipMalloc(&p, want);
             if (timing)
@@ -109,11 +183,21 @@ struct DevCache {
         return p;
     }
     void put(int dev, void* p, size_t bytes) { free_.insert({{dev, bytes}, p}); }
+    void swap_state(DevCache& o) {
+        free_.swap(o.free_);
+        roots_.swap(o.roots_);
+        piece_root_.swap(o.piece_root_);
+    }
 };
 inline DevCache& dev_cache() {
     static thread_local DevCache c;
     return c;
 }
+struct CarveScope {          // large requests inside the scope may be cut out of a very large parked block
+    bool prev;
+    CarveScope() : prev(dev_cache().allow_carve) { dev_cache().allow_carve = true; }
+    ~CarveScope() { dev_cache().allow_carve = prev; }
+};
 
 // ------------------------------------------------------------------ device buffer (owned)
 template <typename T>
@@ -122,15 +206,23 @@ struct DevBuf {
     size_t n = 0;
     size_t cap_bytes = 0;
     int dev = 0;
+    bool is_view = false;        // points into a block somebody else owns (the frame arena of a long episode)
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) dev_cache().put(dev, p, cap_bytes);
+        if (p && !is_view) dev_cache().put(dev, p, cap_bytes);
         p = nullptr;
         n = 0;
         cap_bytes = 0;
+        is_view = false;
+    }
+    void view(T* ptr, size_t count) {
+        release();
+        p = ptr;
+        n = count;
+        is_view = true;
     }
     void alloc(size_t count) {
         release();
@@ -144,6 +236,7 @@ struct DevBuf {
         std::swap(n, o.n);
         std::swap(cap_bytes, o.cap_bytes);
         std::swap(dev, o.dev);
+        std::swap(is_view, o.is_view);
     }
     void ensure(size_t count) {
         // scratch buffers: grow geometrically from a generous floor -- hipFree/hipMalloc synchronise the
@@ -410,6 +503,7 @@ struct hmsg_ctx {
     DevBuf<unsigned long long> bits;  // [F][H][W][NW] mask-membership bitset per pixel
     DevBuf<float> fp;              // [F][MS][D]  F_p
     DevBuf<int> nn;                // [F][H][W]   NN index into the filtered cloud (-1 invalid)
+    DevBuf<unsigned char> frame_arena;   // very large stores: rgb / depth / bits / nn are views into this ONE block (hmsg_api.hip)
     // global voxel map
     bool map_ready = false;
     GridGeom grid;

@@ -340,6 +340,7 @@ struct Merger {
     template <typename T>
     void grow(DevBuf<T>& b, size_t used_elems, size_t need_elems) {
         if (need_elems <= b.n) return;
+        CarveScope carve;           // (the merger's arenas die with it)
         DevBuf<T> nb;
         nb.alloc(std::max(need_elems * 2, (size_t)1 << 18));
         if (used_elems) HIP_TRY(hipMemcpyAsync(nb.p, b.p, used_elems * sizeof(T), hipMemcpyDeviceToDevice, s));
@@ -464,6 +465,7 @@ struct Merger {
         // parked in the allocator's cache and comes back at the next collection (two pools ping-pong, no hipMalloc)
         DevBuf<double> np;
         DevBuf<unsigned char> nc;
+        CarveScope carve;
         const size_t cap = std::max<size_t>((size_t)live + (size_t)live / 2, gc_pool_points + ((size_t)1 << 27));
         np.alloc(cap * 3);
         nc.alloc(cap);
@@ -987,6 +989,9 @@ static bool fold_begin(Folder& m, hmsg_ctx* h, std::vector<Cloud>& G, std::vecto
     if (n_clouds == 0 || live >= (1ll << 28) || n_clouds >= (1ll << 23)) return false;
     // (the fold's clouds keep room to grow and are relocated when they outgrow it: ~8 pool points per mask point over a
     //  1000-frame scene -- allocated once, growing a multi-GB buffer costs a fresh hipMalloc and a copy)
+    // (the arenas of the fold -- pool, hash, bricks, records: ~120 GB for a 10 000-frame episode -- are cut out of the frame
+    //  store's block when hmsg_merge_instances handed a very large one back: DevCache carving.  They all die with `m`.)
+    CarveScope carve;
     const size_t keep_gc = m.gc_pool_points;
     m.gc_pool_points = (size_t)live * 11;
     m.collect(G, frames, f_next);
@@ -1209,7 +1214,7 @@ struct FoldPipe {
         hipStream_t s = nullptr;
         // the fold's scratch lives in a cache of its own that stays with the handle from scene to scene (a service
         // rebuilds scenes over and over: only the first fold pays for its hipMallocs), apart from the calling thread's
-        dev_cache().free_.swap(h->fold_cache.free_);
+        dev_cache().swap_state(h->fold_cache);
         try {
             HIP_TRY(hipSetDevice(h->cfg.device_id));
             int lo = 0, hi = 0;
@@ -1262,7 +1267,7 @@ struct FoldPipe {
             (void)hipStreamSynchronize(s);
             (void)hipStreamDestroy(s);
         }
-        h->fold_cache.free_.swap(dev_cache().free_);
+        h->fold_cache.swap_state(dev_cache());
     }
     void push(std::unique_ptr<Batch> b) {
         std::vector<std::unique_ptr<Batch>> done;

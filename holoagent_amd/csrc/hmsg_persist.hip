@@ -307,3 +307,47 @@ extern "C" int64_t hmsg_test_format_doubles(const double* v, int64_t n, char* ou
     }
     return used;
 }
+
+// test hook (include/hmsg_test.h): DevCache carving
+extern "C" int hmsg_test_allocator_carving(int32_t device_id, int32_t root_gb) {
+    try {
+        HIP_TRY(hipSetDevice(device_id));
+        DevCache& c = dev_cache();
+        const size_t GB = (size_t)1 << 30, root_bytes = (size_t)root_gb * GB;
+        unsigned char* root = nullptr;
+        {
+            DevBuf<unsigned char> big;
+            big.alloc(root_bytes);
+            root = big.p;
+        }                                                       // parked
+        DevBuf<unsigned char> a, b, d;
+        {
+            CarveScope carve;
+            a.alloc(3 * GB);
+            b.alloc(GB);
+            d.alloc(2 * GB + 12345);
+        }
+        auto inside = [&](const DevBuf<unsigned char>& x) { return x.p >= root && x.p + x.cap_bytes <= root + root_bytes; };
+        if (!inside(a) || !inside(b) || !inside(d)) return 1;
+        if (!(a.p + a.cap_bytes <= b.p && b.p + b.cap_bytes <= d.p)) return 2;          // cut off the front, in order
+        DevBuf<unsigned char> e;
+        e.alloc(3 * GB);                                        // outside a scope: never carved (a block of its own)
+        if (inside(e)) return 3;
+        b.release();
+        c.trim();                                               // pieces out: the root must survive
+        if (c.roots_.size() != 1) return 4;
+        a.release();
+        d.release();
+        e.release();
+        DevBuf<unsigned char> again;
+        again.alloc(root_bytes);                                // every piece is back: the whole block, same address
+        if (again.p != root) return 5;
+        if (!c.roots_.empty() || !c.piece_root_.empty()) return 6;
+        again.release();
+        c.trim();
+        return 0;
+    } catch (const hmsg_error& e) {
+        fprintf(stderr, "hmsg_test_allocator_carving: %s\n", e.msg.c_str());
+        return -1;
+    }
+}

@@ -42,6 +42,12 @@ int hmsg_test_repeat_add(const double* s, const double* p, const int32_t* len, d
 int hmsg_test_ckdtree(const double* pts, int64_t n, const double* queries, int64_t nq, int64_t* out_idx,
                       int64_t* out_indices, int64_t* out_n_nodes);
 
+/* the caching allocator's carving of a very large parked block (the frame store of a long episode handed back before the
+ * merge: its block serves the merge's arenas instead of fresh hipMallocs): parks one block of `root_gb` GB, carves
+ * three requests out of it, checks that they lie inside it and are disjoint, that nothing can be freed while a piece is
+ * out, and that the block is whole again (same address) once every piece is back.  0 = ok, otherwise the failed check. */
+int hmsg_test_allocator_carving(int32_t device_id, int32_t root_gb);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,3 +47,20 @@ def test_no_cpu_fallback(tmp_path):
     from holoagent_amd._lib import HmsgError, HmsgLib
     with pytest.raises(HmsgError):
         HmsgLib(str(tmp_path / "libhmsg.so"))
+
+
+def test_allocator_carves_a_large_parked_block():
+    """DevCache carving (hmsg_common.h), on the kernel simulator (its hipMalloc is malloc: the 9 GB block is never touched)."""
+    import pytest
+    from tests import parity_common as PC
+    if not os.path.exists(PC.EMU_PATH):
+        pytest.skip("kernel simulator not built")
+    from holoagent_amd._lib import HmsgLib
+    L = HmsgLib(PC.EMU_PATH)
+    assert L.c.hmsg_test_allocator_carving(0, 9) == 0
+
+
+@pytest.mark.gpu
+def test_allocator_carves_a_large_parked_block_gpu():
+    from holoagent_amd._lib import HmsgLib
+    assert HmsgLib().c.hmsg_test_allocator_carving(0, 9) == 0
