@@ -140,7 +140,12 @@ int hmsg_get_frame_mask_sizes(const hmsg_t* h, int32_t frame, int64_t* sizes);
 int hmsg_get_frame_mask_points(const hmsg_t* h, int32_t frame, double* xyz);
 
 /* ---- A6: seq_merge / hierarchical_merge (graph_utils.py:918-1038) + small-cloud drop
- * (graph.py:445-448). */
+ * (graph.py:445-448).
+ * Threads: a handle is driven by one host thread at a time; distinct handles may be driven from distinct threads.  With
+ * merge_type sequential the library itself starts ONE worker thread per handle inside hmsg_fuse_frames: seq_merge's fold
+ * over the frames begins on the first frames' 3-D masks while the fusion is still producing the later ones (own HIP
+ * stream, nothing shared with the caller); hmsg_merge_instances waits for it, hmsg_reset / hmsg_destroy stop it.  The
+ * instances are the same either way (environment HMSG_FOLD_NOPIPE=1: no worker, the fold runs inside this call). */
 int hmsg_merge_instances(hmsg_t* h);
 int64_t hmsg_num_instances(const hmsg_t* h);
 int hmsg_get_instance_sizes(const hmsg_t* h, int64_t* sizes /*[N]*/);
