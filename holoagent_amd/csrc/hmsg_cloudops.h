@@ -12,6 +12,22 @@ struct SegDesc {                 // one cloud of a batch, points at src[pt_base 
     double mn[3], mx[3];         // AABB (host knows it: union of member boxes / reduction result)
 };
 
+// A batch assembled from pieces of a point pool: piece [src, src + n) of the pool goes to [dst, dst + n) of the batch
+// (the pieces tile the batch in order).  The merge concatenates the members of every component this way
+// (merge_point_clouds_list, graph_utils.py:667-679); dbscan_keep_largest can do the copy inside its binning pass.
+struct CatSeg {
+    long long src, dst;
+    int n, anchor;          // anchor: copy the member's persisted core flags (else the flags are cleared)
+    int blk0, pad;          // first workgroup of this segment (work list of k_concat)
+};
+struct DbGather {
+    const double* pool = nullptr;            // source points
+    const CatSeg* segs = nullptr;            // device table
+    int nsegs = 0;
+    const unsigned char* poolcore = nullptr; // persisted core flags of the pool points (anchor pieces)
+    unsigned char* dstcore = nullptr;        // core0 of the batch, written by the gather (may be null)
+};
+
 struct DbscanResult {            // per segment
     int n_out;
     double mn[3], mx[3];
@@ -56,7 +72,9 @@ struct CloudOps {
     // result is identical to a run without the hint.  dst_core (optional): core flag of every output point.
     long long dbscan_keep_largest(const double* src, const std::vector<SegDesc>& segs, double eps, int min_points,
                                   double* dst, std::vector<DbscanResult>& res, const unsigned char* core0 = nullptr,
-                                  unsigned char* dst_core = nullptr);
+                                  unsigned char* dst_core = nullptr, const DbGather* gather = nullptr);
+    // gather: `src` is an EMPTY buffer of the batch's size; the binning pass fills it (and core0's buffer, gather->dstcore)
+    // from the pool pieces while it bins -- one launch and one pass over the points less than a separate concatenation.
     // Open3D voxel_down_sample of every segment; outputs consecutively to dst (capacity >= total input
     // points); out_n[k] = points of segment k.
     long long voxel_down_sample(const double* src, const std::vector<SegDesc>& segs, double vs, double* dst,

@@ -37,9 +37,31 @@ __device__ __forceinline__ double dist2_f64(const double* __restrict__ a, const 
 }
 
 __global__ void k_db_cell(const double* __restrict__ pts, long long N, int* __restrict__ segid, int K,
-                          const DbSeg* __restrict__ segs, long long* __restrict__ cellid, unsigned* __restrict__ cnt) {
+                          const DbSeg* __restrict__ segs, long long* __restrict__ cellid, unsigned* __restrict__ cnt,
+                          DbGather ga, double* __restrict__ pts_out) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
+    double px, py, pz;
+    if (ga.segs) {                          // the batch is assembled here: point i comes from its piece of the pool
+        int a = 0, b = ga.nsegs - 1;
+        while (a < b) {
+            const int mid = (a + b + 1) >> 1;
+            if (ga.segs[mid].dst <= i) a = mid; else b = mid - 1;
+        }
+        const CatSeg cs = ga.segs[a];
+        const long long sp = cs.src + (i - cs.dst);
+        px = ga.pool[sp * 3];
+        py = ga.pool[sp * 3 + 1];
+        pz = ga.pool[sp * 3 + 2];
+        pts_out[i * 3] = px;
+        pts_out[i * 3 + 1] = py;
+        pts_out[i * 3 + 2] = pz;
+        if (ga.dstcore) ga.dstcore[i] = cs.anchor ? ga.poolcore[sp] : (unsigned char)0;
+    } else {
+        px = pts[i * 3];
+        py = pts[i * 3 + 1];
+        pz = pts[i * 3 + 2];
+    }
     int lo = 0, hi = K - 1;                 // segment of the point (segments tile [0, N) in order)
     while (lo < hi) {
         int mid = (lo + hi + 1) >> 1;
@@ -47,8 +69,7 @@ __global__ void k_db_cell(const double* __restrict__ pts, long long N, int* __re
     }
     segid[i] = lo;
     const DbSeg sg = segs[lo];
-    int ix = (int)floor((pts[i * 3] - sg.ox) / sg.cs), iy = (int)floor((pts[i * 3 + 1] - sg.oy) / sg.cs),
-        iz = (int)floor((pts[i * 3 + 2] - sg.oz) / sg.cs);
+    int ix = (int)floor((px - sg.ox) / sg.cs), iy = (int)floor((py - sg.oy) / sg.cs), iz = (int)floor((pz - sg.oz) / sg.cs);
     ix = ix < 0 ? 0 : (ix >= sg.nx ? sg.nx - 1 : ix);
     iy = iy < 0 ? 0 : (iy >= sg.ny ? sg.ny - 1 : iy);
     iz = iz < 0 ? 0 : (iz >= sg.nz ? sg.nz - 1 : iz);
@@ -278,10 +299,13 @@ __global__ void k_db_core(const double* __restrict__ pts, long long N, const int
     if (ncp) nclist[s_base[2] + off_ncp] = (unsigned)i;
 }
 
-// lowest anchor cell of every segment (one atomic per (wave, segment))
-__global__ void k_db_anchor_min(const int* __restrict__ corecells, const unsigned* __restrict__ ncore,
-                                const int* __restrict__ cseg, const DbSeg* __restrict__ segs, int K, const unsigned char* __restrict__ hasanchor,
-                                unsigned* __restrict__ rep) {
+// Anchor cells start out as ONE component per segment, in one launch: inside a wave the anchor cells of a segment hang
+// under the wave's lowest one; the wave minima are chained through rep[segment] -- an atomicMin hands back the lowest
+// cell seen so far: whichever of the two is higher hangs under the lower.  Every minimum is written by exactly one wave
+// (the one that either brought it in above the current minimum, or took the minimum over from it), parents are always
+// lower cells, and the chain ends at the segment's lowest anchor cell.
+__global__ void k_db_anchor(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, const int* __restrict__ cseg,
+                            const unsigned char* __restrict__ hasanchor, unsigned* __restrict__ rep, int* __restrict__ parent) {
     const unsigned n = *ncore;
     const unsigned stride = gridDim.x * blockDim.x;
     for (unsigned w0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); w0 < n; w0 += stride) {
@@ -290,10 +314,7 @@ __global__ void k_db_anchor_min(const int* __restrict__ corecells, const unsigne
         unsigned c = INF32;
         if (w < n) {
             c = (unsigned)corecells[w];
-            if (hasanchor[c]) {
-                const int lo = cseg[c];             // segment of the cell (written when the cell was registered)
-                seg = lo;
-            }
+            if (hasanchor[c]) seg = cseg[c];           // segment of the cell (written when the cell was registered)
         }
         unsigned long long todo = __ballot(seg >= 0);
         while (todo) {
@@ -306,22 +327,16 @@ __global__ void k_db_anchor_min(const int* __restrict__ corecells, const unsigne
                 unsigned t = __shfl_xor(v, o);
                 v = t < v ? t : v;
             }
-            if ((int)(threadIdx.x & 63) == leader) atomicMin(&rep[key], v);
+            if (mine_b && c != v) parent[c] = (int)v;
+            if ((int)(threadIdx.x & 63) == leader) {
+                const unsigned old = atomicMin(&rep[key], v);
+                if (old != INF32 && old != v) {
+                    if (old > v) parent[old] = (int)v;
+                    else parent[v] = (int)old;
+                }
+            }
             todo &= ~mine;
         }
-    }
-}
-
-// anchor cells start out as one component (root = the lowest anchor cell of the segment)
-__global__ void k_db_anchor(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, const int* __restrict__ cseg, const DbSeg* __restrict__ segs,
-                            int K, const unsigned char* __restrict__ hasanchor, const unsigned* __restrict__ rep,
-                            int* __restrict__ parent) {
-    const unsigned n = *ncore;
-    for (unsigned w = blockIdx.x * blockDim.x + threadIdx.x; w < n; w += gridDim.x * blockDim.x) {
-        const int c = corecells[w];
-        if (!hasanchor[c]) continue;
-        const int lo = cseg[c];             // segment of the cell (written when the cell was registered)
-        parent[c] = (int)rep[lo];
     }
 }
 
@@ -887,7 +902,7 @@ __global__ void k_db_init(DbInit in) {
 
 long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<SegDesc>& segs, double eps, int min_points,
                                         double* dst, std::vector<DbscanResult>& res, const unsigned char* core0,
-                                        unsigned char* dst_core) {
+                                        unsigned char* dst_core, const DbGather* gather) {
     const int K = (int)segs.size();
     res.assign(K, DbscanResult{});
     if (K == 0) return 0;
@@ -959,7 +974,8 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     }
     int maxn = 0;
     for (auto& sd : segs) maxn = std::max(maxn, sd.n);
-    hipLaunchKernelGGL(k_db_cell, dim3(gN), dim3(256), 0, s, src, N, segid.p, K, dsegs, cellid.p, cnt.p);
+    hipLaunchKernelGGL(k_db_cell, dim3(gN), dim3(256), 0, s, src, N, segid.p, K, dsegs, cellid.p, cnt.p, gather ? *gather : DbGather{},
+                       const_cast<double*>(src));
     HMSG_CHECK_LAUNCH();
     hmsg_scan_u32(cnt.p, start.p, (size_t)NC + 1, s, scan_tmp, nullptr);   // start[NC] = N (end sentinel)
     spts.ensure((size_t)N * 3);
@@ -992,12 +1008,9 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     hipLaunchKernelGGL(k_db_cellbox, dim3(gW), dim3(256), 0, s, (const double*)spts.p, (const int*)corelist.p,
                        (const unsigned*)d_nc, (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p,
                        (const unsigned char*)score.p, cellbox.p, ccore.p);
-    if (core0) {
-        hipLaunchKernelGGL(k_db_anchor_min, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc, (const int*)cseg.p, dsegs, K,
-                           (const unsigned char*)hasanchor.p, rep.p);
-        hipLaunchKernelGGL(k_db_anchor, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc, (const int*)cseg.p, dsegs, K,
-                           (const unsigned char*)hasanchor.p, (const unsigned*)rep.p, parent.p);
-    }
+    if (core0)
+        hipLaunchKernelGGL(k_db_anchor, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc, (const int*)cseg.p,
+                           (const unsigned char*)hasanchor.p, rep.p, parent.p);
     {
         ProfScope ps(prof, s, "k_db_union/box", (double)N * 24.0);
         hipLaunchKernelGGL(k_db_union, dim3(gW), dim3(256), 0, s, (const int*)actlist.p, (const unsigned*)d_nact, (const int*)cseg.p, dsegs, K,

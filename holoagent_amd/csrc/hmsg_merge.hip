@@ -217,11 +217,6 @@ __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __rest
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(&counts[ti], local);
 }
 
-struct CatSeg {
-    long long src, dst;
-    int n, anchor;          // anchor: copy the member's persisted core flags (else the flags are cleared)
-    int blk0, pad;          // first workgroup of this segment (work list)
-};
 static const int CAT_CHUNK = 512;      /* points per workgroup of k_concat */
 __global__ void k_concat(const double* __restrict__ pool, const CatSeg* __restrict__ segs, int nsegs, double* __restrict__ dst,
                          const unsigned char* __restrict__ poolcore, unsigned char* __restrict__ dstcore, int chunk) {
@@ -746,14 +741,18 @@ struct Merger {
             h_cat.ensure(cat.size());
             memcpy(h_cat.p, cat.data(), cat.size() * sizeof(CatSeg));
             HIP_TRY(hipMemcpyAsync(d_cat.p, h_cat.p, cat.size() * sizeof(CatSeg), hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(k_concat, dim3(cat_blocks), dim3(256), 0, s, (const double*)pool.p, (const CatSeg*)d_cat.p, (int)cat.size(),
-                               concat.p, (const unsigned char*)poolcore.p, use_anchor ? concat_core.p : nullptr, CAT_CHUNK);
-            HMSG_CHECK_LAUNCH();
+            // (the concatenation itself happens inside the DBSCAN batch's binning pass: DbGather)
             grow(pool, (size_t)pool_used * 3, (size_t)(pool_used + cat_total) * 3);
             grow(poolcore, (size_t)pool_used, (size_t)(pool_used + cat_total));
             lap(3);
+            DbGather ga;
+            ga.pool = pool.p;
+            ga.segs = (const CatSeg*)d_cat.p;
+            ga.nsegs = (int)cat.size();
+            ga.poolcore = poolcore.p;
+            ga.dstcore = use_anchor ? concat_core.p : nullptr;
             ops.dbscan_keep_largest(concat.p, segs, eps, minpts, pool.p + (size_t)pool_used * 3, res,
-                                    use_anchor ? (const unsigned char*)concat_core.p : nullptr, poolcore.p + pool_used);
+                                    use_anchor ? (const unsigned char*)concat_core.p : nullptr, poolcore.p + pool_used, &ga);
             lap(4);
             if (want_stats) {
                 for (size_t c = 0; c < comps.size(); ++c) {
