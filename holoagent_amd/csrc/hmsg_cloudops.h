@@ -22,7 +22,8 @@ struct CatSeg {
 };
 struct DbGather {
     const double* pool = nullptr;            // source points
-    const CatSeg* segs = nullptr;            // device table
+    const CatSeg* segs = nullptr;            // device table -- or
+    const CatSeg* host_segs = nullptr;       // the table on the host: it travels with the batch's geometry table (one upload)
     int nsegs = 0;
     const unsigned char* poolcore = nullptr; // persisted core flags of the pool points (anchor pieces)
     unsigned char* dstcore = nullptr;        // core0 of the batch, written by the gather (may be null)

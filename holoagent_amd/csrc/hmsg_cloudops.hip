@@ -937,10 +937,16 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     HMSG_REQUIRE(span_lo == 0 && span_hi == N, HMSG_ERR_INVALID, "dbscan: segments must tile the source buffer");
     HMSG_REQUIRE(NC < (1ll << 31) && N < (1ll << 31), HMSG_ERR_UNSUPPORTED, "dbscan batch too large");
     if (N == 0) return 0;
-    geom.ensure((size_t)K * sizeof(DbSeg));
-    h_geom.ensure((size_t)K * sizeof(DbSeg));          // (pinned staging; the previous batch ended with a wait on the stream)
+    // (pinned staging; the previous batch ended with a wait on the stream.  A gather table given on the host rides along.)
+    const size_t geom_bytes = ((size_t)K * sizeof(DbSeg) + 15) & ~(size_t)15;
+    const size_t cat_bytes = gather && gather->host_segs ? (size_t)gather->nsegs * sizeof(CatSeg) : 0;
+    geom.ensure(geom_bytes + cat_bytes);
+    h_geom.ensure(geom_bytes + cat_bytes);
     memcpy(h_geom.p, hs.data(), (size_t)K * sizeof(DbSeg));
-    HIP_TRY(hipMemcpyAsync(geom.p, h_geom.p, (size_t)K * sizeof(DbSeg), hipMemcpyHostToDevice, s));
+    if (cat_bytes) memcpy(h_geom.p + geom_bytes, gather->host_segs, cat_bytes);
+    HIP_TRY(hipMemcpyAsync(geom.p, h_geom.p, geom_bytes + cat_bytes, hipMemcpyHostToDevice, s));
+    DbGather ga_dev = gather ? *gather : DbGather{};
+    if (cat_bytes) ga_dev.segs = (const CatSeg*)(geom.p + geom_bytes);
     const DbSeg* dsegs = (const DbSeg*)geom.p;
     segid.ensure(N); cellid.ensure(N); ord.ensure(N); core.ensure(N); label.ensure(N); flags.ensure(N); pos.ensure(N);
     cnt.ensure(NC + 1); start.ensure(NC + 1); cursor.ensure(NC); minidx.ensure(NC); firstidx.ensure(NC); size.ensure(NC);
@@ -974,7 +980,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     }
     int maxn = 0;
     for (auto& sd : segs) maxn = std::max(maxn, sd.n);
-    hipLaunchKernelGGL(k_db_cell, dim3(gN), dim3(256), 0, s, src, N, segid.p, K, dsegs, cellid.p, cnt.p, gather ? *gather : DbGather{},
+    hipLaunchKernelGGL(k_db_cell, dim3(gN), dim3(256), 0, s, src, N, segid.p, K, dsegs, cellid.p, cnt.p, ga_dev,
                        const_cast<double*>(src));
     HMSG_CHECK_LAUNCH();
     hmsg_scan_u32(cnt.p, start.p, (size_t)NC + 1, s, scan_tmp, nullptr);   // start[NC] = N (end sentinel)

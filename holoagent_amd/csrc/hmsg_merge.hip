@@ -737,17 +737,14 @@ struct Merger {
         if (!segs.empty() && cat_total > 0) {
             concat.ensure((size_t)cat_total * 3);
             concat_core.ensure((size_t)cat_total);
-            d_cat.ensure(cat.size());
-            h_cat.ensure(cat.size());
-            memcpy(h_cat.p, cat.data(), cat.size() * sizeof(CatSeg));
-            HIP_TRY(hipMemcpyAsync(d_cat.p, h_cat.p, cat.size() * sizeof(CatSeg), hipMemcpyHostToDevice, s));
-            // (the concatenation itself happens inside the DBSCAN batch's binning pass: DbGather)
+            // (the concatenation itself happens inside the DBSCAN batch's binning pass, and the piece table goes up with the
+            //  batch's geometry table: DbGather)
             grow(pool, (size_t)pool_used * 3, (size_t)(pool_used + cat_total) * 3);
             grow(poolcore, (size_t)pool_used, (size_t)(pool_used + cat_total));
             lap(3);
             DbGather ga;
             ga.pool = pool.p;
-            ga.segs = (const CatSeg*)d_cat.p;
+            ga.host_segs = cat.data();
             ga.nsegs = (int)cat.size();
             ga.poolcore = poolcore.p;
             ga.dstcore = use_anchor ? concat_core.p : nullptr;
