@@ -37,6 +37,19 @@ struct DbscanResult {            // per segment
     int contested;               // some border point had cores of two clusters within eps (only looked for when n_clusters > 1)
 };
 
+// A few hundred bytes of results go from the device to the host without the copy engine: one small workgroup writes them
+// into pinned host memory, fences at system scope and raises a sequence flag the host spins on (a blit kernel + stream
+// event per read-back cost ~7 us of the merge fold's ~400 us step, twice per step).
+struct Publisher {
+    PinnedBuf<unsigned> buf;         // payload, then (last word) the flag
+    unsigned seq = 0;
+    const unsigned* inited = nullptr;
+    // enqueue on s: copy src[0 .. n) (device) to the host buffer; data() is valid after wait()
+    void launch(hipStream_t s, const unsigned* src, size_t n);
+    void wait();
+    const unsigned* data() const { return buf.p; }
+};
+
 struct CloudOps {
     hipStream_t s = nullptr;
     Prof* prof = nullptr;        // optional live timing of the heavy kernels
@@ -57,7 +70,7 @@ struct CloudOps {
     DevBuf<char> geom;           // device copy of per-segment geometry tables
     DevBuf<unsigned long long> vbitmap;
     DevBuf<unsigned> vrank;
-    PinnedBuf<unsigned> h_res;   // per-segment results of a DBSCAN batch (pinned: read back every fold step)
+    Publisher pub;               // per-segment results of a DBSCAN batch, read back every fold step
     PinnedBuf<char> h_geom;      // staging of the DBSCAN batch geometry table (uploaded every fold step)
     SpinWait spin;
     SortBufs vsort;              // ordered voxel sums: (slot, point index) records

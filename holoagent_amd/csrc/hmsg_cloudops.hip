@@ -900,6 +900,30 @@ __global__ void k_db_init(DbInit in) {
     if (i < 4) in.counters[i] = 0u;
 }
 
+__global__ void k_publish(const unsigned* __restrict__ src, int n, unsigned* __restrict__ dst_host, unsigned* __restrict__ flag_host,
+                          unsigned seq) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst_host[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void Publisher::launch(hipStream_t s, const unsigned* src, size_t n) {
+    buf.ensure(n + 32);                                       // (the flag sits behind the payload, on another cache line)
+    if (buf.p != inited) {                                    // fresh pinned memory: the flag must not look raised
+        buf.p[buf.n - 1] = 0u;
+        inited = buf.p;
+    }
+    ++seq;
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, s, src, (int)n, buf.p, buf.p + buf.n - 1, seq);
+    HMSG_CHECK_LAUNCH();
+}
+void Publisher::wait() {
+    volatile unsigned* flag = buf.p + buf.n - 1;
+    while (*flag != seq) {
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+}
+
 long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<SegDesc>& segs, double eps, int min_points,
                                         double* dst, std::vector<DbscanResult>& res, const unsigned char* core0,
                                         unsigned char* dst_core, const DbGather* gather) {
@@ -1070,10 +1094,9 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
         ++call_no;
     }
     // one copy brings back counts, cluster counts, contest flags and the boxes of the kept points
-    h_res.ensure((size_t)K * 16 + 2);
-    unsigned* hres = h_res.p;
-    HIP_TRY(hipMemcpyAsync(hres, kres.p, ((size_t)K * 16 + 2) * 4, hipMemcpyDeviceToHost, s));
-    spin.wait(s);
+    pub.launch(s, (const unsigned*)kres.p, (size_t)K * 16 + 2);
+    pub.wait();
+    const unsigned* hres = pub.data();
     const unsigned long long* hb = reinterpret_cast<const unsigned long long*>(hres + (size_t)K * 4);
     stat_calls += 1;
     stat_points += N;

@@ -1761,10 +1761,9 @@ struct Folder : Merger {
             }
         }
         HMSG_CHECK_LAUNCH();
-        h_counts.ensure(tasks.size());
-        unsigned* hc = h_counts.p;
-        HIP_TRY(hipMemcpyAsync(hc, dc, tasks.size() * 4, hipMemcpyDeviceToHost, s));
-        spin.wait(s);
+        pub_counts.launch(s, (const unsigned*)dc, tasks.size());
+        pub_counts.wait();
+        const unsigned* hc = pub_counts.data();
         double ov_work = 0;
         for (size_t k = 0; k < P; ++k) {
             const int na = std::min(L[pairs[k].first].n, L[pairs[k].second].n), nb = std::max(L[pairs[k].first].n, L[pairs[k].second].n);

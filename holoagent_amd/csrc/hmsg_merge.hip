@@ -303,7 +303,7 @@ struct Merger {
     PinnedBuf<CatSeg> h_cat;
     DevBuf<unsigned> d_cursor;
     DevBuf<CatSeg> d_cat;
-    PinnedBuf<unsigned> h_counts;
+    Publisher pub_counts;           // overlap counts of a step, read back through pinned memory (hmsg_cloudops.h)
     // one packed upload per overlap step: [grids | tasks | zeroed counts], staged in pinned memory (the previous step's
     // copy has completed: every overlap step ends with a wait on the stream)
     PinnedBuf<char> h_ovpack;
@@ -541,10 +541,9 @@ struct Merger {
             }
         }
         HMSG_CHECK_LAUNCH();
-        h_counts.ensure(tasks.size());
-        unsigned* hc = h_counts.p;
-        HIP_TRY(hipMemcpyAsync(hc, dc, tasks.size() * 4, hipMemcpyDeviceToHost, s));
-        spin.wait(s);
+        pub_counts.launch(s, (const unsigned*)dc, tasks.size());
+        pub_counts.wait();
+        const unsigned* hc = pub_counts.data();
         double ov_work = 0;                                  // 12 B per point of every scan the decision needed
         for (size_t k = 0; k < P; ++k) {
             const int na = std::min(L[pairs[k].first].n, L[pairs[k].second].n), nb = std::max(L[pairs[k].first].n, L[pairs[k].second].n);

@@ -28,6 +28,9 @@ using std::min;
 #ifndef __HIP_MEMORY_SCOPE_AGENT
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #endif
+#ifndef __HIP_MEMORY_SCOPE_SYSTEM
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+#endif
 #define __global__
 #define __device__
 #define __host__
@@ -391,6 +394,7 @@ static inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 
 // ---------------------------------------------------------------- device intrinsics
 static inline void __syncthreads() { hipemu::block_barrier(); }
 static inline void __threadfence() {}
+static inline void __threadfence_system() {}
 template <typename T> static inline T __shfl(T v, int src, int = 64) { return hipemu::exchange(v, src); }
 template <typename T> static inline T __shfl_xor(T v, int m, int = 64) { return hipemu::exchange(v, (hipemu::lin_tid() & 63) ^ m); }
 template <typename T> static inline T __shfl_down(T v, unsigned d, int = 64) { int l = hipemu::lin_tid() & 63; return hipemu::exchange(v, l + (int)d < 64 ? l + (int)d : l); }
