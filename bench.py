@@ -372,8 +372,7 @@ def main():
     # leaves the chip almost idle for ~60 % of a scene's build; a service that builds scene after scene fills that time
     # with the next scene's map / fusion on a second handle (own stream, own allocator cache, own fold worker).  Two host
     # threads, one handle each, `--inflight-steps` full scenes per thread from a common start; throughput = scenes / wall.
-    inflight = None
-    if not episode and not use_dist and args.inflight_steps > 0:
+    def measure_inflight():
         import threading
         handles = [sc] + [Scene(lib_=L, device_id=local, height=spec.height, width=spec.width, max_frames=F, max_masks=32, feat_dim=D, merge_type=0)
                           for _ in range(max(args.inflight, 2) - 1)]
@@ -417,12 +416,19 @@ def main():
         dt2 = time.perf_counter() - tt
         for hx in handles[1:]:
             hx.close()
-        if not errs:
-            nh = len(handles)
-            inflight = dict(scenes_in_flight=nh, scenes=nh * args.inflight_steps, seconds=round(dt2, 3),
-                            frames_per_s=round(nh * args.inflight_steps * F / dt2, 1),
-                            note="%d handles driven by %d host threads on this one GPU, every scene built and queried in full; "
-                                 "`value` above is ONE scene at a time" % (nh, nh))
+        if errs:
+            return dict(error="; ".join(errs))
+        nh = len(handles)
+        return dict(scenes_in_flight=nh, scenes=nh * args.inflight_steps, seconds=round(dt2, 3),
+                    frames_per_s=round(nh * args.inflight_steps * F / dt2, 1),
+                    note="%d handles driven by %d host threads on this one GPU, every scene built and queried in full; "
+                         "`value` above is ONE scene at a time" % (nh, nh))
+
+    inflight = None
+    try:
+        inflight = measure_inflight() if (not episode and not use_dist and args.inflight_steps > 0) else None
+    except Exception as e:          # (an extra: it must never take the benchmark line down)
+        inflight = dict(error=repr(e))
 
     # ---- CPU baseline: the oracle on a bounded sample of the same frames (rank 0, N=1)
     cpu = None
