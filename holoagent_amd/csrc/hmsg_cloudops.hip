@@ -439,22 +439,49 @@ __global__ void k_db_union(const int* __restrict__ corecells, const unsigned* __
         const int rc = uf_find_cached(parent, (int)c);       // (may go stale: only costs a redundant uf_union)
         double ba[6];
         for (int a = 0; a < 6; ++a) ba[a] = cellbox[(size_t)cellpos[c] * 6 + a];
-        for (int o = lane; o < 125; o += 64) {
+        // both of the lane's neighbour cells (o = lane and lane + 64) in one straight-line pass: their table entries, their
+        // boxes and their root walks are independent chains of L2 round trips, issued side by side instead of one trip after
+        // the other (the kernel lasts as long as a lane's chain: 39 -> ~30 us per fold step)
+        long long c2[2];
+        bool ok[2];
+        unsigned mi[2] = {INF32, INF32}, ac[2] = {0u, 0u};
+        int p2[2] = {0, 0}, cp2[2] = {0, 0};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int o = lane + 64 * q;
             const int dx = o / 25 - 2, dy = (o / 5) % 5 - 2, dz = o % 5 - 2;
             const int jx = ix + dx, jy = iy + dy, jz = iz + dz;
-            if (o == 62 || jx < 0 || jy < 0 || jz < 0 || jx >= sg.nx || jy >= sg.ny || jz >= sg.nz) continue;   // 62: the cell itself
-            const long long c2 = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz + jz;
-            const unsigned mi = minidx[c2], ac = active[c2];
-            const int p2 = parent[c2], cp2 = cellpos[c2];     // (garbage unless c2 is a core cell; not used then)
-            if (mi == INF32 || (c2 < c && ac)) continue;
-            if (uf_find_cached(parent, p2) == rc) continue;
-            const double* bb = cellbox + (size_t)cp2 * 6;
+            ok[q] = o < 125 && o != 62 && jx >= 0 && jy >= 0 && jz >= 0 && jx < sg.nx && jy < sg.ny && jz < sg.nz;   // 62: the cell itself
+            c2[q] = ok[q] ? sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz + jz : c;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (ok[q]) {
+                mi[q] = minidx[c2[q]];
+                ac[q] = active[c2[q]];
+                p2[q] = parent[c2[q]];
+                cp2[q] = cellpos[c2[q]];         // (garbage unless c2 is a core cell; not used then)
+            }
+        double bb[2][6];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            ok[q] = ok[q] && mi[q] != INF32 && !(c2[q] < c && ac[q]);
+            if (ok[q])
+                for (int a = 0; a < 6; ++a) bb[q][a] = cellbox[(size_t)cp2[q] * 6 + a];
+        }
+        int r2[2] = {rc, rc};
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (ok[q]) r2[q] = uf_find_cached(parent, p2[q]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (!ok[q] || r2[q] == rc) continue;
             double mx2 = 0.0;
             for (int a = 0; a < 3; ++a) {
-                double far = fmax(ba[3 + a] - bb[a], bb[3 + a] - ba[a]);
+                double far = fmax(ba[3 + a] - bb[q][a], bb[q][3 + a] - ba[a]);
                 mx2 += far * far;
             }
-            if (mx2 < eps2 * (1.0 - 1e-12)) uf_union(parent, (int)c, (int)c2);
+            if (mx2 < eps2 * (1.0 - 1e-12)) uf_union(parent, (int)c, (int)c2[q]);
         }
     }
 }
