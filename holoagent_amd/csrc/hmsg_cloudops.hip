@@ -364,16 +364,22 @@ __device__ __forceinline__ int uf_find_cached(const int* parent, int x) {
     }
     return x;
 }
-__device__ __forceinline__ void uf_union(int* parent, int a, int b) {
+// Which of two roots stays a root is a fixed total order over the cells (concurrent CASes cannot close a cycle): cells that
+// hold ANCHOR cores come first, then the lower index.  The anchor cells of a segment are one component from the start
+// (k_db_anchor, rooted at the lowest of them), so that root never moves and every active cell that joins the anchor's
+// cluster CASes its OWN parent word.  (With plain index order every active cell below the anchor's root took the root over
+// in turn, thousands of waves retrying on one word: two thirds of k_db_union's time.)
+__device__ __forceinline__ void uf_union(int* parent, int a, int b, const unsigned char* __restrict__ pri) {
     a = uf_find_cached(parent, a);
     b = uf_find_cached(parent, b);
     for (;;) {
         if (a == b) return;
-        if (a < b) {
+        const unsigned char pa = pri[a], pb = pri[b];
+        if (pa > pb || (pa == pb && a < b)) {
             int t = a;
             a = b;
             b = t;
-        }                                   // a > b: hang the larger root under the smaller
+        }                                   // b stays a root: hang a under it
         if (atomicCAS(&parent[a], a, b) == a) return;
         a = uf_find(parent, a);
         b = uf_find(parent, b);
@@ -425,7 +431,8 @@ __global__ void k_db_cellbox(const double* __restrict__ pts, const int* __restri
 // chain of L2 round trips, and the kernel lasts as long as the longest chain.
 __global__ void k_db_union(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, const int* __restrict__ cseg, const DbSeg* __restrict__ segs,
                            int K, const unsigned* __restrict__ minidx, double eps2, const int* __restrict__ cellpos,
-                           const double* __restrict__ cellbox, int* __restrict__ parent, const unsigned* __restrict__ active) {
+                           const double* __restrict__ cellbox, int* __restrict__ parent, const unsigned* __restrict__ active,
+                           const unsigned char* __restrict__ hasanchor) {
     const int lane = threadIdx.x & 63;
     const unsigned nwaves = (gridDim.x * blockDim.x) >> 6, ncells = *ncore;
     // (two waves per cell, 64 neighbour cells each, was tried: 40 -> 48 us per step -- the per-wave preamble and the
@@ -473,15 +480,29 @@ __global__ void k_db_union(const int* __restrict__ corecells, const unsigned* __
 #pragma unroll
         for (int q = 0; q < 2; ++q)
             if (ok[q]) r2[q] = uf_find_cached(parent, p2[q]);
+        // The wave works for ONE cell: every lane whose neighbour passes the box test would unite c with it, and almost all
+        // of those neighbours already share one root (the anchor's) -- 60 lanes then fail the same CAS on parent[c] and walk
+        // the chain again with atomic loads, which was two thirds of this kernel's time.  One union per DISTINCT neighbour
+        // root is enough: equal (even stale) roots prove two cells connected.
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            if (!ok[q] || r2[q] == rc) continue;
-            double mx2 = 0.0;
-            for (int a = 0; a < 3; ++a) {
-                double far = fmax(ba[3 + a] - bb[q][a], bb[q][3 + a] - ba[a]);
-                mx2 += far * far;
+            bool want = false;
+            if (ok[q] && r2[q] != rc) {
+                double mx2 = 0.0;
+                for (int a = 0; a < 3; ++a) {
+                    double far = fmax(ba[3 + a] - bb[q][a], bb[q][3 + a] - ba[a]);
+                    mx2 += far * far;
+                }
+                want = mx2 < eps2 * (1.0 - 1e-12);
             }
-            if (mx2 < eps2 * (1.0 - 1e-12)) uf_union(parent, (int)c, (int)c2[q]);
+            unsigned long long todo = __ballot(want);
+            while (todo) {
+                const int leader = __ffsll(todo) - 1;
+                const int key = __shfl(r2[q], leader);
+                const unsigned long long same = __ballot(want && r2[q] == key);
+                if (lane == leader) uf_union(parent, (int)c, (int)c2[q], hasanchor);
+                todo &= ~same;
+            }
         }
     }
 }
@@ -496,7 +517,7 @@ __global__ void k_db_union_scan(const double* __restrict__ pts, const int* __res
                                 const unsigned* __restrict__ ord, const unsigned char* __restrict__ core,
                                 const unsigned* __restrict__ minidx, double eps2, const int* __restrict__ cellpos,
                                 const double* __restrict__ cellbox, int* __restrict__ parent,
-                                const unsigned* __restrict__ active) {
+                                const unsigned* __restrict__ active, const unsigned char* __restrict__ hasanchor) {
     const int lane = threadIdx.x & 63;
     const unsigned nwaves = (gridDim.x * blockDim.x) >> 6, ncells = *ncore;
     for (unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < ncells; w += nwaves) {
@@ -570,7 +591,7 @@ __global__ void k_db_union_scan(const double* __restrict__ pts, const int* __res
                     break;
                 }
             }
-            if (hit && lane == 0) uf_union(parent, (int)c, (int)c2);
+            if (hit && lane == 0) uf_union(parent, (int)c, (int)c2, hasanchor);
           }
         }
     }
@@ -1072,14 +1093,15 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
         ProfScope ps(prof, s, "k_db_union/box", (double)N * 24.0);
         hipLaunchKernelGGL(k_db_union, dim3(gW), dim3(256), 0, s, (const int*)actlist.p, (const unsigned*)d_nact, (const int*)cseg.p, dsegs, K,
                            (const unsigned*)minidx.p, eps * eps, (const int*)cellpos.p, (const double*)cellbox.p, parent.p,
-                           (const unsigned*)active.p);
+                           (const unsigned*)active.p, (const unsigned char*)hasanchor.p);
     }
     {
         ProfScope ps(prof, s, "k_db_union/scan", (double)N * 24.0);
         hipLaunchKernelGGL(k_db_union_scan, dim3(gW), dim3(256), 0, s, (const double*)spts.p, (const int*)actlist.p,
                            (const unsigned*)d_nact, (const int*)cseg.p, dsegs, K, (const unsigned*)cnt.p, (const unsigned*)start.p,
                            (const unsigned*)ord.p, (const unsigned char*)score.p, (const unsigned*)minidx.p, eps * eps,
-                           (const int*)cellpos.p, (const double*)cellbox.p, parent.p, (const unsigned*)active.p);
+                           (const int*)cellpos.p, (const double*)cellbox.p, parent.p, (const unsigned*)active.p,
+                           (const unsigned char*)hasanchor.p);
     }
     hipLaunchKernelGGL(k_db_rootmin, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc,
                        parent.p, (const unsigned*)minidx.p, rootmin.p, (const int*)cseg.p, dsegs, K, d_ncl, (const unsigned*)ccore.p, size.p);
