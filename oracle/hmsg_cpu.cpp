@@ -8,7 +8,7 @@
 // (`workers=-1`), the radius counts, the BLAS-backed similarity products.
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may load it; the product (holoagent_amd/) never does.
 // tests/test_cpu_restatement.py pins it against the fixtures the REFERENCE's own Python produced (tests/golden/build_seq,
-// build_ragged: map cloud and merged instances bit for bit, pooled features to 1e-5) and against hmsg_oracle.py on a
+// build_hier, build_ragged: map cloud and merged instances bit for bit, pooled features to 1e-5) and against hmsg_oracle.py on a
 // synthetic scene (3-D masks bit for bit too, retrieval indices exactly).  Open3D / faiss / sklearn internals are restated
 // from their published algorithms exactly as hmsg_oracle.py does (see its header): unpinned there, unpinned here.
 //
@@ -401,8 +401,8 @@ void merge_3d_masks(std::vector<Cloud>& L, double th, double radius, double iou_
 }
 
 struct Cfg {
-    int32_t H, W, D, outlier_nb, feat_dbscan_min, n_threads;
-    double voxel_size, masked_weight, max_mask_distance, init_overlap_thresh, iou_thresh, outlier_radius;
+    int32_t H, W, D, outlier_nb, feat_dbscan_min, merge_hierarchical;
+    double voxel_size, masked_weight, max_mask_distance, init_overlap_thresh, iou_thresh, outlier_radius, overlap_thresh_factor;
 };
 
 inline float f16_round(float v) { return _cvtsh_ss(_cvtss_sh(v, _MM_FROUND_TO_NEAREST_INT)); }
@@ -565,11 +565,36 @@ void* hmsg_cpu_build(const Cfg* cfg, int32_t F, int32_t M, const uint8_t* rgb, c
     }
     // ---- A6 seq_merge (graph_utils.py:1015-1038)
     std::vector<Cloud> G;
-    for (int f = 0; f < F; ++f) {
-        for (int i = cx->frame_first[(size_t)f]; i < cx->frame_first[(size_t)f + 1]; ++i) G.push_back(cx->frames_masks[(size_t)i]);
-        if (f > 0) merge_3d_masks(G, cfg->init_overlap_thresh, cfg->voxel_size, cfg->iou_thresh);
+    if (cfg->merge_hierarchical) {
+        // hierarchical_merge (graph_utils.py:959-1012): adjacent lists pairwise, level by level, the threshold lowered per level
+        std::vector<std::vector<Cloud>> lv((size_t)F);
+        for (int f = 0; f < F; ++f)
+            for (int i = cx->frame_first[(size_t)f]; i < cx->frame_first[(size_t)f + 1]; ++i) lv[(size_t)f].push_back(cx->frames_masks[(size_t)i]);
+        double th = cfg->init_overlap_thresh;
+        while (lv.size() > 1) {
+            std::vector<std::vector<Cloud>> nx;
+            for (size_t i = 0; i < lv.size(); i += 2) {
+                if (i == lv.size() - 1) {
+                    nx.push_back(std::move(lv[i]));
+                    break;
+                }
+                std::vector<Cloud> L = std::move(lv[i]);
+                L.insert(L.end(), lv[i + 1].begin(), lv[i + 1].end());
+                merge_3d_masks(L, th, cfg->voxel_size, cfg->iou_thresh);
+                nx.push_back(std::move(L));
+            }
+            lv = std::move(nx);
+            if (lv.size() > 1) th -= cfg->overlap_thresh_factor * (double)((long long)lv.size() - 2) / (double)std::max<long long>(1, (long long)lv.size() - 1);
+        }
+        G = std::move(lv[0]);
+        merge_3d_masks(G, 0.75, cfg->voxel_size, cfg->iou_thresh);
+    } else {
+        for (int f = 0; f < F; ++f) {
+            for (int i = cx->frame_first[(size_t)f]; i < cx->frame_first[(size_t)f + 1]; ++i) G.push_back(cx->frames_masks[(size_t)i]);
+            if (f > 0) merge_3d_masks(G, cfg->init_overlap_thresh, cfg->voxel_size, cfg->iou_thresh);
+        }
+        merge_3d_masks(G, cfg->init_overlap_thresh, cfg->voxel_size, cfg->iou_thresh);
     }
-    merge_3d_masks(G, cfg->init_overlap_thresh, cfg->voxel_size, cfg->iou_thresh);
     for (auto& c : G)
         if (c.n() >= 10) cx->inst.push_back(c);                            // graph.py:445-448
     // ---- A7 pooling (graph.py:450-488, graph_utils.py:682-728)

@@ -21,8 +21,9 @@ def build(force=False):
 
 class _Cfg(C.Structure):
     _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("D", C.c_int32), ("outlier_nb", C.c_int32), ("feat_dbscan_min", C.c_int32),
-                ("n_threads", C.c_int32), ("voxel_size", C.c_double), ("masked_weight", C.c_double), ("max_mask_distance", C.c_double),
-                ("init_overlap_thresh", C.c_double), ("iou_thresh", C.c_double), ("outlier_radius", C.c_double)]
+                ("merge_hierarchical", C.c_int32), ("voxel_size", C.c_double), ("masked_weight", C.c_double), ("max_mask_distance", C.c_double),
+                ("init_overlap_thresh", C.c_double), ("iou_thresh", C.c_double), ("outlier_radius", C.c_double),
+                ("overlap_thresh_factor", C.c_double)]
 
 
 _P = C.c_void_p
@@ -61,10 +62,10 @@ class CpuBuild:
         fg = np.ascontiguousarray(np.stack([np.asarray(f["f_g"], np.float32).reshape(-1) for f in frames]))
         fm = np.ascontiguousarray(np.stack([pad(np.asarray(f["f_masked"], np.float32).reshape(-1, D), (D,)) for f in frames]))
         fc = np.ascontiguousarray(np.stack([pad(np.asarray(f["f_crop"], np.float32).reshape(-1, D), (D,)) for f in frames]))
-        c = _Cfg(H, W, D, int(cfg.get("outlier_nb", 1000)), int(feat_dbscan_min), 0, float(cfg["voxel_size"]),
-                 float(cfg["clip_masked_weight"]), float(cfg["max_mask_distance"]), float(cfg["init_overlap_thresh"]),
-                 float(cfg["iou_thresh"]), float(cfg.get("outlier_radius", 1.0)))
-        assert cfg.get("merge_type", "sequential") == "sequential", "the compiled restatement covers seq_merge"
+        c = _Cfg(H, W, D, int(cfg.get("outlier_nb", 1000)), int(feat_dbscan_min), int(cfg.get("merge_type", "sequential") == "hierarchical"),
+                 float(cfg["voxel_size"]), float(cfg["clip_masked_weight"]), float(cfg["max_mask_distance"]),
+                 float(cfg["init_overlap_thresh"]), float(cfg["iou_thresh"]), float(cfg.get("outlier_radius", 1.0)),
+                 float(cfg.get("overlap_thresh_factor", 0.025)))
         self.h = _P(L.hmsg_cpu_build(C.byref(c), F, M, _ptr(rgb), _ptr(dep), _ptr(pose), _ptr(K), _ptr(masks), _ptr(nm), _ptr(fg),
                                      _ptr(fm), _ptr(fc)))
 

@@ -1,5 +1,5 @@
 """The compiled CPU restatement of the path (oracle/hmsg_cpu.cpp -- what bench.py times as `cpu_baseline`) against the
-fixtures the REFERENCE's own Python produced (tests/golden/build_seq, build_ragged: oracle/refdrive/gen_golden.py) and
+fixtures the REFERENCE's own Python produced (tests/golden/build_seq, build_hier, build_ragged: oracle/refdrive/gen_golden.py) and
 against the numpy oracle on a synthetic scene: the map cloud and the merged instances bit for bit, the voxel feature map
 within the fp16 knife edge, pooled instance features within 1e-5, retrieval indices exactly.  CPU only."""
 import numpy as np
@@ -10,7 +10,7 @@ from oracle.hmsg_cpu import CpuBuild
 from tests import golden_io as GI
 
 
-@pytest.mark.parametrize("name", ["build_seq", "build_ragged"])
+@pytest.mark.parametrize("name", ["build_seq", "build_hier", "build_ragged"])
 def test_cpp_restatement_matches_reference_run(name):
     z = GI.load(name)
     frames = GI.unpack_frames(z)
