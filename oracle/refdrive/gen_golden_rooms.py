@@ -1,0 +1,206 @@
+"""Golden vectors for the ROOM level (A9 + N1): the reference's own Graph.segment_hmsg_room (graph.py:920-1189) and
+distance_transform (graph_utils.py:391-487) run end to end on a synthetic storey.
+
+OpenCV is absent from this image (and un-vendored in the reference): as for Open3D / faiss (fake_backends.py) a stand-in
+`cv2` module restating the documented semantics of exactly the calls the two functions make is injected under the
+reference's call sites -- built from the SAME restatement the oracle uses (oracle/rooms_oracle.py), function by function.
+What the fixture pins is therefore everything the reference does AROUND those calls: the slab slices, the histogram
+bins and their orientation, the 10-pixel border, the order of the morphology, the seed filter's area rule, the
+background marker, map_grid_to_point_cloud's (-10.5 cell) offset, the extrusion + rotation + nearest-neighbour selection of
+the room clouds, the camera -> room assignment and KMeans views of compute_room_embeddings, Room fields and View ids.
+
+    python -m oracle.refdrive.gen_golden_rooms        # writes tests/golden/rooms.npz
+"""
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path.insert(0, ROOT)
+from oracle import rooms_oracle as RO                      # noqa: E402
+from oracle.refdrive.gen_golden import AttrDict, import_reference   # noqa: E402
+
+
+class Contour:
+    """What findContours hands to drawContours / contourArea here: the filled outer component (a boolean image)."""
+
+    def __init__(self, mask):
+        self.mask = mask
+
+
+def make_cv2():
+    from scipy import ndimage
+    cv2 = types.ModuleType("cv2")
+    cv2.NORM_MINMAX, cv2.THRESH_BINARY, cv2.THRESH_OTSU, cv2.BORDER_CONSTANT = 32, 0, 8, 0
+    cv2.MORPH_RECT, cv2.MORPH_CROSS, cv2.MORPH_CLOSE = 0, 1, 3
+    cv2.RETR_EXTERNAL, cv2.CHAIN_APPROX_SIMPLE, cv2.DIST_L2, cv2.DIST_MASK_PRECISE, cv2.COLOR_GRAY2BGR = 0, 2, 2, 0, 8
+
+    def normalize(src, dst, alpha, beta, norm_type):
+        assert (alpha, beta, norm_type) == (0, 255, cv2.NORM_MINMAX)
+        a = np.asarray(src)
+        lo, hi = float(a.min()), float(a.max())
+        sc = 255.0 * (1.0 / (hi - lo)) if hi > lo else 0.0
+        if a.dtype == np.float32:                      # double scale / shift applied in float32 (distance image)
+            out = (a * np.float32(sc) + np.float32(0.0 - lo * sc)).astype(np.float32)
+        else:
+            out = a.astype(np.float64) * sc + (0.0 - lo * sc)
+        dst[...] = out                                  # (the reference relies on the in-place form for `dist`)
+        return dst
+
+    def GaussianBlur(img, ksize, sigma):
+        return RO._blur_u8(np.asarray(img, np.uint8), ksize[0], ksize[1], float(sigma))
+
+    def threshold(img, thresh, maxval, kind):
+        img = np.asarray(img)
+        t = RO._otsu(img) if kind & cv2.THRESH_OTSU else thresh
+        return t, np.where(img > t, maxval, 0).astype(np.uint8)
+
+    def copyMakeBorder(img, top, bottom, left, right, kind, value=0):
+        assert (top, bottom, left, right, kind, value) == (10, 10, 10, 10, cv2.BORDER_CONSTANT, 0)
+        return RO._pad10(img)
+
+    def getStructuringElement(shape, ksize):
+        return ("cross" if shape == cv2.MORPH_CROSS else "rect", ksize[0])
+
+    def morphologyEx(img, op, kernel, iterations=1):
+        assert op == cv2.MORPH_CLOSE
+        return RO._close(img, kernel[0], kernel[1], iterations)
+
+    def findContours(img, mode, method):
+        assert mode == cv2.RETR_EXTERNAL
+        F = RO._fill_external(np.asarray(img)) > 0
+        lab, n = ndimage.label(F, structure=np.ones((3, 3), bool))
+        return [Contour(lab == i) for i in range(1, n + 1)][::-1], None     # (reverse discovery order, as rooms_oracle states)
+
+    def contourArea(c):
+        inner = ndimage.binary_erosion(c.mask, structure=np.ones((3, 3), bool), border_value=0)
+        return int(c.mask.sum()) - int((c.mask & ~inner).sum()) / 2.0 - 1.0
+
+    def drawContours(img, contours, idx, color, thickness):
+        assert thickness == -1
+        v = color[0] if isinstance(color, (tuple, list)) else color
+        for k, c in enumerate(contours):
+            if idx == -1 or k == idx:
+                img[c.mask] = v
+        return img
+
+    def distanceTransform(bw, dist_type, mask):
+        return RO._edt(np.asarray(bw) > 0)
+
+    def circle(img, centre, radius, value, thickness):
+        yy, xx = np.ogrid[:img.shape[0], :img.shape[1]]
+        img[(yy - centre[1]) ** 2 + (xx - centre[0]) ** 2 <= radius * radius] = value
+        return img
+
+    def cvtColor(img, code):
+        return np.stack([img, img, img], axis=-1)
+
+    def watershed(img, markers):
+        markers[...] = RO.watershed_sync(np.asarray(img[..., 0], np.int32), markers)
+        return markers
+    cv2.normalize, cv2.GaussianBlur, cv2.threshold, cv2.copyMakeBorder = normalize, GaussianBlur, threshold, copyMakeBorder
+    cv2.getStructuringElement, cv2.morphologyEx, cv2.findContours, cv2.contourArea = getStructuringElement, morphologyEx, findContours, contourArea
+    cv2.drawContours, cv2.distanceTransform, cv2.circle, cv2.cvtColor, cv2.watershed = drawContours, distanceTransform, circle, cvtColor, watershed
+    cv2.bitwise_or = lambda a, b: np.bitwise_or(a, b)
+    cv2.bitwise_not = lambda a: np.bitwise_not(a)
+    return cv2
+
+
+def rooms_case():
+    """One storey, two rooms side by side joined by a door, 5 cm lattice points on the floor, the ceiling and the walls
+    (y up, as the map frame), plus camera poses walking through both rooms and a unit feature per image."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    step = 0.05
+    X0, X1, XM, Z0, Z1, H = 0.0, 7.0, 3.6, 0.0, 4.2, 2.5
+    pts = []
+    xs, zs, ys = np.arange(X0, X1 + 1e-9, step), np.arange(Z0, Z1 + 1e-9, step), np.arange(0.0, H + 1e-9, step)
+    gx, gz = np.meshgrid(xs, zs, indexing="ij")
+    for y in (0.0, H):                                            # floor and ceiling
+        pts.append(np.stack([gx.ravel(), np.full(gx.size, y), gz.ravel()], 1))
+    gy, gzz = np.meshgrid(ys, zs, indexing="ij")
+    for x in (X0, X1):                                            # outer walls along z
+        pts.append(np.stack([np.full(gy.size, x), gy.ravel(), gzz.ravel()], 1))
+    gy2, gxx = np.meshgrid(ys, xs, indexing="ij")
+    for z in (Z0, Z1):                                            # outer walls along x
+        pts.append(np.stack([gxx.ravel(), gy2.ravel(), np.full(gy2.size, z)], 1))
+    wall = np.stack([np.full(gy.size, XM), gy.ravel(), gzz.ravel()], 1)        # the dividing wall with a door
+    door = (wall[:, 2] > 1.6) & (wall[:, 2] < 2.5) & (wall[:, 1] < 2.0)
+    pts.append(wall[~door])
+    cloud = np.concatenate(pts)
+    cloud = (cloud + rng.uniform(-0.004, 0.004, cloud.shape)).astype(np.float32).astype(np.float64)     # (no exact lattice ties in the nearest-neighbour step)
+    D, poses, feats = 24, [], []
+    centres = rng.standard_normal((4, D))
+    for k in range(34):
+        if k < 20:
+            x, z, c = rng.uniform(0.5, 3.1), rng.uniform(0.5, 3.7), k % 2
+        else:
+            x, z, c = rng.uniform(4.1, 6.5), rng.uniform(0.5, 3.7), 2 + k % 2
+        T = np.eye(4)
+        T[:3, 3] = [x, 1.4, z]
+        e = centres[c] + 0.1 * rng.standard_normal(D)
+        poses.append(T)
+        feats.append((e / np.linalg.norm(e)).astype(np.float32)[None, :])
+    return cloud, poses, feats
+
+
+def main():
+    G, X = import_reference()
+    import memory.hmsg.utils.graph_utils as GU
+    from memory.hmsg.graph.floor import Floor
+    cv2 = make_cv2()
+    G.cv2 = cv2
+    GU.cv2 = cv2
+    o3d = sys.modules["open3d"]
+    cloud, poses, feats = rooms_case()
+    state = dict(i=-1)
+
+    class DS:
+        frameId2imgPath = {i: "img_%04d.png" % i for i in range(len(poses))}
+
+        def __len__(self):
+            return len(poses)
+
+        def __getitem__(self, i):
+            state["i"] = i
+            return np.zeros((4, 4, 3), np.uint8), None, poses[i], None, None
+    G.get_img_feats = lambda img, pre, model: feats[state["i"]].copy()
+    g = G.Graph.__new__(G.Graph)
+    tmp = tempfile.mkdtemp()
+    g.cfg = AttrDict(main=AttrDict(save_path=tmp), pipeline=AttrDict(grid_resolution=0.05, save_intermediate_results=False, skip_frames=1))
+    g.graph_tmp_folder = tmp
+    g.dataset, g.preprocess, g.clip_model = DS(), None, None
+    g.floors, g.rooms, g.views, g.room_masks = [], [], [], {}
+    fl = Floor("0", name="floor_0")
+    pc = o3d.geometry.PointCloud()
+    pc.points = cloud
+    fl.pcd = pc
+    fl.floor_zero_level = float(cloud[:, 1].min())
+    fl.floor_height = float(cloud[:, 1].max() - fl.floor_zero_level)
+    g.floors.append(fl)
+    g.segment_hmsg_room(fl, tmp)
+    out = dict(cloud=cloud, poses=np.stack(poses), feats=np.concatenate(feats), zero_level=np.array(fl.floor_zero_level),
+               height=np.array(fl.floor_height), n_rooms=np.array(len(g.rooms)),
+               room_masks=np.packbits(np.stack(g.room_masks["0"]) > 0, axis=-1), mask_shape=np.array(g.room_masks["0"][0].shape),
+               view_ids=np.array([v.view_id for v in g.views]), view_room=np.array([v.room_id for v in g.views], np.int64),
+               view_img=np.array([v.img_id for v in g.views], np.int64), view_path=np.array([v.img_path for v in g.views]))
+    for i, r in enumerate(g.rooms):
+        out["vertices_%d" % i] = np.asarray(r.vertices, np.float64)
+        rp = np.asarray(r.pcd.points, np.float64)              # a selection of the storey's points, in their order: kept as indices
+        key = {tuple(p): k for k, p in enumerate(cloud)}
+        idx = np.array([key[tuple(p)] for p in rp], np.int32)
+        assert len(key) == len(cloud) and np.array_equal(cloud[idx], rp) and np.all(np.diff(idx) > 0)
+        out["cloud_idx_%d" % i] = idx
+        out["represent_%d" % i] = np.array(r.represent_images, np.int64)
+        out["sample_%d" % i] = np.array(r.sample_images, np.int64)
+        out["emb_%d" % i] = np.asarray(r.embeddings, np.float32).reshape(len(r.represent_images), -1)
+        out["id_%d" % i] = np.array(r.room_id)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "rooms.npz"), **out)
+    print("rooms", len(g.rooms), [(len(r.vertices), len(r.pcd.points), len(r.sample_images), len(r.represent_images)) for r in g.rooms],
+          "views", len(g.views))
+
+
+if __name__ == "__main__":
+    main()
