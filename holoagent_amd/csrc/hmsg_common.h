@@ -116,7 +116,21 @@ struct DevCache {
             it = free_.erase(it);
         }
     }
+    // HMSG_DEBUG_EXACT_ALLOC=1: every request is its own allocation of exactly the requested size and goes back to the
+    // driver when released -- for runs of the kernel simulator under AddressSanitizer (scripts/emu_sanitize.sh), where the
+    // cache's rounding and reuse would hide an access past the end of a buffer.
+    static bool exact_mode() {
+        static const bool on = getenv("HMSG_DEBUG_EXACT_ALLOC") != nullptr;
+        return on;
+    }
     void* get(int dev, size_t bytes, size_t* got) {
+        if (exact_mode()) {
+            void* q = nullptr;
+            const size_t n = std::max<size_t>((bytes + 15) / 16 * 16, 16);
+            if (hipMalloc(&q, n) != hipSuccess) throw hmsg_error{HMSG_ERR_NOMEM, "hipMalloc (exact mode)"};
+            *got = n;
+            return q;
+        }
         size_t gran = bytes < ((size_t)1 << 20) ? ((size_t)1 << 12) : ((size_t)1 << 21);
         size_t want = (bytes + gran - 1) / gran * gran;
         if (!roots_.empty() && want >= ((size_t)1 << 28)) coalesce();     // (a cut-up block that is whole again)
@@ -182,7 +196,13 @@ struct DevCache {
         *got = want;
         return p;
     }
-    void put(int dev, void* p, size_t bytes) { free_.insert({{dev, bytes}, p}); }
+    void put(int dev, void* p, size_t bytes) {
+        if (exact_mode()) {
+            (void)hipFree(p);
+            return;
+        }
+        free_.insert({{dev, bytes}, p});
+    }
     void swap_state(DevCache& o) {
         free_.swap(o.free_);
         roots_.swap(o.roots_);
@@ -241,7 +261,7 @@ struct DevBuf {
     void ensure(size_t count) {
         // scratch buffers: grow geometrically from a generous floor -- hipFree/hipMalloc synchronise the
         // device, and HBM is plentiful (a 25 % growth policy cost ~0.6 s of re-allocation per 1000-frame merge)
-        if (count > n) alloc(std::max<size_t>(count * 2, (size_t)1 << 16));
+        if (count > n) alloc(DevCache::exact_mode() ? count : std::max<size_t>(count * 2, (size_t)1 << 16));
     }
     void zero(hipStream_t s) { HIP_TRY(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
     size_t bytes() const { return n * sizeof(T); }

@@ -1249,14 +1249,11 @@ struct FoldPipe {
                 HIP_TRY(hipStreamSynchronize(s));
             }
         } catch (const hmsg_error& e) {
-            failed = true;
-            err = e;
+            fail(e);
         } catch (const std::exception& e) {
-            failed = true;
-            err = hmsg_error{HMSG_ERR_HIP, e.what()};
+            fail(hmsg_error{HMSG_ERR_HIP, e.what()});
         } catch (...) {
-            failed = true;
-            err = hmsg_error{HMSG_ERR_HIP, "merge fold worker: unknown exception"};
+            fail(hmsg_error{HMSG_ERR_HIP, "merge fold worker: unknown exception"});
         }
         if (s) {
             (void)hipStreamSynchronize(s);
@@ -1264,11 +1261,16 @@ struct FoldPipe {
         }
         h->fold_cache.swap_state(dev_cache());
     }
+    void fail(const hmsg_error& e) {
+        std::lock_guard<std::mutex> lk(mu);
+        failed = true;
+        err = e;
+    }
     void push(std::unique_ptr<Batch> b) {
         std::vector<std::unique_ptr<Batch>> done;
         {
             std::lock_guard<std::mutex> lk(mu);
-            q.push_back(std::move(b));
+            if (!failed) q.push_back(std::move(b));      // (a worker that gave up consumes nothing: hmsg_merge_instances reports its error)
             done.swap(spent);
         }
         cv.notify_one();

@@ -345,11 +345,12 @@ enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMe
 enum { hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2, hipMemoryTypeUnregistered = 0 };
 struct hipPointerAttribute_t { int type; int device; };
 struct hipDeviceProp_t { int multiProcessorCount; char name[64]; size_t totalGlobalMem; char gcnArchName[64]; };
-static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : 2; }
+// (256-byte alignment as the driver gives: kernels use alignas(32) records and 16-byte vector loads at buffer starts)
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = nullptr; return posix_memalign(p, 256, n ? n : 1) == 0 ? hipSuccess : 2; }
 template <typename T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 #define hipHostMallocDefault 0
-static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = malloc(n ? n : 1); return *p ? hipSuccess : 2; }
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = nullptr; return posix_memalign(p, 256, n ? n : 1) == 0 ? hipSuccess : 2; }
 static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = 0) { if (n) memmove(d, s, n); return hipSuccess; }

@@ -8,7 +8,8 @@ from scipy.spatial import cKDTree
 
 from oracle import hmsg_oracle as O
 
-EMU_PATH = os.path.join(os.path.dirname(__file__), "emu", "libhmsg_emu.so")
+# HMSG_EMU_PATH: another build of the simulator (scripts/emu_sanitize.sh points it at an AddressSanitizer build)
+EMU_PATH = os.environ.get("HMSG_EMU_PATH") or os.path.join(os.path.dirname(__file__), "emu", "libhmsg_emu.so")
 
 
 def _pad(a, rows):

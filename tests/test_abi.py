@@ -55,6 +55,8 @@ def test_allocator_carves_a_large_parked_block():
     from tests import parity_common as PC
     if not os.path.exists(PC.EMU_PATH):
         pytest.skip("kernel simulator not built")
+    if os.environ.get("HMSG_DEBUG_EXACT_ALLOC"):
+        pytest.skip("the allocator's cache is switched off (sanitizer run)")
     from holoagent_amd._lib import HmsgLib
     L = HmsgLib(PC.EMU_PATH)
     assert L.c.hmsg_test_allocator_carving(0, 9) == 0
