@@ -99,6 +99,7 @@ _SIGS = {
     "hmsg_get_nodes": (C.c_int, [_P, _P, _P]),
     "hmsg_index_from_nodes": (C.c_int, [_P, C.POINTER(_P)]),
     "hmsg_room_clouds": (C.c_int, [_P, C.c_double, C.c_double, _P, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "hmsg_object_views": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int64, _P, _P, C.c_double, C.c_double, _P, _P]),
     "hmsg_segment_floors": (C.c_int, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),
     "hmsg_segment_rooms": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P, C.c_int64, C.POINTER(C.c_int32),
                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P]),
@@ -437,6 +438,23 @@ class Scene:
                                            _ptr(sizes), _ptr(out), cap, C.byref(nf)))
         o = np.concatenate([[0], np.cumsum(sizes)])
         return [out[o[r]:o[r + 1]].copy() for r in range(len(room_xz))], int(nf.value)
+
+    def object_views(self, poses_inv, wh, K, pair_inst, pair_view, min_visible_ratio=0.5, max_depth=10.0):
+        """check_object_in_view (utils/graph_utils.py:95-157) for (instance, view) pairs on the device (include/hmsg.h:
+        hmsg_object_views): poses_inv [V, 4, 4] world -> camera, wh [V, 2] image width / height, K [3, 3];
+        returns (visible bool [P], mean_depth f64 [P])."""
+        P_ = np.ascontiguousarray(poses_inv, np.float64).reshape(-1, 16)
+        wh = np.ascontiguousarray(wh, np.int32).reshape(-1, 2)
+        assert len(wh) == len(P_)
+        K = np.ascontiguousarray(K, np.float64).reshape(9)
+        pi = np.ascontiguousarray(pair_inst, np.int32).reshape(-1)
+        pv = np.ascontiguousarray(pair_view, np.int32).reshape(-1)
+        assert len(pi) == len(pv)
+        vis = np.zeros(max(len(pi), 1), np.uint8)
+        md = np.full(max(len(pi), 1), np.inf)
+        self._ck(self.L.c.hmsg_object_views(self.h, len(P_), _ptr(P_), _ptr(wh), _ptr(K), len(pi), _ptr(pi), _ptr(pv),
+                                            float(min_visible_ratio), float(max_depth), _ptr(vis), _ptr(md)))
+        return vis[:len(pi)].astype(bool), md[:len(pi)]
 
     def segment_floors(self):
         """A8 behind the C ABI (include/hmsg.h: hmsg_segment_floors) -> list of dicts (y_lo, y_hi, zero_level, height,

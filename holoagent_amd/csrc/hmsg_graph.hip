@@ -340,3 +340,121 @@ extern "C" int hmsg_room_clouds(hmsg_t* h, double y_lo, double y_hi, const doubl
         return e.code;
     }
 }
+
+// ------------------------------------------------------------------------------------------ A10: view <-> object topology
+// check_object_in_view (utils/graph_utils.py:95-157) for a batch of (instance, view) pairs, the loop of
+// segment_hmsg_objects (graph.py:1712-1734): points into the camera frame (world -> camera matrix), those in front of the
+// camera (z > 0) through K, visible = at least `min_ratio` of ALL the cloud's points land inside the image and their mean
+// depth is <= max_depth.  The knife edges are not rare here: a point seen at pixel column 0 of a frame re-projects into that
+// very frame at u = 0 +- 1e-14, and the frames ARE the views.  The reference's two matmuls go through BLAS dgemm, whose
+// micro-kernel keeps one accumulator per output element and feeds it with fused multiply-adds in k order; the chain
+// fma(a3, b3, fma(a2, b2, fma(a1, b1, a0 * b0))) reproduces numpy + OpenBLAS of this image bit for bit
+// (tests/test_object_views.py holds the kernel to numpy's own matmul results), so the inside / outside decisions are the
+// reference run's.  The mean depth is summed in workgroup order (numpy: pairwise): equal to ~1e-16 relative.
+// One workgroup per pair; the instance's points are read where the merge left them.
+struct ViewPair {
+    long long p0;      // first point of the instance
+    int n;             // its points
+    int view;
+};
+__global__ void __launch_bounds__(256) k_object_views(const double* __restrict__ pts, const ViewPair* __restrict__ pairs,
+                                                      const double* __restrict__ pose_inv, const int* __restrict__ wh, const double* __restrict__ Kmat,
+                                                      double min_ratio, double max_depth, unsigned char* __restrict__ visible,
+                                                      double* __restrict__ mean_depth) {
+    __shared__ double s_z[4];
+    __shared__ int s_c[4][2];
+    const ViewPair pr = pairs[blockIdx.x];
+    const double* P = pose_inv + (size_t)pr.view * 16;
+    const double W = (double)wh[(size_t)pr.view * 2], H = (double)wh[(size_t)pr.view * 2 + 1];
+    double P_[12], K_[9];
+    for (int i = 0; i < 12; ++i) P_[i] = P[i];
+    for (int i = 0; i < 9; ++i) K_[i] = Kmat[i];
+    int n_front = 0, n_in = 0;
+    double zsum = 0.0;
+    for (int k = threadIdx.x; k < pr.n; k += blockDim.x) {
+        const double* q = pts + (size_t)(pr.p0 + k) * 3;
+        const double x = q[0], y = q[1], z = q[2];
+        double c[3];
+        for (int r = 0; r < 3; ++r)
+            c[r] = fma(P_[r * 4 + 3], 1.0, fma(P_[r * 4 + 2], z, fma(P_[r * 4 + 1], y, __dmul_rn(P_[r * 4], x))));
+        if (!(c[2] > 0.0)) continue;
+        ++n_front;
+        double ph[3];
+        for (int r = 0; r < 3; ++r)
+            ph[r] = fma(K_[r * 3 + 2], c[2], fma(K_[r * 3 + 1], c[1], __dmul_rn(K_[r * 3], c[0])));
+        const double u = __ddiv_rn(ph[0], ph[2]), v = __ddiv_rn(ph[1], ph[2]);
+        if (u >= 0.0 && u < W && v >= 0.0 && v < H) {
+            ++n_in;
+            zsum = __dadd_rn(zsum, c[2]);
+        }
+    }
+    n_front = wave_sum_i32(n_front);
+    n_in = wave_sum_i32(n_in);
+    for (int o = 32; o > 0; o >>= 1) zsum = __dadd_rn(zsum, __shfl_xor(zsum, o));
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_z[w] = zsum;
+        s_c[w][0] = n_front;
+        s_c[w][1] = n_in;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nf = (s_c[0][0] + s_c[1][0]) + (s_c[2][0] + s_c[3][0]), ni = (s_c[0][1] + s_c[1][1]) + (s_c[2][1] + s_c[3][1]);
+        const double zs = __dadd_rn(__dadd_rn(s_z[0], s_z[1]), __dadd_rn(s_z[2], s_z[3]));
+        const double inf = 1e308 * 10.0;
+        unsigned char vis = 0;
+        double md = inf;
+        if (pr.n > 0 && nf > 0 && ni > 0 && !((double)ni / (double)pr.n < min_ratio)) {
+            md = __ddiv_rn(zs, (double)ni);
+            vis = md > max_depth ? 0 : 1;
+        }
+        visible[blockIdx.x] = vis;
+        mean_depth[blockIdx.x] = md;
+    }
+}
+
+extern "C" int hmsg_object_views(hmsg_t* h, int32_t n_views, const double* pose_inv, const int32_t* wh, const double* K, int64_t n_pairs,
+                                 const int32_t* pair_inst, const int32_t* pair_view, double min_visible_ratio, double max_depth,
+                                 uint8_t* visible, double* mean_depth) {
+    if (!h) return HMSG_ERR_INVALID;
+    try {
+        HIP_TRY(hipSetDevice(h->cfg.device_id));
+        HMSG_REQUIRE(h->merged, HMSG_ERR_INVALID, "hmsg_object_views: run hmsg_merge_instances first");
+        HMSG_REQUIRE(n_views >= 0 && n_pairs >= 0 && n_pairs < (1ll << 31) && (n_pairs == 0 || (pose_inv && wh && K && pair_inst && pair_view && visible && mean_depth)),
+                     HMSG_ERR_INVALID, "hmsg_object_views: bad argument");
+        if (n_pairs == 0) return HMSG_OK;
+        const long long NI = (long long)h->inst.off.size() - 1;
+        std::vector<ViewPair> hp((size_t)n_pairs);
+        for (int64_t k = 0; k < n_pairs; ++k) {
+            HMSG_REQUIRE(pair_inst[k] >= 0 && pair_inst[k] < NI && pair_view[k] >= 0 && pair_view[k] < n_views, HMSG_ERR_INVALID,
+                         "hmsg_object_views: pair out of range");
+            const long long p0 = h->inst.off[(size_t)pair_inst[k]], p1 = h->inst.off[(size_t)pair_inst[k] + 1];
+            hp[(size_t)k] = ViewPair{p0, (int)(p1 - p0), pair_view[k]};
+        }
+        hipStream_t s = h->stream;
+        DevBuf<ViewPair> d_pairs;
+        DevBuf<double> d_pose, d_K, d_md;
+        DevBuf<int> d_wh;
+        DevBuf<unsigned char> d_vis;
+        d_pairs.alloc((size_t)n_pairs);
+        d_pose.alloc((size_t)n_views * 16);
+        d_K.alloc(9);
+        d_wh.alloc((size_t)n_views * 2);
+        d_md.alloc((size_t)n_pairs);
+        d_vis.alloc((size_t)n_pairs);
+        HIP_TRY(hipMemcpyAsync(d_pairs.p, hp.data(), (size_t)n_pairs * sizeof(ViewPair), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_pose.p, pose_inv, (size_t)n_views * 128, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_K.p, K, 72, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_wh.p, wh, (size_t)n_views * 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_object_views, dim3((unsigned)n_pairs), dim3(256), 0, s, (const double*)h->inst.pts.p, (const ViewPair*)d_pairs.p,
+                           (const double*)d_pose.p, (const int*)d_wh.p, (const double*)d_K.p, min_visible_ratio, max_depth, d_vis.p, d_md.p);
+        HMSG_CHECK_LAUNCH();
+        HIP_TRY(hipStreamSynchronize(s));
+        d2h_bounce(visible, d_vis.p, (size_t)n_pairs);
+        d2h_bounce(mean_depth, d_md.p, (size_t)n_pairs * 8);
+        return HMSG_OK;
+    } catch (const hmsg_error& e) {
+        h->err = e.msg;
+        return e.code;
+    }
+}

@@ -816,6 +816,7 @@ class Graph:
             picks = [(int(n["instance"]), self.rooms[int(n["room"])], int(n["label"])) for n in nodes]
         else:
             picks = self._assign_objects_host(text_feats)
+        made = []
         for i, room, label in picks:
             pcd = self.mask_pcds[i]
             obj = Object(room.room_id + "_" + str(room.object_counter), room.room_id)
@@ -824,21 +825,44 @@ class Graph:
             obj.pcd, obj.embedding = pcd, np.asarray(self.mask_feats[i]).reshape(-1)
             obj._instance = i if isinstance(pcd, _LazyPcd) else None       # (save_hmsg_graph: bulk writer)
             obj.vertices = None                                            # = points[:, [0, 2]], materialised on save
-            best, best_d = None, float("inf")
-            for v in room.views:
-                if self.dataset is None or v.img_id is None:
-                    continue
+            made.append((obj, room, i))
+        # view <-> object topology (:1712-1734).  A view's image is opened once (the reference opens it once per object) for
+        # its size and pose; the test itself is numpy here, or -- pipeline.views_on_device -- one batch on the device
+        # (hmsg_object_views) that never brings an object's points to the host.
+        K, cams = None, {}
+        def camera(v):
+            if v.img_id not in cams:
                 img, _, pose, _, _ = self.dataset[v.img_id]
                 a = np.asarray(img)
-                K = self._K if self._K is not None else np.asarray(self.dataset.get_camera_intrinsics())
-                ok, md = check_object_in_view(a.shape[1], a.shape[0], K, np.linalg.inv(pose), pcd.points)
-                if ok:
-                    obj.view_ids.append(v.view_id)
-                    v.object_ids.append(obj.object_id)
-                    v.text_discription.append(obj.name)
-                    if md < best_d:
-                        best_d, best = md, v.view_id
-            obj.best_view_id = best
+                cams[v.img_id] = (a.shape[1], a.shape[0], np.linalg.inv(pose))
+            return cams[v.img_id]
+        pairs = [(k, v) for k, (obj, room, i) in enumerate(made) for v in room.views
+                 if self.dataset is not None and v.img_id is not None]
+        if pairs:
+            K = self._K if self._K is not None else np.asarray(self.dataset.get_camera_intrinsics())
+        if pairs and self.scene is not None and bool(_get(self.cfg, "pipeline.views_on_device", False)):
+            ids = sorted({v.img_id for _, v in pairs})
+            col = {img_id: c for c, img_id in enumerate(ids)}
+            first = {}
+            for _, v in pairs:
+                first.setdefault(v.img_id, v)
+            cam = {img_id: camera(first[img_id]) for img_id in ids}
+            vis, md = self.scene.object_views(np.stack([cam[i][2] for i in ids]), [[cam[i][0], cam[i][1]] for i in ids], K,
+                                              [made[k][2] for k, _ in pairs], [col[v.img_id] for _, v in pairs])
+            verdicts = list(zip(vis.tolist(), md.tolist()))
+        else:
+            verdicts = [check_object_in_view(*camera(v)[:2], K, camera(v)[2], made[k][0].pcd.points) for k, v in pairs]
+        best = {}
+        for (k, v), (ok, md_) in zip(pairs, verdicts):
+            obj = made[k][0]
+            if ok:
+                obj.view_ids.append(v.view_id)
+                v.object_ids.append(obj.object_id)
+                v.text_discription.append(obj.name)
+                if md_ < best.get(k, (float("inf"), None))[0]:
+                    best[k] = (md_, v.view_id)
+        for k, (obj, room, i) in enumerate(made):
+            obj.best_view_id = best.get(k, (None, None))[1]
             room.add_object(obj)
             self.objects.append(obj)
         self._index = None

@@ -230,6 +230,20 @@ int hmsg_build_object_nodes(hmsg_t* h, int32_t n_floors, const double* floor_zer
                             const int32_t* room_floor, const int64_t* vert_off, const double* verts_xz, int32_t n_labels,
                             const float* label_feats);
 int64_t hmsg_num_nodes(const hmsg_t* h);
+/* The view <-> object topology of segment_hmsg_objects (graph.py:1712-1734): check_object_in_view
+ * (utils/graph_utils.py:95-157) for n_pairs (instance, view) pairs on the instance clouds as they are in the handle (after
+ * hmsg_build_object_nodes: denoised, what the reference's mask_pcds hold at that point).  pose_inv f64 [n_views][4][4] =
+ * np.linalg.inv(pose) row-major (world -> camera, computed by the caller as the reference does); wh i32 [n_views][2] = image
+ * width, height; K f64 [3][3]; pair_inst / pair_view i32 [n_pairs].  visible u8 [n_pairs]: 1 when at least
+ * min_visible_ratio (0.5) of ALL the cloud's points are in front of the camera and project inside the image and their
+ * mean depth is <= max_depth (10.0); mean_depth f64 [n_pairs]: that mean (inf where the reference returns inf: the caller
+ * picks best_view_id = the visible view of smallest mean depth, first on ties).  The two matrix products are evaluated as
+ * BLAS dgemm does (one fused multiply-add chain per element, k ascending): a point seen at the image border of a frame
+ * re-projects onto that border to ~1e-14, so the inside / outside decisions follow the reference only with its
+ * arithmetic.  The mean is summed in a fixed device order (numpy: pairwise), equal to ~1e-16 relative. */
+int hmsg_object_views(hmsg_t* h, int32_t n_views, const double* pose_inv, const int32_t* wh, const double* K, int64_t n_pairs,
+                      const int32_t* pair_inst, const int32_t* pair_view, double min_visible_ratio, double max_depth,
+                      uint8_t* visible, double* mean_depth);
 
 /* ---- A9: the room clouds of segment_hmsg_room (graph.py:1086-1108).  For every room the (x, z) cell centres of its 2-D
  * region (room_xz f64 [sum][2], CSR room_off i64 [n_rooms + 1]: what map_grid_to_point_cloud returns, :1084) are
