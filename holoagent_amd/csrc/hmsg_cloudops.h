@@ -44,6 +44,8 @@ struct Publisher {
     PinnedBuf<unsigned> buf;         // payload, then (last word) the flag
     unsigned seq = 0;
     const unsigned* inited = nullptr;
+    size_t inited_n = 0;
+    hipStream_t stream = nullptr;    // of the last launch (wait() asks it whether it is still alive)
     // enqueue on s: copy src[0 .. n) (device) to the host buffer; data() is valid after wait()
     void launch(hipStream_t s, const unsigned* src, size_t n);
     void wait();

@@ -957,17 +957,26 @@ __global__ void k_publish(const unsigned* __restrict__ src, int n, unsigned* __r
 }
 void Publisher::launch(hipStream_t s, const unsigned* src, size_t n) {
     buf.ensure(n + 32);                                       // (the flag sits behind the payload, on another cache line)
-    if (buf.p != inited) {                                    // fresh pinned memory: the flag must not look raised
+    if (buf.p != inited || buf.n != inited_n) {               // fresh pinned memory: the flag must not look raised
         buf.p[buf.n - 1] = 0u;
         inited = buf.p;
+        inited_n = buf.n;
     }
     ++seq;
+    stream = s;
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, s, src, (int)n, buf.p, buf.p + buf.n - 1, seq);
     HMSG_CHECK_LAUNCH();
 }
 void Publisher::wait() {
     volatile unsigned* flag = buf.p + buf.n - 1;
-    while (*flag != seq) {
+    for (unsigned long long it = 1; *flag != seq; ++it) {
+        if ((it & 0xfffffull) != 0) continue;
+        // about once a millisecond: a stream that failed, or drained without the publish kernel having run, must surface as an
+        // error instead of a host that spins for ever
+        const hipError_t e = hipStreamQuery(stream);
+        if (e == hipErrorNotReady) continue;
+        if (e != hipSuccess) HIP_TRY(e);
+        if (*flag != seq) throw hmsg_error{HMSG_ERR_HIP, "merge fold: the stream drained but the step's results were never published"};
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
 }
