@@ -124,3 +124,12 @@ def test_object_views_device_equals_host_emu():
 def test_graph_views_on_device_switch_emu():
     from holoagent_amd._lib import HmsgLib
     check_graph_switch(HmsgLib(PC.EMU_PATH))
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.environ.get("HMSG_TEST_UNVALIDATED"),
+                    reason="hmsg_object_views has only run on the kernel simulator so far (scripts/round_start_gpu.sh sets HMSG_TEST_UNVALIDATED=1)")
+def test_object_views_gpu():
+    from holoagent_amd._lib import HmsgLib
+    check_device_equals_host(HmsgLib())
+    check_graph_switch(HmsgLib())
