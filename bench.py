@@ -102,6 +102,13 @@ def main():
     ap.add_argument("--inflight-steps", type=int, default=2,
                     help="scenes per handle of the extra scenes-in-flight measurement (0 = skip; N = 1 scene mode only)")
     ap.add_argument("--inflight", type=int, default=2, help="handles (scenes in flight) of that extra measurement")
+    ap.add_argument("--full-graph", action="store_true",
+                    help="graph assembly with nothing handed in: rooms from the device watershed (N1), room clouds, room embeddings and "
+                         "View nodes (A9), objects with the view <-> object test on the device (A10) -- instead of ready-made room "
+                         "regions without views (scene mode)")
+    ap.add_argument("--scene-shape", default=None,
+                    help="development sizes (the simulator test): ROOMS_X,ROOMS_Z,ROOM_X_M,ROOM_Y_M,ROOM_Z_M,YAW_STEP_DEG,OBJECTS_PER_ROOM of "
+                         "the synthetic building instead of configs[1]'s 4 x 2 rooms of 5 x 3 x 4 m, 10 degrees a frame, 8 objects a room")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     args = ap.parse_args()
@@ -141,16 +148,32 @@ def main():
             print(json.dumps({"spawn_check": True, "n_gpus": world, "rank_sum": int(t.item())}))
         dist.destroy_process_group()
         return
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    if use_dist:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-    L = HmsgLib()                      # fails loudly without the HIP library
+    # HMSG_BENCH_EMU=<path of tests/emu/libhmsg_emu.so>: the whole script against the kernel simulator on the CPU with tiny
+    # sizes (tests/test_bench_contract.py: the JSON contract, every code path of a step) -- never a measurement, and the
+    # line says so ("emulated": true)
+    emu = os.environ.get("HMSG_BENCH_EMU")
+    if emu:
+        assert not use_dist, "the simulator run is single-process"
+        device = torch.device("cpu")
+        sync = lambda: None
+        L = HmsgLib(emu)
+    else:
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+        sync = torch.cuda.synchronize
+        if use_dist:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        L = HmsgLib()                      # fails loudly without the HIP library
 
     F, Q, D, k = args.frames, args.queries, args.feat_dim, args.topk
     episode = args.mode == "episode"
     # (episode mode: every rank sees the same episode -- same seed; scene mode: a scene per rank)
-    spec = SceneSpec(seed=1234 + (0 if episode else rank), n_frames=F, feat_dim=D, n_masks=32, width=args.width, height=args.height)
+    assert not (args.full_graph and (use_dist or episode)), "--full-graph: one scene on one GPU (the all-gathered retrieval takes the rooms as given)"
+    shape = {}
+    if args.scene_shape:
+        v = [float(x) for x in args.scene_shape.split(",")]
+        shape = dict(rooms_x=int(v[0]), rooms_z=int(v[1]), room_size=(v[2], v[3], v[4]), yaw_step_deg=v[5], objects_per_room=int(v[6]))
+    spec = SceneSpec(seed=1234 + (0 if episode else rank), n_frames=F, feat_dim=D, n_masks=32, width=args.width, height=args.height, **shape)
     inp = build_scene_inputs(L, spec, device, torch)
     scn = inp["scene"]
     text, q_ent = scn.text_table(Q)                               # [Q, 2, D] (query, negative)
@@ -169,6 +192,33 @@ def main():
     for lo6 in inp["rooms"]:
         xs, zs = np.arange(lo6[0], lo6[3], 0.05), np.arange(lo6[2], lo6[5], 0.05)
         room_specs.append(dict(floor=0, vertices=np.stack(np.meshgrid(xs, zs, indexing="ij"), -1).reshape(-1, 2)))
+    # --full-graph: nothing is handed in -- the Graph gets what the reference's Graph has: a dataset to ask for a frame's pose and
+    # image size (the images themselves stay in HBM) and the frames' global features (the F_g the fusion already received)
+    full_cfg = dict(main=dict(device_id=local), models=dict(clip=dict(feat_dim=D)),
+                    pipeline=dict(grid_resolution=0.05, skip_frames=1, views_on_device=True))
+    poses_host = [np.asarray(inp["pose"][i], np.float64).reshape(4, 4) for i in range(F)]
+    blank = np.broadcast_to(np.zeros((), np.uint8), (spec.height, spec.width, 3))
+
+    class FrameSource:
+        def __len__(self):
+            return F
+
+        def __getitem__(self, i):
+            return blank, None, poses_host[i], None, None
+
+        def get_camera_intrinsics(self):
+            return inp["K"]
+    fg_host = inp["f_g"].cpu().numpy() if args.full_graph else None
+    gt_boxes = np.asarray(inp["rooms"], np.float64)
+
+    def gt_room_of(xz):
+        """ground-truth room of a segmented region: the box that holds the centroid of its cells (nearest centre otherwise)"""
+        c = np.asarray(xz, np.float64).mean(axis=0)
+        inside = (c[0] >= gt_boxes[:, 0]) & (c[0] <= gt_boxes[:, 3]) & (c[1] >= gt_boxes[:, 2]) & (c[1] <= gt_boxes[:, 5])
+        if inside.any():
+            return int(np.argmax(inside))
+        ctr = np.stack([(gt_boxes[:, 0] + gt_boxes[:, 3]) / 2, (gt_boxes[:, 2] + gt_boxes[:, 5]) / 2], 1)
+        return int(np.argmin(np.linalg.norm(ctr - c[None], axis=1)))
     rng_l = np.random.Generator(np.random.PCG64(99))
     label_feats = rng_l.standard_normal((205, D)).astype(np.float32)      # scannet200-sized label vocabulary
     label_feats /= np.linalg.norm(label_feats, axis=1, keepdims=True)
@@ -249,9 +299,19 @@ def main():
         def assemble():
             # A8 floors, A10 objects (device: instance DBSCAN(0.05,10), object->room share, label GEMM), A11 node
             # records -- holoagent_amd.graph.Graph, the mirror of the reference's Graph; rooms are an input.
-            g = T("assemble/from_scene", lambda: Graph.from_scene(sc, lib=L))
-            g.set_label_feats(label_feats, label_names)
-            T("assemble/build_hier", lambda: g.build_hier_multimodal_scene_graph(None, rooms=room_specs))
+            if args.full_graph:
+                g = T("assemble/from_scene", lambda: Graph.from_scene(sc, cfg=full_cfg, lib=L))
+                g.dataset = FrameSource()
+                g.set_view_feats(fg_host)
+                g.set_label_feats(label_feats, label_names)
+                # floors (A8) -> per storey: rooms by the device watershed (N1), room clouds, camera -> room assignment, KMeans
+                # views and View nodes (A9) -> objects with the view <-> object test on the device (A10) -> graph (A11)
+                T("assemble/build_hier", lambda: g.build_hier_multimodal_scene_graph(None))
+                state["graph"] = g
+            else:
+                g = T("assemble/from_scene", lambda: Graph.from_scene(sc, lib=L))
+                g.set_label_feats(label_feats, label_names)
+                T("assemble/build_hier", lambda: g.build_hier_multimodal_scene_graph(None, rooms=room_specs))
             rid = {r.room_id: i for i, r in enumerate(g.rooms)}
             feats = np.stack([o.embedding for o in g.objects]).astype(np.float64) if g.objects else np.zeros((0, D))
             rooms = np.array([rid[o.room_id] for o in g.objects], np.int32)   # embeddings are f64 once stored (object.py:88-89)
@@ -281,6 +341,24 @@ def main():
             # coarse to fine ON THE DEVICE (hmsg_query_hier): floor 0 -> room by its name (label mode: the rooms within
             # 1e-3 of the best name similarity) -> objects of those rooms with one negative prompt -- no room list is
             # handed in.  N GPUs: object-level queries on the all-gathered global table with the rooms' global ids.
+            if not use_dist and args.full_graph:
+                # the rooms are the segmented ones: each is named after the ground-truth room its region lies in (two regions
+                # of one room share the name: the label mode then selects both)
+                g = state["graph"]
+                gt_of = [gt_room_of(r.vertices) for r in g.rooms]
+                pos = {id(r): i for i, r in enumerate(g.rooms)}
+                ix = sc.index_from_nodes()
+                ix.set_profiling(True)
+                ix.set_hierarchy([[pos[id(r)] for r in fl.rooms] for fl in g.floors], room_name_feats[gt_of],
+                                 [np.zeros((0, D))] * len(g.rooms), list(range(len(g.rooms))))
+                sel, idx, room, score = ix.query_hier(tq, np.zeros(len(tq), np.int32), room_text, np.zeros(len(tq), np.int32),
+                                                      np.ones(len(tq), np.int32), k)
+                state["gemm"] = ix.profile()
+                state["rooms_hit"] = float(np.mean([int(ent_room[e]) in {gt_of[j] for j in s_} for e, s_ in zip(q_ent, sel)]))
+                state["graph_counts"] = dict(floors=len(g.floors), rooms=len(g.rooms), views=len(g.views), objects=len(g.objects),
+                                             view_object_edges=int(sum(len(v.object_ids) for v in g.views)))
+                ix.close()
+                return idx, room, score
             if not use_dist:
                 ix = sc.index_from_nodes()
                 ix.set_profiling(True)
@@ -304,11 +382,11 @@ def main():
     stage.clear()
     if use_dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
+    sync()
     if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -398,21 +476,22 @@ def main():
 
         def worker(scx, n):
             try:
-                torch.cuda.set_device(local)
+                if not emu:
+                    torch.cuda.set_device(local)
                 for _ in range(n):
                     build(scx)
             except Exception as e:      # pragma: no cover
                 errs.append(repr(e))
         for hx in handles[1:]:
             build(hx)                                             # warm the other handles' buffers
-        torch.cuda.synchronize()
+        sync()
         tt = time.perf_counter()
         th = [threading.Thread(target=worker, args=(hx, args.inflight_steps)) for hx in handles]
         for t in th:
             t.start()
         for t in th:
             t.join()
-        torch.cuda.synchronize()
+        sync()
         dt2 = time.perf_counter() - tt
         for hx in handles[1:]:
             hx.close()
@@ -480,12 +559,16 @@ def main():
     if rank == 0:
         last = state.get("last")
         out = {
-            "metric": "HMSG frames/sec (%s: map A1-A2, fusion A3-A5, merge A6, pooling A7, floors A8, objects A10 and graph "
-                      "assembly A11 with the rooms' 2-D regions given and without views -- A9's room embeddings / View nodes are "
-                      "not in the timed step -- plus %d coarse-to-fine retrieval queries (A12: floor -> room by its name -> objects with a "
-                      "negative prompt, every stage on the device; object level only in the multi-GPU scene mode) per %d-frame %s; frames, masks and "
-                      "encoder features already resident in HBM, encoders bypassed)"
-                      % ("one episode sharded over the GPUs" if episode else "one scene per GPU", Q, F, "episode" if episode else "scene"),
+            "metric": ("HMSG frames/sec (%s: map A1-A2, fusion A3-A5, merge A6, pooling A7, floors A8, %splus %d coarse-to-fine "
+                       "retrieval queries (A12: floor -> room by its name -> objects with a "
+                       "negative prompt, every stage on the device; object level only in the multi-GPU scene mode) per %d-frame %s; frames, masks and "
+                       "encoder features already resident in HBM, encoders bypassed)")
+                      % ("one episode sharded over the GPUs" if episode else "one scene per GPU",
+                         ("rooms by the device watershed N1, room clouds, room embeddings and View nodes A9, objects with the view <-> object "
+                          "test A10 and graph assembly A11, nothing handed in -- ") if (args.full_graph and not episode) else
+                         ("objects A10 and graph assembly A11 with the rooms' 2-D regions given and without views -- A9's room embeddings / "
+                          "View nodes are not in the timed step -- "),
+                         Q, F, "episode" if episode else "scene"),
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if episode else "weak", "vs_baseline": None,
             "dtype": "f64 geometry / f32 features", "data": "synthetic",
@@ -497,6 +580,8 @@ def main():
                        "frames": F, "queries": Q, "feat_dim": D, "masks": M,
                        "parallelism": ("episode-sharded x%d (frame windows of %d)" % (world, chunk)) if episode else "scene-per-gpu x%d" % world},
             "rccl_ranks": dist.get_world_size() if use_dist else 0,
+            "full_graph": bool(args.full_graph and not episode), "graph_counts": state.get("graph_counts"),
+            "emulated": bool(emu),
             # (scene mode: the sequential fold of A6 starts on a worker thread while hmsg_fuse_frames is still producing
             #  3-D masks, so part of the merge is inside the fuse_frames stage time; HMSG_FOLD_NOPIPE=1 separates them)
             "fold_beside_fusion": (not episode) and not os.environ.get("HMSG_FOLD_NOPIPE"),
