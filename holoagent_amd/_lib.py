@@ -172,6 +172,13 @@ def _ptr(a):
         return C.c_void_p(a.ctypes.data)
     if hasattr(a, "data_ptr"):
         assert a.is_contiguous()
+        # A device tensor may still be in the making on torch's current stream (an all-reduce under the nccl backend
+        # only makes that stream wait; a dtype conversion is a kernel).  The library works on its own non-blocking
+        # stream, which has no ordering against torch's: drain torch's stream before the pointer leaves.  (In the other
+        # direction every entry point that writes into a caller's buffer waits for its own stream before returning.)
+        if getattr(a, "is_cuda", False):
+            import torch
+            torch.cuda.current_stream(a.device).synchronize()
         return C.c_void_p(a.data_ptr())
     raise TypeError(type(a))
 

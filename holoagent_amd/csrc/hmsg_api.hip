@@ -482,9 +482,12 @@ int hmsg_get_feature_sums(const hmsg_t* hc, float* sum, uint32_t* counter) {
     return guard(h, [&] {
         HMSG_REQUIRE(h->feats_final, HMSG_ERR_INVALID, "hmsg_fuse_frames not run");
         const size_t n = (size_t)h->V * h->cfg.feat_dim;
-        if (sum && n) HIP_TRY(hipMemcpy(sum, h->sum.p, n * 4, is_device_ptr(sum) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+        // (on the handle's own stream -- ordered behind whatever produced the sums -- and complete before the call returns:
+        //  the caller's stream has no ordering against ours)
+        if (sum && n) HIP_TRY(hipMemcpyAsync(sum, h->sum.p, n * 4, is_device_ptr(sum) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
         if (counter && h->V)
-            HIP_TRY(hipMemcpy(counter, h->cnt.p, (size_t)h->V * 4, is_device_ptr(counter) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpyAsync(counter, h->cnt.p, (size_t)h->V * 4, is_device_ptr(counter) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
     });
 }
 
@@ -575,9 +578,10 @@ int hmsg_get_instance_points(const hmsg_t* hc, double* xyz) {
     return guard(h, [&] {
         HMSG_REQUIRE((h->merged || h->tree_partial) && xyz, HMSG_ERR_INVALID, "hmsg_merge_instances not run");
         if (h->inst.total) {
-            if (is_device_ptr(xyz))
-                HIP_TRY(hipMemcpy(xyz, h->inst.pts.p, (size_t)h->inst.total * 24, hipMemcpyDeviceToDevice));
-            else
+            if (is_device_ptr(xyz)) {
+                HIP_TRY(hipMemcpyAsync(xyz, h->inst.pts.p, (size_t)h->inst.total * 24, hipMemcpyDeviceToDevice, h->stream));
+                HIP_TRY(hipStreamSynchronize(h->stream));
+            } else
                 d2h_bounce(xyz, h->inst.pts.p, (size_t)h->inst.total * 24);
         }
     });

@@ -353,9 +353,12 @@ __global__ void __launch_bounds__(256) k_room_select(int n_rooms, int n_floors, 
         __syncthreads();
         if (tid == 0) {
             if (L > 1024) s_bad = 1;
-            const int want = min(Lc, m == 2 ? 5 : 10);
+            // graph.py:3259-3264: `{int(room_id.split("_")[-1]): v for ... in sorted(...)}` -- rooms "0_2" and "1_2" (floor -1 on
+            // a multi-storey graph) collapse into ONE key, which keeps the place of its first (best) occurrence; the first
+            // 5 / 10 UNIQUE keys are returned.
+            const int want = m == 2 ? 5 : 10;
             int n = 0;
-            for (; n < want && n < max_sel; ++n) {              // selection sort of the top few, first index wins ties
+            for (int taken = 0; taken < Lc && n < want && n < max_sel; ++taken) {   // selection sort of the top few, first index wins ties
                 int bi = -1;
                 double bv = -1e308;
                 for (int i = 0; i < Lc; ++i)
@@ -364,7 +367,10 @@ __global__ void __launch_bounds__(256) k_room_select(int n_rooms, int n_floors, 
                         bv = s_max[i];
                     }
                 s_taken[bi] = 1;
-                my_sel[n] = room_key[room_at(bi)];
+                const int key = room_key[room_at(bi)];
+                bool seen = false;
+                for (int j = 0; j < n; ++j) seen = seen || my_sel[j] == key;
+                if (!seen) my_sel[n++] = key;
             }
             nsel[q] = n;
         }

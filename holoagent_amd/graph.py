@@ -713,7 +713,9 @@ class Graph:
         oracle/rooms_oracle.py), then map_grid_to_point_cloud (graph_utils.py:359-388) per room.  None when the floor
         cloud is not a slab of the resident map."""
         crop = getattr(floor, "_crop", None)
-        if self.scene is None or crop is None:
+        # (only when the floor cloud IS that slab of the resident map: a Graph with a resident scene whose full_pcd was set or
+        #  loaded from disk gets `_crop` from _segment_floors_host too, and must segment the cloud it actually holds)
+        if self.scene is None or crop is None or not isinstance(self.full_pcd, _LazyFn) or not isinstance(floor.pcd, _LazyFn):
             return None
         res = float(_get(self.cfg, "pipeline.grid_resolution", 0.05))
         markers, n_rooms, xz_min = self.scene.segment_rooms(crop[0], crop[1], floor.floor_zero_level, floor.floor_height, res)
@@ -1224,14 +1226,21 @@ class Graph:
     def _hier_index(self):
         """the node index with the levels above it resident (room name / view embeddings, floors -> rooms)"""
         ix = self._node_index()
-        if not getattr(self, "_hier_ready", False):
+        # The upper levels live ON the index object: a rebuilt index (segment_hmsg_objects, merge_objects, load_hmsg_graph
+        # reset self._index) has none, and new room names / rooms / view embeddings make the resident ones stale.  The
+        # signature is what set_hierarchy consumes, so any change to it re-uploads.
+        sig = (tuple(str(r.room_id) for r in self.rooms), tuple(getattr(r, "name", None) for r in self.rooms),
+               tuple(len(getattr(r, "embeddings", []) or []) for r in self.rooms),
+               tuple(id(getattr(r, "embeddings", None)) for r in self.rooms),
+               tuple(tuple(str(r.room_id) for r in f.rooms) for f in self.floors))
+        if getattr(ix, "_hier_sig", None) != sig:
             gl = {r.room_id: i for i, r in enumerate(self.rooms)}
             named = all(getattr(r, "name", None) is not None for r in self.rooms)
             names = self.get_text_feats_multiple_templates([r.name for r in self.rooms]) if named and self.rooms else None
             views = [np.stack(r.embeddings) if len(getattr(r, "embeddings", []) or []) else np.zeros((0, ix.D)) for r in self.rooms]
             ix.set_hierarchy([[gl[r.room_id] for r in f.rooms] for f in self.floors], names, views,
                              [int(str(r.room_id).split("_")[-1]) for r in self.rooms])
-            self._hier_ready = True
+            ix._hier_sig = sig
         return ix
 
     def query_hierarchy_batch(self, queries, top_k=1):

@@ -239,7 +239,9 @@ def check_query_golden(L):
             rooms_list = list(range(R)) if fl[j] == -1 else floor_rooms[int(fl[j])]
             assert [int(v) for v in room[j][: len(ref)]] == [rooms_list[int(v)] for v in z["ref_obj_room"][qi] if v >= 0]
         # the view-embedding branch of query_hmsg_room (top 5 room keys by their best view)
-        ok = [j for j, qi in enumerate(qs) if fl[j] != -1]       # (with floor -1 the keys are no positions: the reference's quirk)
+        # (floor -1 on the two-storey graph: rooms "0_2" and "1_2" collapse into one key that keeps the place of its best
+        #  occurrence, graph.py:3259-3264 -- the fixture holds the reference's de-duplicated lists)
+        ok = list(range(len(qs)))
         rooms_v, _, _, _ = ix.query_hier(T[ok], np.zeros(len(ok), np.int32), Tr[ok], fl[ok], np.full(len(ok), 2, np.int32), k)
         for jj, j in enumerate(ok):
             assert rooms_v[jj] == [int(v) for v in z["ref_rooms_view"][qs[j]] if v >= 0][:5], (qs[j], rooms_v[jj])
