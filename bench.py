@@ -93,7 +93,10 @@ def main():
     ap.add_argument("--queries", type=int, default=1000)
     ap.add_argument("--feat-dim", type=int, default=512)
     ap.add_argument("--topk", type=int, default=5)
-    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the CPU-oracle baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=100,
+                    help="frames of the CPU baseline (0 = skip).  100 = BASELINE.json configs[0] in full (100 frames + 100 queries, "
+                         "~100 s on the GPU box's host); the CPU rate FALLS with the number of frames -- the sequential merge "
+                         "re-clusters every cloud every frame, as the reference does")
     ap.add_argument("--mode", choices=("scene", "episode"), default="scene",
                     help="scene: one scene per GPU, node tables all-gathered (configs[1]/[3], weak scaling); episode: ONE "
                          "episode of --frames frames sharded over the GPUs -- frame windows per rank, all-reduce of the voxel "
@@ -102,10 +105,11 @@ def main():
     ap.add_argument("--inflight-steps", type=int, default=2,
                     help="scenes per handle of the extra scenes-in-flight measurement (0 = skip; N = 1 scene mode only)")
     ap.add_argument("--inflight", type=int, default=2, help="handles (scenes in flight) of that extra measurement")
-    ap.add_argument("--full-graph", action="store_true",
-                    help="graph assembly with nothing handed in: rooms from the device watershed (N1), room clouds, room embeddings and "
-                         "View nodes (A9), objects with the view <-> object test on the device (A10) -- instead of ready-made room "
-                         "regions without views (scene mode)")
+    ap.add_argument("--rooms-handed-in", action="store_true",
+                    help="round 1-3's line: ready-made room regions without views handed to the graph assembly.  The default (scene "
+                         "mode, one GPU) hands NOTHING in: rooms from the device watershed (N1), room clouds, room embeddings and "
+                         "View nodes (A9), objects with the view <-> object test on the device (A10)")
+    ap.add_argument("--full-graph", action="store_true", help="(accepted for compatibility: the default now)")
     ap.add_argument("--scene-shape", default=None,
                     help="development sizes (the simulator test): ROOMS_X,ROOMS_Z,ROOM_X_M,ROOM_Y_M,ROOM_Z_M,YAW_STEP_DEG,OBJECTS_PER_ROOM of "
                          "the synthetic building instead of configs[1]'s 4 x 2 rooms of 5 x 3 x 4 m, 10 degrees a frame, 8 objects a room")
@@ -168,7 +172,9 @@ def main():
     F, Q, D, k = args.frames, args.queries, args.feat_dim, args.topk
     episode = args.mode == "episode"
     # (episode mode: every rank sees the same episode -- same seed; scene mode: a scene per rank)
-    assert not (args.full_graph and (use_dist or episode)), "--full-graph: one scene on one GPU (the all-gathered retrieval takes the rooms as given)"
+    # the whole graph (A8-A11, nothing handed in) is the line; the multi-GPU legs take the rooms as given (the all-gathered
+    # retrieval of scene mode addresses rooms by their global ids; episode mode assembles on the root only)
+    args.full_graph = not args.rooms_handed_in and not (use_dist or episode)
     shape = {}
     if args.scene_shape:
         v = [float(x) for x in args.scene_shape.split(",")]
@@ -192,7 +198,7 @@ def main():
     for lo6 in inp["rooms"]:
         xs, zs = np.arange(lo6[0], lo6[3], 0.05), np.arange(lo6[2], lo6[5], 0.05)
         room_specs.append(dict(floor=0, vertices=np.stack(np.meshgrid(xs, zs, indexing="ij"), -1).reshape(-1, 2)))
-    # --full-graph: nothing is handed in -- the Graph gets what the reference's Graph has: a dataset to ask for a frame's pose and
+    # the default line hands nothing in -- the Graph gets what the reference's Graph has: a dataset to ask for a frame's pose and
     # image size (the images themselves stay in HBM) and the frames' global features (the F_g the fusion already received)
     full_cfg = dict(main=dict(device_id=local), models=dict(clip=dict(feat_dim=D)),
                     pipeline=dict(grid_resolution=0.05, skip_frames=1, views_on_device=True))
@@ -291,6 +297,19 @@ def main():
         sc.reset()
         T("add_frames", lambda: sc.add_frames(inp["rgb"], inp["depth"], inp["pose"], inp["K"]))
         T("finalize_map", sc.finalize_map)
+        g_early = None
+        if args.full_graph:
+            # the room level needs only the map and the frames' global features: floors, room regions (device watershed), room
+            # clouds and the camera -> room table run here (device, a few ms), scikit-learn's KMeans views on a host thread
+            # beside the fusion and the fold (Graph.start_room_level; Graph.create_feature_map does the same)
+            def rooms_early():
+                g = Graph.from_scene(sc, cfg=full_cfg, lib=L, instances=False)
+                g.dataset = FrameSource()
+                g._poses = poses_host
+                g.set_view_feats(fg_host)
+                g.start_room_level()
+                return g
+            g_early = T("room_level/device", rooms_early)
         T("add_frame_features", lambda: sc.add_frame_features(0, inp["masks"], inp["f_g"], inp["f_masked"], inp["f_crop"]))
         T("fuse_frames", sc.fuse_frames)
         T("merge_instances", sc.merge_instances)
@@ -300,9 +319,9 @@ def main():
             # A8 floors, A10 objects (device: instance DBSCAN(0.05,10), object->room share, label GEMM), A11 node
             # records -- holoagent_amd.graph.Graph, the mirror of the reference's Graph; rooms are an input.
             if args.full_graph:
-                g = T("assemble/from_scene", lambda: Graph.from_scene(sc, cfg=full_cfg, lib=L))
-                g.dataset = FrameSource()
-                g.set_view_feats(fg_host)
+                g = g_early
+                T("assemble/take_instances", g.take_instances)
+                T("assemble/wait_room_level", lambda: g._room_level["thread"].join())
                 g.set_label_feats(label_feats, label_names)
                 # floors (A8) -> per storey: rooms by the device watershed (N1), room clouds, camera -> room assignment, KMeans
                 # views and View nodes (A9) -> objects with the view <-> object test on the device (A10) -> graph (A11)
@@ -459,15 +478,31 @@ def main():
             scx.reset()
             scx.add_frames(inp["rgb"], inp["depth"], inp["pose"], inp["K"])
             scx.finalize_map()
+            if args.full_graph:
+                g = Graph.from_scene(scx, cfg=full_cfg, lib=L, instances=False)
+                g.dataset = FrameSource()
+                g._poses = poses_host
+                g.set_view_feats(fg_host)
+                g.start_room_level()
             scx.add_frame_features(0, inp["masks"], inp["f_g"], inp["f_masked"], inp["f_crop"])
             scx.fuse_frames()
             scx.merge_instances()
             scx.pool_instances()
-            g = Graph.from_scene(scx, lib=L)
-            g.set_label_feats(label_feats, label_names)
-            g.build_hier_multimodal_scene_graph(None, rooms=room_specs)
-            ix = scx.index_from_nodes()
-            ix.set_hierarchy([list(range(n_rooms))], room_name_feats, [np.zeros((0, D))] * n_rooms, list(range(n_rooms)))
+            if args.full_graph:                                    # the same step as the line: nothing handed in
+                g.take_instances()
+                g.set_label_feats(label_feats, label_names)
+                g.build_hier_multimodal_scene_graph(None)
+                gt_of = [gt_room_of(r.vertices) for r in g.rooms]
+                pos = {id(r): i for i, r in enumerate(g.rooms)}
+                ix = scx.index_from_nodes()
+                ix.set_hierarchy([[pos[id(r)] for r in fl.rooms] for fl in g.floors], room_name_feats[gt_of],
+                                 [np.zeros((0, D))] * len(g.rooms), list(range(len(g.rooms))))
+            else:
+                g = Graph.from_scene(scx, lib=L)
+                g.set_label_feats(label_feats, label_names)
+                g.build_hier_multimodal_scene_graph(None, rooms=room_specs)
+                ix = scx.index_from_nodes()
+                ix.set_hierarchy([list(range(n_rooms))], room_name_feats, [np.zeros((0, D))] * n_rooms, list(range(n_rooms)))
             ix.query_hier(text, np.zeros(len(text), np.int32), room_text, np.zeros(len(text), np.int32), np.ones(len(text), np.int32), k)
             ix.close()
             return len(g.objects)
@@ -552,8 +587,9 @@ def main():
             impl = "oracle/hmsg_oracle.py (numpy / scipy / scikit-learn; the compiled restatement was not available: %r)" % (e,)
             threading_note = "numpy / scipy / scikit-learn defaults: cKDTree.query(workers=-1) and BLAS use all cores"
         cpu = dict(value=round(n / t_cpu, 4), unit="frames/s", cores=phys, kind="port",
-                   sample="%s: create_feature_map + 100 queries on the first %d of the %d frames (640x480, D=%d, M=32); "
-                          "--cpu-frames 100 runs BASELINE.json configs[0] in full" % (impl, n, F, D),
+                   sample="%s: create_feature_map + 100 queries on the first %d of the %d frames (640x480, D=%d, M=32)%s"
+                          % (impl, n, F, D, " = BASELINE.json configs[0] in full" if n == 100 else
+                             "; --cpu-frames 100 (the default) runs BASELINE.json configs[0] in full"),
                    threading=threading_note, seconds=round(t_cpu, 2))
 
     if rank == 0:
@@ -598,6 +634,9 @@ def main():
             "scenes_in_flight": inflight,
             "roofline": roof, "cpu_baseline": cpu,
             "speedup_vs_cpu": round(fps / cpu["value"], 1) if cpu else None,
+            "speedup_vs_cpu_note": ("frames/s of the GPU path on configs[1] (%d frames) / frames/s of the CPU restatement on its %d-frame "
+                                    "sample (configs[0] when 100): two different sizes -- the CPU rate falls with the number of frames, so at "
+                                    "equal size the ratio is larger" % (F, min(args.cpu_frames, F))) if cpu else None,
         }
     sc.close()
     if use_dist:

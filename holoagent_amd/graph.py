@@ -357,47 +357,75 @@ def find_intersection_share(map_points, obj_points, radius=0.05):
     return int((idx != obj_points.shape[0]).sum()) / obj_points.shape[0]
 
 
+def camera_room_distances(room_pcds, pose_list, lib=None, device_id=0):
+    """The distance table of compute_room_embeddings (graph_utils.py:244-265): camera (x, z) -> nearest (x, z) point of every
+    room cloud, [F, R], on the device (hmsg_points_min_dist_2d)."""
+    from ._lib import points_min_dist_2d
+    flat = [np.stack([np.asarray(getattr(p, "points", p))[:, 0], np.asarray(getattr(p, "points", p))[:, 2]], axis=1)
+            for p in room_pcds]
+    cam = np.array([[pose[0, 3], pose[2, 3]] for pose in pose_list], dtype=np.float64).reshape(-1, 2)
+    return points_min_dist_2d(flat, cam, device_id=device_id, lib_=lib) if len(cam) and len(flat) else np.zeros((len(cam), len(flat)))
+
+
 def compute_room_embeddings(room_pcds, pose_list, emb_list, pcd_min, pcd_max, num_views=5, save_path=None, lib=None,
-                            device_id=0):
+                            device_id=0, dist=None):
     """utils/graph_utils.py:192-356.  Assign every image to the room whose cloud (projected to x/z) is nearest to the
     camera position, provided the camera height lies inside the floor bounds; a room that got no image takes the
     closest of the cameras OUTSIDE the floor bounds (sic, :267-291; image 0 when there is none); per room with at
     least `num_views` images, KMeans(num_views, n_init=5, max_iter=100, random_state=0) over the image embeddings and
     the member closest (dot product) to every centre.  The camera-to-room distances (F x R x room points) are
-    computed on the device (hmsg_points_min_dist_2d); KMeans is scikit-learn's, as in the reference.
+    computed on the device (camera_room_distances; `dist`: that table, already made); KMeans is scikit-learn's, as in
+    the reference.
     Returns (repr_embs_list, repr_img_ids_list, room_id2img_id, room_clip_embeddings_list)."""
     from collections import defaultdict
     from sklearn.cluster import KMeans
-    from ._lib import points_min_dist_2d
-    flat = [np.stack([np.asarray(getattr(p, "points", p))[:, 0], np.asarray(getattr(p, "points", p))[:, 2]], axis=1)
-            for p in room_pcds]
+    n_rooms = len(room_pcds)
     room_id2img_id = defaultdict(list)
-    cam = np.array([[pose[0, 3], pose[2, 3]] for pose in pose_list], dtype=np.float64).reshape(-1, 2)
     height = np.array([pose[1, 3] for pose in pose_list], dtype=np.float64)
-    dist = points_min_dist_2d(flat, cam, device_id=device_id, lib_=lib) if len(cam) and len(flat) else np.zeros((len(cam), len(flat)))
+    if dist is None:
+        dist = camera_room_distances(room_pcds, pose_list, lib=lib, device_id=device_id)
     inside = ~((height < pcd_min[1]) | (height > pcd_max[1]))
     for i in range(len(pose_list)):
         if not inside[i]:
             continue
         room_id2img_id[int(np.argmin(dist[i]))].append(i)
-    for room_id in range(len(flat)):
+    for room_id in range(n_rooms):
         if room_id not in room_id2img_id:
-            closest = np.where(inside, np.inf, dist[:, room_id]) if len(cam) else np.zeros(0)
+            closest = np.where(inside, np.inf, dist[:, room_id]) if len(pose_list) else np.zeros(0)
             room_id2img_id[room_id].append(int(np.argmin(closest)))
     repr_img_ids_list, repr_embs_list, room_clip_embeddings_list = [], [], []
-    for room_id in range(len(flat)):
+    # KMeans stays scikit-learn's (the reference's own third-party call, :329-333), run with ONE OpenMP / BLAS thread: a fit
+    # over ~10^2 rows is 3x slower with a many-thread pool than with one, and a fit over fewer rows than one Lloyd chunk
+    # (256) is the same arithmetic for any thread count.  (The fits are bound by scikit-learn's Python-level work, so host
+    # threads do not speed them up; Graph.start_room_level runs this whole stage beside the fusion and the merge fold.)
+    clips = {}
+    for room_id in range(n_rooms):
+        img_ids = room_id2img_id[room_id]
+        if len(img_ids):
+            clips[room_id] = np.squeeze(np.array([emb_list[i] for i in img_ids]), axis=1)
+    todo = [r for r in clips if len(room_id2img_id[r]) >= num_views]
+    fits = {}
+    if todo:
+        try:
+            from threadpoolctl import threadpool_limits
+        except Exception:
+            import contextlib
+            threadpool_limits = lambda limits=None: contextlib.nullcontext()
+        with threadpool_limits(limits=1):
+            fits = {r: KMeans(n_clusters=num_views, max_iter=100, n_init=5, random_state=0).fit(clips[r]) for r in todo}
+    for room_id in range(n_rooms):
         img_ids = room_id2img_id[room_id]
         if len(img_ids) == 0:
             repr_img_ids_list.append([])
             repr_embs_list.append([])
             continue
-        room_clip = np.squeeze(np.array([emb_list[i] for i in img_ids]), axis=1)
+        room_clip = clips[room_id]
         room_clip_embeddings_list.append(room_clip)
         if len(img_ids) < num_views:
             repr_img_ids_list.append(img_ids)
             repr_embs_list.append([emb for emb in room_clip])
             continue
-        kmeans = KMeans(n_clusters=num_views, max_iter=100, n_init=5, random_state=0).fit(room_clip)
+        kmeans = fits[room_id]
         labels, centers = kmeans.labels_, kmeans.cluster_centers_
         repr_img_ids, repr_embs = [], []
         for lab in np.unique(labels):
@@ -534,6 +562,14 @@ class Graph:
             sc.add_frame_features(n_done, masks, fg, fm, fc, n_masks)
             self._view_feats.extend(np.asarray(o["f_g"], np.float32).reshape(1, -1) for o in outs)
             n_done += len(outs)
+        # the room level (floors, room regions, room clouds, camera -> room table on the device; KMeans views on a host thread)
+        # needs only the map and the frames' global features: it runs beside the fusion and the fold (start_room_level)
+        if bool(p("room_level_beside_fusion", True)) and len(self._view_feats) == len(ids):
+            try:
+                self.start_room_level()
+            except Exception as e:                                         # build_hier_multimodal_scene_graph does it in place
+                print("room level not started early:", e)
+                self.floors, self._room_level = [], None
         sc.fuse_frames()
         self.full_feats_array = sc.map_feats()
         sc.merge_instances()
@@ -737,29 +773,60 @@ class Graph:
         INDEX (an int, :1176-1189)."""
         if isinstance(floor, (int, np.integer)):
             floor = self.floors[int(floor)]
+        ctx = self._rooms_prepare(floor, room_2d_points, room_pcds)
+        if ctx is None:
+            return None
+        self._rooms_embed(ctx, path)
+        return self._rooms_finish(floor, ctx)
+
+    # segment_hmsg_room in three stages, so that the middle one -- pure host work, scikit-learn's KMeans: ~35 ms per room -- can
+    # run on a host thread beside the fusion and the merge fold (start_room_level); the result is the same either way.
+    def _rooms_prepare(self, floor, room_2d_points=None, room_pcds=None):
+        """Stage 1, device: regions (:942-1084), room clouds (:1086-1108), poses / global features of the processed frames
+        (:1119-1136) and the camera -> room distance table (graph_utils.py:244-265)."""
         if room_2d_points is None:
             room_2d_points = self._room_regions_device(floor)
         if room_2d_points is None:
             print("no room regions: the floor cloud is not a slab of the resident map (pass room_2d_points)")
             return None
         skip = int(_get(self.cfg, "pipeline.skip_frames", 1))
-        floor_pts = np.asarray(floor.pcd.points)
         if room_pcds is None:
             room_pcds = self._room_clouds_device(floor, [np.asarray(r, np.float64).reshape(-1, 2) for r in room_2d_points])
         if room_pcds is None:
+            floor_pts = np.asarray(floor.pcd.points)
             tree = cKDTree(floor_pts)
             room_pcds = [self._room_cloud(floor, tree, np.asarray(r, np.float64).reshape(-1, 2)) for r in room_2d_points]
         ids = list(range(0, len(self.dataset), skip)) if self.dataset is not None else list(range(len(self._poses)))
-        pose_list = [np.asarray(self.dataset[i][2], np.float64) for i in ids] if self.dataset is not None else list(self._poses)
+        have = getattr(self, "_poses", None)
+        if have is not None and len(have) == len(ids):                     # loop A kept them: no second read of every frame
+            pose_list = [np.asarray(q, np.float64) for q in have]
+        else:
+            pose_list = [np.asarray(self.dataset[i][2], np.float64) for i in ids] if self.dataset is not None else list(self._poses)
         F_g_list = self._view_feats
         if len(F_g_list) != len(pose_list) and self.encoders is not None and self.dataset is not None:
             F_g_list = [np.asarray(self.encoders.extract(np.asarray(self.dataset[i][0]))["f_g"], np.float32).reshape(1, -1)
                         for i in ids]
         assert len(F_g_list) == len(pose_list), "one global feature per processed frame (set_view_feats)"
-        pcd_min, pcd_max = floor_pts.min(axis=0), floor_pts.max(axis=0)
-        repr_embs, repr_ids, room_id2img_id, room_clip = compute_room_embeddings(
-            room_pcds, pose_list, F_g_list, pcd_min, pcd_max, 24, path, lib=self.L,
-            device_id=int(_get(self.cfg, "main.device_id", 0)))
+        if isinstance(floor.pcd, _LazyFn) and floor.pcd._n and np.asarray(floor.vertices).shape == (8, 3):
+            # a slab of the resident map: its AABB came back with hmsg_segment_floors (vertices: min first, max fifth)
+            pcd_min, pcd_max = np.asarray(floor.vertices[0], np.float64), np.asarray(floor.vertices[4], np.float64)
+        else:
+            floor_pts = np.asarray(floor.pcd.points)
+            pcd_min, pcd_max = floor_pts.min(axis=0), floor_pts.max(axis=0)
+        dist = camera_room_distances(room_pcds, pose_list, lib=self.L, device_id=int(_get(self.cfg, "main.device_id", 0)))
+        return dict(room_2d_points=room_2d_points, room_pcds=room_pcds, pose_list=pose_list, F_g_list=F_g_list, pcd_min=pcd_min,
+                    pcd_max=pcd_max, dist=dist, skip=skip)
+
+    @staticmethod
+    def _rooms_embed(ctx, path=None):
+        """Stage 2, host only (no handle, no Graph state): camera -> room assignment + KMeans(24) representative views."""
+        ctx["emb"] = compute_room_embeddings(ctx["room_pcds"], ctx["pose_list"], ctx["F_g_list"], ctx["pcd_min"], ctx["pcd_max"], 24,
+                                             path, dist=ctx["dist"])
+
+    def _rooms_finish(self, floor, ctx):
+        """Stage 3: Room nodes (:1147-1168) and one View node per (room, image) (:1176-1189)."""
+        room_2d_points, room_pcds, skip = ctx["room_2d_points"], ctx["room_pcds"], ctx["skip"]
+        repr_embs, repr_ids, room_id2img_id, room_clip = ctx["emb"]
         assert len(repr_embs) == len(room_2d_points) and len(room_id2img_id) == len(room_2d_points)
         self.room_id2img_ids = room_id2img_id
         for i in range(len(room_2d_points)):
@@ -784,6 +851,31 @@ class Graph:
                 view_index += 1
                 floor.rooms[room_id].views.append(view)
         return room_pcds
+
+    def start_room_level(self):
+        """The room level beside the fusion and the merge fold.  Floors (A8), room regions, room clouds and the camera -> room
+        distance table (A9) need only the finished MAP and the frames' global features, not the instances: call this right
+        after hmsg_finalize_map (create_feature_map does) -- the device work (a few ms) runs here, on the handle's stream, and
+        the host-only rest (scikit-learn's KMeans, ~35 ms per room) on a host thread while the calling thread drives the
+        fusion, the fold and the pooling (ctypes calls release the GIL).  build_hier_multimodal_scene_graph picks the result
+        up; without this call it does the same work in place, with the same result."""
+        import threading
+        if self.floors or getattr(self, "_room_level", None) is not None:
+            return
+        self.segment_floors_manually(None)
+        ctxs = [self._rooms_prepare(fl) for fl in self.floors]
+        box = dict(ctxs=ctxs, err=None)
+
+        def work():
+            try:
+                for c in ctxs:
+                    if c is not None:
+                        self._rooms_embed(c)
+            except BaseException as e:                                     # re-raised by the thread that joins
+                box["err"] = e
+        box["thread"] = threading.Thread(target=work, name="hmsg-room-level", daemon=True)
+        box["thread"].start()
+        self._room_level = box
 
     def set_label_feats(self, text_feats, classes):
         self._label_feats = (np.asarray(text_feats, np.float32), list(classes))
@@ -832,38 +924,68 @@ class Graph:
         # its size and pose; the test itself is numpy here, or -- pipeline.views_on_device -- one batch on the device
         # (hmsg_object_views) that never brings an object's points to the host.
         K, cams = None, {}
-        def camera(v):
-            if v.img_id not in cams:
-                img, _, pose, _, _ = self.dataset[v.img_id]
+        def camera(img_id):
+            if img_id not in cams:
+                img, _, pose, _, _ = self.dataset[img_id]
                 a = np.asarray(img)
-                cams[v.img_id] = (a.shape[1], a.shape[0], np.linalg.inv(pose))
-            return cams[v.img_id]
-        pairs = [(k, v) for k, (obj, room, i) in enumerate(made) for v in room.views
-                 if self.dataset is not None and v.img_id is not None]
-        if pairs:
-            K = self._K if self._K is not None else np.asarray(self.dataset.get_camera_intrinsics())
-        if pairs and self.scene is not None and bool(_get(self.cfg, "pipeline.views_on_device", False)):
-            ids = sorted({v.img_id for _, v in pairs})
-            col = {img_id: c for c, img_id in enumerate(ids)}
-            first = {}
-            for _, v in pairs:
-                first.setdefault(v.img_id, v)
-            cam = {img_id: camera(first[img_id]) for img_id in ids}
-            vis, md = self.scene.object_views(np.stack([cam[i][2] for i in ids]), [[cam[i][0], cam[i][1]] for i in ids], K,
-                                              [made[k][2] for k, _ in pairs], [col[v.img_id] for _, v in pairs])
-            verdicts = list(zip(vis.tolist(), md.tolist()))
-        else:
-            verdicts = [check_object_in_view(*camera(v)[:2], K, camera(v)[2], made[k][0].pcd.points) for k, v in pairs]
+                cams[img_id] = (a.shape[1], a.shape[0], np.linalg.inv(pose))
+            return cams[img_id]
+        # (object k, view) pairs in the reference's order -- objects in list order, each with its room's views in order --
+        # as index arrays: ~10^5 pairs at 800 objects x 125 views a room
+        usable = self.dataset is not None
+        room_views = {}
+        for _, room, _ in made:
+            if id(room) not in room_views:
+                room_views[id(room)] = [v for v in room.views if usable and v.img_id is not None]
+        all_views, vpos = [], {}
+        for vs in room_views.values():
+            for v in vs:
+                if id(v) not in vpos:
+                    vpos[id(v)] = len(all_views)
+                    all_views.append(v)
+        room_vidx = {r: np.array([vpos[id(v)] for v in vs], np.int64) for r, vs in room_views.items()}
+        counts = np.array([len(room_vidx[id(room)]) for _, room, _ in made], np.int64)
+        pair_k = np.repeat(np.arange(len(made), dtype=np.int64), counts)
+        pair_v = np.concatenate([room_vidx[id(room)] for _, room, _ in made]) if len(made) and counts.sum() else np.zeros(0, np.int64)
         best = {}
-        for (k, v), (ok, md_) in zip(pairs, verdicts):
-            if not ok:
-                continue
-            obj = made[k][0]
-            obj.view_ids.append(v.view_id)
-            v.object_ids.append(obj.object_id)
-            v.text_discription.append(obj.name)
-            if md_ < best.get(k, (float("inf"), None))[0]:
-                best[k] = (md_, v.view_id)
+        if len(pair_k):
+            K = self._K if self._K is not None else np.asarray(self.dataset.get_camera_intrinsics())
+            view_img = np.array([v.img_id for v in all_views], np.int64)
+            if self.scene is not None and bool(_get(self.cfg, "pipeline.views_on_device", False)):
+                ids = np.unique(view_img)                                   # sorted image ids = camera table rows
+                cam = [camera(int(i)) for i in ids]
+                col_of_view = np.searchsorted(ids, view_img)
+                inst = np.array([i for _, _, i in made], np.int64)
+                vis, md = self.scene.object_views(np.stack([c[2] for c in cam]), [[c[0], c[1]] for c in cam], K,
+                                                  inst[pair_k], col_of_view[pair_v])
+            else:
+                res = [check_object_in_view(*camera(all_views[v].img_id)[:2], K, camera(all_views[v].img_id)[2], made[k][0].pcd.points)
+                       for k, v in zip(pair_k.tolist(), pair_v.tolist())]
+                vis = np.array([r[0] for r in res], bool)
+                md = np.array([r[1] for r in res], np.float64)
+            hit = np.nonzero(vis)[0]
+            hk, hv, hmd = pair_k[hit], pair_v[hit], md[hit]
+            view_ids = [v.view_id for v in all_views]
+            obj_ids = [obj.object_id for obj, _, _ in made]
+            obj_names = [obj.name for obj, _, _ in made]
+            # per object: its visible views in pair order (the pairs are sorted by object already); best view = the first
+            # strictly smallest mean depth (:1727-1731)
+            cut = np.searchsorted(hk, np.arange(len(made) + 1))
+            hv_l = hv.tolist()
+            for k in range(len(made)):
+                a0, a1 = int(cut[k]), int(cut[k + 1])
+                if a1 > a0:
+                    made[k][0].view_ids.extend(view_ids[j] for j in hv_l[a0:a1])
+                    best[k] = (None, view_ids[hv_l[a0 + int(np.argmin(hmd[a0:a1]))]])
+            # per view: the objects that see it, in object order (a stable sort by view keeps the pair order inside a view)
+            order = np.argsort(hv, kind="stable")
+            sv, sk = hv[order], hk[order].tolist()
+            vcut = np.searchsorted(sv, np.arange(len(all_views) + 1))
+            for j, v in enumerate(all_views):
+                a0, a1 = int(vcut[j]), int(vcut[j + 1])
+                if a1 > a0:
+                    v.object_ids.extend(obj_ids[k] for k in sk[a0:a1])
+                    v.text_discription.extend(obj_names[k] for k in sk[a0:a1])
         for k, (obj, room, i) in enumerate(made):
             obj.best_view_id = best.get(k, (None, None))[1]
             room.add_object(obj)
@@ -898,6 +1020,20 @@ class Graph:
         """graph.py:2033-2076 (navigation graph omitted).  Rooms: by default segment_hmsg_room per floor with the
         device room segmentation; `room_regions` = per floor a list of [n, 2] (x, z) region point arrays -> the same
         from the regions on (room clouds, room embeddings, View nodes); or `rooms` = ready-made room specs (set_rooms)."""
+        early = getattr(self, "_room_level", None)
+        if early is not None and rooms is None and room_regions is None:
+            early["thread"].join()
+            self._room_level = None
+            if early["err"] is not None:
+                raise early["err"]
+            for fl, ctx in zip(self.floors, early["ctxs"]):
+                if ctx is not None:
+                    self._rooms_finish(fl, ctx)
+            return self._build_hier_tail(save_path)
+        if early is not None:                                              # (rooms handed in after all: drop the prepared ones)
+            early["thread"].join()
+            self._room_level = None
+            self.floors = []
         self.segment_floors_manually(save_path)
         if room_regions is not None:
             for fl, regions in zip(self.floors, room_regions):
@@ -907,6 +1043,9 @@ class Graph:
                 self.segment_hmsg_room(fl, save_path)
         if rooms is not None:
             self.set_rooms(rooms)
+        return self._build_hier_tail(save_path)
+
+    def _build_hier_tail(self, save_path):
         self.segment_hmsg_objects(save_path)
         if _get(self.cfg, "pipeline.merge_objects_graph", False):          # graph.py:2053-2058 (false in every shipped config)
             for room in self.rooms:
@@ -1284,13 +1423,20 @@ class Graph:
 
     # ------------------------------------------------------------------ assembly on an already built Scene
     @classmethod
-    def from_scene(cls, scene: Scene, cfg=None, encoders=None, lib: HmsgLib | None = None):
+    def from_scene(cls, scene: Scene, cfg=None, encoders=None, lib: HmsgLib | None = None, instances=True):
         """Wrap a Scene whose A1..A7 stages already ran (bench.py / services that drive the C ABI directly):
-        the returned Graph can run build_hier_multimodal_scene_graph (A8, A10, A11) and the queries."""
+        the returned Graph can run build_hier_multimodal_scene_graph (A8, A10, A11) and the queries.
+        instances=False: only the MAP is final so far (hmsg_finalize_map) -- enough for start_room_level; call
+        take_instances() once the merge and the pooling have run."""
         g = cls(cfg or dict(main=dict(), models=dict(clip=dict(feat_dim=scene.cfg.feat_dim))), encoders=encoders,
                 lib=lib or scene.L)
         g.scene = scene
         g.full_pcd = _LazyFn(scene.map_points, scene.map_size())     # stays in HBM until read
-        g.mask_feats = list(scene.instance_feats())
-        g.mask_pcds = [None] * len(g.mask_feats)
+        if instances:
+            g.take_instances()
         return g
+
+    def take_instances(self):
+        """the pooled instance features of the resident scene (after hmsg_pool_instances)"""
+        self.mask_feats = list(self.scene.instance_feats())
+        self.mask_pcds = [None] * len(self.mask_feats)

@@ -9,7 +9,8 @@ bins and their orientation, the 10-pixel border, the order of the morphology, th
 background marker, map_grid_to_point_cloud's (-10.5 cell) offset, the extrusion + rotation + nearest-neighbour selection of
 the room clouds, the camera -> room assignment and KMeans views of compute_room_embeddings, Room fields and View ids.
 
-    python -m oracle.refdrive.gen_golden_rooms        # writes tests/golden/rooms.npz
+    python -m oracle.refdrive.gen_golden_rooms            # writes tests/golden/rooms.npz (from a storey's point cloud)
+    python -m oracle.refdrive.gen_golden_rooms --frames   # writes tests/golden/rooms_frames.npz (from posed RGB-D frames on)
 """
 import os
 import sys
@@ -202,5 +203,73 @@ def main():
           "views", len(g.views))
 
 
+def frames_case():
+    """A storey of two closed rooms side by side, seen from the inside: 60 posed RGB-D frames (160 x 120) -- the input of
+    the WHOLE path, so that the room level can be checked from frames on (map -> floors -> rooms -> room clouds -> views)."""
+    from holoagent_amd.synth import SceneSpec, SynthScene
+    spec = SceneSpec(seed=40, rooms_x=2, rooms_z=1, room_size=(3.2, 2.6, 3.0), objects_per_room=3, width=160, height=120,
+                     n_frames=60, n_masks=2, feat_dim=16, yaw_step_deg=12.0)
+    sc = SynthScene(spec)
+    return spec, [sc.frame(i) for i in range(spec.n_frames)]
+
+
+def main_frames():
+    """tests/golden/rooms_frames.npz: the reference's create_feature_map (map), segment_floors_manually and
+    segment_hmsg_room driven from FRAMES (same stand-ins as above)."""
+    from oracle.refdrive.gen_golden import drive_create_feature_map
+    G, X = import_reference()
+    import memory.hmsg.utils.graph_utils as GU
+    cv2 = make_cv2()
+    G.cv2 = cv2
+    GU.cv2 = cv2
+    spec, frames = frames_case()
+    cfg = dict(voxel_size=0.05, skip_frames=1, init_overlap_thresh=0.75, overlap_thresh_factor=0.025, iou_thresh=0.05,
+               clip_masked_weight=0.4418, clip_bbox_margin=50, max_mask_distance=10000, merge_type="sequential", feat_dim=spec.feat_dim)
+    g = drive_create_feature_map(G, X, frames, cfg)                # graph.py:262-491: the map is g.full_pcd
+    cloud = np.asarray(g.full_pcd.points, np.float64).copy()
+    tmp = tempfile.mkdtemp()
+    g.cfg = AttrDict(main=AttrDict(save_path=tmp), pipeline=AttrDict(grid_resolution=0.05, save_intermediate_results=False, skip_frames=1))
+    g.graph_tmp_folder = tmp
+    g.floors, g.rooms, g.views, g.room_masks = [], [], [], {}
+    ranges = g.segment_floors_manually(None)                       # graph.py:624-787
+    state = dict(i=-1)
+    ds = g.dataset
+    get = type(ds).__getitem__
+
+    class DS(type(ds)):
+        frameId2imgPath = {i: "img_%04d.png" % i for i in range(len(frames))}
+
+        def __getitem__(self, i):
+            state["i"] = i
+            return get(self, i)
+    ds.__class__ = DS
+    G.get_img_feats = lambda img, pre, model: np.asarray(frames[state["i"]]["f_g"], np.float32).reshape(1, -1).copy()
+    g.preprocess, g.clip_model = None, None
+    for fl in g.floors:
+        g.segment_hmsg_room(fl, tmp)                               # graph.py:920-1189
+    out = dict(rgb=np.stack([f["rgb"] for f in frames]), depth=np.stack([f["depth"] for f in frames]),
+               pose=np.stack([f["pose"] for f in frames]), K=frames[0]["K"],
+               f_g=np.stack([np.asarray(f["f_g"], np.float32).reshape(-1) for f in frames]),
+               ref_cloud=cloud, floor_ranges=np.array(ranges, np.float64).reshape(-1, 2),
+               floor_zero=np.array([f.floor_zero_level for f in g.floors]), floor_height=np.array([f.floor_height for f in g.floors]),
+               n_rooms=np.array(len(g.rooms)), room_floor=np.array([int(r.floor_id) for r in g.rooms], np.int64),
+               view_ids=np.array([v.view_id for v in g.views]), view_room=np.array([v.room_id for v in g.views], np.int64),
+               view_img=np.array([v.img_id for v in g.views], np.int64), view_path=np.array([v.img_path for v in g.views]))
+    for i, r in enumerate(g.rooms):
+        out["vertices_%d" % i] = np.asarray(r.vertices, np.float64)
+        rp = np.asarray(r.pcd.points, np.float64)
+        out["cloud_%d" % i] = rp[np.lexsort((rp[:, 2], rp[:, 1], rp[:, 0]))]     # a SET of map points (the map's order is Open3D's hash order)
+        out["represent_%d" % i] = np.array(r.represent_images, np.int64)
+        out["sample_%d" % i] = np.array(r.sample_images, np.int64)
+        out["emb_%d" % i] = np.asarray(r.embeddings, np.float32).reshape(len(r.represent_images), -1)
+        out["id_%d" % i] = np.array(r.room_id)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "rooms_frames.npz"), **out)
+    print("map", cloud.shape, "floors", ranges, "rooms", [(str(r.room_id), len(r.vertices), len(r.pcd.points), len(r.sample_images),
+                                                          len(r.represent_images)) for r in g.rooms], "views", len(g.views))
+
+
 if __name__ == "__main__":
-    main()
+    if "--frames" in sys.argv:
+        main_frames()
+    else:
+        main()

@@ -209,3 +209,26 @@ def segment_rooms(floor_pts, zero_level, height, resolution):
     full, xz_min = full_map_of_floor(floor_pts, zero_level, height, resolution)
     markers, R = distance_transform(full, resolution)
     return markers, R, xz_min
+
+
+def room_cloud(floor_pts, room_xz, zero_level, height):
+    """The room's 3-D cloud (graph.py:1086-1108): the room's 2-D cell centres extruded over the storey in 5 cm steps
+    (`np.arange(zero, zero + height, 0.05)`, negated, :1088-1092), turned into the map frame by Open3D's transform with
+    scipy's 90 degree rotation about x (:1095-1103; cos(90 deg) = 6.1e-17 is part of the arithmetic), every extruded point
+    replaced by its nearest floor point (cKDTree, :1105-1106) and the hits selected from the floor cloud -- unique, in the
+    floor cloud's order (Open3D select_by_index, :1107).  Returns the indices into `floor_pts`."""
+    from scipy.spatial import cKDTree
+    from scipy.spatial.transform import Rotation
+    z_levels = np.arange(zero_level, zero_level + height, 0.05).reshape(-1, 1)
+    z_levels *= -1
+    room_xz = np.asarray(room_xz, np.float64).reshape(-1, 2)
+    m3d = np.concatenate([np.hstack((room_xz, np.ones((room_xz.shape[0], 1)) * z)) for z in z_levels], axis=0)
+    T = np.eye(4)
+    T[:3, :3] = Rotation.from_euler("x", 90, degrees=True).as_matrix()
+    X, Y, Z = m3d[:, 0], m3d[:, 1], m3d[:, 2]
+    rows = [((X * T[r, 0] + Y * T[r, 1]) + Z * T[r, 2]) + T[r, 3] for r in range(4)]       # Open3D's Transform, row by row
+    pts = np.stack([rows[0] / rows[3], rows[1] / rows[3], rows[2] / rows[3]], axis=1)
+    _, idx = cKDTree(np.asarray(floor_pts, np.float64)).query(pts, k=1)
+    keep = np.zeros(len(floor_pts), bool)
+    keep[idx] = True
+    return np.nonzero(keep)[0]

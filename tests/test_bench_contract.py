@@ -21,7 +21,7 @@ def test_bench_line_full_graph_on_the_simulator():
     env.pop("WORLD_SIZE", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "12", "--queries", "8", "--feat-dim", "16", "--width", "96",
            "--height", "72", "--scene-shape", "2,1,3.2,2.6,3.0,36,3", "--steps", "1", "--warmup", "0", "--cpu-frames", "2",
-           "--inflight-steps", "0", "--full-graph"]
+           "--inflight-steps", "0"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]

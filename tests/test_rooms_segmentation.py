@@ -190,9 +190,8 @@ def test_graph_rooms_from_the_device_segmentation_emu():
     from holoagent_amd.graph import Graph, _Pcd
     L = HmsgLib(PC.EMU_PATH)
     sc, frames = _two_storey_scene(L)
-    g = Graph(dict(main=dict(), models=dict(clip=dict(feat_dim=16)), pipeline=dict(grid_resolution=0.1)), lib=L)
-    g.scene = sc
-    g.full_pcd = _Pcd(sc.map_points())
+    g = Graph.from_scene(sc, cfg=dict(main=dict(), models=dict(clip=dict(feat_dim=16)), pipeline=dict(grid_resolution=0.1)), lib=L,
+                         instances=False)
     g._poses = [np.asarray(f["pose"], np.float64) for f in frames]
     g._view_feats = [np.asarray(f["f_g"], np.float32).reshape(1, -1) for f in frames]
     g.segment_floors_manually(None)
