@@ -205,7 +205,84 @@ __global__ void k_floor_mask(const double* __restrict__ pts, long long V, double
     ok[i] = in ? 1 : 0;
     okw[i] = in ? 1u : 0u;
 }
-__global__ void __launch_bounds__(256) k_room_nn(NNIndex I, const unsigned char* __restrict__ ok, const unsigned* __restrict__ floor_rank,
+// The extruded points fill the ROOM'S VOLUME: most of them hang in mid-air, metres from the nearest surviving map point
+// (remove_radius_outlier deletes ~90 % of the voxels of a sparsely furnished room), where ring expansion over the 5 cm
+// occupancy grid costs O(r^2) probes per ring.  For this stage the storey's points are binned once into a COARSE grid
+// (cells of >= 25 cm, at most 64 along the vertical so that one word holds a column's occupancy): a query expands rings of
+// coarse cells, tests the points of the occupied ones, and stops when the cube it has covered reaches past its best hit.
+struct CoarseGrid {
+    double ox, oy, oz, cs;
+    int nx, ny, nz;                           // ny <= 64 (vertical)
+    const unsigned* start;                    // [nx * nz * ny + 1], cell = (ix * nz + iz) * ny + iy
+    const int* idx;                           // map point indices, cell by cell
+    const unsigned long long* col;            // [nx * nz] occupied iy bits
+};
+__device__ __forceinline__ void coarse_cell(const CoarseGrid& c, double x, double y, double z, int& ix, int& iy, int& iz) {
+    ix = (int)floor((x - c.ox) / c.cs);
+    iy = (int)floor((y - c.oy) / c.cs);
+    iz = (int)floor((z - c.oz) / c.cs);
+    ix = ix < 0 ? 0 : (ix >= c.nx ? c.nx - 1 : ix);
+    iy = iy < 0 ? 0 : (iy >= c.ny ? c.ny - 1 : iy);
+    iz = iz < 0 ? 0 : (iz >= c.nz ? c.nz - 1 : iz);
+}
+__global__ void k_coarse_count(const double* __restrict__ pts, const unsigned char* __restrict__ ok, long long V, CoarseGrid c, unsigned* __restrict__ cnt,
+                               unsigned long long* __restrict__ col) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V || !ok[i]) return;
+    int ix, iy, iz;
+    coarse_cell(c, pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2], ix, iy, iz);
+    atomicAdd(&cnt[((size_t)ix * c.nz + iz) * c.ny + iy], 1u);
+    const unsigned long long bit = 1ull << iy;
+    if (!(col[(size_t)ix * c.nz + iz] & bit)) atomicOr(&col[(size_t)ix * c.nz + iz], bit);
+}
+__global__ void k_coarse_fill(const double* __restrict__ pts, const unsigned char* __restrict__ ok, long long V, CoarseGrid c, unsigned* __restrict__ cursor,
+                              int* __restrict__ idx) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V || !ok[i]) return;
+    int ix, iy, iz;
+    coarse_cell(c, pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2], ix, iy, iz);
+    const size_t cell = ((size_t)ix * c.nz + iz) * c.ny + iy;
+    idx[c.start[cell] + atomicAdd(&cursor[cell], 1u)] = (int)i;      // (order inside a cell is irrelevant: minimum + tie COUNT)
+}
+__device__ inline int coarse_nn(const CoarseGrid& c, const double* __restrict__ pts, double qx, double qy, double qz, int* out_ntie) {
+    int cx, cy, cz;
+    coarse_cell(c, qx, qy, qz, cx, cy, cz);
+    NNBest best{1e300, -1, 0};
+    const int rmax = max(c.nx, max(c.ny, c.nz));
+    for (int r = 0; r <= rmax; ++r) {
+        const int y0 = max(cy - r, 0), y1 = min(cy + r, c.ny - 1);
+        const unsigned long long span = (y1 >= 63 ? ~0ull : ((1ull << (y1 + 1)) - 1ull)) & ~((1ull << y0) - 1ull);
+        unsigned long long shell = 0ull;                         // the two new layers of an inner column
+        if (cy - r >= 0) shell |= 1ull << (cy - r);
+        if (cy + r < c.ny) shell |= 1ull << (cy + r);
+        for (int dx = -r; dx <= r; ++dx) {
+            const int ix = cx + dx;
+            if (ix < 0 || ix >= c.nx) continue;
+            for (int dz = -r; dz <= r; ++dz) {
+                const int iz = cz + dz;
+                if (iz < 0 || iz >= c.nz) continue;
+                const bool rim = dx == -r || dx == r || dz == -r || dz == r;
+                unsigned long long m = c.col[(size_t)ix * c.nz + iz] & (rim ? span : shell);
+                while (m) {
+                    const int iy = __ffsll(m) - 1;
+                    m &= m - 1ull;
+                    const size_t cell = ((size_t)ix * c.nz + iz) * c.ny + iy;
+                    for (unsigned k = c.start[cell]; k < c.start[cell + 1]; ++k) {
+                        const int q = c.idx[k];
+                        nn_consider(best, q, nn_dist2(pts + (size_t)q * 3, qx, qy, qz));
+                    }
+                }
+            }
+        }
+        // every cell within Chebyshev distance r of the query's (clamped) cell is done; a point of any other cell is at
+        // least r cell sides away (the query lies in, or beyond, its own cell)
+        const double m = (double)r * c.cs - 1e-9;
+        if (best.idx >= 0 && m > 0.0 && best.d2 < m * m) break;
+    }
+    *out_ntie = best.ntie;
+    return best.idx;
+}
+__global__ void __launch_bounds__(256) k_room_nn(CoarseGrid C, const double* __restrict__ map_pts, const unsigned* __restrict__ floor_rank,
                                                  long long NF, const double* __restrict__ T, int n_levels, const double* __restrict__ z_levels,
                                                  int n_rooms, const long long* __restrict__ room_off, const double* __restrict__ room_xz,
                                                  unsigned char* __restrict__ mark, unsigned* __restrict__ n_ties, RoomTie* __restrict__ ties,
@@ -228,7 +305,7 @@ __global__ void __launch_bounds__(256) k_room_nn(NNIndex I, const unsigned char*
         r[k] = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(X, T[k * 4]), __dmul_rn(Y, T[k * 4 + 1])), __dmul_rn(Z, T[k * 4 + 2])), T[k * 4 + 3]);
     const double px = __ddiv_rn(r[0], r[3]), py = __ddiv_rn(r[1], r[3]), pz = __ddiv_rn(r[2], r[3]);
     int ntie = 0;
-    const int idx = nn_search_subset(I, ok, px, py, pz, &ntie);
+    const int idx = coarse_nn(C, map_pts, px, py, pz, &ntie);
     if (idx < 0) return;
     if (ntie > 1) {
         const unsigned k = atomicAdd(n_ties, 1u);
@@ -286,9 +363,42 @@ extern "C" int hmsg_room_clouds(hmsg_t* h, double y_lo, double y_hi, const doubl
         HIP_TRY(hipMemcpyAsync(doff.p, hoff.data(), hoff.size() * 8, hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemsetAsync(mark.p, 0, (size_t)n_rooms * NF, s));
         HIP_TRY(hipMemsetAsync(nt.p, 0, 4, s));
-        NNIndex I = hmsg_nn_index(h);
+        // the storey's points in a coarse grid over the map's extent (vertical = y; at most 64 cells along it)
+        CoarseGrid C;
+        {
+            const GridGeom& g = h->grid;
+            const double ex = g.nx * g.vs, ey = g.ny * g.vs, ez = g.nz * g.vs;
+            C.cs = std::max(0.25, ey / 60.0);
+            C.ox = g.ox;
+            C.oy = g.oy;
+            C.oz = g.oz;
+            C.nx = (int)std::floor(ex / C.cs) + 1;
+            C.ny = std::min(64, (int)std::floor(ey / C.cs) + 1);
+            C.nz = (int)std::floor(ez / C.cs) + 1;
+        }
+        const size_t ncc = (size_t)C.nx * C.ny * C.nz;
+        HMSG_REQUIRE(ncc < ((size_t)1 << 31), HMSG_ERR_UNSUPPORTED, "hmsg_room_clouds: map extent too large for the coarse grid");
+        DevBuf<unsigned> ccnt, cstart, ccur;
+        DevBuf<int> cidx;
+        DevBuf<unsigned long long> ccol;
+        ccnt.alloc(ncc + 1);
+        cstart.alloc(ncc + 1);
+        ccur.alloc(ncc + 1);
+        cidx.alloc((size_t)NF);
+        ccol.alloc((size_t)C.nx * C.nz);
+        HIP_TRY(hipMemsetAsync(ccnt.p, 0, (ncc + 1) * 4, s));
+        HIP_TRY(hipMemsetAsync(ccur.p, 0, (ncc + 1) * 4, s));
+        HIP_TRY(hipMemsetAsync(ccol.p, 0, (size_t)C.nx * C.nz * 8, s));
+        C.start = cstart.p;
+        C.idx = cidx.p;
+        C.col = ccol.p;
+        hipLaunchKernelGGL(k_coarse_count, dim3(cdiv((size_t)V, 256)), dim3(256), 0, s, (const double*)h->pts.p, (const unsigned char*)ok.p, V, C, ccnt.p, ccol.p);
+        HMSG_CHECK_LAUNCH();
+        hmsg_scan_u32(ccnt.p, cstart.p, ncc + 1, s, h->scan_tmp, nullptr);
+        hipLaunchKernelGGL(k_coarse_fill, dim3(cdiv((size_t)V, 256)), dim3(256), 0, s, (const double*)h->pts.p, (const unsigned char*)ok.p, V, C, ccur.p, cidx.p);
+        HMSG_CHECK_LAUNCH();
         const long long nq = cells * n_levels;
-        hipLaunchKernelGGL(k_room_nn, dim3(cdiv((size_t)nq, 256)), dim3(256), 0, s, I, (const unsigned char*)ok.p, (const unsigned*)frank.p, NF,
+        hipLaunchKernelGGL(k_room_nn, dim3(cdiv((size_t)nq, 256)), dim3(256), 0, s, C, (const double*)h->pts.p, (const unsigned*)frank.p, NF,
                            (const double*)dT.p, n_levels, (const double*)dz.p, n_rooms, (const long long*)doff.p, (const double*)dxz.p, mark.p, nt.p,
                            ties.p, tie_cap);
         HMSG_CHECK_LAUNCH();

@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import json
 import os
+import sys
 from typing import List, Sequence
 
 import numpy as np
@@ -784,14 +785,19 @@ class Graph:
     def _rooms_prepare(self, floor, room_2d_points=None, room_pcds=None):
         """Stage 1, device: regions (:942-1084), room clouds (:1086-1108), poses / global features of the processed frames
         (:1119-1136) and the camera -> room distance table (graph_utils.py:244-265)."""
+        import time
+        dbg = bool(os.environ.get("HMSG_DEBUG_TIMING"))
+        t0 = time.perf_counter()
         if room_2d_points is None:
             room_2d_points = self._room_regions_device(floor)
         if room_2d_points is None:
             print("no room regions: the floor cloud is not a slab of the resident map (pass room_2d_points)")
             return None
+        t1 = time.perf_counter()
         skip = int(_get(self.cfg, "pipeline.skip_frames", 1))
         if room_pcds is None:
             room_pcds = self._room_clouds_device(floor, [np.asarray(r, np.float64).reshape(-1, 2) for r in room_2d_points])
+        t2 = time.perf_counter()
         if room_pcds is None:
             floor_pts = np.asarray(floor.pcd.points)
             tree = cKDTree(floor_pts)
@@ -813,7 +819,11 @@ class Graph:
         else:
             floor_pts = np.asarray(floor.pcd.points)
             pcd_min, pcd_max = floor_pts.min(axis=0), floor_pts.max(axis=0)
+        t3 = time.perf_counter()
         dist = camera_room_distances(room_pcds, pose_list, lib=self.L, device_id=int(_get(self.cfg, "main.device_id", 0)))
+        if dbg:
+            print("[hmsg rooms] regions %.1f  room clouds %.1f  poses/feats %.1f  camera->room table %.1f ms" %
+                  ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (time.perf_counter() - t3) * 1e3), file=sys.stderr)
         return dict(room_2d_points=room_2d_points, room_pcds=room_pcds, pose_list=pose_list, F_g_list=F_g_list, pcd_min=pcd_min,
                     pcd_max=pcd_max, dist=dist, skip=skip)
 
