@@ -1111,13 +1111,22 @@ __device__ __forceinline__ bool f_is_core(const FIndexDev& ix, const FStep& st, 
 //     (thread per entry) the lane-level part of the connections of the points k_f_pre found core
 __global__ void __launch_bounds__(256) k_f_linkpre1(FIndexDev ix, FStep st) {
     const int lane = threadIdx.x & 63;
-    const unsigned n = ix.counters[FC_L_LINK0];
+    // entries: the slots k_f_pre found core, then the slots k_f_count counted -- those of them it found core (acore).
+    // (k_f_count used to append its core slots to the first list: one atomicAdd per WAVE on one counter, ~8 000 waves a
+    //  step, and same-address atomics retire one per ~11 ns on this GPU -- scripts/microbench/atom_bench.hip: that append
+    //  alone was the kernel's 88 us.)
+    const unsigned n0 = ix.counters[FC_L_LINK0], n = n0 + ix.counters[FC_L_COUNT];
     for (unsigned i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += gridDim.x * blockDim.x) {
         const unsigned i = i0 + (unsigned)lane;
         bool hard = false;
         unsigned t = 0u;
-        if (i < n) {
-            t = st.list_link0[i];
+        bool have = i < n0;
+        if (have) t = st.list_link0[i];
+        else if (i < n) {
+            t = st.list_count[i - n0];
+            have = st.acore[t] != 0;
+        }
+        if (have) {
             const FSlot sl = f_slot(st, t);
             if (!sl.own && st.mems[sl.mi].am) f_mark_promoted(ix, st, sl);            // a point of an anchor member promoted in this step
             hard = !f_link_pre(ix, st, sl, t);
@@ -1146,8 +1155,7 @@ __global__ void __launch_bounds__(FWB) k_f_count(FIndexDev ix, FStep st, unsigne
                        (unsigned long long)(st.mems[sl.mi].am ? 1 : 0);
             }
             // (its connections start in k_f_linkpre1, a thread per core point: not on one lane of this wave)
-            if (core && lane == 0) st.acore[t] = 1;
-            f_list_push(&ix.counters[FC_L_LINK0], st.list_link0, core && lane == 0, t);
+            if (core && lane == 0) st.acore[t] = 1;              // (k_f_linkpre1 picks the slot up from list_count + this flag)
         } else {
             const FTouched tr = st.touched[w - n_count];
             const FComp c = st.comps[tr.comp];

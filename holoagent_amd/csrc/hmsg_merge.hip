@@ -202,6 +202,42 @@ __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __rest
     const OvTask t = tasks[ti];
     if (dep_counts && (double)dep_counts[ti] / (double)t.dep_n > th) return;
     const OvGrid X = gr[t.x], Y = gr[t.y];
+    if (dep_counts) {
+        // Second direction, first ratio <= th: the pair merges only if MORE than th * |X| points of X (the larger cloud) have
+        // a point of Y (the smaller one) within r.  Such a point lies in Y's box grown by r, and X's own grid says how many
+        // of its points do: the sum of its cell counts over that box (z-cells of a column are contiguous: two loads per
+        // column).  A floor against a chair-sized mask stays far below the threshold -- no scan of its 10^5 points then.
+        __shared__ unsigned s_in[4];
+        const float m = r + 1e-4f;
+        int lo[3], hi[3];
+        const double xo[3] = {X.ox, X.oy, X.oz};
+        const float ymn[3] = {Y.mnx, Y.mny, Y.mnz}, ymx[3] = {Y.mxx, Y.mxy, Y.mxz};
+        const int gd[3] = {X.gx, X.gy, X.gz};
+        bool empty = false;
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = (int)floor(((double)(ymn[a] - m) - xo[a]) / X.cell);
+            hi[a] = (int)floor(((double)(ymx[a] + m) - xo[a]) / X.cell);
+            lo[a] = max(lo[a], 0);
+            hi[a] = min(hi[a], gd[a] - 1);
+            empty = empty || hi[a] < lo[a];
+        }
+        unsigned inbox = 0;
+        if (!empty) {
+            const int ncol = (hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1), wy = hi[1] - lo[1] + 1;
+            for (int q = (int)threadIdx.x; q < ncol; q += (int)blockDim.x) {
+                const long long c0 = X.ix_cell + ((long long)(lo[0] + q / wy) * X.gy + (lo[1] + q % wy)) * X.gz;
+                inbox += cells[c0 + hi[2] + 1] - cells[c0 + lo[2]];
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) inbox += __shfl_xor(inbox, o);
+        if ((threadIdx.x & 63) == 0) s_in[threadIdx.x >> 6] = inbox;
+        __syncthreads();
+        inbox = s_in[0] + s_in[1] + s_in[2] + s_in[3];
+        if (!((double)inbox / (double)X.n > th)) {
+            if (blockIdx.x == (unsigned)t.blk0 && threadIdx.x == 0) counts[ti] = 0x80000000u;   // (decided by the bound: no scan)
+            return;
+        }
+    }
     unsigned local = 0;
     // a workgroup takes OV_CHUNK consecutive points: every point is a serial chain of L2 round trips, so a
     // million-point X is spread over many workgroups (work list: exactly ceil(n / OV_CHUNK) of them per task)
@@ -547,9 +583,10 @@ struct Merger {
         double ov_work = 0;                                  // 12 B per point of every scan the decision needed
         for (size_t k = 0; k < P; ++k) {
             const int na = std::min(L[pairs[k].first].n, L[pairs[k].second].n), nb = std::max(L[pairs[k].first].n, L[pairs[k].second].n);
-            ratio[k] = std::max((double)hc[k] / (double)na, (double)hc[P + k] / (double)nb);
+            const bool bounded = (hc[P + k] & 0x80000000u) != 0;      // second direction decided by the box bound (k_ov_query)
+            ratio[k] = std::max((double)hc[k] / (double)na, bounded ? 0.0 : (double)hc[P + k] / (double)nb);
             ov_work += 12.0 * na;
-            if (!(decide_th >= 0.0 && (double)hc[k] / (double)na > decide_th)) {
+            if (!(decide_th >= 0.0 && (double)hc[k] / (double)na > decide_th) && !bounded) {
                 ov_work += 12.0 * nb;
                 if (second_ran) (*second_ran)[k] = 1;
             }
