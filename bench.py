@@ -262,7 +262,14 @@ def main():
         T("add_frame_features", lambda: sc.add_frame_features(a, inp["masks"][a:b], inp["f_g"][a:b], inp["f_masked"][a:b], inp["f_crop"][a:b]))
         T("fuse_frames", sc.fuse_frames)
         if use_dist:
-            T("allreduce_feature_sums", lambda: allreduce_feature_sums(sc, device=device))
+            if not emu and not os.environ.get("HMSG_BENCH_TORCH_GATHER"):
+                # behind the C ABI: librccl on the handle's own buffers, in place (hmsg_allreduce_feature_sums)
+                from holoagent_amd._lib import Comm
+                if state.get("comm") is None:
+                    state["comm"] = Comm.from_torch(local, L)
+                T("allreduce_feature_sums", lambda: sc.allreduce_feature_sums(state["comm"]))
+            else:
+                T("allreduce_feature_sums", lambda: allreduce_feature_sums(sc, device=device))
             holds = T("merge_tree", lambda: sharded_hierarchical_merge(sc, F, device=device))
         else:
             def whole():
@@ -345,10 +352,18 @@ def main():
         state["n_nodes_local"] = feats.shape[0]
 
         def retrieve():
+            g_ix = None
             if use_dist:
-                # all-gather of the node tables over RCCL -> global table on every rank (holoagent_amd/dist.py)
-                from holoagent_amd.dist import gather_node_tables, shard_queries
-                g_feats, g_rooms, _node_off, room_off = gather_node_tables(feats, rooms, n_rooms, device)
+                # all-gather of the node tables over RCCL -> global table on every rank.  On the GPUs the exchange runs behind
+                # the C ABI (hmsg_allgather_nodes: librccl on device buffers, the gathered table IS the resident index); the
+                # torch.distributed form (holoagent_amd/dist.py gather_node_tables) remains for the gloo CPU tests.
+                from holoagent_amd.dist import gather_node_tables, gather_node_tables_device, shard_queries
+                if not emu and not os.environ.get("HMSG_BENCH_TORCH_GATHER"):
+                    g_ix, _node_off, room_off, state["comm"] = gather_node_tables_device(sc, n_rooms, state.get("comm"), local)
+                    g_feats = np.zeros((int(_node_off[-1]), 1))            # (shape only: the table itself stays in HBM)
+                    g_rooms = None
+                else:
+                    g_feats, g_rooms, _node_off, room_off = gather_node_tables(feats, rooms, n_rooms, device)
                 qs = shard_queries(Q, rank, world)               # this rank's share of the queries
                 rl = [[r + int(room_off[rank]) for r in q_rooms[q]] for q in qs]
                 tq = np.ascontiguousarray(text[qs])
@@ -388,7 +403,7 @@ def main():
                 state["rooms_hit"] = float(np.mean([int(ent_room[e]) in s_ for e, s_ in zip(q_ent, sel)]))
                 ix.close()
                 return idx, room, score
-            ix = NodeIndex(g_feats, g_rooms, device_id=local, lib_=L)
+            ix = g_ix if g_ix is not None else NodeIndex(g_feats, g_rooms, device_id=local, lib_=L)
             ix.set_profiling(True)
             out = ix.query_objects(tq, np.zeros(len(rl), np.int32), rl, k)
             state["gemm"] = ix.profile()                       # (launches, ms, FLOP) of the float64 MFMA GEMM

@@ -120,6 +120,12 @@ _SIGS = {
     "hmsg_similarity": (C.c_int, [_P, C.c_int32, _P, _P]),
     "hmsg_index_set_hierarchy": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "hmsg_query_hier": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
+    "hmsg_comm_unique_id": (C.c_int, [_P]),
+    "hmsg_comm_create": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    "hmsg_comm_destroy": (None, [_P]),
+    "hmsg_comm_last_error": (C.c_char_p, [_P]),
+    "hmsg_allgather_nodes": (C.c_int, [_P, _P, C.c_int32, C.POINTER(_P), _P, _P]),
+    "hmsg_allreduce_feature_sums": (C.c_int, [_P, _P]),
     "hmsg_test_sort_pairs": (C.c_int, [_P, _P, C.c_int64, C.c_int32]),
     "hmsg_test_repeat_add": (C.c_int, [_P, _P, _P, _P, C.c_int64]),
     "hmsg_test_ckdtree": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P]),
@@ -181,6 +187,62 @@ def _ptr(a):
             torch.cuda.current_stream(a.device).synchronize()
         return C.c_void_p(a.data_ptr())
     raise TypeError(type(a))
+
+
+class Comm:
+    """RCCL communicator behind the C ABI (include/hmsg.h: hmsg_comm_*).  `Comm.single()` = one rank, no communicator (every
+    collective is the identity); `Comm.from_torch(device_id)` = the ranks of an initialised torch.distributed job: rank 0
+    makes the id, the process group carries the 128 bytes to the others, every rank joins with its own GPU."""
+
+    def __init__(self, h, rank, world, lib_):
+        self.h, self.rank, self.world, self.L = h, rank, world, lib_
+
+    @classmethod
+    def single(cls, device_id=0, lib_=None):
+        L = lib_ or lib()
+        h = _P()
+        rc = L.c.hmsg_comm_create(None, 0, 1, int(device_id), C.byref(h))
+        if rc != 0:
+            raise HmsgError(f"hmsg_comm_create failed ({rc})")
+        return cls(h, 0, 1, L)
+
+    @classmethod
+    def create(cls, uid: bytes, rank, world, device_id=0, lib_=None):
+        L = lib_ or lib()
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(uid))
+        h = _P()
+        rc = L.c.hmsg_comm_create(C.cast(buf, _P), int(rank), int(world), int(device_id), C.byref(h))
+        if rc != 0:
+            raise HmsgError(f"hmsg_comm_create failed ({rc}): librccl missing, or the ranks did not all join")
+        return cls(h, int(rank), int(world), L)
+
+    @staticmethod
+    def unique_id(lib_=None) -> bytes:
+        L = lib_ or lib()
+        buf = (C.c_uint8 * 128)()
+        rc = L.c.hmsg_comm_unique_id(C.cast(buf, _P))
+        if rc != 0:
+            raise HmsgError(f"hmsg_comm_unique_id failed ({rc}): librccl could not be loaded")
+        return bytes(buf)
+
+    @classmethod
+    def from_torch(cls, device_id=0, lib_=None, group=None):
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id(lib_) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls.create(box[0], rank, world, device_id, lib_)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.c.hmsg_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Scene:
@@ -482,6 +544,20 @@ class Scene:
         m = np.empty((rows.value, cols.value), np.int32)
         self._ck(self.L.c.hmsg_segment_rooms(*a, _ptr(m), m.size, C.byref(rows), C.byref(cols), C.byref(nr), _ptr(xz)))
         return m, int(nr.value), xz
+
+    def allgather_nodes(self, comm: "Comm", n_rooms_local: int):
+        """Cross-scene retrieval (include/hmsg.h: hmsg_allgather_nodes): the ranks' node tables all-gathered over RCCL, HBM
+        to HBM, into one resident index -> (NodeIndex over the global table, node_off [world + 1], room_off [world + 1])."""
+        ix = _P()
+        node_off = np.zeros(comm.world + 1, np.int64)
+        room_off = np.zeros(comm.world + 1, np.int64)
+        self._ck(self.L.c.hmsg_allgather_nodes(self.h, comm.h, int(n_rooms_local), C.byref(ix), _ptr(node_off), _ptr(room_off)))
+        return NodeIndex._wrap(self.L, ix, int(node_off[-1]), self.cfg.feat_dim), node_off, room_off
+
+    def allreduce_feature_sums(self, comm: "Comm"):
+        """One episode fused in disjoint frame windows (include/hmsg.h: hmsg_allreduce_feature_sums): sums and counters of all
+        ranks all-reduced in place over RCCL."""
+        self._ck(self.L.c.hmsg_allreduce_feature_sums(self.h, comm.h))
 
     def index_from_nodes(self):
         """Resident retrieval index over the node table, gathered on the device."""

@@ -1,0 +1,253 @@
+// Multi-GPU exchange steps behind the C ABI: RCCL collectives on DEVICE buffers, issued by the host that drives
+// the handle (a C++ service, or the Python shim through ctypes) -- no torch, no host staging of the payload.
+//
+//   scene per GPU (configs[3]): the build has no collective; for cross-scene retrieval every rank contributes its node
+//     table (embeddings f32 [n][D] gathered on the device + the parent room of every node) and receives the global table
+//     as a resident retrieval index: counts first (one 16-byte all-gather), then the payload padded to the largest table
+//     (ncclAllGather straight out of / into HBM).  Global node index = prefix offset of the owning rank + local index, room
+//     ids shifted the same way -- the index answers exactly like one built from the concatenated tables.
+//   one episode over several GPUs (configs[4]): the per-voxel feature sums and frame counters of the ranks' frame windows
+//     are all-reduced in place (graph.py:410-415: sums and counts add).
+//
+// librccl is loaded on first use (dlopen): a single-GPU process never needs it, and the kernel simulator build has none.
+#include "hmsg_common.h"
+
+#include <dlfcn.h>
+
+#include <mutex>
+
+// (device code is not linked across translation units: the two small kernels this file needs are stated here)
+__global__ void k_cm_gather_rows(const float* __restrict__ src, const int* __restrict__ row, int n, int D, float* __restrict__ dst) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n * D) return;
+    dst[t] = src[(size_t)row[t / D] * D + t % D];
+}
+// graph.py:413-415 after the sums changed: feats = sum / (count, or 1e-5 where no frame saw the voxel)
+__global__ void k_cm_feats_refresh(const float* __restrict__ sum, const unsigned* __restrict__ cnt, long long V, int D, float* __restrict__ feats) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)V * D) return;
+    const unsigned c = cnt[t / D];
+    const float d = c == 0u ? 1e-5f : (float)c;
+    feats[t] = __fdiv_rn(sum[t], d);
+}
+
+namespace {
+
+// the part of rccl.h this file needs (opaque communicator, 128-byte id, type / op codes as rccl.h:455-480 numbers them)
+typedef void* rcclComm_t;
+struct rcclUniqueId {
+    char internal[128];
+};
+enum { RCCL_INT32 = 2, RCCL_UINT32 = 3, RCCL_INT64 = 4, RCCL_FLOAT32 = 7, RCCL_SUM = 0 };
+
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(rcclUniqueId*) = nullptr;
+    int (*CommInitRank)(rcclComm_t*, int, rcclUniqueId, int) = nullptr;
+    int (*CommDestroy)(rcclComm_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, rcclComm_t, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string why;
+};
+RcclApi& rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char* n : names) {
+            api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (api.lib) break;
+        }
+        if (!api.lib) {
+            api.why = std::string("librccl.so could not be loaded: ") + (dlerror() ? dlerror() : "?");
+            return;
+        }
+        auto sym = [&](const char* s) {
+            void* p = dlsym(api.lib, s);
+            if (!p) api.why = std::string("librccl.so lacks ") + s;
+            return p;
+        };
+        api.GetUniqueId = (int (*)(rcclUniqueId*))sym("ncclGetUniqueId");
+        api.CommInitRank = (int (*)(rcclComm_t*, int, rcclUniqueId, int))sym("ncclCommInitRank");
+        api.CommDestroy = (int (*)(rcclComm_t))sym("ncclCommDestroy");
+        api.AllGather = (int (*)(const void*, void*, size_t, int, rcclComm_t, hipStream_t))sym("ncclAllGather");
+        api.AllReduce = (int (*)(const void*, void*, size_t, int, int, rcclComm_t, hipStream_t))sym("ncclAllReduce");
+        api.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+    });
+    return api;
+}
+void rccl_need() {
+    RcclApi& a = rccl();
+    if (!a.why.empty() || !a.lib) throw hmsg_error{HMSG_ERR_UNSUPPORTED, a.why.empty() ? "RCCL not available" : a.why};
+}
+void rccl_try(int rc, const char* what) {
+    if (rc == 0) return;
+    RcclApi& a = rccl();
+    throw hmsg_error{HMSG_ERR_HIP, std::string(what) + ": " + (a.GetErrorString ? a.GetErrorString(rc) : "RCCL error")};
+}
+
+}  // namespace
+
+struct hmsg_comm {
+    rcclComm_t comm = nullptr;
+    int rank = 0, world = 1, device = 0;
+    std::string err;
+};
+
+extern "C" {
+
+int hmsg_comm_unique_id(uint8_t* out_id) {
+    if (!out_id) return HMSG_ERR_INVALID;
+    try {
+        rccl_need();
+        rcclUniqueId id;
+        rccl_try(rccl().GetUniqueId(&id), "ncclGetUniqueId");
+        memcpy(out_id, id.internal, sizeof(id.internal));
+        return HMSG_OK;
+    } catch (const hmsg_error& e) {
+        return e.code;
+    }
+}
+
+int hmsg_comm_create(const uint8_t* id, int32_t rank, int32_t world, int32_t device_id, hmsg_comm_t** out) {
+    if (!out) return HMSG_ERR_INVALID;
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) return HMSG_ERR_INVALID;
+    hmsg_comm* c = new hmsg_comm();
+    c->rank = rank;
+    c->world = world;
+    c->device = device_id;
+    if (id == nullptr) {                       // one rank and no id: no communicator needed (every collective is the identity)
+        if (world != 1) {
+            delete c;
+            return HMSG_ERR_INVALID;
+        }
+        *out = c;
+        return HMSG_OK;
+    }
+    try {
+        rccl_need();
+        HIP_TRY(hipSetDevice(device_id));
+        rcclUniqueId uid;
+        memcpy(uid.internal, id, sizeof(uid.internal));
+        rccl_try(rccl().CommInitRank(&c->comm, world, uid, rank), "ncclCommInitRank");
+        *out = c;
+        return HMSG_OK;
+    } catch (const hmsg_error& e) {
+        delete c;
+        return e.code;
+    }
+}
+
+void hmsg_comm_destroy(hmsg_comm_t* c) {
+    if (!c) return;
+    if (c->comm) (void)rccl().CommDestroy(c->comm);
+    delete c;
+}
+
+const char* hmsg_comm_last_error(const hmsg_comm_t* c) { return c ? c->err.c_str() : "null communicator"; }
+
+int hmsg_allgather_nodes(hmsg_t* h, hmsg_comm_t* c, int32_t n_rooms_local, hmsg_index_t** out_index, int64_t* node_off, int64_t* room_off) {
+    if (!h || !c || !out_index) return HMSG_ERR_INVALID;
+    *out_index = nullptr;
+    try {
+        HIP_TRY(hipSetDevice(h->cfg.device_id));
+        hipStream_t s = h->stream;
+        const int W = c->world, D = h->cfg.feat_dim;
+        const long long n = (long long)h->nodes.size();
+        HMSG_REQUIRE(n_rooms_local >= 0, HMSG_ERR_INVALID, "hmsg_allgather_nodes: negative room count");
+        // 1. counts (nodes, rooms) of every rank
+        std::vector<long long> meta((size_t)W * 2, 0);
+        meta[(size_t)c->rank * 2] = n;
+        meta[(size_t)c->rank * 2 + 1] = n_rooms_local;
+        if (c->comm) {
+            DevBuf<long long> dm;
+            dm.alloc((size_t)W * 2);
+            HIP_TRY(hipMemcpyAsync(dm.p + (size_t)c->rank * 2, meta.data() + (size_t)c->rank * 2, 16, hipMemcpyHostToDevice, s));
+            rccl_try(rccl().AllGather(dm.p + (size_t)c->rank * 2, dm.p, 2, RCCL_INT64, c->comm, s), "ncclAllGather (counts)");
+            HIP_TRY(hipMemcpyAsync(meta.data(), dm.p, (size_t)W * 16, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
+        std::vector<long long> noff((size_t)W + 1, 0), roff((size_t)W + 1, 0);
+        long long nmax = 1;
+        for (int r = 0; r < W; ++r) {
+            noff[(size_t)r + 1] = noff[(size_t)r] + meta[(size_t)r * 2];
+            roff[(size_t)r + 1] = roff[(size_t)r] + meta[(size_t)r * 2 + 1];
+            nmax = std::max(nmax, meta[(size_t)r * 2]);
+        }
+        const long long N = noff[(size_t)W];
+        if (node_off) for (int r = 0; r <= W; ++r) node_off[r] = noff[(size_t)r];
+        if (room_off) for (int r = 0; r <= W; ++r) room_off[r] = roff[(size_t)r];
+        HMSG_REQUIRE(N > 0, HMSG_ERR_INVALID, "hmsg_allgather_nodes: no nodes on any rank (hmsg_build_object_nodes)");
+        // 2. payload: every rank's slot is nmax rows of D floats + nmax room ids, padded; mine is gathered on the device
+        DevBuf<float> emb;                       // [W][nmax][D]
+        DevBuf<int> room;                        // [W][nmax]
+        emb.alloc((size_t)W * nmax * D);
+        room.alloc((size_t)W * nmax);
+        float* my_emb = emb.p + (size_t)c->rank * nmax * D;
+        int* my_room = room.p + (size_t)c->rank * nmax;
+        if (n) {
+            std::vector<int> inst((size_t)n), rm((size_t)n);
+            for (long long k = 0; k < n; ++k) {
+                inst[(size_t)k] = h->nodes[(size_t)k].instance;
+                rm[(size_t)k] = h->nodes[(size_t)k].room + (int)roff[(size_t)c->rank];        // global room id
+                HMSG_REQUIRE(h->nodes[(size_t)k].room >= 0 && h->nodes[(size_t)k].room < n_rooms_local, HMSG_ERR_INVALID,
+                             "hmsg_allgather_nodes: a node's room lies outside n_rooms_local");
+            }
+            DevBuf<int> d_inst;
+            d_inst.alloc((size_t)n);
+            HIP_TRY(hipMemcpyAsync(d_inst.p, inst.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(my_room, rm.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_cm_gather_rows, dim3(cdiv((size_t)n * D, 256)), dim3(256), 0, s, (const float*)h->inst_feats.p, (const int*)d_inst.p,
+                               (int)n, D, my_emb);
+            HMSG_CHECK_LAUNCH();
+            HIP_TRY(hipStreamSynchronize(s));    // (inst / rm are stack vectors)
+        }
+        if (c->comm) {
+            rccl_try(rccl().AllGather(my_emb, emb.p, (size_t)nmax * D, RCCL_FLOAT32, c->comm, s), "ncclAllGather (embeddings)");
+            rccl_try(rccl().AllGather(my_room, room.p, (size_t)nmax, RCCL_INT32, c->comm, s), "ncclAllGather (rooms)");
+        }
+        // 3. drop the padding (device copies), hand the packed table to the index
+        DevBuf<float> packed;
+        DevBuf<int> proom;
+        packed.alloc((size_t)N * D);
+        proom.alloc((size_t)N);
+        for (int r = 0; r < W; ++r) {
+            const long long nr = meta[(size_t)r * 2];
+            if (!nr) continue;
+            HIP_TRY(hipMemcpyAsync(packed.p + (size_t)noff[(size_t)r] * D, emb.p + (size_t)r * nmax * D, (size_t)nr * D * 4, hipMemcpyDeviceToDevice, s));
+            HIP_TRY(hipMemcpyAsync(proom.p + (size_t)noff[(size_t)r], room.p + (size_t)r * nmax, (size_t)nr * 4, hipMemcpyDeviceToDevice, s));
+        }
+        HIP_TRY(hipStreamSynchronize(s));
+        return hmsg_index_create(h->cfg.device_id, D, N, packed.p, 0, proom.p, out_index);
+    } catch (const hmsg_error& e) {
+        h->err = e.msg;
+        return e.code;
+    }
+}
+
+int hmsg_allreduce_feature_sums(hmsg_t* h, hmsg_comm_t* c) {
+    if (!h || !c) return HMSG_ERR_INVALID;
+    try {
+        HIP_TRY(hipSetDevice(h->cfg.device_id));
+        HMSG_REQUIRE(h->feats_final, HMSG_ERR_INVALID, "hmsg_allreduce_feature_sums: run hmsg_fuse_frames first");
+        HMSG_REQUIRE(!h->pooled, HMSG_ERR_INVALID, "hmsg_allreduce_feature_sums after hmsg_pool_instances");
+        hipStream_t s = h->stream;
+        const size_t n = (size_t)h->V * h->cfg.feat_dim;
+        if (c->comm && n) {
+            rccl_try(rccl().AllReduce(h->sum.p, h->sum.p, n, RCCL_FLOAT32, RCCL_SUM, c->comm, s), "ncclAllReduce (feature sums)");
+            rccl_try(rccl().AllReduce(h->cnt.p, h->cnt.p, (size_t)h->V, RCCL_UINT32, RCCL_SUM, c->comm, s), "ncclAllReduce (frame counters)");
+        }
+        if (n) hipLaunchKernelGGL(k_cm_feats_refresh, dim3(cdiv(n, 256)), dim3(256), 0, s, (const float*)h->sum.p, (const unsigned*)h->cnt.p,
+                                  (long long)h->V, h->cfg.feat_dim, h->feats.p);
+        HMSG_CHECK_LAUNCH();
+        HIP_TRY(hipStreamSynchronize(s));
+        return HMSG_OK;
+    } catch (const hmsg_error& e) {
+        h->err = e.msg;
+        return e.code;
+    }
+}
+
+}  // extern "C"

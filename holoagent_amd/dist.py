@@ -36,6 +36,20 @@ def gather_node_tables(feats, rooms: np.ndarray, n_rooms_local: int, device=None
     return np.ascontiguousarray(tab[:, :D]), tab[:, D].astype(np.int32), node_off, room_off
 
 
+def gather_node_tables_device(scene, n_rooms_local: int, comm=None, device_id: int = 0, group=None):
+    """The same exchange step behind the C ABI (include/hmsg.h: hmsg_allgather_nodes): the ranks' node tables go from HBM to
+    HBM through librccl, called by the library itself on the handle's stream, and come back as ONE resident retrieval index --
+    no torch tensor, no host copy of the payload.  `comm`: a holoagent_amd._lib.Comm (made once per process; by default from
+    the initialised torch.distributed job: rank 0's 128-byte id travels through the process group).
+    Returns (NodeIndex over the global table, node_off [world + 1], room_off [world + 1], comm)."""
+    from ._lib import Comm
+    if comm is None:
+        import torch.distributed as dist
+        comm = Comm.from_torch(device_id, scene.L, group) if dist.is_initialized() else Comm.single(device_id, scene.L)
+    ix, node_off, room_off = scene.allgather_nodes(comm, n_rooms_local)
+    return ix, node_off, room_off, comm
+
+
 def shard_queries(n_queries: int, rank: int, world: int):
     """Round-robin share of the query batch for this rank."""
     return list(range(rank, n_queries, world))
@@ -147,4 +161,16 @@ def allreduce_feature_sums(scene, group=None, device=None):
     tc = tc32.to(torch.int64)
     dist.all_reduce(ts, group=group)
     dist.all_reduce(tc, group=group)
-    scene.set_feature_sums_from(ts, tc.to(torch.int32).contiguous())
+    # (under the nccl backend all_reduce only makes torch's current stream wait: the library works on its own stream, so the
+    #  tensors -- and the int32 conversion below, a kernel -- must be complete before their pointers are handed over;
+    #  _lib._ptr drains torch's stream for every device tensor, this is the explicit form of the same guarantee)
+    tc32 = tc.to(torch.int32).contiguous()
+    if dev.type == "cuda":
+        torch.cuda.current_stream(dev).synchronize()
+    scene.set_feature_sums_from(ts, tc32)
+
+
+def allreduce_feature_sums_device(scene, comm):
+    """The same all-reduce behind the C ABI (include/hmsg.h: hmsg_allreduce_feature_sums): librccl on the handle's own
+    buffers and stream, in place."""
+    scene.allreduce_feature_sums(comm)

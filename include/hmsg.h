@@ -394,6 +394,32 @@ int hmsg_query_hier(hmsg_index_t* ix, int32_t Q, int32_t C, const float* T_obj, 
 /* plain similarity S[Q][N] = T[Q][D] . E[N][D]^T in float64 (query_floor / query_hmsg_room GEMV) */
 int hmsg_similarity(hmsg_index_t* ix, int32_t Q, const float* T, double* S);
 
+/* ---- multi-GPU exchange steps: RCCL collectives on device buffers, issued by the host that drives the handle.
+ * The reference has no multi-GPU path: its benchmark driver loops scenes one after the other
+ * (application/.../offline_mapping_create_hmsg_hm3d_benchmark.py:70-110) -- one process per GPU builds its own scene with no
+ * collective, and these calls are the only exchange steps.  librccl is loaded on first use (a one-GPU process never needs
+ * it).  One communicator per process / GPU:
+ *   hmsg_comm_unique_id   rank 0 makes the 128-byte id (ncclGetUniqueId); the host passes it to the other ranks by its own
+ *                         means (MPI, a TCP store, torch.distributed's store ...);
+ *   hmsg_comm_create      ncclCommInitRank on device_id.  id == NULL with world == 1: no communicator, every collective is
+ *                         the identity (single-GPU runs take the same code path). */
+#define HMSG_COMM_ID_BYTES 128
+typedef struct hmsg_comm hmsg_comm_t;
+int hmsg_comm_unique_id(uint8_t* out_id /* [HMSG_COMM_ID_BYTES] */);
+int hmsg_comm_create(const uint8_t* id, int32_t rank, int32_t world, int32_t device_id, hmsg_comm_t** out);
+void hmsg_comm_destroy(hmsg_comm_t* c);
+const char* hmsg_comm_last_error(const hmsg_comm_t* c);
+/* Cross-scene retrieval (configs[3]): all-gather of the ranks' node tables -- embeddings of the object nodes gathered on
+ * the device (f32 [n][D]) and the parent room of every node -- into ONE resident index on every rank (counts first, then
+ * the payload padded to the largest table, HBM to HBM).  Global node index = node_off[rank] + local index, global room id =
+ * room_off[rank] + local room id (n_rooms_local = rooms of this rank's graph, rooms without objects included); the index
+ * answers like hmsg_index_create over the concatenated tables.  node_off / room_off: [world + 1], optional. */
+int hmsg_allgather_nodes(hmsg_t* h, hmsg_comm_t* c, int32_t n_rooms_local, hmsg_index_t** out_index, int64_t* node_off, int64_t* room_off);
+/* One episode fused in disjoint frame windows (configs[4]): the per-voxel feature sums and frame counters of all ranks are
+ * all-reduced in place (graph.py:410-415: `sum[idx] += F; cnt[idx] += 1` over the frames commute across windows; counters
+ * exact, float32 sums up to summation order) and the voxel features refreshed.  After hmsg_fuse_frames, before pooling. */
+int hmsg_allreduce_feature_sums(hmsg_t* h, hmsg_comm_t* c);
+
 
 #ifdef __cplusplus
 }

@@ -164,6 +164,16 @@ def test_graph_end_to_end_tiny(L, tmp_path):
         a = ixn.query_objects(Tq, np.zeros(1, np.int32), [[0]], 3)
         b = g._node_index().query_objects(Tq, np.zeros(1, np.int32), [[0]], 3)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])
+        # the exchange step of the multi-GPU scene mode behind the C ABI (hmsg_allgather_nodes) with one rank and no
+        # communicator: the "global" table is the local one, offsets [0, n] / [0, rooms]
+        from holoagent_amd._lib import Comm
+        cm = Comm.single(lib_=L)
+        ixg, noff, roff = g.scene.allgather_nodes(cm, len(g.rooms))
+        assert list(noff) == [0, len(nodes)] and list(roff) == [0, len(g.rooms)] and ixg.N == len(nodes)
+        c = ixg.query_objects(Tq, np.zeros(1, np.int32), [[0]], 3)
+        assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1]) and np.array_equal(a[2], c[2])
+        ixg.close()
+        cm.close()
         ixn.close()
     # N2: the objects were written by the library's bulk writer (hmsg_save_objects): byte-identical with Object.save
     import os
