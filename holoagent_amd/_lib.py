@@ -25,7 +25,7 @@ class HmsgConfig(C.Structure):
         ("max_mask_distance", C.c_double), ("merge_type", C.c_int32), ("outlier_nb_points", C.c_int32),
         ("outlier_radius", C.c_double), ("pool_max_dist", C.c_double), ("feat_dbscan_eps", C.c_double),
         ("feat_dbscan_min", C.c_int32), ("merge_dbscan_eps", C.c_double), ("merge_dbscan_min", C.c_int32),
-        ("min_instance_points", C.c_int32),
+        ("min_instance_points", C.c_int32), ("skip_frames", C.c_int32), ("depth_cut", C.c_double), ("grid_resolution", C.c_double),
     ]
 
 

@@ -170,6 +170,9 @@ void hmsg_default_config(hmsg_config* c) {
     c->merge_dbscan_eps = 0.1;
     c->merge_dbscan_min = 10;
     c->min_instance_points = 10;
+    c->skip_frames = 1;
+    c->depth_cut = 0.0;
+    c->grid_resolution = 0.05;
 }
 
 int hmsg_create(const hmsg_config* cfg, hmsg_t** out) {
@@ -228,6 +231,7 @@ int hmsg_reset(hmsg_t* h) {
         hmsg_fold_pipe_abort(h);
         h->n_tie_queries = 0;
         h->n_frames = h->n_feat_frames = h->n_fused = 0;
+        h->n_offered = 0;
         if (h->frames_released) {              // (hmsg_merge_instances gave a very large frame store back)
             alloc_frame_store(h);
             h->frames_released = false;
@@ -297,12 +301,16 @@ int hmsg_profile_entry(hmsg_t* h, int32_t i, char* name, int64_t* launches, doub
     return HMSG_OK;
 }
 
+__global__ void k_depth_cut(unsigned short* __restrict__ depth, size_t n, double limit) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && (double)depth[i] > limit) depth[i] = 0;
+}
+
 int hmsg_add_frames(hmsg_t* h, int32_t n, const uint8_t* rgb, const uint16_t* depth, const double* pose, const double* K) {
     if (!h) return HMSG_ERR_INVALID;
     return guard(h, [&] {
         HMSG_REQUIRE(n >= 0 && rgb && depth && pose && K, HMSG_ERR_INVALID, "hmsg_add_frames: null argument");
         HMSG_REQUIRE(!h->map_ready, HMSG_ERR_INVALID, "hmsg_add_frames after hmsg_finalize_map");
-        HMSG_REQUIRE(h->n_frames + n <= h->cfg.max_frames, HMSG_ERR_INVALID, "frame store full (cfg.max_frames)");
         HMSG_REQUIRE(!h->frames_released, HMSG_ERR_INVALID, "hmsg_add_frames: the frame store was released (hmsg_reset first)");
         double Kh[9];
         if (is_device_ptr(K)) {
@@ -316,11 +324,37 @@ int hmsg_add_frames(hmsg_t* h, int32_t n, const uint8_t* rgb, const uint16_t* de
         h->have_K = true;
         h->cam = CamK{Kh[0], Kh[4], Kh[2], Kh[5]};
         const size_t HW = (size_t)h->cfg.height * h->cfg.width;
-        copy_in(h->rgb.p + (size_t)h->n_frames * HW * 3, rgb, (size_t)n * HW * 3, h->stream);
-        copy_in(h->depth.p + (size_t)h->n_frames * HW, depth, (size_t)n * HW * 2, h->stream);
-        copy_in(h->pose.p + (size_t)h->n_frames * 16, pose, (size_t)n * 16 * 8, h->stream);
+        const int skip = std::max(1, h->cfg.skip_frames);
+        int kept = 0;
+        if (skip == 1) {
+            HMSG_REQUIRE(h->n_frames + n <= h->cfg.max_frames, HMSG_ERR_INVALID, "frame store full (cfg.max_frames)");
+            copy_in(h->rgb.p + (size_t)h->n_frames * HW * 3, rgb, (size_t)n * HW * 3, h->stream);
+            copy_in(h->depth.p + (size_t)h->n_frames * HW, depth, (size_t)n * HW * 2, h->stream);
+            copy_in(h->pose.p + (size_t)h->n_frames * 16, pose, (size_t)n * 16 * 8, h->stream);
+            kept = n;
+        } else {
+            // graph.py:339 / :373 `range(0, len(dataset), skip_frames)`: the k-th frame OFFERED (counted across calls) is kept
+            // iff k % skip_frames == 0
+            for (int i = 0; i < n; ++i) {
+                if ((h->n_offered + i) % skip != 0) continue;
+                HMSG_REQUIRE(h->n_frames + kept < h->cfg.max_frames, HMSG_ERR_INVALID, "frame store full (cfg.max_frames)");
+                const size_t f = (size_t)h->n_frames + kept;
+                copy_in(h->rgb.p + f * HW * 3, rgb + (size_t)i * HW * 3, HW * 3, h->stream);
+                copy_in(h->depth.p + f * HW, depth + (size_t)i * HW, HW * 2, h->stream);
+                copy_in(h->pose.p + f * 16, pose + (size_t)i * 16, 16 * 8, h->stream);
+                ++kept;
+            }
+        }
+        h->n_offered += n;
+        if (h->cfg.depth_cut > 0.0 && kept > 0) {
+            // horizon.py:258-261: `depth[depth > depth_cut * scale] = 0` (uint16 image against a float limit)
+            const size_t cnt = (size_t)kept * HW;
+            hipLaunchKernelGGL(k_depth_cut, dim3(cdiv(cnt, 256)), dim3(256), 0, h->stream, h->depth.p + (size_t)h->n_frames * HW, cnt,
+                               h->cfg.depth_cut * h->cfg.depth_scale);
+            HMSG_CHECK_LAUNCH();
+        }
         HIP_TRY(hipStreamSynchronize(h->stream));
-        h->n_frames += n;
+        h->n_frames += kept;
     });
 }
 

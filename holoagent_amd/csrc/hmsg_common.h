@@ -507,6 +507,7 @@ struct hmsg_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     int n_frames = 0;       // frames with geometry
+    long long n_offered = 0; // frames offered to hmsg_add_frames so far (cfg.skip_frames keeps every skip-th of them)
     int n_feat_frames = 0;  // frames with features handed over (prefix 0..n-1)
     int n_fused = 0;        // frames processed by hmsg_fuse_frames
     int MS = 0;             // mask slots per frame = NW * 64 >= cfg.max_masks (stride of the F_p tables)

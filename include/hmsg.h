@@ -61,6 +61,12 @@ typedef struct hmsg_config {
     double merge_dbscan_eps;      /* graph_utils.py:678 literal 0.1 */
     int32_t merge_dbscan_min;     /* graph_utils.py:678 literal 10 */
     int32_t min_instance_points;  /* graph.py:447 literal 10 */
+    int32_t skip_frames;          /* pipeline.skip_frames (config/semantic_scene_reconstruction_hm3d.yaml; graph.py:339,373
+                                     `range(0, len(dataset), skip_frames)`): of the frames offered to hmsg_add_frames -- counted
+                                     across calls -- every skip_frames-th is kept, the others are ignored; 1 = all */
+    double depth_cut;             /* dataset depth_cut in metres (dataloader/horizon.py:258-261: depth > depth_cut * scale -> 0,
+                                     applied as the frames come in); 0 = none */
+    double grid_resolution;       /* pipeline.grid_resolution of the room level (graph.py:942-974); 0.05 in the shipped configs */
 } hmsg_config;
 
 /* Fill `cfg` with the reference defaults (hm3d yaml + graph.py literals). */

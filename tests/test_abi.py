@@ -5,7 +5,10 @@ import ctypes
 import os
 import re
 
+import numpy as np
 import pytest
+
+from tests import parity_common as PC
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
@@ -66,3 +69,33 @@ def test_allocator_carves_a_large_parked_block():
 def test_allocator_carves_a_large_parked_block_gpu():
     from holoagent_amd._lib import HmsgLib
     assert HmsgLib().c.hmsg_test_allocator_carving(0, 9) == 0
+
+
+@pytest.mark.skipif(not os.path.exists(PC.EMU_PATH), reason="kernel simulator not built")
+def test_config_skip_frames_and_depth_cut():
+    """hmsg_config.skip_frames / depth_cut (config/semantic_scene_reconstruction_hm3d.yaml pipeline.skip_frames, graph.py:339;
+    dataloader/horizon.py:258-261): offering all frames with skip_frames = 3 and a depth limit builds the map of the frames
+    0, 3, 6, ... with the far pixels zeroed."""
+    from holoagent_amd._lib import HmsgLib, Scene
+    from holoagent_amd.synth import SceneSpec, SynthScene
+    L = HmsgLib(PC.EMU_PATH)
+    spec = SceneSpec(seed=9, rooms_x=1, rooms_z=1, room_size=(3.6, 2.5, 3.2), objects_per_room=3, width=96, height=72, n_frames=9, n_masks=4,
+                     feat_dim=16)
+    scn = SynthScene(spec)
+    frames = [scn.frame(i) for i in range(spec.n_frames)]
+    S = PC.stack_frames(frames)
+    cut = 2.0
+    a = Scene(lib_=L, height=72, width=96, max_frames=9, max_masks=4, feat_dim=16, outlier_nb_points=30, outlier_radius=0.5, skip_frames=3,
+              depth_cut=cut)
+    a.add_frames(S["rgb"][:5], S["depth"][:5], S["pose"][:5], S["K"])        # two calls: the count runs across them
+    a.add_frames(S["rgb"][5:], S["depth"][5:], S["pose"][5:], S["K"])
+    a.finalize_map()
+    keep = [0, 3, 6]
+    dep = S["depth"][keep].copy()
+    dep[dep.astype(np.float64) > cut * 1000.0] = 0
+    b = Scene(lib_=L, height=72, width=96, max_frames=9, max_masks=4, feat_dim=16, outlier_nb_points=30, outlier_radius=0.5)
+    b.add_frames(np.ascontiguousarray(S["rgb"][keep]), np.ascontiguousarray(dep), np.ascontiguousarray(S["pose"][keep]), S["K"])
+    b.finalize_map()
+    assert a.map_size() == b.map_size() > 0 and np.array_equal(a.map_points(), b.map_points())
+    a.close()
+    b.close()
