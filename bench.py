@@ -110,6 +110,9 @@ def main():
                          "mode, one GPU) hands NOTHING in: rooms from the device watershed (N1), room clouds, room embeddings and "
                          "View nodes (A9), objects with the view <-> object test on the device (A10)")
     ap.add_argument("--full-graph", action="store_true", help="(accepted for compatibility: the default now)")
+    ap.add_argument("--encoder-frames", type=int, default=8,
+                    help="frames of the extra encoder hand-off leg (random-init ViT-B/32-shaped PyTorch-ROCm module -> features by "
+                         "data_ptr() into hmsg_add_frame_features; reported beside `value`, never in it; 0 = skip)")
     ap.add_argument("--scene-shape", default=None,
                     help="development sizes (the simulator test): ROOMS_X,ROOMS_Z,ROOM_X_M,ROOM_Y_M,ROOM_Z_M,YAW_STEP_DEG,OBJECTS_PER_ROOM of "
                          "the synthetic building instead of configs[1]'s 4 x 2 rooms of 5 x 3 x 4 m, 10 degrees a frame, 8 objects a room")
@@ -559,6 +562,23 @@ def main():
     except Exception as e:          # (an extra: it must never take the benchmark line down)
         inflight = dict(error=repr(e))
 
+    # ---- extra: the encoder hand-off leg (holoagent_amd/encoder_handoff.py): a live PyTorch-ROCm module's outputs go to the
+    # library by device pointer.  A few frames on a handle of their own; never part of `value`.
+    handoff = None
+    if rank == 0 and world == 1 and not emu and not episode and args.encoder_frames > 0:
+        try:
+            from holoagent_amd.encoder_handoff import measure as measure_handoff
+            nf = min(args.encoder_frames, F)
+            hs = Scene(lib_=L, device_id=local, height=spec.height, width=spec.width, max_frames=nf, max_masks=32, feat_dim=D, merge_type=0)
+            hs.add_frames(inp["rgb"][:nf], inp["depth"][:nf], inp["pose"][:nf], inp["K"])
+            hs.finalize_map()
+            handoff = measure_handoff(L, hs, inp, device, torch, frames=nf, feat_dim=D)
+            hs.fuse_frames()                                   # (the handed-over features are usable: the fusion runs on them)
+            handoff["fused_map_voxels"] = int(hs.map_size())
+            hs.close()
+        except Exception as e:      # (an extra: it must never take the benchmark line down)
+            handoff = dict(error=repr(e))
+
     # ---- CPU baseline: the oracle on a bounded sample of the same frames (rank 0, N=1)
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:
@@ -647,6 +667,7 @@ def main():
                                       "TFLOP/s" if k_ in MFMA_KERNELS else "GB/s"]
                                  for k_, v in sorted(prof.items(), key=lambda kv: -kv[1][1]) if v[1] > 0},
             "scenes_in_flight": inflight,
+            "encoder_handoff": handoff,
             "roofline": roof, "cpu_baseline": cpu,
             "speedup_vs_cpu": round(fps / cpu["value"], 1) if cpu else None,
             "speedup_vs_cpu_note": ("frames/s of the GPU path on configs[1] (%d frames) / frames/s of the CPU restatement on its %d-frame "

@@ -35,11 +35,22 @@ def _blas_form_nn_sqdist(q, b):
     return out
 
 
-@pytest.mark.parametrize("name", ["build_seq", "build_ragged"])
+@pytest.mark.parametrize("name", ["build_seq", "build_ragged", "build_hier"])
 def test_blas_form_does_not_flip_a_merge_decision_on_the_fixtures(name):
     z = GI.load(name)
     frames = GI.unpack_frames(z)[:10]                     # (the brute-force BLAS form is quadratic: ten frames, ~a minute)
     cfg = GI.unpack_cfg(z)
+    stat = run_both_forms(frames, cfg)
+    print("%s: %d pairs, %d point decisions, %d differ between the direct and the BLAS form (%.2e); merge decisions that "
+          "differ: %d; smallest |ratio - threshold| = %.4f" % (name, stat["pairs"], stat["points"], stat["point_flips"],
+                                                              stat["point_flips"] / max(1, stat["points"]), stat["pair_flips"], stat["min_margin"]))
+    assert stat["pairs"] > 30
+    assert stat["pair_flips"] == 0
+
+
+def run_both_forms(frames, cfg):
+    """the sequential merge of `frames` with the direct and the BLAS distance form side by side on every pair it evaluates
+    (scripts/fuzz/fuzz_faiss_form.py runs this over random scenes; the counts of its last run are in profiles/)"""
     res = O.create_feature_map(frames, dict(cfg, merge_type="sequential"), keep_intermediates=True)
     frames_pcd = res["frames_pcd"]
     stat = dict(pairs=0, points=0, point_flips=0, pair_flips=0, min_margin=np.inf)
@@ -69,8 +80,4 @@ def test_blas_form_does_not_flip_a_merge_decision_on_the_fixtures(name):
         O.seq_merge(frames_pcd, th, cfg["voxel_size"], cfg["iou_thresh"])
     finally:
         O.find_overlapping_ratio = orig
-    print("%s: %d pairs, %d point decisions, %d differ between the direct and the BLAS form (%.2e); merge decisions that "
-          "differ: %d; smallest |ratio - threshold| = %.4f" % (name, stat["pairs"], stat["points"], stat["point_flips"],
-                                                              stat["point_flips"] / max(1, stat["points"]), stat["pair_flips"], stat["min_margin"]))
-    assert stat["pairs"] > 30
-    assert stat["pair_flips"] == 0
+    return stat

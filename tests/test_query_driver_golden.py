@@ -15,9 +15,18 @@ from tests import parity_common as PC
 @pytest.mark.skipif(not os.path.exists(PC.EMU_PATH), reason="kernel simulator not built")
 def test_driver_matches_reference():
     from holoagent_amd._lib import HmsgLib
+    check_driver_matches_reference(HmsgLib(PC.EMU_PATH))
+
+
+@pytest.mark.gpu
+def test_driver_matches_reference_gpu():
+    from holoagent_amd._lib import HmsgLib
+    check_driver_matches_reference(HmsgLib())
+
+
+def check_driver_matches_reference(L):
     from holoagent_amd.graph import Floor, Graph, Object, Room
     z = GI.load("query")
-    L = HmsgLib(PC.EMU_PATH)
     words = [str(w) for w in z["table_words"]]
     table = {w: z["table"][i] for i, w in enumerate(words)}
     table["Exhibition room1"] = table["room1"]

@@ -117,12 +117,24 @@ def test_stage_artefacts_round_trip(tmp_path):
     assert len(clouds) == 2 and np.array_equal(clouds[1].points, g.mask_pcds[1].points)
 
 
+@pytest.mark.gpu
+def test_graph_build_with_room_regions_gpu(tmp_path):
+    """the same on the MI355X: View nodes, the save / load round trip, rank_goal_views (graph.py:2864-2897) and the
+    string-instruction driver on the HIP library"""
+    check_graph_build_with_room_regions(tmp_path, _lib(True))
+
+
 def test_graph_build_with_room_regions(tmp_path):
+    if not os.path.exists(PC.EMU_PATH):
+        pytest.skip("kernel simulator not built")
+    check_graph_build_with_room_regions(tmp_path, _lib(False))
+
+
+def check_graph_build_with_room_regions(tmp_path, L):
     """The mirrored segment_hmsg_room (graph.py:1073-1189 from the rooms' 2-D regions on): room clouds, representative
     view embeddings, View nodes with the reference's id scheme, and the Room - View edge quirk through a save / load."""
     from holoagent_amd.graph import Graph, Room, View
     from tests.graph_fixture import SynthDataset, SynthEncoders, tiny_scene
-    L = _lib(False)
     scn = tiny_scene(6, 32)
     ds = SynthDataset(scn)
     enc = SynthEncoders(ds, ["background", "wall", "office", "kitchen", "chair", "table"])
