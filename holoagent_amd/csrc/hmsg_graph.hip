@@ -11,6 +11,7 @@
 // object id = (room, running counter of that room) (:1696-1700).
 #include "hmsg_common.h"
 #include "hmsg_nn.h"
+#include <chrono>
 #include "hmsg_ckdtree.h"
 
 #include <cmath>
@@ -402,11 +403,20 @@ extern "C" int hmsg_room_clouds(hmsg_t* h, double y_lo, double y_hi, const doubl
                            (const double*)dT.p, n_levels, (const double*)dz.p, n_rooms, (const long long*)doff.p, (const double*)dxz.p, mark.p, nt.p,
                            ties.p, tie_cap);
         HMSG_CHECK_LAUNCH();
+        const bool dbg = getenv("HMSG_DEBUG_TIMING") != nullptr;
+        auto tnow = [] { return std::chrono::steady_clock::now(); };
+        auto t_a = tnow();
+        if (dbg) HIP_TRY(hipStreamSynchronize(s));
+        auto t_b = tnow();
         std::vector<unsigned char> hmark((size_t)n_rooms * NF);
         unsigned n_t = 0;
-        HIP_TRY(hipMemcpyAsync(hmark.data(), mark.p, hmark.size(), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(&n_t, nt.p, 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
+        d2h_bounce(hmark.data(), mark.p, hmark.size());          // (through pinned memory: a copy into fresh pageable pages crawls)
+        HIP_TRY(hipMemcpy(&n_t, nt.p, 4, hipMemcpyDeviceToHost));
+        auto t_c = tnow();
+        if (dbg)
+            fprintf(stderr, "[hmsg room clouds] %lld queries: kernels %.2f ms, read-back %.2f ms\n", nq,
+                    std::chrono::duration<double, std::milli>(t_b - t_a).count(), std::chrono::duration<double, std::milli>(t_c - t_b).count());
         HMSG_REQUIRE(n_t <= tie_cap, HMSG_ERR_UNSUPPORTED, "hmsg_room_clouds: more than 2^20 bit-equal nearest-neighbour ties");
         if (n_t) {
             // scipy's answer for the tied queries: the restated cKDTree over the floor cloud (crop order)
