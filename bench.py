@@ -307,11 +307,15 @@ def main():
         sc.reset()
         T("add_frames", lambda: sc.add_frames(inp["rgb"], inp["depth"], inp["pose"], inp["K"]))
         T("finalize_map", sc.finalize_map)
+        T("add_frame_features", lambda: sc.add_frame_features(0, inp["masks"], inp["f_g"], inp["f_masked"], inp["f_crop"]))
+        T("fuse_frames", sc.fuse_frames)
         g_early = None
         if args.full_graph:
-            # the room level needs only the map and the frames' global features: floors, room regions (device watershed), room
-            # clouds and the camera -> room table run here (device, a few ms), scikit-learn's KMeans views on a host thread
-            # beside the fusion and the fold (Graph.start_room_level; Graph.create_feature_map does the same)
+            # the room level needs only the map and the frames' global features.  The sequential fold has been running on its
+            # worker thread (own stream) since the first fusion batch and hmsg_merge_instances below only waits for it: the room
+            # level's device stage (floors, device watershed, room clouds, camera -> room table: ~50 ms of launches on the
+            # handle's otherwise idle stream) goes here, beside the fold, and scikit-learn's KMeans views on a host thread
+            # (Graph.start_room_level; Graph.create_feature_map does the same)
             def rooms_early():
                 g = Graph.from_scene(sc, cfg=full_cfg, lib=L, instances=False)
                 g.dataset = FrameSource()
@@ -320,8 +324,6 @@ def main():
                 g.start_room_level()
                 return g
             g_early = T("room_level/device", rooms_early)
-        T("add_frame_features", lambda: sc.add_frame_features(0, inp["masks"], inp["f_g"], inp["f_masked"], inp["f_crop"]))
-        T("fuse_frames", sc.fuse_frames)
         T("merge_instances", sc.merge_instances)
         T("pool_instances", sc.pool_instances)
 
@@ -496,14 +498,14 @@ def main():
             scx.reset()
             scx.add_frames(inp["rgb"], inp["depth"], inp["pose"], inp["K"])
             scx.finalize_map()
+            scx.add_frame_features(0, inp["masks"], inp["f_g"], inp["f_masked"], inp["f_crop"])
+            scx.fuse_frames()
             if args.full_graph:
                 g = Graph.from_scene(scx, cfg=full_cfg, lib=L, instances=False)
                 g.dataset = FrameSource()
                 g._poses = poses_host
                 g.set_view_feats(fg_host)
                 g.start_room_level()
-            scx.add_frame_features(0, inp["masks"], inp["f_g"], inp["f_masked"], inp["f_crop"])
-            scx.fuse_frames()
             scx.merge_instances()
             scx.pool_instances()
             if args.full_graph:                                    # the same step as the line: nothing handed in
