@@ -442,6 +442,13 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     steps = max(args.steps, 1)
+    # per-rank stage times (episode mode replicates the map build on every rank and pools / assembles / answers on the root:
+    # the Amdahl terms of the strong-scaling leg are these numbers)
+    my_stage = {k_: round(v / steps * 1e3, 2) for k_, v in stage.items()}
+    rank_stages = [my_stage]
+    if use_dist:
+        rank_stages = [None] * world
+        dist.all_gather_object(rank_stages, my_stage)
     fps = (1 if episode else world) * F * steps / dt          # (episode mode: ONE episode of F frames over all ranks)
     retr_s = stage.get("retrieval", 0.0) / steps
     qps = Q / retr_s if retr_s > 0 else None
@@ -659,6 +666,7 @@ def main():
             #  3-D masks, so part of the merge is inside the fuse_frames stage time; HMSG_FOLD_NOPIPE=1 separates them)
             "fold_beside_fusion": (not episode) and not os.environ.get("HMSG_FOLD_NOPIPE"),
             "per_rank_frames_per_s": [round(v, 1) for v in per_rank_fps],
+            "per_rank_stage_ms": rank_stages if use_dist else None,
             "queries_per_sec": round(qps, 1) if qps else None,
             "retrieval_room_stage_hit_rate": state.get("rooms_hit"),
             "stage_ms_per_step": {k_: round(v / steps * 1e3, 2) for k_, v in stage.items()},

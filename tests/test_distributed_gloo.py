@@ -92,10 +92,10 @@ def test_bench_spawns_its_own_ranks():
 
 
 # ---- config 5 building block: the hierarchical merge tree of ONE episode sharded over the ranks ---------------------
-def _episode(n_frames=4):
+def _episode(n_frames=4, size=(64, 48)):
     from holoagent_amd.synth import SceneSpec, SynthScene
-    spec = SceneSpec(seed=11, rooms_x=1, rooms_z=1, room_size=(3.6, 2.5, 3.2), objects_per_room=4, width=64, height=48,
-                     n_frames=n_frames, n_masks=8, feat_dim=16, yaw_step_deg=25.0)
+    spec = SceneSpec(seed=11, rooms_x=1, rooms_z=1, room_size=(3.6, 2.5, 3.2), objects_per_room=4, width=size[0], height=size[1],
+                     n_frames=n_frames, n_masks=8, feat_dim=16, yaw_step_deg=25.0 if n_frames <= 16 else 11.0)
     scn = SynthScene(spec)
     return [scn.frame(i) for i in range(n_frames)]
 
@@ -103,7 +103,8 @@ def _episode(n_frames=4):
 def _build(L, frames, window=None):
     """Scene with the whole map; features / masks of frames[window] only (all frames when None)."""
     S = PC.stack_frames(frames)
-    sc = PC.make_scene(L, frames, dict(feat_dim=16, merge_type=1, outlier_nb_points=20, outlier_radius=0.3))
+    big = frames[0]["depth"].shape[1] >= 320          # (the 320 x 240 episodes are dense enough for a real outlier filter)
+    sc = PC.make_scene(L, frames, dict(feat_dim=16, merge_type=1, outlier_nb_points=200 if big else 20, outlier_radius=0.5 if big else 0.3))
     sc.add_frames(S["rgb"], S["depth"], S["pose"], S["K"])
     sc.finalize_map()
     a, b = window if window is not None else (0, len(frames))
@@ -114,14 +115,14 @@ def _build(L, frames, window=None):
     return sc
 
 
-def _merge_worker(rank, world, port, out, n_frames, chunk):
+def _merge_worker(rank, world, port, out, n_frames, chunk, size=(64, 48)):
     import torch.distributed as dist
     from holoagent_amd._lib import HmsgLib
     from holoagent_amd.dist import sharded_hierarchical_merge
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    frames = _episode(n_frames)
+    frames = _episode(n_frames, size)
     sc = _build(HmsgLib(PC.EMU_PATH), frames, (rank * chunk, min(n_frames, (rank + 1) * chunk)))
     from holoagent_amd.dist import allreduce_feature_sums
     allreduce_feature_sums(sc)                       # every rank now holds the whole episode's voxel features
@@ -140,11 +141,17 @@ def _merge_worker(rank, world, port, out, n_frames, chunk):
 
 # (world, frames, frames per rank): two even ranks; THREE ranks with a shorter last window (the last rank stops its local
 # tree two levels below the others and is carried up); four ranks on request
-@pytest.mark.parametrize("world,n_frames,chunk", [
-    (2, 4, 2), (3, 5, 2),
-    pytest.param(4, 4, 1, marks=pytest.mark.skipif(not os.environ.get("HMSG_EMU_SLOW"), reason="another minute on the simulator")),
-    pytest.param(3, 10, 4, marks=pytest.mark.skipif(not os.environ.get("HMSG_EMU_SLOW"), reason="minutes on the simulator"))])
-def test_sharded_hierarchical_merge_equals_single_process(tmp_path, world, n_frames, chunk):
+_slow = pytest.mark.skipif(not os.environ.get("HMSG_EMU_SLOW"), reason="minutes on the simulator (HMSG_EMU_SLOW=1)")
+
+
+@pytest.mark.parametrize("world,n_frames,chunk,size", [
+    (2, 4, 2, (64, 48)), (3, 5, 2, (64, 48)),
+    pytest.param(4, 4, 1, (64, 48), marks=_slow),
+    pytest.param(3, 10, 4, (64, 48), marks=_slow),
+    # a 32-frame 320 x 240 episode over two and over four ranks (last run: profiles/r04_gloo_episode_320x240.txt)
+    pytest.param(2, 32, 16, (320, 240), marks=_slow),
+    pytest.param(4, 32, 8, (320, 240), marks=_slow)])
+def test_sharded_hierarchical_merge_equals_single_process(tmp_path, world, n_frames, chunk, size):
     """Frames of one episode split over the ranks: all-reduce of the voxel feature sums, rank-local merge-tree levels +
     cross-rank joins (torch.distributed send / recv), pooling on the root == one process over all frames (instances bit
     for bit, features within 1e-5)."""
@@ -155,8 +162,8 @@ def test_sharded_hierarchical_merge_equals_single_process(tmp_path, world, n_fra
     port = s.getsockname()[1]
     s.close()
     out = str(tmp_path / "merged.npz")
-    mp.spawn(_merge_worker, args=(world, port, out, n_frames, chunk), nprocs=world, join=True)
-    sc = _build(HmsgLib(PC.EMU_PATH), _episode(n_frames))
+    mp.spawn(_merge_worker, args=(world, port, out, n_frames, chunk, size), nprocs=world, join=True)
+    sc = _build(HmsgLib(PC.EMU_PATH), _episode(n_frames, size))
     sc.merge_instances()
     ref = sc.instances()
     sc.pool_instances()
