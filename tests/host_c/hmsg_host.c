@@ -5,10 +5,13 @@
  * compares that with the same calls made through the Python binding, bit for bit.
  *
  *   hmsg_host <in.bin> <out.bin>
- *   in : i32 F H W M D Q k outlier_nb feat_dbscan_min | f64 K[9] | u8 rgb[F][H][W][3] | u16 depth[F][H][W] |
+ *   in : i32 F H W M D Q k outlier_nb feat_dbscan_min outlier_radius_mm | f64 K[9] | u8 rgb[F][H][W][3] | u16 depth[F][H][W] |
  *        f64 pose[F][16] | u8 masks[F][M][H][W] | i32 n_masks[F] | f32 f_g[F][D] | f32 f_masked[F][M][D] |
- *        f32 f_crop[F][M][D] | f32 text[Q][2][D]
- *   out: i64 V, N, n_floors, n_nodes | i64 sizes[N] | f32 feats[N][D] | i32 idx[Q][k] | f64 score[Q][k]            */
+ *        f32 f_crop[F][M][D] | f32 text[Q][2][D] | f32 room_text[Q][D] | f64 room_names[8][D]
+ *   out: i64 V, N, n_floors, n_nodes | i64 sizes[N] | f32 feats[N][D] | i32 idx[Q][k] | f64 score[Q][k]
+ *        | i64 n_rooms, rows, cols, n_nodes2 | i32 markers[rows][cols] | i32 nsel[Q] | i32 sel[Q][8] | i32 hidx[Q][k] | f64 hscore[Q][k]
+ *   (second part: rooms of storey 0 by the device room segmentation (hmsg_segment_rooms), their regions as the room
+ *    vertices of hmsg_build_object_nodes, and the coarse-to-fine query floor -> room by name -> objects, hmsg_query_hier) */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -35,14 +38,18 @@ static void* rd(FILE* f, size_t bytes) {
 
 int main(int argc, char** argv) {
     FILE *fi, *fo;
-    int32_t hd[9];
+    int32_t hd[10];
     int32_t F, H, W, M, D, Q, k;
     double* K;
     uint8_t *rgb, *masks;
     uint16_t* depth;
     double* pose;
     int32_t* n_masks;
-    float *f_g, *f_masked, *f_crop, *text;
+    float *f_g, *f_masked, *f_crop, *text, *room_text;
+    double* room_names;
+    int32_t rows = 0, cols = 0, n_rooms = 0, r, c2, *markers = NULL, *rfl, *froff, *frooms, *rkey, *fid, *mode, *nsel, *sel, *hidx, *hroom;
+    int64_t *voff2, *view_off, out_hd2[4], n_nodes2 = 0, cells;
+    double xz_min[2], *verts2, *hscore;
     hmsg_config cfg;
     hmsg_t* h = NULL;
     hmsg_index_t* ix = NULL;
@@ -62,7 +69,7 @@ int main(int argc, char** argv) {
     }
     fi = fopen(argv[1], "rb");
     if (!fi) return 1;
-    if (fread(hd, 4, 9, fi) != 9) return 2;
+    if (fread(hd, 4, 10, fi) != 10) return 2;
     F = hd[0]; H = hd[1]; W = hd[2]; M = hd[3]; D = hd[4]; Q = hd[5]; k = hd[6];
     HW = (size_t)H * (size_t)W;
     K = (double*)rd(fi, 9 * sizeof(double));
@@ -75,6 +82,8 @@ int main(int argc, char** argv) {
     f_masked = (float*)rd(fi, (size_t)F * (size_t)M * (size_t)D * 4);
     f_crop = (float*)rd(fi, (size_t)F * (size_t)M * (size_t)D * 4);
     text = (float*)rd(fi, (size_t)Q * 2 * (size_t)D * 4);
+    room_text = (float*)rd(fi, (size_t)Q * (size_t)D * sizeof(float));
+    room_names = (double*)rd(fi, (size_t)8 * (size_t)D * sizeof(double));
     fclose(fi);
 
     hmsg_default_config(&cfg);
@@ -84,6 +93,7 @@ int main(int argc, char** argv) {
     cfg.width = W;
     cfg.max_frames = F;
     cfg.max_masks = M;
+    cfg.outlier_radius = (double)hd[9] / 1000.0;
     cfg.outlier_nb_points = hd[7];
     cfg.feat_dbscan_min = hd[8];
     if (hmsg_create(&cfg, &h) != HMSG_OK || !h) {
@@ -148,6 +158,64 @@ int main(int argc, char** argv) {
         }
         hmsg_index_destroy(ix);
     }
+    /* ---- the room level from the C side: rooms of storey 0 by the device watershed (N1), their regions as room vertices
+     * (map_grid_to_point_cloud, graph_utils.py:359-388: cell (x, y) -> ((x - 10.5) res + min_x, (y - 10.5) res + min_z)),
+     * object nodes against those rooms (A10), then floor -> room by its name -> objects on the device (A12) */
+    nsel = (int32_t*)calloc((size_t)Q, 4);
+    sel = (int32_t*)malloc((size_t)Q * 8 * 4);
+    hidx = (int32_t*)malloc((size_t)Q * (size_t)k * 4);
+    hroom = (int32_t*)malloc((size_t)Q * (size_t)k * 4);
+    hscore = (double*)calloc((size_t)Q * (size_t)k, sizeof(double));
+    memset(sel, 0xff, (size_t)Q * 8 * 4);
+    memset(hidx, 0xff, (size_t)Q * (size_t)k * 4);
+    if (n_floors > 0) {
+        const double res = 0.1;
+        CK(hmsg_segment_rooms(h, floors[0].y_lo, floors[0].y_hi, floors[0].zero_level, floors[0].height, res, NULL, 0, &rows, &cols, &n_rooms, xz_min));
+        markers = (int32_t*)malloc((size_t)rows * (size_t)cols * 4 + 4);
+        CK(hmsg_segment_rooms(h, floors[0].y_lo, floors[0].y_hi, floors[0].zero_level, floors[0].height, res, markers, (int64_t)rows * cols, &rows, &cols,
+                              &n_rooms, xz_min));
+        if (n_rooms > 8) n_rooms = 8;
+        if (n_rooms > 0) {
+            cells = 0;
+            for (r = 0; r < rows * cols; ++r) cells += markers[r] >= 1 && markers[r] <= n_rooms;
+            verts2 = (double*)malloc((size_t)(cells ? cells : 1) * 2 * sizeof(double));
+            voff2 = (int64_t*)calloc((size_t)n_rooms + 1, sizeof(int64_t));
+            rfl = (int32_t*)calloc((size_t)n_rooms, 4);
+            cells = 0;
+            for (r = 0; r < n_rooms; ++r) {                          /* np.where order: rows, then columns */
+                int32_t y, x;
+                for (y = 0; y < rows; ++y)
+                    for (x = 0; x < cols; ++x)
+                        if (markers[(size_t)y * (size_t)cols + (size_t)x] == r + 1) {
+                            verts2[cells * 2] = ((double)x - 10.5) * res + xz_min[0];
+                            verts2[cells * 2 + 1] = ((double)y - 10.5) * res + xz_min[1];
+                            ++cells;
+                        }
+                voff2[r + 1] = cells;
+            }
+            CK(hmsg_build_object_nodes(h, n_floors, fz, fh, n_rooms, rfl, voff2, verts2, 0, NULL));
+            n_nodes2 = hmsg_num_nodes(h);
+            if (n_nodes2 > 0) {
+                froff = (int32_t*)calloc((size_t)n_floors + 1, 4);
+                frooms = (int32_t*)malloc((size_t)n_rooms * 4);
+                rkey = (int32_t*)malloc((size_t)n_rooms * 4);
+                view_off = (int64_t*)calloc((size_t)n_rooms + 1, sizeof(int64_t));
+                for (r = 0; r < n_rooms; ++r) frooms[r] = rkey[r] = r;
+                for (c2 = 1; c2 <= n_floors; ++c2) froff[c2] = n_rooms;      /* every room lies on storey 0 */
+                fid = (int32_t*)calloc((size_t)Q, 4);
+                mode = (int32_t*)malloc((size_t)Q * 4);
+                qid = (int32_t*)calloc((size_t)Q, 4);
+                for (q = 0; q < Q; ++q) mode[q] = 1;
+                if (hmsg_index_from_nodes(h, &ix) != HMSG_OK) return 7;
+                if (hmsg_index_set_hierarchy(ix, n_rooms, n_floors, froff, frooms, room_names, view_off, NULL, rkey) != HMSG_OK ||
+                    hmsg_query_hier(ix, Q, 2, text, qid, room_text, fid, mode, k, 1, 8, sel, nsel, hidx, hroom, hscore) != HMSG_OK) {
+                    fprintf(stderr, "hmsg_host: hierarchical query: %s\n", hmsg_index_last_error(ix));
+                    return 8;
+                }
+                hmsg_index_destroy(ix);
+            }
+        }
+    }
     fo = fopen(argv[2], "wb");
     if (!fo) return 1;
     out_hd[0] = V; out_hd[1] = N; out_hd[2] = n_floors; out_hd[3] = n_nodes;
@@ -156,6 +224,13 @@ int main(int argc, char** argv) {
     fwrite(feats, sizeof(float), (size_t)N * (size_t)D, fo);
     fwrite(idx, 4, (size_t)Q * (size_t)k, fo);
     fwrite(score, sizeof(double), (size_t)Q * (size_t)k, fo);
+    out_hd2[0] = n_rooms; out_hd2[1] = rows; out_hd2[2] = cols; out_hd2[3] = n_nodes2;
+    fwrite(out_hd2, sizeof(int64_t), 4, fo);
+    if (markers) fwrite(markers, 4, (size_t)rows * (size_t)cols, fo);
+    fwrite(nsel, 4, (size_t)Q, fo);
+    fwrite(sel, 4, (size_t)Q * 8, fo);
+    fwrite(hidx, 4, (size_t)Q * (size_t)k, fo);
+    fwrite(hscore, sizeof(double), (size_t)Q * (size_t)k, fo);
     fclose(fo);
     hmsg_destroy(h);
     printf("hmsg_host ok: V %ld instances %ld floors %d nodes %ld\n", (long)V, (long)N, (int)n_floors, (long)n_nodes);

@@ -27,8 +27,9 @@ def _build(lib_path, out):
 
 def _scene():
     from holoagent_amd.synth import SceneSpec, SynthScene
-    spec = SceneSpec(seed=11, rooms_x=1, rooms_z=1, room_size=(3.6, 2.5, 3.2), objects_per_room=4, width=64, height=48,
-                     n_frames=6, n_masks=5, feat_dim=16)
+    # two closed rooms side by side, seen from the inside: the room segmentation finds both
+    spec = SceneSpec(seed=40, rooms_x=2, rooms_z=1, room_size=(3.2, 2.6, 3.0), objects_per_room=3, width=96, height=72,
+                     n_frames=12, n_masks=5, feat_dim=16, yaw_step_deg=60.0)
     sc = SynthScene(spec)
     frames = [sc.frame(i) for i in range(spec.n_frames)]
     text, _ = sc.text_table(5)
@@ -40,13 +41,17 @@ def _run(lib_path, tmp_path):
     spec, frames, text = _scene()
     S = PC.stack_frames(frames)
     F, (H, W), M, D, Q, k = len(frames), frames[0]["depth"].shape, S["masks"].shape[1], spec.feat_dim, text.shape[0], 3
-    over = dict(feat_dim=D, outlier_nb_points=60, feat_dbscan_min=8)
+    over = dict(feat_dim=D, outlier_nb_points=40, feat_dbscan_min=8, outlier_radius=0.5)
+    rng = np.random.Generator(np.random.PCG64(5))
+    room_names = rng.standard_normal((8, D))
+    room_names /= np.linalg.norm(room_names, axis=1, keepdims=True)
+    room_text = np.ascontiguousarray(room_names[np.arange(Q) % 2] + 0.05 * rng.standard_normal((Q, D)), np.float32)
     fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
     with open(fin, "wb") as f:
-        np.array([F, H, W, M, D, Q, k, over["outlier_nb_points"], over["feat_dbscan_min"]], np.int32).tofile(f)
+        np.array([F, H, W, M, D, Q, k, over["outlier_nb_points"], over["feat_dbscan_min"], int(round(over["outlier_radius"] * 1000))], np.int32).tofile(f)
         for a, t in ((S["K"], np.float64), (S["rgb"], np.uint8), (S["depth"], np.uint16), (S["pose"], np.float64),
                      (S["masks"], np.uint8), (S["n_masks"], np.int32), (S["f_g"], np.float32), (S["f_masked"], np.float32),
-                     (S["f_crop"], np.float32), (text, np.float32)):
+                     (S["f_crop"], np.float32), (text, np.float32), (room_text, np.float32), (room_names, np.float64)):
             np.ascontiguousarray(a, t).tofile(f)
     exe = _build(lib_path, str(tmp_path / "hmsg_host"))
     r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=900)
@@ -57,7 +62,13 @@ def _run(lib_path, tmp_path):
     sizes = np.frombuffer(raw, np.int64, N, o); o += 8 * N
     feats = np.frombuffer(raw, np.float32, N * D, o).reshape(N, D); o += 4 * N * D
     idx = np.frombuffer(raw, np.int32, Q * k, o).reshape(Q, k); o += 4 * Q * k
-    score = np.frombuffer(raw, np.float64, Q * k, o).reshape(Q, k)
+    score = np.frombuffer(raw, np.float64, Q * k, o).reshape(Q, k); o += 8 * Q * k
+    n_rooms, rows, cols, n_nodes2 = np.frombuffer(raw, np.int64, 4, o); o += 32
+    markers = np.frombuffer(raw, np.int32, rows * cols, o).reshape(rows, cols); o += 4 * rows * cols
+    nsel = np.frombuffer(raw, np.int32, Q, o); o += 4 * Q
+    sel = np.frombuffer(raw, np.int32, Q * 8, o).reshape(Q, 8); o += 32 * Q
+    hidx = np.frombuffer(raw, np.int32, Q * k, o).reshape(Q, k); o += 4 * Q * k
+    hscore = np.frombuffer(raw, np.float64, Q * k, o).reshape(Q, k)
     # the same calls through the Python binding
     L = HmsgLib(lib_path)
     sc = PC.make_scene(L, frames, over)
@@ -78,6 +89,22 @@ def _run(lib_path, tmp_path):
     ix = sc.index_from_nodes()
     idx2, _, score2 = ix.query_objects(text, np.zeros(Q, np.int32), [[0]] * Q, k)
     assert np.array_equal(idx, idx2) and np.array_equal(score, score2)
+    ix.close()
+    # the room level driven from C: device room segmentation -> regions -> object nodes -> floor / room / object query
+    m2, nr2, xz = sc.segment_rooms(fl[0]["y_lo"], fl[0]["y_hi"], fl[0]["zero_level"], fl[0]["height"], 0.1)
+    assert (rows, cols) == m2.shape and n_rooms == min(nr2, 8) >= 2 and np.array_equal(markers, m2)
+    regions = []
+    for i in range(n_rooms):
+        y_cells, x_cells = np.where(m2 == i + 1)
+        regions.append(np.column_stack(((x_cells - 10.5) * 0.1 + xz[0], (y_cells - 10.5) * 0.1 + xz[1])))
+    nodes2 = sc.build_object_nodes([f["zero_level"] for f in fl], [f["height"] for f in fl], [0] * n_rooms, regions, None)
+    assert n_nodes2 == len(nodes2) >= 1 and len({int(n["room"]) for n in nodes2}) >= 2        # objects in both rooms
+    ix = sc.index_from_nodes()
+    ix.set_hierarchy([list(range(n_rooms))] + [[] for _ in fl[1:]], room_names[:n_rooms], [np.zeros((0, D))] * n_rooms, list(range(n_rooms)))
+    sel2, hidx2, _, hscore2 = ix.query_hier(text, np.zeros(Q, np.int32), room_text, np.zeros(Q, np.int32), np.ones(Q, np.int32), k)
+    for q in range(Q):
+        assert list(sel[q][: nsel[q]]) == list(sel2[q]), q
+    assert np.array_equal(hidx, hidx2) and np.array_equal(hscore, hscore2)
     ix.close()
     sc.close()
 
