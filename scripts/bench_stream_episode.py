@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--feat-dim", type=int, default=512)
     ap.add_argument("--masks", type=int, default=32)
     ap.add_argument("--queries", type=int, default=1000)
+    ap.add_argument("--no-feats-check", action="store_true", help="skip the read-back of the voxel frame counters")
     ap.add_argument("--emu", action="store_true", help="kernel simulator + numpy buffers (API dry run without a GPU)")
     a = ap.parse_args()
     F, H, W, M, D = a.frames, a.height, a.width, a.masks, a.feat_dim
@@ -141,13 +142,31 @@ def main():
         out = ix.query_objects(text, np.zeros(len(q_rooms), np.int32), q_rooms, 5)
         ix.close()
         return out
-    T("retrieval", retrieve)
+    res = T("retrieval", retrieve)
+    # ---- size-independent properties of the result (tests/test_gpu_long_episode.py asserts them at the full configs[4] size)
+    props = {}
+    sizes = sc.instance_sizes()
+    boxes = np.asarray(sc.instance_boxes(), np.float64).reshape(-1, 6) if len(sizes) else np.zeros((0, 6))
+    mp = sc.map_points()
+    lo, hi = mp.min(axis=0), mp.max(axis=0)
+    _, counter = sc.map_feats(counter=True) if not a.no_feats_check else (None, None)
+    props["min_instance_points"] = int(sizes.min()) if len(sizes) else 0
+    props["instance_points"] = int(sizes.sum())
+    # a 3-D mask point is the mean of map points of one 5 cm voxel, an instance is a subset of mask points: inside the map's box
+    props["boxes_inside_map"] = bool(len(boxes) and (boxes[:, :3] >= lo - 1e-9).all() and (boxes[:, 3:] <= hi + 1e-9).all())
+    if counter is not None:
+        props["counter_max"] = float(counter.max())                # a voxel is counted at most once per frame
+        props["voxels_seen"] = float((counter >= 1.0).mean())
+    if res is not None:
+        idx, room, _ = res
+        hit = [int(room[q][0]) == q_rooms[q][0] for q in range(len(q_rooms)) if idx[q][0] >= 0]
+        props["top1_in_the_queried_objects_room"] = round(float(np.mean(hit)), 4) if hit else 0.0
     counted = sum(v for k, v in stage.items() if "not counted" not in k)
     print(json.dumps({"metric": "HMSG frames/sec, one episode streamed in chunks (configs[4] shape on one GPU)",
                       "value": round(F / counted, 3), "unit": "frames/s", "frames": F, "image": [W, H], "chunk": C, "masks": M,
                       "feat_dim": D, "seconds": round(counted, 3), "stage_seconds": {k: round(v, 4) for k, v in stage.items()},
                       "map_voxels": int(sc.map_size()), "instances": int(sc.num_instances()), "objects": len(g.objects),
-                      "tie_queries": int(sc.num_tie_queries()),
+                      "tie_queries": int(sc.num_tie_queries()), "properties": props,
                       "resident_GB": round(F * H * W * (3 + 2 + 8 + 4) / 1e9, 2), "raw_masks_GB_never_resident": round(F * M * H * W / 1e9, 2)}))
     sc.close()
 
