@@ -702,7 +702,8 @@ __device__ __forceinline__ void f_uf_union(int* parent, int a, int b, unsigned* 
             a = b;
             b = t;
         }                                   // a > b: the larger root goes under the smaller (roots = smallest node of the cluster)
-        if (atomicCAS(&parent[a], a, b) == a) return;
+        // (look before the CAS: a failing CAS is a same-address atomic, ~11 ns each in a row; atomic loads are not)
+        if (__hip_atomic_load(&parent[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a && atomicCAS(&parent[a], a, b) == a) return;
         if (hops) *hops += 1000u;           // (a failed CAS)
         a = f_uf_find(parent, a, hops);
         b = f_uf_find(parent, b, hops);
@@ -1298,13 +1299,17 @@ __global__ void __launch_bounds__(FWB) k_f_link(FIndexDev ix, FStep st) {
                    const int mr = f_uf_find_cached(st.parent, me);
                    int m = min(wr, mr);
                    for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
+                   // (every CAS below is preceded by an atomic LOAD of the word: walkers of one cluster all try the same witness
+                   //  roots, and a failing CAS is a same-address atomic -- ~11 ns each, one after the other)
                    if (hit && wr != m) {
-                       const int old = atomicCAS(&st.parent[wr], wr, m);
+                       int old = __hip_atomic_load(&st.parent[wr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                       if (old == wr) old = atomicCAS(&st.parent[wr], wr, m);
                        if (old != wr && old != m) f_uf_union(st.parent, wr, m);
                    }
                    const bool any_hit = __any(hit) != 0;
                    if (lane == 0 && mr != m && any_hit) {
-                       const int old = atomicCAS(&st.parent[mr], mr, m);
+                       int old = __hip_atomic_load(&st.parent[mr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                       if (old == mr) old = atomicCAS(&st.parent[mr], mr, m);
                        if (old != mr && old != m) f_uf_union(st.parent, mr, m);
                    }
                    unsigned long long am_todo = __ballot(am_hit && jj < 64);
