@@ -46,6 +46,10 @@ class HmsgObjectRecord(C.Structure):   # include/hmsg.h: hmsg_object_record
                 ("best_view_id_json", C.c_char_p)]
 
 
+class HmsgJsonField(C.Structure):      # include/hmsg.h: hmsg_json_field
+    _fields_ = [("key", C.c_char_p), ("kind", C.c_int32), ("ndim", C.c_int32), ("n0", C.c_int64), ("n1", C.c_int64), ("data", C.c_void_p)]
+
+
 class HmsgError(RuntimeError):
     pass
 
@@ -107,6 +111,9 @@ _SIGS = {
     "hmsg_lidar_depth": (C.c_int, [C.c_int32, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "hmsg_crop_resize_batch": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, C.c_double, C.c_int32, _P, _P, _P]),
     "hmsg_save_objects": (C.c_int, [_P, C.c_char_p, C.c_int64, _P, C.c_int32]),
+    "hmsg_write_json": (C.c_int, [C.c_char_p, C.c_int32, _P]),
+    "hmsg_write_ply": (C.c_int, [C.c_char_p, _P, C.c_int64]),
+    "hmsg_read_json_numbers": (C.c_int, [C.c_char_p, C.c_char_p, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "hmsg_test_format_doubles": (C.c_int64, [_P, C.c_int64, _P, C.c_int64]),
     "hmsg_test_allocator_carving": (C.c_int, [C.c_int32, C.c_int32]),
     "hmsg_test_dbscan": (C.c_int, [_P, C.c_int32, _P, C.c_double, C.c_int32, _P, _P, _P, _P, _P]),
@@ -631,6 +638,65 @@ def lidar_depth(clouds, poses, intrinsics, width, height, voxel_size=0.02, depth
     if rc != 0:
         raise HmsgError(f"hmsg_lidar_depth failed ({rc})")
     return depth, stats, (state[:int(off[-1])] if state is not None else None), ms.value
+
+
+def write_json_record(path, fields, lib_: "HmsgLib | None" = None):
+    """One node record of the on-disk graph through the C ABI (include/hmsg.h: hmsg_write_json) -- byte for byte json.dump's
+    text.  fields: (key, value) pairs in the reference's key order; a numpy array of floats (float32 / float64, up to 2-D) or
+    of ints is printed by the library, a Python float likewise; everything else (str, None, lists of ids / strings / ints,
+    ragged things) goes through json.dumps here and travels as RAW text."""
+    import json
+    L = lib_ or lib()
+    keep, arr = [], (HmsgJsonField * max(len(fields), 1))()
+    for k, (key, v) in enumerate(fields):
+        f = arr[k]
+        f.key = key.encode()
+        if isinstance(v, np.ndarray) and v.ndim <= 2 and v.dtype in (np.float64, np.float32) or \
+                (isinstance(v, np.ndarray) and v.ndim <= 2 and np.issubdtype(v.dtype, np.integer)):
+            if np.issubdtype(v.dtype, np.integer):
+                a, kind = np.ascontiguousarray(v, np.int64), 3
+            else:
+                a, kind = np.ascontiguousarray(v), (1 if v.dtype == np.float64 else 2)
+            keep.append(a)
+            f.kind, f.ndim = kind, a.ndim
+            f.n0 = a.shape[0] if a.ndim >= 1 else 0
+            f.n1 = a.shape[1] if a.ndim == 2 else 0
+            f.data = a.ctypes.data if a.size else None
+        elif isinstance(v, float):
+            a = np.array([v], np.float64)
+            keep.append(a)
+            f.kind, f.ndim, f.n0, f.n1, f.data = 1, 0, 0, 0, a.ctypes.data
+        else:
+            raw = json.dumps(v).encode()
+            keep.append(raw)
+            f.kind, f.ndim, f.n0, f.n1 = 0, 0, 0, 0
+            f.data = C.cast(C.c_char_p(raw), C.c_void_p)
+    rc = L.c.hmsg_write_json(str(path).encode(), len(fields), C.cast(arr, _P))
+    if rc != 0:
+        raise HmsgError(f"hmsg_write_json failed ({rc}) for {path}")
+
+
+def write_ply(path, pts, lib_: "HmsgLib | None" = None):
+    """A cloud as Open3D's write_point_cloud writes it (include/hmsg.h: hmsg_write_ply)."""
+    L = lib_ or lib()
+    a = np.ascontiguousarray(np.asarray(pts, np.float64).reshape(-1, 3))
+    rc = L.c.hmsg_write_ply(str(path).encode(), _ptr(a) if a.size else None, a.shape[0])
+    if rc != 0:
+        raise HmsgError(f"hmsg_write_ply failed ({rc}) for {path}")
+
+
+def read_json_numbers(path, key, lib_: "HmsgLib | None" = None):
+    """The numbers under `key` of a saved node record, flattened (include/hmsg.h: hmsg_read_json_numbers)."""
+    L = lib_ or lib()
+    n = C.c_int64(0)
+    rc = L.c.hmsg_read_json_numbers(str(path).encode(), key.encode(), None, 0, C.byref(n))
+    if rc != 0:
+        raise HmsgError(f"hmsg_read_json_numbers failed ({rc}) for {key} of {path}")
+    out = np.empty(max(n.value, 1), np.float64)
+    rc = L.c.hmsg_read_json_numbers(str(path).encode(), key.encode(), _ptr(out), n.value, C.byref(n))
+    if rc != 0:
+        raise HmsgError(f"hmsg_read_json_numbers failed ({rc}) for {key} of {path}")
+    return out[: n.value]
 
 
 def crop_all_bounding_boxs(image, masks, bbox_margin=0, size=512, plain=True, masked=True, device_id=0,

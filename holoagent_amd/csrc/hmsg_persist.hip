@@ -196,6 +196,80 @@ extern "C" int hmsg_save_objects(hmsg_t* hc, const char* dir, int64_t n, const h
     }
 }
 
+// ---- the other node records of save_hmsg_graph (graph.py:1801-1824): floors/<f>.{ply,json} (floor.py:37-52),
+// rooms/<f>_<r>.{ply,json} (room.py:309-337), views/<id>.json (view.py:56-74).  Their keys differ, their numbers are all printed by
+// json.dump the same way: a record is a list of fields in the reference's key order; strings, id lists, null and anything else
+// that is not a number array come from the caller JSON-encoded (HMSG_JSON_RAW), numbers are printed here like Python does --
+// float64 / float32 arrays and scalars as float.__repr__ of the double, integer arrays as decimal integers.
+extern "C" int hmsg_write_json(const char* path, int32_t n_fields, const hmsg_json_field* f) {
+    if (!path || n_fields < 0 || (n_fields > 0 && !f)) return HMSG_ERR_INVALID;
+    try {
+        std::string js = "{";
+        char num[40];
+        auto put = [&](const hmsg_json_field& fd, int64_t i) {
+            if (fd.kind == HMSG_JSON_F64) js.append(num, (size_t)(py_repr(num, ((const double*)fd.data)[i]) - num));
+            else if (fd.kind == HMSG_JSON_F32) js.append(num, (size_t)(py_repr(num, (double)((const float*)fd.data)[i]) - num));
+            else js += std::to_string((long long)((const int64_t*)fd.data)[i]);
+        };
+        for (int32_t k = 0; k < n_fields; ++k) {
+            const hmsg_json_field& fd = f[k];
+            if (!fd.key || fd.ndim < 0 || fd.ndim > 2 || fd.n0 < 0 || fd.n1 < 0) return HMSG_ERR_INVALID;
+            if (fd.kind != HMSG_JSON_RAW && fd.kind != HMSG_JSON_F64 && fd.kind != HMSG_JSON_F32 && fd.kind != HMSG_JSON_I64) return HMSG_ERR_INVALID;
+            const int64_t cnt = fd.ndim == 0 ? 1 : (fd.ndim == 1 ? fd.n0 : fd.n0 * fd.n1);
+            if (!fd.data && (fd.kind == HMSG_JSON_RAW || cnt > 0)) return HMSG_ERR_INVALID;
+            if (k) js += ", ";
+            js += '"';
+            js += fd.key;
+            js += "\": ";
+            if (fd.kind == HMSG_JSON_RAW) {
+                js += (const char*)fd.data;
+            } else if (fd.ndim == 0) {
+                put(fd, 0);
+            } else if (fd.ndim == 1) {
+                js += '[';
+                for (int64_t i = 0; i < fd.n0; ++i) {
+                    if (i) js += ", ";
+                    put(fd, i);
+                }
+                js += ']';
+            } else {
+                js += '[';
+                for (int64_t i = 0; i < fd.n0; ++i) {
+                    if (i) js += ", ";
+                    js += '[';
+                    for (int64_t j = 0; j < fd.n1; ++j) {
+                        if (j) js += ", ";
+                        put(fd, i * fd.n1 + j);
+                    }
+                    js += ']';
+                }
+                js += ']';
+            }
+        }
+        js += '}';
+        return write_file(path, js.data(), js.size()) ? HMSG_OK : HMSG_ERR_INVALID;
+    } catch (const std::exception&) {
+        return HMSG_ERR_INVALID;
+    }
+}
+
+// <stem>.ply as Open3D 0.18's write_point_cloud writes a cloud without colours / normals (the header of hmsg_save_objects)
+extern "C" int hmsg_write_ply(const char* path, const double* xyz, int64_t n) {
+    if (!path || n < 0 || (n > 0 && !xyz)) return HMSG_ERR_INVALID;
+    char hdr[200];
+    const int hl = snprintf(hdr, sizeof(hdr),
+                            "ply\nformat binary_little_endian 1.0\ncomment Created by Open3D\nelement vertex %lld\nproperty double x\n"
+                            "property double y\nproperty double z\nend_header\n", (long long)n);
+    try {
+        std::vector<char> ply((size_t)hl + (size_t)n * 24);
+        memcpy(ply.data(), hdr, (size_t)hl);
+        if (n) memcpy(ply.data() + hl, xyz, (size_t)n * 24);
+        return write_file(path, ply.data(), ply.size()) ? HMSG_OK : HMSG_ERR_INVALID;
+    } catch (const std::exception&) {
+        return HMSG_ERR_INVALID;
+    }
+}
+
 // ---- load side: the object table of a saved graph straight into a retrieval index
 // (object.py:75-91: metadata["embedding"] -> np.array, float64; graph.py:1892-1987 load_hmsg_graph walks the objects/
 //  directory).  The caller lists the objects (file stems, in table order) and their rooms; host threads read
@@ -350,4 +424,54 @@ extern "C" int hmsg_test_allocator_carving(int32_t device_id, int32_t root_gb) {
         fprintf(stderr, "hmsg_test_allocator_carving: %s\n", e.msg.c_str());
         return -1;
     }
+}
+
+// The numbers of one key of a saved record, flattened in file order (load side of floors / rooms: "vertices", "embeddings",
+// "clip_embeddings", "represent_images", ...: floor.py:54-67, room.py:339-374 read them with json.load + np.array): strtod is
+// correctly rounded, i.e. the float64 Python's json module yields.  *n = numbers in the file (may exceed capacity: call again).
+extern "C" int hmsg_read_json_numbers(const char* path, const char* key, double* out, int64_t capacity, int64_t* n) {
+    if (!path || !key || !n || capacity < 0 || (capacity > 0 && !out)) return HMSG_ERR_INVALID;
+    *n = 0;
+    FILE* f = fopen(path, "rb");
+    if (!f) return HMSG_ERR_INVALID;
+    std::string txt;
+    char buf[1 << 16];
+    size_t got;
+    while ((got = fread(buf, 1, sizeof(buf), f)) > 0) txt.append(buf, got);
+    fclose(f);
+    const std::string pat = std::string("\"") + key + "\":";
+    size_t at = txt.find(pat);
+    if (at == std::string::npos) return HMSG_ERR_INVALID;
+    const char* p = txt.data() + at + pat.size();
+    const char* end = txt.data() + txt.size();
+    while (p < end && *p == ' ') ++p;
+    if (p >= end) return HMSG_ERR_INVALID;
+    int depth = 0;
+    int64_t cnt = 0;
+    do {                                                   // a scalar, or (nested) arrays of numbers
+        while (p < end && (*p == ' ' || *p == ',' || *p == '\n')) ++p;
+        if (p >= end) return HMSG_ERR_INVALID;
+        if (*p == '[') {
+            ++depth;
+            ++p;
+        } else if (*p == ']') {
+            --depth;
+            ++p;
+        } else {
+            double v;
+            if (!strncmp(p, "NaN", 3)) { v = __builtin_nan(""); p += 3; }
+            else if (!strncmp(p, "Infinity", 8)) { v = __builtin_inf(); p += 8; }
+            else if (!strncmp(p, "-Infinity", 9)) { v = -__builtin_inf(); p += 9; }
+            else {
+                char* q = nullptr;
+                v = strtod(p, &q);
+                if (q == p) return HMSG_ERR_INVALID;       // (a string, null, an object: not a number array)
+                p = q;
+            }
+            if (cnt < capacity) out[cnt] = v;
+            ++cnt;
+        }
+    } while (depth > 0);
+    *n = cnt;
+    return HMSG_OK;
 }

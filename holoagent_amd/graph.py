@@ -172,6 +172,26 @@ def find_overlapping_ratio_faiss(p1, p2, radius=0.02):
     return np.max([np.sum(nn_d2(a, b) < r2) / a.shape[0], np.sum(nn_d2(b, a) < r2) / b.shape[0]])
 
 
+def _num(v):
+    """a scalar for write_json_record: numpy / Python numbers as Python float (json.dump prints float.__repr__), None stays"""
+    return float(v) if isinstance(v, (float, np.floating)) else v
+
+
+def _num2d(v):
+    """`np.asarray(v).tolist()` of a coordinate table as the float64 array the library prints (anything else: as a list)"""
+    a = np.asarray(v)
+    return np.ascontiguousarray(a, np.float64) if a.ndim == 2 and a.dtype.kind == "f" else a.tolist()
+
+
+def _rows(rows):
+    """`[np.asarray(e).tolist() for e in rows]`: equally long float rows go to the library as ONE 2-D array (float32 rows are
+    printed as the double of each float32, which is what tolist() hands json.dump); ragged / empty lists stay lists"""
+    rows = [np.asarray(e) for e in rows]
+    if rows and all(r.ndim == 1 and r.dtype == rows[0].dtype and r.shape == rows[0].shape and r.dtype in (np.float32, np.float64) for r in rows):
+        return np.ascontiguousarray(np.stack(rows))
+    return [r.tolist() for r in rows]
+
+
 class Floor:   # graph/floor.py:10-67
     def __init__(self, floor_id, name=None):
         self.floor_id, self.name = floor_id, name
@@ -181,7 +201,17 @@ class Floor:   # graph/floor.py:10-67
     def add_room(self, room):
         self.rooms.append(room)
 
-    def save(self, path):
+    def save(self, path, lib=None):
+        """floor.py:37-52.  lib: write through the C ABI (hmsg_write_ply / hmsg_write_json: the same bytes, numbers printed by
+        the library) -- what Graph.save_hmsg_graph does, and what a C / C++ host calls directly."""
+        if lib is not None:
+            from ._lib import write_json_record, write_ply
+            write_ply(os.path.join(path, str(self.floor_id) + ".ply"), self.pcd.points, lib)
+            write_json_record(os.path.join(path, str(self.floor_id) + ".json"),
+                              [("floor_id", self.floor_id), ("name", self.name), ("rooms", [r.room_id for r in self.rooms]),
+                               ("vertices", _num2d(self.vertices)), ("floor_height", _num(self.floor_height)),
+                               ("floor_zero_level", _num(self.floor_zero_level))], lib)
+            return
         _write_ply(os.path.join(path, str(self.floor_id) + ".ply"), self.pcd.points)
         meta = dict(floor_id=self.floor_id, name=self.name, rooms=[r.room_id for r in self.rooms],
                     vertices=np.asarray(self.vertices).tolist(), floor_height=self.floor_height,
@@ -259,7 +289,20 @@ class Room:    # graph/room.py:15-60, 309-374
         self.name = default_room_types[int(np.argmax(cnt))]
         return self.name
 
-    def save(self, path):
+    def save(self, path, lib=None):
+        """room.py:309-337 (lib: through the C ABI, see Floor.save)"""
+        if lib is not None:
+            from ._lib import write_json_record, write_ply
+            write_ply(os.path.join(path, str(self.room_id) + ".ply"), self.pcd.points, lib)
+            write_json_record(os.path.join(path, str(self.room_id) + ".json"),
+                              [("room_id", self.room_id), ("name", self.name), ("floor_id", self.floor_id),
+                               ("objects", [o.object_id for o in self.objects]),
+                               ("views", [v.view_id if hasattr(v, "view_id") else v for v in self.views]),
+                               ("vertices", _num2d(self.vertices)), ("room_height", _num(self.room_height)),
+                               ("room_zero_level", _num(self.room_zero_level)), ("embeddings", _rows(self.embeddings)),
+                               ("represent_images", self.represent_images), ("sample_images", self.sample_images),
+                               ("clip_embeddings", _rows(self.clip_embeddings))], lib)
+            return
         _write_ply(os.path.join(path, str(self.room_id) + ".ply"), self.pcd.points)
         meta = dict(room_id=self.room_id, name=self.name, floor_id=self.floor_id,
                     objects=[o.object_id for o in self.objects],
@@ -320,11 +363,15 @@ class View:    # graph/view.py:36-103
         self.view_id, self.room_id, self.img_id, self.name = view_id, room_id, img_id, name
         self.object_ids, self.text_discription, self.img_path = [], [], None
 
-    def save(self, path):
+    def save(self, path, lib=None):
         plain = lambda x: int(x) if isinstance(x, np.integer) else x          # view.py:63-71: numpy ids -> int, text -> str
         meta = dict(view_id=plain(self.view_id), room_id=plain(self.room_id), img_id=plain(self.img_id),
                     object_ids=[plain(x) for x in self.object_ids], img_path=self.img_path,
                     text_discription=[str(x) for x in self.text_discription])
+        if lib is not None:                                                   # (no numbers to print: every field travels as text)
+            from ._lib import write_json_record
+            write_json_record(os.path.join(path, str(self.view_id) + ".json"), list(meta.items()), lib)
+            return
         json.dump(meta, open(os.path.join(path, str(self.view_id) + ".json"), "w", encoding="utf-8"))
 
     def load(self, path):
@@ -1119,7 +1166,10 @@ class Graph:
                 continue
             for cls, sub in ((Floor, "floors"), (Room, "rooms"), (Object, "objects"), (View, "views")):
                 if isinstance(node, cls):
-                    node.save(os.path.join(path, sub))
+                    if cls is Object:
+                        node.save(os.path.join(path, sub))
+                    else:                       # floors / rooms / views through the C ABI (hmsg_write_json / hmsg_write_ply)
+                        node.save(os.path.join(path, sub), lib=self.L)
         if bulk:
             self.scene.save_objects(os.path.join(path, "objects"), bulk)
 

@@ -354,6 +354,25 @@ int hmsg_crop_resize_batch(int32_t device_id, int32_t H, int32_t W, const uint8_
                            const double* bbox, double bbox_margin, int32_t out_size, uint8_t* out_plain, uint8_t* out_masked,
                            double* device_ms);
 
+/* ---- A11: the other node records of save_hmsg_graph (graph.py:1801-1824) -- floors/<f>.{ply,json} (floor.py:37-52),
+ * rooms/<f>_<r>.{ply,json} (room.py:309-337), views/<id>.json (view.py:56-74) -- from a C / C++ host, byte for byte what
+ * json.dump writes: one JSON object per call, fields in the order given (the reference's key order).  A field is either RAW
+ * (value_json: the caller's JSON text for strings, id lists, null ...) or numbers the library prints like Python does
+ * (float.__repr__ of the double for F64 / F32, decimal integers for I64): a scalar (ndim 0), [n0] (ndim 1) or [n0][n1]
+ * (ndim 2; n0 = 0 gives []).  hmsg_write_ply writes a cloud as Open3D's write_point_cloud does (x y z doubles);
+ * hmsg_read_json_numbers reads the numbers of one key back, flattened, as json.load + np.array would see them. */
+enum { HMSG_JSON_RAW = 0, HMSG_JSON_F64 = 1, HMSG_JSON_F32 = 2, HMSG_JSON_I64 = 3 };
+typedef struct hmsg_json_field {
+    const char* key;          /* written between quotes as it is */
+    int32_t kind;             /* HMSG_JSON_* */
+    int32_t ndim;             /* 0, 1, 2 (numbers only) */
+    int64_t n0, n1;
+    const void* data;         /* RAW: const char* JSON text;  numbers: host array */
+} hmsg_json_field;
+int hmsg_write_json(const char* path, int32_t n_fields, const hmsg_json_field* fields);
+int hmsg_write_ply(const char* path, const double* xyz, int64_t n);
+int hmsg_read_json_numbers(const char* path, const char* key, double* out, int64_t capacity, int64_t* n);
+
 /* ---- A12: retrieval over a node table (graph.py:3056-3162 query_hmsg_object and the GEMV of
  * query_hmsg_room / query_floor).  A table is N node embeddings (f64, as after load_hmsg_graph:
  * object.py:88-89, or f32 right after build) with a parent (room) id per node. */

@@ -114,3 +114,37 @@ def test_library_prints_floats_like_python_repr():
     assert len(got) == len(want)
     bad = [(g, w) for g, w in zip(got, want) if g != w]
     assert not bad, bad[:5]
+
+
+def test_node_records_through_the_c_abi_equal_json_dump(tmp_path):
+    """hmsg_write_json / hmsg_write_ply / hmsg_read_json_numbers (include/hmsg.h): floors / rooms / views records written by the
+    library are byte for byte what json.dump writes (floor.py:37-52, room.py:309-337, view.py:56-74 key orders), for awkward
+    numbers too; the numbers read back are json.load's."""
+    import json
+    import os
+    import numpy as np
+    from holoagent_amd._lib import HmsgLib, read_json_numbers, write_json_record, write_ply
+    from holoagent_amd.graph import _read_ply
+    from tests import parity_common as PC
+    path = PC.EMU_PATH if os.path.exists(PC.EMU_PATH) else None
+    L = HmsgLib(path)                       # (host-side code: the product library and the simulator build share it)
+    rng = np.random.default_rng(3)
+    awkward = np.array([0.0, -0.0, 1e-7, 123456789012345678.0, 1e16, 9999999999999998.0, 1.5e-5, 0.1, -2.5e+22, 5e-324, 1 / 3])
+    emb32 = [rng.standard_normal(9).astype(np.float32) for _ in range(4)]
+    verts = np.concatenate([rng.standard_normal((6, 2)) * 10, awkward[:10].reshape(5, 2)])
+    meta = dict(room_id="1_3", name="kitchen \\u00e9", floor_id="1", objects=["1_3_0", "1_3_10"], views=["1_3_7"], vertices=verts.tolist(),
+                room_height=float(awkward[6]), room_zero_level=-0.25, embeddings=[e.tolist() for e in emb32], represent_images=[12, 0, 7],
+                sample_images=[], clip_embeddings=[e.tolist() for e in emb32[:2]])
+    json.dump(meta, open(tmp_path / "py.json", "w"))
+    write_json_record(tmp_path / "c.json", [("room_id", "1_3"), ("name", "kitchen \\u00e9"), ("floor_id", "1"), ("objects", ["1_3_0", "1_3_10"]),
+                                            ("views", ["1_3_7"]), ("vertices", verts), ("room_height", float(awkward[6])),
+                                            ("room_zero_level", -0.25), ("embeddings", np.stack(emb32)), ("represent_images", np.array([12, 0, 7])),
+                                            ("sample_images", []), ("clip_embeddings", np.stack(emb32[:2]))], L)
+    assert open(tmp_path / "py.json", "rb").read() == open(tmp_path / "c.json", "rb").read()
+    assert np.array_equal(read_json_numbers(tmp_path / "c.json", "vertices", L), np.asarray(json.load(open(tmp_path / "py.json"))["vertices"]).ravel())
+    assert np.array_equal(read_json_numbers(tmp_path / "c.json", "embeddings", L), np.stack(emb32).astype(np.float64).ravel())
+    assert list(read_json_numbers(tmp_path / "c.json", "represent_images", L)) == [12.0, 0.0, 7.0]
+    assert len(read_json_numbers(tmp_path / "c.json", "sample_images", L)) == 0
+    pts = rng.standard_normal((17, 3))
+    write_ply(tmp_path / "c.ply", pts, L)
+    assert np.array_equal(_read_ply(str(tmp_path / "c.ply")), pts)
