@@ -305,25 +305,31 @@ def main():
         if episode:
             return step_episode()
         sc.reset()
+        g_early = None
+
+        def room_level():
+            # the room level needs only the map and the frames' global features: floors, room regions (device watershed), room
+            # clouds and the camera -> room table run here (device), scikit-learn's KMeans views on a host thread beside the
+            # fusion and the fold (Graph.start_room_level; Graph.create_feature_map does the same).
+            g = Graph.from_scene(sc, cfg=full_cfg, lib=L, instances=False)
+            g.dataset = FrameSource()
+            g._poses = poses_host
+            g.set_view_feats(fg_host)
+            g.start_room_level()
+            return g
         T("add_frames", lambda: sc.add_frames(inp["rgb"], inp["depth"], inp["pose"], inp["K"]))
         T("finalize_map", sc.finalize_map)
+        # (placement: right after the map -- measured on the MI355X: started after hmsg_fuse_frames instead, i.e. beside the
+        #  merge fold that runs on its worker thread, the room level's launches and the fold's short kernels get in each other's
+        #  way: room level 53 -> 92 ms, fold phases up to 2x slower, 620 -> 630 ms per step.  HMSG_BENCH_ROOMS_BESIDE_FOLD=1 keeps that order.)
+        beside_fold = bool(os.environ.get("HMSG_BENCH_ROOMS_BESIDE_FOLD"))
+        if args.full_graph and not beside_fold:
+            g_early = T("room_level/device", room_level)
         T("add_frame_features", lambda: sc.add_frame_features(0, inp["masks"], inp["f_g"], inp["f_masked"], inp["f_crop"]))
         T("fuse_frames", sc.fuse_frames)
-        g_early = None
-        if args.full_graph:
-            # the room level needs only the map and the frames' global features.  The sequential fold has been running on its
-            # worker thread (own stream) since the first fusion batch and hmsg_merge_instances below only waits for it: the room
-            # level's device stage (floors, device watershed, room clouds, camera -> room table: ~50 ms of launches on the
-            # handle's otherwise idle stream) goes here, beside the fold, and scikit-learn's KMeans views on a host thread
-            # (Graph.start_room_level; Graph.create_feature_map does the same)
-            def rooms_early():
-                g = Graph.from_scene(sc, cfg=full_cfg, lib=L, instances=False)
-                g.dataset = FrameSource()
-                g._poses = poses_host
-                g.set_view_feats(fg_host)
-                g.start_room_level()
-                return g
-            g_early = T("room_level/device", rooms_early)
+        if args.full_graph and beside_fold:
+            g_early = T("room_level/device", room_level)
+
         T("merge_instances", sc.merge_instances)
         T("pool_instances", sc.pool_instances)
 
@@ -505,14 +511,14 @@ def main():
             scx.reset()
             scx.add_frames(inp["rgb"], inp["depth"], inp["pose"], inp["K"])
             scx.finalize_map()
-            scx.add_frame_features(0, inp["masks"], inp["f_g"], inp["f_masked"], inp["f_crop"])
-            scx.fuse_frames()
             if args.full_graph:
                 g = Graph.from_scene(scx, cfg=full_cfg, lib=L, instances=False)
                 g.dataset = FrameSource()
                 g._poses = poses_host
                 g.set_view_feats(fg_host)
                 g.start_room_level()
+            scx.add_frame_features(0, inp["masks"], inp["f_g"], inp["f_masked"], inp["f_crop"])
+            scx.fuse_frames()
             scx.merge_instances()
             scx.pool_instances()
             if args.full_graph:                                    # the same step as the line: nothing handed in

@@ -610,16 +610,16 @@ class Graph:
             sc.add_frame_features(n_done, masks, fg, fm, fc, n_masks)
             self._view_feats.extend(np.asarray(o["f_g"], np.float32).reshape(1, -1) for o in outs)
             n_done += len(outs)
-        sc.fuse_frames()
         # the room level (floors, room regions, room clouds, camera -> room table on the device; KMeans views on a host thread)
-        # needs only the map and the frames' global features: it runs beside the merge fold, which has been folding on its worker thread since the first
-        # fusion batch (start_room_level)
+        # needs only the map and the frames' global features: its device stage runs here, KMeans beside the fusion and the fold
+        # (start_room_level; started after hmsg_fuse_frames instead, its launches and the fold's short kernels slow each other down)
         if bool(p("room_level_beside_fusion", True)) and len(self._view_feats) == len(ids):
             try:
                 self.start_room_level()
             except Exception as e:                                         # build_hier_multimodal_scene_graph does it in place
                 print("room level not started early:", e)
                 self.floors, self._room_level = [], None
+        sc.fuse_frames()
         self.full_feats_array = sc.map_feats()
         sc.merge_instances()
         sc.pool_instances()
