@@ -232,6 +232,8 @@ int hmsg_reset(hmsg_t* h) {
         h->n_tie_queries = 0;
         h->n_frames = h->n_feat_frames = h->n_fused = 0;
         h->n_offered = 0;
+        h->room_n = 0;
+        h->room_total = 0;
         if (h->frames_released) {              // (hmsg_merge_instances gave a very large frame store back)
             alloc_frame_store(h);
             h->frames_released = false;

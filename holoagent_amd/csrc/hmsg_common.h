@@ -563,6 +563,12 @@ struct hmsg_ctx {
     DevCache fold_cache;           // the worker's allocator cache between scenes (its thread-local one while it runs)
     bool inst_denoised = false;    // the per-object pcd_denoise_dbscan(0.05, 10) of graph.py:1589-1591 has run
     std::vector<hmsg_node> nodes;  // object nodes (hmsg_build_object_nodes)
+    // room clouds of the last hmsg_room_clouds call, resident: per room the selected floor points (indices into the storey's
+    // crop), room offsets, floor point -> map point
+    DevBuf<int> room_sel, room_fmap;
+    DevBuf<long long> room_off_dev;
+    int room_n = 0;
+    long long room_total = 0;
     std::vector<int> node_label;   // per instance: arg-max label (-1 without a vocabulary)
     // scratch
     DevBuf<unsigned> scan_tmp;

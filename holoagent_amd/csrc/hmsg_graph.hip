@@ -358,6 +358,54 @@ __global__ void __launch_bounds__(256) k_room_nn(CoarseGrid C, const double* __r
     }
 }
 
+// marks -> compact room lists on the device (what used to be a host loop over rooms x floor points) + the inverse of the floor
+// rank (floor point -> map point), so that the room clouds stay usable on the device: hmsg_room_camera_distances
+__global__ void k_rc_flags(const unsigned char* __restrict__ mark, size_t n, unsigned* __restrict__ flags) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = mark[i] ? 1u : 0u;
+}
+__global__ void k_rc_compact(const unsigned char* __restrict__ mark, const unsigned* __restrict__ pos, size_t n, long long NF, int* __restrict__ sel) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && mark[i]) sel[pos[i]] = (int)(i % (size_t)NF);
+}
+__global__ void k_rc_offsets(const unsigned* __restrict__ pos, const unsigned char* __restrict__ mark, long long NF, int n_rooms, long long* __restrict__ off) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_rooms) off[r] = pos[(size_t)r * NF];
+    if (r == n_rooms) off[r] = (long long)pos[(size_t)n_rooms * NF - 1] + (mark[(size_t)n_rooms * NF - 1] ? 1 : 0);
+}
+__global__ void k_rc_floor_map(const unsigned char* __restrict__ ok, const unsigned* __restrict__ frank, long long V, int* __restrict__ fmap) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < V && ok[i]) fmap[frank[i]] = (int)i;
+}
+__global__ void k_rc_xz(const int* __restrict__ sel, const int* __restrict__ fmap, const double* __restrict__ pts, long long n, double* __restrict__ xz) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t q = (size_t)fmap[sel[i]];
+    xz[i * 2] = pts[q * 3];
+    xz[i * 2 + 1] = pts[q * 3 + 2];
+}
+// compute_room_embeddings (utils/graph_utils.py:244-291): np.min(cdist([pos], room_points)) = sqrt of the smallest
+// dx*dx + dy*dy (float64, that order); one workgroup per (camera, room)  [the statement of hmsg_points_min_dist_2d]
+__global__ void __launch_bounds__(256) k_rc_min_dist(const long long* __restrict__ set_off, const double* __restrict__ pts, int n_sets,
+                                                     const double* __restrict__ q, double* __restrict__ out) {
+    __shared__ double s_m[4];
+    const int qi = blockIdx.y, si = blockIdx.x;
+    const double qx = q[(size_t)qi * 2], qy = q[(size_t)qi * 2 + 1];
+    double m = 1e308 * 10.0;
+    for (long long k = set_off[si] + threadIdx.x; k < set_off[si + 1]; k += blockDim.x) {
+        const double dx = __dsub_rn(qx, pts[k * 2]), dy = __dsub_rn(qy, pts[k * 2 + 1]);
+        const double d2 = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
+        m = d2 < m ? d2 : m;
+    }
+    m = wave_min_f64(m);
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) m = s_m[w] < m ? s_m[w] : m;
+        out[(size_t)qi * n_sets + si] = __dsqrt_rn(m);
+    }
+}
+
 extern "C" int hmsg_room_clouds(hmsg_t* h, double y_lo, double y_hi, const double* T, int32_t n_levels, const double* z_levels,
                                 int32_t n_rooms, const int64_t* room_off, const double* room_xz, int64_t* out_sizes,
                                 int32_t* out_index, int64_t out_capacity, int64_t* n_floor_points) {
@@ -450,14 +498,17 @@ extern "C" int hmsg_room_clouds(hmsg_t* h, double y_lo, double y_hi, const doubl
         auto t_a = tnow();
         if (dbg) HIP_TRY(hipStreamSynchronize(s));
         auto t_b = tnow();
-        std::vector<unsigned char> hmark((size_t)n_rooms * NF);
+        std::vector<unsigned char> hmark;
         unsigned n_t = 0;
         HIP_TRY(hipStreamSynchronize(s));
-        d2h_bounce(hmark.data(), mark.p, hmark.size());          // (through pinned memory: a copy into fresh pageable pages crawls)
         HIP_TRY(hipMemcpy(&n_t, nt.p, 4, hipMemcpyDeviceToHost));
+        if (n_t) {                                                  // (the marks come to the host only to be patched)
+            hmark.resize((size_t)n_rooms * NF);
+            d2h_bounce(hmark.data(), mark.p, hmark.size());
+        }
         auto t_c = tnow();
         if (dbg)
-            fprintf(stderr, "[hmsg room clouds] %lld queries: kernels %.2f ms, read-back %.2f ms\n", nq,
+            fprintf(stderr, "[hmsg room clouds] %lld queries, %u bit-equal ties: kernels %.2f ms, read-back %.2f ms\n", nq, n_t,
                     std::chrono::duration<double, std::milli>(t_b - t_a).count(), std::chrono::duration<double, std::milli>(t_c - t_b).count());
         HMSG_REQUIRE(n_t <= tie_cap, HMSG_ERR_UNSUPPORTED, "hmsg_room_clouds: more than 2^20 bit-equal nearest-neighbour ties");
         if (n_t) {
@@ -484,18 +535,71 @@ extern "C" int hmsg_room_clouds(hmsg_t* h, double y_lo, double y_hi, const doubl
             }
             h->n_tie_queries += n_t;
         }
-        long long total = 0;
-        for (int r = 0; r < n_rooms; ++r) {
-            long long n = 0;
-            for (long long i = 0; i < NF; ++i)
-                if (hmark[(size_t)r * NF + i]) {
-                    if (out_index && total + n < out_capacity) out_index[total + n] = (int32_t)i;
-                    ++n;
-                }
-            out_sizes[r] = n;
-            total += n;
+        if (dbg) fprintf(stderr, "[hmsg room clouds] ties resolved after %.2f ms\n", std::chrono::duration<double, std::milli>(tnow() - t_c).count());
+        if (n_t) HIP_TRY(hipMemcpyAsync(mark.p, hmark.data(), hmark.size(), hipMemcpyHostToDevice, s));       // (the patched ties)
+        // compact room lists on the device; they stay with the handle (hmsg_room_camera_distances)
+        const size_t nm = (size_t)n_rooms * (size_t)NF;
+        DevBuf<unsigned> fl, pos;
+        fl.alloc(nm);
+        pos.alloc(nm);
+        hipLaunchKernelGGL(k_rc_flags, dim3(cdiv(nm, 256)), dim3(256), 0, s, (const unsigned char*)mark.p, nm, fl.p);
+        HMSG_CHECK_LAUNCH();
+        hmsg_scan_u32(fl.p, pos.p, nm, s, h->scan_tmp, nullptr);
+        h->room_off_dev.alloc((size_t)n_rooms + 1);
+        hipLaunchKernelGGL(k_rc_offsets, dim3(cdiv((size_t)n_rooms + 1, 64)), dim3(64), 0, s, (const unsigned*)pos.p, (const unsigned char*)mark.p, NF, n_rooms,
+                           h->room_off_dev.p);
+        HMSG_CHECK_LAUNCH();
+        std::vector<long long> hoff2((size_t)n_rooms + 1);
+        HIP_TRY(hipMemcpyAsync(hoff2.data(), h->room_off_dev.p, hoff2.size() * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        const long long total = hoff2[(size_t)n_rooms];
+        h->room_sel.alloc((size_t)std::max<long long>(total, 1));
+        hipLaunchKernelGGL(k_rc_compact, dim3(cdiv(nm, 256)), dim3(256), 0, s, (const unsigned char*)mark.p, (const unsigned*)pos.p, nm, NF, h->room_sel.p);
+        h->room_fmap.alloc((size_t)NF);
+        hipLaunchKernelGGL(k_rc_floor_map, dim3(cdiv((size_t)V, 256)), dim3(256), 0, s, (const unsigned char*)ok.p, (const unsigned*)frank.p, V, h->room_fmap.p);
+        HMSG_CHECK_LAUNCH();
+        h->room_n = n_rooms;
+        h->room_total = total;
+        for (int r = 0; r < n_rooms; ++r) out_sizes[r] = hoff2[(size_t)r + 1] - hoff2[(size_t)r];
+        if (out_index && total <= out_capacity && total > 0) {
+            HIP_TRY(hipStreamSynchronize(s));
+            d2h_bounce(out_index, h->room_sel.p, (size_t)total * 4);
         }
+        HIP_TRY(hipStreamSynchronize(s));
         HMSG_REQUIRE(!out_index || total <= out_capacity, HMSG_ERR_INVALID, "hmsg_room_clouds: out_index too small (sum of out_sizes needed)");
+        return HMSG_OK;
+    } catch (const hmsg_error& e) {
+        h->err = e.msg;
+        return e.code;
+    }
+}
+
+// camera -> room distance table of compute_room_embeddings (utils/graph_utils.py:244-291) from the room clouds the last
+// hmsg_room_clouds call left on the device: room r = the (x, z) of its selected floor points, in the floor cloud's order
+// (np.min over them is order-independent); out f64 [n_q][n_rooms].
+extern "C" int hmsg_room_camera_distances(hmsg_t* h, int64_t n_q, const double* q_xz, double* out) {
+    if (!h || n_q < 0 || (n_q > 0 && (!q_xz || !out))) return HMSG_ERR_INVALID;
+    try {
+        HIP_TRY(hipSetDevice(h->cfg.device_id));
+        HMSG_REQUIRE(h->room_n > 0, HMSG_ERR_INVALID, "hmsg_room_camera_distances: call hmsg_room_clouds first");
+        if (n_q == 0) return HMSG_OK;
+        hipStream_t s = h->stream;
+        DevBuf<double> xz, dq, dout;
+        xz.alloc((size_t)std::max<long long>(h->room_total, 1) * 2);
+        dq.alloc((size_t)n_q * 2);
+        dout.alloc((size_t)n_q * (size_t)h->room_n);
+        if (h->room_total)
+            hipLaunchKernelGGL(k_rc_xz, dim3(cdiv((size_t)h->room_total, 256)), dim3(256), 0, s, (const int*)h->room_sel.p, (const int*)h->room_fmap.p,
+                               (const double*)h->pts.p, h->room_total, xz.p);
+        HIP_TRY(hipMemcpyAsync(dq.p, q_xz, (size_t)n_q * 16, hipMemcpyHostToDevice, s));
+        for (long long q0 = 0; q0 < n_q; q0 += 32768) {
+            const unsigned nq = (unsigned)std::min<long long>(32768, n_q - q0);
+            hipLaunchKernelGGL(k_rc_min_dist, dim3((unsigned)h->room_n, nq), dim3(256), 0, s, (const long long*)h->room_off_dev.p, (const double*)xz.p, h->room_n,
+                               (const double*)dq.p + q0 * 2, dout.p + q0 * h->room_n);
+        }
+        HMSG_CHECK_LAUNCH();
+        HIP_TRY(hipStreamSynchronize(s));
+        d2h_bounce(out, dout.p, (size_t)n_q * (size_t)h->room_n * 8);
         return HMSG_OK;
     } catch (const hmsg_error& e) {
         h->err = e.msg;

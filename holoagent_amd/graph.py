@@ -785,12 +785,21 @@ class Graph:
         crop = getattr(floor, "_crop", None)
         if self.scene is None or crop is None:
             return None
+        import time
+        t0 = time.perf_counter()
         z_levels, T1 = self._room_extrusion(floor)
         sel, nf = self.scene.room_clouds(crop[0], crop[1], T1, z_levels, room_2d_points)
-        fp = np.asarray(floor.pcd.points)
-        if nf != len(fp):
+        t1 = time.perf_counter()
+        n_floor = floor.pcd._n if isinstance(floor.pcd, _LazyFn) and floor.pcd._n is not None else len(np.asarray(floor.pcd.points))
+        if nf != n_floor:
             return None
-        return [_Pcd(fp[i]) for i in sel]
+        # the clouds stay in HBM: a room's points are fetched (the storey's slab, then the selection) when somebody reads them
+        out = [_LazyFn(lambda i=i: np.asarray(floor.pcd.points)[i], len(i)) for i in sel]
+        self._room_clouds_resident = floor
+        if os.environ.get("HMSG_DEBUG_TIMING"):
+            print("[hmsg rooms] room clouds: library call %.1f ms, floor cloud + selection %.1f ms" % ((t1 - t0) * 1e3, (time.perf_counter() - t1) * 1e3),
+                  file=sys.stderr)
+        return out
 
     def _room_regions_device(self, floor):
         """graph.py:942-1084: the storey's rooms as lists of (x, z) cell centres -- histograms, blur / threshold /
@@ -868,7 +877,13 @@ class Graph:
             floor_pts = np.asarray(floor.pcd.points)
             pcd_min, pcd_max = floor_pts.min(axis=0), floor_pts.max(axis=0)
         t3 = time.perf_counter()
-        dist = camera_room_distances(room_pcds, pose_list, lib=self.L, device_id=int(_get(self.cfg, "main.device_id", 0)))
+        if getattr(self, "_room_clouds_resident", None) is floor and room_pcds and all(isinstance(r, _LazyFn) for r in room_pcds):
+            # the clouds hmsg_room_clouds just made are still on the device: distances there, nothing travels
+            cam = np.array([[pose[0, 3], pose[2, 3]] for pose in pose_list], dtype=np.float64).reshape(-1, 2)
+            dist = self.scene.room_camera_distances(cam) if len(cam) else np.zeros((0, len(room_pcds)))
+        else:
+            dist = camera_room_distances(room_pcds, pose_list, lib=self.L, device_id=int(_get(self.cfg, "main.device_id", 0)))
+        self._room_clouds_resident = None
         if dbg:
             print("[hmsg rooms] regions %.1f  room clouds %.1f  poses/feats %.1f  camera->room table %.1f ms" %
                   ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (time.perf_counter() - t3) * 1e3), file=sys.stderr)
@@ -889,7 +904,7 @@ class Graph:
         self.room_id2img_ids = room_id2img_id
         for i in range(len(room_2d_points)):
             room = Room(str(floor.floor_id) + "_" + str(i), floor.floor_id, name="room_" + str(i))
-            room.pcd = room_pcds[i] if hasattr(room_pcds[i], "points") else _Pcd(room_pcds[i])
+            room.pcd = room_pcds[i] if isinstance(room_pcds[i], (_Pcd, _LazyFn)) or hasattr(type(room_pcds[i]), "points") else _Pcd(room_pcds[i])
             room.vertices = np.asarray(room_2d_points[i], np.float64).reshape(-1, 2)
             floor.add_room(room)
             room.room_height, room.room_zero_level = floor.floor_height, floor.floor_zero_level
