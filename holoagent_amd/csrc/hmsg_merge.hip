@@ -1118,6 +1118,7 @@ struct SeqFold {
         never = getenv("HMSG_FOLD_LEGACY") != nullptr;
         switch_points = getenv("HMSG_FOLD_INCREMENTAL") ? 0.0 : 600000.0;
         if (const char* e = getenv("HMSG_FOLD_SWITCH")) switch_points = atof(e);
+        if (const char* e = getenv("HMSG_FOLD_BIG_ACTIVE")) m.big_active = atoll(e);   // (development: which components take the batch kernels)
     }
     // the 3-D masks of `nm.size()` more frames: npts points at src (device; complete on the fold's stream or synchronised),
     // off[i] .. off[i + 1] = points of mask i (relative to src), nm[f] = masks of frame f.  reserve: pool room per point.
