@@ -367,20 +367,8 @@ __device__ __forceinline__ int uf_find_cached(const int* parent, int x) {
     }
     return x;
 }
-// The same walk, and the start cell is hung directly under what the walk found when that was more than one hop away: a
-// plain store of an ANCESTOR (racy stores only ever shorten paths, as with path halving).  Without it nothing compresses the
-// forest while the cached walks succeed, and the union passes walk chains that grow with the cluster.
-__device__ __forceinline__ int uf_find_compress(int* parent, int x) {
-    const int x0 = x;
-    int hops = 0;
-    for (; hops < 64; ++hops) {
-        const int p = parent[x];
-        if (p == x) break;
-        x = p;
-    }
-    if (hops > 1) parent[x0] = x;
-    return x;
-}
+// (Hanging the start cell directly under what the walk found -- path compression by plain stores -- was measured: k_db_union
+//  37.5 -> 40.2 us per fold step.  The walks are short; the pass is bound by its ~250 scattered cache-line requests per cell.)
 // Which of two roots stays a root is a fixed total order over the cells (concurrent CASes cannot close a cycle): cells that
 // hold ANCHOR cores come first, then the lower index.  The anchor cells of a segment are one component from the start
 // (k_db_anchor, rooted at the lowest of them), so that root never moves and every active cell that joins the anchor's
@@ -464,7 +452,7 @@ __global__ void k_db_union(const int* __restrict__ corecells, const unsigned* __
         const DbSeg sg = segs[lo];
         int ix, iy, iz;
         cell_xyz(sg, c, ix, iy, iz);
-        const int rc = uf_find_compress(parent, (int)c);     // (may go stale: only costs a redundant uf_union)
+        const int rc = uf_find_cached(parent, (int)c);     // (may go stale: only costs a redundant uf_union)
         double ba[6];
         for (int a = 0; a < 6; ++a) ba[a] = cellbox[(size_t)cellpos[c] * 6 + a];
         // both of the lane's neighbour cells (o = lane and lane + 64) in one straight-line pass: their table entries, their
@@ -500,7 +488,7 @@ __global__ void k_db_union(const int* __restrict__ corecells, const unsigned* __
         int r2[2] = {rc, rc};
 #pragma unroll
         for (int q = 0; q < 2; ++q)
-            if (ok[q]) r2[q] = uf_find_compress(parent, p2[q]);
+            if (ok[q]) r2[q] = uf_find_cached(parent, p2[q]);
         // The wave works for ONE cell: every lane whose neighbour passes the box test would unite c with it, and almost all
         // of those neighbours already share one root (the anchor's) -- 60 lanes then fail the same CAS on parent[c] and walk
         // the chain again with atomic loads, which was two thirds of this kernel's time.  One union per DISTINCT neighbour
@@ -562,7 +550,7 @@ __global__ void k_db_union_scan(const double* __restrict__ pts, const int* __res
               int jx = ix + dx, jy = iy + dy, jz = iz + dz;
               if (cheb == pass && jx >= 0 && jy >= 0 && jz >= 0 && jx < sg.nx && jy < sg.ny && jz < sg.nz) {
                   long long cc = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz + jz;
-                  if (minidx[cc] != INF32 && (cc > c || !active[cc]) && uf_find_compress(parent, (int)c) != uf_find_compress(parent, (int)cc)) {
+                  if (minidx[cc] != INF32 && (cc > c || !active[cc]) && uf_find_cached(parent, (int)c) != uf_find_cached(parent, (int)cc)) {
                       const double* bq = cellbox + (size_t)cellpos[cc] * 6;
                       double mn2 = 0.0, mx2 = 0.0;
                       for (int a = 0; a < 3; ++a) {
