@@ -265,11 +265,16 @@ def main():
         T("add_frame_features", lambda: sc.add_frame_features(a, inp["masks"][a:b], inp["f_g"][a:b], inp["f_masked"][a:b], inp["f_crop"][a:b]))
         T("fuse_frames", sc.fuse_frames)
         if use_dist:
-            if not emu and not os.environ.get("HMSG_BENCH_TORCH_GATHER"):
+            if not emu and not os.environ.get("HMSG_BENCH_TORCH_GATHER") and state.get("comm") is not False:
                 # behind the C ABI: librccl on the handle's own buffers, in place (hmsg_allreduce_feature_sums)
                 from holoagent_amd._lib import Comm
-                if state.get("comm") is None:
-                    state["comm"] = Comm.from_torch(local, L)
+                try:
+                    if state.get("comm") is None:
+                        state["comm"] = Comm.from_torch(local, L)
+                except Exception as e:
+                    print("hmsg_comm_create unavailable (%r): torch.distributed all_reduce instead" % (e,), file=sys.stderr)
+                    state["comm"] = False
+            if state.get("comm"):
                 T("allreduce_feature_sums", lambda: sc.allreduce_feature_sums(state["comm"]))
             else:
                 T("allreduce_feature_sums", lambda: allreduce_feature_sums(sc, device=device))
@@ -369,11 +374,17 @@ def main():
                 # the C ABI (hmsg_allgather_nodes: librccl on device buffers, the gathered table IS the resident index); the
                 # torch.distributed form (holoagent_amd/dist.py gather_node_tables) remains for the gloo CPU tests.
                 from holoagent_amd.dist import gather_node_tables, gather_node_tables_device, shard_queries
-                if not emu and not os.environ.get("HMSG_BENCH_TORCH_GATHER"):
-                    g_ix, _node_off, room_off, state["comm"] = gather_node_tables_device(sc, n_rooms, state.get("comm"), local)
-                    g_feats = np.zeros((int(_node_off[-1]), 1))            # (shape only: the table itself stays in HBM)
-                    g_rooms = None
-                else:
+                done = False
+                if not emu and not os.environ.get("HMSG_BENCH_TORCH_GATHER") and state.get("comm") is not False:
+                    try:
+                        g_ix, _node_off, room_off, state["comm"] = gather_node_tables_device(sc, n_rooms, state.get("comm"), local)
+                        g_feats = np.zeros((int(_node_off[-1]), 1))        # (shape only: the table itself stays in HBM)
+                        g_rooms = None
+                        done = True
+                    except Exception as e:                                 # (librccl not loadable ...: the torch.distributed form)
+                        print("hmsg_allgather_nodes unavailable (%r): torch.distributed all_gather instead" % (e,), file=sys.stderr)
+                        state["comm"] = False
+                if not done:
                     g_feats, g_rooms, _node_off, room_off = gather_node_tables(feats, rooms, n_rooms, device)
                 qs = shard_queries(Q, rank, world)               # this rank's share of the queries
                 rl = [[r + int(room_off[rank]) for r in q_rooms[q]] for q in qs]

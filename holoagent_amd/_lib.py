@@ -237,9 +237,26 @@ class Comm:
     def from_torch(cls, device_id=0, lib_=None, group=None):
         import torch.distributed as dist
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [cls.unique_id(lib_) if rank == 0 else None]
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = cls.unique_id(lib_)
+            except HmsgError:
+                box[0] = None                    # (told to the others below: every rank takes the same way out)
         dist.broadcast_object_list(box, src=0, group=group)
-        return cls.create(box[0], rank, world, device_id, lib_)
+        if box[0] is None:
+            raise HmsgError("hmsg_comm_unique_id failed on rank 0 (librccl could not be loaded)")
+        try:
+            c = cls.create(box[0], rank, world, device_id, lib_)
+        except HmsgError:
+            c = None
+        oks = [None] * world
+        dist.all_gather_object(oks, c is not None, group=group)
+        if not all(oks):
+            if c is not None:
+                c.close()
+            raise HmsgError("hmsg_comm_create failed on ranks %s" % [r for r, ok in enumerate(oks) if not ok])
+        return c
 
     def close(self):
         if getattr(self, "h", None):
