@@ -94,3 +94,36 @@ def test_rccl_communicator_with_one_rank_gpu(tmp_path):
     ixg.close()
     ixn.close()
     cm.close()
+
+
+def _from_torch_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from holoagent_amd._lib import Comm, HmsgError, HmsgLib
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        Comm.from_torch(0, HmsgLib(PC.EMU_PATH))
+        res = "created"
+    except HmsgError as e:
+        res = "refused: %s" % e
+    open("%s.%d" % (out, rank), "w").write(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(not os.path.exists(PC.EMU_PATH), reason="kernel simulator not built")
+def test_every_rank_takes_the_same_way_out_without_gpus(tmp_path):
+    """Comm.from_torch with two gloo ranks on a box WITHOUT GPUs: the communicator cannot be made (ncclCommInitRank has no
+    device), and both ranks learn so together -- bench.py then falls back to the torch.distributed forms on every rank instead
+    of hanging half of them in a collective."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "res")
+    mp.spawn(_from_torch_worker, args=(2, port, out), nprocs=2, join=True)
+    r = [open("%s.%d" % (out, k)).read() for k in range(2)]
+    assert r[0].split(":")[0] == r[1].split(":")[0], r
