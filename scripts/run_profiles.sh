@@ -6,7 +6,7 @@ set -u
 OUT=/root/repo/gpurun_out/${1:-prof}
 mkdir -p $OUT
 cd /root/repo
-python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err   # (the whole graph in the step; cpu_baseline = configs[0] in full: ~100 s)
 python bench.py --feat-dim 1024 --cpu-frames 0 > $OUT/bench_d1024.json 2>/dev/null
 HMSG_BENCH_FORCE_DIST=1 python bench.py --cpu-frames 0 > $OUT/bench_force_dist.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
