@@ -1034,7 +1034,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     h_geom.ensure(geom_bytes + cat_bytes);
     memcpy(h_geom.p, hs.data(), (size_t)K * sizeof(DbSeg));
     if (cat_bytes) memcpy(h_geom.p + geom_bytes, gather->host_segs, cat_bytes);
-    HIP_TRY(hipMemcpyAsync(geom.p, h_geom.p, geom_bytes + cat_bytes, hipMemcpyHostToDevice, s));
+    upload_pinned(geom.p, h_geom.p, geom_bytes + cat_bytes, s);
     DbGather ga_dev = gather ? *gather : DbGather{};
     if (cat_bytes) ga_dev.segs = (const CatSeg*)(geom.p + geom_bytes);
     const DbSeg* dsegs = (const DbSeg*)geom.p;

@@ -308,6 +308,25 @@ inline void d2h_bounce(void* dst, const void* src, size_t bytes) {
         memcpy((unsigned char*)dst + o, stage.p, n);
     }
 }
+// A few KB of tables from PINNED host memory to the device inside the stream, by a small kernel that reads the host memory
+// directly (as k_publish writes it): `hipMemcpyAsync` of such a table is a blit-kernel dispatch of ~6.5 us on this stack, three
+// of them per merge-fold step.  src must be hipHostMalloc'ed memory (PinnedBuf) that stays untouched until the stream passes
+// this point.
+static __global__ void k_upload16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16, unsigned tail) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x < tail)
+        ((unsigned char*)(dst + n16))[threadIdx.x] = ((const unsigned char*)(src + n16))[threadIdx.x];
+}
+inline void upload_pinned(void* dst_dev, const void* src_pinned, size_t bytes, hipStream_t s) {
+    if (!bytes) return;
+    if (bytes > ((size_t)1 << 18) || ((uintptr_t)dst_dev & 15) || ((uintptr_t)src_pinned & 15)) {
+        HIP_TRY(hipMemcpyAsync(dst_dev, src_pinned, bytes, hipMemcpyHostToDevice, s));
+        return;
+    }
+    const size_t n16 = bytes / 16;
+    hipLaunchKernelGGL(k_upload16, dim3((unsigned)std::max<size_t>(1, std::min<size_t>((n16 + 255) / 256, 16))), dim3(256), 0, s, (const uint4*)src_pinned,
+                       (uint4*)dst_dev, n16, (unsigned)(bytes % 16));
+}
 struct SpinWait {
     hipEvent_t ev = nullptr;
     ~SpinWait() {

@@ -126,13 +126,16 @@ __global__ void k_ov_fill(const double* __restrict__ pool, const OvGrid* __restr
 
 // one z-run of Y's cell-sorted points: is any of them closer than r to (x, y, z)?  (float32 arithmetic of
 // find_overlapping_ratio_faiss: (dx*dx + dy*dy) + dz*dz < r2)
+#define OV_UNROLL 16
 __device__ __forceinline__ bool ov_scan(const float* __restrict__ sorted, unsigned s0, unsigned e0, float x, float y, float z,
                                         float r2) {
-    // four candidates per step with independent loads: the scan is a serial latency chain per lane
-    for (unsigned k = s0; k < e0; k += 4) {
+    // OV_UNROLL candidates per step with independent loads: the scan is a serial latency chain per lane (one L2 round trip per
+    // step: the early exit keeps the next step's loads from being issued ahead), and the kernel lasts as long as its slowest lane --
+    // a point whose witness sits deep in a cell that has piled up hundreds of re-observations
+    for (unsigned k = s0; k < e0; k += OV_UNROLL) {
         bool h = false;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < OV_UNROLL; ++j) {
             const unsigned kk = min(k + (unsigned)j, e0 - 1u);
             float ddx = __fsub_rn(x, sorted[(size_t)kk * 3]), ddy = __fsub_rn(y, sorted[(size_t)kk * 3 + 1]),
                   ddz = __fsub_rn(z, sorted[(size_t)kk * 3 + 2]);
@@ -434,7 +437,7 @@ struct Merger {
         //  the previous use has completed -- every step and every prebuild ends with a wait on the stream)
         h_grids.ensure(g.size());
         memcpy(h_grids.p, g.data(), g.size() * sizeof(OvGrid));
-        HIP_TRY(hipMemcpyAsync(d_grids.p, h_grids.p, g.size() * sizeof(OvGrid), hipMemcpyHostToDevice, s));
+        upload_pinned(d_grids.p, h_grids.p, g.size() * sizeof(OvGrid), s);
         unsigned* cells = ix_cells.p + ix_cells_used;
         {   // the cursor is zero whenever k_ov_fill has run over what k_ov_count counted: only fresh memory is cleared
             const unsigned* before = d_cursor.p;
@@ -558,7 +561,7 @@ struct Merger {
         memcpy(h_ovpack.p, g.data(), g.size() * sizeof(OvGrid));
         memcpy(h_ovpack.p + off_t, tasks.data(), tasks.size() * sizeof(OvTask));
         memset(h_ovpack.p + off_c, 0, tasks.size() * 4);
-        HIP_TRY(hipMemcpyAsync(d_ovpack.p, h_ovpack.p, pack, hipMemcpyHostToDevice, s));
+        upload_pinned(d_ovpack.p, h_ovpack.p, pack, s);
         const OvGrid* const dg = (const OvGrid*)d_ovpack.p;
         const OvTask* const dt = (const OvTask*)(d_ovpack.p + off_t);
         unsigned* const dc = (unsigned*)(d_ovpack.p + off_c);
