@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--encoder-frames", type=int, default=8,
                     help="frames of the extra encoder hand-off leg (random-init ViT-B/32-shaped PyTorch-ROCm module -> features by "
                          "data_ptr() into hmsg_add_frame_features; reported beside `value`, never in it; 0 = skip)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the timed steps: no CPU baseline, scenes-in-flight, rooms-handed-in or encoder hand-off legs (profiler passes)")
     ap.add_argument("--scene-shape", default=None,
                     help="development sizes (the simulator test): ROOMS_X,ROOMS_Z,ROOM_X_M,ROOM_Y_M,ROOM_Z_M,YAW_STEP_DEG,OBJECTS_PER_ROOM of "
                          "the synthetic building instead of configs[1]'s 4 x 2 rooms of 5 x 3 x 4 m, 10 degrees a frame, 8 objects a room")
@@ -130,6 +132,8 @@ def main():
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         sys.exit(subprocess.call(cmd, env=env))
 
+    if args.no_extras:
+        args.cpu_frames, args.inflight_steps, args.encoder_frames = 0, 0, 0
     import torch
     import torch.distributed as dist
     from holoagent_amd._lib import HmsgLib, Scene, NodeIndex
@@ -591,7 +595,7 @@ def main():
     # ---- extra, for continuity with rounds 1-3's line: the same scene with the rooms' 2-D regions HANDED IN and no views (their
     # `value`; A9's room embeddings / View nodes and A10's view test are then not in the step).  Two steps, never `value`.
     handed_in = None
-    if args.full_graph and not episode and not use_dist and not emu:
+    if args.full_graph and not episode and not use_dist and not emu and not args.no_extras:
         try:
             def step_rooms_given():
                 sc.reset()
