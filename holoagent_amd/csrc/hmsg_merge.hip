@@ -583,14 +583,16 @@ struct Merger {
         pub_counts.launch(s, (const unsigned*)dc, tasks.size());
         pub_counts.wait();
         const unsigned* hc = pub_counts.data();
-        double ov_work = 0;                                  // 12 B per point of every scan the decision needed
+        // Algorithmic bytes of the step (merge): `sum over bbox-overlapping pairs (n_A + n_B) * 12` -- the float32 points
+        // of both clouds of every pair the filter passes, each read once.  What the implementation skips (the larger cloud's scan
+        // when the smaller one's ratio decides, or when the box bound does) is its own cleverness, not a smaller problem.
+        double ov_work = 0;
         for (size_t k = 0; k < P; ++k) {
             const int na = std::min(L[pairs[k].first].n, L[pairs[k].second].n), nb = std::max(L[pairs[k].first].n, L[pairs[k].second].n);
             const bool bounded = (hc[P + k] & 0x80000000u) != 0;      // second direction decided by the box bound (k_ov_query)
             ratio[k] = std::max((double)hc[k] / (double)na, bounded ? 0.0 : (double)hc[P + k] / (double)nb);
-            ov_work += 12.0 * na;
+            ov_work += 12.0 * ((double)na + (double)nb);
             if (!(decide_th >= 0.0 && (double)hc[k] / (double)na > decide_th) && !bounded) {
-                ov_work += 12.0 * nb;
                 if (second_ran) (*second_ran)[k] = 1;
             }
         }
