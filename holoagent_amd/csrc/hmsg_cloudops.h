@@ -56,7 +56,7 @@ struct CloudOps {
     hipStream_t s = nullptr;
     Prof* prof = nullptr;        // optional live timing of the heavy kernels
     // work counters of the DBSCAN batches (debug output of the merge stage)
-    double stat_calls = 0, stat_points = 0, stat_cells = 0, stat_core_cells = 0, stat_active_cells = 0;
+    double stat_calls = 0, stat_points = 0, stat_cells = 0, stat_core_cells = 0, stat_active_cells = 0, stat_maxcell_sum = 0, stat_maxcell_max = 0;
     DevBuf<unsigned> scan_tmp;
     // scratch (grown on demand)
     DevBuf<unsigned> cnt, start, cursor, ord, minidx, firstidx, size, flags, pos, rootmin;

@@ -923,6 +923,12 @@ void CloudOps::bounds(const double* src, std::vector<SegDesc>& segs) {
         }
 }
 
+__global__ void k_db_maxcell(const unsigned* __restrict__ cnt, long long NC, unsigned* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned v = i < NC ? cnt[i] : 0u;
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
+    if ((threadIdx.x & 63) == 0 && v > 16u) atomicMax(out, v);
+}
 struct DbInit {
     unsigned *cnt, *cursor, *minidx, *firstidx, *rootmin, *size, *active;
     unsigned char* hasanchor;
@@ -1073,6 +1079,20 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     hipLaunchKernelGGL(k_db_cell, dim3(gN), dim3(256), 0, s, src, N, segid.p, K, dsegs, cellid.p, cnt.p, ga_dev,
                        const_cast<double*>(src));
     HMSG_CHECK_LAUNCH();
+    {   // development: the fullest cell of the batch (HMSG_DEBUG_MAXCELL=1; its points are same-address atomics in k_db_cell / k_db_fill)
+        static const bool want = getenv("HMSG_DEBUG_MAXCELL") != nullptr;
+        if (want) {
+            static DevBuf<unsigned> mx;
+            mx.ensure(1);
+            HIP_TRY(hipMemsetAsync(mx.p, 0, 4, s));
+            hipLaunchKernelGGL(k_db_maxcell, dim3(cdiv(NC, 256)), dim3(256), 0, s, (const unsigned*)cnt.p, NC, mx.p);
+            unsigned hm = 0;
+            HIP_TRY(hipMemcpyAsync(&hm, mx.p, 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            stat_maxcell_sum += hm;
+            stat_maxcell_max = std::max(stat_maxcell_max, (double)hm);
+        }
+    }
     hmsg_scan_u32(cnt.p, start.p, (size_t)NC + 1, s, scan_tmp, nullptr);   // start[NC] = N (end sentinel)
     spts.ensure((size_t)N * 3);
     score.ensure(N);

@@ -1090,6 +1090,8 @@ static void merge_report(Folder& m) {
         fprintf(stderr, "[hmsg merge] dbscan batches %.0f: mean points %.0f  grid cells %.0f  core cells %.0f  active cells %.0f\n",
                 m.ops.stat_calls, m.ops.stat_points / m.ops.stat_calls, m.ops.stat_cells / m.ops.stat_calls,
                 m.ops.stat_core_cells / m.ops.stat_calls, m.ops.stat_active_cells / m.ops.stat_calls);
+    if (getenv("HMSG_DEBUG_MAXCELL") && m.ops.stat_calls > 0)
+        fprintf(stderr, "[hmsg merge] fullest cell of a dbscan batch: mean %.0f points, max %.0f\n", m.ops.stat_maxcell_sum / m.ops.stat_calls, m.ops.stat_maxcell_max);
 }
 
 // ---- The sequential fold (graph_utils.py:1015-1038) as a RESUMABLE object: frames are handed in as their 3-D masks
