@@ -36,9 +36,19 @@ __device__ __forceinline__ double dist2_f64(const double* __restrict__ a, const 
     return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
 }
 
+#define DBC_LDS 512
 __global__ void k_db_cell(const double* __restrict__ pts, long long N, int* __restrict__ segid, int K,
                           const DbSeg* __restrict__ segs, long long* __restrict__ cellid, unsigned* __restrict__ cnt,
                           DbGather ga, double* __restrict__ pts_out) {
+    // the two binary searches below are chains of dependent loads (6 + 4 round trips per point when they go to L2): the keys they
+    // search -- first batch position of every piece / of every segment -- come into LDS once per workgroup
+    __shared__ long long s_dst[DBC_LDS], s_base[DBC_LDS];
+    const bool lds_g = ga.segs && ga.nsegs <= DBC_LDS, lds_s = K <= DBC_LDS;
+    if (lds_g)
+        for (int q = threadIdx.x; q < ga.nsegs; q += blockDim.x) s_dst[q] = ga.segs[q].dst;
+    if (lds_s)
+        for (int q = threadIdx.x; q < K; q += blockDim.x) s_base[q] = segs[q].pt_base;
+    __syncthreads();
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     double px, py, pz;
@@ -46,7 +56,7 @@ __global__ void k_db_cell(const double* __restrict__ pts, long long N, int* __re
         int a = 0, b = ga.nsegs - 1;
         while (a < b) {
             const int mid = (a + b + 1) >> 1;
-            if (ga.segs[mid].dst <= i) a = mid; else b = mid - 1;
+            if ((lds_g ? s_dst[mid] : ga.segs[mid].dst) <= i) a = mid; else b = mid - 1;
         }
         const CatSeg cs = ga.segs[a];
         const long long sp = cs.src + (i - cs.dst);
@@ -65,7 +75,7 @@ __global__ void k_db_cell(const double* __restrict__ pts, long long N, int* __re
     int lo = 0, hi = K - 1;                 // segment of the point (segments tile [0, N) in order)
     while (lo < hi) {
         int mid = (lo + hi + 1) >> 1;
-        if (segs[mid].pt_base <= i) lo = mid; else hi = mid - 1;
+        if ((lds_s ? s_base[mid] : segs[mid].pt_base) <= i) lo = mid; else hi = mid - 1;
     }
     segid[i] = lo;
     const DbSeg sg = segs[lo];
