@@ -216,6 +216,7 @@ struct CoarseGrid {
     int nx, ny, nz;                           // ny <= 64 (vertical)
     const unsigned* start;                    // [nx * nz * ny + 1], cell = (ix * nz + iz) * ny + iy
     const int* idx;                           // map point indices, cell by cell
+    const float* p32;                         // the same points as float32 (x, y, z), cell by cell: the pre-filter of k_room_nn
     const unsigned long long* col;            // [nx * nz] occupied iy bits
 };
 __device__ __forceinline__ void coarse_cell(const CoarseGrid& c, double x, double y, double z, int& ix, int& iy, int& iz) {
@@ -237,13 +238,17 @@ __global__ void k_coarse_count(const double* __restrict__ pts, const unsigned ch
     if (!(col[(size_t)ix * c.nz + iz] & bit)) atomicOr(&col[(size_t)ix * c.nz + iz], bit);
 }
 __global__ void k_coarse_fill(const double* __restrict__ pts, const unsigned char* __restrict__ ok, long long V, CoarseGrid c, unsigned* __restrict__ cursor,
-                              int* __restrict__ idx) {
+                              int* __restrict__ idx, float* __restrict__ p32) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= V || !ok[i]) return;
     int ix, iy, iz;
     coarse_cell(c, pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2], ix, iy, iz);
     const size_t cell = ((size_t)ix * c.nz + iz) * c.ny + iy;
-    idx[c.start[cell] + atomicAdd(&cursor[cell], 1u)] = (int)i;      // (order inside a cell is irrelevant: minimum + tie COUNT)
+    const size_t k = c.start[cell] + atomicAdd(&cursor[cell], 1u);   // (order inside a cell is irrelevant: minimum + tie COUNT)
+    idx[k] = (int)i;
+    p32[k * 3] = (float)pts[i * 3];
+    p32[k * 3 + 1] = (float)pts[i * 3 + 1];
+    p32[k * 3 + 2] = (float)pts[i * 3 + 2];
 }
 __device__ inline int coarse_nn(const CoarseGrid& c, const double* __restrict__ pts, double qx, double qy, double qz, int* out_ntie) {
     int cx, cy, cz;
@@ -283,6 +288,14 @@ __device__ inline int coarse_nn(const CoarseGrid& c, const double* __restrict__ 
     *out_ntie = best.ntie;
     return best.idx;
 }
+// float32 bound for the pre-filter: everything within sqrt(d2) of the query has a float32 squared distance below this.  With
+// coordinates up to ~10^3 m a float32 coordinate is off by <= 6e-5 m, a difference by <= 1.2e-4, the squared distance of points
+// d apart by <= ~2 d 2.1e-4 + 1.4e-7 plus the float32 rounding of the sum (relative 2e-7): margin 1e-3 (d + 1) + 1e-6 d2, generous.
+__device__ __forceinline__ float best_bound(double d2) {
+    if (d2 > 1e30) return 3.0e38f;
+    const double d = sqrt(d2);
+    return (float)(d2 + 1e-3 * (d + 1.0) + 1e-6 * d2);
+}
 // One WAVE per (x, z) cell of a room's region, one LANE per extrusion level: the 60-odd queries of a cell lie on one line (the
 // storey's height), their nearest neighbours are found by ONE ring traversal of the coarse grid around the box that holds the
 // line -- every lane measures every candidate against its own query (the candidate's load is wave-uniform).  A thread per
@@ -321,6 +334,8 @@ __global__ void __launch_bounds__(256) k_room_nn(CoarseGrid C, const double* __r
             bz0 = min(bz0, __shfl_xor(bz0, o)); bz1 = max(bz1, __shfl_xor(bz1, o));
         }
         NNBest best{1e300, -1, 0};
+        const float qxf = (float)px, qyf = (float)py, qzf = (float)pz;
+        float bestf = 3.0e38f;
         const int rmax = max(C.nx, max(C.ny, C.nz));
         for (int rr = 0; rr <= rmax; ++rr) {
             const int y0 = max(by0 - rr, 0), y1 = min(by1 + rr, C.ny - 1);
@@ -337,8 +352,20 @@ __global__ void __launch_bounds__(256) k_room_nn(CoarseGrid C, const double* __r
                         m &= m - 1ull;
                         const size_t cc = ((size_t)ix * C.nz + iz) * C.ny + iy;
                         for (unsigned k = C.start[cc]; k < C.start[cc + 1]; ++k) {
-                            const int q = C.idx[k];
-                            nn_consider(best, q, nn_dist2(map_pts + (size_t)q * 3, px, py, pz));
+                            // float32 pre-filter (the float64 vector rate is what this kernel is bound by: ~7 000 candidates per
+                            // cell line x 64 lanes): a candidate whose float32 distance exceeds the lane's best by more than the
+                            // float32 error of coordinates of a few hundred metres cannot win or tie -- the exact float64 form
+                            // (scipy's operation order) is evaluated only for the few that pass
+                            const float fx = __fsub_rn(C.p32[(size_t)k * 3], qxf), fy = __fsub_rn(C.p32[(size_t)k * 3 + 1], qyf),
+                                        fz = __fsub_rn(C.p32[(size_t)k * 3 + 2], qzf);
+                            const float f2 = fx * fx + fy * fy + fz * fz;
+                            if (__any(f2 <= bestf)) {
+                                const int q = C.idx[k];
+                                if (f2 <= bestf) {
+                                    nn_consider(best, q, nn_dist2(map_pts + (size_t)q * 3, px, py, pz));
+                                    bestf = best_bound(best.d2);
+                                }
+                            }
                         }
                     }
                 }
@@ -471,22 +498,25 @@ extern "C" int hmsg_room_clouds(hmsg_t* h, double y_lo, double y_hi, const doubl
         HMSG_REQUIRE(ncc < ((size_t)1 << 31), HMSG_ERR_UNSUPPORTED, "hmsg_room_clouds: map extent too large for the coarse grid");
         DevBuf<unsigned> ccnt, cstart, ccur;
         DevBuf<int> cidx;
+        DevBuf<float> cp32;
         DevBuf<unsigned long long> ccol;
         ccnt.alloc(ncc + 1);
         cstart.alloc(ncc + 1);
         ccur.alloc(ncc + 1);
         cidx.alloc((size_t)NF);
+        cp32.alloc((size_t)NF * 3);
         ccol.alloc((size_t)C.nx * C.nz);
         HIP_TRY(hipMemsetAsync(ccnt.p, 0, (ncc + 1) * 4, s));
         HIP_TRY(hipMemsetAsync(ccur.p, 0, (ncc + 1) * 4, s));
         HIP_TRY(hipMemsetAsync(ccol.p, 0, (size_t)C.nx * C.nz * 8, s));
         C.start = cstart.p;
         C.idx = cidx.p;
+        C.p32 = cp32.p;
         C.col = ccol.p;
         hipLaunchKernelGGL(k_coarse_count, dim3(cdiv((size_t)V, 256)), dim3(256), 0, s, (const double*)h->pts.p, (const unsigned char*)ok.p, V, C, ccnt.p, ccol.p);
         HMSG_CHECK_LAUNCH();
         hmsg_scan_u32(ccnt.p, cstart.p, ncc + 1, s, h->scan_tmp, nullptr);
-        hipLaunchKernelGGL(k_coarse_fill, dim3(cdiv((size_t)V, 256)), dim3(256), 0, s, (const double*)h->pts.p, (const unsigned char*)ok.p, V, C, ccur.p, cidx.p);
+        hipLaunchKernelGGL(k_coarse_fill, dim3(cdiv((size_t)V, 256)), dim3(256), 0, s, (const double*)h->pts.p, (const unsigned char*)ok.p, V, C, ccur.p, cidx.p, cp32.p);
         HMSG_CHECK_LAUNCH();
         const long long nq = cells * n_levels;
         hipLaunchKernelGGL(k_room_nn, dim3(cdiv((size_t)cells * 64, 256)), dim3(256), 0, s, C, (const double*)h->pts.p, (const unsigned*)frank.p, NF,
