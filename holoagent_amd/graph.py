@@ -935,8 +935,13 @@ class Graph:
         import threading
         if self.floors or getattr(self, "_room_level", None) is not None:
             return
+        import time
+        t0 = time.perf_counter()
         self.segment_floors_manually(None)
+        t1 = time.perf_counter()
         ctxs = [self._rooms_prepare(fl) for fl in self.floors]
+        if os.environ.get("HMSG_DEBUG_TIMING"):
+            print("[hmsg rooms] floors %.1f ms, room level prepared in %.1f ms" % ((t1 - t0) * 1e3, (time.perf_counter() - t1) * 1e3), file=sys.stderr)
         box = dict(ctxs=ctxs, err=None)
 
         def work():
