@@ -88,7 +88,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2,
+                    help="untimed steps (2: the library's per-thread device allocator cache settles over the first two scenes -- a "
+                         "service that builds scene after scene runs in that state)")
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--queries", type=int, default=1000)
     ap.add_argument("--feat-dim", type=int, default=512)
