@@ -882,6 +882,121 @@ __global__ void k_db_scatter(const double* __restrict__ pts, long long N, const 
     }
 }
 
+
+// k_db_flags + the scan + k_db_scatter as ONE launch (decoupled look-back over the blocks' kept counts).  Every block owns a
+// contiguous chunk of the batch: trip by trip it decides its points (bit `trip` of a register per thread), the block's count
+// goes through the look-back table, and a second walk over the same chunk writes the kept points behind the block's prefix.
+// Whether a segment loses points at all -- its box then has to be re-reduced -- needs no flag from another block: the winning
+// cluster's size IS the number of kept points (k_db_rootmin counted its core members per cell, k_db_label its border points).
+// A segment's output count comes from the positions of its first and last point (ostart / oend; the host subtracts).
+#define DBK_TRIPS 32
+__global__ void __launch_bounds__(256) k_db_compact(const double* __restrict__ pts, long long N, const int* __restrict__ segid,
+                                                    const DbSeg* __restrict__ segs, const int* __restrict__ label,
+                                                    const unsigned long long* __restrict__ best, unsigned* __restrict__ flags_dbg,
+                                                    const unsigned char* __restrict__ core, const long long* __restrict__ cellid,
+                                                    const int* __restrict__ parent, double* __restrict__ dst, int* __restrict__ oend,
+                                                    int* __restrict__ ostart, unsigned char* __restrict__ dst_core,
+                                                    unsigned long long* __restrict__ obounds, unsigned long long* __restrict__ state,
+                                                    unsigned epoch) {
+    __shared__ int slot_seg;
+    __shared__ unsigned long long slot_box[6];
+    __shared__ unsigned wsum[4], wtot[2][4];
+    __shared__ unsigned s_prefix;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) slot_seg = -1;
+    if (tid < 6) slot_box[tid] = tid < 3 ? ~0ull : 0ull;
+    const long long per_block = ((N + (long long)gridDim.x * blockDim.x - 1) / ((long long)gridDim.x * blockDim.x)) * blockDim.x;
+    const long long b0 = (long long)blockIdx.x * per_block, b1 = b0 + per_block < N ? b0 + per_block : N;
+    unsigned mine = 0u, kept = 0u;
+    int trip = 0;
+    for (long long base = b0; base < b1; base += blockDim.x, ++trip) {
+        const long long i = base + tid;
+        if (i >= b1) continue;
+        const int k = segid[i];
+        const unsigned long long b = best[k];
+        bool keep = true;                                    // graph_utils.py:853-880 (see k_db_flags)
+        if ((unsigned)(b >> 32) >= 5u) {
+            const long long fm = segs[k].pt_base + (long long)(INF32 - (unsigned)(b & 0xffffffffull));
+            const int wl = core[fm] ? parent[cellid[fm]] : label[fm];
+            const int my = core[i] ? parent[cellid[i]] : label[i];
+            keep = my == wl;
+        }
+        if (flags_dbg) flags_dbg[i] = keep ? 1u : 0u;
+        if (keep) {
+            mine |= 1u << trip;
+            ++kept;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o);
+    if (lane == 0) wsum[w] = kept;
+    __syncthreads();
+    if (w == 0) {
+        const unsigned prefix = scan_lookback_prefix(state, blockIdx.x, epoch, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+        if (lane == 0) s_prefix = prefix;
+    }
+    __syncthreads();
+    unsigned running = s_prefix;                             // block-uniform: output slot of the trip's first kept point
+    int cur = -1;                                            // segment of the running box
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    trip = 0;
+    for (long long base = b0; base < b1; base += blockDim.x, ++trip) {      // block-uniform trip count
+        const long long i = base + tid;
+        const bool in_range = i < b1;
+        unsigned f = in_range ? (mine >> trip) & 1u : 0u;
+        const unsigned long long m = __ballot(f != 0u);
+        if (lane == 0) wtot[trip & 1][w] = (unsigned)__popcll(m);
+        __syncthreads();                                     // (the other buffer is rewritten only after the next trip's barrier)
+        unsigned woff = 0u, tot = 0u;
+        for (int q = 0; q < 4; ++q) {
+            const unsigned t = wtot[trip & 1][q];
+            woff += q < w ? t : 0u;
+            tot += t;
+        }
+        const unsigned p = running + woff + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        running += tot;
+        int k = cur;
+        double v[3] = {0, 0, 0};
+        bool drops = false;
+        if (in_range) {
+            k = segid[i];
+            const DbSeg sg = segs[k];
+            if (f) {
+                for (int a = 0; a < 3; ++a) {
+                    v[a] = pts[i * 3 + a];
+                    dst[(size_t)p * 3 + a] = v[a];
+                }
+                if (dst_core) dst_core[p] = core[i];
+            }
+            if (i == sg.pt_base) ostart[k] = (int)p;
+            if (i == sg.pt_base + sg.n - 1) oend[k] = (int)(p + f);
+            const unsigned win = (unsigned)(best[k] >> 32);
+            drops = win >= 5u && win < (unsigned)sg.n;
+        }
+        if (f && !drops) f = 0u;                                    // segment keeps every point: its input box stays exact
+        if (__any(f != 0u && cur >= 0 && k != cur)) {               // somebody leaves its segment: flush all
+            db_flush_boxes(cur >= 0, cur, mn, mx, obounds, &slot_seg, slot_box);
+            cur = -1;
+            for (int a = 0; a < 3; ++a) {
+                mn[a] = 1e300;
+                mx[a] = -1e300;
+            }
+        }
+        if (f) {
+            cur = k;
+            for (int a = 0; a < 3; ++a) {
+                mn[a] = v[a] < mn[a] ? v[a] : mn[a];
+                mx[a] = v[a] > mx[a] ? v[a] : mx[a];
+            }
+        }
+    }
+    db_flush_boxes(cur >= 0, cur, mn, mx, obounds, &slot_seg, slot_box);
+    __syncthreads();
+    if (tid < 6 && slot_seg >= 0) {
+        if (tid < 3) atomicMin(&obounds[(size_t)slot_seg * 6 + tid], slot_box[tid]);
+        else atomicMax(&obounds[(size_t)slot_seg * 6 + tid], slot_box[tid]);
+    }
+}
+
 struct BdSeg {
     long long pt_base;
     int n, pad;
@@ -946,7 +1061,7 @@ struct DbInit {
     unsigned *cnt, *cursor, *minidx, *firstidx, *rootmin, *size, *active;
     unsigned char* hasanchor;
     unsigned long long* best;
-    int* ocount;
+    int *ocount, *ostart;
     unsigned long long* obounds;
     unsigned *ncl, *rep, *contested, *dropped, *counters;
     long long NC;
@@ -968,6 +1083,7 @@ __global__ void k_db_init(DbInit in) {
         in.best[i] = 0ull;
         for (int a = 0; a < 6; ++a) in.obounds[(size_t)i * 6 + a] = a < 3 ? ~0ull : 0ull;
         in.ocount[i] = 0;
+        in.ostart[i] = 0;
         in.ncl[i] = 0u;
         in.rep[i] = INF32;
         in.contested[i] = 0u;
@@ -1063,12 +1179,13 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     rootmin.ensure(NC);
     best.ensure(K);
     rep.ensure(K);
-    kres.ensure((size_t)K * 16 + 4);            // per segment: n_out | n_clusters | contested | dropped | 6 x u64 box
+    kres.ensure((size_t)K * 17 + 4);            // per segment: n_out (or output end) | n_clusters | contested | dropped | 6 x u64 box; 4 counters; per segment: output start
     int* const d_ocount = (int*)kres.p;
     unsigned* const d_ncl = kres.p + K;
     unsigned* const d_contested = kres.p + 2 * (size_t)K;
     unsigned* const d_dropped = kres.p + 3 * (size_t)K;
     unsigned long long* const d_obounds = (unsigned long long*)(kres.p + 4 * (size_t)K);
+    int* const d_ostart = (int*)(kres.p + (size_t)K * 16 + 4);
     active.ensure(NC); hasanchor.ensure(NC);
     corelist.ensure((size_t)std::max<long long>(N, 1));
     actlist.ensure((size_t)std::max<long long>(N, 1));
@@ -1082,7 +1199,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
         DbInit in;
         in.cnt = cnt.p; in.cursor = cursor.p; in.minidx = minidx.p; in.firstidx = firstidx.p; in.rootmin = rootmin.p;
         in.size = size.p; in.active = active.p; in.hasanchor = hasanchor.p;
-        in.best = best.p; in.obounds = d_obounds; in.ocount = d_ocount; in.ncl = d_ncl; in.rep = rep.p; in.contested = d_contested; in.dropped = d_dropped;
+        in.best = best.p; in.obounds = d_obounds; in.ocount = d_ocount; in.ostart = d_ostart; in.ncl = d_ncl; in.rep = rep.p; in.contested = d_contested; in.dropped = d_dropped;
         in.counters = kres.p + (size_t)K * 16;   // [0] core cells, [1] active core cells
         in.NC = NC; in.K = K;
         hipLaunchKernelGGL(k_db_init, dim3(cdiv(NC + 1, 256)), dim3(256), 0, s, in);
@@ -1166,6 +1283,10 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     }
     hipLaunchKernelGGL(k_db_pick, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc, (const int*)cseg.p, dsegs, K,
                        (const unsigned*)size.p, (const unsigned*)firstidx.p, (const unsigned*)rootmin.p, best.p);
+    // HMSG_DB_COMPACT_SPLIT=1: flags, scan and scatter as three launches (the form before round 4; kept for comparison runs)
+    static const bool split_compact = getenv("HMSG_DB_COMPACT_SPLIT") != nullptr;
+    static const bool dump_wanted = getenv("HMSG_DEBUG_DUMP") != nullptr;
+    if (split_compact) {
     hipLaunchKernelGGL(k_db_flags, dim3(gN), dim3(256), 0, s, N, (const int*)segid.p, dsegs, (const int*)label.p,
                        (const unsigned long long*)best.p, flags.p, d_dropped, (const unsigned char*)core.p,
                        (const long long*)cellid.p, (const int*)parent.p);
@@ -1175,6 +1296,16 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     ProfScope ps(prof, s, "k_db_scatter", (double)N * 56.0);
     hipLaunchKernelGGL(k_db_scatter, dim3(std::min(gN, (unsigned)n_cu)), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const unsigned*)flags.p,
                        (const unsigned*)pos.p, dst, d_ocount, (const unsigned char*)core.p, dst_core, d_obounds, (const unsigned*)d_dropped);
+    }
+    } else {
+        // one block per CU while a thread's keep bits fit a register (DBK_TRIPS trips of 256 points), more blocks beyond
+        const unsigned gK = std::max(std::min(gN, (unsigned)n_cu), cdiv(N, 256ll * DBK_TRIPS));
+        const unsigned epoch = hmsg_scan_epoch(scan_tmp, gK, s);
+        ProfScope ps(prof, s, "k_db_scatter", (double)N * 56.0);
+        hipLaunchKernelGGL(k_db_compact, dim3(gK), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const int*)label.p,
+                           (const unsigned long long*)best.p, dump_wanted ? flags.p : (unsigned*)nullptr, (const unsigned char*)core.p,
+                           (const long long*)cellid.p, (const int*)parent.p, dst, d_ocount, d_ostart, dst_core, d_obounds,
+                           reinterpret_cast<unsigned long long*>(scan_tmp.p), epoch);
     }
     HMSG_CHECK_LAUNCH();
     {   // debug: HMSG_DEBUG_DBCALL=<n> dumps the n-th batch (inputs + per-point results) under HMSG_DEBUG_DUMP
@@ -1194,7 +1325,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
         ++call_no;
     }
     // one copy brings back counts, cluster counts, contest flags and the boxes of the kept points
-    pub.launch(s, (const unsigned*)kres.p, (size_t)K * 16 + 2);
+    pub.launch(s, (const unsigned*)kres.p, (size_t)K * 17 + 4);
     pub.wait();
     const unsigned* hres = pub.data();
     const unsigned long long* hb = reinterpret_cast<const unsigned long long*>(hres + (size_t)K * 4);
@@ -1205,7 +1336,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     stat_active_cells += hres[(size_t)K * 16 + 1];
     long long total = 0;
     for (int k = 0; k < K; ++k) {
-        const int n_out = (int)hres[k];
+        const int n_out = (int)hres[k] - (split_compact ? 0 : (int)hres[(size_t)K * 16 + 4 + k]);      // (one launch: output end - output start)
         res[k].n_out = n_out;
         res[k].changed = n_out != segs[k].n;
         res[k].n_clusters = (int)hres[(size_t)K + k];

@@ -593,6 +593,49 @@ struct hmsg_ctx {
     DevBuf<unsigned> scan_tmp;
 };
 
+// Decoupled look-back over a table of 64-bit status words {epoch:30 | flag:2 | value:32} (flag 1: the tile's aggregate, 2: its
+// inclusive prefix).  Words carry the epoch of the call, so the table is never cleared (a stale word reads as "not ready").
+// Tiles are numbered by blockIdx: workgroups are dispatched in index order, so every predecessor of a resident tile is
+// resident or finished and the spin cannot starve it.  Called by ONE whole wave of the tile with the tile's aggregate:
+// publishes it, looks back over the predecessors 64 at a time until it meets a published prefix, publishes the tile's
+// inclusive prefix and returns the exclusive one (in every lane).
+__device__ __forceinline__ unsigned long long scan_pack(unsigned epoch, unsigned flag, unsigned value) {
+    return ((unsigned long long)((epoch << 2) | flag) << 32) | (unsigned long long)value;
+}
+__device__ __forceinline__ unsigned scan_lookback_prefix(unsigned long long* __restrict__ state, long long tile, unsigned epoch,
+                                                         unsigned agg) {
+    const int lane = threadIdx.x & 63;
+    if (lane == 0)
+        __hip_atomic_store(&state[tile], scan_pack(epoch, tile == 0 ? 2u : 1u, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned prefix = 0;
+    if (tile > 0) {
+        long long hi = tile - 1;                       // the window is tiles hi, hi-1, ..., hi-63
+        for (;;) {
+            const long long idx = hi - lane;
+            unsigned long long sw = scan_pack(epoch, 2u, 0u);        // before tile 0: prefix 0
+            if (idx >= 0) sw = __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned tag = (unsigned)(sw >> 32);
+            const unsigned flag = (tag >> 2) == (epoch & 0x3fffffffu) ? (tag & 3u) : 0u;
+            const unsigned long long has_prefix = __ballot(flag == 2u), not_ready = __ballot(flag == 0u);
+            unsigned long long take = ~0ull;                          // lanes whose value is added
+            if (has_prefix) {
+                const int first = __ffsll(has_prefix) - 1;            // nearest published prefix
+                take = first == 63 ? ~0ull : ((1ull << (first + 1)) - 1ull);
+            }
+            if (not_ready & take) continue;                           // a needed predecessor is not there yet
+            unsigned part = ((take >> lane) & 1ull) ? (unsigned)sw : 0u;
+            for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+            prefix += part;
+            if (has_prefix) break;
+            hi -= 64;
+        }
+        if (lane == 0)
+            __hip_atomic_store(&state[tile], scan_pack(epoch, 2u, prefix + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return prefix;
+}
+// a fresh epoch for a look-back over `ntiles` tiles of the status table `tmp` (grown, and cleared when it is fresh memory)
+unsigned hmsg_scan_epoch(DevBuf<unsigned>& tmp, size_t ntiles, hipStream_t s);
 // exclusive prefix sum of u32 (returns total via host sync when `total` != nullptr)
 void hmsg_scan_u32(const unsigned* in, unsigned* out, size_t n, hipStream_t s, DevBuf<unsigned>& tmp,
                    unsigned long long* total);

@@ -24,9 +24,6 @@
 // epoch of the scan call, so the status table is never cleared (a stale word reads as "not ready").  Tiles are
 // numbered by blockIdx: workgroups are dispatched in index order, so every predecessor of a resident tile is
 // resident or finished and the spin cannot starve it.
-__device__ __forceinline__ unsigned long long scan_pack(unsigned epoch, unsigned flag, unsigned value) {
-    return ((unsigned long long)((epoch << 2) | flag) << 32) | (unsigned long long)value;
-}
 __global__ void k_scan_lookback(const unsigned* __restrict__ in, unsigned* __restrict__ out, size_t n,
                                 unsigned long long* __restrict__ state, unsigned epoch) {
     __shared__ unsigned wsum[4];
@@ -51,33 +48,7 @@ __global__ void k_scan_lookback(const unsigned* __restrict__ in, unsigned* __res
     for (int i = 0; i < w; ++i) woff += wsum[i];
     const unsigned agg = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     if (w == 0) {
-        if (lane == 0)
-            __hip_atomic_store(&state[tile], scan_pack(epoch, tile == 0 ? 2u : 1u, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned prefix = 0;
-        if (tile > 0) {
-            long long hi = tile - 1;                       // the window is tiles hi, hi-1, ..., hi-63
-            for (;;) {
-                const long long idx = hi - lane;
-                unsigned long long sw = scan_pack(epoch, 2u, 0u);        // before tile 0: prefix 0
-                if (idx >= 0) sw = __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned tag = (unsigned)(sw >> 32);
-                const unsigned flag = (tag >> 2) == (epoch & 0x3fffffffu) ? (tag & 3u) : 0u;
-                const unsigned long long has_prefix = __ballot(flag == 2u), not_ready = __ballot(flag == 0u);
-                unsigned long long take = ~0ull;                          // lanes whose value is added
-                if (has_prefix) {
-                    const int first = __ffsll(has_prefix) - 1;            // nearest published prefix
-                    take = first == 63 ? ~0ull : ((1ull << (first + 1)) - 1ull);
-                }
-                if (not_ready & take) continue;                           // a needed predecessor is not there yet
-                unsigned part = ((take >> lane) & 1ull) ? (unsigned)sw : 0u;
-                for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-                prefix += part;
-                if (has_prefix) break;
-                hi -= 64;
-            }
-            if (lane == 0)
-                __hip_atomic_store(&state[tile], scan_pack(epoch, 2u, prefix + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        const unsigned prefix = scan_lookback_prefix(state, tile, epoch, agg);
         if (lane == 0) s_prefix = prefix;
     }
     __syncthreads();
@@ -88,19 +59,24 @@ __global__ void k_scan_lookback(const unsigned* __restrict__ in, unsigned* __res
     }
 }
 
+unsigned hmsg_scan_epoch(DevBuf<unsigned>& tmp, size_t ntiles, hipStream_t s) {
+    static std::atomic<unsigned> g_epoch{0};
+    const unsigned epoch = (g_epoch.fetch_add(1) + 1u) & 0x3fffffffu;
+    if (tmp.n < ntiles * 2 + 64) {                        // (status words are u64: two u32 slots each)
+        tmp.ensure(ntiles * 2 + 64);
+        HIP_TRY(hipMemsetAsync(tmp.p, 0, tmp.n * 4, s));  // fresh memory: no word may look like a current epoch
+    }
+    return epoch;
+}
+
 void hmsg_scan_u32(const unsigned* in, unsigned* out, size_t n, hipStream_t s, DevBuf<unsigned>& tmp,
                    unsigned long long* total) {
     if (n == 0) {
         if (total) *total = 0;
         return;
     }
-    static std::atomic<unsigned> g_epoch{0};
-    const unsigned epoch = (g_epoch.fetch_add(1) + 1u) & 0x3fffffffu;
     const size_t ntiles = (n + 1023) / 1024;
-    if (tmp.n < ntiles * 2 + 64) {                        // (status words are u64: two u32 slots each)
-        tmp.ensure(ntiles * 2 + 64);
-        HIP_TRY(hipMemsetAsync(tmp.p, 0, tmp.n * 4, s));  // fresh memory: no word may look like a current epoch
-    }
+    const unsigned epoch = hmsg_scan_epoch(tmp, ntiles, s);
     unsigned last_in = 0, last_out = 0;
     if (total) HIP_TRY(hipMemcpyAsync(&last_in, in + n - 1, 4, hipMemcpyDeviceToHost, s));
     hipLaunchKernelGGL(k_scan_lookback, dim3((unsigned)ntiles), dim3(256), 0, s, in, out, n,
