@@ -380,6 +380,14 @@ __device__ __forceinline__ int uf_find_cached(const int* parent, int x) {
     }
     return x;
 }
+// read-only walk with agent-scope loads (sees every union that has landed in L2, stores nothing)
+__device__ __forceinline__ int uf_find_ro(const int* parent, int x) {
+    for (;;) {
+        const int p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p == x) return x;
+        x = p;
+    }
+}
 // (Hanging the start cell directly under what the walk found -- path compression by plain stores -- was measured: k_db_union
 //  37.5 -> 40.2 us per fold step.  The walks are short; the pass is bound by its ~250 scattered cache-line requests per cell.)
 // Which of two roots stays a root is a fixed total order over the cells (concurrent CASes cannot close a cycle): cells that
@@ -549,43 +557,69 @@ __global__ void k_db_union_scan(const double* __restrict__ pts, const int* __res
         int ix, iy, iz;
         cell_xyz(sg, c, ix, iy, iz);
         const unsigned s0 = start[c], e0 = s0 + cnt[c];
-        const double* ba = cellbox + (size_t)cellpos[c] * 6;
-        // Chebyshev distance 1 first (they connect most components), then distance 2
+        double ba[6];
+        for (int a = 0; a < 6; ++a) ba[a] = cellbox[(size_t)cellpos[c] * 6 + a];
+        const int rc = uf_find_cached(parent, (int)c);
+        // phase A, once for all 124 neighbour cells (the lane's two, o = lane and lane + 64, side by side as in k_db_union: table
+        // entries, boxes and root walks are independent chains of L2 round trips): does the pair need a point scan at all?
+        // (Four trips through this chain -- one per Chebyshev distance and half of the neighbourhood -- were most of the kernel.)
+        long long c2[2];
+        bool ok[2];
+        int chb[2];
+        unsigned mi[2] = {INF32, INF32}, ac[2] = {0u, 0u};
+        int p2[2] = {0, 0}, cp2[2] = {0, 0};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int o = lane + 64 * q;
+            const int dx = o / 25 - 2, dy = (o / 5) % 5 - 2, dz = o % 5 - 2;
+            chb[q] = max(abs(dx), max(abs(dy), abs(dz)));
+            const int jx = ix + dx, jy = iy + dy, jz = iz + dz;
+            ok[q] = o < 125 && o != 62 && jx >= 0 && jy >= 0 && jz >= 0 && jx < sg.nx && jy < sg.ny && jz < sg.nz;
+            c2[q] = ok[q] ? sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz + jz : c;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (ok[q]) {
+                mi[q] = minidx[c2[q]];
+                ac[q] = active[c2[q]];
+                p2[q] = parent[c2[q]];
+                cp2[q] = cellpos[c2[q]];         // (garbage unless c2 is a core cell; not used then)
+            }
+        double bq[2][6];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            ok[q] = ok[q] && mi[q] != INF32 && (c2[q] > c || !ac[q]);
+            if (ok[q])
+                for (int a = 0; a < 6; ++a) bq[q][a] = cellbox[(size_t)cp2[q] * 6 + a];
+        }
+        bool need[2] = {false, false};
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (ok[q] && uf_find_cached(parent, p2[q]) != rc) {
+                double mn2 = 0.0, mx2 = 0.0;
+                for (int a = 0; a < 3; ++a) {
+                    double gap = fmax(0.0, fmax(ba[a] - bq[q][3 + a], bq[q][a] - ba[3 + a]));
+                    double far = fmax(ba[3 + a] - bq[q][a], bq[q][3 + a] - ba[a]);
+                    mn2 += gap * gap;
+                    mx2 += far * far;
+                }
+                // (mx2 < eps2: decided by the box pass; mn2 >= eps2: no witness possible)
+                need[q] = !(mx2 < eps2 * (1.0 - 1e-12)) && mn2 < eps2 * (1.0 + 1e-12);
+            }
+        // phase B: the whole wave scans the pairs that need it, one after the other -- Chebyshev distance 1 first (they connect
+        // most components), then distance 2; a pair that an earlier scan of this cell (or another wave) has connected meanwhile
+        // is dropped when its turn comes
         for (int pass = 1; pass <= 2; ++pass)
-        for (int round = 0; round < 2; ++round) {
-          // phase A: one lane per neighbour cell decides whether that pair needs a point scan at all
-          const int oo = round * 64 + lane;
-          bool need = false;
-          long long my_c2 = -1;
-          if (oo < 125) {
-              int dx = oo / 25 - 2, dy = (oo / 5) % 5 - 2, dz = oo % 5 - 2;
-              int cheb = max(abs(dx), max(abs(dy), abs(dz)));
-              int jx = ix + dx, jy = iy + dy, jz = iz + dz;
-              if (cheb == pass && jx >= 0 && jy >= 0 && jz >= 0 && jx < sg.nx && jy < sg.ny && jz < sg.nz) {
-                  long long cc = sg.cell_base + ((long long)jx * sg.ny + jy) * sg.nz + jz;
-                  if (minidx[cc] != INF32 && (cc > c || !active[cc]) && uf_find_cached(parent, (int)c) != uf_find_cached(parent, (int)cc)) {
-                      const double* bq = cellbox + (size_t)cellpos[cc] * 6;
-                      double mn2 = 0.0, mx2 = 0.0;
-                      for (int a = 0; a < 3; ++a) {
-                          double gap = fmax(0.0, fmax(ba[a] - bq[3 + a], bq[a] - ba[3 + a]));
-                          double far = fmax(ba[3 + a] - bq[a], bq[3 + a] - ba[a]);
-                          mn2 += gap * gap;
-                          mx2 += far * far;
-                      }
-                      // (mx2 < eps2: decided by the box pass; mn2 >= eps2: no witness possible)
-                      need = !(mx2 < eps2 * (1.0 - 1e-12)) && mn2 < eps2 * (1.0 + 1e-12);
-                      my_c2 = cc;
-                  }
-              }
-          }
-          unsigned long long todo = __ballot(need);
-          // phase B: the whole wave scans the pairs that need it, one after the other
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          unsigned long long todo = __ballot(need[q] && chb[q] == pass);
           while (todo) {
             const int src_lane = __ffsll(todo) - 1;
             todo &= todo - 1;
-            const long long c2 = __shfl(my_c2, src_lane);
-            const double* bb = cellbox + (size_t)cellpos[c2] * 6;
-            const unsigned s1 = start[c2], e1 = s1 + cnt[c2];
+            const long long c2s = __shfl(c2[q], src_lane);
+            if (uf_find_ro(parent, (int)c) == uf_find_ro(parent, (int)c2s)) continue;
+            const double* bb = cellbox + (size_t)cellpos[c2s] * 6;
+            const unsigned s1 = start[c2s], e1 = s1 + cnt[c2s];
             bool hit = false;
             for (unsigned a0 = s0; a0 < e0; a0 += 64) {
                 unsigned a = a0 + lane;
@@ -594,8 +628,8 @@ __global__ void k_db_union_scan(const double* __restrict__ pts, const int* __res
                     if (core[ia]) {
                         const double* pa = pts + (size_t)ia * 3;
                         double g2 = 0.0;                       // point-to-box lower bound
-                        for (int q = 0; q < 3; ++q) {
-                            double gq = fmax(0.0, fmax(bb[q] - pa[q], pa[q] - bb[3 + q]));
+                        for (int t = 0; t < 3; ++t) {
+                            double gq = fmax(0.0, fmax(bb[t] - pa[t], pa[t] - bb[3 + t]));
                             g2 += gq * gq;
                         }
                         if (g2 < eps2 * (1.0 + 1e-12))
@@ -613,7 +647,7 @@ __global__ void k_db_union_scan(const double* __restrict__ pts, const int* __res
                     break;
                 }
             }
-            if (hit && lane == 0) uf_union(parent, (int)c, (int)c2, hasanchor);
+            if (hit && lane == 0) uf_union(parent, (int)c, (int)c2s, hasanchor);
           }
         }
     }
