@@ -395,9 +395,12 @@ __device__ __forceinline__ int uf_find_ro(const int* parent, int x) {
 // (k_db_anchor, rooted at the lowest of them), so that root never moves and every active cell that joins the anchor's
 // cluster CASes its OWN parent word.  (With plain index order every active cell below the anchor's root took the root over
 // in turn, thousands of waves retrying on one word: two thirds of k_db_union's time.)
+__device__ __forceinline__ void uf_union_from(int* parent, int a, int b, const unsigned char* __restrict__ pri);
 __device__ __forceinline__ void uf_union(int* parent, int a, int b, const unsigned char* __restrict__ pri) {
-    a = uf_find_cached(parent, a);
-    b = uf_find_cached(parent, b);
+    uf_union_from(parent, uf_find_cached(parent, a), uf_find_cached(parent, b), pri);
+}
+// a, b: what cached walks from the two cells ended on (ancestors of them, roots unless stale)
+__device__ __forceinline__ void uf_union_from(int* parent, int a, int b, const unsigned char* __restrict__ pri) {
     for (;;) {
         if (a == b) return;
         const unsigned char pa = pri[a], pb = pri[b];
@@ -514,26 +517,40 @@ __global__ void k_db_union(const int* __restrict__ corecells, const unsigned* __
         // of those neighbours already share one root (the anchor's) -- 60 lanes then fail the same CAS on parent[c] and walk
         // the chain again with atomic loads, which was two thirds of this kernel's time.  One union per DISTINCT neighbour
         // root is enough: equal (even stale) roots prove two cells connected.
+        // The unions themselves are the expensive part (measured with them switched off: 16 of this kernel's 39 us are left):
+        // each is a chain of walk -> priority bytes -> look -> CAS round trips.  So the leaders are picked first (ballots only,
+        // a root that turns up in both halves of the neighbourhood once), then every leader runs its union AT THE SAME TIME,
+        // starting from the roots the wave has walked to already: one chain per wave, not one per distinct root.
+        bool want[2], lead[2] = {false, false};
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            bool want = false;
+            want[q] = false;
             if (ok[q] && r2[q] != rc) {
                 double mx2 = 0.0;
                 for (int a = 0; a < 3; ++a) {
                     double far = fmax(ba[3 + a] - bb[q][a], bb[q][3 + a] - ba[a]);
                     mx2 += far * far;
                 }
-                want = mx2 < eps2 * (1.0 - 1e-12);
-            }
-            unsigned long long todo = __ballot(want);
-            while (todo) {
-                const int leader = __ffsll(todo) - 1;
-                const int key = __shfl(r2[q], leader);
-                const unsigned long long same = __ballot(want && r2[q] == key);
-                if (lane == leader) uf_union(parent, (int)c, (int)c2[q], hasanchor);
-                todo &= ~same;
+                want[q] = mx2 < eps2 * (1.0 - 1e-12);
             }
         }
+        unsigned long long todo = __ballot(want[0]);
+        while (todo) {
+            const int leader = __ffsll(todo) - 1;
+            const int key = __shfl(r2[0], leader);
+            if (lane == leader) lead[0] = true;
+            todo &= ~__ballot(want[0] && r2[0] == key);
+            want[1] = want[1] && r2[1] != key;
+        }
+        todo = __ballot(want[1]);
+        while (todo) {
+            const int leader = __ffsll(todo) - 1;
+            const int key = __shfl(r2[1], leader);
+            if (lane == leader) lead[1] = true;
+            todo &= ~__ballot(want[1] && r2[1] == key);
+        }
+        if (lead[0] || lead[1]) uf_union_from(parent, rc, lead[0] ? r2[0] : r2[1], hasanchor);
+        if (lead[0] && lead[1]) uf_union_from(parent, rc, r2[1], hasanchor);
     }
 }
 

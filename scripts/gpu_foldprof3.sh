@@ -5,7 +5,7 @@ set -u
 OUT=/root/repo/gpurun_out/${1:-foldprof3}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for mode in split fused; do
+for mode in ${MODES:-split fused}; do
   rm -rf /tmp/prof_$mode
   if [ $mode = split ]; then export HMSG_DB_COMPACT_SPLIT=1; else unset HMSG_DB_COMPACT_SPLIT; fi
   HMSG_DEBUG_TIMING=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$mode -- python /root/repo/bench.py --rooms-handed-in --steps 1 --warmup 0 --cpu-frames 0 --inflight-steps 0 --encoder-frames 0 --no-extras > $OUT/bench_$mode.json 2> $OUT/bench_$mode.err
