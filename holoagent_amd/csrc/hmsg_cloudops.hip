@@ -356,21 +356,10 @@ __global__ void k_db_anchor(const int* __restrict__ corecells, const unsigned* _
     }
 }
 
-// parent[] is updated by CAS from other workgroups while we walk it: read it with agent-scope atomic loads
-// (served by L2, never by this CU's non-coherent L1) or a retry loop could spin on a stale line.
-__device__ __forceinline__ int uf_find(int* parent, int x) {
-    for (;;) {
-        int p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (p == x) return x;
-        int gp = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // path halving: any ancestor is a valid parent, so a racy store only shortens chains
-        if (gp != p) __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        x = p;
-    }
-}
+// (parent[] is updated by CAS from other workgroups while a kernel walks it.)
 // Cached variant: ordinary loads (may be served by this CU's L1, i.e. be STALE).  A stale parent is an older
 // ancestor, so whatever this returns is an ancestor of x: equal results for two cells still prove they are
-// connected; a stale "root" only makes the CAS in uf_union fail, which then retries with uf_find.
+// connected; a stale "root" is caught by the look in front of the CAS in uf_union_from.
 // (Thousands of lanes ending their walk on the one hot root word through the L2 was the bottleneck.)
 __device__ __forceinline__ int uf_find_cached(const int* parent, int x) {
     for (int hop = 0; hop < 64; ++hop) {
@@ -399,7 +388,14 @@ __device__ __forceinline__ void uf_union_from(int* parent, int a, int b, const u
 __device__ __forceinline__ void uf_union(int* parent, int a, int b, const unsigned char* __restrict__ pri) {
     uf_union_from(parent, uf_find_cached(parent, a), uf_find_cached(parent, b), pri);
 }
-// a, b: what cached walks from the two cells ended on (ancestors of them, roots unless stale)
+// a, b: what cached walks from the two cells ended on (ancestors of them, roots unless stale).
+// Every hook goes from a node to one that comes EARLIER in the fixed order (anchor cells first, then the lower index), so a
+// node's ancestors all come earlier than the node itself: hanging a root under ANY earlier node of the other set -- a root or
+// not -- cannot close a cycle.  That is what makes the failure path cheap.  Measured on configs[1]: three of four unions find
+// their `a` hooked already when they get there (every wave of a cluster hooks at the same time), and nearly always it was
+// hooked under the very node they were about to hang it under, or under an ancestor of it.  So: look at parent[a]; still a
+// root -> CAS; otherwise step to what it points to and go round again -- no second pair of walks from the bottom (they were
+// ~5 dependent loads per failure and half of k_db_union's time).
 __device__ __forceinline__ void uf_union_from(int* parent, int a, int b, const unsigned char* __restrict__ pri) {
     for (;;) {
         if (a == b) return;
@@ -408,14 +404,16 @@ __device__ __forceinline__ void uf_union_from(int* parent, int a, int b, const u
             int t = a;
             a = b;
             b = t;
-        }                                   // b stays a root: hang a under it
-        // `a` came from cached loads and may have been hooked by another wave long ago: a CAS on it then fails, and failing
-        // CASes are not free -- same-address atomics retire one per ~11 ns on this GPU (scripts/microbench/atom_bench.hip),
-        // and every active cell of a cluster that reaches the anchor tries the SAME root.  Atomic LOADS of one word by
-        // thousands of lanes cost nothing measurable: look first, CAS only a word that still is a root.
-        if (__hip_atomic_load(&parent[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a && atomicCAS(&parent[a], a, b) == a) return;
-        a = uf_find(parent, a);
-        b = uf_find(parent, b);
+        }                                   // b comes earlier: a (if it is a root) goes under it
+        // (a failing CAS is not free -- same-address atomics retire one per ~11 ns on this GPU, scripts/microbench/atom_bench.hip,
+        //  and every active cell of a cluster that reaches the anchor tries the SAME root -- while atomic LOADS of one word by
+        //  thousands of lanes cost nothing measurable: look first, CAS only a word that still is a root)
+        int up = __hip_atomic_load(&parent[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (up == a) {
+            up = atomicCAS(&parent[a], a, b);
+            if (up == a) return;
+        }
+        a = up;                             // a has a parent: the sets meet further up (or are one already: a == b next time round)
     }
 }
 
