@@ -356,7 +356,18 @@ __global__ void k_db_anchor(const int* __restrict__ corecells, const unsigned* _
     }
 }
 
-// (parent[] is updated by CAS from other workgroups while a kernel walks it.)
+// parent[] is updated by CAS from other workgroups while we walk it: read it with agent-scope atomic loads
+// (served by L2, never by this CU's non-coherent L1) or a retry loop could spin on a stale line.
+__device__ __forceinline__ int uf_find(int* parent, int x) {
+    for (;;) {
+        int p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p == x) return x;
+        int gp = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // path halving: any ancestor is a valid parent, so a racy store only shortens chains
+        if (gp != p) __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x = p;
+    }
+}
 // Cached variant: ordinary loads (may be served by this CU's L1, i.e. be STALE).  A stale parent is an older
 // ancestor, so whatever this returns is an ancestor of x: equal results for two cells still prove they are
 // connected; a stale "root" is caught by the look in front of the CAS in uf_union_from.
@@ -388,14 +399,9 @@ __device__ __forceinline__ void uf_union_from(int* parent, int a, int b, const u
 __device__ __forceinline__ void uf_union(int* parent, int a, int b, const unsigned char* __restrict__ pri) {
     uf_union_from(parent, uf_find_cached(parent, a), uf_find_cached(parent, b), pri);
 }
-// a, b: what cached walks from the two cells ended on (ancestors of them, roots unless stale).
-// Every hook goes from a node to one that comes EARLIER in the fixed order (anchor cells first, then the lower index), so a
-// node's ancestors all come earlier than the node itself: hanging a root under ANY earlier node of the other set -- a root or
-// not -- cannot close a cycle.  That is what makes the failure path cheap.  Measured on configs[1]: three of four unions find
-// their `a` hooked already when they get there (every wave of a cluster hooks at the same time), and nearly always it was
-// hooked under the very node they were about to hang it under, or under an ancestor of it.  So: look at parent[a]; still a
-// root -> CAS; otherwise step to what it points to and go round again -- no second pair of walks from the bottom (they were
-// ~5 dependent loads per failure and half of k_db_union's time).
+// a, b: what cached walks from the two cells ended on (ancestors of them, roots unless stale).  Roots are hung under ROOTS
+// (a union that hooks under whatever earlier node it holds was measured: the trees get deep, k_db_union_scan's walks went from
+// 22 to 65 us per fold step), and the walks after a failed look halve the paths they climb.
 __device__ __forceinline__ void uf_union_from(int* parent, int a, int b, const unsigned char* __restrict__ pri) {
     for (;;) {
         if (a == b) return;
@@ -404,16 +410,19 @@ __device__ __forceinline__ void uf_union_from(int* parent, int a, int b, const u
             int t = a;
             a = b;
             b = t;
-        }                                   // b comes earlier: a (if it is a root) goes under it
-        // (a failing CAS is not free -- same-address atomics retire one per ~11 ns on this GPU, scripts/microbench/atom_bench.hip,
-        //  and every active cell of a cluster that reaches the anchor tries the SAME root -- while atomic LOADS of one word by
-        //  thousands of lanes cost nothing measurable: look first, CAS only a word that still is a root)
+        }                                   // b stays a root: hang a under it
+        // `a` came from cached loads and may have been hooked by another wave long ago: a CAS on it then fails, and failing
+        // CASes are not free -- same-address atomics retire one per ~11 ns on this GPU (scripts/microbench/atom_bench.hip),
+        // and every active cell of a cluster that reaches the anchor tries the SAME root.  Atomic LOADS of one word by
+        // thousands of lanes cost nothing measurable: look first, CAS only a word that still is a root.
         int up = __hip_atomic_load(&parent[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (up == a) {
             up = atomicCAS(&parent[a], a, b);
             if (up == a) return;
         }
-        a = up;                             // a has a parent: the sets meet further up (or are one already: a == b next time round)
+        if (up == b) return;                // somebody else made this very hook (the usual way a look fails)
+        a = uf_find(parent, up);
+        b = uf_find(parent, b);
     }
 }
 
@@ -484,6 +493,8 @@ __global__ void k_db_union(const int* __restrict__ corecells, const unsigned* __
         bool ok[2];
         unsigned mi[2] = {INF32, INF32}, ac[2] = {0u, 0u};
         int p2[2] = {0, 0}, cp2[2] = {0, 0};
+        unsigned char ha[2] = {0, 0};
+        const unsigned char ha_own = hasanchor[c];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int o = lane + 64 * q;
@@ -499,6 +510,7 @@ __global__ void k_db_union(const int* __restrict__ corecells, const unsigned* __
                 ac[q] = active[c2[q]];
                 p2[q] = parent[c2[q]];
                 cp2[q] = cellpos[c2[q]];         // (garbage unless c2 is a core cell; not used then)
+                ha[q] = hasanchor[c2[q]];
             }
         double bb[2][6];
 #pragma unroll
@@ -530,6 +542,21 @@ __global__ void k_db_union(const int* __restrict__ corecells, const unsigned* __
                     mx2 += far * far;
                 }
                 want[q] = mx2 < eps2 * (1.0 - 1e-12);
+            }
+        }
+        // A cell that reaches the anchor's cluster makes that ONE hook -- its own root under the anchor's, a word nobody else
+        // writes in this pass -- and leaves its other neighbours to k_db_union_scan, which runs when these hooks have all landed.
+        // Measured on configs[1] before: 7 900 unions a batch, 5 900 of them finding their root hooked already (every cell of
+        // a cluster hooks its neighbours at the same time, and nearly all of them end up under the anchor by their own hook
+        // anyway); a failed look costs two walks.  Almost every pair left over is connected by the time the scan pass looks.
+        {
+            const unsigned long long am0 = __ballot(want[0] && ha[0] != 0), am1 = __ballot(want[1] && ha[1] != 0);
+            if ((am0 | am1) != 0ull || ha_own) {
+                if (am0 | am1) {
+                    const int ra = am0 ? __shfl(r2[0], __ffsll(am0) - 1) : __shfl(r2[1], __ffsll(am1) - 1);
+                    if (lane == 0) uf_union_from(parent, rc, ra, hasanchor);
+                }
+                continue;
             }
         }
         unsigned long long todo = __ballot(want[0]);
@@ -607,10 +634,11 @@ __global__ void k_db_union_scan(const double* __restrict__ pts, const int* __res
             if (ok[q])
                 for (int a = 0; a < 6; ++a) bq[q][a] = cellbox[(size_t)cp2[q] * 6 + a];
         }
-        bool need[2] = {false, false};
+        bool need[2] = {false, false}, direct[2] = {false, false};
+        int r2[2] = {rc, rc};
 #pragma unroll
         for (int q = 0; q < 2; ++q)
-            if (ok[q] && uf_find_cached(parent, p2[q]) != rc) {
+            if (ok[q] && (r2[q] = uf_find_cached(parent, p2[q])) != rc) {
                 double mn2 = 0.0, mx2 = 0.0;
                 for (int a = 0; a < 3; ++a) {
                     double gap = fmax(0.0, fmax(ba[a] - bq[q][3 + a], bq[q][a] - ba[3 + a]));
@@ -619,8 +647,31 @@ __global__ void k_db_union_scan(const double* __restrict__ pts, const int* __res
                     mx2 += far * far;
                 }
                 // (mx2 < eps2: decided by the box pass; mn2 >= eps2: no witness possible)
-                need[q] = !(mx2 < eps2 * (1.0 - 1e-12)) && mn2 < eps2 * (1.0 + 1e-12);
+                direct[q] = mx2 < eps2 * (1.0 - 1e-12);
+                need[q] = !direct[q] && mn2 < eps2 * (1.0 + 1e-12);
             }
+        // pairs the boxes decide that k_db_union left to this pass (its cell had the anchor to reach) and that are still two sets:
+        // one union per distinct root, all at the same time
+        {
+            bool lead[2] = {false, false};
+            unsigned long long todo = __ballot(direct[0]);
+            while (todo) {
+                const int leader = __ffsll(todo) - 1;
+                const int key = __shfl(r2[0], leader);
+                if (lane == leader) lead[0] = true;
+                todo &= ~__ballot(direct[0] && r2[0] == key);
+                direct[1] = direct[1] && r2[1] != key;
+            }
+            todo = __ballot(direct[1]);
+            while (todo) {
+                const int leader = __ffsll(todo) - 1;
+                const int key = __shfl(r2[1], leader);
+                if (lane == leader) lead[1] = true;
+                todo &= ~__ballot(direct[1] && r2[1] == key);
+            }
+            if (lead[0] || lead[1]) uf_union_from(parent, rc, lead[0] ? r2[0] : r2[1], hasanchor);
+            if (lead[0] && lead[1]) uf_union_from(parent, rc, r2[1], hasanchor);
+        }
         // phase B: the whole wave scans the pairs that need it, one after the other -- Chebyshev distance 1 first (they connect
         // most components), then distance 2; a pair that an earlier scan of this cell (or another wave) has connected meanwhile
         // is dropped when its turn comes
@@ -632,7 +683,10 @@ __global__ void k_db_union_scan(const double* __restrict__ pts, const int* __res
             const int src_lane = __ffsll(todo) - 1;
             todo &= todo - 1;
             const long long c2s = __shfl(c2[q], src_lane);
-            if (uf_find_ro(parent, (int)c) == uf_find_ro(parent, (int)c2s)) continue;
+            // (one lane looks, every lane follows: the lanes' own walks could see different trees while other waves hook)
+            int connected = 0;
+            if (lane == 0) connected = uf_find_ro(parent, (int)c) == uf_find_ro(parent, (int)c2s) ? 1 : 0;
+            if (__shfl(connected, 0)) continue;
             const double* bb = cellbox + (size_t)cellpos[c2s] * 6;
             const unsigned s1 = start[c2s], e1 = s1 + cnt[c2s];
             bool hit = false;
