@@ -554,7 +554,9 @@ __global__ void k_db_union(const int* __restrict__ corecells, const unsigned* __
             if ((am0 | am1) != 0ull || ha_own) {
                 if (am0 | am1) {
                     const int ra = am0 ? __shfl(r2[0], __ffsll(am0) - 1) : __shfl(r2[1], __ffsll(am1) - 1);
-                    if (lane == 0) uf_union_from(parent, rc, ra, hasanchor);
+                    // (the cell holds no anchor core, so its root comes after the anchor's in the order: no priority bytes to
+                    //  load, and while the cell is its own root nobody else has a reason to write that word -- CAS straight away)
+                    if (lane == 0 && !(!ha_own && rc == (int)c && atomicCAS(&parent[rc], rc, ra) == rc)) uf_union_from(parent, rc, ra, hasanchor);
                 }
                 continue;
             }
