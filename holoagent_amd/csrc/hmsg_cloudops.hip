@@ -523,15 +523,12 @@ __global__ void k_db_union(const int* __restrict__ corecells, const unsigned* __
 #pragma unroll
         for (int q = 0; q < 2; ++q)
             if (ok[q]) r2[q] = uf_find_cached(parent, p2[q]);
-        // The wave works for ONE cell: every lane whose neighbour passes the box test would unite c with it, and almost all
-        // of those neighbours already share one root (the anchor's) -- 60 lanes then fail the same CAS on parent[c] and walk
-        // the chain again with atomic loads, which was two thirds of this kernel's time.  One union per DISTINCT neighbour
-        // root is enough: equal (even stale) roots prove two cells connected.
-        // The unions themselves are the expensive part (measured with them switched off: 16 of this kernel's 39 us are left):
-        // each is a chain of walk -> priority bytes -> look -> CAS round trips.  So the leaders are picked first (ballots only,
-        // a root that turns up in both halves of the neighbourhood once), then every leader runs its union AT THE SAME TIME,
-        // starting from the roots the wave has walked to already: one chain per wave, not one per distinct root.
-        bool want[2], lead[2] = {false, false};
+        // Which neighbours the boxes connect the cell with (and that the walks do not show connected already).  What is done
+        // about them here is at most ONE hook of the cell's own root (below); round 4 measured why: with one union per distinct
+        // neighbour root, every cell of the batch at once, three of four unions found their root hooked already when they got
+        // there, and each such failure is a look, two walks with atomic loads and another trip (7 900 unions and 5 900 failures
+        // a batch on configs[1]; the kernel took 39 us, 12 with the unions switched off).
+        bool want[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             want[q] = false;
@@ -561,23 +558,18 @@ __global__ void k_db_union(const int* __restrict__ corecells, const unsigned* __
                 continue;
             }
         }
-        unsigned long long todo = __ballot(want[0]);
-        while (todo) {
-            const int leader = __ffsll(todo) - 1;
-            const int key = __shfl(r2[0], leader);
-            if (lane == leader) lead[0] = true;
-            todo &= ~__ballot(want[0] && r2[0] == key);
-            want[1] = want[1] && r2[1] != key;
-        }
-        todo = __ballot(want[1]);
-        while (todo) {
-            const int leader = __ffsll(todo) - 1;
-            const int key = __shfl(r2[1], leader);
-            if (lane == leader) lead[1] = true;
-            todo &= ~__ballot(want[1] && r2[1] == key);
-        }
-        if (lead[0] || lead[1]) uf_union_from(parent, rc, lead[0] ? r2[0] : r2[1], hasanchor);
-        if (lead[0] && lead[1]) uf_union_from(parent, rc, r2[1], hasanchor);
+        // No anchor in reach: the cell hangs ITSELF under the earliest root among the neighbours the boxes connect it with, if
+        // one comes before it -- again a word nobody else writes in this pass (every cell without anchor cores starts the pass
+        // as its own root, and a neighbour only ever hooks its own root) -- and leaves the rest to k_db_union_scan.  Measured
+        // with every root of the neighbourhood united here, all cells at once: 20 of this kernel's 33 us went into looks that
+        // failed and the walks after them; the forest this builds without a single contended word already joins most of a
+        // cluster, and the scan pass unites what is left when it has landed.
+        int m = 0x7fffffff;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (want[q] && r2[q] < rc) m = min(m, r2[q]);
+        for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
+        if (lane == 0 && m != 0x7fffffff && rc == (int)c) atomicCAS(&parent[rc], rc, m);
     }
 }
 
