@@ -10,6 +10,7 @@ struct SegDesc {                 // one cloud of a batch, points at src[pt_base 
     long long pt_base;
     int n;
     double mn[3], mx[3];         // AABB (host knows it: union of member boxes / reduction result)
+    int n_first = 0;             // optional: the segment's first n_first points are one member cloud -- the result then says how many of them were kept
 };
 
 // A batch assembled from pieces of a point pool: piece [src, src + n) of the pool goes to [dst, dst + n) of the batch
@@ -35,6 +36,7 @@ struct DbscanResult {            // per segment
     int changed;                 // 0: output == input (all points kept)
     int n_clusters;              // clusters DBSCAN found in the segment
     int contested;               // some border point had cores of two clusters within eps (only looked for when n_clusters > 1)
+    int first_kept;              // kept points among the segment's first SegDesc::n_first (they come first in the output, in order); -1: not asked for
 };
 
 // A few hundred bytes of results go from the device to the host without the copy engine: one small workgroup writes them

@@ -27,6 +27,7 @@ struct DbSeg {
     double ox, oy, oz, cs;
     int nx, ny, nz, n;
     long long cell_base, pt_base;
+    int n_first, pad;       // (SegDesc::n_first)
 };
 
 #define INF32 0xffffffffu
@@ -992,7 +993,7 @@ __global__ void __launch_bounds__(256) k_db_compact(const double* __restrict__ p
                                                     const unsigned long long* __restrict__ best, unsigned* __restrict__ flags_dbg,
                                                     const unsigned char* __restrict__ core, const long long* __restrict__ cellid,
                                                     const int* __restrict__ parent, double* __restrict__ dst, int* __restrict__ oend,
-                                                    int* __restrict__ ostart, unsigned char* __restrict__ dst_core,
+                                                    int* __restrict__ ostart, int* __restrict__ ofirst, unsigned char* __restrict__ dst_core,
                                                     unsigned long long* __restrict__ obounds, unsigned long long* __restrict__ state,
                                                     unsigned epoch) {
     __shared__ int slot_seg;
@@ -1065,6 +1066,7 @@ __global__ void __launch_bounds__(256) k_db_compact(const double* __restrict__ p
                 if (dst_core) dst_core[p] = core[i];
             }
             if (i == sg.pt_base) ostart[k] = (int)p;
+            if (sg.n_first > 0 && sg.n_first < sg.n && i == sg.pt_base + sg.n_first) ofirst[k] = (int)p;   // where the first member's output ends
             if (i == sg.pt_base + sg.n - 1) oend[k] = (int)(p + f);
             const unsigned win = (unsigned)(best[k] >> 32);
             drops = win >= 5u && win < (unsigned)sg.n;
@@ -1158,7 +1160,7 @@ struct DbInit {
     unsigned *cnt, *cursor, *minidx, *firstidx, *rootmin, *size, *active;
     unsigned char* hasanchor;
     unsigned long long* best;
-    int *ocount, *ostart;
+    int *ocount, *ostart, *ofirst;
     unsigned long long* obounds;
     unsigned *ncl, *rep, *contested, *dropped, *counters;
     long long NC;
@@ -1181,6 +1183,7 @@ __global__ void k_db_init(DbInit in) {
         for (int a = 0; a < 6; ++a) in.obounds[(size_t)i * 6 + a] = a < 3 ? ~0ull : 0ull;
         in.ocount[i] = 0;
         in.ostart[i] = 0;
+        in.ofirst[i] = 0;
         in.ncl[i] = 0u;
         in.rep[i] = INF32;
         in.contested[i] = 0u;
@@ -1238,6 +1241,8 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
         g.cs = cs;
         g.n = sd.n;
         g.pt_base = sd.pt_base;
+        g.n_first = sd.n_first;
+        g.pad = 0;
         g.cell_base = NC;
         if (sd.n > 0) {
             g.ox = sd.mn[0];
@@ -1276,13 +1281,14 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     rootmin.ensure(NC);
     best.ensure(K);
     rep.ensure(K);
-    kres.ensure((size_t)K * 17 + 4);            // per segment: n_out (or output end) | n_clusters | contested | dropped | 6 x u64 box; 4 counters; per segment: output start
+    kres.ensure((size_t)K * 18 + 4);            // per segment: n_out (or output end) | n_clusters | contested | dropped | 6 x u64 box; 4 counters; per segment: output start
     int* const d_ocount = (int*)kres.p;
     unsigned* const d_ncl = kres.p + K;
     unsigned* const d_contested = kres.p + 2 * (size_t)K;
     unsigned* const d_dropped = kres.p + 3 * (size_t)K;
     unsigned long long* const d_obounds = (unsigned long long*)(kres.p + 4 * (size_t)K);
     int* const d_ostart = (int*)(kres.p + (size_t)K * 16 + 4);
+    int* const d_ofirst = d_ostart + K;     // per segment: output position of the first point behind the first member
     active.ensure(NC); hasanchor.ensure(NC);
     corelist.ensure((size_t)std::max<long long>(N, 1));
     actlist.ensure((size_t)std::max<long long>(N, 1));
@@ -1296,7 +1302,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
         DbInit in;
         in.cnt = cnt.p; in.cursor = cursor.p; in.minidx = minidx.p; in.firstidx = firstidx.p; in.rootmin = rootmin.p;
         in.size = size.p; in.active = active.p; in.hasanchor = hasanchor.p;
-        in.best = best.p; in.obounds = d_obounds; in.ocount = d_ocount; in.ostart = d_ostart; in.ncl = d_ncl; in.rep = rep.p; in.contested = d_contested; in.dropped = d_dropped;
+        in.best = best.p; in.obounds = d_obounds; in.ocount = d_ocount; in.ostart = d_ostart; in.ofirst = d_ofirst; in.ncl = d_ncl; in.rep = rep.p; in.contested = d_contested; in.dropped = d_dropped;
         in.counters = kres.p + (size_t)K * 16;   // [0] core cells, [1] active core cells
         in.NC = NC; in.K = K;
         hipLaunchKernelGGL(k_db_init, dim3(cdiv(NC + 1, 256)), dim3(256), 0, s, in);
@@ -1402,7 +1408,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
         ProfScope ps(prof, s, "k_db_scatter", (double)N * 56.0);
         hipLaunchKernelGGL(k_db_compact, dim3(gK), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const int*)label.p,
                            (const unsigned long long*)best.p, dump_wanted ? flags.p : (unsigned*)nullptr, (const unsigned char*)core.p,
-                           (const long long*)cellid.p, (const int*)parent.p, dst, d_ocount, d_ostart, dst_core, d_obounds,
+                           (const long long*)cellid.p, (const int*)parent.p, dst, d_ocount, d_ostart, d_ofirst, dst_core, d_obounds,
                            reinterpret_cast<unsigned long long*>(scan_tmp.p), epoch);
     }
     HMSG_CHECK_LAUNCH();
@@ -1423,7 +1429,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
         ++call_no;
     }
     // one copy brings back counts, cluster counts, contest flags and the boxes of the kept points
-    pub.launch(s, (const unsigned*)kres.p, (size_t)K * 17 + 4);
+    pub.launch(s, (const unsigned*)kres.p, (size_t)K * 18 + 4);
     pub.wait();
     const unsigned* hres = pub.data();
     const unsigned long long* hb = reinterpret_cast<const unsigned long long*>(hres + (size_t)K * 4);
@@ -1439,6 +1445,9 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
         res[k].changed = n_out != segs[k].n;
         res[k].n_clusters = (int)hres[(size_t)K + k];
         res[k].contested = (int)hres[(size_t)2 * K + k];
+        res[k].first_kept = -1;
+        if (!split_compact && segs[k].n_first > 0)
+            res[k].first_kept = segs[k].n_first < segs[k].n ? (int)hres[(size_t)K * 17 + 4 + k] - (int)hres[(size_t)K * 16 + 4 + k] : n_out;
         for (int a = 0; a < 3; ++a) {
             // unchanged: the input box is exact (and maybe tighter bookkeeping upstream relies on it bit for bit)
             res[k].mn[a] = !n_out ? 0.0 : (res[k].changed ? dec_f64(hb[(size_t)k * 6 + a]) : segs[k].mn[a]);

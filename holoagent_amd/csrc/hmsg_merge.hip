@@ -49,11 +49,21 @@ struct Cloud {
     unsigned long long uid = 0;
     unsigned id = 0;        // incremental fold: cloud id in the persistent index
     int cap = 0;            // incremental fold: room of the cloud's pool region (points)
-    // overlap grid (cell side >= r): cellstart[ncell+1] (absolute positions) + cell-sorted float32 points
-    bool has_index = false;
+    // overlap grid (cell side >= r): cellstart[ncell+1] (absolute positions) + cell-sorted float32 points.
+    // Two grids at most: a BASE grid over the cloud's first nb points, laid out on the box the cloud had when it was built, and
+    // a DELTA grid over the points behind them, laid out on the cloud's box of today.  A merged cloud whose first member came
+    // through its DBSCAN whole (DbscanResult::first_kept) takes that member's base grid over -- a grid holds its own sorted
+    // copy of the points, and "some point within r" / "how many points within r" do not care which of two grids answers --
+    // so a fold step re-indexes the points a surface GAINED, not the surface (the floor was 9/10 of the index work).
+    bool has_index = false;          // every point is in one of the two grids
     bool has_index_before = false;   // (statistics)
+    int nb = 0;                      // points in the base grid (0: none)
     long long ix_cell = 0, ix_pt = 0;
     int gd[3] = {0, 0, 0};
+    float bmn[3] = {0, 0, 0};        // float32 lower corner the base grid was laid out on
+    bool has_delta = false;
+    long long ix_cell2 = 0, ix_pt2 = 0;
+    int gd2[3] = {0, 0, 0};
 };
 
 // Work lists: the per-cloud kernels below get ONE workgroup per chunk of a cloud (blk0 = first workgroup of the
@@ -70,12 +80,12 @@ __device__ __forceinline__ int find_entry(const T* __restrict__ e, int n, unsign
 }
 
 struct OvGrid {             // device view of one cloud for the overlap kernels
-    int blk0, pad0;         // first workgroup of this cloud in k_ov_count / k_ov_fill (work list)
-    long long pt_off;       // f64 points in the pool
+    int blk0, next;         // first workgroup of this entry in k_ov_count / k_ov_fill (work list); query tables: the cloud's delta grid (-1: none)
+    long long pt_off;       // f64 points in the pool: the points this grid indexes (building) / the cloud's first point (query tables)
     long long ix_pt;        // its cell-sorted float32 copy in ix_pts (cell starts are relative to it)
     long long ix_cell;
-    int n, gx, gy, gz;
-    float mnx, mny, mnz, mxx, mxy, mxz;   // float32 AABB
+    int n, gx, gy, gz;      // n: points this grid indexes (building) / points of the whole cloud (query tables)
+    float mnx, mny, mnz, mxx, mxy, mxz;   // float32 AABB of the whole cloud
     double ox, oy, oz, cell;
 };
 
@@ -232,6 +242,24 @@ __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __rest
                 inbox += cells[c0 + hi[2] + 1] - cells[c0 + lo[2]];
             }
         }
+        if (X.next >= 0) {                  // ... and the same sum over X's delta grid (the two grids split X's points)
+            const OvGrid X2 = gr[X.next];
+            const double xo2[3] = {X2.ox, X2.oy, X2.oz};
+            const int gd2[3] = {X2.gx, X2.gy, X2.gz};
+            bool empty2 = false;
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = max((int)floor(((double)(ymn[a] - m) - xo2[a]) / X2.cell), 0);
+                hi[a] = min((int)floor(((double)(ymx[a] + m) - xo2[a]) / X2.cell), gd2[a] - 1);
+                empty2 = empty2 || hi[a] < lo[a];
+            }
+            if (!empty2) {
+                const int ncol = (hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1), wy = hi[1] - lo[1] + 1;
+                for (int q = (int)threadIdx.x; q < ncol; q += (int)blockDim.x) {
+                    const long long c0 = X2.ix_cell + ((long long)(lo[0] + q / wy) * X2.gy + (lo[1] + q % wy)) * X2.gz;
+                    inbox += cells[c0 + hi[2] + 1] - cells[c0 + lo[2]];
+                }
+            }
+        }
         for (int o = 32; o > 0; o >>= 1) inbox += __shfl_xor(inbox, o);
         if ((threadIdx.x & 63) == 0) s_in[threadIdx.x >> 6] = inbox;
         __syncthreads();
@@ -247,9 +275,13 @@ __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __rest
     {
         const int b0 = (int)(blockIdx.x - (unsigned)t.blk0) * chunk;
         const int b1 = b0 + chunk < X.n ? b0 + chunk : X.n;
+        const OvGrid Y2 = gr[Y.next >= 0 ? Y.next : t.y];      // (Y's delta grid, if it has one)
         for (int i = b0 + (int)threadIdx.x; i < b1; i += blockDim.x) {
             const double* p = pool + (size_t)(X.pt_off + i) * 3;
-            local += ov_hit(Y, cells, sorted, (float)p[0], (float)p[1], (float)p[2], r2, r) ? 1u : 0u;
+            const float x = (float)p[0], y = (float)p[1], z = (float)p[2];
+            bool hit = ov_hit(Y, cells, sorted, x, y, z, r2, r);
+            if (!hit && Y.next >= 0) hit = ov_hit(Y2, cells, sorted, x, y, z, r2, r);
+            local += hit ? 1u : 0u;
         }
     }
     for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
@@ -382,24 +414,34 @@ struct Merger {
         nb.swap(b);
     }
 
-    OvGrid grid_of(const Cloud& c) const {
+    // float32 rounding can move a coordinate slightly outside the f64 box: the origin is padded
+    OvGrid grid_at(const Cloud& c, const float* lo, const int* gd, long long ix_cell, long long ix_pt, long long pt_off, int n) const {
         OvGrid g;
-        g.blk0 = g.pad0 = 0;
-        g.pt_off = c.off;
-        g.ix_cell = c.ix_cell;
-        g.ix_pt = c.ix_pt;
-        g.n = c.n;
-        g.gx = c.gd[0];
-        g.gy = c.gd[1];
-        g.gz = c.gd[2];
+        g.blk0 = 0;
+        g.next = -1;
+        g.pt_off = pt_off;
+        g.ix_cell = ix_cell;
+        g.ix_pt = ix_pt;
+        g.n = n;
+        g.gx = gd[0];
+        g.gy = gd[1];
+        g.gz = gd[2];
         g.mnx = (float)c.mn[0]; g.mny = (float)c.mn[1]; g.mnz = (float)c.mn[2];
         g.mxx = (float)c.mx[0]; g.mxy = (float)c.mx[1]; g.mxz = (float)c.mx[2];
-        // float32 rounding can move a coordinate slightly outside the f64 box: pad the origin
-        g.ox = (double)g.mnx - 1e-3;
-        g.oy = (double)g.mny - 1e-3;
-        g.oz = (double)g.mnz - 1e-3;
+        g.ox = (double)lo[0] - 1e-3;
+        g.oy = (double)lo[1] - 1e-3;
+        g.oz = (double)lo[2] - 1e-3;
         g.cell = cell;
         return g;
+    }
+    // query-table entries of a cloud: its base grid (carrying the whole cloud's point range) and, if it has one, its delta grid
+    void push_grids(const Cloud& c, std::vector<OvGrid>& g) const {
+        g.push_back(grid_at(c, c.bmn, c.gd, c.ix_cell, c.ix_pt, c.off, c.n));
+        if (c.has_delta) {
+            const float lo[3] = {(float)c.mn[0], (float)c.mn[1], (float)c.mn[2]};
+            g.back().next = (int)g.size();
+            g.push_back(grid_at(c, lo, c.gd2, c.ix_cell2, c.ix_pt2, c.off + c.nb, c.n - c.nb));
+        }
     }
 
     // ---- overlap grids for the clouds that do not have one yet
@@ -407,31 +449,52 @@ struct Merger {
         std::vector<int> todo;
         long long ncell_new = 0, npts_new = 0;
         int maxn = 0;
+        std::vector<OvGrid> g;
+        unsigned nblk = 0;
         for (int i = 0; i < (int)L.size(); ++i) {
             Cloud& c = L[i];
             if (c.has_index || c.n == 0) continue;
-            for (int a = 0; a < 3; ++a)
-                c.gd[a] = (int)std::floor(((double)(float)c.mx[a] - (double)(float)c.mn[a] + 2e-3) / cell) + 1;
-            c.ix_cell = ix_cells_used + ncell_new;
-            c.ix_pt = ix_pts_used;
-            ncell_new += (long long)c.gd[0] * c.gd[1] * c.gd[2] + 1;   // +1: end sentinel
-            npts_new += c.n;
-            maxn = std::max(maxn, c.n);
+            const float lo[3] = {(float)c.mn[0], (float)c.mn[1], (float)c.mn[2]};
+            int gd[3];
+            for (int a = 0; a < 3; ++a) gd[a] = (int)std::floor(((double)(float)c.mx[a] - (double)lo[a] + 2e-3) / cell) + 1;
+            const long long ncell = (long long)gd[0] * gd[1] * gd[2] + 1;   // +1: end sentinel
+            // an inherited base grid stays while what the cloud has gained since is a quarter of it at most (and the grid of the
+            // gain, laid out on the whole box, is not mostly cells): else the cloud is indexed afresh
+            const bool delta = c.nb > 0 && c.nb < c.n && (delta_always || ((long long)(c.n - c.nb) * 4 <= (long long)c.nb && ncell <= 4ll * c.nb));
+            (delta ? grid_delta : grid_full) += 1;
+            (delta ? grid_delta_pts : grid_full_pts) += delta ? c.n - c.nb : c.n;
+            int first = 0;
+            if (delta) {
+                first = c.nb;
+                c.has_delta = true;
+                for (int a = 0; a < 3; ++a) c.gd2[a] = gd[a];
+                c.ix_cell2 = ix_cells_used + ncell_new;
+                c.ix_pt2 = ix_pts_used;                  // (cell starts are relative to the BATCH's first sorted point)
+                g.push_back(grid_at(c, lo, c.gd2, c.ix_cell2, c.ix_pt2, c.off + first, c.n - first));
+            } else {
+                c.nb = c.n;
+                c.has_delta = false;
+                for (int a = 0; a < 3; ++a) {
+                    c.gd[a] = gd[a];
+                    c.bmn[a] = lo[a];
+                }
+                c.ix_cell = ix_cells_used + ncell_new;
+                c.ix_pt = ix_pts_used;
+                g.push_back(grid_at(c, lo, c.gd, c.ix_cell, c.ix_pt, c.off, c.n));
+            }
+            g.back().blk0 = (int)nblk;
+            nblk += cdiv((size_t)(c.n - first), OVI_CHUNK);
+            ncell_new += ncell;
+            npts_new += c.n - first;
+            maxn = std::max(maxn, c.n - first);
             todo.push_back(i);
         }
         if (todo.empty()) return;
-        // (arena offsets are 64-bit; cell starts are relative to the batch's first sorted point, so only a BATCH is bounded)
+        // (arena offsets are 64-bit; cell starts are relative to the grid's first sorted point, so only a BATCH is bounded)
         HMSG_REQUIRE(ncell_new < (1ll << 32) && npts_new < (1ll << 32), HMSG_ERR_UNSUPPORTED,
                      "one batch of overlap grids exceeds 2^32 entries");
         grow(ix_cells, (size_t)ix_cells_used, (size_t)(ix_cells_used + ncell_new));
         grow(ix_pts, (size_t)ix_pts_used * 3, (size_t)(ix_pts_used + npts_new) * 3);
-        std::vector<OvGrid> g(todo.size());
-        unsigned nblk = 0;
-        for (size_t k = 0; k < todo.size(); ++k) {
-            g[k] = grid_of(L[todo[k]]);
-            g[k].blk0 = (int)nblk;
-            nblk += cdiv((size_t)g[k].n, OVI_CHUNK);
-        }
         d_grids.ensure(g.size());
         // (pinned staging: an async copy from pageable memory is staged by the runtime, ~3x the host time per call;
         //  the previous use has completed -- every step and every prebuild ends with a wait on the stream)
@@ -491,6 +554,8 @@ struct Merger {
             c.off = live;
             live += c.n;
             c.has_index = false;
+            c.has_delta = false;
+            c.nb = 0;
         };
         for (auto& c : G) add(c);
         for (size_t f = f_next; f < frames.size(); ++f)
@@ -522,6 +587,12 @@ struct Merger {
         // an episode whose LIVE clouds alone pass the threshold must not collect on every frame
         gc_pool_points = std::max(gc_pool_points, (size_t)live * 2);
     }
+    // HMSG_DEBUG_NO_GRID_INHERIT=1: every merged cloud is indexed afresh (the form before round 4; comparison runs and tests)
+    bool inherit_grids = getenv("HMSG_DEBUG_NO_GRID_INHERIT") == nullptr;
+    // HMSG_DEBUG_GRID_DELTA_ALWAYS=1: an inherited base grid is kept whatever the cloud has gained (tests: small scenes never
+    // meet the thresholds)
+    bool delta_always = getenv("HMSG_DEBUG_GRID_DELTA_ALWAYS") != nullptr;
+    double grid_full = 0, grid_full_pts = 0, grid_delta = 0, grid_delta_pts = 0;     // (statistics)
     size_t gc_pool_points = (size_t)1 << 30;         // 1.07 * 10^9 points = 26 GB
     size_t gc_index_entries = (size_t)1 << 31;       // grid cells (8 GB) / sorted points (26 GB)
     int n_collects = 0;
@@ -546,7 +617,7 @@ struct Merger {
             for (int v : {a, b})
                 if (slot[v] < 0) {
                     slot[v] = (int)g.size();
-                    g.push_back(grid_of(L[v]));
+                    push_grids(L[v], g);
                 }
             if (L[a].n > L[b].n) std::swap(a, b);  // a = the smaller cloud
             tasks[k] = OvTask{slot[a], slot[b], 0, (int)nblk1};
@@ -763,6 +834,7 @@ struct Merger {
                 cat.push_back(CatSeg{L[i].off, cat_total, L[i].n, i == anchor_i ? 1 : 0, (int)cat_blocks, 0});
                 cat_blocks += cdiv((size_t)L[i].n, CAT_CHUNK);
                 cat_total += L[i].n;
+                if (!any) sd.n_first = L[i].n;             // (its overlap grid may outlive the merge: first_kept)
                 sd.n += L[i].n;
                 for (int a = 0; a < 3; ++a) {
                     sd.mn[a] = any ? std::min(sd.mn[a], L[i].mn[a]) : L[i].mn[a];
@@ -896,6 +968,26 @@ struct Merger {
             k.anchor = k.fixed && r.n_clusters >= 1 && (r.changed || r.n_clusters == 1);
             k.fresh = true;
             k.uid = next_uid++;
+            // the first member came through whole: its points are this cloud's first points, in order, and its BASE grid
+            // (a sorted copy of exactly its first nb points) goes on answering for them
+            if (inherit_grids && r.first_kept >= 0) {
+                int f = -1;
+                for (int i : mem)
+                    if (L[i].n > 0) {
+                        f = i;
+                        break;
+                    }
+                if (f >= 0 && r.first_kept == L[f].n && L[f].has_index && L[f].nb > 0) {
+                    k.nb = L[f].nb;
+                    k.ix_cell = L[f].ix_cell;
+                    k.ix_pt = L[f].ix_pt;
+                    for (int a = 0; a < 3; ++a) {
+                        k.gd[a] = L[f].gd[a];
+                        k.bmn[a] = L[f].bmn[a];
+                    }
+                    k.has_index = k.nb == k.n;
+                }
+            }
             out.push_back(k);
             cursor += r.n_out;
         }
@@ -1084,6 +1176,9 @@ static void merge_report(Folder& m) {
                     nmc[c], t.ccount[c] / S, t.cpts[c] / S, t.cB[c] / S, t.ccount[c] ? t.cmem[c] / t.ccount[c] : 0.0, t.cchanged[c],
                     t.cmulti[c], t.ccontested[c], t.cnonfixed[c]);
     }
+    if (getenv("HMSG_DEBUG_TIMING"))
+        fprintf(stderr, "[hmsg merge] overlap grids: %.0f over whole clouds (%.0f points), %.0f delta grids (%.0f points)\n", m.grid_full,
+                m.grid_full_pts, m.grid_delta, m.grid_delta_pts);
     if (getenv("HMSG_DEBUG_TIMING") && m.n_collects)
         fprintf(stderr, "[hmsg merge] %d collections of the point pool / grid arenas\n", m.n_collects);
     if (getenv("HMSG_DEBUG_TIMING") && m.ops.stat_calls > 0)

@@ -19,10 +19,12 @@ def _digest(inst):
     return len(inst), sum(len(a) for a in inst), h.hexdigest()
 
 
-def _host_scene(L, frames, feat_dim, nopipe, split=False):
+def _host_scene(L, frames, feat_dim, nopipe, split=False, env=None):
     os.environ.pop("HMSG_FOLD_NOPIPE", None)
     if nopipe:
         os.environ["HMSG_FOLD_NOPIPE"] = "1"
+    for k, v in (env or {}).items():
+        os.environ[k] = v
     try:
         sc = PC.make_scene(L, frames, dict(feat_dim=feat_dim, outlier_nb_points=60, feat_dbscan_min=8))
         S = PC.stack_frames(frames)
@@ -40,6 +42,8 @@ def _host_scene(L, frames, feat_dim, nopipe, split=False):
         return inst, feats
     finally:
         os.environ.pop("HMSG_FOLD_NOPIPE", None)
+        for k in (env or {}):
+            os.environ.pop(k, None)
 
 
 @pytest.mark.skipif(not os.path.exists(PC.EMU_PATH), reason="kernel simulator not built")
@@ -71,11 +75,36 @@ def test_pipelined_fold_equals_fold_in_merge_on_the_simulator():
     sc.close()
 
 
-def _device_scene(L, spec, inp, nopipe, chunks=1):
+@pytest.mark.skipif(not os.path.exists(PC.EMU_PATH), reason="kernel simulator not built")
+def test_inherited_overlap_grids_on_the_simulator(capfd):
+    """A merged cloud whose first member came through its DBSCAN whole keeps that member's overlap grid and indexes only what it
+    gained (hmsg_merge.hip: Cloud::nb, a base grid + a delta grid): same instances as with every merged cloud indexed afresh."""
+    from holoagent_amd._lib import HmsgLib
+    from holoagent_amd.synth import SceneSpec, SynthScene
+    L = HmsgLib(PC.EMU_PATH)
+    spec = SceneSpec(seed=11, rooms_x=1, rooms_z=1, room_size=(3.6, 2.5, 3.2), objects_per_room=4, width=64, height=48,
+                     n_frames=8, n_masks=5, feat_dim=16)
+    scn = SynthScene(spec)
+    frames = [scn.frame(i) for i in range(spec.n_frames)]
+    ref, ref_f = _host_scene(L, frames, 16, nopipe=True, env={"HMSG_DEBUG_NO_GRID_INHERIT": "1", "HMSG_DEBUG_TIMING": "1"})
+    err0 = capfd.readouterr().err
+    got, got_f = _host_scene(L, frames, 16, nopipe=True, env={"HMSG_DEBUG_GRID_DELTA_ALWAYS": "1", "HMSG_DEBUG_TIMING": "1"})
+    err1 = capfd.readouterr().err
+    import re
+    assert re.search(r"overlap grids: \d+ over whole clouds \(\d+ points\), 0 delta grids", err0), err0
+    m = re.search(r"overlap grids: \d+ over whole clouds \(\d+ points\), (\d+) delta grids", err1)
+    assert m and int(m.group(1)) >= 3, err1
+    assert len(ref) >= 3 and len(got) == len(ref) and all(np.array_equal(a, b) for a, b in zip(got, ref))
+    assert np.array_equal(got_f, ref_f)
+
+
+def _device_scene(L, spec, inp, nopipe, chunks=1, env=None):
     from holoagent_amd._lib import Scene
     os.environ.pop("HMSG_FOLD_NOPIPE", None)
     if nopipe:
         os.environ["HMSG_FOLD_NOPIPE"] = "1"
+    for k, v in (env or {}).items():
+        os.environ[k] = v
     try:
         sc = Scene(lib_=L, height=spec.height, width=spec.width, max_frames=spec.n_frames, max_masks=spec.n_masks, feat_dim=spec.feat_dim)
         sc.add_frames(inp["rgb"], inp["depth"], inp["pose"], inp["K"])
@@ -92,6 +121,8 @@ def _device_scene(L, spec, inp, nopipe, chunks=1):
         return d
     finally:
         os.environ.pop("HMSG_FOLD_NOPIPE", None)
+        for k in (env or {}):
+            os.environ.pop(k, None)
 
 
 @pytest.mark.gpu
@@ -111,3 +142,22 @@ def test_pipelined_fold_equals_fold_in_merge_on_the_gpu():
     assert _device_scene(L, spec, inp, nopipe=False) == ref
     assert _device_scene(L, spec, inp, nopipe=False, chunks=3) == ref
     assert _device_scene(L, spec, inp, nopipe=False) == ref          # (handles re-use the allocator cache of both threads)
+
+
+@pytest.mark.gpu
+def test_inherited_overlap_grids_on_the_gpu():
+    """configs[1]'s scene, 300 frames: merged clouds that keep their first member's overlap grid and index only what they gained
+    (the default), against every merged cloud indexed afresh (HMSG_DEBUG_NO_GRID_INHERIT=1) and against delta grids whatever
+    the gain (HMSG_DEBUG_GRID_DELTA_ALWAYS=1): same instances, same pooled features."""
+    import torch
+    import bench
+    from holoagent_amd._lib import HmsgLib
+    from holoagent_amd.synth import SceneSpec
+    L = HmsgLib()
+    spec = SceneSpec(seed=77, n_frames=300, feat_dim=64, n_masks=32)
+    inp = bench.build_scene_inputs(L, spec, torch.device("cuda", 0), torch)
+    ref = _device_scene(L, spec, inp, nopipe=True, env={"HMSG_DEBUG_NO_GRID_INHERIT": "1"})
+    assert ref[0][0] > 50
+    assert _device_scene(L, spec, inp, nopipe=True) == ref
+    assert _device_scene(L, spec, inp, nopipe=False) == ref
+    assert _device_scene(L, spec, inp, nopipe=True, env={"HMSG_DEBUG_GRID_DELTA_ALWAYS": "1"}) == ref
