@@ -161,44 +161,87 @@ __device__ __forceinline__ bool ov_scan(const float* __restrict__ sorted, unsign
 // the box filter, most points DO overlap, and on a surface that has piled up hundreds of re-observations per
 // cell the witness sits in the own cell -- scanning the 27 cells in grid order found it after thousands of
 // far candidates.
+struct OvProbe {            // where a point falls in one grid
+    int cx, cy, cz, z0, z1;
+    bool own, any;
+};
+__device__ __forceinline__ OvProbe ov_probe(const OvGrid& Y, float x, float y, float z) {
+    OvProbe p;
+    p.cx = (int)floor(((double)x - Y.ox) / Y.cell);
+    p.cy = (int)floor(((double)y - Y.oy) / Y.cell);
+    p.cz = (int)floor(((double)z - Y.oz) / Y.cell);
+    p.z0 = max(p.cz - 1, 0);
+    p.z1 = min(p.cz + 1, Y.gz - 1);
+    p.any = p.z1 >= p.z0;
+    p.own = p.cx >= 0 && p.cx < Y.gx && p.cy >= 0 && p.cy < Y.gy && p.cz >= 0 && p.cz < Y.gz;
+    return p;
+}
+// candidate range of the point's own cell
+__device__ __forceinline__ void ov_own_range(const OvGrid& Y, const OvProbe& p, const unsigned* __restrict__ cells, unsigned& s0, unsigned& e0) {
+    s0 = e0 = 0u;
+    if (p.any && p.own) {
+        const long long c = Y.ix_cell + ((long long)p.cx * Y.gy + p.cy) * Y.gz + p.cz;
+        s0 = cells[c];
+        e0 = cells[c + 1];
+    }
+}
+// a MISS has to rule out all 27 cells: the candidate ranges of the 9 columns around the point (z-cells are contiguous; the own
+// cell, already scanned, is cut out of its column: below it in [4], above it in [9]) -- independent loads, one round trip
+__device__ __forceinline__ void ov_col_ranges(const OvGrid& Y, const OvProbe& p, const unsigned* __restrict__ cells, unsigned* rs, unsigned* re) {
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const int jx = p.cx + q / 3 - 1, jy = p.cy + q % 3 - 1;
+        rs[q] = re[q] = 0u;
+        if (!p.any || jx < 0 || jx >= Y.gx || jy < 0 || jy >= Y.gy) continue;
+        const long long c0 = Y.ix_cell + ((long long)jx * Y.gy + jy) * Y.gz;
+        rs[q] = cells[c0 + p.z0];
+        re[q] = (p.own && q == 4) ? cells[c0 + p.cz] : cells[c0 + p.z1 + 1];
+    }
+    rs[9] = re[9] = 0u;
+    if (p.any && p.own) {
+        const long long c0 = Y.ix_cell + ((long long)p.cx * Y.gy + p.cy) * Y.gz;
+        rs[9] = cells[c0 + p.cz + 1];
+        re[9] = cells[c0 + p.z1 + 1];
+    }
+}
 __device__ __forceinline__ bool ov_hit(const OvGrid& Y, const unsigned* __restrict__ cells, const float* __restrict__ sorted,
                                        float x, float y, float z, float r2, float r) {
     if (x < Y.mnx - r || x > Y.mxx + r || y < Y.mny - r || y > Y.mxy + r || z < Y.mnz - r || z > Y.mxz + r) return false;
-    const int cx = (int)floor(((double)x - Y.ox) / Y.cell), cy = (int)floor(((double)y - Y.oy) / Y.cell),
-              cz = (int)floor(((double)z - Y.oz) / Y.cell);
-    const int z0 = max(cz - 1, 0), z1 = min(cz + 1, Y.gz - 1);
-    if (z1 < z0) return false;
-    const bool own = cx >= 0 && cx < Y.gx && cy >= 0 && cy < Y.gy && cz >= 0 && cz < Y.gz;
-    if (own) {
-        const long long c = Y.ix_cell + ((long long)cx * Y.gy + cy) * Y.gz + cz;
-        if (ov_scan(sorted + (size_t)Y.ix_pt * 3, cells[c], cells[c + 1], x, y, z, r2)) return true;
-    }
-    // a MISS has to rule out all 27 cells: fetch the candidate ranges of the 9 columns first (independent loads,
-    // one round trip), then scan them
+    const OvProbe p = ov_probe(Y, x, y, z);
+    if (!p.any) return false;
+    const float* const sy = sorted + (size_t)Y.ix_pt * 3;
+    unsigned s0, e0;
+    ov_own_range(Y, p, cells, s0, e0);
+    if (ov_scan(sy, s0, e0, x, y, z, r2)) return true;
     unsigned rs[10], re[10];
-#pragma unroll
-    for (int q = 0; q < 9; ++q) {
-        const int jx = cx + q / 3 - 1, jy = cy + q % 3 - 1;
-        rs[q] = re[q] = 0u;
-        if (jx < 0 || jx >= Y.gx || jy < 0 || jy >= Y.gy) continue;
-        const long long c0 = Y.ix_cell + ((long long)jx * Y.gy + jy) * Y.gz;       // z-cells are contiguous
-        if (own && q == 4) {                                                       // own cell already done: below it ...
-            rs[q] = cells[c0 + z0];
-            re[q] = cells[c0 + cz];
-        } else {
-            rs[q] = cells[c0 + z0];
-            re[q] = cells[c0 + z1 + 1];
-        }
-    }
-    rs[9] = re[9] = 0u;
-    if (own) {                                                                     // ... and above it
-        const long long c0 = Y.ix_cell + ((long long)cx * Y.gy + cy) * Y.gz;
-        rs[9] = cells[c0 + cz + 1];
-        re[9] = cells[c0 + z1 + 1];
-    }
+    ov_col_ranges(Y, p, cells, rs, re);
 #pragma unroll
     for (int q = 0; q < 10; ++q)
-        if (ov_scan(sorted + (size_t)Y.ix_pt * 3, rs[q], re[q], x, y, z, r2)) return true;
+        if (ov_scan(sy, rs[q], re[q], x, y, z, r2)) return true;
+    return false;
+}
+// the same against a cloud with two grids (base + delta, hmsg_merge.hip: Cloud::nb): the two grids' table look-ups go out
+// side by side -- every round of look-ups is a round trip, and the kernel lasts as long as a lane's chain of them
+__device__ __forceinline__ bool ov_hit2(const OvGrid& Y, const OvGrid& Y2, const unsigned* __restrict__ cells, const float* __restrict__ sorted,
+                                        float x, float y, float z, float r2, float r) {
+    if (x < Y.mnx - r || x > Y.mxx + r || y < Y.mny - r || y > Y.mxy + r || z < Y.mnz - r || z > Y.mxz + r) return false;   // (both carry the cloud's box)
+    const OvProbe p = ov_probe(Y, x, y, z), p2 = ov_probe(Y2, x, y, z);
+    const float* const sy = sorted + (size_t)Y.ix_pt * 3;
+    const float* const sy2 = sorted + (size_t)Y2.ix_pt * 3;
+    unsigned s0, e0, s2, e2;
+    ov_own_range(Y, p, cells, s0, e0);
+    ov_own_range(Y2, p2, cells, s2, e2);
+    if (ov_scan(sy, s0, e0, x, y, z, r2)) return true;
+    if (ov_scan(sy2, s2, e2, x, y, z, r2)) return true;
+    unsigned rs[10], re[10], rs2[10], re2[10];
+    ov_col_ranges(Y, p, cells, rs, re);
+    ov_col_ranges(Y2, p2, cells, rs2, re2);
+#pragma unroll
+    for (int q = 0; q < 10; ++q)
+        if (ov_scan(sy, rs[q], re[q], x, y, z, r2)) return true;
+#pragma unroll
+    for (int q = 0; q < 10; ++q)
+        if (ov_scan(sy2, rs2[q], re2[q], x, y, z, r2)) return true;
     return false;
 }
 
@@ -279,8 +322,7 @@ __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __rest
         for (int i = b0 + (int)threadIdx.x; i < b1; i += blockDim.x) {
             const double* p = pool + (size_t)(X.pt_off + i) * 3;
             const float x = (float)p[0], y = (float)p[1], z = (float)p[2];
-            bool hit = ov_hit(Y, cells, sorted, x, y, z, r2, r);
-            if (!hit && Y.next >= 0) hit = ov_hit(Y2, cells, sorted, x, y, z, r2, r);
+            const bool hit = Y.next >= 0 ? ov_hit2(Y, Y2, cells, sorted, x, y, z, r2, r) : ov_hit(Y, cells, sorted, x, y, z, r2, r);
             local += hit ? 1u : 0u;
         }
     }
