@@ -115,6 +115,9 @@ _SIGS = {
     "hmsg_write_json": (C.c_int, [C.c_char_p, C.c_int32, _P]),
     "hmsg_write_ply": (C.c_int, [C.c_char_p, _P, C.c_int64]),
     "hmsg_read_json_numbers": (C.c_int, [C.c_char_p, C.c_char_p, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "hmsg_assign_cameras_to_rooms": (C.c_int, [_P, C.c_int64, C.c_int32, _P, C.c_double, C.c_double, _P, _P, _P]),
+    "hmsg_pick_representative_views": (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P, C.c_int32, _P, C.POINTER(C.c_int32)]),
+    "hmsg_graph_edges": (C.c_int, [C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "hmsg_test_format_doubles": (C.c_int64, [_P, C.c_int64, _P, C.c_int64]),
     "hmsg_test_allocator_carving": (C.c_int, [C.c_int32, C.c_int32]),
     "hmsg_test_dbscan": (C.c_int, [_P, C.c_int32, _P, C.c_double, C.c_int32, _P, _P, _P, _P, _P]),
@@ -724,6 +727,59 @@ def read_json_numbers(path, key, lib_: "HmsgLib | None" = None):
     if rc != 0:
         raise HmsgError(f"hmsg_read_json_numbers failed ({rc}) for {key} of {path}")
     return out[: n.value]
+
+
+def assign_cameras_to_rooms(dist, cam_height, y_min, y_max, lib_: "HmsgLib | None" = None):
+    """compute_room_embeddings' camera -> room step (include/hmsg.h: hmsg_assign_cameras_to_rooms).  dist [n_cams, n_rooms].
+    Returns (room_of_cam [n_cams] int32, per-room image id lists)."""
+    L = lib_ or lib()
+    d = np.ascontiguousarray(np.asarray(dist, np.float64))
+    n_cams, n_rooms = (int(d.shape[0]), int(d.shape[1])) if d.ndim == 2 else (0, 0)
+    h = np.ascontiguousarray(np.asarray(cam_height, np.float64).reshape(-1))
+    room_of = np.full(max(n_cams, 1), -1, np.int32)
+    off = np.zeros(n_rooms + 1, np.int64)
+    imgs = np.zeros(max(n_cams + n_rooms, 1), np.int32)
+    rc = L.c.hmsg_assign_cameras_to_rooms(_ptr(d) if d.size else None, n_cams, n_rooms, _ptr(h) if h.size else None, float(y_min),
+                                          float(y_max), _ptr(room_of), _ptr(off), _ptr(imgs))
+    if rc != 0:
+        raise HmsgError(f"hmsg_assign_cameras_to_rooms failed ({rc})")
+    return room_of[:n_cams], [imgs[off[r]:off[r + 1]].tolist() for r in range(n_rooms)]
+
+
+def pick_representative_views(embs, labels, centers, lib_: "HmsgLib | None" = None):
+    """Per KMeans label present (ascending), the member closest (dot product) to its centre (include/hmsg.h:
+    hmsg_pick_representative_views).  Returns indices into the room's image list."""
+    L = lib_ or lib()
+    e = np.ascontiguousarray(np.asarray(embs, np.float32))
+    c = np.ascontiguousarray(np.asarray(centers, np.float32))
+    lab = np.ascontiguousarray(np.asarray(labels, np.int32).reshape(-1))
+    out = np.zeros(max(c.shape[0], 1), np.int32)
+    n = C.c_int32(0)
+    rc = L.c.hmsg_pick_representative_views(_ptr(e) if e.size else None, e.shape[0], e.shape[1], _ptr(lab) if lab.size else None,
+                                            _ptr(c) if c.size else None, c.shape[0], _ptr(out), C.byref(n))
+    if rc != 0:
+        raise HmsgError(f"hmsg_pick_representative_views failed ({rc})")
+    return out[: n.value].tolist()
+
+
+def graph_edges(n_floors, room_floor, obj_room, view_room, view_objs, lib_: "HmsgLib | None" = None):
+    """create_graph_new as an edge list of node ids (0 building, floors, rooms, objects, views; include/hmsg.h:
+    hmsg_graph_edges).  view_objs: per view, the positions of its objects.  Returns int64 [n_edges, 2]."""
+    L = lib_ or lib()
+    rf = np.ascontiguousarray(np.asarray(room_floor, np.int32).reshape(-1))
+    orm = np.ascontiguousarray(np.asarray(obj_room, np.int32).reshape(-1))
+    vr = np.ascontiguousarray(np.asarray(view_room, np.int32).reshape(-1))
+    off = np.zeros(len(vr) + 1, np.int64)
+    off[1:] = np.cumsum([len(v) for v in view_objs]) if len(vr) else 0
+    vo = np.ascontiguousarray(np.asarray([o for v in view_objs for o in v], np.int32))
+    cap = 1 + int(n_floors) + len(rf) + len(orm) + len(vr) + len(vo)
+    edges = np.zeros((max(cap, 1), 2), np.int64)
+    n = C.c_int64(0)
+    rc = L.c.hmsg_graph_edges(int(n_floors), len(rf), _ptr(rf) if rf.size else None, len(orm), _ptr(orm) if orm.size else None, len(vr),
+                              _ptr(vr) if vr.size else None, _ptr(off), _ptr(vo) if vo.size else None, _ptr(edges), cap, C.byref(n))
+    if rc != 0:
+        raise HmsgError(f"hmsg_graph_edges failed ({rc})")
+    return edges[: n.value]
 
 
 def crop_all_bounding_boxs(image, masks, bbox_margin=0, size=512, plain=True, masked=True, device_id=0,

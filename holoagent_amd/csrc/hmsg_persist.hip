@@ -475,3 +475,127 @@ extern "C" int hmsg_read_json_numbers(const char* path, const char* key, double*
     *n = cnt;
     return HMSG_OK;
 }
+
+// ------------------------------------------------------------------------------------------ A9 / A11 bookkeeping (host only)
+// utils/graph_utils.py:257-291
+extern "C" int hmsg_assign_cameras_to_rooms(const double* dist, int64_t n_cams, int32_t n_rooms, const double* cam_height, double y_min,
+                                            double y_max, int32_t* room_of_cam, int64_t* room_off, int32_t* room_imgs) {
+    if (n_cams < 0 || n_rooms < 0 || !room_off || (n_cams > 0 && (!cam_height || !room_of_cam)) ||
+        (n_cams > 0 && n_rooms > 0 && !dist) || ((n_cams > 0 || n_rooms > 0) && !room_imgs))
+        return HMSG_ERR_INVALID;
+    try {
+        std::vector<std::vector<int32_t>> lists((size_t)n_rooms);
+        for (int64_t i = 0; i < n_cams; ++i) {
+            const bool inside = !(cam_height[i] < y_min || cam_height[i] > y_max);
+            room_of_cam[i] = -1;
+            if (!inside || n_rooms == 0) continue;
+            int32_t best = 0;
+            for (int32_t r = 1; r < n_rooms; ++r)
+                if (dist[i * n_rooms + r] < dist[i * n_rooms + best]) best = r;      // (first minimum: np.argmin)
+            room_of_cam[i] = best;
+            lists[(size_t)best].push_back((int32_t)i);
+        }
+        for (int32_t r = 0; r < n_rooms; ++r) {
+            if (!lists[(size_t)r].empty() || n_cams == 0) continue;
+            // closest = np.where(inside, inf, dist[:, r]); np.argmin (camera 0 when every entry is inf)
+            int64_t best = 0;
+            double bd = HUGE_VAL;
+            for (int64_t i = 0; i < n_cams; ++i) {
+                const bool inside = !(cam_height[i] < y_min || cam_height[i] > y_max);
+                const double d = inside ? HUGE_VAL : dist[i * n_rooms + r];
+                if (d < bd) {
+                    bd = d;
+                    best = i;
+                }
+            }
+            lists[(size_t)r].push_back((int32_t)best);
+        }
+        int64_t at = 0;
+        for (int32_t r = 0; r < n_rooms; ++r) {
+            room_off[r] = at;
+            for (int32_t v : lists[(size_t)r]) room_imgs[at++] = v;
+        }
+        room_off[n_rooms] = at;
+        return HMSG_OK;
+    } catch (const std::bad_alloc&) {
+        return HMSG_ERR_NOMEM;
+    }
+}
+
+// utils/graph_utils.py:334-352
+extern "C" int hmsg_pick_representative_views(const float* embs, int64_t n, int32_t dim, const int32_t* labels, const float* centers,
+                                              int32_t k, int32_t* out_member, int32_t* n_out) {
+    if (!n_out || n < 0 || dim <= 0 || k < 0 || (n > 0 && (!embs || !labels)) || (k > 0 && (!centers || !out_member))) return HMSG_ERR_INVALID;
+    *n_out = 0;
+    for (int64_t i = 0; i < n; ++i)
+        if (labels[i] < 0 || labels[i] >= k) return HMSG_ERR_INVALID;
+    for (int32_t lab = 0; lab < k; ++lab) {
+        int64_t best = -1;
+        double bs = 0.0;
+        for (int64_t i = 0; i < n; ++i) {
+            if (labels[i] != lab) continue;
+            double sc = 0.0;
+            for (int32_t d = 0; d < dim; ++d) sc += (double)embs[i * dim + d] * (double)centers[(int64_t)lab * dim + d];
+            if (best < 0 || sc > bs) {
+                best = i;
+                bs = sc;
+            }
+        }
+        if (best >= 0) out_member[(*n_out)++] = (int32_t)best;
+    }
+    return HMSG_OK;
+}
+
+// graph.py:1752-1775
+extern "C" int hmsg_graph_edges(int32_t n_floors, int32_t n_rooms, const int32_t* room_floor, int32_t n_objects, const int32_t* obj_room,
+                                int32_t n_views, const int32_t* view_room, const int64_t* view_obj_off, const int32_t* view_obj,
+                                int64_t* edges, int64_t capacity, int64_t* n_edges) {
+    if (!n_edges || n_floors < 0 || n_rooms < 0 || n_objects < 0 || n_views < 0 || capacity < 0 || (n_rooms > 0 && !room_floor) ||
+        (n_objects > 0 && !obj_room) || (n_views > 0 && (!view_room || !view_obj_off)) || (capacity > 0 && !edges))
+        return HMSG_ERR_INVALID;
+    *n_edges = 0;
+    for (int32_t r = 0; r < n_rooms; ++r)
+        if (room_floor[r] < 0 || room_floor[r] >= n_floors) return HMSG_ERR_INVALID;
+    for (int32_t o = 0; o < n_objects; ++o)
+        if (obj_room[o] < -1 || obj_room[o] >= n_rooms) return HMSG_ERR_INVALID;
+    try {
+        const int64_t f0 = 1, r0 = f0 + n_floors, o0 = r0 + n_rooms, v0 = o0 + n_objects;
+        std::vector<std::vector<int32_t>> rooms_of((size_t)n_floors), objs_of((size_t)n_rooms);
+        for (int32_t r = 0; r < n_rooms; ++r) rooms_of[(size_t)room_floor[r]].push_back(r);
+        for (int32_t o = 0; o < n_objects; ++o)
+            if (obj_room[o] >= 0) objs_of[(size_t)obj_room[o]].push_back(o);
+        int64_t cnt = 0;
+        auto emit = [&](int64_t a, int64_t b) {
+            if (cnt < capacity) {
+                edges[cnt * 2] = a;
+                edges[cnt * 2 + 1] = b;
+            }
+            ++cnt;
+        };
+        for (int32_t f = 0; f < n_floors; ++f) {
+            emit(0, f0 + f);
+            for (int32_t r : rooms_of[(size_t)f]) {
+                emit(f0 + f, r0 + r);
+                for (int32_t o : objs_of[(size_t)r]) emit(r0 + r, o0 + o);
+            }
+        }
+        std::vector<int32_t> objs;
+        for (int32_t v = 0; v < n_views; ++v) {
+            if (view_room[v] >= n_rooms) return HMSG_ERR_INVALID;
+            if (view_room[v] >= 0) emit(r0 + view_room[v], v0 + v);
+            const int64_t a = view_obj_off[v], b = view_obj_off[v + 1];
+            if (a > b || (b > a && !view_obj)) return HMSG_ERR_INVALID;
+            objs.assign(view_obj + a, view_obj + b);
+            std::sort(objs.begin(), objs.end());
+            objs.erase(std::unique(objs.begin(), objs.end()), objs.end());
+            for (int32_t o : objs) {
+                if (o < 0 || o >= n_objects) return HMSG_ERR_INVALID;
+                emit(v0 + v, o0 + o);
+            }
+        }
+        *n_edges = cnt;
+        return cnt <= capacity ? HMSG_OK : HMSG_ERR_INVALID;
+    } catch (const std::bad_alloc&) {
+        return HMSG_ERR_NOMEM;
+    }
+}

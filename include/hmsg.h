@@ -377,6 +377,39 @@ int hmsg_write_json(const char* path, int32_t n_fields, const hmsg_json_field* f
 int hmsg_write_ply(const char* path, const double* xyz, int64_t n);
 int hmsg_read_json_numbers(const char* path, const char* key, double* out, int64_t capacity, int64_t* n);
 
+/* ---- A9 / A11 bookkeeping for a C / C++ host (host arrays in, host arrays out; no device work).
+ *
+ * hmsg_assign_cameras_to_rooms -- compute_room_embeddings' camera -> room step (utils/graph_utils.py:257-291): camera i, if its
+ * height cam_height[i] lies inside [y_min, y_max] (the floor cloud's bounds), goes to the room with the smallest
+ * dist[i * n_rooms + r] (hmsg_room_camera_distances / hmsg_min_dist_2d; first minimum, as np.argmin); a room that got no camera
+ * takes the closest camera OUTSIDE the bounds (sic; camera 0 when there is none, as np.argmin over a table of inf).
+ * room_of_cam[n_cams]: the room of every camera inside the bounds, -1 for the others.  The rooms' image lists come back as
+ * a CSR table: room_off[n_rooms + 1], room_imgs[room_off[r] .. room_off[r + 1]) in ascending camera order (capacity
+ * n_cams + n_rooms entries).
+ *
+ * hmsg_pick_representative_views -- what follows KMeans in compute_room_embeddings (:334-352): for every label that occurs
+ * (ascending, as np.unique), the member whose embedding has the largest dot product with its cluster centre (first maximum).
+ * The KMeans fit itself stays on the host side of the boundary: the reference calls scikit-learn's
+ * KMeans(n_clusters = num_views, n_init = 5, max_iter = 100, random_state = 0) and so does holoagent_amd/graph.py; a C host brings
+ * labels and centres from whatever KMeans it links.  embs [n x D] and centers [k x D] are float32; the products are accumulated
+ * in float64.  (A cluster of two members is an exact tie -- both are equally far from their mean -- which the reference
+ * decides by float32 rounding inside np.dot; there, and only there, the pick may be the other member.)
+ * out_member[<= k]: indices into the room's image list, one per label present; *n_out their number.
+ *
+ * hmsg_graph_edges -- create_graph_new (graph.py:1752-1775) as an edge list.  Node ids: 0 = the building, then the floors,
+ * the rooms (in the order of room_floor), the objects, the views.  Edges in the reference's insertion order: per floor
+ * (0, floor); per room of the floor (floor, room); per object of the room, ascending (room, object); then per view
+ * (room, view) if view_room[v] >= 0 (a freshly built graph has none: graph.py:1176-1189 compares a string id with an int),
+ * and (view, object) for its objects view_obj[view_obj_off[v] .. view_obj_off[v + 1]) in ascending object order, each once.
+ * edges: capacity pairs of int64; *n_edges is set even when the capacity is too small (HMSG_ERR_INVALID then). */
+int hmsg_assign_cameras_to_rooms(const double* dist, int64_t n_cams, int32_t n_rooms, const double* cam_height, double y_min,
+                                 double y_max, int32_t* room_of_cam, int64_t* room_off, int32_t* room_imgs);
+int hmsg_pick_representative_views(const float* embs, int64_t n, int32_t dim, const int32_t* labels, const float* centers,
+                                   int32_t k, int32_t* out_member, int32_t* n_out);
+int hmsg_graph_edges(int32_t n_floors, int32_t n_rooms, const int32_t* room_floor, int32_t n_objects, const int32_t* obj_room,
+                     int32_t n_views, const int32_t* view_room, const int64_t* view_obj_off, const int32_t* view_obj,
+                     int64_t* edges, int64_t capacity, int64_t* n_edges);
+
 /* ---- A12: retrieval over a node table (graph.py:3056-3162 query_hmsg_object and the GEMV of
  * query_hmsg_room / query_floor).  A table is N node embeddings (f64, as after load_hmsg_graph:
  * object.py:88-89, or f32 right after build) with a parent (room) id per node. */
