@@ -586,6 +586,7 @@ struct hmsg_ctx {
     // crop), room offsets, floor point -> map point
     DevBuf<int> room_sel, room_fmap;
     DevBuf<long long> room_off_dev;
+    std::shared_ptr<void> room_scratch;   // hmsg_room_clouds' work buffers (hmsg_graph.hip: RoomScratch), kept from scene to scene
     int room_n = 0;
     long long room_total = 0;
     std::vector<int> node_label;   // per instance: arg-max label (-1 without a vocabulary)

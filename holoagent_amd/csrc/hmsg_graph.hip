@@ -197,6 +197,16 @@ struct RoomTie {
     int room;
     double x, y, z;
 };
+struct RoomScratch {            // hmsg_room_clouds' work buffers (hmsg_ctx::room_scratch)
+    DevBuf<unsigned char> ok, mark;
+    DevBuf<unsigned> okw, frank, nt, ccnt, cstart, ccur, fl, pos;
+    DevBuf<double> dT, dz, dxz;
+    DevBuf<long long> doff;
+    DevBuf<RoomTie> ties;
+    DevBuf<int> cidx;
+    DevBuf<float> cp32;
+    DevBuf<unsigned long long> ccol;
+};
 __global__ void k_floor_mask(const double* __restrict__ pts, long long V, double y_lo, double y_hi, unsigned char* __restrict__ ok,
                              unsigned* __restrict__ okw) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -444,11 +454,23 @@ extern "C" int hmsg_room_clouds(hmsg_t* h, double y_lo, double y_hi, const doubl
         hipStream_t s = h->stream;
         const long long V = h->V, cells = room_off[n_rooms];
         HMSG_REQUIRE(cells == 0 || room_xz, HMSG_ERR_INVALID, "hmsg_room_clouds: room points missing");
-        DevBuf<unsigned char> ok;
-        DevBuf<unsigned> okw, frank;
-        ok.alloc((size_t)std::max<long long>(V, 1));
-        okw.alloc((size_t)std::max<long long>(V, 1));
-        frank.alloc((size_t)std::max<long long>(V, 1));
+        // The work buffers stay with the handle (grow-only): as locals they went through the thread's allocator cache, where the
+        // other stages of a build take and return blocks of similar sizes -- the call then cost 10 ms or 40 ms depending on
+        // what the cache happened to hold (measured: kernels 9.7 ms every time, library call 11.6 / 27.5 / 38.8 / 10.5 ms over
+        // the first scenes of a process).
+        if (!h->room_scratch) h->room_scratch = std::make_shared<RoomScratch>();
+        RoomScratch& W = *static_cast<RoomScratch*>(h->room_scratch.get());
+        DevBuf<unsigned char>&ok = W.ok, &mark = W.mark;
+        DevBuf<unsigned>&okw = W.okw, &frank = W.frank, &nt = W.nt, &ccnt = W.ccnt, &cstart = W.cstart, &ccur = W.ccur, &fl = W.fl, &pos = W.pos;
+        DevBuf<double>&dT = W.dT, &dz = W.dz, &dxz = W.dxz;
+        DevBuf<long long>& doff = W.doff;
+        DevBuf<RoomTie>& ties = W.ties;
+        DevBuf<int>& cidx = W.cidx;
+        DevBuf<float>& cp32 = W.cp32;
+        DevBuf<unsigned long long>& ccol = W.ccol;
+        ok.ensure((size_t)std::max<long long>(V, 1));
+        okw.ensure((size_t)std::max<long long>(V, 1));
+        frank.ensure((size_t)std::max<long long>(V, 1));
         unsigned long long NFu = 0;
         if (V) {
             hipLaunchKernelGGL(k_floor_mask, dim3(cdiv((size_t)V, 256)), dim3(256), 0, s, (const double*)h->pts.p, V, y_lo, y_hi, ok.p, okw.p);
@@ -460,19 +482,14 @@ extern "C" int hmsg_room_clouds(hmsg_t* h, double y_lo, double y_hi, const doubl
         for (int r = 0; r < n_rooms; ++r) out_sizes[r] = 0;
         if (NF == 0 || cells == 0 || n_levels == 0 || n_rooms == 0) return HMSG_OK;
         HMSG_REQUIRE((long long)n_rooms * NF < (1ll << 33), HMSG_ERR_UNSUPPORTED, "hmsg_room_clouds: too many rooms x floor points");
-        DevBuf<double> dT, dz, dxz;
-        DevBuf<long long> doff;
-        DevBuf<unsigned char> mark;
-        DevBuf<unsigned> nt;
-        DevBuf<RoomTie> ties;
         const unsigned tie_cap = 1u << 20;
-        dT.alloc(16);
-        dz.alloc((size_t)n_levels);
-        dxz.alloc((size_t)cells * 2);
-        doff.alloc((size_t)n_rooms + 1);
-        mark.alloc((size_t)n_rooms * NF);
-        nt.alloc(1);
-        ties.alloc(tie_cap);
+        dT.ensure(16);
+        dz.ensure((size_t)n_levels);
+        dxz.ensure((size_t)cells * 2);
+        doff.ensure((size_t)n_rooms + 1);
+        mark.ensure((size_t)n_rooms * NF);
+        nt.ensure(1);
+        ties.ensure(tie_cap);
         std::vector<long long> hoff((size_t)n_rooms + 1);
         for (int r = 0; r <= n_rooms; ++r) hoff[(size_t)r] = room_off[r];
         HIP_TRY(hipMemcpyAsync(dT.p, T, 128, hipMemcpyHostToDevice, s));
@@ -496,16 +513,12 @@ extern "C" int hmsg_room_clouds(hmsg_t* h, double y_lo, double y_hi, const doubl
         }
         const size_t ncc = (size_t)C.nx * C.ny * C.nz;
         HMSG_REQUIRE(ncc < ((size_t)1 << 31), HMSG_ERR_UNSUPPORTED, "hmsg_room_clouds: map extent too large for the coarse grid");
-        DevBuf<unsigned> ccnt, cstart, ccur;
-        DevBuf<int> cidx;
-        DevBuf<float> cp32;
-        DevBuf<unsigned long long> ccol;
-        ccnt.alloc(ncc + 1);
-        cstart.alloc(ncc + 1);
-        ccur.alloc(ncc + 1);
-        cidx.alloc((size_t)NF);
-        cp32.alloc((size_t)NF * 3);
-        ccol.alloc((size_t)C.nx * C.nz);
+        ccnt.ensure(ncc + 1);
+        cstart.ensure(ncc + 1);
+        ccur.ensure(ncc + 1);
+        cidx.ensure((size_t)NF);
+        cp32.ensure((size_t)NF * 3);
+        ccol.ensure((size_t)C.nx * C.nz);
         HIP_TRY(hipMemsetAsync(ccnt.p, 0, (ncc + 1) * 4, s));
         HIP_TRY(hipMemsetAsync(ccur.p, 0, (ncc + 1) * 4, s));
         HIP_TRY(hipMemsetAsync(ccol.p, 0, (size_t)C.nx * C.nz * 8, s));
@@ -569,13 +582,12 @@ extern "C" int hmsg_room_clouds(hmsg_t* h, double y_lo, double y_hi, const doubl
         if (n_t) HIP_TRY(hipMemcpyAsync(mark.p, hmark.data(), hmark.size(), hipMemcpyHostToDevice, s));       // (the patched ties)
         // compact room lists on the device; they stay with the handle (hmsg_room_camera_distances)
         const size_t nm = (size_t)n_rooms * (size_t)NF;
-        DevBuf<unsigned> fl, pos;
-        fl.alloc(nm);
-        pos.alloc(nm);
+        fl.ensure(nm);
+        pos.ensure(nm);
         hipLaunchKernelGGL(k_rc_flags, dim3(cdiv(nm, 256)), dim3(256), 0, s, (const unsigned char*)mark.p, nm, fl.p);
         HMSG_CHECK_LAUNCH();
         hmsg_scan_u32(fl.p, pos.p, nm, s, h->scan_tmp, nullptr);
-        h->room_off_dev.alloc((size_t)n_rooms + 1);
+        h->room_off_dev.ensure((size_t)n_rooms + 1);
         hipLaunchKernelGGL(k_rc_offsets, dim3(cdiv((size_t)n_rooms + 1, 64)), dim3(64), 0, s, (const unsigned*)pos.p, (const unsigned char*)mark.p, NF, n_rooms,
                            h->room_off_dev.p);
         HMSG_CHECK_LAUNCH();
@@ -583,9 +595,9 @@ extern "C" int hmsg_room_clouds(hmsg_t* h, double y_lo, double y_hi, const doubl
         HIP_TRY(hipMemcpyAsync(hoff2.data(), h->room_off_dev.p, hoff2.size() * 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         const long long total = hoff2[(size_t)n_rooms];
-        h->room_sel.alloc((size_t)std::max<long long>(total, 1));
+        h->room_sel.ensure((size_t)std::max<long long>(total, 1));
         hipLaunchKernelGGL(k_rc_compact, dim3(cdiv(nm, 256)), dim3(256), 0, s, (const unsigned char*)mark.p, (const unsigned*)pos.p, nm, NF, h->room_sel.p);
-        h->room_fmap.alloc((size_t)NF);
+        h->room_fmap.ensure((size_t)NF);
         hipLaunchKernelGGL(k_rc_floor_map, dim3(cdiv((size_t)V, 256)), dim3(256), 0, s, (const unsigned char*)ok.p, (const unsigned*)frank.p, V, h->room_fmap.p);
         HMSG_CHECK_LAUNCH();
         h->room_n = n_rooms;
