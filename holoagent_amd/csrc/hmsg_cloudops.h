@@ -11,6 +11,13 @@ struct SegDesc {                 // one cloud of a batch, points at src[pt_base 
     int n;
     double mn[3], mx[3];         // AABB (host knows it: union of member boxes / reduction result)
     int n_first = 0;             // optional: the segment's first n_first points are one member cloud -- the result then says how many of them were kept
+    // Optional crop (forced = 1): the first member is an ANCHOR (fixed single-cluster cloud, core flags given in core0) larger than
+    // the rest of the segment together, so every point of it is kept and its cluster wins the keep-largest rule whatever the
+    // rest does.  Only its points inside [cmn, cmx] -- the other members' boxes grown by 2 eps -- can change status, connect to
+    // a new point or be a new point's witness; the others are left out of the grid altogether (kept, core flag as given).
+    // fmn / fmx: the first member's own AABB (the result's box is its union with the box of the kept rest).
+    int forced = 0;
+    double cmn[3] = {0, 0, 0}, cmx[3] = {0, 0, 0}, fmn[3] = {0, 0, 0}, fmx[3] = {0, 0, 0};
 };
 
 // A batch assembled from pieces of a point pool: piece [src, src + n) of the pool goes to [dst, dst + n) of the batch
@@ -58,6 +65,7 @@ struct CloudOps {
     hipStream_t s = nullptr;
     Prof* prof = nullptr;        // optional live timing of the heavy kernels
     // work counters of the DBSCAN batches (debug output of the merge stage)
+    double stat_forced = 0, stat_forced_first = 0;     // segments binned with their anchor member cropped, and those members' points
     double stat_calls = 0, stat_points = 0, stat_cells = 0, stat_core_cells = 0, stat_active_cells = 0, stat_maxcell_sum = 0, stat_maxcell_max = 0;
     DevBuf<unsigned> scan_tmp;
     // scratch (grown on demand)

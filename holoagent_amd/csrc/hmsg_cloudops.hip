@@ -27,8 +27,10 @@ struct DbSeg {
     double ox, oy, oz, cs;
     int nx, ny, nz, n;
     long long cell_base, pt_base;
-    int n_first, pad;       // (SegDesc::n_first)
+    int n_first, forced;    // (SegDesc::n_first, SegDesc::forced)
+    double cmn[3], cmx[3];  // (SegDesc::cmn / cmx: the crop of a forced segment's first member)
 };
+#define DB_FAR (-1ll)       /* cellid of a point of a forced segment's first member outside the crop: not in the grid */
 
 #define INF32 0xffffffffu
 
@@ -83,6 +85,11 @@ __global__ void k_db_cell(const double* __restrict__ pts, long long N, int* __re
     }
     segid[i] = lo;
     const DbSeg sg = segs[lo];
+    if (sg.forced && i < sg.pt_base + sg.n_first &&
+        (px < sg.cmn[0] || px > sg.cmx[0] || py < sg.cmn[1] || py > sg.cmx[1] || pz < sg.cmn[2] || pz > sg.cmx[2])) {
+        cellid[i] = DB_FAR;
+        return;
+    }
     int ix = (int)floor((px - sg.ox) / sg.cs), iy = (int)floor((py - sg.oy) / sg.cs), iz = (int)floor((pz - sg.oz) / sg.cs);
     ix = ix < 0 ? 0 : (ix >= sg.nx ? sg.nx - 1 : ix);
     iy = iy < 0 ? 0 : (iy >= sg.ny ? sg.ny - 1 : iy);
@@ -104,7 +111,7 @@ __global__ void k_db_fill(const double* __restrict__ pts, long long N, const lon
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < N;
     bool need = false;
-    if (live) {
+    if (live && cellid[i] != DB_FAR) {
         long long c = cellid[i];
         const unsigned s0 = start[c];
         unsigned p = s0 + atomicAdd(&cursor[c], 1u);
@@ -258,16 +265,19 @@ __global__ void k_db_core(const double* __restrict__ pts, long long N, const int
     const int k_seg = segid[i];
     const DbSeg sg = segs[k_seg];
     long long c = cellid[i];
+    const bool far = c == DB_FAR;            // (a forced segment's anchor point outside the crop: keeps its flag, takes part in nothing)
+    if (far) c = sg.cell_base;               // (any valid cell: nothing below touches it for a far point)
     // anchor points: core points of a member cloud that is a known single-cluster fixed point of this DBSCAN.
     // More points only raise neighbour counts, so they stay core -- no counting needed.
     const bool known = core0 != nullptr && core0[i] != 0;
-    bool is_core = known || cnt[c] >= (unsigned)minpts;
-    if (!is_core && in_range) is_core = core[i] != 0;        // counted by k_db_count (the points k_db_fill listed)
+    bool is_core = known || (!far && cnt[c] >= (unsigned)minpts);
+    if (!is_core && in_range && !far) is_core = core[i] != 0;        // counted by k_db_count (the points k_db_fill listed)
     is_core = is_core && in_range;
     if (in_range) {
         core[i] = is_core ? 1 : 0;
-        score[rank[i]] = is_core ? 1 : 0;
+        if (!far) score[rank[i]] = is_core ? 1 : 0;
     }
+    const bool in_grid = !far;
     const int lane = threadIdx.x & 63;
     // the first core point of a cell (it sees the initial INF) registers the cell in the compact list; a core
     // point that is not an anchor puts its cell on the active list (its connections have to be searched).  List
@@ -277,13 +287,13 @@ __global__ void k_db_core(const double* __restrict__ pts, long long N, const int
     if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
     bool reg = false;
-    if (is_core && (unsigned)(i - sg.pt_base) < minidx[c])     // (stale read is only conservative)
+    if (is_core && in_grid && (unsigned)(i - sg.pt_base) < minidx[c])     // (stale read is only conservative)
         reg = atomicMin(&minidx[c], (unsigned)(i - sg.pt_base)) == INF32;
     // cells holding anchor cores are all connected: k_db_anchor hangs them under the segment's lowest one
-    if (is_core && known && !hasanchor[c]) hasanchor[c] = 1;
+    if (is_core && in_grid && known && !hasanchor[c]) hasanchor[c] = 1;
     bool act = false;
-    if (is_core && !known && !active[c]) act = atomicExch(&active[c], 1u) == 0u;
-    const bool ncp = in_range && !is_core;                     // non-core: the only points k_db_label has to visit
+    if (is_core && in_grid && !known && !active[c]) act = atomicExch(&active[c], 1u) == 0u;
+    const bool ncp = in_range && in_grid && !is_core;          // non-core: the only points k_db_label has to visit
     const unsigned long long m_reg = __ballot(reg), m_act = __ballot(act), m_ncp = __ballot(ncp);
     unsigned off_reg = 0, off_act = 0, off_ncp = 0;
     if (m_ncp) {
@@ -990,7 +1000,7 @@ __global__ void k_db_scatter(const double* __restrict__ pts, long long N, const 
 #define DBK_TRIPS 32
 __global__ void __launch_bounds__(256) k_db_compact(const double* __restrict__ pts, long long N, const int* __restrict__ segid,
                                                     const DbSeg* __restrict__ segs, const int* __restrict__ label,
-                                                    const unsigned long long* __restrict__ best, unsigned* __restrict__ flags_dbg,
+                                                    const unsigned long long* __restrict__ best, const unsigned* __restrict__ rep, unsigned* __restrict__ flags_dbg,
                                                     const unsigned char* __restrict__ core, const long long* __restrict__ cellid,
                                                     const int* __restrict__ parent, double* __restrict__ dst, int* __restrict__ oend,
                                                     int* __restrict__ ostart, int* __restrict__ ofirst, unsigned char* __restrict__ dst_core,
@@ -1012,9 +1022,18 @@ __global__ void __launch_bounds__(256) k_db_compact(const double* __restrict__ p
         if (i >= b1) continue;
         const int k = segid[i];
         const unsigned long long b = best[k];
+        const DbSeg sg = segs[k];
         bool keep = true;                                    // graph_utils.py:853-880 (see k_db_flags)
-        if ((unsigned)(b >> 32) >= 5u) {
-            const long long fm = segs[k].pt_base + (long long)(INF32 - (unsigned)(b & 0xffffffffull));
+        if (sg.forced) {
+            // the anchor member is kept whole and its cluster is the winner (SegDesc::forced); the rest is kept where it joined it
+            if (i >= sg.pt_base + sg.n_first) {
+                const unsigned ra = rep[k];                  // lowest cell with anchor cores (INF32: none inside the crop)
+                const int wl = ra != INF32 ? parent[ra] : -2;
+                const int my = core[i] ? parent[cellid[i]] : label[i];
+                keep = my == wl;
+            }
+        } else if ((unsigned)(b >> 32) >= 5u) {
+            const long long fm = sg.pt_base + (long long)(INF32 - (unsigned)(b & 0xffffffffull));
             const int wl = core[fm] ? parent[cellid[fm]] : label[fm];
             const int my = core[i] ? parent[cellid[i]] : label[i];
             keep = my == wl;
@@ -1070,6 +1089,7 @@ __global__ void __launch_bounds__(256) k_db_compact(const double* __restrict__ p
             if (i == sg.pt_base + sg.n - 1) oend[k] = (int)(p + f);
             const unsigned win = (unsigned)(best[k] >> 32);
             drops = win >= 5u && win < (unsigned)sg.n;
+            if (sg.forced) drops = i >= sg.pt_base + sg.n_first;    // (box of the kept REST: the host unites it with the anchor member's own box)
         }
         if (f && !drops) f = 0u;                                    // segment keeps every point: its input box stays exact
         if (__any(f != 0u && cur >= 0 && k != cur)) {               // somebody leaves its segment: flush all
@@ -1233,6 +1253,8 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     if (K == 0) return 0;
     const double cs = eps / std::sqrt(3.0) * (1.0 - 1e-7);
     std::vector<DbSeg> hs(K);
+    // (SegDesc::forced needs the one-launch compaction; HMSG_DEBUG_NO_CROP=1 bins every anchor whole, as before round 4)
+    const bool forced_ok = getenv("HMSG_DB_COMPACT_SPLIT") == nullptr && getenv("HMSG_DEBUG_NO_CROP") == nullptr;   // (per call: tests switch it)
     long long NC = 0, N = 0;
     long long span_lo = segs[0].pt_base, span_hi = segs[0].pt_base;
     for (int k = 0; k < K; ++k) {
@@ -1242,15 +1264,29 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
         g.n = sd.n;
         g.pt_base = sd.pt_base;
         g.n_first = sd.n_first;
-        g.pad = 0;
+        g.forced = 0;
+        for (int a = 0; a < 3; ++a) g.cmn[a] = g.cmx[a] = 0.0;
         g.cell_base = NC;
         if (sd.n > 0) {
-            g.ox = sd.mn[0];
-            g.oy = sd.mn[1];
-            g.oz = sd.mn[2];
-            g.nx = (int)std::floor((sd.mx[0] - sd.mn[0]) / cs) + 1;
-            g.ny = (int)std::floor((sd.mx[1] - sd.mn[1]) / cs) + 1;
-            g.nz = (int)std::floor((sd.mx[2] - sd.mn[2]) / cs) + 1;
+            double lo[3] = {sd.mn[0], sd.mn[1], sd.mn[2]}, hi[3] = {sd.mx[0], sd.mx[1], sd.mx[2]};
+            if (sd.forced && core0 && forced_ok && sd.n_first > 0 && sd.n_first < sd.n) {
+                // the grid covers the crop only (every point that is binned lies inside it)
+                g.forced = 1;
+                stat_forced += 1;
+                stat_forced_first += sd.n_first;
+                for (int a = 0; a < 3; ++a) {
+                    g.cmn[a] = sd.cmn[a];
+                    g.cmx[a] = sd.cmx[a];
+                    lo[a] = std::max(lo[a], sd.cmn[a]);
+                    hi[a] = std::max(lo[a], std::min(hi[a], sd.cmx[a]));
+                }
+            }
+            g.ox = lo[0];
+            g.oy = lo[1];
+            g.oz = lo[2];
+            g.nx = (int)std::floor((hi[0] - lo[0]) / cs) + 1;
+            g.ny = (int)std::floor((hi[1] - lo[1]) / cs) + 1;
+            g.nz = (int)std::floor((hi[2] - lo[2]) / cs) + 1;
         } else {
             g.ox = g.oy = g.oz = 0;
             g.nx = g.ny = g.nz = 1;
@@ -1407,7 +1443,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
         const unsigned epoch = hmsg_scan_epoch(scan_tmp, gK, s);
         ProfScope ps(prof, s, "k_db_scatter", (double)N * 56.0);
         hipLaunchKernelGGL(k_db_compact, dim3(gK), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const int*)label.p,
-                           (const unsigned long long*)best.p, dump_wanted ? flags.p : (unsigned*)nullptr, (const unsigned char*)core.p,
+                           (const unsigned long long*)best.p, (const unsigned*)rep.p, dump_wanted ? flags.p : (unsigned*)nullptr, (const unsigned char*)core.p,
                            (const long long*)cellid.p, (const int*)parent.p, dst, d_ocount, d_ostart, d_ofirst, dst_core, d_obounds,
                            reinterpret_cast<unsigned long long*>(scan_tmp.p), epoch);
     }
@@ -1452,6 +1488,12 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
             // unchanged: the input box is exact (and maybe tighter bookkeeping upstream relies on it bit for bit)
             res[k].mn[a] = !n_out ? 0.0 : (res[k].changed ? dec_f64(hb[(size_t)k * 6 + a]) : segs[k].mn[a]);
             res[k].mx[a] = !n_out ? 0.0 : (res[k].changed ? dec_f64(hb[(size_t)k * 6 + 3 + a]) : segs[k].mx[a]);
+            if (hs[k].forced && res[k].changed) {
+                // the anchor member whole (its own box) + the kept rest (the device's box; none kept: the untouched initial value)
+                const bool any_rest = n_out > segs[k].n_first;
+                res[k].mn[a] = any_rest ? std::min(segs[k].fmn[a], dec_f64(hb[(size_t)k * 6 + a])) : segs[k].fmn[a];
+                res[k].mx[a] = any_rest ? std::max(segs[k].fmx[a], dec_f64(hb[(size_t)k * 6 + 3 + a])) : segs[k].fmx[a];
+            }
         }
         total += n_out;
     }

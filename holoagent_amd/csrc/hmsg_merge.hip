@@ -884,6 +884,35 @@ struct Merger {
                 }
                 any = true;
             }
+            // Crop (SegDesc::forced): the first member is the component's anchor and larger than the rest together -- all of it
+            // is kept and its cluster wins; only what lies within 2 eps of the other members' boxes goes into the DBSCAN grid.
+            if (use_anchor && anchor_i >= 0 && sd.n_first > 0 && sd.n_first < sd.n && (long long)sd.n_first * 2 > (long long)sd.n) {
+                int f = -1;
+                for (int i : mem)
+                    if (L[i].n > 0) {
+                        f = i;
+                        break;
+                    }
+                if (f == anchor_i) {
+                    bool any_r = false;
+                    for (int i : mem) {
+                        if (i == f || L[i].n == 0) continue;
+                        for (int a = 0; a < 3; ++a) {
+                            sd.cmn[a] = any_r ? std::min(sd.cmn[a], L[i].mn[a]) : L[i].mn[a];
+                            sd.cmx[a] = any_r ? std::max(sd.cmx[a], L[i].mx[a]) : L[i].mx[a];
+                        }
+                        any_r = true;
+                    }
+                    const double grow = 2.0 * eps * (1.0 + 1e-9) + 1e-6;
+                    for (int a = 0; a < 3; ++a) {
+                        sd.cmn[a] -= grow;
+                        sd.cmx[a] += grow;
+                        sd.fmn[a] = L[f].mn[a];
+                        sd.fmx[a] = L[f].mx[a];
+                    }
+                    sd.forced = any_r ? 1 : 0;
+                }
+            }
             seg_of_comp[c] = (int)segs.size();
             segs.push_back(sd);
         }
@@ -1227,6 +1256,9 @@ static void merge_report(Folder& m) {
         fprintf(stderr, "[hmsg merge] dbscan batches %.0f: mean points %.0f  grid cells %.0f  core cells %.0f  active cells %.0f\n",
                 m.ops.stat_calls, m.ops.stat_points / m.ops.stat_calls, m.ops.stat_cells / m.ops.stat_calls,
                 m.ops.stat_core_cells / m.ops.stat_calls, m.ops.stat_active_cells / m.ops.stat_calls);
+    if (getenv("HMSG_DEBUG_TIMING") && m.ops.stat_calls > 0)
+        fprintf(stderr, "[hmsg merge] dbscan segments with a cropped anchor member: %.0f (%.0f anchor points a batch)\n", m.ops.stat_forced,
+                m.ops.stat_forced_first / m.ops.stat_calls);
     if (getenv("HMSG_DEBUG_MAXCELL") && m.ops.stat_calls > 0)
         fprintf(stderr, "[hmsg merge] fullest cell of a dbscan batch: mean %.0f points, max %.0f\n", m.ops.stat_maxcell_sum / m.ops.stat_calls, m.ops.stat_maxcell_max);
 }

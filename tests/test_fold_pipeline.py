@@ -161,3 +161,43 @@ def test_inherited_overlap_grids_on_the_gpu():
     assert _device_scene(L, spec, inp, nopipe=True) == ref
     assert _device_scene(L, spec, inp, nopipe=False) == ref
     assert _device_scene(L, spec, inp, nopipe=True, env={"HMSG_DEBUG_GRID_DELTA_ALWAYS": "1"}) == ref
+
+
+@pytest.mark.gpu
+def test_cropped_anchor_members_on_the_gpu():
+    """configs[1]'s scene, 300 frames: DBSCAN batches that bin only the part of an anchor member within 2 eps of the component's
+    other members (SegDesc::forced, the default) against batches that bin every anchor whole (HMSG_DEBUG_NO_CROP=1) and against
+    the fold without the anchor hint at all (HMSG_DEBUG_NOANCHOR=1): same instances, same pooled features."""
+    import torch
+    import bench
+    from holoagent_amd._lib import HmsgLib
+    from holoagent_amd.synth import SceneSpec
+    L = HmsgLib()
+    spec = SceneSpec(seed=4321, n_frames=300, feat_dim=64, n_masks=32)
+    inp = bench.build_scene_inputs(L, spec, torch.device("cuda", 0), torch)
+    ref = _device_scene(L, spec, inp, nopipe=True, env={"HMSG_DEBUG_NO_CROP": "1"})
+    assert ref[0][0] > 50
+    assert _device_scene(L, spec, inp, nopipe=True) == ref
+    assert _device_scene(L, spec, inp, nopipe=False) == ref
+    assert _device_scene(L, spec, inp, nopipe=True, env={"HMSG_DEBUG_NOANCHOR": "1"}) == ref
+
+
+@pytest.mark.skipif(not os.path.exists(PC.EMU_PATH), reason="kernel simulator not built")
+def test_cropped_anchor_members_on_the_simulator(capfd):
+    from holoagent_amd._lib import HmsgLib
+    from holoagent_amd.synth import SceneSpec, SynthScene
+    L = HmsgLib(PC.EMU_PATH)
+    spec = SceneSpec(seed=21, rooms_x=1, rooms_z=1, room_size=(3.6, 2.5, 3.2), objects_per_room=4, width=64, height=48,
+                     n_frames=8, n_masks=5, feat_dim=16)
+    scn = SynthScene(spec)
+    frames = [scn.frame(i) for i in range(spec.n_frames)]
+    ref, ref_f = _host_scene(L, frames, 16, nopipe=True, env={"HMSG_DEBUG_NO_CROP": "1", "HMSG_DEBUG_TIMING": "1"})
+    err0 = capfd.readouterr().err
+    got, got_f = _host_scene(L, frames, 16, nopipe=True, env={"HMSG_DEBUG_TIMING": "1"})
+    err1 = capfd.readouterr().err
+    import re
+    assert re.search(r"cropped anchor member: 0 ", err0), err0
+    m = re.search(r"cropped anchor member: (\d+) ", err1)
+    assert m and int(m.group(1)) >= 2, err1
+    assert len(ref) >= 3 and len(got) == len(ref) and all(np.array_equal(a, b) for a, b in zip(got, ref))
+    assert np.array_equal(got_f, ref_f)
