@@ -6,7 +6,6 @@
 #pragma once
 #include "hmsg_common.h"
 
-#define DB_NCROP 4
 struct SegDesc {                 // one cloud of a batch, points at src[pt_base .. pt_base+n)
     long long pt_base;
     int n;
@@ -17,12 +16,8 @@ struct SegDesc {                 // one cloud of a batch, points at src[pt_base 
     // rest does.  Only its points inside [cmn, cmx] -- the other members' boxes grown by 2 eps -- can change status, connect to
     // a new point or be a new point's witness; the others are left out of the grid altogether (kept, core flag as given).
     // fmn / fmx: the first member's own AABB (the result's box is its union with the box of the kept rest).
-    // The crop itself is the union of up to DB_NCROP boxes (one per other member while they are few: masks are object-sized,
-    // and their common box can span the room); [cmn, cmx] is the box around them all (the grid's extent).
     int forced = 0;
     double cmn[3] = {0, 0, 0}, cmx[3] = {0, 0, 0}, fmn[3] = {0, 0, 0}, fmx[3] = {0, 0, 0};
-    int ncrop = 0;
-    double cbox[4][6] = {};      // DB_NCROP boxes: mn[3], mx[3]
 };
 
 // A batch assembled from pieces of a point pool: piece [src, src + n) of the pool goes to [dst, dst + n) of the batch

@@ -28,9 +28,7 @@ struct DbSeg {
     int nx, ny, nz, n;
     long long cell_base, pt_base;
     int n_first, forced;    // (SegDesc::n_first, SegDesc::forced)
-    double cmn[3], cmx[3];  // (SegDesc::cmn / cmx: box around the crop of a forced segment's first member)
-    int ncrop, pad;
-    double cbox[DB_NCROP][6];   // (SegDesc::cbox: the crop is the union of these)
+    double cmn[3], cmx[3];  // (SegDesc::cmn / cmx: the crop of a forced segment's first member)
 };
 #define DB_FAR (-1ll)       /* cellid of a point of a forced segment's first member outside the crop: not in the grid */
 
@@ -87,14 +85,10 @@ __global__ void k_db_cell(const double* __restrict__ pts, long long N, int* __re
     }
     segid[i] = lo;
     const DbSeg sg = segs[lo];
-    if (sg.forced && i < sg.pt_base + sg.n_first) {
-        bool near = false;
-        for (int q = 0; q < sg.ncrop; ++q)
-            near = near || !(px < sg.cbox[q][0] || px > sg.cbox[q][3] || py < sg.cbox[q][1] || py > sg.cbox[q][4] || pz < sg.cbox[q][2] || pz > sg.cbox[q][5]);
-        if (!near) {
-            cellid[i] = DB_FAR;
-            return;
-        }
+    if (sg.forced && i < sg.pt_base + sg.n_first &&
+        (px < sg.cmn[0] || px > sg.cmx[0] || py < sg.cmn[1] || py > sg.cmx[1] || pz < sg.cmn[2] || pz > sg.cmx[2])) {
+        cellid[i] = DB_FAR;
+        return;
     }
     int ix = (int)floor((px - sg.ox) / sg.cs), iy = (int)floor((py - sg.oy) / sg.cs), iz = (int)floor((pz - sg.oz) / sg.cs);
     ix = ix < 0 ? 0 : (ix >= sg.nx ? sg.nx - 1 : ix);
@@ -1271,19 +1265,13 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
         g.pt_base = sd.pt_base;
         g.n_first = sd.n_first;
         g.forced = 0;
-        g.ncrop = g.pad = 0;
         for (int a = 0; a < 3; ++a) g.cmn[a] = g.cmx[a] = 0.0;
-        for (int q = 0; q < DB_NCROP; ++q)
-            for (int a = 0; a < 6; ++a) g.cbox[q][a] = 0.0;
         g.cell_base = NC;
         if (sd.n > 0) {
             double lo[3] = {sd.mn[0], sd.mn[1], sd.mn[2]}, hi[3] = {sd.mx[0], sd.mx[1], sd.mx[2]};
-            if (sd.forced && sd.ncrop > 0 && core0 && forced_ok && sd.n_first > 0 && sd.n_first < sd.n) {
+            if (sd.forced && core0 && forced_ok && sd.n_first > 0 && sd.n_first < sd.n) {
                 // the grid covers the crop only (every point that is binned lies inside it)
                 g.forced = 1;
-                g.ncrop = std::min(sd.ncrop, DB_NCROP);
-                for (int q = 0; q < g.ncrop; ++q)
-                    for (int a = 0; a < 6; ++a) g.cbox[q][a] = sd.cbox[q][a];
                 stat_forced += 1;
                 stat_forced_first += sd.n_first;
                 for (int a = 0; a < 3; ++a) {

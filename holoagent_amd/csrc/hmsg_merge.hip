@@ -895,24 +895,18 @@ struct Merger {
                     }
                 if (f == anchor_i) {
                     bool any_r = false;
-                    const double grow = 2.0 * eps * (1.0 + 1e-9) + 1e-6;
-                    sd.ncrop = 0;
                     for (int i : mem) {
                         if (i == f || L[i].n == 0) continue;
                         for (int a = 0; a < 3; ++a) {
-                            sd.cmn[a] = any_r ? std::min(sd.cmn[a], L[i].mn[a] - grow) : L[i].mn[a] - grow;
-                            sd.cmx[a] = any_r ? std::max(sd.cmx[a], L[i].mx[a] + grow) : L[i].mx[a] + grow;
+                            sd.cmn[a] = any_r ? std::min(sd.cmn[a], L[i].mn[a]) : L[i].mn[a];
+                            sd.cmx[a] = any_r ? std::max(sd.cmx[a], L[i].mx[a]) : L[i].mx[a];
                         }
                         any_r = true;
-                        // a box of its own while there are boxes left; the last one takes every further member in
-                        const int q = std::min(sd.ncrop, DB_NCROP - 1);
-                        for (int a = 0; a < 3; ++a) {
-                            sd.cbox[q][a] = q < sd.ncrop ? std::min(sd.cbox[q][a], L[i].mn[a] - grow) : L[i].mn[a] - grow;
-                            sd.cbox[q][3 + a] = q < sd.ncrop ? std::max(sd.cbox[q][3 + a], L[i].mx[a] + grow) : L[i].mx[a] + grow;
-                        }
-                        sd.ncrop = std::max(sd.ncrop, q + 1);
                     }
+                    const double grow = 2.0 * eps * (1.0 + 1e-9) + 1e-6;
                     for (int a = 0; a < 3; ++a) {
+                        sd.cmn[a] -= grow;
+                        sd.cmx[a] += grow;
                         sd.fmn[a] = L[f].mn[a];
                         sd.fmx[a] = L[f].mx[a];
                     }
