@@ -369,12 +369,10 @@ __global__ void __launch_bounds__(256) k_room_nn(CoarseGrid C, const double* __r
                             const float fx = __fsub_rn(C.p32[(size_t)k * 3], qxf), fy = __fsub_rn(C.p32[(size_t)k * 3 + 1], qyf),
                                         fz = __fsub_rn(C.p32[(size_t)k * 3 + 2], qzf);
                             const float f2 = fx * fx + fy * fy + fz * fz;
-                            if (__any(f2 <= bestf)) {
+                            if (f2 <= bestf) {               // (a wave in which no lane passes skips the body: no vote needed)
                                 const int q = C.idx[k];
-                                if (f2 <= bestf) {
-                                    nn_consider(best, q, nn_dist2(map_pts + (size_t)q * 3, px, py, pz));
-                                    bestf = best_bound(best.d2);
-                                }
+                                nn_consider(best, q, nn_dist2(map_pts + (size_t)q * 3, px, py, pz));
+                                bestf = best_bound(best.d2);
                             }
                         }
                     }
