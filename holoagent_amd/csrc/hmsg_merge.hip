@@ -93,7 +93,6 @@ struct OvTask {             // count points of grid[x] within r of grid[y]
     int x, y;
     int dep_n;              // second-direction tasks: number of points of the pair's smaller cloud (see k_ov_query)
     int blk0;               // first workgroup of this task (work list)
-    int nblk;               // workgroups of this task
 };
 
 }  // namespace
@@ -252,29 +251,12 @@ static const int OV_CHUNK = 256;       /* points per workgroup of the overlap sc
 // dep_counts (optional): the pair's first direction (the SMALLER cloud against the larger) has already been counted;
 // when that ratio alone exceeds the threshold the pair merges whatever this direction gives -- max(a, b) > th --
 // so the scan of the larger cloud is skipped (sequential merge: only the decision is needed, not the value).
-// Both directions of every pair in ONE launch: tasks [0, P) are the first direction, [P, 2P) the second, whose workgroups come
-// behind all of the first direction's in the grid.  With a threshold (sequential merge) a second-direction workgroup waits until
-// the pair's first direction has been counted in full -- its workgroups, dispatched earlier, each raise done[pair] once after
-// their last count has gone out -- and leaves if that ratio decides the pair.  (Two launches cost the chain of the first plus
-// the chain of the second; now the second direction of one pair runs beside the first direction of the others.)
 __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __restrict__ gr, const OvTask* __restrict__ tasks,
                            const unsigned* __restrict__ cells, const float* __restrict__ sorted, float r2, float r,
-                           int P, unsigned* __restrict__ counts, unsigned* __restrict__ done, bool decide, double th, int chunk) {
-    const int ti = find_entry(tasks, 2 * P, blockIdx.x);
+                           int ntasks, unsigned* __restrict__ counts, const unsigned* __restrict__ dep_counts, double th, int chunk) {
+    const int ti = find_entry(tasks, ntasks, blockIdx.x);
     const OvTask t = tasks[ti];
-    const bool second = ti >= P;
-    const bool dep_counts = second && decide;
-    if (dep_counts) {
-        __shared__ unsigned s_first;
-        if (threadIdx.x == 0) {
-            const unsigned need = (unsigned)tasks[ti - P].nblk;
-            while (__hip_atomic_load(&done[ti - P], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-            }
-            s_first = __hip_atomic_load(&counts[ti - P], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        if ((double)s_first / (double)t.dep_n > th) return;
-    }
+    if (dep_counts && (double)dep_counts[ti] / (double)t.dep_n > th) return;
     const OvGrid X = gr[t.x], Y = gr[t.y];
     if (dep_counts) {
         // Second direction, first ratio <= th: the pair merges only if MORE than th * |X| points of X (the larger cloud) have
@@ -346,13 +328,6 @@ __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __rest
     }
     for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(&counts[ti], local);
-    if (!second && decide) {                 // this workgroup's share of the first direction is in
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __threadfence();
-            atomicAdd(&done[ti], 1u);
-        }
-    }
 }
 
 static const int CAT_CHUNK = 512;      /* points per workgroup of k_concat */
@@ -687,19 +662,18 @@ struct Merger {
                     push_grids(L[v], g);
                 }
             if (L[a].n > L[b].n) std::swap(a, b);  // a = the smaller cloud
-            tasks[k] = OvTask{slot[a], slot[b], 0, (int)nblk1, (int)cdiv((size_t)L[a].n, OV_CHUNK)};
-            tasks[P + k] = OvTask{slot[b], slot[a], L[a].n, (int)nblk2, (int)cdiv((size_t)L[b].n, OV_CHUNK)};
+            tasks[k] = OvTask{slot[a], slot[b], 0, (int)nblk1};
+            tasks[P + k] = OvTask{slot[b], slot[a], L[a].n, (int)nblk2};
             nblk1 += cdiv((size_t)L[a].n, OV_CHUNK);
             nblk2 += cdiv((size_t)L[b].n, OV_CHUNK);
         }
-        for (size_t k = 0; k < P; ++k) tasks[P + k].blk0 += (int)nblk1;      // (one grid: the second direction behind the first)
-        const size_t off_t = (g.size() * sizeof(OvGrid) + 15) & ~(size_t)15, off_c = (off_t + tasks.size() * sizeof(OvTask) + 15) & ~(size_t)15,
-                     pack = off_c + tasks.size() * 4 + P * 4;         // (counts of both directions, then the first direction's done counters)
+        const size_t off_t = (g.size() * sizeof(OvGrid) + 15) & ~(size_t)15, off_c = off_t + tasks.size() * sizeof(OvTask),
+                     pack = off_c + tasks.size() * 4;
         h_ovpack.ensure(pack);
         d_ovpack.ensure(pack);
         memcpy(h_ovpack.p, g.data(), g.size() * sizeof(OvGrid));
         memcpy(h_ovpack.p + off_t, tasks.data(), tasks.size() * sizeof(OvTask));
-        memset(h_ovpack.p + off_c, 0, tasks.size() * 4 + P * 4);
+        memset(h_ovpack.p + off_c, 0, tasks.size() * 4);
         upload_pinned(d_ovpack.p, h_ovpack.p, pack, s);
         const OvGrid* const dg = (const OvGrid*)d_ovpack.p;
         const OvTask* const dt = (const OvTask*)(d_ovpack.p + off_t);
@@ -709,9 +683,14 @@ struct Merger {
         const size_t prof_idx = ops.prof->ev.size();        // (algorithmic bytes are filled in after the read-back)
         {
             ProfScope ps(ops.prof, s, "k_ov_query", 0.0);       // (the kernel launches only: not the read-back below)
-            if (nblk1 + nblk2)
-                hipLaunchKernelGGL(k_ov_query, dim3(nblk1 + nblk2), dim3(256), 0, s, (const double*)pool.p, dg, dt, (const unsigned*)ix_cells.p,
-                                   (const float*)ix_pts.p, r2, r, (int)P, dc, dc + tasks.size(), decide_th >= 0.0, decide_th, OV_CHUNK);
+            for (int dir = 0; dir < 2; ++dir) {
+                const unsigned nb = dir ? nblk2 : nblk1;
+                if (!nb) continue;
+                const size_t o = (size_t)dir * P;
+                hipLaunchKernelGGL(k_ov_query, dim3(nb), dim3(256), 0, s, (const double*)pool.p, dg, dt + o,
+                                   (const unsigned*)ix_cells.p, (const float*)ix_pts.p, r2, r, (int)P, dc + o,
+                                   (dir && decide_th >= 0.0) ? (const unsigned*)dc : (const unsigned*)nullptr, decide_th, OV_CHUNK);
+            }
         }
         HMSG_CHECK_LAUNCH();
         pub_counts.launch(s, (const unsigned*)dc, tasks.size());
