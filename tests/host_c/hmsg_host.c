@@ -11,7 +11,8 @@
  *   out: i64 V, N, n_floors, n_nodes | i64 sizes[N] | f32 feats[N][D] | i32 idx[Q][k] | f64 score[Q][k]
  *        | i64 n_rooms, rows, cols, n_nodes2 | i32 markers[rows][cols] | i32 nsel[Q] | i32 sel[Q][8] | i32 hidx[Q][k] | f64 hscore[Q][k]
  *   (second part: rooms of storey 0 by the device room segmentation (hmsg_segment_rooms), their regions as the room
- *    vertices of hmsg_build_object_nodes, and the coarse-to-fine query floor -> room by name -> objects, hmsg_query_hier) */
+ *    vertices of hmsg_build_object_nodes, create_graph_new's edges of that graph (hmsg_graph_edges), and the coarse-to-fine
+ *    query floor -> room by name -> objects, hmsg_query_hier) */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -48,7 +49,9 @@ int main(int argc, char** argv) {
     float *f_g, *f_masked, *f_crop, *text, *room_text;
     double* room_names;
     int32_t rows = 0, cols = 0, n_rooms = 0, r, c2, *markers = NULL, *rfl, *froff, *frooms, *rkey, *fid, *mode, *nsel, *sel, *hidx, *hroom;
-    int64_t *voff2, *view_off, out_hd2[4], n_nodes2 = 0, cells;
+    int64_t *voff2, *view_off, out_hd2[4], n_nodes2 = 0, cells, n_edges = 0, *edges = NULL;
+    hmsg_node* nd2;
+    int32_t* obj_room;
     double xz_min[2], *verts2, *hscore;
     hmsg_config cfg;
     hmsg_t* h = NULL;
@@ -196,6 +199,17 @@ int main(int argc, char** argv) {
             CK(hmsg_build_object_nodes(h, n_floors, fz, fh, n_rooms, rfl, voff2, verts2, 0, NULL));
             n_nodes2 = hmsg_num_nodes(h);
             if (n_nodes2 > 0) {
+                /* create_graph_new's edges of this graph (no views here): building - storeys - rooms - objects */
+                nd2 = (hmsg_node*)malloc((size_t)n_nodes2 * sizeof(hmsg_node));
+                obj_room = (int32_t*)malloc((size_t)n_nodes2 * 4);
+                CK(hmsg_get_nodes(h, nd2, NULL));
+                for (c2 = 0; c2 < (int32_t)n_nodes2; ++c2) obj_room[c2] = nd2[c2].room;
+                edges = (int64_t*)malloc((size_t)(1 + n_floors + n_rooms + n_nodes2) * 2 * sizeof(int64_t));
+                if (hmsg_graph_edges(n_floors, n_rooms, rfl, (int32_t)n_nodes2, obj_room, 0, NULL, NULL, NULL, edges,
+                                     (int64_t)(1 + n_floors + n_rooms + n_nodes2), &n_edges) != HMSG_OK)
+                    return 9;
+                free(nd2);
+                free(obj_room);
                 froff = (int32_t*)calloc((size_t)n_floors + 1, 4);
                 frooms = (int32_t*)malloc((size_t)n_rooms * 4);
                 rkey = (int32_t*)malloc((size_t)n_rooms * 4);
@@ -231,6 +245,8 @@ int main(int argc, char** argv) {
     fwrite(sel, 4, (size_t)Q * 8, fo);
     fwrite(hidx, 4, (size_t)Q * (size_t)k, fo);
     fwrite(hscore, sizeof(double), (size_t)Q * (size_t)k, fo);
+    fwrite(&n_edges, sizeof(int64_t), 1, fo);
+    if (n_edges) fwrite(edges, sizeof(int64_t), (size_t)n_edges * 2, fo);
     fclose(fo);
     hmsg_destroy(h);
     printf("hmsg_host ok: V %ld instances %ld floors %d nodes %ld\n", (long)V, (long)N, (int)n_floors, (long)n_nodes);

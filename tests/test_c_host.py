@@ -68,7 +68,9 @@ def _run(lib_path, tmp_path):
     nsel = np.frombuffer(raw, np.int32, Q, o); o += 4 * Q
     sel = np.frombuffer(raw, np.int32, Q * 8, o).reshape(Q, 8); o += 32 * Q
     hidx = np.frombuffer(raw, np.int32, Q * k, o).reshape(Q, k); o += 4 * Q * k
-    hscore = np.frombuffer(raw, np.float64, Q * k, o).reshape(Q, k)
+    hscore = np.frombuffer(raw, np.float64, Q * k, o).reshape(Q, k); o += 8 * Q * k
+    n_edges = int(np.frombuffer(raw, np.int64, 1, o)[0]); o += 8
+    c_edges = np.frombuffer(raw, np.int64, n_edges * 2, o).reshape(n_edges, 2)
     # the same calls through the Python binding
     L = HmsgLib(lib_path)
     sc = PC.make_scene(L, frames, over)
@@ -106,6 +108,10 @@ def _run(lib_path, tmp_path):
         assert list(sel[q][: nsel[q]]) == list(sel2[q]), q
     assert np.array_equal(hidx, hidx2) and np.array_equal(hscore, hscore2)
     ix.close()
+    # create_graph_new's edges from C (hmsg_graph_edges): building - storeys - rooms - objects of this graph
+    from holoagent_amd._lib import graph_edges
+    e2 = graph_edges(len(fl), [0] * n_rooms, [int(n["room"]) for n in nodes2], [], [], lib_=L)
+    assert n_edges == len(e2) == len(fl) + n_rooms + len(nodes2) and np.array_equal(c_edges, e2)
     sc.close()
 
 
