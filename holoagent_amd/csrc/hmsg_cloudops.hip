@@ -674,32 +674,8 @@ __global__ void k_db_union_scan(const double* __restrict__ pts, const int* __res
                 if (lane == leader) lead[1] = true;
                 todo &= ~__ballot(direct[1] && r2[1] == key);
             }
-            // A star, not a chain: the earliest of the roots in play (the cell's own and the leaders') takes every other one
-            // directly, each lane hooking ITS root -- distinct words inside the wave -- where unions of (own root, leader's
-            // root) from every leader at once would all go for the own root's word and all but one would have to walk again.
-            unsigned long long key = ~0ull;                  // order: cells with anchor cores first, then the lower index
-            if (lane == 0) key = ((unsigned long long)(hasanchor[rc] ? 0u : 1u) << 32) | (unsigned)rc;
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-                if (lead[q]) {
-                    const unsigned long long kq = ((unsigned long long)(hasanchor[r2[q]] ? 0u : 1u) << 32) | (unsigned)r2[q];
-                    key = kq < key ? kq : key;
-                }
-            for (int o = 32; o > 0; o >>= 1) {
-                const unsigned long long u = __shfl_xor(key, o);
-                key = u < key ? u : key;
-            }
-            if (key != ~0ull && __any(lead[0] || lead[1])) {
-                const int m = (int)(unsigned)key;
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const bool mine = q < 2 ? lead[q] : lane == 0;
-                    const int r = q < 2 ? r2[q] : rc;
-                    if (!mine || r == m) continue;
-                    if (!(__hip_atomic_load(&parent[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == r && atomicCAS(&parent[r], r, m) == r))
-                        uf_union_from(parent, r, m, hasanchor);
-                }
-            }
+            if (lead[0] || lead[1]) uf_union_from(parent, rc, lead[0] ? r2[0] : r2[1], hasanchor);
+            if (lead[0] && lead[1]) uf_union_from(parent, rc, r2[1], hasanchor);
         }
         // phase B: the whole wave scans the pairs that need it, one after the other -- Chebyshev distance 1 first (they connect
         // most components), then distance 2; a pair that an earlier scan of this cell (or another wave) has connected meanwhile
