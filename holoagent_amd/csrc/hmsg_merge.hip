@@ -1271,7 +1271,9 @@ static void merge_report(Folder& m) {
 //   when the batches' running mean passes `switch_points` points -- and only once every frame has arrived, because the
 //   switch indexes the masks of the frames still to come.
 //     HMSG_FOLD_LEGACY=1: batch fold throughout;  HMSG_FOLD_INCREMENTAL=1: incremental from the first step;
-//     HMSG_FOLD_SWITCH=<points>: the threshold (default 600000: ~0.55 ms per step either way on an MI355X).
+//     HMSG_FOLD_SWITCH=<points>: the threshold (default 1500000.  Round 3: 600000; with round 4's batch step the merge of the
+//     10 000-frame 1280x720 episode takes 4.99 / 4.93 / 4.89 / 4.90 s switching at 0.6 / 1.0 / 1.5 / 3.0 million points and
+//     5.46 s without the switch).
 //   The instances are identical either way.
 struct SeqFold {
     Folder m;
@@ -1282,7 +1284,7 @@ struct SeqFold {
     std::vector<Cloud> G;
     bool incremental = false, never = false;
     int f_switch = -1;
-    double batch_mean = 0.0, switch_points = 600000.0;
+    double batch_mean = 0.0, switch_points = 1500000.0;
 
     void init(hmsg_ctx* hh, hipStream_t stream, Prof* prof) {
         h = hh;
@@ -1292,7 +1294,7 @@ struct SeqFold {
         m.ops.prof = prof;
         if (const char* e = getenv("HMSG_DEBUG_GC_POINTS")) m.gc_pool_points = (size_t)atoll(e);   // (tests: force collections)
         never = getenv("HMSG_FOLD_LEGACY") != nullptr;
-        switch_points = getenv("HMSG_FOLD_INCREMENTAL") ? 0.0 : 600000.0;
+        switch_points = getenv("HMSG_FOLD_INCREMENTAL") ? 0.0 : 1500000.0;
         if (const char* e = getenv("HMSG_FOLD_SWITCH")) switch_points = atof(e);
         if (const char* e = getenv("HMSG_FOLD_BIG_ACTIVE")) m.big_active = atoll(e);   // (development: which components take the batch kernels)
     }
