@@ -260,44 +260,6 @@ __global__ void k_coarse_fill(const double* __restrict__ pts, const unsigned cha
     p32[k * 3 + 1] = (float)pts[i * 3 + 1];
     p32[k * 3 + 2] = (float)pts[i * 3 + 2];
 }
-__device__ inline int coarse_nn(const CoarseGrid& c, const double* __restrict__ pts, double qx, double qy, double qz, int* out_ntie) {
-    int cx, cy, cz;
-    coarse_cell(c, qx, qy, qz, cx, cy, cz);
-    NNBest best{1e300, -1, 0};
-    const int rmax = max(c.nx, max(c.ny, c.nz));
-    for (int r = 0; r <= rmax; ++r) {
-        const int y0 = max(cy - r, 0), y1 = min(cy + r, c.ny - 1);
-        const unsigned long long span = (y1 >= 63 ? ~0ull : ((1ull << (y1 + 1)) - 1ull)) & ~((1ull << y0) - 1ull);
-        unsigned long long shell = 0ull;                         // the two new layers of an inner column
-        if (cy - r >= 0) shell |= 1ull << (cy - r);
-        if (cy + r < c.ny) shell |= 1ull << (cy + r);
-        for (int dx = -r; dx <= r; ++dx) {
-            const int ix = cx + dx;
-            if (ix < 0 || ix >= c.nx) continue;
-            for (int dz = -r; dz <= r; ++dz) {
-                const int iz = cz + dz;
-                if (iz < 0 || iz >= c.nz) continue;
-                const bool rim = dx == -r || dx == r || dz == -r || dz == r;
-                unsigned long long m = c.col[(size_t)ix * c.nz + iz] & (rim ? span : shell);
-                while (m) {
-                    const int iy = __ffsll(m) - 1;
-                    m &= m - 1ull;
-                    const size_t cell = ((size_t)ix * c.nz + iz) * c.ny + iy;
-                    for (unsigned k = c.start[cell]; k < c.start[cell + 1]; ++k) {
-                        const int q = c.idx[k];
-                        nn_consider(best, q, nn_dist2(pts + (size_t)q * 3, qx, qy, qz));
-                    }
-                }
-            }
-        }
-        // every cell within Chebyshev distance r of the query's (clamped) cell is done; a point of any other cell is at
-        // least r cell sides away (the query lies in, or beyond, its own cell)
-        const double m = (double)r * c.cs - 1e-9;
-        if (best.idx >= 0 && m > 0.0 && best.d2 < m * m) break;
-    }
-    *out_ntie = best.ntie;
-    return best.idx;
-}
 // float32 bound for the pre-filter: everything within sqrt(d2) of the query has a float32 squared distance below this.  With
 // coordinates up to ~10^3 m a float32 coordinate is off by <= 6e-5 m, a difference by <= 1.2e-4, the squared distance of points
 // d apart by <= ~2 d 2.1e-4 + 1.4e-7 plus the float32 rounding of the sum (relative 2e-7): margin 1e-3 (d + 1) + 1e-6 d2, generous.
