@@ -1148,27 +1148,30 @@ class Graph:
                 for obj in room.objects:
                     self.graph.add_node(obj, name=obj.name, type="object")
                     self.graph.add_edge(room, obj)
-        obj_pos = None
-        for view in self.views:
-            self.graph.add_node(view, name="view", type="view")
-            for floor in self.floors:
-                hit = False
-                for room in floor.rooms:
-                    if room.room_id == view.room_id:
-                        self.graph.add_edge(room, view)
-                        hit = True
-                        break
-                if hit:
-                    pass                         # (the reference's `break` leaves only the inner loop)
-            # (the reference walks ALL objects per view and tests `object_id in view.object_ids`: views x objects x list length
-            #  string compares, seconds at 1000 views x 800 objects.  Same edges, same order -- objects in list order, each
-            #  once -- from a position table.)
-            if obj_pos is None:
-                obj_pos = {}
-                for k, obj in enumerate(self.objects):
-                    obj_pos.setdefault(obj.object_id, []).append(k)
-            self.graph.add_edges_from((view, self.objects[k])
-                                      for k in sorted({k for oid in view.object_ids for k in obj_pos.get(oid, ())}))
+        # (the reference walks ALL objects per view and tests `object_id in view.object_ids`: views x objects x list length
+        #  string compares, seconds at 1000 views x 800 objects.  Same edges, same order -- per view its Room - View edges, then
+        #  its objects in list order, each once -- from a position table, and handed to networkx in ONE call: the View nodes
+        #  first (an edge adds no node here, so the node order is the reference's), then every edge in its order.)
+        obj_pos = {}
+        for k, obj in enumerate(self.objects):
+            obj_pos.setdefault(obj.object_id, []).append(k)
+        def view_edges(views):
+            for view in views:
+                for floor in self.floors:
+                    for room in floor.rooms:
+                        if room.room_id == view.room_id:
+                            yield (room, view)
+                            break                # (the reference's `break` leaves only the inner loop)
+                for k in sorted({k for oid in view.object_ids for k in obj_pos.get(oid, ())}):
+                    yield (view, self.objects[k])
+        if all(self.graph.has_node(obj) for obj in self.objects):
+            for view in self.views:
+                self.graph.add_node(view, name="view", type="view")
+            self.graph.add_edges_from(view_edges(self.views))
+        else:                                    # an object outside every room would become a node by its first edge: view by view
+            for view in self.views:
+                self.graph.add_node(view, name="view", type="view")
+                self.graph.add_edges_from(view_edges([view]))
 
     # ------------------------------------------------------------------ A11 persistence: graph.py:1801-1987
     def save_hmsg_graph(self, path):
