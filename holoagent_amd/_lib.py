@@ -103,7 +103,7 @@ _SIGS = {
     "hmsg_get_nodes": (C.c_int, [_P, _P, _P]),
     "hmsg_index_from_nodes": (C.c_int, [_P, C.POINTER(_P)]),
     "hmsg_room_clouds": (C.c_int, [_P, C.c_double, C.c_double, _P, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
-    "hmsg_room_camera_distances": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "hmsg_room_camera_distances": (C.c_int, [_P, C.c_int32, C.c_int64, _P, _P]),
     "hmsg_object_views": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int64, _P, _P, C.c_double, C.c_double, _P, _P]),
     "hmsg_segment_floors": (C.c_int, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),
     "hmsg_segment_rooms": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P, C.c_int64, C.POINTER(C.c_int32),
@@ -542,7 +542,7 @@ class Scene:
         hmsg_room_camera_distances); [n, R] f64."""
         q = np.ascontiguousarray(cam_xz, np.float64).reshape(-1, 2)
         out = np.empty((len(q), max(self._room_clouds_n, 1)), np.float64)
-        self._ck(self.L.c.hmsg_room_camera_distances(self.h, len(q), _ptr(q), _ptr(out)))
+        self._ck(self.L.c.hmsg_room_camera_distances(self.h, int(self._room_clouds_n), len(q), _ptr(q), _ptr(out)))
         return out[:, : self._room_clouds_n]
 
     def object_views(self, poses_inv, wh, K, pair_inst, pair_view, min_visible_ratio=0.5, max_depth=10.0):

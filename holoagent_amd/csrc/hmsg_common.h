@@ -308,6 +308,28 @@ inline void d2h_bounce(void* dst, const void* src, size_t bytes) {
         memcpy((unsigned char*)dst + o, stage.p, n);
     }
 }
+// The other direction for large CALLER arrays (a numpy text table of 8 MB): hipMemcpyAsync from pageable memory above the runtime's
+// staging threshold pins the caller's pages on the fly -- measured on the MI355X: 24 ms for the 8.2 MB query table of configs[2]
+// against 0.2 ms below the threshold (D = 512: 4.1 MB).  Bounce through a persistent pinned buffer; returns when the bytes are on
+// their way from pinned memory, i.e. the caller's array may change and later work on `s` sees the data.
+inline void h2d_bounce(void* dst_dev, const void* src_host, size_t bytes, hipStream_t s) {
+    constexpr size_t CH = (size_t)16 << 20;
+    if (!bytes) return;
+    if (bytes <= 65536) {                                   // (small tables: the runtime's own staged copy is as fast)
+        HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, s));
+        return;
+    }
+    static std::mutex mu;
+    static PinnedBuf<unsigned char> stage;
+    std::lock_guard<std::mutex> lk(mu);
+    stage.ensure(std::min(bytes, CH));
+    for (size_t o = 0; o < bytes; o += CH) {
+        const size_t n = std::min(CH, bytes - o);
+        memcpy(stage.p, (const unsigned char*)src_host + o, n);
+        HIP_TRY(hipMemcpyAsync((unsigned char*)dst_dev + o, stage.p, n, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));                   // (the staging buffer is shared: it must be free before the lock goes)
+    }
+}
 // A few KB of tables from PINNED host memory to the device inside the stream, by a small kernel that reads the host memory
 // directly (as k_publish writes it): `hipMemcpyAsync` of such a table is a blit-kernel dispatch of ~6.5 us on this stack, three
 // of them per merge-fold step.  src must be hipHostMalloc'ed memory (PinnedBuf) that stays untouched until the stream passes

@@ -414,6 +414,10 @@ extern "C" int hmsg_room_clouds(hmsg_t* h, double y_lo, double y_hi, const doubl
         hipStream_t s = h->stream;
         const long long V = h->V, cells = room_off[n_rooms];
         HMSG_REQUIRE(cells == 0 || room_xz, HMSG_ERR_INVALID, "hmsg_room_clouds: room points missing");
+        // the resident room lists belong to THIS call from here on: a call that fails or finds nothing must not leave the
+        // previous storey's rooms behind for hmsg_room_camera_distances
+        h->room_n = 0;
+        h->room_total = 0;
         // The work buffers stay with the handle (grow-only): as locals they went through the thread's allocator cache, where the
         // other stages of a build take and return blocks of similar sizes -- the call then cost 10 ms or 40 ms depending on
         // what the cache happened to hold (measured: kernels 9.7 ms every time, library call 11.6 / 27.5 / 38.8 / 10.5 ms over
@@ -440,7 +444,15 @@ extern "C" int hmsg_room_clouds(hmsg_t* h, double y_lo, double y_hi, const doubl
         const long long NF = (long long)NFu;
         *n_floor_points = NF;
         for (int r = 0; r < n_rooms; ++r) out_sizes[r] = 0;
-        if (NF == 0 || cells == 0 || n_levels == 0 || n_rooms == 0) return HMSG_OK;
+        if (NF == 0 || cells == 0 || n_levels == 0 || n_rooms == 0) {
+            if (n_rooms > 0) {                                      // n_rooms empty rooms: every distance to them is inf
+                h->room_off_dev.ensure((size_t)n_rooms + 1);
+                HIP_TRY(hipMemsetAsync(h->room_off_dev.p, 0, ((size_t)n_rooms + 1) * 8, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                h->room_n = n_rooms;
+            }
+            return HMSG_OK;
+        }
         HMSG_REQUIRE((long long)n_rooms * NF < (1ll << 33), HMSG_ERR_UNSUPPORTED, "hmsg_room_clouds: too many rooms x floor points");
         const unsigned tie_cap = 1u << 20;
         dT.ensure(16);
@@ -579,11 +591,13 @@ extern "C" int hmsg_room_clouds(hmsg_t* h, double y_lo, double y_hi, const doubl
 // camera -> room distance table of compute_room_embeddings (utils/graph_utils.py:244-291) from the room clouds the last
 // hmsg_room_clouds call left on the device: room r = the (x, z) of its selected floor points, in the floor cloud's order
 // (np.min over them is order-independent); out f64 [n_q][n_rooms].
-extern "C" int hmsg_room_camera_distances(hmsg_t* h, int64_t n_q, const double* q_xz, double* out) {
+extern "C" int hmsg_room_camera_distances(hmsg_t* h, int32_t n_rooms, int64_t n_q, const double* q_xz, double* out) {
     if (!h || n_q < 0 || (n_q > 0 && (!q_xz || !out))) return HMSG_ERR_INVALID;
     try {
         HIP_TRY(hipSetDevice(h->cfg.device_id));
         HMSG_REQUIRE(h->room_n > 0, HMSG_ERR_INVALID, "hmsg_room_camera_distances: call hmsg_room_clouds first");
+        HMSG_REQUIRE(n_rooms == h->room_n, HMSG_ERR_INVALID,
+                     "hmsg_room_camera_distances: n_rooms is not the room count of the last hmsg_room_clouds call (out is [n_q][n_rooms])");
         if (n_q == 0) return HMSG_OK;
         hipStream_t s = h->stream;
         DevBuf<double> xz, dq, dout;

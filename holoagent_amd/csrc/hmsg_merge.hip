@@ -251,14 +251,23 @@ static const int OV_CHUNK = 256;       /* points per workgroup of the overlap sc
 // dep_counts (optional): the pair's first direction (the SMALLER cloud against the larger) has already been counted;
 // when that ratio alone exceeds the threshold the pair merges whatever this direction gives -- max(a, b) > th --
 // so the scan of the larger cloud is skipped (sequential merge: only the decision is needed, not the value).
+// Round 5: BOTH directions of every pair in ONE launch (tasks [0, P): smaller -> larger, [P, 2P): larger -> smaller; blk_task maps a
+// workgroup to its task -- one load instead of a binary search's chain of eight).  The second direction used to be a second,
+// dependent launch that skipped the pairs the first ratio had decided; the kernel is a chain of dependent look-ups per lane and
+// lasts ~25 us whether it covers one direction or both, so the skipped scans cost less than the launch they saved
+// (HMSG_OV_TWO_LAUNCH=1 keeps the dependent form for comparison: dep_counts != nullptr, blk_off = first workgroup of the launch).
+// Decisions are the same either way: max(a, b) > th does not care about b once a > th.
 __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __restrict__ gr, const OvTask* __restrict__ tasks,
                            const unsigned* __restrict__ cells, const float* __restrict__ sorted, float r2, float r,
-                           int ntasks, unsigned* __restrict__ counts, const unsigned* __restrict__ dep_counts, double th, int chunk) {
-    const int ti = find_entry(tasks, ntasks, blockIdx.x);
+                           int npairs, const int* __restrict__ blk_task, unsigned blk_off, unsigned* __restrict__ counts,
+                           const unsigned* __restrict__ dep_counts, double th, int chunk) {
+    const unsigned blk = blockIdx.x + blk_off;
+    const int ti = blk_task[blk];
     const OvTask t = tasks[ti];
-    if (dep_counts && (double)dep_counts[ti] / (double)t.dep_n > th) return;
+    const bool second = ti >= npairs;
+    if (second && dep_counts && (double)dep_counts[ti - npairs] / (double)t.dep_n > th) return;
     const OvGrid X = gr[t.x], Y = gr[t.y];
-    if (dep_counts) {
+    if (second && th >= 0.0) {
         // Second direction, first ratio <= th: the pair merges only if MORE than th * |X| points of X (the larger cloud) have
         // a point of Y (the smaller one) within r.  Such a point lies in Y's box grown by r, and X's own grid says how many
         // of its points do: the sum of its cell counts over that box (z-cells of a column are contiguous: two loads per
@@ -308,7 +317,7 @@ __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __rest
         __syncthreads();
         inbox = s_in[0] + s_in[1] + s_in[2] + s_in[3];
         if (!((double)inbox / (double)X.n > th)) {
-            if (blockIdx.x == (unsigned)t.blk0 && threadIdx.x == 0) counts[ti] = 0x80000000u;   // (decided by the bound: no scan)
+            if (blk == (unsigned)t.blk0 && threadIdx.x == 0) counts[ti] = 0x80000000u;   // (decided by the bound: no scan)
             return;
         }
     }
@@ -316,7 +325,7 @@ __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __rest
     // a workgroup takes OV_CHUNK consecutive points: every point is a serial chain of L2 round trips, so a
     // million-point X is spread over many workgroups (work list: exactly ceil(n / OV_CHUNK) of them per task)
     {
-        const int b0 = (int)(blockIdx.x - (unsigned)t.blk0) * chunk;
+        const int b0 = (int)(blk - (unsigned)t.blk0) * chunk;
         const int b1 = b0 + chunk < X.n ? b0 + chunk : X.n;
         const OvGrid Y2 = gr[Y.next >= 0 ? Y.next : t.y];      // (Y's delta grid, if it has one)
         for (int i = b0 + (int)threadIdx.x; i < b1; i += blockDim.x) {
@@ -667,29 +676,45 @@ struct Merger {
             nblk1 += cdiv((size_t)L[a].n, OV_CHUNK);
             nblk2 += cdiv((size_t)L[b].n, OV_CHUNK);
         }
+        for (size_t k = 0; k < P; ++k) tasks[P + k].blk0 += (int)nblk1;      // (one work list over both directions)
+        const size_t nblk = (size_t)nblk1 + nblk2;
         const size_t off_t = (g.size() * sizeof(OvGrid) + 15) & ~(size_t)15, off_c = off_t + tasks.size() * sizeof(OvTask),
-                     pack = off_c + tasks.size() * 4;
+                     off_b = off_c + tasks.size() * 4, pack = off_b + nblk * 4;
         h_ovpack.ensure(pack);
         d_ovpack.ensure(pack);
         memcpy(h_ovpack.p, g.data(), g.size() * sizeof(OvGrid));
         memcpy(h_ovpack.p + off_t, tasks.data(), tasks.size() * sizeof(OvTask));
         memset(h_ovpack.p + off_c, 0, tasks.size() * 4);
+        {   // workgroup -> task
+            int* bt = (int*)(h_ovpack.p + off_b);
+            for (size_t k = 0; k < 2 * P; ++k) {
+                const size_t e = k + 1 < 2 * P ? (size_t)tasks[k + 1].blk0 : nblk;
+                for (size_t b = (size_t)tasks[k].blk0; b < e; ++b) bt[b] = (int)k;
+            }
+        }
         upload_pinned(d_ovpack.p, h_ovpack.p, pack, s);
         const OvGrid* const dg = (const OvGrid*)d_ovpack.p;
         const OvTask* const dt = (const OvTask*)(d_ovpack.p + off_t);
         unsigned* const dc = (unsigned*)(d_ovpack.p + off_c);
+        const int* const db = (const int*)(d_ovpack.p + off_b);
         const float r = (float)radius;
         const float r2 = (float)(radius * radius);   // `D < radius**2` with a float32 D (graph_utils.py:654-655)
         const size_t prof_idx = ops.prof->ev.size();        // (algorithmic bytes are filled in after the read-back)
+        static const bool two_launch = getenv("HMSG_OV_TWO_LAUNCH") != nullptr;
         {
             ProfScope ps(ops.prof, s, "k_ov_query", 0.0);       // (the kernel launches only: not the read-back below)
-            for (int dir = 0; dir < 2; ++dir) {
-                const unsigned nb = dir ? nblk2 : nblk1;
-                if (!nb) continue;
-                const size_t o = (size_t)dir * P;
-                hipLaunchKernelGGL(k_ov_query, dim3(nb), dim3(256), 0, s, (const double*)pool.p, dg, dt + o,
-                                   (const unsigned*)ix_cells.p, (const float*)ix_pts.p, r2, r, (int)P, dc + o,
-                                   (dir && decide_th >= 0.0) ? (const unsigned*)dc : (const unsigned*)nullptr, decide_th, OV_CHUNK);
+            if (!two_launch) {
+                if (nblk)
+                    hipLaunchKernelGGL(k_ov_query, dim3((unsigned)nblk), dim3(256), 0, s, (const double*)pool.p, dg, dt, (const unsigned*)ix_cells.p,
+                                       (const float*)ix_pts.p, r2, r, (int)P, db, 0u, dc, (const unsigned*)nullptr, decide_th, OV_CHUNK);
+            } else {
+                for (int dir = 0; dir < 2; ++dir) {
+                    const unsigned nb = dir ? nblk2 : nblk1;
+                    if (!nb) continue;
+                    hipLaunchKernelGGL(k_ov_query, dim3(nb), dim3(256), 0, s, (const double*)pool.p, dg, dt, (const unsigned*)ix_cells.p,
+                                       (const float*)ix_pts.p, r2, r, (int)P, db, dir ? nblk1 : 0u, dc,
+                                       (dir && decide_th >= 0.0) ? (const unsigned*)dc : (const unsigned*)nullptr, decide_th, OV_CHUNK);
+                }
             }
         }
         HMSG_CHECK_LAUNCH();

@@ -18,6 +18,7 @@
 #include "hmsg_common.h"
 
 #include <algorithm>
+#include <chrono>
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
@@ -446,7 +447,7 @@ void text_to_f64(hmsg_index* ix, const float* T, size_t n) {
     const float* src = T;
     if (!dev_ptr(T)) {
         ix->Tf.ensure(n);
-        HIP_TRY(hipMemcpyAsync(ix->Tf.p, T, n * 4, hipMemcpyHostToDevice, ix->stream));
+        h2d_bounce(ix->Tf.p, T, n * 4, ix->stream);
         src = ix->Tf.p;
     }
     hipLaunchKernelGGL(k_f32_to_f64, dim3(cdiv(n, 256)), dim3(256), 0, ix->stream, src, ix->T64.p, n);
@@ -470,11 +471,13 @@ int hmsg_index_create(int32_t device_id, int32_t dim, int64_t n, const void* emb
         ix->E.alloc((size_t)n * dim);
         const size_t cnt = (size_t)n * dim;
         if (emb_is_f64) {
-            HIP_TRY(hipMemcpyAsync(ix->E.p, emb, cnt * 8, dev_ptr(emb) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ix->stream));
+            if (dev_ptr(emb)) HIP_TRY(hipMemcpyAsync(ix->E.p, emb, cnt * 8, hipMemcpyDeviceToDevice, ix->stream));
+            else h2d_bounce(ix->E.p, emb, cnt * 8, ix->stream);
         } else {
             DevBuf<float> tmp;
             tmp.alloc(cnt);
-            HIP_TRY(hipMemcpyAsync(tmp.p, emb, cnt * 4, dev_ptr(emb) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ix->stream));
+            if (dev_ptr(emb)) HIP_TRY(hipMemcpyAsync(tmp.p, emb, cnt * 4, hipMemcpyDeviceToDevice, ix->stream));
+            else h2d_bounce(tmp.p, emb, cnt * 4, ix->stream);
             hipLaunchKernelGGL(k_f32_to_f64, dim3(cdiv(cnt, 256)), dim3(256), 0, ix->stream, (const float*)tmp.p, ix->E.p, cnt);
             HMSG_CHECK_LAUNCH();
             HIP_TRY(hipStreamSynchronize(ix->stream));
@@ -616,12 +619,16 @@ int hmsg_index_set_hierarchy(hmsg_index_t* ix, int32_t n_rooms, int32_t n_floors
         if (nfr) HIP_TRY(hipMemcpyAsync(ix->floor_rooms.p, floor_rooms, (size_t)nfr * 4, hipMemcpyHostToDevice, ix->stream));
         if (room_name_emb) {
             ix->room_name_emb.alloc((size_t)std::max(R, 1) * ix->D);
-            HIP_TRY(hipMemcpyAsync(ix->room_name_emb.p, room_name_emb, (size_t)R * ix->D * 8, dev_ptr(room_name_emb) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ix->stream));
+            if (dev_ptr(room_name_emb)) HIP_TRY(hipMemcpyAsync(ix->room_name_emb.p, room_name_emb, (size_t)R * ix->D * 8, hipMemcpyDeviceToDevice, ix->stream));
+            else h2d_bounce(ix->room_name_emb.p, room_name_emb, (size_t)R * ix->D * 8, ix->stream);
         } else {
             ix->room_name_emb.release();
         }
         ix->view_emb.alloc((size_t)std::max<long long>(NV, 1) * ix->D);
-        if (NV) HIP_TRY(hipMemcpyAsync(ix->view_emb.p, view_emb, (size_t)NV * ix->D * 8, dev_ptr(view_emb) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ix->stream));
+        if (NV) {
+            if (dev_ptr(view_emb)) HIP_TRY(hipMemcpyAsync(ix->view_emb.p, view_emb, (size_t)NV * ix->D * 8, hipMemcpyDeviceToDevice, ix->stream));
+            else h2d_bounce(ix->view_emb.p, view_emb, (size_t)NV * ix->D * 8, ix->stream);
+        }
         HIP_TRY(hipStreamSynchronize(ix->stream));
         ix->have_hier = true;
     });
@@ -638,6 +645,16 @@ int hmsg_query_hier(hmsg_index_t* ix, int32_t Q, int32_t C, const float* T_obj, 
                      HMSG_ERR_INVALID, "hmsg_query_hier: bad argument");
         if (Q == 0) return;
         const int R = ix->h_rooms;
+        // HMSG_DEBUG_TIMING: where a call spends its time (each lap drains the stream first)
+        static const bool dbg = getenv("HMSG_DEBUG_TIMING") != nullptr;
+        auto t_prev = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) {
+            if (!dbg) return;
+            (void)hipStreamSynchronize(ix->stream);
+            const auto t = std::chrono::steady_clock::now();
+            fprintf(stderr, "[hmsg query_hier] %-22s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+            t_prev = t;
+        };
         std::vector<int> hm((size_t)Q), hf((size_t)Q);
         memcpy(hm.data(), room_mode, (size_t)Q * 4);
         memcpy(hf.data(), floor_id, (size_t)Q * 4);
@@ -658,7 +675,7 @@ int hmsg_query_hier(hmsg_index_t* ix, int32_t Q, int32_t C, const float* T_obj, 
             const float* src = T_room;
             if (!dev_ptr(T_room)) {
                 ix->Tr.ensure(nT);
-                HIP_TRY(hipMemcpyAsync(ix->Tr.p, T_room, nT * 4, hipMemcpyHostToDevice, ix->stream));
+                h2d_bounce(ix->Tr.p, T_room, nT * 4, ix->stream);
                 src = ix->Tr.p;
             }
             hipLaunchKernelGGL(k_f32_to_f64, dim3(cdiv(nT, 256)), dim3(256), 0, ix->stream, src, ix->Tr64.p, nT);
@@ -666,6 +683,7 @@ int hmsg_query_hier(hmsg_index_t* ix, int32_t Q, int32_t C, const float* T_obj, 
             if (need_label) gemm(ix, ix->Tr64.p, Q, ix->S_room.p, ix->room_name_emb.p, R);
             if (need_view && ix->n_views) gemm(ix, ix->Tr64.p, Q, ix->S_view.p, ix->view_emb.p, ix->n_views);
         }
+        lap("room text + room GEMM");
         ix->d_floor.ensure(Q);
         ix->d_mode.ensure(Q);
         ix->d_sel.ensure((size_t)Q * max_rooms);
@@ -681,11 +699,15 @@ int hmsg_query_hier(hmsg_index_t* ix, int32_t Q, int32_t C, const float* T_obj, 
                            (const int*)ix->d_mode.p, max_rooms, ix->d_sel.p, ix->d_nsel.p, ix->d_rooms.p, ix->d_err.p);
         hipLaunchKernelGGL(k_fill_offsets, dim3(cdiv((size_t)Q + 1, 256)), dim3(256), 0, ix->stream, ix->d_roff.p, Q, max_rooms);
         HMSG_CHECK_LAUNCH();
+        lap("room select");
         // object stage on the rooms the room stage picked, in that order
         const size_t nT = (size_t)Q * C * ix->D;
         text_to_f64(ix, T_obj, nT);
+        lap("object text upload");
         ix->S.ensure((size_t)Q * C * ix->N);
+        lap("S alloc");
         gemm(ix, ix->T64.p, Q * C, ix->S.p);
+        lap("object GEMM");
         ix->d_qid.ensure(Q);
         ix->d_oidx.ensure((size_t)Q * k);
         ix->d_oroom.ensure((size_t)Q * k);
@@ -695,6 +717,7 @@ int hmsg_query_hier(hmsg_index_t* ix, int32_t Q, int32_t C, const float* T_obj, 
                            (const int*)ix->d_roff.p, (const int*)ix->d_rooms.p, (const int*)ix->room_off.p,
                            (const int*)ix->room_nodes.p, ix->n_rooms, k, use_negatives, ix->d_oidx.p, ix->d_oroom.p, ix->d_oscore.p);
         HMSG_CHECK_LAUNCH();
+        lap("top-k");
         std::vector<int> herr((size_t)Q);
         HIP_TRY(hipMemcpyAsync(out_sel, ix->d_sel.p, (size_t)Q * max_rooms * 4, hipMemcpyDeviceToHost, ix->stream));
         HIP_TRY(hipMemcpyAsync(out_nsel, ix->d_nsel.p, (size_t)Q * 4, hipMemcpyDeviceToHost, ix->stream));
@@ -703,6 +726,7 @@ int hmsg_query_hier(hmsg_index_t* ix, int32_t Q, int32_t C, const float* T_obj, 
         HIP_TRY(hipMemcpyAsync(out_room, ix->d_oroom.p, (size_t)Q * k * 4, hipMemcpyDeviceToHost, ix->stream));
         HIP_TRY(hipMemcpyAsync(out_score, ix->d_oscore.p, (size_t)Q * k * 8, hipMemcpyDeviceToHost, ix->stream));
         HIP_TRY(hipStreamSynchronize(ix->stream));
+        lap("read-back");
         for (int q = 0; q < Q; ++q)
             HMSG_REQUIRE(!herr[(size_t)q], HMSG_ERR_INVALID,
                          "hmsg_query_hier: a query's room stage failed like the reference would (a room without view embeddings, or a "

@@ -265,8 +265,11 @@ int hmsg_room_clouds(hmsg_t* h, double y_lo, double y_hi, const double* T, int32
                      int32_t* out_index, int64_t out_capacity, int64_t* n_floor_points);
 /* The camera -> room distance table of compute_room_embeddings (utils/graph_utils.py:244-291: `np.min(cdist([pos],
  * room_points))` with pos = the camera's (x, z)) from the room clouds the last hmsg_room_clouds call left on the device -- the
- * clouds do not travel to the host and back.  q_xz f64 [n_q][2] (host), out f64 [n_q][n_rooms] (host). */
-int hmsg_room_camera_distances(hmsg_t* h, int64_t n_q, const double* q_xz, double* out);
+ * clouds do not travel to the host and back.  q_xz f64 [n_q][2] (host), out f64 [n_q][n_rooms] (host); n_rooms is what the
+ * caller sized `out` for and must be the room count of that hmsg_room_clouds call (HMSG_ERR_INVALID otherwise: a call that
+ * found no floor point or failed leaves n_rooms empty rooms / no rooms, never the previous storey's).  The distance to an
+ * empty room is +inf. */
+int hmsg_room_camera_distances(hmsg_t* h, int32_t n_rooms, int64_t n_q, const double* q_xz, double* out);
 /* ---- N1: the rooms of one storey as a label image -- segment_hmsg_room up to room_vertices (graph.py:942-1071) and
  * distance_transform (graph_utils.py:391-487), every image step a kernel (the reference: numpy + OpenCV on the host).
  * The storey's cloud is the map points with y in [y_lo, y_hi] (as hmsg_room_clouds); zero_level / height are the
