@@ -18,6 +18,15 @@ struct SegDesc {                 // one cloud of a batch, points at src[pt_base 
     // fmn / fmx: the first member's own AABB (the result's box is its union with the box of the kept rest).
     int forced = 0;
     double cmn[3] = {0, 0, 0}, cmx[3] = {0, 0, 0}, fmn[3] = {0, 0, 0}, fmx[3] = {0, 0, 0};
+    // Where the segment's output goes (gather mode only: the batch is assembled from a pool the caller may write to).
+    //   0  densely behind the outputs of the other mode-0 segments at `dst` (the only mode without a gather);
+    //   1  to its own region of the pool, DbGather::pool_w + out_off (points): every kept point is copied there;
+    //   2  IN PLACE (forced segments only): the first member already sits at pool_w + out_off with room behind it for the whole
+    //      rest of the segment -- it is not copied at all, the kept rest is appended behind it, and the core flags the batch
+    //      promotes among its points are set where they are (DbGather::poolcore_w).  The members the anchor cloud leaves
+    //      outside its crop are then not read beyond their coordinates.
+    int out_mode = 0;
+    long long out_off = 0;
 };
 
 // A batch assembled from pieces of a point pool: piece [src, src + n) of the pool goes to [dst, dst + n) of the batch
@@ -35,6 +44,8 @@ struct DbGather {
     int nsegs = 0;
     const unsigned char* poolcore = nullptr; // persisted core flags of the pool points (anchor pieces)
     unsigned char* dstcore = nullptr;        // core0 of the batch, written by the gather (may be null)
+    double* pool_w = nullptr;                // the same pool, writable: output regions of SegDesc::out_mode 1 / 2
+    unsigned char* poolcore_w = nullptr;     // ... and their core flags
 };
 
 struct DbscanResult {            // per segment
@@ -65,6 +76,7 @@ struct CloudOps {
     hipStream_t s = nullptr;
     Prof* prof = nullptr;        // optional live timing of the heavy kernels
     // work counters of the DBSCAN batches (debug output of the merge stage)
+    double stat_inplace = 0;                            // ... of them run in place (SegDesc::out_mode 2)
     double stat_forced = 0, stat_forced_first = 0;     // segments binned with their anchor member cropped, and those members' points
     double stat_calls = 0, stat_points = 0, stat_cells = 0, stat_core_cells = 0, stat_active_cells = 0, stat_maxcell_sum = 0, stat_maxcell_max = 0;
     DevBuf<unsigned> scan_tmp;
@@ -103,6 +115,8 @@ struct CloudOps {
     // from the pool pieces while it bins -- one launch and one pass over the points less than a separate concatenation.
     // Open3D voxel_down_sample of every segment; outputs consecutively to dst (capacity >= total input
     // points); out_n[k] = points of segment k.
+    // SegDesc::out_mode 1 / 2 are available (not with the legacy three-launch compaction or with HMSG_DEBUG_NO_CROP=1)
+    static bool regions_supported();
     long long voxel_down_sample(const double* src, const std::vector<SegDesc>& segs, double vs, double* dst,
                                 std::vector<int>& out_n);
 };

@@ -29,8 +29,17 @@ struct DbSeg {
     long long cell_base, pt_base;
     int n_first, forced;    // (SegDesc::n_first, SegDesc::forced)
     double cmn[3], cmx[3];  // (SegDesc::cmn / cmx: the crop of a forced segment's first member)
+    long long out_off;      // (SegDesc::out_off, out_mode)
+    int out_mode, pad;
 };
 #define DB_FAR (-1ll)       /* cellid of a point of a forced segment's first member outside the crop: not in the grid */
+#define DB_FAR2 (-2ll)      /* ... of a segment that runs IN PLACE (out_mode 2): the point is nowhere in the batch's buffers */
+// one workgroup of k_db_compact: points [p0, p0 + cnt) of the batch; tile `tile` of the look-back chain whose status words start at
+// state[chain0].  Chain 0 = the mode-0 segments (dense output at dst); every segment with an output region of its own is a chain.
+struct DbBlk {
+    long long p0;
+    int cnt, tile, chain0, seg;     // seg: the segment of an own-region chain (-1: chain 0)
+};
 
 #define INF32 0xffffffffu
 
@@ -57,7 +66,15 @@ __global__ void k_db_cell(const double* __restrict__ pts, long long N, int* __re
     //  launch (PMC: 8.4 fetched, 18.4 written, byte and 8-byte stores among them) at ~1.4 TB/s.)
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
+    int lo = 0, hi = K - 1;                 // segment of the point (segments tile [0, N) in order)
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if ((lds_s ? s_base[mid] : segs[mid].pt_base) <= i) lo = mid; else hi = mid - 1;
+    }
+    const DbSeg sg = segs[lo];
     double px, py, pz;
+    long long sp = -1;
+    unsigned char c0 = 0;
     if (ga.segs) {                          // the batch is assembled here: point i comes from its piece of the pool
         int a = 0, b = ga.nsegs - 1;
         while (a < b) {
@@ -65,28 +82,30 @@ __global__ void k_db_cell(const double* __restrict__ pts, long long N, int* __re
             if ((lds_g ? s_dst[mid] : ga.segs[mid].dst) <= i) a = mid; else b = mid - 1;
         }
         const CatSeg cs = ga.segs[a];
-        const long long sp = cs.src + (i - cs.dst);
+        sp = cs.src + (i - cs.dst);
         px = ga.pool[sp * 3];
         py = ga.pool[sp * 3 + 1];
         pz = ga.pool[sp * 3 + 2];
-        pts_out[i * 3] = px;
-        pts_out[i * 3 + 1] = py;
-        pts_out[i * 3 + 2] = pz;
-        if (ga.dstcore) ga.dstcore[i] = cs.anchor ? ga.poolcore[sp] : (unsigned char)0;
+        c0 = cs.anchor ? (unsigned char)1 : (unsigned char)0;
     } else {
         px = pts[i * 3];
         py = pts[i * 3 + 1];
         pz = pts[i * 3 + 2];
     }
-    int lo = 0, hi = K - 1;                 // segment of the point (segments tile [0, N) in order)
-    while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if ((lds_s ? s_base[mid] : segs[mid].pt_base) <= i) lo = mid; else hi = mid - 1;
+    const bool far = sg.forced && i < sg.pt_base + sg.n_first &&
+                     (px < sg.cmn[0] || px > sg.cmx[0] || py < sg.cmn[1] || py > sg.cmx[1] || pz < sg.cmn[2] || pz > sg.cmx[2]);
+    if (far && sg.out_mode == 2) {          // stays where it is: nothing of it enters the batch
+        cellid[i] = DB_FAR2;
+        return;
+    }
+    if (ga.segs) {
+        pts_out[i * 3] = px;
+        pts_out[i * 3 + 1] = py;
+        pts_out[i * 3 + 2] = pz;
+        if (ga.dstcore) ga.dstcore[i] = c0 ? ga.poolcore[sp] : (unsigned char)0;
     }
     segid[i] = lo;
-    const DbSeg sg = segs[lo];
-    if (sg.forced && i < sg.pt_base + sg.n_first &&
-        (px < sg.cmn[0] || px > sg.cmx[0] || py < sg.cmn[1] || py > sg.cmx[1] || pz < sg.cmn[2] || pz > sg.cmx[2])) {
+    if (far) {
         cellid[i] = DB_FAR;
         return;
     }
@@ -111,7 +130,7 @@ __global__ void k_db_fill(const double* __restrict__ pts, long long N, const lon
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < N;
     bool need = false;
-    if (live && cellid[i] != DB_FAR) {
+    if (live && cellid[i] >= 0) {
         long long c = cellid[i];
         const unsigned s0 = start[c];
         unsigned p = s0 + atomicAdd(&cursor[c], 1u);
@@ -258,24 +277,29 @@ __global__ void k_db_core(const double* __restrict__ pts, long long N, const int
                           int* __restrict__ cellpos, int* __restrict__ parent, const unsigned char* __restrict__ core0,
                           unsigned char* __restrict__ hasanchor, unsigned* __restrict__ rep, unsigned* __restrict__ active,
                           int* __restrict__ actlist, unsigned* __restrict__ nact, int* __restrict__ cseg,
-                          unsigned* __restrict__ nclist) {
+                          unsigned* __restrict__ nclist, unsigned char* __restrict__ poolcore_w) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in_range = i < N;
+    bool in_range = i < N;
     if (!in_range) i = N - 1;                // keep the lane alive for the wave collectives below
-    const int k_seg = segid[i];
-    const DbSeg sg = segs[k_seg];
     long long c = cellid[i];
-    const bool far = c == DB_FAR;            // (a forced segment's anchor point outside the crop: keeps its flag, takes part in nothing)
+    // (a point of an in-place segment outside the crop: it is nowhere in the batch -- no segment id, no flag to write)
+    const bool far2 = c == DB_FAR2;
+    if (far2) in_range = false;
+    const int k_seg = far2 ? 0 : segid[i];
+    const DbSeg sg = segs[k_seg];
+    const bool far = c < 0;                  // (a forced segment's anchor point outside the crop: keeps its flag, takes part in nothing)
     if (far) c = sg.cell_base;               // (any valid cell: nothing below touches it for a far point)
     // anchor points: core points of a member cloud that is a known single-cluster fixed point of this DBSCAN.
     // More points only raise neighbour counts, so they stay core -- no counting needed.
-    const bool known = core0 != nullptr && core0[i] != 0;
+    const bool known = core0 != nullptr && !far2 && core0[i] != 0;
     bool is_core = known || (!far && cnt[c] >= (unsigned)minpts);
     if (!is_core && in_range && !far) is_core = core[i] != 0;        // counted by k_db_count (the points k_db_fill listed)
     is_core = is_core && in_range;
     if (in_range) {
         core[i] = is_core ? 1 : 0;
         if (!far) score[rank[i]] = is_core ? 1 : 0;
+        // a segment that runs in place: the anchor member's points are not copied, a flag the batch promotes is set where it lives
+        if (is_core && !known && sg.out_mode == 2 && i < sg.pt_base + sg.n_first) poolcore_w[sg.out_off + (i - sg.pt_base)] = 1;
     }
     const bool in_grid = !far;
     const int lane = threadIdx.x & 63;
@@ -997,15 +1021,18 @@ __global__ void k_db_scatter(const double* __restrict__ pts, long long N, const 
 // Whether a segment loses points at all -- its box then has to be re-reduced -- needs no flag from another block: the winning
 // cluster's size IS the number of kept points (k_db_rootmin counted its core members per cell, k_db_label its border points).
 // A segment's output count comes from the positions of its first and last point (ostart / oend; the host subtracts).
+// Round 5: the workgroups follow a table (DbBlk) instead of cutting [0, N) evenly: a segment whose output has a region of its
+// own (SegDesc::out_mode 1 / 2) is a look-back chain of its own -- its kept points go to that region at the chain's own
+// prefix -- and the anchor member of a segment that runs in place is not visited at all.
 #define DBK_TRIPS 32
-__global__ void __launch_bounds__(256) k_db_compact(const double* __restrict__ pts, long long N, const int* __restrict__ segid,
+__global__ void __launch_bounds__(256) k_db_compact(const double* __restrict__ pts, const DbBlk* __restrict__ blks, const int* __restrict__ segid,
                                                     const DbSeg* __restrict__ segs, const int* __restrict__ label,
                                                     const unsigned long long* __restrict__ best, const unsigned* __restrict__ rep, unsigned* __restrict__ flags_dbg,
                                                     const unsigned char* __restrict__ core, const long long* __restrict__ cellid,
                                                     const int* __restrict__ parent, double* __restrict__ dst, int* __restrict__ oend,
                                                     int* __restrict__ ostart, int* __restrict__ ofirst, unsigned char* __restrict__ dst_core,
                                                     unsigned long long* __restrict__ obounds, unsigned long long* __restrict__ state,
-                                                    unsigned epoch) {
+                                                    unsigned epoch, double* __restrict__ pool_w, unsigned char* __restrict__ poolcore_w) {
     __shared__ int slot_seg;
     __shared__ unsigned long long slot_box[6];
     __shared__ unsigned wsum[4], wtot[2][4];
@@ -1013,8 +1040,14 @@ __global__ void __launch_bounds__(256) k_db_compact(const double* __restrict__ p
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) slot_seg = -1;
     if (tid < 6) slot_box[tid] = tid < 3 ? ~0ull : 0ull;
-    const long long per_block = ((N + (long long)gridDim.x * blockDim.x - 1) / ((long long)gridDim.x * blockDim.x)) * blockDim.x;
-    const long long b0 = (long long)blockIdx.x * per_block, b1 = b0 + per_block < N ? b0 + per_block : N;
+    const DbBlk bk = blks[blockIdx.x];
+    const long long b0 = bk.p0, b1 = bk.p0 + bk.cnt;
+    if (bk.seg >= 0) {                                       // an output region of its own
+        const DbSeg so = segs[bk.seg];
+        const long long o = so.out_off + (so.out_mode == 2 ? so.n_first : 0);
+        dst = pool_w + (size_t)o * 3;
+        if (dst_core) dst_core = poolcore_w + o;
+    }
     unsigned mine = 0u, kept = 0u;
     int trip = 0;
     for (long long base = b0; base < b1; base += blockDim.x, ++trip) {
@@ -1048,7 +1081,7 @@ __global__ void __launch_bounds__(256) k_db_compact(const double* __restrict__ p
     if (lane == 0) wsum[w] = kept;
     __syncthreads();
     if (w == 0) {
-        const unsigned prefix = scan_lookback_prefix(state, blockIdx.x, epoch, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+        const unsigned prefix = scan_lookback_prefix(state + bk.chain0, bk.tile, epoch, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
         if (lane == 0) s_prefix = prefix;
     }
     __syncthreads();
@@ -1245,6 +1278,11 @@ void Publisher::wait() {
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
 }
 
+bool CloudOps::regions_supported() {
+    static const bool split_compact = getenv("HMSG_DB_COMPACT_SPLIT") != nullptr;
+    return !split_compact && getenv("HMSG_DEBUG_NO_CROP") == nullptr;
+}
+
 long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<SegDesc>& segs, double eps, int min_points,
                                         double* dst, std::vector<DbscanResult>& res, const unsigned char* core0,
                                         unsigned char* dst_core, const DbGather* gather) {
@@ -1253,8 +1291,13 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     if (K == 0) return 0;
     const double cs = eps / std::sqrt(3.0) * (1.0 - 1e-7);
     std::vector<DbSeg> hs(K);
+    // HMSG_DB_COMPACT_SPLIT=1: flags, scan and scatter as three launches (the form before round 4; kept for comparison runs).  Read
+    // ONCE per process, for both of the decisions that hang on it: the legacy launches know neither cropped anchors nor output
+    // regions (they index parent[cellid[i]] for every point).
+    static const bool split_compact = getenv("HMSG_DB_COMPACT_SPLIT") != nullptr;
     // (SegDesc::forced needs the one-launch compaction; HMSG_DEBUG_NO_CROP=1 bins every anchor whole, as before round 4)
-    const bool forced_ok = getenv("HMSG_DB_COMPACT_SPLIT") == nullptr && getenv("HMSG_DEBUG_NO_CROP") == nullptr;   // (per call: tests switch it)
+    const bool forced_ok = !split_compact && getenv("HMSG_DEBUG_NO_CROP") == nullptr;   // (per call: tests switch it)
+    const bool regions_ok = forced_ok && gather && gather->pool_w && gather->poolcore_w;
     long long NC = 0, N = 0;
     long long span_lo = segs[0].pt_base, span_hi = segs[0].pt_base;
     for (int k = 0; k < K; ++k) {
@@ -1265,14 +1308,23 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
         g.pt_base = sd.pt_base;
         g.n_first = sd.n_first;
         g.forced = 0;
+        g.out_mode = 0;
+        g.out_off = 0;
+        g.pad = 0;
         for (int a = 0; a < 3; ++a) g.cmn[a] = g.cmx[a] = 0.0;
         g.cell_base = NC;
+        if (sd.out_mode != 0) {
+            HMSG_REQUIRE(regions_ok && (sd.out_mode == 1 || sd.out_mode == 2), HMSG_ERR_INVALID, "dbscan: output regions need a writable pool (DbGather::pool_w)");
+            g.out_mode = sd.out_mode;
+            g.out_off = sd.out_off;
+        }
         if (sd.n > 0) {
             double lo[3] = {sd.mn[0], sd.mn[1], sd.mn[2]}, hi[3] = {sd.mx[0], sd.mx[1], sd.mx[2]};
             if (sd.forced && core0 && forced_ok && sd.n_first > 0 && sd.n_first < sd.n) {
                 // the grid covers the crop only (every point that is binned lies inside it)
                 g.forced = 1;
                 stat_forced += 1;
+                if (g.out_mode == 2) stat_inplace += 1;
                 stat_forced_first += sd.n_first;
                 for (int a = 0; a < 3; ++a) {
                     g.cmn[a] = sd.cmn[a];
@@ -1291,6 +1343,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
             g.ox = g.oy = g.oz = 0;
             g.nx = g.ny = g.nz = 1;
         }
+        HMSG_REQUIRE(g.out_mode != 2 || g.forced, HMSG_ERR_INVALID, "dbscan: a segment runs in place only with its anchor member cropped (SegDesc::forced)");
         NC += (long long)g.nx * g.ny * g.nz;
         N += sd.n;
         span_lo = std::min(span_lo, sd.pt_base);
@@ -1301,16 +1354,75 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     HMSG_REQUIRE(NC < (1ll << 31) && N < (1ll << 31), HMSG_ERR_UNSUPPORTED, "dbscan batch too large");
     if (N == 0) return 0;
     // (pinned staging; the previous batch ended with a wait on the stream.  A gather table given on the host rides along.)
+    static int n_cu = 0;
+    if (!n_cu) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        n_cu = std::max(1, prop.multiProcessorCount);
+    }
+    // The compaction's workgroups (DbBlk): chain 0 covers the mode-0 segments (dense output; a run of consecutive ones is cut into
+    // blocks, no block straddles a segment of another mode), every segment with a region of its own is a chain of its own, and
+    // the anchor member of a segment that runs in place gets no workgroup at all.  Blocks are numbered in batch order, so every
+    // predecessor of a tile has a lower workgroup index (the look-back's progress argument, hmsg_common.h).
+    std::vector<DbBlk> hblk;
+    if (!split_compact) {
+        long long Ns = 0;
+        for (int k = 0; k < K; ++k) Ns += hs[k].out_mode == 2 ? hs[k].n - hs[k].n_first : hs[k].n;
+        // one grid resident at once while a thread's keep bits fit a register (DBK_TRIPS trips of 256 points), more blocks beyond
+        // (two blocks per CU measured best on the MI355X: 28.2 us per fold step with one, 23.8 with two, 24.5 with four, 29.3 with eight)
+        const long long gt = std::max<long long>(std::min<long long>(cdiv(std::max<long long>(Ns, 1), 256), (long long)n_cu * 2),
+                                                 cdiv(std::max<long long>(Ns, 1), 256ll * DBK_TRIPS));
+        const long long per_block = std::min<long long>(256ll * DBK_TRIPS, (cdiv(std::max<long long>(Ns, 1), gt) + 255) / 256 * 256);
+        auto cut = [&](long long lo, long long hi, int seg, int* tile) {
+            for (long long q = lo; q < hi; q += per_block)
+                hblk.push_back(DbBlk{q, (int)std::min<long long>(per_block, hi - q), (*tile)++, seg >= 0 ? -1 : 0, seg});
+        };
+        int t0 = 0;
+        long long run_lo = 0, run_hi = 0;
+        for (int k = 0; k < K; ++k) {
+            const DbSeg& g = hs[k];
+            if (g.n == 0) continue;
+            if (g.out_mode == 0) {
+                if (run_hi > run_lo && run_hi != g.pt_base) {
+                    cut(run_lo, run_hi, -1, &t0);
+                    run_lo = run_hi = g.pt_base;
+                }
+                if (run_hi == run_lo) run_lo = run_hi = g.pt_base;
+                run_hi = g.pt_base + g.n;
+            } else {
+                if (run_hi > run_lo) cut(run_lo, run_hi, -1, &t0);
+                run_lo = run_hi = 0;
+                int t = 0;
+                cut(g.pt_base + (g.out_mode == 2 ? g.n_first : 0), g.pt_base + g.n, k, &t);
+            }
+        }
+        if (run_hi > run_lo) cut(run_lo, run_hi, -1, &t0);
+        size_t next = (size_t)t0;                         // status words of the own-region chains behind chain 0's
+        for (size_t b = 0; b < hblk.size(); ++b)
+            if (hblk[b].seg >= 0 && hblk[b].tile == 0) {
+                size_t nt = 1;
+                while (b + nt < hblk.size() && hblk[b + nt].seg == hblk[b].seg) ++nt;
+                for (size_t q = 0; q < nt; ++q) hblk[b + q].chain0 = (int)next;
+                next += nt;
+            }
+    }
+    // (pinned staging; the previous batch ended with a wait on the stream.  A gather table given on the host and the compaction's
+    //  block table ride along.)
     const size_t geom_bytes = ((size_t)K * sizeof(DbSeg) + 15) & ~(size_t)15;
-    const size_t cat_bytes = gather && gather->host_segs ? (size_t)gather->nsegs * sizeof(CatSeg) : 0;
-    geom.ensure(geom_bytes + cat_bytes);
-    h_geom.ensure(geom_bytes + cat_bytes);
+    const size_t cat_bytes = ((gather && gather->host_segs ? (size_t)gather->nsegs * sizeof(CatSeg) : 0) + 15) & ~(size_t)15;
+    const size_t blk_bytes = hblk.size() * sizeof(DbBlk);
+    geom.ensure(geom_bytes + cat_bytes + blk_bytes);
+    h_geom.ensure(geom_bytes + cat_bytes + blk_bytes);
     memcpy(h_geom.p, hs.data(), (size_t)K * sizeof(DbSeg));
-    if (cat_bytes) memcpy(h_geom.p + geom_bytes, gather->host_segs, cat_bytes);
-    upload_pinned(geom.p, h_geom.p, geom_bytes + cat_bytes, s);
+    if (cat_bytes) memcpy(h_geom.p + geom_bytes, gather->host_segs, (size_t)gather->nsegs * sizeof(CatSeg));
+    if (blk_bytes) memcpy(h_geom.p + geom_bytes + cat_bytes, hblk.data(), blk_bytes);
+    upload_pinned(geom.p, h_geom.p, geom_bytes + cat_bytes + blk_bytes, s);
     DbGather ga_dev = gather ? *gather : DbGather{};
     if (cat_bytes) ga_dev.segs = (const CatSeg*)(geom.p + geom_bytes);
     const DbSeg* dsegs = (const DbSeg*)geom.p;
+    const DbBlk* dblks = (const DbBlk*)(geom.p + geom_bytes + cat_bytes);
     segid.ensure(N); cellid.ensure(N); ord.ensure(N); core.ensure(N); label.ensure(N); flags.ensure(N); pos.ensure(N);
     cnt.ensure(NC + 1); start.ensure(NC + 1); cursor.ensure(NC); minidx.ensure(NC); firstidx.ensure(NC); size.ensure(NC);
     parent.ensure(NC);
@@ -1370,14 +1482,6 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     needy.ensure((size_t)std::max<long long>(N, 1));
     hipLaunchKernelGGL(k_db_fill, dim3(gN), dim3(256), 0, s, src, N, (const long long*)cellid.p, (const unsigned*)start.p, cursor.p,
                        ord.p, spts.p, core0, min_points, needy.p, d_nc + 3);       // ord: slot of every point in the cell-sorted copy
-    static int n_cu = 0;
-    if (!n_cu) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        HIP_TRY(hipGetDevice(&dev));
-        HIP_TRY(hipGetDeviceProperties(&prop, dev));
-        n_cu = std::max(1, prop.multiProcessorCount);
-    }
     {
     ProfScope ps(prof, s, "k_db_core", (double)N * 33.0);    // (k_db_count + k_db_core: one timed unit)
     hipLaunchKernelGGL(k_db_count, dim3((unsigned)n_cu * 8u), dim3(256), 0, s, src, (const int*)segid.p, dsegs, (const long long*)cellid.p,
@@ -1386,7 +1490,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     hipLaunchKernelGGL(k_db_core, dim3(gN), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const long long*)cellid.p,
                        (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p, (const double*)spts.p, score.p,
                        eps * eps, min_points, core.p, minidx.p, corelist.p, d_nc, cellpos.p, parent.p, core0, hasanchor.p, rep.p, active.p, actlist.p,
-                       d_nact, cseg.p, nclist.p);
+                       d_nact, cseg.p, nclist.p, gather ? gather->poolcore_w : (unsigned char*)nullptr);
     }
     // persistent grid (8 blocks per CU): waves / threads stride over the core-cell list
     const unsigned gW = (unsigned)n_cu * 8u;
@@ -1422,8 +1526,6 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     }
     hipLaunchKernelGGL(k_db_pick, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc, (const int*)cseg.p, dsegs, K,
                        (const unsigned*)size.p, (const unsigned*)firstidx.p, (const unsigned*)rootmin.p, best.p);
-    // HMSG_DB_COMPACT_SPLIT=1: flags, scan and scatter as three launches (the form before round 4; kept for comparison runs)
-    static const bool split_compact = getenv("HMSG_DB_COMPACT_SPLIT") != nullptr;
     static const bool dump_wanted = getenv("HMSG_DEBUG_DUMP") != nullptr;
     if (split_compact) {
     hipLaunchKernelGGL(k_db_flags, dim3(gN), dim3(256), 0, s, N, (const int*)segid.p, dsegs, (const int*)label.p,
@@ -1437,15 +1539,15 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
                        (const unsigned*)pos.p, dst, d_ocount, (const unsigned char*)core.p, dst_core, d_obounds, (const unsigned*)d_dropped);
     }
     } else {
-        // a persistent grid while a thread's keep bits fit a register (DBK_TRIPS trips of 256 points), more blocks beyond
-        // (two blocks per CU measured best on the MI355X: 28.2 us per fold step with one, 23.8 with two, 24.5 with four, 29.3 with eight)
-        const unsigned gK = std::max(std::min(gN, (unsigned)n_cu * 2u), cdiv(N, 256ll * DBK_TRIPS));
+        const unsigned gK = (unsigned)hblk.size();
         const unsigned epoch = hmsg_scan_epoch(scan_tmp, gK, s);
         ProfScope ps(prof, s, "k_db_scatter", (double)N * 56.0);
-        hipLaunchKernelGGL(k_db_compact, dim3(gK), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const int*)label.p,
-                           (const unsigned long long*)best.p, (const unsigned*)rep.p, dump_wanted ? flags.p : (unsigned*)nullptr, (const unsigned char*)core.p,
-                           (const long long*)cellid.p, (const int*)parent.p, dst, d_ocount, d_ostart, d_ofirst, dst_core, d_obounds,
-                           reinterpret_cast<unsigned long long*>(scan_tmp.p), epoch);
+        if (gK)
+            hipLaunchKernelGGL(k_db_compact, dim3(gK), dim3(256), 0, s, src, dblks, (const int*)segid.p, dsegs, (const int*)label.p,
+                               (const unsigned long long*)best.p, (const unsigned*)rep.p, dump_wanted ? flags.p : (unsigned*)nullptr, (const unsigned char*)core.p,
+                               (const long long*)cellid.p, (const int*)parent.p, dst, d_ocount, d_ostart, d_ofirst, dst_core, d_obounds,
+                               reinterpret_cast<unsigned long long*>(scan_tmp.p), epoch, gather ? gather->pool_w : (double*)nullptr,
+                               gather ? gather->poolcore_w : (unsigned char*)nullptr);
     }
     HMSG_CHECK_LAUNCH();
     {   // debug: HMSG_DEBUG_DBCALL=<n> dumps the n-th batch (inputs + per-point results) under HMSG_DEBUG_DUMP
@@ -1476,14 +1578,16 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     stat_active_cells += hres[(size_t)K * 16 + 1];
     long long total = 0;
     for (int k = 0; k < K; ++k) {
-        const int n_out = (int)hres[k] - (split_compact ? 0 : (int)hres[(size_t)K * 16 + 4 + k]);      // (one launch: output end - output start)
+        // (one launch: output end - output start, positions in the segment's chain; in place: the anchor member + the kept rest)
+        const int n_out = hs[k].out_mode == 2 ? hs[k].n_first + (int)hres[k] : (int)hres[k] - (split_compact ? 0 : (int)hres[(size_t)K * 16 + 4 + k]);
         res[k].n_out = n_out;
         res[k].changed = n_out != segs[k].n;
         res[k].n_clusters = (int)hres[(size_t)K + k];
         res[k].contested = (int)hres[(size_t)2 * K + k];
         res[k].first_kept = -1;
         if (!split_compact && segs[k].n_first > 0)
-            res[k].first_kept = segs[k].n_first < segs[k].n ? (int)hres[(size_t)K * 17 + 4 + k] - (int)hres[(size_t)K * 16 + 4 + k] : n_out;
+            res[k].first_kept = hs[k].out_mode == 2 ? segs[k].n_first
+                                : (segs[k].n_first < segs[k].n ? (int)hres[(size_t)K * 17 + 4 + k] - (int)hres[(size_t)K * 16 + 4 + k] : n_out);
         for (int a = 0; a < 3; ++a) {
             // unchanged: the input box is exact (and maybe tighter bookkeeping upstream relies on it bit for bit)
             res[k].mn[a] = !n_out ? 0.0 : (res[k].changed ? dec_f64(hb[(size_t)k * 6 + a]) : segs[k].mn[a]);

@@ -138,7 +138,7 @@ __global__ void k_ov_fill(const double* __restrict__ pool, const OvGrid* __restr
 // find_overlapping_ratio_faiss: (dx*dx + dy*dy) + dz*dz < r2)
 #define OV_UNROLL 4     /* (16 was measured: 21 -> 46 us per launch -- short candidate lists dominate, and every step then issues 48 loads) */
 __device__ __forceinline__ bool ov_scan(const float* __restrict__ sorted, unsigned s0, unsigned e0, float x, float y, float z,
-                                        float r2) {
+                                        float r2, unsigned* ncand = nullptr) {
     // OV_UNROLL candidates per step with independent loads: the scan is a serial latency chain per lane (one L2 round trip per
     // step: the early exit keeps the next step's loads from being issued ahead), and the kernel lasts as long as its slowest lane --
     // a point whose witness sits deep in a cell that has piled up hundreds of re-observations
@@ -152,6 +152,7 @@ __device__ __forceinline__ bool ov_scan(const float* __restrict__ sorted, unsign
             float d2 = __fadd_rn(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)), __fmul_rn(ddz, ddz));
             h = h || (k + (unsigned)j < e0 && d2 < r2);
         }
+        if (ncand) *ncand += min(OV_UNROLL, (int)(e0 - k));
         if (h) return true;
     }
     return false;
@@ -204,26 +205,51 @@ __device__ __forceinline__ void ov_col_ranges(const OvGrid& Y, const OvProbe& p,
         re[9] = cells[c0 + p.z1 + 1];
     }
 }
+// (st: HMSG_DEBUG_MERGESTATS counters -- [0] probes, [1] outside Y's box, [2] hits in the own cell, [3] hits in a neighbour cell,
+//  [4] misses, [5] candidates tested in own cells, [6] candidates tested in neighbour cells; nullptr in every other run)
+__device__ __forceinline__ void ov_stat(unsigned long long* st, int k, unsigned v = 1u) {
+    if (st) atomicAdd(&st[k], (unsigned long long)v);
+}
 __device__ __forceinline__ bool ov_hit(const OvGrid& Y, const unsigned* __restrict__ cells, const float* __restrict__ sorted,
-                                       float x, float y, float z, float r2, float r) {
-    if (x < Y.mnx - r || x > Y.mxx + r || y < Y.mny - r || y > Y.mxy + r || z < Y.mnz - r || z > Y.mxz + r) return false;
+                                       float x, float y, float z, float r2, float r, unsigned long long* st = nullptr) {
+    ov_stat(st, 0);
+    if (x < Y.mnx - r || x > Y.mxx + r || y < Y.mny - r || y > Y.mxy + r || z < Y.mnz - r || z > Y.mxz + r) {
+        ov_stat(st, 1);
+        return false;
+    }
     const OvProbe p = ov_probe(Y, x, y, z);
     if (!p.any) return false;
     const float* const sy = sorted + (size_t)Y.ix_pt * 3;
-    unsigned s0, e0;
+    unsigned s0, e0, nc = 0u;
     ov_own_range(Y, p, cells, s0, e0);
-    if (ov_scan(sy, s0, e0, x, y, z, r2)) return true;
+    if (ov_scan(sy, s0, e0, x, y, z, r2, st ? &nc : nullptr)) {
+        ov_stat(st, 2);
+        ov_stat(st, 5, nc);
+        return true;
+    }
+    ov_stat(st, 5, nc);
+    nc = 0u;
     unsigned rs[10], re[10];
     ov_col_ranges(Y, p, cells, rs, re);
 #pragma unroll
     for (int q = 0; q < 10; ++q)
-        if (ov_scan(sy, rs[q], re[q], x, y, z, r2)) return true;
+        if (ov_scan(sy, rs[q], re[q], x, y, z, r2, st ? &nc : nullptr)) {
+            ov_stat(st, 3);
+            ov_stat(st, 6, nc);
+            return true;
+        }
+    ov_stat(st, 4);
+    ov_stat(st, 6, nc);
     return false;
 }
 // the same against a cloud with two grids (base + delta, hmsg_merge.hip: Cloud::nb): the two grids' table look-ups go out
 // side by side -- every round of look-ups is a round trip, and the kernel lasts as long as a lane's chain of them
 __device__ __forceinline__ bool ov_hit2(const OvGrid& Y, const OvGrid& Y2, const unsigned* __restrict__ cells, const float* __restrict__ sorted,
-                                        float x, float y, float z, float r2, float r) {
+                                        float x, float y, float z, float r2, float r, unsigned long long* st = nullptr) {
+    if (st) {                                      // (statistics runs: the two grids one after the other)
+        if (ov_hit(Y, cells, sorted, x, y, z, r2, r, st)) return true;
+        return ov_hit(Y2, cells, sorted, x, y, z, r2, r, st);
+    }
     if (x < Y.mnx - r || x > Y.mxx + r || y < Y.mny - r || y > Y.mxy + r || z < Y.mnz - r || z > Y.mxz + r) return false;   // (both carry the cloud's box)
     const OvProbe p = ov_probe(Y, x, y, z), p2 = ov_probe(Y2, x, y, z);
     const float* const sy = sorted + (size_t)Y.ix_pt * 3;
@@ -254,13 +280,15 @@ static const int OV_CHUNK = 256;       /* points per workgroup of the overlap sc
 // Round 5: BOTH directions of every pair in ONE launch (tasks [0, P): smaller -> larger, [P, 2P): larger -> smaller; blk_task maps a
 // workgroup to its task -- one load instead of a binary search's chain of eight).  The second direction used to be a second,
 // dependent launch that skipped the pairs the first ratio had decided; the kernel is a chain of dependent look-ups per lane and
-// lasts ~25 us whether it covers one direction or both, so the skipped scans cost less than the launch they saved
-// (HMSG_OV_TWO_LAUNCH=1 keeps the dependent form for comparison: dep_counts != nullptr, blk_off = first workgroup of the launch).
+// was expected to last ~25 us whether it covers one direction or both.  Measured on the MI355X (profiles/r05_ov_one_launch.txt): it
+// does not -- 54.2 us for the one launch against 2 x 24.8 us: the scans the first ratio lets the second launch skip are real work
+// (the kernel is bound by its L2 transactions, not by a lane's chain), so the DEPENDENT form stays the default (dep_counts !=
+// nullptr, blk_off = first workgroup of the launch) and HMSG_OV_ONE_LAUNCH=1 selects the single launch.
 // Decisions are the same either way: max(a, b) > th does not care about b once a > th.
 __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __restrict__ gr, const OvTask* __restrict__ tasks,
                            const unsigned* __restrict__ cells, const float* __restrict__ sorted, float r2, float r,
                            int npairs, const int* __restrict__ blk_task, unsigned blk_off, unsigned* __restrict__ counts,
-                           const unsigned* __restrict__ dep_counts, double th, int chunk) {
+                           const unsigned* __restrict__ dep_counts, double th, int chunk, unsigned long long* __restrict__ st) {
     const unsigned blk = blockIdx.x + blk_off;
     const int ti = blk_task[blk];
     const OvTask t = tasks[ti];
@@ -331,7 +359,7 @@ __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __rest
         for (int i = b0 + (int)threadIdx.x; i < b1; i += blockDim.x) {
             const double* p = pool + (size_t)(X.pt_off + i) * 3;
             const float x = (float)p[0], y = (float)p[1], z = (float)p[2];
-            const bool hit = Y.next >= 0 ? ov_hit2(Y, Y2, cells, sorted, x, y, z, r2, r) : ov_hit(Y, cells, sorted, x, y, z, r2, r);
+            const bool hit = Y.next >= 0 ? ov_hit2(Y, Y2, cells, sorted, x, y, z, r2, r, st) : ov_hit(Y, cells, sorted, x, y, z, r2, r, st);
             local += hit ? 1u : 0u;
         }
     }
@@ -425,6 +453,7 @@ struct Merger {
     PinnedBuf<CatSeg> h_cat;
     DevBuf<unsigned> d_cursor;
     DevBuf<CatSeg> d_cat;
+    DevBuf<unsigned long long> ovstat;  // HMSG_DEBUG_MERGESTATS: probe statistics of k_ov_query (ov_stat)
     Publisher pub_counts;           // overlap counts of a step, read back through pinned memory (hmsg_cloudops.h)
     // one packed upload per overlap step: [grids | tasks | zeroed counts], staged in pinned memory (the previous step's
     // copy has completed: every overlap step ends with a wait on the stream)
@@ -436,6 +465,7 @@ struct Merger {
     std::unordered_map<unsigned long long, double> ratio_cache;   // hierarchical merge only
     bool use_cache = false;
     bool use_anchor = true;         // HMSG_DEBUG_NOANCHOR: plain DBSCAN of every batch (tests compare the two)
+    bool inplace_wanted = getenv("HMSG_DEBUG_NO_INPLACE") == nullptr;   // HMSG_DEBUG_NO_INPLACE=1: every output is a dense copy (round 4)
     double radius = 0;              // 1.5 * voxel_size  (merge_3d_masks passes radius=1.5*radius)
     double cell = 0;
     double eps = 0.1;
@@ -603,6 +633,7 @@ struct Merger {
             cat.push_back(CatSeg{c.off, live, c.n, c.anchor ? 1 : 0, (int)blocks, 0});
             blocks += cdiv((size_t)c.n, CAT_CHUNK);
             c.off = live;
+            c.cap = c.n;                 // (packed: no room behind it any more)
             live += c.n;
             c.has_index = false;
             c.has_delta = false;
@@ -700,20 +731,28 @@ struct Merger {
         const float r = (float)radius;
         const float r2 = (float)(radius * radius);   // `D < radius**2` with a float32 D (graph_utils.py:654-655)
         const size_t prof_idx = ops.prof->ev.size();        // (algorithmic bytes are filled in after the read-back)
-        static const bool two_launch = getenv("HMSG_OV_TWO_LAUNCH") != nullptr;
+        static const bool two_launch = getenv("HMSG_OV_ONE_LAUNCH") == nullptr;
+        unsigned long long* d_ovstat = nullptr;
+        if (want_stats) {
+            if (!ovstat.p) {
+                ovstat.alloc(8);
+                HIP_TRY(hipMemsetAsync(ovstat.p, 0, 64, s));
+            }
+            d_ovstat = ovstat.p;
+        }
         {
             ProfScope ps(ops.prof, s, "k_ov_query", 0.0);       // (the kernel launches only: not the read-back below)
             if (!two_launch) {
                 if (nblk)
                     hipLaunchKernelGGL(k_ov_query, dim3((unsigned)nblk), dim3(256), 0, s, (const double*)pool.p, dg, dt, (const unsigned*)ix_cells.p,
-                                       (const float*)ix_pts.p, r2, r, (int)P, db, 0u, dc, (const unsigned*)nullptr, decide_th, OV_CHUNK);
+                                       (const float*)ix_pts.p, r2, r, (int)P, db, 0u, dc, (const unsigned*)nullptr, decide_th, OV_CHUNK, d_ovstat);
             } else {
                 for (int dir = 0; dir < 2; ++dir) {
                     const unsigned nb = dir ? nblk2 : nblk1;
                     if (!nb) continue;
                     hipLaunchKernelGGL(k_ov_query, dim3(nb), dim3(256), 0, s, (const double*)pool.p, dg, dt, (const unsigned*)ix_cells.p,
                                        (const float*)ix_pts.p, r2, r, (int)P, db, dir ? nblk1 : 0u, dc,
-                                       (dir && decide_th >= 0.0) ? (const unsigned*)dc : (const unsigned*)nullptr, decide_th, OV_CHUNK);
+                                       (dir && decide_th >= 0.0) ? (const unsigned*)dc : (const unsigned*)nullptr, decide_th, OV_CHUNK, d_ovstat);
                 }
             }
         }
@@ -882,6 +921,9 @@ struct Merger {
         // 3. merge_point_clouds_list per component: concat in index order + keep-largest DBSCAN
         std::vector<int> seg_of_comp(comps.size(), -1);
         std::vector<SegDesc> segs;
+        std::vector<int> seg_cap;                  // per segment: capacity of its output region (0: dense output)
+        long long region_total = 0;                // points of the fresh output regions (SegDesc::out_mode 1)
+        const bool inplace = use_anchor && inplace_wanted && CloudOps::regions_supported();
         std::vector<CatSeg> cat;
         long long cat_total = 0;
         unsigned cat_blocks = 0;
@@ -936,20 +978,44 @@ struct Merger {
                         sd.fmx[a] = L[f].mx[a];
                     }
                     sd.forced = any_r ? 1 : 0;
+                    // Round 5: such a segment's result IS its anchor member with the kept rest appended.  With room behind the member
+                    // in the pool (Cloud::cap) the batch runs in place -- the member is neither gathered into the batch nor copied to
+                    // a fresh pool range (7.5 MB in and out per step at configs[1]), only its points inside the crop are read; without
+                    // room, this step's output goes to a region of its own with half as much again, and the next ones run in place.
+                    if (sd.forced && inplace) {
+                        if ((long long)L[f].cap >= (long long)sd.n) {
+                            sd.out_mode = 2;
+                            sd.out_off = L[f].off;
+                            seg_cap.push_back(L[f].cap);
+                        } else {
+                            sd.out_mode = 1;
+                            const long long cap = (long long)sd.n + std::max<long long>(sd.n / 2, 1 << 14);
+                            sd.out_off = region_total;       // (relative to the first region: fixed up below)
+                            region_total += cap;
+                            seg_cap.push_back((int)std::min<long long>(cap, 0x7fffffff));
+                        }
+                    }
                 }
             }
+            if (seg_cap.size() <= segs.size()) seg_cap.push_back(0);
             seg_of_comp[c] = (int)segs.size();
             segs.push_back(sd);
         }
         std::vector<DbscanResult> res;
-        long long out_base = pool_used;
+        // pool layout of the step's outputs: [fresh regions of the mode-1 segments | dense outputs of the mode-0 segments]
+        long long dense_total = 0;
+        for (auto& sd : segs) {
+            if (sd.out_mode == 1) sd.out_off += pool_used;
+            if (sd.out_mode == 0) dense_total += sd.n;
+        }
+        long long out_base = pool_used + region_total;
         if (!segs.empty() && cat_total > 0) {
             concat.ensure((size_t)cat_total * 3);
             concat_core.ensure((size_t)cat_total);
             // (the concatenation itself happens inside the DBSCAN batch's binning pass, and the piece table goes up with the
             //  batch's geometry table: DbGather)
-            grow(pool, (size_t)pool_used * 3, (size_t)(pool_used + cat_total) * 3);
-            grow(poolcore, (size_t)pool_used, (size_t)(pool_used + cat_total));
+            grow(pool, (size_t)pool_used * 3, (size_t)(out_base + dense_total) * 3);
+            grow(poolcore, (size_t)pool_used, (size_t)(out_base + dense_total));
             lap(3);
             DbGather ga;
             ga.pool = pool.p;
@@ -957,8 +1023,10 @@ struct Merger {
             ga.nsegs = (int)cat.size();
             ga.poolcore = poolcore.p;
             ga.dstcore = use_anchor ? concat_core.p : nullptr;
-            ops.dbscan_keep_largest(concat.p, segs, eps, minpts, pool.p + (size_t)pool_used * 3, res,
-                                    use_anchor ? (const unsigned char*)concat_core.p : nullptr, poolcore.p + pool_used, &ga);
+            ga.pool_w = pool.p;
+            ga.poolcore_w = poolcore.p;
+            ops.dbscan_keep_largest(concat.p, segs, eps, minpts, pool.p + (size_t)out_base * 3, res,
+                                    use_anchor ? (const unsigned char*)concat_core.p : nullptr, poolcore.p + out_base, &ga);
             lap(4);
             if (want_stats) {
                 for (size_t c = 0; c < comps.size(); ++c) {
@@ -1041,13 +1109,16 @@ struct Merger {
                 k.fixed = true;
                 k.raw = false;
                 k.off = cursor;                 // the identical copy DBSCAN just wrote: it carries the core flags
+                k.cap = k.n;
                 k.anchor = r.n_clusters == 1;
                 out.push_back(k);
                 cursor += r.n_out;
                 continue;
             }
             Cloud k;
-            k.off = cursor;
+            const int mode = segs[sg].out_mode;
+            k.off = mode ? segs[sg].out_off : cursor;      // (an output region of its own / the anchor member's own place)
+            k.cap = mode ? seg_cap[sg] : r.n_out;
             k.n = r.n_out;
             for (int a = 0; a < 3; ++a) {
                 k.mn[a] = r.mn[a];
@@ -1085,7 +1156,7 @@ struct Merger {
                 }
             }
             out.push_back(k);
-            cursor += r.n_out;
+            if (!mode) cursor += r.n_out;
         }
         pool_used = cursor;
         lap(5);
@@ -1266,6 +1337,12 @@ static void merge_report(Folder& m) {
                 t.fresh_raw / S, t.fresh_g / S, t.idx_pts / S);
         fprintf(stderr, "[mstat] pairs/step raw %.1f (scan1 %.0f scan2 %.0f pts)   G-fresh %.1f (scan1 %.0f scan2 %.0f pts)\n", t.pairs_raw / S,
                 t.scan1_raw / S, t.scan2_raw / S, t.pairs_g / S, t.scan1_g / S, t.scan2_g / S);
+        if (m.ovstat.p) {
+            unsigned long long hs[8];
+            (void)hipMemcpy(hs, m.ovstat.p, 64, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[mstat] overlap probes/step %.0f: outside the box %.0f  hit own cell %.0f  hit neighbour %.0f  miss %.0f | candidates/step own %.0f  neighbour %.0f\n",
+                    hs[0] / S, hs[1] / S, hs[2] / S, hs[3] / S, hs[4] / S, hs[5] / S, hs[6] / S);
+        }
         const char* nmc[5] = {"singleton raw", "singleton non-fixed", "anchor+raw", "anchor+any", "other"};
         for (int c = 0; c < 5; ++c)
             fprintf(stderr, "[mstat] dbscan class %-20s comps/step %.2f  pts/step %.0f  B pts/step %.0f  members %.2f  changed %.0f multi %.0f contested %.0f nonfixed %.0f (totals)\n",
@@ -1282,8 +1359,8 @@ static void merge_report(Folder& m) {
                 m.ops.stat_calls, m.ops.stat_points / m.ops.stat_calls, m.ops.stat_cells / m.ops.stat_calls,
                 m.ops.stat_core_cells / m.ops.stat_calls, m.ops.stat_active_cells / m.ops.stat_calls);
     if (getenv("HMSG_DEBUG_TIMING") && m.ops.stat_calls > 0)
-        fprintf(stderr, "[hmsg merge] dbscan segments with a cropped anchor member: %.0f (%.0f anchor points a batch)\n", m.ops.stat_forced,
-                m.ops.stat_forced_first / m.ops.stat_calls);
+        fprintf(stderr, "[hmsg merge] dbscan segments with a cropped anchor member: %.0f (%.0f anchor points a batch), %.0f of them in place; pool %.2f GB\n",
+                m.ops.stat_forced, m.ops.stat_forced_first / m.ops.stat_calls, m.ops.stat_inplace, (double)m.pool_used * 24 / 1e9);
     if (getenv("HMSG_DEBUG_MAXCELL") && m.ops.stat_calls > 0)
         fprintf(stderr, "[hmsg merge] fullest cell of a dbscan batch: mean %.0f points, max %.0f\n", m.ops.stat_maxcell_sum / m.ops.stat_calls, m.ops.stat_maxcell_max);
 }

@@ -180,6 +180,8 @@ def test_cropped_anchor_members_on_the_gpu():
     assert _device_scene(L, spec, inp, nopipe=True) == ref
     assert _device_scene(L, spec, inp, nopipe=False) == ref
     assert _device_scene(L, spec, inp, nopipe=True, env={"HMSG_DEBUG_NOANCHOR": "1"}) == ref
+    # round 5: anchor members that stay where they are in the pool (SegDesc::out_mode 2, the default) against dense copies
+    assert _device_scene(L, spec, inp, nopipe=True, env={"HMSG_DEBUG_NO_INPLACE": "1"}) == ref
 
 
 @pytest.mark.skipif(not os.path.exists(PC.EMU_PATH), reason="kernel simulator not built")
@@ -201,3 +203,11 @@ def test_cropped_anchor_members_on_the_simulator(capfd):
     assert m and int(m.group(1)) >= 2, err1
     assert len(ref) >= 3 and len(got) == len(ref) and all(np.array_equal(a, b) for a, b in zip(got, ref))
     assert np.array_equal(got_f, ref_f)
+    # round 5: some of those segments ran IN PLACE (the anchor member neither gathered nor copied, the kept rest appended behind
+    # it); the same fold with every output a dense copy gives the same instances
+    m = re.search(r"(\d+) of them in place", err1)
+    assert m and int(m.group(1)) >= 1, err1
+    dense, dense_f = _host_scene(L, frames, 16, nopipe=True, env={"HMSG_DEBUG_NO_INPLACE": "1", "HMSG_DEBUG_TIMING": "1"})
+    err2 = capfd.readouterr().err
+    assert re.search(r" 0 of them in place", err2), err2
+    assert len(dense) == len(ref) and all(np.array_equal(a, b) for a, b in zip(dense, ref)) and np.array_equal(dense_f, ref_f)
