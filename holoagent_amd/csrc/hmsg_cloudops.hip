@@ -1032,7 +1032,9 @@ __global__ void __launch_bounds__(256) k_db_compact(const double* __restrict__ p
                                                     const int* __restrict__ parent, double* __restrict__ dst, int* __restrict__ oend,
                                                     int* __restrict__ ostart, int* __restrict__ ofirst, unsigned char* __restrict__ dst_core,
                                                     unsigned long long* __restrict__ obounds, unsigned long long* __restrict__ state,
-                                                    unsigned epoch, double* __restrict__ pool_w, unsigned char* __restrict__ poolcore_w) {
+                                                    unsigned epoch, double* __restrict__ pool_w, unsigned char* __restrict__ poolcore_w,
+                                                    unsigned* __restrict__ done, const unsigned* __restrict__ pub_src, int pub_n,
+                                                    Publisher::Target pub) {
     __shared__ int slot_seg;
     __shared__ unsigned long long slot_box[6];
     __shared__ unsigned wsum[4], wtot[2][4];
@@ -1147,6 +1149,8 @@ __global__ void __launch_bounds__(256) k_db_compact(const double* __restrict__ p
         if (tid < 3) atomicMin(&obounds[(size_t)slot_seg * 6 + tid], slot_box[tid]);
         else atomicMax(&obounds[(size_t)slot_seg * 6 + tid], slot_box[tid]);
     }
+    // the batch's per-segment results go to the host from here (no k_publish launch behind the compaction)
+    if (done) publish_tail(done, pub_src, pub_n, pub);
 }
 
 struct BdSeg {
@@ -1218,9 +1222,15 @@ struct DbInit {
     unsigned *ncl, *rep, *contested, *dropped, *counters;
     long long NC;
     int K;
+    // the batch's tables (segment geometry, gather pieces, compaction blocks) come up from pinned host memory in this launch too
+    // (upload_pinned's k_upload16 was a launch of its own in front of it)
+    const uint4* up_src;
+    uint4* up_dst;
+    size_t up_n16;
 };
 __global__ void k_db_init(DbInit in) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t q = (size_t)i; q < in.up_n16; q += (size_t)gridDim.x * blockDim.x) in.up_dst[q] = in.up_src[q];
     if (i <= in.NC) in.cnt[i] = 0u;          // NC + 1 entries (scan sentinel)
     if (i < in.NC) {
         in.cursor[i] = 0u;
@@ -1242,7 +1252,7 @@ __global__ void k_db_init(DbInit in) {
         in.contested[i] = 0u;
         in.dropped[i] = 0u;
     }
-    if (i < 4) in.counters[i] = 0u;
+    if (i < 8) in.counters[i] = 0u;          // ([4]: workgroups of the compaction that are done, publish_tail)
 }
 
 __global__ void k_publish(const unsigned* __restrict__ src, int n, unsigned* __restrict__ dst_host, unsigned* __restrict__ flag_host,
@@ -1263,6 +1273,17 @@ void Publisher::launch(hipStream_t s, const unsigned* src, size_t n) {
     stream = s;
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, s, src, (int)n, buf.p, buf.p + buf.n - 1, seq);
     HMSG_CHECK_LAUNCH();
+}
+Publisher::Target Publisher::arm(hipStream_t s, size_t n) {
+    buf.ensure(n + 32);
+    if (buf.p != inited || buf.n != inited_n) {
+        buf.p[buf.n - 1] = 0u;
+        inited = buf.p;
+        inited_n = buf.n;
+    }
+    ++seq;
+    stream = s;
+    return Target{buf.p, buf.p + buf.n - 1, seq};
 }
 void Publisher::wait() {
     volatile unsigned* flag = buf.p + buf.n - 1;
@@ -1412,13 +1433,13 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     //  block table ride along.)
     const size_t geom_bytes = ((size_t)K * sizeof(DbSeg) + 15) & ~(size_t)15;
     const size_t cat_bytes = ((gather && gather->host_segs ? (size_t)gather->nsegs * sizeof(CatSeg) : 0) + 15) & ~(size_t)15;
-    const size_t blk_bytes = hblk.size() * sizeof(DbBlk);
+    const size_t blk_bytes = (hblk.size() * sizeof(DbBlk) + 15) & ~(size_t)15;
     geom.ensure(geom_bytes + cat_bytes + blk_bytes);
     h_geom.ensure(geom_bytes + cat_bytes + blk_bytes);
     memcpy(h_geom.p, hs.data(), (size_t)K * sizeof(DbSeg));
     if (cat_bytes) memcpy(h_geom.p + geom_bytes, gather->host_segs, (size_t)gather->nsegs * sizeof(CatSeg));
-    if (blk_bytes) memcpy(h_geom.p + geom_bytes + cat_bytes, hblk.data(), blk_bytes);
-    upload_pinned(geom.p, h_geom.p, geom_bytes + cat_bytes + blk_bytes, s);
+    if (blk_bytes) memcpy(h_geom.p + geom_bytes + cat_bytes, hblk.data(), hblk.size() * sizeof(DbBlk));
+    // (the copy itself rides in k_db_init below)
     DbGather ga_dev = gather ? *gather : DbGather{};
     if (cat_bytes) ga_dev.segs = (const CatSeg*)(geom.p + geom_bytes);
     const DbSeg* dsegs = (const DbSeg*)geom.p;
@@ -1429,13 +1450,13 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     rootmin.ensure(NC);
     best.ensure(K);
     rep.ensure(K);
-    kres.ensure((size_t)K * 18 + 4);            // per segment: n_out (or output end) | n_clusters | contested | dropped | 6 x u64 box; 4 counters; per segment: output start
+    kres.ensure((size_t)K * 18 + 8);            // per segment: n_out (or output end) | n_clusters | contested | dropped | 6 x u64 box; 8 counter words; per segment: output start | end of the first member's output
     int* const d_ocount = (int*)kres.p;
     unsigned* const d_ncl = kres.p + K;
     unsigned* const d_contested = kres.p + 2 * (size_t)K;
     unsigned* const d_dropped = kres.p + 3 * (size_t)K;
     unsigned long long* const d_obounds = (unsigned long long*)(kres.p + 4 * (size_t)K);
-    int* const d_ostart = (int*)(kres.p + (size_t)K * 16 + 4);
+    int* const d_ostart = (int*)(kres.p + (size_t)K * 16 + 8);
     int* const d_ofirst = d_ostart + K;     // per segment: output position of the first point behind the first member
     active.ensure(NC); hasanchor.ensure(NC);
     corelist.ensure((size_t)std::max<long long>(N, 1));
@@ -1453,6 +1474,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
         in.best = best.p; in.obounds = d_obounds; in.ocount = d_ocount; in.ostart = d_ostart; in.ofirst = d_ofirst; in.ncl = d_ncl; in.rep = rep.p; in.contested = d_contested; in.dropped = d_dropped;
         in.counters = kres.p + (size_t)K * 16;   // [0] core cells, [1] active core cells
         in.NC = NC; in.K = K;
+        in.up_src = (const uint4*)h_geom.p; in.up_dst = (uint4*)geom.p; in.up_n16 = (geom_bytes + cat_bytes + blk_bytes) / 16;
         hipLaunchKernelGGL(k_db_init, dim3(cdiv(NC + 1, 256)), dim3(256), 0, s, in);
     }
     int maxn = 0;
@@ -1527,6 +1549,9 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     hipLaunchKernelGGL(k_db_pick, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc, (const int*)cseg.p, dsegs, K,
                        (const unsigned*)size.p, (const unsigned*)firstidx.p, (const unsigned*)rootmin.p, best.p);
     static const bool dump_wanted = getenv("HMSG_DEBUG_DUMP") != nullptr;
+    static const bool no_fused_publish = getenv("HMSG_DEBUG_PUBLISH_LAUNCH") != nullptr;     // (comparison runs: k_publish as a launch of its own)
+    bool fused_publish = false;
+    Publisher::Target pub_t{nullptr, nullptr, 0u};
     if (split_compact) {
     hipLaunchKernelGGL(k_db_flags, dim3(gN), dim3(256), 0, s, N, (const int*)segid.p, dsegs, (const int*)label.p,
                        (const unsigned long long*)best.p, flags.p, d_dropped, (const unsigned char*)core.p,
@@ -1541,13 +1566,16 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     } else {
         const unsigned gK = (unsigned)hblk.size();
         const unsigned epoch = hmsg_scan_epoch(scan_tmp, gK, s);
+        fused_publish = gK > 0 && !no_fused_publish;
+        if (fused_publish) pub_t = pub.arm(s, (size_t)K * 18 + 8);
         ProfScope ps(prof, s, "k_db_scatter", (double)N * 56.0);
         if (gK)
             hipLaunchKernelGGL(k_db_compact, dim3(gK), dim3(256), 0, s, src, dblks, (const int*)segid.p, dsegs, (const int*)label.p,
                                (const unsigned long long*)best.p, (const unsigned*)rep.p, dump_wanted ? flags.p : (unsigned*)nullptr, (const unsigned char*)core.p,
                                (const long long*)cellid.p, (const int*)parent.p, dst, d_ocount, d_ostart, d_ofirst, dst_core, d_obounds,
                                reinterpret_cast<unsigned long long*>(scan_tmp.p), epoch, gather ? gather->pool_w : (double*)nullptr,
-                               gather ? gather->poolcore_w : (unsigned char*)nullptr);
+                               gather ? gather->poolcore_w : (unsigned char*)nullptr, fused_publish ? kres.p + (size_t)K * 16 + 4 : (unsigned*)nullptr,
+                               (const unsigned*)kres.p, (int)((size_t)K * 18 + 8), pub_t);
     }
     HMSG_CHECK_LAUNCH();
     {   // debug: HMSG_DEBUG_DBCALL=<n> dumps the n-th batch (inputs + per-point results) under HMSG_DEBUG_DUMP
@@ -1567,7 +1595,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
         ++call_no;
     }
     // one copy brings back counts, cluster counts, contest flags and the boxes of the kept points
-    pub.launch(s, (const unsigned*)kres.p, (size_t)K * 18 + 4);
+    if (!fused_publish) pub.launch(s, (const unsigned*)kres.p, (size_t)K * 18 + 8);
     pub.wait();
     const unsigned* hres = pub.data();
     const unsigned long long* hb = reinterpret_cast<const unsigned long long*>(hres + (size_t)K * 4);
@@ -1579,7 +1607,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     long long total = 0;
     for (int k = 0; k < K; ++k) {
         // (one launch: output end - output start, positions in the segment's chain; in place: the anchor member + the kept rest)
-        const int n_out = hs[k].out_mode == 2 ? hs[k].n_first + (int)hres[k] : (int)hres[k] - (split_compact ? 0 : (int)hres[(size_t)K * 16 + 4 + k]);
+        const int n_out = hs[k].out_mode == 2 ? hs[k].n_first + (int)hres[k] : (int)hres[k] - (split_compact ? 0 : (int)hres[(size_t)K * 16 + 8 + k]);
         res[k].n_out = n_out;
         res[k].changed = n_out != segs[k].n;
         res[k].n_clusters = (int)hres[(size_t)K + k];
@@ -1587,7 +1615,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
         res[k].first_kept = -1;
         if (!split_compact && segs[k].n_first > 0)
             res[k].first_kept = hs[k].out_mode == 2 ? segs[k].n_first
-                                : (segs[k].n_first < segs[k].n ? (int)hres[(size_t)K * 17 + 4 + k] - (int)hres[(size_t)K * 16 + 4 + k] : n_out);
+                                : (segs[k].n_first < segs[k].n ? (int)hres[(size_t)K * 17 + 8 + k] - (int)hres[(size_t)K * 16 + 8 + k] : n_out);
         for (int a = 0; a < 3; ++a) {
             // unchanged: the input box is exact (and maybe tighter bookkeeping upstream relies on it bit for bit)
             res[k].mn[a] = !n_out ? 0.0 : (res[k].changed ? dec_f64(hb[(size_t)k * 6 + a]) : segs[k].mn[a]);

@@ -288,14 +288,16 @@ static const int OV_CHUNK = 256;       /* points per workgroup of the overlap sc
 __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __restrict__ gr, const OvTask* __restrict__ tasks,
                            const unsigned* __restrict__ cells, const float* __restrict__ sorted, float r2, float r,
                            int npairs, const int* __restrict__ blk_task, unsigned blk_off, unsigned* __restrict__ counts,
-                           const unsigned* __restrict__ dep_counts, double th, int chunk, unsigned long long* __restrict__ st) {
+                           const unsigned* __restrict__ dep_counts, double th, int chunk, unsigned long long* __restrict__ st,
+                           unsigned* __restrict__ done, int pub_n, Publisher::Target pub) {
     const unsigned blk = blockIdx.x + blk_off;
     const int ti = blk_task[blk];
     const OvTask t = tasks[ti];
     const bool second = ti >= npairs;
-    if (second && dep_counts && (double)dep_counts[ti - npairs] / (double)t.dep_n > th) return;
+    // (no early return: the workgroup that finishes last sends the counts to the host, publish_tail at the end)
+    bool run = !(second && dep_counts && (double)dep_counts[ti - npairs] / (double)t.dep_n > th);
     const OvGrid X = gr[t.x], Y = gr[t.y];
-    if (second && th >= 0.0) {
+    if (run && second && th >= 0.0) {
         // Second direction, first ratio <= th: the pair merges only if MORE than th * |X| points of X (the larger cloud) have
         // a point of Y (the smaller one) within r.  Such a point lies in Y's box grown by r, and X's own grid says how many
         // of its points do: the sum of its cell counts over that box (z-cells of a column are contiguous: two loads per
@@ -346,13 +348,13 @@ __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __rest
         inbox = s_in[0] + s_in[1] + s_in[2] + s_in[3];
         if (!((double)inbox / (double)X.n > th)) {
             if (blk == (unsigned)t.blk0 && threadIdx.x == 0) counts[ti] = 0x80000000u;   // (decided by the bound: no scan)
-            return;
+            run = false;
         }
     }
     unsigned local = 0;
     // a workgroup takes OV_CHUNK consecutive points: every point is a serial chain of L2 round trips, so a
     // million-point X is spread over many workgroups (work list: exactly ceil(n / OV_CHUNK) of them per task)
-    {
+    if (run) {
         const int b0 = (int)(blk - (unsigned)t.blk0) * chunk;
         const int b1 = b0 + chunk < X.n ? b0 + chunk : X.n;
         const OvGrid Y2 = gr[Y.next >= 0 ? Y.next : t.y];      // (Y's delta grid, if it has one)
@@ -365,6 +367,7 @@ __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __rest
     }
     for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(&counts[ti], local);
+    if (done) publish_tail(done, counts, pub_n, pub);
 }
 
 static const int CAT_CHUNK = 512;      /* points per workgroup of k_concat */
@@ -710,12 +713,12 @@ struct Merger {
         for (size_t k = 0; k < P; ++k) tasks[P + k].blk0 += (int)nblk1;      // (one work list over both directions)
         const size_t nblk = (size_t)nblk1 + nblk2;
         const size_t off_t = (g.size() * sizeof(OvGrid) + 15) & ~(size_t)15, off_c = off_t + tasks.size() * sizeof(OvTask),
-                     off_b = off_c + tasks.size() * 4, pack = off_b + nblk * 4;
+                     off_b = off_c + tasks.size() * 4 + 16, pack = off_b + nblk * 4;     // (behind the counts: the done counter of publish_tail)
         h_ovpack.ensure(pack);
         d_ovpack.ensure(pack);
         memcpy(h_ovpack.p, g.data(), g.size() * sizeof(OvGrid));
         memcpy(h_ovpack.p + off_t, tasks.data(), tasks.size() * sizeof(OvTask));
-        memset(h_ovpack.p + off_c, 0, tasks.size() * 4);
+        memset(h_ovpack.p + off_c, 0, tasks.size() * 4 + 16);
         {   // workgroup -> task
             int* bt = (int*)(h_ovpack.p + off_b);
             for (size_t k = 0; k < 2 * P; ++k) {
@@ -732,6 +735,11 @@ struct Merger {
         const float r2 = (float)(radius * radius);   // `D < radius**2` with a float32 D (graph_utils.py:654-655)
         const size_t prof_idx = ops.prof->ev.size();        // (algorithmic bytes are filled in after the read-back)
         static const bool two_launch = getenv("HMSG_OV_ONE_LAUNCH") == nullptr;
+        static const bool no_fused_publish = getenv("HMSG_DEBUG_PUBLISH_LAUNCH") != nullptr;
+        unsigned* const d_done = dc + tasks.size();
+        const bool fused_publish = nblk > 0 && !no_fused_publish;
+        Publisher::Target pt{nullptr, nullptr, 0u};
+        if (fused_publish) pt = pub_counts.arm(s, tasks.size());
         unsigned long long* d_ovstat = nullptr;
         if (want_stats) {
             if (!ovstat.p) {
@@ -745,19 +753,22 @@ struct Merger {
             if (!two_launch) {
                 if (nblk)
                     hipLaunchKernelGGL(k_ov_query, dim3((unsigned)nblk), dim3(256), 0, s, (const double*)pool.p, dg, dt, (const unsigned*)ix_cells.p,
-                                       (const float*)ix_pts.p, r2, r, (int)P, db, 0u, dc, (const unsigned*)nullptr, decide_th, OV_CHUNK, d_ovstat);
+                                       (const float*)ix_pts.p, r2, r, (int)P, db, 0u, dc, (const unsigned*)nullptr, decide_th, OV_CHUNK, d_ovstat,
+                                       fused_publish ? d_done : (unsigned*)nullptr, (int)tasks.size(), pt);
             } else {
+                const int last_dir = nblk2 ? 1 : 0;          // (the launch whose last workgroup publishes)
                 for (int dir = 0; dir < 2; ++dir) {
                     const unsigned nb = dir ? nblk2 : nblk1;
                     if (!nb) continue;
                     hipLaunchKernelGGL(k_ov_query, dim3(nb), dim3(256), 0, s, (const double*)pool.p, dg, dt, (const unsigned*)ix_cells.p,
                                        (const float*)ix_pts.p, r2, r, (int)P, db, dir ? nblk1 : 0u, dc,
-                                       (dir && decide_th >= 0.0) ? (const unsigned*)dc : (const unsigned*)nullptr, decide_th, OV_CHUNK, d_ovstat);
+                                       (dir && decide_th >= 0.0) ? (const unsigned*)dc : (const unsigned*)nullptr, decide_th, OV_CHUNK, d_ovstat,
+                                       fused_publish && dir == last_dir ? d_done : (unsigned*)nullptr, (int)tasks.size(), pt);
                 }
             }
         }
         HMSG_CHECK_LAUNCH();
-        pub_counts.launch(s, (const unsigned*)dc, tasks.size());
+        if (!fused_publish) pub_counts.launch(s, (const unsigned*)dc, tasks.size());
         pub_counts.wait();
         const unsigned* hc = pub_counts.data();
         // Algorithmic bytes of the step (merge): `sum over bbox-overlapping pairs (n_A + n_B) * 12` -- the float32 points
