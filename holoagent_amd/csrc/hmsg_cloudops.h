@@ -68,35 +68,9 @@ struct Publisher {
     hipStream_t stream = nullptr;    // of the last launch (wait() asks it whether it is still alive)
     // enqueue on s: copy src[0 .. n) (device) to the host buffer; data() is valid after wait()
     void launch(hipStream_t s, const unsigned* src, size_t n);
-    // the same without a launch of its own: the LAST workgroup of a kernel already in the stream does the copy (publish_tail below);
-    // arm() hands that kernel what it needs
-    struct Target {
-        unsigned* dst_host;
-        unsigned* flag_host;
-        unsigned seq;
-    };
-    Target arm(hipStream_t s, size_t n);
     void wait();
     const unsigned* data() const { return buf.p; }
 };
-
-// Tail of a kernel whose results the host waits for (call it at the very end, every thread of every workgroup): the workgroup
-// that finishes last copies src[0 .. n) to pinned host memory and raises the flag -- what k_publish does as a launch of its own
-// (~4 us + the gap in front of it, twice per fold step).  `done` is a zeroed counter word.
-__device__ __forceinline__ void publish_tail(unsigned* done, const unsigned* src, int n, Publisher::Target t) {
-    __shared__ int s_last;
-    __threadfence();                                  // this thread's results are out before the workgroup counts itself done
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(done, 1u) == gridDim.x - 1u ? 1 : 0;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    for (int i = threadIdx.x; i < n; i += blockDim.x)
-        t.dst_host[i] = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (L2, not this CU's L1)
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(t.flag_host, t.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
 
 struct CloudOps {
     hipStream_t s = nullptr;

@@ -1032,9 +1032,7 @@ __global__ void __launch_bounds__(256) k_db_compact(const double* __restrict__ p
                                                     const int* __restrict__ parent, double* __restrict__ dst, int* __restrict__ oend,
                                                     int* __restrict__ ostart, int* __restrict__ ofirst, unsigned char* __restrict__ dst_core,
                                                     unsigned long long* __restrict__ obounds, unsigned long long* __restrict__ state,
-                                                    unsigned epoch, double* __restrict__ pool_w, unsigned char* __restrict__ poolcore_w,
-                                                    unsigned* __restrict__ done, const unsigned* __restrict__ pub_src, int pub_n,
-                                                    Publisher::Target pub) {
+                                                    unsigned epoch, double* __restrict__ pool_w, unsigned char* __restrict__ poolcore_w) {
     __shared__ int slot_seg;
     __shared__ unsigned long long slot_box[6];
     __shared__ unsigned wsum[4], wtot[2][4];
@@ -1149,8 +1147,6 @@ __global__ void __launch_bounds__(256) k_db_compact(const double* __restrict__ p
         if (tid < 3) atomicMin(&obounds[(size_t)slot_seg * 6 + tid], slot_box[tid]);
         else atomicMax(&obounds[(size_t)slot_seg * 6 + tid], slot_box[tid]);
     }
-    // the batch's per-segment results go to the host from here (no k_publish launch behind the compaction)
-    if (done) publish_tail(done, pub_src, pub_n, pub);
 }
 
 struct BdSeg {
@@ -1273,17 +1269,6 @@ void Publisher::launch(hipStream_t s, const unsigned* src, size_t n) {
     stream = s;
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, s, src, (int)n, buf.p, buf.p + buf.n - 1, seq);
     HMSG_CHECK_LAUNCH();
-}
-Publisher::Target Publisher::arm(hipStream_t s, size_t n) {
-    buf.ensure(n + 32);
-    if (buf.p != inited || buf.n != inited_n) {
-        buf.p[buf.n - 1] = 0u;
-        inited = buf.p;
-        inited_n = buf.n;
-    }
-    ++seq;
-    stream = s;
-    return Target{buf.p, buf.p + buf.n - 1, seq};
 }
 void Publisher::wait() {
     volatile unsigned* flag = buf.p + buf.n - 1;
@@ -1549,9 +1534,6 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     hipLaunchKernelGGL(k_db_pick, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc, (const int*)cseg.p, dsegs, K,
                        (const unsigned*)size.p, (const unsigned*)firstidx.p, (const unsigned*)rootmin.p, best.p);
     static const bool dump_wanted = getenv("HMSG_DEBUG_DUMP") != nullptr;
-    static const bool no_fused_publish = getenv("HMSG_DEBUG_PUBLISH_LAUNCH") != nullptr;     // (comparison runs: k_publish as a launch of its own)
-    bool fused_publish = false;
-    Publisher::Target pub_t{nullptr, nullptr, 0u};
     if (split_compact) {
     hipLaunchKernelGGL(k_db_flags, dim3(gN), dim3(256), 0, s, N, (const int*)segid.p, dsegs, (const int*)label.p,
                        (const unsigned long long*)best.p, flags.p, d_dropped, (const unsigned char*)core.p,
@@ -1566,16 +1548,13 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     } else {
         const unsigned gK = (unsigned)hblk.size();
         const unsigned epoch = hmsg_scan_epoch(scan_tmp, gK, s);
-        fused_publish = gK > 0 && !no_fused_publish;
-        if (fused_publish) pub_t = pub.arm(s, (size_t)K * 18 + 8);
         ProfScope ps(prof, s, "k_db_scatter", (double)N * 56.0);
         if (gK)
             hipLaunchKernelGGL(k_db_compact, dim3(gK), dim3(256), 0, s, src, dblks, (const int*)segid.p, dsegs, (const int*)label.p,
                                (const unsigned long long*)best.p, (const unsigned*)rep.p, dump_wanted ? flags.p : (unsigned*)nullptr, (const unsigned char*)core.p,
                                (const long long*)cellid.p, (const int*)parent.p, dst, d_ocount, d_ostart, d_ofirst, dst_core, d_obounds,
                                reinterpret_cast<unsigned long long*>(scan_tmp.p), epoch, gather ? gather->pool_w : (double*)nullptr,
-                               gather ? gather->poolcore_w : (unsigned char*)nullptr, fused_publish ? kres.p + (size_t)K * 16 + 4 : (unsigned*)nullptr,
-                               (const unsigned*)kres.p, (int)((size_t)K * 18 + 8), pub_t);
+                               gather ? gather->poolcore_w : (unsigned char*)nullptr);
     }
     HMSG_CHECK_LAUNCH();
     {   // debug: HMSG_DEBUG_DBCALL=<n> dumps the n-th batch (inputs + per-point results) under HMSG_DEBUG_DUMP
@@ -1595,7 +1574,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
         ++call_no;
     }
     // one copy brings back counts, cluster counts, contest flags and the boxes of the kept points
-    if (!fused_publish) pub.launch(s, (const unsigned*)kres.p, (size_t)K * 18 + 8);
+    pub.launch(s, (const unsigned*)kres.p, (size_t)K * 18 + 8);
     pub.wait();
     const unsigned* hres = pub.data();
     const unsigned long long* hb = reinterpret_cast<const unsigned long long*>(hres + (size_t)K * 4);

@@ -225,9 +225,12 @@ __device__ __forceinline__ bool ov_hit(const OvGrid& Y, const unsigned* __restri
     if (ov_scan(sy, s0, e0, x, y, z, r2, st ? &nc : nullptr)) {
         ov_stat(st, 2);
         ov_stat(st, 5, nc);
+        if (st && nc > 32u) atomicAdd(&st[8], 1ull), atomicAdd(&st[9], (unsigned long long)nc);
+        if (st) atomicMax(&st[7], (unsigned long long)nc);
         return true;
     }
     ov_stat(st, 5, nc);
+    const unsigned nc_own = nc;
     nc = 0u;
     unsigned rs[10], re[10];
     ov_col_ranges(Y, p, cells, rs, re);
@@ -240,6 +243,8 @@ __device__ __forceinline__ bool ov_hit(const OvGrid& Y, const unsigned* __restri
         }
     ov_stat(st, 4);
     ov_stat(st, 6, nc);
+    if (st && nc + nc_own > 32u) atomicAdd(&st[8], 1ull), atomicAdd(&st[9], (unsigned long long)(nc + nc_own));
+    if (st) atomicMax(&st[7], (unsigned long long)(nc + nc_own));
     return false;
 }
 // the same against a cloud with two grids (base + delta, hmsg_merge.hip: Cloud::nb): the two grids' table look-ups go out
@@ -271,6 +276,87 @@ __device__ __forceinline__ bool ov_hit2(const OvGrid& Y, const OvGrid& Y2, const
     return false;
 }
 
+// ---- Round 5: the tail of the scans.  Measured on configs[1] (HMSG_DEBUG_MERGESTATS, profiles/r05_ov_probe_stats.txt): a fold
+// step makes 1.5 * 10^5 probes that test 1.4 candidates each on average -- but 291 of them walk more than 32 candidates (160
+// on average, 581 at most: a point next to, but not within r of, a cell where a floor has piled up its re-observations), four
+// candidates per round trip, and the launch lasts as long as its slowest lane.  A lane now only attempts probes whose candidate
+// lists are short; a probe with a long list is handed to the WHOLE WAVE afterwards: the lanes test 64 candidates per round trip
+// with a ballot as the early exit.  Same candidates, same float32 arithmetic, same answer.
+#define OV_HEAVY 24u    /* candidates a lane walks on its own at most */
+__device__ __forceinline__ bool ov_scan_wave(const float* __restrict__ sorted, unsigned s0, unsigned e0, float x, float y, float z, float r2) {
+    const unsigned lane = threadIdx.x & 63u;
+    for (unsigned k = s0; k < e0; k += 64u) {                  // (wave-uniform trip count)
+        const unsigned kk = k + lane;
+        bool h = false;
+        if (kk < e0) {
+            float ddx = __fsub_rn(x, sorted[(size_t)kk * 3]), ddy = __fsub_rn(y, sorted[(size_t)kk * 3 + 1]),
+                  ddz = __fsub_rn(z, sorted[(size_t)kk * 3 + 2]);
+            h = __fadd_rn(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)), __fmul_rn(ddz, ddz)) < r2;
+        }
+        if (__any(h)) return true;
+    }
+    return false;
+}
+// every lane of the wave calls this with the SAME point
+__device__ __forceinline__ bool ov_hit_wave(const OvGrid& Y, const unsigned* __restrict__ cells, const float* __restrict__ sorted,
+                                            float x, float y, float z, float r2, float r) {
+    if (x < Y.mnx - r || x > Y.mxx + r || y < Y.mny - r || y > Y.mxy + r || z < Y.mnz - r || z > Y.mxz + r) return false;
+    const OvProbe p = ov_probe(Y, x, y, z);
+    if (!p.any) return false;
+    const float* const sy = sorted + (size_t)Y.ix_pt * 3;
+    unsigned s0, e0;
+    ov_own_range(Y, p, cells, s0, e0);
+    if (ov_scan_wave(sy, s0, e0, x, y, z, r2)) return true;
+    unsigned rs[10], re[10];
+    ov_col_ranges(Y, p, cells, rs, re);
+#pragma unroll
+    for (int q = 0; q < 10; ++q)
+        if (ov_scan_wave(sy, rs[q], re[q], x, y, z, r2)) return true;
+    return false;
+}
+// a lane's own attempt: 1 = some point of Y within r, 0 = none, 2 = the candidate lists are long (the wave takes the probe over)
+__device__ __forceinline__ int ov_try(const OvGrid& Y, const OvGrid& Y2, bool two, const unsigned* __restrict__ cells,
+                                      const float* __restrict__ sorted, float x, float y, float z, float r2, float r) {
+    if (x < Y.mnx - r || x > Y.mxx + r || y < Y.mny - r || y > Y.mxy + r || z < Y.mnz - r || z > Y.mxz + r) return 0;   // (both grids carry the cloud's box)
+    const OvProbe p = ov_probe(Y, x, y, z);
+    const float* const sy = sorted + (size_t)Y.ix_pt * 3;
+    const float* const sy2 = sorted + (size_t)Y2.ix_pt * 3;
+    unsigned s0, e0, s2 = 0u, e2 = 0u;
+    ov_own_range(Y, p, cells, s0, e0);
+    OvProbe p2 = p;
+    if (two) {
+        p2 = ov_probe(Y2, x, y, z);
+        ov_own_range(Y2, p2, cells, s2, e2);
+    }
+    if ((e0 - s0) + (e2 - s2) > OV_HEAVY) return 2;
+    if (ov_scan(sy, s0, e0, x, y, z, r2)) return 1;
+    if (ov_scan(sy2, s2, e2, x, y, z, r2)) return 1;
+    unsigned rs[10], re[10], rs2[10], re2[10];
+    unsigned total = 0u;
+    if (p.any) {
+        ov_col_ranges(Y, p, cells, rs, re);
+#pragma unroll
+        for (int q = 0; q < 10; ++q) total += re[q] - rs[q];
+    }
+    if (two && p2.any) {
+        ov_col_ranges(Y2, p2, cells, rs2, re2);
+#pragma unroll
+        for (int q = 0; q < 10; ++q) total += re2[q] - rs2[q];
+    }
+    if (total > OV_HEAVY) return 2;
+    if (p.any) {
+#pragma unroll
+        for (int q = 0; q < 10; ++q)
+            if (ov_scan(sy, rs[q], re[q], x, y, z, r2)) return 1;
+    }
+    if (two && p2.any) {
+#pragma unroll
+        for (int q = 0; q < 10; ++q)
+            if (ov_scan(sy2, rs2[q], re2[q], x, y, z, r2)) return 1;
+    }
+    return 0;
+}
+
 static const int OV_CHUNK = 256;       /* points per workgroup of the overlap scans (128 .. 512 measured within 3 us of each other) */
 // find_overlapping_ratio_faiss (graph_utils.py:645-662): a point of X overlaps when its exact float32
 // nearest neighbour in Y is closer than r^2, i.e. when SOME y has (dx*dx + dy*dy) + dz*dz < r2 in float32.
@@ -288,13 +374,11 @@ static const int OV_CHUNK = 256;       /* points per workgroup of the overlap sc
 __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __restrict__ gr, const OvTask* __restrict__ tasks,
                            const unsigned* __restrict__ cells, const float* __restrict__ sorted, float r2, float r,
                            int npairs, const int* __restrict__ blk_task, unsigned blk_off, unsigned* __restrict__ counts,
-                           const unsigned* __restrict__ dep_counts, double th, int chunk, unsigned long long* __restrict__ st,
-                           unsigned* __restrict__ done, int pub_n, Publisher::Target pub) {
+                           const unsigned* __restrict__ dep_counts, double th, int chunk, unsigned long long* __restrict__ st) {
     const unsigned blk = blockIdx.x + blk_off;
     const int ti = blk_task[blk];
     const OvTask t = tasks[ti];
     const bool second = ti >= npairs;
-    // (no early return: the workgroup that finishes last sends the counts to the host, publish_tail at the end)
     bool run = !(second && dep_counts && (double)dep_counts[ti - npairs] / (double)t.dep_n > th);
     const OvGrid X = gr[t.x], Y = gr[t.y];
     if (run && second && th >= 0.0) {
@@ -358,16 +442,37 @@ __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __rest
         const int b0 = (int)(blk - (unsigned)t.blk0) * chunk;
         const int b1 = b0 + chunk < X.n ? b0 + chunk : X.n;
         const OvGrid Y2 = gr[Y.next >= 0 ? Y.next : t.y];      // (Y's delta grid, if it has one)
-        for (int i = b0 + (int)threadIdx.x; i < b1; i += blockDim.x) {
-            const double* p = pool + (size_t)(X.pt_off + i) * 3;
-            const float x = (float)p[0], y = (float)p[1], z = (float)p[2];
-            const bool hit = Y.next >= 0 ? ov_hit2(Y, Y2, cells, sorted, x, y, z, r2, r, st) : ov_hit(Y, cells, sorted, x, y, z, r2, r, st);
-            local += hit ? 1u : 0u;
+        const bool two = Y.next >= 0;
+        for (int base = b0; base < b1; base += (int)blockDim.x) {          // (workgroup-uniform trip count: the waves cooperate below)
+            const int i = base + (int)threadIdx.x;
+            const bool act = i < b1;
+            float x = 0.f, y = 0.f, z = 0.f;
+            if (act) {
+                const double* p = pool + (size_t)(X.pt_off + i) * 3;
+                x = (float)p[0];
+                y = (float)p[1];
+                z = (float)p[2];
+            }
+            int state = 0;
+            if (st) {                                                     // (statistics runs: every probe walked by its own lane)
+                if (act) state = (two ? ov_hit2(Y, Y2, cells, sorted, x, y, z, r2, r, st) : ov_hit(Y, cells, sorted, x, y, z, r2, r, st)) ? 1 : 0;
+            } else {
+                if (act) state = ov_try(Y, Y2, two, cells, sorted, x, y, z, r2, r);
+                unsigned long long heavy = __ballot(state == 2);
+                while (heavy) {
+                    const int src = __ffsll(heavy) - 1;
+                    heavy &= heavy - 1ull;
+                    const float hx = __shfl(x, src), hy = __shfl(y, src), hz = __shfl(z, src);
+                    bool h = ov_hit_wave(Y, cells, sorted, hx, hy, hz, r2, r);
+                    if (!h && two) h = ov_hit_wave(Y2, cells, sorted, hx, hy, hz, r2, r);
+                    if ((int)(threadIdx.x & 63u) == src) state = h ? 1 : 0;
+                }
+            }
+            local += state == 1 ? 1u : 0u;
         }
     }
     for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(&counts[ti], local);
-    if (done) publish_tail(done, counts, pub_n, pub);
 }
 
 static const int CAT_CHUNK = 512;      /* points per workgroup of k_concat */
@@ -713,12 +818,12 @@ struct Merger {
         for (size_t k = 0; k < P; ++k) tasks[P + k].blk0 += (int)nblk1;      // (one work list over both directions)
         const size_t nblk = (size_t)nblk1 + nblk2;
         const size_t off_t = (g.size() * sizeof(OvGrid) + 15) & ~(size_t)15, off_c = off_t + tasks.size() * sizeof(OvTask),
-                     off_b = off_c + tasks.size() * 4 + 16, pack = off_b + nblk * 4;     // (behind the counts: the done counter of publish_tail)
+                     off_b = off_c + tasks.size() * 4, pack = off_b + nblk * 4;
         h_ovpack.ensure(pack);
         d_ovpack.ensure(pack);
         memcpy(h_ovpack.p, g.data(), g.size() * sizeof(OvGrid));
         memcpy(h_ovpack.p + off_t, tasks.data(), tasks.size() * sizeof(OvTask));
-        memset(h_ovpack.p + off_c, 0, tasks.size() * 4 + 16);
+        memset(h_ovpack.p + off_c, 0, tasks.size() * 4);
         {   // workgroup -> task
             int* bt = (int*)(h_ovpack.p + off_b);
             for (size_t k = 0; k < 2 * P; ++k) {
@@ -735,16 +840,14 @@ struct Merger {
         const float r2 = (float)(radius * radius);   // `D < radius**2` with a float32 D (graph_utils.py:654-655)
         const size_t prof_idx = ops.prof->ev.size();        // (algorithmic bytes are filled in after the read-back)
         static const bool two_launch = getenv("HMSG_OV_ONE_LAUNCH") == nullptr;
-        static const bool no_fused_publish = getenv("HMSG_DEBUG_PUBLISH_LAUNCH") != nullptr;
-        unsigned* const d_done = dc + tasks.size();
-        const bool fused_publish = nblk > 0 && !no_fused_publish;
-        Publisher::Target pt{nullptr, nullptr, 0u};
-        if (fused_publish) pt = pub_counts.arm(s, tasks.size());
+        // (Round 5, measured and withdrawn: the counts sent to the host by the LAST workgroup of the last launch instead of a
+        //  k_publish launch behind it -- "count yourself done" needs an agent-scope release fence per workgroup, which on this
+        //  chip writes the XCD's L2 back: k_ov_query 25.6 -> 157 us per launch, k_db_compact 13.7 -> 26.9 us; profiles/r05_fused_publish.txt.)
         unsigned long long* d_ovstat = nullptr;
         if (want_stats) {
             if (!ovstat.p) {
-                ovstat.alloc(8);
-                HIP_TRY(hipMemsetAsync(ovstat.p, 0, 64, s));
+                ovstat.alloc(16);
+                HIP_TRY(hipMemsetAsync(ovstat.p, 0, 128, s));
             }
             d_ovstat = ovstat.p;
         }
@@ -753,22 +856,19 @@ struct Merger {
             if (!two_launch) {
                 if (nblk)
                     hipLaunchKernelGGL(k_ov_query, dim3((unsigned)nblk), dim3(256), 0, s, (const double*)pool.p, dg, dt, (const unsigned*)ix_cells.p,
-                                       (const float*)ix_pts.p, r2, r, (int)P, db, 0u, dc, (const unsigned*)nullptr, decide_th, OV_CHUNK, d_ovstat,
-                                       fused_publish ? d_done : (unsigned*)nullptr, (int)tasks.size(), pt);
+                                       (const float*)ix_pts.p, r2, r, (int)P, db, 0u, dc, (const unsigned*)nullptr, decide_th, OV_CHUNK, d_ovstat);
             } else {
-                const int last_dir = nblk2 ? 1 : 0;          // (the launch whose last workgroup publishes)
                 for (int dir = 0; dir < 2; ++dir) {
                     const unsigned nb = dir ? nblk2 : nblk1;
                     if (!nb) continue;
                     hipLaunchKernelGGL(k_ov_query, dim3(nb), dim3(256), 0, s, (const double*)pool.p, dg, dt, (const unsigned*)ix_cells.p,
                                        (const float*)ix_pts.p, r2, r, (int)P, db, dir ? nblk1 : 0u, dc,
-                                       (dir && decide_th >= 0.0) ? (const unsigned*)dc : (const unsigned*)nullptr, decide_th, OV_CHUNK, d_ovstat,
-                                       fused_publish && dir == last_dir ? d_done : (unsigned*)nullptr, (int)tasks.size(), pt);
+                                       (dir && decide_th >= 0.0) ? (const unsigned*)dc : (const unsigned*)nullptr, decide_th, OV_CHUNK, d_ovstat);
                 }
             }
         }
         HMSG_CHECK_LAUNCH();
-        if (!fused_publish) pub_counts.launch(s, (const unsigned*)dc, tasks.size());
+        pub_counts.launch(s, (const unsigned*)dc, tasks.size());
         pub_counts.wait();
         const unsigned* hc = pub_counts.data();
         // Algorithmic bytes of the step (merge): `sum over bbox-overlapping pairs (n_A + n_B) * 12` -- the float32 points
@@ -1349,8 +1449,10 @@ static void merge_report(Folder& m) {
         fprintf(stderr, "[mstat] pairs/step raw %.1f (scan1 %.0f scan2 %.0f pts)   G-fresh %.1f (scan1 %.0f scan2 %.0f pts)\n", t.pairs_raw / S,
                 t.scan1_raw / S, t.scan2_raw / S, t.pairs_g / S, t.scan1_g / S, t.scan2_g / S);
         if (m.ovstat.p) {
-            unsigned long long hs[8];
-            (void)hipMemcpy(hs, m.ovstat.p, 64, hipMemcpyDeviceToHost);
+            unsigned long long hs[16];
+            (void)hipMemcpy(hs, m.ovstat.p, 128, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[mstat] overlap probes with > 32 candidates: %.1f per step, %.0f candidates per step; longest candidate list of a probe %llu\n",
+                    hs[8] / S, hs[9] / S, hs[7]);
             fprintf(stderr, "[mstat] overlap probes/step %.0f: outside the box %.0f  hit own cell %.0f  hit neighbour %.0f  miss %.0f | candidates/step own %.0f  neighbour %.0f\n",
                     hs[0] / S, hs[1] / S, hs[2] / S, hs[3] / S, hs[4] / S, hs[5] / S, hs[6] / S);
         }
