@@ -1248,7 +1248,7 @@ __global__ void k_db_init(DbInit in) {
         in.contested[i] = 0u;
         in.dropped[i] = 0u;
     }
-    if (i < 8) in.counters[i] = 0u;          // ([4]: workgroups of the compaction that are done, publish_tail)
+    if (i < 8) in.counters[i] = 0u;
 }
 
 __global__ void k_publish(const unsigned* __restrict__ src, int n, unsigned* __restrict__ dst_host, unsigned* __restrict__ flag_host,

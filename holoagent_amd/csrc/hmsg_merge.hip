@@ -136,13 +136,22 @@ __global__ void k_ov_fill(const double* __restrict__ pool, const OvGrid* __restr
 
 // one z-run of Y's cell-sorted points: is any of them closer than r to (x, y, z)?  (float32 arithmetic of
 // find_overlapping_ratio_faiss: (dx*dx + dy*dy) + dz*dz < r2)
+#define OV_SHORT 8u     /* candidates of a list walked OV_UNROLL at a time */
+#define OV_LONG 16      /* ... and the rest this many at a time */
 #define OV_UNROLL 4     /* (16 was measured: 21 -> 46 us per launch -- short candidate lists dominate, and every step then issues 48 loads) */
 __device__ __forceinline__ bool ov_scan(const float* __restrict__ sorted, unsigned s0, unsigned e0, float x, float y, float z,
                                         float r2, unsigned* ncand = nullptr) {
     // OV_UNROLL candidates per step with independent loads: the scan is a serial latency chain per lane (one L2 round trip per
     // step: the early exit keeps the next step's loads from being issued ahead), and the kernel lasts as long as its slowest lane --
     // a point whose witness sits deep in a cell that has piled up hundreds of re-observations
-    for (unsigned k = s0; k < e0; k += OV_UNROLL) {
+    // Round 5: the first OV_SHORT candidates four at a time (most lists are that short: 1.4 candidates per probe on average), what
+    // lies beyond them sixteen at a time.  Measured on configs[1] (profiles/r05_ov_probe_stats.txt): 291 of a step's 1.5 * 10^5 probes
+    // walk more than 32 candidates -- 160 on average, 581 at most: a point next to, but not within r of, a cell where a floor has
+    // piled up its re-observations -- and at four per round trip those lanes were the launch's duration.  (Handing such probes to
+    // the whole wave, 64 candidates per trip, was tried: they come in clusters -- a mask's points share their neighbourhood --, a
+    // wave then walks its 30 heavy probes one after the other: 25.6 -> 52.5 us per launch, profiles/r05_ov_wave_cooperative.txt.)
+    const unsigned e_short = min(e0, s0 + OV_SHORT);
+    for (unsigned k = s0; k < e_short; k += OV_UNROLL) {
         bool h = false;
 #pragma unroll
         for (int j = 0; j < OV_UNROLL; ++j) {
@@ -150,9 +159,22 @@ __device__ __forceinline__ bool ov_scan(const float* __restrict__ sorted, unsign
             float ddx = __fsub_rn(x, sorted[(size_t)kk * 3]), ddy = __fsub_rn(y, sorted[(size_t)kk * 3 + 1]),
                   ddz = __fsub_rn(z, sorted[(size_t)kk * 3 + 2]);
             float d2 = __fadd_rn(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)), __fmul_rn(ddz, ddz));
+            h = h || (k + (unsigned)j < e_short && d2 < r2);
+        }
+        if (ncand) *ncand += min(OV_UNROLL, (int)(e_short - k));
+        if (h) return true;
+    }
+    for (unsigned k = e_short; k < e0; k += OV_LONG) {
+        bool h = false;
+#pragma unroll
+        for (int j = 0; j < OV_LONG; ++j) {
+            const unsigned kk = min(k + (unsigned)j, e0 - 1u);
+            float ddx = __fsub_rn(x, sorted[(size_t)kk * 3]), ddy = __fsub_rn(y, sorted[(size_t)kk * 3 + 1]),
+                  ddz = __fsub_rn(z, sorted[(size_t)kk * 3 + 2]);
+            float d2 = __fadd_rn(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)), __fmul_rn(ddz, ddz));
             h = h || (k + (unsigned)j < e0 && d2 < r2);
         }
-        if (ncand) *ncand += min(OV_UNROLL, (int)(e0 - k));
+        if (ncand) *ncand += min(OV_LONG, (int)(e0 - k));
         if (h) return true;
     }
     return false;
@@ -276,87 +298,6 @@ __device__ __forceinline__ bool ov_hit2(const OvGrid& Y, const OvGrid& Y2, const
     return false;
 }
 
-// ---- Round 5: the tail of the scans.  Measured on configs[1] (HMSG_DEBUG_MERGESTATS, profiles/r05_ov_probe_stats.txt): a fold
-// step makes 1.5 * 10^5 probes that test 1.4 candidates each on average -- but 291 of them walk more than 32 candidates (160
-// on average, 581 at most: a point next to, but not within r of, a cell where a floor has piled up its re-observations), four
-// candidates per round trip, and the launch lasts as long as its slowest lane.  A lane now only attempts probes whose candidate
-// lists are short; a probe with a long list is handed to the WHOLE WAVE afterwards: the lanes test 64 candidates per round trip
-// with a ballot as the early exit.  Same candidates, same float32 arithmetic, same answer.
-#define OV_HEAVY 24u    /* candidates a lane walks on its own at most */
-__device__ __forceinline__ bool ov_scan_wave(const float* __restrict__ sorted, unsigned s0, unsigned e0, float x, float y, float z, float r2) {
-    const unsigned lane = threadIdx.x & 63u;
-    for (unsigned k = s0; k < e0; k += 64u) {                  // (wave-uniform trip count)
-        const unsigned kk = k + lane;
-        bool h = false;
-        if (kk < e0) {
-            float ddx = __fsub_rn(x, sorted[(size_t)kk * 3]), ddy = __fsub_rn(y, sorted[(size_t)kk * 3 + 1]),
-                  ddz = __fsub_rn(z, sorted[(size_t)kk * 3 + 2]);
-            h = __fadd_rn(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)), __fmul_rn(ddz, ddz)) < r2;
-        }
-        if (__any(h)) return true;
-    }
-    return false;
-}
-// every lane of the wave calls this with the SAME point
-__device__ __forceinline__ bool ov_hit_wave(const OvGrid& Y, const unsigned* __restrict__ cells, const float* __restrict__ sorted,
-                                            float x, float y, float z, float r2, float r) {
-    if (x < Y.mnx - r || x > Y.mxx + r || y < Y.mny - r || y > Y.mxy + r || z < Y.mnz - r || z > Y.mxz + r) return false;
-    const OvProbe p = ov_probe(Y, x, y, z);
-    if (!p.any) return false;
-    const float* const sy = sorted + (size_t)Y.ix_pt * 3;
-    unsigned s0, e0;
-    ov_own_range(Y, p, cells, s0, e0);
-    if (ov_scan_wave(sy, s0, e0, x, y, z, r2)) return true;
-    unsigned rs[10], re[10];
-    ov_col_ranges(Y, p, cells, rs, re);
-#pragma unroll
-    for (int q = 0; q < 10; ++q)
-        if (ov_scan_wave(sy, rs[q], re[q], x, y, z, r2)) return true;
-    return false;
-}
-// a lane's own attempt: 1 = some point of Y within r, 0 = none, 2 = the candidate lists are long (the wave takes the probe over)
-__device__ __forceinline__ int ov_try(const OvGrid& Y, const OvGrid& Y2, bool two, const unsigned* __restrict__ cells,
-                                      const float* __restrict__ sorted, float x, float y, float z, float r2, float r) {
-    if (x < Y.mnx - r || x > Y.mxx + r || y < Y.mny - r || y > Y.mxy + r || z < Y.mnz - r || z > Y.mxz + r) return 0;   // (both grids carry the cloud's box)
-    const OvProbe p = ov_probe(Y, x, y, z);
-    const float* const sy = sorted + (size_t)Y.ix_pt * 3;
-    const float* const sy2 = sorted + (size_t)Y2.ix_pt * 3;
-    unsigned s0, e0, s2 = 0u, e2 = 0u;
-    ov_own_range(Y, p, cells, s0, e0);
-    OvProbe p2 = p;
-    if (two) {
-        p2 = ov_probe(Y2, x, y, z);
-        ov_own_range(Y2, p2, cells, s2, e2);
-    }
-    if ((e0 - s0) + (e2 - s2) > OV_HEAVY) return 2;
-    if (ov_scan(sy, s0, e0, x, y, z, r2)) return 1;
-    if (ov_scan(sy2, s2, e2, x, y, z, r2)) return 1;
-    unsigned rs[10], re[10], rs2[10], re2[10];
-    unsigned total = 0u;
-    if (p.any) {
-        ov_col_ranges(Y, p, cells, rs, re);
-#pragma unroll
-        for (int q = 0; q < 10; ++q) total += re[q] - rs[q];
-    }
-    if (two && p2.any) {
-        ov_col_ranges(Y2, p2, cells, rs2, re2);
-#pragma unroll
-        for (int q = 0; q < 10; ++q) total += re2[q] - rs2[q];
-    }
-    if (total > OV_HEAVY) return 2;
-    if (p.any) {
-#pragma unroll
-        for (int q = 0; q < 10; ++q)
-            if (ov_scan(sy, rs[q], re[q], x, y, z, r2)) return 1;
-    }
-    if (two && p2.any) {
-#pragma unroll
-        for (int q = 0; q < 10; ++q)
-            if (ov_scan(sy2, rs2[q], re2[q], x, y, z, r2)) return 1;
-    }
-    return 0;
-}
-
 static const int OV_CHUNK = 256;       /* points per workgroup of the overlap scans (128 .. 512 measured within 3 us of each other) */
 // find_overlapping_ratio_faiss (graph_utils.py:645-662): a point of X overlaps when its exact float32
 // nearest neighbour in Y is closer than r^2, i.e. when SOME y has (dx*dx + dy*dy) + dz*dz < r2 in float32.
@@ -442,33 +383,11 @@ __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __rest
         const int b0 = (int)(blk - (unsigned)t.blk0) * chunk;
         const int b1 = b0 + chunk < X.n ? b0 + chunk : X.n;
         const OvGrid Y2 = gr[Y.next >= 0 ? Y.next : t.y];      // (Y's delta grid, if it has one)
-        const bool two = Y.next >= 0;
-        for (int base = b0; base < b1; base += (int)blockDim.x) {          // (workgroup-uniform trip count: the waves cooperate below)
-            const int i = base + (int)threadIdx.x;
-            const bool act = i < b1;
-            float x = 0.f, y = 0.f, z = 0.f;
-            if (act) {
-                const double* p = pool + (size_t)(X.pt_off + i) * 3;
-                x = (float)p[0];
-                y = (float)p[1];
-                z = (float)p[2];
-            }
-            int state = 0;
-            if (st) {                                                     // (statistics runs: every probe walked by its own lane)
-                if (act) state = (two ? ov_hit2(Y, Y2, cells, sorted, x, y, z, r2, r, st) : ov_hit(Y, cells, sorted, x, y, z, r2, r, st)) ? 1 : 0;
-            } else {
-                if (act) state = ov_try(Y, Y2, two, cells, sorted, x, y, z, r2, r);
-                unsigned long long heavy = __ballot(state == 2);
-                while (heavy) {
-                    const int src = __ffsll(heavy) - 1;
-                    heavy &= heavy - 1ull;
-                    const float hx = __shfl(x, src), hy = __shfl(y, src), hz = __shfl(z, src);
-                    bool h = ov_hit_wave(Y, cells, sorted, hx, hy, hz, r2, r);
-                    if (!h && two) h = ov_hit_wave(Y2, cells, sorted, hx, hy, hz, r2, r);
-                    if ((int)(threadIdx.x & 63u) == src) state = h ? 1 : 0;
-                }
-            }
-            local += state == 1 ? 1u : 0u;
+        for (int i = b0 + (int)threadIdx.x; i < b1; i += blockDim.x) {
+            const double* p = pool + (size_t)(X.pt_off + i) * 3;
+            const float x = (float)p[0], y = (float)p[1], z = (float)p[2];
+            const bool hit = Y.next >= 0 ? ov_hit2(Y, Y2, cells, sorted, x, y, z, r2, r, st) : ov_hit(Y, cells, sorted, x, y, z, r2, r, st);
+            local += hit ? 1u : 0u;
         }
     }
     for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
