@@ -355,7 +355,7 @@ __global__ void k_db_core(const double* __restrict__ pts, long long N, const int
 // cell seen so far: whichever of the two is higher hangs under the lower.  Every minimum is written by exactly one wave
 // (the one that either brought it in above the current minimum, or took the minimum over from it), parents are always
 // lower cells, and the chain ends at the segment's lowest anchor cell.
-__global__ void k_db_anchor(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, const int* __restrict__ cseg,
+__device__ __forceinline__ void db_anchor_cells(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, const int* __restrict__ cseg,
                             const unsigned char* __restrict__ hasanchor, unsigned* __restrict__ rep, int* __restrict__ parent) {
     const unsigned n = *ncore;
     const unsigned stride = gridDim.x * blockDim.x;
@@ -465,7 +465,10 @@ __device__ __forceinline__ void uf_union_from(int* parent, int a, int b, const u
 __global__ void k_db_cellbox(const double* __restrict__ pts, const int* __restrict__ corecells, const unsigned* __restrict__ ncore,
                              const unsigned* __restrict__ cnt, const unsigned* __restrict__ start, const unsigned* __restrict__ ord,
                              const unsigned char* __restrict__ core, double* __restrict__ cellbox,
-                             unsigned* __restrict__ ccore) {
+                             unsigned* __restrict__ ccore, const int* __restrict__ cseg, const unsigned char* __restrict__ hasanchor,
+                             unsigned* __restrict__ rep, int* __restrict__ parent) {
+    // (the anchor cells' pre-connection rides in this launch: it needs what k_db_core left, like the boxes, and nothing of them)
+    if (rep) db_anchor_cells(corecells, ncore, cseg, hasanchor, rep, parent);
     const int lane = threadIdx.x & 63;
     const unsigned nwaves = (gridDim.x * blockDim.x) >> 6, ncells = *ncore;
     for (unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < ncells; w += nwaves) {
@@ -730,13 +733,19 @@ __global__ void k_db_union_scan(const double* __restrict__ pts, const int* __res
                             double gq = fmax(0.0, fmax(bb[t] - pa[t], pa[t] - bb[3 + t]));
                             g2 += gq * gq;
                         }
+                        // (eight candidates per step with independent loads: one candidate per step made every step a round trip,
+                        //  and a cell where a surface has piled up its re-observations holds a hundred of them)
                         if (g2 < eps2 * (1.0 + 1e-12))
-                            for (unsigned b = s1; b < e1; ++b) {
-                                unsigned ib = b;
-                                if (core[ib] && dist2_f64(pa, pts + (size_t)ib * 3) < eps2) {
-                                    hit = true;
-                                    break;
+                            for (unsigned b = s1; b < e1 && !hit; b += 8u) {
+                                bool h = false;
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) {
+                                    const unsigned ib = min(b + (unsigned)j, e1 - 1u);
+                                    const bool cb = core[ib] != 0;
+                                    const double d = dist2_f64(pa, pts + (size_t)ib * 3);
+                                    h = h || (b + (unsigned)j < e1 && cb && d < eps2);
                                 }
+                                hit = h;
                             }
                     }
                 }
@@ -1503,10 +1512,8 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     const unsigned gW = (unsigned)n_cu * 8u;
     hipLaunchKernelGGL(k_db_cellbox, dim3(gW), dim3(256), 0, s, (const double*)spts.p, (const int*)corelist.p,
                        (const unsigned*)d_nc, (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p,
-                       (const unsigned char*)score.p, cellbox.p, ccore.p);
-    if (core0)
-        hipLaunchKernelGGL(k_db_anchor, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc, (const int*)cseg.p,
-                           (const unsigned char*)hasanchor.p, rep.p, parent.p);
+                       (const unsigned char*)score.p, cellbox.p, ccore.p, (const int*)cseg.p, (const unsigned char*)hasanchor.p,
+                       core0 ? rep.p : (unsigned*)nullptr, parent.p);
     {
         ProfScope ps(prof, s, "k_db_union/box", (double)N * 24.0);
         hipLaunchKernelGGL(k_db_union, dim3(gW), dim3(256), 0, s, (const int*)actlist.p, (const unsigned*)d_nact, (const int*)cseg.p, dsegs, K,

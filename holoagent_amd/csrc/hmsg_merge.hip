@@ -136,22 +136,19 @@ __global__ void k_ov_fill(const double* __restrict__ pool, const OvGrid* __restr
 
 // one z-run of Y's cell-sorted points: is any of them closer than r to (x, y, z)?  (float32 arithmetic of
 // find_overlapping_ratio_faiss: (dx*dx + dy*dy) + dz*dz < r2)
-#define OV_SHORT 8u     /* candidates of a list walked OV_UNROLL at a time */
-#define OV_LONG 16      /* ... and the rest this many at a time */
 #define OV_UNROLL 4     /* (16 was measured: 21 -> 46 us per launch -- short candidate lists dominate, and every step then issues 48 loads) */
 __device__ __forceinline__ bool ov_scan(const float* __restrict__ sorted, unsigned s0, unsigned e0, float x, float y, float z,
                                         float r2, unsigned* ncand = nullptr) {
     // OV_UNROLL candidates per step with independent loads: the scan is a serial latency chain per lane (one L2 round trip per
     // step: the early exit keeps the next step's loads from being issued ahead), and the kernel lasts as long as its slowest lane --
     // a point whose witness sits deep in a cell that has piled up hundreds of re-observations
-    // Round 5: the first OV_SHORT candidates four at a time (most lists are that short: 1.4 candidates per probe on average), what
-    // lies beyond them sixteen at a time.  Measured on configs[1] (profiles/r05_ov_probe_stats.txt): 291 of a step's 1.5 * 10^5 probes
-    // walk more than 32 candidates -- 160 on average, 581 at most: a point next to, but not within r of, a cell where a floor has
-    // piled up its re-observations -- and at four per round trip those lanes were the launch's duration.  (Handing such probes to
-    // the whole wave, 64 candidates per trip, was tried: they come in clusters -- a mask's points share their neighbourhood --, a
-    // wave then walks its 30 heavy probes one after the other: 25.6 -> 52.5 us per launch, profiles/r05_ov_wave_cooperative.txt.)
-    const unsigned e_short = min(e0, s0 + OV_SHORT);
-    for (unsigned k = s0; k < e_short; k += OV_UNROLL) {
+    // Round 5, measured and withdrawn (profiles/r05_ov_probe_stats.txt, r05_ov_adaptive_unroll.txt, r05_ov_wave_cooperative.txt): a fold
+    // step makes 1.5 * 10^5 probes that test 1.4 candidates each on average, but 291 of them walk more than 32 candidates (160 on
+    // average, 581 at most: a point next to, but not within r of, a cell where a floor has piled up its re-observations).  Walking
+    // what lies beyond the first eight candidates sixteen at a time: 25.6 -> 39.4 us per launch (the second loop's registers cost
+    // every lane its occupancy); handing such probes to the whole wave, 64 candidates per trip: 52.5 us (they come in clusters -- a
+    // mask's points share their neighbourhood --, a wave then walks its 30 heavy probes one after the other).
+    for (unsigned k = s0; k < e0; k += OV_UNROLL) {
         bool h = false;
 #pragma unroll
         for (int j = 0; j < OV_UNROLL; ++j) {
@@ -159,22 +156,9 @@ __device__ __forceinline__ bool ov_scan(const float* __restrict__ sorted, unsign
             float ddx = __fsub_rn(x, sorted[(size_t)kk * 3]), ddy = __fsub_rn(y, sorted[(size_t)kk * 3 + 1]),
                   ddz = __fsub_rn(z, sorted[(size_t)kk * 3 + 2]);
             float d2 = __fadd_rn(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)), __fmul_rn(ddz, ddz));
-            h = h || (k + (unsigned)j < e_short && d2 < r2);
-        }
-        if (ncand) *ncand += min(OV_UNROLL, (int)(e_short - k));
-        if (h) return true;
-    }
-    for (unsigned k = e_short; k < e0; k += OV_LONG) {
-        bool h = false;
-#pragma unroll
-        for (int j = 0; j < OV_LONG; ++j) {
-            const unsigned kk = min(k + (unsigned)j, e0 - 1u);
-            float ddx = __fsub_rn(x, sorted[(size_t)kk * 3]), ddy = __fsub_rn(y, sorted[(size_t)kk * 3 + 1]),
-                  ddz = __fsub_rn(z, sorted[(size_t)kk * 3 + 2]);
-            float d2 = __fadd_rn(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)), __fmul_rn(ddz, ddz));
             h = h || (k + (unsigned)j < e0 && d2 < r2);
         }
-        if (ncand) *ncand += min(OV_LONG, (int)(e0 - k));
+        if (ncand) *ncand += min(OV_UNROLL, (int)(e0 - k));
         if (h) return true;
     }
     return false;
