@@ -103,6 +103,7 @@ _SIGS = {
     "hmsg_get_nodes": (C.c_int, [_P, _P, _P]),
     "hmsg_index_from_nodes": (C.c_int, [_P, C.POINTER(_P)]),
     "hmsg_room_clouds": (C.c_int, [_P, C.c_double, C.c_double, _P, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "hmsg_kmeans": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, _P, _P, _P, _P]),
     "hmsg_room_camera_distances": (C.c_int, [_P, C.c_int32, C.c_int64, _P, _P]),
     "hmsg_object_views": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int64, _P, _P, C.c_double, C.c_double, _P, _P]),
     "hmsg_segment_floors": (C.c_int, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),
@@ -744,6 +745,22 @@ def assign_cameras_to_rooms(dist, cam_height, y_min, y_max, lib_: "HmsgLib | Non
     if rc != 0:
         raise HmsgError(f"hmsg_assign_cameras_to_rooms failed ({rc})")
     return room_of[:n_cams], [imgs[off[r]:off[r + 1]].tolist() for r in range(n_rooms)]
+
+
+def kmeans(X, n_clusters, n_init=5, max_iter=100, seed=0, lib_: "HmsgLib | None" = None):
+    """KMeans(n_clusters, n_init, max_iter, random_state=seed).fit(X) behind the C ABI (include/hmsg.h: hmsg_kmeans; a restatement
+    of scikit-learn's Lloyd KMeans for hosts without it).  Returns (labels i32 [n], centers f32 [k, D], inertia, n_iter)."""
+    L = lib_ or lib()
+    X = np.ascontiguousarray(np.asarray(X, np.float32))
+    n, D = X.shape
+    labels = np.empty(n, np.int32)
+    centers = np.empty((int(n_clusters), D), np.float32)
+    inertia, n_iter = C.c_float(0), C.c_int32(0)
+    rc = L.c.hmsg_kmeans(_ptr(X), n, D, int(n_clusters), int(n_init), int(max_iter), int(seed), _ptr(labels), _ptr(centers),
+                         C.byref(inertia), C.byref(n_iter))
+    if rc != 0:
+        raise HmsgError(f"hmsg_kmeans failed ({rc})")
+    return labels, centers, float(inertia.value), int(n_iter.value)
 
 
 def pick_representative_views(embs, labels, centers, lib_: "HmsgLib | None" = None):

@@ -405,6 +405,15 @@ int hmsg_read_json_numbers(const char* path, const char* key, double* out, int64
  * (room, view) if view_room[v] >= 0 (a freshly built graph has none: graph.py:1176-1189 compares a string id with an int),
  * and (view, object) for its objects view_obj[view_obj_off[v] .. view_obj_off[v + 1]) in ascending object order, each once.
  * edges: capacity pairs of int64; *n_edges is set even when the capacity is too small (HMSG_ERR_INVALID then). */
+/* hmsg_kmeans -- the fit between the two calls above (utils/graph_utils.py:329-333:
+ * `KMeans(n_clusters=num_views, max_iter=100, n_init=5, random_state=0).fit(room_clip_embeddings)`), for a host without
+ * scikit-learn.  X f32 [n][dim] (n >= k); labels i32 [n], centers f32 [k][dim] = labels_ / cluster_centers_; inertia, n_iter
+ * optional.  A restatement of scikit-learn 1.7.2's Lloyd KMeans with k-means++ seeding under numpy's RandomState(seed)
+ * (holoagent_amd/csrc/hmsg_kmeans.hip says statement by statement what it follows, and which three BLAS / einsum sums are
+ * accumulated in float64 here because their order is the library's own: a point whose two nearest centres tie to ~1e-7
+ * relative may be labelled differently).  tests/test_kmeans_cabi.py holds it to scikit-learn itself. */
+int hmsg_kmeans(const float* X, int64_t n, int32_t dim, int32_t k, int32_t n_init, int32_t max_iter, uint32_t seed,
+                int32_t* labels, float* centers, float* inertia, int32_t* n_iter);
 int hmsg_assign_cameras_to_rooms(const double* dist, int64_t n_cams, int32_t n_rooms, const double* cam_height, double y_min,
                                  double y_max, int32_t* room_of_cam, int64_t* room_off, int32_t* room_imgs);
 int hmsg_pick_representative_views(const float* embs, int64_t n, int32_t dim, const int32_t* labels, const float* centers,
