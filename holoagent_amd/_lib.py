@@ -50,6 +50,27 @@ class HmsgJsonField(C.Structure):      # include/hmsg.h: hmsg_json_field
     _fields_ = [("key", C.c_char_p), ("kind", C.c_int32), ("ndim", C.c_int32), ("n0", C.c_int64), ("n1", C.c_int64), ("data", C.c_void_p)]
 
 
+class HmsgGraphParams(C.Structure):    # include/hmsg.h: hmsg_graph_params
+    _fields_ = [("num_views", C.c_int32), ("kmeans_n_init", C.c_int32), ("kmeans_max_iter", C.c_int32), ("kmeans_seed", C.c_uint32),
+                ("skip_frames", C.c_int32), ("image_width", C.c_int32), ("image_height", C.c_int32), ("min_visible_ratio", C.c_double),
+                ("max_view_depth", C.c_double), ("host_threads", C.c_int32)]
+
+
+class HmsgGraphCounts(C.Structure):    # include/hmsg.h: hmsg_graph_counts
+    _fields_ = [("floors", C.c_int32), ("rooms", C.c_int32), ("views", C.c_int32), ("objects", C.c_int32), ("edges", C.c_int64),
+                ("view_object_links", C.c_int64), ("begin_ms", C.c_double), ("finish_ms", C.c_double), ("kmeans_wait_ms", C.c_double)]
+
+
+class HmsgGraphObject(C.Structure):    # include/hmsg.h: hmsg_graph_object
+    _fields_ = [("object_id", C.c_char * 48), ("name", C.c_char * 80), ("room", C.c_int32), ("instance", C.c_int32), ("label", C.c_int32),
+                ("n_views", C.c_int32), ("best_view", C.c_int32)]
+
+
+class HmsgGraphRoom(C.Structure):      # include/hmsg.h: hmsg_graph_room
+    _fields_ = [("room_id", C.c_char * 32), ("name", C.c_char * 80), ("floor", C.c_int32), ("n_vertices", C.c_int64), ("n_points", C.c_int64),
+                ("n_embeddings", C.c_int32), ("n_sample_images", C.c_int32), ("n_objects", C.c_int32), ("n_views", C.c_int32)]
+
+
 class HmsgError(RuntimeError):
     pass
 
@@ -103,6 +124,22 @@ _SIGS = {
     "hmsg_get_nodes": (C.c_int, [_P, _P, _P]),
     "hmsg_index_from_nodes": (C.c_int, [_P, C.POINTER(_P)]),
     "hmsg_room_clouds": (C.c_int, [_P, C.c_double, C.c_double, _P, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "hmsg_graph_default_params": (None, [C.POINTER(HmsgGraphParams)]),
+    "hmsg_build_graph": (C.c_int, [_P, C.POINTER(HmsgGraphParams), C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, C.POINTER(_P)]),
+    "hmsg_graph_begin": (C.c_int, [_P, C.POINTER(HmsgGraphParams), C.c_int32, _P, _P, _P, _P, C.POINTER(_P)]),
+    "hmsg_graph_finish": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "hmsg_graph_destroy": (None, [_P]),
+    "hmsg_graph_last_error": (C.c_char_p, [_P]),
+    "hmsg_graph_get_counts": (C.c_int, [_P, C.POINTER(HmsgGraphCounts)]),
+    "hmsg_graph_get_edges": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "hmsg_graph_get_objects": (C.c_int, [_P, _P, C.c_int64]),
+    "hmsg_graph_get_rooms": (C.c_int, [_P, _P, C.c_int64]),
+    "hmsg_graph_get_room_embeddings": (C.c_int, [_P, C.c_int32, _P, C.c_int64]),
+    "hmsg_graph_to_json": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "hmsg_save": (C.c_int, [_P, C.c_char_p]),
+    "hmsg_load": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(_P)]),
+    "hmsg_graph_index": (C.c_int, [_P, _P, C.POINTER(_P)]),
+    "hmsg_graph_query": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     "hmsg_kmeans": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, _P, _P, _P, _P]),
     "hmsg_room_camera_distances": (C.c_int, [_P, C.c_int32, C.c_int64, _P, _P]),
     "hmsg_object_views": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int64, _P, _P, C.c_double, C.c_double, _P, _P]),
@@ -623,6 +660,152 @@ class Scene:
         if n:
             self._ck(self.L.c.hmsg_get_instance_feats(self.h, _ptr(out)))
         return out
+
+
+class SceneGraph:
+    """The graph as one object behind the C ABI (include/hmsg.h: hmsg_build_graph / hmsg_graph_begin + _finish, hmsg_save, hmsg_load,
+    hmsg_graph_query) -- floors -> rooms -> views -> objects -> edges held by the library."""
+
+    def __init__(self, L, g, D, scene=None):
+        self.L, self.g, self.D, self.scene = L, g, int(D), scene
+        self._keep = []
+
+    @staticmethod
+    def _params(L, **over):
+        p = HmsgGraphParams()
+        L.c.hmsg_graph_default_params(C.byref(p))
+        for k, v in over.items():
+            setattr(p, k, v)
+        return p
+
+    @staticmethod
+    def _strs(items):
+        if items is None:
+            return None, None
+        enc = [None if s is None else str(s).encode() for s in items]
+        arr = (C.c_char_p * max(len(enc), 1))(*enc)
+        return arr, enc
+
+    @classmethod
+    def begin(cls, scene: "Scene", poses, view_feats, poses_inv=None, img_paths=None, **params):
+        """the room level right after hmsg_finalize_map (device stage now, KMeans on host threads); finish() after the pooling"""
+        L = scene.L
+        P_ = np.ascontiguousarray(np.asarray(poses, np.float64).reshape(-1, 16))
+        Pi = None if poses_inv is None else np.ascontiguousarray(np.asarray(poses_inv, np.float64).reshape(-1, 16))
+        Fg = np.ascontiguousarray(np.asarray(view_feats, np.float32).reshape(len(P_), -1))
+        assert Fg.shape[1] == scene.cfg.feat_dim and (Pi is None or Pi.shape == P_.shape)
+        paths, keep = cls._strs(img_paths)
+        prm = cls._params(L, **params)
+        g = _P()
+        scene._ck(L.c.hmsg_graph_begin(scene.h, C.byref(prm), len(P_), _ptr(P_), None if Pi is None else _ptr(Pi), _ptr(Fg),
+                                       None if paths is None else C.cast(paths, _P), C.byref(g)))
+        return cls(L, g, scene.cfg.feat_dim, scene)
+
+    def finish(self, label_feats=None, label_names=None):
+        lf = None if label_feats is None else np.ascontiguousarray(np.asarray(label_feats, np.float32))
+        names, keep = self._strs(label_names if lf is not None else None)
+        self._ck(self.L.c.hmsg_graph_finish(self.g, 0 if lf is None else len(lf), None if lf is None else _ptr(lf),
+                                            None if names is None else C.cast(names, _P)))
+        return self
+
+    @classmethod
+    def build(cls, scene, poses, view_feats, label_feats=None, label_names=None, poses_inv=None, img_paths=None, **params):
+        return cls.begin(scene, poses, view_feats, poses_inv=poses_inv, img_paths=img_paths, **params).finish(label_feats, label_names)
+
+    @classmethod
+    def load(cls, directory, device_id=0, lib_: "HmsgLib | None" = None):
+        L = lib_ or lib()
+        g = _P()
+        rc = L.c.hmsg_load(str(directory).encode(), int(device_id), C.byref(g))
+        if rc != 0:
+            raise HmsgError(f"hmsg_load failed ({rc}) for {directory}")
+        return cls(L, g, 0)
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise HmsgError(self.L.c.hmsg_graph_last_error(self.g).decode() + f" (rc={rc})")
+
+    def close(self):
+        if self.g:
+            self.L.c.hmsg_graph_destroy(self.g)
+            self.g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def counts(self):
+        c = HmsgGraphCounts()
+        self._ck(self.L.c.hmsg_graph_get_counts(self.g, C.byref(c)))
+        return {k: getattr(c, k) for k, _ in HmsgGraphCounts._fields_}
+
+    def edges(self):
+        n = C.c_int64(0)
+        self._ck(self.L.c.hmsg_graph_get_edges(self.g, None, 0, C.byref(n)))
+        e = np.zeros((max(n.value, 1), 2), np.int64)
+        self._ck(self.L.c.hmsg_graph_get_edges(self.g, _ptr(e), n.value, C.byref(n)))
+        return e[: n.value]
+
+    def objects(self):
+        n = self.counts()["objects"]
+        arr = (HmsgGraphObject * max(n, 1))()
+        self._ck(self.L.c.hmsg_graph_get_objects(self.g, C.cast(arr, _P), n))
+        return [dict(object_id=a.object_id.decode(), name=a.name.decode(), room=a.room, instance=a.instance, label=a.label,
+                     n_views=a.n_views, best_view=a.best_view) for a in arr[:n]]
+
+    def rooms(self):
+        n = self.counts()["rooms"]
+        arr = (HmsgGraphRoom * max(n, 1))()
+        self._ck(self.L.c.hmsg_graph_get_rooms(self.g, C.cast(arr, _P), n))
+        return [dict(room_id=a.room_id.decode(), name=a.name.decode(), floor=a.floor, n_vertices=a.n_vertices, n_points=a.n_points,
+                     n_embeddings=a.n_embeddings, n_sample_images=a.n_sample_images, n_objects=a.n_objects, n_views=a.n_views)
+                for a in arr[:n]]
+
+    def room_embeddings(self, room, D=None):
+        r = self.rooms()[room]
+        D = int(D or self.D)
+        out = np.zeros((max(r["n_embeddings"], 1), D), np.float32)
+        self._ck(self.L.c.hmsg_graph_get_room_embeddings(self.g, int(room), _ptr(out), out.size))
+        return out[: r["n_embeddings"]]
+
+    def to_dict(self):
+        import json
+        n = C.c_int64(0)
+        self._ck(self.L.c.hmsg_graph_to_json(self.g, None, 0, C.byref(n)))
+        buf = C.create_string_buffer(n.value)
+        self._ck(self.L.c.hmsg_graph_to_json(self.g, buf, n.value, C.byref(n)))
+        return json.loads(buf.value.decode())
+
+    def save(self, directory):
+        self._ck(self.L.c.hmsg_save(self.g, str(directory).encode()))
+
+    def index(self, room_name_emb=None):
+        ix = _P()
+        rn = None if room_name_emb is None else np.ascontiguousarray(np.asarray(room_name_emb, np.float64))
+        self._ck(self.L.c.hmsg_graph_index(self.g, None if rn is None else _ptr(rn), C.byref(ix)))
+        c = self.counts()
+        nx = NodeIndex._wrap(self.L, ix, c["objects"], rn.shape[1] if rn is not None else self.D)
+        nx._n_rooms = c["rooms"]
+        return nx
+
+    def query(self, T_obj, qid, T_room, floor_id, room_mode, k, use_negatives=True, room_name_emb=None, max_rooms=None):
+        """hmsg_graph_query: floor -> room(s) -> objects on the graph's own index (made on the first call)"""
+        T_obj = np.ascontiguousarray(T_obj, dtype=np.float32)
+        Q, Cn, D = T_obj.shape
+        T_room = None if T_room is None else np.ascontiguousarray(T_room, dtype=np.float32)
+        qid = np.ascontiguousarray(qid, dtype=np.int32)
+        floor_id = np.ascontiguousarray(floor_id, dtype=np.int32)
+        room_mode = np.ascontiguousarray(room_mode, dtype=np.int32)
+        rn = None if room_name_emb is None else np.ascontiguousarray(np.asarray(room_name_emb, np.float64))
+        RM = int(max_rooms or max(self.counts()["rooms"], 10))
+        sel, nsel = np.empty((Q, RM), np.int32), np.empty((Q,), np.int32)
+        idx, room, score = np.empty((Q, k), np.int32), np.empty((Q, k), np.int32), np.empty((Q, k), np.float64)
+        self._ck(self.L.c.hmsg_graph_query(self.g, None if rn is None else _ptr(rn), Q, Cn, _ptr(T_obj), _ptr(qid),
+                                           None if T_room is None else _ptr(T_room), _ptr(floor_id), _ptr(room_mode), int(k), int(use_negatives), RM,
+                                           _ptr(sel), _ptr(nsel), _ptr(idx), _ptr(room), _ptr(score)))
+        return [sel[q, : nsel[q]].tolist() for q in range(Q)], idx, room, score
 
 
 def points_min_dist_2d(sets, queries, device_id=0, lib_: "HmsgLib | None" = None):

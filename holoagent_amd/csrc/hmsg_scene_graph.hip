@@ -1,0 +1,1317 @@
+// The graph as ONE object behind the boundary (hmsg_build_graph, hmsg_save / hmsg_load of the whole directory):
+//   build_hier_multimodal_scene_graph (graph.py:2033-2076) = segment_floors_manually (:624-787) -> per storey segment_hmsg_room
+//   (:920-1189: regions, room clouds, compute_room_embeddings utils/graph_utils.py:192-356, Room and View nodes) ->
+//   segment_hmsg_objects (:1582-1736) -> create_graph_new (:1752-1775); save_hmsg_graph (:1801-1824); load_hmsg_graph (:1892-1987).
+// Every stage is a call that already exists in this library (hmsg_segment_floors / _rooms, hmsg_room_clouds,
+// hmsg_room_camera_distances, hmsg_assign_cameras_to_rooms, hmsg_kmeans, hmsg_pick_representative_views,
+// hmsg_build_object_nodes, hmsg_object_views, hmsg_graph_edges, hmsg_write_json / _ply, hmsg_save_objects); what the Python
+// mirror holoagent_amd/graph.py did between them -- ids, names, lists, the bookkeeping of views and objects -- is host C++ here,
+// so a C / C++ host builds, saves, loads and queries with four calls (tests/host_c/hmsg_host.c) and the benchmark's graph
+// assembly is no longer Python.  The KMeans fits of a storey's rooms run on host threads between hmsg_graph_begin (right
+// after hmsg_finalize_map) and hmsg_graph_finish (after hmsg_pool_instances): beside the fusion and the merge fold.
+#include "hmsg_common.h"
+
+#include <dirent.h>
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+struct GFloor {
+    std::string id, name;
+    hmsg_floor f{};
+    double verts[8][3] = {};
+    bool have_verts = false;
+    std::vector<int> rooms;                 // global room indices, in floors[f].rooms order
+    std::vector<double> pts;                // loaded graphs: the cloud read back (built graphs: the map's slab, fetched on save)
+};
+struct GRoom {
+    std::string id, name;
+    int floor = 0, index_in_floor = 0;
+    std::vector<double> verts;              // [n][2] (x, z)
+    double zero = 0, height = 0;
+    bool have_level = false;
+    std::vector<int> sel;                   // built: indices into the storey's floor cloud (hmsg_room_clouds)
+    std::vector<double> pts;                // loaded: the cloud
+    std::vector<float> emb;                 // [n_emb][D] room.embeddings (representative views)
+    int n_emb = 0;
+    std::vector<double> emb64;              // loaded: the same as json.load gives them
+    std::vector<long long> represent, sample;
+    std::vector<float> clip;                // [n_clip][D] room.clip_embeddings
+    int n_clip = 0;
+    std::vector<int> objects, views;        // global indices
+    std::vector<std::string> view_ids;      // loaded graphs keep the ids as the record has them
+    // the room level in flight (hmsg_graph_begin): rows to cluster
+    std::vector<int> imgs;                  // view (processed-frame) indices assigned to the room
+    std::vector<int> km_labels;
+    std::vector<float> km_centers;
+};
+struct GView {
+    std::string id;
+    int floor = 0, room_in_floor = 0;       // the reference's View.room_id of a freshly built graph: the per-floor room INDEX (:1176-1189)
+    std::string room_id_str;                // loaded graphs: "f_r"
+    long long img = 0;
+    bool have_img = true;
+    std::string img_path;
+    bool have_path = false;
+    std::vector<int> objects;               // global object indices, ascending
+    std::vector<std::string> object_ids, texts;
+};
+struct GObject {
+    std::string id, name, room_id;
+    int room = 0, instance = -1, label = -1, counter = 0;
+    std::vector<int> views;                 // global view indices, in pair order
+    std::vector<std::string> view_ids;
+    int best_view = -1;
+    std::string best_view_id;
+    bool have_best = false;
+    std::vector<double> emb;                // loaded: float64 embedding
+    std::vector<double> pts;                // loaded
+    std::vector<double> verts;              // loaded [n][2]
+};
+
+}  // namespace
+
+struct hmsg_graph {
+    hmsg_ctx* h = nullptr;                  // built graphs: the scene (object clouds and features stay in HBM); NULL after hmsg_load
+    int device = 0, D = 0;
+    hmsg_graph_params prm{};
+    std::string err;
+    std::vector<GFloor> floors;
+    std::vector<GRoom> rooms;
+    std::vector<GView> views;
+    std::vector<GObject> objects;
+    std::vector<long long> edges;           // pairs
+    // inputs of the view level (copies: the caller's arrays may go away between begin and finish)
+    int n_frames = 0;
+    std::vector<double> poses, poses_inv;
+    std::vector<float> feats;
+    std::vector<std::string> img_paths;
+    bool have_inv = false;
+    std::vector<std::thread> workers;
+    std::string worker_err;
+    bool begun = false, finished = false, loaded = false;
+    double t_begin_ms = 0, t_finish_ms = 0, t_kmeans_wait_ms = 0;
+    hmsg_index_t* ix = nullptr;             // hmsg_graph_query's index (made on first use)
+    ~hmsg_graph() {
+        for (auto& t : workers)
+            if (t.joinable()) t.join();
+        if (ix) hmsg_index_destroy(ix);
+    }
+};
+
+namespace {
+
+template <typename F>
+int gguard(hmsg_graph* g, F&& f) {
+    try {
+        f();
+        return HMSG_OK;
+    } catch (const hmsg_error& e) {
+        g->err = e.msg;
+        return e.code;
+    } catch (const std::exception& e) {
+        g->err = e.what();
+        return HMSG_ERR_NOMEM;
+    } catch (...) {
+        g->err = "unknown error";
+        return HMSG_ERR_INVALID;
+    }
+}
+void need(int rc, hmsg_ctx* h, const char* what) {
+    if (rc != HMSG_OK) throw hmsg_error{rc, std::string(what) + ": " + (h ? hmsg_last_error(h) : "failed")};
+}
+
+// json.dumps(str) (ensure_ascii=True)
+std::string jstr(const std::string& s) {
+    std::string o = "\"";
+    char buf[16];
+    for (size_t i = 0; i < s.size();) {
+        const unsigned char c = (unsigned char)s[i];
+        if (c == '"') o += "\\\"", ++i;
+        else if (c == '\\') o += "\\\\", ++i;
+        else if (c == '\n') o += "\\n", ++i;
+        else if (c == '\r') o += "\\r", ++i;
+        else if (c == '\t') o += "\\t", ++i;
+        else if (c == '\b') o += "\\b", ++i;
+        else if (c == '\f') o += "\\f", ++i;
+        else if (c < 0x20) snprintf(buf, sizeof buf, "\\u%04x", c), o += buf, ++i;
+        else if (c < 0x80) o += (char)c, ++i;
+        else {                                        // UTF-8 -> \uXXXX (surrogate pair above the BMP)
+            unsigned cp = 0;
+            int n = c >= 0xf0 ? 4 : (c >= 0xe0 ? 3 : 2);
+            cp = c & (n == 4 ? 0x07 : (n == 3 ? 0x0f : 0x1f));
+            for (int k = 1; k < n && i + k < s.size(); ++k) cp = (cp << 6) | ((unsigned char)s[i + k] & 0x3f);
+            i += (size_t)n;
+            if (cp >= 0x10000) {
+                cp -= 0x10000;
+                snprintf(buf, sizeof buf, "\\u%04x\\u%04x", 0xd800 + (cp >> 10), 0xdc00 + (cp & 0x3ff));
+            } else {
+                snprintf(buf, sizeof buf, "\\u%04x", cp);
+            }
+            o += buf;
+        }
+    }
+    return o + "\"";
+}
+std::string jlist(const std::vector<std::string>& v) {    // json.dumps(list of str)
+    std::string o = "[";
+    for (size_t i = 0; i < v.size(); ++i) {
+        if (i) o += ", ";
+        o += jstr(v[i]);
+    }
+    return o + "]";
+}
+
+// np.arange(start, stop, step): length ceil((stop - start) / step), value i = start + i * ((start + step) - start)
+std::vector<double> np_arange(double start, double stop, double step) {
+    const double len = std::ceil((stop - start) / step);
+    const long long n = len > 0 ? (long long)len : 0;
+    std::vector<double> v((size_t)n);
+    const double delta = (start + step) - start;
+    for (long long i = 0; i < n; ++i) v[(size_t)i] = i == 0 ? start : (i == 1 ? start + step : start + (double)i * delta);
+    return v;
+}
+
+// np.linalg.inv of a 4x4 (LAPACK dgesv on the identity: LU with partial pivoting, then the two triangular solves per column).
+// The sequence of operations is the unblocked algorithm's; a LAPACK build that blocks or recurses differently may differ in the
+// last bit, which is why hmsg_graph_begin also takes the inverses from a caller that has numpy's.
+void inv4(const double* A, double* out) {
+    double a[4][4];
+    int piv[4];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) a[i][j] = A[i * 4 + j];
+    for (int k = 0; k < 4; ++k) {
+        int p = k;
+        for (int i = k + 1; i < 4; ++i)
+            if (std::fabs(a[i][k]) > std::fabs(a[p][k])) p = i;
+        piv[k] = p;
+        if (p != k)
+            for (int j = 0; j < 4; ++j) std::swap(a[k][j], a[p][j]);
+        if (a[k][k] != 0.0) {
+            const double r = 1.0 / a[k][k];
+            for (int i = k + 1; i < 4; ++i) a[i][k] *= r;
+        }
+        for (int j = k + 1; j < 4; ++j)
+            for (int i = k + 1; i < 4; ++i) a[i][j] -= a[i][k] * a[k][j];
+    }
+    for (int c = 0; c < 4; ++c) {
+        double b[4] = {0, 0, 0, 0};
+        b[c] = 1.0;
+        for (int k = 0; k < 4; ++k)
+            if (piv[k] != k) std::swap(b[k], b[piv[k]]);
+        for (int k = 0; k < 4; ++k)                       // L y = P b (unit diagonal), column oriented as dtrsm does
+            for (int i = k + 1; i < 4; ++i) b[i] -= b[k] * a[i][k];
+        for (int k = 3; k >= 0; --k) {                    // U x = y
+            b[k] /= a[k][k];
+            for (int i = 0; i < k; ++i) b[i] -= b[k] * a[i][k];
+        }
+        for (int i = 0; i < 4; ++i) out[i * 4 + c] = b[i];
+    }
+}
+
+void floor_vertices(GFloor& fl) {                         // Open3D AABB corner order (floor.py / SURVEY 8c)
+    if (fl.f.n_points <= 0) return;
+    const double* mn = fl.f.bbox_min;
+    const double* mx = fl.f.bbox_max;
+    const double ex[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+    const double v[8][3] = {{mn[0], mn[1], mn[2]},         {mn[0] + ex[0], mn[1], mn[2]},         {mn[0], mn[1] + ex[1], mn[2]},
+                            {mn[0], mn[1], mn[2] + ex[2]}, {mx[0], mx[1], mx[2]},                 {mn[0], mn[1] + ex[1], mn[2] + ex[2]},
+                            {mn[0] + ex[0], mn[1], mn[2] + ex[2]}, {mn[0] + ex[0], mn[1] + ex[1], mn[2]}};
+    memcpy(fl.verts, v, sizeof v);
+    fl.have_verts = true;
+}
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ---- stage 1 of segment_hmsg_room for one storey (graph.py:942-1136 + graph_utils.py:244-291): regions, room clouds (resident),
+// camera -> room table, image lists; the KMeans rows are left in GRoom::imgs for the worker threads
+void room_level_prepare(hmsg_graph* g, int fi) {
+    hmsg_ctx* h = g->h;
+    GFloor& fl = g->floors[(size_t)fi];
+    const double res = h->cfg.grid_resolution > 0 ? h->cfg.grid_resolution : 0.05;
+    int rows = 0, cols = 0, nr = 0;
+    double xz_min[2] = {0, 0};
+    need(hmsg_segment_rooms(h, fl.f.y_lo, fl.f.y_hi, fl.f.zero_level, fl.f.height, res, nullptr, 0, &rows, &cols, &nr, xz_min), h, "hmsg_segment_rooms");
+    std::vector<int> markers((size_t)rows * (size_t)cols);
+    if (!markers.empty())
+        need(hmsg_segment_rooms(h, fl.f.y_lo, fl.f.y_hi, fl.f.zero_level, fl.f.height, res, markers.data(), (int64_t)markers.size(), &rows, &cols, &nr, xz_min),
+             h, "hmsg_segment_rooms");
+    // map_grid_to_point_cloud (graph_utils.py:359-388) of every room's cells, in np.where order (rows, then columns)
+    std::vector<std::vector<double>> region((size_t)nr);
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) {
+            const int m = markers[(size_t)r * cols + c];
+            if (m >= 1 && m <= nr) {
+                auto& v = region[(size_t)m - 1];
+                v.push_back(((double)c - 10.5) * res + xz_min[0]);
+                v.push_back(((double)r - 10.5) * res + xz_min[1]);
+            }
+        }
+    const size_t room0 = g->rooms.size();
+    for (int i = 0; i < nr; ++i) {
+        GRoom rm;
+        rm.id = fl.id + "_" + std::to_string(i);
+        rm.name = "room_" + std::to_string(i);
+        rm.floor = fi;
+        rm.index_in_floor = i;
+        rm.verts = region[(size_t)i];
+        rm.zero = fl.f.zero_level;
+        rm.height = fl.f.height;
+        rm.have_level = true;
+        fl.rooms.push_back((int)g->rooms.size());
+        g->rooms.push_back(std::move(rm));
+    }
+    if (nr == 0) return;
+    // room clouds (:1086-1108) on the device, resident for the distance table
+    std::vector<double> z_levels = np_arange(fl.f.zero_level, fl.f.zero_level + fl.f.height, 0.05);
+    for (auto& z : z_levels) z *= -1.0;
+    // T1: Rotation.from_euler("x", 90, degrees=True).as_matrix() as scipy gives it (cos 90 deg comes out as 2^-52)
+    const double e = 2.220446049250313e-16;
+    const double T1[16] = {1, 0, 0, 0, 0, e, -1, 0, 0, 1, e, 0, 0, 0, 0, 1};
+    std::vector<int64_t> off((size_t)nr + 1, 0);
+    std::vector<double> xz;
+    for (int i = 0; i < nr; ++i) {
+        const auto& v = g->rooms[room0 + (size_t)i].verts;
+        off[(size_t)i + 1] = off[(size_t)i] + (int64_t)(v.size() / 2);
+        xz.insert(xz.end(), v.begin(), v.end());
+    }
+    std::vector<int64_t> sizes((size_t)nr, 0);
+    int64_t nf = 0;
+    need(hmsg_room_clouds(h, fl.f.y_lo, fl.f.y_hi, T1, (int32_t)z_levels.size(), z_levels.data(), nr, off.data(), xz.data(), sizes.data(), nullptr, 0, &nf),
+         h, "hmsg_room_clouds");
+    int64_t total = 0;
+    for (auto s : sizes) total += s;
+    std::vector<int32_t> sel((size_t)std::max<int64_t>(total, 1));
+    if (total > 0)
+        need(hmsg_room_clouds(h, fl.f.y_lo, fl.f.y_hi, T1, (int32_t)z_levels.size(), z_levels.data(), nr, off.data(), xz.data(), sizes.data(), sel.data(), total,
+                              &nf),
+             h, "hmsg_room_clouds");
+    {
+        int64_t o = 0;
+        for (int i = 0; i < nr; ++i) {
+            g->rooms[room0 + (size_t)i].sel.assign(sel.begin() + o, sel.begin() + o + sizes[(size_t)i]);
+            o += sizes[(size_t)i];
+        }
+    }
+    // camera -> room (compute_room_embeddings :244-291)
+    const int F = g->n_frames;
+    std::vector<double> cam((size_t)F * 2), height((size_t)F), dist((size_t)F * (size_t)nr);
+    for (int i = 0; i < F; ++i) {
+        cam[(size_t)i * 2] = g->poses[(size_t)i * 16 + 3];
+        cam[(size_t)i * 2 + 1] = g->poses[(size_t)i * 16 + 11];
+        height[(size_t)i] = g->poses[(size_t)i * 16 + 7];
+    }
+    if (F) need(hmsg_room_camera_distances(h, nr, F, cam.data(), dist.data()), h, "hmsg_room_camera_distances");
+    std::vector<int32_t> room_of((size_t)std::max(F, 1)), imgs((size_t)F + (size_t)nr);
+    std::vector<int64_t> roff((size_t)nr + 1);
+    // (the floor cloud's y bounds: the storey's box came back with hmsg_segment_floors)
+    need(hmsg_assign_cameras_to_rooms(dist.data(), F, nr, height.data(), fl.f.bbox_min[1], fl.f.bbox_max[1], room_of.data(), roff.data(), imgs.data()), h,
+         "hmsg_assign_cameras_to_rooms");
+    for (int i = 0; i < nr; ++i) g->rooms[room0 + (size_t)i].imgs.assign(imgs.begin() + roff[(size_t)i], imgs.begin() + roff[(size_t)i + 1]);
+}
+
+// ---- stage 2 (host only): KMeans(num_views) over a room's image embeddings + the representative picks (:329-352)
+void room_embed(hmsg_graph* g, GRoom& rm) {
+    const int D = g->D, n = (int)rm.imgs.size(), nv = g->prm.num_views, skip = std::max(1, g->prm.skip_frames);
+    rm.clip.resize((size_t)n * D);
+    for (int i = 0; i < n; ++i) memcpy(&rm.clip[(size_t)i * D], &g->feats[(size_t)rm.imgs[(size_t)i] * D], (size_t)D * 4);
+    rm.n_clip = n;
+    rm.sample.clear();
+    for (int v : rm.imgs) rm.sample.push_back((long long)v * skip);
+    rm.represent.clear();
+    if (n < nv) {                                          // (:297-301: every image represents the room)
+        rm.emb = rm.clip;
+        rm.n_emb = n;
+        for (int v : rm.imgs) rm.represent.push_back((long long)v * skip);
+        return;
+    }
+    rm.km_labels.resize((size_t)n);
+    rm.km_centers.resize((size_t)nv * D);
+    const int rc = hmsg_kmeans(rm.clip.data(), n, D, nv, g->prm.kmeans_n_init, g->prm.kmeans_max_iter, g->prm.kmeans_seed, rm.km_labels.data(),
+                               rm.km_centers.data(), nullptr, nullptr);
+    if (rc != HMSG_OK) throw hmsg_error{rc, "hmsg_kmeans failed"};
+    std::vector<int32_t> member((size_t)nv);
+    int32_t nm = 0;
+    if (hmsg_pick_representative_views(rm.clip.data(), n, D, rm.km_labels.data(), rm.km_centers.data(), nv, member.data(), &nm) != HMSG_OK)
+        throw hmsg_error{HMSG_ERR_INVALID, "hmsg_pick_representative_views failed"};
+    rm.emb.resize((size_t)nm * D);
+    rm.n_emb = nm;
+    for (int k = 0; k < nm; ++k) {
+        memcpy(&rm.emb[(size_t)k * D], &rm.clip[(size_t)member[(size_t)k] * D], (size_t)D * 4);
+        rm.represent.push_back((long long)rm.imgs[(size_t)member[(size_t)k]] * skip);
+    }
+}
+
+void join_workers(hmsg_graph* g) {
+    const double t0 = now_ms();
+    for (auto& t : g->workers)
+        if (t.joinable()) t.join();
+    g->workers.clear();
+    g->t_kmeans_wait_ms += now_ms() - t0;
+    if (!g->worker_err.empty()) throw hmsg_error{HMSG_ERR_INVALID, g->worker_err};
+}
+
+// ---- stage 3: View nodes (:1176-1189), objects (:1582-1736), edges (:1752-1775)
+void graph_finish(hmsg_graph* g, int32_t n_labels, const float* label_feats, const char* const* label_names) {
+    hmsg_ctx* h = g->h;
+    join_workers(g);
+    const int skip = std::max(1, g->prm.skip_frames);
+    // views: per floor, rooms in order, the room's images in order; the running index counts across the floor's rooms
+    for (size_t fi = 0; fi < g->floors.size(); ++fi) {
+        int view_index = 0;
+        for (int ri : g->floors[fi].rooms) {
+            GRoom& rm = g->rooms[(size_t)ri];
+            for (int img : rm.imgs) {
+                GView v;
+                v.id = g->floors[fi].id + "_" + std::to_string(rm.index_in_floor) + "_" + std::to_string(view_index++);
+                v.floor = (int)fi;
+                v.room_in_floor = rm.index_in_floor;
+                v.img = (long long)img * skip;
+                if (!g->img_paths.empty() && (size_t)img < g->img_paths.size()) {
+                    v.img_path = g->img_paths[(size_t)img];
+                    v.have_path = true;
+                }
+                rm.views.push_back((int)g->views.size());
+                g->views.push_back(std::move(v));
+            }
+        }
+    }
+    // objects
+    std::vector<double> fz, fh, verts;
+    std::vector<int32_t> room_floor;
+    std::vector<int64_t> voff(1, 0);
+    for (auto& fl : g->floors) fz.push_back(fl.f.zero_level), fh.push_back(fl.f.height);
+    for (auto& rm : g->rooms) {
+        room_floor.push_back(rm.floor);
+        verts.insert(verts.end(), rm.verts.begin(), rm.verts.end());
+        voff.push_back(voff.back() + (int64_t)(rm.verts.size() / 2));
+    }
+    need(hmsg_build_object_nodes(h, (int32_t)g->floors.size(), fz.data(), fh.data(), (int32_t)g->rooms.size(), room_floor.data(), voff.data(), verts.data(),
+                                 label_feats ? n_labels : 0, label_feats),
+         h, "hmsg_build_object_nodes");
+    const int64_t N = hmsg_num_nodes(h);
+    std::vector<hmsg_node> nodes((size_t)std::max<int64_t>(N, 1));
+    if (N) need(hmsg_get_nodes(h, nodes.data(), nullptr), h, "hmsg_get_nodes");
+    for (int64_t k = 0; k < N; ++k) {
+        const hmsg_node& nd = nodes[(size_t)k];
+        GObject o;
+        GRoom& rm = g->rooms[(size_t)nd.room];
+        o.room = nd.room;
+        o.room_id = rm.id;
+        o.instance = nd.instance;
+        o.label = nd.label;
+        o.counter = nd.counter;
+        o.id = rm.id + "_" + std::to_string(nd.counter);
+        o.name = (label_names && nd.label >= 0 && nd.label < n_labels && label_names[nd.label]) ? label_names[nd.label] : "object";
+        rm.objects.push_back((int)g->objects.size());
+        g->objects.push_back(std::move(o));
+    }
+    // view <-> object topology (:1712-1734): every (object, view of its room) pair in object order
+    std::vector<int32_t> pair_inst, pair_view;
+    std::vector<int> pair_obj;
+    for (size_t k = 0; k < g->objects.size(); ++k)
+        for (int v : g->rooms[(size_t)g->objects[k].room].views) {
+            pair_obj.push_back((int)k);
+            pair_inst.push_back(g->objects[k].instance);
+            pair_view.push_back(v);
+        }
+    if (!pair_obj.empty()) {
+        const size_t NV = g->views.size();
+        std::vector<double> pinv(NV * 16);
+        std::vector<int32_t> wh(NV * 2);
+        const int W = g->prm.image_width > 0 ? g->prm.image_width : h->cfg.width, H = g->prm.image_height > 0 ? g->prm.image_height : h->cfg.height;
+        for (size_t v = 0; v < NV; ++v) {
+            const size_t fr = (size_t)(g->views[v].img / skip);
+            if (g->have_inv) memcpy(&pinv[v * 16], &g->poses_inv[fr * 16], 128);
+            else inv4(&g->poses[fr * 16], &pinv[v * 16]);
+            wh[v * 2] = W;
+            wh[v * 2 + 1] = H;
+        }
+        HMSG_REQUIRE(h->have_K, HMSG_ERR_INVALID, "hmsg_graph_finish: no camera intrinsics (hmsg_add_frames)");
+        std::vector<uint8_t> vis(pair_obj.size());
+        std::vector<double> md(pair_obj.size());
+        need(hmsg_object_views(h, (int32_t)NV, pinv.data(), wh.data(), h->K, (int64_t)pair_obj.size(), pair_inst.data(), pair_view.data(),
+                               g->prm.min_visible_ratio, g->prm.max_view_depth, vis.data(), md.data()),
+             h, "hmsg_object_views");
+        std::vector<double> best_d(g->objects.size(), 0.0);
+        for (size_t p = 0; p < pair_obj.size(); ++p) {
+            if (!vis[p]) continue;
+            GObject& o = g->objects[(size_t)pair_obj[p]];
+            o.views.push_back(pair_view[p]);
+            // best view = the first strictly smallest mean depth, scanning from inf (:1727-1731): a non-finite mean never wins
+            if (md[p] < (o.best_view < 0 ? INFINITY : best_d[(size_t)pair_obj[p]])) {
+                o.best_view = pair_view[p];
+                best_d[(size_t)pair_obj[p]] = md[p];
+            }
+            g->views[(size_t)pair_view[p]].objects.push_back(pair_obj[p]);   // (pairs come in object order: ascending per view)
+        }
+    }
+    for (auto& o : g->objects) {
+        for (int v : o.views) o.view_ids.push_back(g->views[(size_t)v].id);
+        if (o.best_view >= 0) o.best_view_id = g->views[(size_t)o.best_view].id, o.have_best = true;
+    }
+    for (auto& v : g->views)
+        for (int k : v.objects) {
+            v.object_ids.push_back(g->objects[(size_t)k].id);
+            v.texts.push_back(g->objects[(size_t)k].name);
+        }
+    // edges (create_graph_new): a freshly built View carries an int room index, so no Room - View edge (view_room = -1)
+    std::vector<int32_t> obj_room, view_room(g->views.size(), -1), vobj;
+    std::vector<int64_t> vooff(1, 0);
+    for (auto& o : g->objects) obj_room.push_back(o.room);
+    for (auto& v : g->views) {
+        vobj.insert(vobj.end(), v.objects.begin(), v.objects.end());
+        vooff.push_back((int64_t)vobj.size());
+    }
+    int64_t ne = 0;
+    const int64_t cap = (int64_t)g->floors.size() + (int64_t)g->rooms.size() + (int64_t)g->objects.size() + (int64_t)g->views.size() + (int64_t)vobj.size() + 4;
+    g->edges.assign((size_t)cap * 2, 0);
+    if (hmsg_graph_edges((int32_t)g->floors.size(), (int32_t)g->rooms.size(), room_floor.data(), (int32_t)g->objects.size(), obj_room.data(),
+                         (int32_t)g->views.size(), view_room.data(), vooff.data(), vobj.data(), (int64_t*)g->edges.data(), cap, &ne) != HMSG_OK)
+        throw hmsg_error{HMSG_ERR_INVALID, "hmsg_graph_edges failed"};
+    g->edges.resize((size_t)ne * 2);
+    g->finished = true;
+}
+
+// ---------------------------------------------------------------------------------------------- a small JSON reader (load side)
+struct JVal {
+    enum Kind { NUL, BOOL, NUM, STR, ARR, OBJ } kind = NUL;
+    double num = 0;
+    bool b = false;
+    std::string str;
+    std::vector<JVal> arr;
+    std::vector<std::pair<std::string, JVal>> obj;
+    const JVal* get(const char* key) const {
+        for (auto& kv : obj)
+            if (kv.first == key) return &kv.second;
+        return nullptr;
+    }
+};
+struct JParser {
+    const char* p;
+    const char* e;
+    void ws() {
+        while (p < e && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p;
+    }
+    [[noreturn]] void fail(const char* what) { throw hmsg_error{HMSG_ERR_INVALID, std::string("JSON: ") + what}; }
+    std::string str() {
+        std::string o;
+        if (p >= e || *p != '"') fail("string expected");
+        ++p;
+        while (p < e && *p != '"') {
+            if (*p == '\\') {
+                ++p;
+                if (p >= e) fail("bad escape");
+                switch (*p) {
+                    case 'n': o += '\n'; break;
+                    case 't': o += '\t'; break;
+                    case 'r': o += '\r'; break;
+                    case 'b': o += '\b'; break;
+                    case 'f': o += '\f'; break;
+                    case 'u': {
+                        if (e - p < 5) fail("bad \\u");
+                        unsigned cp = (unsigned)strtoul(std::string(p + 1, p + 5).c_str(), nullptr, 16);
+                        p += 4;
+                        if (cp >= 0xd800 && cp < 0xdc00 && e - p >= 7 && p[1] == '\\' && p[2] == 'u') {
+                            const unsigned lo = (unsigned)strtoul(std::string(p + 3, p + 7).c_str(), nullptr, 16);
+                            cp = 0x10000 + ((cp - 0xd800) << 10) + (lo - 0xdc00);
+                            p += 6;
+                        }
+                        if (cp < 0x80) o += (char)cp;
+                        else if (cp < 0x800) o += (char)(0xc0 | (cp >> 6)), o += (char)(0x80 | (cp & 0x3f));
+                        else if (cp < 0x10000) o += (char)(0xe0 | (cp >> 12)), o += (char)(0x80 | ((cp >> 6) & 0x3f)), o += (char)(0x80 | (cp & 0x3f));
+                        else o += (char)(0xf0 | (cp >> 18)), o += (char)(0x80 | ((cp >> 12) & 0x3f)), o += (char)(0x80 | ((cp >> 6) & 0x3f)), o += (char)(0x80 | (cp & 0x3f));
+                        break;
+                    }
+                    default: o += *p;
+                }
+                ++p;
+            } else {
+                o += *p++;
+            }
+        }
+        if (p >= e) fail("unterminated string");
+        ++p;
+        return o;
+    }
+    JVal val() {
+        ws();
+        JVal v;
+        if (p >= e) fail("value expected");
+        if (*p == '{') {
+            v.kind = JVal::OBJ;
+            ++p;
+            ws();
+            if (p < e && *p == '}') {
+                ++p;
+                return v;
+            }
+            for (;;) {
+                ws();
+                std::string k = str();
+                ws();
+                if (p >= e || *p != ':') fail("':' expected");
+                ++p;
+                v.obj.emplace_back(std::move(k), val());
+                ws();
+                if (p < e && *p == ',') {
+                    ++p;
+                    continue;
+                }
+                if (p < e && *p == '}') {
+                    ++p;
+                    return v;
+                }
+                fail("',' or '}' expected");
+            }
+        }
+        if (*p == '[') {
+            v.kind = JVal::ARR;
+            ++p;
+            ws();
+            if (p < e && *p == ']') {
+                ++p;
+                return v;
+            }
+            for (;;) {
+                v.arr.push_back(val());
+                ws();
+                if (p < e && *p == ',') {
+                    ++p;
+                    continue;
+                }
+                if (p < e && *p == ']') {
+                    ++p;
+                    return v;
+                }
+                fail("',' or ']' expected");
+            }
+        }
+        if (*p == '"') {
+            v.kind = JVal::STR;
+            v.str = str();
+            return v;
+        }
+        if (e - p >= 4 && !strncmp(p, "null", 4)) {
+            p += 4;
+            return v;
+        }
+        if (e - p >= 4 && !strncmp(p, "true", 4)) {
+            p += 4;
+            v.kind = JVal::BOOL;
+            v.b = true;
+            return v;
+        }
+        if (e - p >= 5 && !strncmp(p, "false", 5)) {
+            p += 5;
+            v.kind = JVal::BOOL;
+            return v;
+        }
+        if (e - p >= 3 && !strncmp(p, "NaN", 3)) {
+            p += 3;
+            v.kind = JVal::NUM;
+            v.num = NAN;
+            return v;
+        }
+        if (e - p >= 8 && !strncmp(p, "Infinity", 8)) {
+            p += 8;
+            v.kind = JVal::NUM;
+            v.num = INFINITY;
+            return v;
+        }
+        if (e - p >= 9 && !strncmp(p, "-Infinity", 9)) {
+            p += 9;
+            v.kind = JVal::NUM;
+            v.num = -INFINITY;
+            return v;
+        }
+        char* end = nullptr;
+        v.num = strtod(p, &end);                          // (correctly rounded, as Python's float())
+        if (end == p) fail("value expected");
+        v.kind = JVal::NUM;
+        p = end;
+        return v;
+    }
+};
+JVal read_json(const std::string& path) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) throw hmsg_error{HMSG_ERR_INVALID, "cannot open " + path};
+    std::string s;
+    char buf[65536];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) s.append(buf, n);
+    fclose(f);
+    JParser jp{s.data(), s.data() + s.size()};
+    JVal v = jp.val();
+    if (v.kind != JVal::OBJ) throw hmsg_error{HMSG_ERR_INVALID, path + ": not a JSON object"};
+    return v;
+}
+// Open3D read_point_cloud of the files this path writes (and of Open3D's own: double / float x y z first, other properties skipped)
+std::vector<double> read_ply(const std::string& path) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) throw hmsg_error{HMSG_ERR_INVALID, "cannot open " + path};
+    long long n = 0;
+    struct Prop {
+        std::string type, name;
+    };
+    std::vector<Prop> props;
+    char line[512];
+    bool ok = false;
+    while (fgets(line, sizeof line, f)) {
+        std::string s(line);
+        while (!s.empty() && (s.back() == '\n' || s.back() == '\r')) s.pop_back();
+        if (s.rfind("element vertex", 0) == 0) n = atoll(s.c_str() + 14);
+        else if (s.rfind("property", 0) == 0) {
+            char t[64] = "", nm[64] = "";
+            if (sscanf(s.c_str(), "property %63s %63s", t, nm) == 2) props.push_back(Prop{t, nm});
+        } else if (s == "end_header") {
+            ok = true;
+            break;
+        }
+    }
+    if (!ok) {
+        fclose(f);
+        throw hmsg_error{HMSG_ERR_INVALID, path + ": no PLY header"};
+    }
+    size_t stride = 0;
+    int offx[3] = {-1, -1, -1};
+    bool dbl[3] = {true, true, true};
+    for (auto& pr : props) {
+        const size_t sz = pr.type == "double" ? 8 : (pr.type == "float" ? 4 : (pr.type == "uchar" ? 1 : 0));
+        if (!sz) {
+            fclose(f);
+            throw hmsg_error{HMSG_ERR_UNSUPPORTED, path + ": PLY property type " + pr.type};
+        }
+        for (int a = 0; a < 3; ++a)
+            if (pr.name == (a == 0 ? "x" : (a == 1 ? "y" : "z"))) offx[a] = (int)stride, dbl[a] = sz == 8;
+        stride += sz;
+    }
+    std::vector<double> out((size_t)n * 3);
+    std::vector<unsigned char> rec((size_t)n * stride);
+    if (n && fread(rec.data(), stride, (size_t)n, f) != (size_t)n) {
+        fclose(f);
+        throw hmsg_error{HMSG_ERR_INVALID, path + ": truncated PLY"};
+    }
+    fclose(f);
+    for (long long i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) {
+            if (offx[a] < 0) throw hmsg_error{HMSG_ERR_INVALID, path + ": PLY without x / y / z"};
+            const unsigned char* q = rec.data() + (size_t)i * stride + offx[a];
+            if (dbl[a]) {
+                double d;
+                memcpy(&d, q, 8);
+                out[(size_t)i * 3 + a] = d;
+            } else {
+                float fl;
+                memcpy(&fl, q, 4);
+                out[(size_t)i * 3 + a] = fl;
+            }
+        }
+    return out;
+}
+std::vector<std::string> list_dir(const std::string& dir, const char* suffix) {     // sorted(os.listdir(dir)) [endswith(suffix)]
+    std::vector<std::string> v;
+    DIR* d = opendir(dir.c_str());
+    if (!d) throw hmsg_error{HMSG_ERR_INVALID, "graph not found in " + dir};
+    while (dirent* e = readdir(d)) {
+        std::string n = e->d_name;
+        if (n == "." || n == "..") continue;
+        if (suffix && (n.size() < strlen(suffix) || n.compare(n.size() - strlen(suffix), strlen(suffix), suffix) != 0)) continue;
+        v.push_back(n);
+    }
+    closedir(d);
+    std::sort(v.begin(), v.end());
+    return v;
+}
+std::string stem_of(const std::string& file) { return file.substr(0, file.find('.')); }     // f.split(".")[0]
+std::string id_text(const JVal* v) {                                                       // an id as Python would str() it
+    if (!v) return "";
+    if (v->kind == JVal::STR) return v->str;
+    if (v->kind == JVal::NUM) {
+        char b[40];
+        if (v->num == std::floor(v->num) && std::fabs(v->num) < 1e15) snprintf(b, sizeof b, "%lld", (long long)v->num);
+        else snprintf(b, sizeof b, "%.17g", v->num);
+        return b;
+    }
+    return "";
+}
+void numbers_2d(const JVal* v, std::vector<double>& out, int* rows, int* cols) {
+    out.clear();
+    *rows = *cols = 0;
+    if (!v || v->kind != JVal::ARR) return;
+    *rows = (int)v->arr.size();
+    for (auto& r : v->arr) {
+        if (r.kind == JVal::ARR) {
+            *cols = (int)r.arr.size();
+            for (auto& x : r.arr) out.push_back(x.num);
+        } else {
+            out.push_back(r.num);
+            *cols = 1;
+        }
+    }
+}
+
+void mkdirs(const std::string& p) {
+    for (size_t i = 1; i <= p.size(); ++i)
+        if (i == p.size() || p[i] == '/') {
+            const std::string sub = p.substr(0, i);
+            if (mkdir(sub.c_str(), 0777) != 0 && errno != EEXIST) throw hmsg_error{HMSG_ERR_INVALID, "cannot create " + sub};
+        }
+}
+void write_json_fields(const std::string& path, std::vector<hmsg_json_field>& f) {
+    if (hmsg_write_json(path.c_str(), (int32_t)f.size(), f.data()) != HMSG_OK) throw hmsg_error{HMSG_ERR_INVALID, "cannot write " + path};
+}
+hmsg_json_field raw(const char* key, const std::string& text) { return hmsg_json_field{key, HMSG_JSON_RAW, 0, 0, 0, text.c_str()}; }
+hmsg_json_field num0(const char* key, const double* v) { return hmsg_json_field{key, HMSG_JSON_F64, 0, 0, 0, v}; }
+
+}  // namespace
+
+// ================================================================================================= C ABI
+extern "C" {
+
+void hmsg_graph_default_params(hmsg_graph_params* p) {
+    if (!p) return;
+    memset(p, 0, sizeof *p);
+    p->num_views = 24;              /* graph.py:1136 */
+    p->kmeans_n_init = 5;           /* graph_utils.py:329-333 */
+    p->kmeans_max_iter = 100;
+    p->kmeans_seed = 0;
+    p->skip_frames = 1;
+    p->image_width = p->image_height = 0;
+    p->min_visible_ratio = 0.5;     /* graph_utils.py:95-157 defaults */
+    p->max_view_depth = 10.0;
+    p->host_threads = 0;
+}
+
+const char* hmsg_graph_last_error(const hmsg_graph_t* g) { return g ? g->err.c_str() : "null graph"; }
+
+void hmsg_graph_destroy(hmsg_graph_t* g) { delete g; }
+
+int hmsg_graph_begin(hmsg_t* h, const hmsg_graph_params* prm, int32_t n_frames, const double* poses, const double* poses_inv, const float* view_feats,
+                     const char* const* img_paths, hmsg_graph_t** out) {
+    if (!h || !out) return HMSG_ERR_INVALID;
+    *out = nullptr;
+    if (n_frames < 0 || (n_frames > 0 && (!poses || !view_feats))) {
+        h->err = "hmsg_graph_begin: poses / view features missing";
+        return HMSG_ERR_INVALID;
+    }
+    hmsg_graph* g = new hmsg_graph();
+    const int rc = gguard(g, [&] {
+        const double t0 = now_ms();
+        HMSG_REQUIRE(h->map_ready, HMSG_ERR_INVALID, "hmsg_graph_begin: finalize the map first");
+        g->h = h;
+        g->device = h->cfg.device_id;
+        g->D = h->cfg.feat_dim;
+        if (prm) g->prm = *prm;
+        else hmsg_graph_default_params(&g->prm);
+        if (g->prm.skip_frames <= 0) g->prm.skip_frames = h->cfg.skip_frames > 0 ? h->cfg.skip_frames : 1;
+        HMSG_REQUIRE(g->prm.num_views >= 1, HMSG_ERR_INVALID, "hmsg_graph_begin: num_views");
+        g->n_frames = n_frames;
+        g->poses.assign(poses, poses + (size_t)n_frames * 16);
+        if (poses_inv) {
+            g->poses_inv.assign(poses_inv, poses_inv + (size_t)n_frames * 16);
+            g->have_inv = true;
+        }
+        g->feats.assign(view_feats, view_feats + (size_t)n_frames * g->D);
+        if (img_paths)
+            for (int i = 0; i < n_frames; ++i) g->img_paths.push_back(img_paths[i] ? img_paths[i] : "");
+        // floors (A8)
+        int32_t nf = 0;
+        need(hmsg_segment_floors(h, nullptr, 0, &nf), h, "hmsg_segment_floors");
+        std::vector<hmsg_floor> fl((size_t)std::max(nf, 1));
+        if (nf) need(hmsg_segment_floors(h, fl.data(), nf, &nf), h, "hmsg_segment_floors");
+        for (int i = 0; i < nf; ++i) {
+            GFloor f;
+            f.id = std::to_string(i);
+            f.name = "floor_" + std::to_string(i);
+            f.f = fl[(size_t)i];
+            floor_vertices(f);
+            g->floors.push_back(std::move(f));
+        }
+        // the room level's device stage, storey by storey
+        for (int i = 0; i < nf; ++i) room_level_prepare(g, i);
+        // its host stage on worker threads: the rooms are independent fits
+        std::vector<int> todo;
+        for (size_t r = 0; r < g->rooms.size(); ++r) todo.push_back((int)r);
+        int nt = g->prm.host_threads > 0 ? g->prm.host_threads : (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+        nt = std::max(1, std::min<int>(nt, (int)todo.size()));
+        for (int t = 0; t < nt && !todo.empty(); ++t)
+            g->workers.emplace_back([g, t, nt, todo] {
+                try {
+                    for (size_t k = (size_t)t; k < todo.size(); k += (size_t)nt) room_embed(g, g->rooms[(size_t)todo[k]]);
+                } catch (const hmsg_error& e) {
+                    g->worker_err = e.msg;
+                } catch (const std::exception& e) {
+                    g->worker_err = e.what();
+                }
+            });
+        g->begun = true;
+        g->t_begin_ms = now_ms() - t0;
+    });
+    if (rc != HMSG_OK) {
+        h->err = g->err;
+        delete g;
+        return rc;
+    }
+    *out = g;
+    return HMSG_OK;
+}
+
+int hmsg_graph_finish(hmsg_graph_t* g, int32_t n_labels, const float* label_feats, const char* const* label_names) {
+    if (!g) return HMSG_ERR_INVALID;
+    return gguard(g, [&] {
+        HMSG_REQUIRE(g->begun && !g->finished && g->h, HMSG_ERR_INVALID, "hmsg_graph_finish: hmsg_graph_begin first (once)");
+        HMSG_REQUIRE(g->h->pooled, HMSG_ERR_INVALID, "hmsg_graph_finish: run hmsg_pool_instances first");
+        const double t0 = now_ms();
+        graph_finish(g, n_labels, label_feats, label_names);
+        g->t_finish_ms = now_ms() - t0;
+    });
+}
+
+int hmsg_build_graph(hmsg_t* h, const hmsg_graph_params* prm, int32_t n_frames, const double* poses, const double* poses_inv, const float* view_feats,
+                     const char* const* img_paths, int32_t n_labels, const float* label_feats, const char* const* label_names, hmsg_graph_t** out) {
+    int rc = hmsg_graph_begin(h, prm, n_frames, poses, poses_inv, view_feats, img_paths, out);
+    if (rc != HMSG_OK) return rc;
+    rc = hmsg_graph_finish(*out, n_labels, label_feats, label_names);
+    if (rc != HMSG_OK) {
+        h->err = (*out)->err;
+        delete *out;
+        *out = nullptr;
+    }
+    return rc;
+}
+
+int hmsg_graph_get_counts(const hmsg_graph_t* g, hmsg_graph_counts* c) {
+    if (!g || !c) return HMSG_ERR_INVALID;
+    c->floors = (int32_t)g->floors.size();
+    c->rooms = (int32_t)g->rooms.size();
+    c->views = (int32_t)g->views.size();
+    c->objects = (int32_t)g->objects.size();
+    c->edges = (int64_t)(g->edges.size() / 2);
+    int64_t vo = 0;
+    for (auto& v : g->views) vo += (int64_t)(g->loaded ? v.object_ids.size() : v.objects.size());
+    c->view_object_links = vo;
+    c->begin_ms = g->t_begin_ms;
+    c->finish_ms = g->t_finish_ms;
+    c->kmeans_wait_ms = g->t_kmeans_wait_ms;
+    return HMSG_OK;
+}
+
+int hmsg_graph_get_edges(const hmsg_graph_t* g, int64_t* edges, int64_t capacity, int64_t* n_edges) {
+    if (!g || !n_edges) return HMSG_ERR_INVALID;
+    *n_edges = (int64_t)(g->edges.size() / 2);
+    if (!edges) return HMSG_OK;
+    if (capacity < *n_edges) return HMSG_ERR_INVALID;
+    memcpy(edges, g->edges.data(), g->edges.size() * 8);
+    return HMSG_OK;
+}
+
+int hmsg_graph_get_objects(const hmsg_graph_t* g, hmsg_graph_object* out, int64_t capacity) {
+    if (!g || !out || capacity < (int64_t)g->objects.size()) return HMSG_ERR_INVALID;
+    for (size_t k = 0; k < g->objects.size(); ++k) {
+        const GObject& o = g->objects[k];
+        hmsg_graph_object& r = out[k];
+        memset(&r, 0, sizeof r);
+        snprintf(r.object_id, sizeof r.object_id, "%s", o.id.c_str());
+        snprintf(r.name, sizeof r.name, "%s", o.name.c_str());
+        r.room = o.room;
+        r.instance = o.instance;
+        r.label = o.label;
+        r.n_views = (int32_t)(g->loaded ? o.view_ids.size() : o.views.size());
+        r.best_view = o.best_view;
+    }
+    return HMSG_OK;
+}
+
+int hmsg_graph_get_rooms(const hmsg_graph_t* g, hmsg_graph_room* out, int64_t capacity) {
+    if (!g || !out || capacity < (int64_t)g->rooms.size()) return HMSG_ERR_INVALID;
+    for (size_t k = 0; k < g->rooms.size(); ++k) {
+        const GRoom& rm = g->rooms[k];
+        hmsg_graph_room& r = out[k];
+        memset(&r, 0, sizeof r);
+        snprintf(r.room_id, sizeof r.room_id, "%s", rm.id.c_str());
+        snprintf(r.name, sizeof r.name, "%s", rm.name.c_str());
+        r.floor = rm.floor;
+        r.n_vertices = (int64_t)(rm.verts.size() / 2);
+        r.n_points = (int64_t)(g->loaded ? rm.pts.size() / 3 : rm.sel.size());
+        r.n_embeddings = rm.n_emb;
+        r.n_sample_images = (int32_t)rm.sample.size();
+        r.n_objects = (int32_t)rm.objects.size();
+        r.n_views = (int32_t)(g->loaded ? rm.view_ids.size() : rm.views.size());
+    }
+    return HMSG_OK;
+}
+
+int hmsg_graph_get_room_embeddings(const hmsg_graph_t* g, int32_t room, float* emb, int64_t capacity) {
+    if (!g || room < 0 || room >= (int32_t)g->rooms.size() || !emb) return HMSG_ERR_INVALID;
+    const GRoom& rm = g->rooms[(size_t)room];
+    const size_t n = (size_t)rm.n_emb * (size_t)g->D;
+    if ((size_t)capacity < n) return HMSG_ERR_INVALID;
+    if (g->loaded)
+        for (size_t i = 0; i < n; ++i) emb[i] = (float)rm.emb64[i];
+    else if (n) memcpy(emb, rm.emb.data(), n * 4);
+    return HMSG_OK;
+}
+
+/* the whole topology as one JSON text (ids, names, lists): what a test or a scripting host compares / walks */
+int hmsg_graph_to_json(const hmsg_graph_t* g, char* buf, int64_t capacity, int64_t* needed) {
+    if (!g || !needed) return HMSG_ERR_INVALID;
+    try {
+        std::string s = "{\"floors\": [";
+        for (size_t i = 0; i < g->floors.size(); ++i) {
+            const GFloor& f = g->floors[i];
+            if (i) s += ", ";
+            std::vector<std::string> rids;
+            for (int r : f.rooms) rids.push_back(g->rooms[(size_t)r].id);
+            s += "{\"floor_id\": " + jstr(f.id) + ", \"name\": " + jstr(f.name) + ", \"rooms\": " + jlist(rids) + ", \"n_points\": " +
+                 std::to_string((long long)(g->loaded ? (long long)(f.pts.size() / 3) : (long long)f.f.n_points)) + "}";
+        }
+        s += "], \"rooms\": [";
+        for (size_t i = 0; i < g->rooms.size(); ++i) {
+            const GRoom& r = g->rooms[i];
+            if (i) s += ", ";
+            std::vector<std::string> oids, vids;
+            for (int o : r.objects) oids.push_back(g->objects[(size_t)o].id);
+            if (g->loaded) vids = r.view_ids;
+            else
+                for (int v : r.views) vids.push_back(g->views[(size_t)v].id);
+            s += "{\"room_id\": " + jstr(r.id) + ", \"name\": " + jstr(r.name) + ", \"floor_id\": " + jstr(g->floors[(size_t)r.floor].id) + ", \"objects\": " +
+                 jlist(oids) + ", \"views\": " + jlist(vids) + ", \"represent_images\": [";
+            for (size_t k = 0; k < r.represent.size(); ++k) s += (k ? ", " : "") + std::to_string(r.represent[k]);
+            s += "], \"sample_images\": [";
+            for (size_t k = 0; k < r.sample.size(); ++k) s += (k ? ", " : "") + std::to_string(r.sample[k]);
+            s += "], \"n_points\": " + std::to_string((long long)(g->loaded ? r.pts.size() / 3 : r.sel.size())) + ", \"n_vertices\": " +
+                 std::to_string((long long)(r.verts.size() / 2)) + ", \"n_embeddings\": " + std::to_string(r.n_emb) + "}";
+        }
+        s += "], \"views\": [";
+        for (size_t i = 0; i < g->views.size(); ++i) {
+            const GView& v = g->views[i];
+            if (i) s += ", ";
+            s += "{\"view_id\": " + jstr(v.id) + ", \"room_id\": " + (g->loaded ? jstr(v.room_id_str) : std::to_string(v.room_in_floor)) + ", \"img_id\": " +
+                 (v.have_img ? std::to_string(v.img) : std::string("null")) + ", \"object_ids\": " + jlist(v.object_ids) + ", \"img_path\": " +
+                 (v.have_path ? jstr(v.img_path) : std::string("null")) + ", \"text_discription\": " + jlist(v.texts) + "}";
+        }
+        s += "], \"objects\": [";
+        for (size_t i = 0; i < g->objects.size(); ++i) {
+            const GObject& o = g->objects[i];
+            if (i) s += ", ";
+            s += "{\"object_id\": " + jstr(o.id) + ", \"room_id\": " + jstr(o.room_id) + ", \"name\": " + jstr(o.name) + ", \"instance\": " +
+                 std::to_string(o.instance) + ", \"label\": " + std::to_string(o.label) + ", \"view_ids\": " + jlist(o.view_ids) + ", \"best_view_id\": " +
+                 (o.have_best ? jstr(o.best_view_id) : std::string("null")) + "}";
+        }
+        s += "], \"edges\": [";
+        for (size_t i = 0; i + 1 < g->edges.size(); i += 2) s += (i ? ", [" : "[") + std::to_string(g->edges[i]) + ", " + std::to_string(g->edges[i + 1]) + "]";
+        s += "]}";
+        *needed = (int64_t)s.size() + 1;
+        if (!buf) return HMSG_OK;
+        if (capacity < *needed) return HMSG_ERR_INVALID;
+        memcpy(buf, s.c_str(), s.size() + 1);
+        return HMSG_OK;
+    } catch (const std::exception&) {
+        return HMSG_ERR_NOMEM;
+    }
+}
+
+/* save_hmsg_graph (graph.py:1801-1824) in the reference layout: <dir>/floors, rooms, objects, views */
+int hmsg_save(hmsg_graph_t* g, const char* dir) {
+    if (!g || !dir) return HMSG_ERR_INVALID;
+    return gguard(g, [&] {
+        HMSG_REQUIRE(g->finished && g->h, HMSG_ERR_INVALID, "hmsg_save: a graph built by hmsg_build_graph / hmsg_graph_finish (its clouds live in the scene handle)");
+        hmsg_ctx* h = g->h;
+        const std::string root = dir;
+        for (const char* sub : {"floors", "rooms", "objects", "views"}) mkdirs(root + "/" + sub);
+        // the map: floors are slabs of it, room clouds selections of a slab
+        const int64_t V = hmsg_map_size(h);
+        std::vector<double> map((size_t)std::max<int64_t>(V, 1) * 3);
+        if (V) need(hmsg_get_map_points(h, map.data(), nullptr), h, "hmsg_get_map_points");
+        for (size_t fi = 0; fi < g->floors.size(); ++fi) {
+            GFloor& fl = g->floors[fi];
+            std::vector<double> slab;
+            for (int64_t i = 0; i < V; ++i) {
+                const double y = map[(size_t)i * 3 + 1];
+                if (y >= fl.f.y_lo && y <= fl.f.y_hi) slab.insert(slab.end(), &map[(size_t)i * 3], &map[(size_t)i * 3 + 3]);
+            }
+            if (hmsg_write_ply((root + "/floors/" + fl.id + ".ply").c_str(), slab.data(), (int64_t)(slab.size() / 3)) != HMSG_OK)
+                throw hmsg_error{HMSG_ERR_INVALID, "cannot write the floor cloud"};
+            std::vector<std::string> rids;
+            for (int r : fl.rooms) rids.push_back(g->rooms[(size_t)r].id);
+            const std::string s_id = jstr(fl.id), s_name = jstr(fl.name), s_rooms = jlist(rids);
+            double zeros[24] = {0};
+            std::vector<hmsg_json_field> f = {raw("floor_id", s_id), raw("name", s_name), raw("rooms", s_rooms),
+                                              hmsg_json_field{"vertices", HMSG_JSON_F64, 2, 8, 3, fl.have_verts ? &fl.verts[0][0] : zeros},
+                                              num0("floor_height", &fl.f.height), num0("floor_zero_level", &fl.f.zero_level)};
+            write_json_fields(root + "/floors/" + fl.id + ".json", f);
+            for (int ri : fl.rooms) {
+                GRoom& rm = g->rooms[(size_t)ri];
+                std::vector<double> pts;
+                pts.reserve(rm.sel.size() * 3);
+                for (int s : rm.sel) pts.insert(pts.end(), &slab[(size_t)s * 3], &slab[(size_t)s * 3 + 3]);
+                if (hmsg_write_ply((root + "/rooms/" + rm.id + ".ply").c_str(), pts.data(), (int64_t)(pts.size() / 3)) != HMSG_OK)
+                    throw hmsg_error{HMSG_ERR_INVALID, "cannot write a room cloud"};
+                std::vector<std::string> oids, vids;
+                for (int o : rm.objects) oids.push_back(g->objects[(size_t)o].id);
+                for (int v : rm.views) vids.push_back(g->views[(size_t)v].id);
+                const std::string r_id = jstr(rm.id), r_name = jstr(rm.name), r_fl = jstr(fl.id), r_obj = jlist(oids), r_views = jlist(vids), empty = "[]";
+                std::vector<hmsg_json_field> rf = {
+                    raw("room_id", r_id), raw("name", r_name), raw("floor_id", r_fl), raw("objects", r_obj), raw("views", r_views),
+                    hmsg_json_field{"vertices", HMSG_JSON_F64, 2, (int64_t)(rm.verts.size() / 2), 2, rm.verts.data()},
+                    num0("room_height", &rm.height), num0("room_zero_level", &rm.zero),
+                    rm.n_emb ? hmsg_json_field{"embeddings", HMSG_JSON_F32, 2, rm.n_emb, g->D, rm.emb.data()} : raw("embeddings", empty),
+                    hmsg_json_field{"represent_images", HMSG_JSON_I64, 1, (int64_t)rm.represent.size(), 0, rm.represent.data()},
+                    hmsg_json_field{"sample_images", HMSG_JSON_I64, 1, (int64_t)rm.sample.size(), 0, rm.sample.data()},
+                    rm.n_clip ? hmsg_json_field{"clip_embeddings", HMSG_JSON_F32, 2, rm.n_clip, g->D, rm.clip.data()} : raw("clip_embeddings", empty)};
+                if (rm.verts.empty()) rf[5] = raw("vertices", empty);
+                write_json_fields(root + "/rooms/" + rm.id + ".json", rf);
+            }
+        }
+        for (auto& v : g->views) {
+            const std::string v_id = jstr(v.id), v_room = std::to_string(v.room_in_floor), v_img = std::to_string(v.img), v_obj = jlist(v.object_ids),
+                              v_path = v.have_path ? jstr(v.img_path) : std::string("null"), v_txt = jlist(v.texts);
+            std::vector<hmsg_json_field> vf = {raw("view_id", v_id),    raw("room_id", v_room), raw("img_id", v_img),
+                                               raw("object_ids", v_obj), raw("img_path", v_path), raw("text_discription", v_txt)};
+            write_json_fields(root + "/views/" + v.id + ".json", vf);
+        }
+        // objects: the bulk writer (clouds and features read back from HBM once, host threads print)
+        std::vector<std::string> keep;
+        keep.reserve(g->objects.size() * 6);
+        std::vector<hmsg_object_record> recs(g->objects.size());
+        for (size_t k = 0; k < g->objects.size(); ++k) {
+            const GObject& o = g->objects[k];
+            const size_t b = keep.size();
+            keep.push_back(o.id);
+            keep.push_back(jstr(o.id));
+            keep.push_back(jstr(o.room_id));
+            keep.push_back(jstr(o.name));
+            keep.push_back(jlist(o.view_ids));
+            keep.push_back(o.have_best ? jstr(o.best_view_id) : std::string("null"));
+            recs[k] = hmsg_object_record{o.instance, keep[b].c_str(), keep[b + 1].c_str(), keep[b + 2].c_str(), keep[b + 3].c_str(), keep[b + 4].c_str(),
+                                         keep[b + 5].c_str()};
+        }
+        if (!recs.empty()) need(hmsg_save_objects(h, (root + "/objects").c_str(), (int64_t)recs.size(), recs.data(), g->prm.host_threads), h, "hmsg_save_objects");
+    });
+}
+
+/* load_hmsg_graph (graph.py:1892-1987): floors, rooms, objects, views from the reference layout */
+int hmsg_load(const char* dir, int32_t device_id, hmsg_graph_t** out) {
+    if (!dir || !out) return HMSG_ERR_INVALID;
+    *out = nullptr;
+    hmsg_graph* g = new hmsg_graph();
+    const int rc = gguard(g, [&] {
+        const std::string root = dir;
+        g->loaded = g->finished = true;
+        g->device = device_id;
+        hmsg_graph_default_params(&g->prm);
+        std::map<std::string, int> room_of_id;
+        for (auto& f : list_dir(root + "/floors", ".ply")) {                                  // sorted (:1903)
+            GFloor fl;
+            fl.id = stem_of(f);
+            fl.pts = read_ply(root + "/floors/" + f);
+            const JVal m = read_json(root + "/floors/" + fl.id + ".json");
+            fl.name = "floor_" + fl.id;
+            if (const JVal* v = m.get("name"))
+                if (v->kind == JVal::STR) fl.name = v->str;                                    // (Floor.load takes the saved name)
+            if (const JVal* v = m.get("floor_height")) fl.f.height = v->num;
+            if (const JVal* v = m.get("floor_zero_level")) fl.f.zero_level = v->num;
+            std::vector<double> vv;
+            int r = 0, c = 0;
+            numbers_2d(m.get("vertices"), vv, &r, &c);
+            if (r == 8 && c == 3) memcpy(fl.verts, vv.data(), sizeof fl.verts), fl.have_verts = true;
+            fl.f.n_points = (int64_t)(fl.pts.size() / 3);
+            g->floors.push_back(std::move(fl));
+        }
+        for (auto& f : list_dir(root + "/rooms", ".ply")) {                                   // lexicographic (:1931)
+            GRoom rm;
+            rm.id = stem_of(f);
+            const std::string fid = rm.id.substr(0, rm.id.find('_'));
+            rm.pts = read_ply(root + "/rooms/" + f);
+            const JVal m = read_json(root + "/rooms/" + rm.id + ".json");
+            if (const JVal* v = m.get("name"))
+                if (v->kind == JVal::STR) rm.name = v->str;
+            const int fl = atoi(fid.c_str());                                                // self.floors[int(rid.split("_")[0])]
+            HMSG_REQUIRE(fl >= 0 && fl < (int)g->floors.size(), HMSG_ERR_INVALID, "hmsg_load: a room of a floor that is not there");
+            rm.floor = fl;
+            rm.index_in_floor = (int)g->floors[(size_t)fl].rooms.size();
+            int r = 0, c = 0;
+            numbers_2d(m.get("vertices"), rm.verts, &r, &c);
+            if (const JVal* v = m.get("room_height")) rm.height = v->num, rm.have_level = v->kind == JVal::NUM;
+            if (const JVal* v = m.get("room_zero_level")) rm.zero = v->num;
+            numbers_2d(m.get("embeddings"), rm.emb64, &rm.n_emb, &c);
+            if (rm.n_emb) {
+                HMSG_REQUIRE(g->D == 0 || g->D == c, HMSG_ERR_INVALID, "hmsg_load: embeddings of different lengths");
+                g->D = c;
+            }
+            std::vector<double> tmp;
+            numbers_2d(m.get("represent_images"), tmp, &r, &c);
+            for (double x : tmp) rm.represent.push_back((long long)x);
+            numbers_2d(m.get("sample_images"), tmp, &r, &c);
+            for (double x : tmp) rm.sample.push_back((long long)x);
+            std::vector<double> clip64;
+            numbers_2d(m.get("clip_embeddings"), clip64, &rm.n_clip, &c);
+            rm.clip.assign(clip64.begin(), clip64.end());
+            if (const JVal* v = m.get("views"))
+                for (auto& x : v->arr) rm.view_ids.push_back(id_text(&x));
+            room_of_id[rm.id] = (int)g->rooms.size();
+            g->floors[(size_t)fl].rooms.push_back((int)g->rooms.size());
+            g->rooms.push_back(std::move(rm));
+        }
+        for (auto& f : list_dir(root + "/objects", ".ply")) {
+            GObject o;
+            o.id = stem_of(f);
+            const size_t u1 = o.id.find('_'), u2 = u1 == std::string::npos ? u1 : o.id.find('_', u1 + 1);
+            o.room_id = u2 == std::string::npos ? o.id : o.id.substr(0, u2);                  // "_".join(oid.split("_")[:2])
+            auto it = room_of_id.find(o.room_id);
+            HMSG_REQUIRE(it != room_of_id.end(), HMSG_ERR_INVALID, "hmsg_load: Couldn't find the room with room id " + o.room_id);
+            o.room = it->second;
+            o.pts = read_ply(root + "/objects/" + f);
+            const JVal m = read_json(root + "/objects/" + o.id + ".json");
+            o.name = "object_" + o.id;
+            if (const JVal* v = m.get("name"))
+                if (v->kind == JVal::STR) o.name = v->str;
+            int r = 0, c = 0;
+            numbers_2d(m.get("vertices"), o.verts, &r, &c);
+            if (const JVal* v = m.get("embedding"))
+                if (v->kind == JVal::ARR)
+                    for (auto& x : v->arr) o.emb.push_back(x.num);
+            if (!o.emb.empty()) {
+                HMSG_REQUIRE(g->D == 0 || g->D == (int)o.emb.size(), HMSG_ERR_INVALID, "hmsg_load: embeddings of different lengths");
+                g->D = (int)o.emb.size();
+            }
+            if (const JVal* v = m.get("view_ids"))
+                for (auto& x : v->arr) o.view_ids.push_back(id_text(&x));
+            if (const JVal* v = m.get("best_view_id"))
+                if (v->kind != JVal::NUL) o.best_view_id = id_text(v), o.have_best = true;
+            g->rooms[(size_t)o.room].objects.push_back((int)g->objects.size());
+            g->objects.push_back(std::move(o));
+        }
+        std::map<std::string, int> obj_of_id;
+        for (size_t k = 0; k < g->objects.size(); ++k) obj_of_id.emplace(g->objects[k].id, (int)k);     // (first of equal ids)
+        for (auto& f : list_dir(root + "/views", nullptr)) {
+            GView v;
+            v.id = stem_of(f);
+            const size_t u1 = v.id.find('_'), u2 = u1 == std::string::npos ? u1 : v.id.find('_', u1 + 1);
+            v.room_id_str = u2 == std::string::npos ? v.id : v.id.substr(0, u2);
+            auto it = room_of_id.find(v.room_id_str);
+            HMSG_REQUIRE(it != room_of_id.end(), HMSG_ERR_INVALID, "hmsg_load: Couldn't find the room with room id " + v.room_id_str);
+            const JVal m = read_json(root + "/views/" + f);
+            v.floor = g->rooms[(size_t)it->second].floor;
+            v.room_in_floor = g->rooms[(size_t)it->second].index_in_floor;
+            if (const JVal* x = m.get("img_id")) {
+                v.have_img = x->kind == JVal::NUM;
+                v.img = (long long)x->num;
+            }
+            if (const JVal* x = m.get("img_path"))
+                if (x->kind == JVal::STR) v.img_path = x->str, v.have_path = true;
+            if (const JVal* x = m.get("object_ids"))
+                for (auto& y : x->arr) v.object_ids.push_back(id_text(&y));
+            if (const JVal* x = m.get("text_discription"))
+                for (auto& y : x->arr) v.texts.push_back(id_text(&y));
+            for (auto& oid : v.object_ids) {
+                auto o = obj_of_id.find(oid);
+                if (o != obj_of_id.end()) v.objects.push_back(o->second);
+            }
+            std::sort(v.objects.begin(), v.objects.end());
+            v.objects.erase(std::unique(v.objects.begin(), v.objects.end()), v.objects.end());
+            g->rooms[(size_t)it->second].views.push_back((int)g->views.size());
+            g->views.push_back(std::move(v));
+        }
+        // edges as load_hmsg_graph adds them: (0, floor) per floor, (floor, room) per room, (room, object) per object, (room, view)
+        // per view -- the loader adds no View - Object edge
+        const long long F = (long long)g->floors.size(), R = (long long)g->rooms.size(), O = (long long)g->objects.size();
+        for (long long i = 0; i < F; ++i) g->edges.push_back(0), g->edges.push_back(1 + i);
+        for (long long r = 0; r < R; ++r) g->edges.push_back(1 + g->rooms[(size_t)r].floor), g->edges.push_back(1 + F + r);
+        for (long long o = 0; o < O; ++o) g->edges.push_back(1 + F + g->objects[(size_t)o].room), g->edges.push_back(1 + F + R + o);
+        for (size_t v = 0; v < g->views.size(); ++v) {
+            const int r = room_of_id[g->views[v].room_id_str];
+            g->edges.push_back(1 + F + r);
+            g->edges.push_back(1 + F + R + O + (long long)v);
+        }
+    });
+    if (rc != HMSG_OK) {
+        fprintf(stderr, "hmsg_load: %s\n", g->err.c_str());
+        delete g;
+        return rc;
+    }
+    *out = g;
+    return HMSG_OK;
+}
+
+/* the retrieval index of the graph with its upper levels resident (Graph._hier_index of the mirror): object embeddings (gathered
+ * on the device for a built graph, the saved float64 rows for a loaded one), floors -> rooms, the rooms' view embeddings,
+ * room_key = int(room_id.split("_")[-1]); room_name_emb f64 [rooms][D] or NULL (no label mode) */
+int hmsg_graph_index(hmsg_graph_t* g, const double* room_name_emb, hmsg_index_t** out) {
+    if (!g || !out) return HMSG_ERR_INVALID;
+    *out = nullptr;
+    return gguard(g, [&] {
+        HMSG_REQUIRE(g->finished, HMSG_ERR_INVALID, "hmsg_graph_index: the graph is not finished");
+        HMSG_REQUIRE(!g->objects.empty(), HMSG_ERR_INVALID, "hmsg_graph_index: a graph without objects");
+        hmsg_index_t* ix = nullptr;
+        const int D = g->D;
+        if (!g->loaded) {
+            need(hmsg_index_from_nodes(g->h, &ix), g->h, "hmsg_index_from_nodes");
+        } else {
+            std::vector<double> emb(g->objects.size() * (size_t)D);
+            std::vector<int32_t> room(g->objects.size());
+            for (size_t k = 0; k < g->objects.size(); ++k) {
+                HMSG_REQUIRE((int)g->objects[k].emb.size() == D, HMSG_ERR_INVALID, "hmsg_graph_index: object " + g->objects[k].id + " was saved without an embedding");
+                memcpy(&emb[k * (size_t)D], g->objects[k].emb.data(), (size_t)D * 8);
+                room[k] = g->objects[k].room;
+            }
+            if (hmsg_index_create(g->device, D, (int64_t)g->objects.size(), emb.data(), 1, room.data(), &ix) != HMSG_OK)
+                throw hmsg_error{HMSG_ERR_INVALID, "hmsg_index_create failed"};
+        }
+        const int R = (int)g->rooms.size();
+        std::vector<int32_t> fro(1, 0), fr, key((size_t)R);
+        for (auto& fl : g->floors) {
+            for (int r : fl.rooms) fr.push_back(r);
+            fro.push_back((int32_t)fr.size());
+        }
+        std::vector<int64_t> voff(1, 0);
+        std::vector<double> vemb;
+        for (int r = 0; r < R; ++r) {
+            const GRoom& rm = g->rooms[(size_t)r];
+            const size_t us = rm.id.rfind('_');
+            key[(size_t)r] = atoi(rm.id.c_str() + (us == std::string::npos ? 0 : us + 1));
+            if (g->loaded) vemb.insert(vemb.end(), rm.emb64.begin(), rm.emb64.end());
+            else
+                for (float x : rm.emb) vemb.push_back((double)x);
+            voff.push_back(voff.back() + rm.n_emb);
+        }
+        const int rc = hmsg_index_set_hierarchy(ix, R, (int32_t)g->floors.size(), fro.data(), fr.data(), room_name_emb, voff.data(), vemb.empty() ? nullptr : vemb.data(),
+                                                key.data());
+        if (rc != HMSG_OK) {
+            std::string e = hmsg_index_last_error(ix);
+            hmsg_index_destroy(ix);
+            throw hmsg_error{rc, "hmsg_index_set_hierarchy: " + e};
+        }
+        *out = ix;
+    });
+}
+
+/* query_hierarchy_protected{,_icra} (graph.py:3483-3716) on the graph: hmsg_query_hier on its index (made on the first call, with
+ * room_name_emb; pass the same table on later calls or NULL) */
+int hmsg_graph_query(hmsg_graph_t* g, const double* room_name_emb, int32_t Q, int32_t C, const float* T_obj, const int32_t* qid, const float* T_room,
+                     const int32_t* floor_id, const int32_t* room_mode, int32_t k, int32_t use_negatives, int32_t max_rooms, int32_t* out_sel,
+                     int32_t* out_nsel, int32_t* out_idx, int32_t* out_room, double* out_score) {
+    if (!g) return HMSG_ERR_INVALID;
+    if (!g->ix) {
+        const int rc = hmsg_graph_index(g, room_name_emb, &g->ix);
+        if (rc != HMSG_OK) return rc;
+    }
+    const int rc = hmsg_query_hier(g->ix, Q, C, T_obj, qid, T_room, floor_id, room_mode, k, use_negatives, max_rooms, out_sel, out_nsel, out_idx, out_room,
+                                   out_score);
+    if (rc != HMSG_OK) g->err = hmsg_index_last_error(g->ix);
+    return rc;
+}
+
+}  // extern "C"

@@ -415,6 +415,13 @@ def camera_room_distances(room_pcds, pose_list, lib=None, device_id=0):
     return points_min_dist_2d(flat, cam, device_id=device_id, lib_=lib) if len(cam) and len(flat) else np.zeros((len(cam), len(flat)))
 
 
+def _closest_member(cluster, centre):
+    """graph_utils.py:344-346: the member with the largest dot product with its KMeans centre -- float32 np.dot, i.e. BLAS decides
+    an exact tie (a two-member cluster: both are equally far from their mean).  hmsg_pick_representative_views accumulates the
+    products in float64 and takes the first maximum; tests that compare the two sides byte for byte install that rule here."""
+    return int(np.argmax(np.dot(cluster, centre)))
+
+
 def compute_room_embeddings(room_pcds, pose_list, emb_list, pcd_min, pcd_max, num_views=5, save_path=None, lib=None,
                             device_id=0, dist=None):
     """utils/graph_utils.py:192-356.  Assign every image to the room whose cloud (projected to x/z) is nearest to the
@@ -479,7 +486,7 @@ def compute_room_embeddings(room_pcds, pose_list, emb_list, pcd_min, pcd_max, nu
         for lab in np.unique(labels):
             ids = np.where(labels == lab)[0]
             cluster = room_clip[ids]
-            max_idx = int(np.argmax(np.dot(cluster, centers[lab])))
+            max_idx = _closest_member(cluster, centers[lab])
             repr_img_ids.append(img_ids[ids[max_idx]])
             repr_embs.append(cluster[max_idx])
         repr_img_ids_list.append(repr_img_ids)

@@ -422,10 +422,93 @@ int hmsg_graph_edges(int32_t n_floors, int32_t n_rooms, const int32_t* room_floo
                      int32_t n_views, const int32_t* view_room, const int64_t* view_obj_off, const int32_t* view_obj,
                      int64_t* edges, int64_t capacity, int64_t* n_edges);
 
+/* ---- (b) the graph as ONE object behind the boundary: build_hier_multimodal_scene_graph (graph.py:2033-2076), save_hmsg_graph
+ * (:1801-1824) and load_hmsg_graph (:1892-1987) without a line of host bookkeeping on the caller's side.  A C / C++ host builds,
+ * saves, loads and queries with four calls (tests/host_c/hmsg_host.c); holoagent_amd/graph.py's Graph keeps the reference's method
+ * names on top of the same object.
+ *
+ *   hmsg_build_graph   after hmsg_pool_instances: segment_floors_manually (:624-787) -> per storey segment_hmsg_room (:920-1189:
+ *       regions by the device watershed, room clouds, camera -> room assignment, KMeans(num_views) representative views
+ *       (hmsg_kmeans), Room and View nodes with the reference's ids: rooms "<floor>_<i>", views "<floor>_<i>_<k>" with k
+ *       counting across the storey's rooms, View.room_id the per-floor room INDEX) -> segment_hmsg_objects (:1582-1736: objects
+ *       "<room_id>_<counter>", names from the label vocabulary, view_ids / best_view_id by check_object_in_view on the device)
+ *       -> create_graph_new (:1752-1775).
+ *         poses       f64 [n_frames][16] camera -> world of the PROCESSED frames (frame i of this table = dataset image
+ *                     i * skip_frames), row-major;
+ *         poses_inv   their np.linalg.inv, or NULL: computed here by LU with partial pivoting (a LAPACK build that orders the
+ *                     eliminations differently can differ in the last bit, and a point on an image border decides by it);
+ *         view_feats  f32 [n_frames][D]: the frames' global CLIP features (the F_g of loop B; graph.py:1119-1130 recomputes them);
+ *         img_paths   optional, [n_frames]: dataset.frameId2imgPath of those frames (View.img_path);
+ *         label_feats f32 [n_labels][D] + label_names [n_labels] (get_label_feats), or 0 / NULL: every object is "object".
+ *   hmsg_graph_begin / hmsg_graph_finish   the same in two halves, so that the room level runs BESIDE the fusion and the merge
+ *       fold: begin right after hmsg_finalize_map (floors, regions, room clouds and the camera table on the device, then the
+ *       KMeans fits on host threads), finish after hmsg_pool_instances (joins them; views, objects, edges).
+ *   hmsg_save   the whole directory in the reference layout: <dir>/floors/<f>.{ply,json}, rooms/<f>_<r>.{ply,json},
+ *       objects/<id>.{ply,json}, views/<id>.json -- byte for byte what the mirror's Floor / Room / Object / View .save() write
+ *       (tests/test_scene_graph_cabi.py), which tests/golden/persist.json pins to the reference's own classes.
+ *   hmsg_load   the same directory back: nodes in the loader's order (sorted file names: rooms and objects lexicographic),
+ *       object embeddings as float64, Room - View edges by id.  The result is a graph without a scene handle.
+ *   hmsg_graph_index / hmsg_graph_query   the retrieval index with the upper levels resident (floors -> rooms, view
+ *       embeddings, room_key = int(room_id.split("_")[-1]); room_name_emb f64 [rooms][D]: the CLIP embeddings of the rooms' names,
+ *       NULL = no label mode) and hmsg_query_hier on it (declared below; the index of hmsg_graph_query belongs to the graph).
+ *   hmsg_graph_to_json   ids, names and lists of every node + the edge list as one JSON text (buf NULL: *needed only). */
+typedef struct hmsg_graph hmsg_graph_t;
+typedef struct hmsg_index hmsg_index_t;
+typedef struct hmsg_graph_params {
+    int32_t num_views;          /* 24: KMeans clusters per room (graph.py:1136) */
+    int32_t kmeans_n_init;      /* 5   (utils/graph_utils.py:329-333) */
+    int32_t kmeans_max_iter;    /* 100 */
+    uint32_t kmeans_seed;       /* 0   (random_state) */
+    int32_t skip_frames;        /* pipeline.skip_frames: image id of processed frame i = i * skip_frames; <= 0: the handle's */
+    int32_t image_width, image_height;   /* size of the views' images (check_object_in_view); 0: the handle's */
+    double min_visible_ratio;   /* 0.5  (utils/graph_utils.py:95-157) */
+    double max_view_depth;      /* 10.0 */
+    int32_t host_threads;       /* KMeans fits / object writers; 0: one per core, at most 16 */
+} hmsg_graph_params;
+typedef struct hmsg_graph_counts {
+    int32_t floors, rooms, views, objects;
+    int64_t edges, view_object_links;
+    double begin_ms, finish_ms, kmeans_wait_ms;   /* wall time of the two halves; what finish waited for the KMeans threads */
+} hmsg_graph_counts;
+typedef struct hmsg_graph_object {
+    char object_id[48];
+    char name[80];
+    int32_t room;               /* global room index (hmsg_graph_get_rooms order) */
+    int32_t instance, label;    /* hmsg_node.instance / .label; -1 for a loaded graph */
+    int32_t n_views, best_view; /* best_view: global view index, -1 none (loaded graphs: -1, the id is in hmsg_graph_to_json) */
+} hmsg_graph_object;
+typedef struct hmsg_graph_room {
+    char room_id[32];
+    char name[80];
+    int32_t floor;
+    int64_t n_vertices, n_points;
+    int32_t n_embeddings, n_sample_images, n_objects, n_views;
+} hmsg_graph_room;
+void hmsg_graph_default_params(hmsg_graph_params* p);
+int hmsg_build_graph(hmsg_t* h, const hmsg_graph_params* prm, int32_t n_frames, const double* poses, const double* poses_inv,
+                     const float* view_feats, const char* const* img_paths, int32_t n_labels, const float* label_feats,
+                     const char* const* label_names, hmsg_graph_t** out);
+int hmsg_graph_begin(hmsg_t* h, const hmsg_graph_params* prm, int32_t n_frames, const double* poses, const double* poses_inv,
+                     const float* view_feats, const char* const* img_paths, hmsg_graph_t** out);
+int hmsg_graph_finish(hmsg_graph_t* g, int32_t n_labels, const float* label_feats, const char* const* label_names);
+void hmsg_graph_destroy(hmsg_graph_t* g);
+const char* hmsg_graph_last_error(const hmsg_graph_t* g);
+int hmsg_graph_get_counts(const hmsg_graph_t* g, hmsg_graph_counts* counts);
+int hmsg_graph_get_edges(const hmsg_graph_t* g, int64_t* edges /*[capacity][2], may be NULL*/, int64_t capacity, int64_t* n_edges);
+int hmsg_graph_get_objects(const hmsg_graph_t* g, hmsg_graph_object* out, int64_t capacity);
+int hmsg_graph_get_rooms(const hmsg_graph_t* g, hmsg_graph_room* out, int64_t capacity);
+int hmsg_graph_get_room_embeddings(const hmsg_graph_t* g, int32_t room, float* emb /*[n_embeddings][D]*/, int64_t capacity);
+int hmsg_graph_to_json(const hmsg_graph_t* g, char* buf, int64_t capacity, int64_t* needed);
+int hmsg_save(hmsg_graph_t* g, const char* dir);
+int hmsg_load(const char* dir, int32_t device_id, hmsg_graph_t** out);
+int hmsg_graph_index(hmsg_graph_t* g, const double* room_name_emb, hmsg_index_t** out);
+int hmsg_graph_query(hmsg_graph_t* g, const double* room_name_emb, int32_t Q, int32_t C, const float* T_obj, const int32_t* qid,
+                     const float* T_room, const int32_t* floor_id, const int32_t* room_mode, int32_t k, int32_t use_negatives,
+                     int32_t max_rooms, int32_t* out_sel, int32_t* out_nsel, int32_t* out_idx, int32_t* out_room, double* out_score);
+
 /* ---- A12: retrieval over a node table (graph.py:3056-3162 query_hmsg_object and the GEMV of
  * query_hmsg_room / query_floor).  A table is N node embeddings (f64, as after load_hmsg_graph:
  * object.py:88-89, or f32 right after build) with a parent (room) id per node. */
-typedef struct hmsg_index hmsg_index_t;
 int hmsg_index_create(int32_t device_id, int32_t dim, int64_t n, const void* emb, int32_t emb_is_f64,
                       const int32_t* room_of_node, hmsg_index_t** out);
 /* the node table of a built scene as a resident index (embeddings gathered on the device, parent = node.room) */
