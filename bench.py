@@ -112,6 +112,9 @@ def main():
                          "mode, one GPU) hands NOTHING in: rooms from the device watershed (N1), room clouds, room embeddings and "
                          "View nodes (A9), objects with the view <-> object test on the device (A10)")
     ap.add_argument("--full-graph", action="store_true", help="(accepted for compatibility: the default now)")
+    ap.add_argument("--python-graph", action="store_true",
+                    help="the graph level through the Python mirror of the reference's Graph (scikit-learn KMeans, networkx) instead of "
+                         "the graph object behind the C ABI")
     ap.add_argument("--encoder-frames", type=int, default=8,
                     help="frames of the extra encoder hand-off leg (random-init ViT-B/32-shaped PyTorch-ROCm module -> features by "
                          "data_ptr() into hmsg_add_frame_features; reported beside `value`, never in it; 0 = skip)")
@@ -224,6 +227,11 @@ def main():
         def get_camera_intrinsics(self):
             return inp["K"]
     fg_host = inp["f_g"].cpu().numpy() if args.full_graph else None
+    poses_arr = np.ascontiguousarray(np.stack(poses_host))            # [F, 4, 4] camera -> world of the processed frames
+    from holoagent_amd._lib import SceneGraph
+    # --python-graph: the graph level through the Python mirror of the reference's Graph (rounds 3-4's form of the line) instead of
+    # the graph object behind the C ABI (hmsg_graph_begin / hmsg_graph_finish / hmsg_graph_index)
+    c_graph = args.full_graph and not args.python_graph
     gt_boxes = np.asarray(inp["rooms"], np.float64)
 
     def gt_room_of(xz):
@@ -320,8 +328,14 @@ def main():
 
         def room_level():
             # the room level needs only the map and the frames' global features: floors, room regions (device watershed), room
-            # clouds and the camera -> room table run here (device), scikit-learn's KMeans views on a host thread beside the
-            # fusion and the fold (Graph.start_room_level; Graph.create_feature_map does the same).
+            # clouds and the camera -> room table run here (device), the KMeans views on host threads beside the fusion and the
+            # fold -- hmsg_graph_begin (the library's own threads and its restated KMeans); with --python-graph
+            # Graph.start_room_level (scikit-learn on a Python thread), as Graph.create_feature_map does.
+            if c_graph:
+                old = state.pop("graph", None)
+                if old is not None:
+                    old.close()
+                return SceneGraph.begin(sc, poses_arr, fg_host)
             g = Graph.from_scene(sc, cfg=full_cfg, lib=L, instances=False)
             g.dataset = FrameSource()
             g._poses = poses_host
@@ -347,6 +361,13 @@ def main():
         def assemble():
             # A8 floors, A10 objects (device: instance DBSCAN(0.05,10), object->room share, label GEMM), A11 node
             # records -- holoagent_amd.graph.Graph, the mirror of the reference's Graph; rooms are an input.
+            if c_graph:
+                # floors (A8), rooms by the device watershed (N1), room clouds, camera -> room assignment, KMeans views and View
+                # nodes (A9) came with hmsg_graph_begin; objects with the view <-> object test on the device (A10) and the
+                # edges (A11) now -- one call, no Python in between
+                T("assemble/graph_finish", lambda: g_early.finish(label_feats, label_names))
+                state["graph"] = g_early
+                return None, None
             if args.full_graph:
                 g = g_early
                 T("assemble/take_instances", g.take_instances)
@@ -371,7 +392,7 @@ def main():
             pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(25)
         else:
             feats, rooms = T("assemble_graph", assemble)
-        state["n_nodes_local"] = feats.shape[0]
+        state["n_nodes_local"] = feats.shape[0] if feats is not None else state["graph"].counts()["objects"]
 
         def retrieve():
             g_ix = None
@@ -397,12 +418,32 @@ def main():
                 tq = np.ascontiguousarray(text[qs])
             else:
                 g_feats, g_rooms, rl, tq = feats, rooms, q_rooms, text
-            if g_feats.shape[0] == 0:
+            if (state["n_nodes_local"] if g_feats is None else g_feats.shape[0]) == 0:
                 return None
             # one GPU: the index is gathered on the device from the node table (hmsg_index_from_nodes) and the queries run
             # coarse to fine ON THE DEVICE (hmsg_query_hier): floor 0 -> room by its name (label mode: the rooms within
             # 1e-3 of the best name similarity) -> objects of those rooms with one negative prompt -- no room list is
             # handed in.  N GPUs: object-level queries on the all-gathered global table with the rooms' global ids.
+            if c_graph:
+                # the rooms are the segmented ones: each is named after the ground-truth room its region lies in (two regions
+                # of one room share the name: the label mode then selects both); the index comes from the graph object with
+                # floors -> rooms and the rooms' view embeddings resident (hmsg_graph_index)
+                cg = state["graph"]
+                rooms_c = cg.rooms()
+                gt_of = [gt_room_of(cg.room_vertices(i, r["n_vertices"])) for i, r in enumerate(rooms_c)]
+                ix = cg.index(room_name_feats[gt_of])
+                ix.set_profiling(True)
+                sel, idx, room, score = ix.query_hier(tq, np.zeros(len(tq), np.int32), room_text, np.zeros(len(tq), np.int32),
+                                                      np.ones(len(tq), np.int32), k)
+                state["gemm"] = ix.profile()
+                state["rooms_hit"] = float(np.mean([int(ent_room[e]) in {gt_of[j] for j in s_} for e, s_ in zip(q_ent, sel)]))
+                cnt = cg.counts()
+                state["graph_counts"] = dict(floors=cnt["floors"], rooms=cnt["rooms"], views=cnt["views"], objects=cnt["objects"],
+                                             view_object_edges=int(cnt["view_object_links"]))
+                state["graph_ms"] = dict(begin=round(cnt["begin_ms"], 2), finish=round(cnt["finish_ms"], 2),
+                                         kmeans_wait=round(cnt["kmeans_wait_ms"], 2))
+                ix.close()
+                return idx, room, score
             if not use_dist and args.full_graph:
                 # the rooms are the segmented ones: each is named after the ground-truth room its region lies in (two regions
                 # of one room share the name: the label mode then selects both)
@@ -528,7 +569,9 @@ def main():
             scx.reset()
             scx.add_frames(inp["rgb"], inp["depth"], inp["pose"], inp["K"])
             scx.finalize_map()
-            if args.full_graph:
+            if c_graph:
+                cg = SceneGraph.begin(scx, poses_arr, fg_host)
+            elif args.full_graph:
                 g = Graph.from_scene(scx, cfg=full_cfg, lib=L, instances=False)
                 g.dataset = FrameSource()
                 g._poses = poses_host
@@ -538,6 +581,16 @@ def main():
             scx.fuse_frames()
             scx.merge_instances()
             scx.pool_instances()
+            if c_graph:                                            # the same step as the line: nothing handed in
+                cg.finish(label_feats, label_names)
+                rooms_c = cg.rooms()
+                gt_of = [gt_room_of(cg.room_vertices(i, r["n_vertices"])) for i, r in enumerate(rooms_c)]
+                ix = cg.index(room_name_feats[gt_of])
+                ix.query_hier(text, np.zeros(len(text), np.int32), room_text, np.zeros(len(text), np.int32), np.ones(len(text), np.int32), k)
+                ix.close()
+                n_obj = cg.counts()["objects"]
+                cg.close()
+                return n_obj
             if args.full_graph:                                    # the same step as the line: nothing handed in
                 g.take_instances()
                 g.set_label_feats(label_feats, label_names)
@@ -715,6 +768,8 @@ def main():
                        "parallelism": ("episode-sharded x%d (frame windows of %d)" % (world, chunk)) if episode else "scene-per-gpu x%d" % world},
             "rccl_ranks": dist.get_world_size() if use_dist else 0,
             "full_graph": bool(args.full_graph and not episode), "graph_counts": state.get("graph_counts"),
+            "graph_level": ("C ABI graph object (hmsg_graph_begin / _finish / _index)" if c_graph else "Python mirror") if args.full_graph and not episode else None,
+            "graph_ms": state.get("graph_ms"),
             "emulated": bool(emu),
             # (scene mode: the sequential fold of A6 starts on a worker thread while hmsg_fuse_frames is still producing
             #  3-D masks, so part of the merge is inside the fuse_frames stage time; HMSG_FOLD_NOPIPE=1 separates them)

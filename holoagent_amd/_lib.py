@@ -134,6 +134,7 @@ _SIGS = {
     "hmsg_graph_get_edges": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "hmsg_graph_get_objects": (C.c_int, [_P, _P, C.c_int64]),
     "hmsg_graph_get_rooms": (C.c_int, [_P, _P, C.c_int64]),
+    "hmsg_graph_get_room_vertices": (C.c_int, [_P, C.c_int32, _P, C.c_int64]),
     "hmsg_graph_get_room_embeddings": (C.c_int, [_P, C.c_int32, _P, C.c_int64]),
     "hmsg_graph_to_json": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "hmsg_save": (C.c_int, [_P, C.c_char_p]),
@@ -762,6 +763,12 @@ class SceneGraph:
         return [dict(room_id=a.room_id.decode(), name=a.name.decode(), floor=a.floor, n_vertices=a.n_vertices, n_points=a.n_points,
                      n_embeddings=a.n_embeddings, n_sample_images=a.n_sample_images, n_objects=a.n_objects, n_views=a.n_views)
                 for a in arr[:n]]
+
+    def room_vertices(self, room, n=None):
+        n = int(n if n is not None else self.rooms()[room]["n_vertices"])
+        out = np.zeros((max(n, 1), 2), np.float64)
+        self._ck(self.L.c.hmsg_graph_get_room_vertices(self.g, int(room), _ptr(out), out.size))
+        return out[:n]
 
     def room_embeddings(self, room, D=None):
         r = self.rooms()[room]

@@ -953,6 +953,14 @@ int hmsg_graph_get_rooms(const hmsg_graph_t* g, hmsg_graph_room* out, int64_t ca
     return HMSG_OK;
 }
 
+int hmsg_graph_get_room_vertices(const hmsg_graph_t* g, int32_t room, double* xz, int64_t capacity) {
+    if (!g || room < 0 || room >= (int32_t)g->rooms.size() || !xz) return HMSG_ERR_INVALID;
+    const GRoom& rm = g->rooms[(size_t)room];
+    if ((size_t)capacity < rm.verts.size()) return HMSG_ERR_INVALID;
+    if (!rm.verts.empty()) memcpy(xz, rm.verts.data(), rm.verts.size() * 8);
+    return HMSG_OK;
+}
+
 int hmsg_graph_get_room_embeddings(const hmsg_graph_t* g, int32_t room, float* emb, int64_t capacity) {
     if (!g || room < 0 || room >= (int32_t)g->rooms.size() || !emb) return HMSG_ERR_INVALID;
     const GRoom& rm = g->rooms[(size_t)room];

@@ -497,6 +497,7 @@ int hmsg_graph_get_counts(const hmsg_graph_t* g, hmsg_graph_counts* counts);
 int hmsg_graph_get_edges(const hmsg_graph_t* g, int64_t* edges /*[capacity][2], may be NULL*/, int64_t capacity, int64_t* n_edges);
 int hmsg_graph_get_objects(const hmsg_graph_t* g, hmsg_graph_object* out, int64_t capacity);
 int hmsg_graph_get_rooms(const hmsg_graph_t* g, hmsg_graph_room* out, int64_t capacity);
+int hmsg_graph_get_room_vertices(const hmsg_graph_t* g, int32_t room, double* xz /*[n_vertices][2]: room.vertices*/, int64_t capacity);
 int hmsg_graph_get_room_embeddings(const hmsg_graph_t* g, int32_t room, float* emb /*[n_embeddings][D]*/, int64_t capacity);
 int hmsg_graph_to_json(const hmsg_graph_t* g, char* buf, int64_t capacity, int64_t* needed);
 int hmsg_save(hmsg_graph_t* g, const char* dir);
