@@ -4,7 +4,7 @@
  * index, object queries -- on a scene read from a flat binary file, and writes what it got to another one; the test
  * compares that with the same calls made through the Python binding, bit for bit.
  *
- *   hmsg_host <in.bin> <out.bin>
+ *   hmsg_host <in.bin> <out.bin> [<graph dir>]
  *   in : i32 F H W M D Q k outlier_nb feat_dbscan_min outlier_radius_mm | f64 K[9] | u8 rgb[F][H][W][3] | u16 depth[F][H][W] |
  *        f64 pose[F][16] | u8 masks[F][M][H][W] | i32 n_masks[F] | f32 f_g[F][D] | f32 f_masked[F][M][D] |
  *        f32 f_crop[F][M][D] | f32 text[Q][2][D] | f32 room_text[Q][D] | f64 room_names[8][D]
@@ -12,7 +12,11 @@
  *        | i64 n_rooms, rows, cols, n_nodes2 | i32 markers[rows][cols] | i32 nsel[Q] | i32 sel[Q][8] | i32 hidx[Q][k] | f64 hscore[Q][k]
  *   (second part: rooms of storey 0 by the device room segmentation (hmsg_segment_rooms), their regions as the room
  *    vertices of hmsg_build_object_nodes, create_graph_new's edges of that graph (hmsg_graph_edges), and the coarse-to-fine
- *    query floor -> room by name -> objects, hmsg_query_hier) */
+ *    query floor -> room by name -> objects, hmsg_query_hier)
+ *   with <graph dir>, third part -- THE GRAPH WITH FOUR CALLS: hmsg_build_graph (floors, rooms, views, objects, edges held by the
+ *    library), hmsg_save (the reference's directory layout), hmsg_load, hmsg_graph_query (rooms by their view embeddings, then
+ *    objects); appended to out: i32 counts[4] (floors, rooms, views, objects) | i64 n_edges | i32 gsel_n[Q] | i32 gsel[Q][16] |
+ *    i32 gidx[Q][k] | f64 gscore[Q][k] */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -53,6 +57,10 @@ int main(int argc, char** argv) {
     hmsg_node* nd2;
     int32_t* obj_room;
     double xz_min[2], *verts2, *hscore;
+    hmsg_graph_t *g = NULL, *lg = NULL;
+    hmsg_graph_counts gc;
+    int32_t *gfid, *gmode, *gqid, *gnsel, *gsel, *gidx, *groom, gcounts[4];
+    double* gscore;
     hmsg_config cfg;
     hmsg_t* h = NULL;
     hmsg_index_t* ix = NULL;
@@ -66,7 +74,7 @@ int main(int argc, char** argv) {
     int32_t room_floor[1];
     size_t HW;
 
-    if (argc != 3) {
+    if (argc != 3 && argc != 4) {
         fprintf(stderr, "usage: hmsg_host <in.bin> <out.bin>   (%s)\n", hmsg_version());
         return 1;
     }
@@ -247,6 +255,46 @@ int main(int argc, char** argv) {
     fwrite(hscore, sizeof(double), (size_t)Q * (size_t)k, fo);
     fwrite(&n_edges, sizeof(int64_t), 1, fo);
     if (n_edges) fwrite(edges, sizeof(int64_t), (size_t)n_edges * 2, fo);
+    if (argc == 4) {
+        /* 1: build -- build_hier_multimodal_scene_graph (the poses' inverses and the label vocabulary are optional) */
+        CK(hmsg_build_graph(h, NULL, F, pose, NULL, f_g, NULL, 0, NULL, NULL, &g));
+        /* 2: save -- save_hmsg_graph's directory */
+        if (hmsg_save(g, argv[3]) != HMSG_OK) {
+            fprintf(stderr, "hmsg_host: hmsg_save: %s\n", hmsg_graph_last_error(g));
+            return 10;
+        }
+        if (hmsg_graph_get_counts(g, &gc) != HMSG_OK) return 11;
+        hmsg_graph_destroy(g);
+        /* 3: load -- load_hmsg_graph; the scene handle is not needed any more */
+        if (hmsg_load(argv[3], 0, &lg) != HMSG_OK) return 12;
+        /* 4: query -- floor (all) -> rooms by their view embeddings (mode 2) -> objects with one negative prompt */
+        gfid = (int32_t*)malloc((size_t)Q * 4);
+        gmode = (int32_t*)malloc((size_t)Q * 4);
+        gqid = (int32_t*)calloc((size_t)Q, 4);
+        gnsel = (int32_t*)calloc((size_t)Q, 4);
+        gsel = (int32_t*)malloc((size_t)Q * 16 * 4);
+        gidx = (int32_t*)malloc((size_t)Q * (size_t)k * 4);
+        groom = (int32_t*)malloc((size_t)Q * (size_t)k * 4);
+        gscore = (double*)calloc((size_t)Q * (size_t)k, sizeof(double));
+        memset(gsel, 0xff, (size_t)Q * 16 * 4);
+        memset(gidx, 0xff, (size_t)Q * (size_t)k * 4);
+        for (q = 0; q < Q; ++q) {
+            gfid[q] = -1;
+            gmode[q] = 2;
+        }
+        if (gc.objects > 0 && hmsg_graph_query(lg, NULL, Q, 2, text, gqid, room_text, gfid, gmode, k, 1, 16, gsel, gnsel, gidx, groom, gscore) != HMSG_OK) {
+            fprintf(stderr, "hmsg_host: hmsg_graph_query: %s\n", hmsg_graph_last_error(lg));
+            return 13;
+        }
+        gcounts[0] = gc.floors; gcounts[1] = gc.rooms; gcounts[2] = gc.views; gcounts[3] = gc.objects;
+        fwrite(gcounts, 4, 4, fo);
+        fwrite(&gc.edges, sizeof(int64_t), 1, fo);
+        fwrite(gnsel, 4, (size_t)Q, fo);
+        fwrite(gsel, 4, (size_t)Q * 16, fo);
+        fwrite(gidx, 4, (size_t)Q * (size_t)k, fo);
+        fwrite(gscore, sizeof(double), (size_t)Q * (size_t)k, fo);
+        hmsg_graph_destroy(lg);
+    }
     fclose(fo);
     hmsg_destroy(h);
     printf("hmsg_host ok: V %ld instances %ld floors %d nodes %ld\n", (long)V, (long)N, (int)n_floors, (long)n_nodes);

@@ -54,7 +54,8 @@ def _run(lib_path, tmp_path):
                      (S["f_crop"], np.float32), (text, np.float32), (room_text, np.float32), (room_names, np.float64)):
             np.ascontiguousarray(a, t).tofile(f)
     exe = _build(lib_path, str(tmp_path / "hmsg_host"))
-    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=900)
+    gdir = str(tmp_path / "graph_c")
+    r = subprocess.run([exe, fin, fout, gdir], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     raw = open(fout, "rb").read()
     V, N, n_floors, n_nodes = np.frombuffer(raw, np.int64, 4)
@@ -70,7 +71,14 @@ def _run(lib_path, tmp_path):
     hidx = np.frombuffer(raw, np.int32, Q * k, o).reshape(Q, k); o += 4 * Q * k
     hscore = np.frombuffer(raw, np.float64, Q * k, o).reshape(Q, k); o += 8 * Q * k
     n_edges = int(np.frombuffer(raw, np.int64, 1, o)[0]); o += 8
-    c_edges = np.frombuffer(raw, np.int64, n_edges * 2, o).reshape(n_edges, 2)
+    c_edges = np.frombuffer(raw, np.int64, n_edges * 2, o).reshape(n_edges, 2); o += 16 * n_edges
+    gcounts = np.frombuffer(raw, np.int32, 4, o); o += 16
+    g_edges = int(np.frombuffer(raw, np.int64, 1, o)[0]); o += 8
+    gnsel = np.frombuffer(raw, np.int32, Q, o); o += 4 * Q
+    gsel = np.frombuffer(raw, np.int32, Q * 16, o).reshape(Q, 16); o += 64 * Q
+    gidx = np.frombuffer(raw, np.int32, Q * k, o).reshape(Q, k); o += 4 * Q * k
+    gscore = np.frombuffer(raw, np.float64, Q * k, o).reshape(Q, k); o += 8 * Q * k
+    assert o == len(raw)
     # the same calls through the Python binding
     L = HmsgLib(lib_path)
     sc = PC.make_scene(L, frames, over)
@@ -112,6 +120,28 @@ def _run(lib_path, tmp_path):
     from holoagent_amd._lib import graph_edges
     e2 = graph_edges(len(fl), [0] * n_rooms, [int(n["room"]) for n in nodes2], [], [], lib_=L)
     assert n_edges == len(e2) == len(fl) + n_rooms + len(nodes2) and np.array_equal(c_edges, e2)
+    # THE GRAPH WITH FOUR CALLS (hmsg_build_graph, hmsg_save, hmsg_load, hmsg_graph_query) from C == the same four through the binding:
+    # same counts, the two saved directories byte for byte, same answers
+    from holoagent_amd._lib import SceneGraph
+    cg = SceneGraph.build(sc, S["pose"], S["f_g"])
+    cnt = cg.counts()
+    assert list(gcounts) == [cnt["floors"], cnt["rooms"], cnt["views"], cnt["objects"]] and g_edges == cnt["edges"]
+    assert cnt["rooms"] >= 2 and cnt["views"] == F and cnt["objects"] >= 1
+    pdir = tmp_path / "graph_py"
+    cg.save(pdir)
+    for sub in ("floors", "rooms", "objects", "views"):
+        a, b = sorted(os.listdir(pdir / sub)), sorted(os.listdir(os.path.join(gdir, sub)))
+        assert a == b and a, sub
+        for f in a:
+            assert open(pdir / sub / f, "rb").read() == open(os.path.join(gdir, sub, f), "rb").read(), (sub, f)
+    lg = SceneGraph.load(pdir, lib_=L)
+    minus = np.full(Q, -1, np.int32)
+    sel3, idx3, _, score3 = lg.query(text, np.zeros(Q, np.int32), room_text, minus, np.full(Q, 2, np.int32), k, max_rooms=16)
+    for q in range(Q):
+        assert list(gsel[q][: gnsel[q]]) == list(sel3[q]), q
+    assert np.array_equal(gidx, idx3) and np.array_equal(gscore, score3) and (gidx >= 0).any()
+    lg.close()
+    cg.close()
     sc.close()
 
 
