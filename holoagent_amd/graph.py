@@ -466,7 +466,13 @@ def compute_room_embeddings(room_pcds, pose_list, emb_list, pcd_min, pcd_max, nu
         except Exception:
             import contextlib
             threadpool_limits = lambda limits=None: contextlib.nullcontext()
-        with threadpool_limits(limits=1):
+        # (only scikit-learn's own OpenMP pool is limited: limits=1 without user_api also throttles every BLAS pool of the process --
+        #  numpy / torch work on other threads -- for as long as the fits run)
+        try:
+            ctx = threadpool_limits(limits=1, user_api="openmp")
+        except TypeError:
+            ctx = threadpool_limits(limits=1)
+        with ctx:
             fits = {r: KMeans(n_clusters=num_views, max_iter=100, n_init=5, random_state=0).fit(clips[r]) for r in todo}
     for room_id in range(n_rooms):
         img_ids = room_id2img_id[room_id]
@@ -652,6 +658,18 @@ class Graph:
         re-sampling and the height histogram on the device, scipy's filter / peak rules restated in C++), the map never
         leaves HBM and a storey's cloud is fetched only when somebody reads it; `_segment_floors_host` is the numpy /
         scipy mirror used for clouds loaded from disk (tests/test_floors_cabi.py: the two agree bit for bit)."""
+        # a room level started early (start_room_level / create_feature_map) made floors already: a caller that drives this
+        # method itself starts over -- the pending host stage is waited for and dropped with them
+        early = getattr(self, "_room_level", None)
+        if early is not None and not getattr(self, "_in_start_room_level", False):
+            early["thread"].join()
+            self._room_level = None
+        if not getattr(self, "_in_start_room_level", False):
+            for fl in self.floors:
+                for r in fl.rooms:
+                    if r in self.rooms:
+                        self.rooms.remove(r)
+            self.floors = []
         if self.scene is None or not isinstance(self.full_pcd, _LazyFn):     # (a cloud somebody set or loaded from disk)
             return self._segment_floors_host(path)
         floors = []
@@ -944,7 +962,11 @@ class Graph:
             return
         import time
         t0 = time.perf_counter()
-        self.segment_floors_manually(None)
+        self._in_start_room_level = True
+        try:
+            self.segment_floors_manually(None)
+        finally:
+            self._in_start_room_level = False
         t1 = time.perf_counter()
         ctxs = [self._rooms_prepare(fl) for fl in self.floors]
         if os.environ.get("HMSG_DEBUG_TIMING"):
@@ -1061,7 +1083,12 @@ class Graph:
                 a0, a1 = int(cut[k]), int(cut[k + 1])
                 if a1 > a0:
                     made[k][0].view_ids.extend(view_ids[j] for j in hv_l[a0:a1])
-                    best[k] = (None, view_ids[hv_l[a0 + int(np.argmin(hmd[a0:a1]))]])
+                    # the reference scans with `if mean_depth < best_depth` from inf (:1727-1731): a NaN or inf mean never wins,
+                    # and best_view_id stays None when no visible view has a finite one
+                    seg = hmd[a0:a1]
+                    fin = np.isfinite(seg)
+                    if fin.any():
+                        best[k] = (None, view_ids[hv_l[a0 + int(np.argmin(np.where(fin, seg, np.inf)))]])
             # per view: the objects that see it, in object order (a stable sort by view keeps the pair order inside a view)
             order = np.argsort(hv, kind="stable")
             sv, sk = hv[order], hk[order].tolist()
