@@ -263,7 +263,7 @@ class Comm:
         h = _P()
         rc = L.c.hmsg_comm_create(C.cast(buf, _P), int(rank), int(world), int(device_id), C.byref(h))
         if rc != 0:
-            raise HmsgError(f"hmsg_comm_create failed ({rc}): librccl missing, or the ranks did not all join")
+            raise HmsgError(f"hmsg_comm_create failed ({rc}): " + (L.c.hmsg_comm_last_error(None) or b"").decode())
         return cls(h, int(rank), int(world), L)
 
     @staticmethod
@@ -272,7 +272,7 @@ class Comm:
         buf = (C.c_uint8 * 128)()
         rc = L.c.hmsg_comm_unique_id(C.cast(buf, _P))
         if rc != 0:
-            raise HmsgError(f"hmsg_comm_unique_id failed ({rc}): librccl could not be loaded")
+            raise HmsgError(f"hmsg_comm_unique_id failed ({rc}): " + (L.c.hmsg_comm_last_error(None) or b"").decode())
         return bytes(buf)
 
     @classmethod

@@ -54,10 +54,13 @@ RcclApi& rccl() {
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
-        const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        // HMSG_RCCL_LIB: another library with the same six symbols (tests: tests/rccl_double, a shared-memory stand-in that lets
+        // the two exchange steps run with world > 1 on the kernel simulator)
+        const char* over = getenv("HMSG_RCCL_LIB");
+        const char* names[] = {over ? over : "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
         for (const char* n : names) {
             api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-            if (api.lib) break;
+            if (api.lib || over) break;
         }
         if (!api.lib) {
             api.why = std::string("librccl.so could not be loaded: ") + (dlerror() ? dlerror() : "?");
@@ -95,49 +98,84 @@ struct hmsg_comm {
     std::string err;
 };
 
+namespace {
+// the message of a failed hmsg_comm_unique_id / hmsg_comm_create (no communicator to keep it in): hmsg_comm_last_error(NULL)
+thread_local std::string g_comm_err;
+
+// Every rank must reach every collective, or the others wait for ever: a rank that finds something wrong with its OWN inputs
+// (a node whose room lies outside the table, a failed allocation) does not return before the first collective -- the ranks
+// first agree (a 4-byte all-reduce of an ok flag) and then fail together.
+bool all_ranks_ok(hmsg_comm* c, bool mine_ok, hipStream_t s) {
+    if (!c->comm) return mine_ok;
+    DevBuf<unsigned> flag;
+    flag.alloc(1);
+    const unsigned v = mine_ok ? 0u : 1u;
+    unsigned sum = 0u;
+    HIP_TRY(hipMemcpyAsync(flag.p, &v, 4, hipMemcpyHostToDevice, s));
+    rccl_try(rccl().AllReduce(flag.p, flag.p, 1, RCCL_UINT32, RCCL_SUM, c->comm, s), "ncclAllReduce (ok flag)");
+    HIP_TRY(hipMemcpyAsync(&sum, flag.p, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return sum == 0u;
+}
+template <typename F>
+int comm_guard(std::string* err, F&& f) {        // no exception crosses the C boundary
+    try {
+        f();
+        return HMSG_OK;
+    } catch (const hmsg_error& e) {
+        if (err) *err = e.msg;
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        if (err) *err = "out of host memory";
+        return HMSG_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        if (err) *err = e.what();
+        return HMSG_ERR_INVALID;
+    } catch (...) {
+        if (err) *err = "unknown error";
+        return HMSG_ERR_INVALID;
+    }
+}
+}  // namespace
+
 extern "C" {
 
 int hmsg_comm_unique_id(uint8_t* out_id) {
     if (!out_id) return HMSG_ERR_INVALID;
-    try {
+    return comm_guard(&g_comm_err, [&] {
         rccl_need();
         rcclUniqueId id;
         rccl_try(rccl().GetUniqueId(&id), "ncclGetUniqueId");
         memcpy(out_id, id.internal, sizeof(id.internal));
-        return HMSG_OK;
-    } catch (const hmsg_error& e) {
-        return e.code;
-    }
+    });
 }
 
 int hmsg_comm_create(const uint8_t* id, int32_t rank, int32_t world, int32_t device_id, hmsg_comm_t** out) {
     if (!out) return HMSG_ERR_INVALID;
     *out = nullptr;
     if (world < 1 || rank < 0 || rank >= world) return HMSG_ERR_INVALID;
-    hmsg_comm* c = new hmsg_comm();
-    c->rank = rank;
-    c->world = world;
-    c->device = device_id;
-    if (id == nullptr) {                       // one rank and no id: no communicator needed (every collective is the identity)
-        if (world != 1) {
-            delete c;
-            return HMSG_ERR_INVALID;
+    hmsg_comm* c = nullptr;
+    const int rc = comm_guard(&g_comm_err, [&] {
+        c = new hmsg_comm();
+        c->rank = rank;
+        c->world = world;
+        c->device = device_id;
+        if (id == nullptr) {                   // one rank and no id: no communicator needed (every collective is the identity)
+            HMSG_REQUIRE(world == 1, HMSG_ERR_INVALID, "hmsg_comm_create: more than one rank needs the id of hmsg_comm_unique_id");
+            return;
         }
-        *out = c;
-        return HMSG_OK;
-    }
-    try {
         rccl_need();
         HIP_TRY(hipSetDevice(device_id));
         rcclUniqueId uid;
         memcpy(uid.internal, id, sizeof(uid.internal));
         rccl_try(rccl().CommInitRank(&c->comm, world, uid, rank), "ncclCommInitRank");
-        *out = c;
-        return HMSG_OK;
-    } catch (const hmsg_error& e) {
+    });
+    if (rc != HMSG_OK) {
         delete c;
-        return e.code;
+        return rc;
     }
+    *out = c;
+    return HMSG_OK;
 }
 
 void hmsg_comm_destroy(hmsg_comm_t* c) {
@@ -146,17 +184,26 @@ void hmsg_comm_destroy(hmsg_comm_t* c) {
     delete c;
 }
 
-const char* hmsg_comm_last_error(const hmsg_comm_t* c) { return c ? c->err.c_str() : "null communicator"; }
+/* c == NULL: the message of this thread's last failed hmsg_comm_unique_id / hmsg_comm_create */
+const char* hmsg_comm_last_error(const hmsg_comm_t* c) { return c ? c->err.c_str() : g_comm_err.c_str(); }
 
 int hmsg_allgather_nodes(hmsg_t* h, hmsg_comm_t* c, int32_t n_rooms_local, hmsg_index_t** out_index, int64_t* node_off, int64_t* room_off) {
     if (!h || !c || !out_index) return HMSG_ERR_INVALID;
     *out_index = nullptr;
-    try {
+    int rc_index = HMSG_OK;
+    const int rc = comm_guard(&h->err, [&] {
         HIP_TRY(hipSetDevice(h->cfg.device_id));
         hipStream_t s = h->stream;
         const int W = c->world, D = h->cfg.feat_dim;
         const long long n = (long long)h->nodes.size();
-        HMSG_REQUIRE(n_rooms_local >= 0, HMSG_ERR_INVALID, "hmsg_allgather_nodes: negative room count");
+        // everything that can be wrong with THIS rank's inputs is looked at before the first collective, and the ranks agree
+        std::string mine;
+        if (n_rooms_local < 0) mine = "hmsg_allgather_nodes: negative room count";
+        for (long long k = 0; k < n && mine.empty(); ++k)
+            if (h->nodes[(size_t)k].room < 0 || h->nodes[(size_t)k].room >= n_rooms_local) mine = "hmsg_allgather_nodes: a node's room lies outside n_rooms_local";
+        if (n && !h->pooled) mine = "hmsg_allgather_nodes: run hmsg_pool_instances first";
+        if (!all_ranks_ok(c, mine.empty(), s))
+            throw hmsg_error{HMSG_ERR_INVALID, mine.empty() ? "hmsg_allgather_nodes: another rank's node table is invalid (see its hmsg_last_error)" : mine};
         // 1. counts (nodes, rooms) of every rank
         std::vector<long long> meta((size_t)W * 2, 0);
         meta[(size_t)c->rank * 2] = n;
@@ -192,8 +239,6 @@ int hmsg_allgather_nodes(hmsg_t* h, hmsg_comm_t* c, int32_t n_rooms_local, hmsg_
             for (long long k = 0; k < n; ++k) {
                 inst[(size_t)k] = h->nodes[(size_t)k].instance;
                 rm[(size_t)k] = h->nodes[(size_t)k].room + (int)roff[(size_t)c->rank];        // global room id
-                HMSG_REQUIRE(h->nodes[(size_t)k].room >= 0 && h->nodes[(size_t)k].room < n_rooms_local, HMSG_ERR_INVALID,
-                             "hmsg_allgather_nodes: a node's room lies outside n_rooms_local");
             }
             DevBuf<int> d_inst;
             d_inst.alloc((size_t)n);
@@ -220,20 +265,23 @@ int hmsg_allgather_nodes(hmsg_t* h, hmsg_comm_t* c, int32_t n_rooms_local, hmsg_
             HIP_TRY(hipMemcpyAsync(proom.p + (size_t)noff[(size_t)r], room.p + (size_t)r * nmax, (size_t)nr * 4, hipMemcpyDeviceToDevice, s));
         }
         HIP_TRY(hipStreamSynchronize(s));
-        return hmsg_index_create(h->cfg.device_id, D, N, packed.p, 0, proom.p, out_index);
-    } catch (const hmsg_error& e) {
-        h->err = e.msg;
-        return e.code;
-    }
+        rc_index = hmsg_index_create(h->cfg.device_id, D, N, packed.p, 0, proom.p, out_index);
+        if (rc_index != HMSG_OK) throw hmsg_error{rc_index, "hmsg_allgather_nodes: hmsg_index_create failed"};
+    });
+    if (rc != HMSG_OK) c->err = h->err;
+    return rc;
 }
 
 int hmsg_allreduce_feature_sums(hmsg_t* h, hmsg_comm_t* c) {
     if (!h || !c) return HMSG_ERR_INVALID;
-    try {
+    const int rc = comm_guard(&h->err, [&] {
         HIP_TRY(hipSetDevice(h->cfg.device_id));
-        HMSG_REQUIRE(h->feats_final, HMSG_ERR_INVALID, "hmsg_allreduce_feature_sums: run hmsg_fuse_frames first");
-        HMSG_REQUIRE(!h->pooled, HMSG_ERR_INVALID, "hmsg_allreduce_feature_sums after hmsg_pool_instances");
         hipStream_t s = h->stream;
+        std::string mine;
+        if (!h->feats_final) mine = "hmsg_allreduce_feature_sums: run hmsg_fuse_frames first";
+        else if (h->pooled) mine = "hmsg_allreduce_feature_sums after hmsg_pool_instances";
+        if (!all_ranks_ok(c, mine.empty(), s))
+            throw hmsg_error{HMSG_ERR_INVALID, mine.empty() ? "hmsg_allreduce_feature_sums: another rank is not ready (see its hmsg_last_error)" : mine};
         const size_t n = (size_t)h->V * h->cfg.feat_dim;
         if (c->comm && n) {
             rccl_try(rccl().AllReduce(h->sum.p, h->sum.p, n, RCCL_FLOAT32, RCCL_SUM, c->comm, s), "ncclAllReduce (feature sums)");
@@ -243,11 +291,9 @@ int hmsg_allreduce_feature_sums(hmsg_t* h, hmsg_comm_t* c) {
                                   (long long)h->V, h->cfg.feat_dim, h->feats.p);
         HMSG_CHECK_LAUNCH();
         HIP_TRY(hipStreamSynchronize(s));
-        return HMSG_OK;
-    } catch (const hmsg_error& e) {
-        h->err = e.msg;
-        return e.code;
-    }
+    });
+    if (rc != HMSG_OK) c->err = h->err;
+    return rc;
 }
 
 }  // extern "C"
