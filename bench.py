@@ -169,9 +169,14 @@ def main():
     # line says so ("emulated": true)
     emu = os.environ.get("HMSG_BENCH_EMU")
     if emu:
-        assert not use_dist, "the simulator run is single-process"
+        # (several ranks on the simulator only with a stand-in for librccl, HMSG_RCCL_LIB = tests/rccl_double: the test of the
+        #  N > 1 code path of this script, tests/test_bench_contract.py)
+        assert not use_dist or os.environ.get("HMSG_RCCL_LIB"), "the simulator run is single-process"
         device = torch.device("cpu")
         sync = lambda: None
+        local = 0                                   # (the simulator has one device)
+        if use_dist:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         L = HmsgLib(emu)
     else:
         torch.cuda.set_device(local)
@@ -186,7 +191,9 @@ def main():
     # (episode mode: every rank sees the same episode -- same seed; scene mode: a scene per rank)
     # the whole graph (A8-A11, nothing handed in) is the line; the multi-GPU legs take the rooms as given (the all-gathered
     # retrieval of scene mode addresses rooms by their global ids; episode mode assembles on the root only)
-    args.full_graph = not args.rooms_handed_in and not (use_dist or episode)
+    # (round 5: the multi-GPU scene mode times the SAME step as one GPU -- every rank builds its whole graph -- and answers
+    #  hmsg_query_hier on the all-gathered table; episode mode assembles on the root only and takes the rooms as given)
+    args.full_graph = not args.rooms_handed_in and not episode
     shape = {}
     if args.scene_shape:
         v = [float(x) for x in args.scene_shape.split(",")]
@@ -231,7 +238,7 @@ def main():
     from holoagent_amd._lib import SceneGraph
     # --python-graph: the graph level through the Python mirror of the reference's Graph (rounds 3-4's form of the line) instead of
     # the graph object behind the C ABI (hmsg_graph_begin / hmsg_graph_finish / hmsg_graph_index)
-    c_graph = args.full_graph and not args.python_graph
+    c_graph = args.full_graph and (not args.python_graph or use_dist)
     gt_boxes = np.asarray(inp["rooms"], np.float64)
 
     def gt_room_of(xz):
@@ -394,8 +401,51 @@ def main():
             feats, rooms = T("assemble_graph", assemble)
         state["n_nodes_local"] = feats.shape[0] if feats is not None else state["graph"].counts()["objects"]
 
+        def retrieve_dist_graph():
+            """scene per GPU, the whole graph on every rank: node tables all-gathered behind the C ABI (hmsg_allgather_nodes, RCCL on
+            HBM buffers -> ONE resident index), the levels above them -- floors -> rooms, room names, the rooms' view embeddings --
+            gathered as host tables (a few hundred KB) and made resident on the global index with global room ids (room_off);
+            every rank then answers its share of the queries coarse to fine on ITS OWN storey of the global table."""
+            from holoagent_amd.dist import gather_node_tables_device, shard_queries
+            cg = state["graph"]
+            cnt = cg.counts()
+            rooms_c = cg.rooms()
+            gt_of = [gt_room_of(cg.room_vertices(i, r["n_vertices"])) for i, r in enumerate(rooms_c)]
+            g_ix, node_off, room_off, state["comm"] = gather_node_tables_device(sc, cnt["rooms"], state.get("comm"), local)
+            mine = dict(floor_rooms=[[i for i, r in enumerate(rooms_c) if r["floor"] == f] for f in range(cnt["floors"])],
+                        names=np.ascontiguousarray(room_name_feats[gt_of], np.float64),
+                        views=[cg.room_embeddings(i) for i in range(cnt["rooms"])], counts=cnt)
+            every = [None] * world
+            dist.all_gather_object(every, mine)
+            floors_g, names_g, views_g, floor_off = [], [], [], [0]
+            for r, e in enumerate(every):
+                floors_g += [[int(room_off[r]) + i for i in fr] for fr in e["floor_rooms"]]
+                names_g.append(e["names"])
+                views_g += [np.asarray(v, np.float64) for v in e["views"]]
+                floor_off.append(len(floors_g))
+            n_rooms_g = int(room_off[-1])
+            g_ix.set_hierarchy(floors_g, np.concatenate(names_g) if n_rooms_g else None, views_g,
+                               [int(k) for e in every for k in range(e["counts"]["rooms"])])
+            g_ix.set_profiling(True)
+            qs = shard_queries(Q, rank, world)
+            tq, tr = np.ascontiguousarray(text[qs]), np.ascontiguousarray(room_text[qs])
+            fl = np.full(len(qs), floor_off[rank], np.int32)      # (this rank's scene has one storey: its first floor of the global list)
+            sel, idx, room, score = g_ix.query_hier(tq, np.zeros(len(qs), np.int32), tr, fl, np.ones(len(qs), np.int32), k,
+                                                    max_rooms=max(n_rooms_g, 10))
+            state["gemm"] = g_ix.profile()
+            state["rooms_hit"] = float(np.mean([int(ent_room[q_ent[q]]) in {gt_of[j] for j in s_} for q, s_ in zip(qs, sel)])) if len(qs) else None
+            state["graph_counts"] = dict(floors=cnt["floors"], rooms=cnt["rooms"], views=cnt["views"], objects=cnt["objects"],
+                                         view_object_edges=int(cnt["view_object_links"]))
+            state["graph_counts_all_ranks"] = [dict(floors=e["counts"]["floors"], rooms=e["counts"]["rooms"], views=e["counts"]["views"],
+                                                    objects=e["counts"]["objects"]) for e in every]
+            state["graph_ms"] = dict(begin=round(cnt["begin_ms"], 2), finish=round(cnt["finish_ms"], 2), kmeans_wait=round(cnt["kmeans_wait_ms"], 2))
+            g_ix.close()
+            return idx, room, score
+
         def retrieve():
             g_ix = None
+            if use_dist and c_graph:
+                return retrieve_dist_graph()
             if use_dist:
                 # all-gather of the node tables over RCCL -> global table on every rank.  On the GPUs the exchange runs behind
                 # the C ABI (hmsg_allgather_nodes: librccl on device buffers, the gathered table IS the resident index); the
@@ -424,7 +474,7 @@ def main():
             # coarse to fine ON THE DEVICE (hmsg_query_hier): floor 0 -> room by its name (label mode: the rooms within
             # 1e-3 of the best name similarity) -> objects of those rooms with one negative prompt -- no room list is
             # handed in.  N GPUs: object-level queries on the all-gathered global table with the rooms' global ids.
-            if c_graph:
+            if c_graph and not use_dist:
                 # the rooms are the segmented ones: each is named after the ground-truth room its region lies in (two regions
                 # of one room share the name: the label mode then selects both); the index comes from the graph object with
                 # floors -> rooms and the rooms' view embeddings resident (hmsg_graph_index)
@@ -748,7 +798,8 @@ def main():
         out = {
             "metric": ("HMSG frames/sec (%s: map A1-A2, fusion A3-A5, merge A6, pooling A7, floors A8, %splus %d coarse-to-fine "
                        "retrieval queries (A12: floor -> room by its name -> objects with a "
-                       "negative prompt, every stage on the device; object level only in the multi-GPU scene mode) per %d-frame %s; frames, masks and "
+                       "negative prompt, every stage on the device; with several GPUs on the all-gathered table, every rank on its own scene's "
+                       "storey) per %d-frame %s; frames, masks and "
                        "encoder features already resident in HBM, encoders bypassed)")
                       % ("one episode sharded over the GPUs" if episode else "one scene per GPU",
                          ("rooms by the device watershed N1, room clouds, room embeddings and View nodes A9, objects with the view <-> object "
@@ -762,12 +813,14 @@ def main():
             "config": {"workload": ("configs[4] shape: ONE %d-frame episode, %dx%d RGB-D, 32 masks/frame, %d-d features, hierarchical "
                                     "merge tree sharded over the ranks, HMSG build + %d-query retrieval on the root" % (F, spec.width, spec.height, D, Q))
                        if episode else
-                       ("configs[1]: %d-frame single scene per GPU, %dx%d RGB-D, 32 masks/frame, %d-d features, "
-                        "HMSG build + %d-query retrieval" % (F, spec.width, spec.height, D, Q)),
+                                      ("%s: %d-frame single scene per GPU, %dx%d RGB-D, 32 masks/frame, %d-d features, "
+                        "HMSG build + %d-query retrieval" % ("configs[3] (independent scenes, one per GPU, RCCL all-gather of the graph nodes)" if world > 1 else
+                                                             ("configs[2]" if D == 1024 else "configs[1]"), F, spec.width, spec.height, D, Q)),
                        "frames": F, "queries": Q, "feat_dim": D, "masks": M,
                        "parallelism": ("episode-sharded x%d (frame windows of %d)" % (world, chunk)) if episode else "scene-per-gpu x%d" % world},
             "rccl_ranks": dist.get_world_size() if use_dist else 0,
             "full_graph": bool(args.full_graph and not episode), "graph_counts": state.get("graph_counts"),
+            "graph_counts_all_ranks": state.get("graph_counts_all_ranks"),
             "graph_level": ("C ABI graph object (hmsg_graph_begin / _finish / _index)" if c_graph else "Python mirror") if args.full_graph and not episode else None,
             "graph_ms": state.get("graph_ms"),
             "emulated": bool(emu),

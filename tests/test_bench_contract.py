@@ -44,3 +44,29 @@ def test_bench_line_full_graph_on_the_simulator():
     st = d["stage_ms_per_step"]
     for k in ("add_frames", "finalize_map", "fuse_frames", "merge_instances", "pool_instances", "assemble_graph", "retrieval"):
         assert st[k] >= 0
+
+
+@pytest.mark.skipif(not os.path.exists(PC.EMU_PATH), reason="kernel simulator not built")
+def test_bench_two_ranks_time_the_same_step_on_the_simulator():
+    """`bench.py --gpus 2` (scene per GPU) with two simulator ranks: gloo for the process group, the test-double librccl
+    (tests/rccl_double) under the C-ABI collectives.  Every rank builds its WHOLE graph (the step one GPU times), the node tables are
+    all-gathered by hmsg_allgather_nodes, the levels above them made resident on the global index, and the ranks answer their share
+    of the queries coarse to fine -- the line carries the same graph_counts as the one-GPU line, per rank."""
+    from tests.test_comm_world import _double
+    env = dict(os.environ, HMSG_BENCH_EMU=PC.EMU_PATH, HMSG_RCCL_LIB=_double(), MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29631",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "12", "--queries", "8", "--feat-dim", "16", "--width", "96", "--height", "72",
+           "--scene-shape", "2,1,3.2,2.6,3.0,36,3", "--steps", "1", "--warmup", "0", "--cpu-frames", "0", "--inflight-steps", "0"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["emulated"] is True and d["full_graph"] is True and d["scaling"] == "weak"
+    assert d["graph_level"].startswith("C ABI graph object")
+    assert "configs[3]" in d["config"]["workload"] and d["config"]["parallelism"] == "scene-per-gpu x2"
+    per = d["graph_counts_all_ranks"]
+    assert len(per) == 2 and all(c["floors"] >= 1 and c["rooms"] >= 1 and c["views"] == 12 and c["objects"] >= 3 for c in per)
+    assert d["graph_counts"]["views"] == 12 and d["value"] > 0 and len(d["per_rank_frames_per_s"]) == 2
+    st = d["stage_ms_per_step"]
+    assert "room_level/device" in st and "assemble/graph_finish" in st and st["retrieval"] > 0
