@@ -136,6 +136,75 @@ def test_configs1_full_size_properties(L):
         assert x.shape == y.shape and np.array_equal(x, y)
 
 
+def test_configs2_full_size_d1024_properties_and_retrieval_rate(L):
+    """BASELINE.json configs[2] at FULL size: the same 1000-frame 640x480 scene with 1024-d features (the MFMA embedding x query GEMM
+    path), whole graph behind the C ABI, 1000 coarse-to-fine queries.  Size-independent properties at a size the oracle cannot reach
+    -- frame counters, feature norms, top-k equal to a float64 re-score on the host, graph counts -- and the retrieval RATE: round 4's
+    D = 1024 line answered 40 k queries/s where D = 512 answered 400 k (an 8 MB pageable text table pinned on the fly, 24 ms); the
+    two dimensions must stay within 2x of each other now."""
+    import time
+    import torch
+    import bench
+    from holoagent_amd._lib import Scene, SceneGraph
+    from holoagent_amd.synth import SceneSpec
+    from oracle import hmsg_oracle as O
+    F, M, Q, k = 1000, 32, 1000, 5
+    device = torch.device("cuda", 0)
+    rate, counts = {}, {}
+    for D in (1024, 512):
+        spec = SceneSpec(seed=1234, n_frames=F, feat_dim=D, n_masks=M)
+        inp = bench.build_scene_inputs(L, spec, device, torch)
+        poses = np.ascontiguousarray(inp["pose"], np.float64).reshape(F, 4, 4)
+        sc = Scene(lib_=L, height=spec.height, width=spec.width, max_frames=F, max_masks=M, feat_dim=D)
+        sc.add_frames(inp["rgb"], inp["depth"], inp["pose"], inp["K"])
+        sc.finalize_map()
+        cg = SceneGraph.begin(sc, poses, inp["f_g"].cpu().numpy())
+        sc.add_frame_features(0, inp["masks"], inp["f_g"], inp["f_masked"], inp["f_crop"])
+        sc.fuse_frames()
+        if D == 1024:
+            feats, counter = sc.map_feats(counter=True)
+            nrm = np.linalg.norm(feats, axis=1)
+            assert feats.shape[1] == 1024 and nrm.max() <= 1.0 + 1e-3 and np.all(nrm[counter == 0] == 0) and counter.max() >= 2
+            touched = sum(np.unique(nn[nn >= 0]).size for nn in (sc.frame_nn(f) for f in range(0, F, 25)))
+            assert touched > 0 and int(counter.sum()) >= touched
+        sc.merge_instances()
+        sc.pool_instances()
+        cg.finish()
+        cnt = cg.counts()
+        counts[D] = (cnt["floors"], cnt["rooms"], cnt["views"], cnt["objects"])
+        assert cnt["floors"] == 1 and cnt["rooms"] >= 4 and cnt["views"] == F and cnt["objects"] > 300 and cnt["view_object_links"] > 1000
+        text, _ = inp["scene"].text_table(Q)
+        rng = np.random.Generator(np.random.PCG64(4242))
+        names = rng.standard_normal((cnt["rooms"], D))
+        names /= np.linalg.norm(names, axis=1, keepdims=True)
+        room_text = np.ascontiguousarray(names[rng.integers(0, cnt["rooms"], Q)], np.float32)
+        ix = cg.index(names)
+        zero = np.zeros(Q, np.int32)
+        ix.query_hier(text, zero, room_text, zero, zero + 1, k)                    # (warm: buffers, pinned staging)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            sel, idx, room, score = ix.query_hier(text, zero, room_text, zero, zero + 1, k)
+        rate[D] = 3 * Q / (time.perf_counter() - t0)
+        # top-k bit-exact against a float64 re-score on the host: the objects of the selected rooms in room order, one negative prompt
+        nodes, emb = sc.nodes(embeddings=True)
+        emb = emb.astype(np.float64)
+        node_room = np.array([int(n["room"]) for n in nodes])
+        for q in range(0, Q, 37):
+            cand = np.concatenate([np.nonzero(node_room == r)[0] for r in sel[q]]) if len(sel[q]) else np.zeros(0, np.int64)
+            top, s_ref = O.query_object(text[q], 0, emb[cand], k)
+            assert [int(v) for v in idx[q] if v >= 0] == [int(cand[t]) for t in top], (D, q)
+            np.testing.assert_allclose(score[q][: len(top)], s_ref, rtol=0, atol=1e-12)
+        ix.close()
+        cg.close()
+        sc.close()
+        del inp
+        torch.cuda.empty_cache()
+    print("hierarchical queries / s: D = 1024: %.0f, D = 512: %.0f; graphs (floors, rooms, views, objects): %s" % (rate[1024], rate[512], counts))
+    assert rate[1024] > 1e5, rate                                                   # (round 4's line: 4.0e4)
+    assert rate[1024] * 2 >= rate[512], rate
+
+
 def test_episode_shape_1280x720_three_floors_against_oracle(L):
     """configs[4]'s shape: 1280x720 frames of a three-storey scene (three one-floor scenes stacked 3.4 m apart), 12 frames,
     32 masks -- map, fusion, 3-D masks, sequential merge and pooling stage-wise against the oracle (bit-identical clouds,
