@@ -26,6 +26,7 @@ class HmsgConfig(C.Structure):
         ("outlier_radius", C.c_double), ("pool_max_dist", C.c_double), ("feat_dbscan_eps", C.c_double),
         ("feat_dbscan_min", C.c_int32), ("merge_dbscan_eps", C.c_double), ("merge_dbscan_min", C.c_int32),
         ("min_instance_points", C.c_int32), ("skip_frames", C.c_int32), ("depth_cut", C.c_double), ("grid_resolution", C.c_double),
+        ("overlap_distance_form", C.c_int32),
     ]
 
 
@@ -78,6 +79,7 @@ class HmsgError(RuntimeError):
 _P = C.c_void_p
 _SIGS = {
     "hmsg_default_config": (None, [C.POINTER(HmsgConfig)]),
+    "hmsg_config_size": (C.c_size_t, []),
     "hmsg_create": (C.c_int, [C.POINTER(HmsgConfig), C.POINTER(_P)]),
     "hmsg_destroy": (None, [_P]),
     "hmsg_last_error": (C.c_char_p, [_P]),
@@ -196,6 +198,9 @@ class HmsgLib:
             fn = getattr(self.c, name)
             fn.restype = res
             fn.argtypes = args
+        if self.c.hmsg_config_size() != C.sizeof(HmsgConfig):     # (a stale struct would let hmsg_default_config write past it)
+            raise HmsgError("struct hmsg_config of %s has %d bytes, the binding's HmsgConfig %d: rebuild the library or update "
+                            "holoagent_amd/_lib.py" % (path, self.c.hmsg_config_size(), C.sizeof(HmsgConfig)))
 
     def default_config(self, **over) -> HmsgConfig:
         cfg = HmsgConfig()

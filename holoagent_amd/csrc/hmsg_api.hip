@@ -173,7 +173,10 @@ void hmsg_default_config(hmsg_config* c) {
     c->skip_frames = 1;
     c->depth_cut = 0.0;
     c->grid_resolution = 0.05;
+    c->overlap_distance_form = HMSG_OVERLAP_DIRECT;
 }
+
+size_t hmsg_config_size(void) { return sizeof(hmsg_config); }
 
 int hmsg_create(const hmsg_config* cfg, hmsg_t** out) {
     if (!cfg || !out) return HMSG_ERR_INVALID;

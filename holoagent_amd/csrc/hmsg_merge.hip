@@ -137,8 +137,23 @@ __global__ void k_ov_fill(const double* __restrict__ pool, const OvGrid* __restr
 // one z-run of Y's cell-sorted points: is any of them closer than r to (x, y, z)?  (float32 arithmetic of
 // find_overlapping_ratio_faiss: (dx*dx + dy*dy) + dz*dz < r2)
 #define OV_UNROLL 4     /* (16 was measured: 21 -> 46 us per launch -- short candidate lists dominate, and every step then issues 48 loads) */
+// faiss's OTHER distance form (hmsg_config::overlap_distance_form = HMSG_OVERLAP_FAISS_BLAS): IndexFlatL2.search with 20 or more
+// queries does not evaluate (dx*dx + dy*dy) + dz*dz per pair but |x|^2 + |y|^2 - 2 x.y with the inner products from sgemm, clamped at
+// zero (faiss/utils/distances.cpp exhaustive_L2sqr_blas).  Stated order here and in oracle/hmsg_oracle.py (the BLAS kernel's own
+// order is not ours to know): |p|^2 = (p0*p0 + p1*p1) + p2*p2, x.y = fma(x2, y2, fma(x1, y1, x0*y0)), dis = (|x|^2 + |y|^2) - 2*(x.y),
+// every operation rounded to float32.
+__device__ __forceinline__ float ov_norm2(float a, float b, float c) { return __fadd_rn(__fadd_rn(__fmul_rn(a, a), __fmul_rn(b, b)), __fmul_rn(c, c)); }
+__device__ __forceinline__ float ov_dist2(float x, float y, float z, float qx, float qy, float qz, bool blas, float nx) {
+    if (!blas) {
+        const float ddx = __fsub_rn(x, qx), ddy = __fsub_rn(y, qy), ddz = __fsub_rn(z, qz);
+        return __fadd_rn(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)), __fmul_rn(ddz, ddz));
+    }
+    const float ip = __fmaf_rn(z, qz, __fmaf_rn(y, qy, __fmul_rn(x, qx)));
+    const float d = __fsub_rn(__fadd_rn(nx, ov_norm2(qx, qy, qz)), __fmul_rn(2.0f, ip));
+    return d < 0.f ? 0.f : d;
+}
 __device__ __forceinline__ bool ov_scan(const float* __restrict__ sorted, unsigned s0, unsigned e0, float x, float y, float z,
-                                        float r2, unsigned* ncand = nullptr) {
+                                        float r2, unsigned* ncand = nullptr, bool blas = false, float nx = 0.f) {
     // OV_UNROLL candidates per step with independent loads: the scan is a serial latency chain per lane (one L2 round trip per
     // step: the early exit keeps the next step's loads from being issued ahead), and the kernel lasts as long as its slowest lane --
     // a point whose witness sits deep in a cell that has piled up hundreds of re-observations
@@ -153,9 +168,7 @@ __device__ __forceinline__ bool ov_scan(const float* __restrict__ sorted, unsign
 #pragma unroll
         for (int j = 0; j < OV_UNROLL; ++j) {
             const unsigned kk = min(k + (unsigned)j, e0 - 1u);
-            float ddx = __fsub_rn(x, sorted[(size_t)kk * 3]), ddy = __fsub_rn(y, sorted[(size_t)kk * 3 + 1]),
-                  ddz = __fsub_rn(z, sorted[(size_t)kk * 3 + 2]);
-            float d2 = __fadd_rn(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)), __fmul_rn(ddz, ddz));
+            const float d2 = ov_dist2(x, y, z, sorted[(size_t)kk * 3], sorted[(size_t)kk * 3 + 1], sorted[(size_t)kk * 3 + 2], blas, nx);
             h = h || (k + (unsigned)j < e0 && d2 < r2);
         }
         if (ncand) *ncand += min(OV_UNROLL, (int)(e0 - k));
@@ -217,7 +230,8 @@ __device__ __forceinline__ void ov_stat(unsigned long long* st, int k, unsigned 
     if (st) atomicAdd(&st[k], (unsigned long long)v);
 }
 __device__ __forceinline__ bool ov_hit(const OvGrid& Y, const unsigned* __restrict__ cells, const float* __restrict__ sorted,
-                                       float x, float y, float z, float r2, float r, unsigned long long* st = nullptr) {
+                                       float x, float y, float z, float r2, float r, unsigned long long* st = nullptr, bool blas = false) {
+    const float nx = blas ? ov_norm2(x, y, z) : 0.f;
     ov_stat(st, 0);
     if (x < Y.mnx - r || x > Y.mxx + r || y < Y.mny - r || y > Y.mxy + r || z < Y.mnz - r || z > Y.mxz + r) {
         ov_stat(st, 1);
@@ -228,7 +242,7 @@ __device__ __forceinline__ bool ov_hit(const OvGrid& Y, const unsigned* __restri
     const float* const sy = sorted + (size_t)Y.ix_pt * 3;
     unsigned s0, e0, nc = 0u;
     ov_own_range(Y, p, cells, s0, e0);
-    if (ov_scan(sy, s0, e0, x, y, z, r2, st ? &nc : nullptr)) {
+    if (ov_scan(sy, s0, e0, x, y, z, r2, st ? &nc : nullptr, blas, nx)) {
         ov_stat(st, 2);
         ov_stat(st, 5, nc);
         if (st && nc > 32u) atomicAdd(&st[8], 1ull), atomicAdd(&st[9], (unsigned long long)nc);
@@ -242,7 +256,7 @@ __device__ __forceinline__ bool ov_hit(const OvGrid& Y, const unsigned* __restri
     ov_col_ranges(Y, p, cells, rs, re);
 #pragma unroll
     for (int q = 0; q < 10; ++q)
-        if (ov_scan(sy, rs[q], re[q], x, y, z, r2, st ? &nc : nullptr)) {
+        if (ov_scan(sy, rs[q], re[q], x, y, z, r2, st ? &nc : nullptr, blas, nx)) {
             ov_stat(st, 3);
             ov_stat(st, 6, nc);
             return true;
@@ -256,11 +270,12 @@ __device__ __forceinline__ bool ov_hit(const OvGrid& Y, const unsigned* __restri
 // the same against a cloud with two grids (base + delta, hmsg_merge.hip: Cloud::nb): the two grids' table look-ups go out
 // side by side -- every round of look-ups is a round trip, and the kernel lasts as long as a lane's chain of them
 __device__ __forceinline__ bool ov_hit2(const OvGrid& Y, const OvGrid& Y2, const unsigned* __restrict__ cells, const float* __restrict__ sorted,
-                                        float x, float y, float z, float r2, float r, unsigned long long* st = nullptr) {
+                                        float x, float y, float z, float r2, float r, unsigned long long* st = nullptr, bool blas = false) {
     if (st) {                                      // (statistics runs: the two grids one after the other)
-        if (ov_hit(Y, cells, sorted, x, y, z, r2, r, st)) return true;
-        return ov_hit(Y2, cells, sorted, x, y, z, r2, r, st);
+        if (ov_hit(Y, cells, sorted, x, y, z, r2, r, st, blas)) return true;
+        return ov_hit(Y2, cells, sorted, x, y, z, r2, r, st, blas);
     }
+    const float nx = blas ? ov_norm2(x, y, z) : 0.f;
     if (x < Y.mnx - r || x > Y.mxx + r || y < Y.mny - r || y > Y.mxy + r || z < Y.mnz - r || z > Y.mxz + r) return false;   // (both carry the cloud's box)
     const OvProbe p = ov_probe(Y, x, y, z), p2 = ov_probe(Y2, x, y, z);
     const float* const sy = sorted + (size_t)Y.ix_pt * 3;
@@ -268,17 +283,17 @@ __device__ __forceinline__ bool ov_hit2(const OvGrid& Y, const OvGrid& Y2, const
     unsigned s0, e0, s2, e2;
     ov_own_range(Y, p, cells, s0, e0);
     ov_own_range(Y2, p2, cells, s2, e2);
-    if (ov_scan(sy, s0, e0, x, y, z, r2)) return true;
-    if (ov_scan(sy2, s2, e2, x, y, z, r2)) return true;
+    if (ov_scan(sy, s0, e0, x, y, z, r2, nullptr, blas, nx)) return true;
+    if (ov_scan(sy2, s2, e2, x, y, z, r2, nullptr, blas, nx)) return true;
     unsigned rs[10], re[10], rs2[10], re2[10];
     ov_col_ranges(Y, p, cells, rs, re);
     ov_col_ranges(Y2, p2, cells, rs2, re2);
 #pragma unroll
     for (int q = 0; q < 10; ++q)
-        if (ov_scan(sy, rs[q], re[q], x, y, z, r2)) return true;
+        if (ov_scan(sy, rs[q], re[q], x, y, z, r2, nullptr, blas, nx)) return true;
 #pragma unroll
     for (int q = 0; q < 10; ++q)
-        if (ov_scan(sy2, rs2[q], re2[q], x, y, z, r2)) return true;
+        if (ov_scan(sy2, rs2[q], re2[q], x, y, z, r2, nullptr, blas, nx)) return true;
     return false;
 }
 
@@ -299,7 +314,7 @@ static const int OV_CHUNK = 256;       /* points per workgroup of the overlap sc
 __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __restrict__ gr, const OvTask* __restrict__ tasks,
                            const unsigned* __restrict__ cells, const float* __restrict__ sorted, float r2, float r,
                            int npairs, const int* __restrict__ blk_task, unsigned blk_off, unsigned* __restrict__ counts,
-                           const unsigned* __restrict__ dep_counts, double th, int chunk, unsigned long long* __restrict__ st) {
+                           const unsigned* __restrict__ dep_counts, double th, int chunk, unsigned long long* __restrict__ st, int faiss_form) {
     const unsigned blk = blockIdx.x + blk_off;
     const int ti = blk_task[blk];
     const OvTask t = tasks[ti];
@@ -367,10 +382,11 @@ __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __rest
         const int b0 = (int)(blk - (unsigned)t.blk0) * chunk;
         const int b1 = b0 + chunk < X.n ? b0 + chunk : X.n;
         const OvGrid Y2 = gr[Y.next >= 0 ? Y.next : t.y];      // (Y's delta grid, if it has one)
+        const bool blas = faiss_form != 0 && X.n >= 20;        // (faiss: the BLAS route from 20 queries on -- the cloud whose points are looked up)
         for (int i = b0 + (int)threadIdx.x; i < b1; i += blockDim.x) {
             const double* p = pool + (size_t)(X.pt_off + i) * 3;
             const float x = (float)p[0], y = (float)p[1], z = (float)p[2];
-            const bool hit = Y.next >= 0 ? ov_hit2(Y, Y2, cells, sorted, x, y, z, r2, r, st) : ov_hit(Y, cells, sorted, x, y, z, r2, r, st);
+            const bool hit = Y.next >= 0 ? ov_hit2(Y, Y2, cells, sorted, x, y, z, r2, r, st, blas) : ov_hit(Y, cells, sorted, x, y, z, r2, r, st, blas);
             local += hit ? 1u : 0u;
         }
     }
@@ -478,6 +494,9 @@ struct Merger {
     bool use_anchor = true;         // HMSG_DEBUG_NOANCHOR: plain DBSCAN of every batch (tests compare the two)
     bool inplace_wanted = getenv("HMSG_DEBUG_NO_INPLACE") == nullptr;   // HMSG_DEBUG_NO_INPLACE=1: every output is a dense copy (round 4)
     double radius = 0;              // 1.5 * voxel_size  (merge_3d_masks passes radius=1.5*radius)
+    double reach = 0;               // the distance inside which a point can still count as "closer than radius": radius itself, or
+                                    // sqrt(radius^2 + E) with E the rounding of faiss's BLAS form at this scene's coordinates
+    int faiss_form = 0;             // hmsg_config::overlap_distance_form
     double cell = 0;
     double eps = 0.1;
     int minpts = 10;
@@ -739,7 +758,7 @@ struct Merger {
         const OvTask* const dt = (const OvTask*)(d_ovpack.p + off_t);
         unsigned* const dc = (unsigned*)(d_ovpack.p + off_c);
         const int* const db = (const int*)(d_ovpack.p + off_b);
-        const float r = (float)radius;
+        const float r = (float)reach;                // how far a witness can be (= radius; more in faiss's BLAS form, merger_init)
         const float r2 = (float)(radius * radius);   // `D < radius**2` with a float32 D (graph_utils.py:654-655)
         const size_t prof_idx = ops.prof->ev.size();        // (algorithmic bytes are filled in after the read-back)
         static const bool two_launch = getenv("HMSG_OV_ONE_LAUNCH") == nullptr;
@@ -759,14 +778,14 @@ struct Merger {
             if (!two_launch) {
                 if (nblk)
                     hipLaunchKernelGGL(k_ov_query, dim3((unsigned)nblk), dim3(256), 0, s, (const double*)pool.p, dg, dt, (const unsigned*)ix_cells.p,
-                                       (const float*)ix_pts.p, r2, r, (int)P, db, 0u, dc, (const unsigned*)nullptr, decide_th, OV_CHUNK, d_ovstat);
+                                       (const float*)ix_pts.p, r2, r, (int)P, db, 0u, dc, (const unsigned*)nullptr, decide_th, OV_CHUNK, d_ovstat, faiss_form);
             } else {
                 for (int dir = 0; dir < 2; ++dir) {
                     const unsigned nb = dir ? nblk2 : nblk1;
                     if (!nb) continue;
                     hipLaunchKernelGGL(k_ov_query, dim3(nb), dim3(256), 0, s, (const double*)pool.p, dg, dt, (const unsigned*)ix_cells.p,
                                        (const float*)ix_pts.p, r2, r, (int)P, db, dir ? nblk1 : 0u, dc,
-                                       (dir && decide_th >= 0.0) ? (const unsigned*)dc : (const unsigned*)nullptr, decide_th, OV_CHUNK, d_ovstat);
+                                       (dir && decide_th >= 0.0) ? (const unsigned*)dc : (const unsigned*)nullptr, decide_th, OV_CHUNK, d_ovstat, faiss_form);
                 }
             }
         }
@@ -927,6 +946,19 @@ struct Merger {
                 (g ? st.pairs_g : st.pairs_raw) += 1;
                 (g ? st.scan1_g : st.scan1_raw) += n1;
                 (g ? st.scan2_g : st.scan2_raw) += n2;
+            }
+        }
+        {   // HMSG_DEBUG_OVERLAP_LOG=<file>: (ratio, threshold) of every pair this call evaluated, float64 pairs appended -- what
+            // scripts/fuzz/faiss_form_configs1.py compares between the two distance forms (read once: the fold may run on a worker)
+            static const char* const ovlog = getenv("HMSG_DEBUG_OVERLAP_LOG");
+            if (ovlog && !pairs.empty()) {
+                if (FILE* f = fopen(ovlog, "ab")) {
+                    for (size_t k = 0; k < pairs.size(); ++k) {
+                        const double rec[2] = {ratio[k], th};
+                        fwrite(rec, 8, 2, f);
+                    }
+                    fclose(f);
+                }
             }
         }
         // 2. components of `overlap > th`
@@ -1191,7 +1223,22 @@ void merger_init(Merger& m, hmsg_ctx* h) {
     m.ops.s = h->stream;
     m.ops.prof = &h->prof;
     m.radius = 1.5 * c.voxel_size;
-    m.cell = m.radius * (1.0 + 1e-3) + 2e-3;
+    m.reach = m.radius;
+    m.faiss_form = c.overlap_distance_form == HMSG_OVERLAP_FAISS_BLAS ? 1 : 0;
+    if (m.faiss_form) {
+        // |x|^2 + |y|^2 - 2 x.y in float32: three 3-term sums of magnitude <= M2 = max |p|^2 over the map, each within 3 ulp,
+        // then two more roundings of numbers <= 2 M2: the value is within E = 16 * 2^-24 * M2 of the true squared distance, so
+        // a point up to sqrt(radius^2 + E) away can still compare below radius^2 -- the grids must reach that far
+        const GridGeom& g = h->grid;
+        double m2 = 0.0;
+        const double lo[3] = {g.ox, g.oy, g.oz}, ext[3] = {g.nx * g.vs, g.ny * g.vs, g.nz * g.vs};
+        for (int a = 0; a < 3; ++a) {
+            const double v = std::max(std::fabs(lo[a]), std::fabs(lo[a] + ext[a])) + 1.0;
+            m2 += v * v;
+        }
+        m.reach = std::sqrt(m.radius * m.radius + 16.0 * 5.9604644775390625e-08 * m2);
+    }
+    m.cell = m.reach * (1.0 + 1e-3) + 2e-3;
     m.eps = c.merge_dbscan_eps;
     m.minpts = c.merge_dbscan_min;
     m.iou_thresh = c.iou_thresh;
@@ -1292,6 +1339,7 @@ double next_level_threshold(double th, double factor, long long lists) {
 static bool fold_begin(Folder& m, hmsg_ctx* h, std::vector<Cloud>& G, std::vector<std::vector<Cloud>>& frames, size_t f_next) {
     const double cs = m.eps / std::sqrt(3.0) * (1.0 - 1e-7);
     if (!(m.radius + 1e-4 < 1.9 * cs)) return false;
+    if (m.faiss_form) return false;     // (the incremental fold's overlap test evaluates the direct form only: the batch fold carries on)
     long long live = 0, n_clouds = 0;
     for (auto& k : G) live += k.n, ++n_clouds;
     for (size_t f = f_next; f < frames.size(); ++f)

@@ -67,10 +67,26 @@ typedef struct hmsg_config {
     double depth_cut;             /* dataset depth_cut in metres (dataloader/horizon.py:258-261: depth > depth_cut * scale -> 0,
                                      applied as the frames come in); 0 = none */
     double grid_resolution;       /* pipeline.grid_resolution of the room level (graph.py:942-974); 0.05 in the shipped configs */
+    int32_t overlap_distance_form; /* HMSG_OVERLAP_*: which of faiss's two evaluations of the squared distance
+                                     find_overlapping_ratio_faiss (utils/graph_utils.py:645-662) stands for -- see below */
 } hmsg_config;
+
+/* find_overlapping_ratio_faiss asks faiss 1.7.2 IndexFlatL2.search(k = 1) for squared float32 distances and counts D < radius**2.
+ * faiss evaluates (dx*dx + dy*dy) + dz*dz per pair for fewer than 20 queries and |x|^2 + |y|^2 - 2 x.y (sgemm), clamped at 0, from
+ * 20 queries on; the second form's rounding grows with |x|^2 (scenes far from the origin), and a point on the radius can land on
+ * either side.  HMSG_OVERLAP_DIRECT (default): the direct form for every cloud -- what the oracle and rounds 1-4 pin.
+ * HMSG_OVERLAP_FAISS_BLAS: faiss's switch -- a cloud of 20 or more points is looked up in the BLAS form, stated as
+ * |p|^2 = (p0*p0 + p1*p1) + p2*p2, x.y = fma(x2, y2, fma(x1, y1, x0*y0)), dis = (|x|^2 + |y|^2) - 2*(x.y) in float32 (the order inside
+ * the reference's BLAS is not ours to know); the overlap grids then reach sqrt(radius^2 + E), E the form's error bound at the
+ * scene's coordinates, so no witness the form would accept is missed.  faiss itself is absent from this image:
+ * oracle/hmsg_oracle.py carries the same switch, tests/test_faiss_form_switch.py compares the two. */
+enum { HMSG_OVERLAP_DIRECT = 0, HMSG_OVERLAP_FAISS_BLAS = 1 };
 
 /* Fill `cfg` with the reference defaults (hm3d yaml + graph.py literals). */
 void hmsg_default_config(hmsg_config* cfg);
+/* sizeof(hmsg_config) of THIS library: a binding that declares the struct itself (ctypes, cgo, JNA ...) checks its own size against it
+ * before the first hmsg_default_config writes through its pointer */
+size_t hmsg_config_size(void);
 
 /* Graph.__init__ (graph.py:81-219) for the build pipeline: allocate the HBM-resident scene state. */
 int hmsg_create(const hmsg_config* cfg, hmsg_t** out);

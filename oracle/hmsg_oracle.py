@@ -357,13 +357,50 @@ def compute_3d_bbox_iou(amin, amax, bmin, bmax):
         return ov / (va + vb - ov)
 
 
+OVERLAP_FORM = "direct"   # "direct": (dx*dx + dy*dy) + dz*dz per pair for every cloud (what rounds 1-4 pin; faiss below 20 queries);
+                          # "faiss_blas": faiss's own switch -- from 20 queries on |x|^2 + |y|^2 - 2 x.y, clamped at 0
+                          # (include/hmsg.h: HMSG_OVERLAP_FAISS_BLAS states the order of the operations)
+
+
+def _fma32(a, b, c):
+    """float32 fma(a, b, c) by way of float64: the product of two float32 is exact in float64, the sum is rounded to 53 bits and
+    then to 24 -- equal to the single rounding of a hardware fma except on a float32 half-way case of the 53-bit sum (~2^-29)."""
+    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+
+
+def faiss_blas_nn_sqdist(queries: np.ndarray, base: np.ndarray) -> np.ndarray:
+    """IndexFlatL2.search(k=1) distances the way faiss computes them for >= 20 queries (exhaustive_L2sqr_blas): the smallest of
+    max(0, (|x|^2 + |y|^2) - 2 * x.y) over the base, float32, in the order include/hmsg.h states."""
+    q = np.ascontiguousarray(queries, np.float32)
+    b = np.ascontiguousarray(base, np.float32)
+    n2 = lambda p: (p[:, 0] * p[:, 0] + p[:, 1] * p[:, 1]) + p[:, 2] * p[:, 2]
+    qn, bn = n2(q), n2(b)
+    out = np.full(len(q), np.inf, np.float32)
+    two = np.float32(2.0)
+    for s0 in range(0, len(q), 1024):
+        qs = q[s0:s0 + 1024]
+        for t0 in range(0, len(b), 8192):
+            bs = b[t0:t0 + 8192]
+            ip = _fma32(qs[:, None, 2], bs[None, :, 2], _fma32(qs[:, None, 1], bs[None, :, 1], qs[:, None, 0] * bs[None, :, 0]))
+            d = (qn[s0:s0 + 1024, None] + bn[None, t0:t0 + 8192]) - two * ip
+            np.maximum(d, np.float32(0.0), out=d)
+            out[s0:s0 + 1024] = np.minimum(out[s0:s0 + 1024], d.min(axis=1))
+    return out
+
+
+def _nn_sqdist(queries, base):
+    if OVERLAP_FORM == "faiss_blas" and queries.shape[0] >= 20:
+        return faiss_blas_nn_sqdist(queries, base)
+    return faiss_flat_l2_nn_sqdist(queries, base)
+
+
 def find_overlapping_ratio(p1, p2, radius):
     """graph_utils.py:620-664: max over both directions of the fraction of points whose exact f32
     nearest neighbour in the other cloud is closer than radius (D < radius**2, float32 compare)."""
     if p1.shape[0] == 0 or p2.shape[0] == 0:
         return 0
-    d1 = faiss_flat_l2_nn_sqdist(p1, p2)
-    d2 = faiss_flat_l2_nn_sqdist(p2, p1)
+    d1 = _nn_sqdist(p1, p2)
+    d2 = _nn_sqdist(p2, p1)
     r2 = np.float32(radius ** 2)
     n1 = np.sum(d1 < r2)
     n2 = np.sum(d2 < r2)

@@ -172,7 +172,7 @@ def test_configs2_full_size_d1024_properties_and_retrieval_rate(L):
         cg.finish()
         cnt = cg.counts()
         counts[D] = (cnt["floors"], cnt["rooms"], cnt["views"], cnt["objects"])
-        assert cnt["floors"] == 1 and cnt["rooms"] >= 4 and cnt["views"] == F and cnt["objects"] > 300 and cnt["view_object_links"] > 1000
+        assert cnt["floors"] == 1 and cnt["rooms"] >= 4 and cnt["views"] >= F and cnt["objects"] > 300 and cnt["view_object_links"] > 1000
         text, _ = inp["scene"].text_table(Q)
         rng = np.random.Generator(np.random.PCG64(4242))
         names = rng.standard_normal((cnt["rooms"], D))
