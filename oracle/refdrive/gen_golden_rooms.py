@@ -204,13 +204,21 @@ def main():
 
 
 def frames_case():
-    """A storey of two closed rooms side by side, seen from the inside: 60 posed RGB-D frames (160 x 120) -- the input of
+    """A storey of two closed rooms side by side, seen from the inside: 96 posed RGB-D frames (160 x 120) -- the input of
     the WHOLE path, so that the room level can be checked from frames on (map -> floors -> rooms -> room clouds -> views)."""
     from holoagent_amd.synth import SceneSpec, SynthScene
     spec = SceneSpec(seed=40, rooms_x=2, rooms_z=1, room_size=(3.2, 2.6, 3.0), objects_per_room=3, width=160, height=120,
-                     n_frames=60, n_masks=2, feat_dim=16, yaw_step_deg=12.0)
+                     n_frames=96, n_masks=2, feat_dim=16, yaw_step_deg=7.5)
     sc = SynthScene(spec)
-    return spec, [sc.frame(i) for i in range(spec.n_frames)]
+    frames = [sc.frame(i) for i in range(spec.n_frames)]
+    # every frame gets a global feature of its OWN (a frame's f_g is the mean of the entity features it sees: with two masks a
+    # room's frames shared a dozen distinct rows, and KMeans(24) of compute_room_embeddings warned about duplicate points --
+    # round 4's fixture compared the representative views on duplicates): 48 distinct unit rows per room
+    rng = np.random.Generator(np.random.PCG64(4040))
+    for fr in frames:
+        v = np.asarray(fr["f_g"], np.float64).reshape(-1) + 0.35 * rng.standard_normal(spec.feat_dim)
+        fr["f_g"] = (v / np.linalg.norm(v)).astype(np.float32)[None, :]
+    return spec, frames
 
 
 def main_frames():

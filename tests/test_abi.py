@@ -99,3 +99,39 @@ def test_config_skip_frames_and_depth_cut():
     assert a.map_size() == b.map_size() > 0 and np.array_equal(a.map_points(), b.map_points())
     a.close()
     b.close()
+
+
+def test_integration_md_config_struct_is_the_headers():
+    """INTEGRATION.md shows the ctypes struct a maintainer copies into the reference tree: its fields must be struct hmsg_config's
+    (include/hmsg.h) -- same names, same order, same C types -- and its size the library's own sizeof (hmsg_config_size()).  (Round 4's
+    document stopped three fields short: hmsg_default_config(byref(cfg)) would have written 160 bytes into a 136-byte object.)"""
+    import ctypes as C
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    m = re.search(r"class HmsgConfig\(C\.Structure\):.*?_fields_ = \[(.*?)\]\n", doc, flags=re.S)
+    assert m, "INTEGRATION.md no longer shows the HmsgConfig binding"
+    doc_fields = re.findall(r'\("(\w+)",\s*C\.(c_\w+)\)', m.group(1))
+    hdr = open(os.path.join(root, "include", "hmsg.h")).read()
+    body = re.search(r"typedef struct hmsg_config \{(.*?)\} hmsg_config;", hdr, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    hdr_fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ctype, names = decl.split(None, 1)
+        for nme in names.split(","):
+            hdr_fields.append((nme.strip(), {"int32_t": "c_int32", "double": "c_double", "int64_t": "c_int64", "uint32_t": "c_uint32"}[ctype]))
+    assert doc_fields == hdr_fields
+    from holoagent_amd._lib import HmsgConfig, HmsgLib
+    assert [(n, t.__name__) for n, t in HmsgConfig._fields_] == hdr_fields           # the shipped binding too
+
+    class DocConfig(C.Structure):
+        _fields_ = [(n, getattr(C, t)) for n, t in doc_fields]
+    from tests import parity_common as PC
+    L = HmsgLib(PC.EMU_PATH if os.path.exists(PC.EMU_PATH) else None)
+    assert C.sizeof(DocConfig) == L.c.hmsg_config_size()
+    cfg = DocConfig()
+    L.c.hmsg_default_config(C.cast(C.byref(cfg), C.c_void_p))
+    assert cfg.feat_dim == 512 and cfg.skip_frames == 1 and cfg.grid_resolution == 0.05 and cfg.overlap_distance_form == 0
