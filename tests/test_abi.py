@@ -125,7 +125,7 @@ def test_integration_md_config_struct_is_the_headers():
             hdr_fields.append((nme.strip(), {"int32_t": "c_int32", "double": "c_double", "int64_t": "c_int64", "uint32_t": "c_uint32"}[ctype]))
     assert doc_fields == hdr_fields
     from holoagent_amd._lib import HmsgConfig, HmsgLib
-    assert [(n, t.__name__) for n, t in HmsgConfig._fields_] == hdr_fields           # the shipped binding too
+    assert [(n, t) for n, t in HmsgConfig._fields_] == [(n, getattr(C, t)) for n, t in hdr_fields]     # the shipped binding too
 
     class DocConfig(C.Structure):
         _fields_ = [(n, getattr(C, t)) for n, t in doc_fields]
@@ -133,5 +133,6 @@ def test_integration_md_config_struct_is_the_headers():
     L = HmsgLib(PC.EMU_PATH if os.path.exists(PC.EMU_PATH) else None)
     assert C.sizeof(DocConfig) == L.c.hmsg_config_size()
     cfg = DocConfig()
-    L.c.hmsg_default_config(C.cast(C.byref(cfg), C.c_void_p))
+    raw = C.CDLL(L.path)                                       # (an untyped handle: the document's own struct goes through)
+    raw.hmsg_default_config(C.byref(cfg))
     assert cfg.feat_dim == 512 and cfg.skip_frames == 1 and cfg.grid_resolution == 0.05 and cfg.overlap_distance_form == 0
