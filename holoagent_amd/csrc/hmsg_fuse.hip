@@ -308,20 +308,45 @@ __device__ __forceinline__ MaskRun mask_run(const int* __restrict__ nn, const un
 // per (frame, mask): AABB of the snapped points, number of valid pixels and the sum of their depths.
 // grid = (chunks per frame, frames): a workgroup stays inside one frame, combines in LDS (every run of a mask hits
 // the same eight words) and touches the global table once per mask it met.
+// Round 5: this pass -- the only one that has to look at every pixel -- also writes the chunk's RUNS down, in pixel order: (map
+// voxel << 8 | length) and the mask words, 8 (1 + NW) bytes a run, a chunk's runs at runs[chunk * MCHUNK ...] with their number in
+// run_count[chunk].  k_mmark and k_memit then walk runs (a run covers ~8 pixels) instead of detecting them again from 12 bytes a
+// pixel each: the three passes moved 1.47 + 0.85 + 0.94 GB per 64-frame batch (profiles/r04_pmc_traffic.json).
 __global__ void __launch_bounds__(256) k_mbounds(const int* __restrict__ nn, const unsigned long long* __restrict__ bits,
                                                  const unsigned short* __restrict__ depth, size_t HW, int W, int f0,
                                                  int NW, int MS, const double* __restrict__ pts,
                                                  unsigned long long* __restrict__ bounds /*[nfr*MS][6]*/,
-                                                 unsigned long long* __restrict__ dstat /*[nfr*MS][2]: depth sum, pixels*/) {
+                                                 unsigned long long* __restrict__ dstat /*[nfr*MS][2]: depth sum, pixels*/,
+                                                 unsigned long long* __restrict__ runs, unsigned* __restrict__ run_count) {
     __shared__ unsigned long long s_b[HMSG_MAX_MASKS][8];
+    __shared__ unsigned s_w[4];
+    __shared__ unsigned s_run;
     for (int k = threadIdx.x; k < MS * 8; k += 256) s_b[k >> 3][k & 7] = (k & 7) < 3 ? ~0ull : 0ull;
+    if (threadIdx.x == 0) s_run = 0u;
     __syncthreads();
     const int fl = blockIdx.y;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t chunk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    unsigned long long* const my_runs = runs + chunk * (size_t)MCHUNK * (size_t)(1 + NW);
     for (int it = 0; it < MCHUNK / 256; ++it) {
         const size_t t = (size_t)blockIdx.x * MCHUNK + (size_t)it * 256 + threadIdx.x;
         const bool in_range = t < HW;
         const size_t g = (size_t)(f0 + fl) * HW + (in_range ? t : 0);
         const MaskRun r = mask_run(nn, bits, depth, NW, W, g, in_range, true);
+        {   // the run list: tails in lane order = pixel order
+            const unsigned long long tm = __ballot(r.tail);
+            if (lane == 0) s_w[wv] = (unsigned)__popcll(tm);
+            __syncthreads();
+            unsigned pos = s_run + (unsigned)__popcll(tm & ((1ull << lane) - 1ull));
+            for (int q = 0; q < wv; ++q) pos += s_w[q];
+            if (r.tail) {
+                unsigned long long* rec = my_runs + (size_t)pos * (size_t)(1 + NW);
+                rec[0] = ((unsigned long long)(unsigned)r.v << 8) | (unsigned long long)r.len;
+                for (int w = 0; w < NW; ++w) rec[1 + w] = r.b[w];
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) s_run += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        }
         if (!r.tail) continue;
         unsigned long long e[3] = {enc_f64(pts[(size_t)r.v * 3]), enc_f64(pts[(size_t)r.v * 3 + 1]), enc_f64(pts[(size_t)r.v * 3 + 2])};
         for (int w = 0; w < NW; ++w) {
@@ -348,6 +373,7 @@ __global__ void __launch_bounds__(256) k_mbounds(const int* __restrict__ nn, con
         else if (a < 6) atomicMax(&bounds[m * 6 + a], s_b[i][a]);
         else atomicAdd(&dstat[m * 2 + (a - 6)], s_b[i][a]);
     }
+    if (threadIdx.x == 0) run_count[chunk] = s_run;
 }
 
 __device__ __forceinline__ long long mask_cell(const MaskGeom& mg, double vs, const double* __restrict__ p, int& ix, int& iy,
@@ -358,31 +384,30 @@ __device__ __forceinline__ long long mask_cell(const MaskGeom& mg, double vs, co
     return ((long long)ix * mg.ny + iy) * mg.nz + iz;
 }
 
-// occupancy bitmaps of the per-mask Open3D grids + number of records every chunk will emit
-__global__ void __launch_bounds__(256) k_mmark(const int* __restrict__ nn, const unsigned long long* __restrict__ bits, size_t HW,
-                                               int W, int f0, int NW, int MS, const double* __restrict__ pts,
-                                               const MaskGeom* __restrict__ geom, double vs,
+// occupancy bitmaps of the per-mask Open3D grids + number of records every chunk will emit; one thread per RUN of the chunk's list
+__global__ void __launch_bounds__(256) k_mmark(const unsigned long long* __restrict__ runs, const unsigned* __restrict__ run_count, int NW,
+                                               int MS, const double* __restrict__ pts, const MaskGeom* __restrict__ geom, double vs,
                                                unsigned long long* __restrict__ mbitmap, unsigned* __restrict__ chunk_recs) {
     __shared__ unsigned s_n;
     if (threadIdx.x == 0) s_n = 0u;
     __syncthreads();
     unsigned mine = 0;
     const int fl = blockIdx.y;
-    for (int it = 0; it < MCHUNK / 256; ++it) {
-        const size_t t = (size_t)blockIdx.x * MCHUNK + (size_t)it * 256 + threadIdx.x;
-        const bool in_range = t < HW;
-        const size_t g = (size_t)(f0 + fl) * HW + (in_range ? t : 0);
-        const MaskRun r = mask_run(nn, bits, nullptr, NW, W, g, in_range, false);
-        if (!r.tail) continue;
+    const size_t chunk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned n = run_count[chunk];
+    const unsigned long long* const my_runs = runs + chunk * (size_t)MCHUNK * (size_t)(1 + NW);
+    for (unsigned k = threadIdx.x; k < n; k += 256u) {
+        const unsigned long long* rec = my_runs + (size_t)k * (size_t)(1 + NW);
+        const int v = (int)(rec[0] >> 8);
         for (int w = 0; w < NW; ++w) {
-            unsigned long long b = r.b[w];
+            unsigned long long b = rec[1 + w];
             while (b) {
                 const int i = w * 64 + __ffsll(b) - 1;
                 b &= b - 1;
                 const MaskGeom mg = geom[(size_t)fl * MS + i];
                 if (mg.nx == 0) continue;                       // mask rejected by filter_distance
                 int ix, iy, iz;
-                const long long lin = mask_cell(mg, vs, pts + (size_t)r.v * 3, ix, iy, iz);
+                const long long lin = mask_cell(mg, vs, pts + (size_t)v * 3, ix, iy, iz);
                 unsigned long long* wp = mbitmap + mg.word_off + (lin >> 6);
                 const unsigned long long bit = 1ull << (lin & 63);
                 if (!(*wp & bit)) atomicOr(wp, bit);
@@ -393,38 +418,43 @@ __global__ void __launch_bounds__(256) k_mmark(const int* __restrict__ nn, const
     mine = (unsigned)wave_sum_i32((int)mine);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_n, mine);
     __syncthreads();
-    if (threadIdx.x == 0) chunk_recs[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s_n;
+    if (threadIdx.x == 0) chunk_recs[chunk] = s_n;
 }
 
-// records (key = slot of the mask voxel, value = map voxel << 8 | run length) in pixel order
-__global__ void __launch_bounds__(256) k_memit(const int* __restrict__ nn, const unsigned long long* __restrict__ bits, size_t HW,
-                                               int W, int f0, int NW, int MS, const double* __restrict__ pts,
-                                               const MaskGeom* __restrict__ geom, double vs,
+// records (key = slot of the mask voxel, value = map voxel << 8 | run length) in pixel order = run order, then mask order
+__global__ void __launch_bounds__(256) k_memit(const unsigned long long* __restrict__ runs, const unsigned* __restrict__ run_count, int NW,
+                                               int MS, const double* __restrict__ pts, const MaskGeom* __restrict__ geom, double vs,
                                                const unsigned long long* __restrict__ mbitmap, const unsigned* __restrict__ mrank,
                                                const unsigned* __restrict__ chunk_base, unsigned* __restrict__ keys,
                                                unsigned long long* __restrict__ vals) {
     __shared__ unsigned s_w[4];
     __shared__ unsigned s_run;
-    if (threadIdx.x == 0) s_run = chunk_base[(size_t)blockIdx.y * gridDim.x + blockIdx.x];
+    const size_t chunk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    if (threadIdx.x == 0) s_run = chunk_base[chunk];
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int fl = blockIdx.y;
-    for (int it = 0; it < MCHUNK / 256; ++it) {
-        const size_t t = (size_t)blockIdx.x * MCHUNK + (size_t)it * 256 + threadIdx.x;
-        const bool in_range = t < HW;
-        const size_t g = (size_t)(f0 + fl) * HW + (in_range ? t : 0);
-        const MaskRun r = mask_run(nn, bits, nullptr, NW, W, g, in_range, false);
+    const unsigned n = run_count[chunk];
+    const unsigned long long* const my_runs = runs + chunk * (size_t)MCHUNK * (size_t)(1 + NW);
+    for (unsigned k0 = 0; k0 < n; k0 += 256u) {                 // (workgroup-uniform trip count)
+        const unsigned k = k0 + threadIdx.x;
+        const bool live = k < n;
+        unsigned long long head = 0ull, b4[4] = {0ull, 0ull, 0ull, 0ull};
+        if (live) {
+            const unsigned long long* rec = my_runs + (size_t)k * (size_t)(1 + NW);
+            head = rec[0];
+            for (int w = 0; w < NW; ++w) b4[w] = rec[1 + w];
+        }
         // records of this lane: its masks whose cloud was not rejected
         unsigned nrec = 0;
-        if (r.tail)
-            for (int w = 0; w < NW; ++w) {
-                unsigned long long b = r.b[w];
-                while (b) {
-                    const int i = w * 64 + __ffsll(b) - 1;
-                    b &= b - 1;
-                    nrec += geom[(size_t)fl * MS + i].nx != 0 ? 1u : 0u;
-                }
+        for (int w = 0; w < NW; ++w) {
+            unsigned long long b = b4[w];
+            while (b) {
+                const int i = w * 64 + __ffsll(b) - 1;
+                b &= b - 1;
+                nrec += geom[(size_t)fl * MS + i].nx != 0 ? 1u : 0u;
             }
+        }
         unsigned incl = nrec;                       // inclusive wave scan
         for (int o = 1; o < 64; o <<= 1) {
             unsigned u = __shfl_up(incl, o);
@@ -434,22 +464,24 @@ __global__ void __launch_bounds__(256) k_memit(const int* __restrict__ nn, const
         __syncthreads();
         unsigned pos = s_run + incl - nrec;
         for (int q = 0; q < wv; ++q) pos += s_w[q];
-        if (nrec)
+        if (nrec) {
+            const int v = (int)(head >> 8);
             for (int w = 0; w < NW; ++w) {
-                unsigned long long b = r.b[w];
+                unsigned long long b = b4[w];
                 while (b) {
                     const int i = w * 64 + __ffsll(b) - 1;
                     b &= b - 1;
                     const MaskGeom mg = geom[(size_t)fl * MS + i];
                     if (mg.nx == 0) continue;
                     int ix, iy, iz;
-                    const long long lin = mask_cell(mg, vs, pts + (size_t)r.v * 3, ix, iy, iz);
+                    const long long lin = mask_cell(mg, vs, pts + (size_t)v * 3, ix, iy, iz);
                     const long long wd = mg.word_off + (lin >> 6);
                     keys[pos] = mrank[wd] + (unsigned)__popcll(mbitmap[wd] & ((1ull << (lin & 63)) - 1ull));
-                    vals[pos] = ((unsigned long long)(unsigned)r.v << 8) | (unsigned long long)r.len;
+                    vals[pos] = head;
                     ++pos;
                 }
             }
+        }
         __syncthreads();
         if (threadIdx.x == 0) s_run += s_w[0] + s_w[1] + s_w[2] + s_w[3];
         __syncthreads();
@@ -685,7 +717,8 @@ void hmsg_fuse(hmsg_ctx* h) {
     DevBuf<MaskGeom> d_geom;
     d_geom.alloc((size_t)nmask_max);
     DevBuf<unsigned long long> mbitmap;
-    DevBuf<unsigned> mrank, chunk_recs, rec_off, heavy;
+    DevBuf<unsigned> mrank, chunk_recs, rec_off, heavy, run_count;
+    DevBuf<unsigned long long> runs;                  // the batch's run lists: MCHUNK slots of (1 + NW) words per chunk
     // (HMSG_DEBUG_MWALK_HEAVY: tests push every voxel through the wave-per-voxel replay)
     const unsigned heavy_thr = getenv("HMSG_DEBUG_MWALK_HEAVY") ? (unsigned)atoi(getenv("HMSG_DEBUG_MWALK_HEAVY")) : 32u;
     DevBuf<long long> d_offidx;
@@ -732,11 +765,13 @@ void hmsg_fuse(hmsg_ctx* h) {
             for (int a = 0; a < 6; ++a) hb[(size_t)i * 6 + a] = a < 3 ? ~0ull : 0ull;
         HIP_TRY(hipMemcpyAsync(d_bounds.p, hb.data(), (size_t)nmask * 48, hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemsetAsync(d_dstat.p, 0, (size_t)nmask * 16, s));
+        runs.ensure((size_t)nchunks * MCHUNK * (size_t)(1 + NW));
+        run_count.ensure((size_t)nchunks);
         {
             ProfScope ps(h->prof, s, "k_mbounds", (double)nb * (double)HW * (6.0 + 8.0 * NW));
             hipLaunchKernelGGL(k_mbounds, dim3(cpf, nb), dim3(256), 0, s, (const int*)h->nn.p, (const unsigned long long*)h->bits.p,
                                (const unsigned short*)h->depth.p, HW, W, fb0, NW, MS, (const double*)h->pts.p, d_bounds.p,
-                               d_dstat.p);
+                               d_dstat.p, runs.p, run_count.p);
         }
         HMSG_CHECK_LAUNCH();
         HIP_TRY(hipMemcpyAsync(hb.data(), d_bounds.p, (size_t)nmask * 48, hipMemcpyDeviceToHost, s));
@@ -778,9 +813,8 @@ void hmsg_fuse(hmsg_ctx* h) {
             HIP_TRY(hipMemsetAsync(mbitmap.p, 0, (size_t)nwords * 8, s));
             {
                 ProfScope ps(h->prof, s, "k_mmark", (double)nb * (double)HW * (4.0 + 8.0 * NW));
-                hipLaunchKernelGGL(k_mmark, dim3(cpf, nb), dim3(256), 0, s, (const int*)h->nn.p, (const unsigned long long*)h->bits.p,
-                                   HW, W, fb0, NW, MS, (const double*)h->pts.p, (const MaskGeom*)d_geom.p, c.voxel_size,
-                                   mbitmap.p, chunk_recs.p);
+                hipLaunchKernelGGL(k_mmark, dim3(cpf, nb), dim3(256), 0, s, (const unsigned long long*)runs.p, (const unsigned*)run_count.p, NW,
+                                   MS, (const double*)h->pts.p, (const MaskGeom*)d_geom.p, c.voxel_size, mbitmap.p, chunk_recs.p);
             }
             HMSG_CHECK_LAUNCH();
             npts = (long long)hmsg_bitmap_rank(mbitmap.p, mrank.p, (size_t)nwords, s, h->scan_tmp);
@@ -791,8 +825,8 @@ void hmsg_fuse(hmsg_ctx* h) {
             sb.vals.ensure((size_t)std::max<unsigned long long>(nrec, 1));
             {
                 ProfScope ps(h->prof, s, "k_memit", (double)nb * (double)HW * (4.0 + 8.0 * NW) + (double)nrec * 12.0);
-                hipLaunchKernelGGL(k_memit, dim3(cpf, nb), dim3(256), 0, s, (const int*)h->nn.p, (const unsigned long long*)h->bits.p,
-                                   HW, W, fb0, NW, MS, (const double*)h->pts.p, (const MaskGeom*)d_geom.p, c.voxel_size,
+                hipLaunchKernelGGL(k_memit, dim3(cpf, nb), dim3(256), 0, s, (const unsigned long long*)runs.p, (const unsigned*)run_count.p, NW,
+                                   MS, (const double*)h->pts.p, (const MaskGeom*)d_geom.p, c.voxel_size,
                                    (const unsigned long long*)mbitmap.p, (const unsigned*)mrank.p, (const unsigned*)chunk_recs.p,
                                    sb.keys.p, sb.vals.p);
             }

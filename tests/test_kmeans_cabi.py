@@ -83,3 +83,27 @@ def test_kmeans_rejects_bad_arguments():
     L = _lib()
     with pytest.raises(HmsgError):
         kmeans(np.zeros((3, 4), np.float32), 5, lib_=L)        # fewer rows than clusters (scikit-learn raises too)
+
+
+def test_kmeans_reproduces_the_reference_runs_representative_views():
+    """tests/golden/rooms_frames.npz (round 5: 48 DISTINCT global features per room, so that KMeans(24) of the reference's
+    compute_room_embeddings clusters real points -- round 4's fixture clustered a dozen repeated rows): hmsg_kmeans +
+    hmsg_pick_representative_views on a room's sample images give the representative images the REFERENCE RUN picked with
+    scikit-learn, cluster by cluster; only a two-member cluster may differ (an exact tie that the reference decides inside BLAS)."""
+    from holoagent_amd._lib import kmeans, pick_representative_views
+    L = _lib()
+    z = np.load(os.path.join(GI.GOLDEN, "rooms_frames.npz"))
+    f_g = np.asarray(z["f_g"], np.float32)
+    assert len(np.unique(f_g, axis=0)) == len(f_g)                       # every frame has a feature of its own
+    for r in range(int(z["n_rooms"])):
+        ids, ref = np.asarray(z["sample_%d" % r], np.int64), [int(v) for v in z["represent_%d" % r]]
+        assert len(ids) >= 24 and len(ref) == 24
+        X = np.ascontiguousarray(f_g[ids])
+        labels, centers, _, _ = kmeans(X, 24, lib_=L)
+        sizes = np.bincount(labels, minlength=24)
+        assert (sizes > 0).all()                                         # 24 distinct clusters: no duplicate-point warning in the run
+        got = [int(ids[p]) for p in pick_representative_views(X, labels, centers, lib_=L)]
+        assert len(got) == 24
+        for lab, (g, w) in enumerate(zip(got, ref)):
+            assert g == w or sizes[lab] == 2, (r, lab, g, w, int(sizes[lab]))
+        assert sum(g == w for g, w in zip(got, ref)) >= 24 - int((sizes == 2).sum())
