@@ -143,8 +143,9 @@ __global__ void k_ov_fill(const double* __restrict__ pool, const OvGrid* __restr
 // order is not ours to know): |p|^2 = (p0*p0 + p1*p1) + p2*p2, x.y = fma(x2, y2, fma(x1, y1, x0*y0)), dis = (|x|^2 + |y|^2) - 2*(x.y),
 // every operation rounded to float32.
 __device__ __forceinline__ float ov_norm2(float a, float b, float c) { return __fadd_rn(__fadd_rn(__fmul_rn(a, a), __fmul_rn(b, b)), __fmul_rn(c, c)); }
-__device__ __forceinline__ float ov_dist2(float x, float y, float z, float qx, float qy, float qz, bool blas, float nx) {
-    if (!blas) {
+template <bool BLAS>
+__device__ __forceinline__ float ov_dist2(float x, float y, float z, float qx, float qy, float qz, float nx) {
+    if (!BLAS) {
         const float ddx = __fsub_rn(x, qx), ddy = __fsub_rn(y, qy), ddz = __fsub_rn(z, qz);
         return __fadd_rn(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)), __fmul_rn(ddz, ddz));
     }
@@ -152,8 +153,11 @@ __device__ __forceinline__ float ov_dist2(float x, float y, float z, float qx, f
     const float d = __fsub_rn(__fadd_rn(nx, ov_norm2(qx, qy, qz)), __fmul_rn(2.0f, ip));
     return d < 0.f ? 0.f : d;
 }
+// (BLAS is a template parameter down to the kernel: as a run-time flag in this innermost loop it cost the DEFAULT form 27.6 -> 32.0 us
+//  per launch on the MI355X, profiles/r05_ov_blas_flag.txt)
+template <bool BLAS = false>
 __device__ __forceinline__ bool ov_scan(const float* __restrict__ sorted, unsigned s0, unsigned e0, float x, float y, float z,
-                                        float r2, unsigned* ncand = nullptr, bool blas = false, float nx = 0.f) {
+                                        float r2, unsigned* ncand = nullptr, float nx = 0.f) {
     // OV_UNROLL candidates per step with independent loads: the scan is a serial latency chain per lane (one L2 round trip per
     // step: the early exit keeps the next step's loads from being issued ahead), and the kernel lasts as long as its slowest lane --
     // a point whose witness sits deep in a cell that has piled up hundreds of re-observations
@@ -168,7 +172,7 @@ __device__ __forceinline__ bool ov_scan(const float* __restrict__ sorted, unsign
 #pragma unroll
         for (int j = 0; j < OV_UNROLL; ++j) {
             const unsigned kk = min(k + (unsigned)j, e0 - 1u);
-            const float d2 = ov_dist2(x, y, z, sorted[(size_t)kk * 3], sorted[(size_t)kk * 3 + 1], sorted[(size_t)kk * 3 + 2], blas, nx);
+            const float d2 = ov_dist2<BLAS>(x, y, z, sorted[(size_t)kk * 3], sorted[(size_t)kk * 3 + 1], sorted[(size_t)kk * 3 + 2], nx);
             h = h || (k + (unsigned)j < e0 && d2 < r2);
         }
         if (ncand) *ncand += min(OV_UNROLL, (int)(e0 - k));
@@ -229,9 +233,10 @@ __device__ __forceinline__ void ov_col_ranges(const OvGrid& Y, const OvProbe& p,
 __device__ __forceinline__ void ov_stat(unsigned long long* st, int k, unsigned v = 1u) {
     if (st) atomicAdd(&st[k], (unsigned long long)v);
 }
+template <bool BLAS = false>
 __device__ __forceinline__ bool ov_hit(const OvGrid& Y, const unsigned* __restrict__ cells, const float* __restrict__ sorted,
-                                       float x, float y, float z, float r2, float r, unsigned long long* st = nullptr, bool blas = false) {
-    const float nx = blas ? ov_norm2(x, y, z) : 0.f;
+                                       float x, float y, float z, float r2, float r, unsigned long long* st = nullptr) {
+    const float nx = BLAS ? ov_norm2(x, y, z) : 0.f;
     ov_stat(st, 0);
     if (x < Y.mnx - r || x > Y.mxx + r || y < Y.mny - r || y > Y.mxy + r || z < Y.mnz - r || z > Y.mxz + r) {
         ov_stat(st, 1);
@@ -242,7 +247,7 @@ __device__ __forceinline__ bool ov_hit(const OvGrid& Y, const unsigned* __restri
     const float* const sy = sorted + (size_t)Y.ix_pt * 3;
     unsigned s0, e0, nc = 0u;
     ov_own_range(Y, p, cells, s0, e0);
-    if (ov_scan(sy, s0, e0, x, y, z, r2, st ? &nc : nullptr, blas, nx)) {
+    if (ov_scan<BLAS>(sy, s0, e0, x, y, z, r2, st ? &nc : nullptr, nx)) {
         ov_stat(st, 2);
         ov_stat(st, 5, nc);
         if (st && nc > 32u) atomicAdd(&st[8], 1ull), atomicAdd(&st[9], (unsigned long long)nc);
@@ -256,7 +261,7 @@ __device__ __forceinline__ bool ov_hit(const OvGrid& Y, const unsigned* __restri
     ov_col_ranges(Y, p, cells, rs, re);
 #pragma unroll
     for (int q = 0; q < 10; ++q)
-        if (ov_scan(sy, rs[q], re[q], x, y, z, r2, st ? &nc : nullptr, blas, nx)) {
+        if (ov_scan<BLAS>(sy, rs[q], re[q], x, y, z, r2, st ? &nc : nullptr, nx)) {
             ov_stat(st, 3);
             ov_stat(st, 6, nc);
             return true;
@@ -269,13 +274,14 @@ __device__ __forceinline__ bool ov_hit(const OvGrid& Y, const unsigned* __restri
 }
 // the same against a cloud with two grids (base + delta, hmsg_merge.hip: Cloud::nb): the two grids' table look-ups go out
 // side by side -- every round of look-ups is a round trip, and the kernel lasts as long as a lane's chain of them
+template <bool BLAS = false>
 __device__ __forceinline__ bool ov_hit2(const OvGrid& Y, const OvGrid& Y2, const unsigned* __restrict__ cells, const float* __restrict__ sorted,
-                                        float x, float y, float z, float r2, float r, unsigned long long* st = nullptr, bool blas = false) {
+                                        float x, float y, float z, float r2, float r, unsigned long long* st = nullptr) {
     if (st) {                                      // (statistics runs: the two grids one after the other)
-        if (ov_hit(Y, cells, sorted, x, y, z, r2, r, st, blas)) return true;
-        return ov_hit(Y2, cells, sorted, x, y, z, r2, r, st, blas);
+        if (ov_hit<BLAS>(Y, cells, sorted, x, y, z, r2, r, st)) return true;
+        return ov_hit<BLAS>(Y2, cells, sorted, x, y, z, r2, r, st);
     }
-    const float nx = blas ? ov_norm2(x, y, z) : 0.f;
+    const float nx = BLAS ? ov_norm2(x, y, z) : 0.f;
     if (x < Y.mnx - r || x > Y.mxx + r || y < Y.mny - r || y > Y.mxy + r || z < Y.mnz - r || z > Y.mxz + r) return false;   // (both carry the cloud's box)
     const OvProbe p = ov_probe(Y, x, y, z), p2 = ov_probe(Y2, x, y, z);
     const float* const sy = sorted + (size_t)Y.ix_pt * 3;
@@ -283,17 +289,17 @@ __device__ __forceinline__ bool ov_hit2(const OvGrid& Y, const OvGrid& Y2, const
     unsigned s0, e0, s2, e2;
     ov_own_range(Y, p, cells, s0, e0);
     ov_own_range(Y2, p2, cells, s2, e2);
-    if (ov_scan(sy, s0, e0, x, y, z, r2, nullptr, blas, nx)) return true;
-    if (ov_scan(sy2, s2, e2, x, y, z, r2, nullptr, blas, nx)) return true;
+    if (ov_scan<BLAS>(sy, s0, e0, x, y, z, r2, nullptr, nx)) return true;
+    if (ov_scan<BLAS>(sy2, s2, e2, x, y, z, r2, nullptr, nx)) return true;
     unsigned rs[10], re[10], rs2[10], re2[10];
     ov_col_ranges(Y, p, cells, rs, re);
     ov_col_ranges(Y2, p2, cells, rs2, re2);
 #pragma unroll
     for (int q = 0; q < 10; ++q)
-        if (ov_scan(sy, rs[q], re[q], x, y, z, r2, nullptr, blas, nx)) return true;
+        if (ov_scan<BLAS>(sy, rs[q], re[q], x, y, z, r2, nullptr, nx)) return true;
 #pragma unroll
     for (int q = 0; q < 10; ++q)
-        if (ov_scan(sy2, rs2[q], re2[q], x, y, z, r2, nullptr, blas, nx)) return true;
+        if (ov_scan<BLAS>(sy2, rs2[q], re2[q], x, y, z, r2, nullptr, nx)) return true;
     return false;
 }
 
@@ -311,10 +317,11 @@ static const int OV_CHUNK = 256;       /* points per workgroup of the overlap sc
 // (the kernel is bound by its L2 transactions, not by a lane's chain), so the DEPENDENT form stays the default (dep_counts !=
 // nullptr, blk_off = first workgroup of the launch) and HMSG_OV_ONE_LAUNCH=1 selects the single launch.
 // Decisions are the same either way: max(a, b) > th does not care about b once a > th.
+template <bool BLAS>
 __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __restrict__ gr, const OvTask* __restrict__ tasks,
                            const unsigned* __restrict__ cells, const float* __restrict__ sorted, float r2, float r,
                            int npairs, const int* __restrict__ blk_task, unsigned blk_off, unsigned* __restrict__ counts,
-                           const unsigned* __restrict__ dep_counts, double th, int chunk, unsigned long long* __restrict__ st, int faiss_form) {
+                           const unsigned* __restrict__ dep_counts, double th, int chunk, unsigned long long* __restrict__ st) {
     const unsigned blk = blockIdx.x + blk_off;
     const int ti = blk_task[blk];
     const OvTask t = tasks[ti];
@@ -382,11 +389,13 @@ __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __rest
         const int b0 = (int)(blk - (unsigned)t.blk0) * chunk;
         const int b1 = b0 + chunk < X.n ? b0 + chunk : X.n;
         const OvGrid Y2 = gr[Y.next >= 0 ? Y.next : t.y];      // (Y's delta grid, if it has one)
-        const bool blas = faiss_form != 0 && X.n >= 20;        // (faiss: the BLAS route from 20 queries on -- the cloud whose points are looked up)
+        const bool blas = BLAS && X.n >= 20;                   // (faiss: the BLAS route from 20 queries on -- the cloud whose points are looked up)
         for (int i = b0 + (int)threadIdx.x; i < b1; i += blockDim.x) {
             const double* p = pool + (size_t)(X.pt_off + i) * 3;
             const float x = (float)p[0], y = (float)p[1], z = (float)p[2];
-            const bool hit = Y.next >= 0 ? ov_hit2(Y, Y2, cells, sorted, x, y, z, r2, r, st, blas) : ov_hit(Y, cells, sorted, x, y, z, r2, r, st, blas);
+            bool hit;
+            if (BLAS && blas) hit = Y.next >= 0 ? ov_hit2<true>(Y, Y2, cells, sorted, x, y, z, r2, r, st) : ov_hit<true>(Y, cells, sorted, x, y, z, r2, r, st);
+            else hit = Y.next >= 0 ? ov_hit2<false>(Y, Y2, cells, sorted, x, y, z, r2, r, st) : ov_hit<false>(Y, cells, sorted, x, y, z, r2, r, st);
             local += hit ? 1u : 0u;
         }
     }
@@ -777,15 +786,16 @@ struct Merger {
             ProfScope ps(ops.prof, s, "k_ov_query", 0.0);       // (the kernel launches only: not the read-back below)
             if (!two_launch) {
                 if (nblk)
-                    hipLaunchKernelGGL(k_ov_query, dim3((unsigned)nblk), dim3(256), 0, s, (const double*)pool.p, dg, dt, (const unsigned*)ix_cells.p,
-                                       (const float*)ix_pts.p, r2, r, (int)P, db, 0u, dc, (const unsigned*)nullptr, decide_th, OV_CHUNK, d_ovstat, faiss_form);
+                    hipLaunchKernelGGL(faiss_form ? k_ov_query<true> : k_ov_query<false>, dim3((unsigned)nblk), dim3(256), 0, s, (const double*)pool.p, dg, dt,
+                                       (const unsigned*)ix_cells.p, (const float*)ix_pts.p, r2, r, (int)P, db, 0u, dc, (const unsigned*)nullptr, decide_th, OV_CHUNK,
+                                       d_ovstat);
             } else {
                 for (int dir = 0; dir < 2; ++dir) {
                     const unsigned nb = dir ? nblk2 : nblk1;
                     if (!nb) continue;
-                    hipLaunchKernelGGL(k_ov_query, dim3(nb), dim3(256), 0, s, (const double*)pool.p, dg, dt, (const unsigned*)ix_cells.p,
-                                       (const float*)ix_pts.p, r2, r, (int)P, db, dir ? nblk1 : 0u, dc,
-                                       (dir && decide_th >= 0.0) ? (const unsigned*)dc : (const unsigned*)nullptr, decide_th, OV_CHUNK, d_ovstat, faiss_form);
+                    hipLaunchKernelGGL(faiss_form ? k_ov_query<true> : k_ov_query<false>, dim3(nb), dim3(256), 0, s, (const double*)pool.p, dg, dt,
+                                       (const unsigned*)ix_cells.p, (const float*)ix_pts.p, r2, r, (int)P, db, dir ? nblk1 : 0u, dc,
+                                       (dir && decide_th >= 0.0) ? (const unsigned*)dc : (const unsigned*)nullptr, decide_th, OV_CHUNK, d_ovstat);
                 }
             }
         }

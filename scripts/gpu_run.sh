@@ -24,7 +24,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 tot = 0.0
 for r in rows:
-    n = r['Name'].replace('(anonymous namespace)::', '').split('(')[0]
+    n = r['Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0].split('<')[0]
     if n.startswith(('k_db_', 'k_ov_', 'k_f_', 'k_ix_', 'k_publish', 'k_scan', 'k_concat', 'k_upload', 'k_uf_', '__amd_rocclr_copy')):
         tot += float(r['TotalDurationNs'])
         print("%-26s calls %6s total %8.1f ms avg %8.1f us" % (n[:26], r['Calls'], float(r['TotalDurationNs']) / 1e6, float(r['AverageNs']) / 1e3))
