@@ -46,7 +46,7 @@ __global__ void k_bitset(const unsigned char* __restrict__ masks, int M, size_t 
     const unsigned char* mf = masks + (size_t)f * mask_stride_frame;
     const int nm = min(nmask[f], M);
     unsigned long long* o = bits + ((size_t)f * HW + p0) * NW;
-    for (int w = 0; w < NW; ++w) {
+    _Pragma("unroll") for (int w = 0; w < 4; ++w) if (w < NW) {
         unsigned long long b[16];
         for (int j = 0; j < 16; ++j) b[j] = 0ull;
         const int i0 = w * 64, i1 = min(nm, i0 + 64);
@@ -199,7 +199,7 @@ __global__ void k_fuse(const unsigned* __restrict__ stamp, long long V, int f0, 
         float x[NJ * VEC];
 #pragma unroll
         for (int q = 0; q < NJ * VEC; ++q) x[q] = 0.f;
-        for (int w = 0; w < NW; ++w) {          // masks in index order (sam_clip_feats_extractor.py:183-187)
+        _Pragma("unroll") for (int w = 0; w < 4; ++w) if (w < NW) {          // masks in index order (sam_clip_feats_extractor.py:183-187)
             unsigned long long b = bits[((size_t)f * HW + p) * NW + w];
             while (b) {
                 int i = w * 64 + __ffsll(b) - 1;
@@ -257,6 +257,9 @@ struct MaskGeom {           // per (frame, mask) local Open3D voxel grid of the 
 // A run = consecutive pixels of one image row, inside one 64-pixel wave slice, with the same nearest voxel and
 // the same mask set.  Every mask kernel below re-detects the runs from (nn, bits) with this routine, so they
 // all see the same runs; the lane holding a run's LAST pixel works for the run.
+// (the mask words are indexed by fully unrolled loops only -- `for (w < 4) if (w < NW)` -- so that r.b[] stays in registers: with a
+//  run-time bound the array went to scratch memory, 120 bytes a lane, and k_mbounds wrote 1.1 - 1.5 GB of it per 64-frame batch,
+//  profiles/r05_pmc_traffic.json vs r04)
 struct MaskRun {
     bool tail;              // this lane closes a run that has a voxel and at least one mask
     int v, len;
@@ -277,7 +280,7 @@ __device__ __forceinline__ MaskRun mask_run(const int* __restrict__ nn, const un
     const int x = in_range ? (int)(g % (size_t)W) : 0;
     const int pv = __shfl_up(r.v, 1);                  // (shuffles outside any short-circuit: all lanes take part)
     bool head = lane == 0 || x == 0 || pv != r.v;
-    for (int w = 0; w < NW; ++w) {
+    _Pragma("unroll") for (int w = 0; w < 4; ++w) if (w < NW) {
         const unsigned long long pb = __shfl_up(r.b[w], 1);
         head = head || pb != r.b[w];
     }
@@ -342,14 +345,14 @@ __global__ void __launch_bounds__(256) k_mbounds(const int* __restrict__ nn, con
             if (r.tail) {
                 unsigned long long* rec = my_runs + (size_t)pos * (size_t)(1 + NW);
                 rec[0] = ((unsigned long long)(unsigned)r.v << 8) | (unsigned long long)r.len;
-                for (int w = 0; w < NW; ++w) rec[1 + w] = r.b[w];
+                _Pragma("unroll") for (int w = 0; w < 4; ++w) if (w < NW) rec[1 + w] = r.b[w];
             }
             __syncthreads();
             if (threadIdx.x == 0) s_run += s_w[0] + s_w[1] + s_w[2] + s_w[3];
         }
         if (!r.tail) continue;
         unsigned long long e[3] = {enc_f64(pts[(size_t)r.v * 3]), enc_f64(pts[(size_t)r.v * 3 + 1]), enc_f64(pts[(size_t)r.v * 3 + 2])};
-        for (int w = 0; w < NW; ++w) {
+        _Pragma("unroll") for (int w = 0; w < 4; ++w) if (w < NW) {
             unsigned long long b = r.b[w];
             while (b) {
                 const int i = w * 64 + __ffsll(b) - 1;
@@ -399,7 +402,7 @@ __global__ void __launch_bounds__(256) k_mmark(const unsigned long long* __restr
     for (unsigned k = threadIdx.x; k < n; k += 256u) {
         const unsigned long long* rec = my_runs + (size_t)k * (size_t)(1 + NW);
         const int v = (int)(rec[0] >> 8);
-        for (int w = 0; w < NW; ++w) {
+        _Pragma("unroll") for (int w = 0; w < 4; ++w) if (w < NW) {
             unsigned long long b = rec[1 + w];
             while (b) {
                 const int i = w * 64 + __ffsll(b) - 1;
@@ -443,11 +446,11 @@ __global__ void __launch_bounds__(256) k_memit(const unsigned long long* __restr
         if (live) {
             const unsigned long long* rec = my_runs + (size_t)k * (size_t)(1 + NW);
             head = rec[0];
-            for (int w = 0; w < NW; ++w) b4[w] = rec[1 + w];
+            _Pragma("unroll") for (int w = 0; w < 4; ++w) if (w < NW) b4[w] = rec[1 + w];
         }
         // records of this lane: its masks whose cloud was not rejected
         unsigned nrec = 0;
-        for (int w = 0; w < NW; ++w) {
+        _Pragma("unroll") for (int w = 0; w < 4; ++w) if (w < NW) {
             unsigned long long b = b4[w];
             while (b) {
                 const int i = w * 64 + __ffsll(b) - 1;
@@ -466,7 +469,7 @@ __global__ void __launch_bounds__(256) k_memit(const unsigned long long* __restr
         for (int q = 0; q < wv; ++q) pos += s_w[q];
         if (nrec) {
             const int v = (int)(head >> 8);
-            for (int w = 0; w < NW; ++w) {
+            _Pragma("unroll") for (int w = 0; w < 4; ++w) if (w < NW) {
                 unsigned long long b = b4[w];
                 while (b) {
                     const int i = w * 64 + __ffsll(b) - 1;

@@ -154,7 +154,7 @@ __device__ __forceinline__ float ov_dist2(float x, float y, float z, float qx, f
     return d < 0.f ? 0.f : d;
 }
 // (BLAS is a template parameter down to the kernel: as a run-time flag in this innermost loop it cost the DEFAULT form 27.6 -> 32.0 us
-//  per launch on the MI355X, profiles/r05_ov_blas_flag.txt)
+//  per launch on the MI355X, profiles/r05_ov_experiments.txt)
 template <bool BLAS = false>
 __device__ __forceinline__ bool ov_scan(const float* __restrict__ sorted, unsigned s0, unsigned e0, float x, float y, float z,
                                         float r2, unsigned* ncand = nullptr, float nx = 0.f) {
@@ -233,9 +233,12 @@ __device__ __forceinline__ void ov_col_ranges(const OvGrid& Y, const OvProbe& p,
 __device__ __forceinline__ void ov_stat(unsigned long long* st, int k, unsigned v = 1u) {
     if (st) atomicAdd(&st[k], (unsigned long long)v);
 }
-template <bool BLAS = false>
+// (STATS, like BLAS, is a template parameter: the statistics' candidate counter has its address taken, and with a run-time `st` the
+//  default kernel carried 8 bytes of scratch per lane for it)
+template <bool BLAS = false, bool STATS = false>
 __device__ __forceinline__ bool ov_hit(const OvGrid& Y, const unsigned* __restrict__ cells, const float* __restrict__ sorted,
-                                       float x, float y, float z, float r2, float r, unsigned long long* st = nullptr) {
+                                       float x, float y, float z, float r2, float r, unsigned long long* st_in = nullptr) {
+    unsigned long long* const st = STATS ? st_in : nullptr;
     const float nx = BLAS ? ov_norm2(x, y, z) : 0.f;
     ov_stat(st, 0);
     if (x < Y.mnx - r || x > Y.mxx + r || y < Y.mny - r || y > Y.mxy + r || z < Y.mnz - r || z > Y.mxz + r) {
@@ -247,7 +250,7 @@ __device__ __forceinline__ bool ov_hit(const OvGrid& Y, const unsigned* __restri
     const float* const sy = sorted + (size_t)Y.ix_pt * 3;
     unsigned s0, e0, nc = 0u;
     ov_own_range(Y, p, cells, s0, e0);
-    if (ov_scan<BLAS>(sy, s0, e0, x, y, z, r2, st ? &nc : nullptr, nx)) {
+    if (ov_scan<BLAS>(sy, s0, e0, x, y, z, r2, STATS ? &nc : nullptr, nx)) {
         ov_stat(st, 2);
         ov_stat(st, 5, nc);
         if (st && nc > 32u) atomicAdd(&st[8], 1ull), atomicAdd(&st[9], (unsigned long long)nc);
@@ -261,7 +264,7 @@ __device__ __forceinline__ bool ov_hit(const OvGrid& Y, const unsigned* __restri
     ov_col_ranges(Y, p, cells, rs, re);
 #pragma unroll
     for (int q = 0; q < 10; ++q)
-        if (ov_scan<BLAS>(sy, rs[q], re[q], x, y, z, r2, st ? &nc : nullptr, nx)) {
+        if (ov_scan<BLAS>(sy, rs[q], re[q], x, y, z, r2, STATS ? &nc : nullptr, nx)) {
             ov_stat(st, 3);
             ov_stat(st, 6, nc);
             return true;
@@ -274,12 +277,12 @@ __device__ __forceinline__ bool ov_hit(const OvGrid& Y, const unsigned* __restri
 }
 // the same against a cloud with two grids (base + delta, hmsg_merge.hip: Cloud::nb): the two grids' table look-ups go out
 // side by side -- every round of look-ups is a round trip, and the kernel lasts as long as a lane's chain of them
-template <bool BLAS = false>
+template <bool BLAS = false, bool STATS = false>
 __device__ __forceinline__ bool ov_hit2(const OvGrid& Y, const OvGrid& Y2, const unsigned* __restrict__ cells, const float* __restrict__ sorted,
                                         float x, float y, float z, float r2, float r, unsigned long long* st = nullptr) {
-    if (st) {                                      // (statistics runs: the two grids one after the other)
-        if (ov_hit<BLAS>(Y, cells, sorted, x, y, z, r2, r, st)) return true;
-        return ov_hit<BLAS>(Y2, cells, sorted, x, y, z, r2, r, st);
+    if (STATS) {                                   // (statistics runs: the two grids one after the other)
+        if (ov_hit<BLAS, STATS>(Y, cells, sorted, x, y, z, r2, r, st)) return true;
+        return ov_hit<BLAS, STATS>(Y2, cells, sorted, x, y, z, r2, r, st);
     }
     const float nx = BLAS ? ov_norm2(x, y, z) : 0.f;
     if (x < Y.mnx - r || x > Y.mxx + r || y < Y.mny - r || y > Y.mxy + r || z < Y.mnz - r || z > Y.mxz + r) return false;   // (both carry the cloud's box)
@@ -317,7 +320,7 @@ static const int OV_CHUNK = 256;       /* points per workgroup of the overlap sc
 // (the kernel is bound by its L2 transactions, not by a lane's chain), so the DEPENDENT form stays the default (dep_counts !=
 // nullptr, blk_off = first workgroup of the launch) and HMSG_OV_ONE_LAUNCH=1 selects the single launch.
 // Decisions are the same either way: max(a, b) > th does not care about b once a > th.
-template <bool BLAS>
+template <bool BLAS, bool STATS>
 __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __restrict__ gr, const OvTask* __restrict__ tasks,
                            const unsigned* __restrict__ cells, const float* __restrict__ sorted, float r2, float r,
                            int npairs, const int* __restrict__ blk_task, unsigned blk_off, unsigned* __restrict__ counts,
@@ -394,8 +397,8 @@ __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __rest
             const double* p = pool + (size_t)(X.pt_off + i) * 3;
             const float x = (float)p[0], y = (float)p[1], z = (float)p[2];
             bool hit;
-            if (BLAS && blas) hit = Y.next >= 0 ? ov_hit2<true>(Y, Y2, cells, sorted, x, y, z, r2, r, st) : ov_hit<true>(Y, cells, sorted, x, y, z, r2, r, st);
-            else hit = Y.next >= 0 ? ov_hit2<false>(Y, Y2, cells, sorted, x, y, z, r2, r, st) : ov_hit<false>(Y, cells, sorted, x, y, z, r2, r, st);
+            if (BLAS && blas) hit = Y.next >= 0 ? ov_hit2<true, STATS>(Y, Y2, cells, sorted, x, y, z, r2, r, st) : ov_hit<true, STATS>(Y, cells, sorted, x, y, z, r2, r, st);
+            else hit = Y.next >= 0 ? ov_hit2<false, STATS>(Y, Y2, cells, sorted, x, y, z, r2, r, st) : ov_hit<false, STATS>(Y, cells, sorted, x, y, z, r2, r, st);
             local += hit ? 1u : 0u;
         }
     }
@@ -782,18 +785,20 @@ struct Merger {
             }
             d_ovstat = ovstat.p;
         }
+        auto* const ovk = d_ovstat ? (faiss_form ? k_ov_query<true, true> : k_ov_query<false, true>)
+                                   : (faiss_form ? k_ov_query<true, false> : k_ov_query<false, false>);
         {
             ProfScope ps(ops.prof, s, "k_ov_query", 0.0);       // (the kernel launches only: not the read-back below)
             if (!two_launch) {
                 if (nblk)
-                    hipLaunchKernelGGL(faiss_form ? k_ov_query<true> : k_ov_query<false>, dim3((unsigned)nblk), dim3(256), 0, s, (const double*)pool.p, dg, dt,
+                    hipLaunchKernelGGL(ovk, dim3((unsigned)nblk), dim3(256), 0, s, (const double*)pool.p, dg, dt,
                                        (const unsigned*)ix_cells.p, (const float*)ix_pts.p, r2, r, (int)P, db, 0u, dc, (const unsigned*)nullptr, decide_th, OV_CHUNK,
                                        d_ovstat);
             } else {
                 for (int dir = 0; dir < 2; ++dir) {
                     const unsigned nb = dir ? nblk2 : nblk1;
                     if (!nb) continue;
-                    hipLaunchKernelGGL(faiss_form ? k_ov_query<true> : k_ov_query<false>, dim3(nb), dim3(256), 0, s, (const double*)pool.p, dg, dt,
+                    hipLaunchKernelGGL(ovk, dim3(nb), dim3(256), 0, s, (const double*)pool.p, dg, dt,
                                        (const unsigned*)ix_cells.p, (const float*)ix_pts.p, r2, r, (int)P, db, dir ? nblk1 : 0u, dc,
                                        (dir && decide_th >= 0.0) ? (const unsigned*)dc : (const unsigned*)nullptr, decide_th, OV_CHUNK, d_ovstat);
                 }
