@@ -793,6 +793,19 @@ def main():
                              "; --cpu-frames 100 (the default) runs BASELINE.json configs[0] in full"),
                    threading=threading_note, seconds=round(t_cpu, 2))
 
+    mfma_util = None
+    try:
+        import glob
+        mp = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_mfma.json")))[-1]
+        mk = json.load(open(mp))["kernels"]
+        mfma_util = {"source": "profiles/%s (offline PMC passes, same command)" % os.path.basename(mp)}
+        for name, key in (("k_pool_gram", "k_pool_gram"), ("k_gemm_f64", "k_gemm_f64_tiled")):
+            if key in mk and "MfmaUtil_percent" in mk[key]:
+                mfma_util[name] = {"MfmaUtil_percent": round(mk[key]["MfmaUtil_percent"], 2),
+                                   "SQ_VALU_MFMA_BUSY_CYCLES": mk[key]["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_launch"],
+                                   "GRBM_GUI_ACTIVE": mk[key]["GRBM_GUI_ACTIVE"]["mean_per_launch"]}
+    except Exception:
+        mfma_util = None
     if rank == 0:
         last = state.get("last")
         out = {
@@ -838,6 +851,9 @@ def main():
             "kernels_achieved": {k_: [round(v[2] / (v[1] * 1e-3) / (1e12 if k_ in MFMA_KERNELS else 1e9), 2),
                                       "TFLOP/s" if k_ in MFMA_KERNELS else "GB/s"]
                                  for k_, v in sorted(prof.items(), key=lambda kv: -kv[1][1]) if v[1] > 0},
+            # MFMA utilisation of the two matrix-core kernels from the PMC passes committed under profiles/ (rocprofv3 --pmc
+            # SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE ..., one counter per pass over this same command: scripts/gpu_run.sh mfma)
+            "mfma_utilisation": mfma_util,
             "scenes_in_flight": inflight,
             "encoder_handoff": handoff,
             "rooms_handed_in": handed_in,

@@ -3,15 +3,17 @@
 
 MfmaUtil is the gfx94x derived-counter formula (ROCm 7.2 ships no gfx950 section, MI355X_MICROARCH.md "rocprofv3 PMC slots"):
     100 * SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * CUs * 4 SIMDs)
-and, beside it, the share of the shader-busy time SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES * CUs / SEs...) is NOT derived here:
-SQ_BUSY_CYCLES is reported raw (its aggregation over shader engines differs between ROCm releases).  MOPS counters are in units of
-512 FLOP-equivalents ("MOPS" = 512 ops) per the gfx9 counter descriptions; raw values are kept so the reader can re-derive."""
+with one correction for this chip: rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs (for k_pool_gram it is 8.6 x the kernel's
+duration x 2.1 GHz, and SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 FLOP reproduces the kernel's FLOP count to 2 %), so the elapsed cycles
+of ONE clock domain are GRBM_GUI_ACTIVE / 8:
+    MfmaUtil = 100 * SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 256 CUs * 4 SIMDs)
+The uncorrected gfx94x figure is kept beside it.  SQ_BUSY_CYCLES and the MOPS counters are reported raw."""
 import json
 import os
 import sys
 
 d, out = sys.argv[1], sys.argv[2]
-CUS, SIMDS = 256, 4
+CUS, SIMDS, XCDS = 256, 4, 8
 counters = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_VALU_MFMA_MOPS_F64", "GRBM_GUI_ACTIVE"]
 data = {}
 for c in counters:
@@ -31,8 +33,9 @@ for kern in sorted({k for v in data.values() for k in v}):
     gui = row.get("GRBM_GUI_ACTIVE", {}).get("mean_per_launch")
     if busy and gui:
         row["MfmaUtil_percent_gfx94x_formula"] = 100.0 * busy / (gui * CUS * SIMDS)
+        row["MfmaUtil_percent"] = 100.0 * busy / (gui / XCDS * CUS * SIMDS)
     res[kern] = row
 json.dump(dict(note="rocprofv3 --kernel-trace --pmc <one counter per pass> over python bench.py --steps 1 --warmup 0 --no-extras; "
-                    "MfmaUtil = 100 * SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs) (gfx94x derived formula)",
+                    "MfmaUtil = 100 * SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 256 CUs * 4 SIMDs); the uncorrected gfx94x formula beside it",
                kernels=res), open(out, "w"), indent=1)
 print(json.dumps(res, indent=1)[:2000])

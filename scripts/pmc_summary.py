@@ -5,6 +5,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 with open(path) as f:
     for r in csv.DictReader(f):
         name = r.get("Kernel_Name", r.get("Kernel Name", "?")).split("(")[0]
+        name = name.replace("void ", "").split("<")[0].strip()          # k_ov_query<false, false> -> k_ov_query
         a = acc[name][r["Counter_Name"]]
         a[0] += 1
         a[1] += float(r["Counter_Value"])
