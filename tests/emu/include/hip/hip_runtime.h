@@ -25,6 +25,9 @@ using std::max;
 using std::min;
 
 #define HMSG_EMU_BUILD 1
+#ifndef __HIP_MEMORY_SCOPE_WORKGROUP
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
+#endif
 #ifndef __HIP_MEMORY_SCOPE_AGENT
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #endif
@@ -53,6 +56,7 @@ struct int2 { int x, y; };
 struct int4 { int x, y, z, w; };
 static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
 static inline uint2 make_uint2(unsigned a, unsigned b) { return uint2{a, b}; }
+static inline int2 make_int2(int a, int b) { return int2{a, b}; }
 
 static inline double hipemu_now();
 namespace hipemu {
