@@ -351,10 +351,14 @@ def main():
             return g
         T("add_frames", lambda: sc.add_frames(inp["rgb"], inp["depth"], inp["pose"], inp["K"]))
         T("finalize_map", sc.finalize_map)
-        # (placement: right after the map -- measured on the MI355X: started after hmsg_fuse_frames instead, i.e. beside the
-        #  merge fold that runs on its worker thread, the room level's launches and the fold's short kernels get in each other's
-        #  way: room level 53 -> 92 ms, fold phases up to 2x slower, 620 -> 630 ms per step.  HMSG_BENCH_ROOMS_BESIDE_FOLD=1 keeps that order.)
-        beside_fold = bool(os.environ.get("HMSG_BENCH_ROOMS_BESIDE_FOLD"))
+        # Placement of the room level (floors, regions, room clouds, camera -> room table on the device; KMeans on the library's host
+        # threads): AFTER hmsg_fuse_frames, i.e. beside the merge fold, which runs on its worker thread and stream and leaves the chip
+        # almost idle between its short launches -- the room level's 20 ms of kernels run in those gaps.  Measured on the MI355X,
+        # alternating runs of 5 steps on one box (profiles/r05_rooms_beside_fold.txt): 503.8 / 496.5 ms per step with the room level
+        # in front of the fusion, 481.2 / 492.2 ms beside the fold (room level 20 -> 22 ms, the rest of the fold 299 -> 284 ms).
+        # Round 4 measured the opposite (620 -> 630 ms) when the room level was 53 ms of long ring searches; its kernels are short
+        # now.  HMSG_BENCH_ROOMS_BEFORE_FUSE=1 keeps the old order.
+        beside_fold = not os.environ.get("HMSG_BENCH_ROOMS_BEFORE_FUSE")
         if args.full_graph and not beside_fold:
             g_early = T("room_level/device", room_level)
         T("add_frame_features", lambda: sc.add_frame_features(0, inp["masks"], inp["f_g"], inp["f_masked"], inp["f_crop"]))
@@ -599,8 +603,9 @@ def main():
             pmc = json.load(open(pmc_path))["kernels"]
             key = {"k_db_union/box": "k_db_union", "k_db_union/scan": "k_db_union_scan"}.get(roof["kernel"], roof["kernel"])
             if key in pmc:
-                # (a timed "launch" of k_ov_query is the pair of launches of one fold step: scale by the dispatch counts)
-                per = max(1.0, pmc[key]["dispatches"] / max(roof["launches"], 1)) if key == "k_ov_query" else 1.0
+                # (a timed "launch" of k_ov_query is the pair of launches of one fold step; the PMC passes run ONE step of the same
+                #  scene, this run args.steps of them: scale by dispatches per step / timed launches per step)
+                per = max(1.0, round(pmc[key]["dispatches"] / max(roof["launches"] / max(args.steps, 1), 1))) if key == "k_ov_query" else 1.0
                 roof["traffic"] = int(pmc[key]["hbm_bytes_per_launch"] * per)
                 roof["traffic_source"] = "profiles/%s (offline PMC passes, same command)" % os.path.basename(pmc_path)
         except Exception:
