@@ -604,8 +604,8 @@ def main():
             key = {"k_db_union/box": "k_db_union", "k_db_union/scan": "k_db_union_scan"}.get(roof["kernel"], roof["kernel"])
             if key in pmc:
                 # (a timed "launch" of k_ov_query is the pair of launches of one fold step; the PMC passes run ONE step of the same
-                #  scene, this run args.steps of them: scale by dispatches per step / timed launches per step)
-                per = max(1.0, round(pmc[key]["dispatches"] / max(roof["launches"] / max(args.steps, 1), 1))) if key == "k_ov_query" else 1.0
+                #  scene and roof["launches"] counts the LAST step's timed launches: dispatches per timed launch)
+                per = max(1.0, round(pmc[key]["dispatches"] / max(roof["launches"], 1))) if key == "k_ov_query" else 1.0
                 roof["traffic"] = int(pmc[key]["hbm_bytes_per_launch"] * per)
                 roof["traffic_source"] = "profiles/%s (offline PMC passes, same command)" % os.path.basename(pmc_path)
         except Exception:
