@@ -211,3 +211,42 @@ def test_cropped_anchor_members_on_the_simulator(capfd):
     err2 = capfd.readouterr().err
     assert re.search(r" 0 of them in place", err2), err2
     assert len(dense) == len(ref) and all(np.array_equal(a, b) for a, b in zip(dense, ref)) and np.array_equal(dense_f, ref_f)
+
+
+_SPLIT_SNIPPET = """
+import sys, json
+sys.path.insert(0, {root!r})
+from tests import parity_common as PC
+from tests.test_fold_pipeline import _host_scene, _digest
+from holoagent_amd._lib import HmsgLib
+from holoagent_amd.synth import SceneSpec, SynthScene
+L = HmsgLib(PC.EMU_PATH)
+spec = SceneSpec(seed=21, rooms_x=1, rooms_z=1, room_size=(3.6, 2.5, 3.2), objects_per_room=4, width=64, height=48,
+                 n_frames=8, n_masks=5, feat_dim=16)
+scn = SynthScene(spec)
+frames = [scn.frame(i) for i in range(spec.n_frames)]
+inst, feats = _host_scene(L, frames, 16, nopipe=True)
+import hashlib
+print("DIGEST", json.dumps([list(_digest(inst)), hashlib.sha1(feats.tobytes()).hexdigest()]))
+"""
+
+
+@pytest.mark.skipif(not os.path.exists(PC.EMU_PATH), reason="kernel simulator not built")
+def test_three_launch_compaction_equals_the_fused_one_on_the_simulator():
+    """HMSG_DB_COMPACT_SPLIT=1 (keep flags, scan and scatter as three launches: the form before round 4, kept for comparison runs)
+    is read ONCE per process and decides both the compaction kernels and whether anchor members may be cropped / extended in place
+    (the legacy kernels know neither).  Two processes, the switch on and off, same scene: same instances, same pooled features."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for split in (False, True):
+        env = dict(os.environ)
+        env.pop("HMSG_DB_COMPACT_SPLIT", None)
+        if split:
+            env["HMSG_DB_COMPACT_SPLIT"] = "1"
+        r = subprocess.run([sys.executable, "-c", _SPLIT_SNIPPET.format(root=root)], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout + r.stderr
+        out.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1][7:]))
+    assert out[0] == out[1] and out[0][0][0] >= 3, out
