@@ -218,28 +218,53 @@ __global__ void k_pool_init(const unsigned* __restrict__ ncount, long long N, in
 }
 __global__ void k_pool_prop(const unsigned* __restrict__ adj, const PoolSeg* __restrict__ segs, const int* __restrict__ seg_of_row,
                             const unsigned* __restrict__ ncount, int minpts, long long N, int* __restrict__ label,
-                            int* __restrict__ changed, const int* __restrict__ seg_first) {
+                            int* __restrict__ changed, const int* __restrict__ seg_first, int first_round) {
     const int lane = threadIdx.x & 63;
     const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (i >= N) return;
     if (ncount[i] < (unsigned)minpts) return;                 // wave-uniform
     const int k = seg_of_row[i];
     int best = label[i];
-    if (best == seg_first[k]) return;                         // already at the instance's lowest core row (wave-uniform)
+    const int lowest = seg_first[k];
+    if (best == lowest) return;                               // already at the instance's lowest core row (wave-uniform)
     const PoolSeg sg = segs[k];
     const unsigned* row = adj + sg.bit_base + (size_t)(i - sg.row_base) * sg.nw;
-    for (int w = lane; w < sg.nw; w += 64) {
-        unsigned bits = row[w];
-        while (bits) {
-            int b = __ffs(bits) - 1;
-            bits &= bits - 1;
-            long long j = sg.row_base + (long long)w * 32 + b;
-            if (ncount[j] >= (unsigned)minpts) {
-                // plain (L1-cacheable) load: a stale label is an older, larger one -- it only delays the drop to
-                // a later launch, and the host loop runs until a whole round changes nothing
-                const int lj = label[j];
-                best = lj < best ? lj : best;
+    if (first_round) {
+        // Every core row still carries its own index (k_pool_init), and a lane meets its columns in rising order: the first core
+        // neighbour it finds is its smallest label, and columns at or beyond the row's own label cannot lower it.
+        for (int w = lane; w < sg.nw; w += 64) {
+            unsigned bits = row[w];
+            bool found = false;
+            while (bits && !found) {
+                const int b = __ffs(bits) - 1;
+                bits &= bits - 1;
+                const int jr = w * 32 + b;
+                if (jr >= best) {
+                    found = true;
+                } else if (ncount[sg.row_base + jr] >= (unsigned)minpts) {
+                    best = jr;
+                    found = true;
+                }
             }
+            if (found) break;
+        }
+    } else {
+        // later rounds: a row is done as soon as ONE neighbour carries the instance's lowest core row -- nothing is lower
+        for (int w0 = 0; w0 < sg.nw; w0 += 64) {
+            const int w = w0 + lane;
+            unsigned bits = w < sg.nw ? row[w] : 0u;
+            while (bits && best != lowest) {
+                int b = __ffs(bits) - 1;
+                bits &= bits - 1;
+                long long j = sg.row_base + (long long)w * 32 + b;
+                if (ncount[j] >= (unsigned)minpts) {
+                    // plain (L1-cacheable) load: a stale label is an older, larger one -- it only delays the drop to
+                    // a later launch, and the host loop runs until a whole round changes nothing
+                    const int lj = label[j];
+                    best = lj < best ? lj : best;
+                }
+            }
+            if (__any(best == lowest)) break;
         }
     }
     for (int o = 32; o > 0; o >>= 1) {
@@ -484,7 +509,7 @@ void hmsg_pool(hmsg_ctx* h) {
             for (int rep = 0; rep < 2; ++rep) {
                 hipLaunchKernelGGL(k_pool_prop, dim3(cdiv((size_t)R * 64, 256)), dim3(256), 0, s, (const unsigned*)adj.p,
                                    (const PoolSeg*)d_ps.p, (const int*)seg_of_row.p, (const unsigned*)ncount.p,
-                                   c.feat_dbscan_min, (long long)R, label.p, d_changed.p, (const int*)seg_first.p);
+                                   c.feat_dbscan_min, (long long)R, label.p, d_changed.p, (const int*)seg_first.p, (it == 0 && rep == 0) ? 1 : 0);
                 hipLaunchKernelGGL(k_pool_jump, dim3(cdiv((size_t)R, 256)), dim3(256), 0, s, (const PoolSeg*)d_ps.p,
                                    (const int*)seg_of_row.p, (const unsigned*)ncount.p, c.feat_dbscan_min, (long long)R, label.p);
             }
