@@ -506,7 +506,9 @@ void hmsg_pool(hmsg_ctx* h) {
         HMSG_CHECK_LAUNCH();
         for (int it = 0; it < 100000; ++it) {
             HIP_TRY(hipMemsetAsync(d_changed.p, 0, 4, s));
-            for (int rep = 0; rep < 2; ++rep) {
+            // (two rounds before the first look at the flag -- the first one is cheap and always changes something --, then one round
+            //  per look: a round over rows that no longer change costs 1.2 ms, a look 20 us)
+            for (int rep = 0; rep < (it == 0 ? 2 : 1); ++rep) {
                 hipLaunchKernelGGL(k_pool_prop, dim3(cdiv((size_t)R * 64, 256)), dim3(256), 0, s, (const unsigned*)adj.p,
                                    (const PoolSeg*)d_ps.p, (const int*)seg_of_row.p, (const unsigned*)ncount.p,
                                    c.feat_dbscan_min, (long long)R, label.p, d_changed.p, (const int*)seg_first.p, (it == 0 && rep == 0) ? 1 : 0);
