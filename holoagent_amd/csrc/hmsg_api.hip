@@ -93,6 +93,9 @@ int guard(hmsg_ctx* h, F&& fn) {
     } catch (const std::exception& e) {
         if (h) h->err = e.what();
         return HMSG_ERR_INVALID;
+    } catch (...) {      // nothing may cross the C boundary
+        if (h) h->err = "unknown error";
+        return HMSG_ERR_INVALID;
     }
 }
 

@@ -78,18 +78,17 @@ struct CloudOps {
     // work counters of the DBSCAN batches (debug output of the merge stage)
     double stat_inplace = 0;                            // ... of them run in place (SegDesc::out_mode 2)
     double stat_forced = 0, stat_forced_first = 0;     // segments binned with their anchor member cropped, and those members' points
-    double stat_calls = 0, stat_points = 0, stat_cells = 0, stat_core_cells = 0, stat_active_cells = 0, stat_maxcell_sum = 0, stat_maxcell_max = 0;
+    double stat_calls = 0, stat_points = 0, stat_cells = 0, stat_core_cells = 0, stat_needy = 0, stat_maxcell_sum = 0, stat_maxcell_max = 0;
     DevBuf<unsigned> scan_tmp;
     // scratch (grown on demand)
     DevBuf<unsigned> cnt, start, cursor, ord, minidx, firstidx, size, flags, pos, rootmin;
-    DevBuf<int> parent, label, segid, cellpos, corelist, cseg;
+    DevBuf<int> parent, label, segid, cellpos, corelist, cseg, roots, rhead, rnext;   // roots / rhead / rnext: a segment's cluster roots (k_db_rootmin)
     DevBuf<double> cellbox;
     DevBuf<long long> cellid;
     DevBuf<unsigned char> core, score;     // core flag per point / per slot of the cell-sorted copy
     DevBuf<double> spts;                   // cell-sorted copy of the batch's points
     DevBuf<unsigned long long> best, obounds;
-    DevBuf<unsigned> rep, active, kres, ccore, nclist, needy;
-    DevBuf<int> actlist;
+    DevBuf<unsigned> rep, active, kres, ccore, needy, nclist;
     DevBuf<unsigned char> hasanchor;
     DevBuf<char> geom;           // device copy of per-segment geometry tables
     DevBuf<unsigned long long> vbitmap;

@@ -118,29 +118,162 @@ __global__ void k_db_cell(const double* __restrict__ pts, long long N, int* __re
     atomicAdd(&cnt[c], 1u);
 }
 
+// Cell starts AND the list of occupied cells in one launch (round 6).  The exclusive prefix sum of the cells' point counts is the
+// decoupled look-back of k_scan_lookback (tiles of 1024 cells); the same tiles carry a second look-back -- run by the tile's second
+// wave beside the first -- over "the cell holds a point", which gives every occupied cell its position in a compact list in cell
+// order: `cells` (hence grouped by segment), cellpos[c], and the cell's entries of the tables the later passes work on (its own
+// union-find node, its segment, no core point seen yet ...).  Until round 5 that list was built by the core points themselves
+// (atomicMin on the cell's smallest core index, first one registers the cell, slots from an atomic counter per workgroup) in a
+// launch of its own, k_db_core, after the neighbour counts; now a cell is listed whether it turns out to hold a core point or not
+// -- the passes that walk the list skip a cell whose minidx is still INF (no core) or that is not active -- and the launch is gone.
+// The per-cell tables the batch needs are initialised here too (one visit per cell): k_db_init only clears the counts.
+struct DbCellTables {
+    unsigned *cursor, *minidx, *firstidx, *rootmin, *size, *active;
+    unsigned char* hasanchor;
+    int *cells, *cellpos, *parent, *cseg;
+    unsigned* n_cells;                  // [0] occupied cells
+};
+#define DBS_LDS 512
+__global__ void __launch_bounds__(256) k_db_scan(const unsigned* __restrict__ cnt, unsigned* __restrict__ start, long long NC /* cells; entry NC is the end sentinel */,
+                                                 unsigned long long* __restrict__ state, unsigned long long* __restrict__ state_o, unsigned epoch,
+                                                 const DbSeg* __restrict__ segs, int K, DbCellTables tb) {
+    __shared__ unsigned wsum[4], wsum_o[4];
+    __shared__ unsigned s_prefix, s_prefix_o;
+    __shared__ long long s_cb[DBS_LDS];
+    const bool lds_s = K <= DBS_LDS;
+    if (lds_s)
+        for (int q = threadIdx.x; q < K; q += blockDim.x) s_cb[q] = segs[q].cell_base;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const long long tile = blockIdx.x;
+    const long long base = (tile * 256 + tid) * 4;
+    unsigned v[4];
+    unsigned t = 0, to = 0;
+    for (int i = 0; i < 4; ++i) {
+        v[i] = base + i <= NC ? cnt[base + i] : 0u;
+        t += v[i];
+        to += v[i] ? 1u : 0u;
+    }
+    unsigned incl = t, incl_o = to;   // inclusive wave scans
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned u = __shfl_up(incl, o), uo = __shfl_up(incl_o, o);
+        if (lane >= o) {
+            incl += u;
+            incl_o += uo;
+        }
+    }
+    if (lane == 63) {
+        wsum[w] = incl;
+        wsum_o[w] = incl_o;
+    }
+    __syncthreads();
+    unsigned woff = 0, woff_o = 0;
+    for (int i = 0; i < w; ++i) {
+        woff += wsum[i];
+        woff_o += wsum_o[i];
+    }
+    if (w == 0) {
+        const unsigned prefix = scan_lookback_prefix(state, tile, epoch, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+        if (lane == 0) s_prefix = prefix;
+    } else if (w == 1) {
+        const unsigned prefix = scan_lookback_prefix(state_o, tile, epoch, wsum_o[0] + wsum_o[1] + wsum_o[2] + wsum_o[3]);
+        if (lane == 0) s_prefix_o = prefix;
+    }
+    __syncthreads();
+    unsigned excl = s_prefix + woff + incl - t, pos = s_prefix_o + woff_o + incl_o - to;
+    for (int i = 0; i < 4; ++i) {
+        const long long c = base + i;
+        if (c <= NC) start[c] = excl;
+        excl += v[i];
+        if (c < NC) {
+            tb.minidx[c] = INF32;               // (read for every neighbour cell: INF = no core point there, nothing else of it is looked at)
+            if (v[i]) {
+                tb.cursor[c] = 0u;
+                tb.firstidx[c] = INF32;
+                tb.rootmin[c] = INF32;
+                tb.size[c] = 0u;
+                tb.active[c] = 0u;
+                tb.hasanchor[c] = 0;
+                int lo = 0, hi = K - 1;         // segment of the cell (the segments' cell ranges tile [0, NC) in order)
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if ((lds_s ? s_cb[mid] : segs[mid].cell_base) <= c) lo = mid; else hi = mid - 1;
+                }
+                tb.cells[pos] = (int)c;
+                tb.cellpos[c] = (int)pos;
+                tb.parent[c] = (int)c;
+                tb.cseg[c] = lo;
+                ++pos;
+            }
+        } else if (c == NC) {
+            tb.n_cells[0] = pos;                // (the sentinel holds no point: its position is the number of occupied cells)
+        }
+    }
+}
+
+// What a point's core status means for its cell (shared by k_db_fill, which settles the points whose status needs no neighbour count,
+// and k_db_count, which settles the others): the flag itself (per point and per slot of the cell-sorted copy; a flag the batch
+// promotes inside the anchor member of a segment that runs in place is set where the point lives), the cell's smallest core index,
+// "holds an anchor core", and "active" (holds a core point that is not an anchor: the cell's connections have to be searched).
+// No value comes back from any of it: nobody waits for these atomics.
+__device__ __forceinline__ void db_settle_point(long long i, long long c, unsigned slot, bool is_core, bool known, int k_seg,
+                                                const DbSeg* __restrict__ segs, unsigned char* __restrict__ core,
+                                                unsigned char* __restrict__ score, unsigned char* __restrict__ poolcore_w,
+                                                unsigned* __restrict__ minidx, unsigned char* __restrict__ hasanchor,
+                                                unsigned* __restrict__ active) {
+    core[i] = is_core ? 1 : 0;
+    score[slot] = is_core ? 1 : 0;
+    if (!is_core) return;
+    // (indices are positions in the BATCH: they order a segment's points like positions in the segment do, and an anchor core --
+    //  the bulk of this pass -- then needs nothing from the segment table)
+    if ((unsigned)i < minidx[c]) atomicMin(&minidx[c], (unsigned)i);     // (stale read is only conservative)
+    if (known) {
+        // cells holding anchor cores are all connected: db_anchor_cells hangs them under the segment's lowest one
+        if (!hasanchor[c]) hasanchor[c] = 1;
+        return;
+    }
+    if (!active[c]) active[c] = 1u;
+    if (segs[k_seg].out_mode == 2) {
+        const long long pt_base = segs[k_seg].pt_base;
+        if (i < pt_base + segs[k_seg].n_first) poolcore_w[segs[k_seg].out_off + (i - pt_base)] = 1;
+    }
+}
+
 // Cell-sorted COPY of the points (+ each point's slot): every neighbourhood scan below walks contiguous runs of
 // it.  Those scans are serial, latency-bound chains per lane (the kernel runs as long as its slowest lane), so
 // a candidate must cost one load, not the ord -> point -> flag chain of an index sort.
 // It also lists the points whose core status needs a neighbour COUNT (not an anchor core, cell holds fewer than
 // min_points): k_db_count gives each of them a whole wave.
+// Round 6: every OTHER point's status is known right here -- an anchor core, or a point of a cell that holds min_points points, is
+// core; a point a cropped anchor leaves outside its crop keeps the flag it came with -- so this pass settles them and k_db_count
+// settles the counted ones (until round 5: a separate k_db_core launch over all points behind the counts).
 __global__ void k_db_fill(const double* __restrict__ pts, long long N, const long long* __restrict__ cellid,
                           const unsigned* __restrict__ start, unsigned* __restrict__ cursor, unsigned* __restrict__ rank,
                           double* __restrict__ spts, const unsigned char* __restrict__ core0, int minpts,
-                          unsigned* __restrict__ needy, unsigned* __restrict__ n_needy) {
+                          unsigned* __restrict__ needy, unsigned* __restrict__ n_needy, const int* __restrict__ segid,
+                          const DbSeg* __restrict__ segs, unsigned char* __restrict__ core, unsigned char* __restrict__ score,
+                          unsigned char* __restrict__ poolcore_w, unsigned* __restrict__ minidx, unsigned char* __restrict__ hasanchor,
+                          unsigned* __restrict__ active) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < N;
     bool need = false;
-    if (live && cellid[i] >= 0) {
-        long long c = cellid[i];
-        const unsigned s0 = start[c];
-        unsigned p = s0 + atomicAdd(&cursor[c], 1u);
-        rank[i] = p;
-        for (int a = 0; a < 3; ++a) spts[(size_t)p * 3 + a] = pts[(size_t)i * 3 + a];
-        need = !(core0 != nullptr && core0[i] != 0) && start[c + 1] - s0 < (unsigned)minpts;
+    if (live) {
+        const long long c = cellid[i];
+        if (c >= 0) {
+            const unsigned s0 = start[c];
+            unsigned p = s0 + atomicAdd(&cursor[c], 1u);
+            rank[i] = p;
+            for (int a = 0; a < 3; ++a) spts[(size_t)p * 3 + a] = pts[(size_t)i * 3 + a];
+            const bool known = core0 != nullptr && core0[i] != 0;
+            need = !known && start[c + 1] - s0 < (unsigned)minpts;
+            if (!need) db_settle_point(i, c, p, true, known, segid[i], segs, core, score, poolcore_w, minidx, hasanchor, active);
+        } else if (c == DB_FAR) {
+            // a forced segment's anchor point outside the crop: keeps its flag, takes part in nothing
+            core[i] = (core0 != nullptr && core0[i] != 0) ? 1 : 0;
+        }
+        // (DB_FAR2: a point of an in-place segment outside the crop -- it is nowhere in the batch, no flag to write)
     }
-    // (one atomic per wave that holds needy points.  Handing the slots out per 1024-thread block instead -- and k_db_core's three
-    //  counters likewise -- was measured on the MI355X: k_db_fill 18.8 -> 21.3 us, k_db_core 17.2 -> 20.1 us per fold step.  These
-    //  two are not bound by their counters but by the per-point chains above.)
+    // (one atomic per wave that holds needy points.  Handing the slots out per 1024-thread block instead was measured on the
+    //  MI355X: 18.8 -> 21.3 us per fold step.  This pass is not bound by that counter but by the per-point chains above.)
     const unsigned long long m = __ballot(need);
     if (m) {
         const int lane = threadIdx.x & 63, leader = __ffsll(m) - 1;
@@ -220,19 +353,26 @@ __device__ const signed char DB_COL[25][2] = {{0, 0},  {-1, 0}, {1, 0},  {0, -1}
 // contiguous ranges of the cell-sorted copy; lanes 0..24 look their range up side by side, the ranges are laid end
 // to end (wave prefix sum) and the 64 lanes test 64 candidates per trip -- a handful of L2 round trips per point instead
 // of the ~75 of one lane walking the columns one after the other.  core[i] = (neighbours within eps, the point itself
-// included, >= min_points), the same predicate as before.
+// included, >= min_points), the same predicate as before; the wave's first lane then settles the point (db_settle_point).
+// The points that come out non-core need no list of their own: they are the entries of THIS list whose flag is 0 (k_db_label).
 __global__ void __launch_bounds__(256) k_db_count(const double* __restrict__ pts, const int* __restrict__ segid,
                                                   const DbSeg* __restrict__ segs, const long long* __restrict__ cellid,
                                                   const unsigned* __restrict__ start, const double* __restrict__ spts, double eps2,
                                                   int minpts, const unsigned* __restrict__ needy,
-                                                  const unsigned* __restrict__ n_needy, unsigned char* __restrict__ core) {
+                                                  const unsigned* __restrict__ n_needy, unsigned char* __restrict__ core,
+                                                  const unsigned* __restrict__ rank, unsigned char* __restrict__ score,
+                                                  unsigned char* __restrict__ poolcore_w, unsigned* __restrict__ minidx,
+                                                  unsigned char* __restrict__ hasanchor, unsigned* __restrict__ active) {
     const int lane = threadIdx.x & 63;
     const unsigned nwaves = (gridDim.x * blockDim.x) >> 6, n = *n_needy;
     for (unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
         const long long i = needy[w];
-        const DbSeg sg = segs[segid[i]];
+        const int k_seg = segid[i];
+        const long long c = cellid[i];
+        const unsigned slot = rank[i];
+        const DbSeg sg = segs[k_seg];
         int ix, iy, iz;
-        cell_xyz(sg, cellid[i], ix, iy, iz);
+        cell_xyz(sg, c, ix, iy, iz);
         const double pi[3] = {pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2]};
         unsigned s0 = 0, len = 0;
         if (lane < 25) {
@@ -265,89 +405,8 @@ __global__ void __launch_bounds__(256) k_db_count(const double* __restrict__ pts
             if (t < total) hit = dist2_f64(spts + (size_t)(c_s0 + (t - (c_incl - c_len))) * 3, pi) < eps2;
             have += __popcll(__ballot(hit));
         }
-        if (lane == 0) core[i] = have >= minpts ? 1 : 0;
+        if (lane == 0) db_settle_point(i, c, slot, have >= minpts, false, k_seg, segs, core, score, poolcore_w, minidx, hasanchor, active);
     }
-}
-
-__global__ void k_db_core(const double* __restrict__ pts, long long N, const int* __restrict__ segid,
-                          const DbSeg* __restrict__ segs, const long long* __restrict__ cellid,
-                          const unsigned* __restrict__ cnt, const unsigned* __restrict__ start,
-                          const unsigned* __restrict__ rank, const double* __restrict__ spts, unsigned char* __restrict__ score,
-                          double eps2, int minpts, unsigned char* __restrict__ core, unsigned* __restrict__ minidx, int* __restrict__ corecells, unsigned* __restrict__ ncore,
-                          int* __restrict__ cellpos, int* __restrict__ parent, const unsigned char* __restrict__ core0,
-                          unsigned char* __restrict__ hasanchor, unsigned* __restrict__ rep, unsigned* __restrict__ active,
-                          int* __restrict__ actlist, unsigned* __restrict__ nact, int* __restrict__ cseg,
-                          unsigned* __restrict__ nclist, unsigned char* __restrict__ poolcore_w) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    bool in_range = i < N;
-    if (!in_range) i = N - 1;                // keep the lane alive for the wave collectives below
-    long long c = cellid[i];
-    // (a point of an in-place segment outside the crop: it is nowhere in the batch -- no segment id, no flag to write)
-    const bool far2 = c == DB_FAR2;
-    if (far2) in_range = false;
-    const int k_seg = far2 ? 0 : segid[i];
-    const DbSeg sg = segs[k_seg];
-    const bool far = c < 0;                  // (a forced segment's anchor point outside the crop: keeps its flag, takes part in nothing)
-    if (far) c = sg.cell_base;               // (any valid cell: nothing below touches it for a far point)
-    // anchor points: core points of a member cloud that is a known single-cluster fixed point of this DBSCAN.
-    // More points only raise neighbour counts, so they stay core -- no counting needed.
-    const bool known = core0 != nullptr && !far2 && core0[i] != 0;
-    bool is_core = known || (!far && cnt[c] >= (unsigned)minpts);
-    if (!is_core && in_range && !far) is_core = core[i] != 0;        // counted by k_db_count (the points k_db_fill listed)
-    is_core = is_core && in_range;
-    if (in_range) {
-        core[i] = is_core ? 1 : 0;
-        if (!far) score[rank[i]] = is_core ? 1 : 0;
-        // a segment that runs in place: the anchor member's points are not copied, a flag the batch promotes is set where it lives
-        if (is_core && !known && sg.out_mode == 2 && i < sg.pt_base + sg.n_first) poolcore_w[sg.out_off + (i - sg.pt_base)] = 1;
-    }
-    const bool in_grid = !far;
-    const int lane = threadIdx.x & 63;
-    // the first core point of a cell (it sees the initial INF) registers the cell in the compact list; a core
-    // point that is not an anchor puts its cell on the active list (its connections have to be searched).  List
-    // slots are handed out per BLOCK (waves take block-local offsets from LDS, one global atomic per block and
-    // list): the two counters share a cache line, and an atomic per wave on it was a third of this kernel.
-    __shared__ unsigned s_cnt[3], s_base[3];
-    if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0u;
-    __syncthreads();
-    bool reg = false;
-    if (is_core && in_grid && (unsigned)(i - sg.pt_base) < minidx[c])     // (stale read is only conservative)
-        reg = atomicMin(&minidx[c], (unsigned)(i - sg.pt_base)) == INF32;
-    // cells holding anchor cores are all connected: k_db_anchor hangs them under the segment's lowest one
-    if (is_core && in_grid && known && !hasanchor[c]) hasanchor[c] = 1;
-    bool act = false;
-    if (is_core && in_grid && !known && !active[c]) act = atomicExch(&active[c], 1u) == 0u;
-    const bool ncp = in_range && in_grid && !is_core;          // non-core: the only points k_db_label has to visit
-    const unsigned long long m_reg = __ballot(reg), m_act = __ballot(act), m_ncp = __ballot(ncp);
-    unsigned off_reg = 0, off_act = 0, off_ncp = 0;
-    if (m_ncp) {
-        const int leader = __ffsll(m_ncp) - 1;
-        if (lane == leader) off_ncp = atomicAdd(&s_cnt[2], (unsigned)__popcll(m_ncp));
-        off_ncp = __shfl(off_ncp, leader) + (unsigned)__popcll(m_ncp & ((1ull << lane) - 1ull));
-    }
-    if (m_reg) {
-        const int leader = __ffsll(m_reg) - 1;
-        if (lane == leader) off_reg = atomicAdd(&s_cnt[0], (unsigned)__popcll(m_reg));
-        off_reg = __shfl(off_reg, leader) + (unsigned)__popcll(m_reg & ((1ull << lane) - 1ull));
-    }
-    if (m_act) {
-        const int leader = __ffsll(m_act) - 1;
-        if (lane == leader) off_act = atomicAdd(&s_cnt[1], (unsigned)__popcll(m_act));
-        off_act = __shfl(off_act, leader) + (unsigned)__popcll(m_act & ((1ull << lane) - 1ull));
-    }
-    __syncthreads();
-    if (threadIdx.x < 3 && s_cnt[threadIdx.x])     // (the three counters are consecutive words: ncore, nact, n_noncore)
-        s_base[threadIdx.x] = atomicAdd(ncore + threadIdx.x, s_cnt[threadIdx.x]);
-    __syncthreads();
-    if (reg) {
-        const unsigned p = s_base[0] + off_reg;
-        corecells[p] = (int)c;
-        cellpos[c] = (int)p;
-        parent[c] = (int)c;
-        cseg[c] = k_seg;
-    }
-    if (act) actlist[s_base[1] + off_act] = (int)c;
-    if (ncp) nclist[s_base[2] + off_ncp] = (unsigned)i;
 }
 
 // Anchor cells start out as ONE component per segment, in one launch: inside a wave the anchor cells of a segment hang
@@ -517,7 +576,8 @@ __global__ void k_db_union(const int* __restrict__ corecells, const unsigned* __
     //  contention on the roots cost more than the second trip through the lane's chain)
     for (unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < ncells; w += nwaves) {
         const long long c = corecells[w];
-        const int lo = cseg[c];             // segment of the cell (written when the cell was registered)
+        if (!active[c]) continue;           // (the list holds every occupied cell: only those with a core point that is not an anchor search)
+        const int lo = cseg[c];             // segment of the cell (written when the cell was listed)
         const DbSeg sg = segs[lo];
         int ix, iy, iz;
         cell_xyz(sg, c, ix, iy, iz);
@@ -626,7 +686,8 @@ __global__ void k_db_union_scan(const double* __restrict__ pts, const int* __res
     const unsigned nwaves = (gridDim.x * blockDim.x) >> 6, ncells = *ncore;
     for (unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < ncells; w += nwaves) {
         const long long c = corecells[w];
-        const int lo = cseg[c];             // segment of the cell (written when the cell was registered)
+        if (!active[c]) continue;           // (see k_db_union)
+        const int lo = cseg[c];             // segment of the cell (written when the cell was listed)
         const DbSeg sg = segs[lo];
         int ix, iy, iz;
         cell_xyz(sg, c, ix, iy, iz);
@@ -767,18 +828,51 @@ __global__ void k_db_union_scan(const double* __restrict__ pts, const int* __res
 // straight from it.  (No path halving here: a halving store of one thread may land after another thread has
 // written the root into the same word and put an inner node back.)  Then, per cluster: order key = smallest core
 // index (kept at the root cell), number of core members, and the number of clusters per segment.
+#define DB_ROOTS 8u
 __global__ void k_db_rootmin(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, int* __restrict__ parent,
                              const unsigned* __restrict__ minidx, unsigned* __restrict__ rootmin,
                              const int* __restrict__ cseg, const DbSeg* __restrict__ segs, int K,
-                             unsigned* __restrict__ ncl, const unsigned* __restrict__ ccore, unsigned* __restrict__ size) {
+                             unsigned* __restrict__ ncl, const unsigned* __restrict__ ccore, unsigned* __restrict__ size,
+                             int* __restrict__ roots, int* __restrict__ rhead, int* __restrict__ rnext,
+                             const unsigned* __restrict__ needy, const unsigned* __restrict__ n_needy, const unsigned char* __restrict__ core,
+                             unsigned* __restrict__ nclist, unsigned* __restrict__ n_noncore) {
+    // (riding along, on the workgroups from the END of the grid -- the cell list keeps the first few dozen busy --: the counted
+    //  points that came out non-core, as a compact list for k_db_label; one atomic per workgroup trip)
+    {
+        __shared__ unsigned s_w[4], s_base;
+        const unsigned nn = *n_needy;
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        for (unsigned t0 = (gridDim.x - 1u - blockIdx.x) * blockDim.x; t0 < nn; t0 += gridDim.x * blockDim.x) {   // block-uniform
+            const unsigned t = t0 + threadIdx.x;
+            unsigned i = 0;
+            bool nc = false;
+            if (t < nn) {
+                i = needy[t];
+                nc = core[i] == 0;
+            }
+            const unsigned long long m = __ballot(nc);
+            if (lane == 0) s_w[wv] = (unsigned)__popcll(m);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const unsigned tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+                s_base = tot ? atomicAdd(n_noncore, tot) : 0u;
+            }
+            __syncthreads();
+            unsigned pos = s_base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            for (int q = 0; q < wv; ++q) pos += s_w[q];
+            if (nc) nclist[pos] = i;
+            __syncthreads();                     // (s_w / s_base are rewritten by the next trip)
+        }
+    }
     const unsigned n = *ncore;
     const unsigned stride = gridDim.x * blockDim.x;
     // wave-uniform trip count; one atomic per (wave, root): a cluster's cells all target the same word
     for (unsigned w0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); w0 < n; w0 += stride) {
         unsigned w = w0 + (threadIdx.x & 63u);
-        const bool valid = w < n;
+        bool valid = w < n;
         int root = -1;
         unsigned mi = INF32, nc = 0;
+        if (valid && minidx[corecells[w]] == INF32) valid = false;      // (an occupied cell without a core point: in no cluster)
         if (valid) {
             int c = corecells[w];
             root = c;
@@ -792,7 +886,12 @@ __global__ void k_db_rootmin(const int* __restrict__ corecells, const unsigned* 
             nc = ccore[w];
             if (root == c) {                    // one root cell per cluster: clusters of the segment
                 const int lo = cseg[c];             // segment of the cell (written when the cell was registered)
-                atomicAdd(&ncl[lo], 1u);
+                // ... listed per segment: k_db_compact picks the segment's largest cluster from this list itself (db_best_cluster;
+                // until round 5 a launch of its own, k_db_pick, between k_db_label and the compaction).  The first DB_ROOTS roots
+                // of a segment sit side by side (one round trip to fetch them all), further ones are chained up.
+                const unsigned slot = atomicAdd(&ncl[lo], 1u);
+                if (slot < DB_ROOTS) roots[(size_t)lo * DB_ROOTS + slot] = c;
+                else rnext[c] = atomicExch(&rhead[lo], c);
             }
         }
         unsigned long long todo = __ballot(valid);
@@ -824,7 +923,7 @@ __global__ void k_db_label(const double* __restrict__ pts, const int* __restrict
                            const unsigned* __restrict__ ncl, double eps2, int* __restrict__ label, unsigned* __restrict__ size,
                            unsigned* __restrict__ firstidx, unsigned* __restrict__ contested, const unsigned* __restrict__ nclist,
                            const unsigned* __restrict__ n_noncore) {
-    // Border search for the NON-CORE points only (compact list from k_db_core; a core point's label is simply the
+    // Border search for the NON-CORE points only (the counted points that did not reach min_points, listed by k_db_rootmin; a core point's label is simply the
     // root of its cell, k_db_flags looks it up itself).  One WAVE per point, one LANE per neighbour cell (125 cells
     // in two rounds): a lane decides its cell -- core cell? tight box of its core points in reach? a core point
     // within eps? -- and the wave reduces to the cluster with the smallest order key (Open3D: the first cluster
@@ -883,14 +982,47 @@ __global__ void k_db_label(const double* __restrict__ pts, const int* __restrict
             if (lab >= 0) {
                 // (core members were counted per cell by k_db_rootmin, and their smallest index is the cluster key)
                 atomicAdd(&size[lab], 1u);
-                atomicMin(&firstidx[lab], (unsigned)(i - sg.pt_base));
+                atomicMin(&firstidx[lab], (unsigned)i);          // (batch position, like minidx)
                 if (contest && ncl[k] > 1u && !contested[k]) contested[k] = 1u;
             }
         }
     }
 }
 
+// The segment's largest cluster (ties: first label in point order) as size << 32 | ~first member index, 0 if it has none: a walk
+// over the segment's root cells (k_db_rootmin's chain; a segment has a handful of clusters).  Sizes and first border members are
+// complete when k_db_label has ended.
+__device__ __forceinline__ unsigned long long db_cluster_key(int c, const unsigned* __restrict__ size, const unsigned* __restrict__ firstidx,
+                                                            const unsigned* __restrict__ rootmin) {
+    const unsigned sz = size[c];
+    if (sz == 0u) return 0ull;
+    const unsigned first = min(firstidx[c], rootmin[c]);
+    return ((unsigned long long)sz << 32) | (unsigned long long)(INF32 - first);
+}
+__device__ __forceinline__ unsigned long long db_best_cluster(int k, const unsigned* __restrict__ ncl, const int* __restrict__ roots,
+                                                              const int* __restrict__ rhead, const int* __restrict__ rnext,
+                                                              const unsigned* __restrict__ size, const unsigned* __restrict__ firstidx,
+                                                              const unsigned* __restrict__ rootmin) {
+    const unsigned n = ncl[k];
+    int r[DB_ROOTS];
+#pragma unroll
+    for (unsigned j = 0; j < DB_ROOTS; ++j) r[j] = j < n ? roots[(size_t)k * DB_ROOTS + j] : -1;
+    unsigned long long b = 0ull;
+#pragma unroll
+    for (unsigned j = 0; j < DB_ROOTS; ++j)
+        if (r[j] >= 0) {
+            const unsigned long long key = db_cluster_key(r[j], size, firstidx, rootmin);
+            b = key > b ? key : b;
+        }
+    if (n > DB_ROOTS)
+        for (int c = rhead[k]; c >= 0; c = rnext[c]) {
+            const unsigned long long key = db_cluster_key(c, size, firstidx, rootmin);
+            b = key > b ? key : b;
+        }
+    return b;
+}
 // cluster roots are core cells: pick the largest cluster per segment (ties: first label in point order)
+// (the legacy three-launch compaction's form, HMSG_DB_COMPACT_SPLIT=1)
 __global__ void k_db_pick(const int* __restrict__ corecells, const unsigned* __restrict__ ncore, const int* __restrict__ cseg, const DbSeg* __restrict__ segs,
                           int K, const unsigned* __restrict__ size, const unsigned* __restrict__ firstidx,
                           const unsigned* __restrict__ rootmin, unsigned long long* __restrict__ best) {
@@ -918,7 +1050,7 @@ __global__ void k_db_flags(long long N, const int* __restrict__ segid, const DbS
     const unsigned long long b = best[k];
     bool keep = true;
     if ((unsigned)(b >> 32) >= 5u) {
-        const long long fm = segs[k].pt_base + (long long)(INF32 - (unsigned)(b & 0xffffffffull));
+        const long long fm = (long long)(INF32 - (unsigned)(b & 0xffffffffull));
         const int wl = core[fm] ? parent[cellid[fm]] : label[fm];
         const int my = core[i] ? parent[cellid[i]] : label[i];
         keep = my == wl;
@@ -1034,9 +1166,13 @@ __global__ void k_db_scatter(const double* __restrict__ pts, long long N, const 
 // own (SegDesc::out_mode 1 / 2) is a look-back chain of its own -- its kept points go to that region at the chain's own
 // prefix -- and the anchor member of a segment that runs in place is not visited at all.
 #define DBK_TRIPS 32
+#define DBK_SEGS 256
 __global__ void __launch_bounds__(256) k_db_compact(const double* __restrict__ pts, const DbBlk* __restrict__ blks, const int* __restrict__ segid,
                                                     const DbSeg* __restrict__ segs, const int* __restrict__ label,
-                                                    const unsigned long long* __restrict__ best, const unsigned* __restrict__ rep, unsigned* __restrict__ flags_dbg,
+                                                    const unsigned* __restrict__ ncl, const int* __restrict__ roots,
+                                                    const int* __restrict__ rhead, const int* __restrict__ rnext, const unsigned* __restrict__ size,
+                                                    const unsigned* __restrict__ firstidx, const unsigned* __restrict__ rootmin,
+                                                    const unsigned* __restrict__ rep, unsigned* __restrict__ flags_dbg,
                                                     const unsigned char* __restrict__ core, const long long* __restrict__ cellid,
                                                     const int* __restrict__ parent, double* __restrict__ dst, int* __restrict__ oend,
                                                     int* __restrict__ ostart, int* __restrict__ ofirst, unsigned char* __restrict__ dst_core,
@@ -1057,14 +1193,22 @@ __global__ void __launch_bounds__(256) k_db_compact(const double* __restrict__ p
         dst = pool_w + (size_t)o * 3;
         if (dst_core) dst_core = poolcore_w + o;
     }
+    // the winners of the segments this workgroup's points belong to (segments are contiguous in the batch: those of its first and of
+    // its last point and the ones between), one thread per segment, side by side
+    __shared__ unsigned long long s_best[DBK_SEGS];
+    const int k_lo = bk.cnt > 0 ? segid[b0] : 0, k_hi = bk.cnt > 0 ? segid[b1 - 1] : -1;
+    const bool best_in_lds = k_hi - k_lo < DBK_SEGS;
+    if (best_in_lds && tid <= k_hi - k_lo)
+        s_best[tid] = segs[k_lo + tid].forced ? 0ull : db_best_cluster(k_lo + tid, ncl, roots, rhead, rnext, size, firstidx, rootmin);
+    __syncthreads();
     unsigned mine = 0u, kept = 0u;
     int trip = 0;
     for (long long base = b0; base < b1; base += blockDim.x, ++trip) {
         const long long i = base + tid;
         if (i >= b1) continue;
         const int k = segid[i];
-        const unsigned long long b = best[k];
         const DbSeg sg = segs[k];
+        const unsigned long long b = sg.forced ? 0ull : (best_in_lds ? s_best[k - k_lo] : db_best_cluster(k, ncl, roots, rhead, rnext, size, firstidx, rootmin));
         bool keep = true;                                    // graph_utils.py:853-880 (see k_db_flags)
         if (sg.forced) {
             // the anchor member is kept whole and its cluster is the winner (SegDesc::forced); the rest is kept where it joined it
@@ -1075,7 +1219,7 @@ __global__ void __launch_bounds__(256) k_db_compact(const double* __restrict__ p
                 keep = my == wl;
             }
         } else if ((unsigned)(b >> 32) >= 5u) {
-            const long long fm = sg.pt_base + (long long)(INF32 - (unsigned)(b & 0xffffffffull));
+            const long long fm = (long long)(INF32 - (unsigned)(b & 0xffffffffull));      // (batch position of the winner's first member)
             const int wl = core[fm] ? parent[cellid[fm]] : label[fm];
             const int my = core[i] ? parent[cellid[i]] : label[i];
             keep = my == wl;
@@ -1129,9 +1273,12 @@ __global__ void __launch_bounds__(256) k_db_compact(const double* __restrict__ p
             if (i == sg.pt_base) ostart[k] = (int)p;
             if (sg.n_first > 0 && sg.n_first < sg.n && i == sg.pt_base + sg.n_first) ofirst[k] = (int)p;   // where the first member's output ends
             if (i == sg.pt_base + sg.n - 1) oend[k] = (int)(p + f);
-            const unsigned win = (unsigned)(best[k] >> 32);
-            drops = win >= 5u && win < (unsigned)sg.n;
-            if (sg.forced) drops = i >= sg.pt_base + sg.n_first;    // (box of the kept REST: the host unites it with the anchor member's own box)
+            if (sg.forced) {
+                drops = i >= sg.pt_base + sg.n_first;               // (box of the kept REST: the host unites it with the anchor member's own box)
+            } else {
+                const unsigned win = (unsigned)((best_in_lds ? s_best[k - k_lo] : db_best_cluster(k, ncl, roots, rhead, rnext, size, firstidx, rootmin)) >> 32);
+                drops = win >= 5u && win < (unsigned)sg.n;
+            }
         }
         if (f && !drops) f = 0u;                                    // segment keeps every point: its input box stays exact
         if (__any(f != 0u && cur >= 0 && k != cur)) {               // somebody leaves its segment: flush all
@@ -1219,10 +1366,9 @@ __global__ void k_db_maxcell(const unsigned* __restrict__ cnt, long long NC, uns
     if ((threadIdx.x & 63) == 0 && v > 16u) atomicMax(out, v);
 }
 struct DbInit {
-    unsigned *cnt, *cursor, *minidx, *firstidx, *rootmin, *size, *active;
-    unsigned char* hasanchor;
+    unsigned* cnt;
     unsigned long long* best;
-    int *ocount, *ostart, *ofirst;
+    int *ocount, *ostart, *ofirst, *rhead;
     unsigned long long* obounds;
     unsigned *ncl, *rep, *contested, *dropped, *counters;
     long long NC;
@@ -1236,22 +1382,14 @@ struct DbInit {
 __global__ void k_db_init(DbInit in) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     for (size_t q = (size_t)i; q < in.up_n16; q += (size_t)gridDim.x * blockDim.x) in.up_dst[q] = in.up_src[q];
-    if (i <= in.NC) in.cnt[i] = 0u;          // NC + 1 entries (scan sentinel)
-    if (i < in.NC) {
-        in.cursor[i] = 0u;
-        in.minidx[i] = INF32;
-        in.firstidx[i] = INF32;
-        in.rootmin[i] = INF32;
-        in.size[i] = 0u;
-        in.active[i] = 0u;
-        in.hasanchor[i] = 0;
-    }
+    if (i <= in.NC) in.cnt[i] = 0u;          // NC + 1 entries (scan sentinel); the other per-cell tables: k_db_scan
     if (i < in.K) {
         in.best[i] = 0ull;
         for (int a = 0; a < 6; ++a) in.obounds[(size_t)i * 6 + a] = a < 3 ? ~0ull : 0ull;
         in.ocount[i] = 0;
         in.ostart[i] = 0;
         in.ofirst[i] = 0;
+        in.rhead[i] = -1;
         in.ncl[i] = 0u;
         in.rep[i] = INF32;
         in.contested[i] = 0u;
@@ -1444,6 +1582,9 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     rootmin.ensure(NC);
     best.ensure(K);
     rep.ensure(K);
+    rhead.ensure(K);
+    rnext.ensure(NC);
+    roots.ensure((size_t)K * DB_ROOTS);
     kres.ensure((size_t)K * 18 + 8);            // per segment: n_out (or output end) | n_clusters | contested | dropped | 6 x u64 box; 8 counter words; per segment: output start | end of the first member's output
     int* const d_ocount = (int*)kres.p;
     unsigned* const d_ncl = kres.p + K;
@@ -1454,8 +1595,6 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     int* const d_ofirst = d_ostart + K;     // per segment: output position of the first point behind the first member
     active.ensure(NC); hasanchor.ensure(NC);
     corelist.ensure((size_t)std::max<long long>(N, 1));
-    actlist.ensure((size_t)std::max<long long>(N, 1));
-    nclist.ensure((size_t)std::max<long long>(N, 1));
     cellpos.ensure((size_t)NC);
     cseg.ensure((size_t)NC);
     cellbox.ensure((size_t)std::min<long long>(NC, N) * 6);
@@ -1463,9 +1602,8 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     const unsigned gN = cdiv(N, 256), gC = cdiv(NC, 256);
     {   // every per-cell / per-segment table initialised by one launch (was a dozen memsets per batch)
         DbInit in;
-        in.cnt = cnt.p; in.cursor = cursor.p; in.minidx = minidx.p; in.firstidx = firstidx.p; in.rootmin = rootmin.p;
-        in.size = size.p; in.active = active.p; in.hasanchor = hasanchor.p;
-        in.best = best.p; in.obounds = d_obounds; in.ocount = d_ocount; in.ostart = d_ostart; in.ofirst = d_ofirst; in.ncl = d_ncl; in.rep = rep.p; in.contested = d_contested; in.dropped = d_dropped;
+        in.cnt = cnt.p;
+        in.best = best.p; in.obounds = d_obounds; in.ocount = d_ocount; in.ostart = d_ostart; in.ofirst = d_ofirst; in.rhead = rhead.p; in.ncl = d_ncl; in.rep = rep.p; in.contested = d_contested; in.dropped = d_dropped;
         in.counters = kres.p + (size_t)K * 16;   // [0] core cells, [1] active core cells
         in.NC = NC; in.K = K;
         in.up_src = (const uint4*)h_geom.p; in.up_dst = (uint4*)geom.p; in.up_n16 = (geom_bytes + cat_bytes + blk_bytes) / 16;
@@ -1490,23 +1628,30 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
             stat_maxcell_max = std::max(stat_maxcell_max, (double)hm);
         }
     }
-    hmsg_scan_u32(cnt.p, start.p, (size_t)NC + 1, s, scan_tmp, nullptr);   // start[NC] = N (end sentinel)
+    unsigned* const d_nc = kres.p + (size_t)K * 16;      // counters: [0] occupied cells, [3] counted points
+    {   // cell starts (start[NC] = N: end sentinel) + the list of occupied cells + the per-cell tables, one launch
+        const size_t ntiles = ((size_t)NC + 1 + 1023) / 1024;
+        const unsigned epoch = hmsg_scan_epoch(scan_tmp, 2 * ntiles, s);
+        DbCellTables tb;
+        tb.cursor = cursor.p; tb.minidx = minidx.p; tb.firstidx = firstidx.p; tb.rootmin = rootmin.p; tb.size = size.p; tb.active = active.p;
+        tb.hasanchor = hasanchor.p; tb.cells = corelist.p; tb.cellpos = cellpos.p; tb.parent = parent.p; tb.cseg = cseg.p; tb.n_cells = d_nc;
+        unsigned long long* const st = reinterpret_cast<unsigned long long*>(scan_tmp.p);
+        hipLaunchKernelGGL(k_db_scan, dim3((unsigned)ntiles), dim3(256), 0, s, (const unsigned*)cnt.p, start.p, NC, st, st + ntiles, epoch, dsegs, K, tb);
+        HMSG_CHECK_LAUNCH();
+    }
     spts.ensure((size_t)N * 3);
     score.ensure(N);
-    unsigned* const d_nc = kres.p + (size_t)K * 16;
-    unsigned* d_nact = d_nc + 1;
     needy.ensure((size_t)std::max<long long>(N, 1));
-    hipLaunchKernelGGL(k_db_fill, dim3(gN), dim3(256), 0, s, src, N, (const long long*)cellid.p, (const unsigned*)start.p, cursor.p,
-                       ord.p, spts.p, core0, min_points, needy.p, d_nc + 3);       // ord: slot of every point in the cell-sorted copy
+    nclist.ensure((size_t)std::max<long long>(N, 1));
+    unsigned char* const pc_w = gather ? gather->poolcore_w : (unsigned char*)nullptr;
     {
-    ProfScope ps(prof, s, "k_db_core", (double)N * 33.0);    // (k_db_count + k_db_core: one timed unit)
+    ProfScope ps(prof, s, "k_db_core", (double)N * 33.0);    // (k_db_fill + k_db_count: sorted copy, core flags -- one timed unit)
+    hipLaunchKernelGGL(k_db_fill, dim3(gN), dim3(256), 0, s, src, N, (const long long*)cellid.p, (const unsigned*)start.p, cursor.p,
+                       ord.p, spts.p, core0, min_points, needy.p, d_nc + 3, (const int*)segid.p, dsegs, core.p, score.p, pc_w, minidx.p,
+                       hasanchor.p, active.p);       // ord: slot of every point in the cell-sorted copy
     hipLaunchKernelGGL(k_db_count, dim3((unsigned)n_cu * 8u), dim3(256), 0, s, src, (const int*)segid.p, dsegs, (const long long*)cellid.p,
                        (const unsigned*)start.p, (const double*)spts.p, eps * eps, min_points, (const unsigned*)needy.p,
-                       (const unsigned*)(d_nc + 3), core.p);
-    hipLaunchKernelGGL(k_db_core, dim3(gN), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const long long*)cellid.p,
-                       (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p, (const double*)spts.p, score.p,
-                       eps * eps, min_points, core.p, minidx.p, corelist.p, d_nc, cellpos.p, parent.p, core0, hasanchor.p, rep.p, active.p, actlist.p,
-                       d_nact, cseg.p, nclist.p, gather ? gather->poolcore_w : (unsigned char*)nullptr);
+                       (const unsigned*)(d_nc + 3), core.p, (const unsigned*)ord.p, score.p, pc_w, minidx.p, hasanchor.p, active.p);
     }
     // persistent grid (8 blocks per CU): waves / threads stride over the core-cell list
     const unsigned gW = (unsigned)n_cu * 8u;
@@ -1516,20 +1661,21 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
                        core0 ? rep.p : (unsigned*)nullptr, parent.p);
     {
         ProfScope ps(prof, s, "k_db_union/box", (double)N * 24.0);
-        hipLaunchKernelGGL(k_db_union, dim3(gW), dim3(256), 0, s, (const int*)actlist.p, (const unsigned*)d_nact, (const int*)cseg.p, dsegs, K,
+        hipLaunchKernelGGL(k_db_union, dim3(gW), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc, (const int*)cseg.p, dsegs, K,
                            (const unsigned*)minidx.p, eps * eps, (const int*)cellpos.p, (const double*)cellbox.p, parent.p,
                            (const unsigned*)active.p, (const unsigned char*)hasanchor.p);
     }
     {
         ProfScope ps(prof, s, "k_db_union/scan", (double)N * 24.0);
-        hipLaunchKernelGGL(k_db_union_scan, dim3(gW), dim3(256), 0, s, (const double*)spts.p, (const int*)actlist.p,
-                           (const unsigned*)d_nact, (const int*)cseg.p, dsegs, K, (const unsigned*)cnt.p, (const unsigned*)start.p,
+        hipLaunchKernelGGL(k_db_union_scan, dim3(gW), dim3(256), 0, s, (const double*)spts.p, (const int*)corelist.p,
+                           (const unsigned*)d_nc, (const int*)cseg.p, dsegs, K, (const unsigned*)cnt.p, (const unsigned*)start.p,
                            (const unsigned*)ord.p, (const unsigned char*)score.p, (const unsigned*)minidx.p, eps * eps,
                            (const int*)cellpos.p, (const double*)cellbox.p, parent.p, (const unsigned*)active.p,
                            (const unsigned char*)hasanchor.p);
     }
     hipLaunchKernelGGL(k_db_rootmin, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc,
-                       parent.p, (const unsigned*)minidx.p, rootmin.p, (const int*)cseg.p, dsegs, K, d_ncl, (const unsigned*)ccore.p, size.p);
+                       parent.p, (const unsigned*)minidx.p, rootmin.p, (const int*)cseg.p, dsegs, K, d_ncl, (const unsigned*)ccore.p, size.p,
+                       roots.p, rhead.p, rnext.p, (const unsigned*)needy.p, (const unsigned*)(d_nc + 3), (const unsigned char*)core.p, nclist.p, d_nc + 2);
     {
     ProfScope ps(prof, s, "k_db_label", (double)N * 28.0);
     hipLaunchKernelGGL(k_db_label, dim3(std::min(gN, (unsigned)n_cu * 8u)), dim3(256), 0, s, src, (const int*)segid.p, dsegs,
@@ -1538,10 +1684,10 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
                        (const unsigned*)rootmin.p, (const unsigned*)d_ncl, eps * eps, label.p, size.p, firstidx.p, d_contested,
                        (const unsigned*)nclist.p, (const unsigned*)(d_nc + 2));
     }
-    hipLaunchKernelGGL(k_db_pick, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc, (const int*)cseg.p, dsegs, K,
-                       (const unsigned*)size.p, (const unsigned*)firstidx.p, (const unsigned*)rootmin.p, best.p);
     static const bool dump_wanted = getenv("HMSG_DEBUG_DUMP") != nullptr;
     if (split_compact) {
+    hipLaunchKernelGGL(k_db_pick, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc, (const int*)cseg.p, dsegs, K,
+                       (const unsigned*)size.p, (const unsigned*)firstidx.p, (const unsigned*)rootmin.p, best.p);
     hipLaunchKernelGGL(k_db_flags, dim3(gN), dim3(256), 0, s, N, (const int*)segid.p, dsegs, (const int*)label.p,
                        (const unsigned long long*)best.p, flags.p, d_dropped, (const unsigned char*)core.p,
                        (const long long*)cellid.p, (const int*)parent.p);
@@ -1558,7 +1704,8 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
         ProfScope ps(prof, s, "k_db_scatter", (double)N * 56.0);
         if (gK)
             hipLaunchKernelGGL(k_db_compact, dim3(gK), dim3(256), 0, s, src, dblks, (const int*)segid.p, dsegs, (const int*)label.p,
-                               (const unsigned long long*)best.p, (const unsigned*)rep.p, dump_wanted ? flags.p : (unsigned*)nullptr, (const unsigned char*)core.p,
+                               (const unsigned*)d_ncl, (const int*)roots.p, (const int*)rhead.p, (const int*)rnext.p, (const unsigned*)size.p, (const unsigned*)firstidx.p, (const unsigned*)rootmin.p,
+                               (const unsigned*)rep.p, dump_wanted ? flags.p : (unsigned*)nullptr, (const unsigned char*)core.p,
                                (const long long*)cellid.p, (const int*)parent.p, dst, d_ocount, d_ostart, d_ofirst, dst_core, d_obounds,
                                reinterpret_cast<unsigned long long*>(scan_tmp.p), epoch, gather ? gather->pool_w : (double*)nullptr,
                                gather ? gather->poolcore_w : (unsigned char*)nullptr);
@@ -1589,7 +1736,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     stat_points += N;
     stat_cells += NC;
     stat_core_cells += hres[(size_t)K * 16];
-    stat_active_cells += hres[(size_t)K * 16 + 1];
+    stat_needy += hres[(size_t)K * 16 + 3];
     long long total = 0;
     for (int k = 0; k < K; ++k) {
         // (one launch: output end - output start, positions in the segment's chain; in place: the anchor member + the kept rest)

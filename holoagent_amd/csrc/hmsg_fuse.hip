@@ -342,13 +342,16 @@ __global__ void __launch_bounds__(256) k_mbounds(const int* __restrict__ nn, con
             __syncthreads();
             unsigned pos = s_run + (unsigned)__popcll(tm & ((1ull << lane) - 1ull));
             for (int q = 0; q < wv; ++q) pos += s_w[q];
+            // (the trip's total is read BEFORE the barrier below: behind it the other waves may already be writing the next
+            //  trip's s_w while thread 0 has not advanced s_run yet)
+            const unsigned trip_total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
             if (r.tail) {
                 unsigned long long* rec = my_runs + (size_t)pos * (size_t)(1 + NW);
                 rec[0] = ((unsigned long long)(unsigned)r.v << 8) | (unsigned long long)r.len;
                 _Pragma("unroll") for (int w = 0; w < 4; ++w) if (w < NW) rec[1 + w] = r.b[w];
             }
             __syncthreads();
-            if (threadIdx.x == 0) s_run += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+            if (threadIdx.x == 0) s_run += trip_total;
         }
         if (!r.tail) continue;
         unsigned long long e[3] = {enc_f64(pts[(size_t)r.v * 3]), enc_f64(pts[(size_t)r.v * 3 + 1]), enc_f64(pts[(size_t)r.v * 3 + 2])};

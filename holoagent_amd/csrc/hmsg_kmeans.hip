@@ -392,5 +392,7 @@ extern "C" int hmsg_kmeans(const float* X_in, int64_t n64, int32_t D, int32_t k,
         return HMSG_OK;
     } catch (const std::exception&) {
         return HMSG_ERR_NOMEM;
+    } catch (...) {
+        return HMSG_ERR_INVALID;
     }
 }

@@ -1434,9 +1434,9 @@ static void merge_report(Folder& m) {
     if (getenv("HMSG_DEBUG_TIMING") && m.n_collects)
         fprintf(stderr, "[hmsg merge] %d collections of the point pool / grid arenas\n", m.n_collects);
     if (getenv("HMSG_DEBUG_TIMING") && m.ops.stat_calls > 0)
-        fprintf(stderr, "[hmsg merge] dbscan batches %.0f: mean points %.0f  grid cells %.0f  core cells %.0f  active cells %.0f\n",
+        fprintf(stderr, "[hmsg merge] dbscan batches %.0f: mean points %.0f  grid cells %.0f  occupied cells %.0f  counted points %.0f\n",
                 m.ops.stat_calls, m.ops.stat_points / m.ops.stat_calls, m.ops.stat_cells / m.ops.stat_calls,
-                m.ops.stat_core_cells / m.ops.stat_calls, m.ops.stat_active_cells / m.ops.stat_calls);
+                m.ops.stat_core_cells / m.ops.stat_calls, m.ops.stat_needy / m.ops.stat_calls);
     if (getenv("HMSG_DEBUG_TIMING") && m.ops.stat_calls > 0)
         fprintf(stderr, "[hmsg merge] dbscan segments with a cropped anchor member: %.0f (%.0f anchor points a batch), %.0f of them in place; pool %.2f GB\n",
                 m.ops.stat_forced, m.ops.stat_forced_first / m.ops.stat_calls, m.ops.stat_inplace, (double)m.pool_used * 24 / 1e9);

@@ -193,6 +193,9 @@ extern "C" int hmsg_save_objects(hmsg_t* hc, const char* dir, int64_t n, const h
     } catch (const std::exception& e) {
         h->err = e.what();
         return HMSG_ERR_INVALID;
+    } catch (...) {
+        h->err = "unknown error";
+        return HMSG_ERR_INVALID;
     }
 }
 
@@ -250,6 +253,8 @@ extern "C" int hmsg_write_json(const char* path, int32_t n_fields, const hmsg_js
         return write_file(path, js.data(), js.size()) ? HMSG_OK : HMSG_ERR_INVALID;
     } catch (const std::exception&) {
         return HMSG_ERR_INVALID;
+    } catch (...) {
+        return HMSG_ERR_INVALID;
     }
 }
 
@@ -266,6 +271,8 @@ extern "C" int hmsg_write_ply(const char* path, const double* xyz, int64_t n) {
         if (n) memcpy(ply.data() + hl, xyz, (size_t)n * 24);
         return write_file(path, ply.data(), ply.size()) ? HMSG_OK : HMSG_ERR_INVALID;
     } catch (const std::exception&) {
+        return HMSG_ERR_INVALID;
+    } catch (...) {
         return HMSG_ERR_INVALID;
     }
 }

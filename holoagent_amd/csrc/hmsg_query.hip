@@ -414,6 +414,9 @@ int iguard(hmsg_index* ix, F&& fn) {
     } catch (const std::exception& e) {
         ix->err = e.what();
         return HMSG_ERR_INVALID;
+    } catch (...) {
+        ix->err = "unknown error";
+        return HMSG_ERR_INVALID;
     }
 }
 bool dev_ptr(const void* p) {

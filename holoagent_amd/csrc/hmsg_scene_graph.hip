@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <map>
 #include <string>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -97,8 +98,10 @@ struct hmsg_graph {
     std::vector<std::string> img_paths;
     bool have_inv = false;
     std::vector<std::thread> workers;
-    std::string worker_err;
+    std::string worker_err;                 // first error of a KMeans worker (under worker_mu)
+    std::mutex worker_mu;
     bool begun = false, finished = false, loaded = false;
+    bool failed = false;                    // hmsg_graph_finish threw half way: views / objects are partly appended -- the graph only accepts hmsg_graph_destroy
     double t_begin_ms = 0, t_finish_ms = 0, t_kmeans_wait_ms = 0;
     hmsg_index_t* ix = nullptr;             // hmsg_graph_query's index (made on first use)
     ~hmsg_graph() {
@@ -356,6 +359,7 @@ void join_workers(hmsg_graph* g) {
         if (t.joinable()) t.join();
     g->workers.clear();
     g->t_kmeans_wait_ms += now_ms() - t0;
+    // (the workers are joined: no lock needed; the error stays, so every later call reports it again)
     if (!g->worker_err.empty()) throw hmsg_error{HMSG_ERR_INVALID, g->worker_err};
 }
 
@@ -848,9 +852,14 @@ int hmsg_graph_begin(hmsg_t* h, const hmsg_graph_params* prm, int32_t n_frames, 
                 try {
                     for (size_t k = (size_t)t; k < todo.size(); k += (size_t)nt) room_embed(g, g->rooms[(size_t)todo[k]]);
                 } catch (const hmsg_error& e) {
-                    g->worker_err = e.msg;
+                    std::lock_guard<std::mutex> lk(g->worker_mu);
+                    if (g->worker_err.empty()) g->worker_err = e.msg;
                 } catch (const std::exception& e) {
-                    g->worker_err = e.what();
+                    std::lock_guard<std::mutex> lk(g->worker_mu);
+                    if (g->worker_err.empty()) g->worker_err = e.what();
+                } catch (...) {
+                    std::lock_guard<std::mutex> lk(g->worker_mu);
+                    if (g->worker_err.empty()) g->worker_err = "room level worker: unknown exception";
                 }
             });
         g->begun = true;
@@ -868,10 +877,18 @@ int hmsg_graph_begin(hmsg_t* h, const hmsg_graph_params* prm, int32_t n_frames, 
 int hmsg_graph_finish(hmsg_graph_t* g, int32_t n_labels, const float* label_feats, const char* const* label_names) {
     if (!g) return HMSG_ERR_INVALID;
     return gguard(g, [&] {
+        HMSG_REQUIRE(!g->failed, HMSG_ERR_INVALID, "hmsg_graph_finish: an earlier hmsg_graph_finish failed half way; destroy the graph and begin again");
         HMSG_REQUIRE(g->begun && !g->finished && g->h, HMSG_ERR_INVALID, "hmsg_graph_finish: hmsg_graph_begin first (once)");
+        // everything that can be checked is checked before the graph is touched: a call that fails here can be repeated
         HMSG_REQUIRE(g->h->pooled, HMSG_ERR_INVALID, "hmsg_graph_finish: run hmsg_pool_instances first");
+        HMSG_REQUIRE(g->h->have_K, HMSG_ERR_INVALID, "hmsg_graph_finish: no camera intrinsics (hmsg_add_frames)");
         const double t0 = now_ms();
-        graph_finish(g, n_labels, label_feats, label_names);
+        try {
+            graph_finish(g, n_labels, label_feats, label_names);
+        } catch (...) {
+            g->failed = true;
+            throw;
+        }
         g->t_finish_ms = now_ms() - t0;
     });
 }
@@ -1025,6 +1042,8 @@ int hmsg_graph_to_json(const hmsg_graph_t* g, char* buf, int64_t capacity, int64
         return HMSG_OK;
     } catch (const std::exception&) {
         return HMSG_ERR_NOMEM;
+    } catch (...) {
+        return HMSG_ERR_INVALID;
     }
 }
 

@@ -4,6 +4,8 @@
 # Everything lands in gpurun_out/<tag>/.  Tasks:
 #   foldprof[:ENV=1,ENV2=1]  rocprofv3 --kernel-trace --stats of ONE 1000-frame step (rooms handed in, no extras) with the given
 #                            environment switches; prints the fold's kernels (k_db_*, k_ov_*, scans, uploads, publishes) and their sum
+#   foldtrace[:ENV=1,..]     rocprofv3 --kernel-trace of one scene -> scripts/fold_timeline.py: per-position kernel durations and launch gaps of a fold step
+#   foldtime[:ENV=1,..]      HMSG_DEBUG_TIMING laps of the fold without the profiler (bench.py --rooms-handed-in --steps 2)
 #   d1024                    the configs[2] line (D = 1024) with HMSG_DEBUG_TIMING laps of hmsg_query_hier
 #   bench[:args]             python bench.py <args> -> bench_<n>.json (default args: --no-extras --cpu-frames 0 --steps 3)
 #   tests[:pytest-args]      python -m pytest -m gpu -x -q <args> (default: tests)
@@ -46,6 +48,28 @@ for task in "$@"; do
       echo "== foldprof $arg"
       grep "hmsg merge\]" $OUT/foldprof_$label.err | tail -n 4
       fold_table $OUT/kernel_stats_fold_$label.csv
+      ;;
+    foldtrace)
+      # per-dispatch kernel trace of one scene's fold -> scripts/fold_timeline.py (durations and gaps by position in the step)
+      label=$(echo "${arg:-default}" | tr -c 'A-Za-z0-9_\n' '_')
+      ( cd /tmp
+        for kv in $(echo "$arg" | tr ',' ' '); do export "$kv"; done
+        rm -rf /tmp/trace_$label
+        rocprofv3 --kernel-trace --output-format csv -d /tmp/trace_$label -- python /root/repo/bench.py --rooms-handed-in --steps 1 --warmup 0 --cpu-frames 0 --inflight-steps 0 --encoder-frames 0 --no-extras > /dev/null 2> $OUT/foldtrace_$label.err
+        python /root/repo/scripts/fold_timeline.py /tmp/trace_$label/*/*kernel_trace.csv > $OUT/fold_timeline_$label.txt )
+      echo "== foldtrace $arg"
+      cat $OUT/fold_timeline_$label.txt
+      ;;
+    foldtime)
+      # host-side phase times of the fold WITHOUT the profiler (HMSG_DEBUG_TIMING laps), one scene, rooms handed in
+      label=$(echo "${arg:-default}" | tr -c 'A-Za-z0-9_\n' '_')
+      ( cd /root/repo
+        for kv in $(echo "$arg" | tr ',' ' '); do export "$kv"; done
+        HMSG_DEBUG_TIMING=1 python bench.py --rooms-handed-in --steps 2 --warmup 1 --cpu-frames 0 --inflight-steps 0 --encoder-frames 0 --no-extras > $OUT/foldtime_$label.json 2> $OUT/foldtime_$label.err )
+      echo "== foldtime $arg"
+      grep "hmsg merge\]\|hmsg fold\]" $OUT/foldtime_$label.err | tail -n 6
+      python -c "
+import json; d = json.loads([l for l in open('$OUT/foldtime_$label.json').read().splitlines() if l.startswith('{')][-1]); print('foldtime:', d['value'], d['stage_ms_per_step'])"
       ;;
     d1024)
       cd /root/repo
