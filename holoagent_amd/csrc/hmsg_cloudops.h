@@ -88,7 +88,7 @@ struct CloudOps {
     DevBuf<unsigned char> core, score;     // core flag per point / per slot of the cell-sorted copy
     DevBuf<double> spts;                   // cell-sorted copy of the batch's points
     DevBuf<unsigned long long> best, obounds;
-    DevBuf<unsigned> rep, active, kres, ccore, needy, nclist;
+    DevBuf<unsigned> rep, active, kres, ccore, needy, nclist, sidx;    // sidx: the point of every slot of the cell-sorted copy
     DevBuf<unsigned char> hasanchor;
     DevBuf<char> geom;           // device copy of per-segment geometry tables
     DevBuf<unsigned long long> vbitmap;

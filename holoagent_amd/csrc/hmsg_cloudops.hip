@@ -128,7 +128,7 @@ __global__ void k_db_cell(const double* __restrict__ pts, long long N, int* __re
 // -- the passes that walk the list skip a cell whose minidx is still INF (no core) or that is not active -- and the launch is gone.
 // The per-cell tables the batch needs are initialised here too (one visit per cell): k_db_init only clears the counts.
 struct DbCellTables {
-    unsigned *cursor, *minidx, *firstidx, *rootmin, *size, *active;
+    unsigned *cursor, *minidx, *firstidx, *rootmin, *size;
     unsigned char* hasanchor;
     int *cells, *cellpos, *parent, *cseg;
     unsigned* n_cells;                  // [0] occupied cells
@@ -185,13 +185,13 @@ __global__ void __launch_bounds__(256) k_db_scan(const unsigned* __restrict__ cn
         if (c <= NC) start[c] = excl;
         excl += v[i];
         if (c < NC) {
-            tb.minidx[c] = INF32;               // (read for every neighbour cell: INF = no core point there, nothing else of it is looked at)
+            if (!v[i]) tb.minidx[c] = INF32;    // (read for every neighbour cell: INF = no core point there, nothing else of it is looked at;
+                                                //  an occupied cell's is written by k_db_cellbox, like its `active`)
             if (v[i]) {
                 tb.cursor[c] = 0u;
                 tb.firstidx[c] = INF32;
                 tb.rootmin[c] = INF32;
                 tb.size[c] = 0u;
-                tb.active[c] = 0u;
                 tb.hasanchor[c] = 0;
                 int lo = 0, hi = K - 1;         // segment of the cell (the segments' cell ranges tile [0, NC) in order)
                 while (lo < hi) {
@@ -210,49 +210,23 @@ __global__ void __launch_bounds__(256) k_db_scan(const unsigned* __restrict__ cn
     }
 }
 
-// What a point's core status means for its cell (shared by k_db_fill, which settles the points whose status needs no neighbour count,
-// and k_db_count, which settles the others): the flag itself (per point and per slot of the cell-sorted copy; a flag the batch
-// promotes inside the anchor member of a segment that runs in place is set where the point lives), the cell's smallest core index,
-// "holds an anchor core", and "active" (holds a core point that is not an anchor: the cell's connections have to be searched).
-// No value comes back from any of it: nobody waits for these atomics.
-__device__ __forceinline__ void db_settle_point(long long i, long long c, unsigned slot, bool is_core, bool known, int k_seg,
-                                                const DbSeg* __restrict__ segs, unsigned char* __restrict__ core,
-                                                unsigned char* __restrict__ score, unsigned char* __restrict__ poolcore_w,
-                                                unsigned* __restrict__ minidx, unsigned char* __restrict__ hasanchor,
-                                                unsigned* __restrict__ active) {
-    core[i] = is_core ? 1 : 0;
-    score[slot] = is_core ? 1 : 0;
-    if (!is_core) return;
-    // (indices are positions in the BATCH: they order a segment's points like positions in the segment do, and an anchor core --
-    //  the bulk of this pass -- then needs nothing from the segment table)
-    if ((unsigned)i < minidx[c]) atomicMin(&minidx[c], (unsigned)i);     // (stale read is only conservative)
-    if (known) {
-        // cells holding anchor cores are all connected: db_anchor_cells hangs them under the segment's lowest one
-        if (!hasanchor[c]) hasanchor[c] = 1;
-        return;
-    }
-    if (!active[c]) active[c] = 1u;
-    if (segs[k_seg].out_mode == 2) {
-        const long long pt_base = segs[k_seg].pt_base;
-        if (i < pt_base + segs[k_seg].n_first) poolcore_w[segs[k_seg].out_off + (i - pt_base)] = 1;
-    }
-}
-
-// Cell-sorted COPY of the points (+ each point's slot): every neighbourhood scan below walks contiguous runs of
-// it.  Those scans are serial, latency-bound chains per lane (the kernel runs as long as its slowest lane), so
+// Cell-sorted COPY of the points (+ each point's slot, and the point of each slot): every neighbourhood scan below walks
+// contiguous runs of it.  Those scans are serial, latency-bound chains per lane (the kernel runs as long as its slowest lane), so
 // a candidate must cost one load, not the ord -> point -> flag chain of an index sort.
 // It also lists the points whose core status needs a neighbour COUNT (not an anchor core, cell holds fewer than
 // min_points): k_db_count gives each of them a whole wave.
 // Round 6: every OTHER point's status is known right here -- an anchor core, or a point of a cell that holds min_points points, is
-// core; a point a cropped anchor leaves outside its crop keeps the flag it came with -- so this pass settles them and k_db_count
-// settles the counted ones (until round 5: a separate k_db_core launch over all points behind the counts).
+// core; a point a cropped anchor leaves outside its crop keeps the flag it came with -- so this pass writes their flags (per point,
+// and per slot of the sorted copy: DB_SLOT_ANCHOR / DB_SLOT_CORE, 0 = to be counted), and what the flags mean for the CELL is worked
+// out by the wave that visits the cell anyway (k_db_cellbox) instead of by atomics from every point (until round 5: a separate
+// k_db_core launch over all points behind the counts).
+#define DB_SLOT_CORE 1
+#define DB_SLOT_ANCHOR 2
 __global__ void k_db_fill(const double* __restrict__ pts, long long N, const long long* __restrict__ cellid,
                           const unsigned* __restrict__ start, unsigned* __restrict__ cursor, unsigned* __restrict__ rank,
                           double* __restrict__ spts, const unsigned char* __restrict__ core0, int minpts,
-                          unsigned* __restrict__ needy, unsigned* __restrict__ n_needy, const int* __restrict__ segid,
-                          const DbSeg* __restrict__ segs, unsigned char* __restrict__ core, unsigned char* __restrict__ score,
-                          unsigned char* __restrict__ poolcore_w, unsigned* __restrict__ minidx, unsigned char* __restrict__ hasanchor,
-                          unsigned* __restrict__ active) {
+                          unsigned* __restrict__ needy, unsigned* __restrict__ n_needy, unsigned* __restrict__ sidx,
+                          unsigned char* __restrict__ core, unsigned char* __restrict__ score, unsigned char* __restrict__ hasanchor) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < N;
     bool need = false;
@@ -262,10 +236,14 @@ __global__ void k_db_fill(const double* __restrict__ pts, long long N, const lon
             const unsigned s0 = start[c];
             unsigned p = s0 + atomicAdd(&cursor[c], 1u);
             rank[i] = p;
+            sidx[p] = (unsigned)i;
             for (int a = 0; a < 3; ++a) spts[(size_t)p * 3 + a] = pts[(size_t)i * 3 + a];
             const bool known = core0 != nullptr && core0[i] != 0;
             need = !known && start[c + 1] - s0 < (unsigned)minpts;
-            if (!need) db_settle_point(i, c, p, true, known, segid[i], segs, core, score, poolcore_w, minidx, hasanchor, active);
+            score[p] = known ? DB_SLOT_ANCHOR : (need ? 0 : DB_SLOT_CORE);
+            if (!need) core[i] = 1;
+            // cells holding anchor cores are all connected: db_anchor_cells (k_db_cellbox's launch) hangs them under the segment's lowest one
+            if (known && !hasanchor[c]) hasanchor[c] = 1;
         } else if (c == DB_FAR) {
             // a forced segment's anchor point outside the crop: keeps its flag, takes part in nothing
             core[i] = (core0 != nullptr && core0[i] != 0) ? 1 : 0;
@@ -353,26 +331,20 @@ __device__ const signed char DB_COL[25][2] = {{0, 0},  {-1, 0}, {1, 0},  {0, -1}
 // contiguous ranges of the cell-sorted copy; lanes 0..24 look their range up side by side, the ranges are laid end
 // to end (wave prefix sum) and the 64 lanes test 64 candidates per trip -- a handful of L2 round trips per point instead
 // of the ~75 of one lane walking the columns one after the other.  core[i] = (neighbours within eps, the point itself
-// included, >= min_points), the same predicate as before; the wave's first lane then settles the point (db_settle_point).
-// The points that come out non-core need no list of their own: they are the entries of THIS list whose flag is 0 (k_db_label).
+// included, >= min_points), the same predicate as before.
+// The points that come out non-core are the entries of THIS list whose flag is 0 (k_db_rootmin compacts them for k_db_label).
 __global__ void __launch_bounds__(256) k_db_count(const double* __restrict__ pts, const int* __restrict__ segid,
                                                   const DbSeg* __restrict__ segs, const long long* __restrict__ cellid,
                                                   const unsigned* __restrict__ start, const double* __restrict__ spts, double eps2,
                                                   int minpts, const unsigned* __restrict__ needy,
-                                                  const unsigned* __restrict__ n_needy, unsigned char* __restrict__ core,
-                                                  const unsigned* __restrict__ rank, unsigned char* __restrict__ score,
-                                                  unsigned char* __restrict__ poolcore_w, unsigned* __restrict__ minidx,
-                                                  unsigned char* __restrict__ hasanchor, unsigned* __restrict__ active) {
+                                                  const unsigned* __restrict__ n_needy, unsigned char* __restrict__ core) {
     const int lane = threadIdx.x & 63;
     const unsigned nwaves = (gridDim.x * blockDim.x) >> 6, n = *n_needy;
     for (unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
         const long long i = needy[w];
-        const int k_seg = segid[i];
-        const long long c = cellid[i];
-        const unsigned slot = rank[i];
-        const DbSeg sg = segs[k_seg];
+        const DbSeg sg = segs[segid[i]];
         int ix, iy, iz;
-        cell_xyz(sg, c, ix, iy, iz);
+        cell_xyz(sg, cellid[i], ix, iy, iz);
         const double pi[3] = {pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2]};
         unsigned s0 = 0, len = 0;
         if (lane < 25) {
@@ -405,7 +377,7 @@ __global__ void __launch_bounds__(256) k_db_count(const double* __restrict__ pts
             if (t < total) hit = dist2_f64(spts + (size_t)(c_s0 + (t - (c_incl - c_len))) * 3, pi) < eps2;
             have += __popcll(__ballot(hit));
         }
-        if (lane == 0) db_settle_point(i, c, slot, have >= minpts, false, k_seg, segs, core, score, poolcore_w, minidx, hasanchor, active);
+        if (lane == 0) core[i] = have >= minpts ? 1 : 0;
     }
 }
 
@@ -520,27 +492,50 @@ __device__ __forceinline__ void uf_union_from(int* parent, int a, int b, const u
     }
 }
 
-// AABB of the core points of every core cell (one wave per cell)
+// One wave per occupied cell: AABB and number of its core points -- and, round 6, what the points' core flags mean for the cell
+// (until round 5 every point told its cell by atomics in a launch of its own): the slots of the counted points take their
+// flag over from k_db_count, minidx[c] = the cell's smallest core index (INF: none -- the later passes skip the cell), active[c] =
+// it holds a core point that is not an anchor (its connections have to be searched); a flag the batch promotes inside the
+// anchor member of a segment that runs in place is set where the point lives.  Indices are positions in the BATCH: they order a
+// segment's points like positions in the segment do.
 __global__ void k_db_cellbox(const double* __restrict__ pts, const int* __restrict__ corecells, const unsigned* __restrict__ ncore,
-                             const unsigned* __restrict__ cnt, const unsigned* __restrict__ start, const unsigned* __restrict__ ord,
-                             const unsigned char* __restrict__ core, double* __restrict__ cellbox,
+                             const unsigned* __restrict__ cnt, const unsigned* __restrict__ start, const unsigned* __restrict__ sidx,
+                             unsigned char* __restrict__ score, const unsigned char* __restrict__ core, double* __restrict__ cellbox,
                              unsigned* __restrict__ ccore, const int* __restrict__ cseg, const unsigned char* __restrict__ hasanchor,
-                             unsigned* __restrict__ rep, int* __restrict__ parent) {
-    // (the anchor cells' pre-connection rides in this launch: it needs what k_db_core left, like the boxes, and nothing of them)
+                             unsigned* __restrict__ rep, int* __restrict__ parent, const DbSeg* __restrict__ segs,
+                             unsigned* __restrict__ minidx, unsigned* __restrict__ active, unsigned char* __restrict__ poolcore_w) {
+    // (the anchor cells' pre-connection rides in this launch: it needs the cell list and k_db_fill's hasanchor[], and nothing of the boxes)
     if (rep) db_anchor_cells(corecells, ncore, cseg, hasanchor, rep, parent);
     const int lane = threadIdx.x & 63;
     const unsigned nwaves = (gridDim.x * blockDim.x) >> 6, ncells = *ncore;
     for (unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < ncells; w += nwaves) {
     const long long c = corecells[w];
     const unsigned s0 = start[c], e0 = s0 + cnt[c];
+    const int k_seg = cseg[c];
+    const int out_mode = segs[k_seg].out_mode;
     double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
     int ncorepts = 0;
-    for (unsigned k = s0 + lane; k < e0; k += 64) {
-        unsigned i = k;                          // (pts / core: the cell-sorted copies)
-        if (!core[i]) continue;
+    unsigned first = INF32;
+    bool act = false;
+    for (unsigned k = s0 + lane; k < e0; k += 64) {          // (pts / score: the cell-sorted copies)
+        unsigned char sc = score[k];
+        const unsigned i = sidx[k];
+        if (sc == 0) {                           // a counted point
+            sc = core[i] ? DB_SLOT_CORE : 0;
+            if (sc) score[k] = sc;
+        }
+        if (!sc) continue;
         ++ncorepts;
+        first = i < first ? i : first;
+        if (sc != DB_SLOT_ANCHOR) {
+            act = true;
+            if (out_mode == 2) {
+                const long long pt_base = segs[k_seg].pt_base;
+                if ((long long)i < pt_base + segs[k_seg].n_first) poolcore_w[segs[k_seg].out_off + ((long long)i - pt_base)] = 1;
+            }
+        }
         for (int a = 0; a < 3; ++a) {
-            double v = pts[(size_t)i * 3 + a];
+            double v = pts[(size_t)k * 3 + a];
             mn[a] = v < mn[a] ? v : mn[a];
             mx[a] = v > mx[a] ? v : mx[a];
         }
@@ -550,12 +545,19 @@ __global__ void k_db_cellbox(const double* __restrict__ pts, const int* __restri
         mx[a] = wave_max_f64(mx[a]);
     }
     ncorepts = wave_sum_i32(ncorepts);
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned t = __shfl_xor(first, o);
+        first = t < first ? t : first;
+    }
+    const bool any_act = __any(act) != 0;
     if (lane == 0) {
         for (int a = 0; a < 3; ++a) {
             cellbox[(size_t)w * 6 + a] = mn[a];
             cellbox[(size_t)w * 6 + 3 + a] = mx[a];
         }
         ccore[w] = (unsigned)ncorepts;           // core points of the cell (cluster sizes are summed per cell)
+        minidx[c] = first;
+        active[c] = any_act ? 1u : 0u;
     }
     }
 }
@@ -1633,7 +1635,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
         const size_t ntiles = ((size_t)NC + 1 + 1023) / 1024;
         const unsigned epoch = hmsg_scan_epoch(scan_tmp, 2 * ntiles, s);
         DbCellTables tb;
-        tb.cursor = cursor.p; tb.minidx = minidx.p; tb.firstidx = firstidx.p; tb.rootmin = rootmin.p; tb.size = size.p; tb.active = active.p;
+        tb.cursor = cursor.p; tb.minidx = minidx.p; tb.firstidx = firstidx.p; tb.rootmin = rootmin.p; tb.size = size.p;
         tb.hasanchor = hasanchor.p; tb.cells = corelist.p; tb.cellpos = cellpos.p; tb.parent = parent.p; tb.cseg = cseg.p; tb.n_cells = d_nc;
         unsigned long long* const st = reinterpret_cast<unsigned long long*>(scan_tmp.p);
         hipLaunchKernelGGL(k_db_scan, dim3((unsigned)ntiles), dim3(256), 0, s, (const unsigned*)cnt.p, start.p, NC, st, st + ntiles, epoch, dsegs, K, tb);
@@ -1642,23 +1644,23 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     spts.ensure((size_t)N * 3);
     score.ensure(N);
     needy.ensure((size_t)std::max<long long>(N, 1));
+    sidx.ensure((size_t)std::max<long long>(N, 1));
     nclist.ensure((size_t)std::max<long long>(N, 1));
     unsigned char* const pc_w = gather ? gather->poolcore_w : (unsigned char*)nullptr;
     {
     ProfScope ps(prof, s, "k_db_core", (double)N * 33.0);    // (k_db_fill + k_db_count: sorted copy, core flags -- one timed unit)
     hipLaunchKernelGGL(k_db_fill, dim3(gN), dim3(256), 0, s, src, N, (const long long*)cellid.p, (const unsigned*)start.p, cursor.p,
-                       ord.p, spts.p, core0, min_points, needy.p, d_nc + 3, (const int*)segid.p, dsegs, core.p, score.p, pc_w, minidx.p,
-                       hasanchor.p, active.p);       // ord: slot of every point in the cell-sorted copy
+                       ord.p, spts.p, core0, min_points, needy.p, d_nc + 3, sidx.p, core.p, score.p, hasanchor.p);   // ord: slot of every point in the cell-sorted copy
     hipLaunchKernelGGL(k_db_count, dim3((unsigned)n_cu * 8u), dim3(256), 0, s, src, (const int*)segid.p, dsegs, (const long long*)cellid.p,
                        (const unsigned*)start.p, (const double*)spts.p, eps * eps, min_points, (const unsigned*)needy.p,
-                       (const unsigned*)(d_nc + 3), core.p, (const unsigned*)ord.p, score.p, pc_w, minidx.p, hasanchor.p, active.p);
+                       (const unsigned*)(d_nc + 3), core.p);
     }
-    // persistent grid (8 blocks per CU): waves / threads stride over the core-cell list
+    // persistent grid (8 blocks per CU): waves / threads stride over the cell list
     const unsigned gW = (unsigned)n_cu * 8u;
     hipLaunchKernelGGL(k_db_cellbox, dim3(gW), dim3(256), 0, s, (const double*)spts.p, (const int*)corelist.p,
-                       (const unsigned*)d_nc, (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)ord.p,
-                       (const unsigned char*)score.p, cellbox.p, ccore.p, (const int*)cseg.p, (const unsigned char*)hasanchor.p,
-                       core0 ? rep.p : (unsigned*)nullptr, parent.p);
+                       (const unsigned*)d_nc, (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)sidx.p,
+                       score.p, (const unsigned char*)core.p, cellbox.p, ccore.p, (const int*)cseg.p, (const unsigned char*)hasanchor.p,
+                       core0 ? rep.p : (unsigned*)nullptr, parent.p, dsegs, minidx.p, active.p, pc_w);
     {
         ProfScope ps(prof, s, "k_db_union/box", (double)N * 24.0);
         hipLaunchKernelGGL(k_db_union, dim3(gW), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc, (const int*)cseg.p, dsegs, K,
