@@ -6,6 +6,8 @@
 #pragma once
 #include "hmsg_common.h"
 
+#include <functional>
+
 struct SegDesc {                 // one cloud of a batch, points at src[pt_base .. pt_base+n)
     long long pt_base;
     int n;
@@ -109,7 +111,14 @@ struct CloudOps {
     // result is identical to a run without the hint.  dst_core (optional): core flag of every output point.
     long long dbscan_keep_largest(const double* src, const std::vector<SegDesc>& segs, double eps, int min_points,
                                   double* dst, std::vector<DbscanResult>& res, const unsigned char* core0 = nullptr,
-                                  unsigned char* dst_core = nullptr, const DbGather* gather = nullptr);
+                                  unsigned char* dst_core = nullptr, const DbGather* gather = nullptr,
+                                  const std::function<void(const unsigned* d_res, int K)>& behind_publish = nullptr);
+    // behind_publish (optional): called when every launch of the batch AND the publish of its results are enqueued, before the
+    // host waits for them -- work the caller enqueues there runs on the GPU while the host reads the results and does its
+    // bookkeeping (the merge fold indexes the batch's output clouds that way: their sizes are read from d_res on the device).
+    // d_res = the batch's result words as they will be published: per segment k of K
+    //   [k] output end | [K + k] clusters | [2K + k] contested | [3K + k] dropped | [4K ..] 6 x u64 box | [16K .. 16K + 8) counters |
+    //   [16K + 8 + k] output start | [17K + 8 + k] end of the first member's output   (positions in the segment's output chain)
     // gather: `src` is an EMPTY buffer of the batch's size; the binning pass fills it (and core0's buffer, gather->dstcore)
     // from the pool pieces while it bins -- one launch and one pass over the points less than a separate concatenation.
     // Open3D voxel_down_sample of every segment; outputs consecutively to dst (capacity >= total input

@@ -1440,7 +1440,8 @@ bool CloudOps::regions_supported() {
 
 long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<SegDesc>& segs, double eps, int min_points,
                                         double* dst, std::vector<DbscanResult>& res, const unsigned char* core0,
-                                        unsigned char* dst_core, const DbGather* gather) {
+                                        unsigned char* dst_core, const DbGather* gather,
+                                        const std::function<void(const unsigned* d_res, int K)>& behind_publish) {
     const int K = (int)segs.size();
     res.assign(K, DbscanResult{});
     if (K == 0) return 0;
@@ -1731,6 +1732,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     }
     // one copy brings back counts, cluster counts, contest flags and the boxes of the kept points
     pub.launch(s, (const unsigned*)kres.p, (size_t)K * 18 + 8);
+    if (behind_publish && !split_compact) behind_publish((const unsigned*)kres.p, K);
     pub.wait();
     const unsigned* hres = pub.data();
     const unsigned long long* hb = reinterpret_cast<const unsigned long long*>(hres + (size_t)K * 4);

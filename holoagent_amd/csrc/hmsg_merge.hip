@@ -64,6 +64,7 @@ struct Cloud {
     bool has_delta = false;
     long long ix_cell2 = 0, ix_pt2 = 0;
     int gd2[3] = {0, 0, 0};
+    float dmn[3] = {0, 0, 0};        // float32 lower corner the delta grid was laid out on
 };
 
 // Work lists: the per-cloud kernels below get ONE workgroup per chunk of a cloud (blk0 = first workgroup of the
@@ -94,6 +95,56 @@ struct OvTask {             // count points of grid[x] within r of grid[y]
     int dep_n;              // second-direction tasks: number of points of the pair's smaller cloud (see k_ov_query)
     int blk0;               // first workgroup of this task (work list)
 };
+
+// Round 6 -- the overlap grids of a fold step's OUTPUT clouds are built while the host still waits for that step's DBSCAN batch
+// (Merger::speculate_indices).  The host cannot know yet how many points a merged cloud keeps, nor whether its first member came
+// through whole (only then its base grid is taken over) -- the device can: one entry per output cloud, laid out by the host on the
+// segment's INPUT box (every kept point lies in it) with room for all input points, and k_ov_spec fills in which points the grid
+// indexes from the batch's result words.  ov_spec_decide is that decision, evaluated by the device for the build and by the host,
+// once the results have arrived, for its bookkeeping: 0 nothing to build (a single cloud that came through unchanged keeps the
+// grids it has; an empty cloud has none), 1 the first member's base grid covers the whole cloud, 2 that base grid + a delta grid
+// over the points behind it, 3 a grid over the whole cloud.
+struct OvSpec {
+    OvGrid g;
+    int seg, singleton, inherit, nb_first, n_first, n_in, out_mode, delta_always;
+    long long out_off;      // mode 1 / 2: the cloud's first point in the pool; mode 0: first point of the dense outputs (its place among them is added)
+    long long ncell;
+};
+__host__ __device__ inline int ov_spec_decide(const OvSpec& sp, int n_out, int first_kept, int* first, int* n_idx) {
+    *first = 0;
+    *n_idx = 0;
+    if (n_out <= 0) return 0;
+    if (sp.singleton && n_out == sp.n_in) return 0;
+    const bool inherit = sp.inherit && first_kept >= 0 && first_kept == sp.n_first && sp.nb_first > 0;
+    if (inherit && sp.nb_first == n_out) return 1;
+    // (build_indices' rule: an inherited base grid stays while what the cloud has gained since is a quarter of it at most and the
+    //  grid of the gain, laid out on the whole box, is not mostly cells)
+    const bool delta = inherit && sp.nb_first < n_out &&
+                       (sp.delta_always || ((long long)(n_out - sp.nb_first) * 4 <= (long long)sp.nb_first && sp.ncell <= 4ll * sp.nb_first));
+    *first = delta ? sp.nb_first : 0;
+    *n_idx = n_out - *first;
+    return delta ? 2 : 3;
+}
+// the batch's result words -> (points kept, points kept of the first member): CloudOps::dbscan_keep_largest's own read-back formulas
+__host__ __device__ inline void ov_spec_result(const OvSpec& sp, const unsigned* res, int K, int* n_out, int* first_kept, int* start) {
+    const int oend = (int)res[sp.seg], ostart = (int)res[(size_t)K * 16 + 8 + sp.seg], ofirst = (int)res[(size_t)K * 17 + 8 + sp.seg];
+    *start = ostart;
+    *n_out = sp.out_mode == 2 ? sp.n_first + oend : oend - ostart;
+    *first_kept = sp.n_first <= 0 ? -1 : (sp.out_mode == 2 ? sp.n_first : (sp.n_first < sp.n_in ? ofirst - ostart : *n_out));
+}
+__global__ void k_ov_spec(const OvSpec* __restrict__ spec /* pinned host memory */, int nspec, const unsigned* __restrict__ res, int K,
+                          OvGrid* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nspec) return;
+    const OvSpec sp = spec[j];
+    int n_out, first_kept, start, first, n_idx;
+    ov_spec_result(sp, res, K, &n_out, &first_kept, &start);
+    ov_spec_decide(sp, n_out, first_kept, &first, &n_idx);
+    OvGrid g = sp.g;
+    g.n = n_idx;
+    g.pt_off = sp.out_off + (sp.out_mode == 0 ? (long long)start : 0ll) + first;
+    out[j] = g;
+}
 
 }  // namespace
 
@@ -498,6 +549,14 @@ struct Merger {
     // copy has completed: every overlap step ends with a wait on the stream)
     PinnedBuf<char> h_ovpack;
     DevBuf<char> d_ovpack;
+    // grids of a step's output clouds, built behind the DBSCAN batch's publish (speculate_indices)
+    PinnedBuf<OvSpec> h_spec[2];               // (two sets, used in turn: a step without candidate pairs waits for nothing between two
+    DevBuf<OvGrid> d_spec[2];                  //  batches, and the GPU may still be reading the previous step's table)
+    int spec_turn = 0;
+    std::vector<OvSpec> spec;                  // this step's entries (host copy: the bookkeeping replays the device's decisions)
+    std::vector<int> spec_of_seg;
+    bool spec_wanted = getenv("HMSG_DEBUG_NO_SPEC_INDEX") == nullptr;   // HMSG_DEBUG_NO_SPEC_INDEX=1: every grid is built at the start of the next step (round 5)
+    double spec_built = 0, spec_built_pts = 0, spec_skipped = 0;        // (statistics)
     size_t cursor_clean = 0;        // entries of d_cursor known to be zero (k_ov_fill counts every cell back down to zero)
     SpinWait spin;
     unsigned long long next_uid = 1;
@@ -561,9 +620,8 @@ struct Merger {
     void push_grids(const Cloud& c, std::vector<OvGrid>& g) const {
         g.push_back(grid_at(c, c.bmn, c.gd, c.ix_cell, c.ix_pt, c.off, c.n));
         if (c.has_delta) {
-            const float lo[3] = {(float)c.mn[0], (float)c.mn[1], (float)c.mn[2]};
             g.back().next = (int)g.size();
-            g.push_back(grid_at(c, lo, c.gd2, c.ix_cell2, c.ix_pt2, c.off + c.nb, c.n - c.nb));
+            g.push_back(grid_at(c, c.dmn, c.gd2, c.ix_cell2, c.ix_pt2, c.off + c.nb, c.n - c.nb));
         }
     }
 
@@ -590,7 +648,10 @@ struct Merger {
             if (delta) {
                 first = c.nb;
                 c.has_delta = true;
-                for (int a = 0; a < 3; ++a) c.gd2[a] = gd[a];
+                for (int a = 0; a < 3; ++a) {
+                    c.gd2[a] = gd[a];
+                    c.dmn[a] = lo[a];
+                }
                 c.ix_cell2 = ix_cells_used + ncell_new;
                 c.ix_pt2 = ix_pts_used;                  // (cell starts are relative to the BATCH's first sorted point)
                 g.push_back(grid_at(c, lo, c.gd2, c.ix_cell2, c.ix_pt2, c.off + first, c.n - first));
@@ -721,6 +782,92 @@ struct Merger {
     size_t gc_index_entries = (size_t)1 << 31;       // grid cells (8 GB) / sorted points (26 GB)
     int n_collects = 0;
     static constexpr size_t PREBUILD_WINDOW = 64;    // frames (one fusion batch; measured: the overlap scans of a 1000-frame fold take 90 ms with 64-frame windows, 110 ms with one 1024-frame window)
+
+    // ---- Overlap grids of the clouds a DBSCAN batch is about to put out, enqueued BEHIND the batch's publish: the GPU builds them
+    // while the host waits for the results, reads them and does its bookkeeping (the ~40 us of index kernels used to open the
+    // next step, in front of its overlap scans).  One entry per segment, merged components first and single clouds last (a single
+    // cloud nearly always comes through unchanged and keeps its grids: the cells reserved for the trailing entries nobody used
+    // are handed back).  Layout on the segment's input box; what is indexed is decided on the device (k_ov_spec).
+    void speculate_indices(const std::vector<Cloud>& L, const CompList& comps, const std::vector<int>& seg_of_comp,
+                           const std::vector<SegDesc>& segs, long long out_base, const unsigned* d_res, int K) {
+        spec.clear();
+        spec_of_seg.assign(segs.size(), -1);
+        long long ncell_new = 0, npts_max = 0;
+        unsigned nblk = 0;
+        for (int pass = 0; pass < 2; ++pass)
+            for (size_t c = 0; c < comps.size(); ++c) {
+                const int sg = seg_of_comp[c];
+                if (sg < 0) continue;
+                const auto& mem = comps[c];
+                if ((mem.size() == 1) != (pass == 1)) continue;
+                const SegDesc& sd = segs[(size_t)sg];
+                if (sd.n <= 0) continue;
+                int f = -1;
+                for (int i : mem)
+                    if (L[i].n > 0) {
+                        f = i;
+                        break;
+                    }
+                Cloud box;                                   // (carrier of the input box for grid_at)
+                for (int a = 0; a < 3; ++a) {
+                    box.mn[a] = sd.mn[a];
+                    box.mx[a] = sd.mx[a];
+                }
+                const float lo[3] = {(float)sd.mn[0], (float)sd.mn[1], (float)sd.mn[2]};
+                int gd[3];
+                for (int a = 0; a < 3; ++a) gd[a] = (int)std::floor(((double)(float)sd.mx[a] - (double)lo[a] + 2e-3) / cell) + 1;
+                const long long ncell = (long long)gd[0] * gd[1] * gd[2] + 1;   // +1: end sentinel
+                OvSpec sp;
+                sp.g = grid_at(box, lo, gd, ix_cells_used + ncell_new, ix_pts_used, 0, 0);
+                sp.g.blk0 = (int)nblk;
+                sp.seg = sg;
+                sp.singleton = mem.size() == 1 ? 1 : 0;
+                sp.inherit = (inherit_grids && f >= 0 && L[f].has_index && L[f].nb > 0) ? 1 : 0;
+                sp.nb_first = f >= 0 ? L[f].nb : 0;
+                sp.n_first = sd.n_first;
+                sp.n_in = sd.n;
+                sp.out_mode = sd.out_mode;
+                sp.delta_always = delta_always ? 1 : 0;
+                sp.out_off = sd.out_mode ? sd.out_off : out_base;
+                sp.ncell = ncell;
+                spec_of_seg[(size_t)sg] = (int)spec.size();
+                spec.push_back(sp);
+                nblk += cdiv((size_t)sd.n, OVI_CHUNK);
+                ncell_new += ncell;
+                npts_max += sd.n;
+            }
+        if (spec.empty()) return;
+        if (!(ncell_new < (1ll << 31) && npts_max < (1ll << 31))) {      // (a batch of grids is bounded by its 32-bit cell starts: the next step builds them)
+            spec.clear();
+            spec_of_seg.assign(segs.size(), -1);
+            return;
+        }
+        grow(ix_cells, (size_t)ix_cells_used, (size_t)(ix_cells_used + ncell_new));
+        grow(ix_pts, (size_t)ix_pts_used * 3, (size_t)(ix_pts_used + npts_max) * 3);
+        spec_turn ^= 1;
+        PinnedBuf<OvSpec>& hs = h_spec[spec_turn];
+        DevBuf<OvGrid>& ds = d_spec[spec_turn];
+        hs.ensure(spec.size());
+        ds.ensure(spec.size());
+        memcpy(hs.p, spec.data(), spec.size() * sizeof(OvSpec));
+        hipLaunchKernelGGL(k_ov_spec, dim3(cdiv(spec.size(), 64)), dim3(64), 0, s, (const OvSpec*)hs.p, (int)spec.size(), d_res, K, ds.p);
+        {   // (the cursor is zero whenever k_ov_fill has run over what k_ov_count counted: only fresh memory is cleared)
+            const unsigned* before = d_cursor.p;
+            d_cursor.ensure((size_t)ncell_new);
+            if (d_cursor.p != before) cursor_clean = 0;
+            if (cursor_clean < (size_t)ncell_new) {
+                HIP_TRY(hipMemsetAsync(d_cursor.p, 0, d_cursor.n * 4, s));
+                cursor_clean = d_cursor.n;
+            }
+        }
+        hipLaunchKernelGGL(k_ov_count, dim3(nblk), dim3(256), 0, s, (const double*)pool.p, (const OvGrid*)ds.p, (int)spec.size(),
+                           d_cursor.p, ix_cells_used, OVI_CHUNK);
+        HMSG_CHECK_LAUNCH();
+        hmsg_scan_u32(d_cursor.p, ix_cells.p + ix_cells_used, (size_t)ncell_new, s, ops.scan_tmp, nullptr);
+        hipLaunchKernelGGL(k_ov_fill, dim3(nblk), dim3(256), 0, s, (const double*)pool.p, (const OvGrid*)ds.p, (int)spec.size(),
+                           (const unsigned*)ix_cells.p, d_cursor.p, ix_cells_used, ix_pts.p, OVI_CHUNK);
+        HMSG_CHECK_LAUNCH();
+    }
 
     // ---- overlap ratios for a list of (i, j) pairs of L.  `decide_th` >= 0 (sequential merge): only `ratio > th`
     // is needed downstream, so the pair's smaller cloud is counted first and the scan of the larger one is skipped on
@@ -1086,8 +1233,14 @@ struct Merger {
             ga.dstcore = use_anchor ? concat_core.p : nullptr;
             ga.pool_w = pool.p;
             ga.poolcore_w = poolcore.p;
+            spec.clear();
+            spec_of_seg.assign(segs.size(), -1);
+            const bool speculate = spec_wanted && CloudOps::regions_supported();
             ops.dbscan_keep_largest(concat.p, segs, eps, minpts, pool.p + (size_t)out_base * 3, res,
-                                    use_anchor ? (const unsigned char*)concat_core.p : nullptr, poolcore.p + out_base, &ga);
+                                    use_anchor ? (const unsigned char*)concat_core.p : nullptr, poolcore.p + out_base, &ga,
+                                    speculate ? std::function<void(const unsigned*, int)>([&](const unsigned* d_res, int K) {
+                                        speculate_indices(L, comps, seg_of_comp, segs, out_base, d_res, K);
+                                    }) : std::function<void(const unsigned*, int)>());
             lap(4);
             if (want_stats) {
                 for (size_t c = 0; c < comps.size(); ++c) {
@@ -1148,6 +1301,33 @@ struct Merger {
             }
         } else {
             res.assign(segs.size(), DbscanResult{});
+            spec.clear();
+            spec_of_seg.assign(segs.size(), -1);
+        }
+        // the grids built behind the batch: which of them exist (the device's decisions, replayed from the results) and how much
+        // of the arenas they took -- sorted points densely one grid after the other, cells as laid out up to the last grid in use
+        std::vector<int> spec_code(spec.size(), 0), spec_first(spec.size(), 0);
+        std::vector<long long> spec_pt(spec.size(), 0);
+        {
+            long long pts = 0, cells_end = 0;
+            for (size_t j = 0; j < spec.size(); ++j) {
+                const DbscanResult& r = res[(size_t)spec[j].seg];
+                int n_idx = 0;
+                spec_code[j] = ov_spec_decide(spec[j], r.n_out, r.first_kept, &spec_first[j], &n_idx);
+                spec_pt[j] = pts;
+                pts += n_idx;
+                if (n_idx > 0) {
+                    cells_end = (spec[j].g.ix_cell - ix_cells_used) + spec[j].ncell;
+                    spec_built += 1;
+                    spec_built_pts += n_idx;
+                } else {
+                    spec_skipped += 1;
+                }
+            }
+            // (all of this step's grids share ix_pt = the arena level before them: cell starts are relative to it)
+            for (size_t j = 0; j < spec.size(); ++j) spec_pt[j] = ix_pts_used;
+            ix_cells_used += cells_end;
+            ix_pts_used += pts;
         }
         // 4. new list in component order
         std::vector<Cloud> out;
@@ -1198,23 +1378,45 @@ struct Merger {
             k.uid = next_uid++;
             // the first member came through whole: its points are this cloud's first points, in order, and its BASE grid
             // (a sorted copy of exactly its first nb points) goes on answering for them
-            if (inherit_grids && r.first_kept >= 0) {
-                int f = -1;
-                for (int i : mem)
-                    if (L[i].n > 0) {
-                        f = i;
-                        break;
-                    }
-                if (f >= 0 && r.first_kept == L[f].n && L[f].has_index && L[f].nb > 0) {
-                    k.nb = L[f].nb;
-                    k.ix_cell = L[f].ix_cell;
-                    k.ix_pt = L[f].ix_pt;
-                    for (int a = 0; a < 3; ++a) {
-                        k.gd[a] = L[f].gd[a];
-                        k.bmn[a] = L[f].bmn[a];
-                    }
-                    k.has_index = k.nb == k.n;
+            int f = -1;
+            for (int i : mem)
+                if (L[i].n > 0) {
+                    f = i;
+                    break;
                 }
+            auto take_base = [&] {
+                k.nb = L[f].nb;
+                k.ix_cell = L[f].ix_cell;
+                k.ix_pt = L[f].ix_pt;
+                for (int a = 0; a < 3; ++a) {
+                    k.gd[a] = L[f].gd[a];
+                    k.bmn[a] = L[f].bmn[a];
+                }
+            };
+            const int sj = spec_of_seg.empty() ? -1 : spec_of_seg[(size_t)sg];
+            if (sj >= 0) {
+                // its grids exist already (speculate_indices): 1 the first member's base grid covers it, 2 base + delta, 3 a grid of its own
+                const OvSpec& sp = spec[(size_t)sj];
+                const int code = spec_code[(size_t)sj];
+                if (code == 1 || code == 2) take_base();
+                if (code == 2) {
+                    k.has_delta = true;
+                    k.ix_cell2 = sp.g.ix_cell;
+                    k.ix_pt2 = spec_pt[(size_t)sj];
+                    k.gd2[0] = sp.g.gx, k.gd2[1] = sp.g.gy, k.gd2[2] = sp.g.gz;
+                    for (int a = 0; a < 3; ++a) k.dmn[a] = (float)segs[sg].mn[a];
+                }
+                if (code == 3) {
+                    k.nb = k.n;
+                    k.ix_cell = sp.g.ix_cell;
+                    k.ix_pt = spec_pt[(size_t)sj];
+                    k.gd[0] = sp.g.gx, k.gd[1] = sp.g.gy, k.gd[2] = sp.g.gz;
+                    for (int a = 0; a < 3; ++a) k.bmn[a] = (float)segs[sg].mn[a];
+                }
+                k.has_index = code != 0;
+            } else if (inherit_grids && r.first_kept >= 0 && f >= 0 && r.first_kept == L[f].n && L[f].has_index && L[f].nb > 0) {
+                take_base();
+                k.has_index = k.nb == k.n;
             }
             out.push_back(k);
             if (!mode) cursor += r.n_out;
@@ -1429,8 +1631,8 @@ static void merge_report(Folder& m) {
                     t.cmulti[c], t.ccontested[c], t.cnonfixed[c]);
     }
     if (getenv("HMSG_DEBUG_TIMING"))
-        fprintf(stderr, "[hmsg merge] overlap grids: %.0f over whole clouds (%.0f points), %.0f delta grids (%.0f points)\n", m.grid_full,
-                m.grid_full_pts, m.grid_delta, m.grid_delta_pts);
+        fprintf(stderr, "[hmsg merge] overlap grids: %.0f over whole clouds (%.0f points), %.0f delta grids (%.0f points); behind the DBSCAN batches: %.0f built (%.0f points), %.0f not needed\n", m.grid_full,
+                m.grid_full_pts, m.grid_delta, m.grid_delta_pts, m.spec_built, m.spec_built_pts, m.spec_skipped);
     if (getenv("HMSG_DEBUG_TIMING") && m.n_collects)
         fprintf(stderr, "[hmsg merge] %d collections of the point pool / grid arenas\n", m.n_collects);
     if (getenv("HMSG_DEBUG_TIMING") && m.ops.stat_calls > 0)
