@@ -1095,9 +1095,12 @@ class NodeIndex:
     def query_hier(self, T_obj, qid, T_room, floor_id, room_mode, k, use_negatives=True, max_rooms=None):
         """floor -> room(s) -> objects on the device (include/hmsg.h: hmsg_query_hier).  Returns (rooms per query as
         query_hmsg_room reports them, idx [Q, k], room [Q, k] (global ids), score [Q, k])."""
-        T_obj = np.ascontiguousarray(T_obj, dtype=np.float32)
+        # (text rows: numpy arrays, or float32 torch tensors -- on the device they are used where they are: hmsg.h, "host or device pointers")
+        if not hasattr(T_obj, "data_ptr"):
+            T_obj = np.ascontiguousarray(T_obj, dtype=np.float32)
         Q, Cn, D = T_obj.shape
-        T_room = None if T_room is None else np.ascontiguousarray(T_room, dtype=np.float32)
+        if T_room is not None and not hasattr(T_room, "data_ptr"):
+            T_room = np.ascontiguousarray(T_room, dtype=np.float32)
         qid = np.ascontiguousarray(qid, dtype=np.int32)
         floor_id = np.ascontiguousarray(floor_id, dtype=np.int32)
         room_mode = np.ascontiguousarray(room_mode, dtype=np.int32)

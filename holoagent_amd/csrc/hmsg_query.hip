@@ -52,6 +52,12 @@ struct hmsg_index {
     DevBuf<float> Tr;
     DevBuf<double> Tr64;
     DevBuf<int> d_floor, d_mode, d_sel, d_nsel, d_err;
+    // hmsg_query_hier: the per-query words in (floor | mode | qid) and every result out (score | sel | nsel | err | idx | room) travel as
+    // ONE packed copy each way through pinned memory (round 5: three pageable uploads and six pageable read-backs per call)
+    PinnedBuf<int> h_qin;
+    DevBuf<int> d_qin;
+    PinnedBuf<char> h_qout;
+    DevBuf<char> d_qout;
     Prof prof;                   // live timing of the GEMM (hmsg_index_set_profiling)
 };
 
@@ -687,19 +693,35 @@ int hmsg_query_hier(hmsg_index_t* ix, int32_t Q, int32_t C, const float* T_obj, 
             if (need_view && ix->n_views) gemm(ix, ix->Tr64.p, Q, ix->S_view.p, ix->view_emb.p, ix->n_views);
         }
         lap("room text + room GEMM");
-        ix->d_floor.ensure(Q);
-        ix->d_mode.ensure(Q);
-        ix->d_sel.ensure((size_t)Q * max_rooms);
-        ix->d_nsel.ensure(Q);
-        ix->d_err.ensure(Q);
+        // per-query words: one packed upload from pinned memory
+        const bool qid_dev = dev_ptr(qid);
+        ix->h_qin.ensure((size_t)Q * 3 + 4);
+        ix->d_qin.ensure((size_t)Q * 3 + 4);
+        memcpy(ix->h_qin.p, hf.data(), (size_t)Q * 4);
+        memcpy(ix->h_qin.p + Q, hm.data(), (size_t)Q * 4);
+        if (!qid_dev) memcpy(ix->h_qin.p + 2 * (size_t)Q, qid, (size_t)Q * 4);
+        upload_pinned(ix->d_qin.p, ix->h_qin.p, (((size_t)Q * 3 + 3) / 4) * 16, ix->stream);
+        int* const d_floor = ix->d_qin.p;
+        int* const d_mode = ix->d_qin.p + Q;
+        int* const d_qid = ix->d_qin.p + 2 * (size_t)Q;
+        if (qid_dev) HIP_TRY(hipMemcpyAsync(d_qid, qid, (size_t)Q * 4, hipMemcpyDeviceToDevice, ix->stream));
+        // results: one packed buffer [score f64 Q*k | sel Q*max_rooms | nsel Q | err Q | idx Q*k | room Q*k]
+        const size_t o_sel = (size_t)Q * k * 8, o_nsel = o_sel + (size_t)Q * max_rooms * 4, o_err = o_nsel + (size_t)Q * 4,
+                     o_idx = o_err + (size_t)Q * 4, o_room = o_idx + (size_t)Q * k * 4, out_bytes = o_room + (size_t)Q * k * 4;
+        ix->d_qout.ensure(out_bytes);
+        ix->h_qout.ensure(out_bytes);
+        double* const d_oscore = (double*)ix->d_qout.p;
+        int* const d_sel = (int*)(ix->d_qout.p + o_sel);
+        int* const d_nsel = (int*)(ix->d_qout.p + o_nsel);
+        int* const d_err = (int*)(ix->d_qout.p + o_err);
+        int* const d_oidx = (int*)(ix->d_qout.p + o_idx);
+        int* const d_oroom = (int*)(ix->d_qout.p + o_room);
         ix->d_rooms.ensure((size_t)Q * max_rooms);
         ix->d_roff.ensure((size_t)Q + 1);
-        HIP_TRY(hipMemcpyAsync(ix->d_floor.p, hf.data(), (size_t)Q * 4, hipMemcpyHostToDevice, ix->stream));
-        HIP_TRY(hipMemcpyAsync(ix->d_mode.p, hm.data(), (size_t)Q * 4, hipMemcpyHostToDevice, ix->stream));
         hipLaunchKernelGGL(k_room_select, dim3(Q), dim3(256), 0, ix->stream, R, ix->n_floors, (const double*)ix->S_room.p,
                            (const double*)ix->S_view.p, ix->n_views, (const int*)ix->view_off.p, (const int*)ix->room_key.p,
-                           (const int*)ix->floor_room_off.p, (const int*)ix->floor_rooms.p, (const int*)ix->d_floor.p,
-                           (const int*)ix->d_mode.p, max_rooms, ix->d_sel.p, ix->d_nsel.p, ix->d_rooms.p, ix->d_err.p);
+                           (const int*)ix->floor_room_off.p, (const int*)ix->floor_rooms.p, (const int*)d_floor,
+                           (const int*)d_mode, max_rooms, d_sel, d_nsel, ix->d_rooms.p, d_err);
         hipLaunchKernelGGL(k_fill_offsets, dim3(cdiv((size_t)Q + 1, 256)), dim3(256), 0, ix->stream, ix->d_roff.p, Q, max_rooms);
         HMSG_CHECK_LAUNCH();
         lap("room select");
@@ -711,24 +733,30 @@ int hmsg_query_hier(hmsg_index_t* ix, int32_t Q, int32_t C, const float* T_obj, 
         lap("S alloc");
         gemm(ix, ix->T64.p, Q * C, ix->S.p);
         lap("object GEMM");
-        ix->d_qid.ensure(Q);
-        ix->d_oidx.ensure((size_t)Q * k);
-        ix->d_oroom.ensure((size_t)Q * k);
-        ix->d_oscore.ensure((size_t)Q * k);
-        HIP_TRY(hipMemcpyAsync(ix->d_qid.p, qid, (size_t)Q * 4, dev_ptr(qid) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ix->stream));
-        hipLaunchKernelGGL(k_query_topk, dim3(Q), dim3(256), 0, ix->stream, (const double*)ix->S.p, ix->N, C, (const int*)ix->d_qid.p,
+        hipLaunchKernelGGL(k_query_topk, dim3(Q), dim3(256), 0, ix->stream, (const double*)ix->S.p, ix->N, C, (const int*)d_qid,
                            (const int*)ix->d_roff.p, (const int*)ix->d_rooms.p, (const int*)ix->room_off.p,
-                           (const int*)ix->room_nodes.p, ix->n_rooms, k, use_negatives, ix->d_oidx.p, ix->d_oroom.p, ix->d_oscore.p);
+                           (const int*)ix->room_nodes.p, ix->n_rooms, k, use_negatives, d_oidx, d_oroom, d_oscore);
         HMSG_CHECK_LAUNCH();
         lap("top-k");
-        std::vector<int> herr((size_t)Q);
-        HIP_TRY(hipMemcpyAsync(out_sel, ix->d_sel.p, (size_t)Q * max_rooms * 4, hipMemcpyDeviceToHost, ix->stream));
-        HIP_TRY(hipMemcpyAsync(out_nsel, ix->d_nsel.p, (size_t)Q * 4, hipMemcpyDeviceToHost, ix->stream));
-        HIP_TRY(hipMemcpyAsync(herr.data(), ix->d_err.p, (size_t)Q * 4, hipMemcpyDeviceToHost, ix->stream));
-        HIP_TRY(hipMemcpyAsync(out_idx, ix->d_oidx.p, (size_t)Q * k * 4, hipMemcpyDeviceToHost, ix->stream));
-        HIP_TRY(hipMemcpyAsync(out_room, ix->d_oroom.p, (size_t)Q * k * 4, hipMemcpyDeviceToHost, ix->stream));
-        HIP_TRY(hipMemcpyAsync(out_score, ix->d_oscore.p, (size_t)Q * k * 8, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(hipMemcpyAsync(ix->h_qout.p, ix->d_qout.p, out_bytes, hipMemcpyDeviceToHost, ix->stream));
         HIP_TRY(hipStreamSynchronize(ix->stream));
+        const int* const herr = (const int*)(ix->h_qout.p + o_err);
+        // (results into the caller's arrays: host memory, or device memory -- the reference's callers take numpy arrays)
+        bool any_dev = false;
+        auto give = [&](void* dst, size_t off, size_t bytes) {
+            if (dev_ptr(dst)) {
+                HIP_TRY(hipMemcpyAsync(dst, ix->d_qout.p + off, bytes, hipMemcpyDeviceToDevice, ix->stream));
+                any_dev = true;
+            } else {
+                memcpy(dst, ix->h_qout.p + off, bytes);
+            }
+        };
+        give(out_score, 0, (size_t)Q * k * 8);
+        give(out_sel, o_sel, (size_t)Q * max_rooms * 4);
+        give(out_nsel, o_nsel, (size_t)Q * 4);
+        give(out_idx, o_idx, (size_t)Q * k * 4);
+        give(out_room, o_room, (size_t)Q * k * 4);
+        if (any_dev) HIP_TRY(hipStreamSynchronize(ix->stream));
         lap("read-back");
         for (int q = 0; q < Q; ++q)
             HMSG_REQUIRE(!herr[(size_t)q], HMSG_ERR_INVALID,

@@ -700,17 +700,20 @@ void hmsg_cpu_instance_points(void* h, double* p) {
     }
 }
 void hmsg_cpu_instance_feats(void* h, float* f) { memcpy(f, ((Ctx*)h)->inst_feats.data(), ((Ctx*)h)->inst_feats.size() * 4); }
-// query_hmsg_object (graph.py:3112-3151) over all instances: text f32 [Q][C][D] (row qid the query, the others negatives)
-void hmsg_cpu_query(void* h, int32_t Q, int32_t C, const float* text, int32_t qid, int32_t k, int32_t* out_idx, double* out_score) {
-    Ctx* c = (Ctx*)h;
-    const int D = c->D;
-    const size_t N = c->inst.size();
+// query_hmsg_object (graph.py:3112-3151) over a node table feats f32 [N][D]: text f32 [Q][C][D] (row qid the query, the others
+// negatives).  The reference answers one query at a time with `text @ feats.T` (BLAS, all cores); here the queries of a batch
+// run side by side on the OpenMP threads -- the same arithmetic per query (float64 dot products in index order), and the more
+// generous form for the CPU side of bench.py's queries/s.
+void hmsg_cpu_query_table(const float* feats, int64_t N_, int32_t D, int32_t Q, int32_t C, const float* text, int32_t qid, int32_t k,
+                          int32_t* out_idx, double* out_score) {
+    const size_t N = (size_t)N_;
+#pragma omp parallel for schedule(dynamic, 4)
     for (int q = 0; q < Q; ++q) {
         std::vector<double> sim((size_t)C * N);
         for (int r = 0; r < C; ++r)
             for (size_t n = 0; n < N; ++n) {
                 double s = 0;
-                for (int d = 0; d < D; ++d) s += (double)text[((size_t)q * C + r) * D + d] * (double)c->inst_feats[n * D + d];
+                for (int d = 0; d < D; ++d) s += (double)text[((size_t)q * C + r) * D + d] * (double)feats[n * D + d];
                 sim[(size_t)r * N + n] = s;
             }
         std::vector<int> ids;
@@ -723,15 +726,18 @@ void hmsg_cpu_query(void* h, int32_t Q, int32_t C, const float* text, int32_t qi
         if (ids.empty()) {
             ids.resize(N);
             std::iota(ids.begin(), ids.end(), 0);
-            std::stable_sort(ids.begin(), ids.end(), [&](int a, int b) { return sim[(size_t)qid * N + a] > sim[(size_t)qid * N + b]; });
-        } else {
-            std::stable_sort(ids.begin(), ids.end(), [&](int a, int b) { return sim[(size_t)qid * N + a] > sim[(size_t)qid * N + b]; });
         }
+        std::stable_sort(ids.begin(), ids.end(), [&](int a, int b) { return sim[(size_t)qid * N + a] > sim[(size_t)qid * N + b]; });
         for (int j = 0; j < k; ++j) {
             out_idx[(size_t)q * k + j] = j < (int)ids.size() ? ids[(size_t)j] : -1;
             out_score[(size_t)q * k + j] = j < (int)ids.size() ? sim[(size_t)qid * N + ids[(size_t)j]] : 0.0;
         }
     }
+}
+// ... over the instances of a build
+void hmsg_cpu_query(void* h, int32_t Q, int32_t C, const float* text, int32_t qid, int32_t k, int32_t* out_idx, double* out_score) {
+    Ctx* c = (Ctx*)h;
+    hmsg_cpu_query_table(c->inst_feats.data(), (int64_t)c->inst.size(), c->D, Q, C, text, qid, k, out_idx, out_score);
 }
 void hmsg_cpu_free(void* h) { delete (Ctx*)h; }
 int32_t hmsg_cpu_threads(void) { return (int32_t)omp_get_max_threads(); }

@@ -113,3 +113,19 @@ class CpuBuild:
         if self.h:
             self.lib.hmsg_cpu_free(self.h)
             self.h = None
+
+
+def query_table(feats, text, qid=0, k=3):
+    """query_hmsg_object over a node table on the host cores (hmsg_cpu_query_table): feats f32 [N, D], text f32 [Q, C, D]
+    -> (idx i32 [Q, k], score f64 [Q, k]).  The CPU side of bench.py's queries/s."""
+    L = C.CDLL(build())
+    feats = np.ascontiguousarray(feats, np.float32)
+    text = np.ascontiguousarray(text, np.float32)
+    Q, Cn, D = text.shape
+    assert feats.shape[1] == D
+    idx = np.empty((Q, k), np.int32)
+    sc = np.empty((Q, k), np.float64)
+    L.hmsg_cpu_query_table.argtypes = [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P]
+    L.hmsg_cpu_query_table(_ptr(feats), feats.shape[0], D, Q, Cn, _ptr(text), int(qid), int(k), _ptr(idx), _ptr(sc))
+    return idx, sc
+
