@@ -54,7 +54,7 @@ class HmsgJsonField(C.Structure):      # include/hmsg.h: hmsg_json_field
 class HmsgGraphParams(C.Structure):    # include/hmsg.h: hmsg_graph_params
     _fields_ = [("num_views", C.c_int32), ("kmeans_n_init", C.c_int32), ("kmeans_max_iter", C.c_int32), ("kmeans_seed", C.c_uint32),
                 ("skip_frames", C.c_int32), ("image_width", C.c_int32), ("image_height", C.c_int32), ("min_visible_ratio", C.c_double),
-                ("max_view_depth", C.c_double), ("host_threads", C.c_int32)]
+                ("max_view_depth", C.c_double), ("host_threads", C.c_int32), ("merge_objects_graph", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class HmsgGraphCounts(C.Structure):    # include/hmsg.h: hmsg_graph_counts
@@ -153,6 +153,7 @@ _SIGS = {
     "hmsg_lidar_depth": (C.c_int, [C.c_int32, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "hmsg_crop_resize_batch": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, C.c_double, C.c_int32, _P, _P, _P]),
     "hmsg_save_objects": (C.c_int, [_P, C.c_char_p, C.c_int64, _P, C.c_int32]),
+    "hmsg_merge_room_objects": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_double, C.c_double, C.POINTER(C.c_int32), _P, _P, C.c_int32]),
     "hmsg_write_json": (C.c_int, [C.c_char_p, C.c_int32, _P]),
     "hmsg_write_ply": (C.c_int, [C.c_char_p, _P, C.c_int64]),
     "hmsg_read_json_numbers": (C.c_int, [C.c_char_p, C.c_char_p, _P, C.c_int64, C.POINTER(C.c_int64)]),
@@ -562,6 +563,23 @@ class Scene:
             a.view_ids_json = json.dumps([plain(v) for v in r["view_ids"]]).encode()
             a.best_view_id_json = json.dumps(plain(r["best_view_id"])).encode()
         self._ck(self.L.c.hmsg_save_objects(self.h, str(directory).encode(), n, C.cast(arr, _P), int(n_threads)))
+
+    def merge_room_objects(self, clouds, names, overlap_threshold=0.01, radius=0.1):
+        """Room.merge_objects (room.py:62-129) for the objects of one room (include/hmsg.h: hmsg_merge_room_objects): `clouds` = the
+        objects' point arrays in room.objects order, `names` = their names.  Returns the new room.objects list as groups: [key object,
+        objects added to it in the reference's order ...] -- the same-name overlap tests run on the device."""
+        n = len(clouds)
+        off = np.zeros(n + 1, np.int64)
+        off[1:] = np.cumsum([len(c) for c in clouds])
+        pts = np.ascontiguousarray(np.concatenate([np.asarray(c, np.float64).reshape(-1, 3) for c in clouds]) if off[-1] else np.zeros((1, 3)), np.float64)
+        ids = {}
+        name_id = np.ascontiguousarray([ids.setdefault(str(v), len(ids)) for v in names], np.int32)
+        ng = C.c_int32()
+        goff = np.zeros(n + 1, np.int32)
+        mem = np.zeros(max(n * (n + 1), 1), np.int32)     # (every object can become a key, and a key's list can hold every other object)
+        self._ck(self.L.c.hmsg_merge_room_objects(self.h, n, _ptr(pts), _ptr(off), _ptr(name_id), float(overlap_threshold), float(radius),
+                                                  C.byref(ng), _ptr(goff), _ptr(mem), len(mem)))
+        return [mem[goff[g]:goff[g + 1]].tolist() for g in range(ng.value)]
 
     def room_clouds(self, y_lo, y_hi, T, z_levels, room_xz):
         """segment_hmsg_room's room clouds on the device (include/hmsg.h: hmsg_room_clouds): room_xz = list of [n, 2] arrays;

@@ -77,6 +77,11 @@ struct GObject {
     std::vector<double> emb;                // loaded: float64 embedding
     std::vector<double> pts;                // loaded
     std::vector<double> verts;              // loaded [n][2]
+    // Room.merge_objects (hmsg_graph_params::merge_objects_graph): the instances whose clouds make up the object's cloud, in the
+    // order Object.__add__ concatenated them (one: the object as segment_hmsg_objects made it), and its float32 embedding
+    // (the mean chain of object.py:102); filled for every object once a graph has merged
+    std::vector<int> parts;
+    std::vector<float> emb32;
 };
 
 }  // namespace
@@ -101,6 +106,7 @@ struct hmsg_graph {
     std::string worker_err;                 // first error of a KMeans worker (under worker_mu)
     std::mutex worker_mu;
     bool begun = false, finished = false, loaded = false;
+    bool merged = false;                    // Room.merge_objects has run: objects carry parts / emb32, the index comes from them
     bool failed = false;                    // hmsg_graph_finish threw half way: views / objects are partly appended -- the graph only accepts hmsg_graph_destroy
     double t_begin_ms = 0, t_finish_ms = 0, t_kmeans_wait_ms = 0;
     hmsg_index_t* ix = nullptr;             // hmsg_graph_query's index (made on first use)
@@ -353,6 +359,70 @@ void room_embed(hmsg_graph* g, GRoom& rm) {
     }
 }
 
+}  // namespace
+// (hmsg_objmerge.hip) room.py:62-129 for the objects of one room: groups [key object, objects added to it ...] in the new list's order
+void hmsg_merge_groups(hmsg_ctx* h, int n, const double* points, const long long* start, const int* count, const int* name_id,
+                       double overlap_threshold, double radius, std::vector<int>& group_off, std::vector<int>& members);
+namespace {
+
+// graph.py:2053-2058: every room fuses its same-name objects whose clouds overlap (Room.merge_objects) and re-numbers them; the
+// graph's object list becomes the rooms' lists one after the other; a view keeps the object ids it was given (text_discription
+// too) and is linked to the objects that carry one of those ids NOW (create_graph_new, :1764-1773) -- as the Python mirror does.
+void graph_merge_objects(hmsg_graph* g, const std::vector<float>& node_emb) {
+    hmsg_ctx* h = g->h;
+    const int D = g->D;
+    for (size_t k = 0; k < g->objects.size(); ++k) {
+        GObject& o = g->objects[k];
+        o.parts.assign(1, o.instance);
+        o.emb32.assign(node_emb.begin() + (ptrdiff_t)(k * (size_t)D), node_emb.begin() + (ptrdiff_t)((k + 1) * (size_t)D));
+    }
+    std::vector<GObject> out;
+    for (auto& rm : g->rooms) {
+        const int n = (int)rm.objects.size();
+        std::vector<int> name_id((size_t)n), count((size_t)n);
+        std::vector<long long> start((size_t)n);
+        std::map<std::string, int> ids;
+        for (int i = 0; i < n; ++i) {
+            const GObject& o = g->objects[(size_t)rm.objects[(size_t)i]];
+            name_id[(size_t)i] = ids.emplace(o.name, (int)ids.size()).first->second;
+            start[(size_t)i] = h->inst.off[(size_t)o.instance];
+            count[(size_t)i] = (int)(h->inst.off[(size_t)o.instance + 1] - h->inst.off[(size_t)o.instance]);
+        }
+        std::vector<int> goff, mem;
+        if (n) hmsg_merge_groups(h, n, h->inst.pts.p, start.data(), count.data(), name_id.data(), 0.01, 0.1, goff, mem);
+        std::vector<int> fresh;
+        for (size_t gi = 0; gi + 1 < goff.size(); ++gi) {
+            GObject& key = g->objects[(size_t)rm.objects[(size_t)mem[(size_t)goff[gi]]]];
+            for (int q = goff[gi] + 1; q < goff[gi + 1]; ++q) {
+                // Object.__add__ (object.py:93-103; an object of the graph never has an empty cloud): clouds concatenated, embedding
+                // = np.mean([a, b], axis=0) of two float32 rows
+                const GObject& other = g->objects[(size_t)rm.objects[(size_t)mem[(size_t)q]]];
+                key.parts.insert(key.parts.end(), other.parts.begin(), other.parts.end());
+                for (int d = 0; d < D; ++d) key.emb32[(size_t)d] = (key.emb32[(size_t)d] + other.emb32[(size_t)d]) / 2.0f;
+            }
+            key.id = rm.id + "_" + std::to_string(gi);
+            key.counter = (int)gi;
+            fresh.push_back((int)out.size());
+            out.push_back(key);             // (a copy: a later group may add to an object that an earlier one absorbed, as the reference does)
+        }
+        rm.objects = fresh;
+    }
+    g->objects.swap(out);
+    std::map<std::string, std::vector<int>> pos;
+    for (size_t k = 0; k < g->objects.size(); ++k) pos[g->objects[k].id].push_back((int)k);
+    for (auto& v : g->views) {
+        std::vector<int> ks;
+        for (auto& oid : v.object_ids) {
+            auto it = pos.find(oid);
+            if (it != pos.end()) ks.insert(ks.end(), it->second.begin(), it->second.end());
+        }
+        std::sort(ks.begin(), ks.end());
+        ks.erase(std::unique(ks.begin(), ks.end()), ks.end());
+        v.objects = ks;
+    }
+    g->merged = true;
+}
+
 void join_workers(hmsg_graph* g) {
     const double t0 = now_ms();
     for (auto& t : g->workers)
@@ -467,6 +537,11 @@ void graph_finish(hmsg_graph* g, int32_t n_labels, const float* label_feats, con
             v.object_ids.push_back(g->objects[(size_t)k].id);
             v.texts.push_back(g->objects[(size_t)k].name);
         }
+    if (g->prm.merge_objects_graph && !g->objects.empty()) {
+        std::vector<float> node_emb(g->objects.size() * (size_t)g->D);
+        need(hmsg_get_nodes(h, nodes.data(), node_emb.data()), h, "hmsg_get_nodes");
+        graph_merge_objects(g, node_emb);
+    }
     // edges (create_graph_new): a freshly built View carries an int room index, so no Room - View edge (view_room = -1)
     std::vector<int32_t> obj_room, view_room(g->views.size(), -1), vobj;
     std::vector<int64_t> vooff(1, 0);
@@ -793,6 +868,7 @@ void hmsg_graph_default_params(hmsg_graph_params* p) {
     p->min_visible_ratio = 0.5;     /* graph_utils.py:95-157 defaults */
     p->max_view_depth = 10.0;
     p->host_threads = 0;
+    p->merge_objects_graph = 0;     /* false in every shipped config */
 }
 
 const char* hmsg_graph_last_error(const hmsg_graph_t* g) { return g ? g->err.c_str() : "null graph"; }
@@ -1109,9 +1185,42 @@ int hmsg_save(hmsg_graph_t* g, const char* dir) {
         // objects: the bulk writer (clouds and features read back from HBM once, host threads print)
         std::vector<std::string> keep;
         keep.reserve(g->objects.size() * 6);
-        std::vector<hmsg_object_record> recs(g->objects.size());
+        std::vector<hmsg_object_record> recs;
+        recs.reserve(g->objects.size());
+        std::vector<double> inst_pts;              // (merged objects: their clouds are pieced together on the host)
         for (size_t k = 0; k < g->objects.size(); ++k) {
             const GObject& o = g->objects[k];
+            if (o.parts.size() > 1) {
+                // an object Room.merge_objects added others to: Object.save (object.py:37-57) of the concatenated cloud, the 8 corners of
+                // its box (get_box_points' order) and the mean embedding -- what the Python mirror writes for it
+                if (inst_pts.empty()) {
+                    inst_pts.resize((size_t)std::max<long long>(h->inst.total, 1) * 3);
+                    need(hmsg_get_instance_points(h, inst_pts.data()), h, "hmsg_get_instance_points");
+                }
+                std::vector<double> pts;
+                for (int inst : o.parts)
+                    pts.insert(pts.end(), inst_pts.begin() + (ptrdiff_t)(h->inst.off[(size_t)inst] * 3), inst_pts.begin() + (ptrdiff_t)(h->inst.off[(size_t)inst + 1] * 3));
+                if (hmsg_write_ply((root + "/objects/" + o.id + ".ply").c_str(), pts.data(), (int64_t)(pts.size() / 3)) != HMSG_OK)
+                    throw hmsg_error{HMSG_ERR_INVALID, "cannot write an object cloud"};
+                double mn[3] = {pts[0], pts[1], pts[2]}, mx[3] = {pts[0], pts[1], pts[2]};
+                for (size_t i = 0; i < pts.size(); i += 3)
+                    for (int a = 0; a < 3; ++a) {
+                        mn[a] = std::min(mn[a], pts[i + a]);
+                        mx[a] = std::max(mx[a], pts[i + a]);
+                    }
+                const double ex[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+                const double box[8][3] = {{mn[0], mn[1], mn[2]},         {mn[0] + ex[0], mn[1], mn[2]},         {mn[0], mn[1] + ex[1], mn[2]},
+                                          {mn[0], mn[1], mn[2] + ex[2]}, {mx[0], mx[1], mx[2]},                 {mn[0], mn[1] + ex[1], mn[2] + ex[2]},
+                                          {mn[0] + ex[0], mn[1], mn[2] + ex[2]}, {mn[0] + ex[0], mn[1] + ex[1], mn[2]}};
+                const std::string o_id = jstr(o.id), o_room = jstr(o.room_id), o_name = jstr(o.name), o_views = jlist(o.view_ids),
+                                  o_best = o.have_best ? jstr(o.best_view_id) : std::string("null");
+                std::vector<hmsg_json_field> of = {raw("object_id", o_id), hmsg_json_field{"vertices", HMSG_JSON_F64, 2, 8, 3, &box[0][0]},
+                                                   raw("room_id", o_room), raw("name", o_name),
+                                                   hmsg_json_field{"embedding", HMSG_JSON_F32, 1, (int64_t)o.emb32.size(), 0, o.emb32.data()},
+                                                   raw("view_ids", o_views), raw("best_view_id", o_best)};
+                write_json_fields(root + "/objects/" + o.id + ".json", of);
+                continue;
+            }
             const size_t b = keep.size();
             keep.push_back(o.id);
             keep.push_back(jstr(o.id));
@@ -1119,8 +1228,8 @@ int hmsg_save(hmsg_graph_t* g, const char* dir) {
             keep.push_back(jstr(o.name));
             keep.push_back(jlist(o.view_ids));
             keep.push_back(o.have_best ? jstr(o.best_view_id) : std::string("null"));
-            recs[k] = hmsg_object_record{o.instance, keep[b].c_str(), keep[b + 1].c_str(), keep[b + 2].c_str(), keep[b + 3].c_str(), keep[b + 4].c_str(),
-                                         keep[b + 5].c_str()};
+            recs.push_back(hmsg_object_record{o.instance, keep[b].c_str(), keep[b + 1].c_str(), keep[b + 2].c_str(), keep[b + 3].c_str(), keep[b + 4].c_str(),
+                                              keep[b + 5].c_str()});
         }
         if (!recs.empty()) need(hmsg_save_objects(h, (root + "/objects").c_str(), (int64_t)recs.size(), recs.data(), g->prm.host_threads), h, "hmsg_save_objects");
     });
@@ -1281,8 +1390,18 @@ int hmsg_graph_index(hmsg_graph_t* g, const double* room_name_emb, hmsg_index_t*
         HMSG_REQUIRE(!g->objects.empty(), HMSG_ERR_INVALID, "hmsg_graph_index: a graph without objects");
         hmsg_index_t* ix = nullptr;
         const int D = g->D;
-        if (!g->loaded) {
+        if (!g->loaded && !g->merged) {
             need(hmsg_index_from_nodes(g->h, &ix), g->h, "hmsg_index_from_nodes");
+        } else if (g->merged && !g->loaded) {
+            // merged objects are no rows of the scene's node table any more: the table of the graph's own objects
+            std::vector<float> emb(g->objects.size() * (size_t)D);
+            std::vector<int32_t> room(g->objects.size());
+            for (size_t k = 0; k < g->objects.size(); ++k) {
+                memcpy(&emb[k * (size_t)D], g->objects[k].emb32.data(), (size_t)D * 4);
+                room[k] = g->objects[k].room;
+            }
+            if (hmsg_index_create(g->device, D, (int64_t)g->objects.size(), emb.data(), 0, room.data(), &ix) != HMSG_OK)
+                throw hmsg_error{HMSG_ERR_INVALID, "hmsg_index_create failed"};
         } else {
             std::vector<double> emb(g->objects.size() * (size_t)D);
             std::vector<int32_t> room(g->objects.size());

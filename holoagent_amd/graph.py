@@ -236,9 +236,9 @@ class Room:    # graph/room.py:15-60, 309-374
     def add_object(self, obj):
         self.objects.append(obj)
 
-    def merge_objects(self, overlap_threshold=0.01, radius=0.1):
-        """room.py:62-129: fuse same-name objects of the room whose clouds overlap, then re-number the objects.
-        Follows the reference step by step (including what its dictionary bookkeeping does with chains)."""
+    def merge_groups(self, overlap_threshold=0.01, radius=0.1):
+        """room.py:62-106, host form: the new room.objects list as groups [key object, objects added to it ...] -- numpy / cKDTree
+        overlap tests, Python's own dict and set (the library's hmsg_merge_room_objects restates both and is compared with this)."""
         n = len(self.objects)
         scores = np.zeros((n, n))
         for i in range(n):
@@ -262,22 +262,29 @@ class Room:    # graph/room.py:15-60, 309-374
         for idx in range(n):
             if idx not in merging:
                 groups.setdefault(idx, []).append(idx)
-        new_objects, counter = [], 0
+        out = []
         for i, js in groups.items():
             js = list(set(js))
-            if len(js) == 1:
-                jj = js[0]
-                obj = self.objects[i] if i == jj else self.objects[i] + self.objects[jj]
+            out.append([i] if (len(js) == 1 and js[0] == i) else [i] + js)
+        return out
+
+    def merge_objects(self, overlap_threshold=0.01, radius=0.1, scene=None):
+        """room.py:62-129: fuse same-name objects of the room whose clouds overlap, then re-number the objects.
+        Follows the reference step by step (including what its dictionary bookkeeping does with chains).  scene: the overlap
+        tests and the bookkeeping behind the C ABI (hmsg_merge_room_objects: tests on the device); None: numpy on the host."""
+        if scene is not None:
+            groups = scene.merge_room_objects([np.asarray(o.pcd.points).reshape(-1, 3) for o in self.objects], [o.name for o in self.objects],
+                                              overlap_threshold, radius)
+        else:
+            groups = self.merge_groups(overlap_threshold, radius)
+        new_objects = []
+        for counter, g in enumerate(groups):
+            obj = self.objects[g[0]]
+            for jj in g[1:]:
+                obj = obj + self.objects[jj]                   # (Object.__add__: an empty side yields the other object)
                 obj.object_id = self.room_id + "_" + str(counter)
-                new_objects.append(obj)
-                counter += 1
-            elif len(js) > 1:
-                obj = self.objects[i]
-                for jj in js:
-                    obj = obj + self.objects[jj]
-                    obj.object_id = self.room_id + "_" + str(counter)
-                new_objects.append(obj)
-                counter += 1
+            obj.object_id = self.room_id + "_" + str(counter)
+            new_objects.append(obj)
         self.objects = new_objects
 
     def infer_room_type_from_view_embedding(self, default_room_types, text_feats):
@@ -1161,7 +1168,7 @@ class Graph:
         self.segment_hmsg_objects(save_path)
         if _get(self.cfg, "pipeline.merge_objects_graph", False):          # graph.py:2053-2058 (false in every shipped config)
             for room in self.rooms:
-                room.merge_objects()
+                room.merge_objects(scene=self.scene)           # (the same-name overlap tests on the device when there is one)
             self.objects = [o for room in self.rooms for o in room.objects]
             self._index = None
         self.create_graph_new()

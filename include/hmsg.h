@@ -320,6 +320,19 @@ typedef struct {
     const char* best_view_id_json;
 } hmsg_object_record;
 int hmsg_save_objects(hmsg_t* h, const char* dir, int64_t n, const hmsg_object_record* recs, int32_t n_threads);
+/* N2: Room.merge_objects (fsr_vln/memory/hmsg/graph/room.py:62-129; the optional post-pass of build_hier_multimodal_scene_graph,
+ * graph.py:2053-2058, `pipeline.merge_objects_graph`) for the n objects of ONE room, in room.objects order: cloud i =
+ * points[off[i] .. off[i + 1]) (f64 [.][3], host or device memory), name_id[i] = any numbering of the names (equal ids = equal
+ * names).  Every same-name pair i < j is tested on the device (find_overlapping_ratio_faiss(obj_i.pcd, obj_j.pcd, radius) >
+ * overlap_threshold; the reference calls it with 0.01 / 0.1), then the reference's bookkeeping is followed step by step:
+ * np.where order, the dictionary chaining (an object that was absorbed can still become a key), the untouched objects behind them,
+ * list(set(j)) in CPython's order.  Out: n_groups groups in the order the new room.objects list has; group g = group_members[
+ * group_off[g] .. group_off[g + 1]): the object that stays (and is re-numbered room_id + "_" + g) first, then the objects the
+ * reference adds to it (Object.__add__, object.py:93-103), in that order.  group_off: n + 1 entries, group_members: members_capacity
+ * entries (n (n + 1) always suffice: every object can become a key, a key's list holds an object once). */
+int hmsg_merge_room_objects(hmsg_t* h, int32_t n, const double* points, const int64_t* off, const int32_t* name_id,
+                            double overlap_threshold, double radius, int32_t* n_groups, int32_t* group_off, int32_t* group_members,
+                            int32_t members_capacity);
 /* N2, load side: the object table of a saved graph straight into a retrieval index.  For every stem <dir>/<stem>.json is
  * read and its "embedding" array parsed as float64 (object.py:75-91 load; graph.py:1892-1987 load_hmsg_graph), rows in
  * the order given; room_of_node as for hmsg_index_create (declared below).  feat_dim (optional) receives the row length.
@@ -480,6 +493,10 @@ typedef struct hmsg_graph_params {
     double min_visible_ratio;   /* 0.5  (utils/graph_utils.py:95-157) */
     double max_view_depth;      /* 10.0 */
     int32_t host_threads;       /* KMeans fits / object writers; 0: one per core, at most 16 */
+    int32_t merge_objects_graph;   /* pipeline.merge_objects_graph (graph.py:2053-2058; false in every shipped config): after the objects, every
+                                    * room fuses its same-name objects whose clouds overlap (Room.merge_objects, hmsg_merge_room_objects with
+                                    * the reference's 0.01 / 0.1) and re-numbers them; the graph's object list is then the rooms' lists */
+    int32_t reserved_;
 } hmsg_graph_params;
 typedef struct hmsg_graph_counts {
     int32_t floors, rooms, views, objects;

@@ -59,6 +59,7 @@ int main(int argc, char** argv) {
     double xz_min[2], *verts2, *hscore;
     hmsg_graph_t *g = NULL, *lg = NULL;
     hmsg_graph_counts gc;
+    hmsg_graph_params gprm;
     int32_t *gfid, *gmode, *gqid, *gnsel, *gsel, *gidx, *groom, gcounts[4];
     double* gscore;
     hmsg_config cfg;
@@ -257,7 +258,11 @@ int main(int argc, char** argv) {
     if (n_edges) fwrite(edges, sizeof(int64_t), (size_t)n_edges * 2, fo);
     if (argc == 4) {
         /* 1: build -- build_hier_multimodal_scene_graph (the poses' inverses and the label vocabulary are optional) */
-        CK(hmsg_build_graph(h, NULL, F, pose, NULL, f_g, NULL, 0, NULL, NULL, &g));
+        /* (HMSG_HOST_MERGE_OBJECTS=1: with pipeline.merge_objects_graph -- every room fuses its same-name objects whose clouds overlap,
+         *  Room.merge_objects room.py:62-129; without a vocabulary every object is named "object") */
+        hmsg_graph_default_params(&gprm);
+        if (getenv("HMSG_HOST_MERGE_OBJECTS")) gprm.merge_objects_graph = 1;
+        CK(hmsg_build_graph(h, &gprm, F, pose, NULL, f_g, NULL, 0, NULL, NULL, &g));
         /* 2: save -- save_hmsg_graph's directory */
         if (hmsg_save(g, argv[3]) != HMSG_OK) {
             fprintf(stderr, "hmsg_host: hmsg_save: %s\n", hmsg_graph_last_error(g));

@@ -36,7 +36,7 @@ def _scene():
     return spec, frames, np.ascontiguousarray(text, np.float32)
 
 
-def _run(lib_path, tmp_path):
+def _run(lib_path, tmp_path, merge=False):
     from holoagent_amd._lib import HmsgLib
     spec, frames, text = _scene()
     S = PC.stack_frames(frames)
@@ -55,7 +55,10 @@ def _run(lib_path, tmp_path):
             np.ascontiguousarray(a, t).tofile(f)
     exe = _build(lib_path, str(tmp_path / "hmsg_host"))
     gdir = str(tmp_path / "graph_c")
-    r = subprocess.run([exe, fin, fout, gdir], capture_output=True, text=True, timeout=900)
+    env = dict(os.environ)
+    if merge:
+        env["HMSG_HOST_MERGE_OBJECTS"] = "1"       # hmsg_graph_params::merge_objects_graph from the C host
+    r = subprocess.run([exe, fin, fout, gdir], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     raw = open(fout, "rb").read()
     V, N, n_floors, n_nodes = np.frombuffer(raw, np.int64, 4)
@@ -123,7 +126,9 @@ def _run(lib_path, tmp_path):
     # THE GRAPH WITH FOUR CALLS (hmsg_build_graph, hmsg_save, hmsg_load, hmsg_graph_query) from C == the same four through the binding:
     # same counts, the two saved directories byte for byte, same answers
     from holoagent_amd._lib import SceneGraph
-    cg = SceneGraph.build(sc, S["pose"], S["f_g"])
+    cg = SceneGraph.build(sc, S["pose"], S["f_g"], merge_objects_graph=1 if merge else 0)
+    if merge:
+        assert cg.counts()["objects"] < len(sc.nodes()), "no pair of objects was merged"     # (Room.merge_objects did fuse something)
     cnt = cg.counts()
     assert list(gcounts) == [cnt["floors"], cnt["rooms"], cnt["views"], cnt["objects"]] and g_edges == cnt["edges"]
     assert cnt["rooms"] >= 2 and cnt["views"] == F and cnt["objects"] >= 1
@@ -165,3 +170,16 @@ def test_c_host_equals_binding_emu(tmp_path):
 @pytest.mark.gpu
 def test_c_host_equals_binding_gpu(tmp_path):
     _run(LIB, tmp_path)
+
+
+@pytest.mark.skipif(not os.path.exists(PC.EMU_PATH), reason="kernel simulator not built")
+def test_c_host_merges_objects_like_the_binding_emu(tmp_path):
+    """pipeline.merge_objects_graph from the strict-C99 host: hmsg_graph_params::merge_objects_graph = 1 -> the same merged graph (counts,
+    saved directory byte for byte, answers of the loaded graph) as through the binding"""
+    _run(PC.EMU_PATH, tmp_path, merge=True)
+
+
+@pytest.mark.gpu
+def test_c_host_merges_objects_like_the_binding_gpu(tmp_path):
+    _run(LIB, tmp_path, merge=True)
+

@@ -54,7 +54,7 @@ def _rest(sc, inp):
     sc.pool_instances()
 
 
-def check_graph_object(L, device, tmp_path, storeys=1):
+def check_graph_object(L, device, tmp_path, storeys=1, merge=False):
     from holoagent_amd._lib import SceneGraph
     from holoagent_amd.graph import Graph
     spec, inp, sc = _build(L, device, storeys)
@@ -65,6 +65,10 @@ def check_graph_object(L, device, tmp_path, storeys=1):
     label_feats = rng.standard_normal((9, D)).astype(np.float32)
     label_feats /= np.linalg.norm(label_feats, axis=1, keepdims=True)
     label_names = ["label%d" % i for i in range(8)] + ["café \"table\""]              # (an id the JSON writer has to escape)
+    if merge:
+        # pipeline.merge_objects_graph (graph.py:2053-2058): ONE name for every object, so that every pair of a room's objects is a
+        # candidate and the ones whose clouds touch are fused (Room.merge_objects) -- in the C graph by hmsg_graph_params::merge_objects_graph
+        label_feats, label_names = label_feats[:1], ["thing"]
     blank = np.broadcast_to(np.zeros((), np.uint8), (spec.height, spec.width, 3))
 
     class FrameSource:
@@ -80,12 +84,13 @@ def check_graph_object(L, device, tmp_path, storeys=1):
             return inp["K"]
     # ---- the C graph: room level right after the map (KMeans on its host threads), the rest after the pooling
     cg = SceneGraph.begin(sc, np.stack(poses), fg, poses_inv=np.stack([np.linalg.inv(p) for p in poses]), img_paths=FrameSource.frameId2imgPath,
-                          num_views=5, host_threads=2)
+                          num_views=5, host_threads=2, merge_objects_graph=1 if merge else 0)
     _rest(sc, inp)
     cg.finish(label_feats, label_names)
     # ---- the mirror on the same handle (num_views = 5 like the C graph: the scene has 12 frames)
     import holoagent_amd.graph as G
-    full_cfg = dict(main=dict(device_id=0), models=dict(clip=dict(feat_dim=D)), pipeline=dict(grid_resolution=0.05, skip_frames=1, views_on_device=True))
+    full_cfg = dict(main=dict(device_id=0), models=dict(clip=dict(feat_dim=D)),
+                    pipeline=dict(grid_resolution=0.05, skip_frames=1, views_on_device=True, merge_objects_graph=bool(merge)))
     g = Graph.from_scene(sc, cfg=full_cfg, lib=L)
     g.dataset = FrameSource()
     g._poses = poses
@@ -103,6 +108,8 @@ def check_graph_object(L, device, tmp_path, storeys=1):
     cnt = cg.counts()
     assert (cnt["floors"], cnt["rooms"], cnt["views"], cnt["objects"]) == (len(g.floors), len(g.rooms), len(g.views), len(g.objects))
     assert cnt["rooms"] >= 1 and cnt["objects"] >= 3 and cnt["view_object_links"] >= 3
+    if merge:
+        assert len(g.objects) < len(sc.nodes()), "no pair of objects was merged: the test scene does not exercise Room.merge_objects"
     # (every camera lands in one room of its storey; a room nobody stands in borrows its nearest camera: graph_utils.py:280-291)
     assert cnt["views"] == F if storeys == 1 else (cnt["views"] >= F and cnt["floors"] >= storeys and cnt["rooms"] >= storeys)
     assert any(len(r.sample_images) >= 5 for r in g.rooms), "no room went through KMeans"
@@ -209,3 +216,21 @@ def test_graph_object_equals_the_mirror_gpu(tmp_path):
     import torch
     from holoagent_amd._lib import HmsgLib
     check_graph_object(HmsgLib(), torch.device("cuda", 0), tmp_path)
+
+
+@pytest.mark.skipif(not os.path.exists(PC.EMU_PATH), reason="kernel simulator not built")
+def test_graph_object_merges_objects_like_the_mirror_on_the_simulator(tmp_path):
+    """pipeline.merge_objects_graph: Room.merge_objects inside hmsg_graph_finish (same-name overlap tests on the device, the
+    reference's chaining, ids re-numbered, merged clouds / mean embeddings saved) against the mirror with the same switch:
+    nodes, edges in order, saved directories byte for byte, the loaded graph's answers."""
+    import torch
+    from holoagent_amd._lib import HmsgLib
+    check_graph_object(HmsgLib(PC.EMU_PATH), torch.device("cpu"), tmp_path, merge=True)
+
+
+@pytest.mark.gpu
+def test_graph_object_merges_objects_like_the_mirror_gpu(tmp_path):
+    import torch
+    from holoagent_amd._lib import HmsgLib
+    check_graph_object(HmsgLib(), torch.device("cuda", 0), tmp_path, merge=True)
+
