@@ -556,6 +556,11 @@ class Graph:
         clip_type = str(_get(cfg, "models.clip.type", "ViT-B/32")).replace("/", "-")
         self.clip_feat_dim = int(_get(cfg, "models.clip.feat_dim", CLIP_DIM.get(clip_type, 512)))
         self.build_mode = _get(cfg, "pipeline") is not None           # graph.py:166-168
+        if self.build_mode:
+            # every pipeline.* key is accounted for: honoured, the collaborators' business, ignored like the reference ignores it --
+            # or refused (an unknown key, a value this path cannot honour): holoagent_amd/config_surface.py
+            from .config_surface import check_config
+            self.config_report = check_config(cfg)
         self.scene: Scene | None = None
         self._index: NodeIndex | None = None
         self._text_cache = {}
