@@ -153,6 +153,9 @@ _SIGS = {
     "hmsg_lidar_depth": (C.c_int, [C.c_int32, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "hmsg_crop_resize_batch": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, C.c_double, C.c_int32, _P, _P, _P]),
     "hmsg_save_objects": (C.c_int, [_P, C.c_char_p, C.c_int64, _P, C.c_int32]),
+    "hmsg_comm_send": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32]),
+    "hmsg_comm_recv": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32]),
+    "hmsg_merge_tree_sharded": (C.c_int, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),
     "hmsg_merge_room_objects": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_double, C.c_double, C.POINTER(C.c_int32), _P, _P, C.c_int32]),
     "hmsg_write_json": (C.c_int, [C.c_char_p, C.c_int32, _P]),
     "hmsg_write_ply": (C.c_int, [C.c_char_p, _P, C.c_int64]),
@@ -657,6 +660,19 @@ class Scene:
         """One episode fused in disjoint frame windows (include/hmsg.h: hmsg_allreduce_feature_sums): sums and counters of all
         ranks all-reduced in place over RCCL."""
         self._ck(self.L.c.hmsg_allreduce_feature_sums(self.h, comm.h))
+
+    def merge_tree_sharded(self, comm: "Comm", total_frames: int) -> bool:
+        """hierarchical_merge of one episode sharded over the ranks, behind the C ABI (include/hmsg.h: hmsg_merge_tree_sharded): local
+        levels, agreement, cross-rank joins over ncclSend / ncclRecv.  True on the rank that holds the episode's instances."""
+        holds = C.c_int32()
+        self._ck(self.L.c.hmsg_merge_tree_sharded(self.h, comm.h, int(total_frames), C.byref(holds)))
+        return bool(holds.value)
+
+    def comm_send(self, comm: "Comm", dev_tensor, dst: int):
+        self._ck(self.L.c.hmsg_comm_send(self.h, comm.h, _ptr(dev_tensor), int(dev_tensor.numel() * dev_tensor.element_size()), int(dst)))
+
+    def comm_recv(self, comm: "Comm", dev_tensor, src: int):
+        self._ck(self.L.c.hmsg_comm_recv(self.h, comm.h, _ptr(dev_tensor), int(dev_tensor.numel() * dev_tensor.element_size()), int(src)))
 
     def index_from_nodes(self):
         """Resident retrieval index over the node table, gathered on the device."""

@@ -14,6 +14,8 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
+
 #include <mutex>
 
 // (device code is not linked across translation units: the two small kernels this file needs are stated here)
@@ -38,7 +40,7 @@ typedef void* rcclComm_t;
 struct rcclUniqueId {
     char internal[128];
 };
-enum { RCCL_INT32 = 2, RCCL_UINT32 = 3, RCCL_INT64 = 4, RCCL_FLOAT32 = 7, RCCL_SUM = 0 };
+enum { RCCL_INT8 = 0, RCCL_INT32 = 2, RCCL_UINT32 = 3, RCCL_INT64 = 4, RCCL_FLOAT32 = 7, RCCL_FLOAT64 = 8, RCCL_SUM = 0 };
 
 struct RcclApi {
     void* lib = nullptr;
@@ -47,6 +49,8 @@ struct RcclApi {
     int (*CommDestroy)(rcclComm_t) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, rcclComm_t, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
+    int (*Send)(const void*, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;     // (point to point: the merge tree's joins)
+    int (*Recv)(void*, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     std::string why;
 };
@@ -77,6 +81,8 @@ RcclApi& rccl() {
         api.AllGather = (int (*)(const void*, void*, size_t, int, rcclComm_t, hipStream_t))sym("ncclAllGather");
         api.AllReduce = (int (*)(const void*, void*, size_t, int, int, rcclComm_t, hipStream_t))sym("ncclAllReduce");
         api.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+        api.Send = (int (*)(const void*, size_t, int, int, rcclComm_t, hipStream_t))sym("ncclSend");
+        api.Recv = (int (*)(void*, size_t, int, int, rcclComm_t, hipStream_t))sym("ncclRecv");
     });
     return api;
 }
@@ -291,6 +297,165 @@ int hmsg_allreduce_feature_sums(hmsg_t* h, hmsg_comm_t* c) {
                                   (long long)h->V, h->cfg.feat_dim, h->feats.p);
         HMSG_CHECK_LAUNCH();
         HIP_TRY(hipStreamSynchronize(s));
+    });
+    if (rc != HMSG_OK) c->err = h->err;
+    return rc;
+}
+
+/* ---- point to point: `bytes` of a DEVICE buffer to / from another rank (ncclSend / ncclRecv on the handle's stream; returns when
+ * the transfer has completed).  What the cross-rank joins of the sharded merge tree are made of; a host that schedules them itself
+ * can use the pair directly. */
+int hmsg_comm_send(hmsg_t* h, hmsg_comm_t* c, const void* dev_buf, int64_t bytes, int32_t dst) {
+    if (!h || !c || bytes < 0 || (bytes && !dev_buf) || dst < 0 || dst >= c->world || dst == c->rank) return HMSG_ERR_INVALID;
+    const int rc = comm_guard(&h->err, [&] {
+        HMSG_REQUIRE(c->comm, HMSG_ERR_INVALID, "hmsg_comm_send: a communicator of one rank has nobody to send to");
+        HIP_TRY(hipSetDevice(h->cfg.device_id));
+        if (bytes) rccl_try(rccl().Send(dev_buf, (size_t)bytes, RCCL_INT8, dst, c->comm, h->stream), "ncclSend");
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    });
+    if (rc != HMSG_OK) c->err = h->err;
+    return rc;
+}
+int hmsg_comm_recv(hmsg_t* h, hmsg_comm_t* c, void* dev_buf, int64_t bytes, int32_t src) {
+    if (!h || !c || bytes < 0 || (bytes && !dev_buf) || src < 0 || src >= c->world || src == c->rank) return HMSG_ERR_INVALID;
+    const int rc = comm_guard(&h->err, [&] {
+        HMSG_REQUIRE(c->comm, HMSG_ERR_INVALID, "hmsg_comm_recv: a communicator of one rank has nobody to receive from");
+        HIP_TRY(hipSetDevice(h->cfg.device_id));
+        if (bytes) rccl_try(rccl().Recv(dev_buf, (size_t)bytes, RCCL_INT8, src, c->comm, h->stream), "ncclRecv");
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    });
+    if (rc != HMSG_OK) c->err = h->err;
+    return rc;
+}
+
+/* ---- hierarchical_merge (graph_utils.py:989-1012) of ONE episode whose frame windows are spread over the ranks, in one call per
+ * rank (configs[4]; until round 5 the schedule was Python: holoagent_amd/dist.py sharded_hierarchical_merge over torch.distributed):
+ *   1. hmsg_merge_tree_local: the levels inside this rank's window;
+ *   2. all-gather of (lists, index): the ranks agree on the level they meet at -- a rank that stopped lower holds the last, unpaired
+ *      list of its level and carries it up unchanged, as merge_adjacent_frames does with an odd last list;
+ *   3. level by level: the owner of list 2k + 1 sends its clouds (count, sizes, points: HBM to HBM, ncclSend / ncclRecv) to the
+ *      owner of list 2k, which merges [mine ++ theirs] (hmsg_merge_tree_join; the last join runs the final pass).  Owners are
+ *      tracked per list: any number of ranks.
+ * holds_result = 1 on the rank that ends with the episode's instances (rank 0's window starts the episode), bit-identical to a
+ * one-process hmsg_merge_instances. */
+int hmsg_merge_tree_sharded(hmsg_t* h, hmsg_comm_t* c, int32_t total_frames, int32_t* holds_result) {
+    if (!h || !c || !holds_result) return HMSG_ERR_INVALID;
+    *holds_result = 0;
+    const int rc = comm_guard(&h->err, [&] {
+        HIP_TRY(hipSetDevice(h->cfg.device_id));
+        hipStream_t s = h->stream;
+        const int W = c->world, me = c->rank;
+        const double factor = h->cfg.overlap_thresh_factor;
+        auto next_th = [&](double th, long long lists) { return lists > 1 ? th - factor * (double)(lists - 2) / (double)std::max<long long>(1, lists - 1) : th; };
+        double th = 0.0;
+        int64_t lists = 0, idx = 0;
+        const int rc_local = hmsg_merge_tree_local(h, total_frames, &th, &lists, &idx);
+        // (a rank whose local levels failed must not leave the others in the collective below: agree first)
+        if (!all_ranks_ok(c, rc_local == HMSG_OK, s))
+            throw hmsg_error{rc_local != HMSG_OK ? rc_local : HMSG_ERR_INVALID,
+                             rc_local != HMSG_OK ? h->err : std::string("hmsg_merge_tree_sharded: another rank's local merge failed (see its hmsg_last_error)")};
+        std::vector<long long> meta((size_t)W * 2, 0);
+        meta[(size_t)me * 2] = lists;
+        meta[(size_t)me * 2 + 1] = idx;
+        if (c->comm) {
+            DevBuf<long long> dm;
+            dm.alloc((size_t)W * 2);
+            HIP_TRY(hipMemcpyAsync(dm.p + (size_t)me * 2, meta.data() + (size_t)me * 2, 16, hipMemcpyHostToDevice, s));
+            rccl_try(rccl().AllGather(dm.p + (size_t)me * 2, dm.p, 2, RCCL_INT64, c->comm, s), "ncclAllGather (tree levels)");
+            HIP_TRY(hipMemcpyAsync(meta.data(), dm.p, (size_t)W * 16, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
+        long long target = meta[0];
+        for (int r = 0; r < W; ++r) target = std::min(target, meta[(size_t)r * 2]);
+        std::vector<int> owner;                  // list index at the common level -> rank (every rank derives the same table)
+        for (int r = 0; r < W; ++r) {
+            long long l = meta[(size_t)r * 2], i = meta[(size_t)r * 2 + 1];
+            double t = th;
+            while (l > target) {
+                HMSG_REQUIRE(i == l - 1 && l % 2 == 1, HMSG_ERR_INVALID,
+                             "hmsg_merge_tree_sharded: rank " + std::to_string(r) + "'s frame window is not a subtree of the merge tree");
+                i /= 2;
+                l = (l + 1) / 2;
+                t = next_th(t, l);
+            }
+            if ((long long)owner.size() <= i) owner.resize((size_t)i + 1, -1);
+            HMSG_REQUIRE(owner[(size_t)i] < 0, HMSG_ERR_INVALID, "hmsg_merge_tree_sharded: two ranks hold list " + std::to_string(i));
+            owner[(size_t)i] = r;
+            if (r == me) {
+                th = t;
+                lists = l;
+                idx = i;
+            }
+        }
+        HMSG_REQUIRE((long long)owner.size() == lists && std::find(owner.begin(), owner.end(), -1) == owner.end(), HMSG_ERR_INVALID,
+                     "hmsg_merge_tree_sharded: the ranks' windows do not cover the lists of their common level");
+        if (lists == 1) {                        // one rank held every frame
+            if (owner[0] == me) {
+                const int rj = hmsg_merge_tree_join(h, 0, nullptr, nullptr, th, 1);
+                if (rj != HMSG_OK) throw hmsg_error{rj, h->err};
+                *holds_result = 1;
+            }
+            return;
+        }
+        bool active = true;
+        DevBuf<long long> d_n, d_sizes;
+        DevBuf<double> d_pts;
+        d_n.alloc(1);
+        while (lists > 1) {
+            const long long nxt = (lists + 1) / 2;
+            if (active && idx % 2 == 1) {        // my list is the odd one of its pair: it travels
+                const int dst = owner[(size_t)idx - 1];
+                const long long n = hmsg_num_instances(h);
+                std::vector<int64_t> sizes((size_t)std::max<long long>(n, 1));
+                if (n && hmsg_get_instance_sizes(h, sizes.data()) != HMSG_OK) throw hmsg_error{HMSG_ERR_INVALID, h->err};
+                long long total = 0;
+                for (long long k = 0; k < n; ++k) total += sizes[(size_t)k];
+                HIP_TRY(hipMemcpyAsync(d_n.p, &n, 8, hipMemcpyHostToDevice, s));
+                rccl_try(rccl().Send(d_n.p, 1, RCCL_INT64, dst, c->comm, s), "ncclSend (count)");
+                if (n) {
+                    d_sizes.ensure((size_t)n);
+                    HIP_TRY(hipMemcpyAsync(d_sizes.p, sizes.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
+                    rccl_try(rccl().Send(d_sizes.p, (size_t)n, RCCL_INT64, dst, c->comm, s), "ncclSend (sizes)");
+                    if (total) {
+                        d_pts.ensure((size_t)total * 3);
+                        if (hmsg_get_instance_points(h, d_pts.p) != HMSG_OK) throw hmsg_error{HMSG_ERR_INVALID, h->err};      // HBM -> HBM
+                        rccl_try(rccl().Send(d_pts.p, (size_t)total * 3, RCCL_FLOAT64, dst, c->comm, s), "ncclSend (points)");
+                    }
+                }
+                HIP_TRY(hipStreamSynchronize(s));
+                active = false;
+            } else if (active && idx + 1 < lists) {      // I hold the even one: merge [mine ++ theirs]
+                const int src = owner[(size_t)idx + 1];
+                long long n = 0;
+                rccl_try(rccl().Recv(d_n.p, 1, RCCL_INT64, src, c->comm, s), "ncclRecv (count)");
+                HIP_TRY(hipMemcpyAsync(&n, d_n.p, 8, hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                std::vector<int64_t> sizes((size_t)std::max<long long>(n, 1));
+                long long total = 0;
+                if (n) {
+                    d_sizes.ensure((size_t)n);
+                    rccl_try(rccl().Recv(d_sizes.p, (size_t)n, RCCL_INT64, src, c->comm, s), "ncclRecv (sizes)");
+                    HIP_TRY(hipMemcpyAsync(sizes.data(), d_sizes.p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+                    HIP_TRY(hipStreamSynchronize(s));
+                    for (long long k = 0; k < n; ++k) total += sizes[(size_t)k];
+                    if (total) {
+                        d_pts.ensure((size_t)total * 3);
+                        rccl_try(rccl().Recv(d_pts.p, (size_t)total * 3, RCCL_FLOAT64, src, c->comm, s), "ncclRecv (points)");
+                        HIP_TRY(hipStreamSynchronize(s));
+                    }
+                }
+                const int rj = hmsg_merge_tree_join(h, (int32_t)n, sizes.data(), total ? d_pts.p : nullptr, th, nxt == 1 ? 1 : 0);   // (reads the receive buffer in place)
+                if (rj != HMSG_OK) throw hmsg_error{rj, h->err};
+            }
+            // (an even list without a partner is carried to the next level unchanged)
+            std::vector<int> up((size_t)nxt, -1);
+            for (long long k = 0; k < lists; k += 2) up[(size_t)(k / 2)] = owner[(size_t)k];
+            owner.swap(up);
+            idx /= 2;
+            lists = nxt;
+            th = next_th(th, lists);
+        }
+        *holds_result = active ? 1 : 0;
     });
     if (rc != HMSG_OK) c->err = h->err;
     return rc;

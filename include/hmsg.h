@@ -606,6 +606,19 @@ const char* hmsg_comm_last_error(const hmsg_comm_t* c);
  * room_off[rank] + local room id (n_rooms_local = rooms of this rank's graph, rooms without objects included); the index
  * answers like hmsg_index_create over the concatenated tables.  node_off / room_off: [world + 1], optional. */
 int hmsg_allgather_nodes(hmsg_t* h, hmsg_comm_t* c, int32_t n_rooms_local, hmsg_index_t** out_index, int64_t* node_off, int64_t* room_off);
+/* Point to point: `bytes` of a DEVICE buffer to / from rank dst / src (ncclSend / ncclRecv on the handle's stream; returns when the
+ * transfer has completed).  The cross-rank joins of the sharded merge tree are made of these; a host that schedules them itself can
+ * use the pair directly. */
+int hmsg_comm_send(hmsg_t* h, hmsg_comm_t* c, const void* dev_buf, int64_t bytes, int32_t dst);
+int hmsg_comm_recv(hmsg_t* h, hmsg_comm_t* c, void* dev_buf, int64_t bytes, int32_t src);
+/* hierarchical_merge (graph_utils.py:989-1012) of ONE episode whose frame windows are spread over the ranks (configs[4]), one call
+ * per rank after hmsg_fuse_frames (+ hmsg_allreduce_feature_sums): the levels inside the rank's window (hmsg_merge_tree_local), the
+ * ranks' agreement on the level they meet at (an all-gather of 16 bytes), then level by level the owner of list 2k + 1 sends its
+ * clouds -- count, sizes, points, HBM to HBM -- to the owner of list 2k, which merges [mine ++ theirs] (hmsg_merge_tree_join; the
+ * last join runs the final pass).  Any number of ranks whose windows are subtrees of the merge tree (hmsg_set_frame_window).
+ * *holds_result = 1 on the rank that ends with the episode's instances (the rank of frame 0), bit-identical to a one-process
+ * hmsg_merge_instances; hmsg_pool_instances follows there.  Until round 5 this schedule lived in Python over torch.distributed. */
+int hmsg_merge_tree_sharded(hmsg_t* h, hmsg_comm_t* c, int32_t total_frames, int32_t* holds_result);
 /* One episode fused in disjoint frame windows (configs[4]): the per-voxel feature sums and frame counters of all ranks are
  * all-reduced in place (graph.py:410-415: `sum[idx] += F; cnt[idx] += 1` over the frames commute across windows; counters
  * exact, float32 sums up to summation order) and the voxel features refreshed.  After hmsg_fuse_frames, before pooling. */

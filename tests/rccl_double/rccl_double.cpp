@@ -1,4 +1,4 @@
-// TEST DOUBLE of librccl.so (tests only; never part of the product): the six nccl* symbols holoagent_amd/csrc/hmsg_comm.hip
+// TEST DOUBLE of librccl.so (tests only; never part of the product): the nccl* symbols holoagent_amd/csrc/hmsg_comm.hip
 // resolves -- ncclGetUniqueId, ncclCommInitRank, ncclCommDestroy, ncclAllGather, ncclAllReduce, ncclGetErrorString -- over
 // POSIX shared memory between the processes of one machine, so that hmsg_allgather_nodes / hmsg_allreduce_feature_sums run with
 // world > 1 on the kernel simulator (where "device" buffers are host memory and a stream's work is done when the call returns):
@@ -22,9 +22,17 @@
 
 namespace {
 const size_t DATA_BYTES = (size_t)256 << 20;          // payload area (all ranks' pieces of one collective)
+const int MAX_RANKS = 16;
+const size_t P2P_BYTES = (size_t)8 << 20;             // one sender's mailbox (behind the collectives' payload area); larger messages go in pieces
+struct Mail {
+    std::atomic<int> full;                            // 1: the sender's mailbox holds `bytes` for rank `dst`
+    int dst;
+    size_t bytes;
+};
 struct Shared {
     std::atomic<int> ready;                           // 1 once rank 0 has initialised the barrier
     pthread_barrier_t bar;
+    Mail mail[MAX_RANKS];
     unsigned char data[1];
 };
 struct Comm {
@@ -64,7 +72,8 @@ int ncclCommInitRank(void** out, int world, ncclUniqueId id, int rank) {
     c->rank = rank;
     c->world = world;
     snprintf(c->name, sizeof c->name, "%s", id.internal);
-    c->map_bytes = sizeof(Shared) + DATA_BYTES;
+    if (world > MAX_RANKS) return 2;
+    c->map_bytes = sizeof(Shared) + DATA_BYTES + (size_t)MAX_RANKS * P2P_BYTES;
     int fd = -1;
     for (int tries = 0; tries < 20000 && fd < 0; ++tries) {
         fd = shm_open(c->name, rank == 0 ? (O_CREAT | O_RDWR) : O_RDWR, 0600);
@@ -88,6 +97,7 @@ int ncclCommInitRank(void** out, int world, ncclUniqueId id, int rank) {
         pthread_barrierattr_init(&a);
         pthread_barrierattr_setpshared(&a, PTHREAD_PROCESS_SHARED);
         pthread_barrier_init(&c->sh->bar, &a, (unsigned)world);
+        for (int r = 0; r < MAX_RANKS; ++r) c->sh->mail[r].full.store(0);
         c->sh->ready.store(1);
     } else {
         while (c->sh->ready.load() != 1) usleep(200);
@@ -136,6 +146,47 @@ int ncclAllReduce(const void* send, void* recv, size_t count, int type, int op, 
         }
     }
     pthread_barrier_wait(&c->sh->bar);
+    return 0;
+}
+
+// point to point: the sender's mailbox, a piece at a time (blocking: the call returns when the receiver has taken the last piece --
+// a stream's work is done when the call returns on the simulator)
+int ncclSend(const void* buf, size_t count, int type, int peer, void* comm, void* /*stream*/) {
+    Comm* c = (Comm*)comm;
+    size_t left = count * elsize(type);
+    if (!elsize(type) || peer < 0 || peer >= c->world || peer == c->rank) return 3;
+    Mail& m = c->sh->mail[c->rank];
+    unsigned char* box = c->sh->data + DATA_BYTES + (size_t)c->rank * P2P_BYTES;
+    const unsigned char* src = (const unsigned char*)buf;
+    while (left) {
+        const size_t n = left < P2P_BYTES ? left : P2P_BYTES;
+        while (m.full.load(std::memory_order_acquire) != 0) usleep(50);
+        memcpy(box, src, n);
+        m.dst = peer;
+        m.bytes = n;
+        m.full.store(1, std::memory_order_release);
+        src += n;
+        left -= n;
+    }
+    while (m.full.load(std::memory_order_acquire) != 0) usleep(50);
+    return 0;
+}
+int ncclRecv(void* buf, size_t count, int type, int peer, void* comm, void* /*stream*/) {
+    Comm* c = (Comm*)comm;
+    size_t left = count * elsize(type);
+    if (!elsize(type) || peer < 0 || peer >= c->world || peer == c->rank) return 3;
+    Mail& m = c->sh->mail[peer];
+    const unsigned char* box = c->sh->data + DATA_BYTES + (size_t)peer * P2P_BYTES;
+    unsigned char* dst = (unsigned char*)buf;
+    while (left) {
+        while (!(m.full.load(std::memory_order_acquire) == 1 && m.dst == c->rank)) usleep(50);
+        const size_t n = m.bytes;
+        if (n > left) return 3;
+        memcpy(dst, box, n);
+        m.full.store(0, std::memory_order_release);
+        dst += n;
+        left -= n;
+    }
     return 0;
 }
 

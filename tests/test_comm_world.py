@@ -196,3 +196,68 @@ def test_allreduce_feature_sums_with_two_ranks(tmp_path):
     assert np.array_equal(a["cnt"], cnt) and cnt.max() >= 2                                   # frame counters: exact
     np.testing.assert_allclose(a["sums"], sums, rtol=0, atol=1e-5)                            # float32 sums up to the order of addition
     np.testing.assert_allclose(a["feats"], feats, rtol=0, atol=1e-5)
+
+
+# ---- configs[4] behind the C ABI only: hmsg_allreduce_feature_sums + hmsg_merge_tree_sharded (local levels, agreement, cross-rank
+# joins over ncclSend / ncclRecv) -- no torch.distributed anywhere in the episode's path
+def _episode_frames(n_frames):
+    from holoagent_amd.synth import SceneSpec, SynthScene
+    spec = SceneSpec(seed=11, rooms_x=1, rooms_z=1, room_size=(3.6, 2.5, 3.2), objects_per_room=4, width=64, height=48, n_frames=n_frames,
+                     n_masks=8, feat_dim=16, yaw_step_deg=25.0)
+    scn = SynthScene(spec)
+    return [scn.frame(i) for i in range(n_frames)]
+
+
+def _episode_scene(L, frames, window=None):
+    S = PC.stack_frames(frames)
+    sc = PC.make_scene(L, frames, dict(feat_dim=16, merge_type=1, outlier_nb_points=20, outlier_radius=0.3))
+    sc.add_frames(S["rgb"], S["depth"], S["pose"], S["K"])
+    sc.finalize_map()
+    a, b = window if window is not None else (0, len(frames))
+    if window is not None:
+        sc.set_frame_window(a)
+    sc.add_frame_features(a, S["masks"][a:b], S["f_g"][a:b], S["f_masked"][a:b], S["f_crop"][a:b], S["n_masks"][a:b])
+    sc.fuse_frames()
+    return sc
+
+
+def _episode_worker(rank, world, tmp, n_frames, chunk):
+    os.environ["HMSG_RCCL_LIB"] = DOUBLE
+    from holoagent_amd._lib import Comm, HmsgLib
+    L = HmsgLib(PC.EMU_PATH)
+    idp = os.path.join(tmp, "id.bin")
+    if rank == 0:
+        open(idp + ".tmp", "wb").write(Comm.unique_id(lib_=L))
+        os.replace(idp + ".tmp", idp)
+    comm = Comm.create(_wait_id(idp), rank, world, lib_=L)
+    sc = _episode_scene(L, _episode_frames(n_frames), (rank * chunk, min(n_frames, (rank + 1) * chunk)))
+    sc.allreduce_feature_sums(comm)
+    holds = sc.merge_tree_sharded(comm, n_frames)
+    assert holds == (rank == 0)
+    if holds:
+        inst = sc.instances()
+        sc.pool_instances()
+        np.savez(os.path.join(tmp, "episode.npz"), sizes=np.array([len(c) for c in inst]), pts=np.concatenate(inst) if inst else np.zeros((0, 3)),
+                 pooled=sc.instance_feats())
+    comm.close()
+    sc.close()
+
+
+@pytest.mark.parametrize("world,n_frames,chunk", [(2, 4, 2), (3, 5, 2)])
+def test_sharded_merge_tree_behind_the_c_abi(tmp_path, world, n_frames, chunk):
+    """two even ranks; three ranks with a shorter last window (the last rank stops its local tree below the others and is carried
+    up): the root's instances are bit-identical to one process over all frames, the pooled features within 1e-5"""
+    from holoagent_amd._lib import HmsgLib
+    _double()
+    _spawn(_episode_worker, world, str(tmp_path), n_frames, chunk)
+    sc = _episode_scene(HmsgLib(PC.EMU_PATH), _episode_frames(n_frames))
+    sc.merge_instances()
+    ref = sc.instances()
+    sc.pool_instances()
+    ref_pooled = sc.instance_feats()
+    sc.close()
+    z = np.load(tmp_path / "episode.npz")
+    assert len(ref) > 3 and z["sizes"].tolist() == [len(c) for c in ref]
+    assert np.array_equal(z["pts"], np.concatenate(ref))
+    np.testing.assert_allclose(z["pooled"], ref_pooled, rtol=0, atol=1e-5)
+
