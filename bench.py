@@ -307,7 +307,11 @@ def main():
                 T("allreduce_feature_sums", lambda: sc.allreduce_feature_sums(state["comm"]))
             else:
                 T("allreduce_feature_sums", lambda: allreduce_feature_sums(sc, device=device))
-            holds = T("merge_tree", lambda: sharded_hierarchical_merge(sc, F, device=device))
+            if state.get("comm"):
+                # the whole sharded tree behind the C ABI (hmsg_merge_tree_sharded: local levels, agreement, joins over ncclSend / ncclRecv)
+                holds = T("merge_tree", lambda: sc.merge_tree_sharded(state["comm"], F))
+            else:
+                holds = T("merge_tree", lambda: sharded_hierarchical_merge(sc, F, device=device))
         else:
             def whole():
                 th, lists, idx = sc.merge_tree_local(F)
@@ -416,40 +420,36 @@ def main():
         def retrieve_dist_graph():
             """scene per GPU, the whole graph on every rank: node tables all-gathered behind the C ABI (hmsg_allgather_nodes, RCCL on
             HBM buffers -> ONE resident index), the levels above them -- floors -> rooms, room names, the rooms' view embeddings --
-            gathered as host tables (a few hundred KB) and made resident on the global index with global room ids (room_off);
+            as one small table per rank through the same communicator (hmsg_graph_allgather_index: global room / floor ids);
             every rank then answers its share of the queries coarse to fine on ITS OWN storey of the global table."""
-            from holoagent_amd.dist import gather_node_tables_device, shard_queries
+            from holoagent_amd.dist import shard_queries
+            from holoagent_amd._lib import Comm
             cg = state["graph"]
             cnt = cg.counts()
             rooms_c = cg.rooms()
-            gt_of = [gt_room_of(cg.room_vertices(i, r["n_vertices"])) for i, r in enumerate(rooms_c)]
-            g_ix, node_off, room_off, state["comm"] = gather_node_tables_device(sc, cnt["rooms"], state.get("comm"), local)
-            mine = dict(floor_rooms=[[i for i, r in enumerate(rooms_c) if r["floor"] == f] for f in range(cnt["floors"])],
-                        names=np.ascontiguousarray(room_name_feats[gt_of], np.float64),
-                        views=[cg.room_embeddings(i) for i in range(cnt["rooms"])], counts=cnt)
-            every = [None] * world
-            dist.all_gather_object(every, mine)
-            floors_g, names_g, views_g, floor_off = [], [], [], [0]
-            for r, e in enumerate(every):
-                floors_g += [[int(room_off[r]) + i for i in fr] for fr in e["floor_rooms"]]
-                names_g.append(e["names"])
-                views_g += [np.asarray(v, np.float64) for v in e["views"]]
-                floor_off.append(len(floors_g))
+            # (which ground-truth room a segmented region lies in only names the synthetic queries; the scene is the same every step)
+            if state.get("gt_of_key") != (cnt["rooms"], tuple(r["n_vertices"] for r in rooms_c)):
+                state["gt_of"] = [gt_room_of(cg.room_vertices(i, r["n_vertices"])) for i, r in enumerate(rooms_c)]
+                state["gt_of_key"] = (cnt["rooms"], tuple(r["n_vertices"] for r in rooms_c))
+            gt_of = state["gt_of"]
+            if state.get("comm") is None:
+                state["comm"] = Comm.from_torch(local, L)
+            # ONE call behind the C ABI: node tables (RCCL all-gather out of / into HBM) + floors -> rooms, room names, view embeddings
+            # with global ids (hmsg_graph_allgather_index) -- no Python objects travel any more
+            g_ix, node_off, room_off, floor_off = cg.allgather_index(state["comm"], np.ascontiguousarray(room_name_feats[gt_of], np.float64))
             n_rooms_g = int(room_off[-1])
-            g_ix.set_hierarchy(floors_g, np.concatenate(names_g) if n_rooms_g else None, views_g,
-                               [int(k) for e in every for k in range(e["counts"]["rooms"])])
             g_ix.set_profiling(prof_on["on"])
             qs = shard_queries(Q, rank, world)
             tq, tr = np.ascontiguousarray(text[qs]), np.ascontiguousarray(room_text[qs])
-            fl = np.full(len(qs), floor_off[rank], np.int32)      # (this rank's scene has one storey: its first floor of the global list)
+            fl = np.full(len(qs), int(floor_off[rank]), np.int32)      # (this rank's scene has one storey: its first floor of the global list)
             sel, idx, room, score = g_ix.query_hier(tq, np.zeros(len(qs), np.int32), tr, fl, np.ones(len(qs), np.int32), k,
                                                     max_rooms=max(n_rooms_g, 10))
             state["gemm"] = g_ix.profile()
             state["rooms_hit"] = float(np.mean([int(ent_room[q_ent[q]]) in {gt_of[j] for j in s_} for q, s_ in zip(qs, sel)])) if len(qs) else None
             state["graph_counts"] = dict(floors=cnt["floors"], rooms=cnt["rooms"], views=cnt["views"], objects=cnt["objects"],
                                          view_object_edges=int(cnt["view_object_links"]))
-            state["graph_counts_all_ranks"] = [dict(floors=e["counts"]["floors"], rooms=e["counts"]["rooms"], views=e["counts"]["views"],
-                                                    objects=e["counts"]["objects"]) for e in every]
+            state["graph_counts_all_ranks"] = [dict(floors=int(floor_off[r + 1] - floor_off[r]), rooms=int(room_off[r + 1] - room_off[r]),
+                                                    objects=int(node_off[r + 1] - node_off[r])) for r in range(world)]
             state["graph_ms"] = dict(begin=round(cnt["begin_ms"], 2), finish=round(cnt["finish_ms"], 2), kmeans_wait=round(cnt["kmeans_wait_ms"], 2))
             g_ix.close()
             return idx, room, score

@@ -153,6 +153,7 @@ _SIGS = {
     "hmsg_lidar_depth": (C.c_int, [C.c_int32, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "hmsg_crop_resize_batch": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, C.c_double, C.c_int32, _P, _P, _P]),
     "hmsg_save_objects": (C.c_int, [_P, C.c_char_p, C.c_int64, _P, C.c_int32]),
+    "hmsg_graph_allgather_index": (C.c_int, [_P, _P, _P, C.POINTER(_P), _P, _P, _P]),
     "hmsg_comm_send": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32]),
     "hmsg_comm_recv": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32]),
     "hmsg_merge_tree_sharded": (C.c_int, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),
@@ -835,6 +836,18 @@ class SceneGraph:
         nx = NodeIndex._wrap(self.L, ix, c["objects"], rn.shape[1] if rn is not None else self.D)
         nx._n_rooms = c["rooms"]
         return nx
+
+    def allgather_index(self, comm: "Comm", room_name_emb=None):
+        """configs[3] through the graph object (include/hmsg.h: hmsg_graph_allgather_index): the ranks' node tables AND the levels above
+        them -- floors -> rooms, room keys, view embeddings, room names -- into one resident index per rank, global ids throughout.
+        -> (NodeIndex, node_off, room_off, floor_off), offsets [world + 1]."""
+        ix = _P()
+        rn = None if room_name_emb is None else np.ascontiguousarray(np.asarray(room_name_emb, np.float64))
+        noff, roff, foff = (np.zeros(comm.world + 1, np.int64) for _ in range(3))
+        self._ck(self.L.c.hmsg_graph_allgather_index(self.g, comm.h, None if rn is None else _ptr(rn), C.byref(ix), _ptr(noff), _ptr(roff), _ptr(foff)))
+        nx = NodeIndex._wrap(self.L, ix, int(noff[-1]), self.D)
+        nx._n_rooms = int(roff[-1])
+        return nx, noff, roff, foff
 
     def query(self, T_obj, qid, T_room, floor_id, room_mode, k, use_negatives=True, room_name_emb=None, max_rooms=None):
         """hmsg_graph_query: floor -> room(s) -> objects on the graph's own index (made on the first call)"""

@@ -302,6 +302,44 @@ int hmsg_allreduce_feature_sums(hmsg_t* h, hmsg_comm_t* c) {
     return rc;
 }
 
+}  // extern "C"
+
+// all-gather of one byte string per rank (lengths first, then the payload padded to the longest): the small host-side tables that
+// travel with the node tables (hmsg_graph_allgather_index).  all[r] = rank r's bytes, on every rank.
+void hmsg_comm_allgather_bytes(hmsg_ctx* h, hmsg_comm* c, const void* mine, size_t my_bytes, std::vector<std::vector<char>>& all) {
+    const int W = c->world;
+    all.assign((size_t)W, std::vector<char>());
+    if (!c->comm) {
+        all[0].assign((const char*)mine, (const char*)mine + my_bytes);
+        return;
+    }
+    hipStream_t s = h->stream;
+    std::vector<long long> len((size_t)W, 0);
+    len[(size_t)c->rank] = (long long)my_bytes;
+    DevBuf<long long> dl;
+    dl.alloc((size_t)W);
+    HIP_TRY(hipMemcpyAsync(dl.p + c->rank, &len[(size_t)c->rank], 8, hipMemcpyHostToDevice, s));
+    rccl_try(rccl().AllGather(dl.p + c->rank, dl.p, 1, RCCL_INT64, c->comm, s), "ncclAllGather (table lengths)");
+    HIP_TRY(hipMemcpyAsync(len.data(), dl.p, (size_t)W * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    long long mx = 1;
+    for (long long v : len) mx = std::max(mx, v);
+    mx = (mx + 15) & ~15ll;
+    DevBuf<char> buf;
+    buf.alloc((size_t)W * (size_t)mx);
+    if (my_bytes) HIP_TRY(hipMemcpyAsync(buf.p + (size_t)c->rank * (size_t)mx, mine, my_bytes, hipMemcpyHostToDevice, s));
+    rccl_try(rccl().AllGather(buf.p + (size_t)c->rank * (size_t)mx, buf.p, (size_t)mx, RCCL_INT8, c->comm, s), "ncclAllGather (tables)");
+    std::vector<char> hostbuf((size_t)W * (size_t)mx);
+    HIP_TRY(hipMemcpyAsync(hostbuf.data(), buf.p, hostbuf.size(), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int r = 0; r < W; ++r) all[(size_t)r].assign(hostbuf.begin() + (ptrdiff_t)((size_t)r * (size_t)mx), hostbuf.begin() + (ptrdiff_t)((size_t)r * (size_t)mx + (size_t)len[(size_t)r]));
+}
+int hmsg_comm_rank(const hmsg_comm* c) { return c->rank; }
+int hmsg_comm_world(const hmsg_comm* c) { return c->world; }
+void hmsg_comm_set_error(hmsg_comm* c, const std::string& e) { c->err = e; }
+
+extern "C" {
+
 /* ---- point to point: `bytes` of a DEVICE buffer to / from another rank (ncclSend / ncclRecv on the handle's stream; returns when
  * the transfer has completed).  What the cross-rank joins of the sharded merge tree are made of; a host that schedules them itself
  * can use the pair directly. */

@@ -1441,6 +1441,118 @@ int hmsg_graph_index(hmsg_graph_t* g, const double* room_name_emb, hmsg_index_t*
     });
 }
 
+}  // extern "C"
+// (hmsg_comm.hip)
+struct hmsg_comm;
+void hmsg_comm_allgather_bytes(hmsg_ctx* h, hmsg_comm* c, const void* mine, size_t my_bytes, std::vector<std::vector<char>>& all);
+int hmsg_comm_rank(const hmsg_comm* c);
+int hmsg_comm_world(const hmsg_comm* c);
+void hmsg_comm_set_error(hmsg_comm* c, const std::string& e);
+extern "C" {
+
+/* configs[3], cross-scene retrieval with the levels above the nodes: every rank's graph -> ONE resident index on every rank.  The node
+ * tables travel as in hmsg_allgather_nodes (embeddings gathered on the device, HBM to HBM); the hierarchy -- floors -> rooms, the
+ * rooms' keys, their view embeddings and (optionally, on every rank or on none) the embeddings of their names -- as one small table per
+ * rank.  Global ids: node = node_off[rank] + local, room = room_off[rank] + local, floor = floor_off[rank] + local ([world + 1] each,
+ * optional); a query names its storey by the global floor id.  Until round 5 the benchmark gathered these tables as pickled Python
+ * objects (torch.distributed.all_gather_object) inside its timed step. */
+int hmsg_graph_allgather_index(hmsg_graph_t* g, hmsg_comm_t* c, const double* room_name_emb, hmsg_index_t** out, int64_t* node_off, int64_t* room_off,
+                               int64_t* floor_off) {
+    if (!g || !c || !out) return HMSG_ERR_INVALID;
+    *out = nullptr;
+    const int rc = gguard(g, [&] {
+        HMSG_REQUIRE(g->finished && g->h && !g->loaded, HMSG_ERR_INVALID, "hmsg_graph_allgather_index: a graph built by hmsg_graph_finish");
+        HMSG_REQUIRE(!g->merged, HMSG_ERR_UNSUPPORTED, "hmsg_graph_allgather_index: not with merge_objects_graph (the merged objects are no rows of the scene's node table)");
+        hmsg_ctx* h = g->h;
+        const int D = g->D, W = hmsg_comm_world(c), me = hmsg_comm_rank(c);
+        const int R = (int)g->rooms.size(), F = (int)g->floors.size();
+        // this rank's table: header | floor_room_off | floor_rooms | room_key | view_off | names | views
+        std::vector<int64_t> hdr = {F, R, 0, room_name_emb ? 1 : 0}, fro(1, 0), fr, key((size_t)R), voff(1, 0);
+        std::vector<double> vemb;
+        for (auto& fl : g->floors) {
+            for (int r : fl.rooms) fr.push_back(r);
+            fro.push_back((int64_t)fr.size());
+        }
+        for (int r = 0; r < R; ++r) {
+            const GRoom& rm = g->rooms[(size_t)r];
+            const size_t us = rm.id.rfind('_');
+            key[(size_t)r] = atoi(rm.id.c_str() + (us == std::string::npos ? 0 : us + 1));
+            for (float x : rm.emb) vemb.push_back((double)x);
+            voff.push_back(voff.back() + rm.n_emb);
+        }
+        hdr[2] = voff.back();
+        std::vector<char> blob;
+        auto put = [&](const void* p, size_t n) { blob.insert(blob.end(), (const char*)p, (const char*)p + n); };
+        put(hdr.data(), 32);
+        put(fro.data(), fro.size() * 8);
+        put(fr.data(), fr.size() * 8);
+        put(key.data(), key.size() * 8);
+        put(voff.data(), voff.size() * 8);
+        if (room_name_emb) put(room_name_emb, (size_t)R * D * 8);
+        put(vemb.data(), vemb.size() * 8);
+        // the node tables first (its own agreement step makes every rank fail together on a bad table)
+        std::vector<int64_t> noff((size_t)W + 1, 0), roff((size_t)W + 1, 0);
+        hmsg_index_t* ix = nullptr;
+        const int rn = hmsg_allgather_nodes(h, c, R, &ix, noff.data(), roff.data());
+        if (rn != HMSG_OK) throw hmsg_error{rn, h->err};
+        std::vector<std::vector<char>> all;
+        try {
+            hmsg_comm_allgather_bytes(h, c, blob.data(), blob.size(), all);
+            std::vector<int32_t> g_fro(1, 0), g_fr, g_key;
+            std::vector<int64_t> g_voff(1, 0), foff((size_t)W + 1, 0);
+            std::vector<double> g_names, g_views;
+            bool names_all = true, names_any = false;
+            for (int r = 0; r < W; ++r) {
+                const char* p = all[(size_t)r].data();
+                HMSG_REQUIRE(all[(size_t)r].size() >= 32, HMSG_ERR_INVALID, "hmsg_graph_allgather_index: a rank sent no table");
+                const int64_t* hd = (const int64_t*)p;
+                const int64_t Fr = hd[0], Rr = hd[1], NVr = hd[2], hn = hd[3];
+                HMSG_REQUIRE(Rr == roff[(size_t)r + 1] - roff[(size_t)r], HMSG_ERR_INVALID, "hmsg_graph_allgather_index: room counts of the two exchanges differ");
+                const int64_t* q = hd + 4;
+                const int64_t* r_fro = q;
+                q += Fr + 1;
+                const int64_t* r_fr = q;
+                q += r_fro[Fr];
+                const int64_t* r_key = q;
+                q += Rr;
+                const int64_t* r_voff = q;
+                q += Rr + 1;
+                const double* r_names = (const double*)q;
+                const double* r_views = r_names + (hn ? (size_t)Rr * D : 0);
+                names_all = names_all && hn != 0;
+                names_any = names_any || hn != 0;
+                for (int64_t f = 0; f < Fr; ++f) {
+                    for (int64_t k = r_fro[f]; k < r_fro[f + 1]; ++k) g_fr.push_back((int32_t)(r_fr[k] + roff[(size_t)r]));
+                    g_fro.push_back((int32_t)g_fr.size());
+                }
+                foff[(size_t)r + 1] = foff[(size_t)r] + Fr;
+                for (int64_t k = 0; k < Rr; ++k) {
+                    g_key.push_back((int32_t)r_key[k]);
+                    g_voff.push_back(g_voff.back() + (r_voff[k + 1] - r_voff[k]));
+                }
+                if (hn) g_names.insert(g_names.end(), r_names, r_names + (size_t)Rr * D);
+                g_views.insert(g_views.end(), r_views, r_views + (size_t)NVr * D);
+            }
+            HMSG_REQUIRE(names_all || !names_any, HMSG_ERR_INVALID, "hmsg_graph_allgather_index: room name embeddings on every rank or on none");
+            const int rs = hmsg_index_set_hierarchy(ix, (int32_t)roff[(size_t)W], (int32_t)foff[(size_t)W], g_fro.data(), g_fr.data(), names_all ? g_names.data() : nullptr,
+                                                    g_voff.data(), g_views.empty() ? nullptr : g_views.data(), g_key.data());
+            if (rs != HMSG_OK) throw hmsg_error{rs, std::string("hmsg_index_set_hierarchy: ") + hmsg_index_last_error(ix)};
+            for (int r = 0; r <= W; ++r) {
+                if (node_off) node_off[r] = noff[(size_t)r];
+                if (room_off) room_off[r] = roff[(size_t)r];
+                if (floor_off) floor_off[r] = foff[(size_t)r];
+            }
+            (void)me;
+        } catch (...) {
+            hmsg_index_destroy(ix);
+            throw;
+        }
+        *out = ix;
+    });
+    if (rc != HMSG_OK) hmsg_comm_set_error(c, g->err);
+    return rc;
+}
+
 /* query_hierarchy_protected{,_icra} (graph.py:3483-3716) on the graph: hmsg_query_hier on its index (made on the first call, with
  * room_name_emb; pass the same table on later calls or NULL) */
 int hmsg_graph_query(hmsg_graph_t* g, const double* room_name_emb, int32_t Q, int32_t C, const float* T_obj, const int32_t* qid, const float* T_room,

@@ -606,6 +606,13 @@ const char* hmsg_comm_last_error(const hmsg_comm_t* c);
  * room_off[rank] + local room id (n_rooms_local = rooms of this rank's graph, rooms without objects included); the index
  * answers like hmsg_index_create over the concatenated tables.  node_off / room_off: [world + 1], optional. */
 int hmsg_allgather_nodes(hmsg_t* h, hmsg_comm_t* c, int32_t n_rooms_local, hmsg_index_t** out_index, int64_t* node_off, int64_t* room_off);
+/* The same with the levels above the nodes (configs[3] through the graph object): every rank's graph -> ONE resident index on every
+ * rank -- node tables as above, plus floors -> rooms, the rooms' keys and view embeddings and (on every rank or on none) the embeddings of
+ * the rooms' names, all with global ids: room = room_off[rank] + local, floor = floor_off[rank] + local ([world + 1] each, optional).
+ * hmsg_query_hier on the result addresses a storey by its global floor id.  (The benchmark driver used to gather these tables as
+ * pickled Python objects inside its timed step.) */
+int hmsg_graph_allgather_index(hmsg_graph_t* g, hmsg_comm_t* c, const double* room_name_emb, hmsg_index_t** out, int64_t* node_off,
+                               int64_t* room_off, int64_t* floor_off);
 /* Point to point: `bytes` of a DEVICE buffer to / from rank dst / src (ncclSend / ncclRecv on the handle's stream; returns when the
  * transfer has completed).  The cross-rank joins of the sharded merge tree are made of these; a host that schedules them itself can
  * use the pair directly. */

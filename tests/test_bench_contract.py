@@ -50,7 +50,7 @@ def test_bench_line_full_graph_on_the_simulator():
 def test_bench_two_ranks_time_the_same_step_on_the_simulator():
     """`bench.py --gpus 2` (scene per GPU) with two simulator ranks: gloo for the process group, the test-double librccl
     (tests/rccl_double) under the C-ABI collectives.  Every rank builds its WHOLE graph (the step one GPU times), the node tables are
-    all-gathered by hmsg_allgather_nodes, the levels above them made resident on the global index, and the ranks answer their share
+    all-gathered together with the levels above them by hmsg_graph_allgather_index, and the ranks answer their share
     of the queries coarse to fine -- the line carries the same graph_counts as the one-GPU line, per rank."""
     from tests.test_comm_world import _double
     env = dict(os.environ, HMSG_BENCH_EMU=PC.EMU_PATH, HMSG_RCCL_LIB=_double(), MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
@@ -66,7 +66,8 @@ def test_bench_two_ranks_time_the_same_step_on_the_simulator():
     assert d["graph_level"].startswith("C ABI graph object")
     assert "configs[3]" in d["config"]["workload"] and d["config"]["parallelism"] == "scene-per-gpu x2"
     per = d["graph_counts_all_ranks"]
-    assert len(per) == 2 and all(c["floors"] >= 1 and c["rooms"] >= 1 and c["views"] == 12 and c["objects"] >= 3 for c in per)
+    # (per rank: what hmsg_graph_allgather_index's offsets say -- floors, rooms, object nodes of every rank's graph)
+    assert len(per) == 2 and all(c["floors"] >= 1 and c["rooms"] >= 1 and c["objects"] >= 3 for c in per)
     assert d["graph_counts"]["views"] == 12 and d["value"] > 0 and len(d["per_rank_frames_per_s"]) == 2
     st = d["stage_ms_per_step"]
     assert "room_level/device" in st and "assemble/graph_finish" in st and st["retrieval"] > 0

@@ -261,3 +261,93 @@ def test_sharded_merge_tree_behind_the_c_abi(tmp_path, world, n_frames, chunk):
     assert np.array_equal(z["pts"], np.concatenate(ref))
     np.testing.assert_allclose(z["pooled"], ref_pooled, rtol=0, atol=1e-5)
 
+
+# ---- configs[3] through the graph object: hmsg_graph_allgather_index (node tables + the levels above them, global ids)
+def _graph_worker(rank, world, tmp):
+    os.environ["HMSG_RCCL_LIB"] = DOUBLE
+    from holoagent_amd._lib import Comm, HmsgLib, SceneGraph
+    L = HmsgLib(PC.EMU_PATH)
+    idp = os.path.join(tmp, "id.bin")
+    if rank == 0:
+        open(idp + ".tmp", "wb").write(Comm.unique_id(lib_=L))
+        os.replace(idp + ".tmp", idp)
+    comm = Comm.create(_wait_id(idp), rank, world, lib_=L)
+    frames = _scene_frames(40 + rank, n_frames=6)
+    S = PC.stack_frames(frames)
+    sc = PC.make_scene(L, frames, dict(feat_dim=16, outlier_nb_points=20, outlier_radius=0.3, feat_dbscan_min=8))
+    sc.add_frames(S["rgb"], S["depth"], S["pose"], S["K"])
+    sc.finalize_map()
+    sc.add_frame_features(0, S["masks"], S["f_g"], S["f_masked"], S["f_crop"], S["n_masks"])
+    sc.fuse_frames()
+    sc.merge_instances()
+    sc.pool_instances()
+    cg = SceneGraph.build(sc, S["pose"], S["f_g"], num_views=3, host_threads=1)
+    cnt = cg.counts()
+    rooms = cg.rooms()
+    rng = np.random.Generator(np.random.PCG64(100 + rank))
+    names = rng.standard_normal((cnt["rooms"], 16))
+    names /= np.linalg.norm(names, axis=1, keepdims=True)
+    nodes, emb = sc.nodes(embeddings=True)
+    np.savez(os.path.join(tmp, "graph%d.npz" % rank), emb=emb, room=np.array([int(n["room"]) for n in nodes], np.int32), names=names,
+             floors=np.array([r["floor"] for r in rooms], np.int32), n_floors=cnt["floors"],
+             keys=np.array([int(r["room_id"].split("_")[-1]) for r in rooms], np.int32),
+             views=np.concatenate([np.asarray(cg.room_embeddings(i), np.float64).reshape(-1, 16) for i in range(cnt["rooms"])] + [np.zeros((0, 16))]),
+             n_views=np.array([len(cg.room_embeddings(i)) for i in range(cnt["rooms"])], np.int64))
+    ix, noff, roff, foff = cg.allgather_index(comm, names)
+    T, Tr, fl = _hier_queries(int(foff[-1]))
+    out = {}
+    for mode in (1, 2, 0):
+        sel, idx, room, score = ix.query_hier(T, np.zeros(len(T), np.int32), Tr, fl, np.full(len(T), mode, np.int32), 3, max_rooms=16)
+        out["sel%d" % mode] = np.array([s + [-1] * (16 - len(s)) for s in sel], np.int32)
+        out["idx%d" % mode], out["room%d" % mode], out["score%d" % mode] = idx, room, score
+    np.savez(os.path.join(tmp, "gans%d.npz" % rank), noff=noff, roff=roff, foff=foff, **out)
+    ix.close()
+    cg.close()
+    comm.close()
+    sc.close()
+
+
+def _hier_queries(n_floors_total, Q=8, D=16):
+    rng = np.random.Generator(np.random.PCG64(3))
+    T = rng.standard_normal((Q, 2, D)).astype(np.float32)
+    Tr = rng.standard_normal((Q, D)).astype(np.float32)
+    Tr /= np.linalg.norm(Tr, axis=1, keepdims=True)
+    return T, Tr, (np.arange(Q) % max(n_floors_total, 1)).astype(np.int32)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_graph_allgather_index_with_several_ranks(tmp_path, world):
+    """every rank's graph (its own scene: floors, rooms, KMeans views, objects) -> one index per rank; each answers hmsg_query_hier
+    (label mode, view mode, no room stage) like ONE index built from the concatenated tables with shifted room / floor ids"""
+    from holoagent_amd._lib import HmsgLib, NodeIndex
+    _double()
+    _spawn(_graph_worker, world, str(tmp_path))
+    tabs = [np.load(tmp_path / ("graph%d.npz" % r)) for r in range(world)]
+    roff = np.concatenate([[0], np.cumsum([len(t["floors"]) for t in tabs])])
+    foff = np.concatenate([[0], np.cumsum([int(t["n_floors"]) for t in tabs])])
+    noff = np.concatenate([[0], np.cumsum([len(t["room"]) for t in tabs])])
+    emb = np.concatenate([t["emb"].reshape(-1, 16) for t in tabs]).astype(np.float32)
+    rooms = np.concatenate([t["room"] + roff[r] for r, t in enumerate(tabs)]).astype(np.int32)
+    floor_rooms = []
+    for r, t in enumerate(tabs):
+        for f in range(int(t["n_floors"])):
+            floor_rooms.append([int(roff[r] + i) for i in np.where(t["floors"] == f)[0]])
+    views = []
+    for t in tabs:
+        o = np.concatenate([[0], np.cumsum(t["n_views"])])
+        views += [t["views"][o[i]:o[i + 1]] for i in range(len(t["n_views"]))]
+    one = NodeIndex(emb.astype(np.float64), rooms, lib_=HmsgLib(PC.EMU_PATH))
+    one.set_hierarchy(floor_rooms, np.concatenate([t["names"] for t in tabs]), views, np.concatenate([t["keys"] for t in tabs]).tolist())
+    T, Tr, fl = _hier_queries(int(foff[-1]))
+    assert len(emb) >= 2 * world and int(foff[-1]) == world
+    for mode in (1, 2, 0):
+        sel, idx, room, score = one.query_hier(T, np.zeros(len(T), np.int32), Tr, fl, np.full(len(T), mode, np.int32), 3, max_rooms=16)
+        sel = np.array([s + [-1] * (16 - len(s)) for s in sel], np.int32)
+        assert (idx >= 0).any()
+        for r in range(world):
+            z = np.load(tmp_path / ("gans%d.npz" % r))
+            assert list(z["noff"]) == list(noff) and list(z["roff"]) == list(roff) and list(z["foff"]) == list(foff)
+            assert np.array_equal(z["sel%d" % mode], sel) and np.array_equal(z["idx%d" % mode], idx), (mode, r)
+            assert np.array_equal(z["room%d" % mode], room) and np.array_equal(z["score%d" % mode], score), (mode, r)
+    one.close()
+
