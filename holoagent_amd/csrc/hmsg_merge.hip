@@ -995,38 +995,69 @@ struct Merger {
         } else {
             // shortcut (2): only pairs with a fresh member; enumerate from the (few) fresh clouds
             // (AABBs in SoA form: the reject test -- boxes disjoint on some axis, overlap volume 0 -- is the hot loop)
-            std::vector<double> lo[3], hi[3];
-            std::vector<unsigned char> fr(n), cand((size_t)n + 8, 0);
+            // Round 6: the fresh clouds of a step -- a frame's masks and what the last step changed -- sit in the camera's view, the
+            // list holds the whole scene: ONE pass keeps the clouds whose box meets the fresh clouds' common box, the per-cloud
+            // passes then run over those (a tenth of the list at configs[1]); buffers are kept between steps.
+            std::vector<double>* lo = fp_lo;
+            std::vector<double>* hi = fp_hi;
             for (int a = 0; a < 3; ++a) {
-                lo[a].resize(n);
-                hi[a].resize(n);
+                lo[a].resize((size_t)n);
+                hi[a].resize((size_t)n);
             }
+            fp_fr.resize((size_t)n);
+            fp_cand.assign((size_t)n + 8, 0);
+            std::vector<unsigned char>& fr = fp_fr;
+            double u[6] = {1e300, -1e300, 1e300, -1e300, 1e300, -1e300};
             for (int j = 0; j < n; ++j) {
-                fr[j] = L[j].fresh ? 1 : 0;
+                fr[(size_t)j] = L[j].fresh ? 1 : 0;
                 for (int a = 0; a < 3; ++a) {
-                    lo[a][j] = L[j].n ? L[j].mn[a] : 1e300;      // empty clouds never pair
-                    hi[a][j] = L[j].n ? L[j].mx[a] : -1e300;
+                    lo[a][(size_t)j] = L[j].n ? L[j].mn[a] : 1e300;      // empty clouds never pair
+                    hi[a][(size_t)j] = L[j].n ? L[j].mx[a] : -1e300;
+                }
+                if (fr[(size_t)j] && L[j].n)
+                    for (int a = 0; a < 3; ++a) {
+                        u[2 * a] = std::min(u[2 * a], L[j].mn[a]);
+                        u[2 * a + 1] = std::max(u[2 * a + 1], L[j].mx[a]);
+                    }
+            }
+            if (!(u[0] <= u[1])) return;                        // no fresh cloud with points
+            box_mask(n, lo[0].data(), hi[0].data(), lo[1].data(), hi[1].data(), lo[2].data(), hi[2].data(), u, fp_cand.data());
+            fp_sub.clear();
+            for (int j = 0; j < n; ++j)
+                if (fp_cand[(size_t)j]) fp_sub.push_back(j);
+            const int m = (int)fp_sub.size();
+            for (int a = 0; a < 3; ++a) {
+                fp_slo[a].resize((size_t)m);
+                fp_shi[a].resize((size_t)m);
+                for (int q = 0; q < m; ++q) {
+                    fp_slo[a][(size_t)q] = lo[a][(size_t)fp_sub[(size_t)q]];
+                    fp_shi[a][(size_t)q] = hi[a][(size_t)fp_sub[(size_t)q]];
                 }
             }
+            fp_cand.assign((size_t)m + 8, 0);
             for (int i = 0; i < n; ++i) {
-                if (!fr[i] || L[i].n == 0) continue;
-                const double l0 = lo[0][i], h0 = hi[0][i], l1 = lo[1][i], h1 = hi[1][i], l2 = lo[2][i], h2 = hi[2][i];
+                if (!fr[(size_t)i] || L[i].n == 0) continue;
                 // branch-free mask pass (vectorised), then a sparse walk over the few survivors
-                unsigned char* cm = cand.data();
-                const double q[6] = {l0, h0, l1, h1, l2, h2};
-                box_mask(n, lo[0].data(), hi[0].data(), lo[1].data(), hi[1].data(), lo[2].data(), hi[2].data(), q, cm);
-                for (int j0 = 0; j0 < n; j0 += 8) {
+                unsigned char* cm = fp_cand.data();
+                const double q[6] = {lo[0][(size_t)i], hi[0][(size_t)i], lo[1][(size_t)i], hi[1][(size_t)i], lo[2][(size_t)i], hi[2][(size_t)i]};
+                box_mask(m, fp_slo[0].data(), fp_shi[0].data(), fp_slo[1].data(), fp_shi[1].data(), fp_slo[2].data(), fp_shi[2].data(), q, cm);
+                for (int j0 = 0; j0 < m; j0 += 8) {
                     unsigned long long w;
                     std::memcpy(&w, cm + j0, 8);               // cand is padded to a multiple of 8
                     if (!w) continue;
-                    for (int j = j0; j < std::min(j0 + 8, n); ++j) {
-                        if (!cm[j] || j == i || (fr[j] && j < i)) continue;
+                    for (int jq = j0; jq < std::min(j0 + 8, m); ++jq) {
+                        const int j = fp_sub[(size_t)jq];
+                        if (!cm[jq] || j == i || (fr[(size_t)j] && j < i)) continue;
                         consider(std::min(i, j), std::max(i, j));
                     }
                 }
             }
         }
     }
+    // (find_pairs' buffers, kept between steps)
+    std::vector<double> fp_lo[3], fp_hi[3], fp_slo[3], fp_shi[3];
+    std::vector<unsigned char> fp_fr, fp_cand;
+    std::vector<int> fp_sub;
 
     // ---- components of `overlap > th` (scipy connected_components labels by lowest member index)
     void make_components(const std::vector<Cloud>& L, const std::vector<std::pair<int, int>>& pairs, const std::vector<double>& ratio,
