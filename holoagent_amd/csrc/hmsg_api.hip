@@ -262,6 +262,7 @@ int hmsg_reset(hmsg_t* h) {
 int hmsg_set_profiling(hmsg_t* h, int32_t on) {
     if (!h) return HMSG_ERR_INVALID;
     h->prof.enabled = on != 0;
+    h->prof.detail = on >= 2;
     return HMSG_OK;
 }
 

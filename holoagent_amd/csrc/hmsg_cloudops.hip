@@ -1649,7 +1649,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     nclist.ensure((size_t)std::max<long long>(N, 1));
     unsigned char* const pc_w = gather ? gather->poolcore_w : (unsigned char*)nullptr;
     {
-    ProfScope ps(prof, s, "k_db_core", (double)N * 33.0);    // (k_db_fill + k_db_count: sorted copy, core flags -- one timed unit)
+    ProfScope ps(prof, s, "k_db_core", (double)N * 33.0, true);    // (k_db_fill + k_db_count: sorted copy, core flags -- one timed unit)
     hipLaunchKernelGGL(k_db_fill, dim3(gN), dim3(256), 0, s, src, N, (const long long*)cellid.p, (const unsigned*)start.p, cursor.p,
                        ord.p, spts.p, core0, min_points, needy.p, d_nc + 3, sidx.p, core.p, score.p, hasanchor.p);   // ord: slot of every point in the cell-sorted copy
     hipLaunchKernelGGL(k_db_count, dim3((unsigned)n_cu * 8u), dim3(256), 0, s, src, (const int*)segid.p, dsegs, (const long long*)cellid.p,
@@ -1663,7 +1663,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
                        score.p, (const unsigned char*)core.p, cellbox.p, ccore.p, (const int*)cseg.p, (const unsigned char*)hasanchor.p,
                        core0 ? rep.p : (unsigned*)nullptr, parent.p, dsegs, minidx.p, active.p, pc_w);
     {
-        ProfScope ps(prof, s, "k_db_union/box", (double)N * 24.0);
+        ProfScope ps(prof, s, "k_db_union/box", (double)N * 24.0, true);
         hipLaunchKernelGGL(k_db_union, dim3(gW), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc, (const int*)cseg.p, dsegs, K,
                            (const unsigned*)minidx.p, eps * eps, (const int*)cellpos.p, (const double*)cellbox.p, parent.p,
                            (const unsigned*)active.p, (const unsigned char*)hasanchor.p);
@@ -1680,7 +1680,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
                        parent.p, (const unsigned*)minidx.p, rootmin.p, (const int*)cseg.p, dsegs, K, d_ncl, (const unsigned*)ccore.p, size.p,
                        roots.p, rhead.p, rnext.p, (const unsigned*)needy.p, (const unsigned*)(d_nc + 3), (const unsigned char*)core.p, nclist.p, d_nc + 2);
     {
-    ProfScope ps(prof, s, "k_db_label", (double)N * 28.0);
+    ProfScope ps(prof, s, "k_db_label", (double)N * 28.0, true);
     hipLaunchKernelGGL(k_db_label, dim3(std::min(gN, (unsigned)n_cu * 8u)), dim3(256), 0, s, src, (const int*)segid.p, dsegs,
                        (const long long*)cellid.p, (const unsigned*)minidx.p, (const unsigned*)start.p, (const double*)spts.p,
                        (const unsigned char*)score.p, (const int*)cellpos.p, (const double*)cellbox.p, (const int*)parent.p,
@@ -1697,14 +1697,14 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     HMSG_CHECK_LAUNCH();
     hmsg_scan_u32(flags.p, pos.p, (size_t)N, s, scan_tmp, nullptr);
     {
-    ProfScope ps(prof, s, "k_db_scatter", (double)N * 56.0);
+    ProfScope ps(prof, s, "k_db_scatter", (double)N * 56.0, true);
     hipLaunchKernelGGL(k_db_scatter, dim3(std::min(gN, (unsigned)n_cu)), dim3(256), 0, s, src, N, (const int*)segid.p, dsegs, (const unsigned*)flags.p,
                        (const unsigned*)pos.p, dst, d_ocount, (const unsigned char*)core.p, dst_core, d_obounds, (const unsigned*)d_dropped);
     }
     } else {
         const unsigned gK = (unsigned)hblk.size();
         const unsigned epoch = hmsg_scan_epoch(scan_tmp, gK, s);
-        ProfScope ps(prof, s, "k_db_scatter", (double)N * 56.0);
+        ProfScope ps(prof, s, "k_db_scatter", (double)N * 56.0, true);
         if (gK)
             hipLaunchKernelGGL(k_db_compact, dim3(gK), dim3(256), 0, s, src, dblks, (const int*)segid.p, dsegs, (const int*)label.p,
                                (const unsigned*)d_ncl, (const int*)roots.p, (const int*)rhead.p, (const int*)rnext.p, (const unsigned*)size.p, (const unsigned*)firstidx.p, (const unsigned*)rootmin.p,

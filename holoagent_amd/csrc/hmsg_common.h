@@ -512,6 +512,7 @@ struct ProfEntry {
 };
 struct Prof {
     bool enabled = false;
+    bool detail = false;        // also the FINE scopes (the DBSCAN batch's phases: a bracket costs the fold's dependent chain ~3 us each)
     std::vector<ProfEntry> ev;
     void clear() {
         for (auto& e : ev) {
@@ -525,8 +526,9 @@ struct ProfScope {
     Prof* p;
     hipStream_t s;
     size_t i = 0;
-    ProfScope(Prof& pr, hipStream_t st, const char* name, double work = 0.0) : ProfScope(&pr, st, name, work) {}
-    ProfScope(Prof* pr, hipStream_t st, const char* name, double work = 0.0) : p(pr && pr->enabled ? pr : nullptr), s(st) {
+    ProfScope(Prof& pr, hipStream_t st, const char* name, double work = 0.0, bool fine = false) : ProfScope(&pr, st, name, work, fine) {}
+    ProfScope(Prof* pr, hipStream_t st, const char* name, double work = 0.0, bool fine = false)
+        : p(pr && pr->enabled && (!fine || pr->detail) ? pr : nullptr), s(st) {
         if (!p) return;
         ProfEntry e;
         e.name = name;

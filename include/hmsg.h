@@ -104,7 +104,9 @@ void hmsg_release_cached_memory(void);
 int hmsg_reset(hmsg_t* h);
 
 /* Live kernel timing with HIP events on the handle's stream (measurement aid for bench.py): when on, the
- * heavy kernels are bracketed by event pairs; hmsg_profile_entry aggregates them per kernel name. */
+ * heavy kernels are bracketed by event pairs; hmsg_profile_entry aggregates them per kernel name.  on = 1: the wide kernels and, in
+ * the merge fold, the overlap scans and the component pass; on = 2: every phase of the fold's DBSCAN batch as well (a bracket costs
+ * that chain of dependent launches ~3 us each: 35 us per fold step with all of them). */
 int hmsg_set_profiling(hmsg_t* h, int32_t on);
 int32_t hmsg_profile_count(hmsg_t* h);   /* distinct kernel names recorded since the last reset */
 int hmsg_profile_entry(hmsg_t* h, int32_t i, char* name /*[64]*/, int64_t* launches, double* total_ms,
