@@ -102,6 +102,7 @@ struct hmsg_comm {
     rcclComm_t comm = nullptr;
     int rank = 0, world = 1, device = 0;
     std::string err;
+    unsigned* flag = nullptr;       // 4 bytes of HBM for the ranks' agreement (made with the communicator: agreeing must not need an allocation)
 };
 
 namespace {
@@ -113,15 +114,31 @@ thread_local std::string g_comm_err;
 // first agree (a 4-byte all-reduce of an ok flag) and then fail together.
 bool all_ranks_ok(hmsg_comm* c, bool mine_ok, hipStream_t s) {
     if (!c->comm) return mine_ok;
-    DevBuf<unsigned> flag;
-    flag.alloc(1);
     const unsigned v = mine_ok ? 0u : 1u;
     unsigned sum = 0u;
-    HIP_TRY(hipMemcpyAsync(flag.p, &v, 4, hipMemcpyHostToDevice, s));
-    rccl_try(rccl().AllReduce(flag.p, flag.p, 1, RCCL_UINT32, RCCL_SUM, c->comm, s), "ncclAllReduce (ok flag)");
-    HIP_TRY(hipMemcpyAsync(&sum, flag.p, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(c->flag, &v, 4, hipMemcpyHostToDevice, s));
+    rccl_try(rccl().AllReduce(c->flag, c->flag, 1, RCCL_UINT32, RCCL_SUM, c->comm, s), "ncclAllReduce (ok flag)");
+    HIP_TRY(hipMemcpyAsync(&sum, c->flag, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return sum == 0u;
+}
+// a rank-local phase between two collectives: what it throws is kept, the ranks agree, and then all of them fail together (the rank
+// with the error reports it, the others that another rank failed) -- nobody is left waiting in the next collective
+template <typename F>
+void local_phase_then_agree(hmsg_comm* c, hipStream_t s, const char* what, F&& f) {
+    std::string mine;
+    int code = HMSG_OK;
+    try {
+        f();
+    } catch (const hmsg_error& e) {
+        mine = e.msg;
+        code = e.code;
+    } catch (const std::exception& e) {
+        mine = e.what();
+        code = HMSG_ERR_INVALID;
+    }
+    if (!all_ranks_ok(c, mine.empty(), s))
+        throw hmsg_error{mine.empty() ? HMSG_ERR_INVALID : code, mine.empty() ? std::string(what) + ": another rank failed (see its hmsg_last_error)" : mine};
 }
 template <typename F>
 int comm_guard(std::string* err, F&& f) {        // no exception crosses the C boundary
@@ -175,6 +192,7 @@ int hmsg_comm_create(const uint8_t* id, int32_t rank, int32_t world, int32_t dev
         rcclUniqueId uid;
         memcpy(uid.internal, id, sizeof(uid.internal));
         rccl_try(rccl().CommInitRank(&c->comm, world, uid, rank), "ncclCommInitRank");
+        HIP_TRY(hipMalloc((void**)&c->flag, 64));
     });
     if (rc != HMSG_OK) {
         delete c;
@@ -187,6 +205,7 @@ int hmsg_comm_create(const uint8_t* id, int32_t rank, int32_t world, int32_t dev
 void hmsg_comm_destroy(hmsg_comm_t* c) {
     if (!c) return;
     if (c->comm) (void)rccl().CommDestroy(c->comm);
+    if (c->flag) (void)hipFree(c->flag);
     delete c;
 }
 
@@ -236,10 +255,13 @@ int hmsg_allgather_nodes(hmsg_t* h, hmsg_comm_t* c, int32_t n_rooms_local, hmsg_
         // 2. payload: every rank's slot is nmax rows of D floats + nmax room ids, padded; mine is gathered on the device
         DevBuf<float> emb;                       // [W][nmax][D]
         DevBuf<int> room;                        // [W][nmax]
+        float* my_emb = nullptr;
+        int* my_room = nullptr;
+        local_phase_then_agree(c, s, "hmsg_allgather_nodes", [&] {
         emb.alloc((size_t)W * nmax * D);
         room.alloc((size_t)W * nmax);
-        float* my_emb = emb.p + (size_t)c->rank * nmax * D;
-        int* my_room = room.p + (size_t)c->rank * nmax;
+        my_emb = emb.p + (size_t)c->rank * nmax * D;
+        my_room = room.p + (size_t)c->rank * nmax;
         if (n) {
             std::vector<int> inst((size_t)n), rm((size_t)n);
             for (long long k = 0; k < n; ++k) {
@@ -255,6 +277,7 @@ int hmsg_allgather_nodes(hmsg_t* h, hmsg_comm_t* c, int32_t n_rooms_local, hmsg_
             HMSG_CHECK_LAUNCH();
             HIP_TRY(hipStreamSynchronize(s));    // (inst / rm are stack vectors)
         }
+        });
         if (c->comm) {
             rccl_try(rccl().AllGather(my_emb, emb.p, (size_t)nmax * D, RCCL_FLOAT32, c->comm, s), "ncclAllGather (embeddings)");
             rccl_try(rccl().AllGather(my_room, room.p, (size_t)nmax, RCCL_INT32, c->comm, s), "ncclAllGather (rooms)");

@@ -1231,7 +1231,8 @@ struct Merger {
                             const long long cap = (long long)sd.n + std::max<long long>(sd.n / 2, 1 << 14);
                             sd.out_off = region_total;       // (relative to the first region: fixed up below)
                             region_total += cap;
-                            seg_cap.push_back((int)std::min<long long>(cap, 0x7fffffff));
+                            HMSG_REQUIRE(cap <= 0x7fffffffll, HMSG_ERR_UNSUPPORTED, "merge fold: a merged cloud's pool region exceeds 2^31 points");
+                            seg_cap.push_back((int)cap);
                         }
                     }
                 }

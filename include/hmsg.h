@@ -519,6 +519,9 @@ typedef struct hmsg_graph_room {
     int64_t n_vertices, n_points;
     int32_t n_embeddings, n_sample_images, n_objects, n_views;
 } hmsg_graph_room;
+/* Lifetime: a BUILT graph (hmsg_build_graph / hmsg_graph_begin) keeps a plain reference to its scene handle -- the object clouds and
+ * features stay in the handle's HBM -- so hmsg_graph_finish, hmsg_save, hmsg_graph_index and hmsg_graph_allgather_index need the
+ * handle alive and not reset: destroy or reset the graph's scene only after hmsg_graph_destroy (a LOADED graph has no handle). */
 void hmsg_graph_default_params(hmsg_graph_params* p);
 int hmsg_build_graph(hmsg_t* h, const hmsg_graph_params* prm, int32_t n_frames, const double* poses, const double* poses_inv,
                      const float* view_feats, const char* const* img_paths, int32_t n_labels, const float* label_feats,
