@@ -621,6 +621,12 @@ def main():
                 per = max(1.0, round(pmc[key]["dispatches"] / max(roof["launches"], 1))) if key == "k_ov_query" else 1.0
                 roof["traffic"] = int(pmc[key]["hbm_bytes_per_launch"] * per)
                 roof["traffic_source"] = "profiles/%s (offline PMC passes, same command)" % os.path.basename(pmc_path)
+                try:
+                    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+                    from csrc_sha import csrc_sha16
+                    roof["traffic_same_build"] = json.load(open(pmc_path)).get("csrc_sha16") == csrc_sha16(ROOT)
+                except Exception:
+                    roof["traffic_same_build"] = None
         except Exception:
             pass
 
@@ -931,7 +937,15 @@ def main():
         import glob
         mp = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_mfma.json")))[-1]
         mk = json.load(open(mp))["kernels"]
-        mfma_util = {"source": "profiles/%s (offline PMC passes, same command)" % os.path.basename(mp)}
+        mj = json.load(open(mp))
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            from csrc_sha import csrc_sha16
+            same = mj.get("csrc_sha16") == csrc_sha16(ROOT)
+        except Exception:
+            same = None
+        # (committed counters, not a measurement of this run: `same_build` says whether they were taken on the sources being timed)
+        mfma_util = {"source": "profiles/%s (offline PMC passes, same command)" % os.path.basename(mp), "same_build": same}
         for name, key in (("k_pool_gram", "k_pool_gram"), ("k_gemm_f64", "k_gemm_f64_tiled")):
             if key in mk and "MfmaUtil_percent" in mk[key]:
                 mfma_util[name] = {"MfmaUtil_percent": round(mk[key]["MfmaUtil_percent"], 2),

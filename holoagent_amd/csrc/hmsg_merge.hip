@@ -1352,6 +1352,8 @@ struct Merger {
                     cells_end = (spec[j].g.ix_cell - ix_cells_used) + spec[j].ncell;
                     spec_built += 1;
                     spec_built_pts += n_idx;
+                    (spec_code[j] == 2 ? grid_delta : grid_full) += 1;
+                    (spec_code[j] == 2 ? grid_delta_pts : grid_full_pts) += n_idx;
                 } else {
                     spec_skipped += 1;
                 }
@@ -1663,7 +1665,7 @@ static void merge_report(Folder& m) {
                     t.cmulti[c], t.ccontested[c], t.cnonfixed[c]);
     }
     if (getenv("HMSG_DEBUG_TIMING"))
-        fprintf(stderr, "[hmsg merge] overlap grids: %.0f over whole clouds (%.0f points), %.0f delta grids (%.0f points); behind the DBSCAN batches: %.0f built (%.0f points), %.0f not needed\n", m.grid_full,
+        fprintf(stderr, "[hmsg merge] overlap grids: %.0f over whole clouds (%.0f points), %.0f delta grids (%.0f points); of them behind the DBSCAN batches: %.0f (%.0f points), %.0f not needed\n", m.grid_full,
                 m.grid_full_pts, m.grid_delta, m.grid_delta_pts, m.spec_built, m.spec_built_pts, m.spec_skipped);
     if (getenv("HMSG_DEBUG_TIMING") && m.n_collects)
         fprintf(stderr, "[hmsg merge] %d collections of the point pool / grid arenas\n", m.n_collects);

@@ -12,6 +12,10 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import os
+import sys
+
 d, out = sys.argv[1], sys.argv[2]
 CUS, SIMDS, XCDS = 256, 4, 8
 counters = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_VALU_MFMA_MOPS_F64", "GRBM_GUI_ACTIVE"]
@@ -35,7 +39,7 @@ for kern in sorted({k for v in data.values() for k in v}):
         row["MfmaUtil_percent_gfx94x_formula"] = 100.0 * busy / (gui * CUS * SIMDS)
         row["MfmaUtil_percent"] = 100.0 * busy / (gui / XCDS * CUS * SIMDS)
     res[kern] = row
-json.dump(dict(note="rocprofv3 --kernel-trace --pmc <one counter per pass> over python bench.py --steps 1 --warmup 0 --no-extras; "
+json.dump(dict(csrc_sha16=__import__('csrc_sha').csrc_sha16(), note="rocprofv3 --kernel-trace --pmc <one counter per pass> over python bench.py --steps 1 --warmup 0 --no-extras; "
                     "MfmaUtil = 100 * SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 256 CUs * 4 SIMDs); the uncorrected gfx94x formula beside it",
                kernels=res), open(out, "w"), indent=1)
 print(json.dumps(res, indent=1)[:2000])
