@@ -404,6 +404,14 @@ __device__ __forceinline__ bool backproject(unsigned short d, int x, int y, cons
     double a = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(X, T[0]), __dmul_rn(Y, T[1])), __dmul_rn(Z, T[2])), T[3]);
     double b = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(X, T[4]), __dmul_rn(Y, T[5])), __dmul_rn(Z, T[6])), T[7]);
     double c = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(X, T[8]), __dmul_rn(Y, T[9])), __dmul_rn(Z, T[10])), T[11]);
+    // The last row of a rigid pose is (0, 0, 0, 1): w = X*0 + Y*0 + Z*0 + 1 is 1.0 exactly (X, Y, Z are finite) and a / 1.0 is a -- the
+    // same bits without three of this function's five float64 divisions (the map and fusion passes are bound by them).
+    if (T[12] == 0.0 && T[13] == 0.0 && T[14] == 0.0 && T[15] == 1.0) {
+        wx = a;
+        wy = b;
+        wz = c;
+        return true;
+    }
     double w = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(X, T[12]), __dmul_rn(Y, T[13])), __dmul_rn(Z, T[14])), T[15]);
     wx = __ddiv_rn(a, w);
     wy = __ddiv_rn(b, w);

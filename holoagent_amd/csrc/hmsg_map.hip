@@ -104,6 +104,44 @@ unsigned long long hmsg_bitmap_rank(const unsigned long long* bitmap, unsigned* 
 }
 
 // ------------------------------------------------------------------------------------------ bounds
+// Pixel index -> (frame, row, column).  `i / HW` and `p / W` as a 64-bit and a 32-bit integer division per pixel cost these
+// streaming passes about as much as the back-projection itself (a 64-bit udiv is ~80 instructions here).  The passes walk the
+// pixels in chunks of PIX_CHUNK consecutive indices: the chunk's first frame is one division per chunk, a pixel of the chunk is at
+// most a few frames behind it (subtractions), and the row comes from a float32 reciprocal with a one-step correction (exact for
+// p < 2^24; larger frames take the integer division).
+#define PIX_CHUNK 4096
+struct PixWalk {
+    unsigned hw, w;
+    float inv_w;
+    unsigned f0, p0;        // frame / in-frame index of the chunk's first pixel
+};
+__device__ __forceinline__ PixWalk pix_walk(size_t chunk_first, size_t HW, int W) {
+    PixWalk k;
+    k.hw = (unsigned)HW;
+    k.w = (unsigned)W;
+    k.inv_w = 1.0f / (float)W;
+    k.f0 = (unsigned)(chunk_first / HW);
+    k.p0 = (unsigned)(chunk_first - (size_t)k.f0 * HW);
+    return k;
+}
+__device__ __forceinline__ void pix_at(const PixWalk& k, unsigned d /* pixels behind the chunk's first */, int& f, int& x, int& y) {
+    unsigned p = k.p0 + d, ff = k.f0;
+    while (p >= k.hw) {
+        p -= k.hw;
+        ++ff;
+    }
+    unsigned yy;
+    if (k.hw <= (1u << 24)) {
+        yy = (unsigned)((float)p * k.inv_w);
+        while (yy * k.w > p) --yy;
+        while ((yy + 1u) * k.w <= p) ++yy;
+    } else {
+        yy = p / k.w;
+    }
+    f = (int)ff;
+    y = (int)yy;
+    x = (int)(p - yy * k.w);
+}
 __global__ void k_bounds(const unsigned short* __restrict__ depth, const double* __restrict__ pose, CamK cam,
                          float scale, int H, int W, int F, unsigned long long* __restrict__ out /*[6] enc min3,max3*/,
                          unsigned long long* __restrict__ npts) {
@@ -111,17 +149,20 @@ __global__ void k_bounds(const unsigned short* __restrict__ depth, const double*
     const size_t total = HW * F;
     double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
     unsigned cnt = 0;
-    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
-        int f = (int)(g / HW);
-        int p = (int)(g - (size_t)f * HW);
-        int y = p / W, x = p - y * W;
-        double w[3];
-        if (backproject(depth[g], x, y, cam, scale, pose + (size_t)f * 16, w[0], w[1], w[2])) {
-            for (int a = 0; a < 3; ++a) {
-                mn[a] = w[a] < mn[a] ? w[a] : mn[a];
-                mx[a] = w[a] > mx[a] ? w[a] : mx[a];
+    for (size_t c0 = (size_t)blockIdx.x * PIX_CHUNK; c0 < total; c0 += (size_t)gridDim.x * PIX_CHUNK) {
+        const PixWalk pw = pix_walk(c0, HW, W);
+        for (unsigned d = threadIdx.x; d < PIX_CHUNK && c0 + d < total; d += blockDim.x) {
+            const size_t g = c0 + d;
+            int f, x, y;
+            pix_at(pw, d, f, x, y);
+            double w[3];
+            if (backproject(depth[g], x, y, cam, scale, pose + (size_t)f * 16, w[0], w[1], w[2])) {
+                for (int a = 0; a < 3; ++a) {
+                    mn[a] = w[a] < mn[a] ? w[a] : mn[a];
+                    mx[a] = w[a] > mx[a] ? w[a] : mx[a];
+                }
+                cnt++;
             }
-            cnt++;
         }
     }
     for (int a = 0; a < 3; ++a) {
@@ -143,18 +184,21 @@ __global__ void k_mark(const unsigned short* __restrict__ depth, const double* _
                        int H, int W, int F, GridGeom g, unsigned long long* __restrict__ bitmap) {
     const size_t HW = (size_t)H * W;
     const size_t total = HW * F;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        int f = (int)(i / HW);
-        int p = (int)(i - (size_t)f * HW);
-        int y = p / W, x = p - y * W;
-        double wx, wy, wz;
-        if (!backproject(depth[i], x, y, cam, scale, pose + (size_t)f * 16, wx, wy, wz)) continue;
-        int ix, iy, iz;
-        cell_of(g, wx, wy, wz, ix, iy, iz);
-        long long lin = lin_of(g, ix, iy, iz);
-        unsigned long long bit = 1ull << (lin & 63);
-        unsigned long long* wp = bitmap + (lin >> 6);
-        if (!(*wp & bit)) atomicOr(wp, bit);
+    for (size_t c0 = (size_t)blockIdx.x * PIX_CHUNK; c0 < total; c0 += (size_t)gridDim.x * PIX_CHUNK) {
+        const PixWalk pw = pix_walk(c0, HW, W);
+        for (unsigned d = threadIdx.x; d < PIX_CHUNK && c0 + d < total; d += blockDim.x) {
+            const size_t i = c0 + d;
+            int f, x, y;
+            pix_at(pw, d, f, x, y);
+            double wx, wy, wz;
+            if (!backproject(depth[i], x, y, cam, scale, pose + (size_t)f * 16, wx, wy, wz)) continue;
+            int ix, iy, iz;
+            cell_of(g, wx, wy, wz, ix, iy, iz);
+            long long lin = lin_of(g, ix, iy, iz);
+            unsigned long long bit = 1ull << (lin & 63);
+            unsigned long long* wp = bitmap + (lin >> 6);
+            if (!(*wp & bit)) atomicOr(wp, bit);
+        }
     }
 }
 
@@ -177,11 +221,8 @@ struct VoxAcc {                 // per-slot colour / count accumulators (SoA)
 //   k_accum_ordered  one lane per voxel walks its runs in order: back-project again, s += p, centroid = s / n
 #define RUN_CHUNK 4096
 __device__ __forceinline__ unsigned pixel_slot(const unsigned short* __restrict__ depth, const double* __restrict__ pose,
-                                               const CamK& cam, float scale, int W, size_t HW, size_t i, const GridGeom& g,
+                                               const CamK& cam, float scale, size_t i, int f, int x, int y, const GridGeom& g,
                                                const unsigned long long* __restrict__ bitmap, const unsigned* __restrict__ rank) {
-    const int f = (int)(i / HW);
-    const int p = (int)(i - (size_t)f * HW);
-    const int y = p / W, x = p - y * W;
     double wx, wy, wz;
     if (!backproject(depth[i], x, y, cam, scale, pose + (size_t)f * 16, wx, wy, wz)) return 0xffffffffu;
     int ix, iy, iz;
@@ -203,6 +244,7 @@ __global__ void __launch_bounds__(256) k_slots(const unsigned short* __restrict_
     const size_t total = HW * F;
     const int lane = threadIdx.x & 63;
     unsigned myruns = 0;
+    const PixWalk pw = pix_walk((size_t)blockIdx.x * RUN_CHUNK, HW, W);
     for (int it = 0; it < RUN_CHUNK / 256; ++it) {
         const size_t i = (size_t)blockIdx.x * RUN_CHUNK + (size_t)it * 256 + threadIdx.x;
         const bool in_range = i < total;
@@ -210,9 +252,10 @@ __global__ void __launch_bounds__(256) k_slots(const unsigned short* __restrict_
         unsigned cr = 0, cg = 0, cb = 0, cn = 0;
         int x = 0;
         if (in_range) {
-            slot = pixel_slot(depth, pose, cam, scale, W, HW, i, g, bitmap, rank);
+            int f, y;
+            pix_at(pw, (unsigned)it * 256u + threadIdx.x, f, x, y);
+            slot = pixel_slot(depth, pose, cam, scale, i, f, x, y, g, bitmap, rank);
             slots[i] = slot;
-            x = (int)(i % (size_t)W);
             if (slot != 0xffffffffu) {
                 const unsigned char* c = rgb + i * 3;
                 cr = c[0];
@@ -257,11 +300,13 @@ __global__ void __launch_bounds__(256) k_emit_runs(const unsigned* __restrict__ 
     if (threadIdx.x == 0) s_run = chunk_base[blockIdx.x];
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const PixWalk pw = pix_walk((size_t)blockIdx.x * RUN_CHUNK, HW, W);
     for (int it = 0; it < RUN_CHUNK / 256; ++it) {
         const size_t i = (size_t)blockIdx.x * RUN_CHUNK + (size_t)it * 256 + threadIdx.x;
         const bool in_range = i < total;
         const unsigned slot = in_range ? slots[i] : 0xffffffffu;
-        const int x = in_range ? (int)(i % (size_t)W) : 0;
+        int pf = 0, x = 0, py = 0;
+        if (in_range) pix_at(pw, (unsigned)it * 256u + threadIdx.x, pf, x, py);
         const unsigned prev = __shfl_up(slot, 1);
         const bool head = lane == 0 || prev != slot || x == 0;
         const unsigned long long heads = __ballot(head);
@@ -278,9 +323,9 @@ __global__ void __launch_bounds__(256) k_emit_runs(const unsigned* __restrict__ 
             const unsigned len = (unsigned)(lane - start_lane + 1);
             const unsigned pos = base + (unsigned)__popcll(tails & ((1ull << lane) - 1ull));
             keys[pos] = slot;
-            const size_t i0 = i - (size_t)(lane - start_lane);
-            const unsigned long long f = i0 / HW, p = i0 - f * HW;
-            vals[pos] = (f << 32) | ((p / (unsigned)W) << 20) | ((p % (unsigned)W) << 8) | (unsigned long long)len;
+            // (a run lies inside one image row: its first pixel is this lane's pixel moved left)
+            vals[pos] = ((unsigned long long)(unsigned)pf << 32) | ((unsigned long long)(unsigned)py << 20) |
+                        ((unsigned long long)(unsigned)(x - (lane - start_lane)) << 8) | (unsigned long long)len;
         }
         __syncthreads();
         if (threadIdx.x == 0) s_run += s_w[0] + s_w[1] + s_w[2] + s_w[3];
@@ -294,11 +339,20 @@ __global__ void __launch_bounds__(256) k_emit_runs(const unsigned* __restrict__ 
 // one pixel, and the points are then folded into the sum in order with broadcasts (uniform across lanes, so every
 // lane holds the sum).  A voxel seen from close by has thousands of runs: packing them 64 pixels at a time keeps
 // that chain -- the kernel lasts as long as the longest one -- short.
+// Round 6: the kernel is bound by the instructions it issues, not by the depth lines it fetches nor by the length of a chain (the
+// heaviest voxel of configs[1] holds 66 000 of the 3 * 10^8 pixels; profiles/r06_map_accum.txt).  With every lane carrying the sum, a pixel
+// costs the wave 6 lane reads and 3 additions.  LDS_SUM: the 64 points of a pack go to LDS and THREE lanes walk them, lane a adding
+// coordinate a -- one LDS read and one addition per pixel, issued once for the three chains; the points are read in the order they
+// would have been broadcast in, so every sum sees the same additions in the same order.  (LDS_SUM = false: the form until round 5,
+// HMSG_DEBUG_ACCUM_WAVES=1, kept as the comparison route of the tests.)
+template <bool LDS_SUM>
 __global__ void __launch_bounds__(256) k_accum_ordered(const unsigned short* __restrict__ depth, const double* __restrict__ pose,
                                                        CamK cam, float scale, int W, size_t HW, long long V,
                                                        const unsigned* __restrict__ off, const unsigned long long* __restrict__ runs,
                                                        const unsigned* __restrict__ cnt, double* __restrict__ pts) {
+    __shared__ double s_pt[LDS_SUM ? 4 : 1][LDS_SUM ? 64 * 3 : 1];
     const int lane = threadIdx.x & 63;
+    double* const my_pt = s_pt[LDS_SUM ? (threadIdx.x >> 6) : 0];
     const long long v = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (v >= V) return;
     double sx = 0.0, sy = 0.0, sz = 0.0;
@@ -339,15 +393,29 @@ __global__ void __launch_bounds__(256) k_accum_ordered(const unsigned short* __r
                 const int x = x0 + (lane - start);
                 backproject(depth[(size_t)f * HW + (size_t)y * W + x], x, y, cam, scale, pose + (size_t)f * 16, wx, wy, wz);
             }
-            for (int j = 0; j < npix; ++j) {
-                sx = __dadd_rn(sx, wave_bcast_f64(wx, j));
-                sy = __dadd_rn(sy, wave_bcast_f64(wy, j));
-                sz = __dadd_rn(sz, wave_bcast_f64(wz, j));
+            if (LDS_SUM) {
+                // (one wave, its own slice of LDS: the LDS queue keeps a wave's accesses in order, the barrier keeps the compiler from
+                //  moving them across each other)
+                my_pt[lane * 3] = wx;
+                my_pt[lane * 3 + 1] = wy;
+                my_pt[lane * 3 + 2] = wz;
+                __builtin_amdgcn_wave_barrier();
+                if (lane < 3)
+                    for (int j = 0; j < npix; ++j) sx = __dadd_rn(sx, my_pt[j * 3 + lane]);     // (lane a: coordinate a, in sx)
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                for (int j = 0; j < npix; ++j) {
+                    sx = __dadd_rn(sx, wave_bcast_f64(wx, j));
+                    sy = __dadd_rn(sy, wave_bcast_f64(wy, j));
+                    sz = __dadd_rn(sz, wave_bcast_f64(wz, j));
+                }
             }
             q0 = q1;
         }
     }
-    if (lane == 0) {
+    if (LDS_SUM) {
+        if (lane < 3) pts[v * 3 + lane] = __ddiv_rn(sx, (double)cnt[v]);
+    } else if (lane == 0) {
         const double n = (double)cnt[v];
         pts[v * 3 + 0] = __ddiv_rn(sx, n);
         pts[v * 3 + 1] = __ddiv_rn(sy, n);
@@ -691,10 +759,30 @@ void hmsg_build_map(hmsg_ctx* h) {
     pts0.alloc(V0 * 3);
     cols0.alloc(V0 * 3);
     {
+        // HMSG_DEBUG_ACCUM_WAVES=1: every lane carries the sums (the form until round 5)
+        static const bool lds_sum = getenv("HMSG_DEBUG_ACCUM_WAVES") == nullptr;
         ProfScope ps(h->prof, s, "k_accum_ordered", (double)total * 2.0 + (double)nruns * 8.0 + (double)V0 * 32.0);
-        hipLaunchKernelGGL(k_accum_ordered, dim3(cdiv(V0 * 64, 256)), dim3(256), 0, s, (const unsigned short*)h->depth.p,
-                           (const double*)h->pose.p, h->cam, scale, W, (size_t)H * W, (long long)V0, (const unsigned*)run_off.p,
-                           (const unsigned long long*)sb.res_vals, (const unsigned*)sn.p, pts0.p);
+        hipLaunchKernelGGL(lds_sum ? k_accum_ordered<true> : k_accum_ordered<false>, dim3(cdiv(V0 * 64, 256)), dim3(256), 0, s,
+                           (const unsigned short*)h->depth.p, (const double*)h->pose.p, h->cam, scale, W, (size_t)H * W, (long long)V0,
+                           (const unsigned*)run_off.p, (const unsigned long long*)sb.res_vals, (const unsigned*)sn.p, pts0.p);
+        HMSG_CHECK_LAUNCH();
+        if (getenv("HMSG_DEBUG_ACCUM_STATS")) {     // development aid: how the pixels are spread over the voxels
+            std::vector<unsigned> hc((size_t)V0);
+            HIP_TRY(hipMemcpyAsync(hc.data(), sn.p, (size_t)V0 * 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            std::sort(hc.begin(), hc.end());
+            double tot = 0;
+            for (unsigned c : hc) tot += c;
+            fprintf(stderr, "[hmsg map] voxels %lld  runs %llu  pixels %.0f  max %u  median %u  p99 %u\n", (long long)V0, nruns, tot, hc.back(),
+                    hc[hc.size() / 2], hc[(size_t)(hc.size() * 0.99)]);
+            for (unsigned th : {512u, 2048u, 8192u, 32768u, 131072u}) {
+                double px = 0;
+                long long nv = 0;
+                for (unsigned c : hc)
+                    if (c > th) px += c, ++nv;
+                fprintf(stderr, "[hmsg map]   more than %6u pixels: %7lld voxels holding %.3f of the pixels\n", th, nv, px / tot);
+            }
+        }
     }
     hipLaunchKernelGGL(k_finalize, dim3(cdiv(V0, 256)), dim3(256), 0, s, acc, (long long)V0, cols0.p);
     HMSG_CHECK_LAUNCH();

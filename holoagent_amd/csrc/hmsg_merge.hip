@@ -81,7 +81,7 @@ __device__ __forceinline__ int find_entry(const T* __restrict__ e, int n, unsign
 }
 
 struct OvGrid {             // device view of one cloud for the overlap kernels
-    int blk0, next;         // first workgroup of this entry in k_ov_count / k_ov_fill (work list); query tables: the cloud's delta grid (-1: none)
+    int blk0, next;         // first workgroup of this entry in k_ov_count / k_ov_fill (work list); query tables: blk0 = points in the base grid, next = the cloud's delta grid (-1: none)
     long long pt_off;       // f64 points in the pool: the points this grid indexes (building) / the cloud's first point (query tables)
     long long ix_pt;        // its cell-sorted float32 copy in ix_pts (cell starts are relative to it)
     long long ix_cell;
@@ -375,7 +375,8 @@ template <bool BLAS, bool STATS>
 __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __restrict__ gr, const OvTask* __restrict__ tasks,
                            const unsigned* __restrict__ cells, const float* __restrict__ sorted, float r2, float r,
                            int npairs, const int* __restrict__ blk_task, unsigned blk_off, unsigned* __restrict__ counts,
-                           const unsigned* __restrict__ dep_counts, double th, int chunk, unsigned long long* __restrict__ st) {
+                           const unsigned* __restrict__ dep_counts, double th, int chunk, unsigned long long* __restrict__ st,
+                           int sorted_src) {
     const unsigned blk = blockIdx.x + blk_off;
     const int ti = blk_task[blk];
     const OvTask t = tasks[ti];
@@ -444,9 +445,28 @@ __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __rest
         const int b1 = b0 + chunk < X.n ? b0 + chunk : X.n;
         const OvGrid Y2 = gr[Y.next >= 0 ? Y.next : t.y];      // (Y's delta grid, if it has one)
         const bool blas = BLAS && X.n >= 20;                   // (faiss: the BLAS route from 20 queries on -- the cloud whose points are looked up)
+        // Round 6: X's points are taken from X's OWN cell-sorted float32 copies (base grid, then delta grid: together they hold
+        // every point of the cloud once, rounded exactly as `(float)p[a]` rounds it), not from the pool in pool order -- the count
+        // does not care in which order the points are asked, and the lanes of a wave then stand in one or two cells of X, i.e. in
+        // a handful of cells of Y: their table look-ups and candidate walks fall on the same cache lines (the launch is bound by
+        // its L1 / L2 transactions, profiles/r06_fold_experiments.txt), and a point costs 12 bytes instead of 24.
+        const OvGrid X2 = gr[X.next >= 0 ? X.next : t.x];
+        const int nbx = sorted_src ? X.blk0 : 0;               // (query tables: points in the base grid)
+        const float* sx1 = nullptr;
+        const float* sx2 = nullptr;
+        if (sorted_src) {
+            sx1 = sorted + ((size_t)X.ix_pt + cells[X.ix_cell]) * 3;
+            if (X.next >= 0) sx2 = sorted + ((size_t)X2.ix_pt + cells[X2.ix_cell]) * 3 - (size_t)nbx * 3;
+        }
         for (int i = b0 + (int)threadIdx.x; i < b1; i += blockDim.x) {
-            const double* p = pool + (size_t)(X.pt_off + i) * 3;
-            const float x = (float)p[0], y = (float)p[1], z = (float)p[2];
+            float x, y, z;
+            if (sorted_src) {
+                const float* p = (i < nbx ? sx1 : sx2) + (size_t)i * 3;
+                x = p[0], y = p[1], z = p[2];
+            } else {
+                const double* p = pool + (size_t)(X.pt_off + i) * 3;
+                x = (float)p[0], y = (float)p[1], z = (float)p[2];
+            }
             bool hit;
             if (BLAS && blas) hit = Y.next >= 0 ? ov_hit2<true, STATS>(Y, Y2, cells, sorted, x, y, z, r2, r, st) : ov_hit<true, STATS>(Y, cells, sorted, x, y, z, r2, r, st);
             else hit = Y.next >= 0 ? ov_hit2<false, STATS>(Y, Y2, cells, sorted, x, y, z, r2, r, st) : ov_hit<false, STATS>(Y, cells, sorted, x, y, z, r2, r, st);
@@ -619,6 +639,7 @@ struct Merger {
     // query-table entries of a cloud: its base grid (carrying the whole cloud's point range) and, if it has one, its delta grid
     void push_grids(const Cloud& c, std::vector<OvGrid>& g) const {
         g.push_back(grid_at(c, c.bmn, c.gd, c.ix_cell, c.ix_pt, c.off, c.n));
+        g.back().blk0 = c.nb;           // (query tables: the points of the base grid -- k_ov_query walks X's sorted copies)
         if (c.has_delta) {
             g.back().next = (int)g.size();
             g.push_back(grid_at(c, c.dmn, c.gd2, c.ix_cell2, c.ix_pt2, c.off + c.nb, c.n - c.nb));
@@ -921,6 +942,7 @@ struct Merger {
         const float r2 = (float)(radius * radius);   // `D < radius**2` with a float32 D (graph_utils.py:654-655)
         const size_t prof_idx = ops.prof->ev.size();        // (algorithmic bytes are filled in after the read-back)
         static const bool two_launch = getenv("HMSG_OV_ONE_LAUNCH") == nullptr;
+        static const int ov_sorted_src = getenv("HMSG_OV_POOL_ORDER") == nullptr ? 1 : 0;   // HMSG_OV_POOL_ORDER=1: X's points from the pool (until round 5)
         // (Round 5, measured and withdrawn: the counts sent to the host by the LAST workgroup of the last launch instead of a
         //  k_publish launch behind it -- "count yourself done" needs an agent-scope release fence per workgroup, which on this
         //  chip writes the XCD's L2 back: k_ov_query 25.6 -> 157 us per launch, k_db_compact 13.7 -> 26.9 us; profiles/r05_fused_publish.txt.)
@@ -940,14 +962,14 @@ struct Merger {
                 if (nblk)
                     hipLaunchKernelGGL(ovk, dim3((unsigned)nblk), dim3(256), 0, s, (const double*)pool.p, dg, dt,
                                        (const unsigned*)ix_cells.p, (const float*)ix_pts.p, r2, r, (int)P, db, 0u, dc, (const unsigned*)nullptr, decide_th, OV_CHUNK,
-                                       d_ovstat);
+                                       d_ovstat, ov_sorted_src);
             } else {
                 for (int dir = 0; dir < 2; ++dir) {
                     const unsigned nb = dir ? nblk2 : nblk1;
                     if (!nb) continue;
                     hipLaunchKernelGGL(ovk, dim3(nb), dim3(256), 0, s, (const double*)pool.p, dg, dt,
                                        (const unsigned*)ix_cells.p, (const float*)ix_pts.p, r2, r, (int)P, db, dir ? nblk1 : 0u, dc,
-                                       (dir && decide_th >= 0.0) ? (const unsigned*)dc : (const unsigned*)nullptr, decide_th, OV_CHUNK, d_ovstat);
+                                       (dir && decide_th >= 0.0) ? (const unsigned*)dc : (const unsigned*)nullptr, decide_th, OV_CHUNK, d_ovstat, ov_sorted_src);
                 }
             }
         }

@@ -421,6 +421,7 @@ static inline unsigned long long __ballot(int pred) {
     return m;
 }
 static inline int __builtin_amdgcn_readlane(int v, int src) { return hipemu::exchange(v, src); }
+static inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_barrier(); }   // (HW: a scheduling barrier; here the lanes of a wave meet)
 static inline unsigned long long __umul64hi(unsigned long long a, unsigned long long b) { return (unsigned long long)(((unsigned __int128)a * b) >> 64); }
 static inline unsigned long long wall_clock64() { return (unsigned long long)(hipemu_now() * 1e5); }   // 100 MHz ticks
 static inline int __any(int p) { return __ballot(p) != 0; }

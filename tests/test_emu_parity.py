@@ -259,3 +259,45 @@ def test_query_exact_score_ties(L):
         assert sorted(int(i) for i in idx[0][score[0] == v]) == sorted(int(t) for t in top[sc == v])
     assert [int(i) for i in idx[0][:3]] == [0, 2, 5]             # tied nodes in candidate order
     ix.close()
+
+
+_ACCUM_SNIPPET = """
+import sys, json, hashlib
+sys.path.insert(0, {root!r})
+import numpy as np
+from tests import golden_io as GI
+from tests import parity_common as PC
+from holoagent_amd._lib import HmsgLib
+L = HmsgLib({lib!r})
+z = GI.load("build_hier")
+frames = GI.unpack_frames(z)[:6]
+cfg = GI.unpack_cfg(z)
+cfg["outlier_nb"] = 300
+sc = PC.make_scene(L, frames, dict(feat_dim=cfg["feat_dim"], outlier_nb_points=300))
+PC.check_map(sc, frames, cfg)               # (bit-identical with the oracle's ordered float64 sums)
+pts, cols = sc.map_points(colors=True)
+print("DIGEST", json.dumps([int(pts.shape[0]), hashlib.sha1(pts.tobytes()).hexdigest()]))
+"""
+
+
+def _accum_routes(lib):
+    """The ordered voxel sums (A2, hmsg_map.hip) by their two routes -- the points of a pack staged in LDS and three lanes adding a
+    coordinate each (round 6, the default), and every lane of the wave carrying all three sums (the form until round 5,
+    HMSG_DEBUG_ACCUM_WAVES=1).  The switch is read once per process: two processes, each compared with the oracle, one cloud."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for over in ({}, {"HMSG_DEBUG_ACCUM_WAVES": "1"}):
+        env = dict(os.environ)
+        env.pop("HMSG_DEBUG_ACCUM_WAVES", None)
+        env.update(over)
+        r = subprocess.run([sys.executable, "-c", _ACCUM_SNIPPET.format(root=root, lib=lib)], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout + r.stderr
+        out.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1][7:]))
+    assert out[0] == out[1] and out[0][0] > 100, out
+
+
+def test_ordered_voxel_sums_two_routes():
+    _accum_routes(PC.EMU_PATH)

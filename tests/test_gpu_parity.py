@@ -142,3 +142,42 @@ def test_merge_shortcuts_are_exact(L):
         assert len(other) == len(base)
         for a, b in zip(base, other):
             assert a.shape == b.shape and np.array_equal(a, b)
+
+
+_ACCUM_GPU_SNIPPET = """
+import sys, json, hashlib
+sys.path.insert(0, {root!r})
+import numpy as np
+from tests import parity_common as PC
+from holoagent_amd._lib import HmsgLib
+from holoagent_amd.synth import SceneSpec, SynthScene
+L = HmsgLib()
+spec = SceneSpec(seed=21, rooms_x=2, rooms_z=1, room_size=(4.0, 2.6, 3.5), objects_per_room=5, width=160,
+                 height=120, n_frames=70, n_masks=4, feat_dim=16)
+scn = SynthScene(spec)
+frames = [scn.frame(i) for i in range(spec.n_frames)]
+cfg = dict(voxel_size=0.05, clip_masked_weight=0.4418, max_mask_distance=10000, feat_dim=16)
+sc = PC.make_scene(L, frames, dict(feat_dim=16))
+PC.check_map(sc, frames, cfg)               # (bit-identical with the oracle's ordered float64 sums)
+pts, cols = sc.map_points(colors=True)
+print("DIGEST", json.dumps([int(pts.shape[0]), hashlib.sha1(pts.tobytes()).hexdigest()]))
+"""
+
+
+def test_ordered_voxel_sums_two_routes_gpu():
+    """Round 6: the ordered float64 voxel sums with a pack's points staged in LDS and three lanes adding a coordinate each (the
+    default), and with every lane carrying the sums (until round 5) -- each against the oracle, one cloud."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for over in ({}, {"HMSG_DEBUG_ACCUM_WAVES": "1"}):
+        env = dict(os.environ)
+        env.pop("HMSG_DEBUG_ACCUM_WAVES", None)
+        env.update(over)
+        r = subprocess.run([sys.executable, "-c", _ACCUM_GPU_SNIPPET.format(root=root)], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout + r.stderr
+        out.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1][7:]))
+    assert out[0] == out[1] and out[0][0] > 1000, out
