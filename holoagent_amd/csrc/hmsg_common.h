@@ -693,6 +693,28 @@ static inline int bits_for(unsigned long long n) {   // bits needed to hold valu
     return b;
 }
 
+// development aid, HMSG_DEBUG_TIMING=1: host wall time of the phases of a call (every lap drains the stream first, so the phases do
+// not overlap as they do in a normal run)
+struct DbgLaps {
+    const char* tag;
+    hipStream_t s;
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    DbgLaps(const char* tag_, hipStream_t s_) : tag(tag_), s(s_), on(getenv("HMSG_DEBUG_TIMING") != nullptr) {
+        if (on) {
+            (void)hipStreamSynchronize(s);
+            t = std::chrono::steady_clock::now();
+        }
+    }
+    void lap(const char* what) {
+        if (!on) return;
+        (void)hipStreamSynchronize(s);
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[hmsg %s] %-26s %.3f ms\n", tag, what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+
 // development aid: when HMSG_DEBUG_DUMP=<dir> is set, write a device array to <dir>/<name>.bin
 static inline void hmsg_dump(const char* name, const void* dev, size_t bytes, hipStream_t s) {
     const char* dir = getenv("HMSG_DEBUG_DUMP");

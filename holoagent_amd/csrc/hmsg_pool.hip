@@ -338,6 +338,7 @@ __global__ void k_pool_pick(const PoolSeg* __restrict__ segs, const int* __restr
     atomicMax(&best[seg_of_row[i]], key);
 }
 // mean over the selected rows in index order (np.mean axis 0 = sequential float32 adds, then / n)
+#define POOL_MEAN_AHEAD 16
 __global__ void k_pool_mean(const float* __restrict__ X, int D, const PoolSeg* __restrict__ segs, int K,
                             const int* __restrict__ final_label, const unsigned* __restrict__ csize,
                             const unsigned* __restrict__ cfirst, const unsigned long long* __restrict__ best,
@@ -357,12 +358,42 @@ __global__ void k_pool_mean(const float* __restrict__ X, int D, const PoolSeg* _
         unsigned first = 0xffffffffu - (unsigned)(key & 0xffffffffull);
         want = final_label[sg.row_base + first];
     }
+    // The additions are one serial chain per feature, but the rows that feed it are not: POOL_MEAN_AHEAD rows (and their labels) are
+    // fetched side by side, the next group while this one is being added -- a row per round trip (round 5) made the largest
+    // instance's ~5 000 rows a 3.6 ms chain on the critical path behind the Gram.
     float acc = 0.f;
     unsigned cnt = 0;
-    for (int r = 0; r < sg.n; ++r) {
-        if (want != -2 && final_label[sg.row_base + r] != want) continue;
-        acc = __fadd_rn(acc, X[(size_t)(sg.row_base + r) * D + d]);
-        ++cnt;
+    const float* const xb = X + (size_t)sg.row_base * D + d;
+    const int* const lb = final_label + sg.row_base;
+    float cur[POOL_MEAN_AHEAD], nxt[POOL_MEAN_AHEAD];
+    int curl[POOL_MEAN_AHEAD], nxtl[POOL_MEAN_AHEAD];
+#pragma unroll
+    for (int j = 0; j < POOL_MEAN_AHEAD; ++j) {
+        const int rr = min(j, sg.n - 1);
+        cur[j] = xb[(size_t)rr * D];
+        curl[j] = lb[rr];
+    }
+    for (int r = 0; r < sg.n; r += POOL_MEAN_AHEAD) {
+        if (r + POOL_MEAN_AHEAD < sg.n) {
+#pragma unroll
+            for (int j = 0; j < POOL_MEAN_AHEAD; ++j) {
+                const int rr = min(r + POOL_MEAN_AHEAD + j, sg.n - 1);
+                nxt[j] = xb[(size_t)rr * D];
+                nxtl[j] = lb[rr];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < POOL_MEAN_AHEAD; ++j) {
+            if (r + j < sg.n && (want == -2 || curl[j] == want)) {
+                acc = __fadd_rn(acc, cur[j]);
+                ++cnt;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < POOL_MEAN_AHEAD; ++j) {
+            cur[j] = nxt[j];
+            curl[j] = nxtl[j];
+        }
     }
     o[d] = cnt > 1 ? __fdiv_rn(acc, (float)cnt) : acc;
 }
@@ -390,6 +421,7 @@ void hmsg_pool(hmsg_ctx* h) {
     }
     CloudOps ops;
     ops.s = s;
+    DbgLaps laps("pool", s);
     // (a) voxel_down_sample(voxel_size) of every instance (graph.py:456)
     std::vector<SegDesc> segs(K);
     for (int k = 0; k < K; ++k) {
@@ -401,6 +433,7 @@ void hmsg_pool(hmsg_ctx* h) {
     ds.alloc((size_t)std::max<long long>(h->inst.total, 1) * 3);
     std::vector<int> dn;
     const long long P = ops.voxel_down_sample(h->inst.pts.p, segs, c.voxel_size, ds.p, dn);
+    laps.lap("voxel_down_sample");
     // (b) nearest map voxel, dist <= 0.8
     DevBuf<int> idx;
     DevBuf<unsigned> valid, pos;
@@ -417,6 +450,7 @@ void hmsg_pool(hmsg_ctx* h) {
             if (hmsg_resolve_ties(h, ties, idx.p)) break;     // bit-equal ties answered like cKDTree (hmsg_ckdtree.h)
         }
     }
+    laps.lap("nearest map voxel");
     unsigned long long R = 0;   // total valid rows
     if (P) hmsg_scan_u32(valid.p, pos.p, (size_t)P, s, ops.scan_tmp, &R);
     // rows per instance = pos at the instance boundaries
@@ -489,11 +523,13 @@ void hmsg_pool(hmsg_ctx* h) {
     csize.zero(s);
     HIP_TRY(hipMemsetAsync(cfirst.p, 0xff, Rn * 4, s));
     best.zero(s);
+    laps.lap("row offsets + buffers");
     if (R) {
         hipLaunchKernelGGL(k_pool_gather, dim3(cdiv((size_t)P * 64, 256)), dim3(256), 0, s, (const int*)idx.p,
                            (const unsigned*)valid.p, (const unsigned*)pos.p, P, (const float*)h->feats.p, D, X.p, Xn.p);
         hipLaunchKernelGGL(k_seg_rows, dim3(std::max(1u, std::min(cdiv(maxn, 256), 256u)), K), dim3(256), 0, s,
                            (const PoolSeg*)d_ps.p, seg_of_row.p);
+        laps.lap("gather + normalise");
         {
             double flop = 0;
             for (auto& g : ps) flop += (double)g.n * ((double)g.n + 1.0) * D;   // unique pairs x 2 FLOP x D
@@ -501,6 +537,7 @@ void hmsg_pool(hmsg_ctx* h) {
             hipLaunchKernelGGL(k_pool_gram, dim3((unsigned)tiles), dim3(256), 0, s, (const float*)Xn.p, D, (const PoolSeg*)d_ps.p, K,
                                (float)c.feat_dbscan_eps, adj.p, ncount.p);
         }
+        laps.lap("k_pool_gram");
         hipLaunchKernelGGL(k_pool_init, dim3(cdiv((size_t)R, 256)), dim3(256), 0, s, (const unsigned*)ncount.p, (long long)R,
                            c.feat_dbscan_min, label.p, (const PoolSeg*)d_ps.p, (const int*)seg_of_row.p, seg_first.p);
         HMSG_CHECK_LAUNCH();
@@ -521,6 +558,7 @@ void hmsg_pool(hmsg_ctx* h) {
             HIP_TRY(hipStreamSynchronize(s));
             if (!ch) break;
         }
+        laps.lap("label propagation");
         hipLaunchKernelGGL(k_pool_border, dim3(cdiv((size_t)R * 64, 256)), dim3(256), 0, s, (const unsigned*)adj.p,
                            (const PoolSeg*)d_ps.p, (const int*)seg_of_row.p, (const unsigned*)ncount.p, c.feat_dbscan_min,
                            (long long)R, (const int*)label.p, flabel.p, csize.p, cfirst.p);
@@ -528,6 +566,7 @@ void hmsg_pool(hmsg_ctx* h) {
                            (const int*)seg_of_row.p, (long long)R, (const unsigned*)csize.p, (const unsigned*)cfirst.p, best.p);
         HMSG_CHECK_LAUNCH();
     }
+    laps.lap("border + pick");
     hmsg_dump("pool_ds", ds.p, (size_t)P * 24, s);
     hmsg_dump("pool_idx", idx.p, (size_t)P * 4, s);
     hmsg_dump("pool_valid", valid.p, (size_t)P * 4, s);
@@ -540,5 +579,6 @@ void hmsg_pool(hmsg_ctx* h) {
                        (const unsigned long long*)best.p, h->inst_feats.p);
     HMSG_CHECK_LAUNCH();
     HIP_TRY(hipStreamSynchronize(s));
+    laps.lap("k_pool_mean");
     h->pooled = true;
 }

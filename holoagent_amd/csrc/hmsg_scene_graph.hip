@@ -436,7 +436,9 @@ void join_workers(hmsg_graph* g) {
 // ---- stage 3: View nodes (:1176-1189), objects (:1582-1736), edges (:1752-1775)
 void graph_finish(hmsg_graph* g, int32_t n_labels, const float* label_feats, const char* const* label_names) {
     hmsg_ctx* h = g->h;
+    DbgLaps laps("graph_finish", h->stream);
     join_workers(g);
+    laps.lap("join workers");
     const int skip = std::max(1, g->prm.skip_frames);
     // views: per floor, rooms in order, the room's images in order; the running index counts across the floor's rooms
     for (size_t fi = 0; fi < g->floors.size(); ++fi) {
@@ -458,6 +460,7 @@ void graph_finish(hmsg_graph* g, int32_t n_labels, const float* label_feats, con
             }
         }
     }
+    laps.lap("view nodes");
     // objects
     std::vector<double> fz, fh, verts;
     std::vector<int32_t> room_floor;
@@ -471,6 +474,7 @@ void graph_finish(hmsg_graph* g, int32_t n_labels, const float* label_feats, con
     need(hmsg_build_object_nodes(h, (int32_t)g->floors.size(), fz.data(), fh.data(), (int32_t)g->rooms.size(), room_floor.data(), voff.data(), verts.data(),
                                  label_feats ? n_labels : 0, label_feats),
          h, "hmsg_build_object_nodes");
+    laps.lap("hmsg_build_object_nodes");
     const int64_t N = hmsg_num_nodes(h);
     std::vector<hmsg_node> nodes((size_t)std::max<int64_t>(N, 1));
     if (N) need(hmsg_get_nodes(h, nodes.data(), nullptr), h, "hmsg_get_nodes");
@@ -488,6 +492,7 @@ void graph_finish(hmsg_graph* g, int32_t n_labels, const float* label_feats, con
         rm.objects.push_back((int)g->objects.size());
         g->objects.push_back(std::move(o));
     }
+    laps.lap("object nodes (host)");
     // view <-> object topology (:1712-1734): every (object, view of its room) pair in object order
     std::vector<int32_t> pair_inst, pair_view;
     std::vector<int> pair_obj;
@@ -515,6 +520,7 @@ void graph_finish(hmsg_graph* g, int32_t n_labels, const float* label_feats, con
         need(hmsg_object_views(h, (int32_t)NV, pinv.data(), wh.data(), h->K, (int64_t)pair_obj.size(), pair_inst.data(), pair_view.data(),
                                g->prm.min_visible_ratio, g->prm.max_view_depth, vis.data(), md.data()),
              h, "hmsg_object_views");
+        laps.lap("hmsg_object_views");
         std::vector<double> best_d(g->objects.size(), 0.0);
         for (size_t p = 0; p < pair_obj.size(); ++p) {
             if (!vis[p]) continue;
@@ -528,6 +534,7 @@ void graph_finish(hmsg_graph* g, int32_t n_labels, const float* label_feats, con
             g->views[(size_t)pair_view[p]].objects.push_back(pair_obj[p]);   // (pairs come in object order: ascending per view)
         }
     }
+    laps.lap("view lists (host)");
     for (auto& o : g->objects) {
         for (int v : o.views) o.view_ids.push_back(g->views[(size_t)v].id);
         if (o.best_view >= 0) o.best_view_id = g->views[(size_t)o.best_view].id, o.have_best = true;
@@ -542,6 +549,7 @@ void graph_finish(hmsg_graph* g, int32_t n_labels, const float* label_feats, con
         need(hmsg_get_nodes(h, nodes.data(), node_emb.data()), h, "hmsg_get_nodes");
         graph_merge_objects(g, node_emb);
     }
+    laps.lap("id / text lists (host)");
     // edges (create_graph_new): a freshly built View carries an int room index, so no Room - View edge (view_room = -1)
     std::vector<int32_t> obj_room, view_room(g->views.size(), -1), vobj;
     std::vector<int64_t> vooff(1, 0);
@@ -557,6 +565,7 @@ void graph_finish(hmsg_graph* g, int32_t n_labels, const float* label_feats, con
                          (int32_t)g->views.size(), view_room.data(), vooff.data(), vobj.data(), (int64_t*)g->edges.data(), cap, &ne) != HMSG_OK)
         throw hmsg_error{HMSG_ERR_INVALID, "hmsg_graph_edges failed"};
     g->edges.resize((size_t)ne * 2);
+    laps.lap("edges");
     g->finished = true;
 }
 
