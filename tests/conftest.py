@@ -17,7 +17,7 @@ def pytest_cmdline_main(config):
         import xdist  # noqa: F401
     except Exception:
         return None
-    want = int(os.environ.get("HMSG_TEST_WORKERS", "4"))
+    want = int(os.environ.get("HMSG_TEST_WORKERS", "6"))
     if (want > 1 and getattr(config.option, "numprocesses", None) is None and not getattr(config.option, "collectonly", False)
             and (getattr(config.option, "markexpr", "") or "").strip() == "not gpu"
             and len(getattr(config.option, "file_or_dir", None) or []) <= 1 and not os.environ.get("PYTEST_XDIST_WORKER")):

@@ -15,6 +15,7 @@ from tests import parity_common as PC
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.mark.skipif(not os.environ.get("HMSG_EMU_SLOW"), reason="minutes on the kernel simulator (HMSG_EMU_SLOW=1); its twin runs on the MI355X")
 @pytest.mark.skipif(not os.path.exists(PC.EMU_PATH), reason="kernel simulator not built")
 def test_bench_line_full_graph_on_the_simulator():
     env = dict(os.environ, HMSG_BENCH_EMU=PC.EMU_PATH)

@@ -172,6 +172,7 @@ def test_c_host_equals_binding_gpu(tmp_path):
     _run(LIB, tmp_path)
 
 
+@pytest.mark.skipif(not os.environ.get("HMSG_EMU_SLOW"), reason="minutes on the kernel simulator (HMSG_EMU_SLOW=1); its twin runs on the MI355X")
 @pytest.mark.skipif(not os.path.exists(PC.EMU_PATH), reason="kernel simulator not built")
 def test_c_host_merges_objects_like_the_binding_emu(tmp_path):
     """pipeline.merge_objects_graph from the strict-C99 host: hmsg_graph_params::merge_objects_graph = 1 -> the same merged graph (counts,

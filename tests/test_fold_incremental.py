@@ -56,6 +56,7 @@ def _same(a, b):
     return len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))
 
 
+@pytest.mark.skipif(not os.environ.get("HMSG_EMU_SLOW"), reason="minutes on the kernel simulator (HMSG_EMU_SLOW=1); its twin runs on the MI355X")
 @pytest.mark.skipif(not os.path.exists(PC.EMU_PATH), reason="kernel simulator not built")
 def test_incremental_fold_equals_batch_fold_on_the_simulator():
     """8 low-resolution frames of one room: the batch fold, the incremental fold from the first step (with and without

@@ -75,6 +75,7 @@ def test_pipelined_fold_equals_fold_in_merge_on_the_simulator():
     sc.close()
 
 
+@pytest.mark.skipif(not os.environ.get("HMSG_EMU_SLOW"), reason="minutes on the kernel simulator (HMSG_EMU_SLOW=1); its twin runs on the MI355X")
 @pytest.mark.skipif(not os.path.exists(PC.EMU_PATH), reason="kernel simulator not built")
 def test_inherited_overlap_grids_on_the_simulator(capfd):
     """A merged cloud whose first member came through its DBSCAN whole keeps that member's overlap grid and indexes only what it
@@ -231,6 +232,7 @@ print("DIGEST", json.dumps([list(_digest(inst)), hashlib.sha1(feats.tobytes()).h
 """
 
 
+@pytest.mark.skipif(not os.environ.get("HMSG_EMU_SLOW"), reason="minutes on the kernel simulator (HMSG_EMU_SLOW=1); its twin runs on the MI355X")
 @pytest.mark.skipif(not os.path.exists(PC.EMU_PATH), reason="kernel simulator not built")
 def test_three_launch_compaction_equals_the_fused_one_on_the_simulator():
     """HMSG_DB_COMPACT_SPLIT=1 (keep flags, scan and scatter as three launches: the form before round 4, kept for comparison runs)
