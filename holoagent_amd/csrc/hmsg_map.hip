@@ -124,6 +124,13 @@ __device__ __forceinline__ PixWalk pix_walk(size_t chunk_first, size_t HW, int W
     k.p0 = (unsigned)(chunk_first - (size_t)k.f0 * HW);
     return k;
 }
+// frames [f0, pix_last_frame] are the ones a chunk of n pixels touches (two at most while a frame is larger than a chunk).  The passes
+// below walk a chunk once per frame it touches with that frame's pose taken from a WAVE-UNIFORM address: sixteen scalar loads per
+// chunk side instead of sixteen vector loads of one and the same address per pixel (which is what bounded k_bounds: its 0.6 GB of depth
+// stream in 0.1 ms, its 5 * 10^9 redundant pose loads took 1).
+__device__ __forceinline__ unsigned pix_last_frame(const PixWalk& k, unsigned n) {
+    return k.f0 + (unsigned)(((unsigned long long)k.p0 + n - 1ull) / k.hw);
+}
 __device__ __forceinline__ void pix_at(const PixWalk& k, unsigned d /* pixels behind the chunk's first */, int& f, int& x, int& y) {
     unsigned p = k.p0 + d, ff = k.f0;
     while (p >= k.hw) {
@@ -151,17 +158,22 @@ __global__ void k_bounds(const unsigned short* __restrict__ depth, const double*
     unsigned cnt = 0;
     for (size_t c0 = (size_t)blockIdx.x * PIX_CHUNK; c0 < total; c0 += (size_t)gridDim.x * PIX_CHUNK) {
         const PixWalk pw = pix_walk(c0, HW, W);
-        for (unsigned d = threadIdx.x; d < PIX_CHUNK && c0 + d < total; d += blockDim.x) {
-            const size_t g = c0 + d;
-            int f, x, y;
-            pix_at(pw, d, f, x, y);
-            double w[3];
-            if (backproject(depth[g], x, y, cam, scale, pose + (size_t)f * 16, w[0], w[1], w[2])) {
-                for (int a = 0; a < 3; ++a) {
-                    mn[a] = w[a] < mn[a] ? w[a] : mn[a];
-                    mx[a] = w[a] > mx[a] ? w[a] : mx[a];
+        const unsigned npix = (unsigned)(total - c0 < (size_t)PIX_CHUNK ? total - c0 : (size_t)PIX_CHUNK);
+        const unsigned fl = pix_last_frame(pw, npix);
+        for (unsigned ff = pw.f0; ff <= fl; ++ff) {                 // (uniform: the chunk's frames, one or two)
+            const double* const T = pose + (size_t)ff * 16;
+            for (unsigned d = threadIdx.x; d < npix; d += blockDim.x) {
+                const size_t g = c0 + d;
+                int f, x, y;
+                pix_at(pw, d, f, x, y);
+                double w[3];
+                if ((unsigned)f == ff && backproject(depth[g], x, y, cam, scale, T, w[0], w[1], w[2])) {
+                    for (int a = 0; a < 3; ++a) {
+                        mn[a] = w[a] < mn[a] ? w[a] : mn[a];
+                        mx[a] = w[a] > mx[a] ? w[a] : mx[a];
+                    }
+                    cnt++;
                 }
-                cnt++;
             }
         }
     }
@@ -186,18 +198,23 @@ __global__ void k_mark(const unsigned short* __restrict__ depth, const double* _
     const size_t total = HW * F;
     for (size_t c0 = (size_t)blockIdx.x * PIX_CHUNK; c0 < total; c0 += (size_t)gridDim.x * PIX_CHUNK) {
         const PixWalk pw = pix_walk(c0, HW, W);
-        for (unsigned d = threadIdx.x; d < PIX_CHUNK && c0 + d < total; d += blockDim.x) {
-            const size_t i = c0 + d;
-            int f, x, y;
-            pix_at(pw, d, f, x, y);
-            double wx, wy, wz;
-            if (!backproject(depth[i], x, y, cam, scale, pose + (size_t)f * 16, wx, wy, wz)) continue;
-            int ix, iy, iz;
-            cell_of(g, wx, wy, wz, ix, iy, iz);
-            long long lin = lin_of(g, ix, iy, iz);
-            unsigned long long bit = 1ull << (lin & 63);
-            unsigned long long* wp = bitmap + (lin >> 6);
-            if (!(*wp & bit)) atomicOr(wp, bit);
+        const unsigned npix = (unsigned)(total - c0 < (size_t)PIX_CHUNK ? total - c0 : (size_t)PIX_CHUNK);
+        const unsigned fl = pix_last_frame(pw, npix);
+        for (unsigned ff = pw.f0; ff <= fl; ++ff) {                 // (uniform: the chunk's frames, one or two)
+            const double* const T = pose + (size_t)ff * 16;
+            for (unsigned d = threadIdx.x; d < npix; d += blockDim.x) {
+                const size_t i = c0 + d;
+                int f, x, y;
+                pix_at(pw, d, f, x, y);
+                double wx, wy, wz;
+                if ((unsigned)f != ff || !backproject(depth[i], x, y, cam, scale, T, wx, wy, wz)) continue;
+                int ix, iy, iz;
+                cell_of(g, wx, wy, wz, ix, iy, iz);
+                long long lin = lin_of(g, ix, iy, iz);
+                unsigned long long bit = 1ull << (lin & 63);
+                unsigned long long* wp = bitmap + (lin >> 6);
+                if (!(*wp & bit)) atomicOr(wp, bit);
+            }
         }
     }
 }
@@ -220,11 +237,11 @@ struct VoxAcc {                 // per-slot colour / count accumulators (SoA)
 //   stable sort by slot (hmsg_sort.hip), segment starts
 //   k_accum_ordered  one lane per voxel walks its runs in order: back-project again, s += p, centroid = s / n
 #define RUN_CHUNK 4096
-__device__ __forceinline__ unsigned pixel_slot(const unsigned short* __restrict__ depth, const double* __restrict__ pose,
-                                               const CamK& cam, float scale, size_t i, int f, int x, int y, const GridGeom& g,
+__device__ __forceinline__ unsigned pixel_slot(const unsigned short* __restrict__ depth, const double* __restrict__ T /* the frame's pose */,
+                                               const CamK& cam, float scale, size_t i, int x, int y, const GridGeom& g,
                                                const unsigned long long* __restrict__ bitmap, const unsigned* __restrict__ rank) {
     double wx, wy, wz;
-    if (!backproject(depth[i], x, y, cam, scale, pose + (size_t)f * 16, wx, wy, wz)) return 0xffffffffu;
+    if (!backproject(depth[i], x, y, cam, scale, T, wx, wy, wz)) return 0xffffffffu;
     int ix, iy, iz;
     cell_of(g, wx, wy, wz, ix, iy, iz);
     const long long lin = lin_of(g, ix, iy, iz);
@@ -245,6 +262,8 @@ __global__ void __launch_bounds__(256) k_slots(const unsigned short* __restrict_
     const int lane = threadIdx.x & 63;
     unsigned myruns = 0;
     const PixWalk pw = pix_walk((size_t)blockIdx.x * RUN_CHUNK, HW, W);
+    const size_t left = total - (size_t)blockIdx.x * RUN_CHUNK;
+    const unsigned fl = pix_last_frame(pw, (unsigned)(left < (size_t)RUN_CHUNK ? left : (size_t)RUN_CHUNK));
     for (int it = 0; it < RUN_CHUNK / 256; ++it) {
         const size_t i = (size_t)blockIdx.x * RUN_CHUNK + (size_t)it * 256 + threadIdx.x;
         const bool in_range = i < total;
@@ -254,7 +273,8 @@ __global__ void __launch_bounds__(256) k_slots(const unsigned short* __restrict_
         if (in_range) {
             int f, y;
             pix_at(pw, (unsigned)it * 256u + threadIdx.x, f, x, y);
-            slot = pixel_slot(depth, pose, cam, scale, i, f, x, y, g, bitmap, rank);
+            for (unsigned ff = pw.f0; ff <= fl; ++ff)                // (uniform: the chunk's frames, one or two; pose at a uniform address)
+                if ((unsigned)f == ff) slot = pixel_slot(depth, pose + (size_t)ff * 16, cam, scale, i, x, y, g, bitmap, rank);
             slots[i] = slot;
             if (slot != 0xffffffffu) {
                 const unsigned char* c = rgb + i * 3;
