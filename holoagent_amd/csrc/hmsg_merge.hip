@@ -371,68 +371,128 @@ static const int OV_CHUNK = 256;       /* points per workgroup of the overlap sc
 // (the kernel is bound by its L2 transactions, not by a lane's chain), so the DEPENDENT form stays the default (dep_counts !=
 // nullptr, blk_off = first workgroup of the launch) and HMSG_OV_ONE_LAUNCH=1 selects the single launch.
 // Decisions are the same either way: max(a, b) > th does not care about b once a > th.
+// "More than th * |X| points of X (the larger cloud) have a point of Y within r" needs at least that many points of X inside Y's box
+// grown by r, and X's own grid says how many it has there: the sum of its cell counts over that box (z-cells of a column are
+// contiguous: two loads per column), plus the same over X's delta grid.  A floor against a chair-sized mask stays far below the
+// threshold -- no scan of its 10^5 points then.  Evaluated by one workgroup (all 256 threads); true = the pair's second direction is
+// decided (no merge by this direction) without a scan.
+__device__ __forceinline__ bool ov_second_bounded(const OvGrid* __restrict__ gr, const OvGrid& X, const OvGrid& Y, const unsigned* __restrict__ cells,
+                                                  float r, double th, unsigned* s_in /* [4] LDS */) {
+    const float m = r + 1e-4f;
+    int lo[3], hi[3];
+    const double xo[3] = {X.ox, X.oy, X.oz};
+    const float ymn[3] = {Y.mnx, Y.mny, Y.mnz}, ymx[3] = {Y.mxx, Y.mxy, Y.mxz};
+    const int gd[3] = {X.gx, X.gy, X.gz};
+    bool empty = false;
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = (int)floor(((double)(ymn[a] - m) - xo[a]) / X.cell);
+        hi[a] = (int)floor(((double)(ymx[a] + m) - xo[a]) / X.cell);
+        lo[a] = max(lo[a], 0);
+        hi[a] = min(hi[a], gd[a] - 1);
+        empty = empty || hi[a] < lo[a];
+    }
+    unsigned inbox = 0;
+    if (!empty) {
+        const int ncol = (hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1), wy = hi[1] - lo[1] + 1;
+        for (int q = (int)threadIdx.x; q < ncol; q += (int)blockDim.x) {
+            const long long c0 = X.ix_cell + ((long long)(lo[0] + q / wy) * X.gy + (lo[1] + q % wy)) * X.gz;
+            inbox += cells[c0 + hi[2] + 1] - cells[c0 + lo[2]];
+        }
+    }
+    if (X.next >= 0) {                  // ... and the same sum over X's delta grid (the two grids split X's points)
+        const OvGrid X2 = gr[X.next];
+        const double xo2[3] = {X2.ox, X2.oy, X2.oz};
+        const int gd2[3] = {X2.gx, X2.gy, X2.gz};
+        bool empty2 = false;
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = max((int)floor(((double)(ymn[a] - m) - xo2[a]) / X2.cell), 0);
+            hi[a] = min((int)floor(((double)(ymx[a] + m) - xo2[a]) / X2.cell), gd2[a] - 1);
+            empty2 = empty2 || hi[a] < lo[a];
+        }
+        if (!empty2) {
+            const int ncol = (hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1), wy = hi[1] - lo[1] + 1;
+            for (int q = (int)threadIdx.x; q < ncol; q += (int)blockDim.x) {
+                const long long c0 = X2.ix_cell + ((long long)(lo[0] + q / wy) * X2.gy + (lo[1] + q % wy)) * X2.gz;
+                inbox += cells[c0 + hi[2] + 1] - cells[c0 + lo[2]];
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) inbox += __shfl_xor(inbox, o);
+    __syncthreads();                                        // (s_in may still be read from an earlier use)
+    if ((threadIdx.x & 63) == 0) s_in[threadIdx.x >> 6] = inbox;
+    __syncthreads();
+    inbox = s_in[0] + s_in[1] + s_in[2] + s_in[3];
+    return !((double)inbox / (double)X.n > th);
+}
+// points [b0, b1) of X against Y: how many have a point of Y within r (this thread's share; the caller reduces)
+template <bool BLAS, bool STATS>
+__device__ __forceinline__ unsigned ov_probe_chunk(const double* __restrict__ pool, const OvGrid* __restrict__ gr, const OvGrid& X, const OvGrid& Y,
+                                                   int ix, int iy, const unsigned* __restrict__ cells, const float* __restrict__ sorted, float r2,
+                                                   float r, int b0, int b1, int sorted_src, unsigned long long* __restrict__ st) {
+    unsigned local = 0;
+    const OvGrid Y2 = gr[Y.next >= 0 ? Y.next : iy];        // (Y's delta grid, if it has one)
+    const bool blas = BLAS && X.n >= 20;                   // (faiss: the BLAS route from 20 queries on -- the cloud whose points are looked up)
+    // Round 6: X's points are taken from X's OWN cell-sorted float32 copies (base grid, then delta grid: together they hold
+    // every point of the cloud once, rounded exactly as `(float)p[a]` rounds it), not from the pool in pool order -- the count
+    // does not care in which order the points are asked, and the lanes of a wave then stand in one or two cells of X, i.e. in
+    // a handful of cells of Y; a point costs 12 bytes instead of 24 (profiles/r06_map_accum.txt: 4.7 -> 3.6 MB per launch, the
+    // launch itself no faster).
+    const OvGrid X2 = gr[X.next >= 0 ? X.next : ix];
+    const int nbx = sorted_src ? X.blk0 : 0;               // (query tables: points in the base grid)
+    const float* sx1 = nullptr;
+    const float* sx2 = nullptr;
+    if (sorted_src) {
+        sx1 = sorted + ((size_t)X.ix_pt + cells[X.ix_cell]) * 3;
+        if (X.next >= 0) sx2 = sorted + ((size_t)X2.ix_pt + cells[X2.ix_cell]) * 3 - (size_t)nbx * 3;
+    }
+    for (int i = b0 + (int)threadIdx.x; i < b1; i += blockDim.x) {
+        float x, y, z;
+        if (sorted_src) {
+            const float* p = (i < nbx ? sx1 : sx2) + (size_t)i * 3;
+            x = p[0], y = p[1], z = p[2];
+        } else {
+            const double* p = pool + (size_t)(X.pt_off + i) * 3;
+            x = (float)p[0], y = (float)p[1], z = (float)p[2];
+        }
+        bool hit;
+        if (BLAS && blas) hit = Y.next >= 0 ? ov_hit2<true, STATS>(Y, Y2, cells, sorted, x, y, z, r2, r, st) : ov_hit<true, STATS>(Y, cells, sorted, x, y, z, r2, r, st);
+        else hit = Y.next >= 0 ? ov_hit2<false, STATS>(Y, Y2, cells, sorted, x, y, z, r2, r, st) : ov_hit<false, STATS>(Y, cells, sorted, x, y, z, r2, r, st);
+        local += hit ? 1u : 0u;
+    }
+    return local;
+}
+// `bound_ahead` (round 6, with k_ov_query_second; first-direction launches of a sequential-merge step only): npairs extra workgroups
+// evaluate the box bound of every pair's second direction and leave the verdict in counts[npairs + pair] (0x80000000 = decided), so
+// that the second launch can be PLANNED from what lies in device memory (see there) instead of starting a workgroup per chunk of
+// every larger cloud only to find out that nearly all of them have nothing to do.
 template <bool BLAS, bool STATS>
 __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __restrict__ gr, const OvTask* __restrict__ tasks,
                            const unsigned* __restrict__ cells, const float* __restrict__ sorted, float r2, float r,
                            int npairs, const int* __restrict__ blk_task, unsigned blk_off, unsigned* __restrict__ counts,
                            const unsigned* __restrict__ dep_counts, double th, int chunk, unsigned long long* __restrict__ st,
-                           int sorted_src) {
-    const unsigned blk = blockIdx.x + blk_off;
+                           int sorted_src, int bound_ahead) {
+    __shared__ unsigned s_in[4];
+    if (bound_ahead) {
+        // the launch's first npairs workgroups only evaluate the box bound of their pair's second direction (X and Y change
+        // places), beside the probes of the others -- as a prologue of a task's first probing workgroup it lengthened that
+        // workgroup's chain, and the launch lasts as long as its longest chain
+        if ((int)blockIdx.x < npairs) {
+            const OvTask t0 = tasks[blockIdx.x];
+            const OvGrid A = gr[t0.x], B = gr[t0.y];
+            if (ov_second_bounded(gr, B, A, cells, r, th, s_in) && threadIdx.x == 0) counts[npairs + (int)blockIdx.x] = 0x80000000u;
+            return;
+        }
+    }
+    const unsigned blk = blockIdx.x - (bound_ahead ? (unsigned)npairs : 0u) + blk_off;
     const int ti = blk_task[blk];
     const OvTask t = tasks[ti];
     const bool second = ti >= npairs;
     bool run = !(second && dep_counts && (double)dep_counts[ti - npairs] / (double)t.dep_n > th);
     const OvGrid X = gr[t.x], Y = gr[t.y];
-    if (run && second && th >= 0.0) {
+    if (run && second && th >= 0.0 && !bound_ahead) {
         // Second direction, first ratio <= th: the pair merges only if MORE than th * |X| points of X (the larger cloud) have
-        // a point of Y (the smaller one) within r.  Such a point lies in Y's box grown by r, and X's own grid says how many
-        // of its points do: the sum of its cell counts over that box (z-cells of a column are contiguous: two loads per
-        // column).  A floor against a chair-sized mask stays far below the threshold -- no scan of its 10^5 points then.
-        __shared__ unsigned s_in[4];
-        const float m = r + 1e-4f;
-        int lo[3], hi[3];
-        const double xo[3] = {X.ox, X.oy, X.oz};
-        const float ymn[3] = {Y.mnx, Y.mny, Y.mnz}, ymx[3] = {Y.mxx, Y.mxy, Y.mxz};
-        const int gd[3] = {X.gx, X.gy, X.gz};
-        bool empty = false;
-        for (int a = 0; a < 3; ++a) {
-            lo[a] = (int)floor(((double)(ymn[a] - m) - xo[a]) / X.cell);
-            hi[a] = (int)floor(((double)(ymx[a] + m) - xo[a]) / X.cell);
-            lo[a] = max(lo[a], 0);
-            hi[a] = min(hi[a], gd[a] - 1);
-            empty = empty || hi[a] < lo[a];
-        }
-        unsigned inbox = 0;
-        if (!empty) {
-            const int ncol = (hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1), wy = hi[1] - lo[1] + 1;
-            for (int q = (int)threadIdx.x; q < ncol; q += (int)blockDim.x) {
-                const long long c0 = X.ix_cell + ((long long)(lo[0] + q / wy) * X.gy + (lo[1] + q % wy)) * X.gz;
-                inbox += cells[c0 + hi[2] + 1] - cells[c0 + lo[2]];
-            }
-        }
-        if (X.next >= 0) {                  // ... and the same sum over X's delta grid (the two grids split X's points)
-            const OvGrid X2 = gr[X.next];
-            const double xo2[3] = {X2.ox, X2.oy, X2.oz};
-            const int gd2[3] = {X2.gx, X2.gy, X2.gz};
-            bool empty2 = false;
-            for (int a = 0; a < 3; ++a) {
-                lo[a] = max((int)floor(((double)(ymn[a] - m) - xo2[a]) / X2.cell), 0);
-                hi[a] = min((int)floor(((double)(ymx[a] + m) - xo2[a]) / X2.cell), gd2[a] - 1);
-                empty2 = empty2 || hi[a] < lo[a];
-            }
-            if (!empty2) {
-                const int ncol = (hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1), wy = hi[1] - lo[1] + 1;
-                for (int q = (int)threadIdx.x; q < ncol; q += (int)blockDim.x) {
-                    const long long c0 = X2.ix_cell + ((long long)(lo[0] + q / wy) * X2.gy + (lo[1] + q % wy)) * X2.gz;
-                    inbox += cells[c0 + hi[2] + 1] - cells[c0 + lo[2]];
-                }
-            }
-        }
-        for (int o = 32; o > 0; o >>= 1) inbox += __shfl_xor(inbox, o);
-        if ((threadIdx.x & 63) == 0) s_in[threadIdx.x >> 6] = inbox;
-        __syncthreads();
-        inbox = s_in[0] + s_in[1] + s_in[2] + s_in[3];
-        if (!((double)inbox / (double)X.n > th)) {
+        // a point of Y (the smaller one) within r (ov_second_bounded).
+        if (ov_second_bounded(gr, X, Y, cells, r, th, s_in)) {
             if (blk == (unsigned)t.blk0 && threadIdx.x == 0) counts[ti] = 0x80000000u;   // (decided by the bound: no scan)
             run = false;
         }
@@ -443,38 +503,70 @@ __global__ void k_ov_query(const double* __restrict__ pool, const OvGrid* __rest
     if (run) {
         const int b0 = (int)(blk - (unsigned)t.blk0) * chunk;
         const int b1 = b0 + chunk < X.n ? b0 + chunk : X.n;
-        const OvGrid Y2 = gr[Y.next >= 0 ? Y.next : t.y];      // (Y's delta grid, if it has one)
-        const bool blas = BLAS && X.n >= 20;                   // (faiss: the BLAS route from 20 queries on -- the cloud whose points are looked up)
-        // Round 6: X's points are taken from X's OWN cell-sorted float32 copies (base grid, then delta grid: together they hold
-        // every point of the cloud once, rounded exactly as `(float)p[a]` rounds it), not from the pool in pool order -- the count
-        // does not care in which order the points are asked, and the lanes of a wave then stand in one or two cells of X, i.e. in
-        // a handful of cells of Y: their table look-ups and candidate walks fall on the same cache lines (the launch is bound by
-        // its L1 / L2 transactions, profiles/r06_fold_experiments.txt), and a point costs 12 bytes instead of 24.
-        const OvGrid X2 = gr[X.next >= 0 ? X.next : t.x];
-        const int nbx = sorted_src ? X.blk0 : 0;               // (query tables: points in the base grid)
-        const float* sx1 = nullptr;
-        const float* sx2 = nullptr;
-        if (sorted_src) {
-            sx1 = sorted + ((size_t)X.ix_pt + cells[X.ix_cell]) * 3;
-            if (X.next >= 0) sx2 = sorted + ((size_t)X2.ix_pt + cells[X2.ix_cell]) * 3 - (size_t)nbx * 3;
-        }
-        for (int i = b0 + (int)threadIdx.x; i < b1; i += blockDim.x) {
-            float x, y, z;
-            if (sorted_src) {
-                const float* p = (i < nbx ? sx1 : sx2) + (size_t)i * 3;
-                x = p[0], y = p[1], z = p[2];
-            } else {
-                const double* p = pool + (size_t)(X.pt_off + i) * 3;
-                x = (float)p[0], y = (float)p[1], z = (float)p[2];
-            }
-            bool hit;
-            if (BLAS && blas) hit = Y.next >= 0 ? ov_hit2<true, STATS>(Y, Y2, cells, sorted, x, y, z, r2, r, st) : ov_hit<true, STATS>(Y, cells, sorted, x, y, z, r2, r, st);
-            else hit = Y.next >= 0 ? ov_hit2<false, STATS>(Y, Y2, cells, sorted, x, y, z, r2, r, st) : ov_hit<false, STATS>(Y, cells, sorted, x, y, z, r2, r, st);
-            local += hit ? 1u : 0u;
-        }
+        local = ov_probe_chunk<BLAS, STATS>(pool, gr, X, Y, t.x, t.y, cells, sorted, r2, r, b0, b1, sorted_src, st);
     }
     for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(&counts[ti], local);
+}
+// Round 6 -- the second direction of a sequential-merge step, planned on the device.  Until now the second launch started a
+// workgroup per OV_CHUNK points of every pair's LARGER cloud (~10^4 workgroups a step), each of which loaded its task and both
+// grids and summed the box bound, only for nearly all of them to find the pair decided (by the first ratio or by the bound: 22 000 of a
+// step's ~10^6 larger-cloud points are ever scanned) -- the launch took 25 us for a quarter of the first launch's probes.  Now the
+// verdicts lie in device memory when the first launch ends (first counts; the bound, evaluated once per pair by the first launch),
+// and a FIXED grid plans its own work: every workgroup reads the <= OV2_MAX_PAIRS verdicts (a coalesced load or two), lays the chunks of the
+// undecided pairs end to end in LDS (a block scan) and takes the chunks blockIdx.x, blockIdx.x + gridDim.x, ... of that list.  No
+// host round trip (the grid does not depend on how many pairs are left), no workgroup per skipped chunk.  Same counts, same flags.
+#define OV2_MAX_PAIRS 2048
+template <bool BLAS, bool STATS>
+__global__ void __launch_bounds__(256) k_ov_query_second(const double* __restrict__ pool, const OvGrid* __restrict__ gr, const OvTask* __restrict__ tasks,
+                                                         const unsigned* __restrict__ cells, const float* __restrict__ sorted, float r2, float r,
+                                                         int npairs, unsigned* __restrict__ counts, double th, int chunk,
+                                                         unsigned long long* __restrict__ st, int sorted_src) {
+    __shared__ unsigned s_off[OV2_MAX_PAIRS + 1];           // first chunk of every pair in the list of chunks to scan
+    __shared__ unsigned s_w[4], s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_carry = 0u;
+    __syncthreads();
+    for (int k0 = 0; k0 < npairs; k0 += 256) {              // (block-uniform)
+        const int k = k0 + tid;
+        unsigned nch = 0;
+        if (k < npairs) {
+            const OvTask t = tasks[npairs + k];
+            const bool first_decides = (double)counts[k] / (double)t.dep_n > th;
+            const bool bounded = counts[npairs + k] == 0x80000000u;
+            if (!first_decides && !bounded) nch = ((unsigned)gr[t.x].n + (unsigned)chunk - 1u) / (unsigned)chunk;
+        }
+        unsigned incl = nch;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned u = __shfl_up(incl, o);
+            if (lane >= o) incl += u;
+        }
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        unsigned base = s_carry;
+        for (int q = 0; q < wv; ++q) base += s_w[q];
+        if (k < npairs) s_off[k] = base + incl - nch;
+        __syncthreads();
+        if (tid == 0) s_carry += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+    if (tid == 0) s_off[npairs] = s_carry;
+    __syncthreads();
+    const unsigned total = s_off[npairs];
+    for (unsigned j = blockIdx.x; j < total; j += gridDim.x) {      // (block-uniform)
+        int lo = 0, hi = npairs - 1;                        // the pair of chunk j: the last one whose first chunk is <= j
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_off[mid] <= j) lo = mid; else hi = mid - 1;
+        }
+        const OvTask t = tasks[npairs + lo];
+        const OvGrid X = gr[t.x], Y = gr[t.y];
+        const int b0 = (int)(j - s_off[lo]) * chunk;
+        const int b1 = b0 + chunk < X.n ? b0 + chunk : X.n;
+        unsigned local = ov_probe_chunk<BLAS, STATS>(pool, gr, X, Y, t.x, t.y, cells, sorted, r2, r, b0, b1, sorted_src, st);
+        for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+        if (lane == 0 && local) atomicAdd(&counts[npairs + lo], local);
+    }
 }
 
 static const int CAT_CHUNK = 512;      /* points per workgroup of k_concat */
@@ -956,20 +1048,33 @@ struct Merger {
         }
         auto* const ovk = d_ovstat ? (faiss_form ? k_ov_query<true, true> : k_ov_query<false, true>)
                                    : (faiss_form ? k_ov_query<true, false> : k_ov_query<false, false>);
+        auto* const ovk2 = d_ovstat ? (faiss_form ? k_ov_query_second<true, true> : k_ov_query_second<false, true>)
+                                    : (faiss_form ? k_ov_query_second<true, false> : k_ov_query_second<false, false>);
+        // HMSG_OV_LEGACY_SECOND=1: the second direction as a workgroup per chunk of every larger cloud (until round 6)
+        static const bool plan_wanted = getenv("HMSG_OV_LEGACY_SECOND") == nullptr;
+        const bool plan = plan_wanted && two_launch && decide_th >= 0.0 && P <= (size_t)OV2_MAX_PAIRS;
         {
             ProfScope ps(ops.prof, s, "k_ov_query", 0.0);       // (the kernel launches only: not the read-back below)
             if (!two_launch) {
                 if (nblk)
                     hipLaunchKernelGGL(ovk, dim3((unsigned)nblk), dim3(256), 0, s, (const double*)pool.p, dg, dt,
                                        (const unsigned*)ix_cells.p, (const float*)ix_pts.p, r2, r, (int)P, db, 0u, dc, (const unsigned*)nullptr, decide_th, OV_CHUNK,
-                                       d_ovstat, ov_sorted_src);
+                                       d_ovstat, ov_sorted_src, 0);
             } else {
                 for (int dir = 0; dir < 2; ++dir) {
                     const unsigned nb = dir ? nblk2 : nblk1;
                     if (!nb) continue;
-                    hipLaunchKernelGGL(ovk, dim3(nb), dim3(256), 0, s, (const double*)pool.p, dg, dt,
+                    if (dir && plan) {
+                        // (a fixed grid that plans its own work from the verdicts in device memory; 512 workgroups take the ~90 chunks of
+                        //  a usual step in one trip and the 400 of a floor that does get scanned as well)
+                        hipLaunchKernelGGL(ovk2, dim3(std::min(nb, 512u)), dim3(256), 0, s, (const double*)pool.p, dg, dt,
+                                           (const unsigned*)ix_cells.p, (const float*)ix_pts.p, r2, r, (int)P, dc, decide_th, OV_CHUNK, d_ovstat, ov_sorted_src);
+                        continue;
+                    }
+                    hipLaunchKernelGGL(ovk, dim3(nb + ((!dir && plan) ? (unsigned)P : 0u)), dim3(256), 0, s, (const double*)pool.p, dg, dt,
                                        (const unsigned*)ix_cells.p, (const float*)ix_pts.p, r2, r, (int)P, db, dir ? nblk1 : 0u, dc,
-                                       (dir && decide_th >= 0.0) ? (const unsigned*)dc : (const unsigned*)nullptr, decide_th, OV_CHUNK, d_ovstat, ov_sorted_src);
+                                       (dir && decide_th >= 0.0) ? (const unsigned*)dc : (const unsigned*)nullptr, decide_th, OV_CHUNK, d_ovstat, ov_sorted_src,
+                                       (!dir && plan) ? 1 : 0);
                 }
             }
         }
