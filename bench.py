@@ -620,6 +620,9 @@ def main():
                 #  scene and roof["launches"] counts the LAST step's timed launches: dispatches per timed launch)
                 per = max(1.0, round(pmc[key]["dispatches"] / max(roof["launches"], 1))) if key == "k_ov_query" else 1.0
                 roof["traffic"] = int(pmc[key]["hbm_bytes_per_launch"] * per)
+                if key == "k_ov_query" and "k_ov_query_second" in pmc:      # (round 6: the pair's second launch is a kernel of its own)
+                    k2 = pmc["k_ov_query_second"]
+                    roof["traffic"] += int(k2["hbm_bytes_per_launch"] * max(1.0, round(k2["dispatches"] / max(roof["launches"], 1))))
                 roof["traffic_source"] = "profiles/%s (offline PMC passes, same command)" % os.path.basename(pmc_path)
                 try:
                     sys.path.insert(0, os.path.join(ROOT, "scripts"))
