@@ -218,10 +218,12 @@ __global__ void k_pool_init(const unsigned* __restrict__ ncount, long long N, in
 }
 __global__ void k_pool_prop(const unsigned* __restrict__ adj, const PoolSeg* __restrict__ segs, const int* __restrict__ seg_of_row,
                             const unsigned* __restrict__ ncount, int minpts, long long N, int* __restrict__ label,
-                            int* __restrict__ changed, const int* __restrict__ seg_first, int first_round) {
+                            int* __restrict__ changed, const int* __restrict__ seg_first, int first_round,
+                            const unsigned* __restrict__ list /* rows still on their way (k_pool_list), or nullptr: every row */) {
     const int lane = threadIdx.x & 63;
-    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (i >= N) return;
+    long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (i >= N) return;                                       // (N: rows, or entries of the list)
+    if (list) i = list[i];
     if (ncount[i] < (unsigned)minpts) return;                 // wave-uniform
     const int k = seg_of_row[i];
     int best = label[i];
@@ -280,9 +282,11 @@ __global__ void k_pool_prop(const unsigned* __restrict__ adj, const PoolSeg* __r
 // component that is not larger than its own, so label[label[i]] is one too -- following the chain to its end makes
 // the propagation converge in O(log diameter) rounds instead of O(diameter).  (Races only read older, larger labels.)
 __global__ void k_pool_jump(const PoolSeg* __restrict__ segs, const int* __restrict__ seg_of_row, const unsigned* __restrict__ ncount,
-                            int minpts, long long N, int* __restrict__ label) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N || ncount[i] < (unsigned)minpts) return;
+                            int minpts, long long N, int* __restrict__ label, const unsigned* __restrict__ list) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    if (list) i = list[i];
+    if (ncount[i] < (unsigned)minpts) return;
     const long long base = segs[seg_of_row[i]].row_base;
     int l = label[i];
     for (int hop = 0; hop < 64; ++hop) {
@@ -291,6 +295,22 @@ __global__ void k_pool_jump(const PoolSeg* __restrict__ segs, const int* __restr
         l = p;
     }
     if (l < label[i]) atomicMin(&label[i], l);
+}
+// The core rows that have not reached their instance's lowest core row yet.  A row that has is finished for good (nothing lower
+// exists in its instance), and after the first two rounds that is most of them: the later rounds run over this list instead of
+// starting a wave per row of the scene only to find it done (950 000 waves a round at configs[1], 1.1 ms).
+__global__ void k_pool_list(const PoolSeg* __restrict__ segs, const int* __restrict__ seg_of_row, const unsigned* __restrict__ ncount,
+                            int minpts, long long N, const int* __restrict__ label, const int* __restrict__ seg_first,
+                            unsigned* __restrict__ list, unsigned* __restrict__ n_list) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool open = i < N && ncount[i] >= (unsigned)minpts && label[i] != seg_first[seg_of_row[i]];
+    const unsigned long long m = __ballot(open);
+    if (!m) return;
+    const int lane = threadIdx.x & 63, leader = __ffsll(m) - 1;
+    unsigned base = 0;
+    if (lane == leader) base = atomicAdd(n_list, (unsigned)__popcll(m));
+    base = __shfl(base, leader);
+    if (open) list[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (unsigned)i;
 }
 // border points: smallest cluster label among adjacent cores; then sizes / first index per cluster
 __global__ void k_pool_border(const unsigned* __restrict__ adj, const PoolSeg* __restrict__ segs, const int* __restrict__ seg_of_row,
@@ -541,21 +561,37 @@ void hmsg_pool(hmsg_ctx* h) {
         hipLaunchKernelGGL(k_pool_init, dim3(cdiv((size_t)R, 256)), dim3(256), 0, s, (const unsigned*)ncount.p, (long long)R,
                            c.feat_dbscan_min, label.p, (const PoolSeg*)d_ps.p, (const int*)seg_of_row.p, seg_first.p);
         HMSG_CHECK_LAUNCH();
+        // (two rounds before the first look at the flag -- the first one is cheap and always changes something --, then one round
+        //  per look: a round over rows that no longer change costs 1.2 ms, a look 20 us.  Round 6: behind those two rounds the rows
+        //  that are still on their way are listed, and the later rounds run over the list.)
+        DevBuf<unsigned> open_list;
+        open_list.alloc(Rn + 1);                            // [0] the count, the rows behind it
+        const unsigned* d_list = nullptr;
+        unsigned n_open = 0;
+        static const bool list_wanted = getenv("HMSG_DEBUG_POOL_ALL_ROWS") == nullptr;   // HMSG_DEBUG_POOL_ALL_ROWS=1: every round over every row (until round 5)
         for (int it = 0; it < 100000; ++it) {
             HIP_TRY(hipMemsetAsync(d_changed.p, 0, 4, s));
-            // (two rounds before the first look at the flag -- the first one is cheap and always changes something --, then one round
-            //  per look: a round over rows that no longer change costs 1.2 ms, a look 20 us)
-            for (int rep = 0; rep < (it == 0 ? 2 : 1); ++rep) {
-                hipLaunchKernelGGL(k_pool_prop, dim3(cdiv((size_t)R * 64, 256)), dim3(256), 0, s, (const unsigned*)adj.p,
+            const size_t rows = d_list ? (size_t)n_open : (size_t)R;
+            for (int rep = 0; rep < (it == 0 ? 2 : 1) && rows; ++rep) {
+                hipLaunchKernelGGL(k_pool_prop, dim3(cdiv(rows * 64, 256)), dim3(256), 0, s, (const unsigned*)adj.p,
                                    (const PoolSeg*)d_ps.p, (const int*)seg_of_row.p, (const unsigned*)ncount.p,
-                                   c.feat_dbscan_min, (long long)R, label.p, d_changed.p, (const int*)seg_first.p, (it == 0 && rep == 0) ? 1 : 0);
-                hipLaunchKernelGGL(k_pool_jump, dim3(cdiv((size_t)R, 256)), dim3(256), 0, s, (const PoolSeg*)d_ps.p,
-                                   (const int*)seg_of_row.p, (const unsigned*)ncount.p, c.feat_dbscan_min, (long long)R, label.p);
+                                   c.feat_dbscan_min, (long long)rows, label.p, d_changed.p, (const int*)seg_first.p, (it == 0 && rep == 0) ? 1 : 0, d_list);
+                hipLaunchKernelGGL(k_pool_jump, dim3(cdiv(rows, 256)), dim3(256), 0, s, (const PoolSeg*)d_ps.p,
+                                   (const int*)seg_of_row.p, (const unsigned*)ncount.p, c.feat_dbscan_min, (long long)rows, label.p, d_list);
             }
             HMSG_CHECK_LAUNCH();
+            if (it == 0 && list_wanted) {
+                HIP_TRY(hipMemsetAsync(open_list.p, 0, 4, s));
+                hipLaunchKernelGGL(k_pool_list, dim3(cdiv((size_t)R, 256)), dim3(256), 0, s, (const PoolSeg*)d_ps.p, (const int*)seg_of_row.p,
+                                   (const unsigned*)ncount.p, c.feat_dbscan_min, (long long)R, (const int*)label.p, (const int*)seg_first.p,
+                                   open_list.p + 1, open_list.p);
+                HMSG_CHECK_LAUNCH();
+                HIP_TRY(hipMemcpyAsync(&n_open, open_list.p, 4, hipMemcpyDeviceToHost, s));
+            }
             int ch = 0;
             HIP_TRY(hipMemcpyAsync(&ch, d_changed.p, 4, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
+            if (it == 0 && list_wanted) d_list = open_list.p + 1;
             if (!ch) break;
         }
         laps.lap("label propagation");

@@ -27,4 +27,7 @@ else
   export LD_PRELOAD=$RT/libclang_rt.ubsan_standalone-x86_64.so UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
 fi
 cd $ROOT
-exec python -m pytest tests/ -q -m "not gpu" -p no:cacheprovider "$@"
+# (test files / pytest options may follow the kind; without any: the whole CPU suite)
+TARGETS="tests/"
+for a in "$@"; do case "$a" in tests/*) TARGETS="";; esac; done
+exec python -m pytest $TARGETS -q -m "not gpu" -p no:cacheprovider "$@"
