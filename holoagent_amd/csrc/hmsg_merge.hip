@@ -1011,8 +1011,14 @@ struct Merger {
         }
         for (size_t k = 0; k < P; ++k) tasks[P + k].blk0 += (int)nblk1;      // (one work list over both directions)
         const size_t nblk = (size_t)nblk1 + nblk2;
+        // (the planned second launch finds its work itself: the workgroup -> task table then covers the first direction only --
+        //  the second direction's ~10^4 entries were two thirds of the packed upload and of the host's time to fill it)
+        static const bool two_launch = getenv("HMSG_OV_ONE_LAUNCH") == nullptr;
+        static const bool plan_wanted = getenv("HMSG_OV_LEGACY_SECOND") == nullptr;   // HMSG_OV_LEGACY_SECOND=1: a workgroup per chunk of every larger cloud (until round 6)
+        const bool plan = plan_wanted && two_launch && decide_th >= 0.0 && P <= (size_t)OV2_MAX_PAIRS;
+        const size_t nblk_tab = plan ? (size_t)nblk1 : nblk;
         const size_t off_t = (g.size() * sizeof(OvGrid) + 15) & ~(size_t)15, off_c = off_t + tasks.size() * sizeof(OvTask),
-                     off_b = off_c + tasks.size() * 4, pack = off_b + nblk * 4;
+                     off_b = off_c + tasks.size() * 4, pack = off_b + nblk_tab * 4;
         h_ovpack.ensure(pack);
         d_ovpack.ensure(pack);
         memcpy(h_ovpack.p, g.data(), g.size() * sizeof(OvGrid));
@@ -1020,7 +1026,7 @@ struct Merger {
         memset(h_ovpack.p + off_c, 0, tasks.size() * 4);
         {   // workgroup -> task
             int* bt = (int*)(h_ovpack.p + off_b);
-            for (size_t k = 0; k < 2 * P; ++k) {
+            for (size_t k = 0; k < (plan ? P : 2 * P); ++k) {
                 const size_t e = k + 1 < 2 * P ? (size_t)tasks[k + 1].blk0 : nblk;
                 for (size_t b = (size_t)tasks[k].blk0; b < e; ++b) bt[b] = (int)k;
             }
@@ -1033,7 +1039,6 @@ struct Merger {
         const float r = (float)reach;                // how far a witness can be (= radius; more in faiss's BLAS form, merger_init)
         const float r2 = (float)(radius * radius);   // `D < radius**2` with a float32 D (graph_utils.py:654-655)
         const size_t prof_idx = ops.prof->ev.size();        // (algorithmic bytes are filled in after the read-back)
-        static const bool two_launch = getenv("HMSG_OV_ONE_LAUNCH") == nullptr;
         static const int ov_sorted_src = getenv("HMSG_OV_POOL_ORDER") == nullptr ? 1 : 0;   // HMSG_OV_POOL_ORDER=1: X's points from the pool (until round 5)
         // (Round 5, measured and withdrawn: the counts sent to the host by the LAST workgroup of the last launch instead of a
         //  k_publish launch behind it -- "count yourself done" needs an agent-scope release fence per workgroup, which on this
@@ -1050,9 +1055,6 @@ struct Merger {
                                    : (faiss_form ? k_ov_query<true, false> : k_ov_query<false, false>);
         auto* const ovk2 = d_ovstat ? (faiss_form ? k_ov_query_second<true, true> : k_ov_query_second<false, true>)
                                     : (faiss_form ? k_ov_query_second<true, false> : k_ov_query_second<false, false>);
-        // HMSG_OV_LEGACY_SECOND=1: the second direction as a workgroup per chunk of every larger cloud (until round 6)
-        static const bool plan_wanted = getenv("HMSG_OV_LEGACY_SECOND") == nullptr;
-        const bool plan = plan_wanted && two_launch && decide_th >= 0.0 && P <= (size_t)OV2_MAX_PAIRS;
         {
             ProfScope ps(ops.prof, s, "k_ov_query", 0.0);       // (the kernel launches only: not the read-back below)
             if (!two_launch) {
