@@ -252,3 +252,55 @@ def test_three_launch_compaction_equals_the_fused_one_on_the_simulator():
         assert r.returncode == 0, r.stdout + r.stderr
         out.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1][7:]))
     assert out[0] == out[1] and out[0][0][0] >= 3, out
+
+
+_OV_GPU_SNIPPET = """
+import sys, json
+sys.path.insert(0, {root!r})
+import torch
+import bench
+from tests.test_fold_pipeline import _device_scene
+from holoagent_amd._lib import HmsgLib
+from holoagent_amd.synth import SceneSpec
+L = HmsgLib()
+spec = SceneSpec(seed=1234, n_frames=300, feat_dim=64, n_masks=32)
+inp = bench.build_scene_inputs(L, spec, torch.device("cuda", 0), torch)
+d = _device_scene(L, spec, inp, nopipe=True)
+print("DIGEST", json.dumps([list(d[0]), d[1]]))
+"""
+
+
+def _overlap_launch_forms(snippet):
+    """Round 6's forms of the overlap test -- X's points from X's own cell-sorted copies, the second direction planned on the device
+    (k_ov_query_second), the workgroup table of the first direction only in the packed upload (the default) -- against the second
+    direction as a workgroup per chunk of every larger cloud (HMSG_OV_LEGACY_SECOND=1), X's points from the pool
+    (HMSG_OV_POOL_ORDER=1) and both directions in one launch (HMSG_OV_ONE_LAUNCH=1).  The switches are read once per process: four
+    processes, one scene, the same instances and pooled features from all."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    keys = ("HMSG_OV_LEGACY_SECOND", "HMSG_OV_POOL_ORDER", "HMSG_OV_ONE_LAUNCH")
+    for over in ({}, {"HMSG_OV_LEGACY_SECOND": "1"}, {"HMSG_OV_POOL_ORDER": "1", "HMSG_OV_LEGACY_SECOND": "1"}, {"HMSG_OV_ONE_LAUNCH": "1"}):
+        env = dict(os.environ)
+        for k in keys:
+            env.pop(k, None)
+        env.update(over)
+        r = subprocess.run([sys.executable, "-c", snippet.format(root=root)], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout + r.stderr
+        out.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1][7:]))
+    assert out[0] == out[1] == out[2] == out[3], out
+    return out[0]
+
+
+@pytest.mark.skipif(not os.environ.get("HMSG_EMU_SLOW"), reason="minutes on the kernel simulator (HMSG_EMU_SLOW=1); its twin runs on the MI355X")
+@pytest.mark.skipif(not os.path.exists(PC.EMU_PATH), reason="kernel simulator not built")
+def test_overlap_launch_forms_on_the_simulator():
+    assert _overlap_launch_forms(_SPLIT_SNIPPET)[0][0] >= 3
+
+
+@pytest.mark.gpu
+def test_overlap_launch_forms_on_the_gpu():
+    """configs[1]'s scene, 300 frames (see _overlap_launch_forms)."""
+    assert _overlap_launch_forms(_OV_GPU_SNIPPET)[0][0] > 50
