@@ -1179,7 +1179,8 @@ __global__ void __launch_bounds__(256) k_db_compact(const double* __restrict__ p
                                                     const int* __restrict__ parent, double* __restrict__ dst, int* __restrict__ oend,
                                                     int* __restrict__ ostart, int* __restrict__ ofirst, unsigned char* __restrict__ dst_core,
                                                     unsigned long long* __restrict__ obounds, unsigned long long* __restrict__ state,
-                                                    unsigned epoch, double* __restrict__ pool_w, unsigned char* __restrict__ poolcore_w) {
+                                                    unsigned epoch, double* __restrict__ pool_w, unsigned char* __restrict__ poolcore_w,
+                                                    const unsigned long long* __restrict__ best_pre /* k_db_pick's winners (large batches), or nullptr */) {
     __shared__ int slot_seg;
     __shared__ unsigned long long slot_box[6];
     __shared__ unsigned wsum[4], wtot[2][4];
@@ -1201,7 +1202,7 @@ __global__ void __launch_bounds__(256) k_db_compact(const double* __restrict__ p
     const int k_lo = bk.cnt > 0 ? segid[b0] : 0, k_hi = bk.cnt > 0 ? segid[b1 - 1] : -1;
     const bool best_in_lds = k_hi - k_lo < DBK_SEGS;
     if (best_in_lds && tid <= k_hi - k_lo)
-        s_best[tid] = segs[k_lo + tid].forced ? 0ull : db_best_cluster(k_lo + tid, ncl, roots, rhead, rnext, size, firstidx, rootmin);
+        s_best[tid] = segs[k_lo + tid].forced ? 0ull : (best_pre ? best_pre[k_lo + tid] : db_best_cluster(k_lo + tid, ncl, roots, rhead, rnext, size, firstidx, rootmin));
     __syncthreads();
     unsigned mine = 0u, kept = 0u;
     int trip = 0;
@@ -1210,7 +1211,7 @@ __global__ void __launch_bounds__(256) k_db_compact(const double* __restrict__ p
         if (i >= b1) continue;
         const int k = segid[i];
         const DbSeg sg = segs[k];
-        const unsigned long long b = sg.forced ? 0ull : (best_in_lds ? s_best[k - k_lo] : db_best_cluster(k, ncl, roots, rhead, rnext, size, firstidx, rootmin));
+        const unsigned long long b = sg.forced ? 0ull : (best_in_lds ? s_best[k - k_lo] : (best_pre ? best_pre[k] : db_best_cluster(k, ncl, roots, rhead, rnext, size, firstidx, rootmin)));
         bool keep = true;                                    // graph_utils.py:853-880 (see k_db_flags)
         if (sg.forced) {
             // the anchor member is kept whole and its cluster is the winner (SegDesc::forced); the rest is kept where it joined it
@@ -1278,7 +1279,7 @@ __global__ void __launch_bounds__(256) k_db_compact(const double* __restrict__ p
             if (sg.forced) {
                 drops = i >= sg.pt_base + sg.n_first;               // (box of the kept REST: the host unites it with the anchor member's own box)
             } else {
-                const unsigned win = (unsigned)((best_in_lds ? s_best[k - k_lo] : db_best_cluster(k, ncl, roots, rhead, rnext, size, firstidx, rootmin)) >> 32);
+                const unsigned win = (unsigned)((best_in_lds ? s_best[k - k_lo] : (best_pre ? best_pre[k] : db_best_cluster(k, ncl, roots, rhead, rnext, size, firstidx, rootmin))) >> 32);
                 drops = win >= 5u && win < (unsigned)sg.n;
             }
         }
@@ -1704,6 +1705,16 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     } else {
         const unsigned gK = (unsigned)hblk.size();
         const unsigned epoch = hmsg_scan_epoch(scan_tmp, gK, s);
+        // A fold step's segments have a handful of clusters each and the compaction picks the winner itself (db_best_cluster: no launch
+        // for it).  A LARGE batch -- the per-object DBSCAN(0.05, 10) over every instance of the scene, the final pass -- is the opposite:
+        // an instance of piled-up re-observations falls into hundreds of little clusters, and every one of the compaction's workgroups
+        // that touches the segment walked that chain of roots for itself (k_db_compact 2.2 ms of hmsg_build_object_nodes' 7 ms of DBSCAN).
+        // There the winners are picked once, by k_db_pick, and the launch it costs is nothing against the batch.
+        static const int pick_env = getenv("HMSG_DEBUG_DB_PICK") ? atoi(getenv("HMSG_DEBUG_DB_PICK")) : -1;   // 1 / 0: always / never (tests)
+        const bool pick_first = pick_env >= 0 ? pick_env != 0 : (N >= (1ll << 20) || K > 64);
+        if (pick_first)
+            hipLaunchKernelGGL(k_db_pick, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc, (const int*)cseg.p, dsegs, K,
+                               (const unsigned*)size.p, (const unsigned*)firstidx.p, (const unsigned*)rootmin.p, best.p);
         ProfScope ps(prof, s, "k_db_scatter", (double)N * 56.0, true);
         if (gK)
             hipLaunchKernelGGL(k_db_compact, dim3(gK), dim3(256), 0, s, src, dblks, (const int*)segid.p, dsegs, (const int*)label.p,
@@ -1711,7 +1722,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
                                (const unsigned*)rep.p, dump_wanted ? flags.p : (unsigned*)nullptr, (const unsigned char*)core.p,
                                (const long long*)cellid.p, (const int*)parent.p, dst, d_ocount, d_ostart, d_ofirst, dst_core, d_obounds,
                                reinterpret_cast<unsigned long long*>(scan_tmp.p), epoch, gather ? gather->pool_w : (double*)nullptr,
-                               gather ? gather->poolcore_w : (unsigned char*)nullptr);
+                               gather ? gather->poolcore_w : (unsigned char*)nullptr, pick_first ? (const unsigned long long*)best.p : (const unsigned long long*)nullptr);
     }
     HMSG_CHECK_LAUNCH();
     {   // debug: HMSG_DEBUG_DBCALL=<n> dumps the n-th batch (inputs + per-point results) under HMSG_DEBUG_DUMP
