@@ -86,8 +86,6 @@ struct CloudOps {
     DevBuf<unsigned> cnt, start, cursor, ord, minidx, firstidx, size, flags, pos, rootmin;
     DevBuf<int> parent, label, segid, cellpos, corelist, cseg, roots, rhead, rnext;   // roots / rhead / rnext: a segment's cluster roots (k_db_rootmin)
     DevBuf<double> cellbox;
-    DevBuf<double> creps;                  // large batches: up to DB_REPS DISTINCT core points per listed cell (k_db_cellbox -> k_db_union_scan)
-    DevBuf<unsigned char> nreps;           // ... and how many (0: more than DB_REPS, scan the cell)
     DevBuf<long long> cellid;
     DevBuf<unsigned char> core, score;     // core flag per point / per slot of the cell-sorted copy
     DevBuf<double> spts;                   // cell-sorted copy of the batch's points

@@ -220,7 +220,6 @@ __global__ void __launch_bounds__(256) k_db_scan(const unsigned* __restrict__ cn
 // and per slot of the sorted copy: DB_SLOT_ANCHOR / DB_SLOT_CORE, 0 = to be counted), and what the flags mean for the CELL is worked
 // out by the wave that visits the cell anyway (k_db_cellbox) instead of by atomics from every point (until round 5: a separate
 // k_db_core launch over all points behind the counts).
-#define DB_REPS 4          /* distinct core points listed per cell in large batches (k_db_cellbox) */
 #define DB_SLOT_CORE 1
 #define DB_SLOT_ANCHOR 2
 __global__ void k_db_fill(const double* __restrict__ pts, long long N, const long long* __restrict__ cellid,
@@ -504,8 +503,7 @@ __global__ void k_db_cellbox(const double* __restrict__ pts, const int* __restri
                              unsigned char* __restrict__ score, const unsigned char* __restrict__ core, double* __restrict__ cellbox,
                              unsigned* __restrict__ ccore, const int* __restrict__ cseg, const unsigned char* __restrict__ hasanchor,
                              unsigned* __restrict__ rep, int* __restrict__ parent, const DbSeg* __restrict__ segs,
-                             unsigned* __restrict__ minidx, unsigned* __restrict__ active, unsigned char* __restrict__ poolcore_w,
-                             double* __restrict__ creps, unsigned char* __restrict__ nreps) {
+                             unsigned* __restrict__ minidx, unsigned* __restrict__ active, unsigned char* __restrict__ poolcore_w) {
     // (the anchor cells' pre-connection rides in this launch: it needs the cell list and k_db_fill's hasanchor[], and nothing of the boxes)
     if (rep) db_anchor_cells(corecells, ncore, cseg, hasanchor, rep, parent);
     const int lane = threadIdx.x & 63;
@@ -552,45 +550,6 @@ __global__ void k_db_cellbox(const double* __restrict__ pts, const int* __restri
         first = t < first ? t : first;
     }
     const bool any_act = __any(act) != 0;
-    if (creps) {
-        // Large batches (the per-object DBSCAN over every instance of a scene): a cell of a surface that was observed hundreds of times
-        // holds hundreds of COPIES of one or two points, and a pair of such cells without a witness made k_db_union_scan test every
-        // copy against every copy (5.1 of the call's 7 ms).  Connectivity only asks for the DISTINCT core points: up to DB_REPS of
-        // them per cell are listed here (copies of a point share their core status: same neighbours); a cell with more scans as before.
-        double rx[DB_REPS], ry[DB_REPS], rz[DB_REPS];
-        int nr = 0;
-        bool over = false;
-        for (unsigned k0 = s0; k0 < e0 && !over; k0 += 64) {         // (wave-uniform trips)
-            const unsigned k = k0 + lane;
-            const bool in = k < e0 && score[k] != 0;
-            const double px = in ? pts[(size_t)k * 3] : 0.0, py = in ? pts[(size_t)k * 3 + 1] : 0.0, pz = in ? pts[(size_t)k * 3 + 2] : 0.0;
-            bool fresh = in;
-            for (int j = 0; j < nr; ++j) fresh = fresh && !(px == rx[j] && py == ry[j] && pz == rz[j]);
-            unsigned long long todo = __ballot(fresh);
-            while (todo) {
-                if (nr == DB_REPS) {
-                    over = true;
-                    break;
-                }
-                const int leader = __ffsll(todo) - 1;
-                rx[nr] = __shfl(px, leader);
-                ry[nr] = __shfl(py, leader);
-                rz[nr] = __shfl(pz, leader);
-                fresh = fresh && !(px == rx[nr] && py == ry[nr] && pz == rz[nr]);
-                ++nr;
-                todo = __ballot(fresh);
-            }
-        }
-        if (lane == 0) {
-            nreps[w] = over ? (unsigned char)0 : (unsigned char)nr;
-            for (int j = 0; j < DB_REPS; ++j)
-                if (j < nr) {
-                    creps[((size_t)w * DB_REPS + j) * 3] = rx[j];
-                    creps[((size_t)w * DB_REPS + j) * 3 + 1] = ry[j];
-                    creps[((size_t)w * DB_REPS + j) * 3 + 2] = rz[j];
-                }
-        }
-    }
     if (lane == 0) {
         for (int a = 0; a < 3; ++a) {
             cellbox[(size_t)w * 6 + a] = mn[a];
@@ -724,8 +683,7 @@ __global__ void k_db_union_scan(const double* __restrict__ pts, const int* __res
                                 const unsigned* __restrict__ ord, const unsigned char* __restrict__ core,
                                 const unsigned* __restrict__ minidx, double eps2, const int* __restrict__ cellpos,
                                 const double* __restrict__ cellbox, int* __restrict__ parent,
-                                const unsigned* __restrict__ active, const unsigned char* __restrict__ hasanchor,
-                                const double* __restrict__ creps, const unsigned char* __restrict__ nreps) {
+                                const unsigned* __restrict__ active, const unsigned char* __restrict__ hasanchor) {
     const int lane = threadIdx.x & 63;
     const unsigned nwaves = (gridDim.x * blockDim.x) >> 6, ncells = *ncore;
     for (unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < ncells; w += nwaves) {
@@ -736,7 +694,6 @@ __global__ void k_db_union_scan(const double* __restrict__ pts, const int* __res
         int ix, iy, iz;
         cell_xyz(sg, c, ix, iy, iz);
         const unsigned s0 = start[c], e0 = s0 + cnt[c];
-        const int na = creps ? (int)nreps[w] : 0;           // (w = cellpos[c]: the cell's place in the list)
         double ba[6];
         for (int a = 0; a < 6; ++a) ba[a] = cellbox[(size_t)cellpos[c] * 6 + a];
         const int rc = uf_find_cached(parent, (int)c);
@@ -828,14 +785,6 @@ __global__ void k_db_union_scan(const double* __restrict__ pts, const int* __res
             const double* bb = cellbox + (size_t)cellpos[c2s] * 6;
             const unsigned s1 = start[c2s], e1 = s1 + cnt[c2s];
             bool hit = false;
-            const int nb = na ? (int)nreps[cellpos[c2s]] : 0;
-            if (na && nb) {
-                // both cells list their distinct core points: at most DB_REPS x DB_REPS pairs, one lane each
-                const int i = lane / DB_REPS, j = lane % DB_REPS;
-                if (i < na && j < nb)
-                    hit = dist2_f64(creps + ((size_t)w * DB_REPS + i) * 3, creps + ((size_t)cellpos[c2s] * DB_REPS + j) * 3) < eps2;
-                hit = __any(hit) != 0;
-            } else
             for (unsigned a0 = s0; a0 < e0; a0 += 64) {
                 unsigned a = a0 + lane;
                 if (a < e0) {
@@ -1710,18 +1659,10 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
     }
     // persistent grid (8 blocks per CU): waves / threads stride over the cell list
     const unsigned gW = (unsigned)n_cu * 8u;
-    // large batches list the distinct core points of their cells for the witness tests (k_db_cellbox); HMSG_DEBUG_DB_REPS=1 / 0: always / never (tests)
-    static const int reps_env = getenv("HMSG_DEBUG_DB_REPS") ? atoi(getenv("HMSG_DEBUG_DB_REPS")) : -1;
-    const bool with_reps = reps_env >= 0 ? reps_env != 0 : N >= (1ll << 20);
-    if (with_reps) {
-        creps.ensure((size_t)std::min<long long>(NC, N) * DB_REPS * 3);
-        nreps.ensure((size_t)std::min<long long>(NC, N));
-    }
     hipLaunchKernelGGL(k_db_cellbox, dim3(gW), dim3(256), 0, s, (const double*)spts.p, (const int*)corelist.p,
                        (const unsigned*)d_nc, (const unsigned*)cnt.p, (const unsigned*)start.p, (const unsigned*)sidx.p,
                        score.p, (const unsigned char*)core.p, cellbox.p, ccore.p, (const int*)cseg.p, (const unsigned char*)hasanchor.p,
-                       core0 ? rep.p : (unsigned*)nullptr, parent.p, dsegs, minidx.p, active.p, pc_w,
-                       with_reps ? creps.p : (double*)nullptr, with_reps ? nreps.p : (unsigned char*)nullptr);
+                       core0 ? rep.p : (unsigned*)nullptr, parent.p, dsegs, minidx.p, active.p, pc_w);
     {
         ProfScope ps(prof, s, "k_db_union/box", (double)N * 24.0, true);
         hipLaunchKernelGGL(k_db_union, dim3(gW), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc, (const int*)cseg.p, dsegs, K,
@@ -1734,8 +1675,7 @@ long long CloudOps::dbscan_keep_largest(const double* src, const std::vector<Seg
                            (const unsigned*)d_nc, (const int*)cseg.p, dsegs, K, (const unsigned*)cnt.p, (const unsigned*)start.p,
                            (const unsigned*)ord.p, (const unsigned char*)score.p, (const unsigned*)minidx.p, eps * eps,
                            (const int*)cellpos.p, (const double*)cellbox.p, parent.p, (const unsigned*)active.p,
-                           (const unsigned char*)hasanchor.p, with_reps ? (const double*)creps.p : (const double*)nullptr,
-                           with_reps ? (const unsigned char*)nreps.p : (const unsigned char*)nullptr);
+                           (const unsigned char*)hasanchor.p);
     }
     hipLaunchKernelGGL(k_db_rootmin, dim3(256), dim3(256), 0, s, (const int*)corelist.p, (const unsigned*)d_nc,
                        parent.p, (const unsigned*)minidx.p, rootmin.p, (const int*)cseg.p, dsegs, K, d_ncl, (const unsigned*)ccore.p, size.p,
