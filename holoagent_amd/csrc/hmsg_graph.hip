@@ -29,10 +29,12 @@ int hmsg_build_object_nodes(hmsg_t* h, int32_t n_floors, const double* floor_zer
                          (n_rooms == 0 || (room_floor && vert_off && verts_xz)) && (n_labels == 0 || label_feats),
                      HMSG_ERR_INVALID, "hmsg_build_object_nodes: bad argument");
         const int D = h->cfg.feat_dim;
+        DbgLaps laps("object nodes", h->stream);
         if (!h->inst_denoised) {
             hmsg_denoise_inst(h, 0.05, 10);
             h->inst_denoised = true;
         }
+        laps.lap("per-object DBSCAN");
         const int N = (int)h->inst.off.size() - 1;
         h->nodes.clear();
         h->node_label.assign((size_t)std::max(N, 0), -1);
@@ -54,8 +56,10 @@ int hmsg_build_object_nodes(hmsg_t* h, int32_t n_floors, const double* floor_zer
                 h->node_label[(size_t)i] = best;
             }
         }
+        laps.lap("label similarity");
         std::vector<double> share((size_t)N * std::max(n_rooms, 1), 0.0);
         if (n_rooms > 0) hmsg_room_share(h, n_rooms, (const long long*)vert_off, verts_xz, 0.2, share.data());
+        laps.lap("room shares");
         // room vertex centroids (np.mean(axis=0): rows added in order)
         std::vector<double> rc((size_t)n_rooms * 2, 0.0);
         for (int r = 0; r < n_rooms; ++r) {
@@ -116,6 +120,7 @@ int hmsg_build_object_nodes(hmsg_t* h, int32_t n_floors, const double* floor_zer
                 h->nodes.push_back(hmsg_node{i, f, best, counter[(size_t)best]++, h->node_label[(size_t)i], (int64_t)n_i});
             }
         }
+        laps.lap("floors / rooms (host)");
         return HMSG_OK;
     } catch (const hmsg_error& e) {
         h->err = e.msg;
