@@ -2338,18 +2338,30 @@ __global__ void k_sh_query(const ShGrid* __restrict__ gr, const ShTask* __restri
         int cx = (int)floor((x - g.ox) / g.cell), cz = (int)floor((z - g.oz) / g.cell);
         if (cx < -1 || cz < -1 || cx > g.gx || cz > g.gz) continue;
         bool hit = false;
-        for (int dx = -1; dx <= 1 && !hit; ++dx) {
-            int jx = cx + dx;
-            if (jx < 0 || jx >= g.gx) continue;
-            int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.gz - 1);
-            if (z1 < z0) continue;
-            long long c0 = g.cell_off + (long long)jx * g.gz;
-            for (unsigned k = cells[c0 + z0]; k < cells[c0 + z1 + 1]; ++k) {
-                double ddx = __dsub_rn(sorted[(size_t)k * 2], x), ddz = __dsub_rn(sorted[(size_t)k * 2 + 1], z);
-                if (__dadd_rn(__dmul_rn(ddx, ddx), __dmul_rn(ddz, ddz)) < r2) {
-                    hit = true;
-                    break;
-                }
+        // The vertex's own cell first, then the rest of its column, then the neighbour columns: inside an object's footprint the
+        // witness is in the own cell, and a cell of a surface that has piled up its re-observations holds hundreds of points -- walked
+        // to the end in vain when a neighbour comes first (the count does not care which point is the witness).
+        auto scan = [&](unsigned k, unsigned k1) {
+            for (; k < k1; ++k) {
+                const double ddx = __dsub_rn(sorted[(size_t)k * 2], x), ddz = __dsub_rn(sorted[(size_t)k * 2 + 1], z);
+                if (__dadd_rn(__dmul_rn(ddx, ddx), __dmul_rn(ddz, ddz)) < r2) return true;
+            }
+            return false;
+        };
+        const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.gz - 1);
+        if (z1 >= z0) {
+            const bool own = cx >= 0 && cx < g.gx && cz >= 0 && cz < g.gz;
+            if (own) {
+                const long long c0 = g.cell_off + (long long)cx * g.gz;
+                hit = scan(cells[c0 + cz], cells[c0 + cz + 1]);
+                if (!hit) hit = scan(cells[c0 + z0], cells[c0 + cz]);              // (below the own cell)
+                if (!hit) hit = scan(cells[c0 + cz + 1], cells[c0 + z1 + 1]);      // (above it)
+            }
+            for (int q = own ? 1 : 0; q < 3 && !hit; ++q) {
+                const int jx = cx + (q == 0 ? 0 : (q == 1 ? -1 : 1));
+                if (jx < 0 || jx >= g.gx) continue;
+                const long long c0 = g.cell_off + (long long)jx * g.gz;
+                hit = scan(cells[c0 + z0], cells[c0 + z1 + 1]);
             }
         }
         local += hit ? 1u : 0u;
